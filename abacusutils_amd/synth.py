@@ -1,0 +1,116 @@
+"""Seeded synthetic inputs for the hot path.
+
+Shapes, dtypes and key names are those `AbacusHOD.staging()` produces in the
+reference (abacusnbody/hod/abacus_hod.py:355-383,659-702): float64 arrays,
+(N,3) C-order positions/velocities, int64 ids.  Used by bench.py, the parity
+tests and oracle/make_golden.py so all three see identical inputs.
+"""
+
+import numpy as np
+
+# AbacusSummit base box header values (tests/halo_light_cones/.../lc_halo_info.asdf:253,346,383)
+LBOX_BASE = 2000.0
+MPART_BASE = 2109081520.453063
+VELZSPACE_TO_KMS_BASE = 208774.9025637363
+
+# tests/abacus_hod.yaml:31-47,50-70,73-90 of the reference (the HOD the reference tests run)
+LRG_PARAMS = dict(
+    logM_cut=13.3, logM1=14.3, sigma=0.3, alpha=1.0, kappa=0.4,
+    alpha_c=0, alpha_s=1, s=0, s_v=0, s_p=0, s_r=0,
+    Acent=0, Asat=0, Bcent=0, Bsat=0, ic=0.97,
+)
+ELG_PARAMS = dict(
+    p_max=0.33, Q=100.0, logM_cut=11.75, kappa=1.0, sigma=0.58, logM1=13.53,
+    alpha=1.0, gamma=4.12, A_s=1.0, alpha_c=0, alpha_s=1, s=0, s_v=0, s_p=0,
+    s_r=0, Acent=0, Asat=0, Bcent=0, Bsat=0, ic=1.0,
+)
+QSO_PARAMS = dict(
+    p_max=0.33, logM_cut=12.21, kappa=1.0, sigma=0.56, logM1=13.94, alpha=0.4,
+    A_s=1.0, alpha_c=0, alpha_s=1, s=0, s_v=0, s_p=0, s_r=0,
+    Acent=0, Asat=0, Bcent=0, Bsat=0, ic=1.0,
+)
+
+
+def _downfactor_lrg(m):
+    """halo subsampling fraction, LRG-only branch (hod/prepare_sim.py:103-107)"""
+    x = np.log10(m)
+    d = 1.0 / (1.0 + 0.1 * np.exp(-(x - 11.8) * 10))
+    d[x > 13.0] = 1
+    return d
+
+
+def synth_hod_inputs(n_halo, n_part, seed=600, lbox=LBOX_BASE, z=0.5,
+                     with_ranks=False, with_shear=True, origin=None):
+    """Synthetic halo + particle subsample in the `staging()` layout.
+
+    Returns (halo_data, particle_data, params).
+    """
+    rng = np.random.default_rng(seed)
+    logm = 11.0 + rng.exponential(0.45, n_halo)
+    logm = np.minimum(logm, 15.5)
+    hmass = 10.0**logm
+    hpos = (rng.random((n_halo, 3)) - 0.5) * lbox
+    hvel = rng.standard_normal((n_halo, 3)) * 300.0
+    hsigma3d = 300.0 * (hmass / 1e13) ** (1.0 / 3.0)
+    hveldev = rng.standard_normal((n_halo, 3)) * (hsigma3d / np.sqrt(3.0))[:, None]
+    hmultis = 1.0 / _downfactor_lrg(hmass)
+    hrandoms = rng.random(n_halo)
+    hdeltac = rng.random(n_halo) - 0.5
+    hfenv = rng.random(n_halo) - 0.5
+    hshear = rng.random(n_halo) - 0.5
+    hid = 1000 * np.arange(n_halo, dtype=np.int64)
+
+    # particles: host drawn proportional to mass, stored in host order (as the
+    # slab files are), so `pinds` is non-decreasing
+    cdf = np.cumsum(hmass)
+    host = np.searchsorted(cdf, rng.random(n_part) * cdf[-1])
+    host = np.minimum(host, n_halo - 1)
+    host.sort()
+    np_host = np.bincount(host, minlength=n_halo).astype(np.float64)
+    ppos = hpos[host] + rng.standard_normal((n_part, 3)) * 0.3
+    pvel = hvel[host] + rng.standard_normal((n_part, 3)) * hsigma3d[host][:, None] / np.sqrt(3.0)
+    halo_data = dict(
+        hpos=hpos, hvel=hvel, hmass=hmass, hid=hid, hmultis=hmultis,
+        hrandoms=hrandoms, hveldev=hveldev, hsigma3d=hsigma3d,
+        hc=np.full(n_halo, 5.0), hrvir=np.full(n_halo, 0.5),
+        hdeltac=hdeltac, hfenv=hfenv,
+    )
+    particle_data = dict(
+        ppos=ppos, pvel=pvel, phvel=np.ascontiguousarray(hvel[host]),
+        phmass=hmass[host], phid=hid[host],
+        pweights=1.0 / np_host[host], prandoms=rng.random(n_part),
+        pinds=host.astype(np.int64), pdeltac=hdeltac[host], pfenv=hfenv[host],
+    )
+    if with_shear:
+        halo_data['hshear'] = hshear
+        particle_data['pshear'] = hshear[host]
+    if with_ranks:
+        for k in ('pranks', 'pranksv', 'pranksp', 'pranksr', 'pranksc'):
+            particle_data[k] = rng.random(n_part) * 2.0 - 1.0
+    else:
+        # hod/abacus_hod.py:698-702
+        for k in ('pranks', 'pranksv', 'pranksp', 'pranksr', 'pranksc'):
+            particle_data[k] = np.ones(n_part)
+    params = dict(
+        z=z, h=0.6736, Lbox=lbox, Mpart=MPART_BASE,
+        velz2kms=VELZSPACE_TO_KMS_BASE / lbox,
+        origin=None if origin is None else np.asarray(origin, dtype=np.float64),
+        chunk=-1, numslabs=1,
+    )
+    return halo_data, particle_data, params
+
+
+def synth_positions(n, lbox, seed=300, dtype=np.float32, clustered=False):
+    """Particle positions for the P(k) path (scripts/power/bench.py:28,39 protocol:
+    `rng.random((N,3), dtype='f4')`, seed 300), scaled to `lbox`."""
+    rng = np.random.default_rng(seed)
+    pos = rng.random((n, 3), dtype=np.float32)
+    if clustered:
+        # cheap non-Poisson signal: displace along a few long-wavelength modes
+        for ax in range(3):
+            pos[:, ax] += np.float32(0.02) * np.sin(
+                np.float32(2 * np.pi * (ax + 2)) * pos[:, (ax + 1) % 3]
+            ).astype(np.float32)
+        pos -= np.floor(pos)
+    pos = (pos * np.float32(lbox)).astype(dtype)
+    return pos

@@ -1,0 +1,446 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+TEST INFRASTRUCTURE.  Needs /root/reference (absent on the GPU box); only its
+outputs - small data fixtures - are committed.  The reference's numba-decorated
+functions run as plain Python through the identity shim in oracle/shim/
+(numba is not importable here).
+
+What is captured
+  hod_mini.npz / hod_lc.npz   the reference's own test fixtures
+        (tests/ref_hod/**: HDF5 subsamples -> staging()-layout arrays,
+        galaxies_rsd/*.dat ECSV -> expected columns), plus a check that the
+        shimmed reference reproduces the ECSV exactly.
+  hod_synth_*.npz             gen_gal_cat / gen_cent outputs of the reference on
+        seeded synthetic halos (abacusutils_amd.synth) for the branches its
+        tests do not pin (QSO, ranks, AB, shear, conformity, light cone, ...).
+  tsc_ref.npz                 tests/ref_tsc/*.asdf grids (blosc-decoded), sparse.
+  tsc_cases.npz               _tsc_scatter / tsc_parallel / partition_parallel
+        outputs for dtype / weights / offset / anisotropic cases (2-D grids raise in
+        the reference itself: 3 indices on a 2-D array, tsc.py:471).
+  power_cases.npz             calc_power for all paste x compensated x interlaced
+        modes, cross spectra, poles, logk; bin_kmu / calc_pk_from_deltak.
+
+usage: python oracle/make_golden.py [hod] [tsc] [power]
+"""
+import ctypes
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+import types
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+REF = Path('/root/reference')
+GOLD = REPO / 'tests' / 'golden'
+H5PY_PYTHON = '/opt/conda/bin/python3.9'
+LIBBLOSC = '/opt/conda/lib/libblosc.so.1'
+
+sys.path.insert(0, str(REPO / 'oracle' / 'shim'))
+sys.path.insert(0, str(REPO))
+
+
+def import_reference():
+    """abacusnbody/__init__.py imports a generated version.py that is not in the
+    tree -> register a bare package object pointing at the reference directory."""
+    pkg = types.ModuleType('abacusnbody')
+    pkg.__path__ = [str(REF / 'abacusnbody')]
+    sys.modules['abacusnbody'] = pkg
+    import abacusnbody.hod.GRAND_HOD as G
+    import abacusnbody.analysis.tsc as T
+    import abacusnbody.analysis.power_spectrum as P
+    import abacusnbody.analysis.cic as C
+    return G, T, P, C
+
+
+# ----------------------------------------------------------------------------
+# fixture readers
+# ----------------------------------------------------------------------------
+def read_h5(fn, dset):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'a.npy')
+        subprocess.check_call([H5PY_PYTHON, str(REPO / 'oracle' / '_h5dump.py'), str(fn), dset, out])
+        return np.load(out)
+
+
+def read_ecsv(fn):
+    """ECSV -> dict of float64 columns + int64 id, and the Ncent meta value."""
+    ncent = None
+    rows = []
+    header = None
+    for line in open(fn):
+        if line.startswith('#'):
+            m = re.search(r'Ncent: (\d+)', line)
+            if m:
+                ncent = int(m.group(1))
+            continue
+        if header is None:
+            header = line.split()
+            continue
+        rows.append(line.split())
+    cols = {}
+    for j, name in enumerate(header):
+        if name == 'id':
+            cols[name] = np.array([int(r[j]) for r in rows], dtype=np.int64)
+        else:
+            cols[name] = np.array([float(r[j]) for r in rows], dtype=np.float64)
+    return cols, ncent
+
+
+def read_asdf_blsc(fn, key):
+    """First binary block of an ASDF file compressed with the reference's 'blsc'
+    extension (abacusnbody/data/asdf.py:81-93,128-181): block header, then chunks
+    of [!I nbytes][blosc frame]."""
+    raw = open(fn, 'rb').read()
+    # yaml tree: dtype/shape of `key`
+    tree = raw[: raw.index(b'\xd3BLK')].decode('latin1')
+    import re
+    m = re.search(key + r': !core/ndarray-[\d.]+\s*\n((?:\s+.*\n)+)', tree)
+    body = m.group(1)
+    shape = [int(s) for s in re.search(r'shape: \[([\d, ]+)\]', body).group(1).split(',')]
+    dt = re.search(r'datatype: (\w+)', body).group(1)
+    bo = re.search(r'byteorder: (\w+)', body).group(1)
+    dtype = np.dtype({'float32': 'f4', 'float64': 'f8'}[dt]).newbyteorder('<' if bo == 'little' else '>')
+    p = raw.index(b'\xd3BLK') + 4
+    (hsize,) = struct.unpack('>H', raw[p : p + 2])
+    flags, comp, alloc, used, dsize = struct.unpack('>I4sQQQ', raw[p + 2 : p + 2 + 32])
+    assert comp == b'blsc', comp
+    p = p + 2 + hsize
+    end = p + used
+    lib = ctypes.CDLL(LIBBLOSC)
+    out = bytearray()
+    while p < end:
+        (n,) = struct.unpack('!I', raw[p : p + 4])
+        p += 4
+        frame = raw[p : p + n]
+        p += n
+        nbytes = ctypes.c_size_t()
+        cbytes = ctypes.c_size_t()
+        bs = ctypes.c_size_t()
+        lib.blosc_cbuffer_sizes(frame, ctypes.byref(nbytes), ctypes.byref(cbytes), ctypes.byref(bs))
+        buf = ctypes.create_string_buffer(nbytes.value)
+        r = lib.blosc_decompress(frame, buf, ctypes.c_size_t(nbytes.value))
+        assert r == nbytes.value
+        out += buf.raw
+    assert len(out) == dsize
+    return np.frombuffer(bytes(out), dtype=dtype).reshape(shape).astype(dtype.newbyteorder('='))
+
+
+# ----------------------------------------------------------------------------
+# HOD
+# ----------------------------------------------------------------------------
+def stage_from_h5(dirn, nslab, Mpart, Lbox, velzspace_to_kms, origin, z):
+    """Builds halo_data / particle_data / params the way staging() does
+    (hod/abacus_hod.py:289-298,355-383,423-552,566-588,659-702) for
+    want_AB=True, want_shear=False, want_ranks=False, MT files."""
+    halos = [read_h5(dirn / f'halos_xcom_{i}_seed600_abacushod_oldfenv_MT_new.h5', 'halos') for i in range(nslab)]
+    parts = [read_h5(dirn / f'particles_xcom_{i}_seed600_abacushod_oldfenv_MT_new.h5', 'particles') for i in range(nslab)]
+    H = np.concatenate(halos)
+    Pt = np.concatenate(parts)
+    nh, npart = len(H), len(Pt)
+    hpos = np.empty((nh, 3)); hpos[:] = H['x_L2com']
+    hvel = np.empty((nh, 3)); hvel[:] = H['v_L2com']
+    hmass = np.empty(nh); hmass[:] = H['N'] * Mpart
+    hid = np.empty(nh, dtype=int); hid[:] = H['id'].astype(int)
+    hmultis = np.empty(nh); hmultis[:] = H['multi_halos']
+    hrandoms = np.empty(nh); hrandoms[:] = H['randoms']
+    hveldev = np.empty((nh, 3)); hveldev[:] = H['randoms_gaus_vrms']
+    hsigma3d = np.empty(nh); hsigma3d[:] = H['sigmav3d_L2com']
+    hc = np.empty(nh); hc[:] = H['r98_L2com'] / H['r25_L2com']
+    hrvir = np.empty(nh); hrvir[:] = H['r98_L2com']
+    hdeltac = np.empty(nh); hdeltac[:] = H['deltac_rank']
+    hfenv = np.empty(nh); hfenv[:] = H['fenv_rank']
+    ppos = np.empty((npart, 3)); ppos[:] = Pt['pos']
+    pvel = np.empty((npart, 3)); pvel[:] = Pt['vel']
+    phvel = np.empty((npart, 3)); phvel[:] = Pt['halo_vel']
+    phmass = np.empty(npart); phmass[:] = Pt['halo_mass']
+    phid = np.empty(npart, dtype=int); phid[:] = Pt['halo_id'].astype(int)
+    pNp = np.empty(npart); pNp[:] = Pt['Np']
+    psub = np.empty(npart); psub[:] = Pt['downsample_halo']
+    prandoms = np.empty(npart); prandoms[:] = Pt['randoms']
+    pdeltac = np.empty(npart); pdeltac[:] = Pt['halo_deltac']
+    pfenv = np.empty(npart); pfenv[:] = Pt['halo_fenv']
+    if not np.all(hid[:-1] <= hid[1:]):
+        s = np.argsort(hid)
+        hpos, hvel, hmass, hid, hmultis, hrandoms, hveldev = (a[s] for a in (hpos, hvel, hmass, hid, hmultis, hrandoms, hveldev))
+        hsigma3d, hc, hrvir, hdeltac, hfenv = (a[s] for a in (hsigma3d, hc, hrvir, hdeltac, hfenv))
+    pweights = 1 / pNp / psub
+    pinds = np.searchsorted(hid, phid).astype(np.int64)
+    halo_data = dict(hpos=hpos, hvel=hvel, hmass=hmass, hid=hid, hmultis=hmultis, hrandoms=hrandoms,
+                     hveldev=hveldev, hsigma3d=hsigma3d, hc=hc, hrvir=hrvir, hdeltac=hdeltac, hfenv=hfenv)
+    particle_data = dict(ppos=ppos, pvel=pvel, phvel=phvel, phmass=phmass, phid=phid, pweights=pweights,
+                         prandoms=prandoms, pinds=pinds, pdeltac=pdeltac, pfenv=pfenv)
+    for k in ('pranks', 'pranksv', 'pranksp', 'pranksr', 'pranksc'):
+        particle_data[k] = np.ones(npart)
+    params = dict(z=z, h=0.6736, Lbox=Lbox, Mpart=Mpart, velz2kms=velzspace_to_kms / Lbox,
+                  origin=None if origin is None else np.array(origin, dtype=np.float64), chunk=-1, numslabs=nslab)
+    return halo_data, particle_data, params
+
+
+def pack_inputs(halo_data, particle_data, params):
+    d = {}
+    for k, v in halo_data.items():
+        d['h.' + k] = v
+    for k, v in particle_data.items():
+        d['p.' + k] = v
+    for k, v in params.items():
+        if v is None:
+            continue
+        d['params.' + k] = np.asarray(v)
+    return d
+
+
+def pack_mock(prefix, mock):
+    d = {}
+    for tr, cols in mock.items():
+        for k, v in cols.items():
+            d[f'{prefix}.{tr}.{k}'] = np.asarray(v)
+    return d
+
+
+def checksum(halo_data, particle_data):
+    """order-sensitive float64 checksum of the synthetic inputs (detects a
+    change of numpy's Generator streams between build container and GPU box)"""
+    s = 0.0
+    for d in (halo_data, particle_data):
+        for k in sorted(d):
+            a = np.asarray(d[k], dtype=np.float64).ravel()
+            s += float(np.dot(a, np.cos(np.arange(a.size) * 0.001)))
+    return s
+
+
+def gen_hod(G):
+    import yaml
+    from abacusutils_amd import synth
+
+    cfg = yaml.safe_load(open(REF / 'tests' / 'abacus_hod.yaml'))
+    tracers = {'LRG': cfg['HOD_params']['LRG_params'], 'ELG': cfg['HOD_params']['ELG_params']}
+
+    # --- the reference's own fixtures -----------------------------------
+    for name, dirn, nslab, Mpart, Lbox, vz, origin, z in (
+        ('hod_mini', REF / 'tests/ref_hod/Mini_N64_L32/z0.000', 3, 1.088239739e10, 32.0, 3200.0, None, 0.0),
+        ('hod_lc', REF / 'tests/ref_hod/AbacusSummit_base_c000_ph001-abridged/z2.250', 1,
+         2109081520.453063, 2000.0, 208774.9025637363, (-990.0, -990.0, -990.0), 2.25),
+    ):
+        hd, pd, params = stage_from_h5(dirn, nslab, Mpart, Lbox, vz, origin, z)
+        out = pack_inputs(hd, pd, params)
+        mock = G.gen_gal_cat(hd, pd, tracers, params, Nthread=4, enable_ranks=False, rsd=True)
+        for tr in ('LRG', 'ELG'):
+            cols, ncent = read_ecsv(dirn / 'galaxies_rsd' / f'{tr}s.dat')
+            assert ncent == mock[tr]['Ncent'], (name, tr, ncent, mock[tr]['Ncent'])
+            for k in cols:
+                if k == 'id':
+                    np.testing.assert_array_equal(cols[k], mock[tr][k])
+                else:
+                    np.testing.assert_allclose(cols[k], mock[tr][k], rtol=1e-14, atol=0)
+                out[f'expect.{tr}.{k}'] = cols[k]
+            out[f'expect.{tr}.Ncent'] = np.int64(ncent)
+            print(name, tr, 'N', len(cols['x']), 'Ncent', ncent, 'shimmed reference == ECSV fixture')
+        # also keep what the shimmed reference returned (bitwise target for the oracle)
+        out.update(pack_mock('shim', mock))
+        np.savez_compressed(GOLD / f'{name}.npz', **out)
+
+    # --- synthetic cases: branches the reference tests do not pin --------
+    rich = {
+        'LRG': dict(synth.LRG_PARAMS, alpha_c=0.3, alpha_s=0.8, Acent=0.1, Asat=-0.2, Bcent=-0.05, Bsat=0.15,
+                    s=0.1, s_v=-0.1, s_p=0.05, s_r=0.2, logM_cut=12.6, logM1=13.6, z_pivot=0.8,
+                    logM_cut_pr=0.2, logM1_pr=-0.1),
+        'ELG': dict(synth.ELG_PARAMS, alpha_c=0.2, alpha_s=1.1, Acent=0.1, Asat=0.1, Bcent=0.05, Bsat=-0.1,
+                    Ccent=0.07, Csat=-0.04, logM1_EE=13.0, alpha_EE=0.9, logM1_EL=13.2, alpha_EL=1.1,
+                    s=0.2, s_v=0.1, s_p=-0.1, s_r=0.0, logM1=13.0),
+        'QSO': dict(synth.QSO_PARAMS, alpha_c=0.5, alpha_s=0.9, Acent=-0.1, Asat=0.2, Bcent=0.1, Bsat=0.0,
+                    s=-0.1, s_v=0.0, s_p=0.1, s_r=0.1, logM1=13.0),
+    }
+    cases = [
+        # name, tracers, ranks, rsd, origin, nh, np
+        ('lrg', {'LRG': dict(synth.LRG_PARAMS, logM_cut=12.6, logM1=13.6)}, False, True, None),
+        ('all_rich', rich, False, True, None),
+        ('all_rich_ranks', rich, True, True, None),
+        ('all_rich_norsd', rich, False, False, None),
+        ('all_rich_lc', rich, True, True, (-990.0, -990.0, -990.0)),
+        ('elg_only', {'ELG': rich['ELG']}, False, True, None),
+        ('qso_only', {'QSO': rich['QSO']}, False, True, None),
+        ('lrg_qso', {'LRG': rich['LRG'], 'QSO': rich['QSO']}, True, True, None),
+    ]
+    NH, NP, SEED = 20000, 30000, 600
+    for name, trs, ranks, rsd, origin in cases:
+        hd, pd, params = synth.synth_hod_inputs(NH, NP, seed=SEED, with_ranks=ranks, origin=origin)
+        mock = G.gen_gal_cat(hd, pd, trs, params, Nthread=3, enable_ranks=ranks, rsd=rsd)
+        out = pack_mock('expect', mock)
+        out['meta.nh'] = np.int64(NH)
+        out['meta.np'] = np.int64(NP)
+        out['meta.seed'] = np.int64(SEED)
+        out['meta.ranks'] = np.bool_(ranks)
+        out['meta.rsd'] = np.bool_(rsd)
+        out['meta.checksum'] = np.float64(checksum(hd, pd))
+        if origin is not None:
+            out['meta.origin'] = np.array(origin)
+        import json
+        out['meta.tracers'] = np.array(json.dumps(trs))
+        print('hod_synth_' + name, {t: (len(m['x']), m['Ncent']) for t, m in mock.items()})
+        np.savez_compressed(GOLD / f'hod_synth_{name}.npz', **out)
+
+
+# ----------------------------------------------------------------------------
+# TSC
+# ----------------------------------------------------------------------------
+def sparse(grid):
+    flat = grid.ravel()
+    idx = np.flatnonzero(flat).astype(np.int32)
+    return idx, flat[idx]
+
+
+def gen_tsc(T, C):
+    out = {}
+    for ng in (10, 256):
+        for pre, key in (('tsc', 'pydens'), ('nbodykit_tsc', 'mesh')):
+            g = read_asdf_blsc(REF / 'tests' / 'ref_tsc' / f'{pre}_ngrid{ng}.asdf', key)
+            assert g.shape == (ng, ng, ng)
+            idx, val = sparse(g)
+            out[f'{pre}_ngrid{ng}.idx'] = idx
+            out[f'{pre}_ngrid{ng}.val'] = val
+            print(pre, ng, g.dtype, 'sum', g.sum(dtype='f8'), 'nnz', len(idx))
+    np.savez_compressed(GOLD / 'tsc_ref.npz', **out)
+
+    # check the shimmed reference against its own saved grid (tests/test_tsc.py:105-136)
+    box = 123.0
+    rng = np.random.default_rng(234)
+    pos = rng.random((10000, 3), dtype='f4').astype('f8') * box
+    w = rng.random((10000,), dtype='f4').astype('f8')
+    d10 = np.zeros((10, 10, 10), dtype=np.float32)
+    T._tsc_scatter(pos, d10, box, w)
+    idx, val = out['tsc_ngrid10.idx'], out['tsc_ngrid10.val']
+    ref = np.zeros(1000, dtype=np.float32); ref[idx] = val
+    assert np.allclose(d10.ravel(), ref, rtol=1e-4, atol=1e-5)
+    print('shimmed _tsc_scatter == ref_tsc/tsc_ngrid10.asdf (max abs diff %.3g)' % np.abs(d10.ravel() - ref).max())
+
+    cases = {}
+    N = 3000
+    rng = np.random.default_rng(77)
+    base = rng.random((N, 3), dtype='f4')
+    wts = rng.random(N, dtype='f4')
+    warnings.simplefilter('ignore')
+    for name, dtype, shape, useW, offset, boxs in (
+        ('f4_w', 'f4', (12, 12, 12), True, 0.0, 50.0),
+        ('f4_now', 'f4', (12, 12, 12), False, 0.0, 50.0),
+        ('f8_w', 'f8', (12, 12, 12), True, 0.0, 50.0),
+        ('f4_offset', 'f4', (16, 16, 16), True, 0.5 * 50.0 / 16, 50.0),
+        ('f4_aniso', 'f4', (8, 12, 20), True, 0.0, 50.0),
+        ('f8_grid64', 'f8', (9, 9, 9), False, 0.0, 7.0),
+    ):
+        p = (base.astype(dtype) * boxs).astype(dtype)
+        ww = wts.astype(dtype) if useW else None
+        gdt = np.float64 if name == 'f8_grid64' else np.float32
+        g = np.zeros(shape, dtype=gdt)
+        T._tsc_scatter(p, g, boxs, ww, offset)
+        cases[f'{name}.grid'] = g
+        cases[f'{name}.box'] = np.float64(boxs)
+        cases[f'{name}.offset'] = np.float64(offset)
+    # tsc_parallel end to end incl. in-place wrap of out-of-box particles and accumulation
+    p = ((base - np.float32(0.3)) * np.float32(1.6) * np.float32(50.0)).astype('f4')  # spills both sides
+    p0 = p.copy()
+    g = np.full((12, 12, 12), 0.25, dtype=np.float32)
+    r = T.tsc_parallel(p, g, 50.0, weights=wts, nthread=1)
+    assert r is None
+    cases['parallel_wrap.pos_in'] = p0
+    cases['parallel_wrap.pos_out'] = p
+    cases['parallel_wrap.grid'] = g
+    cases['base'] = base
+    cases['wts'] = wts
+    # partition_parallel (stable counting sort)
+    pp = (base * np.float32(50.0)).astype('f4')
+    ps, st, ws = T.partition_parallel(pp, 7, 50.0, weights=wts, nthread=1)
+    cases['partition.psort'] = ps
+    cases['partition.starts'] = st
+    cases['partition.wsort'] = ws
+    # CIC (cic_serial) - float64 math into a float32 grid
+    g = np.zeros((12, 12, 12), dtype=np.float32)
+    C.cic_serial((base * np.float32(50.0)).astype('f4'), g, 50.0, weights=wts)
+    cases['cic_f4_w.grid'] = g
+    np.savez_compressed(GOLD / 'tsc_cases.npz', **cases)
+    print('tsc_cases written')
+
+
+# ----------------------------------------------------------------------------
+# power spectrum
+# ----------------------------------------------------------------------------
+def gen_power(P):
+    from abacusutils_amd import synth
+    warnings.simplefilter('ignore')
+    L = 500.0
+    N = 20000
+    pos = synth.synth_positions(N, L, seed=300, clustered=True)
+    pos2 = synth.synth_positions(N // 2, L, seed=301, clustered=True)
+    rng = np.random.default_rng(5)
+    w = (0.5 + rng.random(N, dtype='f4')).astype('f4')
+    out = {'meta.L': np.float64(L), 'meta.N': np.int64(N)}
+
+    def store(name, tab):
+        for k in ('k_avg', 'power', 'N_mode', 'poles', 'N_mode_poles', 'k_mid', 'mu_mid'):
+            if k in tab:
+                out[f'{name}.{k}'] = np.asarray(tab[k])
+
+    nmesh = 32
+    for paste in ('TSC', 'CIC'):
+        for comp in (False, True):
+            for inter in (False, True):
+                name = f'{paste}_c{int(comp)}_i{int(inter)}'
+                tab = P.calc_power(pos.copy(), L, kbins=12, mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste=paste,
+                                   nmesh=nmesh, compensated=comp, interlaced=inter, poles=[0, 2, 4], nthread=1)
+                store(name, tab)
+                print(name, 'P[1:4,0]', np.asarray(tab['power'])[1:4, 0])
+    # weights, cross, logk, squeeze, default bins
+    tab = P.calc_power(pos.copy(), L, kbins=10, mubins=None, paste='TSC', nmesh=nmesh, compensated=True,
+                       interlaced=False, w=w, poles=[0, 2], nthread=1)
+    store('TSC_weights_squeeze', tab)
+    tab = P.calc_power(pos.copy(), L, kbins=9, mubins=3, paste='TSC', nmesh=nmesh, compensated=True,
+                       interlaced=True, pos2=pos2.copy(), poles=[0, 2, 4], nthread=1)
+    store('TSC_cross', tab)
+    tab = P.calc_power(pos.copy(), L, kbins=8, mubins=2, logk=True, paste='TSC', nmesh=nmesh, compensated=False,
+                       interlaced=False, nthread=1)
+    store('TSC_logk', tab)
+    tab = P.calc_power(pos.copy(), L, paste='TSC', nmesh=24, compensated=True, interlaced=True, nthread=1)
+    store('TSC_defaults_n24', tab)
+    # odd mesh
+    tab = P.calc_power(pos.copy(), L, kbins=7, mubins=2, paste='TSC', nmesh=27, compensated=True, interlaced=True,
+                       poles=[0, 2], nthread=1)
+    store('TSC_odd27', tab)
+
+    # calc_pk_from_deltak / bin_kmu on a seeded complex field (zcv call pattern)
+    n = 20
+    rng = np.random.default_rng(9)
+    f1 = (rng.standard_normal((n, n, n // 2 + 1)) + 1j * rng.standard_normal((n, n, n // 2 + 1))).astype(np.complex64)
+    f2 = (rng.standard_normal((n, n, n // 2 + 1)) + 1j * rng.standard_normal((n, n, n // 2 + 1))).astype(np.complex64)
+    ke, me = P.get_k_mu_edges(L, np.pi * n / L, 6, 3, False)
+    r = P.calc_pk_from_deltak(f1, L, ke, me, field2_fft=f2, poles=np.array([0, 2, 4, 6]), nthread=1)
+    out['deltak.f1'] = f1
+    out['deltak.f2'] = f2
+    for k, v in r.items():
+        out[f'deltak.cross.{k}'] = np.asarray(v)
+    r = P.calc_pk_from_deltak(f1, L, ke, me, poles=np.array([], dtype='i8'), squeeze_mu_axis=False, nthread=1)
+    for k, v in r.items():
+        out[f'deltak.auto.{k}'] = np.asarray(v)
+    # window functions
+    for paste in ('TSC', 'CIC'):
+        for inter in (False, True):
+            out[f'W.{paste}_i{int(inter)}'] = P.get_W_compensated(L, 32, paste, inter)
+    np.savez_compressed(GOLD / 'power_cases.npz', **out)
+    print('power_cases written')
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['hod', 'tsc', 'power']
+    G, T, P, C = import_reference()
+    GOLD.mkdir(parents=True, exist_ok=True)
+    if 'hod' in which:
+        gen_hod(G)
+    if 'tsc' in which:
+        gen_tsc(T, C)
+    if 'power' in which:
+        gen_power(P)
