@@ -1,0 +1,421 @@
+"""ctypes front-end of the CPU oracle (oracle/abacus_oracle.c) - TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module; the product path (abacusutils_amd) never does.  Function names and
+signatures follow the reference (abacusnbody/...; file:line cited per function);
+the heavy loops are in C, the 3-D FFT is scipy.fft.rfftn (pocketfft), which is
+the reference's own FFT (analysis/power_spectrum.py:12,980,986,1059).
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', str(_HERE)])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = _HERE / 'liboracle.so'
+        src = _HERE / 'abacus_oracle.c'
+        if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+            build()
+        _LIB = C.CDLL(str(so))
+    return _LIB
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+_D = C.c_double
+_LRG_KEYS = ['logM_cut', 'logM1', 'sigma', 'alpha', 'kappa', 'alpha_c', 'alpha_s', 's', 's_v', 's_p', 's_r',
+             'Acent', 'Asat', 'Bcent', 'Bsat', 'ic']
+_ELG_KEYS = ['p_max', 'Q', 'logM_cut', 'kappa', 'sigma', 'logM1', 'alpha', 'gamma', 'A_s', 'alpha_c', 'alpha_s',
+             's', 's_v', 's_p', 's_r', 'Acent', 'Asat', 'Bcent', 'Bsat', 'Ccent', 'Csat', 'ic',
+             'logM1_EE', 'alpha_EE', 'logM1_EL', 'alpha_EL']
+_QSO_KEYS = ['logM_cut', 'kappa', 'sigma', 'logM1', 'alpha', 'alpha_c', 'alpha_s', 's', 's_v', 's_p', 's_r',
+             'Acent', 'Asat', 'Bcent', 'Bsat', 'ic']
+
+
+class HodParams(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ('want_LRG', 'want_ELG', 'want_QSO', 'rsd', 'has_origin', 'enable_ranks', 'pad0', 'pad1')]
+        + [('inv_velz2kms', _D), ('lbox', _D), ('origin', _D * 3)]
+        + [('L_' + k, _D) for k in _LRG_KEYS]
+        + [('E_' + k, _D) for k in _ELG_KEYS]
+        + [('Q_' + k, _D) for k in _QSO_KEYS]
+    )
+
+
+def marshal_params(tracers, params, enable_ranks, rsd):
+    """gen_gals parameter handling (hod/GRAND_HOD.py:1342-1475): z-evolution of
+    logM_cut/logM1, defaults for the optional keys, inv_velz2kms."""
+    p = HodParams()
+    p.rsd = int(bool(rsd))
+    p.enable_ranks = int(bool(enable_ranks))
+    p.inv_velz2kms = 1 / params['velz2kms']
+    p.lbox = params['Lbox']
+    origin = params.get('origin', None)
+    p.has_origin = int(origin is not None)
+    if origin is not None:
+        for i in range(3):
+            p.origin[i] = float(origin[i])
+    for tr, pre, keys in (('LRG', 'L_', _LRG_KEYS), ('ELG', 'E_', _ELG_KEYS), ('QSO', 'Q_', _QSO_KEYS)):
+        if tr not in tracers:
+            continue
+        setattr(p, 'want_' + tr, 1)
+        hod = dict(tracers[tr])
+        delta_a = 1.0 / (1 + params['z']) - 1.0 / (1 + hod.get('z_pivot', params['z']))
+        hod['logM_cut'] = hod['logM_cut'] + hod.get('logM_cut_pr', 0.0) * delta_a
+        hod['logM1'] = hod['logM1'] + hod.get('logM1_pr', 0.0) * delta_a
+        for k in ('Acent', 'Asat', 'Bcent', 'Bsat', 'Ccent', 'Csat'):
+            hod.setdefault(k, 0.0)
+        hod.setdefault('ic', 1.0)
+        if tr == 'ELG':
+            hod.setdefault('logM1_EE', hod['logM1'])
+            hod.setdefault('alpha_EE', hod['alpha'])
+            hod.setdefault('logM1_EL', hod['logM1'])
+            hod.setdefault('alpha_EL', hod['alpha'])
+        for k in keys:
+            setattr(p, pre + k, float(hod[k]))  # KeyError for a missing required key, as the typed dict lookup
+    return p
+
+
+def _f8(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, t=C.c_void_p):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+TRACERS = ('LRG', 'ELG', 'QSO')
+COLS = ('x', 'y', 'z', 'vx', 'vy', 'vz', 'mass')
+
+
+def _two_pass(fn, n, args_before, p, nthread):
+    keep = np.empty(n, dtype=np.int8)
+    counts = np.zeros(3, dtype=np.int64)
+    fn(*args_before, C.byref(p), nthread, _ptr(keep), _ptr(counts), None, None)
+    outs = [[np.empty(counts[t], dtype=np.float64) for _ in COLS] for t in range(3)]
+    ids = [np.empty(counts[t], dtype=np.int64) for t in range(3)]
+    outp = (C.c_void_p * 21)(*[a.ctypes.data for t in range(3) for a in outs[t]])
+    idp = (C.c_void_p * 3)(*[a.ctypes.data for a in ids])
+    fn(*args_before, C.byref(p), nthread, _ptr(keep), _ptr(counts), outp, idp)
+    return keep, outs, ids
+
+
+def gen_cent(halo_data, p, nthread):
+    """hod/GRAND_HOD.py:139-414"""
+    h = halo_data
+    n = len(h['hmass'])
+    arrs = [_f8(h['hpos']), _f8(h['hvel']), _f8(h['hmass']), np.ascontiguousarray(h['hid'], dtype=np.int64),
+            _f8(h['hmultis']), _f8(h['hrandoms']), _f8(h['hveldev'])]
+    opt = [(_f8(h[k]) if k in h else None) for k in ('hdeltac', 'hfenv', 'hshear')]
+    args = [C.c_int64(n)] + [_ptr(a) for a in arrs] + [_ptr(a) for a in opt]
+    return _two_pass(lib().oracle_gen_cent, n, args, p, nthread)
+
+
+def gen_sats(particle_data, p, nthread, keep_cent_at_pinds):
+    """hod/GRAND_HOD.py:825-1262"""
+    s = particle_data
+    n = len(s['phmass'])
+    arrs = [_f8(s['ppos']), _f8(s['pvel']), _f8(s['phvel']), _f8(s['phmass']),
+            np.ascontiguousarray(s['phid'], dtype=np.int64), _f8(s['pweights']), _f8(s['prandoms'])]
+    opt = [(_f8(s[k]) if k in s else None) for k in ('pdeltac', 'pfenv', 'pshear')]
+    ranks = [_f8(s[k]) for k in ('pranks', 'pranksv', 'pranksp', 'pranksr')]
+    kc = np.ascontiguousarray(keep_cent_at_pinds, dtype=np.int8)
+    args = [C.c_int64(n)] + [_ptr(a) for a in arrs + opt + ranks] + [_ptr(kc)]
+    return _two_pass(lib().oracle_gen_sats, n, args, p, nthread)
+
+
+def gen_gal_cat(halo_data, particle_data, tracers, params, Nthread=16, enable_ranks=False, rsd=True,
+                return_keep=False):
+    """gen_gal_cat -> gen_gals (hod/GRAND_HOD.py:1595-1724,1302-1592), particle-based path"""
+    if not isinstance(rsd, bool):
+        raise ValueError('Error: rsd has to be a boolean')
+    p = marshal_params(tracers, params, enable_ranks, rsd)
+    keep_c, out_c, id_c = gen_cent(halo_data, p, Nthread)
+    keep_s, out_s, id_s = gen_sats(particle_data, p, Nthread, keep_c[particle_data['pinds']])
+    mock = {}
+    for tr in tracers:
+        t = TRACERS.index(tr)
+        d = {'Ncent': len(out_c[t][0])}
+        for c, name in enumerate(COLS):
+            d[name] = np.concatenate((out_c[t][c], out_s[t][c]))
+        d['id'] = np.concatenate((id_c[t], id_s[t]))
+        mock[tr] = d
+    if return_keep:
+        return mock, keep_c, keep_s
+    return mock
+
+
+# ---------------------------------------------------------------------------
+# TSC / CIC / partition
+# ---------------------------------------------------------------------------
+def _suffix(a):
+    return {np.dtype('f4'): 'f32', np.dtype('f8'): 'f64'}[a.dtype]
+
+
+def wrap_inplace(pos, box):
+    """analysis/tsc.py:219-226"""
+    getattr(lib(), 'oracle_wrap_inplace_' + _suffix(pos))(_ptr(pos), C.c_int64(len(pos)), _D(box))
+
+
+def tsc_scatter(positions, density, boxsize, weights=None, offset=0.0):
+    """analysis/tsc.py:394-507 (3-D; serial, input order)"""
+    assert positions.flags.c_contiguous and density.flags.c_contiguous and density.ndim == 3
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=positions.dtype)
+    fn = getattr(lib(), f'oracle_tsc_scatter_{_suffix(positions)}_{_suffix(density)}')
+    gx, gy, gz = density.shape
+    fn(_ptr(positions), C.c_int64(len(positions)), _ptr(density), gx, gy, gz, _D(boxsize), _ptr(weights), _D(offset))
+
+
+def cic_serial(positions, density, boxsize, weights=None):
+    """analysis/cic.py:13-125"""
+    assert positions.flags.c_contiguous and density.dtype == np.float32
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=positions.dtype)
+    gx, gy, gz = density.shape
+    getattr(lib(), 'oracle_cic_' + _suffix(positions))(
+        _ptr(positions), C.c_int64(len(positions)), _ptr(density), gx, gy, gz, _D(boxsize), _ptr(weights))
+
+
+def partition_parallel(pos, npartition, boxsize, weights=None, coord=0, nthread=-1, sort=False):
+    """analysis/tsc.py:259-384 (sort=False only)"""
+    assert not sort
+    if nthread < 0:
+        nthread = max_threads()
+    pos = np.ascontiguousarray(pos)
+    psort = np.empty_like(pos)
+    starts = np.empty(npartition + 1, dtype=np.int64)
+    wsort = None
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=pos.dtype)
+        wsort = np.empty_like(weights)
+    getattr(lib(), 'oracle_partition_' + _suffix(pos))(
+        _ptr(pos), C.c_int64(len(pos)), int(npartition), _D(boxsize), _ptr(weights), int(coord), int(nthread),
+        _ptr(psort), _ptr(starts), _ptr(wsort))
+    return psort, starts, wsort
+
+
+def default_npartition(n1d, nthread):
+    """analysis/tsc.py:126-139"""
+    if nthread > 1:
+        if 2 * nthread >= n1d // 2:
+            npartition = n1d // 2
+            npartition = 2 * (npartition // 2)
+            if npartition < n1d // 2:
+                npartition = n1d // 3
+        else:
+            npartition = min(n1d // 3, 2 * nthread)
+        npartition = 2 * (npartition // 2)
+    else:
+        npartition = 1
+    return max(npartition, 1)
+
+
+def tsc_parallel(pos, densgrid, box, weights=None, nthread=-1, wrap=True, npartition=None, offset=0.0):
+    """analysis/tsc.py:10-206: wrap in place -> stripe partition -> even/odd stripe scatter"""
+    if nthread < 0:
+        nthread = max_threads()
+    if isinstance(densgrid, (int, np.integer)):
+        densgrid = (densgrid,) * 3
+    user = not isinstance(densgrid, tuple)
+    if not user:
+        densgrid = np.zeros(densgrid, dtype=np.float32)
+    n1d = densgrid.shape[0]
+    if not npartition:
+        npartition = default_npartition(n1d, nthread)
+    if npartition > n1d // 3 and npartition != n1d // 2 and nthread > 1:
+        raise ValueError(f'npartition {npartition} must be less than ngrid//3 = {n1d // 3} or equal to ngrid//2 = {n1d // 2}')
+    if npartition > 1 and npartition % 2 != 0 and nthread > 1:
+        raise ValueError(f'npartition {npartition} not divisible by 2')
+    if wrap:
+        wrap_inplace(pos, box)
+    if npartition > 1:
+        ppart, starts, wpart = partition_parallel(pos, npartition, box, weights=weights, nthread=nthread)
+    else:
+        ppart, wpart = pos, (None if weights is None else np.ascontiguousarray(weights, dtype=pos.dtype))
+        starts = np.array([0, len(pos)], dtype=np.int64)
+    fn = getattr(lib(), f'oracle_tsc_parallel_{_suffix(ppart)}_f32')
+    gx, gy, gz = densgrid.shape
+    fn(_ptr(ppart), _ptr(starts), int(len(starts) - 1), _ptr(densgrid), gx, gy, gz, _D(box), _ptr(wpart),
+       _D(offset), int(nthread))
+    return None if user else densgrid
+
+
+# ---------------------------------------------------------------------------
+# power spectrum
+# ---------------------------------------------------------------------------
+def get_k_mu_edges(Lbox, k_max, kbins, mubins, logk):
+    """analysis/power_spectrum.py:663-704"""
+    if isinstance(kbins, int):
+        if logk:
+            kbins = np.geomspace((1.0 - 1.0e-4) * 2.0 * np.pi / Lbox, k_max, kbins + 1)
+        else:
+            kbins = np.linspace(0.0, k_max, kbins + 1)
+    if isinstance(mubins, int):
+        mubins = np.linspace(0.0, 1.0, mubins + 1)
+    return kbins, mubins
+
+
+def get_W_compensated(Lbox, nmesh, paste, interlaced):
+    """analysis/power_spectrum.py:1081-1128"""
+    from scipy.fft import fftfreq
+    d = Lbox / nmesh
+    kN = np.pi / d
+    k = (fftfreq(nmesh, d=d) * 2.0 * np.pi).astype(np.float32)
+    paste = paste.upper()
+    if interlaced:
+        if paste == 'TSC':
+            p = 3.0
+        elif paste == 'CIC':
+            p = 2.0
+        else:
+            raise ValueError(f'Unknown pasting method {paste}')
+        W = np.sinc(0.5 * k / kN) ** p
+    else:
+        s = np.sin(0.5 * np.pi * k / kN) ** 2
+        if paste == 'TSC':
+            W = (1 - s + 2.0 / 15 * s**2) ** 0.5
+        elif paste == 'CIC':
+            W = (1 - 2.0 / 3 * s) ** 0.5
+        else:
+            raise ValueError(f'Unknown pasting method {paste}')
+    return W
+
+
+def get_field(pos, Lbox, nmesh, paste, w=None, d=0.0, nthread=1):
+    """analysis/power_spectrum.py:808-857 (float32 mesh)"""
+    field = np.zeros((nmesh, nmesh, nmesh), dtype=np.float32)
+    paste = paste.upper()
+    if paste == 'TSC':
+        tsc_parallel(pos, field, Lbox, weights=w, nthread=nthread, offset=d)
+    elif paste == 'CIC':
+        cic_serial(np.ascontiguousarray(pos + d) if d != 0.0 else pos, field, Lbox, weights=w)
+    else:
+        raise ValueError(f'Unknown pasting method: {paste}')
+    lib().oracle_normalize_field_f32(_ptr(field), C.c_int64(field.size), _D(len(pos)))
+    return field
+
+
+def get_field_fft(pos, Lbox, nmesh, paste, w, W, compensated, interlaced, nthread=1):
+    """analysis/power_spectrum.py:1001-1070, 951-998"""
+    from scipy.fft import rfftn
+    L = lib()
+    if interlaced:
+        d = Lbox / nmesh
+        f = rfftn(get_field(pos, Lbox, nmesh, paste, w, nthread=nthread), workers=nthread)
+        fs = rfftn(get_field(pos, Lbox, nmesh, paste, w, d=0.5 * d, nthread=nthread), workers=nthread)
+        assert f.dtype == np.complex64
+        L.oracle_shift_field_fft(_ptr(f), _ptr(fs), int(nmesh), _D(Lbox), _D(d))
+    else:
+        field = get_field(pos, Lbox, nmesh, paste, w, nthread=nthread)
+        inv_size = np.float32(1 / field.size)
+        f = rfftn(field, overwrite_x=True, workers=nthread)
+        L.oracle_scale_c64(_ptr(f), C.c_int64(f.size), C.c_float(inv_size))
+    if compensated:
+        L.oracle_compensate(_ptr(f), int(nmesh), _ptr(np.ascontiguousarray(W, dtype=np.float32)))
+    return f
+
+
+def bin_kmu(n1d, L, kedges, muedges, weights, poles=np.empty(0, 'i8'), fourier=True, accum64=False, nthread=1):
+    """analysis/power_spectrum.py:150-300"""
+    kedges = _f8(kedges)
+    muedges = _f8(muedges)
+    poles = np.ascontiguousarray(poles, dtype=np.int64)
+    Nk, Nmu, Np = len(kedges) - 1, len(muedges) - 1, len(poles)
+    weights = np.ascontiguousarray(weights, dtype=np.float32)
+    power = np.zeros((Nk, Nmu), dtype=np.float32)
+    counts = np.zeros((Nk, Nmu), dtype=np.int64)
+    bpoles = np.zeros((Np, Nk), dtype=np.float32)
+    cpoles = np.zeros(Nk, dtype=np.int64)
+    kavg = np.zeros((Nk, Nmu), dtype=np.float32)
+    lib().oracle_bin_kmu(int(n1d), _D(L), _ptr(kedges), Nk, _ptr(muedges), Nmu, _ptr(weights), _ptr(poles), Np,
+                         int(fourier), int(accum64), int(nthread), _ptr(power), _ptr(counts), _ptr(bpoles),
+                         _ptr(cpoles), _ptr(kavg))
+    return power, counts, bpoles, cpoles, kavg
+
+
+def calc_pk_from_deltak(field_fft, Lbox, k_bin_edges, mu_bin_edges, field2_fft=None, poles=np.empty(0, 'i8'),
+                        squeeze_mu_axis=True, nthread=1, accum64=False):
+    """analysis/power_spectrum.py:730-805"""
+    field_fft = np.ascontiguousarray(field_fft, dtype=np.complex64)
+    raw = np.empty(field_fft.shape, dtype=np.float32)
+    f2 = None if field2_fft is None else np.ascontiguousarray(field2_fft, dtype=np.complex64)
+    lib().oracle_raw_power(_ptr(field_fft), _ptr(f2), C.c_int64(field_fft.size), _ptr(raw))
+    nmesh = raw.shape[0]
+    power, N_mode, binned_poles, N_mode_poles, k_avg = bin_kmu(
+        nmesh, Lbox, k_bin_edges, mu_bin_edges, raw, poles, accum64=accum64, nthread=nthread)
+    power *= Lbox**3
+    if len(poles) > 0:
+        binned_poles *= Lbox**3
+    if squeeze_mu_axis and len(mu_bin_edges) == 2:
+        power, N_mode, k_avg = power[:, 0], N_mode[:, 0], k_avg[:, 0]
+    return dict(power=power, N_mode=N_mode, binned_poles=binned_poles, N_mode_poles=N_mode_poles, k_avg=k_avg)
+
+
+def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste='TSC', nmesh=128,
+               compensated=True, interlaced=True, w=None, pos2=None, w2=None, poles=None, squeeze_mu_axis=True,
+               nthread=1, accum64=False):
+    """analysis/power_spectrum.py:1131-1319; returns a plain dict with the Table's columns"""
+    if kbins is None:
+        kbins = nmesh
+    if k_max is None:
+        k_max = np.pi * nmesh / Lbox
+    return_mubins = mubins is not None
+    if mubins is None:
+        mubins = 1
+    W = get_W_compensated(Lbox, nmesh, paste, interlaced) if compensated else None
+    f1 = get_field_fft(pos, Lbox, nmesh, paste, w, W, compensated, interlaced, nthread=nthread)
+    f2 = None
+    if pos2 is not None:
+        f2 = get_field_fft(pos2, Lbox, nmesh, paste, w2, W, compensated, interlaced, nthread=nthread)
+    poles = np.asarray(poles or [], dtype=np.int64)
+    kbins, mubins = get_k_mu_edges(Lbox, k_max, kbins, mubins, logk)
+    P = calc_pk_from_deltak(f1, Lbox, kbins, mubins, field2_fft=f2, poles=poles, squeeze_mu_axis=squeeze_mu_axis,
+                            nthread=nthread, accum64=accum64)
+    res = dict(k_min=kbins[:-1], k_max=kbins[1:], k_mid=(kbins[1:] + kbins[:-1]) * 0.5, k_avg=P['k_avg'],
+               power=P['power'], N_mode=P['N_mode'])
+    if len(poles) > 0:
+        res.update(poles=P['binned_poles'].T, N_mode_poles=P['N_mode_poles'])
+    if return_mubins:
+        mu_binc = (mubins[1:] + mubins[:-1]) * 0.5
+        res.update(mu_min=np.broadcast_to(mubins[:-1], res['power'].shape),
+                   mu_max=np.broadcast_to(mubins[1:], res['power'].shape),
+                   mu_mid=np.broadcast_to(mu_binc, res['power'].shape))
+    return res
+
+
+# ---------------------------------------------------------------------------
+# pair counting (parity unpinned - Corrfunc is third party)
+# ---------------------------------------------------------------------------
+def paircount_brute(mode, x1, y1, z1, boxsize, bins, x2=None, y2=None, z2=None, pimax=0.0, npibins=0,
+                    mu_max=1.0, nmubins=0, nthread=-1):
+    """mode 'r' | 'rppi' | 'smu' ; float32 inputs as analysis/tpcf_corrfunc.py:134-139 casts them"""
+    m = {'r': 0, 'rppi': 1, 'smu': 2}[mode]
+    if nthread < 0:
+        nthread = max_threads()
+    f4 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    x1, y1, z1, x2, y2, z2 = map(f4, (x1, y1, z1, x2, y2, z2))
+    bins = f4(bins)
+    nb = len(bins) - 1
+    nsub = 1 if m == 0 else (npibins if m == 1 else nmubins)
+    out = np.zeros(nb * nsub, dtype=np.uint64)
+    auto = x2 is None
+    lib().oracle_paircount_brute(m, int(auto), _ptr(x1), _ptr(y1), _ptr(z1), C.c_int64(len(x1)),
+                                 _ptr(x2), _ptr(y2), _ptr(z2), C.c_int64(0 if auto else len(x2)),
+                                 C.c_float(boxsize), _ptr(bins), nb, C.c_float(pimax), int(npibins),
+                                 C.c_float(mu_max), int(nmubins), int(nthread), _ptr(out))
+    return out

@@ -1,0 +1,58 @@
+"""CPU oracle (oracle/abacus_oracle.c) vs the reference's own fixtures and the golden
+vectors captured from the reference (oracle/make_golden.py).  No GPU needed."""
+import numpy as np
+import pytest
+from conftest import (SYNTH_CASES, assert_mock_equal, input_checksum, load_golden, synth_case, unpack_inputs,
+                      unpack_mock)
+
+from oracle import oracle
+
+
+@pytest.mark.parametrize('name', ['hod_mini', 'hod_lc'])
+@pytest.mark.parametrize('nthread', [1, 4])
+def test_reference_fixture(name, nthread):
+    """tests/ref_hod/**/galaxies_rsd/{LRGs,ELGs}.dat of the reference (tests/test_hod.py:109-134,
+    tests/test_lc_hod.py): ids exact, floats to tests/common.py's rtol 1e-7 - here bit-exact."""
+    g = load_golden(name)
+    hd, pd, params = unpack_inputs(g)
+    import yaml  # noqa: F401  (HOD of tests/abacus_hod.yaml:31-70)
+    from abacusutils_amd import synth
+    tracers = {'LRG': synth.LRG_PARAMS, 'ELG': synth.ELG_PARAMS}
+    mock = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=nthread, enable_ranks=False, rsd=True)
+    want = unpack_mock(g, 'expect')
+    assert_mock_equal(mock, want, exact=False, rtol=1e-14)   # ECSV text round trip
+    assert_mock_equal(mock, unpack_mock(g, 'shim'), exact=True)   # what the reference returned, bitwise
+
+
+@pytest.mark.parametrize('name', SYNTH_CASES)
+def test_synthetic_golden(name):
+    g = load_golden('hod_synth_' + name)
+    hd, pd, params, tracers, ranks, rsd = synth_case(g)
+    assert input_checksum(hd, pd) == float(g['meta.checksum']), 'numpy Generator stream changed'
+    mock = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=5, enable_ranks=ranks, rsd=rsd)
+    assert_mock_equal(mock, unpack_mock(g, 'expect'), exact=True)
+
+
+def test_thread_count_invariance():
+    g = load_golden('hod_synth_all_rich')
+    hd, pd, params, tracers, ranks, rsd = synth_case(g)
+    a = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=1, enable_ranks=ranks, rsd=rsd)
+    b = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=7, enable_ranks=ranks, rsd=rsd)
+    assert_mock_equal(a, b)
+
+
+def test_rsd_must_be_bool():
+    g = load_golden('hod_mini')
+    hd, pd, params = unpack_inputs(g)
+    from abacusutils_amd import synth
+    with pytest.raises(ValueError):
+        oracle.gen_gal_cat(hd, pd, {'LRG': synth.LRG_PARAMS}, params, rsd=1)
+
+
+def test_empty_inputs():
+    from abacusutils_amd import synth
+    hd, pd, params = synth.synth_hod_inputs(50, 50, seed=1)
+    hd = {k: v[:0] for k, v in hd.items()}
+    pd = {k: v[:0] for k, v in pd.items()}
+    mock = oracle.gen_gal_cat(hd, pd, {'LRG': synth.LRG_PARAMS}, params, Nthread=3)
+    assert mock['LRG']['Ncent'] == 0 and len(mock['LRG']['x']) == 0
