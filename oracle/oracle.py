@@ -250,8 +250,13 @@ def tsc_parallel(pos, densgrid, box, weights=None, nthread=-1, wrap=True, nparti
         starts = np.array([0, len(pos)], dtype=np.int64)
     fn = getattr(lib(), f'oracle_tsc_parallel_{_suffix(ppart)}_f32')
     gx, gy, gz = densgrid.shape
+    # The reference admits npartition == n1d//2 (tsc.py:128-134,141): stripes two cells wide, while a TSC cloud
+    # reaches 1.5 cells past its stripe on each side, so same-parity stripes can touch the same x-plane (a data
+    # race in the reference; it needs two threads in the same cell at the same instant).  The oracle must be
+    # deterministic: stripes narrower than three cells are scattered serially.
+    scatter_threads = nthread if npartition <= max(n1d // 3, 1) else 1
     fn(_ptr(ppart), _ptr(starts), int(len(starts) - 1), _ptr(densgrid), gx, gy, gz, _D(box), _ptr(wpart),
-       _D(offset), int(nthread))
+       _D(offset), int(scatter_threads))
     return None if user else densgrid
 
 
