@@ -1,0 +1,186 @@
+"""ctypes binding of libabacus_hip.so (C ABI: include/abacus_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is
+visible when a compute entry point is called, the call raises.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / 'libabacus_hip.so'
+_lib = None
+
+
+class AbacusHipError(RuntimeError):
+    pass
+
+
+_D = C.c_double
+_LRG_KEYS = ['logM_cut', 'logM1', 'sigma', 'alpha', 'kappa', 'alpha_c', 'alpha_s', 's', 's_v', 's_p', 's_r',
+             'Acent', 'Asat', 'Bcent', 'Bsat', 'ic']
+_ELG_KEYS = ['p_max', 'Q', 'logM_cut', 'kappa', 'sigma', 'logM1', 'alpha', 'gamma', 'A_s', 'alpha_c', 'alpha_s',
+             's', 's_v', 's_p', 's_r', 'Acent', 'Asat', 'Bcent', 'Bsat', 'Ccent', 'Csat', 'ic',
+             'logM1_EE', 'alpha_EE', 'logM1_EL', 'alpha_EL']
+_QSO_KEYS = ['logM_cut', 'kappa', 'sigma', 'logM1', 'alpha', 'alpha_c', 'alpha_s', 's', 's_v', 's_p', 's_r',
+             'Acent', 'Asat', 'Bcent', 'Bsat', 'ic']
+TRACER_KEYS = {'LRG': ('L_', _LRG_KEYS), 'ELG': ('E_', _ELG_KEYS), 'QSO': ('Q_', _QSO_KEYS)}
+
+
+class HodParams(C.Structure):
+    """struct abacus_hod_params"""
+    _fields_ = (
+        [(n, C.c_int32) for n in ('want_LRG', 'want_ELG', 'want_QSO', 'rsd', 'has_origin', 'enable_ranks',
+                                  'pad0', 'pad1')]
+        + [('inv_velz2kms', _D), ('lbox', _D), ('origin', _D * 3)]
+        + [('L_' + k, _D) for k in _LRG_KEYS]
+        + [('E_' + k, _D) for k in _ELG_KEYS]
+        + [('Q_' + k, _D) for k in _QSO_KEYS]
+    )
+
+
+_HALO_F8 = ('hpos', 'hvel', 'hmass')
+_P = C.c_void_p
+
+
+class HodArrays(C.Structure):
+    """struct abacus_hod_arrays"""
+    _fields_ = (
+        [('n_halo', C.c_int64)]
+        + [(k, _P) for k in ('hpos', 'hvel', 'hmass', 'hid', 'hmultis', 'hrandoms', 'hveldev', 'hdeltac', 'hfenv',
+                             'hshear')]
+        + [('n_part', C.c_int64)]
+        + [(k, _P) for k in ('ppos', 'pvel', 'phvel', 'phmass', 'phid', 'pweights', 'prandoms', 'pdeltac', 'pfenv',
+                             'pshear', 'pranks', 'pranksv', 'pranksp', 'pranksr', 'pinds')]
+    )
+
+
+def available():
+    """True if the shared library exists (says nothing about a GPU being present)."""
+    return _SO.exists()
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not _SO.exists():
+            raise AbacusHipError(
+                f'{_SO} not found: build it with `make -C {_HERE / "csrc"}` (or __graft_entry__.build()). '
+                'abacusutils_amd has no CPU fallback.')
+        L = C.CDLL(str(_SO))
+        L.abacus_last_error.restype = C.c_char_p
+        L.abacus_get_stream.restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AbacusHipError(lib().abacus_last_error().decode())
+
+
+def ptr(a):
+    """void* of a C-contiguous ndarray (None -> NULL)"""
+    if a is None:
+        return None
+    assert a.flags.c_contiguous
+    return C.c_void_p(a.ctypes.data)
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    check(lib().abacus_device_name(buf, 256))
+    return buf.value.decode()
+
+
+def device_count():
+    n = C.c_int(0)
+    try:
+        check(lib().abacus_device_count(C.byref(n)))
+    except AbacusHipError:
+        return 0
+    return n.value
+
+
+def set_device(i):
+    check(lib().abacus_set_device(int(i)))
+
+
+def sync():
+    check(lib().abacus_device_sync())
+
+
+class DeviceArray:
+    """A raw HBM allocation holding a copy of a NumPy array (bench / tests keep inputs resident this way)."""
+
+    def __init__(self, host=None, nbytes=None, dtype=None, shape=None):
+        self.ptr = C.c_void_p()
+        if host is not None:
+            host = np.ascontiguousarray(host)
+            nbytes, dtype, shape = host.nbytes, host.dtype, host.shape
+        self.nbytes, self.dtype, self.shape = int(nbytes), np.dtype(dtype), tuple(shape)
+        check(lib().abacus_malloc(C.byref(self.ptr), C.c_uint64(self.nbytes)))
+        if host is not None and self.nbytes:
+            check(lib().abacus_memcpy_h2d(self.ptr, ptr(host), C.c_uint64(self.nbytes)))
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            check(lib().abacus_memcpy_d2h(ptr(out), self.ptr, C.c_uint64(self.nbytes)))
+        return out
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.nbytes == self.nbytes
+        check(lib().abacus_memcpy_h2d(self.ptr, ptr(host), C.c_uint64(self.nbytes)))
+
+    def free(self):
+        if self.ptr:
+            lib().abacus_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.ev = C.c_void_p()
+        check(lib().abacus_event_create(C.byref(self.ev)))
+
+    def record(self):
+        check(lib().abacus_event_record(self.ev))
+
+    def elapsed_ms_since(self, start):
+        ms = C.c_float(0)
+        check(lib().abacus_event_elapsed_ms(start.ev, self.ev, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().abacus_event_destroy(self.ev)
+        except Exception:
+            pass
+
+
+def profile_enable(on=True):
+    check(lib().abacus_profile_enable(int(on)))
+
+
+def profile_reset():
+    check(lib().abacus_profile_reset())
+
+
+def profile_get():
+    """{kernel name: (total ms, launches)} measured with HIP events on the library stream"""
+    cap = 64
+    names = (C.c_char_p * cap)()
+    ms = (C.c_double * cap)()
+    n = (C.c_int64 * cap)()
+    k = lib().abacus_profile_get(names, ms, n, cap)
+    return {names[i].decode(): (ms[i], n[i]) for i in range(min(k, cap))}

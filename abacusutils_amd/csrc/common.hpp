@@ -1,0 +1,70 @@
+// Shared runtime plumbing of libabacus_hip.so: error reporting, the library stream, device buffers and the
+// per-kernel event profiler behind abacus_profile_* (include/abacus_hip.h).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace abacus {
+
+int fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int ensure_init();
+hipStream_t stream();
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return ::abacus::fail("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);      \
+    } while (0)
+
+#define ABACUS_TRY(expr)        \
+    do {                        \
+        int r_ = (expr);        \
+        if (r_ != 0) return r_; \
+    } while (0)
+
+// profiler hooks: no-ops unless abacus_profile_enable(1)
+void prof_begin(const char *name);
+void prof_end(const char *name);
+
+// Launch a kernel on the library stream, bracketed by profiler events when profiling is on.
+#define ABACUS_LAUNCH(name, kernel, grid, block, shmem, ...)                                     \
+    do {                                                                                         \
+        ::abacus::prof_begin(name);                                                              \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, ::abacus::stream(), __VA_ARGS__);         \
+        ::abacus::prof_end(name);                                                                \
+        HIP_TRY(hipGetLastError());                                                              \
+    } while (0)
+
+// growable device allocation (never shrinks); contents are NOT preserved across grow()
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t nbytes) {
+        if (nbytes <= cap) return 0;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc(&p, nbytes));
+        cap = nbytes;
+        return 0;
+    }
+    int release() {
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        return 0;
+    }
+    template <class T>
+    T *as() const {
+        return static_cast<T *>(p);
+    }
+};
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace abacus

@@ -1,0 +1,222 @@
+// Runtime entry points of include/abacus_hip.h: device selection, the library stream, raw device memory,
+// HIP-event timers and the per-kernel profiler.
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/abacus_hip.h"
+#include "common.hpp"
+
+namespace abacus {
+
+static thread_local std::string g_err;
+static int g_device = 0;
+static bool g_inited = false;
+static hipStream_t g_stream = nullptr;
+static bool g_own_stream = false;
+static std::mutex g_mu;
+
+int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+int ensure_init() {
+    if (g_inited) return 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_inited) return 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail("no HIP device available (%s); libabacus_hip.so has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    HIP_TRY(hipSetDevice(g_device));
+    if (!g_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        g_own_stream = true;
+    }
+    g_inited = true;
+    return 0;
+}
+
+hipStream_t stream() { return g_stream; }
+
+// ---- profiler -------------------------------------------------------------------------------------------
+struct ProfEntry {
+    double total_ms = 0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+static bool g_prof = false;
+static std::map<std::string, ProfEntry> g_prof_map;
+static std::vector<hipEvent_t> g_event_pool;
+static hipEvent_t g_prof_open = nullptr;
+
+static hipEvent_t pool_get() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(const char *name) {
+    if (!g_prof) return;
+    g_prof_open = pool_get();
+    (void)hipEventRecord(g_prof_open, g_stream);
+}
+
+void prof_end(const char *name) {
+    if (!g_prof || !g_prof_open) return;
+    hipEvent_t stop = pool_get();
+    (void)hipEventRecord(stop, g_stream);
+    g_prof_map[name].pending.emplace_back(g_prof_open, stop);
+    g_prof_open = nullptr;
+}
+
+static void prof_drain() {
+    for (auto &kv : g_prof_map) {
+        for (auto &pr : kv.second.pending) {
+            float ms = 0;
+            if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                kv.second.total_ms += ms;
+                kv.second.launches += 1;
+            }
+            g_event_pool.push_back(pr.first);
+            g_event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+}  // namespace abacus
+
+using namespace abacus;
+
+extern "C" {
+
+const char *abacus_last_error(void) { return g_err.c_str(); }
+
+int abacus_device_count(int *n) {
+    HIP_TRY(hipGetDeviceCount(n));
+    return 0;
+}
+
+int abacus_set_device(int device) {
+    if (g_inited && device != g_device) return fail("abacus_set_device(%d) after initialisation on device %d", device, g_device);
+    g_device = device;
+    return 0;
+}
+
+int abacus_device_name(char *buf, int len) {
+    ABACUS_TRY(ensure_init());
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+    snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int abacus_device_sync(void) {
+    ABACUS_TRY(ensure_init());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+void *abacus_get_stream(void) {
+    if (ensure_init() != 0) return nullptr;
+    return (void *)g_stream;
+}
+
+int abacus_set_stream(void *s) {
+    if (g_inited && g_own_stream && g_stream) {
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipStreamDestroy(g_stream));
+    }
+    g_stream = (hipStream_t)s;
+    g_own_stream = false;
+    return ensure_init();
+}
+
+int abacus_malloc(void **dptr, uint64_t nbytes) {
+    ABACUS_TRY(ensure_init());
+    HIP_TRY(hipMalloc(dptr, nbytes ? nbytes : 1));
+    return 0;
+}
+int abacus_free(void *dptr) {
+    if (dptr) HIP_TRY(hipFree(dptr));
+    return 0;
+}
+int abacus_memcpy_h2d(void *dst, const void *src, uint64_t nbytes) {
+    ABACUS_TRY(ensure_init());
+    HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+int abacus_memcpy_d2h(void *dst, const void *src, uint64_t nbytes) {
+    ABACUS_TRY(ensure_init());
+    HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+int abacus_memset(void *dptr, int value, uint64_t nbytes) {
+    ABACUS_TRY(ensure_init());
+    HIP_TRY(hipMemsetAsync(dptr, value, nbytes, g_stream));
+    return 0;
+}
+
+int abacus_event_create(void **ev) {
+    ABACUS_TRY(ensure_init());
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = (void *)e;
+    return 0;
+}
+int abacus_event_record(void *ev) {
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, g_stream));
+    return 0;
+}
+int abacus_event_elapsed_ms(void *start, void *stop, float *ms) {
+    HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+int abacus_event_destroy(void *ev) {
+    HIP_TRY(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+
+int abacus_profile_enable(int on) {
+    ABACUS_TRY(ensure_init());
+    if (!on && g_prof) prof_drain();
+    g_prof = on != 0;
+    return 0;
+}
+int abacus_profile_reset(void) {
+    prof_drain();
+    g_prof_map.clear();
+    return 0;
+}
+int abacus_profile_get(const char **names, double *total_ms, int64_t *launches, int cap) {
+    prof_drain();
+    int i = 0;
+    for (auto &kv : g_prof_map) {
+        if (i < cap) {
+            names[i] = kv.first.c_str();  // stable until the next abacus_profile_reset
+            total_ms[i] = kv.second.total_ms;
+            launches[i] = kv.second.launches;
+        }
+        i++;
+    }
+    return i;
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+"""MI355X drop-in for the reference's `abacusnbody.hod.GRAND_HOD` population entry points.
+
+`gen_gal_cat` / `gen_gals` keep the reference signatures and return structure
+(abacusnbody/hod/GRAND_HOD.py:1595-1724, 1302-1592); the central/satellite loops
+(`gen_cent` :139-414, `gen_sats` :825-1262) and the concatenation
+(`fast_concatenate` :1265-1299) run as HIP kernels behind include/abacus_hip.h
+(`abacus_hod_*`).  `Nthread` is accepted and ignored (there are no host threads).
+
+Device residency: `StagedCatalog` uploads the halo/particle subsample once and is
+reused for any number of `populate` calls, which is what `AbacusHOD.staging()`
+does on the host in the reference (hod/abacus_hod.py:193-197).  `gen_gal_cat`
+called with plain dicts stages, populates and frees (stateless, like the
+reference); `AbacusHOD.run_hod` keeps the staged catalog alive.
+"""
+import ctypes as C
+import os
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+from .. import _lib
+from .._lib import HodArrays, HodParams, TRACER_KEYS, check, ptr
+
+TRACERS = ('LRG', 'ELG', 'QSO')
+COLS = ('x', 'y', 'z', 'vx', 'vy', 'vz', 'mass')
+
+_HALO_REQ = ('hpos', 'hvel', 'hmass', 'hid', 'hmultis', 'hrandoms', 'hveldev')
+_HALO_OPT = ('hdeltac', 'hfenv', 'hshear')
+_PART_REQ = ('ppos', 'pvel', 'phvel', 'phmass', 'phid', 'pweights', 'prandoms')
+_PART_OPT = ('pdeltac', 'pfenv', 'pshear', 'pranks', 'pranksv', 'pranksp', 'pranksr', 'pinds')
+
+
+def marshal_params(tracers, params, enable_ranks, rsd):
+    """Parameter handling of gen_gals (hod/GRAND_HOD.py:1342-1475) -> struct abacus_hod_params.
+
+    z-evolution `logM_cut += logM_cut_pr * Delta_a`, `logM1 += logM1_pr * Delta_a` with
+    `Delta_a = 1/(1+z) - 1/(1+z_pivot)` (:1362-1371); defaults `Acent..Csat = 0`, `ic = 1`,
+    `logM1_EE/EL = logM1`, `alpha_EE/EL = alpha` (:1373-1379,1411-1421,1456-1460).  Keys without a
+    default (`alpha_c`, `alpha_s`, `s`, ...) raise KeyError exactly as the typed-dict lookup would.
+    """
+    p = HodParams()
+    p.rsd = int(bool(rsd))
+    p.enable_ranks = int(bool(enable_ranks))
+    p.inv_velz2kms = 1 / params['velz2kms']
+    p.lbox = params['Lbox']
+    origin = params.get('origin', None)
+    p.has_origin = int(origin is not None)
+    if origin is not None:
+        for i in range(3):
+            p.origin[i] = float(origin[i])
+    for tr in tracers.keys():
+        if tr not in TRACER_KEYS:
+            continue
+        pre, keys = TRACER_KEYS[tr]
+        setattr(p, 'want_' + tr, 1)
+        hod = dict(tracers[tr])
+        delta_a = 1.0 / (1 + params['z']) - 1.0 / (1 + hod.get('z_pivot', params['z']))
+        hod['logM_cut'] = hod['logM_cut'] + hod.get('logM_cut_pr', 0.0) * delta_a
+        hod['logM1'] = hod['logM1'] + hod.get('logM1_pr', 0.0) * delta_a
+        for k in ('Acent', 'Asat', 'Bcent', 'Bsat', 'Ccent', 'Csat'):
+            hod.setdefault(k, 0.0)
+        hod.setdefault('ic', 1.0)
+        if tr == 'ELG':
+            hod.setdefault('logM1_EE', hod['logM1'])
+            hod.setdefault('alpha_EE', hod['alpha'])
+            hod.setdefault('logM1_EL', hod['logM1'])
+            hod.setdefault('alpha_EL', hod['alpha'])
+        for k in keys:
+            setattr(p, pre + k, float(hod[k]))
+    return p
+
+
+def _as(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class StagedCatalog:
+    """The halo + particle subsample resident in HBM (abacus_hod_stage).
+
+    `halo_data` / `particle_data` are the dicts `AbacusHOD.staging()` builds
+    (hod/abacus_hod.py:659-702).  float64 / int64 conversion happens here once.
+    """
+
+    def __init__(self, halo_data, particle_data):
+        self._h = C.c_void_p()
+        self.n_halo = len(halo_data['hmass'])
+        self.n_part = len(particle_data['phmass']) if 'phmass' in particle_data else 0
+        arrs = HodArrays()
+        keep = []  # host copies must outlive the upload call
+
+        def put(name, src, dtype, required):
+            if name in src and src[name] is not None:
+                a = _as(src[name], dtype)
+                keep.append(a)
+                setattr(arrs, name, a.ctypes.data)
+            elif required:
+                raise KeyError(name)
+
+        arrs.n_halo = self.n_halo
+        arrs.n_part = self.n_part
+        for k in _HALO_REQ:
+            put(k, halo_data, np.int64 if k == 'hid' else np.float64, True)
+        for k in _HALO_OPT:
+            put(k, halo_data, np.float64, False)
+        if self.n_part or 'ppos' in particle_data:
+            for k in _PART_REQ:
+                put(k, particle_data, np.int64 if k == 'phid' else np.float64, True)
+            for k in _PART_OPT:
+                put(k, particle_data, np.int64 if k == 'pinds' else np.float64, False)
+        hv = halo_data['hveldev']
+        if np.ndim(hv) != 2:
+            raise ValueError('hveldev must have shape (N, 3)')
+        check(_lib.lib().abacus_hod_stage(C.byref(arrs), 0, C.byref(self._h)))
+        self.has_ranks = all(k in particle_data for k in ('pranks', 'pranksv', 'pranksp', 'pranksr'))
+        self.counts = None
+
+    def update(self, field, values):
+        """re-upload `hrandoms`, `hveldev` or `prandoms` (the arrays `reseed` rewrites, hod/abacus_hod.py:824-835)"""
+        a = _as(values, np.float64)
+        check(_lib.lib().abacus_hod_update(self._h, field.encode(), ptr(a)))
+
+    def populate(self, p):
+        """decide + emit on the device; returns (Ncent[3], Nsat[3])"""
+        counts = (C.c_int64 * 6)()
+        check(_lib.lib().abacus_hod_populate(self._h, C.byref(p), counts))
+        self.counts = np.array(counts[:], dtype=np.int64)
+        return self.counts[:3].copy(), self.counts[3:].copy()
+
+    def populate_async(self, p):
+        """enqueue only (bench): no host synchronisation, no result copy"""
+        check(_lib.lib().abacus_hod_populate_async(self._h, C.byref(p)))
+
+    def wait_counts(self):
+        counts = (C.c_int64 * 6)()
+        check(_lib.lib().abacus_hod_counts(self._h, counts))
+        self.counts = np.array(counts[:], dtype=np.int64)
+        return self.counts
+
+    def fetch(self, tracer):
+        """device -> host copy of one tracer's catalog, in the reference's dict form (:1573-1589)"""
+        t = TRACERS.index(tracer)
+        n = int(self.counts[t] + self.counts[3 + t])
+        cols = {c: np.empty(n, dtype=np.float64) for c in COLS}
+        ids = np.empty(n, dtype=np.int64)
+        check(_lib.lib().abacus_hod_fetch(self._h, t, *[ptr(cols[c]) for c in COLS], ptr(ids)))
+        d = {'Ncent': int(self.counts[t])}
+        d.update(cols)
+        d['id'] = ids
+        return d
+
+    def device_columns(self, tracer):
+        """device pointers (x,y,z,vx,vy,vz,mass,id) of one tracer's catalog, valid until the next populate"""
+        cols = (C.c_void_p * 8)()
+        check(_lib.lib().abacus_hod_device_columns(self._h, TRACERS.index(tracer), cols))
+        return list(cols)
+
+    def fetch_keep(self):
+        kc = np.empty(self.n_halo, dtype=np.int8)
+        ks = np.empty(self.n_part, dtype=np.int8)
+        check(_lib.lib().abacus_hod_fetch_keep(self._h, ptr(kc), ptr(ks)))
+        return kc, ks
+
+    def free(self):
+        if self._h:
+            _lib.lib().abacus_hod_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def gen_gals(halos_array, subsample, tracers, params, Nthread, enable_ranks, rsd, verbose, nfw, NFW_draw=None,
+             staged=None):
+    """hod/GRAND_HOD.py:1302-1592.  `staged`: a StagedCatalog to reuse (extension); otherwise the arrays are
+    uploaded for this call only."""
+    if nfw:
+        raise NotImplementedError(
+            'want_nfw=True (gen_sats_nfw, hod/GRAND_HOD.py:522-822) is not part of the MI355X path yet; '
+            'the reference itself flags it as unoptimized and it draws from an unseeded per-thread RNG')
+    p = marshal_params(tracers, params, enable_ranks, rsd)
+    own = staged is None
+    if own:
+        staged = StagedCatalog(halos_array, subsample)
+    try:
+        if enable_ranks and not staged.has_ranks:
+            raise KeyError('pranks')
+        ncent, nsat = staged.populate(p)
+        HOD_dict = {}
+        for tracer in tracers:
+            if tracer not in TRACERS:
+                continue
+            HOD_dict[tracer] = staged.fetch(tracer)
+            if verbose:
+                n = len(HOD_dict[tracer]['x'])
+                print(tracer, 'number of galaxies ', n)
+                print('satellite fraction ', (n - HOD_dict[tracer]['Ncent']) / n if n else 0.0)
+    finally:
+        if own:
+            staged.free()
+    return HOD_dict
+
+
+def _write_ecsv(path, cols, meta):
+    """ECSV 1.0 table as `astropy.io.ascii.write(format='ecsv')` lays it out (hod/GRAND_HOD.py:1708-1722)"""
+    names = list(cols.keys())
+    with open(path, 'w') as f:
+        f.write('# %ECSV 1.0\n# ---\n# datatype:\n')
+        for n in names:
+            dt = 'int64' if np.issubdtype(np.asarray(cols[n]).dtype, np.integer) else 'float64'
+            f.write(f'# - {{name: {n}, datatype: {dt}}}\n')
+        f.write('# meta: !!omap\n')
+        for k, v in meta.items():
+            if isinstance(v, (bool, np.bool_)):
+                v = 'true' if v else 'false'
+            elif isinstance(v, (np.floating, np.integer)):
+                v = v.item()
+            f.write(f'# - {{{k}: {v}}}\n')
+        f.write('# schema: astropy-2.0\n')
+        f.write(' '.join(names) + '\n')
+        arrs = [np.asarray(cols[n]) for n in names]
+        for i in range(len(arrs[0]) if arrs else 0):
+            f.write(' '.join(repr(a[i].item()) for a in arrs) + '\n')
+
+
+def gen_gal_cat(halo_data, particle_data, tracers, params, Nthread=16, enable_ranks=False, rsd=True, nfw=False,
+                NFW_draw=None, write_to_disk=False, savedir='./', verbose=False, fn_ext=None, staged=None):
+    """Drop-in for hod/GRAND_HOD.py:1595-1724: returns {tracer: {'x','y','z','vx','vy','vz','mass' (float64),
+    'id' (int64), 'Ncent' (int)}} with centrals first; optionally writes `{tracer}s.dat` ECSV files."""
+    if not isinstance(rsd, bool):
+        raise ValueError('Error: rsd has to be a boolean')
+
+    HOD_dict = gen_gals(halo_data, particle_data, tracers, params, Nthread, enable_ranks, rsd, verbose, nfw,
+                        NFW_draw, staged=staged)
+
+    if write_to_disk and tracers:
+        rsd_string = '_rsd' if rsd else ''
+        savedir = Path(savedir)
+        outdir = savedir / ('galaxies' + rsd_string + (fn_ext or ''))
+        os.makedirs(outdir, exist_ok=True)
+
+    for tracer in tracers.keys():
+        Ncent = HOD_dict[tracer]['Ncent']
+        if verbose:
+            n = len(HOD_dict[tracer]['x'])
+            print('generated %ss:' % tracer, n, 'satellite fraction ', 1 - Ncent / n if n else 0.0)
+        if write_to_disk:
+            HOD_dict[tracer].pop('Ncent', None)  # the reference drops it from the returned dict too (:1707)
+            meta = {'Ncent': Ncent, 'Gal_type': tracer, **tracers[tracer]}
+            if params['chunk'] == -1:
+                fn = outdir / f'{tracer}s.dat'
+            else:
+                fn = outdir / f'{tracer}s_chunk{params["chunk"]:d}.dat'
+            _write_ecsv(fn, HOD_dict[tracer], meta)
+    return HOD_dict

@@ -1,0 +1,210 @@
+/*
+ * abacus_hip.h - C ABI of libabacus_hip.so (MI355X / gfx950).
+ *
+ * The reference (abacusorg/abacusutils) has no FFI seam: its hot path is Python + Numba and the drop-in
+ * boundary is the Python call signature.  This header is the C boundary underneath our
+ * Python mirror of those signatures; each entry point names the reference function(s) it replaces
+ * (paths relative to abacusnbody/).  INTEGRATION.md shows the ctypes binding a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; abacus_last_error() returns a thread-local message;
+ *   - the caller owns all host buffers; the library reads/writes them only during the call;
+ *   - device state lives behind explicit handles (`*_stage` / `*_free`), mirroring the residency of
+ *     AbacusHOD.staging() (hod/abacus_hod.py:193-197): stage once, populate many times;
+ *   - `*_dev` variants take DEVICE pointers and never synchronise with the host: they enqueue on the library
+ *     stream (abacus_get_stream), for callers that keep data in HBM (bench, multi-GPU slab path);
+ *   - calls are blocking unless stated; re-entrant per handle; HIP is initialised lazily on first use
+ *     (fork-safe in the sense of NUMBA_THREADING_LAYER=forksafe, docs/hod.rst:226-240);
+ *   - thread counts of the reference API (`Nthread`, `nthread`) have no meaning here and are not part of the ABI.
+ */
+#ifndef ABACUS_HIP_H
+#define ABACUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- runtime ------------------------------ */
+const char *abacus_last_error(void);
+int abacus_device_count(int *n);
+int abacus_set_device(int device);          /* before any other call; default device 0 */
+int abacus_device_name(char *buf, int len);
+int abacus_device_sync(void);               /* wait for the library stream */
+void *abacus_get_stream(void);              /* hipStream_t the library launches on */
+int abacus_set_stream(void *hip_stream);    /* adopt a caller stream (e.g. torch's current stream) */
+
+/* raw device memory for callers that keep inputs resident (bench.py, slab-parallel path) */
+int abacus_malloc(void **dptr, uint64_t nbytes);
+int abacus_free(void *dptr);
+int abacus_memcpy_h2d(void *dst, const void *src, uint64_t nbytes);
+int abacus_memcpy_d2h(void *dst, const void *src, uint64_t nbytes);
+int abacus_memset(void *dptr, int value, uint64_t nbytes);
+
+/* HIP-event timers on the library stream (bench.py: roofline.achieved) */
+int abacus_event_create(void **ev);
+int abacus_event_record(void *ev);
+int abacus_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+int abacus_event_destroy(void *ev);
+/* per-kernel timing: when enabled every kernel launch is bracketed by events on the library stream */
+int abacus_profile_enable(int on);
+int abacus_profile_reset(void);
+/* writes up to `cap` entries; returns the number of distinct kernels (names are static strings) */
+int abacus_profile_get(const char **names, double *total_ms, int64_t *launches, int cap);
+
+/* ---------------------------------------------------------------- HOD ---------------------------------- */
+/*
+ * Flat form of the three numba typed dicts gen_gals builds (hod/GRAND_HOD.py:1342-1468) plus the scalars it
+ * passes to gen_cent / gen_sats (:1472-1475).  z-evolution and defaults are applied by the caller (Python
+ * mirror of gen_gals) before filling this struct.
+ */
+typedef struct abacus_hod_params {
+    int32_t want_LRG, want_ELG, want_QSO;
+    int32_t rsd, has_origin, enable_ranks;
+    int32_t pad0, pad1;
+    double inv_velz2kms, lbox, origin[3];
+    /* LRG_hod_dict */
+    double L_logM_cut, L_logM1, L_sigma, L_alpha, L_kappa, L_alpha_c, L_alpha_s;
+    double L_s, L_s_v, L_s_p, L_s_r, L_Acent, L_Asat, L_Bcent, L_Bsat, L_ic;
+    /* ELG_hod_dict */
+    double E_p_max, E_Q, E_logM_cut, E_kappa, E_sigma, E_logM1, E_alpha, E_gamma, E_A_s;
+    double E_alpha_c, E_alpha_s, E_s, E_s_v, E_s_p, E_s_r;
+    double E_Acent, E_Asat, E_Bcent, E_Bsat, E_Ccent, E_Csat, E_ic;
+    double E_logM1_EE, E_alpha_EE, E_logM1_EL, E_alpha_EL;
+    /* QSO_hod_dict */
+    double Q_logM_cut, Q_kappa, Q_sigma, Q_logM1, Q_alpha, Q_alpha_c, Q_alpha_s;
+    double Q_s, Q_s_v, Q_s_p, Q_s_r, Q_Acent, Q_Asat, Q_Bcent, Q_Bsat, Q_ic;
+} abacus_hod_params;
+
+/*
+ * The staged halo / particle subsample: the arrays of AbacusHOD.halo_data / particle_data
+ * (hod/abacus_hod.py:659-702) in their reference layout - float64, (N,3) C-order, int64 ids.
+ * Optional arrays (NULL = absent, treated as zeros like gen_gals does, hod/GRAND_HOD.py:1485-1487,1541-1543):
+ * hdeltac, hfenv, hshear, pdeltac, pfenv, pshear.  pranks* may be NULL when ranks are never enabled.
+ * pinds[i] = index of particle i's host halo (hod/abacus_hod.py:588); the keep_cent[pinds] gather the
+ * reference does on the host (hod/GRAND_HOD.py:1562) happens on the device.
+ */
+typedef struct abacus_hod_arrays {
+    int64_t n_halo;
+    const double *hpos, *hvel, *hmass;
+    const int64_t *hid;
+    const double *hmultis, *hrandoms, *hveldev, *hdeltac, *hfenv, *hshear;
+    int64_t n_part;
+    const double *ppos, *pvel, *phvel, *phmass;
+    const int64_t *phid;
+    const double *pweights, *prandoms, *pdeltac, *pfenv, *pshear;
+    const double *pranks, *pranksv, *pranksp, *pranksr;
+    const int64_t *pinds;
+} abacus_hod_arrays;
+
+typedef struct abacus_hod_state abacus_hod_state;
+
+/* replaces: the host residency set up by AbacusHOD.staging() (hod/abacus_hod.py:253-704); uploads once.
+ * `arrays_on_device` != 0: the pointers are device pointers that the handle adopts WITHOUT copying (the caller
+ * keeps them alive until abacus_hod_free). */
+int abacus_hod_stage(const abacus_hod_arrays *arrays, int arrays_on_device, abacus_hod_state **out);
+/* re-upload one staged array after `reseed` rewrote it (hod/abacus_hod.py:824-835).
+ * field: "hrandoms" | "hveldev" | "prandoms" (float64 host data, staged length) */
+int abacus_hod_update(abacus_hod_state *st, const char *field, const double *host);
+/*
+ * replaces: gen_cent + gen_sats + fast_concatenate (hod/GRAND_HOD.py:139-414, 825-1262, 1265-1299) as called from
+ * gen_gals (:1477-1589).  Decides and emits on the device; galaxies of tracer t are left in device buffers in the
+ * reference's order: centrals (halo order) then satellites (particle order).
+ * counts[0..2] = Ncent (LRG, ELG, QSO), counts[3..5] = Nsat.
+ */
+int abacus_hod_populate(abacus_hod_state *st, const abacus_hod_params *p, int64_t counts[6]);
+/* as above but enqueue only (no host sync, counts stay on the device until abacus_hod_counts) */
+int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p);
+int abacus_hod_counts(abacus_hod_state *st, int64_t counts[6]); /* syncs; re-runs emission if buffers grew */
+/* copy tracer t's catalog (x,y,z,vx,vy,vz,mass: float64; id: int64), each of length Ncent+Nsat, to the host */
+int abacus_hod_fetch(abacus_hod_state *st, int tracer, double *x, double *y, double *z, double *vx, double *vy,
+                     double *vz, double *mass, int64_t *id);
+/* device pointers of tracer t's catalog columns (7 float64 + 1 int64), valid until the next populate */
+int abacus_hod_device_columns(abacus_hod_state *st, int tracer, void *cols[8]);
+/* the int8 masks gen_cent / gen_sats compute (hod/GRAND_HOD.py:210,954); either pointer may be NULL */
+int abacus_hod_fetch_keep(abacus_hod_state *st, int8_t *keep_cent, int8_t *keep_sat);
+int abacus_hod_free(abacus_hod_state *st);
+
+/* ---------------------------------------------------------------- TSC / CIC ---------------------------- */
+/* dtype codes */
+#define ABACUS_F32 0
+#define ABACUS_F64 1
+
+/*
+ * replaces: tsc_parallel = _wrap_inplace + partition_parallel + _tsc_parallel/_tsc_scatter
+ * (analysis/tsc.py:10-206, 219-226, 259-384, 229-256, 394-507).
+ * pos: (n,3) host array of `pos_dtype`; weights: (n,) same dtype or NULL; grid: (gx,gy,gz) host array of
+ * `grid_dtype`, ACCUMULATED into (not zeroed), as the reference does (tsc.py:45-50).
+ * wrap != 0: positions are wrapped to [0,box) and the wrapped values are written back to `pos` (the reference
+ * mutates the caller's array, tsc.py:171-173).
+ */
+int abacus_tsc_deposit(void *pos, int64_t n, const void *weights, int pos_dtype, void *grid, int gx, int gy,
+                       int gz, int grid_dtype, double box, double offset, int wrap);
+/* device-resident variant: pos/weights/grid are device pointers; float32 positions and grid only.
+ * zero_grid != 0 overwrites the grid instead of accumulating (saves the separate zeroing pass of get_field,
+ * analysis/power_spectrum.py:842).  Enqueues on the library stream. */
+int abacus_tsc_deposit_dev(float *pos, int64_t n, const float *weights, float *grid, int gx, int gy, int gz,
+                           double box, double offset, int wrap, int zero_grid, int cic);
+/* replaces: cic_serial (analysis/cic.py:13-125): float64 math, float32 grid, no wrap */
+int abacus_cic_deposit(const void *pos, int64_t n, const void *weights, int pos_dtype, float *grid, int gx, int gy,
+                       int gz, double box);
+/* replaces: partition_parallel (analysis/tsc.py:259-384), sort=False: stable counting sort into `npartition`
+ * stripes along `coord`.  psort (n,3), starts (npartition+1) int64, wsort (n,) or NULL. */
+int abacus_partition(const void *pos, int64_t n, const void *weights, int dtype, int npartition, double box,
+                     int coord, void *psort, int64_t *starts, void *wsort);
+
+/* ---------------------------------------------------------------- power spectrum ----------------------- */
+/*
+ * replaces: get_field_fft (analysis/power_spectrum.py:1001-1070) = get_field (:808-857: zero mesh, deposit,
+ * normalize_field :860-901) + scipy.fft.rfftn (:980,986,1059) + _normalize (:1073-1078) or the interlacing
+ * combine shift_field_fft (:904-948) + compensation divide (:1063-1069).
+ * pos (n,3) float32 host; w (n,) float32 or NULL; W (nmesh,) float32 window or NULL (= not compensated);
+ * out: (nmesh, nmesh, nmesh/2+1) complex64 host.  paste: 0 TSC, 1 CIC.
+ */
+int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nmesh, int paste, const float *W,
+                     int interlaced, void *out_c64);
+/*
+ * replaces: calc_pk_from_deltak = get_raw_power + bin_kmu (analysis/power_spectrum.py:730-805, 707-727, 150-300)
+ * on host spectra.  field2 may be NULL (auto power).  Outputs as bin_kmu returns them, already multiplied by L^3:
+ * power (Nk,Nmu) f32, N_mode (Nk,Nmu) i64, binned_poles (Np,Nk) f32, N_mode_poles (Nk) i64, k_avg (Nk,Nmu) f32.
+ */
+int abacus_pk_from_deltak(const void *field_c64, const void *field2_c64, int nmesh, double Lbox,
+                          const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
+                          float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg);
+/*
+ * replaces: the whole calc_power chain (analysis/power_spectrum.py:1131-1319) without the spectrum ever leaving
+ * HBM: deposit(s) -> FFT(s) -> [interlace combine] -> fused scale/compensate/|delta_k|^2/bin pass.
+ * pos2 == NULL -> auto power.  Host inputs; `pos`/`pos2` are wrapped in place like the reference.
+ */
+int abacus_power_from_particles(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, const float *w2,
+                                double Lbox, int nmesh, int paste, const float *W, int interlaced,
+                                const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
+                                int Np, float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles,
+                                float *k_avg);
+/* same with DEVICE particle arrays (bench / HOD-to-P(k) without leaving HBM); outputs are host arrays */
+int abacus_power_from_particles_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2,
+                                    const float *w2, double Lbox, int nmesh, int paste, const float *W_host,
+                                    int interlaced, const double *kedges, int Nk, const double *muedges, int Nmu,
+                                    const int64_t *poles, int Np, float *power, int64_t *N_mode,
+                                    float *binned_poles, int64_t *N_mode_poles, float *k_avg);
+/* releases cached FFT plans / work meshes */
+int abacus_power_release(void);
+
+/* ---------------------------------------------------------------- pair counting ------------------------ */
+/*
+ * replaces: Corrfunc.theory.DD / DDrppi / DDsmu as called at analysis/tpcf_corrfunc.py:144-156,164-179,
+ * 240-273,328-362 and scripts/emulator/generate_cfs/generate_cf.py:65-74 (third-party C, periodic box,
+ * float32 coordinates).  mode 0: DD(r), 1: DD(rp,pi) with pi bins of width pimax/npibins, 2: DD(s,mu) with
+ * nmubins in [0,mu_max).  x2 == NULL -> autocorrelation (ordered pairs, no self pairs).
+ * npairs: nbins * (1 | npibins | nmubins) uint64.
+ */
+int abacus_paircount(int mode, const float *x1, const float *y1, const float *z1, int64_t n1, const float *x2,
+                     const float *y2, const float *z2, int64_t n2, float boxsize, const float *bins, int nbins,
+                     float pimax, int npibins, float mu_max, int nmubins, uint64_t *npairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABACUS_HIP_H */

@@ -1,0 +1,134 @@
+"""HIP HOD path (libabacus_hip.so through the C ABI) vs the CPU oracle, the reference's fixtures and the
+golden vectors.  Needs an MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+from conftest import (SYNTH_CASES, assert_mock_equal, load_golden, synth_case, unpack_inputs, unpack_mock)
+
+from abacusutils_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def G():
+    from abacusutils_amd.hod import GRAND_HOD
+    return GRAND_HOD
+
+
+@pytest.mark.parametrize('name', ['hod_mini', 'hod_lc'])
+def test_reference_fixture(G, name):
+    """tests/ref_hod/**/galaxies_rsd/*.dat of the reference (tests/test_hod.py:109-134, test_lc_hod.py)"""
+    g = load_golden(name)
+    hd, pd, params = unpack_inputs(g)
+    tracers = {'LRG': synth.LRG_PARAMS, 'ELG': synth.ELG_PARAMS}
+    mock = G.gen_gal_cat(hd, pd, tracers, params, Nthread=4, enable_ranks=False, rsd=True)
+    assert_mock_equal(mock, unpack_mock(g, 'expect'), exact=False, rtol=1e-14)
+    assert_mock_equal(mock, unpack_mock(g, 'shim'), exact=True)
+
+
+@pytest.mark.parametrize('name', SYNTH_CASES)
+def test_synthetic_golden(G, name):
+    """bit-exact against what the reference returned on the same seeded inputs"""
+    g = load_golden('hod_synth_' + name)
+    hd, pd, params, tracers, ranks, rsd = synth_case(g)
+    mock = G.gen_gal_cat(hd, pd, tracers, params, enable_ranks=ranks, rsd=rsd)
+    assert_mock_equal(mock, unpack_mock(g, 'expect'), exact=True)
+
+
+@pytest.mark.parametrize('nh,npart', [(1, 1), (2047, 2049), (2048, 4096), (100003, 250007), (0, 0), (5000, 0)])
+def test_vs_oracle_ragged_sizes(G, nh, npart):
+    """tile edges (2048 objects / workgroup), odd tails, empty inputs: keep masks and catalogs bit-equal"""
+    from oracle import oracle
+    hd, pd, params = synth.synth_hod_inputs(max(nh, 1), max(npart, 1), seed=11, with_ranks=True)
+    hd = {k: v[:nh] for k, v in hd.items()}
+    pd = {k: v[:npart] for k, v in pd.items()}
+    if npart:
+        pd['pinds'] = np.minimum(pd['pinds'], max(nh - 1, 0))
+    if nh == 0:
+        pd = {k: v[:0] for k, v in pd.items()}
+    tracers = {'LRG': dict(synth.LRG_PARAMS, logM_cut=12.5, logM1=13.5, alpha_c=0.2, alpha_s=0.9, s=0.1),
+               'ELG': dict(synth.ELG_PARAMS, Ccent=0.05, logM1_EE=13.0, alpha_EL=1.2),
+               'QSO': synth.QSO_PARAMS}
+    st = G.StagedCatalog(hd, pd)
+    p = G.marshal_params(tracers, params, True, True)
+    st.populate(p)
+    kc, ks = st.fetch_keep()
+    mock = {tr: st.fetch(tr) for tr in tracers}
+    want, wkc, wks = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=4, enable_ranks=True, rsd=True,
+                                        return_keep=True)
+    np.testing.assert_array_equal(kc, wkc)
+    np.testing.assert_array_equal(ks, wks)
+    assert_mock_equal(mock, want, exact=True)
+    st.free()
+
+
+def test_full_size_c2_bit_exact(G):
+    """BASELINE config 2: 10^7 halos + 10^7 particles, LRG HOD of tests/abacus_hod.yaml:31-47, fixed seed:
+    galaxy counts, keep masks and every output array bit-equal to the CPU oracle; stable order."""
+    from oracle import oracle
+    n = 10_000_000
+    hd, pd, params = synth.synth_hod_inputs(n, n, seed=600)
+    tracers = {'LRG': synth.LRG_PARAMS}
+    st = G.StagedCatalog(hd, pd)
+    p = G.marshal_params(tracers, params, False, True)
+    ncent, nsat = st.populate(p)
+    kc, ks = st.fetch_keep()
+    mock = {'LRG': st.fetch('LRG')}
+    # repeat populate on the resident catalog (MCMC pattern): identical result
+    st.populate(p)
+    again = {'LRG': st.fetch('LRG')}
+    assert_mock_equal(again, mock, exact=True)
+    st.free()
+    want, wkc, wks = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=oracle.max_threads(), enable_ranks=False,
+                                        rsd=True, return_keep=True)
+    assert ncent[0] == want['LRG']['Ncent'] and ncent[0] + nsat[0] == len(want['LRG']['x'])
+    np.testing.assert_array_equal(kc, wkc)
+    np.testing.assert_array_equal(ks, wks)
+    assert_mock_equal(mock, want, exact=True)
+    # size-independent properties: ids of centrals strictly increasing (stable compaction of hid = 1000*arange),
+    # satellites' host ids non-decreasing, RSD keeps z inside the box
+    idc = mock['LRG']['id'][: ncent[0]]
+    assert np.all(np.diff(idc) > 0)
+    assert np.all(np.diff(mock['LRG']['id'][ncent[0]:]) >= 0)
+    L = params['Lbox']
+    assert np.all((mock['LRG']['z'] >= -L / 2 - 1.0) & (mock['LRG']['z'] < L / 2 + 1.0))
+
+
+def test_capacity_growth_and_param_change(G):
+    """first populate emits few galaxies, second many more than the catalog buffers hold: buffers grow, order kept"""
+    from oracle import oracle
+    hd, pd, params = synth.synth_hod_inputs(300000, 300000, seed=3)
+    st = G.StagedCatalog(hd, pd)
+    for logM_cut in (14.5, 11.2):
+        tracers = {'LRG': dict(synth.LRG_PARAMS, logM_cut=logM_cut, logM1=logM_cut + 0.8)}
+        p = G.marshal_params(tracers, params, False, True)
+        st.populate(p)
+        got = {'LRG': st.fetch('LRG')}
+        want = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=4)
+        assert_mock_equal(got, want, exact=True)
+    st.free()
+
+
+def test_errors(G):
+    g = load_golden('hod_mini')
+    hd, pd, params = unpack_inputs(g)
+    with pytest.raises(ValueError):
+        G.gen_gal_cat(hd, pd, {'LRG': synth.LRG_PARAMS}, params, rsd=1)
+    bad = dict(synth.LRG_PARAMS)
+    del bad['alpha_c']
+    with pytest.raises(KeyError):
+        G.gen_gal_cat(hd, pd, {'LRG': bad}, params)
+    with pytest.raises(NotImplementedError):
+        G.gen_gal_cat(hd, pd, {'LRG': synth.LRG_PARAMS}, params, nfw=True)
+
+
+def test_write_to_disk(G, tmp_path):
+    g = load_golden('hod_mini')
+    hd, pd, params = unpack_inputs(g)
+    tracers = {'LRG': synth.LRG_PARAMS, 'ELG': synth.ELG_PARAMS}
+    G.gen_gal_cat(hd, pd, tracers, params, write_to_disk=True, savedir=tmp_path)
+    txt = (tmp_path / 'galaxies_rsd' / 'LRGs.dat').read_text().splitlines()
+    assert txt[0] == '# %ECSV 1.0' and any('Ncent: 7' in line for line in txt)
+    rows = [line.split() for line in txt if not line.startswith('#')][1:]
+    np.testing.assert_array_equal(np.array([int(r[7]) for r in rows]), g['expect.LRG.id'])
+    np.testing.assert_array_equal(np.array([float(r[2]) for r in rows]), g['expect.LRG.z'])
