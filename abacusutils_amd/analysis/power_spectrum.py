@@ -1,0 +1,232 @@
+r"""MI355X drop-in for `abacusnbody.analysis.power_spectrum` (reference: abacusnbody/analysis/power_spectrum.py).
+
+Same public functions, signatures and return structures for the calc_power chain:
+
+    calc_power            (:1131-1319)   deposit -> FFT -> binning without the mesh leaving HBM
+    calc_pk_from_deltak   (:730-805)     binning of caller-supplied spectra (the zcv call pattern)
+    get_k_mu_edges        (:663-704)
+    get_field_fft         (:1001-1070)   returns the complex64 half-spectrum as a NumPy array
+    get_field             (:808-857)     returns the float32 overdensity mesh
+    get_W_compensated     (:1081-1128)
+    normalize_field       (:860-901)
+
+`nthread` arguments are accepted and ignored.  Multipoles are limited to even l <= 10 (the range `P_n` is
+stated to be valid for, :124-125).  Sums are accumulated in float64 on the device (the reference uses per-thread
+float32 accumulators, :221-229), so results agree with the reference to its own float32 accumulation error.
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from .. import _lib
+from .._lib import check, ptr
+from .cic import cic_serial
+from .tsc import tsc_parallel
+
+__all__ = ['calc_power', 'calc_pk_from_deltak', 'get_k_mu_edges', 'get_field_fft', 'get_field',
+           'get_W_compensated', 'normalize_field']
+
+MAX_THREADS = 1
+
+try:  # the reference returns an astropy Table; fall back to a dict with `.meta` and the same column access
+    from astropy.table import Table
+except Exception:  # astropy is not part of this image
+    class Table(dict):
+        def __init__(self, data=None, meta=None):
+            super().__init__(data or {})
+            self.meta = meta or {}
+
+        @property
+        def colnames(self):
+            return list(self.keys())
+
+
+_PASTE = {'TSC': 0, 'CIC': 1}
+
+
+def _paste_code(paste, where):
+    p = paste.upper()
+    if p not in _PASTE:
+        raise ValueError(f'Unknown pasting method{where} {paste}')
+    return _PASTE[p]
+
+
+def get_k_mu_edges(Lbox, k_max, kbins, mubins, logk):
+    """Bin edges of k and mu (:663-704): ints become linspace/geomspace edges, array-likes pass through."""
+    if isinstance(kbins, int):
+        if logk:
+            k_min = (1.0 - 1.0e-4) * 2.0 * np.pi / Lbox
+            kbins = np.geomspace(k_min, k_max, kbins + 1)
+        else:
+            kbins = np.linspace(0.0, k_max, kbins + 1)
+    if isinstance(mubins, int):
+        mubins = np.linspace(0.0, 1.0, mubins + 1)
+    return kbins, mubins
+
+
+def get_W_compensated(Lbox, nmesh, paste, interlaced):
+    """1-D float32 TSC/CIC window (:1081-1128)."""
+    d = Lbox / nmesh
+    kN = np.pi / d
+    k = (np.fft.fftfreq(nmesh, d=d) * 2.0 * np.pi).astype(np.float32)
+    paste = paste.upper()
+    if interlaced:
+        if paste == 'TSC':
+            p = 3.0
+        elif paste == 'CIC':
+            p = 2.0
+        else:
+            raise ValueError(f'Unknown pasting method {paste}')
+        W = np.sinc(0.5 * k / kN) ** p
+    else:
+        s = np.sin(0.5 * np.pi * k / kN) ** 2
+        if paste == 'TSC':
+            W = (1 - s + 2.0 / 15 * s**2) ** 0.5
+        elif paste == 'CIC':
+            W = (1 - 2.0 / 3 * s) ** 0.5
+        else:
+            raise ValueError(f'Unknown pasting method {paste}')
+    return W
+
+
+def normalize_field(field, tot_weight=None, inplace=False, nthread=MAX_THREADS):
+    """overdens = field * dtype(field.size / tot_weight) - 1 (:860-901); small host helper kept for API parity
+    (inside calc_power the normalisation is fused into the deposit kernel)."""
+    dtype = field.dtype.type
+    if tot_weight is None:
+        tot_weight = field.sum()
+    norm = dtype(field.size / tot_weight)
+    if inplace:
+        field *= norm
+        field -= dtype(1.0)
+        return field
+    return field * norm - dtype(1.0)
+
+
+def get_field(pos, Lbox, nmesh, paste, w=None, d=0.0, nthread=MAX_THREADS, dtype=np.float32):
+    """Overdensity mesh of the particles (:808-857).  `pos` is wrapped in place for TSC, like the reference."""
+    if w is not None:
+        assert pos.shape[0] == len(w)
+    field = np.zeros((nmesh, nmesh, nmesh), dtype=dtype)
+    paste_u = paste.upper()
+    if paste_u == 'TSC':
+        tsc_parallel(pos, field, Lbox, weights=w, nthread=nthread, offset=d)
+    elif paste_u == 'CIC':
+        warnings.warn('Note that currently CIC pasting, unlike TSC, supports only a non-parallel implementation.')
+        cic_serial(pos + d if d != 0.0 else pos, field, Lbox, weights=w)
+    else:
+        raise ValueError(f'Unknown pasting method: {paste}')
+    normalize_field(field, inplace=True, tot_weight=len(pos), nthread=nthread)
+    return field
+
+
+def _f4(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _pos_f4(pos):
+    """the device path computes in float32 (the reference's default mesh dtype); float32 C-contiguous inputs are used
+    in place (and wrapped in place), anything else is converted to a float32 copy"""
+    if pos.dtype == np.float32 and pos.flags.c_contiguous and pos.flags.writeable:
+        return pos
+    return np.ascontiguousarray(pos, dtype=np.float32).copy()
+
+
+def get_field_fft(pos, Lbox, nmesh, paste, w, W, compensated, interlaced, nthread=MAX_THREADS, verbose=False,
+                  dtype=np.float32):
+    """delta_k of the particles as a complex64 (nmesh, nmesh, nmesh//2+1) array (:1001-1070)."""
+    code = _paste_code(paste, ':')
+    if np.dtype(dtype) != np.float32:
+        raise NotImplementedError('the device path works on float32 meshes (the reference default)')
+    if compensated:
+        assert W is not None
+    p = _pos_f4(pos)
+    out = np.empty((nmesh, nmesh, nmesh // 2 + 1), dtype=np.complex64)
+    check(_lib.lib().abacus_field_fft(ptr(p), C.c_int64(len(p)), ptr(_f4(w)), C.c_double(Lbox), int(nmesh), code,
+                                      ptr(_f4(W)) if compensated else None, int(bool(interlaced)), ptr(out)))
+    return out
+
+
+def _alloc_outputs(Nk, Nmu, Np):
+    return (np.zeros((Nk, Nmu), dtype=np.float32), np.zeros((Nk, Nmu), dtype=np.int64),
+            np.zeros((Np, Nk), dtype=np.float32), np.zeros(Nk, dtype=np.int64),
+            np.zeros((Nk, Nmu), dtype=np.float32))
+
+
+def _pack(power, N_mode, binned_poles, N_mode_poles, k_avg, mu_bin_edges, squeeze_mu_axis):
+    if squeeze_mu_axis and len(mu_bin_edges) == 2:
+        power = power[:, 0]
+        N_mode = N_mode[:, 0]
+        k_avg = k_avg[:, 0]
+    return dict(power=power, N_mode=N_mode, binned_poles=binned_poles, N_mode_poles=N_mode_poles, k_avg=k_avg)
+
+
+def calc_pk_from_deltak(field_fft, Lbox, k_bin_edges, mu_bin_edges, field2_fft=None, poles=np.empty(0, 'i8'),
+                        squeeze_mu_axis=True, nthread=MAX_THREADS):
+    """Power spectrum of a given Fourier field with (k, mu) binning and optional multipoles (:730-805).
+    Returns dict(power, N_mode, binned_poles, N_mode_poles, k_avg); power and binned_poles include L^3."""
+    f1 = np.ascontiguousarray(field_fft, dtype=np.complex64)
+    f2 = None if field2_fft is None else np.ascontiguousarray(field2_fft, dtype=np.complex64)
+    nmesh = f1.shape[0]
+    if f1.shape != (nmesh, nmesh, nmesh // 2 + 1) or (f2 is not None and f2.shape != f1.shape):
+        raise ValueError('field_fft must have the rfftn shape (N, N, N//2+1)')
+    ke = np.ascontiguousarray(k_bin_edges, dtype=np.float64)
+    me = np.ascontiguousarray(mu_bin_edges, dtype=np.float64)
+    pl = np.ascontiguousarray(poles, dtype=np.int64)
+    outs = _alloc_outputs(len(ke) - 1, len(me) - 1, len(pl))
+    check(_lib.lib().abacus_pk_from_deltak(ptr(f1), ptr(f2), int(nmesh), C.c_double(Lbox), ptr(ke), len(ke) - 1,
+                                           ptr(me), len(me) - 1, ptr(pl), len(pl), *[ptr(o) for o in outs]))
+    return _pack(*outs, me, squeeze_mu_axis)
+
+
+def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste='TSC', nmesh=128,
+               compensated=True, interlaced=True, w=None, pos2=None, w2=None, poles=None, squeeze_mu_axis=True,
+               nthread=MAX_THREADS, dtype=np.float32):
+    """3-D power spectrum of particle positions in a periodic box: (k, mu) wedges and optional Legendre
+    multipoles.  Drop-in for abacusnbody/analysis/power_spectrum.py:1131-1319 (same arguments, same Table
+    columns: k_min, k_max, k_mid, k_avg, power, N_mode[, poles, N_mode_poles][, mu_min, mu_max, mu_mid])."""
+    if kbins is None:
+        kbins = nmesh
+    if k_max is None:
+        k_max = np.pi * nmesh / Lbox
+    return_mubins = mubins is not None
+    if mubins is None:
+        mubins = 1
+    if np.dtype(dtype) != np.float32:
+        raise NotImplementedError('the device path works on float32 meshes (the reference default)')
+
+    meta = dict(Lbox=Lbox, logk=logk, paste=paste, nmesh=nmesh, compensated=compensated, interlaced=interlaced,
+                poles=poles, nthread=nthread, N_pos=len(pos), is_weighted=w is not None, field_dtype=dtype,
+                squeeze_mu_axis=squeeze_mu_axis)
+    if pos2 is not None:
+        meta['N_pos2'] = len(pos2)
+        meta['is_weighted2'] = w2 is not None
+
+    code = _paste_code(paste, '')
+    W = get_W_compensated(Lbox, nmesh, paste, interlaced) if compensated else None
+    poles_arr = np.asarray(poles or [], dtype=np.int64)
+    kbins, mubins = get_k_mu_edges(Lbox, k_max, kbins, mubins, logk)
+    ke = np.ascontiguousarray(kbins, dtype=np.float64)
+    me = np.ascontiguousarray(mubins, dtype=np.float64)
+
+    p1 = _pos_f4(pos)
+    p2 = None if pos2 is None else _pos_f4(pos2)
+    outs = _alloc_outputs(len(ke) - 1, len(me) - 1, len(poles_arr))
+    check(_lib.lib().abacus_power_from_particles(
+        ptr(p1), C.c_int64(len(p1)), ptr(_f4(w)), ptr(p2), C.c_int64(0 if p2 is None else len(p2)), ptr(_f4(w2)),
+        C.c_double(Lbox), int(nmesh), code, ptr(_f4(W)), int(bool(interlaced)), ptr(ke), len(ke) - 1, ptr(me),
+        len(me) - 1, ptr(poles_arr), len(poles_arr), *[ptr(o) for o in outs]))
+    P = _pack(*outs, me, squeeze_mu_axis)
+
+    k_binc = (kbins[1:] + kbins[:-1]) * 0.5
+    mu_binc = (mubins[1:] + mubins[:-1]) * 0.5
+    res = dict(k_min=kbins[:-1], k_max=kbins[1:], k_mid=k_binc, k_avg=P['k_avg'], power=P['power'],
+               N_mode=P['N_mode'])
+    if len(poles_arr) > 0:
+        res.update(poles=P['binned_poles'].T, N_mode_poles=P['N_mode_poles'])
+    if return_mubins:
+        res.update(mu_min=np.broadcast_to(mubins[:-1], res['power'].shape),
+                   mu_max=np.broadcast_to(mubins[1:], res['power'].shape),
+                   mu_mid=np.broadcast_to(mu_binc, res['power'].shape))
+    return Table(res, meta=meta)

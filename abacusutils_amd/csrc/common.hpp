@@ -35,7 +35,7 @@ void prof_end(const char *name);
 #define ABACUS_LAUNCH(name, kernel, grid, block, shmem, ...)                                     \
     do {                                                                                         \
         ::abacus::prof_begin(name);                                                              \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, ::abacus::stream(), __VA_ARGS__);         \
+        kernel<<<grid, block, shmem, ::abacus::stream()>>>(__VA_ARGS__);                         \
         ::abacus::prof_end(name);                                                                \
         HIP_TRY(hipGetLastError());                                                              \
     } while (0)

@@ -1,0 +1,118 @@
+// partition_parallel (abacusnbody/analysis/tsc.py:259-384, sort=False) on the device: stable counting sort of the
+// particles into `npartition` stripes along one coordinate.  Our own deposit does not need stripes (tsc.hip cuts the
+// mesh into LDS tiles instead); this entry point exists because partition_parallel is public API of the reference
+// (`__all__`, tsc.py:7) with a tested contract (tests/test_tsc.py:162-208): same keys, same `starts`, stable order.
+//
+// key = min(int32(pos[coord] * dtype(npartition/box)), npartition-1)   (tsc.py:329,335)
+// Stable order comes from an LSD radix sort of (key, original index) pairs (hipCUB, stable by construction); a
+// gather then writes the particles.  HBM-bound: ~3 passes over 8-B pairs + one 12-B gather.
+#include <hipcub/hipcub.hpp>
+
+#include "../../include/abacus_hip.h"
+#include "common.hpp"
+
+using namespace abacus;
+
+namespace {
+
+template <typename PT>
+__global__ void part_keys(const PT *__restrict__ pos, int64_t n, int coord, PT inv_pwidth, int npartition,
+                          int *__restrict__ keys, unsigned int *__restrict__ idx, unsigned long long *__restrict__ hist) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int k = (int)(pos[3 * i + coord] * inv_pwidth);
+        k = max(min(k, npartition - 1), 0);
+        keys[i] = k;
+        idx[i] = (unsigned int)i;
+        atomicAdd(&hist[k], 1ull);
+    }
+}
+
+template <typename PT>
+__global__ void part_gather(const PT *__restrict__ pos, const PT *__restrict__ w, const unsigned int *__restrict__ idx,
+                            int64_t n, PT *__restrict__ psort, PT *__restrict__ wsort) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx[s];
+        psort[3 * s] = pos[3 * i];
+        psort[3 * s + 1] = pos[3 * i + 1];
+        psort[3 * s + 2] = pos[3 * i + 2];
+        if (w) wsort[s] = w[i];
+    }
+}
+
+template <typename PT>
+int partition_impl(const void *pos_, int64_t n, const void *w_, int npartition, double box, int coord, void *psort_,
+                   int64_t *starts, void *wsort_) {
+    ABACUS_TRY(ensure_init());
+    if (npartition < 1) return fail("abacus_partition: npartition < 1");
+    if (coord < 0 || coord > 2) return fail("abacus_partition: coord out of range");
+    if (n >= (int64_t)1 << 32) return fail("abacus_partition: more than 2^32 particles");
+    DevBuf dpos, dw, dps, dws, keys, keys2, idx, idx2, hist, tmp;
+    int rc = 0;
+    std::vector<unsigned long long> h((size_t)npartition);
+    do {
+#define TRYB(x) if ((rc = (x)) != 0) break
+        const size_t n1 = (size_t)std::max<int64_t>(n, 1);
+        TRYB(dpos.reserve(3 * n1 * sizeof(PT)));
+        TRYB(dps.reserve(3 * n1 * sizeof(PT)));
+        if (w_) {
+            TRYB(dw.reserve(n1 * sizeof(PT)));
+            TRYB(dws.reserve(n1 * sizeof(PT)));
+        }
+        TRYB(keys.reserve(n1 * 4));
+        TRYB(keys2.reserve(n1 * 4));
+        TRYB(idx.reserve(n1 * 4));
+        TRYB(idx2.reserve(n1 * 4));
+        TRYB(hist.reserve((size_t)npartition * 8));
+        (void)hipMemcpyAsync(dpos.p, pos_, 3 * n * sizeof(PT), hipMemcpyHostToDevice, stream());
+        if (w_) (void)hipMemcpyAsync(dw.p, w_, n * sizeof(PT), hipMemcpyHostToDevice, stream());
+        (void)hipMemsetAsync(hist.p, 0, (size_t)npartition * 8, stream());
+        const PT inv_pwidth = (PT)(npartition / box);
+        const int nblk = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 256), 1), 4096);
+        if (n > 0) {
+            hipLaunchKernelGGL(part_keys<PT>, dim3(nblk), dim3(256), 0, stream(), dpos.as<PT>(), n, coord, inv_pwidth,
+                               npartition, keys.as<int>(), idx.as<unsigned int>(), hist.as<unsigned long long>());
+            int end_bit = 1;
+            while ((1ll << end_bit) < npartition) end_bit++;
+            size_t tmp_bytes = 0;
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<int>(), keys2.as<int>(),
+                                               idx.as<unsigned int>(), idx2.as<unsigned int>(), (int)n, 0, end_bit,
+                                               stream());
+            TRYB(tmp.reserve(tmp_bytes));
+            if (hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<int>(), keys2.as<int>(),
+                                                   idx.as<unsigned int>(), idx2.as<unsigned int>(), (int)n, 0, end_bit,
+                                                   stream()) != hipSuccess) {
+                rc = fail("abacus_partition: radix sort failed");
+                break;
+            }
+            hipLaunchKernelGGL(part_gather<PT>, dim3(nblk), dim3(256), 0, stream(), dpos.as<PT>(),
+                               w_ ? dw.as<PT>() : (const PT *)nullptr, idx2.as<unsigned int>(), n, dps.as<PT>(),
+                               w_ ? dws.as<PT>() : (PT *)nullptr);
+            (void)hipMemcpyAsync(psort_, dps.p, 3 * n * sizeof(PT), hipMemcpyDeviceToHost, stream());
+            if (w_) (void)hipMemcpyAsync(wsort_, dws.p, n * sizeof(PT), hipMemcpyDeviceToHost, stream());
+        }
+        (void)hipMemcpyAsync(h.data(), hist.p, (size_t)npartition * 8, hipMemcpyDeviceToHost, stream());
+        if (hipStreamSynchronize(stream()) != hipSuccess || hipGetLastError() != hipSuccess) {
+            rc = fail("abacus_partition: device error");
+            break;
+        }
+        int64_t run = 0;
+        for (int k = 0; k < npartition; k++) {
+            starts[k] = run;
+            run += (int64_t)h[k];
+        }
+        starts[npartition] = n;
+#undef TRYB
+    } while (0);
+    for (DevBuf *b : {&dpos, &dw, &dps, &dws, &keys, &keys2, &idx, &idx2, &hist, &tmp}) (void)b->release();
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int abacus_partition(const void *pos, int64_t n, const void *weights, int dtype, int npartition,
+                                double box, int coord, void *psort, int64_t *starts, void *wsort) {
+    if ((n > 0 && (!pos || !psort)) || !starts) return fail("abacus_partition: null argument");
+    if (dtype == ABACUS_F32) return partition_impl<float>(pos, n, weights, npartition, box, coord, psort, starts, wsort);
+    if (dtype == ABACUS_F64) return partition_impl<double>(pos, n, weights, npartition, box, coord, psort, starts, wsort);
+    return fail("abacus_partition: unknown dtype code");
+}

@@ -1,9 +1,438 @@
+// TSC / CIC particle-to-mesh deposit on MI355X (gfx950): replaces tsc_parallel and its helpers
+// (abacusnbody/analysis/tsc.py:10-206 _wrap_inplace :219-226, partition_parallel :259-384, _tsc_scatter :394-507)
+// and cic_serial (analysis/cic.py:13-125).
+//
+// The reference avoids write races with x-stripes processed even-then-odd by CPU threads.  Here the mesh is cut
+// into LDS-sized tiles (16 x 16 x 32 cells = 64 KiB of float64 accumulators, two workgroups per CU):
+//   tsc_bin<COUNT>   one pass over the particles: wrap (in place, like the reference), find the tiles the 3x3x3
+//                    cloud touches (1..8, 1.3 on average) and count them per tile (integer atomics, L2);
+//   tsc_scan_tiles   exclusive scan of the tile counts;
+//   tsc_bin<FILL>    second pass: append (x, y, z, w) to every touched tile's list (16-B stores);
+//   tsc_tile_deposit one workgroup per tile: zero the tile in LDS, accumulate the list with LDS float atomics
+//                    (contributions falling outside the tile are dropped - the neighbour tile has its own copy of
+//                    the particle), then write the tile to HBM with plain coalesced 128-B row stores.  No global
+//                    atomics, no separate zeroing pass, optional fused normalisation delta = rho*norm - 1
+//                    (normalize_field, analysis/power_spectrum.py:860-901).
+// HBM traffic: 2 x 12 B/particle reads + ~1.3 x 16 B/particle list write+read + 4 B/cell mesh write.
+//
+// Arithmetic follows _tsc_scatter exactly (math in the position dtype, round-half-even, int16 cell index,
+// weights 0.75-d^2 and 0.5(0.5+-d)^2, product order wx*wy*wz*W; built with -ffp-contract=off); only the order in
+// which contributions are summed into a cell differs (unordered LDS atomics vs the reference's particle order),
+// a float32 rounding-level effect covered by the reference's own tolerance (tests/test_tsc.py:136).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
 #include "../../include/abacus_hip.h"
 #include "common.hpp"
+
 using namespace abacus;
-extern "C" {
-int abacus_tsc_deposit(void *, int64_t, const void *, int, void *, int, int, int, int, double, double, int) { return fail("abacus_tsc_deposit: not built yet"); }
-int abacus_tsc_deposit_dev(float *, int64_t, const float *, float *, int, int, int, double, double, int, int, int) { return fail("not built yet"); }
-int abacus_cic_deposit(const void *, int64_t, const void *, int, float *, int, int, int, double) { return fail("not built yet"); }
-int abacus_partition(const void *, int64_t, const void *, int, int, double, int, void *, int64_t *, void *) { return fail("not built yet"); }
+
+namespace {
+
+constexpr int TSC_BLOCK = 256;
+
+struct TileGeom {
+    int gx, gy, gz;       // mesh
+    int tx, ty, tz;       // tile shape (cells)
+    int ntx, nty, ntz;    // tiles per dimension
+    int64_t zstride;      // elements per z-row in memory (gz, or 2*(gz/2+1) for an in-place R2C layout)
+};
+
+__device__ __forceinline__ int wrapcell(int c, int g) {
+    // _rightwrap (tsc.py:387-391) + NumPy negative indexing; general modulo for far-out-of-box positions
+    if (c >= g) {
+        c -= g;
+        if (c >= g) c %= g;
+    } else if (c < 0) {
+        c += g;
+        if (c < 0) c = ((c % g) + g) % g;
+    }
+    return c;
 }
+
+template <typename PT>
+struct Cloud {
+    int i[3];      // nearest cell per dimension (unwrapped, int16 range like the reference)
+    PT w[3][3];    // [dim][-1,0,+1]
+};
+
+template <typename PT>
+__device__ __forceinline__ PT rnd(PT x);
+template <>
+__device__ __forceinline__ float rnd<float>(float x) { return rintf(x); }
+template <>
+__device__ __forceinline__ double rnd<double>(double x) { return rint(x); }
+
+// TSC weights, _tsc_scatter (tsc.py:419-451)
+template <typename PT>
+__device__ __forceinline__ void tsc_cloud(PT x, PT y, PT z, PT offset, PT ihx, PT ihy, PT ihz, Cloud<PT> &c) {
+    const PT HALF = (PT)0.5, P75 = (PT)0.75;
+    PT p[3] = {(x + offset) * ihx, (y + offset) * ihy, (z + offset) * ihz};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        int i = (int)(short)rnd<PT>(p[a]);
+        PT d = (PT)i - p[a];
+        PT tm = HALF + d, tp = HALF - d;
+        c.i[a] = i;
+        c.w[a][1] = P75 - d * d;
+        c.w[a][0] = HALF * (tm * tm);
+        c.w[a][2] = HALF * (tp * tp);
+    }
+}
+
+// CIC weights, cic_serial (cic.py:29-71): float64 math whatever the position dtype, positions NOT wrapped
+template <typename PT>
+__device__ __forceinline__ void cic_cloud(PT x, PT y, PT z, double box, int gx, int gy, int gz, Cloud<double> &c) {
+    double p[3] = {((double)x / box) * gx, ((double)y / box) * gy, ((double)z / box) * gz};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        int i = (int)rint(p[a]);
+        double d = i - p[a];
+        c.i[a] = i;
+        c.w[a][1] = 1.0 - fabs(d);
+        if (d > 0.0) {
+            c.w[a][0] = d;
+            c.w[a][2] = 0.0;
+        } else {
+            c.w[a][2] = -d;
+            c.w[a][0] = 0.0;
+        }
+    }
+}
+
+// distinct tiles touched along one dimension by cells i-1, i, i+1 (2 at most unless the mesh is tiny)
+__device__ __forceinline__ int tiles_1d(int i, int g, int t, int out[3]) {
+    int a = wrapcell(i - 1, g) / t, b = wrapcell(i, g) / t, c = wrapcell(i + 1, g) / t;
+    int n = 1;
+    out[0] = a;
+    if (b != a) out[n++] = b;
+    if (c != a && c != b) out[n++] = c;
+    return n;
+}
+
+template <typename PT>
+struct Entry {
+    PT x, y, z, w;
+};
+
+// _wrap_inplace (tsc.py:219-226): one +-box shift, compared/shifted in float64 (Numba promotion), stored back as PT
+template <typename PT>
+__device__ __forceinline__ PT wrap1(PT v, double box, bool &changed) {
+    if ((double)v >= box) {
+        changed = true;
+        return (PT)((double)v - box);
+    }
+    if (v < 0) {
+        changed = true;
+        return (PT)((double)v + box);
+    }
+    return v;
+}
+
+// pass over the particles: FILL=false counts list lengths (and wraps in place), FILL=true appends entries
+template <typename PT, bool FILL, bool CIC>
+__global__ __launch_bounds__(TSC_BLOCK) void tsc_bin(PT *__restrict__ pos, int64_t n, const PT *__restrict__ weights,
+                                                     TileGeom g, double box, double offset_, int wrap,
+                                                     unsigned int *__restrict__ tile_count,
+                                                     const int64_t *__restrict__ tile_start,
+                                                     Entry<PT> *__restrict__ entries, int *__restrict__ wrapped_flag) {
+    const PT ihx = (PT)(g.gx / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
+    const PT offset = (PT)offset_;
+    bool any_changed = false;
+    for (int64_t p = (int64_t)blockIdx.x * TSC_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * TSC_BLOCK) {
+        PT x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+        if (!FILL && wrap) {
+            bool ch = false;
+            x = wrap1(x, box, ch);
+            y = wrap1(y, box, ch);
+            z = wrap1(z, box, ch);
+            if (ch) {
+                pos[3 * p] = x;
+                pos[3 * p + 1] = y;
+                pos[3 * p + 2] = z;
+                any_changed = true;
+            }
+        }
+        int ci[3];
+        if (CIC) {
+            Cloud<double> c;
+            cic_cloud<PT>(x + offset, y + offset, z + offset, box, g.gx, g.gy, g.gz, c);
+            ci[0] = c.i[0], ci[1] = c.i[1], ci[2] = c.i[2];
+        } else {
+            Cloud<PT> c;
+            tsc_cloud<PT>(x, y, z, offset, ihx, ihy, ihz, c);
+            ci[0] = c.i[0], ci[1] = c.i[1], ci[2] = c.i[2];
+        }
+        int ax[3], ay[3], az[3];
+        const int nx = tiles_1d(ci[0], g.gx, g.tx, ax), ny = tiles_1d(ci[1], g.gy, g.ty, ay),
+                  nz = tiles_1d(ci[2], g.gz, g.tz, az);
+        const PT w = (FILL && weights) ? weights[p] : (PT)1;
+        for (int a = 0; a < nx; a++)
+            for (int b = 0; b < ny; b++)
+                for (int c = 0; c < nz; c++) {
+                    const int tile = (ax[a] * g.nty + ay[b]) * g.ntz + az[c];
+                    const unsigned int slot = atomicAdd(&tile_count[tile], 1u);
+                    if (FILL) entries[tile_start[tile] + slot] = Entry<PT>{x, y, z, w};
+                }
+    }
+    if (!FILL && any_changed) *wrapped_flag = 1;
+}
+
+// exclusive scan of the per-tile counts (one workgroup); also re-zeroes the counters for the FILL pass
+constexpr int TSCAN_BLOCK = 1024;
+__global__ __launch_bounds__(TSCAN_BLOCK) void tsc_scan_tiles(unsigned int *__restrict__ tile_count, int ntiles,
+                                                              int64_t *__restrict__ tile_start) {
+    __shared__ int64_t part[TSCAN_BLOCK];
+    const int per = (ntiles + TSCAN_BLOCK - 1) / TSCAN_BLOCK;
+    const int lo = min(ntiles, (int)threadIdx.x * per), hi = min(ntiles, lo + per);
+    int64_t s = 0;
+    for (int t = lo; t < hi; t++) s += tile_count[t];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < TSCAN_BLOCK; off <<= 1) {
+        int64_t v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int64_t run = part[threadIdx.x] - s;
+    for (int t = lo; t < hi; t++) {
+        tile_start[t] = run;
+        run += tile_count[t];
+        tile_count[t] = 0;
+    }
+    if (threadIdx.x == TSCAN_BLOCK - 1) tile_start[ntiles] = part[threadIdx.x];
+}
+
+// One workgroup per tile.  LDS tile: tx*ty*tz cells of GT, strides (TYS*TZS, TZS, 1) fixed at compile time.
+template <typename PT, typename GT, int TXS, int TYS, int TZS, bool CIC>
+__global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *__restrict__ entries,
+                                                              const int64_t *__restrict__ tile_start, TileGeom g,
+                                                              double box, double offset_, GT *__restrict__ grid,
+                                                              int zero_grid, GT norm) {
+    // The tile is accumulated in float64 whatever the mesh dtype: the order of the LDS atomics then only matters at
+    // the 1e-16 level, so the float32 mesh is reproducible run to run (and each cell is rounded once, not per add).
+    __shared__ double tile[TXS * TYS * TZS];
+    const int tid = threadIdx.x;
+    const int tzi = blockIdx.x % g.ntz, tyi = (blockIdx.x / g.ntz) % g.nty, txi = blockIdx.x / (g.ntz * g.nty);
+    const int ox = txi * g.tx, oy = tyi * g.ty, oz = tzi * g.tz;
+    const int dx = min(g.tx, g.gx - ox), dy = min(g.ty, g.gy - oy), dz = min(g.tz, g.gz - oz);
+    for (int q = tid; q < TXS * TYS * TZS; q += TSC_BLOCK) tile[q] = 0.0;
+    __syncthreads();
+    const int64_t e0 = tile_start[blockIdx.x], e1 = tile_start[blockIdx.x + 1];
+    const PT ihx = (PT)(g.gx / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
+    const PT offset = (PT)offset_;
+    for (int64_t e = e0 + tid; e < e1; e += TSC_BLOCK) {
+        const Entry<PT> en = entries[e];
+        int lx[3], ly[3], lz[3];
+        if (CIC) {
+            Cloud<double> c;
+            cic_cloud<PT>(en.x + offset, en.y + offset, en.z + offset, box, g.gx, g.gy, g.gz, c);
+            const double W = (double)en.w;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                lx[a] = wrapcell(c.i[0] + a - 1, g.gx) - ox;
+                ly[a] = wrapcell(c.i[1] + a - 1, g.gy) - oy;
+                lz[a] = wrapcell(c.i[2] + a - 1, g.gz) - oz;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                if ((unsigned)lx[a] >= (unsigned)dx) continue;
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    if ((unsigned)ly[b] >= (unsigned)dy) continue;
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++) {
+                        if ((unsigned)lz[cc] >= (unsigned)dz) continue;
+                        const double v = c.w[0][a] * c.w[1][b] * c.w[2][cc] * W;
+                        if (v != 0.0) atomicAdd(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], v);
+                    }
+                }
+            }
+        } else {
+            Cloud<PT> c;
+            tsc_cloud<PT>(en.x, en.y, en.z, offset, ihx, ihy, ihz, c);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                lx[a] = wrapcell(c.i[0] + a - 1, g.gx) - ox;
+                ly[a] = wrapcell(c.i[1] + a - 1, g.gy) - oy;
+                lz[a] = wrapcell(c.i[2] + a - 1, g.gz) - oz;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                if ((unsigned)lx[a] >= (unsigned)dx) continue;
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    if ((unsigned)ly[b] >= (unsigned)dy) continue;
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++) {
+                        if ((unsigned)lz[cc] >= (unsigned)dz) continue;
+                        const PT v = c.w[0][a] * c.w[1][b] * c.w[2][cc] * en.w;  // wx*wy*wz*W (tsc.py:471-507)
+                        atomicAdd(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], (double)v);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flush: consecutive threads walk z, so a wave writes whole 256-B rows
+    const int cells = dx * dy * dz;
+    for (int q = tid; q < cells; q += TSC_BLOCK) {
+        const int z = q % dz, y = (q / dz) % dy, x = q / (dz * dy);
+        double acc = tile[(x * TYS + y) * TZS + z];
+        GT *dst = grid + ((int64_t)(ox + x) * g.gy + (oy + y)) * g.zstride + (oz + z);
+        if (!zero_grid) acc += (double)*dst;
+        GT v = (GT)acc;
+        if (norm != (GT)0) v = v * norm - (GT)1;
+        *dst = v;
+    }
+}
+
+// ---- host-side driver ------------------------------------------------------------------------------------
+struct TscWork {
+    DevBuf tile_count, tile_start, entries, flag;
+};
+TscWork g_work;
+
+TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int TZ) {
+    TileGeom g;
+    g.gx = gx, g.gy = gy, g.gz = gz;
+    g.tx = std::min(TX, gx), g.ty = std::min(TY, gy), g.tz = std::min(TZ, gz);
+    g.ntx = (gx + g.tx - 1) / g.tx, g.nty = (gy + g.ty - 1) / g.ty, g.ntz = (gz + g.tz - 1) / g.tz;
+    g.zstride = zstride;
+    return g;
+}
+
+template <typename PT, typename GT, bool CIC>
+int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy, int gz, int64_t zstride, double box,
+                double offset, int wrap, int zero_grid, double norm, int *wrapped_out) {
+    if (gx < 1 || gy < 1 || gz < 1) return fail("tsc: empty mesh");
+    if (gx > 32767 || gy > 32767 || gz > 32767) return fail("tsc: mesh dimension > 32767 (int16 cell index of the reference)");
+    constexpr int TX = 16, TY = 16, TZ = 32;   // 8192 float64 cells = 64 KiB of LDS -> two workgroups per CU
+    const TileGeom g = make_geom(gx, gy, gz, zstride, TX, TY, TZ);
+    const int64_t ntiles64 = (int64_t)g.ntx * g.nty * g.ntz;
+    if (ntiles64 > 0x7fffffff) return fail("tsc: too many tiles");
+    const int ntiles = (int)ntiles64;
+    ABACUS_TRY(g_work.tile_count.reserve((size_t)(ntiles + 1) * sizeof(unsigned int)));
+    ABACUS_TRY(g_work.tile_start.reserve((size_t)(ntiles + 1) * sizeof(int64_t)));
+    ABACUS_TRY(g_work.flag.reserve(256));
+    unsigned int *tile_count = g_work.tile_count.as<unsigned int>();
+    int64_t *tile_start = g_work.tile_start.as<int64_t>();
+    int *flag = g_work.flag.as<int>();
+    HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)(ntiles + 1) * sizeof(unsigned int), stream()));
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), stream()));
+    const int nblk = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, TSC_BLOCK), 1), 256 * 16);
+    if (n > 0)
+        ABACUS_LAUNCH("tsc_bin_count", (tsc_bin<PT, false, CIC>), dim3(nblk), dim3(TSC_BLOCK), 0, pos, n, weights, g,
+                      box, offset, wrap, tile_count, (const int64_t *)nullptr, (Entry<PT> *)nullptr, flag);
+    ABACUS_LAUNCH("tsc_scan_tiles", tsc_scan_tiles, dim3(1), dim3(TSCAN_BLOCK), 0, tile_count, ntiles, tile_start);
+    // list length (needed to size the entry buffer): one 8-byte read-back
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, tile_start + ntiles, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+    int h_flag = 0;
+    HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    if (wrapped_out) *wrapped_out = h_flag;
+    ABACUS_TRY(g_work.entries.reserve((size_t)std::max<int64_t>(total, 1) * sizeof(Entry<PT>)));
+    Entry<PT> *entries = g_work.entries.as<Entry<PT>>();
+    if (n > 0)
+        ABACUS_LAUNCH("tsc_bin_fill", (tsc_bin<PT, true, CIC>), dim3(nblk), dim3(TSC_BLOCK), 0, pos, n, weights, g, box,
+                      offset, 0, tile_count, (const int64_t *)tile_start, entries, flag);
+    ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit<PT, GT, TX, TY, TZ, CIC>), dim3(ntiles), dim3(TSC_BLOCK), 0,
+                  (const Entry<PT> *)entries, (const int64_t *)tile_start, g, box, offset, grid, zero_grid, (GT)norm);
+    return 0;
+}
+
+template <typename PT, typename GT, bool CIC>
+int deposit_host(void *pos_, int64_t n, const void *weights_, void *grid_, int gx, int gy, int gz, double box,
+                 double offset, int wrap) {
+    ABACUS_TRY(ensure_init());
+    const size_t cells = (size_t)gx * gy * gz;
+    PT *dpos = nullptr, *dw = nullptr;
+    GT *dgrid = nullptr;
+    int rc = 0, wrapped = 0;
+    do {
+        if (hipMalloc((void **)&dpos, std::max<size_t>(3 * n * sizeof(PT), 16)) != hipSuccess ||
+            hipMalloc((void **)&dgrid, cells * sizeof(GT)) != hipSuccess ||
+            (weights_ && hipMalloc((void **)&dw, std::max<size_t>(n * sizeof(PT), 16)) != hipSuccess)) {
+            rc = fail("tsc: device allocation failed");
+            break;
+        }
+        (void)hipMemcpyAsync(dpos, pos_, 3 * n * sizeof(PT), hipMemcpyHostToDevice, stream());
+        if (weights_) (void)hipMemcpyAsync(dw, weights_, n * sizeof(PT), hipMemcpyHostToDevice, stream());
+        (void)hipMemcpyAsync(dgrid, grid_, cells * sizeof(GT), hipMemcpyHostToDevice, stream());  // accumulate semantics
+        rc = deposit_dev<PT, GT, CIC>(dpos, n, dw, dgrid, gx, gy, gz, gz, box, offset, wrap, 0, 0.0, &wrapped);
+        if (rc) break;
+        if (hipMemcpyAsync(grid_, dgrid, cells * sizeof(GT), hipMemcpyDeviceToHost, stream()) != hipSuccess) {
+            rc = fail("tsc: D2H of the grid failed");
+            break;
+        }
+        if (wrap && wrapped)  // the reference wraps the caller's array in place (tsc.py:171-173)
+            (void)hipMemcpyAsync(pos_, dpos, 3 * n * sizeof(PT), hipMemcpyDeviceToHost, stream());
+        if (hipStreamSynchronize(stream()) != hipSuccess) rc = fail("tsc: stream synchronisation failed");
+    } while (0);
+    if (dpos) (void)hipFree(dpos);
+    if (dw) (void)hipFree(dw);
+    if (dgrid) (void)hipFree(dgrid);
+    return rc;
+}
+
+}  // namespace
+
+namespace abacus {
+// used by power.hip: float32 deposit into a (possibly padded) device mesh with fused normalisation
+int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
+                    double offset, int wrap, double norm, int cic) {
+    if (cic)
+        return deposit_dev<float, float, true>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, 0, 1, norm,
+                                               nullptr);
+    return deposit_dev<float, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
+                                            nullptr);
+}
+int tsc_release_work() {
+    ABACUS_TRY(g_work.tile_count.release());
+    ABACUS_TRY(g_work.tile_start.release());
+    ABACUS_TRY(g_work.entries.release());
+    ABACUS_TRY(g_work.flag.release());
+    return 0;
+}
+}  // namespace abacus
+
+extern "C" {
+
+int abacus_tsc_deposit(void *pos, int64_t n, const void *weights, int pos_dtype, void *grid, int gx, int gy, int gz,
+                       int grid_dtype, double box, double offset, int wrap) {
+    if (!grid || (n > 0 && !pos)) return fail("abacus_tsc_deposit: null argument");
+    if (pos_dtype == ABACUS_F32 && grid_dtype == ABACUS_F32)
+        return deposit_host<float, float, false>(pos, n, weights, grid, gx, gy, gz, box, offset, wrap);
+    if (pos_dtype == ABACUS_F64 && grid_dtype == ABACUS_F32)
+        return deposit_host<double, float, false>(pos, n, weights, grid, gx, gy, gz, box, offset, wrap);
+    if (pos_dtype == ABACUS_F32 && grid_dtype == ABACUS_F64)
+        return deposit_host<float, double, false>(pos, n, weights, grid, gx, gy, gz, box, offset, wrap);
+    if (pos_dtype == ABACUS_F64 && grid_dtype == ABACUS_F64)
+        return deposit_host<double, double, false>(pos, n, weights, grid, gx, gy, gz, box, offset, wrap);
+    return fail("abacus_tsc_deposit: unknown dtype code");
+}
+
+int abacus_tsc_deposit_dev(float *pos, int64_t n, const float *weights, float *grid, int gx, int gy, int gz,
+                           double box, double offset, int wrap, int zero_grid, int cic) {
+    ABACUS_TRY(ensure_init());
+    if (cic)
+        return deposit_dev<float, float, true>(pos, n, weights, grid, gx, gy, gz, gz, box, offset, 0, zero_grid, 0.0,
+                                               nullptr);
+    return deposit_dev<float, float, false>(pos, n, weights, grid, gx, gy, gz, gz, box, offset, wrap, zero_grid, 0.0,
+                                            nullptr);
+}
+
+int abacus_cic_deposit(const void *pos, int64_t n, const void *weights, int pos_dtype, float *grid, int gx, int gy,
+                       int gz, double box) {
+    if (!grid || (n > 0 && !pos)) return fail("abacus_cic_deposit: null argument");
+    if (pos_dtype == ABACUS_F32)
+        return deposit_host<float, float, true>(const_cast<void *>(pos), n, weights, grid, gx, gy, gz, box, 0.0, 0);
+    if (pos_dtype == ABACUS_F64)
+        return deposit_host<double, float, true>(const_cast<void *>(pos), n, weights, grid, gx, gy, gz, box, 0.0, 0);
+    return fail("abacus_cic_deposit: unknown dtype code");
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+"""P(k) leg of bench.py: TSC deposit + 3-D R2C FFT + fused (k,mu)/multipole binning on one MI355X.
+
+Workload = BASELINE config 3 (seed 300, `rng.random((N,3), f4) * L`, L = 2000, scripts/power/bench.py:28-39
+protocol): N = 1e8 particles on a 1024^3 mesh by default; `--nmesh 2048` is the north-star mesh.
+A step = one full calc_power chain (non-interlaced, uncompensated like scripts/power/bench.py:31) with particles
+already resident in HBM; the spectrum never leaves the device.
+"""
+import os
+import time
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0
+
+
+def bench_pk(args, dist, headline):
+    import ctypes as C
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis import power_spectrum as ps
+
+    nmesh, n = args.nmesh, args.npk
+    L = 2000.0
+    rng = np.random.default_rng(300 + dist.rank)
+    pos = rng.random((n, 3), dtype=np.float32)
+    pos *= np.float32(L)
+    dpos = _lib.DeviceArray(pos)
+    kbins, mubins = ps.get_k_mu_edges(L, np.pi * nmesh / L + 1e-6, min(512, nmesh // 2), 4, False)
+    ke = np.ascontiguousarray(kbins, dtype=np.float64)
+    me = np.ascontiguousarray(mubins, dtype=np.float64)
+    poles = np.array([0, 2, 4], dtype=np.int64)
+    outs = ps._alloc_outputs(len(ke) - 1, len(me) - 1, len(poles))
+    lib = _lib.lib()
+
+    def step(interlaced=0, W=None):
+        _lib.check(lib.abacus_power_from_particles_dev(
+            dpos.ptr, C.c_int64(n), None, None, C.c_int64(0), None, C.c_double(L), int(nmesh), 0,
+            _lib.ptr(W), int(interlaced), _lib.ptr(ke), len(ke) - 1, _lib.ptr(me), len(me) - 1, _lib.ptr(poles),
+            len(poles), *[_lib.ptr(o) for o in outs]))
+
+    steps = max(1, min(args.steps, 10))
+    for _ in range(max(1, min(args.warmup, 2))):
+        step()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    dist.barrier()
+    _lib.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    _lib.sync()
+    dist.barrier()
+    dt = dist.max(time.perf_counter() - t0) / steps
+    _lib.profile_enable(False)
+    prof = _lib.profile_get()
+    kern = {k: ms / c for k, (ms, c) in prof.items() if c}
+
+    power = outs[0].copy()
+    shot = L**3 / n
+    M = float(nmesh) ** 3
+    alg_bytes_total = 12.0 * n + 36.0 * M   # SURVEY.md 8d, non-interlaced
+    alg = {
+        'hipfft_r2c': 24.0 * M,            # three 1-D passes x (read + write) of the 4M-byte mesh/half-spectrum
+        'tsc_tile_deposit': 4.0 * M + 16.0 * 1.3 * n,
+        'spectrum_bin': 4.0 * M,
+        'tsc_bin_count': 12.0 * n,
+        'tsc_bin_fill': 12.0 * n + 16.0 * 1.3 * n,
+    }
+    dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
+    ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
+    out = {
+        'metric': f'wall-clock of {nmesh}^3 TSC+FFT P(k)',
+        'value': dt * 1e3,
+        'unit': 'ms',
+        'n_gpus': dist.world,
+        'steps': steps,
+        'warmup': max(1, min(args.warmup, 2)),
+        'ms_per_step': dt * 1e3,
+        'higher_is_better': False,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': f'C3-style: {n:.0e} uniform float32 particles (seed 300+rank), L=2000, nmesh={nmesh}, '
+                               'TSC, non-interlaced, uncompensated, 4 mu bins, poles 0/2/4; particles resident in HBM',
+                   'nmesh': nmesh, 'n_particles': n},
+        'kernels_ms': {k: round(v, 4) for k, v in kern.items()},
+        'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot),
+        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                     'whole_step_GBs': alg_bytes_total / dt / 1e9,
+                     'whole_step_frac': alg_bytes_total / dt / 1e9 / HBM_PEAK_GBS},
+    }
+    # interlaced + compensated variant (the calc_power defaults): 24 N + 80 M algorithmic bytes
+    try:
+        W = ps.get_W_compensated(L, nmesh, 'TSC', True).astype(np.float32)
+        step(1, W)
+        _lib.sync()
+        t1 = time.perf_counter()
+        for _ in range(max(1, steps // 2)):
+            step(1, W)
+        _lib.sync()
+        dti = (time.perf_counter() - t1) / max(1, steps // 2)
+        out['interlaced_compensated'] = {'ms_per_step': dti * 1e3,
+                                         'whole_step_GBs': (24.0 * n + 80.0 * M) / dti / 1e9}
+    except Exception as e:
+        out['interlaced_compensated'] = {'error': repr(e)}
+    dpos.free()
+    lib.abacus_power_release()
+    if dist.rank == 0 and not args.no_cpu:
+        out['cpu_baseline'] = cpu_baseline_pk(L)
+    return out
+
+
+def cpu_baseline_pk(L):
+    """oracle (C+OpenMP stripe TSC, scipy pocketfft rfftn = the reference's FFT, OpenMP bin_kmu) on a bounded
+    sample with the same particle density per cell as C3: nmesh 512, 1.25e7 particles"""
+    from oracle import oracle
+    cores = len(os.sched_getaffinity(0))
+    nmesh, n = 512, 12_500_000
+    rng = np.random.default_rng(300)
+    pos = rng.random((n, 3), dtype=np.float32) * np.float32(L)
+    kw = dict(kbins=256, mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste='TSC', nmesh=nmesh, compensated=False,
+              interlaced=False, poles=[0, 2, 4], nthread=cores, accum64=True)
+    oracle.calc_power(pos.copy(), L, **kw)
+    ts = []
+    for _ in range(2):
+        p = pos.copy()
+        t = time.perf_counter()
+        oracle.calc_power(p, L, **kw)
+        ts.append(time.perf_counter() - t)
+    return {'value': float(nmesh) ** 3 / min(ts), 'unit': 'mesh cells/s', 'cores': cores, 'kind': 'port',
+            'sample': f'nmesh {nmesh}, {n} particles (same particles per cell as the GPU workload), '
+                      f'{min(ts) * 1e3:.0f} ms per calc_power, min of 2 after 1 warm-up',
+            'ms': min(ts) * 1e3}

@@ -1,0 +1,144 @@
+"""HIP power-spectrum path (deposit -> hipFFT -> fused binning) vs golden vectors of the reference's calc_power and
+vs the float64-accumulating CPU oracle.  Tolerance: 1e-5 relative on P (north_star), exact N_mode.
+Needs an MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+from conftest import load_golden
+
+from abacusutils_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+L, N, NMESH = 500.0, 20000, 32
+RTOL = 1e-5
+
+
+def _pos():
+    return synth.synth_positions(N, L, seed=300, clustered=True)
+
+
+def _check_golden(tab, g, name, rtol):
+    for k in ('power', 'k_avg', 'poles'):
+        if f'{name}.{k}' in g:
+            want = g[f'{name}.{k}']
+            np.testing.assert_allclose(np.asarray(tab[k]), want, rtol=rtol, atol=rtol * np.abs(want).max() * 0.1,
+                                       err_msg=f'{name}.{k}')
+    for k in ('N_mode', 'N_mode_poles'):
+        if f'{name}.{k}' in g:
+            np.testing.assert_array_equal(np.asarray(tab[k]), g[f'{name}.{k}'], err_msg=f'{name}.{k}')
+    np.testing.assert_allclose(tab['k_mid'], g[f'{name}.k_mid'], rtol=1e-15)
+
+
+def _check_oracle(tab, ref, rtol=RTOL):
+    np.testing.assert_array_equal(np.asarray(tab['N_mode']), ref['N_mode'])
+    for k in ('power', 'k_avg', 'poles'):
+        if k in ref:
+            want = np.asarray(ref[k], dtype='f8')
+            np.testing.assert_allclose(np.asarray(tab[k], dtype='f8'), want, rtol=rtol,
+                                       atol=rtol * np.abs(want).max() * 0.1, err_msg=k)
+
+
+@pytest.mark.parametrize('paste', ['TSC', 'CIC'])
+@pytest.mark.parametrize('comp', [False, True])
+@pytest.mark.parametrize('inter', [False, True])
+def test_calc_power_modes(paste, comp, inter):
+    """the 8 paste x compensated x interlaced combinations of the reference's tests/test_power.py:22-35"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    g = load_golden('power_cases')
+    kw = dict(kbins=12, mubins=4, k_max=np.pi * NMESH / L + 1e-6, paste=paste, nmesh=NMESH, compensated=comp,
+              interlaced=inter, poles=[0, 2, 4])
+    tab = calc_power(_pos(), L, **kw)
+    # vs what the reference returned (its own float32 accumulators limit this comparison)
+    _check_golden(tab, g, f'{paste}_c{int(comp)}_i{int(inter)}', rtol=3e-5 if paste == 'TSC' else 1e-4)
+    # vs the float64-accumulating oracle: the north_star tolerance
+    _check_oracle(tab, oracle.calc_power(_pos(), L, nthread=4, accum64=True, **kw))
+    # tests/test_power.py:58-61: monopole == mode-weighted mean of the wedges
+    p, nm = np.asarray(tab['power'], dtype='f8'), np.asarray(tab['N_mode'], dtype='f8')
+    ok = nm.sum(axis=1) > 0
+    mono = (p * nm).sum(axis=1)[ok] / nm.sum(axis=1)[ok]
+    np.testing.assert_allclose(np.asarray(tab['poles'])[ok, 0], mono, rtol=1e-6)
+
+
+def test_weights_cross_logk_defaults_odd():
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    g = load_golden('power_cases')
+    rng = np.random.default_rng(5)
+    w = (0.5 + rng.random(N, dtype='f4')).astype('f4')
+    pos2 = synth.synth_positions(N // 2, L, seed=301, clustered=True)
+    cases = [
+        ('TSC_weights_squeeze', dict(kbins=10, mubins=None, paste='TSC', nmesh=NMESH, compensated=True,
+                                     interlaced=False, w=w, poles=[0, 2]), None),
+        ('TSC_cross', dict(kbins=9, mubins=3, paste='TSC', nmesh=NMESH, compensated=True, interlaced=True,
+                           poles=[0, 2, 4]), pos2),
+        ('TSC_logk', dict(kbins=8, mubins=2, logk=True, paste='TSC', nmesh=NMESH, compensated=False,
+                          interlaced=False), None),
+        ('TSC_defaults_n24', dict(paste='TSC', nmesh=24, compensated=True, interlaced=True), None),
+        ('TSC_odd27', dict(kbins=7, mubins=2, paste='TSC', nmesh=27, compensated=True, interlaced=True,
+                           poles=[0, 2]), None),
+    ]
+    for name, kw, p2 in cases:
+        tab = calc_power(_pos(), L, pos2=None if p2 is None else p2.copy(), **kw)
+        _check_golden(tab, g, name, rtol=5e-4 if name == 'TSC_cross' else 3e-5)
+        ref = oracle.calc_power(_pos(), L, pos2=None if p2 is None else p2.copy(), nthread=4, accum64=True, **kw)
+        _check_oracle(tab, ref, rtol=RTOL if name != 'TSC_cross' else 1e-4)
+        if kw.get('mubins', 1) is None:
+            assert np.asarray(tab['power']).ndim == 1 and 'mu_mid' not in tab
+
+
+def test_pk_from_deltak():
+    """calc_pk_from_deltak on caller-supplied spectra (the zcv call pattern, hod/zcv/tracer_power.py:160,208)"""
+    from abacusutils_amd.analysis.power_spectrum import calc_pk_from_deltak, get_k_mu_edges
+    g = load_golden('power_cases')
+    n = 20
+    ke, me = get_k_mu_edges(L, np.pi * n / L, 6, 3, False)
+    r = calc_pk_from_deltak(g['deltak.f1'], L, ke, me, field2_fft=g['deltak.f2'], poles=np.array([0, 2, 4, 6]))
+    for k in ('N_mode', 'N_mode_poles'):
+        np.testing.assert_array_equal(r[k], g[f'deltak.cross.{k}'])
+    for k in ('power', 'binned_poles', 'k_avg'):
+        want = g[f'deltak.cross.{k}']
+        np.testing.assert_allclose(r[k], want, rtol=1e-5, atol=3e-6 * np.abs(want).max(), err_msg=k)
+    r = calc_pk_from_deltak(g['deltak.f1'], L, ke, me, squeeze_mu_axis=False)
+    np.testing.assert_array_equal(r['N_mode'], g['deltak.auto.N_mode'])
+    np.testing.assert_allclose(r['power'], g['deltak.auto.power'], rtol=5e-6)
+    np.testing.assert_allclose(r['k_avg'], g['deltak.auto.k_avg'], rtol=5e-6)
+    assert r['binned_poles'].shape == (0, 6)
+
+
+def test_get_field_fft_and_window():
+    from abacusutils_amd.analysis.power_spectrum import get_field_fft, get_W_compensated
+    from oracle import oracle
+    g = load_golden('power_cases')
+    for paste in ('TSC', 'CIC'):
+        for inter in (False, True):
+            np.testing.assert_array_equal(get_W_compensated(L, 32, paste, inter), g[f'W.{paste}_i{int(inter)}'])
+    with pytest.raises(ValueError):
+        get_W_compensated(L, 32, 'NGP', True)
+    W = get_W_compensated(L, NMESH, 'TSC', True)
+    a = get_field_fft(_pos(), L, NMESH, 'TSC', None, W, True, True)
+    b = oracle.get_field_fft(_pos(), L, NMESH, 'TSC', None, W, True, True, nthread=2)
+    assert a.shape == b.shape and a.dtype == np.complex64
+    assert np.abs(a - b).max() < 2e-6 * np.abs(b).max()
+
+
+def test_errors():
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    with pytest.raises(ValueError):
+        calc_power(_pos(), L, paste='NGP', nmesh=16)
+
+
+@pytest.mark.parametrize('nmesh,interlaced', [(256, False), (384, True)])
+def test_shot_noise_and_oracle_at_scale(nmesh, interlaced):
+    """uniform randoms: P(k) -> L^3/N (SURVEY 8d known answer), and 1e-5 agreement with the oracle at 3e6 particles"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    n, box = 3_000_000, 2000.0
+    pos = synth.synth_positions(n, box, seed=300)
+    kw = dict(kbins=64, mubins=4, paste='TSC', nmesh=nmesh, compensated=True, interlaced=interlaced, poles=[0, 2, 4])
+    tab = calc_power(pos.copy(), box, **kw)
+    shot = box**3 / n
+    p = np.asarray(tab['poles'])[:, 0]
+    assert abs(np.mean(p[8:48]) / shot - 1) < 0.01
+    ref = oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw)
+    _check_oracle(tab, ref)

@@ -1,0 +1,159 @@
+"""HIP TSC / CIC / partition path vs the reference's saved grids, the golden vectors and the CPU oracle.
+Mirrors the reference's tests/test_tsc.py.  Needs an MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense(g, key, ng):
+    a = np.zeros(ng**3, dtype=np.float32)
+    a[g[key + '.idx']] = g[key + '.val']
+    return a.reshape(ng, ng, ng)
+
+
+@pytest.mark.parametrize('ngrid', [10, 256])
+@pytest.mark.parametrize('dtype', ['f4', 'f8'])
+@pytest.mark.parametrize('nthread', [1, -1])
+@pytest.mark.filterwarnings('ignore:.*dtype')
+class TestTSC:
+    box = 123.0
+
+    def test_single(self, ngrid, dtype, nthread):
+        """tests/test_tsc.py:25-90"""
+        from abacusutils_amd.analysis.tsc import tsc_parallel
+        cen = np.array([5, 6, 7])
+        single = (cen / ngrid * self.box).astype(dtype).reshape(1, -1)
+        dens = tsc_parallel(single, ngrid, self.box, nthread=nthread)
+        assert (dens == 0).sum() == ngrid**3 - 27
+        assert np.isclose(dens.sum(), 1.0)
+        cube = dens[4:7, 5:8, 6:9]
+        assert np.allclose([cube[0, 0, 0], cube[0, 0, 2], cube[0, 2, 0], cube[0, 2, 2], cube[2, 0, 0], cube[2, 0, 2],
+                            cube[2, 2, 0], cube[2, 2, 2]], 0.5**9)
+        assert np.allclose([cube[0, 0, 1], cube[0, 1, 0], cube[1, 0, 0], cube[0, 2, 1], cube[0, 1, 2], cube[1, 0, 2],
+                            cube[2, 0, 1], cube[2, 1, 0], cube[1, 2, 0], cube[2, 2, 1], cube[2, 1, 2], cube[1, 2, 2]],
+                           0.5**6 * 0.75)
+        assert np.allclose([cube[1, 1, 0], cube[1, 0, 1], cube[0, 1, 1], cube[1, 1, 2], cube[1, 2, 1], cube[2, 1, 1]],
+                           0.5**3 * 0.75**2)
+        assert np.allclose(cube[1, 1, 1], 0.75**3)
+
+    def test_multi(self, ngrid, dtype, nthread):
+        """tests/test_tsc.py:92-159: mass conservation, saved reference grid, nbodykit grid (rtol 1e-4, atol 1e-5)"""
+        from abacusutils_amd.analysis.tsc import tsc_parallel
+        from oracle import oracle
+        rng = np.random.default_rng(234)
+        pos = rng.random((10000, 3), dtype='f4').astype(dtype) * self.box
+        weights = rng.random((10000,), dtype='f4').astype(dtype)
+        dens = tsc_parallel(pos, ngrid, self.box, nthread=nthread, weights=weights)
+        assert np.isclose(dens.sum(dtype='f8'), weights.sum(dtype='f8'))
+        pydens = np.zeros((ngrid, ngrid, ngrid), dtype=np.float32)
+        oracle.tsc_scatter(pos, pydens, self.box, weights)
+        assert np.allclose(dens, pydens)
+        ref = load_golden('tsc_ref')
+        assert np.allclose(dens, _dense(ref, f'tsc_ngrid{ngrid}', ngrid), rtol=1e-4, atol=1e-5)
+        assert np.allclose(dens, _dense(ref, f'nbodykit_tsc_ngrid{ngrid}', ngrid), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('name,dtype', [('f4_w', 'f4'), ('f4_now', 'f4'), ('f8_w', 'f8'), ('f4_offset', 'f4'),
+                                        ('f4_aniso', 'f4'), ('f8_grid64', 'f8')])
+@pytest.mark.filterwarnings('ignore:.*dtype')
+def test_scatter_cases(name, dtype):
+    """golden vectors of _tsc_scatter: offset, anisotropic mesh, float64 mesh, no weights"""
+    from abacusutils_amd.analysis.tsc import tsc_parallel
+    g = load_golden('tsc_cases')
+    box = float(g[name + '.box'])
+    pos = (g['base'].astype(dtype) * box).astype(dtype)
+    w = g['wts'].astype(dtype) if name not in ('f4_now', 'f8_grid64') else None
+    want = g[name + '.grid']
+    dens = np.zeros(want.shape, dtype=want.dtype)
+    r = tsc_parallel(pos, dens, box, weights=w, offset=float(g[name + '.offset']), wrap=False)
+    assert r is None
+    np.testing.assert_allclose(dens, want, rtol=2e-5 if want.dtype == np.float32 else 1e-12, atol=1e-6)
+
+
+def test_wrap_in_place_and_accumulate():
+    """tsc.py:45-50,171-173: pos wrapped IN PLACE, the user grid is accumulated into, returns None"""
+    from abacusutils_amd.analysis.tsc import tsc_parallel
+    g = load_golden('tsc_cases')
+    pos = g['parallel_wrap.pos_in'].copy()
+    grid = np.full((12, 12, 12), 0.25, dtype=np.float32)
+    assert tsc_parallel(pos, grid, 50.0, weights=g['wts']) is None
+    np.testing.assert_array_equal(pos, g['parallel_wrap.pos_out'])
+    np.testing.assert_allclose(grid, g['parallel_wrap.grid'], rtol=1e-5, atol=1e-6)
+
+
+def test_returns(seed=123):
+    """tests/test_tsc.py:211-230"""
+    from abacusutils_amd.analysis.tsc import tsc_parallel
+    rng = np.random.default_rng(seed)
+    pos = rng.random((100, 3), dtype='f4') * 123.0
+    dens = tsc_parallel(pos, 10, 123.0)
+    assert dens.shape == (10, 10, 10)
+    dens_allocated = np.zeros((10, 10, 10), dtype=np.float32)
+    assert tsc_parallel(pos, dens_allocated, 123.0) is None
+    np.testing.assert_allclose(dens_allocated, dens)
+
+
+def test_bad_npartition():
+    from abacusutils_amd.analysis.tsc import tsc_parallel
+    with pytest.raises(ValueError):
+        tsc_parallel(np.zeros((10, 3), dtype='f4'), 12, 1.0, nthread=4, npartition=5)
+    with pytest.raises(ValueError):
+        tsc_parallel(np.zeros((10, 3), dtype='f4'), 30, 1.0, nthread=4, npartition=3)
+
+
+@pytest.mark.parametrize('seed', [123, 456])
+@pytest.mark.parametrize('dtype', ['f4', 'f8'])
+@pytest.mark.parametrize('npartition', [1, 1000])
+def test_partition(seed, dtype, npartition):
+    """tests/test_tsc.py:162-208 (and stronger: the stable order itself)"""
+    from abacusutils_amd.analysis.tsc import partition_parallel
+    rng = np.random.default_rng(seed)
+    box, N = 123.0, 10000
+    pos = rng.random((N, 3), dtype=dtype) * box
+    weights = rng.random((N,), dtype=dtype)
+    ppart, starts, wpart = partition_parallel(pos, npartition, box, weights=weights)
+    keys = (pos[:, 0] * (npartition / box)).astype(np.int32)
+    iord = keys.argsort(kind='stable')
+    np_starts = np.zeros(npartition + 1, dtype=np.int64)
+    np_starts[1:] = np.bincount(keys, minlength=npartition).cumsum()
+    np.testing.assert_array_equal(starts, np_starts)
+    np.testing.assert_array_equal(ppart, pos[iord])
+    np.testing.assert_array_equal(wpart, weights[iord])
+
+
+def test_partition_golden():
+    from abacusutils_amd.analysis.tsc import partition_parallel
+    g = load_golden('tsc_cases')
+    pos = (g['base'] * np.float32(50.0)).astype('f4')
+    ps, st, ws = partition_parallel(pos, 7, 50.0, weights=g['wts'])
+    np.testing.assert_array_equal(st, g['partition.starts'])
+    np.testing.assert_array_equal(ps, g['partition.psort'])
+    np.testing.assert_array_equal(ws, g['partition.wsort'])
+
+
+def test_cic_golden():
+    from abacusutils_amd.analysis.cic import cic_serial
+    g = load_golden('tsc_cases')
+    pos = (g['base'] * np.float32(50.0)).astype('f4')
+    dens = np.zeros((12, 12, 12), dtype=np.float32)
+    cic_serial(pos, dens, 50.0, weights=g['wts'])
+    assert np.allclose(dens, g['cic_f4_w.grid'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('n,ngrid', [(0, 16), (1, 3), (5, 2), (200000, 77), (3000000, 200)])
+def test_vs_oracle_sizes(n, ngrid):
+    """empty input, meshes smaller than a tile / than the cloud, non-multiple-of-tile meshes, 3e6 particles"""
+    from abacusutils_amd.analysis.tsc import tsc_parallel
+    from oracle import oracle
+    rng = np.random.default_rng(n + ngrid)
+    box = 100.0
+    pos = ((rng.random((n, 3), dtype='f4') * 1.2 - 0.1) * np.float32(box)).astype('f4')   # some outside the box
+    w = rng.random(n, dtype='f4')
+    p1, p2 = pos.copy(), pos.copy()
+    a = tsc_parallel(p1, ngrid, box, weights=w)
+    b = oracle.tsc_parallel(p2, ngrid, box, weights=w, nthread=1)
+    np.testing.assert_array_equal(p1, p2)   # wrapped identically
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6)
+    assert np.isclose(a.sum(dtype='f8'), w.sum(dtype='f8'), rtol=1e-6)
