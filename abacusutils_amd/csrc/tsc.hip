@@ -6,7 +6,7 @@
 // into LDS-sized tiles (16 x 16 x 32 cells = 64 KiB of float64 accumulators, two workgroups per CU):
 //   tsc_bin<COUNT>   one pass over the particles: wrap (in place, like the reference), find the tiles the 3x3x3
 //                    cloud touches (1..8, 1.3 on average) and count them per tile (integer atomics, L2);
-//   tsc_scan_tiles   exclusive scan of the tile counts;
+//   scan.hip         exclusive scan of the tile counts;
 //   tsc_bin<FILL>    second pass: append (x, y, z, w) to every touched tile's list (16-B stores);
 //   tsc_tile_deposit one workgroup per tile: zero the tile in LDS, accumulate the list with LDS float atomics
 //                    (contributions falling outside the tile are dropped - the neighbour tile has its own copy of
@@ -27,6 +27,10 @@
 #include "common.hpp"
 
 using namespace abacus;
+
+namespace abacus {
+int exclusive_scan_u32(unsigned int *counters, int64_t n, int64_t *out, DevBuf &scratch, int zero_counters);
+}
 
 namespace {
 
@@ -179,32 +183,6 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_bin(PT *__restrict__ pos, int64
     if (!FILL && any_changed) *wrapped_flag = 1;
 }
 
-// exclusive scan of the per-tile counts (one workgroup); also re-zeroes the counters for the FILL pass
-constexpr int TSCAN_BLOCK = 1024;
-__global__ __launch_bounds__(TSCAN_BLOCK) void tsc_scan_tiles(unsigned int *__restrict__ tile_count, int ntiles,
-                                                              int64_t *__restrict__ tile_start) {
-    __shared__ int64_t part[TSCAN_BLOCK];
-    const int per = (ntiles + TSCAN_BLOCK - 1) / TSCAN_BLOCK;
-    const int lo = min(ntiles, (int)threadIdx.x * per), hi = min(ntiles, lo + per);
-    int64_t s = 0;
-    for (int t = lo; t < hi; t++) s += tile_count[t];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < TSCAN_BLOCK; off <<= 1) {
-        int64_t v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int64_t run = part[threadIdx.x] - s;
-    for (int t = lo; t < hi; t++) {
-        tile_start[t] = run;
-        run += tile_count[t];
-        tile_count[t] = 0;
-    }
-    if (threadIdx.x == TSCAN_BLOCK - 1) tile_start[ntiles] = part[threadIdx.x];
-}
-
 // One workgroup per tile.  LDS tile: tx*ty*tz cells of GT, strides (TYS*TZS, TZS, 1) fixed at compile time.
 template <typename PT, typename GT, int TXS, int TYS, int TZS, bool CIC>
 __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *__restrict__ entries,
@@ -291,7 +269,7 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *_
 
 // ---- host-side driver ------------------------------------------------------------------------------------
 struct TscWork {
-    DevBuf tile_count, tile_start, entries, flag;
+    DevBuf tile_count, tile_start, entries, flag, scan;
 };
 TscWork g_work;
 
@@ -326,7 +304,8 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     if (n > 0)
         ABACUS_LAUNCH("tsc_bin_count", (tsc_bin<PT, false, CIC>), dim3(nblk), dim3(TSC_BLOCK), 0, pos, n, weights, g,
                       box, offset, wrap, tile_count, (const int64_t *)nullptr, (Entry<PT> *)nullptr, flag);
-    ABACUS_LAUNCH("tsc_scan_tiles", tsc_scan_tiles, dim3(1), dim3(TSCAN_BLOCK), 0, tile_count, ntiles, tile_start);
+    // exclusive scan of the tile counts (also re-zeroes the counters: they become the FILL cursors)
+    ABACUS_TRY(exclusive_scan_u32(tile_count, ntiles, tile_start, g_work.scan, 1));
     // list length (needed to size the entry buffer): one 8-byte read-back
     int64_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, tile_start + ntiles, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
@@ -395,6 +374,7 @@ int tsc_release_work() {
     ABACUS_TRY(g_work.tile_start.release());
     ABACUS_TRY(g_work.entries.release());
     ABACUS_TRY(g_work.flag.release());
+    ABACUS_TRY(g_work.scan.release());
     return 0;
 }
 }  // namespace abacus

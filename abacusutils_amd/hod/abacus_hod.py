@@ -1,0 +1,555 @@
+"""MI355X drop-in for `abacusnbody.hod.abacus_hod.AbacusHOD` (reference: abacusnbody/hod/abacus_hod.py).
+
+Same constructor, attributes and method signatures for the calls on the hot path:
+
+    run_hod            (:706-859)   -> gen_gal_cat on the device-resident subsample (csrc/hod.hip)
+    compute_power      (:1338-1472) -> calc_power (csrc/tsc.hip, power.hip)
+    compute_xirppi / compute_wp / compute_multipole / compute_clustering  (:1181-1336, :1826-1885) -> csrc/pairs.hip
+    compute_ngal       (:861-1179)  host-side NumPy evaluation of the same sums ("next" row of SURVEY.md 8f)
+
+The halo/particle subsample is uploaded to HBM on the first `run_hod` and stays there (the reference keeps it in
+host RAM across calls, :193-197); `reseed` rewrites the three random arrays on host and device (:824-835).
+`AbacusHOD.from_arrays` builds the object from in-memory arrays (tests, synthetic data); the regular constructor
+runs `staging()` (needs h5py for the `halos_xcom_*`/`particles_xcom_*` files).
+ZCV (`apply_zcv*`) is outside the hot path and not provided.
+"""
+import logging
+import math
+import time
+from pathlib import Path
+
+import numpy as np
+
+from ..analysis.power_spectrum import calc_power
+from ..analysis.tpcf_corrfunc import calc_multipole_fast, calc_wp_fast, calc_xirppi_fast
+from .GRAND_HOD import StagedCatalog, gen_gal_cat
+
+_PRIMARY_Z = [3.0, 2.5, 2.0, 1.7, 1.4, 1.1, 0.8, 0.5, 0.4, 0.3, 0.2, 0.1, 0.0]
+_SECONDARY_Z = [0.15, 0.25, 0.35, 0.45, 0.575, 0.65, 0.725, 0.875, 0.95, 1.025, 1.175, 1.25, 1.325, 1.475, 1.55,
+                1.625, 1.85, 2.25, 2.75, 3.0, 5.0, 8.0]
+
+
+def _read_asdf_header(fn):
+    """`header` mapping of an Abacus ASDF file without the asdf package: the tree is YAML ahead of the first block"""
+    import re
+
+    import yaml
+    raw = open(fn, 'rb').read()
+    end = raw.find(b'\n...')
+    text = raw[: end if end >= 0 else len(raw)].decode('utf-8', errors='replace')
+    text = re.sub(r'!\S+', '', text)  # drop YAML tags (core/asdf, core/ndarray, ...)
+    text = '\n'.join(line for line in text.splitlines() if not line.startswith('%') and not line.startswith('#'))
+    tree = yaml.safe_load(text)
+    return tree['header']
+
+
+def _searchsorted(a, b):
+    return np.searchsorted(a, b).astype(np.int64)
+
+
+def calc_fenv_opt(Menv, mbins, halosM):
+    """global environment rank per mass bin (:1961-1970)"""
+    fenv_rank = np.zeros(len(Menv))
+    for ibin in range(len(mbins) - 1):
+        mmask = (halosM > mbins[ibin]) & (halosM < mbins[ibin + 1])
+        Nmask = np.sum(mmask)
+        if Nmask > 1:
+            new_fenv_rank = Menv[mmask].argsort().argsort()
+            fenv_rank[mmask] = new_fenv_rank / (Nmask - 1) - 0.5
+    return fenv_rank
+
+
+class AbacusHOD:
+    """A multi-tracer HOD code for the AbacusSummit simulations (MI355X path)."""
+
+    def __init__(self, sim_params, HOD_params, clustering_params=None, chunk=-1, n_chunks=1, skip_staging=False):
+        self.logger = logging.getLogger('AbacusHOD')
+        self.sim_name = sim_params['sim_name']
+        self.sim_dir = sim_params['sim_dir']
+        self.subsample_dir = sim_params['subsample_dir']
+        self.z_mock = sim_params['z_mock']
+        self.output_dir = sim_params.get('output_dir', './')
+        self.halo_lc = sim_params.get('halo_lc', False)
+        self.force_mt = sim_params.get('force_mt', False)
+        self.local_env = sim_params.get('local_env', {})
+
+        if self.halo_lc:
+            ztype = 'lightcone'
+        elif self.z_mock in _PRIMARY_Z:
+            ztype = 'primary'
+        elif self.z_mock in _SECONDARY_Z:
+            ztype = 'secondary'
+        else:
+            raise Exception('illegal redshift')
+        self.z_type = ztype
+        self._init_hod(HOD_params, clustering_params)
+        self.chunk = chunk
+        self.n_chunks = n_chunks
+        assert self.chunk < self.n_chunks, 'Total number of chunks needs to be larger than current chunk index'
+        self._staged = None
+        if not skip_staging:
+            self.halo_data, self.particle_data, self.params, self.mock_dir = self.staging()
+            self._build_mass_function()
+        else:
+            raise NotImplementedError('skip_staging=True needs abacusnbody.metadata (out of the hot-path scope); '
+                                      'use AbacusHOD.from_arrays for in-memory data')
+
+    def _init_hod(self, HOD_params, clustering_params):
+        tracer_flags = HOD_params['tracer_flags']
+        tracers = {}
+        for key in tracer_flags.keys():
+            if tracer_flags[key]:
+                tracers[key] = HOD_params[key + '_params']
+        self.tracers = tracers
+        self.want_ranks = HOD_params.get('want_ranks', False)
+        self.want_AB = HOD_params.get('want_AB', False)
+        self.want_shear = HOD_params.get('want_shear', False)
+        self.want_expvel = HOD_params.get('want_expvel', False)
+        self.want_rsd = HOD_params['want_rsd']
+        if clustering_params is not None:
+            self.pimax = clustering_params.get('pimax', None)
+            self.pi_bin_size = clustering_params.get('pi_bin_size', None)
+            bin_params = clustering_params['bin_params']
+            self.rpbins = np.logspace(bin_params['logmin'], bin_params['logmax'], bin_params['nbins'] + 1)
+            self.clustering_type = clustering_params.get('clustering_type', None)
+
+    @classmethod
+    def from_arrays(cls, halo_data, particle_data, params, HOD_params, clustering_params=None, mock_dir='./',
+                    z_type='primary'):
+        """Build the object from the dictionaries `staging()` would produce (hod/abacus_hod.py:659-704)."""
+        self = cls.__new__(cls)
+        self.logger = logging.getLogger('AbacusHOD')
+        self.sim_name = self.sim_dir = self.subsample_dir = None
+        self.z_mock = params['z']
+        self.output_dir = str(mock_dir)
+        self.halo_lc = params.get('origin', None) is not None
+        self.force_mt = False
+        self.local_env = {}
+        self.z_type = 'lightcone' if self.halo_lc else z_type
+        self._init_hod(HOD_params, clustering_params)
+        self.chunk, self.n_chunks = params.get('chunk', -1), 1
+        self.halo_data, self.particle_data, self.params = halo_data, particle_data, params
+        self.mock_dir = Path(mock_dir)
+        self.lbox = params['Lbox']
+        self._staged = None
+        if self.want_AB:
+            assert 'hfenv' in self.halo_data.keys()
+            assert 'hdeltac' in self.halo_data.keys()
+        if self.want_shear:
+            assert 'hshear' in self.halo_data.keys()
+        self._build_mass_function()
+        return self
+
+    def _build_mass_function(self):
+        """weighted halo histograms used by compute_ngal (:199-251)"""
+        hd = self.halo_data
+        n = len(hd['hmass'])
+        self.logMbins = np.linspace(np.log10(np.min(hd['hmass'])), np.log10(np.max(hd['hmass'])), 101)
+        self.deltacbins = np.linspace(-0.5, 0.5, 101)
+        self.fenvbins = np.linspace(-0.5, 0.5, 101)
+        self.shearbins = np.linspace(-0.5, 0.5, 101)
+        cols = (np.log10(hd['hmass']), hd.get('hdeltac', np.zeros(n)), hd.get('hfenv', np.zeros(n)))
+        self.halo_mass_func, _ = np.histogramdd(np.vstack(cols).T, bins=[self.logMbins, self.deltacbins, self.fenvbins],
+                                                weights=hd['hmultis'])
+        self._mass_func_wshear = None  # 100^4 histogram, built on first ELG compute_ngal
+
+    @property
+    def halo_mass_func_wshear(self):
+        if self._mass_func_wshear is None:
+            hd = self.halo_data
+            n = len(hd['hmass'])
+            cols = (np.log10(hd['hmass']), hd.get('hdeltac', np.zeros(n)), hd.get('hfenv', np.zeros(n)),
+                    hd.get('hshear', np.zeros(n)))
+            self._mass_func_wshear, _ = np.histogramdd(
+                np.vstack(cols).T, bins=[self.logMbins, self.deltacbins, self.fenvbins, self.shearbins],
+                weights=hd['hmultis'])
+        return self._mass_func_wshear
+
+    # ------------------------------------------------------------------------------------------------------
+    def staging(self):
+        """Load the halo+particle subsamples (hod/abacus_hod.py:253-704) into the float64 dictionaries the
+        population kernels consume."""
+        try:
+            import h5py
+        except ImportError as e:
+            raise ImportError('AbacusHOD.staging() reads the prepare_sim HDF5 subsamples and needs h5py; '
+                              'use AbacusHOD.from_arrays for in-memory data') from e
+        output_dir = Path(self.output_dir)
+        simname = Path(self.sim_name)
+        sim_dir = Path(self.sim_dir)
+        mock_dir = output_dir / simname / ('z%4.3f' % self.z_mock)
+        subsample_dir = Path(self.subsample_dir) / simname / ('z%4.3f' % self.z_mock)
+        if not (sim_dir / simname).exists():
+            raise FileNotFoundError(f'Simulation directory {sim_dir / simname} not found.')
+        if not subsample_dir.exists():
+            raise FileNotFoundError(f'Subsample directory {subsample_dir} not found.')
+        if self.halo_lc:
+            halo_info_fns = [str(sim_dir / simname / ('z%4.3f' % self.z_mock) / 'lc_halo_info.asdf')]
+        else:
+            halo_info_fns = list((sim_dir / simname / 'halos' / ('z%4.3f' % self.z_mock) / 'halo_info').glob('*.asdf'))
+        header = _read_asdf_header(halo_info_fns[0])
+
+        params = {}
+        params['z'] = self.z_mock
+        params['h'] = header['H0'] / 100.0
+        params['Lbox'] = header['BoxSize']
+        params['Mpart'] = header['ParticleMassHMsun']
+        params['velz2kms'] = header['VelZSpace_to_kms'] / params['Lbox']
+        if self.halo_lc:
+            params['origin'] = np.array(header['LightConeOrigins']).reshape(-1, 3)[0]
+        else:
+            params['origin'] = None
+        n_chunks = self.n_chunks
+        params['chunk'] = self.chunk
+        chunk = 0 if self.chunk == -1 else self.chunk
+        n_jump = int(np.ceil(len(halo_info_fns) / n_chunks))
+        start = chunk * n_jump
+        end = min((chunk + 1) * n_jump, len(halo_info_fns))
+        params['numslabs'] = end - start
+        self.lbox = header['BoxSize']
+
+        def fnames(eslab):
+            if ('ELG' not in self.tracers) and ('QSO' not in self.tracers) and (not self.force_mt):
+                h = subsample_dir / ('halos_xcom_%d_seed600_abacushod_oldfenv' % eslab)
+                p = subsample_dir / ('particles_xcom_%d_seed600_abacushod_oldfenv' % eslab)
+            else:
+                h = subsample_dir / ('halos_xcom_%d_seed600_abacushod_oldfenv_MT' % eslab)
+                p = subsample_dir / ('particles_xcom_%d_seed600_abacushod_oldfenv_MT' % eslab)
+            if self.want_ranks:
+                p = str(p) + '_withranks'
+            return str(h) + '_new.h5', str(p) + '_new.h5'
+
+        with_parts = self.z_type in ('primary', 'lightcone')
+        H, P = [], []
+        for eslab in range(start, end):
+            self.logger.info(f'Loading simulation slab {eslab}')
+            hfn, pfn = fnames(eslab)
+            with h5py.File(hfn, 'r') as f:
+                H.append(f['halos'][:])
+            if with_parts:
+                with h5py.File(pfn, 'r') as f:
+                    P.append(f['particles'][:])
+        Hc = np.concatenate(H)
+        f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        hpos, hvel = f8(Hc['x_L2com']), f8(Hc['v_L2com'])
+        hmass = f8(Hc['N'] * params['Mpart'])
+        hid = Hc['id'].astype(int)
+        hmultis, hrandoms = f8(Hc['multi_halos']), f8(Hc['randoms'])
+        vdev = Hc['randoms_exp'] if self.want_expvel else Hc['randoms_gaus_vrms']
+        if vdev.ndim == 1:
+            self.logger.warning('Warning: galaxy x, y velocity bias randoms not set, using z randoms instead. '
+                                'x, y velocities may be unreliable.')
+            vdev = np.concatenate((vdev, vdev, vdev)).reshape(-1, 3)
+        hveldev = f8(vdev)
+        hsigma3d = f8(Hc['sigmav3d_L2com'])
+        hc = f8(Hc['r98_L2com'] / Hc['r25_L2com'])
+        hrvir = f8(Hc['r98_L2com'])
+        hdeltac = f8(Hc['deltac_rank']) if self.want_AB else None
+        hfenv = f8(Hc['fenv_rank']) if self.want_AB else None
+        hshear = f8(Hc['shear_rank']) if self.want_shear else None
+
+        particle_data = {}
+        if with_parts:
+            Pc = np.concatenate(P)
+            fields = Pc.dtype.fields.keys()
+            ppos, pvel, phvel = f8(Pc['pos']), f8(Pc['vel']), f8(Pc['halo_vel'])
+            phmass = f8(Pc['halo_mass'])
+            phid = Pc['halo_id'].astype(int)
+            pNp, psub, prandoms = f8(Pc['Np']), f8(Pc['downsample_halo']), f8(Pc['randoms'])
+            pdeltac = f8(Pc['halo_deltac']) if self.want_AB else None
+            pfenv = f8(Pc['halo_fenv']) if self.want_AB else None
+            pshear = f8(Pc['halo_shear']) if self.want_shear else None
+            ranks = {}
+            if self.want_ranks:
+                assert 'ranks' in fields and 'ranksv' in fields
+                for src, dst in (('ranks', 'pranks'), ('ranksv', 'pranksv'), ('ranksp', 'pranksp'),
+                                 ('ranksr', 'pranksr'), ('ranksc', 'pranksc')):
+                    ranks[dst] = f8(Pc[src]) if src in fields else np.zeros(len(Pc))
+        # sort halos by id, important for conformity (:566-585)
+        if not np.all(hid[:-1] <= hid[1:]):
+            self.logger.info('Sorting halos for conformity calculation.')
+            s = np.argsort(hid)
+            hpos, hvel, hmass, hid, hmultis, hrandoms, hveldev, hsigma3d, hc, hrvir = (
+                a[s] for a in (hpos, hvel, hmass, hid, hmultis, hrandoms, hveldev, hsigma3d, hc, hrvir))
+            if self.want_AB:
+                hdeltac, hfenv = hdeltac[s], hfenv[s]
+            if self.want_shear:
+                hshear = hshear[s]
+        assert np.all(hid[:-1] <= hid[1:])
+        if with_parts:
+            pweights = 1 / pNp / psub
+            pinds = _searchsorted(hid, phid)
+
+        # global environment ranking from the env sidecars (:595-657)
+        if self.want_AB and (not self.halo_lc):
+            mcut_env = self.local_env.get('mcut', 1e11)
+            nbins_env = self.local_env.get('nbins', 100)
+            ids, masses, menvs = [], [], []
+            for eslab in range(len(halo_info_fns)):
+                envfilename = subsample_dir / f'env_xcom_{eslab}_abacushod_localenv_new.h5'
+                if not envfilename.exists():
+                    raise FileNotFoundError(f'Missing env sidecar: {envfilename}')
+                with h5py.File(envfilename, 'r') as fenv:
+                    ids.append(fenv['id'][:].astype(np.int64))
+                    masses.append(fenv['mass'][:])
+                    menvs.append(fenv['Menv'][:])
+            env_id, env_mass, env_Menv = np.concatenate(ids), np.concatenate(masses), np.concatenate(menvs)
+            mbins_env = np.logspace(np.log10(mcut_env), 15.5, nbins_env + 1)
+            hfenv_full = calc_fenv_opt(env_Menv, mbins_env, env_mass)
+            env_sort = np.argsort(env_id)
+            env_id, hfenv_full = env_id[env_sort], hfenv_full[env_sort]
+            hmatch = _searchsorted(env_id, hid)
+            if not np.all(env_id[hmatch] == hid):
+                raise RuntimeError('Failed to map global env sidecars onto staged halos by halo ID.')
+            hfenv = hfenv_full[hmatch]
+            if with_parts:
+                if not np.all(hid[pinds] == phid):
+                    raise RuntimeError('Particle-to-halo mapping pinds is inconsistent with phid.')
+                pfenv = hfenv[pinds]
+
+        halo_data = {'hpos': hpos, 'hvel': hvel, 'hmass': hmass, 'hid': hid, 'hmultis': hmultis,
+                     'hrandoms': hrandoms, 'hveldev': hveldev, 'hsigma3d': hsigma3d, 'hc': hc, 'hrvir': hrvir}
+        if with_parts:
+            particle_data = {'ppos': ppos, 'pvel': pvel, 'phvel': phvel, 'phmass': phmass, 'phid': phid,
+                             'pweights': pweights, 'prandoms': prandoms, 'pinds': pinds}
+            npart = len(phmass)
+            if self.want_ranks:
+                particle_data.update(ranks)
+            else:
+                for k in ('pranks', 'pranksv', 'pranksp', 'pranksr', 'pranksc'):
+                    particle_data[k] = np.ones(npart)
+        if self.want_AB:
+            halo_data['hdeltac'], halo_data['hfenv'] = hdeltac, hfenv
+            if with_parts:
+                particle_data['pdeltac'], particle_data['pfenv'] = pdeltac, pfenv
+        if self.want_shear:
+            halo_data['hshear'] = hshear
+            if with_parts:
+                particle_data['pshear'] = pshear
+        return halo_data, particle_data, params, mock_dir
+
+    # ------------------------------------------------------------------------------------------------------
+    def restage(self):
+        """Drop the device copy of the subsample (call after modifying halo_data / particle_data in place)."""
+        if self._staged is not None:
+            self._staged.free()
+            self._staged = None
+
+    def _device_catalog(self):
+        if self._staged is None:
+            self._staged = StagedCatalog(self.halo_data, self.particle_data)
+        return self._staged
+
+    def run_hod(self, tracers=None, want_rsd=True, want_nfw=False, NFW_draw=None, reseed=None, write_to_disk=False,
+                Nthread=16, verbose=False, fn_ext=None):
+        """Runs a custom HOD; returns `mock_dict` {tracer: {'x','y','z','vx','vy','vz','mass','id','Ncent'}}
+        with centrals first (hod/abacus_hod.py:706-859)."""
+        if tracers is None:
+            tracers = self.tracers
+        if self.z_type == 'secondary' and not want_nfw:
+            raise RuntimeError('Secondary redshifts do not have particle pos/vel outputs and so only NFW profiles '
+                               'are supported')
+        if reseed:
+            start = time.time()
+            # The reference draws float32 streams from parallel_numpy_rng.MTGenerator(PCG64(reseed)) (:778-823), a
+            # third-party generator that is not available here: same distributions, same dtypes, NumPy's own PCG64
+            # streams (parity with the reference's stream is unpinned; it only smoke-tests this path).
+            rng = np.random.Generator(np.random.PCG64(reseed))
+            nh = len(self.halo_data['hrandoms'])
+            r1 = rng.random(size=nh, dtype=np.float32)
+            if self.want_expvel:
+                rt = np.vstack([rng.random(size=nh, dtype=np.float32) for _ in range(3)]).T
+                r2 = np.zeros((len(rt), 3), dtype=np.float32)
+                r2[rt >= 0.5] = -np.log(2 * (1 - rt[rt >= 0.5]))
+                r2[rt < 0.5] = np.log(2 * rt[rt < 0.5])
+            else:
+                r20, r21, r22 = (rng.standard_normal(size=nh, dtype=np.float32) for _ in range(3))
+                r2 = np.vstack((r20, r21, r22)).T
+            r3 = rng.random(size=len(self.particle_data['prandoms']), dtype=np.float32)
+            self.halo_data['hrandoms'] = r1
+            self.halo_data['hveldev'] = (r2 * np.repeat(self.halo_data['hsigma3d'], 3).reshape((-1, 3)) / np.sqrt(3))
+            self.particle_data['prandoms'] = r3
+            if self._staged is not None:
+                self._staged.update('hrandoms', r1)
+                self._staged.update('hveldev', self.halo_data['hveldev'])
+                self._staged.update('prandoms', r3)
+            self.logger.info(f'Randoms generated in elapsed time {time.time() - start:.2f} s.')
+
+        start = time.time()
+        mock_dict = gen_gal_cat(self.halo_data, self.particle_data, tracers, self.params, Nthread,
+                                enable_ranks=self.want_ranks, rsd=want_rsd, nfw=want_nfw, NFW_draw=NFW_draw,
+                                write_to_disk=write_to_disk, savedir=self.mock_dir, verbose=verbose, fn_ext=fn_ext,
+                                staged=self._device_catalog() if not want_nfw else None)
+        self.logger.info(f'HOD generated in elapsed time {time.time() - start:.2f} s.')
+        return mock_dict
+
+    # ------------------------------------------------------------------------------------------------------
+    def compute_ngal(self, tracers=None, Nthread=16):
+        """Expected number of each tracer and its satellite fraction from the weighted halo histogram
+        (hod/abacus_hod.py:861-1179).  Host-side NumPy evaluation of the reference's triple/quadruple sums."""
+        if tracers is None:
+            tracers = self.tracers
+        ngal_dict, fsat_dict = {}, {}
+        erfc = np.vectorize(math.erfc)
+        erf = np.vectorize(math.erf)
+        logMs = 0.5 * (self.logMbins[1:] + self.logMbins[:-1])
+        deltacs = 0.5 * (self.deltacbins[1:] + self.deltacbins[:-1])
+        fenvs = 0.5 * (self.fenvbins[1:] + self.fenvbins[:-1])
+        shears = 0.5 * (self.shearbins[1:] + self.shearbins[:-1])
+        for etracer, hod in tracers.items():
+            Delta_a = 1.0 / (1 + self.z_mock) - 1.0 / (1 + hod.get('z_pivot', self.z_mock))
+            logM_cut = hod['logM_cut'] + hod.get('logM_cut_pr', 0) * Delta_a
+            logM1 = hod['logM1'] + hod.get('logM1_pr', 0) * Delta_a
+            Ac, As, Bc, Bs = (hod.get(k, 0) for k in ('Acent', 'Asat', 'Bcent', 'Bsat'))
+            ic = hod.get('ic', 1)
+            Mh = (10 ** logMs)[:, None, None]
+            lc = logM_cut + Ac * deltacs[None, :, None] + Bc * fenvs[None, None, :]
+            M1 = 10 ** (logM1 + As * deltacs[None, :, None] + Bs * fenvs[None, None, :])
+            if etracer == 'LRG':
+                ncent = 0.5 * erfc((lc - np.log10(Mh)) / (1.41421356 * hod['sigma']))
+                base = Mh - hod['kappa'] * 10**lc
+                nsat = np.where(base < 0, 0.0, (np.maximum(base, 0) / M1) ** hod['alpha'] * ncent)
+                ngal_cent = np.sum(self.halo_mass_func * ncent * ic)
+                ngal_sat = np.sum(self.halo_mass_func * nsat * ic)
+            elif etracer == 'QSO':
+                ncent = 0.5 * (1 + erf((np.log10(Mh) - lc) / 1.41421356 / hod['sigma']))
+                base = Mh - hod['kappa'] * 10**lc
+                nsat = np.where(base < 0, 0.0, (np.maximum(base, 0) / M1) ** hod['alpha'])
+                ngal_cent = np.sum(self.halo_mass_func * ncent * ic)
+                ngal_sat = np.sum(self.halo_mass_func * nsat * ic)
+            elif etracer == 'ELG':
+                Cc, Cs = hod.get('Ccent', 0), hod.get('Csat', 0)
+                A_s = hod.get('A_s', 1)
+                logM1_EE, alpha_EE = hod.get('logM1_EE', hod['logM1']), hod.get('alpha_EE', hod['alpha'])
+                ngal_cent = ngal_sat = 0.0
+                hmf = self.halo_mass_func_wshear
+                logMh = np.log10(Mh)
+                for el, sh in enumerate(shears):  # one shear slice at a time keeps the temporaries at 100^3
+                    lce = lc + Cc * sh
+                    M1e = 10 ** (logM1 + As * deltacs[None, :, None] + Bs * fenvs[None, None, :] + Cs * sh)
+                    phi = 0.3989422804014327 / hod['sigma'] * np.exp(-((logMh - lce) ** 2) / 2 / hod['sigma'] ** 2)
+                    Phi = 0.5 * (1 + erf(hod['gamma'] * (logMh - lce) / hod['sigma'] / np.sqrt(2)))
+                    ncent = 2.0 * (hod['p_max'] - 1.0 / hod['Q']) * phi * Phi * ic
+                    base = Mh - hod['kappa'] * 10**lce
+                    nsat = np.where(base < 0, 0.0, A_s * (np.maximum(base, 0) / M1e) ** hod['alpha']) * ic
+                    M1c = 10 ** (logM1_EE + As * deltacs[None, :, None] + Bs * fenvs[None, None, :] + Cs * sh)
+                    nconf = np.where(base < 0, 0.0, A_s * (np.maximum(base, 0) / M1c) ** alpha_EE) * ic
+                    w = hmf[:, :, :, el]
+                    ngal_cent += np.sum(w * ncent)
+                    ngal_sat += np.sum(w * (nsat * (1 - ncent) + nconf * ncent))
+            else:
+                continue
+            ngal_dict[etracer] = ngal_cent + ngal_sat
+            fsat_dict[etracer] = ngal_sat / (ngal_cent + ngal_sat)
+        return ngal_dict, fsat_dict
+
+    # ------------------------------------------------------------------------------------------------------
+    def compute_clustering(self, mock_dict, *args, **kwargs):
+        """(:1181-1219)"""
+        if self.clustering_type == 'xirppi':
+            return self.compute_xirppi(mock_dict, *args, **kwargs)
+        elif self.clustering_type == 'wp':
+            return self.compute_wp(mock_dict, *args, **kwargs)
+        elif self.clustering_type == 'multipole':
+            return self.compute_multipole(mock_dict, *args, **kwargs)
+        raise ValueError('clustering_type not implemented or not specified, use xirppi, wp, multipole')
+
+    def _pairs(self, mock_dict, fn):
+        clustering = {}
+        for i1, tr1 in enumerate(mock_dict.keys()):
+            x1, y1, z1 = mock_dict[tr1]['x'], mock_dict[tr1]['y'], mock_dict[tr1]['z']
+            for i2, tr2 in enumerate(mock_dict.keys()):
+                if i1 > i2:
+                    continue  # cross-correlations are symmetric
+                if i1 == i2:
+                    clustering[tr1 + '_' + tr2] = fn(x1, y1, z1, None, None, None)
+                else:
+                    x2, y2, z2 = mock_dict[tr2]['x'], mock_dict[tr2]['y'], mock_dict[tr2]['z']
+                    clustering[tr1 + '_' + tr2] = fn(x1, y1, z1, x2, y2, z2)
+                    clustering[tr2 + '_' + tr1] = clustering[tr1 + '_' + tr2]
+        return clustering
+
+    def compute_xirppi(self, mock_dict, rpbins, pimax, pi_bin_size, Nthread=8):
+        """xi(rp, pi) for every tracer pair (:1221-1279)"""
+        return self._pairs(mock_dict, lambda x1, y1, z1, x2, y2, z2: calc_xirppi_fast(
+            x1, y1, z1, rpbins, pimax, pi_bin_size, self.lbox, Nthread, x2=x2, y2=y2, z2=z2))
+
+    def compute_wp(self, mock_dict, rpbins, pimax, pi_bin_size, Nthread=8):
+        """wp(rp) for every tracer pair (:1826-1885)"""
+        return self._pairs(mock_dict, lambda x1, y1, z1, x2, y2, z2: calc_wp_fast(
+            x1, y1, z1, rpbins, pimax, self.lbox, Nthread, x2=x2, y2=y2, z2=z2))
+
+    def compute_multipole(self, mock_dict, rpbins, pimax, sbins, nbins_mu, orders=[0, 2], Nthread=8):
+        """wp concatenated with xi_l(s) (:1281-1336; like the reference, cross pairs use `rpbins` as s bins, :1313)"""
+        def fn(x1, y1, z1, x2, y2, z2):
+            sb = sbins if x2 is None else rpbins
+            new_multi = calc_multipole_fast(x1, y1, z1, sb, self.lbox, Nthread, nbins_mu=nbins_mu, orders=orders,
+                                            x2=x2, y2=y2, z2=z2)
+            new_wp = calc_wp_fast(x1, y1, z1, rpbins, pimax, self.lbox, Nthread, x2=x2, y2=y2, z2=z2)
+            return np.concatenate((new_wp, new_multi))
+        return self._pairs(mock_dict, fn)
+
+    def compute_power(self, mock_dict, nbins_k, nbins_mu, k_hMpc_max, logk, poles=[], paste='TSC', num_cells=550,
+                      compensated=False, interlaced=False):
+        r"""P(k, mu) and/or P_l(k) for every tracer pair (:1338-1472).  Returned keys: '{a}_{b}', '..._modes',
+        '..._ell', '..._ell_modes', 'k_binc', 'mu_binc'."""
+        Lbox = self.lbox
+        clustering = {}
+        for i1, tr1 in enumerate(mock_dict.keys()):
+            pos1 = np.stack((mock_dict[tr1]['x'], mock_dict[tr1]['y'], mock_dict[tr1]['z']), axis=1)
+            w1 = mock_dict[tr1].get('w', None)
+            for i2, tr2 in enumerate(mock_dict.keys()):
+                if i1 > i2:
+                    continue
+                if i1 == i2:
+                    power = calc_power(pos1, Lbox, nbins_k, nbins_mu, k_hMpc_max, logk, paste, num_cells, compensated,
+                                       interlaced, w=w1, poles=poles)
+                else:
+                    pos2 = np.stack((mock_dict[tr2]['x'], mock_dict[tr2]['y'], mock_dict[tr2]['z']), axis=1)
+                    w2 = mock_dict[tr2].get('w', None)
+                    power = calc_power(pos1, Lbox, nbins_k, nbins_mu, k_hMpc_max, logk, paste, num_cells, compensated,
+                                       interlaced, w=w1, pos2=pos2, w2=w2, poles=poles)
+                key = tr1 + '_' + tr2
+                clustering[key] = power['power']
+                clustering[key + '_modes'] = power['N_mode']
+                clustering[key + '_ell'] = power['poles']  # KeyError with poles=[] exactly like the reference (:1431)
+                clustering[key + '_ell_modes'] = power['N_mode_poles']
+                if i1 != i2:
+                    rkey = tr2 + '_' + tr1
+                    for suffix in ('', '_modes', '_ell', '_ell_modes'):
+                        clustering[rkey + suffix] = clustering[key + suffix]
+        clustering['k_binc'] = power['k_mid']
+        clustering['mu_binc'] = power['mu_mid'][0]
+        return clustering
+
+    def apply_zcv(self, *a, **k):
+        raise NotImplementedError('Zel\'dovich control variates (hod/zcv) are outside the MI355X hot-path scope')
+
+    apply_zcv_xi = apply_zcv
+
+    def gal_reader(self, output_dir=None, simname=None, sim_dir=None, z_mock=None, want_rsd=None, tracers=None):
+        """Load `{tracer}s.dat` ECSV catalogs written by run_hod(write_to_disk=True) (:1887-1950)."""
+        if want_rsd is None:
+            want_rsd = self.want_rsd
+        if tracers is None:
+            tracers = self.tracers.keys()
+        outdir = Path(self.mock_dir) / ('galaxies' + ('_rsd' if want_rsd else ''))
+        mockdict = {}
+        for tracer in tracers:
+            header, rows, meta = None, [], {}
+            for line in open(outdir / (tracer + 's.dat')):
+                if line.startswith('#'):
+                    if 'Ncent:' in line:
+                        meta['Ncent'] = int(line.split('Ncent:')[1].strip(' }\n'))
+                    continue
+                if header is None:
+                    header = line.split()
+                    continue
+                rows.append(line.split())
+            cols = {}
+            for j, name in enumerate(header):
+                conv = int if name == 'id' else float
+                cols[name] = np.array([conv(r[j]) for r in rows], dtype=np.int64 if name == 'id' else np.float64)
+            cols.update(meta)
+            mockdict[tracer] = cols
+        return mockdict

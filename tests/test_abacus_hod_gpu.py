@@ -1,0 +1,100 @@
+"""AbacusHOD class on the MI355X path: the reference's own mini-box fixture through run_hod (C1 plumbing config),
+the MCMC call pattern of scripts/hod/run_hod.py:40-73, compute_power / compute_xirppi / compute_wp / compute_ngal.
+Needs an MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+from conftest import assert_mock_equal, load_golden, unpack_inputs, unpack_mock
+
+from abacusutils_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+HOD_PARAMS = dict(tracer_flags={'LRG': True, 'ELG': True, 'QSO': False}, want_ranks=False, want_AB=True,
+                  want_shear=False, want_rsd=True, LRG_params=synth.LRG_PARAMS, ELG_params=synth.ELG_PARAMS,
+                  QSO_params=synth.QSO_PARAMS)
+CLUSTERING = dict(clustering_type='xirppi', pimax=30, pi_bin_size=5,
+                  bin_params=dict(logmin=-0.7728787904780005, logmax=1.4771212597864314, nbins=9))
+
+
+def _ball(name='hod_mini', tmp_path='./'):
+    from abacusutils_amd.hod.abacus_hod import AbacusHOD
+    g = load_golden(name)
+    hd, pd, params = unpack_inputs(g)
+    return AbacusHOD.from_arrays(hd, pd, params, HOD_PARAMS, CLUSTERING, mock_dir=tmp_path), g
+
+
+def test_run_hod_reference_fixture(tmp_path):
+    """tests/test_hod.py:102-134 of the reference: write_to_disk run, catalogs equal to galaxies_rsd/*.dat"""
+    ball, g = _ball('hod_mini', tmp_path)
+    assert ball.want_rsd and set(ball.tracers) == {'LRG', 'ELG'} and ball.rpbins.shape == (10,)
+    mock = ball.run_hod(ball.tracers, ball.want_rsd, write_to_disk=False, Nthread=4)
+    assert_mock_equal(mock, unpack_mock(g, 'shim'), exact=True)
+    ball.run_hod(ball.tracers, ball.want_rsd, write_to_disk=True, Nthread=4)
+    back = ball.gal_reader()
+    for tr in ('LRG', 'ELG'):
+        np.testing.assert_array_equal(back[tr]['id'], g[f'expect.{tr}.id'])
+        np.testing.assert_array_equal(back[tr]['x'], g[f'expect.{tr}.x'])
+        assert back[tr]['Ncent'] == int(g[f'expect.{tr}.Ncent'])
+
+
+def test_lightcone_fixture():
+    ball, g = _ball('hod_lc')
+    mock = ball.run_hod()
+    assert_mock_equal(mock, unpack_mock(g, 'shim'), exact=True)
+
+
+def test_mcmc_pattern_and_reseed():
+    """resident catalog, parameters mutated between calls (scripts/hod/run_hod.py:62-73); reseed smoke
+    (tests/test_hod.py:136-143) - the reseeded run is deterministic for a given seed and changes the catalog"""
+    from abacusutils_amd.hod.abacus_hod import AbacusHOD
+    from oracle import oracle
+    hd, pd, params = synth.synth_hod_inputs(200000, 200000, seed=8)
+    ball = AbacusHOD.from_arrays(hd, pd, params, dict(HOD_PARAMS, tracer_flags={'LRG': True, 'ELG': False}))
+    for logM_cut in (12.8, 13.0, 13.3):
+        ball.tracers['LRG'] = dict(ball.tracers['LRG'], logM_cut=logM_cut)
+        mock = ball.run_hod(ball.tracers, want_rsd=True, Nthread=16)
+        want = oracle.gen_gal_cat(ball.halo_data, ball.particle_data, ball.tracers, ball.params, Nthread=4)
+        assert_mock_equal(mock, want, exact=True)
+    a = ball.run_hod(reseed=0xABCDEF)
+    assert ball.halo_data['hrandoms'].dtype == np.float32
+    want = oracle.gen_gal_cat(ball.halo_data, ball.particle_data, ball.tracers, ball.params, Nthread=4)
+    assert_mock_equal(a, want, exact=True)    # device copy of the randoms was refreshed
+    b = ball.run_hod(reseed=0xABCDEF)
+    assert_mock_equal(a, b, exact=True)
+    assert len(a['LRG']['x']) != len(mock['LRG']['x']) or not np.array_equal(a['LRG']['id'], mock['LRG']['id'])
+    with pytest.raises(ValueError):
+        ball.run_hod(want_rsd=1)
+
+
+def test_secondary_redshift_needs_nfw():
+    from abacusutils_amd.hod.abacus_hod import AbacusHOD
+    hd, pd, params = synth.synth_hod_inputs(1000, 1000, seed=8)
+    ball = AbacusHOD.from_arrays(hd, pd, params, HOD_PARAMS, z_type='secondary')
+    with pytest.raises(RuntimeError):
+        ball.run_hod()
+
+
+def test_compute_power_and_clustering():
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from abacusutils_amd.hod.abacus_hod import AbacusHOD
+    hd, pd, params = synth.synth_hod_inputs(300000, 300000, seed=9, lbox=1000.0)
+    hod = dict(HOD_PARAMS, LRG_params=dict(synth.LRG_PARAMS, logM_cut=12.3, logM1=13.3),
+               ELG_params=dict(synth.ELG_PARAMS))
+    ball = AbacusHOD.from_arrays(hd, pd, params, hod, CLUSTERING)
+    mock = ball.run_hod()
+    # positions live in [-L/2, L/2): both estimators must cope (periodic)
+    spec = ball.compute_power(mock, nbins_k=8, nbins_mu=2, k_hMpc_max=0.2, logk=False, poles=[0, 2], num_cells=64)
+    assert set(spec) >= {'LRG_LRG', 'LRG_ELG', 'ELG_LRG', 'ELG_ELG', 'LRG_LRG_ell', 'LRG_ELG_modes', 'k_binc', 'mu_binc'}
+    assert spec['LRG_LRG'].shape == (8, 2) and spec['LRG_ELG_ell'].shape == (8, 2)
+    pos = np.stack((mock['LRG']['x'], mock['LRG']['y'], mock['LRG']['z']), axis=1)
+    tab = calc_power(pos, 1000.0, 8, 2, 0.2, False, 'TSC', 64, False, False, poles=[0, 2])
+    np.testing.assert_allclose(spec['LRG_LRG'], tab['power'], rtol=1e-6)
+    with pytest.raises(KeyError):   # the reference reads power['poles'] unconditionally (abacus_hod.py:1431)
+        ball.compute_power(mock, 8, 2, 0.2, False, poles=[], num_cells=32)
+    xi = ball.compute_clustering(mock, ball.rpbins, ball.pimax, ball.pi_bin_size)
+    assert xi['LRG_LRG'].shape == (9, 6) and np.array_equal(xi['LRG_ELG'], xi['ELG_LRG'])
+    wp = ball.compute_wp(mock, ball.rpbins, ball.pimax, ball.pi_bin_size)
+    assert wp['ELG_ELG'].shape == (9,)
+    ngal, fsat = ball.compute_ngal()
+    n_lrg = len(mock['LRG']['x'])
+    assert abs(ngal['LRG'] / n_lrg - 1) < 0.15 and 0 <= fsat['LRG'] <= 1
