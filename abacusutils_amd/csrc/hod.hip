@@ -5,13 +5,17 @@
 // pos/vel, int64 ids) and stay resident across populate calls (the MCMC use case of staging()).
 //
 // Kernels (all HBM-bound streaming, no MFMA - there is no contraction on this path):
-//   hod_decide_cent / hod_decide_sat   one pass over the per-halo / per-particle scalars (16-B coalesced loads,
-//        FP64 occupation math), writes the int8 keep mask and per-tile tracer counts (wave ballots).
+//   hod_filter_cent / hod_filter_sat   one pass over the per-halo / per-particle scalars (16-B coalesced loads):
+//        a float32 upper bound of the marker chain proves keep = 0 for the bulk of the objects; the rest is queued.
 //        Tiles of 2048 objects -> thousands of workgroups for the 256 CUs.
-//   hod_scan_tiles                     exclusive scan of the tile counts -> per-tile output offsets; satellites
-//        start at Ncent so centrals||satellites land concatenated (no fast_concatenate pass).
-//   hod_emit                           re-reads the 1-byte mask in blocked order, block-scans per-thread counts
-//        and writes the galaxies in input order (stable compaction = the reference's order for any Nthread).
+//   hod_exact_cent / hod_exact_sat     exact FP64 occupation math (erfc, log10, pow) for the queued objects only;
+//        writes their int8 keep bytes and bumps per-tile and per-"superblock" (32 tiles) tracer counters, so no
+//        separate scan launch is needed.
+//   hod_emit                           8192 objects per workgroup: sums the superblock / tile counters in front of
+//        it (a few hundred L2-resident ints) for its output offset - satellites start at Ncent, so
+//        centrals||satellites land concatenated (no fast_concatenate pass) - re-reads the 1-byte mask in blocked
+//        order, block-scans per-thread counts and writes the galaxies in input order (stable compaction = the
+//        reference's order for any Nthread).
 // All FP64 arithmetic that reaches an OUTPUT (velocity bias, RSD) is + - * / sqrt in the reference's order,
 // compiled with -ffp-contract=off, so outputs are bit-identical to the CPU; the keep decision compares
 // randoms against erfc/log10/pow-based markers whose last-ulp differences (ocml vs libm) only matter for a
@@ -29,20 +33,23 @@ namespace {
 constexpr int TILE = 2048;    // objects per workgroup
 constexpr int BLOCK = 256;    // threads per workgroup (4 waves)
 constexpr int PER_THREAD = TILE / BLOCK;
+constexpr int SB_TILES = 32;                       // decide tiles per superblock counter
 
 // ---- occupation functions (hod/GRAND_HOD.py:23-136) ------------------------------------------------------
 __device__ __forceinline__ double n_cen_LRG(double M_h, double logM_cut, double sigma) {
     return 0.5 * erfc((logM_cut - log10(M_h)) / (1.41421356 * sigma));
 }
+// x**alpha; x**1.0 is x exactly (also what libm and ocml return), and alpha = 1 is the usual HOD choice
+__device__ __forceinline__ double powa(double x, double alpha) { return alpha == 1.0 ? x : pow(x, alpha); }
 __device__ __forceinline__ double n_sat_LRG_modified(double M_h, double logM_cut, double M_cut, double M_1,
                                                      double sigma, double alpha, double kappa) {
     if (M_h - kappa * M_cut < 0) return 0;
-    return pow((M_h - kappa * M_cut) / M_1, alpha) * 0.5 * erfc((logM_cut - log10(M_h)) / (1.41421356 * sigma));
+    return powa((M_h - kappa * M_cut) / M_1, alpha) * 0.5 * erfc((logM_cut - log10(M_h)) / (1.41421356 * sigma));
 }
 __device__ __forceinline__ double N_sat_generic(double M_h, double M_cut, double kappa, double M_1, double alpha,
                                                 double A_s) {
     if (M_h - kappa * M_cut < 0) return 0;
-    return A_s * pow((M_h - kappa * M_cut) / M_1, alpha);
+    return A_s * powa((M_h - kappa * M_cut) / M_1, alpha);
 }
 __device__ __forceinline__ double N_cen_ELG_v1(double M_h, double p_max, double Q, double logM_cut, double sigma,
                                                double gamma) {
@@ -91,16 +98,24 @@ __device__ __forceinline__ int8_t cent_decide(const abacus_hod_params &p, double
     return pick(randoms, LRG_marker, ELG_marker, QSO_marker);
 }
 
+// 10**x of values that do not depend on the particle (all assembly-bias coefficients of a tracer zero:
+// `logM1 + 0*d + 0*f == logM1` exactly), evaluated once on the host with libm's pow
+struct SatPre {
+    int L_const, E_const, Q_const;
+    int pad;
+    double L_M1, L_Mcut, E_M1, E_Mcut, E_M1_EL, E_M1_EE, Q_M1, Q_Mcut;
+};
+
 // marker chain of gen_sats pass 1 (hod/GRAND_HOD.py:957-1088)
-__device__ __forceinline__ int8_t sat_decide(const abacus_hod_params &p, double hmass, double weights,
-                                             double randoms, double d, double f, double sh, double r, double rv,
-                                             double rp, double rr, int8_t keep_cent) {
+__device__ __forceinline__ int8_t sat_decide(const abacus_hod_params &p, const SatPre &pre, double hmass,
+                                             double weights, double randoms, double d, double f, double sh, double r,
+                                             double rv, double rp, double rr, int8_t keep_cent) {
     double LRG_marker = 0;
     if (p.want_LRG) {
-        double M1 = pow(10.0, p.L_logM1 + p.L_Asat * d + p.L_Bsat * f);
         double lc = p.L_logM_cut + p.L_Acent * d + p.L_Bcent * f;
-        double base =
-            n_sat_LRG_modified(hmass, lc, pow(10.0, lc), M1, p.L_sigma, p.L_alpha, p.L_kappa) * weights * p.L_ic;
+        double M1 = pre.L_const ? pre.L_M1 : pow(10.0, p.L_logM1 + p.L_Asat * d + p.L_Bsat * f);
+        double Mcut = pre.L_const ? pre.L_Mcut : pow(10.0, lc);
+        double base = n_sat_LRG_modified(hmass, lc, Mcut, M1, p.L_sigma, p.L_alpha, p.L_kappa) * weights * p.L_ic;
         double exp_sat = base;
         if (p.enable_ranks) {
             double dec = 1 + p.L_s * r + p.L_s_v * rv + p.L_s_p * rp + p.L_s_r * rr;
@@ -110,17 +125,19 @@ __device__ __forceinline__ int8_t sat_decide(const abacus_hod_params &p, double 
     }
     double ELG_marker = LRG_marker;
     if (p.want_ELG) {
-        double M1 = pow(10.0, p.E_logM1 + p.E_Asat * d + p.E_Bsat * f + p.E_Csat * sh);
         double lc = p.E_logM_cut + p.E_Acent * d + p.E_Bcent * f + p.E_Ccent * sh;
-        double alpha = p.E_alpha;
+        double alpha = p.E_alpha, M1;
         if (keep_cent == 1) {  // ELG conformity (:1006-1035); these branches carry no Csat term
-            M1 = pow(10.0, p.E_logM1_EL + p.E_Asat * d + p.E_Bsat * f);
+            M1 = pre.E_const ? pre.E_M1_EL : pow(10.0, p.E_logM1_EL + p.E_Asat * d + p.E_Bsat * f);
             alpha = p.E_alpha_EL;
         } else if (keep_cent == 2) {
-            M1 = pow(10.0, p.E_logM1_EE + p.E_Asat * d + p.E_Bsat * f);
+            M1 = pre.E_const ? pre.E_M1_EE : pow(10.0, p.E_logM1_EE + p.E_Asat * d + p.E_Bsat * f);
             alpha = p.E_alpha_EE;
+        } else {
+            M1 = pre.E_const ? pre.E_M1 : pow(10.0, p.E_logM1 + p.E_Asat * d + p.E_Bsat * f + p.E_Csat * sh);
         }
-        double base = N_sat_generic(hmass, pow(10.0, lc), p.E_kappa, M1, alpha, p.E_A_s) * weights * p.E_ic;
+        double Mcut = pre.E_const ? pre.E_Mcut : pow(10.0, lc);
+        double base = N_sat_generic(hmass, Mcut, p.E_kappa, M1, alpha, p.E_A_s) * weights * p.E_ic;
         if (p.enable_ranks) {
             double dec = 1 + p.E_s * r + p.E_s_v * rv + p.E_s_p * rp + p.E_s_r * rr;
             base = base * dec;
@@ -129,9 +146,10 @@ __device__ __forceinline__ int8_t sat_decide(const abacus_hod_params &p, double 
     }
     double QSO_marker = ELG_marker;
     if (p.want_QSO) {
-        double M1 = pow(10.0, p.Q_logM1 + p.Q_Asat * d + p.Q_Bsat * f);
         double lc = p.Q_logM_cut + p.Q_Acent * d + p.Q_Bcent * f;
-        double base = N_sat_generic(hmass, pow(10.0, lc), p.Q_kappa, M1, p.Q_alpha, 1.0) * weights * p.Q_ic;
+        double M1 = pre.Q_const ? pre.Q_M1 : pow(10.0, p.Q_logM1 + p.Q_Asat * d + p.Q_Bsat * f);
+        double Mcut = pre.Q_const ? pre.Q_Mcut : pow(10.0, lc);
+        double base = N_sat_generic(hmass, Mcut, p.Q_kappa, M1, p.Q_alpha, 1.0) * weights * p.Q_ic;
         double exp_sat = base;
         if (p.enable_ranks) {
             double dec = 1 + p.Q_s * r + p.Q_s_v * rv + p.Q_s_p * rp + p.Q_s_r * rr;
@@ -155,161 +173,336 @@ __device__ __forceinline__ void load2(const double *a, int64_t i, int64_t n, dou
         v1 = fill;
     }
 }
+__device__ __forceinline__ double load1(const double *a, int64_t i, double fill) { return a ? a[i] : fill; }
 
-// per-tile tracer counts from the 64-lane ballots of each wave
-__device__ __forceinline__ void tile_count(int8_t k0, int8_t k1, int *lds_counts) {
-#pragma unroll
-    for (int t = 1; t <= 3; t++) {
-        unsigned long long b0 = __ballot(k0 == t), b1 = __ballot(k1 == t);
-        if ((threadIdx.x & 63) == 0) {
-            int c = __popcll(b0) + __popcll(b1);
-            if (c) atomicAdd(&lds_counts[t - 1], c);
+// ---- float32 rejection filter ----------------------------------------------------------------------------
+// Most objects host no galaxy: their random exceeds the last marker by orders of magnitude.  A float32 UPPER BOUND
+// U >= (largest marker of the chain) is ~10x cheaper than the FP64 erfc/log10/pow chain; `random > U` proves keep = 0
+// without changing any decision.  Everything else (including every accepted object) goes through the exact FP64
+// path.  The bounds carry explicit slack for float32 rounding (1e-6 per operand), for the ocml float functions
+// (1e-4 relative) and for the propagated argument error of erfc; `filter` is switched off by the host for parameter
+// sets the bounds do not cover (negative ic / A_s / kappa-free cases, non-finite values).
+struct Filt {
+    int cent_ok, sat_ok;
+    float L_lc, L_Ac, L_Bc, L_inv_s, L_ic;                      // centrals + LRG satellites share lc, sigma
+    float E_lc, E_Ac, E_Bc, E_Cc, E_c_phi, E_half_inv_s2, E_ic;  // c_phi = max(2(pmax-1/Q),0) * 0.39894/sigma
+    float Q_lc, Q_Ac, Q_Bc, Q_inv_s, Q_ic;
+    // satellites (only used when the tracer's 10**x values are particle independent, SatPre::*_const)
+    float L_invM1, L_alpha, L_s[4];
+    float E_invM1[3], E_alpha[3], E_As, E_s[4];                  // [default, cent is LRG (EL), cent is ELG (EE)]
+    float Q_invM1, Q_alpha, Q_s[4];
+    double L_kMcut, E_kMcut, Q_kMcut;                            // kappa * M_cut
+};
+
+// upper bound of 0.5*erfc(t_true): t = num*inv_s with |num_true - num| <= dnum; erfc is decreasing
+__device__ __forceinline__ float half_erfc_ub(float num, float dnum, float inv_s) {
+    const float t = num * inv_s;
+    const float tl = t - (dnum * inv_s * 1.001f + fabsf(t) * 2e-6f);
+    // erfc(t) <= exp(-t^2) for t >= 0 and <= 2 always; hardware exp (v_exp_f32, 1 ulp) with slack
+    if (tl <= 0.f) return 1.0f;
+    if (tl >= 9.0f) return 4e-36f;   // 0.5*exp(-81) = 3.3e-36
+    return 0.5f * __expf(-(tl * tl) * 0.9999f) * 1.0002f;
+}
+
+__device__ __forceinline__ bool cent_reject(const abacus_hod_params &p, const Filt &F, double mass, double multis,
+                                            double randoms, double deltac, double fenv, double shear) {
+    if (!(multis >= 0.0)) return false;
+    const float lM = __log10f((float)mass);   // v_log_f32 (1 ulp); its error is inside `dn` below
+    const float mu = (float)multis * 1.00001f;
+    const float d = (float)deltac, f = (float)fenv, sh = (float)shear;
+    float U = 0.f;
+    if (p.want_LRG) {
+        const float a1 = F.L_Ac * d, a2 = F.L_Bc * f;
+        const float lc = F.L_lc + a1 + a2;
+        const float dn = 1e-6f * (fabsf(F.L_lc) + fabsf(a1) + fabsf(a2) + fabsf(lM) + 4.f);
+        U += half_erfc_ub(lc - lM, dn, F.L_inv_s) * F.L_ic * mu;
+    }
+    if (p.want_ELG) {
+        const float a1 = F.E_Ac * d, a2 = F.E_Bc * f, a3 = F.E_Cc * sh;
+        const float lc = F.E_lc + a1 + a2 + a3;
+        const float dn = 1e-6f * (fabsf(F.E_lc) + fabsf(a1) + fabsf(a2) + fabsf(a3) + fabsf(lM) + 4.f);
+        const float dl = fmaxf(fabsf(lM - lc) - dn, 0.f);            // |logM - logM_cut| is at least this
+        const float phi = F.E_c_phi * __expf(-(dl * dl) * F.E_half_inv_s2 * 0.9999f) * 1.0002f + 1e-37f;
+        U += phi * F.E_ic * mu;                                      // Phi <= 1
+    }
+    if (p.want_QSO) {  // 0.5*(1+erf(u)) = 0.5*erfc(-u)
+        const float a1 = F.Q_Ac * d, a2 = F.Q_Bc * f;
+        const float lc = F.Q_lc + a1 + a2;
+        const float dn = 1e-6f * (fabsf(F.Q_lc) + fabsf(a1) + fabsf(a2) + fabsf(lM) + 4.f);
+        U += half_erfc_ub(lc - lM, dn, F.Q_inv_s) * F.Q_ic * mu;
+    }
+    return randoms > (double)(U * 1.001f);
+}
+
+__device__ __forceinline__ float pow_ub(float x, float alpha) {   // upper bound of x_true**alpha, x within 1e-6
+    if (alpha == 1.0f) return x * 1.00001f;
+    return powf(x, alpha) * (1.0002f + fabsf(alpha) * 4e-6f);
+}
+__device__ __forceinline__ float dec_ub(const float s[4], double r, double rv, double rp, double rr) {
+    return (1.f + fabsf(s[0] * (float)r) + fabsf(s[1] * (float)rv) + fabsf(s[2] * (float)rp) + fabsf(s[3] * (float)rr)) *
+           1.00001f;
+}
+
+__device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Filt &F, double hmass, double weights,
+                                           double randoms, double r, double rv, double rp, double rr,
+                                           int8_t keep_cent) {
+    if (!(weights >= 0.0)) return false;
+    const float w = (float)weights * 1.00001f;
+    float U = 0.f;
+    if (p.want_LRG) {
+        const double xd = hmass - F.L_kMcut;   // the exact FP64 test of n_sat_LRG_modified (:28)
+        if (!(xd < 0)) {
+            const float lM = __log10f((float)hmass);
+            const float dn = 1e-6f * (fabsf(F.L_lc) + fabsf(lM) + 4.f);
+            float term = pow_ub((float)xd * F.L_invM1, F.L_alpha) * half_erfc_ub(F.L_lc - lM, dn, F.L_inv_s) * w * F.L_ic;
+            if (p.enable_ranks) term *= dec_ub(F.L_s, r, rv, rp, rr);
+            U += term;
         }
+    }
+    if (p.want_ELG) {
+        const double xd = hmass - F.E_kMcut;
+        if (!(xd < 0)) {
+            const int v = keep_cent == 1 ? 1 : (keep_cent == 2 ? 2 : 0);
+            float term = F.E_As * pow_ub((float)xd * F.E_invM1[v], F.E_alpha[v]) * w * F.E_ic;
+            if (p.enable_ranks) term *= dec_ub(F.E_s, r, rv, rp, rr);
+            U += term;
+        }
+    }
+    if (p.want_QSO) {
+        const double xd = hmass - F.Q_kMcut;
+        if (!(xd < 0)) {
+            float term = pow_ub((float)xd * F.Q_invM1, F.Q_alpha) * w * F.Q_ic;
+            if (p.enable_ranks) term *= dec_ub(F.Q_s, r, rv, rp, rr);
+            U += term;
+        }
+    }
+    return randoms > (double)(U * 1.001f);
+}
+
+// Decide = two launches per object kind:
+//   hod_filter_*  streams the per-object scalars (16-B coalesced loads) through the float32 filter, zeroes the int8
+//                 mask, and writes the tile-local indices of the survivors to the tile's slice of a queue;
+//   hod_exact_*   evaluates the exact FP64 marker chain for the queued objects with all lanes busy (typically 1-2 %
+//                 of the objects), writes their mask bytes and the tile / superblock counters.
+// Splitting keeps the streaming kernel light (no FP64 transcendental code, few registers, 8 waves per SIMD).
+constexpr int FBLOCK = 256;
+
+__global__ __launch_bounds__(FBLOCK) void hod_filter_cent(int64_t n, const double *__restrict__ mass,
+                                                          const double *__restrict__ multis,
+                                                          const double *__restrict__ randoms,
+                                                          const double *__restrict__ deltac,
+                                                          const double *__restrict__ fenv,
+                                                          const double *__restrict__ shear, int want_LRG, int want_ELG,
+                                                          int want_QSO, Filt F, int8_t *__restrict__ keep,
+                                                          int *__restrict__ q_count,
+                                                          unsigned short *__restrict__ queue) {
+    __shared__ int nq;
+    __shared__ unsigned short q[TILE];
+    const int tid = threadIdx.x;
+    if (tid == 0) nq = 0;
+    __syncthreads();
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    abacus_hod_params pw;   // only the want_* flags are read by cent_reject
+    pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO;
+    const double *sh_arr = want_ELG ? shear : nullptr;
+#pragma unroll 2
+    for (int k = 0; k < PER_THREAD / 2; k++) {
+        const int loc = k * (2 * FBLOCK) + 2 * tid;
+        const int64_t i = tile0 + loc;
+        if (i < n) {
+            bool need0 = true, need1 = i + 1 < n;
+            if (F.cent_ok) {
+                double m0, m1, mu0, mu1, r0, r1, d0, d1, f0, f1, s0 = 0, s1 = 0;
+                load2(mass, i, n, 1.0, m0, m1);
+                load2(multis, i, n, 0.0, mu0, mu1);
+                load2(randoms, i, n, 2.0, r0, r1);
+                load2(deltac, i, n, 0.0, d0, d1);
+                load2(fenv, i, n, 0.0, f0, f1);
+                if (sh_arr) load2(sh_arr, i, n, 0.0, s0, s1);
+                need0 = !cent_reject(pw, F, m0, mu0, r0, d0, f0, s0);
+                need1 = need1 && !cent_reject(pw, F, m1, mu1, r1, d1, f1, s1);
+            }
+            if (need0) q[atomicAdd(&nq, 1)] = (unsigned short)loc;
+            if (need1) q[atomicAdd(&nq, 1)] = (unsigned short)(loc + 1);
+        }
+    }
+    {   // zero this tile's mask: 8 consecutive bytes per thread
+        const int64_t o = tile0 + (int64_t)tid * 8;
+        if (o + 8 <= n) *reinterpret_cast<unsigned long long *>(keep + o) = 0ull;
+        else
+            for (int q8 = 0; q8 < 8; q8++)
+                if (o + q8 < n) keep[o + q8] = 0;
+    }
+    __syncthreads();
+    // the tile's survivors go to the tile's own slice of the queue: no global atomics anywhere
+    const int cnt = nq;
+    if (tid == 0) q_count[blockIdx.x] = cnt;
+    for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
+}
+
+__global__ __launch_bounds__(FBLOCK) void hod_filter_sat(
+    int64_t n, const double *__restrict__ hmass, const double *__restrict__ weights,
+    const double *__restrict__ randoms, const double *__restrict__ ranks, const double *__restrict__ ranksv,
+    const double *__restrict__ ranksp, const double *__restrict__ ranksr, const int64_t *__restrict__ pinds,
+    const int8_t *__restrict__ keep_cent, int want_LRG, int want_ELG, int want_QSO, int enable_ranks, Filt F,
+    int8_t *__restrict__ keep, int *__restrict__ q_count, unsigned short *__restrict__ queue) {
+    __shared__ int nq;
+    __shared__ unsigned short q[TILE];
+    const int tid = threadIdx.x;
+    if (tid == 0) nq = 0;
+    __syncthreads();
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    abacus_hod_params pw;
+    pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO, pw.enable_ranks = enable_ranks;
+    const bool need_conf = want_ELG && pinds != nullptr;
+#pragma unroll 2
+    for (int k = 0; k < PER_THREAD / 2; k++) {
+        const int loc = k * (2 * FBLOCK) + 2 * tid;
+        const int64_t i = tile0 + loc;
+        if (i < n) {
+            bool need0 = true, need1 = i + 1 < n;
+            if (F.sat_ok) {
+                double m0, m1, w0, w1, r0, r1;
+                double a0 = 1, a1 = 1, b0 = 1, b1 = 1, c0 = 1, c1 = 1, e0 = 1, e1 = 1;
+                int8_t kc0 = 0, kc1 = 0;
+                load2(hmass, i, n, 1.0, m0, m1);
+                load2(weights, i, n, 0.0, w0, w1);
+                load2(randoms, i, n, 2.0, r0, r1);
+                if (enable_ranks) {
+                    load2(ranks, i, n, 1.0, a0, a1);
+                    load2(ranksv, i, n, 1.0, b0, b1);
+                    load2(ranksp, i, n, 1.0, c0, c1);
+                    load2(ranksr, i, n, 1.0, e0, e1);
+                }
+                if (need_conf) {
+                    kc0 = keep_cent[pinds[i]];
+                    if (i + 1 < n) kc1 = keep_cent[pinds[i + 1]];
+                }
+                need0 = !sat_reject(pw, F, m0, w0, r0, a0, b0, c0, e0, kc0);
+                need1 = need1 && !sat_reject(pw, F, m1, w1, r1, a1, b1, c1, e1, kc1);
+            }
+            if (need0) q[atomicAdd(&nq, 1)] = (unsigned short)loc;
+            if (need1) q[atomicAdd(&nq, 1)] = (unsigned short)(loc + 1);
+        }
+    }
+    {   // zero this tile's mask: 8 consecutive bytes per thread
+        const int64_t o = tile0 + (int64_t)tid * 8;
+        if (o + 8 <= n) *reinterpret_cast<unsigned long long *>(keep + o) = 0ull;
+        else
+            for (int q8 = 0; q8 < 8; q8++)
+                if (o + q8 < n) keep[o + q8] = 0;
+    }
+    __syncthreads();
+    // the tile's survivors go to the tile's own slice of the queue: no global atomics anywhere
+    const int cnt = nq;
+    if (tid == 0) q_count[blockIdx.x] = cnt;
+    for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
+}
+
+// Exact kernels: one workgroup per superblock (32 tiles).  The tiles' queue lengths are prefix-summed in LDS so the
+// ~500 survivors of the superblock are processed as one dense list; tile and superblock counters are accumulated
+// in LDS and written with plain stores.
+struct ExactLds {
+    int pre[SB_TILES + 1];
+    int cnt[SB_TILES][4];
+};
+
+__device__ __forceinline__ int exact_setup(ExactLds &L, const int *q_count, int ntile, int &tile_first) {
+    const int tid = threadIdx.x;
+    tile_first = blockIdx.x * SB_TILES;
+    if (tid < SB_TILES) {
+        const int t = tile_first + tid;
+        L.pre[tid + 1] = t < ntile ? q_count[t] : 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) L.cnt[tid][c] = 0;
+    }
+    if (tid == 0) L.pre[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int q = 1; q <= SB_TILES; q++) L.pre[q] += L.pre[q - 1];
+    __syncthreads();
+    return L.pre[SB_TILES];
+}
+__device__ __forceinline__ int exact_find_tile(const ExactLds &L, int j) {   // largest q with pre[q] <= j
+    int lo = 0, hi = SB_TILES - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (L.pre[mid] <= j) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ void exact_finish(ExactLds &L, int ntile, int tile_first, int *tile_counts, int *sb_counts) {
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < SB_TILES * 4) {
+        const int q = tid >> 2, c = tid & 3, t = tile_first + q;
+        if (t < ntile) tile_counts[(int64_t)t * 4 + c] = L.cnt[q][c];
+    }
+    if (tid < 4) {
+        int s = 0;
+        for (int q = 0; q < SB_TILES; q++) s += L.cnt[q][tid];
+        sb_counts[(int64_t)blockIdx.x * 4 + tid] = s;
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void hod_decide_cent(int64_t n, const double *__restrict__ mass,
+__global__ __launch_bounds__(FBLOCK) void hod_exact_cent(const int *__restrict__ q_count,
+                                                         const unsigned short *__restrict__ queue, int ntile,
+                                                         const double *__restrict__ mass,
                                                          const double *__restrict__ multis,
                                                          const double *__restrict__ randoms,
                                                          const double *__restrict__ deltac,
                                                          const double *__restrict__ fenv,
                                                          const double *__restrict__ shear, abacus_hod_params p,
-                                                         int8_t *__restrict__ keep, int *__restrict__ tile_counts) {
-    __shared__ int cnt[4];
-    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
-    const bool need_shear = p.want_ELG && shear != nullptr;
-#pragma unroll
-    for (int k = 0; k < PER_THREAD / 2; k++) {
-        int64_t i = tile0 + (int64_t)k * (2 * BLOCK) + 2 * threadIdx.x;
-        int8_t k0 = 0, k1 = 0;
-        if (i < n) {
-            double m0, m1, mu0, mu1, r0, r1, d0, d1, f0, f1, s0 = 0, s1 = 0;
-            load2(mass, i, n, 1.0, m0, m1);
-            load2(multis, i, n, 0.0, mu0, mu1);
-            load2(randoms, i, n, 2.0, r0, r1);
-            load2(deltac, i, n, 0.0, d0, d1);
-            load2(fenv, i, n, 0.0, f0, f1);
-            if (need_shear) load2(shear, i, n, 0.0, s0, s1);
-            k0 = cent_decide(p, m0, mu0, r0, d0, f0, s0);
-            if (i + 1 < n) {
-                k1 = cent_decide(p, m1, mu1, r1, d1, f1, s1);
-                *reinterpret_cast<char2 *>(keep + i) = make_char2(k0, k1);
-            } else {
-                keep[i] = k0;
-            }
+                                                         int8_t *__restrict__ keep, int *__restrict__ tile_counts,
+                                                         int *__restrict__ sb_counts) {
+    __shared__ ExactLds L;
+    int tile_first;
+    const int total = exact_setup(L, q_count, ntile, tile_first);
+    const double *sh_arr = p.want_ELG ? shear : nullptr;
+    for (int j = threadIdx.x; j < total; j += FBLOCK) {
+        const int q = exact_find_tile(L, j);
+        const int64_t t0 = (int64_t)(tile_first + q) * TILE;
+        const int64_t i = t0 + queue[t0 + (j - L.pre[q])];
+        const int8_t kk = cent_decide(p, mass[i], multis[i], randoms[i], load1(deltac, i, 0.0), load1(fenv, i, 0.0),
+                                      load1(sh_arr, i, 0.0));
+        if (kk) {
+            keep[i] = kk;
+            atomicAdd(&L.cnt[q][kk - 1], 1);
         }
-        tile_count(k0, k1, cnt);
     }
-    __syncthreads();
-    if (threadIdx.x < 4) tile_counts[(int64_t)blockIdx.x * 4 + threadIdx.x] = cnt[threadIdx.x];
+    exact_finish(L, ntile, tile_first, tile_counts, sb_counts);
 }
 
-__global__ __launch_bounds__(BLOCK) void hod_decide_sat(
-    int64_t n, const double *__restrict__ hmass, const double *__restrict__ weights,
-    const double *__restrict__ randoms, const double *__restrict__ deltac, const double *__restrict__ fenv,
-    const double *__restrict__ shear, const double *__restrict__ ranks, const double *__restrict__ ranksv,
-    const double *__restrict__ ranksp, const double *__restrict__ ranksr, const int64_t *__restrict__ pinds,
-    const int8_t *__restrict__ keep_cent, abacus_hod_params p, int8_t *__restrict__ keep,
-    int *__restrict__ tile_counts) {
-    __shared__ int cnt[4];
-    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
-    const bool need_shear = p.want_ELG && shear != nullptr;
+__global__ __launch_bounds__(FBLOCK) void hod_exact_sat(
+    const int *__restrict__ q_count, const unsigned short *__restrict__ queue, int ntile,
+    const double *__restrict__ hmass, const double *__restrict__ weights, const double *__restrict__ randoms,
+    const double *__restrict__ deltac, const double *__restrict__ fenv, const double *__restrict__ shear,
+    const double *__restrict__ ranks, const double *__restrict__ ranksv, const double *__restrict__ ranksp,
+    const double *__restrict__ ranksr, const int64_t *__restrict__ pinds, const int8_t *__restrict__ keep_cent,
+    abacus_hod_params p, SatPre pre, int8_t *__restrict__ keep, int *__restrict__ tile_counts,
+    int *__restrict__ sb_counts) {
+    __shared__ ExactLds L;
+    int tile_first;
+    const int total = exact_setup(L, q_count, ntile, tile_first);
+    const double *sh_arr = p.want_ELG ? shear : nullptr;
     const bool need_conf = p.want_ELG && pinds != nullptr;
     const bool need_ranks = p.enable_ranks != 0;
-#pragma unroll
-    for (int k = 0; k < PER_THREAD / 2; k++) {
-        int64_t i = tile0 + (int64_t)k * (2 * BLOCK) + 2 * threadIdx.x;
-        int8_t k0 = 0, k1 = 0;
-        if (i < n) {
-            double m0, m1, w0, w1, r0, r1, d0, d1, f0, f1, s0 = 0, s1 = 0;
-            double a0 = 1, a1 = 1, b0 = 1, b1 = 1, c0 = 1, c1 = 1, e0 = 1, e1 = 1;
-            int8_t kc0 = 0, kc1 = 0;
-            load2(hmass, i, n, 1.0, m0, m1);
-            load2(weights, i, n, 0.0, w0, w1);
-            load2(randoms, i, n, 2.0, r0, r1);
-            load2(deltac, i, n, 0.0, d0, d1);
-            load2(fenv, i, n, 0.0, f0, f1);
-            if (need_shear) load2(shear, i, n, 0.0, s0, s1);
-            if (need_ranks) {
-                load2(ranks, i, n, 1.0, a0, a1);
-                load2(ranksv, i, n, 1.0, b0, b1);
-                load2(ranksp, i, n, 1.0, c0, c1);
-                load2(ranksr, i, n, 1.0, e0, e1);
-            }
-            if (need_conf) {  // keep_cent[pinds[i]] (hod/GRAND_HOD.py:1562), gathered here instead of on the host
-                kc0 = keep_cent[pinds[i]];
-                if (i + 1 < n) kc1 = keep_cent[pinds[i + 1]];
-            }
-            k0 = sat_decide(p, m0, w0, r0, d0, f0, s0, a0, b0, c0, e0, kc0);
-            if (i + 1 < n) {
-                k1 = sat_decide(p, m1, w1, r1, d1, f1, s1, a1, b1, c1, e1, kc1);
-                *reinterpret_cast<char2 *>(keep + i) = make_char2(k0, k1);
-            } else {
-                keep[i] = k0;
-            }
+    for (int j = threadIdx.x; j < total; j += FBLOCK) {
+        const int q = exact_find_tile(L, j);
+        const int64_t t0 = (int64_t)(tile_first + q) * TILE;
+        const int64_t i = t0 + queue[t0 + (j - L.pre[q])];
+        const int8_t kc = need_conf ? keep_cent[pinds[i]] : (int8_t)0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
+        const int8_t kk = sat_decide(p, pre, hmass[i], weights[i], randoms[i], load1(deltac, i, 0.0),
+                                     load1(fenv, i, 0.0), load1(sh_arr, i, 0.0), need_ranks ? ranks[i] : 1.0,
+                                     need_ranks ? ranksv[i] : 1.0, need_ranks ? ranksp[i] : 1.0,
+                                     need_ranks ? ranksr[i] : 1.0, kc);
+        if (kk) {
+            keep[i] = kk;
+            atomicAdd(&L.cnt[q][kk - 1], 1);
         }
-        tile_count(k0, k1, cnt);
     }
-    __syncthreads();
-    if (threadIdx.x < 4) tile_counts[(int64_t)blockIdx.x * 4 + threadIdx.x] = cnt[threadIdx.x];
-}
-
-// Exclusive scan over tile counts.  One workgroup; thread t owns a contiguous run of tiles.
-// tile_counts / tile_offsets: [(ntile_c + ntile_s)][4]; totals: [0..2] Ncent, [3..5] Nsat.
-constexpr int SCAN_BLOCK = 1024;
-__global__ __launch_bounds__(SCAN_BLOCK) void hod_scan_tiles(const int *__restrict__ tile_counts, int ntile_c,
-                                                             int ntile_s, int64_t *__restrict__ tile_offsets,
-                                                             int64_t *__restrict__ totals) {
-    __shared__ int64_t part[SCAN_BLOCK][3];
-    __shared__ int64_t ncent[3];
-    for (int phase = 0; phase < 2; phase++) {
-        const int base = phase == 0 ? 0 : ntile_c;
-        const int nt = phase == 0 ? ntile_c : ntile_s;
-        const int per = (nt + SCAN_BLOCK - 1) / SCAN_BLOCK;
-        const int lo = min(nt, (int)threadIdx.x * per), hi = min(nt, lo + per);
-        int64_t s[3] = {0, 0, 0};
-        for (int b = lo; b < hi; b++)
-#pragma unroll
-            for (int t = 0; t < 3; t++) s[t] += tile_counts[(int64_t)(base + b) * 4 + t];
-#pragma unroll
-        for (int t = 0; t < 3; t++) part[threadIdx.x][t] = s[t];
-        __syncthreads();
-        // Hillis-Steele inclusive scan over the 1024 partial sums
-        for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-            int64_t v[3] = {0, 0, 0};
-            if ((int)threadIdx.x >= off)
-#pragma unroll
-                for (int t = 0; t < 3; t++) v[t] = part[threadIdx.x - off][t];
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < 3; t++) part[threadIdx.x][t] += v[t];
-            __syncthreads();
-        }
-        int64_t run[3];
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            run[t] = part[threadIdx.x][t] - s[t];       // exclusive prefix of this thread's run
-            if (phase == 1) run[t] += ncent[t];          // satellites follow the centrals of their tracer
-        }
-        for (int b = lo; b < hi; b++)
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                tile_offsets[(int64_t)(base + b) * 4 + t] = run[t];
-                run[t] += tile_counts[(int64_t)(base + b) * 4 + t];
-            }
-        if (threadIdx.x == SCAN_BLOCK - 1) {
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                totals[phase * 3 + t] = part[threadIdx.x][t];
-                if (phase == 0) ncent[t] = part[threadIdx.x][t];
-            }
-        }
-        __syncthreads();
-    }
+    exact_finish(L, ntile, tile_first, tile_counts, sb_counts);
 }
 
 struct OutCols {
@@ -346,80 +539,168 @@ __device__ __forceinline__ void emit_one(const abacus_hod_params &p, const OutCo
     o.id[t][j] = id;
 }
 
-// Ordered emission.  Workgroups [0, ntile_c) handle central tiles, the rest satellite tiles.
-// Thread t owns objects [tile0 + 8t, tile0 + 8t + 8): one 8-byte load of the mask, a packed 3x20-bit block scan.
-__global__ __launch_bounds__(BLOCK) void hod_emit(int64_t nh, int64_t np, int ntile_c, const int8_t *__restrict__ keep_c,
-                                                  const int8_t *__restrict__ keep_s,
-                                                  const int64_t *__restrict__ tile_offsets,
-                                                  const double *__restrict__ hpos, const double *__restrict__ hvel,
-                                                  const double *__restrict__ hvdev, const double *__restrict__ hmass,
-                                                  const int64_t *__restrict__ hid, const double *__restrict__ ppos,
-                                                  const double *__restrict__ pvel, const double *__restrict__ phvel,
-                                                  const double *__restrict__ phmass,
-                                                  const int64_t *__restrict__ phid, abacus_hod_params p, OutCols o) {
+// Ordered emission, one WAVE per decide tile (2048 objects, 32 consecutive objects per lane: two 16-B loads of the
+// mask).  No LDS and no barriers: the output offset is a wave reduction over the counters in front of the tile
+// (whole superblocks from the superblock counters, the rest from the tile counters; satellites start after all
+// centrals of their tracer, so centrals||satellites land concatenated and fast_concatenate never runs), the rank
+// inside the tile a packed 3 x 20-bit wave scan.  Waves [0, ntile_c) handle centrals, the rest satellites.
+constexpr int EBLOCK = 64;
+constexpr int EMIT_PER_LANE = TILE / EBLOCK;   // 32
+
+__device__ __forceinline__ int64_t wave_sum(int64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(EBLOCK) void hod_emit(int64_t nh, int64_t np, int ntile_c, int ntile_s,
+                                                   const int8_t *__restrict__ keep_c,
+                                                   const int8_t *__restrict__ keep_s,
+                                                   const int *__restrict__ tile_counts,
+                                                   const int *__restrict__ sb_counts, int64_t *__restrict__ totals,
+                                                   const double *__restrict__ hpos, const double *__restrict__ hvel,
+                                                   const double *__restrict__ hvdev, const double *__restrict__ hmass,
+                                                   const int64_t *__restrict__ hid, const double *__restrict__ ppos,
+                                                   const double *__restrict__ pvel, const double *__restrict__ phvel,
+                                                   const double *__restrict__ phmass,
+                                                   const int64_t *__restrict__ phid, abacus_hod_params p, OutCols o) {
+    const int nsb_c = (ntile_c + SB_TILES - 1) / SB_TILES, nsb_s = (ntile_s + SB_TILES - 1) / SB_TILES;
     const bool sat = (int)blockIdx.x >= ntile_c;
-    const int tile = sat ? blockIdx.x - ntile_c : blockIdx.x;
+    const int T0 = sat ? blockIdx.x - ntile_c : blockIdx.x;
     const int64_t n = sat ? np : nh;
     const int8_t *keep = sat ? keep_s : keep_c;
-    const int64_t i0 = (int64_t)tile * TILE + (int64_t)threadIdx.x * PER_THREAD;
-    int8_t k[PER_THREAD];
-    if (i0 + PER_THREAD <= n) {
-        unsigned long long bits = *reinterpret_cast<const unsigned long long *>(keep + i0);
+    const int lane = threadIdx.x;
+    const int *sb_c = sb_counts, *sb_s = sb_counts + (int64_t)nsb_c * 4;
+    const int *tc = tile_counts + (sat ? (int64_t)ntile_c * 4 : 0);
+
+    if (blockIdx.x == 0) {  // totals for the host: Ncent[3], Nsat[3]
+        int64_t c3[3] = {0, 0, 0}, s3[3] = {0, 0, 0};
+        for (int s = lane; s < nsb_c; s += EBLOCK)
 #pragma unroll
-        for (int q = 0; q < PER_THREAD; q++) k[q] = (int8_t)((bits >> (8 * q)) & 0xff);
+            for (int t = 0; t < 3; t++) c3[t] += sb_c[(int64_t)s * 4 + t];
+        for (int s = lane; s < nsb_s; s += EBLOCK)
+#pragma unroll
+            for (int t = 0; t < 3; t++) s3[t] += sb_s[(int64_t)s * 4 + t];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            c3[t] = wave_sum(c3[t]);
+            s3[t] = wave_sum(s3[t]);
+        }
+        if (lane < 3) {
+            totals[lane] = lane == 0 ? c3[0] : (lane == 1 ? c3[1] : c3[2]);
+            totals[3 + lane] = lane == 0 ? s3[0] : (lane == 1 ? s3[1] : s3[2]);
+        }
+    }
+    // nothing selected in this tile: done (the common case for rare tracers is still a non-empty tile)
+    const int4 mine_cnt = *reinterpret_cast<const int4 *>(tc + (int64_t)T0 * 4);
+    if (mine_cnt.x + mine_cnt.y + mine_cnt.z == 0) return;
+
+    // ---- mask of this lane's 32 objects ----
+    const int64_t i0 = (int64_t)T0 * TILE + (int64_t)lane * EMIT_PER_LANE;
+    unsigned long long bits[EMIT_PER_LANE / 8];
+    if (i0 + EMIT_PER_LANE <= n) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(keep + i0);
+        const uint4 b = *reinterpret_cast<const uint4 *>(keep + i0 + 16);
+        bits[0] = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
+        bits[1] = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
+        bits[2] = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
+        bits[3] = (unsigned long long)b.z | ((unsigned long long)b.w << 32);
     } else {
 #pragma unroll
-        for (int q = 0; q < PER_THREAD; q++) k[q] = (i0 + q < n) ? keep[i0 + q] : (int8_t)0;
+        for (int w = 0; w < EMIT_PER_LANE / 8; w++) {
+            bits[w] = 0;
+            for (int q = 0; q < 8; q++) {
+                const int64_t i = i0 + w * 8 + q;
+                if (i < n) bits[w] |= (unsigned long long)(unsigned char)keep[i] << (8 * q);
+            }
+        }
     }
-    unsigned long long mine = 0;  // counts of tracer 1,2,3 in 20-bit fields
+
+    // ---- offset of this tile ----
+    const int *sb_mine = sat ? sb_s : sb_c;
+    const int S = T0 / SB_TILES;
+    int64_t off[3] = {0, 0, 0};
+    for (int s = lane; s < S; s += EBLOCK)
 #pragma unroll
-    for (int q = 0; q < PER_THREAD; q++)
-        if (k[q]) mine += 1ull << (20 * (k[q] - 1));
-    // block-wide exclusive scan of `mine`: wave scan by shuffles, then the 4 wave totals through LDS
-    __shared__ unsigned long long wave_tot[BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int t = 0; t < 3; t++) off[t] += sb_mine[(int64_t)s * 4 + t];
+    {
+        const int T = S * SB_TILES + lane;   // SB_TILES <= 64: one lane per tile of the superblock
+        if (T < T0)
+#pragma unroll
+            for (int t = 0; t < 3; t++) off[t] += tc[(int64_t)T * 4 + t];
+    }
+    if (sat)  // satellites follow all centrals of their tracer
+        for (int s = lane; s < nsb_c; s += EBLOCK)
+#pragma unroll
+            for (int t = 0; t < 3; t++) off[t] += sb_c[(int64_t)s * 4 + t];
+#pragma unroll
+    for (int t = 0; t < 3; t++) off[t] = wave_sum(off[t]);
+
+    // ---- ranks inside the tile: mask bytes are 0..3, counted with bit tricks (3 popcounts per 8 objects) ----
+    unsigned long long mine = 0;
+    constexpr unsigned long long LSB = 0x0101010101010101ull;
+#pragma unroll
+    for (int w = 0; w < EMIT_PER_LANE / 8; w++) {
+        const unsigned long long b0 = bits[w] & LSB, b1 = (bits[w] >> 1) & LSB;
+        mine += (unsigned long long)__popcll(b0 & ~b1) | ((unsigned long long)__popcll(b1 & ~b0) << 20) |
+                ((unsigned long long)__popcll(b0 & b1) << 40);
+    }
     unsigned long long incl = mine;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned long long v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
     }
-    if (lane == 63) wave_tot[wave] = incl;
+    // ---- compact the selected objects of the tile into LDS (entry = loc | tracer << 11 | rank-in-tracer << 13),
+    //      then let consecutive lanes emit consecutive entries: the gathers of a tile issue together instead of one
+    //      divergent lane at a time ----
+    __shared__ unsigned int entries[TILE];
+    const unsigned long long excl = incl - mine;
+    const unsigned long long tot = __shfl(incl, 63, 64);
+    const int total = (int)((tot & 0xfffff) + ((tot >> 20) & 0xfffff) + ((tot >> 40) & 0xfffff));
+    {
+        int e = (int)((excl & 0xfffff) + ((excl >> 20) & 0xfffff) + ((excl >> 40) & 0xfffff));
+        unsigned int r[3] = {(unsigned int)(excl & 0xfffff), (unsigned int)((excl >> 20) & 0xfffff),
+                             (unsigned int)((excl >> 40) & 0xfffff)};
+        for (int w = 0; w < EMIT_PER_LANE / 8; w++) {
+            unsigned long long nz = (bits[w] | (bits[w] >> 1)) & LSB;   // one flag bit per selected object
+            while (nz) {
+                const int q = __ffsll((long long)nz) >> 3;              // byte index of the lowest flag
+                nz &= nz - 1;
+                const unsigned int t = (unsigned int)((bits[w] >> (8 * q)) & 0xff) - 1u;
+                const unsigned int loc = (unsigned int)(lane * EMIT_PER_LANE + w * 8 + q);
+                const unsigned int rk = t == 0 ? r[0]++ : (t == 1 ? r[1]++ : r[2]++);
+                entries[e++] = loc | (t << 11) | (rk << 13);
+            }
+        }
+    }
     __syncthreads();
-    unsigned long long excl = incl - mine;
-    for (int w = 0; w < wave; w++) excl += wave_tot[w];
-    if (!__syncthreads_or(mine != 0)) return;
-    int64_t j[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++)
-        j[t] = tile_offsets[(int64_t)blockIdx.x * 4 + t] + (int64_t)((excl >> (20 * t)) & 0xfffff);
-    if (mine == 0) return;
-    const double alpha[3] = {sat ? p.L_alpha_s : p.L_alpha_c, sat ? p.E_alpha_s : p.E_alpha_c,
-                             sat ? p.Q_alpha_s : p.Q_alpha_c};
-#pragma unroll
-    for (int q = 0; q < PER_THREAD; q++) {
-        const int t = k[q] - 1;
-        if (t < 0) continue;
-        const int64_t i = i0 + q;
+    const double a0 = sat ? p.L_alpha_s : p.L_alpha_c, a1 = sat ? p.E_alpha_s : p.E_alpha_c,
+                 a2 = sat ? p.Q_alpha_s : p.Q_alpha_c;
+    for (int e = lane; e < total; e += EBLOCK) {
+        const unsigned int en = entries[e];
+        const int t = (int)((en >> 11) & 3u);
+        const int64_t i = (int64_t)T0 * TILE + (en & 2047u);
+        const int64_t j = (t == 0 ? off[0] : (t == 1 ? off[1] : off[2])) + (int64_t)(en >> 13);
+        const double al = t == 0 ? a0 : (t == 1 ? a1 : a2);
         double x, y, z, vx, vy, vz, m;
         int64_t id;
         if (!sat) {
             x = hpos[3 * i], y = hpos[3 * i + 1], z = hpos[3 * i + 2];
-            vx = hvel[3 * i] + alpha[t] * hvdev[3 * i];  // velocity bias (:301-305)
-            vy = hvel[3 * i + 1] + alpha[t] * hvdev[3 * i + 1];
-            vz = hvel[3 * i + 2] + alpha[t] * hvdev[3 * i + 2];
+            vx = hvel[3 * i] + al * hvdev[3 * i];  // velocity bias (:301-305)
+            vy = hvel[3 * i + 1] + al * hvdev[3 * i + 1];
+            vz = hvel[3 * i + 2] + al * hvdev[3 * i + 2];
             m = hmass[i];
             id = hid[i];
         } else {
             x = ppos[3 * i], y = ppos[3 * i + 1], z = ppos[3 * i + 2];
-            vx = phvel[3 * i] + alpha[t] * (pvel[3 * i] - phvel[3 * i]);  // (:1136-1146)
-            vy = phvel[3 * i + 1] + alpha[t] * (pvel[3 * i + 1] - phvel[3 * i + 1]);
-            vz = phvel[3 * i + 2] + alpha[t] * (pvel[3 * i + 2] - phvel[3 * i + 2]);
+            vx = phvel[3 * i] + al * (pvel[3 * i] - phvel[3 * i]);  // (:1136-1146)
+            vy = phvel[3 * i + 1] + al * (pvel[3 * i + 1] - phvel[3 * i + 1]);
+            vz = phvel[3 * i + 2] + al * (pvel[3 * i + 2] - phvel[3 * i + 2]);
             m = phmass[i];
             id = phid[i];
         }
-        emit_one(p, o, t, j[t], x, y, z, vx, vy, vz, m, id);
-        j[t]++;
+        emit_one(p, o, t, j, x, y, z, vx, vy, vz, m, id);
     }
 }
 
@@ -441,7 +722,10 @@ struct abacus_hod_state {
     int ntile_c = 0, ntile_s = 0;
     int8_t *keep_c = nullptr, *keep_s = nullptr;
     int *tile_counts = nullptr;
-    int64_t *tile_offsets = nullptr;
+    int *sb_counts = nullptr;   // [(nsb_c + nsb_s)][4]
+    int *q_count = nullptr;                                  // [ntile_c + ntile_s] survivors of the float32 filter
+    unsigned short *queue_c = nullptr, *queue_s = nullptr;   // tile-local indices, one TILE-sized slice per tile
+    int nsb_c = 0, nsb_s = 0;
     int64_t *d_totals = nullptr;  // 6
     int64_t *h_totals = nullptr;  // pinned, 6
     // outputs
@@ -453,6 +737,60 @@ struct abacus_hod_state {
 };
 
 namespace {
+
+
+// host side of the float32 rejection filter: constants rounded so that every bound stays an upper bound
+Filt make_filter(const abacus_hod_params &p, const SatPre &pre) {
+    Filt F;
+    memset(&F, 0, sizeof F);
+    auto up = [](double v) { return (float)(v * (v >= 0 ? 1.000001 : 0.999999)); };   // >= v after rounding
+    auto finite = [](double v) { return std::isfinite(v); };
+    bool ok = true;
+    auto tracer = [&](bool want, double lc, double Ac, double Bc, double Cc, double sigma, double ic) {
+        if (!want) return;
+        ok = ok && finite(lc) && finite(Ac) && finite(Bc) && finite(Cc) && finite(sigma) && sigma > 1e-3 && finite(ic) &&
+             ic >= 0;
+    };
+    tracer(p.want_LRG, p.L_logM_cut, p.L_Acent, p.L_Bcent, 0, p.L_sigma, p.L_ic);
+    tracer(p.want_ELG, p.E_logM_cut, p.E_Acent, p.E_Bcent, p.E_Ccent, p.E_sigma, p.E_ic);
+    tracer(p.want_QSO, p.Q_logM_cut, p.Q_Acent, p.Q_Bcent, 0, p.Q_sigma, p.Q_ic);
+    if (p.want_ELG) ok = ok && finite(p.E_p_max) && finite(p.E_Q) && p.E_Q != 0;
+    F.cent_ok = ok;
+    F.L_lc = (float)p.L_logM_cut, F.L_Ac = (float)p.L_Acent, F.L_Bc = (float)p.L_Bcent;
+    F.L_inv_s = (float)(1.0 / (1.41421356 * p.L_sigma)), F.L_ic = up(p.L_ic);
+    F.E_lc = (float)p.E_logM_cut, F.E_Ac = (float)p.E_Acent, F.E_Bc = (float)p.E_Bcent, F.E_Cc = (float)p.E_Ccent;
+    F.E_c_phi = up(std::max(2.0 * (p.E_p_max - 1.0 / p.E_Q), 0.0) * 0.3989422804014327 / p.E_sigma);
+    F.E_half_inv_s2 = (float)(0.5 / (p.E_sigma * p.E_sigma)), F.E_ic = up(p.E_ic);
+    F.Q_lc = (float)p.Q_logM_cut, F.Q_Ac = (float)p.Q_Acent, F.Q_Bc = (float)p.Q_Bcent;
+    F.Q_inv_s = (float)(1.0 / (1.41421356 * p.Q_sigma)), F.Q_ic = up(p.Q_ic);
+    // satellites: only when every wanted tracer has particle-independent M1 / M_cut, positive masses and alpha >= 0
+    bool sok = ok;
+    auto sat = [&](bool want, int is_const, double M1, double alpha, double kappa, double Mcut) {
+        if (!want) return;
+        sok = sok && is_const && finite(M1) && M1 > 0 && finite(alpha) && alpha >= 0 && finite(kappa) && finite(Mcut);
+    };
+    sat(p.want_LRG, pre.L_const, pre.L_M1, p.L_alpha, p.L_kappa, pre.L_Mcut);
+    sat(p.want_ELG, pre.E_const, pre.E_M1, p.E_alpha, p.E_kappa, pre.E_Mcut);
+    sat(p.want_ELG, pre.E_const, pre.E_M1_EL, p.E_alpha_EL, p.E_kappa, pre.E_Mcut);
+    sat(p.want_ELG, pre.E_const, pre.E_M1_EE, p.E_alpha_EE, p.E_kappa, pre.E_Mcut);
+    sat(p.want_QSO, pre.Q_const, pre.Q_M1, p.Q_alpha, p.Q_kappa, pre.Q_Mcut);
+    if (p.want_ELG) sok = sok && finite(p.E_A_s) && p.E_A_s >= 0;
+    F.sat_ok = sok;
+    F.L_invM1 = up(1.0 / pre.L_M1), F.L_alpha = (float)p.L_alpha;
+    F.E_invM1[0] = up(1.0 / pre.E_M1), F.E_invM1[1] = up(1.0 / pre.E_M1_EL), F.E_invM1[2] = up(1.0 / pre.E_M1_EE);
+    F.E_alpha[0] = (float)p.E_alpha, F.E_alpha[1] = (float)p.E_alpha_EL, F.E_alpha[2] = (float)p.E_alpha_EE;
+    F.E_As = up(p.E_A_s);
+    F.Q_invM1 = up(1.0 / pre.Q_M1), F.Q_alpha = (float)p.Q_alpha;
+    const double Ls[4] = {p.L_s, p.L_s_v, p.L_s_p, p.L_s_r}, Es[4] = {p.E_s, p.E_s_v, p.E_s_p, p.E_s_r},
+                 Qs[4] = {p.Q_s, p.Q_s_v, p.Q_s_p, p.Q_s_r};
+    for (int q = 0; q < 4; q++) {
+        F.L_s[q] = up(std::fabs(Ls[q])), F.E_s[q] = up(std::fabs(Es[q])), F.Q_s[q] = up(std::fabs(Qs[q]));
+        if (p.enable_ranks) F.sat_ok = F.sat_ok && finite(Ls[q]) && finite(Es[q]) && finite(Qs[q]);
+    }
+    // kappa*M_cut exactly as n_sat_* forms it (FP64 product)
+    F.L_kMcut = p.L_kappa * pre.L_Mcut, F.E_kMcut = p.E_kappa * pre.E_Mcut, F.Q_kMcut = p.Q_kappa * pre.Q_Mcut;
+    return F;
+}
 
 template <class T>
 int upload(T *&dst, const T *src, int64_t n, bool on_device) {
@@ -489,11 +827,15 @@ OutCols out_cols(abacus_hod_state *st) {
 }
 
 int launch_emit(abacus_hod_state *st) {
-    const int ntiles = st->ntile_c + st->ntile_s;
-    if (ntiles == 0) return 0;
-    ABACUS_LAUNCH("hod_emit", hod_emit, dim3(ntiles), dim3(BLOCK), 0, st->nh, st->np, st->ntile_c, st->keep_c,
-                  st->keep_s, st->tile_offsets, st->hpos, st->hvel, st->hveldev, st->hmass, st->hid, st->ppos,
-                  st->pvel, st->phvel, st->phmass, st->phid, st->params, out_cols(st));
+    const int nemit = st->ntile_c + st->ntile_s;
+    if (nemit == 0) {
+        HIP_TRY(hipMemsetAsync(st->d_totals, 0, 6 * sizeof(int64_t), stream()));
+        return 0;
+    }
+    ABACUS_LAUNCH("hod_emit", hod_emit, dim3(nemit), dim3(EBLOCK), 0, st->nh, st->np, st->ntile_c, st->ntile_s,
+                  st->keep_c, st->keep_s, st->tile_counts, st->sb_counts, st->d_totals, st->hpos, st->hvel,
+                  st->hveldev, st->hmass, st->hid, st->ppos, st->pvel, st->phvel, st->phmass, st->phid, st->params,
+                  out_cols(st));
     return 0;
 }
 
@@ -509,7 +851,7 @@ int abacus_hod_stage(const abacus_hod_arrays *a, int on_device, abacus_hod_state
         return fail("abacus_hod_stage: a required halo array is NULL");
     if (a->n_part > 0 && (!a->ppos || !a->pvel || !a->phvel || !a->phmass || !a->phid || !a->pweights || !a->prandoms))
         return fail("abacus_hod_stage: a required particle array is NULL");
-    if (a->n_halo >= (int64_t)TILE * 0x7fffffff || a->n_part >= (int64_t)TILE * 0x7fffffff)
+    if (a->n_halo >= ((int64_t)1 << 32) || a->n_part >= ((int64_t)1 << 32))
         return fail("abacus_hod_stage: too many objects for one device");
     auto *st = new abacus_hod_state();
     st->nh = a->n_halo;
@@ -527,11 +869,16 @@ int abacus_hod_stage(const abacus_hod_arrays *a, int on_device, abacus_hod_state
     st->ntile_c = (int)ceil_div(nh, TILE);
     st->ntile_s = (int)ceil_div(np, TILE);
     const int64_t ntiles = (int64_t)st->ntile_c + st->ntile_s;
-    HIP_TRY(hipMalloc((void **)&st->keep_c, nh > 0 ? nh + 16 : 16));
-    HIP_TRY(hipMalloc((void **)&st->keep_s, np > 0 ? np + 16 : 16));
+    HIP_TRY(hipMalloc((void **)&st->keep_c, nh > 0 ? nh + 64 : 64));
+    HIP_TRY(hipMalloc((void **)&st->keep_s, np > 0 ? np + 64 : 64));
     HIP_TRY(hipMalloc((void **)&st->tile_counts, (ntiles > 0 ? ntiles : 1) * 4 * sizeof(int)));
-    HIP_TRY(hipMalloc((void **)&st->tile_offsets, (ntiles > 0 ? ntiles : 1) * 4 * sizeof(int64_t)));
+    st->nsb_c = (int)ceil_div(st->ntile_c, SB_TILES);
+    st->nsb_s = (int)ceil_div(st->ntile_s, SB_TILES);
+    HIP_TRY(hipMalloc((void **)&st->sb_counts, (size_t)(st->nsb_c + st->nsb_s + 1) * 4 * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&st->d_totals, 8 * sizeof(int64_t)));
+    HIP_TRY(hipMalloc((void **)&st->q_count, (size_t)(ntiles > 0 ? ntiles : 1) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&st->queue_c, (size_t)(st->ntile_c > 0 ? st->ntile_c : 1) * TILE * sizeof(unsigned short)));
+    HIP_TRY(hipMalloc((void **)&st->queue_s, (size_t)(st->ntile_s > 0 ? st->ntile_s : 1) * TILE * sizeof(unsigned short)));
     HIP_TRY(hipHostMalloc((void **)&st->h_totals, 8 * sizeof(int64_t), hipHostMallocDefault));
     // first guess for the catalog buffers; grown on demand by abacus_hod_counts
     for (int t = 0; t < 3; t++) ABACUS_TRY(set_capacity(st, t, (nh + np) / 64));
@@ -562,16 +909,37 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     if (p->want_ELG && st->np > 0 && !st->pinds)
         return fail("abacus_hod_populate: ELG conformity needs pinds to be staged");
     st->params = *p;
-    if (st->ntile_c)
-        ABACUS_LAUNCH("hod_decide_cent", hod_decide_cent, dim3(st->ntile_c), dim3(BLOCK), 0, st->nh, st->hmass,
-                      st->hmultis, st->hrandoms, st->hdeltac, st->hfenv, st->hshear, *p, st->keep_c, st->tile_counts);
-    if (st->ntile_s)
-        ABACUS_LAUNCH("hod_decide_sat", hod_decide_sat, dim3(st->ntile_s), dim3(BLOCK), 0, st->np, st->phmass,
-                      st->pweights, st->prandoms, st->pdeltac, st->pfenv, st->pshear, st->pranks, st->pranksv,
-                      st->pranksp, st->pranksr, st->pinds, st->keep_c, *p, st->keep_s,
-                      st->tile_counts + (int64_t)st->ntile_c * 4);
-    ABACUS_LAUNCH("hod_scan_tiles", hod_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, st->tile_counts, st->ntile_c,
-                  st->ntile_s, st->tile_offsets, st->d_totals);
+    // particle-independent 10**x values, with libm's pow (the function the CPU path uses for every particle)
+    SatPre pre;
+    memset(&pre, 0, sizeof pre);
+    pre.L_const = p->L_Acent == 0 && p->L_Asat == 0 && p->L_Bcent == 0 && p->L_Bsat == 0;
+    pre.E_const = p->E_Acent == 0 && p->E_Asat == 0 && p->E_Bcent == 0 && p->E_Bsat == 0 && p->E_Ccent == 0 &&
+                  p->E_Csat == 0;
+    pre.Q_const = p->Q_Acent == 0 && p->Q_Asat == 0 && p->Q_Bcent == 0 && p->Q_Bsat == 0;
+    pre.L_M1 = pow(10.0, p->L_logM1), pre.L_Mcut = pow(10.0, p->L_logM_cut);
+    pre.E_M1 = pow(10.0, p->E_logM1), pre.E_Mcut = pow(10.0, p->E_logM_cut);
+    pre.E_M1_EL = pow(10.0, p->E_logM1_EL), pre.E_M1_EE = pow(10.0, p->E_logM1_EE);
+    pre.Q_M1 = pow(10.0, p->Q_logM1), pre.Q_Mcut = pow(10.0, p->Q_logM_cut);
+    Filt F = make_filter(*p, pre);
+    if (st->ntile_c) {
+        ABACUS_LAUNCH("hod_filter_cent", hod_filter_cent, dim3(st->ntile_c), dim3(FBLOCK), 0, st->nh, st->hmass,
+                      st->hmultis, st->hrandoms, st->hdeltac, st->hfenv, st->hshear, p->want_LRG, p->want_ELG,
+                      p->want_QSO, F, st->keep_c, st->q_count, st->queue_c);
+        ABACUS_LAUNCH("hod_exact_cent", hod_exact_cent, dim3(st->nsb_c), dim3(FBLOCK), 0, st->q_count, st->queue_c,
+                      st->ntile_c, st->hmass, st->hmultis, st->hrandoms, st->hdeltac, st->hfenv, st->hshear, *p,
+                      st->keep_c, st->tile_counts, st->sb_counts);
+    }
+    if (st->ntile_s) {
+        int *tc_s = st->tile_counts + (int64_t)st->ntile_c * 4, *sb_s = st->sb_counts + (int64_t)st->nsb_c * 4;
+        int *qc_s = st->q_count + st->ntile_c;
+        ABACUS_LAUNCH("hod_filter_sat", hod_filter_sat, dim3(st->ntile_s), dim3(FBLOCK), 0, st->np, st->phmass,
+                      st->pweights, st->prandoms, st->pranks, st->pranksv, st->pranksp, st->pranksr, st->pinds,
+                      st->keep_c, p->want_LRG, p->want_ELG, p->want_QSO, p->enable_ranks, F, st->keep_s, qc_s,
+                      st->queue_s);
+        ABACUS_LAUNCH("hod_exact_sat", hod_exact_sat, dim3(st->nsb_s), dim3(FBLOCK), 0, qc_s, st->queue_s, st->ntile_s,
+                      st->phmass, st->pweights, st->prandoms, st->pdeltac, st->pfenv, st->pshear, st->pranks,
+                      st->pranksv, st->pranksp, st->pranksr, st->pinds, st->keep_c, *p, pre, st->keep_s, tc_s, sb_s);
+    }
     // speculative emission into the current buffers (writes past capacity are suppressed on the device)
     ABACUS_TRY(launch_emit(st));
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
@@ -652,7 +1020,7 @@ int abacus_hod_free(abacus_hod_state *st) {
         for (void *q : ptrs)
             if (q) (void)hipFree(q);
     }
-    void *work[] = {st->keep_c, st->keep_s, st->tile_counts, st->tile_offsets, st->d_totals};
+    void *work[] = {st->keep_c, st->keep_s, st->tile_counts, st->sb_counts, st->d_totals, st->q_count, st->queue_c, st->queue_s};
     for (void *q : work)
         if (q) (void)hipFree(q);
     if (st->h_totals) (void)hipHostFree(st->h_totals);

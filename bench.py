@@ -147,10 +147,12 @@ def bench_hod(args, dist):
         'ms_per_step_with_d2h': dt_fetch * 1e3,
     }
     # roofline of the dominant kernel: algorithmic bytes / HIP-event duration
+    # (the satellite filter of an LRG-only HOD without assembly bias needs hmass, weights, randoms only: deltac and
+    #  fenv enter with zero coefficients and are not read, so its algorithmic bytes are 24 B, not 40 B, per particle)
     alg_bytes = {
-        'hod_decide_cent': 40.0 * nh,       # mass, multis, randoms, deltac, fenv
-        'hod_decide_sat': 40.0 * npart,     # hmass, weights, randoms, deltac, fenv
-        'hod_emit': 152.0 * ngal,           # gather 88 B + write 64 B per galaxy
+        'hod_filter_cent': 40.0 * nh,       # mass, multis, randoms, deltac, fenv
+        'hod_filter_sat': 24.0 * npart,     # hmass, weights, randoms
+        'hod_emit': 1.0 * (nh + npart) + 152.0 * ngal,   # mask + gather 88 B + write 64 B per galaxy
     }
     kern = {k: (ms / n) for k, (ms, n) in prof.items() if n}
     out['kernels_ms'] = {k: round(v, 5) for k, v in kern.items()}
@@ -159,7 +161,8 @@ def bench_hod(args, dist):
         ach = alg_bytes[dom] / (kern[dom] * 1e-3) / 1e9
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                            'frac': ach / HBM_PEAK_GBS, 'traffic': None,
-                           'whole_step_GBs': (40.0 * nh + 40.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9}
+                           'whole_step_GBs': (40.0 * nh + 40.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9,
+                           'whole_step_frac': (40.0 * nh + 40.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
     st.free()
     if dist.rank == 0 and not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline_hod(hd, pd, params, tracers, nh)
