@@ -3,9 +3,11 @@
 // scipy.fft.rfftn :980,986,1059 + _normalize :1073-1078, get_interlaced_field_fft / shift_field_fft :951-998,
 // :904-948, the compensation divide :1063-1069, get_raw_power :707-727 and bin_kmu :150-300.
 //
-// Data layout in HBM: one float32 mesh per field in the in-place R2C layout (n, n, 2*(n/2+1)); after the FFT the
-// same buffer is the complex64 half-spectrum (n, n, n/2+1).  Nothing else of mesh size is allocated (plus rocFFT's
-// work area); the spectrum never goes back over PCIe in the fused path.
+// Data layout in HBM: one float32 mesh per field, rows of `pitch_r` floats with pitch_r = roundup(n + 2, 32): an
+// in-place R2C layout whose rows start on 128-B boundaries (with the minimal n + 2 pitch every 128-B row segment of a
+// tile straddles two cache lines and partial-line writes run 4x slower - measured 1.3 vs 5.5 TB/s).  After the FFT the
+// same buffer is the complex64 half-spectrum, rows of pitch_r/2 complex of which n/2+1 are valid.  Nothing else of
+// mesh size is allocated (plus rocFFT's work area); the spectrum never goes back over PCIe in the fused path.
 //
 // Passes over mesh-sized data (algorithmic bytes 36*M non-interlaced):
 //   tsc_tile_deposit  writes the mesh once, normalisation delta = rho*M/N - 1 fused into the tile flush (4M)
@@ -13,15 +15,17 @@
 //   spectrum_bin      reads the half-spectrum once and fuses scale (1/M), interlacing combine, compensation,
 //                     |delta_k|^2 (or the cross power) and the (k, mu) / multipole binning            (4M, 8M, 16M)
 //
-// spectrum_bin: persistent workgroups (one per CU).  Each stages a block of consecutive (kx, ky) rows as float32
-// power values in LDS (coalesced HBM reads), then every thread walks a contiguous run of kz of one row exactly like
-// the reference's inner loop (monotone bin search, :246-256) but accumulates the run in registers and only touches
-// the workgroup's LDS histogram when the bin changes.  Histograms are float64 / integer; they are flushed to HBM
-// with one atomic per non-empty bin per workgroup at the very end.  (The reference keeps float32 per-thread
-// accumulators, :221-229; float64 sums are strictly more accurate and thread-count independent.)
+// spectrum_bin: persistent workgroups (one per CU, 1024 threads).  A tile is a flat range of the half-spectrum;
+// while a tile is binned the next one is already in flight into registers (16-B loads).  The power of each mode is
+// staged in LDS; every thread then walks 16 consecutive kz exactly like the reference's inner loop (monotone bin
+// search, :246-256), accumulating runs of equal bins in registers and touching the workgroup's LDS histogram only
+// when the bin changes.  Histograms are float64 / integer and are flushed to HBM with one atomic per non-empty bin
+// per workgroup at the very end.  (The reference keeps float32 per-thread accumulators, :221-229; float64 sums are
+// strictly more accurate and thread-count independent.)
 #include <hipfft/hipfft.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -43,7 +47,7 @@ constexpr int MAX_POLES = 8;     // requested multipoles
 constexpr int BIN_THREADS = 1024;
 
 struct SpecArgs {
-    int n, kzlen;
+    int n, kzlen, pitch;      // pitch: complex elements per (kx, ky) row in memory (>= kzlen)
     int mode;                 // 0: raw fields (deltak API), 1: FFT output needing scale/interlace/compensation
     int interlaced, compensated, cross;
     float inv_size;           // f32(1/M)            (:1058)
@@ -55,10 +59,9 @@ struct SpecArgs {
 
 __device__ __forceinline__ int fold(int i, int n) { return i < n / 2 ? i : i - n; }   // (:234,237,940-942)
 
-// final delta_k of one field at (i, j, k): what get_field_fft returns (:1046-1070)
-__device__ __forceinline__ float2 field_value(const SpecArgs &s, const float2 *f, const float2 *fs, int64_t idx,
-                                              int i, int j, int k) {
-    float2 v = f[idx];
+// final delta_k of one field at (i, j, k) from the raw FFT output v (and the shifted field's w): what get_field_fft
+// returns (:1046-1070)
+__device__ __forceinline__ float2 finish_value(const SpecArgs &s, float2 v, float2 w, int i, int j, int k) {
     if (s.mode == 0) return v;
     if (s.interlaced) {
         // (delta_k + delta'_k * exp(i*(d/2)*(kx+ky+kz))) * f32(0.5/M); (d/2)*dk = pi/n, so the phase only depends
@@ -67,7 +70,6 @@ __device__ __forceinline__ float2 field_value(const SpecArgs &s, const float2 *f
         m %= 2 * s.n;
         if (m < 0) m += 2 * s.n;
         const float2 ph = s.phase[m];
-        const float2 w = fs[idx];
         const float re = w.x * ph.x - w.y * ph.y, im = w.x * ph.y + w.y * ph.x;
         v.x = (v.x + re) * s.half_inv_size;
         v.y = (v.y + im) * s.half_inv_size;
@@ -76,8 +78,8 @@ __device__ __forceinline__ float2 field_value(const SpecArgs &s, const float2 *f
         v.y *= s.inv_size;
     }
     if (s.compensated) {
-        const float w = (s.W[i] * s.W[j]) * s.W[k];   // (:1065-1069), NumPy divides complex by real as *(1/w)
-        const float scl = 1.0f / w;
+        const float wgt = (s.W[i] * s.W[j]) * s.W[k];   // (:1065-1069), NumPy divides complex by real as *(1/w)
+        const float scl = 1.0f / wgt;
         v.x *= scl;
         v.y *= scl;
     }
@@ -87,29 +89,30 @@ __device__ __forceinline__ float2 field_value(const SpecArgs &s, const float2 *f
 // in-place finalisation for abacus_field_fft (spectrum returned to the host)
 __global__ void spectrum_apply(SpecArgs s, float2 *out) {
     const int64_t total = (int64_t)s.n * s.n * s.kzlen;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % s.kzlen);
-        const int64_t row = idx / s.kzlen;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(q % s.kzlen);
+        const int64_t row = q / s.kzlen;
         const int j = (int)(row % s.n), i = (int)(row / s.n);
-        out[idx] = field_value(s, s.a, s.as, idx, i, j, k);
+        const int64_t idx = row * s.pitch + k;
+        const float2 w = s.interlaced ? s.as[idx] : make_float2(0.f, 0.f);
+        out[idx] = finish_value(s, s.a[idx], w, i, j, k);
     }
 }
 
 struct BinArgs {
     int Nk, Nmu, Np;          // Np = number of requested poles with ell != 0 (ell = 0 comes from the wedges)
-    int rows;                 // rows staged per tile
-    int chunk;                // consecutive elements per thread (odd -> conflict-free LDS reads)
     const float *kedges2;     // (Nk+1) f32((kedges/dk)^2)  (:217)
     const float *muedges2;    // (Nmu+1) f32(muedges^2)     (:218)
     float polecoef[MAX_POLES][6];   // (2l+1) * P_l as a polynomial in mu^2: sum_m c[m] * (mu^2)^m
+    int poledeg[MAX_POLES];         // l/2
+    int dbg;                        // ablation switches (ABACUS_DBG): 1 skip binning, 2 skip staging
     unsigned long long *g_cnt;      // (Nk*Nmu)
     double *g_sum, *g_ksum;         // (Nk*Nmu)
     double *g_pole;                 // (Np*Nk)
 };
 
 // number of edges[1..N] strictly below v  ==  the bin the reference's `while v > edges[b+1]: b += 1` stops at
-__device__ __forceinline__ int lower_bin(const float *edges, int N, float v) {
+__device__ __noinline__ int lower_bin(const float *edges, int N, float v) {
     int lo = 0, hi = N;   // answer in [lo, hi]
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
@@ -119,9 +122,103 @@ __device__ __forceinline__ int lower_bin(const float *edges, int N, float v) {
     return lo;
 }
 
+// Tile geometry: a tile is a flat range of the (pitched) half-spectrum, EPT consecutive elements per thread.
+// Registers hold the next tile of every field that is read (1, 2 or 4 fields): 16 per thread, 8 when all four are live.
+template <bool INTER, bool CROSS>
+struct BinCfg {
+    static constexpr int EPT = (INTER && CROSS) ? 8 : 16;
+    static constexpr int TILE_MODES = BIN_THREADS * EPT;
+    static constexpr int LOADS = EPT / 2;                   // float4 loads per thread per field and tile
+};
+
+template <bool INTER, bool CROSS>
+struct TileRegs {
+    float4 a[BinCfg<INTER, CROSS>::LOADS];
+    float4 as[INTER ? BinCfg<INTER, CROSS>::LOADS : 1];
+    float4 b[CROSS ? BinCfg<INTER, CROSS>::LOADS : 1];
+    float4 bs[(INTER && CROSS) ? BinCfg<INTER, CROSS>::LOADS : 1];
+};
+
+__device__ __forceinline__ float4 ld4(const float2 *p, int64_t idx, int64_t total) {
+    if (idx + 1 < total) return *reinterpret_cast<const float4 *>(p + idx);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < total) {
+        const float2 t = p[idx];
+        v.x = t.x, v.y = t.y;
+    }
+    return v;
+}
+
+template <bool INTER, bool CROSS>
+__device__ __forceinline__ void tile_load(const SpecArgs &s, int64_t base, int64_t total, TileRegs<INTER, CROSS> &r) {
+#pragma unroll
+    for (int q = 0; q < BinCfg<INTER, CROSS>::LOADS; q++) {
+        const int64_t idx = base + (int64_t)(q * BIN_THREADS + threadIdx.x) * 2;
+        r.a[q] = ld4(s.a, idx, total);
+        if (INTER) r.as[q] = ld4(s.as, idx, total);
+        if (CROSS) r.b[q] = ld4(s.b, idx, total);
+        if (INTER && CROSS) r.bs[q] = ld4(s.bs, idx, total);
+    }
+}
+
+// LDS tile index with one pad word per EPT modes: a thread's run starts EPT+1 words after its neighbour's -> no conflicts
+template <int EPT>
+__device__ __forceinline__ int tpad(int e) { return e + e / EPT; }
+
+template <bool INTER, bool CROSS>
+__device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int64_t total,
+                                           const TileRegs<INTER, CROSS> &r, float *tile) {
+    constexpr int EPT = BinCfg<INTER, CROSS>::EPT;
+    const bool need_idx = s.mode == 1 && (INTER || s.compensated);
+    // (row, k) of the tile's first element, once per thread; the per-load offsets are < 2^16
+    int64_t row0 = 0;
+    int k0 = 0;
+    if (need_idx) {
+        row0 = base / s.pitch;
+        k0 = (int)(base - row0 * s.pitch);
+    }
+#pragma unroll
+    for (int q = 0; q < BinCfg<INTER, CROSS>::LOADS; q++) {
+        const int e = (q * BIN_THREADS + threadIdx.x) * 2;
+        int i = 0, j = 0, k = 0, i2 = 0, j2 = 0, k2 = 0;
+        if (need_idx) {
+            const unsigned int kk = (unsigned int)(k0 + e);
+            const unsigned int dr = kk / (unsigned int)s.pitch;
+            k = (int)(kk - dr * (unsigned int)s.pitch);
+            const int64_t row = row0 + dr;
+            j = (int)(row % s.n), i = (int)(row / s.n);
+            k2 = k + 1, j2 = j, i2 = i;   // pitch is even and e is even: the pair never straddles two rows
+            // padding elements (k >= kzlen) and rows past the end are never binned: clamp their indices
+            if (k >= s.kzlen || i >= s.n) i = j = k = i2 = j2 = k2 = 0;
+            if (k2 >= s.kzlen) i2 = j2 = k2 = 0;
+        }
+        const float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 ras = INTER ? r.as[q] : zs, rbs = (INTER && CROSS) ? r.bs[q] : zs;
+        const float2 va0 = finish_value(s, make_float2(r.a[q].x, r.a[q].y), make_float2(ras.x, ras.y), i, j, k);
+        const float2 va1 = finish_value(s, make_float2(r.a[q].z, r.a[q].w), make_float2(ras.z, ras.w), i2, j2, k2);
+        float p0, p1;
+        if (CROSS) {
+            const float2 vb0 = finish_value(s, make_float2(r.b[q].x, r.b[q].y), make_float2(rbs.x, rbs.y), i, j, k);
+            const float2 vb1 = finish_value(s, make_float2(r.b[q].z, r.b[q].w), make_float2(rbs.z, rbs.w), i2, j2, k2);
+            p0 = va0.x * vb0.x + va0.y * vb0.y;   // Re(conj(a) b)  (:724)
+            p1 = va1.x * vb1.x + va1.y * vb1.y;
+        } else {
+            p0 = va0.x * va0.x + va0.y * va0.y;   // |a|^2          (:726)
+            p1 = va1.x * va1.x + va1.y * va1.y;
+        }
+        tile[tpad<EPT>(e)] = p0;
+        tile[tpad<EPT>(e + 1)] = p1;
+    }
+}
+
+// NP: compile-time number of ell != 0 multipoles (0..3), or -1 for the generic loop over b.Np
+template <bool INTER, bool CROSS, int NP>
 __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs b) {
+    constexpr int BIN_EPT = BinCfg<INTER, CROSS>::EPT, BIN_TILE = BinCfg<INTER, CROSS>::TILE_MODES;
+    constexpr int NPC = NP < 0 ? MAX_POLES : (NP > 0 ? NP : 1);
     extern __shared__ __align__(16) unsigned char smem[];
     const int nb = b.Nk * b.Nmu;
+    const int np = NP < 0 ? b.Np : NP;
     // LDS carve-up: [sum f64 nb][ksum f64 nb][pole f64 Np*Nk][cnt u32 nb][kedges2 Nk+1][muedges2 Nmu+1][tile f32]
     double *h_sum = reinterpret_cast<double *>(smem);
     double *h_ksum = h_sum + nb;
@@ -141,118 +238,127 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
     for (int q = tid; q <= b.Nmu; q += BIN_THREADS) me[q] = b.muedges2[q];
     __syncthreads();
     const float klo = ke[0], khi = ke[b.Nk];
-    const int n = s.n, kzlen = s.kzlen;
-    const int64_t nrows = (int64_t)n * n;
-    const int64_t ntiles = (nrows + b.rows - 1) / b.rows;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = BIN_THREADS / 64;
+    const int n = s.n, kzlen = s.kzlen, pitch = s.pitch;
+    const int64_t total = (int64_t)n * n * pitch;
+    const int64_t ntiles = (total + BIN_TILE - 1) / BIN_TILE;
 
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t row0 = t * b.rows;
-        const int nr = (int)min((int64_t)b.rows, nrows - row0);
-        // ---- stage: power of every mode of these rows -> LDS (coalesced reads along kz) ----
-        for (int r = wave; r < nr; r += nwaves) {
-            const int64_t row = row0 + r;
-            const int j = (int)(row % n), i = (int)(row / n);
-            for (int k = lane; k < kzlen; k += 64) {
-                const int64_t idx = row * kzlen + k;
-                const float2 va = field_value(s, s.a, s.as, idx, i, j, k);
-                float p;
-                if (s.cross) {
-                    const float2 vb = field_value(s, s.b, s.bs, idx, i, j, k);
-                    p = va.x * vb.x + va.y * vb.y;   // Re(conj(a) b)  (:724)
-                } else {
-                    p = va.x * va.x + va.y * va.y;   // |a|^2          (:726)
-                }
-                tile[r * kzlen + k] = p;
-            }
-        }
+    TileRegs<INTER, CROSS> regs;
+    int64_t t = blockIdx.x;
+    if (t < ntiles) tile_load<INTER, CROSS>(s, t * BIN_TILE, total, regs);
+    for (; t < ntiles; t += gridDim.x) {
+        const int64_t base = t * BIN_TILE;
+        // ---- power of this tile's modes: registers -> LDS; then prefetch the next tile into the registers, so its
+        //      HBM latency is covered by the binning below ----
+        if (!(b.dbg & 2)) tile_store<INTER, CROSS>(s, base, total, regs, tile);
         __syncthreads();
-        // ---- bin: thread walks `chunk` consecutive kz (may cross into the next row) ----
-        const int total = nr * kzlen;
-        int e = tid * b.chunk;
-        const int e1 = min(e + b.chunk, total);
-        if (e < e1) {
-            int r = e / kzlen, k = e - r * kzlen;
-            int cur = -1, bk = 0, bmu = 0;          // open run
+        if (t + gridDim.x < ntiles) tile_load<INTER, CROSS>(s, (t + gridDim.x) * BIN_TILE, total, regs);
+        // ---- bin: every thread walks EPT consecutive elements (a run may cross into the next row).  One pass, one
+        //      flush site: the target bin `tb` of each element is found first (-1 = not binned), a change of `tb`
+        //      flushes the register accumulators of the finished run into the LDS histogram ----
+        const int e0 = tid * BIN_EPT;
+        const int64_t idx0 = base + e0;
+        if (idx0 < total && !(b.dbg & 1)) {
+            int64_t row = idx0 / pitch;
+            int k = (int)(idx0 - row * pitch);
+            int r2 = 0;                               // i'^2 + j'^2 <= 2*(n/2)^2 < 2^30 for n <= 32767
+            {
+                const int jj = fold((int)(row % n), n), ii = fold((int)(row / n), n);
+                r2 = ii * ii + jj * jj;
+            }
+            int cur = -1, cur_bk = 0, bk = 0, bmu = 0;
+            bool located = false;                     // bk, bmu and the cached edges are valid for this row
+            float ke_hi = 0.f, me_lo = 0.f, me_hi = 0.f;
             int cnt = 0;
-            float sp = 0.f, sk = 0.f, spole[MAX_POLES];
+            float sp = 0.f, sk = 0.f, spole[NPC];
 #pragma unroll
-            for (int q = 0; q < MAX_POLES; q++) spole[q] = 0.f;
-            bool fresh = true, dead = false;
-            long long r2 = 0;
-            auto flush = [&]() {
-                if (cnt) {
-                    atomicAdd(&h_cnt[cur], (unsigned int)cnt);
-                    atomicAdd(&h_sum[cur], (double)sp);
-                    atomicAdd(&h_ksum[cur], (double)sk);
-                    for (int q = 0; q < b.Np; q++) atomicAdd(&h_pole[q * b.Nk + bk], (double)spole[q]);
+            for (int q = 0; q < NPC; q++) spole[q] = 0.f;
+#pragma unroll 1
+            for (int e = 0; e <= BIN_EPT; e++, k++) {
+                int tb = -1;
+                float p = 0.f, mu2 = 0.f, kmag2 = 0.f;
+                if (e < BIN_EPT) {
+                    if (k == pitch) {                 // next (kx, ky) row
+                        k = 0;
+                        row++;
+                        const int jj = fold((int)(row % n), n), ii = fold((int)(row / n), n);
+                        r2 = ii * ii + jj * jj;
+                        located = false;
+                    }
+                    const int k2 = k * k;
+                    kmag2 = (float)(r2 + k2);         // dtype(i2 + j2 + k**2) (:239); exact integer below 2^24
+                    // `continue` below the first edge (:246), `break` from the last edge on (:249), padding, array end
+                    const bool inrange = k < kzlen && row < (int64_t)n * n && kmag2 >= klo && kmag2 < khi;
+                    if (inrange) {
+                        // mu^2 = f32(k^2) * (1/kmag2) (:240-244).  The hardware reciprocal (1 ulp) picks the bin unless
+                        // mu^2 lands within a few ulp of an edge; only then the correctly rounded value is formed.
+                        const float k2f = (float)k2;
+                        mu2 = kmag2 > 0.f ? k2f * __builtin_amdgcn_rcpf(kmag2) : 0.f;
+                        bool moved = !located;
+                        if (!located) {
+                            bk = lower_bin(ke, b.Nk - 1, kmag2);
+                            bmu = lower_bin(me, b.Nmu - 1, mu2);
+                            located = true;
+                        } else {
+                            while (kmag2 > ke_hi) {   // (:252-253)
+                                bk++;
+                                ke_hi = ke[bk + 1];
+                            }
+                            while (bmu + 1 < b.Nmu && mu2 > me_hi) {   // (:255-256)
+                                bmu++;
+                                me_hi = me[bmu + 1];
+                                moved = true;
+                            }
+                        }
+                        if (moved) {
+                            ke_hi = ke[bk + 1];
+                            me_lo = me[bmu];
+                            me_hi = me[bmu + 1];
+                        }
+                        const float tol = 6e-7f * mu2;
+                        if (fabsf(mu2 - me_hi) <= tol || fabsf(mu2 - me_lo) <= tol) {
+                            mu2 = kmag2 > 0.f ? k2f * (1.0f / kmag2) : 0.f;   // IEEE division, as the reference rounds it
+                            bmu = lower_bin(me, b.Nmu - 1, mu2);
+                            me_lo = me[bmu];
+                            me_hi = me[bmu + 1];
+                        }
+                        tb = bk * b.Nmu + bmu;
+                        p = tile[tpad<BIN_EPT>(e0 + e)];
+                    } else {
+                        if (kmag2 < klo) located = false;   // re-locate when the row enters the binned range
+                    }
                 }
-                cnt = 0;
-                sp = sk = 0.f;
+                if (tb != cur) {                      // the one flush site
+                    if (cnt) {
+                        atomicAdd(&h_cnt[cur], (unsigned int)cnt);
+                        atomicAdd(&h_sum[cur], (double)sp);
+                        atomicAdd(&h_ksum[cur], (double)sk);
 #pragma unroll
-                for (int q = 0; q < MAX_POLES; q++) spole[q] = 0.f;
-            };
-            for (; e < e1; e++, k++) {
-                if (k == kzlen) {
-                    k = 0;
-                    r++;
-                    fresh = true;
+                        for (int q = 0; q < NPC; q++)
+                            if (q < np) atomicAdd(&h_pole[q * b.Nk + cur_bk], (double)spole[q]);
+                    }
+                    cnt = 0;
+                    sp = sk = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NPC; q++) spole[q] = 0.f;
+                    cur = tb;
+                    cur_bk = bk;
                 }
-                if (fresh) {
-                    flush();
-                    cur = -1;
-                    const int64_t row = row0 + r;
-                    const int jj = fold((int)(row % n), n), ii = fold((int)(row / n), n);
-                    r2 = (long long)ii * ii + (long long)jj * jj;
-                    dead = false;
-                }
-                if (dead) {
-                    fresh = false;
-                    continue;
-                }
-                const float kmag2 = (float)(r2 + (long long)k * k);   // dtype(i2 + j2 + k**2)   (:239)
-                float mu2 = 0.f;
-                if (kmag2 > 0.f) mu2 = (float)((long long)k * k) * (1.0f / kmag2);   // (:240-244)
-                if (kmag2 < klo) {
-                    fresh = false;   // `continue` (:246): bins are searched again when the row enters the range
-                    cur = -1;
-                    continue;
-                }
-                if (kmag2 >= khi) {  // `break` (:249): nothing further along kz can be in range
-                    dead = true;
-                    fresh = false;
-                    continue;
-                }
-                int nbk, nbmu;
-                if (cur < 0) {
-                    nbk = lower_bin(ke, b.Nk - 1, kmag2);
-                    nbmu = lower_bin(me, b.Nmu - 1, mu2);
-                } else {
-                    nbk = bk;
-                    nbmu = bmu;
-                    while (kmag2 > ke[nbk + 1]) nbk++;                           // (:252-253)
-                    while (nbmu + 1 < b.Nmu && mu2 > me[nbmu + 1]) nbmu++;       // (:255-256)
-                }
-                const int nb_idx = nbk * b.Nmu + nbmu;
-                if (nb_idx != cur) {
-                    flush();
-                    cur = nb_idx;
-                    bk = nbk;
-                    bmu = nbmu;
-                }
-                fresh = false;
-                const float p = tile[e];
-                const float wgt = k == 0 ? 1.f : 2.f;
-                cnt += k == 0 ? 1 : 2;
-                sp += wgt * p;
-                sk += wgt * sqrtf(kmag2);
-                for (int q = 0; q < b.Np; q++) {
-                    const float *c = b.polecoef[q];
-                    const float L = c[0] + mu2 * (c[1] + mu2 * (c[2] + mu2 * (c[3] + mu2 * (c[4] + mu2 * c[5]))));
-                    spole[q] += wgt * p * L;
+                if (tb >= 0) {
+                    const float wgt = k == 0 ? 1.f : 2.f;
+                    cnt += k == 0 ? 1 : 2;
+                    const float wp = wgt * p;
+                    sp += wp;
+                    sk += wgt * __builtin_amdgcn_sqrtf(kmag2);
+#pragma unroll
+                    for (int q = 0; q < NPC; q++)
+                        if (q < np) {
+                            const float *c = b.polecoef[q];
+                            float Lq = c[b.poledeg[q]];
+                            for (int m = b.poledeg[q] - 1; m >= 0; m--) Lq = Lq * mu2 + c[m];
+                            spole[q] += wp * Lq;
+                        }
                 }
             }
-            flush();
         }
         __syncthreads();
     }
@@ -282,11 +388,18 @@ int fft_check(hipfftResult r, const char *what) {
     return 0;
 }
 
+// real-row pitch (floats): rows start on 128-B boundaries, >= n + 2 for the in-place R2C layout
+int pitch_r(int n) { return (n + 2 + 31) / 32 * 32; }
+
 int get_plan(int n, hipfftHandle *out) {
     auto it = g_ctx.plans.find(n);
     if (it == g_ctx.plans.end()) {
         hipfftHandle h;
-        ABACUS_TRY(fft_check(hipfftPlan3d(&h, n, n, n, HIPFFT_R2C), "hipfftPlan3d"));
+        int dims[3] = {n, n, n};
+        int inembed[3] = {n, n, pitch_r(n)}, onembed[3] = {n, n, pitch_r(n) / 2};
+        ABACUS_TRY(fft_check(hipfftPlanMany(&h, 3, dims, inembed, 1, n * n * pitch_r(n), onembed, 1,
+                                            n * n * (pitch_r(n) / 2), HIPFFT_R2C, 1),
+                             "hipfftPlanMany"));
         it = g_ctx.plans.emplace(n, h).first;
     }
     ABACUS_TRY(fft_check(hipfftSetStream(it->second, stream()), "hipfftSetStream"));
@@ -294,7 +407,7 @@ int get_plan(int n, hipfftHandle *out) {
     return 0;
 }
 
-size_t mesh_bytes(int n) { return (size_t)n * n * (2 * (n / 2 + 1)) * sizeof(float); }
+size_t mesh_bytes(int n) { return (size_t)n * n * pitch_r(n) * sizeof(float); }
 
 int ensure_phase(int n) {
     if (g_ctx.phase_n == n) return 0;
@@ -315,7 +428,7 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
     if (n <= 0) return fail("power: empty particle set");
     hipfftHandle plan;
     ABACUS_TRY(get_plan(nmesh, &plan));
-    const int64_t zstride = 2 * (nmesh / 2 + 1);
+    const int64_t zstride = pitch_r(nmesh);
     const double M = (double)nmesh * nmesh * nmesh;
     const double norm = (double)(float)(M / (double)n);   // dtype(field.size / tot_weight), tot_weight = len(pos) (:856,894)
     const double d = L / nmesh;
@@ -335,6 +448,7 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
 void fill_spec(SpecArgs &s, int nmesh, int mode, int interlaced, const float *W_dev, bool cross) {
     s.n = nmesh;
     s.kzlen = nmesh / 2 + 1;
+    s.pitch = mode == 1 ? pitch_r(nmesh) / 2 : nmesh / 2 + 1;   // caller-supplied spectra (mode 0) are contiguous
     s.mode = mode;
     s.interlaced = interlaced;
     s.compensated = W_dev != nullptr;
@@ -367,17 +481,19 @@ int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const 
             int64_t *N_mode_poles, float *k_avg) {
     if (Nk < 1 || Nmu < 1) return fail("power: need at least one k bin and one mu bin");
     if (Np_all > MAX_POLES) return fail("power: more than %d multipoles requested", MAX_POLES);
-    const int nmesh = s.n, kzlen = s.kzlen;
+    const int nmesh = s.n;
     const double dk = 2.0 * M_PI / Lbox;
     BinArgs b;
     b.Nk = Nk;
     b.Nmu = Nmu;
+    b.dbg = getenv("ABACUS_DBG") ? atoi(getenv("ABACUS_DBG")) : 0;
     int nz_index[MAX_POLES];   // requested pole -> slot among the ell != 0 accumulators
     b.Np = 0;
     for (int q = 0; q < Np_all; q++) {
         nz_index[q] = -1;
         if (poles[q] != 0) {
             ABACUS_TRY(pole_coefs((int)poles[q], b.polecoef[b.Np]));
+            b.poledeg[b.Np] = (int)poles[q] / 2;
             nz_index[q] = b.Np++;
         }
     }
@@ -400,24 +516,37 @@ int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const 
     // LDS budget: histogram + edges + tile
     const size_t hist_bytes = nb * (8 + 8 + 4) + npk * 8 + (size_t)(Nk + 1 + Nmu + 1) * 4 + 64;
     const size_t lds_max = 160 * 1024;
-    if (hist_bytes + (size_t)kzlen * 4 * 2 > lds_max)
+    const bool inter = s.mode == 1 && s.interlaced, cross = s.cross != 0;
+    const int ept = (inter && cross) ? 8 : 16;
+    const int64_t tile_modes = (int64_t)BIN_THREADS * ept;
+    const size_t tile_bytes = (size_t)(tile_modes + BIN_THREADS + 16) * 4;
+    if (hist_bytes + tile_bytes > lds_max)
         return fail("power: %d x %d bins with %d multipoles do not fit the 160 KiB LDS histogram", Nk, Nmu, b.Np);
-    int rows = (int)((lds_max - hist_bytes) / ((size_t)kzlen * 4));
-    const int rows_wanted = std::max(1, (BIN_THREADS * 17 + kzlen - 1) / kzlen);   // ~17 modes per thread
-    rows = std::max(1, std::min(rows, rows_wanted));
-    int chunk = (int)(((int64_t)rows * kzlen + BIN_THREADS - 1) / BIN_THREADS);
-    if (chunk % 2 == 0) chunk++;
-    b.rows = rows;
-    b.chunk = chunk;
-    const size_t lds = hist_bytes + (size_t)rows * kzlen * 4;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spectrum_bin), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+    const size_t lds = hist_bytes + tile_bytes;
     int dev = 0, ncu = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t ntiles = ((int64_t)nmesh * nmesh + rows - 1) / rows;
+    const int64_t ntiles = ((int64_t)nmesh * nmesh * s.pitch + tile_modes - 1) / tile_modes;
     const int grid = (int)std::min<int64_t>(ntiles, ncu);
-    ABACUS_LAUNCH("spectrum_bin", spectrum_bin, dim3(grid), dim3(BIN_THREADS), lds, s, b);
+#define LAUNCH_BIN(I, C, P)                                                                                          \
+    do {                                                                                                             \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spectrum_bin<I, C, P>),                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+        ABACUS_LAUNCH("spectrum_bin", (spectrum_bin<I, C, P>), dim3(grid), dim3(BIN_THREADS), lds, s, b);            \
+    } while (0)
+#define LAUNCH_NP(I, C)                                 \
+    do {                                                \
+        if (b.Np == 0) LAUNCH_BIN(I, C, 0);             \
+        else if (b.Np == 1) LAUNCH_BIN(I, C, 1);        \
+        else if (b.Np == 2) LAUNCH_BIN(I, C, 2);        \
+        else LAUNCH_BIN(I, C, -1);                      \
+    } while (0)
+    if (inter && cross) LAUNCH_NP(true, true);
+    else if (inter) LAUNCH_NP(true, false);
+    else if (cross) LAUNCH_NP(false, true);
+    else LAUNCH_NP(false, false);
+#undef LAUNCH_NP
+#undef LAUNCH_BIN
     // tiny read-back and the normalisation of bin_kmu (:276-293) / calc_pk_from_deltak (:789-792) in float64
     std::vector<unsigned char> host(acc_bytes);
     HIP_TRY(hipMemcpyAsync(host.data(), g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
@@ -548,7 +677,9 @@ int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nme
     const int64_t total = (int64_t)nmesh * nmesh * (nmesh / 2 + 1);
     const int grid = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 32);
     ABACUS_LAUNCH("spectrum_apply", spectrum_apply, dim3(grid), dim3(256), 0, s, g_ctx.mesh[0].as<float2>());
-    HIP_TRY(hipMemcpyAsync(out_c64, g_ctx.mesh[0].p, (size_t)total * 8, hipMemcpyDeviceToHost, stream()));
+    const size_t kz = (size_t)nmesh / 2 + 1;   // rows are pitched on the device, contiguous for the caller
+    HIP_TRY(hipMemcpy2DAsync(out_c64, kz * 8, g_ctx.mesh[0].p, (size_t)s.pitch * 8, kz * 8, (size_t)nmesh * nmesh,
+                             hipMemcpyDeviceToHost, stream()));
     if (paste == 0) HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 12, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;

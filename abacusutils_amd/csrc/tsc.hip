@@ -4,6 +4,7 @@
 //
 // The reference avoids write races with x-stripes processed even-then-odd by CPU threads.  Here the mesh is cut
 // into LDS-sized tiles (16 x 16 x 32 cells = 64 KiB of float64 accumulators, two workgroups per CU):
+//   (lists for >= 2e6 particles are built by the two-level LDS multisplit ms_coarse / ms_fine instead of tsc_bin)
 //   tsc_bin<COUNT>   one pass over the particles: wrap (in place, like the reference), find the tiles the 3x3x3
 //                    cloud touches (1..8, 1.3 on average) and count them per tile (integer atomics, L2);
 //   scan.hip         exclusive scan of the tile counts;
@@ -20,6 +21,7 @@
 // which contributions are summed into a cell differs (unordered LDS atomics vs the reference's particle order),
 // a float32 rounding-level effect covered by the reference's own tolerance (tests/test_tsc.py:136).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -183,12 +185,141 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_bin(PT *__restrict__ pos, int64
     if (!FILL && any_changed) *wrapped_flag = 1;
 }
 
+// ---- two-level multisplit (large particle counts) -------------------------------------------------------------
+// tsc_bin above costs one scattered global atomic per list entry (~2.4e10/s on MI355X whatever the address pattern).
+// For large inputs the lists are built by an MSD multisplit instead: a coarse pass over <= 1024 groups of tiles and a
+// fine pass inside each group, both with workgroup-private LDS histograms, so global atomics are issued once per
+// (workgroup, bucket) instead of once per entry.  Order inside a list is arbitrary (the float64 tile accumulation
+// makes the mesh independent of it at the 1e-16 level).
+constexpr int MS_BLOCK = 512;
+constexpr int MS_CHUNK = 32768;    // particles per workgroup in the coarse passes
+constexpr int MS_FCHUNK = 32768;   // list entries per workgroup in the fine passes
+constexpr int MS_BINS = 1024;
+
+template <typename PT, bool CIC, typename F>
+__device__ __forceinline__ void for_each_tile(PT x, PT y, PT z, const TileGeom &g, double box, PT offset, PT ihx, PT ihy,
+                                              PT ihz, F f) {
+    int ci[3];
+    if (CIC) {
+        Cloud<double> c;
+        cic_cloud<PT>(x + offset, y + offset, z + offset, box, g.gx, g.gy, g.gz, c);
+        ci[0] = c.i[0], ci[1] = c.i[1], ci[2] = c.i[2];
+    } else {
+        Cloud<PT> c;
+        tsc_cloud<PT>(x, y, z, offset, ihx, ihy, ihz, c);
+        ci[0] = c.i[0], ci[1] = c.i[1], ci[2] = c.i[2];
+    }
+    int ax[3], ay[3], az[3];
+    const int nx = tiles_1d(ci[0], g.gx, g.tx, ax), ny = tiles_1d(ci[1], g.gy, g.ty, ay),
+              nz = tiles_1d(ci[2], g.gz, g.tz, az);
+    for (int a = 0; a < nx; a++)
+        for (int b = 0; b < ny; b++)
+            for (int c = 0; c < nz; c++) f((unsigned int)((ax[a] * g.nty + ay[b]) * g.ntz + az[c]));
+}
+
+// coarse pass over the particles: SCATTER=false counts entries per coarse bucket (and wraps in place),
+// SCATTER=true writes (entry, tile id) grouped by coarse bucket
+template <typename PT, bool CIC, bool SCATTER>
+__global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int64_t n, const PT *__restrict__ weights,
+                                                      TileGeom g, double box, double offset_, int wrap, int cshift,
+                                                      int ncoarse, unsigned int *__restrict__ gcount,
+                                                      const int64_t *__restrict__ gstart,
+                                                      Entry<PT> *__restrict__ stage_entry,
+                                                      unsigned int *__restrict__ stage_key, int *__restrict__ wrapped_flag) {
+    __shared__ unsigned int hist[MS_BINS];
+    __shared__ int64_t base[MS_BINS];
+    const int tid = threadIdx.x;
+    for (int b = tid; b < MS_BINS; b += MS_BLOCK) hist[b] = 0u;
+    __syncthreads();
+    const PT ihx = (PT)(g.gx / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
+    const PT offset = (PT)offset_;
+    const int64_t p0 = (int64_t)blockIdx.x * MS_CHUNK, p1 = min(p0 + MS_CHUNK, n);
+    bool any_changed = false;
+    for (int64_t p = p0 + tid; p < p1; p += MS_BLOCK) {
+        PT x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+        if (!SCATTER && wrap) {
+            bool ch = false;
+            x = wrap1(x, box, ch);
+            y = wrap1(y, box, ch);
+            z = wrap1(z, box, ch);
+            if (ch) {
+                pos[3 * p] = x;
+                pos[3 * p + 1] = y;
+                pos[3 * p + 2] = z;
+                any_changed = true;
+            }
+        }
+        for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz,
+                               [&](unsigned int tile) { atomicAdd(&hist[tile >> cshift], 1u); });
+    }
+    if (!SCATTER && any_changed) *wrapped_flag = 1;
+    __syncthreads();
+    if (!SCATTER) {
+        for (int b = tid; b < ncoarse; b += MS_BLOCK)
+            if (hist[b]) atomicAdd(&gcount[b], hist[b]);
+        return;
+    }
+    // reserve this workgroup's slice of every bucket, then place the entries
+    for (int b = tid; b < ncoarse; b += MS_BLOCK) {
+        const unsigned int c = hist[b];
+        base[b] = c ? gstart[b] + (int64_t)atomicAdd(&gcount[b], c) : 0;
+        hist[b] = 0u;
+    }
+    __syncthreads();
+    for (int64_t p = p0 + tid; p < p1; p += MS_BLOCK) {
+        const PT x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+        const PT w = weights ? weights[p] : (PT)1;
+        for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, [&](unsigned int tile) {
+            const unsigned int b = tile >> cshift;
+            const int64_t dst = base[b] + atomicAdd(&hist[b], 1u);
+            stage_entry[dst] = Entry<PT>{x, y, z, w};
+            stage_key[dst] = tile;
+        });
+    }
+}
+
+// fine pass inside coarse bucket blockIdx.y, chunk blockIdx.x of its entries
+template <typename PT, bool SCATTER>
+__global__ __launch_bounds__(MS_BLOCK) void ms_fine(const int64_t *__restrict__ gstart, int cshift, int ntiles,
+                                                    const Entry<PT> *__restrict__ stage_entry,
+                                                    const unsigned int *__restrict__ stage_key,
+                                                    unsigned int *__restrict__ tile_count,
+                                                    const int64_t *__restrict__ tile_start,
+                                                    Entry<PT> *__restrict__ entries) {
+    __shared__ unsigned int hist[MS_BINS];
+    __shared__ int64_t base[MS_BINS];
+    const int B = blockIdx.y, tid = threadIdx.x;
+    const int64_t e0 = gstart[B] + (int64_t)blockIdx.x * MS_FCHUNK, e1 = min(gstart[B + 1], e0 + MS_FCHUNK);
+    if (e0 >= e1) return;
+    const unsigned int tile0 = (unsigned int)B << cshift;
+    const int nfine = min(1 << cshift, ntiles - (int)tile0);
+    for (int f = tid; f < nfine; f += MS_BLOCK) hist[f] = 0u;
+    __syncthreads();
+    for (int64_t e = e0 + tid; e < e1; e += MS_BLOCK) atomicAdd(&hist[stage_key[e] - tile0], 1u);
+    __syncthreads();
+    if (!SCATTER) {
+        for (int f = tid; f < nfine; f += MS_BLOCK)
+            if (hist[f]) atomicAdd(&tile_count[tile0 + f], hist[f]);
+        return;
+    }
+    for (int f = tid; f < nfine; f += MS_BLOCK) {
+        const unsigned int c = hist[f];
+        base[f] = c ? tile_start[tile0 + f] + (int64_t)atomicAdd(&tile_count[tile0 + f], c) : 0;
+        hist[f] = 0u;
+    }
+    __syncthreads();
+    for (int64_t e = e0 + tid; e < e1; e += MS_BLOCK) {
+        const unsigned int f = stage_key[e] - tile0;
+        entries[base[f] + atomicAdd(&hist[f], 1u)] = stage_entry[e];
+    }
+}
+
 // One workgroup per tile.  LDS tile: tx*ty*tz cells of GT, strides (TYS*TZS, TZS, 1) fixed at compile time.
 template <typename PT, typename GT, int TXS, int TYS, int TZS, bool CIC>
 __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *__restrict__ entries,
                                                               const int64_t *__restrict__ tile_start, TileGeom g,
                                                               double box, double offset_, GT *__restrict__ grid,
-                                                              int zero_grid, GT norm) {
+                                                              int zero_grid, GT norm, int dbg) {
     // The tile is accumulated in float64 whatever the mesh dtype: the order of the LDS atomics then only matters at
     // the 1e-16 level, so the float32 mesh is reproducible run to run (and each cell is rounded once, not per add).
     __shared__ double tile[TXS * TYS * TZS];
@@ -196,13 +327,20 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *_
     const int tzi = blockIdx.x % g.ntz, tyi = (blockIdx.x / g.ntz) % g.nty, txi = blockIdx.x / (g.ntz * g.nty);
     const int ox = txi * g.tx, oy = tyi * g.ty, oz = tzi * g.tz;
     const int dx = min(g.tx, g.gx - ox), dy = min(g.ty, g.gy - oy), dz = min(g.tz, g.gz - oz);
-    for (int q = tid; q < TXS * TYS * TZS; q += TSC_BLOCK) tile[q] = 0.0;
-    __syncthreads();
+    // the list bounds and the first entry of every thread are requested before the tile is zeroed, so their HBM
+    // latency overlaps the LDS stores
     const int64_t e0 = tile_start[blockIdx.x], e1 = tile_start[blockIdx.x + 1];
+    Entry<PT> first = Entry<PT>{(PT)0, (PT)0, (PT)0, (PT)0};
+    if (e0 + tid < e1) first = entries[e0 + tid];
+    {   // zero the tile with 16-B LDS stores
+        double2 *t2 = reinterpret_cast<double2 *>(tile);
+        for (int q = tid; q < TXS * TYS * TZS / 2; q += TSC_BLOCK) t2[q] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
     const PT ihx = (PT)(g.gx / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
     const PT offset = (PT)offset_;
-    for (int64_t e = e0 + tid; e < e1; e += TSC_BLOCK) {
-        const Entry<PT> en = entries[e];
+    for (int64_t e = e0 + tid; e < e1 && !(dbg & 1); e += TSC_BLOCK) {
+        const Entry<PT> en = e == e0 + tid ? first : entries[e];
         int lx[3], ly[3], lz[3];
         if (CIC) {
             Cloud<double> c;
@@ -254,22 +392,47 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *_
         }
     }
     __syncthreads();
-    // flush: consecutive threads walk z, so a wave writes whole 256-B rows
-    const int cells = dx * dy * dz;
-    for (int q = tid; q < cells; q += TSC_BLOCK) {
-        const int z = q % dz, y = (q / dz) % dy, x = q / (dz * dy);
-        double acc = tile[(x * TYS + y) * TZS + z];
-        GT *dst = grid + ((int64_t)(ox + x) * g.gy + (oy + y)) * g.zstride + (oz + z);
-        if (!zero_grid) acc += (double)*dst;
-        GT v = (GT)acc;
-        if (norm != (GT)0) v = v * norm - (GT)1;
-        *dst = v;
+    // flush: consecutive threads walk z, so a wave writes whole rows
+    if (dbg & 2) return;
+    if (dx == TXS && dy == TYS && dz == TZS && sizeof(GT) == 4) {
+        // full tile of a float32 mesh: two cells per thread and store (8-B aligned for any even zstride), index math
+        // by shifts; a wave covers four 128-B rows per store instruction
+        static_assert((TZS & (TZS - 1)) == 0 && (TYS & (TYS - 1)) == 0, "tile dims must be powers of two");
+        constexpr int ZP = TZS / 2;   // pairs per row
+        for (int q = tid; q < TXS * TYS * ZP; q += TSC_BLOCK) {
+            const int zp = q & (ZP - 1), y = (q / ZP) & (TYS - 1), x = q / (ZP * TYS);
+            const double2 acc = *reinterpret_cast<const double2 *>(&tile[(x * TYS + y) * TZS + 2 * zp]);
+            float2 *dst = reinterpret_cast<float2 *>(grid + ((int64_t)(ox + x) * g.gy + (oy + y)) * g.zstride + oz) + zp;
+            double a0 = acc.x, a1 = acc.y;
+            if (!zero_grid) {
+                const float2 old = *dst;
+                a0 += (double)old.x;
+                a1 += (double)old.y;
+            }
+            float2 v = make_float2((float)a0, (float)a1);
+            if (norm != (GT)0) {
+                v.x = v.x * (float)norm - 1.0f;
+                v.y = v.y * (float)norm - 1.0f;
+            }
+            *dst = v;
+        }
+    } else {
+        const int cells = dx * dy * dz;
+        for (int q = tid; q < cells; q += TSC_BLOCK) {
+            const int z = q % dz, y = (q / dz) % dy, x = q / (dz * dy);
+            double acc = tile[(x * TYS + y) * TZS + z];
+            GT *dst = grid + ((int64_t)(ox + x) * g.gy + (oy + y)) * g.zstride + (oz + z);
+            if (!zero_grid) acc += (double)*dst;
+            GT v = (GT)acc;
+            if (norm != (GT)0) v = v * norm - (GT)1;
+            *dst = v;
+        }
     }
 }
 
 // ---- host-side driver ------------------------------------------------------------------------------------
 struct TscWork {
-    DevBuf tile_count, tile_start, entries, flag, scan;
+    DevBuf tile_count, tile_start, entries, flag, scan, gcount, gstart, stage_entry, stage_key;
 };
 TscWork g_work;
 
@@ -298,28 +461,81 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     unsigned int *tile_count = g_work.tile_count.as<unsigned int>();
     int64_t *tile_start = g_work.tile_start.as<int64_t>();
     int *flag = g_work.flag.as<int>();
-    HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)(ntiles + 1) * sizeof(unsigned int), stream()));
     HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), stream()));
-    const int nblk = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, TSC_BLOCK), 1), 256 * 16);
-    if (n > 0)
-        ABACUS_LAUNCH("tsc_bin_count", (tsc_bin<PT, false, CIC>), dim3(nblk), dim3(TSC_BLOCK), 0, pos, n, weights, g,
-                      box, offset, wrap, tile_count, (const int64_t *)nullptr, (Entry<PT> *)nullptr, flag);
-    // exclusive scan of the tile counts (also re-zeroes the counters: they become the FILL cursors)
-    ABACUS_TRY(exclusive_scan_u32(tile_count, ntiles, tile_start, g_work.scan, 1));
-    // list length (needed to size the entry buffer): one 8-byte read-back
-    int64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, tile_start + ntiles, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
-    int h_flag = 0;
-    HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    HIP_TRY(hipStreamSynchronize(stream()));
-    if (wrapped_out) *wrapped_out = h_flag;
-    ABACUS_TRY(g_work.entries.reserve((size_t)std::max<int64_t>(total, 1) * sizeof(Entry<PT>)));
-    Entry<PT> *entries = g_work.entries.as<Entry<PT>>();
-    if (n > 0)
-        ABACUS_LAUNCH("tsc_bin_fill", (tsc_bin<PT, true, CIC>), dim3(nblk), dim3(TSC_BLOCK), 0, pos, n, weights, g, box,
-                      offset, 0, tile_count, (const int64_t *)tile_start, entries, flag);
+    Entry<PT> *entries = nullptr;
+    int cshift = 0;
+    while (((int64_t)ntiles + (1 << cshift) - 1) >> cshift > MS_BINS) cshift++;
+    const bool multisplit = n >= 2000000 && cshift <= 10 && !getenv("ABACUS_TSC_ATOMIC");
+    if (multisplit) {
+        const int ncoarse = (int)(((int64_t)ntiles + (1 << cshift) - 1) >> cshift);
+        ABACUS_TRY(g_work.gcount.reserve((size_t)(MS_BINS + 1) * sizeof(unsigned int)));
+        ABACUS_TRY(g_work.gstart.reserve((size_t)(MS_BINS + 1) * sizeof(int64_t)));
+        unsigned int *gcount = g_work.gcount.as<unsigned int>();
+        int64_t *gstart = g_work.gstart.as<int64_t>();
+        HIP_TRY(hipMemsetAsync(gcount, 0, (size_t)(MS_BINS + 1) * sizeof(unsigned int), stream()));
+        const int cgrid = (int)ceil_div(n, MS_CHUNK);
+        ABACUS_LAUNCH("tsc_ms_coarse_count", (ms_coarse<PT, CIC, false>), dim3(cgrid), dim3(MS_BLOCK), 0, pos, n, weights, g,
+                      box, offset, wrap, cshift, ncoarse, gcount, (const int64_t *)nullptr, (Entry<PT> *)nullptr,
+                      (unsigned int *)nullptr, flag);
+        ABACUS_TRY(exclusive_scan_u32(gcount, ncoarse, gstart, g_work.scan, 1));   // counters re-zeroed: cursors
+        std::vector<int64_t> h_start((size_t)ncoarse + 1);
+        int h_flag = 0;
+        HIP_TRY(hipMemcpyAsync(h_start.data(), gstart, (size_t)(ncoarse + 1) * sizeof(int64_t), hipMemcpyDeviceToHost,
+                               stream()));
+        HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        if (wrapped_out) *wrapped_out = h_flag;
+        const int64_t total = h_start[ncoarse];
+        int64_t maxbucket = 0;
+        for (int b = 0; b < ncoarse; b++) maxbucket = std::max(maxbucket, h_start[b + 1] - h_start[b]);
+        const size_t t1 = (size_t)std::max<int64_t>(total, 1);
+        ABACUS_TRY(g_work.stage_entry.reserve(t1 * sizeof(Entry<PT>)));
+        ABACUS_TRY(g_work.stage_key.reserve(t1 * sizeof(unsigned int)));
+        Entry<PT> *stage_entry = g_work.stage_entry.as<Entry<PT>>();
+        unsigned int *stage_key = g_work.stage_key.as<unsigned int>();
+        ABACUS_LAUNCH("tsc_ms_coarse_scatter", (ms_coarse<PT, CIC, true>), dim3(cgrid), dim3(MS_BLOCK), 0, pos, n, weights,
+                      g, box, offset, 0, cshift, ncoarse, gcount, (const int64_t *)gstart, stage_entry, stage_key, flag);
+        if (cshift == 0) {   // every bucket is a tile already
+            HIP_TRY(hipMemcpyAsync(tile_start, gstart, (size_t)(ntiles + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice,
+                                   stream()));
+            entries = stage_entry;
+        } else {
+            ABACUS_TRY(g_work.entries.reserve(t1 * sizeof(Entry<PT>)));
+            entries = g_work.entries.as<Entry<PT>>();
+            HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)(ntiles + 1) * sizeof(unsigned int), stream()));
+            const dim3 fgrid((unsigned int)std::max<int64_t>(ceil_div(maxbucket, MS_FCHUNK), 1), (unsigned int)ncoarse);
+            ABACUS_LAUNCH("tsc_ms_fine_count", (ms_fine<PT, false>), fgrid, dim3(MS_BLOCK), 0, (const int64_t *)gstart, cshift,
+                          ntiles, (const Entry<PT> *)stage_entry, (const unsigned int *)stage_key, tile_count,
+                          (const int64_t *)nullptr, (Entry<PT> *)nullptr);
+            ABACUS_TRY(exclusive_scan_u32(tile_count, ntiles, tile_start, g_work.scan, 1));
+            ABACUS_LAUNCH("tsc_ms_fine_scatter", (ms_fine<PT, true>), fgrid, dim3(MS_BLOCK), 0, (const int64_t *)gstart, cshift,
+                          ntiles, (const Entry<PT> *)stage_entry, (const unsigned int *)stage_key, tile_count,
+                          (const int64_t *)tile_start, entries);
+        }
+    } else {
+        HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)(ntiles + 1) * sizeof(unsigned int), stream()));
+        const int nblk = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, TSC_BLOCK), 1), 256 * 16);
+        if (n > 0)
+            ABACUS_LAUNCH("tsc_bin_count", (tsc_bin<PT, false, CIC>), dim3(nblk), dim3(TSC_BLOCK), 0, pos, n, weights, g,
+                          box, offset, wrap, tile_count, (const int64_t *)nullptr, (Entry<PT> *)nullptr, flag);
+        // exclusive scan of the tile counts (also re-zeroes the counters: they become the FILL cursors)
+        ABACUS_TRY(exclusive_scan_u32(tile_count, ntiles, tile_start, g_work.scan, 1));
+        // list length (needed to size the entry buffer): one 8-byte read-back
+        int64_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&total, tile_start + ntiles, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+        int h_flag = 0;
+        HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        if (wrapped_out) *wrapped_out = h_flag;
+        ABACUS_TRY(g_work.entries.reserve((size_t)std::max<int64_t>(total, 1) * sizeof(Entry<PT>)));
+        entries = g_work.entries.as<Entry<PT>>();
+        if (n > 0)
+            ABACUS_LAUNCH("tsc_bin_fill", (tsc_bin<PT, true, CIC>), dim3(nblk), dim3(TSC_BLOCK), 0, pos, n, weights, g, box,
+                          offset, 0, tile_count, (const int64_t *)tile_start, entries, flag);
+    }
     ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit<PT, GT, TX, TY, TZ, CIC>), dim3(ntiles), dim3(TSC_BLOCK), 0,
-                  (const Entry<PT> *)entries, (const int64_t *)tile_start, g, box, offset, grid, zero_grid, (GT)norm);
+                  (const Entry<PT> *)entries, (const int64_t *)tile_start, g, box, offset, grid, zero_grid, (GT)norm,
+                  getenv("ABACUS_DBG_TSC") ? atoi(getenv("ABACUS_DBG_TSC")) : 0);
     return 0;
 }
 
@@ -375,6 +591,10 @@ int tsc_release_work() {
     ABACUS_TRY(g_work.entries.release());
     ABACUS_TRY(g_work.flag.release());
     ABACUS_TRY(g_work.scan.release());
+    ABACUS_TRY(g_work.gcount.release());
+    ABACUS_TRY(g_work.gstart.release());
+    ABACUS_TRY(g_work.stage_entry.release());
+    ABACUS_TRY(g_work.stage_key.release());
     return 0;
 }
 }  // namespace abacus

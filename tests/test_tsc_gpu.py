@@ -142,9 +142,10 @@ def test_cic_golden():
     assert np.allclose(dens, g['cic_f4_w.grid'], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize('n,ngrid', [(0, 16), (1, 3), (5, 2), (200000, 77), (3000000, 200)])
+@pytest.mark.parametrize('n,ngrid', [(0, 16), (1, 3), (5, 2), (200000, 77), (3000000, 200), (2500000, 100)])
 def test_vs_oracle_sizes(n, ngrid):
-    """empty input, meshes smaller than a tile / than the cloud, non-multiple-of-tile meshes, 3e6 particles"""
+    """empty input, meshes smaller than a tile / than the cloud, non-multiple-of-tile meshes; the >= 2e6-particle
+    cases go through the two-level multisplit (with and without a fine pass)"""
     from abacusutils_amd.analysis.tsc import tsc_parallel
     from oracle import oracle
     rng = np.random.default_rng(n + ngrid)
