@@ -1,0 +1,322 @@
+// Hand-written 3-D real-to-complex FFT for the P(k) path on MI355X (gfx950): replaces scipy.fft.rfftn at
+// abacusnbody/analysis/power_spectrum.py:980,986,1059 for power-of-two meshes (64 <= n <= 2048); other sizes use
+// hipFFT (power.hip).  Unnormalised forward transform, in place on the pitched mesh layout of power.hip.
+//
+// rocFFT runs this transform as six passes over the mesh (three 1-D FFTs + three transposes, 2.3 TB/s effective);
+// here it is three passes, one per axis, each reading and writing the mesh exactly once:
+//   fft_z_r2c      rows along z (unit stride): a length-n real FFT as a length-n/2 complex FFT in LDS plus the
+//                  even/odd split post-processing; B rows per workgroup, 16-B coalesced loads.
+//   fft_cols       columns along y, then along x (strided): a workgroup stages C adjacent columns (C*8 B contiguous
+//                  per row: 128 B for n <= 1024, 64 B for n = 2048) x n rows in LDS, transposed so that every column
+//                  is contiguous, transforms them in place and writes them back with the same access pattern.
+// The LDS transform is an in-place radix-8/4/2 Sande-Tukey (DIF) FFT: no ping-pong buffer (at n = 2048 a tile of
+// eight columns is 136 KiB of the 160 KiB LDS); the output is left digit-reversed in LDS and un-permuted for free by
+// the write-back.  Twiddles come from a host-computed (float64 -> float32) table held in LDS.
+// HBM traffic: 3 x (4M + 4M) bytes for a mesh of M cells = the 24 B/cell of SURVEY.md 8d.
+#include <cmath>
+#include <map>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace abacus;
+
+namespace {
+
+constexpr int FFT_THREADS = 512;
+constexpr int PADSHIFT = 4;   // one pad element per 16: de-conflicts the stride-R accesses of the late passes
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ int padq(int q) { return q + (q >> PADSHIFT); }
+
+// forward DFTs of size R in registers, natural order in and out (W = exp(-2 pi i / R))
+template <int R>
+__device__ __forceinline__ void dft(float2 (&a)[R]);
+template <>
+__device__ __forceinline__ void dft<2>(float2 (&a)[2]) {
+    const float2 t = a[0];
+    a[0] = cadd(t, a[1]);
+    a[1] = csub(t, a[1]);
+}
+__device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
+    a0 = cadd(t0, t2);
+    a2 = csub(t0, t2);
+    a1 = make_float2(t1.x + t3.y, t1.y - t3.x);   // t1 - i t3
+    a3 = make_float2(t1.x - t3.y, t1.y + t3.x);   // t1 + i t3
+}
+template <>
+__device__ __forceinline__ void dft<4>(float2 (&a)[4]) { dft4(a[0], a[1], a[2], a[3]); }
+template <>
+__device__ __forceinline__ void dft<8>(float2 (&a)[8]) {
+    dft4(a[0], a[2], a[4], a[6]);   // even
+    dft4(a[1], a[3], a[5], a[7]);   // odd
+    const float h = 0.70710678118654752440f;
+    const float2 o0 = a[1];
+    const float2 o1 = make_float2(h * (a[3].x + a[3].y), h * (a[3].y - a[3].x));   // * (h, -h)
+    const float2 o2 = make_float2(a[5].y, -a[5].x);                                // * (-i)
+    const float2 o3 = make_float2(h * (a[7].y - a[7].x), -h * (a[7].x + a[7].y));  // * (-h, -h)
+    const float2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+    a[0] = cadd(e0, o0);
+    a[4] = csub(e0, o0);
+    a[1] = cadd(e1, o1);
+    a[5] = csub(e1, o1);
+    a[2] = cadd(e2, o2);
+    a[6] = csub(e2, o2);
+    a[3] = cadd(e3, o3);
+    a[7] = csub(e3, o3);
+}
+
+constexpr int radix_of(int L) { return L >= 8 ? 8 : L; }   // greedy radix-8, then one radix-4 or radix-2 pass
+
+// position of frequency f after the in-place DIF passes (mixed-radix digit reversal)
+template <int N>
+__device__ __forceinline__ int revpos(int f) {
+    int pos = 0, L = N;
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        if (L == 1) break;
+        const int R = radix_of(L);
+        pos += (f % R) * (L / R);
+        f /= R;
+        L /= R;
+    }
+    return pos;
+}
+
+// one DIF pass of sub-length L over `ncol` columns of N elements each (column c at lds + c*colpitch, padded index)
+template <int N, int L, int R>
+__device__ __forceinline__ void dif_pass(float2 *lds, int colpitch, int ncol, const float2 *tw) {
+    constexpr int BPC = N / R;      // butterflies per column
+    constexpr int LR = L / R;
+    const int total = ncol * BPC;
+    for (int b = threadIdx.x; b < total; b += FFT_THREADS) {
+        const int col = b / BPC, t = b % BPC;
+        const int blk = t / LR, j = t % LR;
+        float2 *c = lds + col * colpitch;
+        const int base = blk * L + j;
+        float2 a[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) a[r] = c[padq(base + r * LR)];
+        dft<R>(a);
+        if (L > R) {   // the last pass has j = 0: all twiddles are one
+#pragma unroll
+            for (int r = 1; r < R; r++) a[r] = cmul(a[r], tw[j * r * (N / L)]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) c[padq(base + r * LR)] = a[r];
+    }
+    __syncthreads();
+}
+
+template <int N, int L>
+struct Passes {
+    static __device__ __forceinline__ void run(float2 *lds, int colpitch, int ncol, const float2 *tw) {
+        constexpr int R = radix_of(L);
+        dif_pass<N, L, R>(lds, colpitch, ncol, tw);
+        Passes<N, L / R>::run(lds, colpitch, ncol, tw);
+    }
+};
+template <int N>
+struct Passes<N, 1> {
+    static __device__ __forceinline__ void run(float2 *, int, int, const float2 *) {}
+};
+
+template <int N>
+constexpr int colpitch_of() { return N + (N >> PADSHIFT) + 1; }   // odd: adjacent columns fall into different banks
+
+// ---- z pass: real rows -> half-spectrum rows, in place ---------------------------------------------------------
+// N = n/2.  mesh rows have `pitch_r` floats; row r of the (n*n) rows starts at r*pitch_r.
+template <int N, int B>
+__global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
+                                                         const float2 *__restrict__ twN, const float2 *__restrict__ tw2N) {
+    constexpr int CP = colpitch_of<N>();
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float2 *lds = tw + N;
+    const int tid = threadIdx.x;
+    for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
+    const int64_t row0 = (int64_t)blockIdx.x * B;
+    const int nb = (int)min((int64_t)B, nrows - row0);
+    // load: two complex (= four consecutive reals) per 16-B load
+    for (int e = tid; e < nb * (N / 2); e += FFT_THREADS) {
+        const int r = e / (N / 2), m = (e % (N / 2)) * 2;
+        const float4 v = *reinterpret_cast<const float4 *>(mesh + (row0 + r) * pitch_r + 2 * m);
+        float2 *c = lds + r * CP;
+        c[padq(m)] = make_float2(v.x, v.y);
+        c[padq(m + 1)] = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    Passes<N, N>::run(lds, CP, nb, tw);
+    // even/odd split: X_k = E + (-i W_2N^k) O, E = (Z_k + conj Z_{N-k})/2, O = (Z_k - conj Z_{N-k})/2, k = 0..N
+    for (int e = tid; e < nb * (N + 1); e += FFT_THREADS) {
+        const int r = e / (N + 1), k = e % (N + 1);
+        const float2 *c = lds + r * CP;
+        const float2 zk = c[padq(revpos<N>(k & (N - 1)))];
+        const float2 zn = c[padq(revpos<N>((N - k) & (N - 1)))];
+        const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const float2 O = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
+        const float2 w = tw2N[k];                            // exp(-2 pi i k / 2N) = (cos, -sin)
+        const float2 miw = make_float2(w.y, -w.x);           // -i * w
+        const float2 X = cadd(E, cmul(miw, O));
+        reinterpret_cast<float2 *>(mesh + (row0 + r) * pitch_r)[k] = X;
+    }
+}
+
+// ---- strided pass: C adjacent columns x N elements (element stride S complex), in place ----------------------
+// tile t -> (outer index o = t / ntile_c, column tile ct = t % ntile_c); first element at o*outer_stride + ct*C
+template <int N, int C>
+__global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ data, int64_t S, int ntile_c,
+                                                        int64_t outer_stride, const float2 *__restrict__ twN) {
+    constexpr int CP = colpitch_of<N>();
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float2 *lds = tw + N;
+    const int tid = threadIdx.x;
+    for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
+    const int64_t o = blockIdx.x / ntile_c;
+    const int ct = blockIdx.x % ntile_c;
+    float2 *g = data + o * outer_stride + (int64_t)ct * C;
+    // load: lanes walk the C columns of one row first (C*8 B contiguous), two columns per 16-B load
+    for (int e = tid; e < N * (C / 2); e += FFT_THREADS) {
+        const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
+        const float4 v = *reinterpret_cast<const float4 *>(g + (int64_t)y * S + c2);
+        lds[c2 * CP + padq(y)] = make_float2(v.x, v.y);
+        lds[(c2 + 1) * CP + padq(y)] = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    Passes<N, N>::run(lds, CP, C, tw);
+    for (int e = tid; e < N * (C / 2); e += FFT_THREADS) {
+        const int c2 = (e % (C / 2)) * 2, f = e / (C / 2);
+        const int p = padq(revpos<N>(f));
+        const float2 a = lds[c2 * CP + p], b = lds[(c2 + 1) * CP + p];
+        *reinterpret_cast<float4 *>(g + (int64_t)f * S + c2) = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+struct Tables {
+    DevBuf twN, twHalf, tw2;   // exp(-2 pi i m / n), exp(-2 pi i m / (n/2)), exp(-2 pi i k / n) for k <= n/2
+};
+std::map<int, Tables> g_tables;
+
+int get_tables(int n, Tables **out) {
+    auto it = g_tables.find(n);
+    if (it == g_tables.end()) {
+        Tables t;
+        auto fill = [&](DevBuf &buf, int len, int count) -> int {
+            std::vector<float2> h((size_t)count);
+            for (int m = 0; m < count; m++) {
+                const double th = -2.0 * M_PI * (double)m / (double)len;
+                h[m] = make_float2((float)cos(th), (float)sin(th));
+            }
+            ABACUS_TRY(buf.reserve(h.size() * sizeof(float2)));
+            HIP_TRY(hipMemcpyAsync(buf.p, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, stream()));
+            HIP_TRY(hipStreamSynchronize(stream()));
+            return 0;
+        };
+        ABACUS_TRY(fill(t.twN, n, n));
+        ABACUS_TRY(fill(t.twHalf, n / 2, n / 2));
+        ABACUS_TRY(fill(t.tw2, n, n / 2 + 1));
+        it = g_tables.emplace(n, t).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+template <int N, int B>
+int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
+    const size_t lds = (size_t)(N + B * colpitch_of<N>()) * sizeof(float2);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_z_r2c<N, B>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    ABACUS_LAUNCH("fft_z_r2c", (fft_z_r2c<N, B>), dim3((unsigned int)ceil_div(nrows, B)), dim3(FFT_THREADS), lds, mesh, nrows,
+                  pitch_r, t->twHalf.as<float2>(), t->tw2.as<float2>());
+    return 0;
+}
+
+template <int N, int C>
+int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t outer, int64_t outer_stride, Tables *t) {
+    const size_t lds = (size_t)(N + C * colpitch_of<N>()) * sizeof(float2);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    ABACUS_LAUNCH(name, (fft_cols<N, C>), dim3((unsigned int)(outer * ntile_c)), dim3(FFT_THREADS), lds, data, S, ntile_c,
+                  outer_stride, t->twN.as<float2>());
+    return 0;
+}
+
+template <int N, int C, int BZ>
+int fft3d(float *mesh, int pitch_r, Tables *t, int64_t nx_local) {
+    // nx_local x N x N real mesh (nx_local = N for the single-GPU transform)
+    const int pitch_c = pitch_r / 2, kzlen = N / 2 + 1;
+    const int ntile_c = (kzlen + C - 1) / C;   // the last tile reads into the row padding (pitch_c >= ntile_c*C)
+    if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
+    ABACUS_TRY((launch_z<N / 2, BZ>(mesh, nx_local * N, pitch_r, t)));
+    float2 *data = reinterpret_cast<float2 *>(mesh);
+    // y: for every x-plane, columns along y (element stride pitch_c)
+    ABACUS_TRY((launch_cols<N, C>("fft_cols_y", data, pitch_c, ntile_c, nx_local, (int64_t)N * pitch_c, t)));
+    return 0;
+}
+
+template <int N, int C>
+int fft_x(float2 *data, int pitch_c, Tables *t, int64_t ny_local, int64_t x_stride) {
+    // x: for every y, columns along x (element stride x_stride)
+    const int kzlen = N / 2 + 1;
+    const int ntile_c = (kzlen + C - 1) / C;
+    return launch_cols<N, C>("fft_cols_x", data, x_stride, ntile_c, ny_local, pitch_c, t);
+}
+
+}  // namespace
+
+namespace abacus {
+
+bool fft_native_supported(int n) { return n >= 64 && n <= 2048 && (n & (n - 1)) == 0; }
+
+// z and y passes over `nx_local` consecutive x-planes (the part of the transform that is local to an x-slab)
+int fft_native_zy(float *mesh, int n, int pitch_r, int64_t nx_local) {
+    Tables *t;
+    ABACUS_TRY(get_tables(n, &t));
+    switch (n) {
+        case 64: return fft3d<64, 16, 16>(mesh, pitch_r, t, nx_local);
+        case 128: return fft3d<128, 16, 16>(mesh, pitch_r, t, nx_local);
+        case 256: return fft3d<256, 16, 8>(mesh, pitch_r, t, nx_local);
+        case 512: return fft3d<512, 16, 8>(mesh, pitch_r, t, nx_local);
+        case 1024: return fft3d<1024, 16, 4>(mesh, pitch_r, t, nx_local);
+        case 2048: return fft3d<2048, 8, 4>(mesh, pitch_r, t, nx_local);
+    }
+    return fail("fft: unsupported size %d", n);
+}
+
+// x pass over `ny_local` rows of y: element (x, y, k) at data[x*x_stride + y*pitch_c + k]
+int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_stride) {
+    Tables *t;
+    ABACUS_TRY(get_tables(n, &t));
+    float2 *data = reinterpret_cast<float2 *>(mesh);
+    const int pitch_c = pitch_r / 2;
+    switch (n) {
+        case 64: return fft_x<64, 16>(data, pitch_c, t, ny_local, x_stride);
+        case 128: return fft_x<128, 16>(data, pitch_c, t, ny_local, x_stride);
+        case 256: return fft_x<256, 16>(data, pitch_c, t, ny_local, x_stride);
+        case 512: return fft_x<512, 16>(data, pitch_c, t, ny_local, x_stride);
+        case 1024: return fft_x<1024, 16>(data, pitch_c, t, ny_local, x_stride);
+        case 2048: return fft_x<2048, 8>(data, pitch_c, t, ny_local, x_stride);
+    }
+    return fail("fft: unsupported size %d", n);
+}
+
+int fft_native_r2c_inplace(float *mesh, int n, int pitch_r) {
+    ABACUS_TRY(fft_native_zy(mesh, n, pitch_r, n));
+    return fft_native_x(mesh, n, pitch_r, n, (int64_t)n * (pitch_r / 2));
+}
+
+int fft_native_release() {
+    for (auto &kv : g_tables) {
+        ABACUS_TRY(kv.second.twN.release());
+        ABACUS_TRY(kv.second.twHalf.release());
+        ABACUS_TRY(kv.second.tw2.release());
+    }
+    g_tables.clear();
+    return 0;
+}
+
+}  // namespace abacus

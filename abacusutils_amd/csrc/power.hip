@@ -39,6 +39,9 @@ namespace abacus {
 int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
                     double offset, int wrap, double norm, int cic);
 int tsc_release_work();
+bool fft_native_supported(int n);
+int fft_native_r2c_inplace(float *mesh, int n, int pitch_r);
+int fft_native_release();
 }  // namespace abacus
 
 namespace {
@@ -426,8 +429,9 @@ int ensure_phase(int n) {
 // deposit + FFT of one particle set into mesh slots [slot] (and [slot+1] when interlaced); device particle arrays
 int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, int paste, int interlaced, int slot) {
     if (n <= 0) return fail("power: empty particle set");
-    hipfftHandle plan;
-    ABACUS_TRY(get_plan(nmesh, &plan));
+    const bool native = fft_native_supported(nmesh) && !getenv("ABACUS_FFT_HIPFFT");
+    hipfftHandle plan = 0;
+    if (!native) ABACUS_TRY(get_plan(nmesh, &plan));
     const int64_t zstride = pitch_r(nmesh);
     const double M = (double)nmesh * nmesh * nmesh;
     const double norm = (double)(float)(M / (double)n);   // dtype(field.size / tot_weight), tot_weight = len(pos) (:856,894)
@@ -437,10 +441,14 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
         float *mesh = g_ctx.mesh[slot + s].as<float>();
         // tsc_parallel wraps pos in place on the first call (tsc.py:171-173); the shifted deposit sees wrapped pos
         ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste));
-        prof_begin("hipfft_r2c");
-        hipfftResult r = hipfftExecR2C(plan, (hipfftReal *)mesh, (hipfftComplex *)mesh);
-        prof_end("hipfft_r2c");
-        ABACUS_TRY(fft_check(r, "hipfftExecR2C"));
+        if (native) {
+            ABACUS_TRY(fft_native_r2c_inplace(mesh, nmesh, (int)zstride));   // fft.hip: three passes, one per axis
+        } else {
+            prof_begin("hipfft_r2c");
+            hipfftResult r = hipfftExecR2C(plan, (hipfftReal *)mesh, (hipfftComplex *)mesh);
+            prof_end("hipfft_r2c");
+            ABACUS_TRY(fft_check(r, "hipfftExecR2C"));
+        }
     }
     return 0;
 }
@@ -713,6 +721,7 @@ int abacus_power_release(void) {
     for (DevBuf *b : {&g_ctx.W, &g_ctx.phase, &g_ctx.edges, &g_ctx.accum, &g_ctx.pos, &g_ctx.pos2, &g_ctx.w, &g_ctx.w2})
         ABACUS_TRY(b->release());
     g_ctx.phase_n = 0;
+    ABACUS_TRY(fft_native_release());
     return tsc_release_work();
 }
 

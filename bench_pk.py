@@ -60,6 +60,7 @@ def bench_pk(args, dist, headline):
     alg_bytes_total = 12.0 * n + 36.0 * M   # SURVEY.md 8d, non-interlaced
     alg = {
         'hipfft_r2c': 24.0 * M,            # three 1-D passes x (read + write) of the 4M-byte mesh/half-spectrum
+        'fft_z_r2c': 8.0 * M, 'fft_cols_y': 8.0 * M, 'fft_cols_x': 8.0 * M,   # one pass each: read 4M + write 4M
         'tsc_tile_deposit': 4.0 * M + 16.0 * 1.3 * n,
         'spectrum_bin': 4.0 * M,
         'tsc_bin_count': 12.0 * n,
