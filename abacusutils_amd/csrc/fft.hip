@@ -14,6 +14,7 @@
 // the write-back.  Twiddles come from a host-computed (float64 -> float32) table held in LDS.
 // HBM traffic: 3 x (4M + 4M) bytes for a mesh of M cells = the 24 B/cell of SURVEY.md 8d.
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -128,72 +129,142 @@ template <int N>
 constexpr int colpitch_of() { return N + (N >> PADSHIFT) + 1; }   // odd: adjacent columns fall into different banks
 
 // ---- z pass: real rows -> half-spectrum rows, in place ---------------------------------------------------------
-// N = n/2.  mesh rows have `pitch_r` floats; row r of the (n*n) rows starts at r*pitch_r.
+// N = n/2.  mesh rows have `pitch_r` floats; row r of the (n*n) rows starts at r*pitch_r.  Persistent workgroups:
+// while a tile of B rows is transformed in LDS the next tile is already in flight into registers.
 template <int N, int B>
 __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
-                                                         const float2 *__restrict__ twN, const float2 *__restrict__ tw2N) {
+                                                         const float2 *__restrict__ twN, const float2 *__restrict__ tw2N,
+                                                         int dbg) {
     constexpr int CP = colpitch_of<N>();
+    constexpr int NLD = (B * (N / 2) + FFT_THREADS - 1) / FFT_THREADS;   // 16-B loads per thread and tile
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float2 *lds = tw + N;
     const int tid = threadIdx.x;
     for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
-    const int64_t row0 = (int64_t)blockIdx.x * B;
-    const int nb = (int)min((int64_t)B, nrows - row0);
-    // load: two complex (= four consecutive reals) per 16-B load
-    for (int e = tid; e < nb * (N / 2); e += FFT_THREADS) {
-        const int r = e / (N / 2), m = (e % (N / 2)) * 2;
-        const float4 v = *reinterpret_cast<const float4 *>(mesh + (row0 + r) * pitch_r + 2 * m);
-        float2 *c = lds + r * CP;
-        c[padq(m)] = make_float2(v.x, v.y);
-        c[padq(m + 1)] = make_float2(v.z, v.w);
-    }
-    __syncthreads();
-    Passes<N, N>::run(lds, CP, nb, tw);
-    // even/odd split: X_k = E + (-i W_2N^k) O, E = (Z_k + conj Z_{N-k})/2, O = (Z_k - conj Z_{N-k})/2, k = 0..N
-    for (int e = tid; e < nb * (N + 1); e += FFT_THREADS) {
-        const int r = e / (N + 1), k = e % (N + 1);
-        const float2 *c = lds + r * CP;
-        const float2 zk = c[padq(revpos<N>(k & (N - 1)))];
-        const float2 zn = c[padq(revpos<N>((N - k) & (N - 1)))];
-        const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-        const float2 O = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-        const float2 w = tw2N[k];                            // exp(-2 pi i k / 2N) = (cos, -sin)
-        const float2 miw = make_float2(w.y, -w.x);           // -i * w
-        const float2 X = cadd(E, cmul(miw, O));
-        reinterpret_cast<float2 *>(mesh + (row0 + r) * pitch_r)[k] = X;
+    const int64_t ntiles = (nrows + B - 1) / B;
+    const int pitch_c = pitch_r / 2;
+    float4 regs[NLD];
+    auto prefetch = [&](int64_t tile) {
+        const int64_t row0 = tile * B;
+        const int nb = (int)min((int64_t)B, nrows - row0);
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int e = q * FFT_THREADS + tid;
+            const int r = e / (N / 2), m = (e % (N / 2)) * 2;
+            regs[q] = r < nb ? *reinterpret_cast<const float4 *>(mesh + (row0 + r) * pitch_r + 2 * m)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * B;
+        const int nb = (int)min((int64_t)B, nrows - row0);
+        // registers -> LDS: two complex (= four consecutive reals) per 16-B load
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int e = q * FFT_THREADS + tid;
+            const int r = e / (N / 2), m = (e % (N / 2)) * 2;
+            if (r < B) {
+                float2 *c = lds + r * CP;
+                c[padq(m)] = make_float2(regs[q].x, regs[q].y);
+                c[padq(m + 1)] = make_float2(regs[q].z, regs[q].w);
+            }
+        }
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);   // in flight during the transform below
+        if (!(dbg & 1)) Passes<N, N>::run(lds, CP, nb, tw);
+        // even/odd split: X_k = E + (-i W_2N^k) O with E = (Z_k + conj Z_{N-k})/2, O = (Z_k - conj Z_{N-k})/2, k = 0..N.
+        // A thread forms two adjacent outputs (one 16-B store); the row is written over its whole pitch (zeros behind
+        // k = N) so that no partial 128-B line is ever written.
+        if (!(dbg & 2))
+            for (int e = tid; e < nb * (pitch_c / 2); e += FFT_THREADS) {
+                const int r = e / (pitch_c / 2), k0 = (e % (pitch_c / 2)) * 2;
+                const float2 *c = lds + r * CP;
+                float2 X[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int k = k0 + u;
+                    X[u] = make_float2(0.f, 0.f);
+                    if (k <= N) {
+                        const float2 zk = c[padq(revpos<N>(k & (N - 1)))];
+                        const float2 zn = c[padq(revpos<N>((N - k) & (N - 1)))];
+                        const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+                        const float2 O = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
+                        const float2 w = tw2N[k];                            // exp(-2 pi i k / 2N) = (cos, -sin)
+                        const float2 miw = make_float2(w.y, -w.x);           // -i * w
+                        X[u] = cadd(E, cmul(miw, O));
+                    }
+                }
+                *reinterpret_cast<float4 *>(mesh + (row0 + r) * pitch_r + 2 * k0) =
+                    make_float4(X[0].x, X[0].y, X[1].x, X[1].y);
+            }
+        __syncthreads();
     }
 }
 
 // ---- strided pass: C adjacent columns x N elements (element stride S complex), in place ----------------------
-// tile t -> (outer index o = t / ntile_c, column tile ct = t % ntile_c); first element at o*outer_stride + ct*C
+// tile t -> (outer index o = t / ntile_c, column tile ct = t % ntile_c); first element at o*outer_stride + ct*C.
+// Persistent workgroups with the next tile prefetched into registers, as above.
 template <int N, int C>
 __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ data, int64_t S, int ntile_c,
-                                                        int64_t outer_stride, const float2 *__restrict__ twN) {
+                                                        int64_t ntiles, int64_t outer_stride,
+                                                        const float2 *__restrict__ twN, int dbg) {
     constexpr int CP = colpitch_of<N>();
+    constexpr int NLD = (N * (C / 2) + FFT_THREADS - 1) / FFT_THREADS;
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float2 *lds = tw + N;
     const int tid = threadIdx.x;
     for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
-    const int64_t o = blockIdx.x / ntile_c;
-    const int ct = blockIdx.x % ntile_c;
-    float2 *g = data + o * outer_stride + (int64_t)ct * C;
-    // load: lanes walk the C columns of one row first (C*8 B contiguous), two columns per 16-B load
-    for (int e = tid; e < N * (C / 2); e += FFT_THREADS) {
-        const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
-        const float4 v = *reinterpret_cast<const float4 *>(g + (int64_t)y * S + c2);
-        lds[c2 * CP + padq(y)] = make_float2(v.x, v.y);
-        lds[(c2 + 1) * CP + padq(y)] = make_float2(v.z, v.w);
+    float4 regs[NLD];
+    auto tile_base = [&](int64_t t) { return data + (t / ntile_c) * outer_stride + (t % ntile_c) * C; };
+    auto prefetch = [&](int64_t t) {
+        const float2 *g = tile_base(t);
+        // lanes walk the C columns of one row first (C*8 B contiguous), two columns per 16-B load
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int e = q * FFT_THREADS + tid;
+            const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
+            regs[q] = y < N ? *reinterpret_cast<const float4 *>(g + (int64_t)y * S + c2) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int64_t t = blockIdx.x;
+    if (t < ntiles) prefetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int e = q * FFT_THREADS + tid;
+            const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
+            if (y < N) {
+                lds[c2 * CP + padq(y)] = make_float2(regs[q].x, regs[q].y);
+                lds[(c2 + 1) * CP + padq(y)] = make_float2(regs[q].z, regs[q].w);
+            }
+        }
+        __syncthreads();
+        if (t + gridDim.x < ntiles) prefetch(t + gridDim.x);
+        if (!(dbg & 1)) Passes<N, N>::run(lds, CP, C, tw);
+        if (!(dbg & 2)) {
+            float2 *g = tile_base(t);
+            for (int e = tid; e < N * (C / 2); e += FFT_THREADS) {
+                const int c2 = (e % (C / 2)) * 2, f = e / (C / 2);
+                const int p = padq(revpos<N>(f));
+                const float2 a = lds[c2 * CP + p], b = lds[(c2 + 1) * CP + p];
+                *reinterpret_cast<float4 *>(g + (int64_t)f * S + c2) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    Passes<N, N>::run(lds, CP, C, tw);
-    for (int e = tid; e < N * (C / 2); e += FFT_THREADS) {
-        const int c2 = (e % (C / 2)) * 2, f = e / (C / 2);
-        const int p = padq(revpos<N>(f));
-        const float2 a = lds[c2 * CP + p], b = lds[(c2 + 1) * CP + p];
-        *reinterpret_cast<float4 *>(g + (int64_t)f * S + c2) = make_float4(a.x, a.y, b.x, b.y);
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     }
+    return n;
 }
 
 struct Tables {
@@ -230,8 +301,12 @@ int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
     const size_t lds = (size_t)(N + B * colpitch_of<N>()) * sizeof(float2);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_z_r2c<N, B>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    ABACUS_LAUNCH("fft_z_r2c", (fft_z_r2c<N, B>), dim3((unsigned int)ceil_div(nrows, B)), dim3(FFT_THREADS), lds, mesh, nrows,
-                  pitch_r, t->twHalf.as<float2>(), t->tw2.as<float2>());
+    const int64_t ntiles = ceil_div(nrows, B);
+    int per_cu = 1;   // persistent grid = exactly the resident workgroups (a larger grid would run in two uneven waves)
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_z_r2c<N, B>, FFT_THREADS, lds));
+    const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
+    ABACUS_LAUNCH("fft_z_r2c", (fft_z_r2c<N, B>), dim3(grid), dim3(FFT_THREADS), lds, mesh, nrows,
+                  pitch_r, t->twHalf.as<float2>(), t->tw2.as<float2>(), getenv("ABACUS_DBG_FFT") ? atoi(getenv("ABACUS_DBG_FFT")) : 0);
     return 0;
 }
 
@@ -240,8 +315,12 @@ int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t 
     const size_t lds = (size_t)(N + C * colpitch_of<N>()) * sizeof(float2);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    ABACUS_LAUNCH(name, (fft_cols<N, C>), dim3((unsigned int)(outer * ntile_c)), dim3(FFT_THREADS), lds, data, S, ntile_c,
-                  outer_stride, t->twN.as<float2>());
+    const int64_t ntiles = outer * ntile_c;
+    int per_cu = 1;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_cols<N, C>, FFT_THREADS, lds));
+    const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
+    ABACUS_LAUNCH(name, (fft_cols<N, C>), dim3(grid), dim3(FFT_THREADS), lds, data, S, ntile_c, ntiles,
+                  outer_stride, t->twN.as<float2>(), getenv("ABACUS_DBG_FFT") ? atoi(getenv("ABACUS_DBG_FFT")) : 0);
     return 0;
 }
 
