@@ -1,0 +1,386 @@
+"""Multi-GPU P(k): x-slab mesh decomposition of `calc_power` over the GPUs of one node.
+
+New functionality relative to the reference (its TSC "can't readily scale to multiple nodes",
+docs/tutorials/analysis/tsc.ipynb:19); the result is the same estimator as
+abacusnbody/analysis/power_spectrum.py:1131-1319 evaluated on the union of the ranks' particles.
+
+One process per GPU.  Rank r owns mesh planes [r*n/W, (r+1)*n/W) and the particles whose wrapped x lies in that
+slab (`route_particles` moves them there).  Per field:
+
+    deposit           local planes + GHOST planes on both sides (TSC cloud +-1 cell, +1 for the half-cell
+                      interlacing shift, +1 for round-half-even at the upper slab edge)      [device]
+    ghost exchange    the ghost blocks go to the two ring neighbours, which add them         [send/recv, 2 x 3 planes]
+    z, y FFT passes   on the owned planes                                                    [device]
+    pencil transpose  (x_local, y, k) -> (y_local, x, k): pack, ALL-TO-ALL, unpack           [RCCL all-to-all over xGMI:
+                      one block per peer, every link busy at once]
+    x FFT pass        on the y-slab                                                          [device]
+    binning           raw (k, mu) / multipole sums of the y-slab                             [device]
+    all-reduce        of the few-KB histogram, then bin_kmu's normalisation                  [RCCL all-reduce]
+
+Collectives go through torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests); the device
+buffers are exposed to torch through `__cuda_array_interface__`, so RCCL works on the library's own allocations
+without staging.  `SlabComm(..., device_collectives=False)` stages through host memory instead (gloo): used for
+tests, including two ranks sharing one GPU.
+Restrictions: nmesh a power of two in [64, 2048] (hand-written FFT passes), nmesh % W == 0, nmesh/W >= GHOST.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .power_spectrum import Table, get_k_mu_edges, get_W_compensated
+
+GHOST = 3  # ghost planes on each side of a slab
+
+
+class HipBuf:
+    """float32 device buffer (DeviceArray) with the views the communicator needs"""
+
+    def __init__(self, nfloat):
+        self.n = int(nfloat)
+        self.dev = _lib.DeviceArray(nbytes=self.n * 4, dtype=np.float32, shape=(self.n,))
+
+    def ptr(self, off=0):
+        return C.c_void_p(self.dev.ptr.value + 4 * int(off))
+
+    def get(self, off, n):
+        out = np.empty(int(n), dtype=np.float32)
+        _lib.check(_lib.lib().abacus_memcpy_d2h(_lib.ptr(out), self.ptr(off), C.c_uint64(out.nbytes)))
+        return out
+
+    def set(self, off, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        _lib.check(_lib.lib().abacus_memcpy_h2d(self.ptr(off), _lib.ptr(arr), C.c_uint64(arr.nbytes)))
+
+    def torch_view(self, off, n):
+        import torch
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f4', 'data': (self.dev.ptr.value + 4 * int(off), False),
+                                      'version': 2, 'strides': None}
+        return torch.as_tensor(v, device='cuda')
+
+    def free(self):
+        self.dev.free()
+
+
+class HipSlabBackend:
+    """device side of the slab estimator: thin wrappers over the abacus_slab_* entry points"""
+    name = 'hip'
+
+    def pitch(self, nmesh):
+        return int(_lib.lib().abacus_slab_pitch(int(nmesh)))
+
+    def new_buffer(self, nfloat):
+        return HipBuf(nfloat)
+
+    def upload_particles(self, pos, w):
+        self._pos = _lib.DeviceArray(np.ascontiguousarray(pos, dtype=np.float32))
+        self._w = None if w is None else _lib.DeviceArray(np.ascontiguousarray(w, dtype=np.float32))
+        return self._pos, self._w
+
+    def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste):
+        pos, w = particles
+        n = pos.shape[0]
+        _lib.check(_lib.lib().abacus_slab_deposit_dev(pos.ptr, C.c_int64(n), None if w is None else w.ptr, mesh.ptr(0),
+                                                      int(nmesh), int(xoff), int(nx_total), C.c_double(Lbox),
+                                                      C.c_double(offset), C.c_double(norm), int(paste)))
+
+    def axpy(self, dst, dst_off, src, src_off, nfloat, add):
+        _lib.check(_lib.lib().abacus_slab_axpy_dev(dst.ptr(dst_off), None if src is None else src.ptr(src_off),
+                                                   C.c_int64(nfloat), C.c_float(add)))
+
+    def fft_zy(self, mesh, off, nmesh, nxl):
+        _lib.check(_lib.lib().abacus_slab_fft_zy_dev(mesh.ptr(off), int(nmesh), int(nxl)))
+
+    def pack(self, mesh, off, send, nmesh, nxl, world):
+        _lib.check(_lib.lib().abacus_slab_pack_dev(mesh.ptr(off), send.ptr(0), int(nmesh), int(nxl), int(world)))
+
+    def unpack(self, recv, out, off, nmesh, nxl, world):
+        _lib.check(_lib.lib().abacus_slab_unpack_dev(recv.ptr(0), out.ptr(off), int(nmesh), int(nxl), int(world)))
+
+    def fft_x(self, data, off, nmesh, nyl):
+        _lib.check(_lib.lib().abacus_slab_fft_x_dev(data.ptr(off), int(nmesh), int(nyl)))
+
+    def raw_bytes(self, Nk, Nmu, poles):
+        return int(_lib.lib().abacus_bin_raw_bytes(int(Nk), int(Nmu), _lib.ptr(poles), len(poles)))
+
+    def bin_raw(self, fields, nmesh, y0, nyl, Lbox, W, interlaced, ke, me, poles):
+        (a, ao), (as_, aso), (b, bo), (bs, bso) = fields
+        raw = np.zeros(self.raw_bytes(len(ke) - 1, len(me) - 1, poles), dtype=np.uint8)
+        p = lambda buf, off: None if buf is None else buf.ptr(off)  # noqa: E731
+        _lib.check(_lib.lib().abacus_slab_bin_dev(p(a, ao), p(as_, aso), p(b, bo), p(bs, bso), int(nmesh), int(y0), int(nyl),
+                                                  C.c_double(Lbox), None if W is None else _lib.ptr(W), int(interlaced),
+                                                  _lib.ptr(ke), len(ke) - 1, _lib.ptr(me), len(me) - 1, _lib.ptr(poles),
+                                                  len(poles), _lib.ptr(raw)))
+        return raw
+
+    def finalize(self, raw, Lbox, Nk, Nmu, poles):
+        return finalize_raw(raw, Lbox, Nk, Nmu, poles)
+
+    def sync(self):
+        _lib.sync()
+
+
+def finalize_raw(raw, Lbox, Nk, Nmu, poles):
+    """bin_kmu's normalisation of (all-reduced) raw sums through the C ABI (host only)"""
+    power = np.zeros((Nk, Nmu), dtype=np.float32)
+    N_mode = np.zeros((Nk, Nmu), dtype=np.int64)
+    bp = np.zeros((len(poles), Nk), dtype=np.float32)
+    Nmp = np.zeros(Nk, dtype=np.int64)
+    k_avg = np.zeros((Nk, Nmu), dtype=np.float32)
+    _lib.check(_lib.lib().abacus_bin_finalize(_lib.ptr(raw), C.c_double(Lbox), int(Nk), int(Nmu), _lib.ptr(poles),
+                                              len(poles), _lib.ptr(power), _lib.ptr(N_mode), _lib.ptr(bp), _lib.ptr(Nmp),
+                                              _lib.ptr(k_avg)))
+    return power, N_mode, bp, Nmp, k_avg
+
+
+class SlabComm:
+    """ring send/recv, all-to-all and all-reduce over torch.distributed (or trivially for a single rank)"""
+
+    def __init__(self, device_collectives=False, group=None):
+        self.dist = None
+        self.rank, self.world = 0, 1
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.dist = dist
+                self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        except ImportError:
+            pass
+        self.group = group
+        self.device = bool(device_collectives) and self.world > 1
+
+    def _tensor(self, buf, off, n):
+        import torch
+        if self.device:
+            return buf.torch_view(off, n), None
+        host = buf.get(off, n)
+        return torch.from_numpy(host), host
+
+    def ring_exchange(self, backend, buf, left_off, right_off, recv, n):
+        """send buf[left_off:+n] to rank-1 and buf[right_off:+n] to rank+1;
+        recv[0:n] <- what rank+1 sent left, recv[n:2n] <- what rank-1 sent right"""
+        if self.world == 1:   # the ring neighbour is this rank (periodic box): callers add the ghosts in place
+            raise RuntimeError('ring_exchange needs more than one rank')
+        import torch
+        backend.sync()
+        left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        s_l, _ = self._tensor(buf, left_off, n)
+        s_r, _ = self._tensor(buf, right_off, n)
+        if self.device:
+            r_from_right, r_from_left = recv.torch_view(0, n), recv.torch_view(n, n)
+        else:
+            r_from_right = torch.empty(n, dtype=torch.float32)
+            r_from_left = torch.empty(n, dtype=torch.float32)
+        ops = [self.dist.P2POp(self.dist.isend, s_l, left, self.group), self.dist.P2POp(self.dist.isend, s_r, right, self.group),
+               self.dist.P2POp(self.dist.irecv, r_from_right, right, self.group),
+               self.dist.P2POp(self.dist.irecv, r_from_left, left, self.group)]
+        for req in self.dist.batch_isend_irecv(ops):
+            req.wait()
+        if self.device:
+            torch.cuda.synchronize()
+        else:
+            recv.set(0, r_from_right.numpy())
+            recv.set(n, r_from_left.numpy())
+
+    def all_to_all(self, backend, send, recv, n_total):
+        if self.world == 1:   # callers unpack straight from the send buffer
+            raise RuntimeError('all_to_all needs more than one rank')
+        import torch
+        backend.sync()
+        s, _ = self._tensor(send, 0, n_total)
+        if self.device:
+            r = recv.torch_view(0, n_total)
+            self.dist.all_to_all_single(r, s, group=self.group)
+            torch.cuda.synchronize()
+        else:
+            r = torch.empty(n_total, dtype=torch.float32)
+            if self.dist.get_backend(self.group) == 'gloo':
+                # gloo has no all_to_all_single: W scatter rounds of equal blocks
+                blk = n_total // self.world
+                outs = list(r.split(blk))
+                ins = list(s.split(blk))
+                reqs = []
+                for peer in range(self.world):
+                    if peer == self.rank:
+                        outs[peer].copy_(ins[peer])
+                    else:
+                        reqs.append(self.dist.isend(ins[peer].contiguous(), peer, group=self.group))
+                        reqs.append(self.dist.irecv(outs[peer], peer, group=self.group))
+                for q in reqs:
+                    q.wait()
+            else:
+                self.dist.all_to_all_single(r, s, group=self.group)
+            recv.set(0, r.numpy())
+
+    def all_reduce_raw(self, raw, n_u64):
+        """sum the raw histogram over ranks: first n_u64 entries are uint64 counts, the rest float64"""
+        if self.world == 1:
+            return raw
+        import torch
+        cnt = torch.from_numpy(raw[: n_u64 * 8].view(np.int64).copy())
+        val = torch.from_numpy(raw[n_u64 * 8:].view(np.float64).copy())
+        self.dist.all_reduce(cnt, group=self.group)
+        self.dist.all_reduce(val, group=self.group)
+        out = np.empty_like(raw)
+        out[: n_u64 * 8] = cnt.numpy().view(np.uint8)
+        out[n_u64 * 8:] = val.numpy().view(np.uint8)
+        return out
+
+    def all_reduce_int(self, v):
+        if self.world == 1:
+            return int(v)
+        import torch
+        t = torch.tensor([int(v)], dtype=torch.int64)
+        self.dist.all_reduce(t, group=self.group)
+        return int(t[0])
+
+    def all_reduce_float(self, v):
+        if self.world == 1:
+            return float(v)
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self.dist.all_reduce(t, group=self.group)
+        return float(t[0])
+
+    def all_to_all_host(self, arrays):
+        """variable-size host all-to-all of float32 arrays (particle routing): arrays[p] goes to rank p"""
+        if self.world == 1:
+            return [arrays[0]]
+        import torch
+        sizes = torch.tensor([a.size for a in arrays], dtype=torch.int64)
+        rsizes = torch.empty(self.world, dtype=torch.int64)
+        reqs = []
+        all_sizes = [torch.empty(self.world, dtype=torch.int64) for _ in range(self.world)]
+        self.dist.all_gather(all_sizes, sizes, group=self.group)
+        for p in range(self.world):
+            rsizes[p] = all_sizes[p][self.rank]
+        outs = [np.empty(int(rsizes[p]), dtype=np.float32) for p in range(self.world)]
+        for p in range(self.world):
+            if p == self.rank:
+                outs[p][:] = arrays[p].ravel()
+            else:
+                if arrays[p].size:
+                    reqs.append(self.dist.isend(torch.from_numpy(np.ascontiguousarray(arrays[p].ravel())), p, group=self.group))
+                if outs[p].size:
+                    reqs.append(self.dist.irecv(torch.from_numpy(outs[p]), p, group=self.group))
+        for q in reqs:
+            q.wait()
+        return outs
+
+
+def route_particles(pos, w, Lbox, comm):
+    """send every particle to the rank that owns its x-slab (wrapped x in [r*L/W, (r+1)*L/W)); host-side, for
+    catalogs whose order is not slab-local (e.g. light-cone RSD moves galaxies across slabs)"""
+    pos = np.ascontiguousarray(pos, dtype=np.float32)
+    xw = pos[:, 0] - np.floor(pos[:, 0] / np.float32(Lbox)) * np.float32(Lbox)
+    owner = np.minimum((xw * (comm.world / np.float32(Lbox))).astype(np.int64), comm.world - 1)
+    order = np.argsort(owner, kind='stable')
+    counts = np.bincount(owner, minlength=comm.world)
+    starts = np.concatenate(([0], np.cumsum(counts)))
+    cols = [pos[order]] + ([np.ascontiguousarray(w, dtype=np.float32)[order]] if w is not None else [])
+    out = []
+    for c in cols:
+        parts = [np.ascontiguousarray(c[starts[p]:starts[p + 1]]) for p in range(comm.world)]
+        got = comm.all_to_all_host(parts)
+        out.append(np.concatenate([g.reshape(-1, 3) if c.ndim == 2 else g for g in got]))
+    return out[0], (out[1] if w is not None else None)
+
+
+def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None, k_max=None, logk=False, paste='TSC',
+                    nmesh=128, compensated=True, interlaced=True, w=None, pos2=None, w2=None, poles=None,
+                    squeeze_mu_axis=True, n_total=None, n_total2=None):
+    """`calc_power` (abacusnbody/analysis/power_spectrum.py:1131-1319) over x-slabs.  `pos` / `pos2` are THIS rank's
+    particles (already inside its x-slab, see `route_particles`); every rank returns the full Table."""
+    comm = comm or SlabComm()
+    backend = backend or HipSlabBackend()
+    W, r = comm.world, comm.rank
+    if nmesh % W or nmesh // W < GHOST:
+        raise ValueError(f'nmesh={nmesh} must be divisible by the {W} ranks and leave at least {GHOST} planes per slab')
+    if kbins is None:
+        kbins = nmesh
+    if k_max is None:
+        k_max = np.pi * nmesh / Lbox
+    return_mubins = mubins is not None
+    if mubins is None:
+        mubins = 1
+    code = {'TSC': 0, 'CIC': 1}.get(paste.upper())
+    if code is None:
+        raise ValueError(f'Unknown pasting method {paste}')
+    Wk = get_W_compensated(Lbox, nmesh, paste, interlaced).astype(np.float32) if compensated else None
+    poles_arr = np.asarray(poles or [], dtype=np.int64)
+    kbins, mubins = get_k_mu_edges(Lbox, k_max, kbins, mubins, logk)
+    ke = np.ascontiguousarray(kbins, dtype=np.float64)
+    me = np.ascontiguousarray(mubins, dtype=np.float64)
+
+    nxl = nmesh // W
+    pitch = backend.pitch(nmesh)
+    plane = nmesh * pitch
+    g = GHOST * plane
+    d = Lbox / nmesh
+    nfields = (2 if interlaced else 1) * (2 if pos2 is not None else 1)
+    meshes = [backend.new_buffer((nxl + 2 * GHOST) * plane) for _ in range(nfields)]
+    send = backend.new_buffer(nxl * plane)
+    recv = backend.new_buffer(nxl * plane)
+    ghost = backend.new_buffer(2 * g)
+    x0 = r * nxl
+
+    def spectrum(particles, ntot, offset, mesh):
+        norm = float(np.float32(float(nmesh) ** 3 / float(ntot)))   # dtype(field.size / tot_weight) (:856,894)
+        backend.deposit(particles, mesh, nmesh, (x0 - GHOST) % nmesh, nxl + 2 * GHOST, Lbox, offset, norm, code)
+        # left ghost block -> left neighbour, right ghost block -> right neighbour
+        if W > 1:
+            comm.ring_exchange(backend, mesh, 0, (GHOST + nxl) * plane, ghost, g)
+            # ghost[0:g]  came from the right neighbour (its left ghosts)  = my last GHOST owned planes
+            # ghost[g:2g] came from the left neighbour (its right ghosts)  = my first GHOST owned planes
+            backend.axpy(mesh, nxl * plane, ghost, 0, g, 0.0)
+            backend.axpy(mesh, GHOST * plane, ghost, g, g, 0.0)
+        else:                                                                  # periodic box on one rank
+            backend.axpy(mesh, nxl * plane, mesh, 0, g, 0.0)
+            backend.axpy(mesh, GHOST * plane, mesh, (GHOST + nxl) * plane, g, 0.0)
+        backend.axpy(mesh, GHOST * plane, None, 0, nxl * plane, -1.0)          # delta = rho*norm - 1 on the owned planes
+        backend.fft_zy(mesh, GHOST * plane, nmesh, nxl)
+        backend.pack(mesh, GHOST * plane, send, nmesh, nxl, W)
+        if W > 1:
+            comm.all_to_all(backend, send, recv, nxl * plane)
+        backend.unpack(recv if W > 1 else send, mesh, GHOST * plane, nmesh, nxl, W)   # mesh now holds (y_local, x, k)
+        backend.fft_x(mesh, GHOST * plane, nmesh, nxl)
+        return (mesh, GHOST * plane)
+
+    sets = [(pos, w, n_total)] + ([(pos2, w2, n_total2)] if pos2 is not None else [])
+    fields = []
+    mi = 0
+    for p_, w_, nt in sets:
+        ntot = nt if nt is not None else comm.all_reduce_int(len(p_))   # tot_weight = len(pos), also with weights (:1021)
+        particles = backend.upload_particles(p_, w_)
+        fields.append(spectrum(particles, ntot, 0.0, meshes[mi]))
+        mi += 1
+        if interlaced:
+            fields.append(spectrum(particles, ntot, 0.5 * d, meshes[mi]))
+            mi += 1
+        else:
+            fields.append((None, 0))
+    if pos2 is None:
+        fields += [(None, 0), (None, 0)]
+    raw = backend.bin_raw(fields, nmesh, r * nxl, nxl, Lbox, Wk, interlaced, ke, me, poles_arr)
+    raw = comm.all_reduce_raw(raw, (len(ke) - 1) * (len(me) - 1))
+    power, N_mode, bp, Nmp, k_avg = backend.finalize(raw, Lbox, len(ke) - 1, len(me) - 1, poles_arr)
+    for b in meshes + [send, recv, ghost]:
+        if hasattr(b, 'free'):
+            b.free()
+    if squeeze_mu_axis and len(me) == 2:
+        power, N_mode, k_avg = power[:, 0], N_mode[:, 0], k_avg[:, 0]
+    res = dict(k_min=kbins[:-1], k_max=kbins[1:], k_mid=(kbins[1:] + kbins[:-1]) * 0.5, k_avg=k_avg, power=power,
+               N_mode=N_mode)
+    if len(poles_arr) > 0:
+        res.update(poles=bp.T, N_mode_poles=Nmp)
+    if return_mubins:
+        mu_binc = (mubins[1:] + mubins[:-1]) * 0.5
+        res.update(mu_min=np.broadcast_to(mubins[:-1], res['power'].shape),
+                   mu_max=np.broadcast_to(mubins[1:], res['power'].shape),
+                   mu_mid=np.broadcast_to(mu_binc, res['power'].shape))
+    return Table(res, meta=dict(Lbox=Lbox, nmesh=nmesh, paste=paste, compensated=compensated, interlaced=interlaced,
+                                n_ranks=W))

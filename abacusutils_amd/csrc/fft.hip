@@ -338,11 +338,12 @@ int fft3d(float *mesh, int pitch_r, Tables *t, int64_t nx_local) {
 }
 
 template <int N, int C>
-int fft_x(float2 *data, int pitch_c, Tables *t, int64_t ny_local, int64_t x_stride) {
+int fft_x(float2 *data, int pitch_c, Tables *t, int64_t ny_local, int64_t x_stride, int64_t y_stride) {
     // x: for every y, columns along x (element stride x_stride)
     const int kzlen = N / 2 + 1;
     const int ntile_c = (kzlen + C - 1) / C;
-    return launch_cols<N, C>("fft_cols_x", data, x_stride, ntile_c, ny_local, pitch_c, t);
+    (void)pitch_c;
+    return launch_cols<N, C>("fft_cols_x", data, x_stride, ntile_c, ny_local, y_stride, t);
 }
 
 }  // namespace
@@ -366,26 +367,26 @@ int fft_native_zy(float *mesh, int n, int pitch_r, int64_t nx_local) {
     return fail("fft: unsupported size %d", n);
 }
 
-// x pass over `ny_local` rows of y: element (x, y, k) at data[x*x_stride + y*pitch_c + k]
-int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_stride) {
+// x pass over `ny_local` rows of y: element (x, y, k) at data[x*x_stride + y*y_stride + k]
+int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_stride, int64_t y_stride) {
     Tables *t;
     ABACUS_TRY(get_tables(n, &t));
     float2 *data = reinterpret_cast<float2 *>(mesh);
     const int pitch_c = pitch_r / 2;
     switch (n) {
-        case 64: return fft_x<64, 16>(data, pitch_c, t, ny_local, x_stride);
-        case 128: return fft_x<128, 16>(data, pitch_c, t, ny_local, x_stride);
-        case 256: return fft_x<256, 16>(data, pitch_c, t, ny_local, x_stride);
-        case 512: return fft_x<512, 16>(data, pitch_c, t, ny_local, x_stride);
-        case 1024: return fft_x<1024, 16>(data, pitch_c, t, ny_local, x_stride);
-        case 2048: return fft_x<2048, 8>(data, pitch_c, t, ny_local, x_stride);
+        case 64: return fft_x<64, 16>(data, pitch_c, t, ny_local, x_stride, y_stride);
+        case 128: return fft_x<128, 16>(data, pitch_c, t, ny_local, x_stride, y_stride);
+        case 256: return fft_x<256, 16>(data, pitch_c, t, ny_local, x_stride, y_stride);
+        case 512: return fft_x<512, 16>(data, pitch_c, t, ny_local, x_stride, y_stride);
+        case 1024: return fft_x<1024, 16>(data, pitch_c, t, ny_local, x_stride, y_stride);
+        case 2048: return fft_x<2048, 8>(data, pitch_c, t, ny_local, x_stride, y_stride);
     }
     return fail("fft: unsupported size %d", n);
 }
 
 int fft_native_r2c_inplace(float *mesh, int n, int pitch_r) {
     ABACUS_TRY(fft_native_zy(mesh, n, pitch_r, n));
-    return fft_native_x(mesh, n, pitch_r, n, (int64_t)n * (pitch_r / 2));
+    return fft_native_x(mesh, n, pitch_r, n, (int64_t)n * (pitch_r / 2), pitch_r / 2);
 }
 
 int fft_native_release() {

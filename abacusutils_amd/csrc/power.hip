@@ -41,6 +41,10 @@ int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmes
 int tsc_release_work();
 bool fft_native_supported(int n);
 int fft_native_r2c_inplace(float *mesh, int n, int pitch_r);
+int fft_native_zy(float *mesh, int n, int pitch_r, int64_t nx_local);
+int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_stride, int64_t y_stride);
+int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
+                         int64_t zstride, double box, double offset, int wrap, double norm, int cic);
 int fft_native_release();
 }  // namespace abacus
 
@@ -51,6 +55,8 @@ constexpr int BIN_THREADS = 1024;
 
 struct SpecArgs {
     int n, kzlen, pitch;      // pitch: complex elements per (kx, ky) row in memory (>= kzlen)
+    int rowmode, y0;          // 0: row = kx*n + ky (full spectrum); 1: row = ky_local*n + kx, ky = y0 + ky_local (y-slab)
+    int64_t nrows;            // rows held in memory (n*n, or ny_local*n for a y-slab)
     int mode;                 // 0: raw fields (deltak API), 1: FFT output needing scale/interlace/compensation
     int interlaced, compensated, cross;
     float inv_size;           // f32(1/M)            (:1058)
@@ -61,6 +67,13 @@ struct SpecArgs {
 };
 
 __device__ __forceinline__ int fold(int i, int n) { return i < n / 2 ? i : i - n; }   // (:234,237,940-942)
+__device__ __forceinline__ void row_ij(const SpecArgs &s, int64_t row, int &i, int &j) {
+    if (s.rowmode == 0) {
+        j = (int)(row % s.n), i = (int)(row / s.n);
+    } else {
+        i = (int)(row % s.n), j = s.y0 + (int)(row / s.n);
+    }
+}
 
 // final delta_k of one field at (i, j, k) from the raw FFT output v (and the shifted field's w): what get_field_fft
 // returns (:1046-1070)
@@ -91,11 +104,12 @@ __device__ __forceinline__ float2 finish_value(const SpecArgs &s, float2 v, floa
 
 // in-place finalisation for abacus_field_fft (spectrum returned to the host)
 __global__ void spectrum_apply(SpecArgs s, float2 *out) {
-    const int64_t total = (int64_t)s.n * s.n * s.kzlen;
+    const int64_t total = s.nrows * s.kzlen;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(q % s.kzlen);
         const int64_t row = q / s.kzlen;
-        const int j = (int)(row % s.n), i = (int)(row / s.n);
+        int i, j;
+        row_ij(s, row, i, j);
         const int64_t idx = row * s.pitch + k;
         const float2 w = s.interlaced ? s.as[idx] : make_float2(0.f, 0.f);
         out[idx] = finish_value(s, s.a[idx], w, i, j, k);
@@ -189,10 +203,10 @@ __device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int6
             const unsigned int dr = kk / (unsigned int)s.pitch;
             k = (int)(kk - dr * (unsigned int)s.pitch);
             const int64_t row = row0 + dr;
-            j = (int)(row % s.n), i = (int)(row / s.n);
+            row_ij(s, row < s.nrows ? row : 0, i, j);
             k2 = k + 1, j2 = j, i2 = i;   // pitch is even and e is even: the pair never straddles two rows
             // padding elements (k >= kzlen) and rows past the end are never binned: clamp their indices
-            if (k >= s.kzlen || i >= s.n) i = j = k = i2 = j2 = k2 = 0;
+            if (k >= s.kzlen || row >= s.nrows) i = j = k = i2 = j2 = k2 = 0;
             if (k2 >= s.kzlen) i2 = j2 = k2 = 0;
         }
         const float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
     __syncthreads();
     const float klo = ke[0], khi = ke[b.Nk];
     const int n = s.n, kzlen = s.kzlen, pitch = s.pitch;
-    const int64_t total = (int64_t)n * n * pitch;
+    const int64_t total = s.nrows * pitch;
     const int64_t ntiles = (total + BIN_TILE - 1) / BIN_TILE;
 
     TileRegs<INTER, CROSS> regs;
@@ -265,7 +279,9 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
             int k = (int)(idx0 - row * pitch);
             int r2 = 0;                               // i'^2 + j'^2 <= 2*(n/2)^2 < 2^30 for n <= 32767
             {
-                const int jj = fold((int)(row % n), n), ii = fold((int)(row / n), n);
+                int ii, jj;
+                row_ij(s, row, ii, jj);
+                ii = fold(ii, n), jj = fold(jj, n);
                 r2 = ii * ii + jj * jj;
             }
             int cur = -1, cur_bk = 0, bk = 0, bmu = 0;
@@ -283,14 +299,16 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
                     if (k == pitch) {                 // next (kx, ky) row
                         k = 0;
                         row++;
-                        const int jj = fold((int)(row % n), n), ii = fold((int)(row / n), n);
+                        int ii, jj;
+                        row_ij(s, row, ii, jj);
+                        ii = fold(ii, n), jj = fold(jj, n);
                         r2 = ii * ii + jj * jj;
                         located = false;
                     }
                     const int k2 = k * k;
                     kmag2 = (float)(r2 + k2);         // dtype(i2 + j2 + k**2) (:239); exact integer below 2^24
                     // `continue` below the first edge (:246), `break` from the last edge on (:249), padding, array end
-                    const bool inrange = k < kzlen && row < (int64_t)n * n && kmag2 >= klo && kmag2 < khi;
+                    const bool inrange = k < kzlen && row < s.nrows && kmag2 >= klo && kmag2 < khi;
                     if (inrange) {
                         // mu^2 = f32(k^2) * (1/kmag2) (:240-244).  The hardware reciprocal (1 ulp) picks the bin unless
                         // mu^2 lands within a few ulp of an edge; only then the correctly rounded value is formed.
@@ -377,6 +395,48 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
         if (h_pole[q] != 0.0) atomicAdd(&b.g_pole[q], h_pole[q]);
 }
 
+
+// ---- x-slab / y-slab building blocks of the multi-GPU estimator -----------------------------------
+// Host code (abacusutils_amd/parallel/slab_power.py) owns the communication: ghost planes by send/recv, the
+// pencil transpose by all-to-all, the histogram by all-reduce; everything of mesh size stays on the device.
+__global__ void slab_axpy(float *__restrict__ dst, const float *__restrict__ src, int64_t n4, float add) {
+    // dst = dst + src + add  (float4 lanes; src may be null)
+    float4 *d = reinterpret_cast<float4 *>(dst);
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = d[i];
+        if (s4) {
+            const float4 w = s4[i];
+            v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+        }
+        v.x += add, v.y += add, v.z += add, v.w += add;
+        d[i] = v;
+    }
+}
+
+// send[p][xl][yl][k] = data[xl][p*nyl + yl][k]   (rows of `pitch` complex, copied as 16-B pieces)
+__global__ void slab_pack(const float4 *__restrict__ data, float4 *__restrict__ send, int n, int nxl, int nyl, int world,
+                          int pitch4) {
+    const int64_t rows = (int64_t)world * nxl * nyl;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int yl = (int)(r % nyl), xl = (int)((r / nyl) % nxl), p = (int)(r / ((int64_t)nyl * nxl));
+        const float4 *src = data + ((int64_t)xl * n + (p * nyl + yl)) * pitch4;
+        float4 *dst = send + r * pitch4;
+        for (int q = threadIdx.x; q < pitch4; q += blockDim.x) dst[q] = src[q];
+    }
+}
+// out[yl][r*nxl + xl][k] = recv[r][xl][yl][k]
+__global__ void slab_unpack(const float4 *__restrict__ recv, float4 *__restrict__ out, int n, int nxl, int nyl, int world,
+                            int pitch4) {
+    const int64_t rows = (int64_t)world * nxl * nyl;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int yl = (int)(r % nyl), xl = (int)((r / nyl) % nxl), p = (int)(r / ((int64_t)nyl * nxl));
+        const float4 *src = recv + r * pitch4;
+        float4 *dst = out + ((int64_t)yl * n + (p * nxl + xl)) * pitch4;
+        for (int q = threadIdx.x; q < pitch4; q += blockDim.x) dst[q] = src[q];
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 struct PowerCtx {
     std::map<int, hipfftHandle> plans;
@@ -400,8 +460,7 @@ int get_plan(int n, hipfftHandle *out) {
         hipfftHandle h;
         int dims[3] = {n, n, n};
         int inembed[3] = {n, n, pitch_r(n)}, onembed[3] = {n, n, pitch_r(n) / 2};
-        ABACUS_TRY(fft_check(hipfftPlanMany(&h, 3, dims, inembed, 1, n * n * pitch_r(n), onembed, 1,
-                                            n * n * (pitch_r(n) / 2), HIPFFT_R2C, 1),
+        ABACUS_TRY(fft_check(hipfftPlanMany(&h, 3, dims, inembed, 1, 1, onembed, 1, 1, HIPFFT_R2C, 1),   // batch 1: dist unused
                              "hipfftPlanMany"));
         it = g_ctx.plans.emplace(n, h).first;
     }
@@ -457,6 +516,9 @@ void fill_spec(SpecArgs &s, int nmesh, int mode, int interlaced, const float *W_
     s.n = nmesh;
     s.kzlen = nmesh / 2 + 1;
     s.pitch = mode == 1 ? pitch_r(nmesh) / 2 : nmesh / 2 + 1;   // caller-supplied spectra (mode 0) are contiguous
+    s.rowmode = 0;
+    s.y0 = 0;
+    s.nrows = (int64_t)nmesh * nmesh;
     s.mode = mode;
     s.interlaced = interlaced;
     s.compensated = W_dev != nullptr;
@@ -484,9 +546,43 @@ int pole_coefs(int l, float c[6]) {
     return 0;
 }
 
+// normalisation of bin_kmu (:276-293) / calc_pk_from_deltak (:789-792) in float64 from the raw sums
+// raw layout: [cnt u64 Nk*Nmu][sum f64 Nk*Nmu][ksum f64 Nk*Nmu][pole f64 Np'*Nk], Np' = poles with l != 0 in order
+int finalize_bins(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *poles, int Np_all, float *power,
+                  int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
+    const size_t nb = (size_t)Nk * Nmu;
+    const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(raw);
+    const double *sum = reinterpret_cast<const double *>(cnt + nb);
+    const double *ksum = sum + nb;
+    const double *pole = ksum + nb;
+    const double dk = 2.0 * M_PI / Lbox;
+    const double L3 = Lbox * Lbox * Lbox;
+    int nz_index[MAX_POLES], nnz = 0;
+    for (int q = 0; q < Np_all; q++) nz_index[q] = poles[q] != 0 ? nnz++ : -1;
+    for (int i = 0; i < Nk; i++) {
+        int64_t cp = 0;
+        double wedge = 0;
+        for (int j = 0; j < Nmu; j++) {
+            const size_t q = (size_t)i * Nmu + j;
+            const int64_t c = (int64_t)cnt[q];
+            N_mode[q] = c;
+            power[q] = (float)((c ? sum[q] / (double)c : sum[q]) * L3);
+            k_avg[q] = (float)(c ? ksum[q] * dk / (double)c : ksum[q] * dk);
+            cp += c;
+            wedge += sum[q];
+        }
+        N_mode_poles[i] = cp;
+        for (int q = 0; q < Np_all; q++) {
+            const double v = poles[q] == 0 ? wedge : pole[(size_t)nz_index[q] * Nk + i];   // l=0 from the wedges (:282-284)
+            binned_poles[(size_t)q * Nk + i] = (float)((cp ? v / (double)cp : v) * L3);
+        }
+    }
+    return 0;
+}
+
 int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu,
             const int64_t *poles, int Np_all, float *power, int64_t *N_mode, float *binned_poles,
-            int64_t *N_mode_poles, float *k_avg) {
+            int64_t *N_mode_poles, float *k_avg, void *raw_out = nullptr) {
     if (Nk < 1 || Nmu < 1) return fail("power: need at least one k bin and one mu bin");
     if (Np_all > MAX_POLES) return fail("power: more than %d multipoles requested", MAX_POLES);
     const int nmesh = s.n;
@@ -534,7 +630,7 @@ int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const 
     int dev = 0, ncu = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t ntiles = ((int64_t)nmesh * nmesh * s.pitch + tile_modes - 1) / tile_modes;
+    const int64_t ntiles = (s.nrows * s.pitch + tile_modes - 1) / tile_modes;
     const int grid = (int)std::min<int64_t>(ntiles, ncu);
 #define LAUNCH_BIN(I, C, P)                                                                                          \
     do {                                                                                                             \
@@ -555,34 +651,16 @@ int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const 
     else LAUNCH_NP(false, false);
 #undef LAUNCH_NP
 #undef LAUNCH_BIN
-    // tiny read-back and the normalisation of bin_kmu (:276-293) / calc_pk_from_deltak (:789-792) in float64
+    // tiny read-back of the raw sums: counts (u64), sum P, sum k, pole sums (f64)
+    if (raw_out) {
+        HIP_TRY(hipMemcpyAsync(raw_out, g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        return 0;
+    }
     std::vector<unsigned char> host(acc_bytes);
     HIP_TRY(hipMemcpyAsync(host.data(), g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
-    const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(host.data());
-    const double *sum = reinterpret_cast<const double *>(cnt + nb);
-    const double *ksum = sum + nb;
-    const double *pole = ksum + nb;
-    const double L3 = Lbox * Lbox * Lbox;
-    for (int i = 0; i < Nk; i++) {
-        int64_t cp = 0;
-        double wedge = 0;
-        for (int j = 0; j < Nmu; j++) {
-            const size_t q = (size_t)i * Nmu + j;
-            const int64_t c = (int64_t)cnt[q];
-            N_mode[q] = c;
-            power[q] = (float)((c ? sum[q] / (double)c : sum[q]) * L3);
-            k_avg[q] = (float)(c ? ksum[q] * dk / (double)c : ksum[q] * dk);
-            cp += c;
-            wedge += sum[q];
-        }
-        N_mode_poles[i] = cp;
-        for (int q = 0; q < Np_all; q++) {
-            const double v = poles[q] == 0 ? wedge : pole[(size_t)nz_index[q] * Nk + i];   // l=0 from the wedges (:282-284)
-            binned_poles[(size_t)q * Nk + i] = (float)((cp ? v / (double)cp : v) * L3);
-        }
-    }
-    return 0;
+    return finalize_bins(host.data(), Lbox, Nk, Nmu, poles, Np_all, power, N_mode, binned_poles, N_mode_poles, k_avg);
 }
 
 int upload_W(const float *W_host, int nmesh, const float **W_dev) {
@@ -712,6 +790,86 @@ int abacus_pk_from_deltak(const void *field, const void *field2, int nmesh, doub
     s.b = field2 ? g_ctx.mesh[2].as<float2>() : nullptr;
     s.as = s.bs = nullptr;
     return run_bin(s, Lbox, kedges, Nk, muedges, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
+}
+
+
+int abacus_slab_pitch(int nmesh) { return pitch_r(nmesh); }
+
+int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int nx_local,
+                            double Lbox, double offset, double norm, int paste) {
+    ABACUS_TRY(ensure_init());
+    ABACUS_TRY(check_common(nmesh, paste));
+    if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    return tsc_deposit_slab_f32(pos, n, w, mesh, nmesh, xoff, nx_local, pitch_r(nmesh), Lbox, offset, paste == 0, norm,
+                                paste);
+}
+
+int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add) {
+    ABACUS_TRY(ensure_init());
+    if (nfloat % 4) return fail("abacus_slab_axpy_dev: length must be a multiple of 4");
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(nfloat / 4, 256), 1), 256 * 32);
+    ABACUS_LAUNCH("slab_axpy", slab_axpy, dim3(grid), dim3(256), 0, dst, src, nfloat / 4, add);
+    return 0;
+}
+
+int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local) {
+    ABACUS_TRY(ensure_init());
+    if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    return fft_native_zy(mesh, nmesh, pitch_r(nmesh), nx_local);
+}
+
+int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world) {
+    ABACUS_TRY(ensure_init());
+    if (nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
+    const int nyl = nmesh / world, pitch4 = pitch_r(nmesh) / 4;
+    const int grid = (int)std::min<int64_t>((int64_t)world * nx_local * nyl, 256 * 32);
+    ABACUS_LAUNCH("slab_pack", slab_pack, dim3(grid), dim3(256), 0, (const float4 *)data, (float4 *)send, nmesh, nx_local,
+                  nyl, world, pitch4);
+    return 0;
+}
+
+int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int nx_local, int world) {
+    ABACUS_TRY(ensure_init());
+    if (nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
+    const int nyl = nmesh / world, pitch4 = pitch_r(nmesh) / 4;
+    const int grid = (int)std::min<int64_t>((int64_t)world * nx_local * nyl, 256 * 32);
+    ABACUS_LAUNCH("slab_unpack", slab_unpack, dim3(grid), dim3(256), 0, (const float4 *)recv, (float4 *)out, nmesh,
+                  nx_local, nyl, world, pitch4);
+    return 0;
+}
+
+int abacus_slab_fft_x_dev(float *data, int nmesh, int ny_local) {
+    ABACUS_TRY(ensure_init());
+    if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    const int pc = pitch_r(nmesh) / 2;
+    return fft_native_x(data, nmesh, pitch_r(nmesh), ny_local, pc, (int64_t)nmesh * pc);   // layout (y_local, x, k)
+}
+
+int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void *bs, int nmesh, int y0, int ny_local,
+                        double Lbox, const float *W_host, int interlaced, const double *kedges, int Nk,
+                        const double *muedges, int Nmu, const int64_t *poles, int Np, void *raw_out) {
+    ABACUS_TRY(ensure_init());
+    ABACUS_TRY(ensure_phase(nmesh));
+    const float *W_dev;
+    ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
+    SpecArgs s;
+    fill_spec(s, nmesh, 1, interlaced, W_dev, b != nullptr);
+    s.rowmode = 1;
+    s.y0 = y0;
+    s.nrows = (int64_t)ny_local * nmesh;
+    s.a = (const float2 *)a, s.as = (const float2 *)as, s.b = (const float2 *)b, s.bs = (const float2 *)bs;
+    return run_bin(s, Lbox, kedges, Nk, muedges, Nmu, poles, Np, nullptr, nullptr, nullptr, nullptr, nullptr, raw_out);
+}
+
+int64_t abacus_bin_raw_bytes(int Nk, int Nmu, const int64_t *poles, int Np) {
+    int nnz = 0;
+    for (int q = 0; q < Np; q++) nnz += poles[q] != 0;
+    return (int64_t)Nk * Nmu * 24 + (int64_t)nnz * Nk * 8;
+}
+
+int abacus_bin_finalize(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *poles, int Np, float *power,
+                        int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
+    return finalize_bins(raw, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
 }
 
 int abacus_power_release(void) {

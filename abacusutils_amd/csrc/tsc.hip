@@ -42,7 +42,9 @@ struct TileGeom {
     int gx, gy, gz;       // mesh
     int tx, ty, tz;       // tile shape (cells)
     int ntx, nty, ntz;    // tiles per dimension
-    int64_t zstride;      // elements per z-row in memory (gz, or 2*(gz/2+1) for an in-place R2C layout)
+    int64_t zstride;      // elements per z-row in memory (gz, or a padded pitch for the in-place R2C layout)
+    int gxg, xoff;        // x-slab meshes: global x size (scale + periodic wrap) and global index of local plane 0;
+                          // gxg == gx, xoff == 0 for a full mesh
 };
 
 __device__ __forceinline__ int wrapcell(int c, int g) {
@@ -55,6 +57,13 @@ __device__ __forceinline__ int wrapcell(int c, int g) {
         if (c < 0) c = ((c % g) + g) % g;
     }
     return c;
+}
+
+// global x cell -> local plane index of an x-slab mesh (-1: not held by this slab)
+__device__ __forceinline__ int xloc(int i, const TileGeom &g) {
+    int l = wrapcell(i, g.gxg) - g.xoff;
+    if (l < 0) l += g.gxg;
+    return l < g.gx ? l : -1;
 }
 
 template <typename PT>
@@ -107,6 +116,21 @@ __device__ __forceinline__ void cic_cloud(PT x, PT y, PT z, double box, int gx, 
     }
 }
 
+// x: like tiles_1d below, on local plane indices; planes outside the slab are skipped
+__device__ __forceinline__ int tiles_1d_x(int i, const TileGeom &g, int out[3]) {
+    int n = 0;
+#pragma unroll
+    for (int a = -1; a <= 1; a++) {
+        const int l = xloc(i + a, g);
+        if (l < 0) continue;
+        const int t = l / g.tx;
+        bool dup = false;
+        for (int q = 0; q < n; q++) dup = dup || out[q] == t;
+        if (!dup) out[n++] = t;
+    }
+    return n;
+}
+
 // distinct tiles touched along one dimension by cells i-1, i, i+1 (2 at most unless the mesh is tiny)
 __device__ __forceinline__ int tiles_1d(int i, int g, int t, int out[3]) {
     int a = wrapcell(i - 1, g) / t, b = wrapcell(i, g) / t, c = wrapcell(i + 1, g) / t;
@@ -143,7 +167,7 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_bin(PT *__restrict__ pos, int64
                                                      unsigned int *__restrict__ tile_count,
                                                      const int64_t *__restrict__ tile_start,
                                                      Entry<PT> *__restrict__ entries, int *__restrict__ wrapped_flag) {
-    const PT ihx = (PT)(g.gx / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
+    const PT ihx = (PT)(g.gxg / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
     const PT offset = (PT)offset_;
     bool any_changed = false;
     for (int64_t p = (int64_t)blockIdx.x * TSC_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * TSC_BLOCK) {
@@ -163,7 +187,7 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_bin(PT *__restrict__ pos, int64
         int ci[3];
         if (CIC) {
             Cloud<double> c;
-            cic_cloud<PT>(x + offset, y + offset, z + offset, box, g.gx, g.gy, g.gz, c);
+            cic_cloud<PT>(x + offset, y + offset, z + offset, box, g.gxg, g.gy, g.gz, c);
             ci[0] = c.i[0], ci[1] = c.i[1], ci[2] = c.i[2];
         } else {
             Cloud<PT> c;
@@ -171,7 +195,7 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_bin(PT *__restrict__ pos, int64
             ci[0] = c.i[0], ci[1] = c.i[1], ci[2] = c.i[2];
         }
         int ax[3], ay[3], az[3];
-        const int nx = tiles_1d(ci[0], g.gx, g.tx, ax), ny = tiles_1d(ci[1], g.gy, g.ty, ay),
+        const int nx = tiles_1d_x(ci[0], g, ax), ny = tiles_1d(ci[1], g.gy, g.ty, ay),
                   nz = tiles_1d(ci[2], g.gz, g.tz, az);
         const PT w = (FILL && weights) ? weights[p] : (PT)1;
         for (int a = 0; a < nx; a++)
@@ -202,7 +226,7 @@ __device__ __forceinline__ void for_each_tile(PT x, PT y, PT z, const TileGeom &
     int ci[3];
     if (CIC) {
         Cloud<double> c;
-        cic_cloud<PT>(x + offset, y + offset, z + offset, box, g.gx, g.gy, g.gz, c);
+        cic_cloud<PT>(x + offset, y + offset, z + offset, box, g.gxg, g.gy, g.gz, c);
         ci[0] = c.i[0], ci[1] = c.i[1], ci[2] = c.i[2];
     } else {
         Cloud<PT> c;
@@ -210,7 +234,7 @@ __device__ __forceinline__ void for_each_tile(PT x, PT y, PT z, const TileGeom &
         ci[0] = c.i[0], ci[1] = c.i[1], ci[2] = c.i[2];
     }
     int ax[3], ay[3], az[3];
-    const int nx = tiles_1d(ci[0], g.gx, g.tx, ax), ny = tiles_1d(ci[1], g.gy, g.ty, ay),
+    const int nx = tiles_1d_x(ci[0], g, ax), ny = tiles_1d(ci[1], g.gy, g.ty, ay),
               nz = tiles_1d(ci[2], g.gz, g.tz, az);
     for (int a = 0; a < nx; a++)
         for (int b = 0; b < ny; b++)
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
     const int tid = threadIdx.x;
     for (int b = tid; b < MS_BINS; b += MS_BLOCK) hist[b] = 0u;
     __syncthreads();
-    const PT ihx = (PT)(g.gx / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
+    const PT ihx = (PT)(g.gxg / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
     const PT offset = (PT)offset_;
     const int64_t p0 = (int64_t)blockIdx.x * MS_CHUNK, p1 = min(p0 + MS_CHUNK, n);
     bool any_changed = false;
@@ -319,7 +343,7 @@ template <typename PT, typename GT, int TXS, int TYS, int TZS, bool CIC>
 __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *__restrict__ entries,
                                                               const int64_t *__restrict__ tile_start, TileGeom g,
                                                               double box, double offset_, GT *__restrict__ grid,
-                                                              int zero_grid, GT norm, int dbg) {
+                                                              int zero_grid, GT norm, GT sub, int dbg) {
     // The tile is accumulated in float64 whatever the mesh dtype: the order of the LDS atomics then only matters at
     // the 1e-16 level, so the float32 mesh is reproducible run to run (and each cell is rounded once, not per add).
     __shared__ double tile[TXS * TYS * TZS];
@@ -337,18 +361,18 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *_
         for (int q = tid; q < TXS * TYS * TZS / 2; q += TSC_BLOCK) t2[q] = make_double2(0.0, 0.0);
     }
     __syncthreads();
-    const PT ihx = (PT)(g.gx / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
+    const PT ihx = (PT)(g.gxg / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
     const PT offset = (PT)offset_;
     for (int64_t e = e0 + tid; e < e1 && !(dbg & 1); e += TSC_BLOCK) {
         const Entry<PT> en = e == e0 + tid ? first : entries[e];
         int lx[3], ly[3], lz[3];
         if (CIC) {
             Cloud<double> c;
-            cic_cloud<PT>(en.x + offset, en.y + offset, en.z + offset, box, g.gx, g.gy, g.gz, c);
+            cic_cloud<PT>(en.x + offset, en.y + offset, en.z + offset, box, g.gxg, g.gy, g.gz, c);
             const double W = (double)en.w;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                lx[a] = wrapcell(c.i[0] + a - 1, g.gx) - ox;
+                lx[a] = xloc(c.i[0] + a - 1, g) - ox;
                 ly[a] = wrapcell(c.i[1] + a - 1, g.gy) - oy;
                 lz[a] = wrapcell(c.i[2] + a - 1, g.gz) - oz;
             }
@@ -371,7 +395,7 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *_
             tsc_cloud<PT>(en.x, en.y, en.z, offset, ihx, ihy, ihz, c);
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                lx[a] = wrapcell(c.i[0] + a - 1, g.gx) - ox;
+                lx[a] = xloc(c.i[0] + a - 1, g) - ox;
                 ly[a] = wrapcell(c.i[1] + a - 1, g.gy) - oy;
                 lz[a] = wrapcell(c.i[2] + a - 1, g.gz) - oz;
             }
@@ -411,8 +435,8 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *_
             }
             float2 v = make_float2((float)a0, (float)a1);
             if (norm != (GT)0) {
-                v.x = v.x * (float)norm - 1.0f;
-                v.y = v.y * (float)norm - 1.0f;
+                v.x = v.x * (float)norm - (float)sub;
+                v.y = v.y * (float)norm - (float)sub;
             }
             *dst = v;
         }
@@ -424,7 +448,7 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *_
             GT *dst = grid + ((int64_t)(ox + x) * g.gy + (oy + y)) * g.zstride + (oz + z);
             if (!zero_grid) acc += (double)*dst;
             GT v = (GT)acc;
-            if (norm != (GT)0) v = v * norm - (GT)1;
+            if (norm != (GT)0) v = v * norm - sub;
             *dst = v;
         }
     }
@@ -436,9 +460,10 @@ struct TscWork {
 };
 TscWork g_work;
 
-TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int TZ) {
+TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int TZ, int gxg, int xoff) {
     TileGeom g;
     g.gx = gx, g.gy = gy, g.gz = gz;
+    g.gxg = gxg, g.xoff = xoff;
     g.tx = std::min(TX, gx), g.ty = std::min(TY, gy), g.tz = std::min(TZ, gz);
     g.ntx = (gx + g.tx - 1) / g.tx, g.nty = (gy + g.ty - 1) / g.ty, g.ntz = (gz + g.tz - 1) / g.tz;
     g.zstride = zstride;
@@ -447,11 +472,13 @@ TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int 
 
 template <typename PT, typename GT, bool CIC>
 int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy, int gz, int64_t zstride, double box,
-                double offset, int wrap, int zero_grid, double norm, int *wrapped_out) {
+                double offset, int wrap, int zero_grid, double norm, int *wrapped_out, int gxg = -1, int xoff = 0,
+                double sub = 1.0) {
+    if (gxg < 0) gxg = gx;
     if (gx < 1 || gy < 1 || gz < 1) return fail("tsc: empty mesh");
-    if (gx > 32767 || gy > 32767 || gz > 32767) return fail("tsc: mesh dimension > 32767 (int16 cell index of the reference)");
+    if (gxg > 32767 || gy > 32767 || gz > 32767) return fail("tsc: mesh dimension > 32767 (int16 cell index of the reference)");
     constexpr int TX = 16, TY = 16, TZ = 32;   // 8192 float64 cells = 64 KiB of LDS -> two workgroups per CU
-    const TileGeom g = make_geom(gx, gy, gz, zstride, TX, TY, TZ);
+    const TileGeom g = make_geom(gx, gy, gz, zstride, TX, TY, TZ, gxg, xoff);
     const int64_t ntiles64 = (int64_t)g.ntx * g.nty * g.ntz;
     if (ntiles64 > 0x7fffffff) return fail("tsc: too many tiles");
     const int ntiles = (int)ntiles64;
@@ -534,7 +561,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
                           offset, 0, tile_count, (const int64_t *)tile_start, entries, flag);
     }
     ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit<PT, GT, TX, TY, TZ, CIC>), dim3(ntiles), dim3(TSC_BLOCK), 0,
-                  (const Entry<PT> *)entries, (const int64_t *)tile_start, g, box, offset, grid, zero_grid, (GT)norm,
+                  (const Entry<PT> *)entries, (const int64_t *)tile_start, g, box, offset, grid, zero_grid, (GT)norm, (GT)sub,
                   getenv("ABACUS_DBG_TSC") ? atoi(getenv("ABACUS_DBG_TSC")) : 0);
     return 0;
 }
@@ -584,6 +611,16 @@ int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmes
                                                nullptr);
     return deposit_dev<float, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
                                             nullptr);
+}
+// x-slab variant: `grid` holds planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh, ghosts included;
+// written as rho*norm (no "-1": ghost planes are added to their owners first)
+int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
+                         int64_t zstride, double box, double offset, int wrap, double norm, int cic) {
+    if (cic)
+        return deposit_dev<float, float, true>(pos, n, w, grid, nx_local, nmesh, nmesh, zstride, box, offset, 0, 1, norm,
+                                               nullptr, nmesh, xoff, 0.0);
+    return deposit_dev<float, float, false>(pos, n, w, grid, nx_local, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
+                                            nullptr, nmesh, xoff, 0.0);
 }
 int tsc_release_work() {
     ABACUS_TRY(g_work.tile_count.release());

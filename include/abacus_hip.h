@@ -192,6 +192,39 @@ int abacus_power_from_particles_dev(float *pos, int64_t n, const float *w, float
 /* releases cached FFT plans / work meshes */
 int abacus_power_release(void);
 
+
+/* ---------------------------------------------------------------- multi-GPU slab building blocks ------- */
+/*
+ * The reference has no distributed mesh (docs/tutorials/analysis/tsc.ipynb:19); this is new functionality behind
+ * calc_power: x-slab mesh decomposition, ghost-plane exchange-add, local z/y FFT passes, all-to-all pencil transpose,
+ * x FFT pass and binning on y-slabs, all-reduce of the (k, mu) histogram.  The collectives are issued by
+ * the host code (torch.distributed: RCCL on GPUs, gloo in tests); these entry points are the device-side pieces.
+ * All pointers are DEVICE pointers; nmesh must be a power of two in [64, 2048] and divisible by the number of ranks.
+ * Mesh rows have abacus_slab_pitch(nmesh) floats (128-B aligned rows; complex rows of pitch/2).
+ */
+int abacus_slab_pitch(int nmesh);
+/* deposit into planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh as rho*norm (ghost planes included) */
+int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int nx_local,
+                            double Lbox, double offset, double norm, int paste);
+/* dst[i] += src[i] + add  (ghost-plane accumulation; "-1" of the overdensity with src == NULL) */
+int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add);
+/* z and y passes of the 3-D R2C FFT on nx_local owned planes, in place */
+int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local);
+/* (x_local, y, k) -> send[p][x_local][y_local][k] and recv[r][x_local][y_local][k] -> (y_local, x, k) */
+int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world);
+int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int nx_local, int world);
+/* x pass on a y-slab in the (y_local, x, k) layout, in place */
+int abacus_slab_fft_x_dev(float *data, int nmesh, int ny_local);
+/* raw (un-normalised) bin sums of a y-slab: counts u64[Nk*Nmu], sum P f64[Nk*Nmu], sum k f64[Nk*Nmu],
+ * pole sums f64[Np'*Nk]; `raw_out` is a HOST buffer of abacus_bin_raw_bytes() bytes (to be all-reduced) */
+int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void *bs, int nmesh, int y0, int ny_local,
+                        double Lbox, const float *W_host, int interlaced, const double *kedges, int Nk,
+                        const double *muedges, int Nmu, const int64_t *poles, int Np, void *raw_out);
+int64_t abacus_bin_raw_bytes(int Nk, int Nmu, const int64_t *poles, int Np);
+/* bin_kmu's normalisation (analysis/power_spectrum.py:276-293, 789-792) of reduced raw sums; host only */
+int abacus_bin_finalize(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *poles, int Np, float *power,
+                        int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg);
+
 /* ---------------------------------------------------------------- pair counting ------------------------ */
 /*
  * replaces: Corrfunc.theory.DD / DDrppi / DDsmu as called at analysis/tpcf_corrfunc.py:144-156,164-179,

@@ -1,0 +1,61 @@
+"""worker for test_slab_power: one rank of the slab estimator.  `--backend numpy` = CPU stand-in device side
+(tests/slab_numpy_backend.py) with gloo; `--backend hip` = the HIP entry points (ranks may share one GPU) with
+gloo host staging, or RCCL device collectives when --device-collectives is given."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--backend', default='numpy')
+    ap.add_argument('--device-collectives', action='store_true')
+    ap.add_argument('--nmesh', type=int, default=64)
+    ap.add_argument('--n', type=int, default=20000)
+    ap.add_argument('--interlaced', type=int, default=1)
+    ap.add_argument('--compensated', type=int, default=1)
+    ap.add_argument('--cross', type=int, default=0)
+    ap.add_argument('--out', required=True)
+    a = ap.parse_args()
+    import torch  # noqa: F401  (before the HIP library: one HIP runtime per process)
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        if a.device_collectives:
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
+        dist.init_process_group('nccl' if a.device_collectives else 'gloo')
+    from abacusutils_amd.analysis import slab_power as sp
+    from abacusutils_amd.synth import synth_positions
+    comm = sp.SlabComm(device_collectives=a.device_collectives)
+    L = 500.0
+    # every rank draws the same catalogue and keeps an arbitrary half: route_particles moves them to their slabs
+    pos = synth_positions(a.n, L, seed=11)
+    w = np.random.default_rng(5).random(a.n, dtype=np.float32) + np.float32(0.5)
+    mine = slice(comm.rank, None, comm.world)
+    p1, w1 = sp.route_particles(pos[mine], w[mine], L, comm)
+    kw = dict(kbins=16, mubins=4, paste='TSC', nmesh=a.nmesh, compensated=bool(a.compensated),
+              interlaced=bool(a.interlaced), poles=[0, 2, 4])
+    if a.backend == 'numpy':
+        from slab_numpy_backend import NumpySlabBackend
+        backend = NumpySlabBackend()
+    else:
+        backend = sp.HipSlabBackend()
+    extra = {}
+    if a.cross:
+        pos2 = synth_positions(a.n // 2, L, seed=12)
+        p2, _ = sp.route_particles(pos2[mine], None, L, comm)
+        extra = dict(pos2=p2)
+    t = sp.calc_power_slab(p1, L, comm=comm, backend=backend, w=w1, **kw, **extra)
+    np.savez(f'{a.out}.rank{comm.rank}.npz', n_local=len(p1), **{k: np.asarray(t[k]) for k in t.keys()})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

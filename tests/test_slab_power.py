@@ -1,0 +1,86 @@
+"""x-slab P(k) (abacusutils_amd/analysis/slab_power.py): host orchestration at world_size 1 and 2 (gloo) against the
+oracle's calc_power on the union catalogue.  The CPU tests use the NumPy stand-in for the device side
+(tests/slab_numpy_backend.py); the GPU tests run the HIP entry points (two ranks share the one GPU, gloo staging)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from abacusutils_amd.synth import synth_positions
+from oracle import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+L = 500.0
+
+
+def run_ranks(tmp_path, world, backend, port, **kw):
+    out = str(tmp_path / f'slab_{backend}_{world}')
+    args = [f'--{k.replace("_", "-")}={v}' for k, v in kw.items()]
+    worker = os.path.join(HERE, '_slab_worker.py')
+    if world == 1:
+        cmd = [sys.executable, worker, '--backend', backend, '--out', out] + args
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), worker, '--backend', backend, '--out', out] + args
+    env = dict(os.environ, OMP_NUM_THREADS='2')
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [np.load(f'{out}.rank{k}.npz') for k in range(world)]
+
+
+def reference(nmesh=64, n=20000, interlaced=1, compensated=1, cross=0):
+    pos = synth_positions(n, L, seed=11)
+    w = np.random.default_rng(5).random(n, dtype=np.float32) + np.float32(0.5)
+    kw = dict(kbins=16, mubins=4, paste='TSC', nmesh=nmesh, compensated=bool(compensated), interlaced=bool(interlaced),
+              poles=[0, 2, 4], nthread=2, accum64=True)
+    if cross:
+        kw['pos2'] = synth_positions(n // 2, L, seed=12)
+    return oracle.calc_power(pos, L, w=w, **kw)
+
+
+def check(res, ref, world, n):
+    assert sum(int(r['n_local']) for r in res) == n
+    for r in res:
+        np.testing.assert_array_equal(r['N_mode'], ref['N_mode'])
+        np.testing.assert_array_equal(r['N_mode_poles'], ref['N_mode_poles'])
+        scale = np.abs(ref['power']).max()
+        np.testing.assert_allclose(r['power'], ref['power'], rtol=1e-5, atol=1e-5 * scale)
+        np.testing.assert_allclose(r['poles'], ref['poles'], rtol=1e-5, atol=1e-5 * scale)
+        np.testing.assert_allclose(r['k_avg'], ref['k_avg'], rtol=1e-6)
+    for r in res[1:]:                          # every rank holds the same all-reduced result
+        np.testing.assert_array_equal(r['power'], res[0]['power'])
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_slab_orchestration_cpu(tmp_path, world):
+    res = run_ranks(tmp_path, world, 'numpy', 29611 + world)
+    check(res, reference(), world, 20000)
+
+
+def test_slab_cross_cpu(tmp_path):
+    res = run_ranks(tmp_path, 2, 'numpy', 29621, cross=1, interlaced=0)
+    check(res, reference(cross=1, interlaced=0), 2, 20000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,interlaced,compensated,cross', [(1, 1, 1, 0), (2, 1, 1, 0), (2, 0, 0, 1), (4, 1, 1, 1)])
+def test_slab_hip(tmp_path, world, interlaced, compensated, cross):
+    res = run_ranks(tmp_path, world, 'hip', 29631 + world, interlaced=interlaced, compensated=compensated, cross=cross)
+    check(res, reference(interlaced=interlaced, compensated=compensated, cross=cross), world, 20000)
+
+
+@pytest.mark.gpu
+def test_slab_hip_matches_single_gpu_path(tmp_path):
+    """world=1 slab path against the product's own calc_power at a larger mesh"""
+    from abacusutils_amd.analysis import power_spectrum as ps
+    from abacusutils_amd.analysis import slab_power as sp
+    n, nmesh = 400000, 128
+    pos = synth_positions(n, L, seed=21, clustered=True)
+    kw = dict(kbins=32, mubins=5, paste='TSC', nmesh=nmesh, compensated=True, interlaced=True, poles=[0, 2, 4])
+    a = ps.calc_power(pos.copy(), L, **kw)
+    b = sp.calc_power_slab(pos.copy(), L, **kw)
+    np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
+    np.testing.assert_allclose(b['power'], a['power'], rtol=2e-5, atol=1e-6 * np.abs(a['power']).max())
+    np.testing.assert_allclose(b['poles'], a['poles'], rtol=2e-5, atol=1e-6 * np.abs(a['power']).max())
