@@ -26,6 +26,9 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+from bench_pk import pmc_traffic  # noqa: E402
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -160,7 +163,9 @@ def bench_hod(args, dist):
     if dom:
         ach = alg_bytes[dom] / (kern[dom] * 1e-3) / 1e9
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                           'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                           'frac': ach / HBM_PEAK_GBS,
+                           'traffic': pmc_traffic('hod', dom) if (nh, npart) == (10_000_000, 10_000_000) else None,
+                           'algorithmic_bytes': alg_bytes[dom],
                            'whole_step_GBs': (40.0 * nh + 40.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9,
                            'whole_step_frac': (40.0 * nh + 40.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
     st.free()

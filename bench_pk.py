@@ -11,6 +11,24 @@ import time
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0
+REPO = os.path.dirname(os.path.abspath(__file__))
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/rNN/pmc_traffic.json, written by scripts/gpu_round.sh + scripts/collect_profiles.py: FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 correction applied).  None when there is no committed pass."""
+    import glob
+    import json
+    for f in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*', 'pmc_traffic.json')), reverse=True):
+        try:
+            tab = json.load(open(f)).get(workload, {})
+        except (OSError, ValueError):
+            continue
+        for k, e in tab.items():
+            if k.split('<')[0] == kernel:
+                return e['hbm_bytes_per_launch']
+    return None
 
 
 def bench_pk(args, dist, headline):
@@ -87,7 +105,8 @@ def bench_pk(args, dist, headline):
         'kernels_ms': {k: round(v, 4) for k, v in kern.items()},
         'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot),
         'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                     'frac': ach / HBM_PEAK_GBS, 'algorithmic_bytes': alg[dom],
+                     'traffic': pmc_traffic('pk2048', dom) if (nmesh, n) == (2048, 100_000_000) else None,
                      'whole_step_GBs': alg_bytes_total / dt / 1e9,
                      'whole_step_frac': alg_bytes_total / dt / 1e9 / HBM_PEAK_GBS},
     }

@@ -1,0 +1,49 @@
+"""copy the judged summaries of the last `scripts/gpu_round.sh` run from gpurun_out/round (scratch) into
+profiles/<round>/ (tracked): rocprofv3 --kernel-trace --stats kernel tables, the bench JSON lines, test logs and the
+PMC traffic table.
+
+PMC correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB, collected in
+separate passes; on gfx950 FETCH_SIZE tallies a 128-B request at 64 B, so wide streaming reads are doubled.  Kernels whose
+reads are 64-B segments (the strided column FFT passes: 8 complex columns per row) issue 64-B requests that are
+tallied exactly -- calibrated here against the known byte count (raw FETCH_SIZE of fft_cols == 4M bytes of the
+half-spectrum to 0.5 %), so they take factor 1."""
+import glob
+import json
+import os
+import shutil
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = 'gpurun_out/round'
+dst = os.path.join('profiles', rnd)
+os.makedirs(dst, exist_ok=True)
+FETCH_FACTOR = {'fft_cols': 1.0}
+
+for d in ('prof_hod', 'prof_pk1024', 'prof_pk2048'):
+    for f in glob.glob(os.path.join(src, d, '**', '*kernel_stats.csv'), recursive=True):
+        shutil.copy(f, os.path.join(dst, f'{d[5:]}_kernel_stats.csv'))
+    log = os.path.join(src, d + '.log')
+    if os.path.exists(log):   # the bench JSON line printed under the profiler
+        lines = [ln for ln in open(log) if ln.startswith('{"metric"')]
+        if lines:
+            open(os.path.join(dst, f'{d[5:]}_bench_under_rocprof.json'), 'w').write(lines[-1])
+for f in ('bench_default.json', 'gpu_tests.log', 'smoke.log'):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+p = os.path.join(src, 'pmc_summary.json')
+if os.path.exists(p):
+    raw = json.load(open(p))
+    out = {}
+    for wl, ks in raw.items():
+        for k, e in ks.items():
+            if 'FETCH_SIZE_KiB_per_launch_raw' not in e or 'WRITE_SIZE_KiB_per_launch_raw' not in e:
+                continue
+            base = k.split('<')[0]
+            fac = FETCH_FACTOR.get(base, 2.0)
+            rd = e['FETCH_SIZE_KiB_per_launch_raw'] * 1024 * fac
+            wr = e['WRITE_SIZE_KiB_per_launch_raw'] * 1024
+            out.setdefault(wl, {})[k] = {'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
+                                         'hbm_bytes_per_launch': rd + wr, 'fetch_factor': fac,
+                                         'launches': e.get('launches_FETCH_SIZE')}
+    json.dump(out, open(os.path.join(dst, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
+print(sorted(os.listdir(dst)))
