@@ -172,6 +172,10 @@ def profile_enable(on=True):
     check(lib().abacus_profile_enable(int(on)))
 
 
+def profile_select(name=None):
+    check(lib().abacus_profile_select(None if not name else name.encode()))
+
+
 def profile_reset():
     check(lib().abacus_profile_reset())
 

@@ -5,10 +5,10 @@
 // pos/vel, int64 ids) and stay resident across populate calls (the MCMC use case of staging()).
 //
 // Kernels (all HBM-bound streaming, no MFMA - there is no contraction on this path):
-//   hod_filter_cent / hod_filter_sat   one pass over the per-halo / per-particle scalars (16-B coalesced loads):
+//   hod_filter (central + satellite tiles in one launch)   one pass over the per-halo / per-particle scalars (16-B coalesced loads):
 //        a float32 upper bound of the marker chain proves keep = 0 for the bulk of the objects; the rest is queued.
 //        Tiles of 2048 objects -> thousands of workgroups for the 256 CUs.
-//   hod_exact_cent / hod_exact_sat     exact FP64 occupation math (erfc, log10, pow) for the queued objects only;
+//   hod_exact (central + satellite superblocks)   exact FP64 occupation math (erfc, log10, pow) for the queued objects only;
 //        writes their int8 keep bytes and bumps per-tile and per-"superblock" (32 tiles) tracer counters, so no
 //        separate scan launch is needed.
 //   hod_emit                           8192 objects per workgroup: sums the superblock / tile counters in front of
@@ -287,102 +287,95 @@ __device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Fil
 // Splitting keeps the streaming kernel light (no FP64 transcendental code, few registers, 8 waves per SIMD).
 constexpr int FBLOCK = 256;
 
-__global__ __launch_bounds__(FBLOCK) void hod_filter_cent(int64_t n, const double *__restrict__ mass,
-                                                          const double *__restrict__ multis,
-                                                          const double *__restrict__ randoms,
-                                                          const double *__restrict__ deltac,
-                                                          const double *__restrict__ fenv,
-                                                          const double *__restrict__ shear, int want_LRG, int want_ELG,
-                                                          int want_QSO, Filt F, int8_t *__restrict__ keep,
-                                                          int *__restrict__ q_count,
-                                                          unsigned short *__restrict__ queue) {
-    __shared__ int nq;
-    __shared__ unsigned short q[TILE];
-    const int tid = threadIdx.x;
-    if (tid == 0) nq = 0;
-    __syncthreads();
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
-    abacus_hod_params pw;   // only the want_* flags are read by cent_reject
-    pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO;
-    const double *sh_arr = want_ELG ? shear : nullptr;
-#pragma unroll 2
-    for (int k = 0; k < PER_THREAD / 2; k++) {
-        const int loc = k * (2 * FBLOCK) + 2 * tid;
-        const int64_t i = tile0 + loc;
-        if (i < n) {
-            bool need0 = true, need1 = i + 1 < n;
-            if (F.cent_ok) {
-                double m0, m1, mu0, mu1, r0, r1, d0, d1, f0, f1, s0 = 0, s1 = 0;
-                load2(mass, i, n, 1.0, m0, m1);
-                load2(multis, i, n, 0.0, mu0, mu1);
-                load2(randoms, i, n, 2.0, r0, r1);
-                load2(deltac, i, n, 0.0, d0, d1);
-                load2(fenv, i, n, 0.0, f0, f1);
-                if (sh_arr) load2(sh_arr, i, n, 0.0, s0, s1);
-                need0 = !cent_reject(pw, F, m0, mu0, r0, d0, f0, s0);
-                need1 = need1 && !cent_reject(pw, F, m1, mu1, r1, d1, f1, s1);
-            }
-            if (need0) q[atomicAdd(&nq, 1)] = (unsigned short)loc;
-            if (need1) q[atomicAdd(&nq, 1)] = (unsigned short)(loc + 1);
-        }
-    }
-    {   // zero this tile's mask: 8 consecutive bytes per thread
-        const int64_t o = tile0 + (int64_t)tid * 8;
-        if (o + 8 <= n) *reinterpret_cast<unsigned long long *>(keep + o) = 0ull;
-        else
-            for (int q8 = 0; q8 < 8; q8++)
-                if (o + q8 < n) keep[o + q8] = 0;
-    }
-    __syncthreads();
-    // the tile's survivors go to the tile's own slice of the queue: no global atomics anywhere
-    const int cnt = nq;
-    if (tid == 0) q_count[blockIdx.x] = cnt;
-    for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
-}
+// All device pointers of the staged catalogue + work arrays, passed by value to the fused kernels
+struct HodPtrs {
+    int64_t nh, np;
+    int ntile_c, ntile_s, nsb_c, nsb_s;
+    const double *hmass, *hmultis, *hrandoms, *hdeltac, *hfenv, *hshear;
+    const double *phmass, *pweights, *prandoms, *pdeltac, *pfenv, *pshear, *pranks, *pranksv, *pranksp, *pranksr;
+    const int64_t *pinds;
+    int8_t *keep_c, *keep_s;
+    int *q_count;                       // [ntile_c + ntile_s]
+    unsigned short *queue_c, *queue_s;  // one TILE-sized slice per tile
+    int *tile_counts, *sb_counts;       // [ntile_c + ntile_s][4], [nsb_c + nsb_s][4]
+};
 
-__global__ __launch_bounds__(FBLOCK) void hod_filter_sat(
-    int64_t n, const double *__restrict__ hmass, const double *__restrict__ weights,
-    const double *__restrict__ randoms, const double *__restrict__ ranks, const double *__restrict__ ranksv,
-    const double *__restrict__ ranksp, const double *__restrict__ ranksr, const int64_t *__restrict__ pinds,
-    const int8_t *__restrict__ keep_cent, int want_LRG, int want_ELG, int want_QSO, int enable_ranks, Filt F,
-    int8_t *__restrict__ keep, int *__restrict__ q_count, unsigned short *__restrict__ queue) {
+// One launch filters central tiles (global tile id < ntile_c) and satellite tiles alike; `first_tile` lets the host
+// split it in two when the satellite filter needs the exact central decisions (ELG conformity reads keep_cent[pinds]).
+// `need_env`: some wanted tracer has a non-zero Acent/Bcent (Ccent for the shear); otherwise deltac / fenv / shear
+// enter the reference's formula as `0 * x` and are not read (a non-finite x makes the exact marker NaN = never kept,
+// which a filter that does not reject is consistent with).
+__global__ __launch_bounds__(FBLOCK) void hod_filter(HodPtrs a, int first_tile, int want_LRG, int want_ELG,
+                                                     int want_QSO, int enable_ranks, int need_env, int need_shear,
+                                                     Filt F) {
     __shared__ int nq;
     __shared__ unsigned short q[TILE];
     const int tid = threadIdx.x;
     if (tid == 0) nq = 0;
     __syncthreads();
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
-    abacus_hod_params pw;
+    const int g = (int)blockIdx.x + first_tile;
+    const bool sat = g >= a.ntile_c;
+    const int T = sat ? g - a.ntile_c : g;
+    const int64_t n = sat ? a.np : a.nh;
+    const int64_t tile0 = (int64_t)T * TILE;
+    int8_t *keep = sat ? a.keep_s : a.keep_c;
+    abacus_hod_params pw;   // only the want_* / enable_ranks flags are read by *_reject
     pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO, pw.enable_ranks = enable_ranks;
-    const bool need_conf = want_ELG && pinds != nullptr;
+    if (!sat) {
 #pragma unroll 2
-    for (int k = 0; k < PER_THREAD / 2; k++) {
-        const int loc = k * (2 * FBLOCK) + 2 * tid;
-        const int64_t i = tile0 + loc;
-        if (i < n) {
-            bool need0 = true, need1 = i + 1 < n;
-            if (F.sat_ok) {
-                double m0, m1, w0, w1, r0, r1;
-                double a0 = 1, a1 = 1, b0 = 1, b1 = 1, c0 = 1, c1 = 1, e0 = 1, e1 = 1;
-                int8_t kc0 = 0, kc1 = 0;
-                load2(hmass, i, n, 1.0, m0, m1);
-                load2(weights, i, n, 0.0, w0, w1);
-                load2(randoms, i, n, 2.0, r0, r1);
-                if (enable_ranks) {
-                    load2(ranks, i, n, 1.0, a0, a1);
-                    load2(ranksv, i, n, 1.0, b0, b1);
-                    load2(ranksp, i, n, 1.0, c0, c1);
-                    load2(ranksr, i, n, 1.0, e0, e1);
+        for (int k = 0; k < PER_THREAD / 2; k++) {
+            const int loc = k * (2 * FBLOCK) + 2 * tid;
+            const int64_t i = tile0 + loc;
+            if (i < n) {
+                bool need0 = true, need1 = i + 1 < n;
+                if (F.cent_ok) {
+                    double m0, m1, mu0, mu1, r0, r1, d0 = 0, d1 = 0, f0 = 0, f1 = 0, s0 = 0, s1 = 0;
+                    load2(a.hmass, i, n, 1.0, m0, m1);
+                    load2(a.hmultis, i, n, 0.0, mu0, mu1);
+                    load2(a.hrandoms, i, n, 2.0, r0, r1);
+                    if (need_env) {
+                        load2(a.hdeltac, i, n, 0.0, d0, d1);
+                        load2(a.hfenv, i, n, 0.0, f0, f1);
+                    }
+                    if (need_shear) load2(a.hshear, i, n, 0.0, s0, s1);
+                    need0 = !cent_reject(pw, F, m0, mu0, r0, d0, f0, s0);
+                    need1 = need1 && !cent_reject(pw, F, m1, mu1, r1, d1, f1, s1);
                 }
-                if (need_conf) {
-                    kc0 = keep_cent[pinds[i]];
-                    if (i + 1 < n) kc1 = keep_cent[pinds[i + 1]];
-                }
-                need0 = !sat_reject(pw, F, m0, w0, r0, a0, b0, c0, e0, kc0);
-                need1 = need1 && !sat_reject(pw, F, m1, w1, r1, a1, b1, c1, e1, kc1);
+                if (need0) q[atomicAdd(&nq, 1)] = (unsigned short)loc;
+                if (need1) q[atomicAdd(&nq, 1)] = (unsigned short)(loc + 1);
             }
-            if (need0) q[atomicAdd(&nq, 1)] = (unsigned short)loc;
-            if (need1) q[atomicAdd(&nq, 1)] = (unsigned short)(loc + 1);
+        }
+    } else {
+        const bool need_conf = want_ELG && a.pinds != nullptr;
+#pragma unroll 2
+        for (int k = 0; k < PER_THREAD / 2; k++) {
+            const int loc = k * (2 * FBLOCK) + 2 * tid;
+            const int64_t i = tile0 + loc;
+            if (i < n) {
+                bool need0 = true, need1 = i + 1 < n;
+                if (F.sat_ok) {
+                    double m0, m1, w0, w1, r0, r1;
+                    double a0 = 1, a1 = 1, b0 = 1, b1 = 1, c0 = 1, c1 = 1, e0 = 1, e1 = 1;
+                    int8_t kc0 = 0, kc1 = 0;
+                    load2(a.phmass, i, n, 1.0, m0, m1);
+                    load2(a.pweights, i, n, 0.0, w0, w1);
+                    load2(a.prandoms, i, n, 2.0, r0, r1);
+                    if (enable_ranks) {
+                        load2(a.pranks, i, n, 1.0, a0, a1);
+                        load2(a.pranksv, i, n, 1.0, b0, b1);
+                        load2(a.pranksp, i, n, 1.0, c0, c1);
+                        load2(a.pranksr, i, n, 1.0, e0, e1);
+                    }
+                    if (need_conf) {
+                        kc0 = a.keep_c[a.pinds[i]];
+                        if (i + 1 < n) kc1 = a.keep_c[a.pinds[i + 1]];
+                    }
+                    need0 = !sat_reject(pw, F, m0, w0, r0, a0, b0, c0, e0, kc0);
+                    need1 = need1 && !sat_reject(pw, F, m1, w1, r1, a1, b1, c1, e1, kc1);
+                }
+                if (need0) q[atomicAdd(&nq, 1)] = (unsigned short)loc;
+                if (need1) q[atomicAdd(&nq, 1)] = (unsigned short)(loc + 1);
+            }
         }
     }
     {   // zero this tile's mask: 8 consecutive bytes per thread
@@ -395,7 +388,8 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_sat(
     __syncthreads();
     // the tile's survivors go to the tile's own slice of the queue: no global atomics anywhere
     const int cnt = nq;
-    if (tid == 0) q_count[blockIdx.x] = cnt;
+    if (tid == 0) a.q_count[g] = cnt;
+    unsigned short *queue = sat ? a.queue_s : a.queue_c;
     for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
 }
 
@@ -407,9 +401,8 @@ struct ExactLds {
     int cnt[SB_TILES][4];
 };
 
-__device__ __forceinline__ int exact_setup(ExactLds &L, const int *q_count, int ntile, int &tile_first) {
+__device__ __forceinline__ int exact_setup(ExactLds &L, const int *q_count, int ntile, int tile_first) {
     const int tid = threadIdx.x;
-    tile_first = blockIdx.x * SB_TILES;
     if (tid < SB_TILES) {
         const int t = tile_first + tid;
         L.pre[tid + 1] = t < ntile ? q_count[t] : 0;
@@ -432,7 +425,7 @@ __device__ __forceinline__ int exact_find_tile(const ExactLds &L, int j) {   // 
     }
     return lo;
 }
-__device__ __forceinline__ void exact_finish(ExactLds &L, int ntile, int tile_first, int *tile_counts, int *sb_counts) {
+__device__ __forceinline__ void exact_finish(ExactLds &L, int ntile, int tile_first, int *tile_counts, int *sb_count) {
     __syncthreads();
     const int tid = threadIdx.x;
     if (tid < SB_TILES * 4) {
@@ -442,67 +435,55 @@ __device__ __forceinline__ void exact_finish(ExactLds &L, int ntile, int tile_fi
     if (tid < 4) {
         int s = 0;
         for (int q = 0; q < SB_TILES; q++) s += L.cnt[q][tid];
-        sb_counts[(int64_t)blockIdx.x * 4 + tid] = s;
+        sb_count[tid] = s;
     }
 }
 
-__global__ __launch_bounds__(FBLOCK) void hod_exact_cent(const int *__restrict__ q_count,
-                                                         const unsigned short *__restrict__ queue, int ntile,
-                                                         const double *__restrict__ mass,
-                                                         const double *__restrict__ multis,
-                                                         const double *__restrict__ randoms,
-                                                         const double *__restrict__ deltac,
-                                                         const double *__restrict__ fenv,
-                                                         const double *__restrict__ shear, abacus_hod_params p,
-                                                         int8_t *__restrict__ keep, int *__restrict__ tile_counts,
-                                                         int *__restrict__ sb_counts) {
+// One launch for the central superblocks (global superblock id < nsb_c) and the satellite ones; `first_sb` splits
+// it when the satellites depend on the exact central decisions (ELG conformity).
+__global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre) {
     __shared__ ExactLds L;
-    int tile_first;
+    const int g = (int)blockIdx.x + first_sb;
+    const bool sat = g >= a.nsb_c;
+    const int S = sat ? g - a.nsb_c : g;
+    const int ntile = sat ? a.ntile_s : a.ntile_c;
+    const int tile_first = S * SB_TILES;
+    const int *q_count = a.q_count + (sat ? a.ntile_c : 0);
+    int *tile_counts = a.tile_counts + (sat ? (int64_t)a.ntile_c * 4 : 0);
     const int total = exact_setup(L, q_count, ntile, tile_first);
-    const double *sh_arr = p.want_ELG ? shear : nullptr;
-    for (int j = threadIdx.x; j < total; j += FBLOCK) {
-        const int q = exact_find_tile(L, j);
-        const int64_t t0 = (int64_t)(tile_first + q) * TILE;
-        const int64_t i = t0 + queue[t0 + (j - L.pre[q])];
-        const int8_t kk = cent_decide(p, mass[i], multis[i], randoms[i], load1(deltac, i, 0.0), load1(fenv, i, 0.0),
-                                      load1(sh_arr, i, 0.0));
-        if (kk) {
-            keep[i] = kk;
-            atomicAdd(&L.cnt[q][kk - 1], 1);
+    if (!sat) {
+        const double *sh_arr = p.want_ELG ? a.hshear : nullptr;
+        for (int j = threadIdx.x; j < total; j += FBLOCK) {
+            const int q = exact_find_tile(L, j);
+            const int64_t t0 = (int64_t)(tile_first + q) * TILE;
+            const int64_t i = t0 + a.queue_c[t0 + (j - L.pre[q])];
+            const int8_t kk = cent_decide(p, a.hmass[i], a.hmultis[i], a.hrandoms[i], load1(a.hdeltac, i, 0.0),
+                                          load1(a.hfenv, i, 0.0), load1(sh_arr, i, 0.0));
+            if (kk) {
+                a.keep_c[i] = kk;
+                atomicAdd(&L.cnt[q][kk - 1], 1);
+            }
+        }
+    } else {
+        const double *sh_arr = p.want_ELG ? a.pshear : nullptr;
+        const bool need_conf = p.want_ELG && a.pinds != nullptr;
+        const bool need_ranks = p.enable_ranks != 0;
+        for (int j = threadIdx.x; j < total; j += FBLOCK) {
+            const int q = exact_find_tile(L, j);
+            const int64_t t0 = (int64_t)(tile_first + q) * TILE;
+            const int64_t i = t0 + a.queue_s[t0 + (j - L.pre[q])];
+            const int8_t kc = need_conf ? a.keep_c[a.pinds[i]] : (int8_t)0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
+            const int8_t kk = sat_decide(p, pre, a.phmass[i], a.pweights[i], a.prandoms[i], load1(a.pdeltac, i, 0.0),
+                                         load1(a.pfenv, i, 0.0), load1(sh_arr, i, 0.0), need_ranks ? a.pranks[i] : 1.0,
+                                         need_ranks ? a.pranksv[i] : 1.0, need_ranks ? a.pranksp[i] : 1.0,
+                                         need_ranks ? a.pranksr[i] : 1.0, kc);
+            if (kk) {
+                a.keep_s[i] = kk;
+                atomicAdd(&L.cnt[q][kk - 1], 1);
+            }
         }
     }
-    exact_finish(L, ntile, tile_first, tile_counts, sb_counts);
-}
-
-__global__ __launch_bounds__(FBLOCK) void hod_exact_sat(
-    const int *__restrict__ q_count, const unsigned short *__restrict__ queue, int ntile,
-    const double *__restrict__ hmass, const double *__restrict__ weights, const double *__restrict__ randoms,
-    const double *__restrict__ deltac, const double *__restrict__ fenv, const double *__restrict__ shear,
-    const double *__restrict__ ranks, const double *__restrict__ ranksv, const double *__restrict__ ranksp,
-    const double *__restrict__ ranksr, const int64_t *__restrict__ pinds, const int8_t *__restrict__ keep_cent,
-    abacus_hod_params p, SatPre pre, int8_t *__restrict__ keep, int *__restrict__ tile_counts,
-    int *__restrict__ sb_counts) {
-    __shared__ ExactLds L;
-    int tile_first;
-    const int total = exact_setup(L, q_count, ntile, tile_first);
-    const double *sh_arr = p.want_ELG ? shear : nullptr;
-    const bool need_conf = p.want_ELG && pinds != nullptr;
-    const bool need_ranks = p.enable_ranks != 0;
-    for (int j = threadIdx.x; j < total; j += FBLOCK) {
-        const int q = exact_find_tile(L, j);
-        const int64_t t0 = (int64_t)(tile_first + q) * TILE;
-        const int64_t i = t0 + queue[t0 + (j - L.pre[q])];
-        const int8_t kc = need_conf ? keep_cent[pinds[i]] : (int8_t)0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
-        const int8_t kk = sat_decide(p, pre, hmass[i], weights[i], randoms[i], load1(deltac, i, 0.0),
-                                     load1(fenv, i, 0.0), load1(sh_arr, i, 0.0), need_ranks ? ranks[i] : 1.0,
-                                     need_ranks ? ranksv[i] : 1.0, need_ranks ? ranksp[i] : 1.0,
-                                     need_ranks ? ranksr[i] : 1.0, kc);
-        if (kk) {
-            keep[i] = kk;
-            atomicAdd(&L.cnt[q][kk - 1], 1);
-        }
-    }
-    exact_finish(L, ntile, tile_first, tile_counts, sb_counts);
+    exact_finish(L, ntile, tile_first, tile_counts, a.sb_counts + (int64_t)g * 4);
 }
 
 struct OutCols {
@@ -921,25 +902,39 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     pre.E_M1_EL = pow(10.0, p->E_logM1_EL), pre.E_M1_EE = pow(10.0, p->E_logM1_EE);
     pre.Q_M1 = pow(10.0, p->Q_logM1), pre.Q_Mcut = pow(10.0, p->Q_logM_cut);
     Filt F = make_filter(*p, pre);
-    if (st->ntile_c) {
-        ABACUS_LAUNCH("hod_filter_cent", hod_filter_cent, dim3(st->ntile_c), dim3(FBLOCK), 0, st->nh, st->hmass,
-                      st->hmultis, st->hrandoms, st->hdeltac, st->hfenv, st->hshear, p->want_LRG, p->want_ELG,
-                      p->want_QSO, F, st->keep_c, st->q_count, st->queue_c);
-        ABACUS_LAUNCH("hod_exact_cent", hod_exact_cent, dim3(st->nsb_c), dim3(FBLOCK), 0, st->q_count, st->queue_c,
-                      st->ntile_c, st->hmass, st->hmultis, st->hrandoms, st->hdeltac, st->hfenv, st->hshear, *p,
-                      st->keep_c, st->tile_counts, st->sb_counts);
+    HodPtrs a;
+    a.nh = st->nh, a.np = st->np, a.ntile_c = st->ntile_c, a.ntile_s = st->ntile_s, a.nsb_c = st->nsb_c, a.nsb_s = st->nsb_s;
+    a.hmass = st->hmass, a.hmultis = st->hmultis, a.hrandoms = st->hrandoms, a.hdeltac = st->hdeltac,
+    a.hfenv = st->hfenv, a.hshear = st->hshear;
+    a.phmass = st->phmass, a.pweights = st->pweights, a.prandoms = st->prandoms, a.pdeltac = st->pdeltac,
+    a.pfenv = st->pfenv, a.pshear = st->pshear, a.pranks = st->pranks, a.pranksv = st->pranksv,
+    a.pranksp = st->pranksp, a.pranksr = st->pranksr, a.pinds = st->pinds;
+    a.keep_c = st->keep_c, a.keep_s = st->keep_s, a.q_count = st->q_count, a.queue_c = st->queue_c,
+    a.queue_s = st->queue_s, a.tile_counts = st->tile_counts, a.sb_counts = st->sb_counts;
+    // deltac / fenv / shear are streamed by the central filter only when some wanted tracer weights them
+    const int need_env = (p->want_LRG && (p->L_Acent != 0 || p->L_Bcent != 0)) ||
+                         (p->want_ELG && (p->E_Acent != 0 || p->E_Bcent != 0)) ||
+                         (p->want_QSO && (p->Q_Acent != 0 || p->Q_Bcent != 0));
+    const int need_shear = p->want_ELG && p->E_Ccent != 0 && st->hshear != nullptr;
+    const bool conf = p->want_ELG && st->pinds != nullptr && st->ntile_s > 0;   // satellites read keep_cent[pinds]
+    const int ntile = st->ntile_c + st->ntile_s, nsb = st->nsb_c + st->nsb_s;
+#define FILTER(first, count)                                                                                         \
+    if ((count) > 0)                                                                                                 \
+    ABACUS_LAUNCH("hod_filter", hod_filter, dim3(count), dim3(FBLOCK), 0, a, first, p->want_LRG, p->want_ELG,        \
+                  p->want_QSO, p->enable_ranks, need_env, need_shear, F)
+#define EXACT(first, count) \
+    if ((count) > 0) ABACUS_LAUNCH("hod_exact", hod_exact, dim3(count), dim3(FBLOCK), 0, a, first, *p, pre)
+    if (!conf) {
+        FILTER(0, ntile);
+        EXACT(0, nsb);
+    } else {
+        FILTER(0, st->ntile_c);
+        EXACT(0, st->nsb_c);
+        FILTER(st->ntile_c, st->ntile_s);
+        EXACT(st->nsb_c, st->nsb_s);
     }
-    if (st->ntile_s) {
-        int *tc_s = st->tile_counts + (int64_t)st->ntile_c * 4, *sb_s = st->sb_counts + (int64_t)st->nsb_c * 4;
-        int *qc_s = st->q_count + st->ntile_c;
-        ABACUS_LAUNCH("hod_filter_sat", hod_filter_sat, dim3(st->ntile_s), dim3(FBLOCK), 0, st->np, st->phmass,
-                      st->pweights, st->prandoms, st->pranks, st->pranksv, st->pranksp, st->pranksr, st->pinds,
-                      st->keep_c, p->want_LRG, p->want_ELG, p->want_QSO, p->enable_ranks, F, st->keep_s, qc_s,
-                      st->queue_s);
-        ABACUS_LAUNCH("hod_exact_sat", hod_exact_sat, dim3(st->nsb_s), dim3(FBLOCK), 0, qc_s, st->queue_s, st->ntile_s,
-                      st->phmass, st->pweights, st->prandoms, st->pdeltac, st->pfenv, st->pshear, st->pranks,
-                      st->pranksv, st->pranksp, st->pranksr, st->pinds, st->keep_c, *p, pre, st->keep_s, tc_s, sb_s);
-    }
+#undef FILTER
+#undef EXACT
     // speculative emission into the current buffers (writes past capacity are suppressed on the device)
     ABACUS_TRY(launch_emit(st));
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));

@@ -585,7 +585,6 @@ int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const 
             int64_t *N_mode_poles, float *k_avg, void *raw_out = nullptr) {
     if (Nk < 1 || Nmu < 1) return fail("power: need at least one k bin and one mu bin");
     if (Np_all > MAX_POLES) return fail("power: more than %d multipoles requested", MAX_POLES);
-    const int nmesh = s.n;
     const double dk = 2.0 * M_PI / Lbox;
     BinArgs b;
     b.Nk = Nk;

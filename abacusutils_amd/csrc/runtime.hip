@@ -57,6 +57,7 @@ static bool g_prof = false;
 static std::map<std::string, ProfEntry> g_prof_map;
 static std::vector<hipEvent_t> g_event_pool;
 static hipEvent_t g_prof_open = nullptr;
+static std::string g_prof_only;   // when set, only this kernel is bracketed (two event records cost a few us per launch)
 
 static hipEvent_t pool_get() {
     if (!g_event_pool.empty()) {
@@ -71,6 +72,7 @@ static hipEvent_t pool_get() {
 
 void prof_begin(const char *name) {
     if (!g_prof) return;
+    if (!g_prof_only.empty() && g_prof_only != name) return;
     g_prof_open = pool_get();
     (void)hipEventRecord(g_prof_open, g_stream);
 }
@@ -200,6 +202,11 @@ int abacus_profile_enable(int on) {
     g_prof = on != 0;
     return 0;
 }
+int abacus_profile_select(const char *name) {
+    g_prof_only = name ? name : "";
+    return 0;
+}
+
 int abacus_profile_reset(void) {
     prof_drain();
     g_prof_map.clear();

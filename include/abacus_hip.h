@@ -51,6 +51,8 @@ int abacus_event_destroy(void *ev);
 /* per-kernel timing: when enabled every kernel launch is bracketed by events on the library stream */
 int abacus_profile_enable(int on);
 int abacus_profile_reset(void);
+/* bracket only the kernel called `name` (NULL or "": all kernels) - keeps the event overhead out of short steps */
+int abacus_profile_select(const char *name);
 /* writes up to `cap` entries; returns the number of distinct kernels (names are static strings) */
 int abacus_profile_get(const char **names, double *total_ms, int64_t *launches, int cap);
 
