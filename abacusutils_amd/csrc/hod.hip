@@ -5,17 +5,16 @@
 // pos/vel, int64 ids) and stay resident across populate calls (the MCMC use case of staging()).
 //
 // Kernels (all HBM-bound streaming, no MFMA - there is no contraction on this path):
-//   hod_filter (central + satellite tiles in one launch)   one pass over the per-halo / per-particle scalars (16-B coalesced loads):
-//        a float32 upper bound of the marker chain proves keep = 0 for the bulk of the objects; the rest is queued.
-//        Tiles of 2048 objects -> thousands of workgroups for the 256 CUs.
-//   hod_exact (central + satellite superblocks)   exact FP64 occupation math (erfc, log10, pow) for the queued objects only;
-//        writes their int8 keep bytes and bumps per-tile and per-"superblock" (32 tiles) tracer counters, so no
-//        separate scan launch is needed.
-//   hod_emit                           8192 objects per workgroup: sums the superblock / tile counters in front of
-//        it (a few hundred L2-resident ints) for its output offset - satellites start at Ncent, so
-//        centrals||satellites land concatenated (no fast_concatenate pass) - re-reads the 1-byte mask in blocked
-//        order, block-scans per-thread counts and writes the galaxies in input order (stable compaction = the
-//        reference's order for any Nthread).
+//   hod_filter   central + satellite tiles (2048 objects) in one launch: one pass over the per-halo / per-particle
+//        scalars (16-B coalesced loads); a float32 upper bound of the marker chain proves keep = 0 for the bulk of
+//        the objects, the rest is queued per tile.  Thousands of workgroups for the 256 CUs.
+//   hod_exact    one workgroup per superblock (16 tiles): exact FP64 occupation math (erfc, log10, pow) for the
+//        queued objects only; writes their int8 keep bytes, and - through per-tracer LDS bitmaps and a popcount scan -
+//        the superblock's kept list in index order plus its three counts.
+//   hod_emit     one workgroup per superblock: sums the counters of the superblocks in front of it (a few hundred
+//        L2-resident ints) for its output offset - satellites start at Ncent, so centrals||satellites land
+//        concatenated (no fast_concatenate pass) - and gathers / writes the kept rows in input order (stable
+//        compaction = the reference's order for any Nthread).
 // All FP64 arithmetic that reaches an OUTPUT (velocity bias, RSD) is + - * / sqrt in the reference's order,
 // compiled with -ffp-contract=off, so outputs are bit-identical to the CPU; the keep decision compares
 // randoms against erfc/log10/pow-based markers whose last-ulp differences (ocml vs libm) only matter for a
@@ -33,7 +32,9 @@ namespace {
 constexpr int TILE = 2048;    // objects per workgroup
 constexpr int BLOCK = 256;    // threads per workgroup (4 waves)
 constexpr int PER_THREAD = TILE / BLOCK;
-constexpr int SB_TILES = 32;                       // decide tiles per superblock counter
+constexpr int SB_TILES = 16;                       // decide tiles per superblock (one exact / emit workgroup)
+constexpr int SB_OBJ = SB_TILES * TILE;            // 32768 objects: an in-superblock index fits uint16
+constexpr int SB_WORDS = SB_OBJ / 32;              // words of one tracer's keep bitmap
 
 // ---- occupation functions (hod/GRAND_HOD.py:23-136) ------------------------------------------------------
 __device__ __forceinline__ double n_cen_LRG(double M_h, double logM_cut, double sigma) {
@@ -297,7 +298,8 @@ struct HodPtrs {
     int8_t *keep_c, *keep_s;
     int *q_count;                       // [ntile_c + ntile_s]
     unsigned short *queue_c, *queue_s;  // one TILE-sized slice per tile
-    int *tile_counts, *sb_counts;       // [ntile_c + ntile_s][4], [nsb_c + nsb_s][4]
+    unsigned short *kept_c, *kept_s;    // one SB_OBJ-sized slice per superblock: kept objects, tracer-major, index order
+    int *sb_counts;                     // [nsb_c + nsb_s][4]
 };
 
 // One launch filters central tiles (global tile id < ntile_c) and satellite tiles alike; `first_tile` lets the host
@@ -393,29 +395,19 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter(HodPtrs a, int first_tile, 
     for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
 }
 
-// Exact kernels: one workgroup per superblock (32 tiles).  The tiles' queue lengths are prefix-summed in LDS so the
-// ~500 survivors of the superblock are processed as one dense list; tile and superblock counters are accumulated
-// in LDS and written with plain stores.
+// Exact kernel: one workgroup per superblock (16 tiles = 32768 objects).  The tiles' queue lengths are prefix-summed
+// in LDS so the few hundred survivors of the superblock are processed as one dense list.  Kept objects set a bit in
+// one of three LDS bitmaps (one per tracer); a popcount scan of the bitmaps then yields every kept object's rank in
+// index order, and the workgroup writes the superblock's kept list (uint16 in-superblock indices, tracer-major,
+// ascending) plus its three counts.  hod_emit needs nothing else: no mask re-read, no per-tile counters.
 struct ExactLds {
     int pre[SB_TILES + 1];
-    int cnt[SB_TILES][4];
+    unsigned int bm[3][SB_WORDS];
+    unsigned long long wave_tot[FBLOCK / 64];
 };
+constexpr int WORDS_PER_THREAD = SB_WORDS / FBLOCK;   // 4
+static_assert(SB_WORDS % FBLOCK == 0, "bitmap words must divide over the workgroup");
 
-__device__ __forceinline__ int exact_setup(ExactLds &L, const int *q_count, int ntile, int tile_first) {
-    const int tid = threadIdx.x;
-    if (tid < SB_TILES) {
-        const int t = tile_first + tid;
-        L.pre[tid + 1] = t < ntile ? q_count[t] : 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) L.cnt[tid][c] = 0;
-    }
-    if (tid == 0) L.pre[0] = 0;
-    __syncthreads();
-    if (tid == 0)
-        for (int q = 1; q <= SB_TILES; q++) L.pre[q] += L.pre[q - 1];
-    __syncthreads();
-    return L.pre[SB_TILES];
-}
 __device__ __forceinline__ int exact_find_tile(const ExactLds &L, int j) {   // largest q with pre[q] <= j
     int lo = 0, hi = SB_TILES - 1;
     while (lo < hi) {
@@ -425,53 +417,54 @@ __device__ __forceinline__ int exact_find_tile(const ExactLds &L, int j) {   // 
     }
     return lo;
 }
-__device__ __forceinline__ void exact_finish(ExactLds &L, int ntile, int tile_first, int *tile_counts, int *sb_count) {
-    __syncthreads();
-    const int tid = threadIdx.x;
-    if (tid < SB_TILES * 4) {
-        const int q = tid >> 2, c = tid & 3, t = tile_first + q;
-        if (t < ntile) tile_counts[(int64_t)t * 4 + c] = L.cnt[q][c];
-    }
-    if (tid < 4) {
-        int s = 0;
-        for (int q = 0; q < SB_TILES; q++) s += L.cnt[q][tid];
-        sb_count[tid] = s;
-    }
-}
 
 // One launch for the central superblocks (global superblock id < nsb_c) and the satellite ones; `first_sb` splits
 // it when the satellites depend on the exact central decisions (ELG conformity).
 __global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre) {
     __shared__ ExactLds L;
+    const int tid = threadIdx.x;
     const int g = (int)blockIdx.x + first_sb;
     const bool sat = g >= a.nsb_c;
     const int S = sat ? g - a.nsb_c : g;
     const int ntile = sat ? a.ntile_s : a.ntile_c;
     const int tile_first = S * SB_TILES;
     const int *q_count = a.q_count + (sat ? a.ntile_c : 0);
-    int *tile_counts = a.tile_counts + (sat ? (int64_t)a.ntile_c * 4 : 0);
-    const int total = exact_setup(L, q_count, ntile, tile_first);
+    if (tid < SB_TILES) {
+        const int t = tile_first + tid;
+        L.pre[tid + 1] = t < ntile ? q_count[t] : 0;
+    }
+    if (tid == 0) L.pre[0] = 0;
+#pragma unroll
+    for (int w = 0; w < 3 * WORDS_PER_THREAD; w++) (&L.bm[0][0])[w * FBLOCK + tid] = 0u;
+    __syncthreads();
+    if (tid == 0)
+        for (int q = 1; q <= SB_TILES; q++) L.pre[q] += L.pre[q - 1];
+    __syncthreads();
+    const int total = L.pre[SB_TILES];
     if (!sat) {
         const double *sh_arr = p.want_ELG ? a.hshear : nullptr;
-        for (int j = threadIdx.x; j < total; j += FBLOCK) {
+        for (int j = tid; j < total; j += FBLOCK) {
             const int q = exact_find_tile(L, j);
             const int64_t t0 = (int64_t)(tile_first + q) * TILE;
-            const int64_t i = t0 + a.queue_c[t0 + (j - L.pre[q])];
+            const int loc = a.queue_c[t0 + (j - L.pre[q])];
+            const int64_t i = t0 + loc;
             const int8_t kk = cent_decide(p, a.hmass[i], a.hmultis[i], a.hrandoms[i], load1(a.hdeltac, i, 0.0),
                                           load1(a.hfenv, i, 0.0), load1(sh_arr, i, 0.0));
             if (kk) {
                 a.keep_c[i] = kk;
-                atomicAdd(&L.cnt[q][kk - 1], 1);
+                const int ls = q * TILE + loc;
+                atomicOr(&L.bm[kk - 1][ls >> 5], 1u << (ls & 31));
             }
         }
     } else {
         const double *sh_arr = p.want_ELG ? a.pshear : nullptr;
         const bool need_conf = p.want_ELG && a.pinds != nullptr;
         const bool need_ranks = p.enable_ranks != 0;
-        for (int j = threadIdx.x; j < total; j += FBLOCK) {
+        for (int j = tid; j < total; j += FBLOCK) {
             const int q = exact_find_tile(L, j);
             const int64_t t0 = (int64_t)(tile_first + q) * TILE;
-            const int64_t i = t0 + a.queue_s[t0 + (j - L.pre[q])];
+            const int loc = a.queue_s[t0 + (j - L.pre[q])];
+            const int64_t i = t0 + loc;
             const int8_t kc = need_conf ? a.keep_c[a.pinds[i]] : (int8_t)0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
             const int8_t kk = sat_decide(p, pre, a.phmass[i], a.pweights[i], a.prandoms[i], load1(a.pdeltac, i, 0.0),
                                          load1(a.pfenv, i, 0.0), load1(sh_arr, i, 0.0), need_ranks ? a.pranks[i] : 1.0,
@@ -479,11 +472,58 @@ __global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, aba
                                          need_ranks ? a.pranksr[i] : 1.0, kc);
             if (kk) {
                 a.keep_s[i] = kk;
-                atomicAdd(&L.cnt[q][kk - 1], 1);
+                const int ls = q * TILE + loc;
+                atomicOr(&L.bm[kk - 1][ls >> 5], 1u << (ls & 31));
             }
         }
     }
-    exact_finish(L, ntile, tile_first, tile_counts, a.sb_counts + (int64_t)g * 4);
+    __syncthreads();
+    // ranks: thread t owns words [4t, 4t+4) of each bitmap; packed 3 x 21-bit exclusive scan over the workgroup
+    unsigned int wbits[3][WORDS_PER_THREAD];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        unsigned int c = 0;
+#pragma unroll
+        for (int w = 0; w < WORDS_PER_THREAD; w++) {
+            wbits[t][w] = L.bm[t][tid * WORDS_PER_THREAD + w];
+            c += __popc(wbits[t][w]);
+        }
+        mine |= (unsigned long long)c << (21 * t);
+    }
+    unsigned long long incl = mine;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) L.wave_tot[wv] = incl;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < FBLOCK / 64; w++) {
+        if (w < wv) before += L.wave_tot[w];
+        all += L.wave_tot[w];
+    }
+    const unsigned long long excl = before + incl - mine;
+    const int T0 = (int)(all & 0x1fffff), T1 = (int)((all >> 21) & 0x1fffff), T2 = (int)((all >> 42) & 0x1fffff);
+    unsigned short *kept = (sat ? a.kept_s : a.kept_c) + (int64_t)S * SB_OBJ;
+    const int base[3] = {0, T0, T0 + T1};
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        int r = base[t] + (int)((excl >> (21 * t)) & 0x1fffff);
+#pragma unroll
+        for (int w = 0; w < WORDS_PER_THREAD; w++) {
+            unsigned int bits = wbits[t][w];
+            while (bits) {
+                const int bpos = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                kept[r++] = (unsigned short)((tid * WORDS_PER_THREAD + w) * 32 + bpos);
+            }
+        }
+    }
+    if (tid < 4) a.sb_counts[(int64_t)g * 4 + tid] = tid == 0 ? T0 : (tid == 1 ? T1 : (tid == 2 ? T2 : 0));
 }
 
 struct OutCols {
@@ -520,13 +560,12 @@ __device__ __forceinline__ void emit_one(const abacus_hod_params &p, const OutCo
     o.id[t][j] = id;
 }
 
-// Ordered emission, one WAVE per decide tile (2048 objects, 32 consecutive objects per lane: two 16-B loads of the
-// mask).  No LDS and no barriers: the output offset is a wave reduction over the counters in front of the tile
-// (whole superblocks from the superblock counters, the rest from the tile counters; satellites start after all
-// centrals of their tracer, so centrals||satellites land concatenated and fast_concatenate never runs), the rank
-// inside the tile a packed 3 x 20-bit wave scan.  Waves [0, ntile_c) handle centrals, the rest satellites.
-constexpr int EBLOCK = 64;
-constexpr int EMIT_PER_LANE = TILE / EBLOCK;   // 32
+// Ordered emission, one workgroup per superblock.  The output offset of a superblock is a workgroup reduction over
+// the counts of the superblocks in front of it (satellites start after all centrals of their tracer, so
+// centrals||satellites land concatenated and fast_concatenate never runs); the rank inside the superblock is the
+// position in the kept list hod_exact wrote.  All lanes gather and emit: the only inputs are the counters, the kept
+// list and the kept rows.  Workgroups [0, nsb_c) handle centrals, the rest satellites.
+constexpr int EBLOCK = 256;
 
 __device__ __forceinline__ int64_t wave_sum(int64_t v) {
 #pragma unroll
@@ -534,152 +573,91 @@ __device__ __forceinline__ int64_t wave_sum(int64_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(EBLOCK) void hod_emit(int64_t nh, int64_t np, int ntile_c, int ntile_s,
-                                                   const int8_t *__restrict__ keep_c,
-                                                   const int8_t *__restrict__ keep_s,
-                                                   const int *__restrict__ tile_counts,
-                                                   const int *__restrict__ sb_counts, int64_t *__restrict__ totals,
-                                                   const double *__restrict__ hpos, const double *__restrict__ hvel,
-                                                   const double *__restrict__ hvdev, const double *__restrict__ hmass,
-                                                   const int64_t *__restrict__ hid, const double *__restrict__ ppos,
-                                                   const double *__restrict__ pvel, const double *__restrict__ phvel,
-                                                   const double *__restrict__ phmass,
-                                                   const int64_t *__restrict__ phid, abacus_hod_params p, OutCols o) {
-    const int nsb_c = (ntile_c + SB_TILES - 1) / SB_TILES, nsb_s = (ntile_s + SB_TILES - 1) / SB_TILES;
-    const bool sat = (int)blockIdx.x >= ntile_c;
-    const int T0 = sat ? blockIdx.x - ntile_c : blockIdx.x;
-    const int64_t n = sat ? np : nh;
-    const int8_t *keep = sat ? keep_s : keep_c;
-    const int lane = threadIdx.x;
-    const int *sb_c = sb_counts, *sb_s = sb_counts + (int64_t)nsb_c * 4;
-    const int *tc = tile_counts + (sat ? (int64_t)ntile_c * 4 : 0);
+struct EmitPtrs {
+    const double *hpos, *hvel, *hvdev, *hmass, *ppos, *pvel, *phvel, *phmass;
+    const int64_t *hid, *phid;
+};
 
-    if (blockIdx.x == 0) {  // totals for the host: Ncent[3], Nsat[3]
-        int64_t c3[3] = {0, 0, 0}, s3[3] = {0, 0, 0};
-        for (int s = lane; s < nsb_c; s += EBLOCK)
+__global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const unsigned short *__restrict__ kept_c,
+                                                   const unsigned short *__restrict__ kept_s,
+                                                   const int *__restrict__ sb_counts, int64_t *__restrict__ totals,
+                                                   EmitPtrs in, abacus_hod_params p, OutCols o) {
+    __shared__ int64_t red[EBLOCK / 64][6];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = blockIdx.x;
+    const bool sat = g >= nsb_c;
+    const int S = sat ? g - nsb_c : g;
+    const int *sb_c = sb_counts, *sb_s = sb_counts + (int64_t)nsb_c * 4;
+    const int *sb_mine = sat ? sb_s : sb_c;
+    // v[0..2]: counts of the superblocks of my kind in front of me; v[3..5]: all central counts (satellite offset,
+    // and block 0 reports the totals)
+    int64_t v[6] = {0, 0, 0, 0, 0, 0};
+    for (int s = tid; s < S; s += EBLOCK)
 #pragma unroll
-            for (int t = 0; t < 3; t++) c3[t] += sb_c[(int64_t)s * 4 + t];
-        for (int s = lane; s < nsb_s; s += EBLOCK)
+        for (int t = 0; t < 3; t++) v[t] += sb_mine[(int64_t)s * 4 + t];
+    if (sat || g == 0)
+        for (int s = tid; s < nsb_c; s += EBLOCK)
+#pragma unroll
+            for (int t = 0; t < 3; t++) v[3 + t] += sb_c[(int64_t)s * 4 + t];
+#pragma unroll
+    for (int t = 0; t < 6; t++) v[t] = wave_sum(v[t]);
+    if (lane == 0)
+#pragma unroll
+        for (int t = 0; t < 6; t++) red[wv][t] = v[t];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        v[t] = 0;
+#pragma unroll
+        for (int w = 0; w < EBLOCK / 64; w++) v[t] += red[w][t];
+    }
+    if (g == 0) {   // totals for the host: Ncent[3], Nsat[3]
+        int64_t s3[3] = {0, 0, 0};
+        for (int s = tid; s < nsb_s; s += EBLOCK)
 #pragma unroll
             for (int t = 0; t < 3; t++) s3[t] += sb_s[(int64_t)s * 4 + t];
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            c3[t] = wave_sum(c3[t]);
-            s3[t] = wave_sum(s3[t]);
-        }
-        if (lane < 3) {
-            totals[lane] = lane == 0 ? c3[0] : (lane == 1 ? c3[1] : c3[2]);
-            totals[3 + lane] = lane == 0 ? s3[0] : (lane == 1 ? s3[1] : s3[2]);
-        }
-    }
-    // nothing selected in this tile: done (the common case for rare tracers is still a non-empty tile)
-    const int4 mine_cnt = *reinterpret_cast<const int4 *>(tc + (int64_t)T0 * 4);
-    if (mine_cnt.x + mine_cnt.y + mine_cnt.z == 0) return;
-
-    // ---- mask of this lane's 32 objects ----
-    const int64_t i0 = (int64_t)T0 * TILE + (int64_t)lane * EMIT_PER_LANE;
-    unsigned long long bits[EMIT_PER_LANE / 8];
-    if (i0 + EMIT_PER_LANE <= n) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(keep + i0);
-        const uint4 b = *reinterpret_cast<const uint4 *>(keep + i0 + 16);
-        bits[0] = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
-        bits[1] = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
-        bits[2] = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
-        bits[3] = (unsigned long long)b.z | ((unsigned long long)b.w << 32);
-    } else {
+        for (int t = 0; t < 3; t++) s3[t] = wave_sum(s3[t]);
+        if (lane == 0)
 #pragma unroll
-        for (int w = 0; w < EMIT_PER_LANE / 8; w++) {
-            bits[w] = 0;
-            for (int q = 0; q < 8; q++) {
-                const int64_t i = i0 + w * 8 + q;
-                if (i < n) bits[w] |= (unsigned long long)(unsigned char)keep[i] << (8 * q);
-            }
+            for (int t = 0; t < 3; t++) red[wv][t] = s3[t];
+        __syncthreads();
+        if (tid < 3) {
+            int64_t tot = 0;
+            for (int w = 0; w < EBLOCK / 64; w++) tot += red[w][tid];
+            totals[3 + tid] = tot;
+            totals[tid] = tid == 0 ? v[3] : (tid == 1 ? v[4] : v[5]);
         }
     }
-
-    // ---- offset of this tile ----
-    const int *sb_mine = sat ? sb_s : sb_c;
-    const int S = T0 / SB_TILES;
-    int64_t off[3] = {0, 0, 0};
-    for (int s = lane; s < S; s += EBLOCK)
-#pragma unroll
-        for (int t = 0; t < 3; t++) off[t] += sb_mine[(int64_t)s * 4 + t];
-    {
-        const int T = S * SB_TILES + lane;   // SB_TILES <= 64: one lane per tile of the superblock
-        if (T < T0)
-#pragma unroll
-            for (int t = 0; t < 3; t++) off[t] += tc[(int64_t)T * 4 + t];
-    }
-    if (sat)  // satellites follow all centrals of their tracer
-        for (int s = lane; s < nsb_c; s += EBLOCK)
-#pragma unroll
-            for (int t = 0; t < 3; t++) off[t] += sb_c[(int64_t)s * 4 + t];
-#pragma unroll
-    for (int t = 0; t < 3; t++) off[t] = wave_sum(off[t]);
-
-    // ---- ranks inside the tile: mask bytes are 0..3, counted with bit tricks (3 popcounts per 8 objects) ----
-    unsigned long long mine = 0;
-    constexpr unsigned long long LSB = 0x0101010101010101ull;
-#pragma unroll
-    for (int w = 0; w < EMIT_PER_LANE / 8; w++) {
-        const unsigned long long b0 = bits[w] & LSB, b1 = (bits[w] >> 1) & LSB;
-        mine += (unsigned long long)__popcll(b0 & ~b1) | ((unsigned long long)__popcll(b1 & ~b0) << 20) |
-                ((unsigned long long)__popcll(b0 & b1) << 40);
-    }
-    unsigned long long incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        unsigned long long v = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += v;
-    }
-    // ---- compact the selected objects of the tile into LDS (entry = loc | tracer << 11 | rank-in-tracer << 13),
-    //      then let consecutive lanes emit consecutive entries: the gathers of a tile issue together instead of one
-    //      divergent lane at a time ----
-    __shared__ unsigned int entries[TILE];
-    const unsigned long long excl = incl - mine;
-    const unsigned long long tot = __shfl(incl, 63, 64);
-    const int total = (int)((tot & 0xfffff) + ((tot >> 20) & 0xfffff) + ((tot >> 40) & 0xfffff));
-    {
-        int e = (int)((excl & 0xfffff) + ((excl >> 20) & 0xfffff) + ((excl >> 40) & 0xfffff));
-        unsigned int r[3] = {(unsigned int)(excl & 0xfffff), (unsigned int)((excl >> 20) & 0xfffff),
-                             (unsigned int)((excl >> 40) & 0xfffff)};
-        for (int w = 0; w < EMIT_PER_LANE / 8; w++) {
-            unsigned long long nz = (bits[w] | (bits[w] >> 1)) & LSB;   // one flag bit per selected object
-            while (nz) {
-                const int q = __ffsll((long long)nz) >> 3;              // byte index of the lowest flag
-                nz &= nz - 1;
-                const unsigned int t = (unsigned int)((bits[w] >> (8 * q)) & 0xff) - 1u;
-                const unsigned int loc = (unsigned int)(lane * EMIT_PER_LANE + w * 8 + q);
-                const unsigned int rk = t == 0 ? r[0]++ : (t == 1 ? r[1]++ : r[2]++);
-                entries[e++] = loc | (t << 11) | (rk << 13);
-            }
-        }
-    }
-    __syncthreads();
+    const int m0 = sb_counts[(int64_t)g * 4], m1 = sb_counts[(int64_t)g * 4 + 1], m2 = sb_counts[(int64_t)g * 4 + 2];
+    const int total = m0 + m1 + m2;
+    if (total == 0) return;
+    const int64_t off0 = v[0] + (sat ? v[3] : 0), off1 = v[1] + (sat ? v[4] : 0), off2 = v[2] + (sat ? v[5] : 0);
+    const unsigned short *kept = (sat ? kept_s : kept_c) + (int64_t)S * SB_OBJ;
     const double a0 = sat ? p.L_alpha_s : p.L_alpha_c, a1 = sat ? p.E_alpha_s : p.E_alpha_c,
                  a2 = sat ? p.Q_alpha_s : p.Q_alpha_c;
-    for (int e = lane; e < total; e += EBLOCK) {
-        const unsigned int en = entries[e];
-        const int t = (int)((en >> 11) & 3u);
-        const int64_t i = (int64_t)T0 * TILE + (en & 2047u);
-        const int64_t j = (t == 0 ? off[0] : (t == 1 ? off[1] : off[2])) + (int64_t)(en >> 13);
+    for (int e = tid; e < total; e += EBLOCK) {
+        const int t = e < m0 ? 0 : (e < m0 + m1 ? 1 : 2);
+        const int64_t j = t == 0 ? off0 + e : (t == 1 ? off1 + (e - m0) : off2 + (e - m0 - m1));
+        const int64_t i = (int64_t)S * SB_OBJ + kept[e];
         const double al = t == 0 ? a0 : (t == 1 ? a1 : a2);
         double x, y, z, vx, vy, vz, m;
         int64_t id;
         if (!sat) {
-            x = hpos[3 * i], y = hpos[3 * i + 1], z = hpos[3 * i + 2];
-            vx = hvel[3 * i] + al * hvdev[3 * i];  // velocity bias (:301-305)
-            vy = hvel[3 * i + 1] + al * hvdev[3 * i + 1];
-            vz = hvel[3 * i + 2] + al * hvdev[3 * i + 2];
-            m = hmass[i];
-            id = hid[i];
+            x = in.hpos[3 * i], y = in.hpos[3 * i + 1], z = in.hpos[3 * i + 2];
+            vx = in.hvel[3 * i] + al * in.hvdev[3 * i];  // velocity bias (:301-305)
+            vy = in.hvel[3 * i + 1] + al * in.hvdev[3 * i + 1];
+            vz = in.hvel[3 * i + 2] + al * in.hvdev[3 * i + 2];
+            m = in.hmass[i];
+            id = in.hid[i];
         } else {
-            x = ppos[3 * i], y = ppos[3 * i + 1], z = ppos[3 * i + 2];
-            vx = phvel[3 * i] + al * (pvel[3 * i] - phvel[3 * i]);  // (:1136-1146)
-            vy = phvel[3 * i + 1] + al * (pvel[3 * i + 1] - phvel[3 * i + 1]);
-            vz = phvel[3 * i + 2] + al * (pvel[3 * i + 2] - phvel[3 * i + 2]);
-            m = phmass[i];
-            id = phid[i];
+            x = in.ppos[3 * i], y = in.ppos[3 * i + 1], z = in.ppos[3 * i + 2];
+            vx = in.phvel[3 * i] + al * (in.pvel[3 * i] - in.phvel[3 * i]);  // (:1136-1146)
+            vy = in.phvel[3 * i + 1] + al * (in.pvel[3 * i + 1] - in.phvel[3 * i + 1]);
+            vz = in.phvel[3 * i + 2] + al * (in.pvel[3 * i + 2] - in.phvel[3 * i + 2]);
+            m = in.phmass[i];
+            id = in.phid[i];
         }
         emit_one(p, o, t, j, x, y, z, vx, vy, vz, m, id);
     }
@@ -702,10 +680,10 @@ struct abacus_hod_state {
     // work arrays
     int ntile_c = 0, ntile_s = 0;
     int8_t *keep_c = nullptr, *keep_s = nullptr;
-    int *tile_counts = nullptr;
     int *sb_counts = nullptr;   // [(nsb_c + nsb_s)][4]
     int *q_count = nullptr;                                  // [ntile_c + ntile_s] survivors of the float32 filter
     unsigned short *queue_c = nullptr, *queue_s = nullptr;   // tile-local indices, one TILE-sized slice per tile
+    unsigned short *kept_c = nullptr, *kept_s = nullptr;     // kept lists, one SB_OBJ-sized slice per superblock
     int nsb_c = 0, nsb_s = 0;
     int64_t *d_totals = nullptr;  // 6
     int64_t *h_totals = nullptr;  // pinned, 6
@@ -808,15 +786,16 @@ OutCols out_cols(abacus_hod_state *st) {
 }
 
 int launch_emit(abacus_hod_state *st) {
-    const int nemit = st->ntile_c + st->ntile_s;
+    const int nemit = st->nsb_c + st->nsb_s;
     if (nemit == 0) {
         HIP_TRY(hipMemsetAsync(st->d_totals, 0, 6 * sizeof(int64_t), stream()));
         return 0;
     }
-    ABACUS_LAUNCH("hod_emit", hod_emit, dim3(nemit), dim3(EBLOCK), 0, st->nh, st->np, st->ntile_c, st->ntile_s,
-                  st->keep_c, st->keep_s, st->tile_counts, st->sb_counts, st->d_totals, st->hpos, st->hvel,
-                  st->hveldev, st->hmass, st->hid, st->ppos, st->pvel, st->phvel, st->phmass, st->phid, st->params,
-                  out_cols(st));
+    EmitPtrs in;
+    in.hpos = st->hpos, in.hvel = st->hvel, in.hvdev = st->hveldev, in.hmass = st->hmass, in.hid = st->hid;
+    in.ppos = st->ppos, in.pvel = st->pvel, in.phvel = st->phvel, in.phmass = st->phmass, in.phid = st->phid;
+    ABACUS_LAUNCH("hod_emit", hod_emit, dim3(nemit), dim3(EBLOCK), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s,
+                  st->sb_counts, st->d_totals, in, st->params, out_cols(st));
     return 0;
 }
 
@@ -852,7 +831,6 @@ int abacus_hod_stage(const abacus_hod_arrays *a, int on_device, abacus_hod_state
     const int64_t ntiles = (int64_t)st->ntile_c + st->ntile_s;
     HIP_TRY(hipMalloc((void **)&st->keep_c, nh > 0 ? nh + 64 : 64));
     HIP_TRY(hipMalloc((void **)&st->keep_s, np > 0 ? np + 64 : 64));
-    HIP_TRY(hipMalloc((void **)&st->tile_counts, (ntiles > 0 ? ntiles : 1) * 4 * sizeof(int)));
     st->nsb_c = (int)ceil_div(st->ntile_c, SB_TILES);
     st->nsb_s = (int)ceil_div(st->ntile_s, SB_TILES);
     HIP_TRY(hipMalloc((void **)&st->sb_counts, (size_t)(st->nsb_c + st->nsb_s + 1) * 4 * sizeof(int)));
@@ -860,6 +838,8 @@ int abacus_hod_stage(const abacus_hod_arrays *a, int on_device, abacus_hod_state
     HIP_TRY(hipMalloc((void **)&st->q_count, (size_t)(ntiles > 0 ? ntiles : 1) * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&st->queue_c, (size_t)(st->ntile_c > 0 ? st->ntile_c : 1) * TILE * sizeof(unsigned short)));
     HIP_TRY(hipMalloc((void **)&st->queue_s, (size_t)(st->ntile_s > 0 ? st->ntile_s : 1) * TILE * sizeof(unsigned short)));
+    HIP_TRY(hipMalloc((void **)&st->kept_c, (size_t)(st->nsb_c > 0 ? st->nsb_c : 1) * SB_OBJ * sizeof(unsigned short)));
+    HIP_TRY(hipMalloc((void **)&st->kept_s, (size_t)(st->nsb_s > 0 ? st->nsb_s : 1) * SB_OBJ * sizeof(unsigned short)));
     HIP_TRY(hipHostMalloc((void **)&st->h_totals, 8 * sizeof(int64_t), hipHostMallocDefault));
     // first guess for the catalog buffers; grown on demand by abacus_hod_counts
     for (int t = 0; t < 3; t++) ABACUS_TRY(set_capacity(st, t, (nh + np) / 64));
@@ -910,7 +890,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     a.pfenv = st->pfenv, a.pshear = st->pshear, a.pranks = st->pranks, a.pranksv = st->pranksv,
     a.pranksp = st->pranksp, a.pranksr = st->pranksr, a.pinds = st->pinds;
     a.keep_c = st->keep_c, a.keep_s = st->keep_s, a.q_count = st->q_count, a.queue_c = st->queue_c,
-    a.queue_s = st->queue_s, a.tile_counts = st->tile_counts, a.sb_counts = st->sb_counts;
+    a.queue_s = st->queue_s, a.kept_c = st->kept_c, a.kept_s = st->kept_s, a.sb_counts = st->sb_counts;
     // deltac / fenv / shear are streamed by the central filter only when some wanted tracer weights them
     const int need_env = (p->want_LRG && (p->L_Acent != 0 || p->L_Bcent != 0)) ||
                          (p->want_ELG && (p->E_Acent != 0 || p->E_Bcent != 0)) ||
@@ -1015,7 +995,7 @@ int abacus_hod_free(abacus_hod_state *st) {
         for (void *q : ptrs)
             if (q) (void)hipFree(q);
     }
-    void *work[] = {st->keep_c, st->keep_s, st->tile_counts, st->sb_counts, st->d_totals, st->q_count, st->queue_c, st->queue_s};
+    void *work[] = {st->keep_c, st->keep_s, st->kept_c, st->kept_s, st->sb_counts, st->d_totals, st->q_count, st->queue_c, st->queue_s};
     for (void *q : work)
         if (q) (void)hipFree(q);
     if (st->h_totals) (void)hipHostFree(st->h_totals);
