@@ -32,6 +32,41 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ int padq(int q) { return q + (q >> PADSHIFT); }
 
+// Asynchronous 16-B global load the compiler does not track: the prefetch of the next tile stays in flight across the
+// transform AND the write-back of the current one.  hipcc's own vmcnt bookkeeping cannot express "wait for the loads
+// but not for the stores issued after them" once loop paths merge (it degenerates to waiting for every store, which
+// exposes the store latency once per tile), so the wait is written by hand: vmcnt retires in issue order on gfx9, so
+// after `prefetch; ...; K stores` a vmcnt(K) guarantees that every prefetch load has landed.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload16_async(v4f &dst, const void *p) {
+    v4f t;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(p) : "memory");
+    dst = t;
+}
+template <int K>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
+}
+__device__ __forceinline__ void wait_vmcnt_upto8(int k) {   // runtime count (uniform), immediate operand
+    switch (k) {
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
+// ties registers to the wait above: their uses cannot be scheduled before it
+__device__ __forceinline__ void touch(v4f &a) {
+    v4f t = a;
+    asm volatile("" : "+v"(t));
+    a = t;
+}
+
 // forward DFTs of size R in registers, natural order in and out (W = exp(-2 pi i / R))
 template <int R>
 __device__ __forceinline__ void dft(float2 (&a)[R]);
@@ -131,6 +166,11 @@ constexpr int colpitch_of() { return N + (N >> PADSHIFT) + 1; }   // odd: adjace
 // ---- z pass: real rows -> half-spectrum rows, in place ---------------------------------------------------------
 // N = n/2.  mesh rows have `pitch_r` floats; row r of the (n*n) rows starts at r*pitch_r.  Persistent workgroups:
 // while a tile of B rows is transformed in LDS the next tile is already in flight into registers.
+// Loop shape (both kernels): the staging of tile t+1 (registers -> LDS) sits at the END of the body, after the
+// write-back of tile t, so it is reached on a single path where the outstanding vector-memory operations are exactly
+// "loads of t+1, then stores of t": the compiler then waits with a counted vmcnt that leaves the stores in flight
+// (with the staging at the top of the loop the prologue path merges in and every wait degenerates to "all stores
+// done", which exposes the full store latency once per tile).
 template <int N, int B>
 __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
                                                          const float2 *__restrict__ twN, const float2 *__restrict__ tw2N,
@@ -139,41 +179,52 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
     constexpr int NLD = (B * (N / 2) + FFT_THREADS - 1) / FFT_THREADS;   // 16-B loads per thread and tile
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *tw = reinterpret_cast<float2 *>(smem);
-    float2 *lds = tw + N;
+    float2 *tw2 = tw + N;            // exp(-2 pi i k / 2N), k = 0..N (kept in LDS: a global load inside the loop would
+    float2 *lds = tw2 + N + 2;       //  make the compiler drain the prefetch with vmcnt(0))
     const int tid = threadIdx.x;
     for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
+    for (int q = tid; q <= N; q += FFT_THREADS) tw2[q] = tw2N[q];
     const int64_t ntiles = (nrows + B - 1) / B;
     const int pitch_c = pitch_r / 2;
-    float4 regs[NLD];
+    v4f regs[NLD];
     auto prefetch = [&](int64_t tile) {
         const int64_t row0 = tile * B;
         const int nb = (int)min((int64_t)B, nrows - row0);
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int e = q * FFT_THREADS + tid;
-            const int r = e / (N / 2), m = (e % (N / 2)) * 2;
-            regs[q] = r < nb ? *reinterpret_cast<const float4 *>(mesh + (row0 + r) * pitch_r + 2 * m)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int r = min(e / (N / 2), nb - 1), m = (e % (N / 2)) * 2;   // rows past the end re-read the last row
+            gload16_async(regs[q], mesh + (row0 + r) * pitch_r + 2 * m);
         }
     };
-    int64_t tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * B;
-        const int nb = (int)min((int64_t)B, nrows - row0);
-        // registers -> LDS: two complex (= four consecutive reals) per 16-B load
+    auto stage = [&]() {   // registers -> LDS: two complex (= four consecutive reals) per 16-B load
+#pragma unroll
+        for (int q = 0; q < NLD; q++) touch(regs[q]);
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int e = q * FFT_THREADS + tid;
             const int r = e / (N / 2), m = (e % (N / 2)) * 2;
-            if (r < B) {
+            if ((B * (N / 2)) % FFT_THREADS == 0 || r < B) {
                 float2 *c = lds + r * CP;
                 c[padq(m)] = make_float2(regs[q].x, regs[q].y);
                 c[padq(m + 1)] = make_float2(regs[q].z, regs[q].w);
             }
         }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    prefetch(tile);
+    wait_vmcnt<0>();
+    stage();
+    // stores every thread issues per full tile (threads with one more only wait longer): vmcnt(that) = loads landed
+    const int stores_min = (B * (pitch_c / 2)) / FFT_THREADS;
+    for (;;) {
         __syncthreads();
-        if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);   // in flight during the transform below
+        const int64_t next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) prefetch(next);   // in flight during the transform and the write-back below
+        const int64_t row0 = tile * B;
+        const int nb = (int)min((int64_t)B, nrows - row0);
         if (!(dbg & 1)) Passes<N, N>::run(lds, CP, nb, tw);
         // even/odd split: X_k = E + (-i W_2N^k) O with E = (Z_k + conj Z_{N-k})/2, O = (Z_k - conj Z_{N-k})/2, k = 0..N.
         // A thread forms two adjacent outputs (one 16-B store); the row is written over its whole pitch (zeros behind
@@ -192,7 +243,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
                         const float2 zn = c[padq(revpos<N>((N - k) & (N - 1)))];
                         const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
                         const float2 O = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-                        const float2 w = tw2N[k];                            // exp(-2 pi i k / 2N) = (cos, -sin)
+                        const float2 w = tw2[k];                             // exp(-2 pi i k / 2N) = (cos, -sin)
                         const float2 miw = make_float2(w.y, -w.x);           // -i * w
                         X[u] = cadd(E, cmul(miw, O));
                     }
@@ -200,7 +251,11 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
                 *reinterpret_cast<float4 *>(mesh + (row0 + r) * pitch_r + 2 * k0) =
                     make_float4(X[0].x, X[0].y, X[1].x, X[1].y);
             }
-        __syncthreads();
+        if (!has_next) break;
+        __syncthreads();   // every LDS read of this tile is done
+        wait_vmcnt_upto8((dbg & 2) || nb < B ? 0 : stores_min);
+        stage();
+        tile = next;
     }
 }
 
@@ -213,12 +268,13 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
                                                         const float2 *__restrict__ twN, int dbg) {
     constexpr int CP = colpitch_of<N>();
     constexpr int NLD = (N * (C / 2) + FFT_THREADS - 1) / FFT_THREADS;
+    constexpr bool WHOLE = (N * (C / 2)) % FFT_THREADS == 0;
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float2 *lds = tw + N;
     const int tid = threadIdx.x;
     for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
-    float4 regs[NLD];
+    v4f regs[NLD];
     auto tile_base = [&](int64_t t) { return data + (t / ntile_c) * outer_stride + (t % ntile_c) * C; };
     auto prefetch = [&](int64_t t) {
         const float2 *g = tile_base(t);
@@ -226,35 +282,55 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int e = q * FFT_THREADS + tid;
-            const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
-            regs[q] = y < N ? *reinterpret_cast<const float4 *>(g + (int64_t)y * S + c2) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c2 = (e % (C / 2)) * 2, y = WHOLE ? e / (C / 2) : min(e / (C / 2), N - 1);
+            gload16_async(regs[q], g + (int64_t)y * S + c2);
         }
     };
-    int64_t t = blockIdx.x;
-    if (t < ntiles) prefetch(t);
-    for (; t < ntiles; t += gridDim.x) {
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) touch(regs[q]);
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int e = q * FFT_THREADS + tid;
             const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
-            if (y < N) {
+            if (WHOLE || y < N) {
                 lds[c2 * CP + padq(y)] = make_float2(regs[q].x, regs[q].y);
                 lds[(c2 + 1) * CP + padq(y)] = make_float2(regs[q].z, regs[q].w);
             }
         }
+    };
+    int64_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    prefetch(t);
+    wait_vmcnt<0>();
+    stage();
+    for (;;) {
         __syncthreads();
-        if (t + gridDim.x < ntiles) prefetch(t + gridDim.x);
+        const int64_t next = t + gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) prefetch(next);
         if (!(dbg & 1)) Passes<N, N>::run(lds, CP, C, tw);
         if (!(dbg & 2)) {
             float2 *g = tile_base(t);
-            for (int e = tid; e < N * (C / 2); e += FFT_THREADS) {
+            // constant trip count: the compiler can then count these stores in its vmcnt bookkeeping
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                const int e = q * FFT_THREADS + tid;
                 const int c2 = (e % (C / 2)) * 2, f = e / (C / 2);
-                const int p = padq(revpos<N>(f));
-                const float2 a = lds[c2 * CP + p], b = lds[(c2 + 1) * CP + p];
-                *reinterpret_cast<float4 *>(g + (int64_t)f * S + c2) = make_float4(a.x, a.y, b.x, b.y);
+                if (WHOLE || f < N) {
+                    const int p = padq(revpos<N>(f));
+                    const float2 a = lds[c2 * CP + p], b = lds[(c2 + 1) * CP + p];
+                    *reinterpret_cast<float4 *>(g + (int64_t)f * S + c2) = make_float4(a.x, a.y, b.x, b.y);
+                }
             }
         }
+        if (!has_next) break;
         __syncthreads();
+        // the NLD stores above were issued after the prefetch loads: vmcnt(NLD) = all loads landed, stores in flight
+        if (dbg & 2) wait_vmcnt<0>();
+        else wait_vmcnt<(NLD < 60 ? NLD : 0)>();
+        stage();
+        t = next;
     }
 }
 
@@ -298,7 +374,7 @@ int get_tables(int n, Tables **out) {
 
 template <int N, int B>
 int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
-    const size_t lds = (size_t)(N + B * colpitch_of<N>()) * sizeof(float2);
+    const size_t lds = (size_t)(2 * N + 2 + B * colpitch_of<N>()) * sizeof(float2);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_z_r2c<N, B>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     const int64_t ntiles = ceil_div(nrows, B);

@@ -1,13 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 make -s -C oracle
-timeout 1200 python -m pytest tests/test_tsc_gpu.py tests/test_power_gpu.py -m gpu -x -q 2>&1 | tail -8
-for nm in 1024 2048; do
-timeout 900 python bench.py --workload pk --nmesh $nm --steps 4 --warmup 1 --no-cpu > gpurun_out/bench_pk$nm.json 2> gpurun_out/bench_pk$nm.err
-python - <<PY
-import json
-d=json.load(open('gpurun_out/bench_pk$nm.json'))
-print($nm, {k:d[k] for k in ('ms_per_step','kernels_ms','interlaced_compensated')}); print(d['roofline'])
-PY
-tail -2 gpurun_out/bench_pk$nm.err
+timeout 1200 python -m pytest tests/test_power_gpu.py tests/test_slab_power.py -m gpu -x -q 2>&1 | tail -5
+for NM in 1024 2048; do
+timeout 900 python bench.py --workload pk --nmesh $NM --steps 3 --warmup 1 --no-cpu 2>gpurun_out/pk$NM.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('nmesh $NM', d['ms_per_step'], d['kernels_ms'], d['mean_P_over_shot_noise'], d.get('interlaced_compensated'))"
+tail -2 gpurun_out/pk$NM.err
 done
