@@ -123,12 +123,12 @@ __device__ __forceinline__ int revpos(int f) {
 }
 
 // one DIF pass of sub-length L over `ncol` columns of N elements each (column c at lds + c*colpitch, padded index)
-template <int N, int L, int R>
+template <int N, int L, int R, int NT = FFT_THREADS>
 __device__ __forceinline__ void dif_pass(float2 *lds, int colpitch, int ncol, const float2 *tw) {
     constexpr int BPC = N / R;      // butterflies per column
     constexpr int LR = L / R;
     const int total = ncol * BPC;
-    for (int b = threadIdx.x; b < total; b += FFT_THREADS) {
+    for (int b = threadIdx.x; b < total; b += NT) {
         const int col = b / BPC, t = b % BPC;
         const int blk = t / LR, j = t % LR;
         float2 *c = lds + col * colpitch;
@@ -147,16 +147,16 @@ __device__ __forceinline__ void dif_pass(float2 *lds, int colpitch, int ncol, co
     __syncthreads();
 }
 
-template <int N, int L>
+template <int N, int L, int NT = FFT_THREADS>
 struct Passes {
     static __device__ __forceinline__ void run(float2 *lds, int colpitch, int ncol, const float2 *tw) {
         constexpr int R = radix_of(L);
-        dif_pass<N, L, R>(lds, colpitch, ncol, tw);
-        Passes<N, L / R>::run(lds, colpitch, ncol, tw);
+        dif_pass<N, L, R, NT>(lds, colpitch, ncol, tw);
+        Passes<N, L / R, NT>::run(lds, colpitch, ncol, tw);
     }
 };
-template <int N>
-struct Passes<N, 1> {
+template <int N, int NT>
+struct Passes<N, 1, NT> {
     static __device__ __forceinline__ void run(float2 *, int, int, const float2 *) {}
 };
 
@@ -404,21 +404,19 @@ template <int N, int C, int BZ>
 int fft3d(float *mesh, int pitch_r, Tables *t, int64_t nx_local) {
     // nx_local x N x N real mesh (nx_local = N for the single-GPU transform)
     const int pitch_c = pitch_r / 2, kzlen = N / 2 + 1;
-    const int ntile_c = (kzlen + C - 1) / C;   // the last tile reads into the row padding (pitch_c >= ntile_c*C)
-    if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
     ABACUS_TRY((launch_z<N / 2, BZ>(mesh, nx_local * N, pitch_r, t)));
     float2 *data = reinterpret_cast<float2 *>(mesh);
     // y: for every x-plane, columns along y (element stride pitch_c)
-    ABACUS_TRY((launch_cols<N, C>("fft_cols_y", data, pitch_c, ntile_c, nx_local, (int64_t)N * pitch_c, t)));
-    return 0;
+    const int ntile_c = (kzlen + C - 1) / C;   // the last tile reads into the row padding (pitch_c >= ntile_c*C)
+    if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
+    return launch_cols<N, C>("fft_cols_y", data, pitch_c, ntile_c, nx_local, (int64_t)N * pitch_c, t);
 }
 
 template <int N, int C>
 int fft_x(float2 *data, int pitch_c, Tables *t, int64_t ny_local, int64_t x_stride, int64_t y_stride) {
     // x: for every y, columns along x (element stride x_stride)
-    const int kzlen = N / 2 + 1;
-    const int ntile_c = (kzlen + C - 1) / C;
-    (void)pitch_c;
+    const int ntile_c = (N / 2 + 1 + C - 1) / C;
+    if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
     return launch_cols<N, C>("fft_cols_x", data, x_stride, ntile_c, ny_local, y_stride, t);
 }
 
