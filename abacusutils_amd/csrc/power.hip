@@ -349,13 +349,15 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
                     }
                 }
                 if (tb != cur) {                      // the one flush site
-                    if (cnt) {
-                        atomicAdd(&h_cnt[cur], (unsigned int)cnt);
+                    if (cnt && !(b.dbg & 4)) {
                         atomicAdd(&h_sum[cur], (double)sp);
+                        if (!(b.dbg & 8)) {
+                        atomicAdd(&h_cnt[cur], (unsigned int)cnt);
                         atomicAdd(&h_ksum[cur], (double)sk);
 #pragma unroll
                         for (int q = 0; q < NPC; q++)
                             if (q < np) atomicAdd(&h_pole[q * b.Nk + cur_bk], (double)spole[q]);
+                        }
                     }
                     cnt = 0;
                     sp = sk = 0.f;

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/abacus_hip.h"
@@ -338,6 +339,61 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_fine(const int64_t *__restrict__ 
     }
 }
 
+// contribution of one list entry to the LDS tile with origin (ox, oy, oz) and extent (dx, dy, dz)
+template <typename PT, int TYS, int TZS, bool CIC, typename ACC = double>
+__device__ __forceinline__ void tile_accumulate(ACC *tile, const Entry<PT> &en, const TileGeom &g, int ox, int oy, int oz,
+                                                int dx, int dy, int dz, double box, PT offset, PT ihx, PT ihy, PT ihz) {
+    int lx[3], ly[3], lz[3];
+    if (CIC) {
+        Cloud<double> c;
+        cic_cloud<PT>(en.x + offset, en.y + offset, en.z + offset, box, g.gxg, g.gy, g.gz, c);
+        const double W = (double)en.w;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lx[a] = xloc(c.i[0] + a - 1, g) - ox;
+            ly[a] = wrapcell(c.i[1] + a - 1, g.gy) - oy;
+            lz[a] = wrapcell(c.i[2] + a - 1, g.gz) - oz;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if ((unsigned)lx[a] >= (unsigned)dx) continue;
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                if ((unsigned)ly[b] >= (unsigned)dy) continue;
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) {
+                    if ((unsigned)lz[cc] >= (unsigned)dz) continue;
+                    const double v = c.w[0][a] * c.w[1][b] * c.w[2][cc] * W;
+                    if (v != 0.0) atomicAdd(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], (ACC)v);
+                }
+            }
+        }
+    } else {
+        Cloud<PT> c;
+        tsc_cloud<PT>(en.x, en.y, en.z, offset, ihx, ihy, ihz, c);
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lx[a] = xloc(c.i[0] + a - 1, g) - ox;
+            ly[a] = wrapcell(c.i[1] + a - 1, g.gy) - oy;
+            lz[a] = wrapcell(c.i[2] + a - 1, g.gz) - oz;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if ((unsigned)lx[a] >= (unsigned)dx) continue;
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                if ((unsigned)ly[b] >= (unsigned)dy) continue;
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) {
+                    if ((unsigned)lz[cc] >= (unsigned)dz) continue;
+                    const PT v = c.w[0][a] * c.w[1][b] * c.w[2][cc] * en.w;  // wx*wy*wz*W (tsc.py:471-507)
+                    atomicAdd(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], (ACC)v);
+                }
+            }
+        }
+    }
+}
+
 // One workgroup per tile.  LDS tile: tx*ty*tz cells of GT, strides (TYS*TZS, TZS, 1) fixed at compile time.
 template <typename PT, typename GT, int TXS, int TYS, int TZS, bool CIC>
 __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *__restrict__ entries,
@@ -365,55 +421,7 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *_
     const PT offset = (PT)offset_;
     for (int64_t e = e0 + tid; e < e1 && !(dbg & 1); e += TSC_BLOCK) {
         const Entry<PT> en = e == e0 + tid ? first : entries[e];
-        int lx[3], ly[3], lz[3];
-        if (CIC) {
-            Cloud<double> c;
-            cic_cloud<PT>(en.x + offset, en.y + offset, en.z + offset, box, g.gxg, g.gy, g.gz, c);
-            const double W = (double)en.w;
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                lx[a] = xloc(c.i[0] + a - 1, g) - ox;
-                ly[a] = wrapcell(c.i[1] + a - 1, g.gy) - oy;
-                lz[a] = wrapcell(c.i[2] + a - 1, g.gz) - oz;
-            }
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                if ((unsigned)lx[a] >= (unsigned)dx) continue;
-#pragma unroll
-                for (int b = 0; b < 3; b++) {
-                    if ((unsigned)ly[b] >= (unsigned)dy) continue;
-#pragma unroll
-                    for (int cc = 0; cc < 3; cc++) {
-                        if ((unsigned)lz[cc] >= (unsigned)dz) continue;
-                        const double v = c.w[0][a] * c.w[1][b] * c.w[2][cc] * W;
-                        if (v != 0.0) atomicAdd(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], v);
-                    }
-                }
-            }
-        } else {
-            Cloud<PT> c;
-            tsc_cloud<PT>(en.x, en.y, en.z, offset, ihx, ihy, ihz, c);
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                lx[a] = xloc(c.i[0] + a - 1, g) - ox;
-                ly[a] = wrapcell(c.i[1] + a - 1, g.gy) - oy;
-                lz[a] = wrapcell(c.i[2] + a - 1, g.gz) - oz;
-            }
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                if ((unsigned)lx[a] >= (unsigned)dx) continue;
-#pragma unroll
-                for (int b = 0; b < 3; b++) {
-                    if ((unsigned)ly[b] >= (unsigned)dy) continue;
-#pragma unroll
-                    for (int cc = 0; cc < 3; cc++) {
-                        if ((unsigned)lz[cc] >= (unsigned)dz) continue;
-                        const PT v = c.w[0][a] * c.w[1][b] * c.w[2][cc] * en.w;  // wx*wy*wz*W (tsc.py:471-507)
-                        atomicAdd(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], (double)v);
-                    }
-                }
-            }
-        }
+        tile_accumulate<PT, TYS, TZS, CIC>(tile, en, g, ox, oy, oz, dx, dy, dz, box, offset, ihx, ihy, ihz);
     }
     __syncthreads();
     // flush: consecutive threads walk z, so a wave writes whole rows
@@ -450,6 +458,158 @@ __global__ __launch_bounds__(TSC_BLOCK) void tsc_tile_deposit(const Entry<PT> *_
             GT v = (GT)acc;
             if (norm != (GT)0) v = v * norm - sub;
             *dst = v;
+        }
+    }
+}
+
+// Persistent variant for the hot case (float32 positions and mesh).  With one short-lived workgroup per tile the
+// kernel is latency-bound: bounds -> entries -> LDS zero -> atomics -> flush is a chain of dependent round trips and
+// only two 64-KiB tiles fit a CU.  Here a workgroup walks tiles t, t+G, ...: the list bounds of tile t+2G and the first
+// entries of tile t+G are requested (untracked asynchronous loads, see fft.hip) before tile t is flushed, the flush
+// re-zeroes the LDS tile as it reads it, and the stores of a flush stay in flight while the next tile is accumulated.
+typedef float tsc_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tsc_gload16_async(tsc_v4f &dst, const void *p) {
+    tsc_v4f t;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(p) : "memory");
+    dst = t;
+}
+__device__ __forceinline__ void tsc_touch(tsc_v4f &a) {
+    tsc_v4f t = a;
+    asm volatile("" : "+v"(t));
+    a = t;
+}
+template <int K>
+__device__ __forceinline__ void tsc_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
+}
+
+constexpr int TP_RANGE = 2048;   // consecutive tiles a persistent workgroup takes at a time (their list bounds sit in LDS)
+
+template <int TXS, int TYS, int TZS, bool CIC, int NT, typename ACC>
+__global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__restrict__ entries, int64_t nentries,
+                                                         const int64_t *__restrict__ tile_start, int ntiles, int range_len,
+                                                         TileGeom g, double box, double offset_,
+                                                         float *__restrict__ grid, int zero_grid, float norm, float sub,
+                                                         int dbg) {
+    constexpr int NPRE = 2;                                // prefetched entries per thread
+    constexpr int CPS = 16 / (int)sizeof(ACC);             // cells per flush step: one 16-B LDS read (2 f64 / 4 f32)
+    constexpr int ZP = TZS / CPS;
+    constexpr int FL = TXS * TYS * ZP / NT;                // flush stores per thread of a full tile
+    static_assert((TXS * TYS * ZP) % NT == 0 && 2 * FL + NPRE <= 60, "whole flush stores per thread");
+    __shared__ __align__(16) ACC tile[TXS * TYS * TZS];
+    __shared__ unsigned int bnd[TP_RANGE + 1];             // list bounds of the range, relative to its first entry
+    const int tid = threadIdx.x;
+    {
+        float4 *t4 = reinterpret_cast<float4 *>(tile);     // all-zero bits are 0.0 in either type
+        for (int q = tid; q < (int)(sizeof(tile) / 16); q += NT) t4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float ihx = (float)(g.gxg / box), ihy = (float)(g.gy / box), ihz = (float)(g.gz / box);
+    const float offset = (float)offset_;
+    const int64_t last = nentries > 0 ? nentries - 1 : 0;
+    const int nranges = (ntiles + range_len - 1) / range_len;   // range_len <= TP_RANGE
+    for (int r = blockIdx.x; r < nranges; r += gridDim.x) {
+        const int t0 = r * range_len, nt = min(range_len, ntiles - t0);
+        const int64_t ebase = tile_start[t0];
+        __syncthreads();                                   // previous range: all bnd reads done
+        for (int q = tid; q <= nt; q += NT) bnd[q] = (unsigned int)(tile_start[t0 + q] - ebase);
+        __syncthreads();
+        tsc_v4f X[NPRE], Y[NPRE];
+        auto issue = [&](tsc_v4f(&set)[NPRE], int tt) {    // first NPRE*NT entries of tile tt of this range
+            const int64_t e0 = ebase + bnd[tt];
+#pragma unroll
+            for (int q = 0; q < NPRE; q++) tsc_gload16_async(set[q], entries + min(e0 + q * NT + tid, last));
+        };
+        // one tile: accumulate (from `cur`), request tile tt+2 into `cur`, flush; returns with `nxt` (tile tt+1) landed
+        bool prev_plain = false;                           // the previous tile issued exactly FL stores and no load
+        auto process = [&](tsc_v4f(&cur)[NPRE], int tt) {
+            const int t = t0 + tt;
+            const int tzi = t % g.ntz, tyi = (t / g.ntz) % g.nty, txi = t / (g.ntz * g.nty);
+            const int ox = txi * g.tx, oy = tyi * g.ty, oz = tzi * g.tz;
+            const int dx = min(g.tx, g.gx - ox), dy = min(g.ty, g.gy - oy), dz = min(g.tz, g.gz - oz);
+            const int64_t e0 = ebase + bnd[tt], e1 = ebase + bnd[tt + 1];
+#pragma unroll
+            for (int q = 0; q < NPRE; q++) tsc_touch(cur[q]);
+#pragma unroll
+            for (int q = 0; q < NPRE; q++) {
+                if (e0 + q * NT + tid < e1 && !(dbg & 1)) {
+                    const Entry<float> en{cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+                    tile_accumulate<float, TYS, TZS, CIC, ACC>(tile, en, g, ox, oy, oz, dx, dy, dz, box, offset, ihx, ihy, ihz);
+                }
+            }
+            bool extra = false;                            // tracked loads below: fall back to a full wait
+            for (int64_t e = e0 + NPRE * NT + tid; e < e1; e += NT) {
+                const Entry<float> en = entries[e];        // a copy: a reference would be re-read around every LDS atomic
+                tile_accumulate<float, TYS, TZS, CIC, ACC>(tile, en, g, ox, oy, oz, dx, dy, dz, box, offset, ihx, ihy, ihz);
+            }
+            extra = e1 - e0 > NPRE * NT;
+            __syncthreads();
+            const bool more = tt + 2 < nt;
+            if (more) issue(cur, tt + 2);                  // BEFORE this tile's stores
+            const bool full = dx == TXS && dy == TYS && dz == TZS;
+            if (full) {
+                static_assert((TZS & (TZS - 1)) == 0 && (TYS & (TYS - 1)) == 0, "tile dims must be powers of two");
+#pragma unroll 4
+                for (int q = tid; q < TXS * TYS * ZP; q += NT) {
+                    const int zp = q & (ZP - 1), y = (q / ZP) & (TYS - 1), x = q / (ZP * TYS);
+                    float4 *cell = reinterpret_cast<float4 *>(&tile[(x * TYS + y) * TZS + CPS * zp]);
+                    const float4 raw = *cell;
+                    *cell = make_float4(0.f, 0.f, 0.f, 0.f);   // the tile is zero again for the next one
+                    float *dst = grid + ((int64_t)(ox + x) * g.gy + (oy + y)) * g.zstride + oz + CPS * zp;
+                    float v[CPS];
+                    if constexpr (sizeof(ACC) == 8) {
+                        double a0 = __hiloint2double(__float_as_int(raw.y), __float_as_int(raw.x));
+                        double a1 = __hiloint2double(__float_as_int(raw.w), __float_as_int(raw.z));
+                        if (!zero_grid) {
+                            const float2 old = *reinterpret_cast<const float2 *>(dst);
+                            a0 += (double)old.x;
+                            a1 += (double)old.y;
+                        }
+                        v[0] = (float)a0, v[1] = (float)a1;
+                    } else {
+                        v[0] = raw.x, v[1] = raw.y, v[2] = raw.z, v[3] = raw.w;
+                        if (!zero_grid) {
+                            const float4 old = *reinterpret_cast<const float4 *>(dst);
+                            v[0] += old.x, v[1] += old.y, v[2] += old.z, v[3] += old.w;
+                        }
+                    }
+                    if (norm != 0.f) {
+#pragma unroll
+                        for (int c = 0; c < CPS; c++) v[c] = v[c] * norm - sub;
+                    }
+                    if (!(dbg & 2)) {
+                        if constexpr (CPS == 2) *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[1]);
+                        else *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            } else {
+                for (int q = tid; q < TXS * TYS * TZS; q += NT) {
+                    const int z = q % TZS, y = (q / TZS) % TYS, x = q / (TZS * TYS);
+                    double acc = (double)tile[q];
+                    tile[q] = (ACC)0;
+                    if (x < dx && y < dy && z < dz) {
+                        float *dst = grid + ((int64_t)(ox + x) * g.gy + (oy + y)) * g.zstride + (oz + z);
+                        if (!zero_grid) acc += (double)*dst;
+                        float v = (float)acc;
+                        if (norm != 0.f) v = v * norm - sub;
+                        *dst = v;
+                    }
+                }
+            }
+            __syncthreads();
+            // vector-memory operations issued since the request for tile tt+1: [FL stores of tile tt-1] [NPRE loads of
+            // tile tt+2] [FL stores of this tile] - when exactly so, vmcnt(2 FL + NPRE) means tile tt+1 has landed and
+            // everything younger may stay in flight; otherwise wait for everything
+            const bool plain = full && zero_grid && !extra;
+            if (plain && prev_plain && more) tsc_wait_vmcnt<2 * FL + NPRE>();
+            else tsc_wait_vmcnt<0>();
+            prev_plain = plain;
+        };
+        issue(X, 0);
+        if (nt > 1) issue(Y, 1);
+        tsc_wait_vmcnt<0>();
+        for (int tt = 0; tt < nt; tt += 2) {
+            process(X, tt);
+            if (tt + 1 < nt) process(Y, tt + 1);
         }
     }
 }
@@ -493,6 +653,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     int cshift = 0;
     while (((int64_t)ntiles + (1 << cshift) - 1) >> cshift > MS_BINS) cshift++;
     const bool multisplit = n >= 2000000 && cshift <= 10 && !getenv("ABACUS_TSC_ATOMIC");
+    int64_t nentries_total = 0;
     if (multisplit) {
         const int ncoarse = (int)(((int64_t)ntiles + (1 << cshift) - 1) >> cshift);
         ABACUS_TRY(g_work.gcount.reserve((size_t)(MS_BINS + 1) * sizeof(unsigned int)));
@@ -513,6 +674,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         HIP_TRY(hipStreamSynchronize(stream()));
         if (wrapped_out) *wrapped_out = h_flag;
         const int64_t total = h_start[ncoarse];
+        nentries_total = total;
         int64_t maxbucket = 0;
         for (int b = 0; b < ncoarse; b++) maxbucket = std::max(maxbucket, h_start[b + 1] - h_start[b]);
         const size_t t1 = (size_t)std::max<int64_t>(total, 1);
@@ -554,15 +716,40 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
         HIP_TRY(hipStreamSynchronize(stream()));
         if (wrapped_out) *wrapped_out = h_flag;
+        nentries_total = total;
         ABACUS_TRY(g_work.entries.reserve((size_t)std::max<int64_t>(total, 1) * sizeof(Entry<PT>)));
         entries = g_work.entries.as<Entry<PT>>();
         if (n > 0)
             ABACUS_LAUNCH("tsc_bin_fill", (tsc_bin<PT, true, CIC>), dim3(nblk), dim3(TSC_BLOCK), 0, pos, n, weights, g, box,
                           offset, 0, tile_count, (const int64_t *)tile_start, entries, flag);
     }
+    const int dbg = getenv("ABACUS_DBG_TSC") ? atoi(getenv("ABACUS_DBG_TSC")) : 0;
+    if constexpr (std::is_same<PT, float>::value && std::is_same<GT, float>::value) {
+        if (!(dbg & 4) && ntiles >= 4096) {   // persistent workgroups: two 64-KiB tiles per CU
+            int dev = 0, ncu = 256;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+            // ranges of consecutive tiles: long enough to amortise the bounds staging, short enough to fill the chip
+            const int range_len = (int)std::min<int64_t>(TP_RANGE, std::max<int64_t>(64, ceil_div(ntiles, (int64_t)ncu * 8)));
+            const int nranges = (int)ceil_div(ntiles, range_len);
+            const int grid_p = (int)std::min<int64_t>(nranges, (int64_t)ncu * 2);
+            // dense lists: more threads per tile shorten the accumulation; sparse ones are flush-bound
+            const bool dense = nentries_total / std::max<int64_t>(ntiles, 1) > 400;
+            // ACC = float (32-KiB tiles, 4 workgroups per CU) was measured 1.6-4.5x SLOWER: float LDS atomics compile to
+            // a compare-and-swap loop under the default denormal mode, float64 ones to native ds_add_f64
+#define LAUNCH_P(NTP, ACC, GRID)                                                                                      \
+    ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit_p<TX, TY, TZ, CIC, NTP, ACC>), dim3(GRID), dim3(NTP), 0,      \
+                  (const Entry<float> *)entries, (int64_t)nentries_total, (const int64_t *)tile_start, (int)ntiles,   \
+                  range_len, g, box, offset, grid, zero_grid, (float)norm, (float)sub, dbg)
+            if (dense) LAUNCH_P(512, double, grid_p);
+            else LAUNCH_P(256, double, grid_p);
+#undef LAUNCH_P
+            return 0;
+        }
+    }
     ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit<PT, GT, TX, TY, TZ, CIC>), dim3(ntiles), dim3(TSC_BLOCK), 0,
                   (const Entry<PT> *)entries, (const int64_t *)tile_start, g, box, offset, grid, zero_grid, (GT)norm, (GT)sub,
-                  getenv("ABACUS_DBG_TSC") ? atoi(getenv("ABACUS_DBG_TSC")) : 0);
+                  dbg);
     return 0;
 }
 

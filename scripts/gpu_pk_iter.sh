@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 make -s -C oracle
-timeout 1200 python -m pytest tests/test_power_gpu.py tests/test_slab_power.py -m gpu -x -q 2>&1 | tail -5
+timeout 1200 python -m pytest tests/test_tsc_gpu.py tests/test_power_gpu.py tests/test_slab_power.py -m gpu -x -q 2>&1 | tail -5
 for NM in 1024 2048; do
 timeout 900 python bench.py --workload pk --nmesh $NM --steps 3 --warmup 1 --no-cpu 2>gpurun_out/pk$NM.err | python -c "
 import json,sys
