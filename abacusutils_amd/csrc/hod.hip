@@ -663,6 +663,71 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
     }
 }
 
+// ---- device RNG for `run_hod(reseed=...)` (hod/abacus_hod.py:775-839) ------------------------------------------------
+// Philox4x32-10, counter-based: the value of an object depends only on (seed, stream, object index), never on the
+// launch geometry, so a catalogue sharded over GPUs draws the same numbers as the unsharded one when the caller
+// passes its global index offset.  The reference draws float32 uniforms / normals from parallel_numpy_rng (absent
+// here: stream parity unpinned); distributions and dtypes are the same: hrandoms, prandoms = float32 U[0,1);
+// hveldev = float32 N(0,1) (or the two-sided exponential of `want_expvel`) * hsigma3d / sqrt(3) in float64.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned int hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned int hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ float u01(unsigned int x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }   // [0, 1)
+__device__ __forceinline__ float laplace_f32(float rt) {   // (:799-801)
+    return rt >= 0.5f ? -logf(2.f * (1.f - rt)) : logf(2.f * rt);
+}
+
+__global__ __launch_bounds__(256) void hod_reseed_halos(int64_t n, int64_t index0, unsigned long long seed,
+                                                        const double *__restrict__ sigma3d, int expvel,
+                                                        double *__restrict__ hrandoms, double *__restrict__ hveldev) {
+    const uint2 key = make_uint2((unsigned int)seed, (unsigned int)(seed >> 32));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long gi = (unsigned long long)(index0 + i);
+        const uint4 a = philox4x32_10(make_uint4((unsigned int)gi, (unsigned int)(gi >> 32), 0u, 0u), key);   // stream 0
+        const uint4 b = philox4x32_10(make_uint4((unsigned int)gi, (unsigned int)(gi >> 32), 1u, 0u), key);   // stream 1
+        hrandoms[i] = (double)u01(a.x);
+        float r[3];
+        if (expvel) {
+            r[0] = laplace_f32(fmaxf(u01(a.y), 1e-30f)), r[1] = laplace_f32(fmaxf(u01(a.z), 1e-30f));
+            r[2] = laplace_f32(fmaxf(u01(a.w), 1e-30f));
+        } else {   // Box-Muller on (0, 1] x [0, 1)
+            const float m0 = sqrtf(-2.f * logf(1.f - u01(a.y))), m1 = sqrtf(-2.f * logf(1.f - u01(b.x)));
+            float s0, c0, s1, c1;
+            sincosf(6.28318530717958647692f * u01(a.z), &s0, &c0);
+            sincosf(6.28318530717958647692f * u01(b.y), &s1, &c1);
+            r[0] = m0 * c0, r[1] = m0 * s0, r[2] = m1 * c1;
+            (void)s1;
+        }
+        const double sg = sigma3d ? sigma3d[i] : 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; d++) hveldev[3 * i + d] = (double)r[d] * sg / 1.7320508075688772;   // r2 * hsigma3d / sqrt(3)
+    }
+}
+
+__global__ __launch_bounds__(256) void hod_reseed_particles(int64_t n, int64_t index0, unsigned long long seed,
+                                                            double *__restrict__ prandoms) {
+    const uint2 key = make_uint2((unsigned int)seed, (unsigned int)(seed >> 32));
+    // one Philox call serves the four particles 4q .. 4q+3 (q is a GLOBAL index: sharding-invariant)
+    const int64_t q0 = index0 >> 2, q1 = (index0 + n + 3) >> 2;
+    for (int64_t q = q0 + (int64_t)blockIdx.x * 256 + threadIdx.x; q < q1; q += (int64_t)gridDim.x * 256) {
+        const uint4 a = philox4x32_10(make_uint4((unsigned int)q, (unsigned int)((unsigned long long)q >> 32), 2u, 0u), key);
+        const unsigned int w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int64_t i = 4 * q + d - index0;
+            if (i >= 0 && i < n) prandoms[i] = (double)u01(w[d]);
+        }
+    }
+}
+
 }  // namespace
 
 // ---- handle ---------------------------------------------------------------------------------------------
@@ -672,6 +737,8 @@ struct abacus_hod_state {
     // staged inputs (device)
     double *hpos = nullptr, *hvel = nullptr, *hmass = nullptr, *hmultis = nullptr, *hrandoms = nullptr,
            *hveldev = nullptr, *hdeltac = nullptr, *hfenv = nullptr, *hshear = nullptr;
+    double *hsigma3d = nullptr;   // optional (abacus_hod_set_sigma3d): needed by the device reseed only
+    bool owns_sigma = false;
     int64_t *hid = nullptr;
     double *ppos = nullptr, *pvel = nullptr, *phvel = nullptr, *phmass = nullptr, *pweights = nullptr,
            *prandoms = nullptr, *pdeltac = nullptr, *pfenv = nullptr, *pshear = nullptr, *pranks = nullptr,
@@ -862,6 +929,56 @@ int abacus_hod_update(abacus_hod_state *st, const char *field, const double *hos
     return 0;
 }
 
+int abacus_hod_set_sigma3d(abacus_hod_state *st, const double *sigma3d, int on_device) {
+    ABACUS_TRY(ensure_init());
+    if (!st || !sigma3d) return fail("abacus_hod_set_sigma3d: null argument");
+    if (st->owns_sigma && st->hsigma3d) HIP_TRY(hipFree(st->hsigma3d));
+    st->hsigma3d = nullptr;
+    st->owns_sigma = false;
+    if (on_device) {
+        st->hsigma3d = const_cast<double *>(sigma3d);
+        return 0;
+    }
+    HIP_TRY(hipMalloc((void **)&st->hsigma3d, (size_t)(st->nh > 0 ? st->nh : 1) * sizeof(double)));
+    st->owns_sigma = true;
+    HIP_TRY(hipMemcpyAsync(st->hsigma3d, sigma3d, (size_t)st->nh * sizeof(double), hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_hod_reseed(abacus_hod_state *st, uint64_t seed, int want_expvel, int64_t halo_index0, int64_t part_index0) {
+    ABACUS_TRY(ensure_init());
+    if (!st) return fail("abacus_hod_reseed: null handle");
+    if (!st->owns) return fail("abacus_hod_reseed: the catalogue was staged from caller-owned device arrays (read-only)");
+    if (st->nh > 0 && !st->hsigma3d) return fail("abacus_hod_reseed: hsigma3d has not been set (abacus_hod_set_sigma3d)");
+    if (halo_index0 < 0 || part_index0 < 0) return fail("abacus_hod_reseed: negative index offset");
+    if (st->nh > 0) {
+        const int grid = (int)std::min<int64_t>(ceil_div(st->nh, 256), 256 * 32);
+        ABACUS_LAUNCH("hod_reseed_halos", hod_reseed_halos, dim3(grid), dim3(256), 0, st->nh, halo_index0,
+                      (unsigned long long)seed, st->hsigma3d, want_expvel, st->hrandoms, st->hveldev);
+    }
+    if (st->np > 0) {
+        const int grid = (int)std::min<int64_t>(ceil_div(ceil_div(st->np, 4) + 1, 256), 256 * 32);
+        ABACUS_LAUNCH("hod_reseed_particles", hod_reseed_particles, dim3(grid), dim3(256), 0, st->np, part_index0,
+                      (unsigned long long)seed, st->prandoms);
+    }
+    return 0;
+}
+
+int abacus_hod_fetch_field(abacus_hod_state *st, const char *field, double *host) {
+    if (!st || !field || !host) return fail("abacus_hod_fetch_field: null argument");
+    const double *src = nullptr;
+    int64_t n = 0;
+    if (!strcmp(field, "hrandoms")) src = st->hrandoms, n = st->nh;
+    else if (!strcmp(field, "hveldev")) src = st->hveldev, n = 3 * st->nh;
+    else if (!strcmp(field, "prandoms")) src = st->prandoms, n = st->np;
+    else return fail("abacus_hod_fetch_field: unknown field '%s'", field);
+    if (n == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(host, src, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
 int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) {
     ABACUS_TRY(ensure_init());
     if (!st || !p) return fail("abacus_hod_populate: null argument");
@@ -998,6 +1115,7 @@ int abacus_hod_free(abacus_hod_state *st) {
     void *work[] = {st->keep_c, st->keep_s, st->kept_c, st->kept_s, st->sb_counts, st->d_totals, st->q_count, st->queue_c, st->queue_s};
     for (void *q : work)
         if (q) (void)hipFree(q);
+    if (st->owns_sigma && st->hsigma3d) (void)hipFree(st->hsigma3d);
     if (st->h_totals) (void)hipHostFree(st->h_totals);
     for (int t = 0; t < 3; t++) (void)st->out[t].release();
     delete st;

@@ -120,6 +120,25 @@ class StagedCatalog:
         a = _as(values, np.float64)
         check(_lib.lib().abacus_hod_update(self._h, field.encode(), ptr(a)))
 
+    def reseed(self, seed, hsigma3d=None, want_expvel=False, halo_index0=0, part_index0=0):
+        """rewrite hrandoms / hveldev / prandoms in HBM from the device Philox generator (abacus_hod_reseed);
+        `hsigma3d` is staged on the first call"""
+        if hsigma3d is not None and not getattr(self, '_sigma_set', False):
+            a = _as(hsigma3d, np.float64)
+            if len(a) != self.n_halo:
+                raise ValueError('hsigma3d must have one value per halo')
+            check(_lib.lib().abacus_hod_set_sigma3d(self._h, ptr(a), 0))
+            self._sigma_set = True
+        check(_lib.lib().abacus_hod_reseed(self._h, C.c_uint64(int(seed) & (2**64 - 1)), int(bool(want_expvel)),
+                                           C.c_int64(halo_index0), C.c_int64(part_index0)))
+
+    def fetch_field(self, field):
+        """device -> host copy of `hrandoms` (N,), `hveldev` (N,3) or `prandoms` (Np,)"""
+        n = {'hrandoms': self.n_halo, 'hveldev': 3 * self.n_halo, 'prandoms': self.n_part}[field]
+        out = np.empty(n, dtype=np.float64)
+        check(_lib.lib().abacus_hod_fetch_field(self._h, field.encode(), ptr(out)))
+        return out.reshape(-1, 3) if field == 'hveldev' else out
+
     def populate(self, p):
         """decide + emit on the device; returns (Ncent[3], Nsat[3])"""
         counts = (C.c_int64 * 6)()

@@ -8,7 +8,8 @@ Same constructor, attributes and method signatures for the calls on the hot path
     compute_ngal       (:861-1179)  host-side NumPy evaluation of the same sums ("next" row of SURVEY.md 8f)
 
 The halo/particle subsample is uploaded to HBM on the first `run_hod` and stays there (the reference keeps it in
-host RAM across calls, :193-197); `reseed` rewrites the three random arrays on host and device (:824-835).
+host RAM across calls, :193-197); `reseed` rewrites the three random arrays in HBM with the device Philox generator
+and mirrors them to the host dicts (:824-835).
 `AbacusHOD.from_arrays` builds the object from in-memory arrays (tests, synthetic data); the regular constructor
 runs `staging()` (needs h5py for the `halos_xcom_*`/`particles_xcom_*` files).
 ZCV (`apply_zcv*`) is outside the hot path and not provided.
@@ -352,27 +353,19 @@ class AbacusHOD:
         if reseed:
             start = time.time()
             # The reference draws float32 streams from parallel_numpy_rng.MTGenerator(PCG64(reseed)) (:778-823), a
-            # third-party generator that is not available here: same distributions, same dtypes, NumPy's own PCG64
-            # streams (parity with the reference's stream is unpinned; it only smoke-tests this path).
-            rng = np.random.Generator(np.random.PCG64(reseed))
-            nh = len(self.halo_data['hrandoms'])
-            r1 = rng.random(size=nh, dtype=np.float32)
-            if self.want_expvel:
-                rt = np.vstack([rng.random(size=nh, dtype=np.float32) for _ in range(3)]).T
-                r2 = np.zeros((len(rt), 3), dtype=np.float32)
-                r2[rt >= 0.5] = -np.log(2 * (1 - rt[rt >= 0.5]))
-                r2[rt < 0.5] = np.log(2 * rt[rt < 0.5])
+            # third-party generator that is not available here (stream parity unpinned; the reference only smoke-tests
+            # this path).  Same distributions and dtypes from the device's counter-based Philox generator: the three
+            # arrays are rewritten in HBM, then copied back so that `halo_data` / `particle_data` are mutated exactly
+            # as the reference mutates them (:824-835).  `reseed_sync_host = False` skips the copy (MCMC loops).
+            if not want_nfw:
+                st = self._device_catalog()
+                st.reseed(reseed, hsigma3d=self.halo_data['hsigma3d'], want_expvel=self.want_expvel)
+                if getattr(self, 'reseed_sync_host', True):
+                    self.halo_data['hrandoms'] = st.fetch_field('hrandoms').astype(np.float32)    # float32 draws (:780)
+                    self.halo_data['hveldev'] = st.fetch_field('hveldev')                         # float32 * float64
+                    self.particle_data['prandoms'] = st.fetch_field('prandoms').astype(np.float32)
             else:
-                r20, r21, r22 = (rng.standard_normal(size=nh, dtype=np.float32) for _ in range(3))
-                r2 = np.vstack((r20, r21, r22)).T
-            r3 = rng.random(size=len(self.particle_data['prandoms']), dtype=np.float32)
-            self.halo_data['hrandoms'] = r1
-            self.halo_data['hveldev'] = (r2 * np.repeat(self.halo_data['hsigma3d'], 3).reshape((-1, 3)) / np.sqrt(3))
-            self.particle_data['prandoms'] = r3
-            if self._staged is not None:
-                self._staged.update('hrandoms', r1)
-                self._staged.update('hveldev', self.halo_data['hveldev'])
-                self._staged.update('prandoms', r3)
+                raise NotImplementedError('reseed with want_nfw=True')
             self.logger.info(f'Randoms generated in elapsed time {time.time() - start:.2f} s.')
 
         start = time.time()

@@ -110,6 +110,17 @@ int abacus_hod_stage(const abacus_hod_arrays *arrays, int arrays_on_device, abac
 /* re-upload one staged array after `reseed` rewrote it (hod/abacus_hod.py:824-835).
  * field: "hrandoms" | "hveldev" | "prandoms" (float64 host data, staged length) */
 int abacus_hod_update(abacus_hod_state *st, const char *field, const double *host);
+/* Device-side `reseed` (hod/abacus_hod.py:775-839): rewrites hrandoms, hveldev and prandoms in HBM from a counter-based
+ * Philox4x32-10 generator keyed by `seed` - float32 U[0,1) uniforms, float32 N(0,1) (want_expvel: the two-sided
+ * exponential of :799-801) times hsigma3d / sqrt(3) - with no host traffic.  A value depends only on (seed, global
+ * object index): `halo_index0` / `part_index0` are the global indices of this catalogue's first halo / particle, so
+ * the shards of a multi-GPU run draw what the unsharded catalogue would.  The reference's own stream comes from the
+ * third-party parallel_numpy_rng (not in its tree): stream parity is unpinned, distributions and dtypes are the same.
+ * abacus_hod_set_sigma3d stages the per-halo hsigma3d once; abacus_hod_fetch_field copies a rewritten array back
+ * ("hrandoms" | "hveldev" | "prandoms") for callers that need the reference's host-side mutation (:824-835). */
+int abacus_hod_set_sigma3d(abacus_hod_state *st, const double *hsigma3d, int on_device);
+int abacus_hod_reseed(abacus_hod_state *st, uint64_t seed, int want_expvel, int64_t halo_index0, int64_t part_index0);
+int abacus_hod_fetch_field(abacus_hod_state *st, const char *field, double *host);
 /*
  * replaces: gen_cent + gen_sats + fast_concatenate (hod/GRAND_HOD.py:139-414, 825-1262, 1265-1299) as called from
  * gen_gals (:1477-1589).  Decides and emits on the device; galaxies of tracer t are left in device buffers in the
