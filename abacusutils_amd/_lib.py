@@ -57,6 +57,12 @@ class HodArrays(C.Structure):
     )
 
 
+class NfwParams(C.Structure):
+    """struct abacus_nfw_params"""
+    _fields_ = [('seed', C.c_uint64), ('f_sigv', C.c_double * 3), ('exp_frac', C.c_double), ('exp_scale', C.c_double),
+                ('nfw_rescale', C.c_double), ('halo_index0', C.c_int64)]
+
+
 def available():
     """True if the shared library exists (says nothing about a GPU being present)."""
     return _SO.exists()

@@ -25,6 +25,9 @@
 #include "../../include/abacus_hip.h"
 #include "common.hpp"
 
+namespace abacus {
+int exclusive_scan_u32(unsigned int *counters, int64_t n, int64_t *out, DevBuf &scratch, int zero_counters);
+}
 using namespace abacus;
 
 namespace {
@@ -728,6 +731,169 @@ __global__ __launch_bounds__(256) void hod_reseed_particles(int64_t n, int64_t i
     }
 }
 
+// ---- NFW satellites (gen_sats_nfw / compute_fast_NFW / getPointsOnSphere, hod/GRAND_HOD.py:417-822) ------------------
+// The reference draws from NumPy's unseeded per-thread generators, so only the DISTRIBUTIONS can be matched:
+// N_sat ~ Poisson(n_sat(M) * ic) per halo and tracer (no particle weights on this path, :634-706); isotropic
+// direction (:433-441); radius r = eta * Rvir with eta = NFW_draw[k] / c for a random table entry k with
+// NFW_draw[k] <= c (rejection, :503-508; times nfw_rescale), or with probability exp_frac an exponential of scale
+// exp_scale over c (:499-501); velocity ~ N(v_halo, (0.577 f_sigv vrms)^2) per component (:513-516); RSD
+// z = (z + vz / velz2kms) mod L (:787-789: [0, L), unlike the particle path).  Counter-based Philox streams keyed by
+// (seed, global halo index, tracer, satellite rank) make a run reproducible and sharding-invariant.
+struct NfwArgs {
+    unsigned long long seed;
+    double f_sigv[3];
+    double exp_frac, exp_scale, nfw_rescale;
+    int64_t halo_index0;
+    int64_t n_draw;
+};
+
+struct PhiloxStream {   // 4 words per block; blocks (c0, c1, stream, block#)
+    uint4 ctr, buf;
+    uint2 key;
+    int have;
+    __device__ PhiloxStream(unsigned long long seed, unsigned long long index, unsigned int stream) {
+        ctr = make_uint4((unsigned int)index, (unsigned int)(index >> 32), stream, 0u);
+        key = make_uint2((unsigned int)seed, (unsigned int)(seed >> 32));
+        have = 0;
+        buf = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __device__ unsigned int next() {
+        if (have == 0) {
+            buf = philox4x32_10(ctr, key);
+            ctr.w++;
+            have = 4;
+        }
+        const unsigned int v = have == 4 ? buf.x : (have == 3 ? buf.y : (have == 2 ? buf.z : buf.w));
+        have--;
+        return v;
+    }
+    __device__ double uniform() {   // (0, 1): 53 bits would need two words; 32 bits are plenty for these draws
+        return ((double)next() + 0.5) * 2.3283064365386963e-10;
+    }
+};
+
+__device__ int poisson_draw(PhiloxStream &g, double lam) {
+    if (!(lam > 0.0)) return 0;
+    if (lam < 10.0) {   // multiplication method
+        const double L = exp(-lam);
+        int k = 0;
+        double pr = g.uniform();
+        while (pr > L && k < 1000) {
+            k++;
+            pr *= g.uniform();
+        }
+        return k;
+    }
+    // transformed rejection (Hoermann 1993, PTRS)
+    const double slam = sqrt(lam), loglam = log(lam), b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (int it = 0; it < 1000; it++) {
+        const double U = g.uniform() - 0.5, V = g.uniform();
+        const double us = 0.5 - fabs(U);
+        const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return (int)kf;
+        if (kf < 0.0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0)) return (int)kf;
+    }
+    return (int)lam;
+}
+
+// expected satellites per halo of the NFW path (:634-706) and their Poisson draws
+__global__ __launch_bounds__(256) void hod_nfw_count(HodPtrs a, abacus_hod_params p, NfwArgs nf,
+                                                     unsigned int *__restrict__ nL, unsigned int *__restrict__ nE,
+                                                     unsigned int *__restrict__ nQ) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.nh; i += (int64_t)gridDim.x * 256) {
+        const double m = a.hmass[i], dc = load1(a.hdeltac, i, 0.0), fe = load1(a.hfenv, i, 0.0),
+                     sh = load1(a.hshear, i, 0.0);
+        const unsigned long long gi = (unsigned long long)(nf.halo_index0 + i);
+        if (p.want_LRG) {
+            const double M1 = pow(10.0, p.L_logM1 + p.L_Asat * dc + p.L_Bsat * fe);
+            const double lc = p.L_logM_cut + p.L_Acent * dc + p.L_Bcent * fe;
+            const double base = n_sat_LRG_modified(m, lc, pow(10.0, lc), M1, p.L_sigma, p.L_alpha, p.L_kappa) * p.L_ic;
+            PhiloxStream g(nf.seed, gi, 10u);
+            nL[i] = (unsigned int)poisson_draw(g, base);
+        }
+        if (p.want_ELG) {
+            double M1 = pow(10.0, p.E_logM1 + p.E_Asat * dc + p.E_Bsat * fe + p.E_Csat * sh);
+            const double lc = p.E_logM_cut + p.E_Acent * dc + p.E_Bcent * fe + p.E_Ccent * sh;
+            double alpha = p.E_alpha;
+            const int8_t kc = a.keep_c[i];   // ELG conformity (:664-693)
+            if (kc == 1) M1 = pow(10.0, p.E_logM1_EL + p.E_Asat * dc + p.E_Bsat * fe), alpha = p.E_alpha_EL;
+            else if (kc == 2) M1 = pow(10.0, p.E_logM1_EE + p.E_Asat * dc + p.E_Bsat * fe), alpha = p.E_alpha_EE;
+            const double base = N_sat_generic(m, pow(10.0, lc), p.E_kappa, M1, alpha, p.E_A_s) * p.E_ic;
+            PhiloxStream g(nf.seed, gi, 11u);
+            nE[i] = (unsigned int)poisson_draw(g, base);
+        }
+        if (p.want_QSO) {
+            const double M1 = pow(10.0, p.Q_logM1 + p.Q_Asat * dc + p.Q_Bsat * fe);
+            const double lc = p.Q_logM_cut + p.Q_Acent * dc + p.Q_Bcent * fe;
+            const double base = N_sat_generic(m, pow(10.0, lc), p.Q_kappa, M1, p.Q_alpha, 1.0) * p.Q_ic;   // A_s = 1 (:697-703)
+            PhiloxStream g(nf.seed, gi, 12u);
+            nQ[i] = (unsigned int)poisson_draw(g, base);
+        }
+    }
+}
+
+// one thread per satellite of tracer `t`: host halo by binary search in the exclusive offsets
+__global__ __launch_bounds__(256) void hod_nfw_emit(int t, int64_t nsat, int64_t nh, const int64_t *__restrict__ off,
+                                                    int64_t out0, const double *__restrict__ hpos,
+                                                    const double *__restrict__ hvel, const double *__restrict__ hmass,
+                                                    const int64_t *__restrict__ hid, const double *__restrict__ hvrms,
+                                                    const double *__restrict__ hc, const double *__restrict__ hrvir,
+                                                    const double *__restrict__ draw, abacus_hod_params p, NfwArgs nf,
+                                                    OutCols o) {
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < nsat; j += (int64_t)gridDim.x * 256) {
+        int64_t lo = 0, hi = nh;   // largest h with off[h] <= j
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (off[mid] <= j) lo = mid;
+            else hi = mid;
+        }
+        const int64_t h = lo;
+        const unsigned long long rank = (unsigned long long)(j - off[h]);
+        PhiloxStream g(nf.seed ^ (rank * 0x9E3779B97F4A7C15ull), (unsigned long long)(nf.halo_index0 + h), 20u + (unsigned int)t);
+        // direction (:433-441)
+        const double u1 = g.uniform(), u2 = g.uniform();
+        const double ra = u1 * 6.283185307179586, dec = 3.141592653589793 - acos(-1.0 + 2.0 * u2);
+        const double sd = sin(dec), ux = sd * cos(ra), uy = sd * sin(ra), uz = cos(dec);
+        // radius (:497-510)
+        const double c = hc[h];
+        double eta;
+        if (g.uniform() < nf.exp_frac) {
+            eta = -nf.exp_scale * log(g.uniform()) / c;
+        } else {
+            double d = 0.0;
+            bool ok = false;
+            for (int it = 0; it < 256 && !ok; it++) {
+                const int64_t k = (int64_t)(g.uniform() * (double)nf.n_draw);
+                d = draw[k < nf.n_draw ? k : nf.n_draw - 1];
+                ok = !(d > c);
+            }
+            if (!ok) d = c * g.uniform();   // a table without entries below this concentration
+            eta = d / c * nf.nfw_rescale;
+        }
+        const double r = eta * hrvir[h];
+        double x = hpos[3 * h] + ux * r, y = hpos[3 * h + 1] + uy * r, z = hpos[3 * h + 2] + uz * r;
+        // velocity (:511-516): Box-Muller pairs
+        const double sig = hvrms[h] * 0.577 * nf.f_sigv[t];
+        const double m0 = sqrt(-2.0 * log(g.uniform())), m1 = sqrt(-2.0 * log(g.uniform()));
+        const double a0 = 6.283185307179586 * g.uniform(), a1 = 6.283185307179586 * g.uniform();
+        const double vx = hvel[3 * h] + sig * m0 * cos(a0), vy = hvel[3 * h + 1] + sig * m0 * sin(a0),
+                     vz = hvel[3 * h + 2] + sig * m1 * cos(a1);
+        if (p.rsd) {   // (z + vz * inv_velz2kms) % lbox, Python modulo (:787-789)
+            z = z + vz * p.inv_velz2kms;
+            z = z - floor(z / p.lbox) * p.lbox;
+        }
+        const int64_t q = out0 + j;
+        if (q < o.cap[t]) {
+            o.c[t][0][q] = x, o.c[t][1][q] = y, o.c[t][2][q] = z;
+            o.c[t][3][q] = vx, o.c[t][4][q] = vy, o.c[t][5][q] = vz;
+            o.c[t][6][q] = hmass[h];
+            o.id[t][q] = hid[h];
+        }
+    }
+}
+
 }  // namespace
 
 // ---- handle ---------------------------------------------------------------------------------------------
@@ -737,8 +903,10 @@ struct abacus_hod_state {
     // staged inputs (device)
     double *hpos = nullptr, *hvel = nullptr, *hmass = nullptr, *hmultis = nullptr, *hrandoms = nullptr,
            *hveldev = nullptr, *hdeltac = nullptr, *hfenv = nullptr, *hshear = nullptr;
-    double *hsigma3d = nullptr;   // optional (abacus_hod_set_sigma3d): needed by the device reseed only
+    double *hsigma3d = nullptr;   // optional (abacus_hod_set_sigma3d): device reseed and NFW satellites
     bool owns_sigma = false;
+    double *hc = nullptr, *hrvir = nullptr;   // optional (abacus_hod_set_profile): NFW satellites
+    DevBuf nfw_counts, nfw_offsets, nfw_draw, nfw_scan;
     int64_t *hid = nullptr;
     double *ppos = nullptr, *pvel = nullptr, *phvel = nullptr, *phmass = nullptr, *pweights = nullptr,
            *prandoms = nullptr, *pdeltac = nullptr, *pfenv = nullptr, *pshear = nullptr, *pranks = nullptr,
@@ -979,6 +1147,104 @@ int abacus_hod_fetch_field(abacus_hod_state *st, const char *field, double *host
     return 0;
 }
 
+int abacus_hod_set_profile(abacus_hod_state *st, const double *hc, const double *hrvir) {
+    ABACUS_TRY(ensure_init());
+    if (!st || !hc || !hrvir) return fail("abacus_hod_set_profile: null argument");
+    const size_t bytes = (size_t)(st->nh > 0 ? st->nh : 1) * sizeof(double);
+    if (!st->hc) HIP_TRY(hipMalloc((void **)&st->hc, bytes));
+    if (!st->hrvir) HIP_TRY(hipMalloc((void **)&st->hrvir, bytes));
+    HIP_TRY(hipMemcpyAsync(st->hc, hc, (size_t)st->nh * sizeof(double), hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemcpyAsync(st->hrvir, hrvir, (size_t)st->nh * sizeof(double), hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, const abacus_nfw_params *nfw,
+                            const double *NFW_draw, int64_t n_draw, int64_t counts[6]) {
+    ABACUS_TRY(ensure_init());
+    if (!st || !p || !nfw) return fail("abacus_hod_populate_nfw: null argument");
+    if (p->has_origin) return fail("abacus_hod_populate_nfw: the NFW path does not support light cones (hod/GRAND_HOD.py:551)");
+    if (st->nh > 0 && (!st->hsigma3d || !st->hc || !st->hrvir))
+        return fail("abacus_hod_populate_nfw: hsigma3d / hc / hrvir have not been staged (abacus_hod_set_sigma3d, _set_profile)");
+    if (!NFW_draw || n_draw < 1) return fail("abacus_hod_populate_nfw: NFW_draw is empty");
+    st->params = *p;
+    SatPre pre;
+    memset(&pre, 0, sizeof pre);
+    Filt F = make_filter(*p, pre);
+    HodPtrs a;
+    memset(&a, 0, sizeof a);
+    a.nh = st->nh, a.np = 0, a.ntile_c = st->ntile_c, a.ntile_s = 0, a.nsb_c = st->nsb_c, a.nsb_s = 0;
+    a.hmass = st->hmass, a.hmultis = st->hmultis, a.hrandoms = st->hrandoms, a.hdeltac = st->hdeltac,
+    a.hfenv = st->hfenv, a.hshear = st->hshear;
+    a.keep_c = st->keep_c, a.keep_s = st->keep_s, a.q_count = st->q_count, a.queue_c = st->queue_c,
+    a.queue_s = st->queue_s, a.kept_c = st->kept_c, a.kept_s = st->kept_s, a.sb_counts = st->sb_counts;
+    const int need_env = (p->want_LRG && (p->L_Acent != 0 || p->L_Bcent != 0)) ||
+                         (p->want_ELG && (p->E_Acent != 0 || p->E_Bcent != 0)) ||
+                         (p->want_QSO && (p->Q_Acent != 0 || p->Q_Bcent != 0));
+    const int need_shear = p->want_ELG && p->E_Ccent != 0 && st->hshear != nullptr;
+    // centrals exactly as the particle path decides them; no particle satellites
+    if (st->nsb_s) HIP_TRY(hipMemsetAsync(st->sb_counts + (int64_t)st->nsb_c * 4, 0, (size_t)st->nsb_s * 4 * sizeof(int), stream()));
+    if (st->ntile_c) {
+        ABACUS_LAUNCH("hod_filter", hod_filter, dim3(st->ntile_c), dim3(FBLOCK), 0, a, 0, p->want_LRG, p->want_ELG,
+                      p->want_QSO, p->enable_ranks, need_env, need_shear, F);
+        ABACUS_LAUNCH("hod_exact", hod_exact, dim3(st->nsb_c), dim3(FBLOCK), 0, a, 0, *p, pre);
+    }
+    ABACUS_TRY(launch_emit(st));
+    HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+    // Poisson satellite numbers per halo and tracer, their exclusive offsets
+    const int64_t nh = st->nh;
+    ABACUS_TRY(st->nfw_counts.reserve((size_t)(3 * (nh + 1)) * sizeof(unsigned int)));
+    ABACUS_TRY(st->nfw_offsets.reserve((size_t)(3 * (nh + 1)) * sizeof(int64_t)));
+    ABACUS_TRY(st->nfw_draw.reserve((size_t)n_draw * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(st->nfw_draw.p, NFW_draw, (size_t)n_draw * sizeof(double), hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemsetAsync(st->nfw_counts.p, 0, (size_t)(3 * (nh + 1)) * sizeof(unsigned int), stream()));
+    unsigned int *cnt[3];
+    int64_t *off[3];
+    for (int t = 0; t < 3; t++) {
+        cnt[t] = st->nfw_counts.as<unsigned int>() + (int64_t)t * (nh + 1);
+        off[t] = st->nfw_offsets.as<int64_t>() + (int64_t)t * (nh + 1);
+    }
+    NfwArgs nf;
+    nf.seed = nfw->seed;
+    for (int t = 0; t < 3; t++) nf.f_sigv[t] = nfw->f_sigv[t];
+    nf.exp_frac = nfw->exp_frac, nf.exp_scale = nfw->exp_scale, nf.nfw_rescale = nfw->nfw_rescale;
+    nf.halo_index0 = nfw->halo_index0;
+    nf.n_draw = n_draw;
+    int64_t nsat[3] = {0, 0, 0};
+    if (nh > 0) {
+        const int grid = (int)std::min<int64_t>(ceil_div(nh, 256), 256 * 32);
+        ABACUS_LAUNCH("hod_nfw_count", hod_nfw_count, dim3(grid), dim3(256), 0, a, *p, nf, cnt[0], cnt[1], cnt[2]);
+        for (int t = 0; t < 3; t++) {
+            ABACUS_TRY(exclusive_scan_u32(cnt[t], nh, off[t], st->nfw_scan, 0));
+            HIP_TRY(hipMemcpyAsync(&nsat[t], off[t] + nh, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(stream()));
+    bool grew = false;
+    for (int t = 0; t < 3; t++) {
+        st->counts[t] = st->h_totals[t];
+        st->counts[3 + t] = nsat[t];
+        const int64_t need = st->counts[t] + st->counts[3 + t];
+        if (need > st->cap[t]) {
+            ABACUS_TRY(set_capacity(st, t, need + need / 8));
+            grew = true;
+        }
+    }
+    if (grew) ABACUS_TRY(launch_emit(st));   // the centrals again, into the new buffers
+    for (int t = 0; t < 3; t++) {
+        if (nsat[t] == 0) continue;
+        const int grid = (int)std::min<int64_t>(ceil_div(nsat[t], 256), 256 * 32);
+        ABACUS_LAUNCH("hod_nfw_emit", hod_nfw_emit, dim3(grid), dim3(256), 0, t, nsat[t], nh, (const int64_t *)off[t],
+                      st->counts[t], st->hpos, st->hvel, st->hmass, st->hid, st->hsigma3d, st->hc, st->hrvir,
+                      st->nfw_draw.as<double>(), *p, nf, out_cols(st));
+    }
+    HIP_TRY(hipStreamSynchronize(stream()));
+    st->have_run = true;
+    st->counts_valid = true;
+    if (counts) memcpy(counts, st->counts, sizeof st->counts);
+    return 0;
+}
+
 int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) {
     ABACUS_TRY(ensure_init());
     if (!st || !p) return fail("abacus_hod_populate: null argument");
@@ -1116,6 +1382,9 @@ int abacus_hod_free(abacus_hod_state *st) {
     for (void *q : work)
         if (q) (void)hipFree(q);
     if (st->owns_sigma && st->hsigma3d) (void)hipFree(st->hsigma3d);
+    if (st->hc) (void)hipFree(st->hc);
+    if (st->hrvir) (void)hipFree(st->hrvir);
+    (void)st->nfw_counts.release(), (void)st->nfw_offsets.release(), (void)st->nfw_draw.release(), (void)st->nfw_scan.release();
     if (st->h_totals) (void)hipHostFree(st->h_totals);
     for (int t = 0; t < 3; t++) (void)st->out[t].release();
     delete st;

@@ -146,6 +146,29 @@ class StagedCatalog:
         self.counts = np.array(counts[:], dtype=np.int64)
         return self.counts[:3].copy(), self.counts[3:].copy()
 
+    def populate_nfw(self, p, tracers, halo_data, NFW_draw, seed, halo_index0=0):
+        """centrals as usual + NFW satellites (abacus_hod_populate_nfw); stages hsigma3d / hc / hrvir on first use"""
+        if not getattr(self, '_sigma_set', False):
+            check(_lib.lib().abacus_hod_set_sigma3d(self._h, ptr(_as(halo_data['hsigma3d'], np.float64)), 0))
+            self._sigma_set = True
+        if not getattr(self, '_profile_set', False):
+            check(_lib.lib().abacus_hod_set_profile(self._h, ptr(_as(halo_data['hc'], np.float64)),
+                                                    ptr(_as(halo_data['hrvir'], np.float64))))
+            self._profile_set = True
+        nf = _lib.NfwParams()
+        nf.seed = int(seed) & (2**64 - 1)
+        for t, tr in enumerate(TRACERS):   # f_sigv defaults to 0 (hod/GRAND_HOD.py:1376,1418,1457)
+            nf.f_sigv[t] = float(tracers.get(tr, {}).get('f_sigv', 0.0))
+        elg = tracers.get('ELG', {})       # the reference takes these from the ELG dict for every tracer (:606-608)
+        nf.exp_frac, nf.exp_scale = float(elg.get('exp_frac', 0.0)), float(elg.get('exp_scale', 1.0))
+        nf.nfw_rescale = float(elg.get('nfw_rescale', 1.0))
+        nf.halo_index0 = int(halo_index0)
+        draw = _as(NFW_draw, np.float64)
+        counts = (C.c_int64 * 6)()
+        check(_lib.lib().abacus_hod_populate_nfw(self._h, C.byref(p), C.byref(nf), ptr(draw), C.c_int64(len(draw)), counts))
+        self.counts = np.array(counts[:], dtype=np.int64)
+        return self.counts[:3].copy(), self.counts[3:].copy()
+
     def populate_async(self, p):
         """enqueue only (bench): no host synchronisation, no result copy"""
         check(_lib.lib().abacus_hod_populate_async(self._h, C.byref(p)))
@@ -196,10 +219,6 @@ def gen_gals(halos_array, subsample, tracers, params, Nthread, enable_ranks, rsd
              staged=None):
     """hod/GRAND_HOD.py:1302-1592.  `staged`: a StagedCatalog to reuse (extension); otherwise the arrays are
     uploaded for this call only."""
-    if nfw:
-        raise NotImplementedError(
-            'want_nfw=True (gen_sats_nfw, hod/GRAND_HOD.py:522-822) is not part of the MI355X path yet; '
-            'the reference itself flags it as unoptimized and it draws from an unseeded per-thread RNG')
     p = marshal_params(tracers, params, enable_ranks, rsd)
     own = staged is None
     if own:
@@ -207,7 +226,21 @@ def gen_gals(halos_array, subsample, tracers, params, Nthread, enable_ranks, rsd
     try:
         if enable_ranks and not staged.has_ranks:
             raise KeyError('pranks')
-        ncent, nsat = staged.populate(p)
+        if nfw:
+            # NFW satellites (gen_sats_nfw, :522-822).  The reference draws them from Numba's unseeded per-thread
+            # generators; here the Philox key comes from NumPy's global generator, so `np.random.seed` makes a run
+            # reproducible.  Parity with the reference is statistical by construction.
+            warnings.warn('NFW profile is unoptimized. It has different velocity bias. It does not support lightcone.')
+            if NFW_draw is None:
+                raise ValueError('nfw=True needs NFW_draw (the table of NFW radial draws in units of r_s)')
+            for k in ('hsigma3d', 'hc', 'hrvir'):
+                if k not in halos_array:
+                    raise KeyError(k)
+            seed = nfw if (isinstance(nfw, (int, np.integer)) and not isinstance(nfw, (bool, np.bool_))) else \
+                int(np.random.randint(0, 2**62))
+            ncent, nsat = staged.populate_nfw(p, tracers, halos_array, NFW_draw, seed)
+        else:
+            ncent, nsat = staged.populate(p)
         HOD_dict = {}
         for tracer in tracers:
             if tracer not in TRACERS:

@@ -357,22 +357,19 @@ class AbacusHOD:
             # this path).  Same distributions and dtypes from the device's counter-based Philox generator: the three
             # arrays are rewritten in HBM, then copied back so that `halo_data` / `particle_data` are mutated exactly
             # as the reference mutates them (:824-835).  `reseed_sync_host = False` skips the copy (MCMC loops).
-            if not want_nfw:
-                st = self._device_catalog()
-                st.reseed(reseed, hsigma3d=self.halo_data['hsigma3d'], want_expvel=self.want_expvel)
-                if getattr(self, 'reseed_sync_host', True):
-                    self.halo_data['hrandoms'] = st.fetch_field('hrandoms').astype(np.float32)    # float32 draws (:780)
-                    self.halo_data['hveldev'] = st.fetch_field('hveldev')                         # float32 * float64
-                    self.particle_data['prandoms'] = st.fetch_field('prandoms').astype(np.float32)
-            else:
-                raise NotImplementedError('reseed with want_nfw=True')
+            st = self._device_catalog()
+            st.reseed(reseed, hsigma3d=self.halo_data['hsigma3d'], want_expvel=self.want_expvel)
+            if getattr(self, 'reseed_sync_host', True):
+                self.halo_data['hrandoms'] = st.fetch_field('hrandoms').astype(np.float32)    # float32 draws (:780)
+                self.halo_data['hveldev'] = st.fetch_field('hveldev')                         # float32 * float64
+                self.particle_data['prandoms'] = st.fetch_field('prandoms').astype(np.float32)
             self.logger.info(f'Randoms generated in elapsed time {time.time() - start:.2f} s.')
 
         start = time.time()
         mock_dict = gen_gal_cat(self.halo_data, self.particle_data, tracers, self.params, Nthread,
                                 enable_ranks=self.want_ranks, rsd=want_rsd, nfw=want_nfw, NFW_draw=NFW_draw,
                                 write_to_disk=write_to_disk, savedir=self.mock_dir, verbose=verbose, fn_ext=fn_ext,
-                                staged=self._device_catalog() if not want_nfw else None)
+                                staged=self._device_catalog())
         self.logger.info(f'HOD generated in elapsed time {time.time() - start:.2f} s.')
         return mock_dict
 

@@ -121,6 +121,23 @@ int abacus_hod_update(abacus_hod_state *st, const char *field, const double *hos
 int abacus_hod_set_sigma3d(abacus_hod_state *st, const double *hsigma3d, int on_device);
 int abacus_hod_reseed(abacus_hod_state *st, uint64_t seed, int want_expvel, int64_t halo_index0, int64_t part_index0);
 int abacus_hod_fetch_field(abacus_hod_state *st, const char *field, double *host);
+
+/* NFW satellites: `gen_gal_cat(..., nfw=True, NFW_draw=...)` (gen_sats_nfw, compute_fast_NFW, getPointsOnSphere,
+ * hod/GRAND_HOD.py:417-822).  Centrals are decided exactly as on the particle path; satellites are Poisson(n_sat(M) ic)
+ * per halo and tracer, placed isotropically at r = NFW_draw[k] / c * Rvir (k random with NFW_draw[k] <= c) around
+ * their halo with N(v_halo, (0.577 f_sigv vrms)^2) velocities; box RSD only.  The reference draws from NumPy's
+ * unseeded per-thread generators (never reproducible): parity is statistical; here the draws are
+ * Philox streams of (seed, global halo index, tracer, satellite rank).  Needs abacus_hod_set_sigma3d (vrms) and
+ * abacus_hod_set_profile (hc = r98/r25 concentration, hrvir) once per staged catalogue. */
+typedef struct abacus_nfw_params {
+    uint64_t seed;
+    double f_sigv[3];                         /* LRG, ELG, QSO (:566,605,623) */
+    double exp_frac, exp_scale, nfw_rescale;  /* ELG_hod_dict values, applied to every tracer as the reference does (:606-608) */
+    int64_t halo_index0;                      /* global index of this catalogue's first halo (sharding) */
+} abacus_nfw_params;
+int abacus_hod_set_profile(abacus_hod_state *st, const double *hc, const double *hrvir);
+int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, const abacus_nfw_params *nfw,
+                            const double *NFW_draw, int64_t n_draw, int64_t counts[6]);
 /*
  * replaces: gen_cent + gen_sats + fast_concatenate (hod/GRAND_HOD.py:139-414, 825-1262, 1265-1299) as called from
  * gen_gals (:1477-1589).  Decides and emits on the device; galaxies of tracer t are left in device buffers in the

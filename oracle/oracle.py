@@ -424,3 +424,42 @@ def paircount_brute(mode, x1, y1, z1, boxsize, bins, x2=None, y2=None, z2=None, 
                                  C.c_float(boxsize), _ptr(bins), nb, C.c_float(pimax), int(npibins),
                                  C.c_float(mu_max), int(nmubins), int(nthread), _ptr(out))
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# NFW satellites: the deterministic part of gen_sats_nfw (hod/GRAND_HOD.py:634-706) - the Poisson MEAN per halo and
+# tracer - restated in NumPy.  The draws themselves come from Numba's unseeded generators in the reference, so tests
+# compare distributions (counts against these means, radii against the NFW_draw table, velocities against N(0, sig)).
+def nfw_expected_counts(halo_data, tracers, params, keep_cent):
+    from scipy.special import erfc
+    p = marshal_params(tracers, params, False, True)
+    m = _f8(halo_data['hmass'])
+    z = np.zeros_like(m)
+    dc, fe, sh = (_f8(halo_data.get(k, z)) for k in ('hdeltac', 'hfenv', 'hshear'))
+    out = {}
+
+    def n_sat_generic(M_h, M_cut, kappa, M_1, alpha, A_s=1.0):   # N_sat_generic / N_sat_elg (:45-65)
+        x = M_h - kappa * M_cut
+        with np.errstate(invalid='ignore'):
+            return np.where(x < 0, 0.0, A_s * (np.maximum(x, 0) / M_1) ** alpha)
+
+    if p.want_LRG:
+        M1 = 10 ** (p.L_logM1 + p.L_Asat * dc + p.L_Bsat * fe)
+        lc = p.L_logM_cut + p.L_Acent * dc + p.L_Bcent * fe
+        ncen = 0.5 * erfc((lc - np.log10(m)) / (1.41421356 * p.L_sigma))
+        out['LRG'] = n_sat_generic(m, 10 ** lc, p.L_kappa, M1, p.L_alpha) * ncen * p.L_ic   # n_sat_LRG_modified (:23-34)
+    if p.want_ELG:
+        M1 = 10 ** (p.E_logM1 + p.E_Asat * dc + p.E_Bsat * fe + p.E_Csat * sh)
+        lc = p.E_logM_cut + p.E_Acent * dc + p.E_Bcent * fe + p.E_Ccent * sh
+        alpha = np.full_like(m, p.E_alpha)
+        kc = np.asarray(keep_cent)
+        M1 = np.where(kc == 1, 10 ** (p.E_logM1_EL + p.E_Asat * dc + p.E_Bsat * fe), M1)
+        alpha = np.where(kc == 1, p.E_alpha_EL, alpha)
+        M1 = np.where(kc == 2, 10 ** (p.E_logM1_EE + p.E_Asat * dc + p.E_Bsat * fe), M1)
+        alpha = np.where(kc == 2, p.E_alpha_EE, alpha)
+        out['ELG'] = n_sat_generic(m, 10 ** lc, p.E_kappa, M1, alpha, p.E_A_s) * p.E_ic
+    if p.want_QSO:
+        M1 = 10 ** (p.Q_logM1 + p.Q_Asat * dc + p.Q_Bsat * fe)
+        lc = p.Q_logM_cut + p.Q_Acent * dc + p.Q_Bcent * fe
+        out['QSO'] = n_sat_generic(m, 10 ** lc, p.Q_kappa, M1, p.Q_alpha) * p.Q_ic
+    return out

@@ -118,7 +118,7 @@ def test_errors(G):
     del bad['alpha_c']
     with pytest.raises(KeyError):
         G.gen_gal_cat(hd, pd, {'LRG': bad}, params)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         G.gen_gal_cat(hd, pd, {'LRG': synth.LRG_PARAMS}, params, nfw=True)
 
 
