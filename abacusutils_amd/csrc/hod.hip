@@ -894,6 +894,61 @@ __global__ __launch_bounds__(256) void hod_nfw_emit(int t, int64_t nsat, int64_t
     }
 }
 
+// ---- compute_ngal (hod/abacus_hod.py:861-1179) -----------------------------------------------------------------------
+// The reference sums  hist[cell] * n(centre of cell)  over a 100^3 (LRG, QSO) or 100^4 (ELG) weighted halo histogram.
+// The same sum runs over the HALOS here: sum_i multis[i] * n(centre of the cell of halo i) - identical terms, no
+// 800-MB histogram, one streaming pass over 12 bytes per halo.  The cell indices come from the host once
+// (np.histogramdd's own edge rule), 255 = outside the histogram range.
+struct NgalTables {
+    const double *Mh, *deltac, *fenv, *shear;   // 10**logM centre, deltac / fenv / shear centres
+};
+
+__global__ __launch_bounds__(256) void hod_ngal(int64_t n, const uchar4 *__restrict__ bins,
+                                                const double *__restrict__ multis, NgalTables tb, abacus_hod_params p,
+                                                double *__restrict__ out) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};   // cent L, E, Q; sat L, E, Q
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uchar4 b = bins[i];
+        if (b.x == 255 || b.y == 255 || b.z == 255) continue;
+        const double w = multis[i], Mh = tb.Mh[b.x], dc = tb.deltac[b.y], fe = tb.fenv[b.z];
+        if (p.want_LRG) {   // _compute_ngal_lrg (:980-1033)
+            const double lc = p.L_logM_cut + p.L_Acent * dc + p.L_Bcent * fe;
+            const double M1 = pow(10.0, p.L_logM1 + p.L_Asat * dc + p.L_Bsat * fe);
+            acc[0] += w * n_cen_LRG(Mh, lc, p.L_sigma) * p.L_ic;
+            acc[3] += w * n_sat_LRG_modified(Mh, lc, pow(10.0, lc), M1, p.L_sigma, p.L_alpha, p.L_kappa) * p.L_ic;
+        }
+        if (p.want_QSO) {   // _compute_ngal_qso (:1135-1179)
+            const double lc = p.Q_logM_cut + p.Q_Acent * dc + p.Q_Bcent * fe;
+            const double M1 = pow(10.0, p.Q_logM1 + p.Q_Asat * dc + p.Q_Bsat * fe);
+            acc[2] += w * N_cen_QSO(Mh, lc, p.Q_sigma) * p.Q_ic;
+            acc[5] += w * N_sat_generic(Mh, pow(10.0, lc), p.Q_kappa, M1, p.Q_alpha, 1.0) * p.Q_ic;
+        }
+        if (p.want_ELG && b.w != 255) {   // _compute_ngal_elg (:1035-1132)
+            const double sh = tb.shear[b.w];
+            const double lc = p.E_logM_cut + p.E_Acent * dc + p.E_Bcent * fe + p.E_Ccent * sh;
+            const double M1 = pow(10.0, p.E_logM1 + p.E_Asat * dc + p.E_Bsat * fe + p.E_Csat * sh);
+            const double ncent = N_cen_ELG_v1(Mh, p.E_p_max, p.E_Q, lc, p.E_sigma, p.E_gamma) * p.E_ic;
+            const double Mc = pow(10.0, lc);
+            const double nsat = N_sat_generic(Mh, Mc, p.E_kappa, M1, p.E_alpha, p.E_A_s) * p.E_ic;
+            const double M1c = pow(10.0, p.E_logM1_EE + p.E_Asat * dc + p.E_Bsat * fe + p.E_Csat * sh);
+            const double nconf = N_sat_generic(Mh, Mc, p.E_kappa, M1c, p.E_alpha_EE, p.E_A_s) * p.E_ic;
+            acc[1] += w * ncent;
+            acc[4] += w * (nsat * (1 - ncent) + nconf * ncent);
+        }
+    }
+    __shared__ double red[4][6];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        double v = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) atomicAdd(&out[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 }  // namespace
 
 // ---- handle ---------------------------------------------------------------------------------------------
@@ -907,6 +962,8 @@ struct abacus_hod_state {
     bool owns_sigma = false;
     double *hc = nullptr, *hrvir = nullptr;   // optional (abacus_hod_set_profile): NFW satellites
     DevBuf nfw_counts, nfw_offsets, nfw_draw, nfw_scan;
+    DevBuf ngal_bins, ngal_tables, ngal_out;   // compute_ngal: cell indices, 4 x nbin centres, 6 sums
+    int ngal_nbin = 0;
     int64_t *hid = nullptr;
     double *ppos = nullptr, *pvel = nullptr, *phvel = nullptr, *phmass = nullptr, *pweights = nullptr,
            *prandoms = nullptr, *pdeltac = nullptr, *pfenv = nullptr, *pshear = nullptr, *pranks = nullptr,
@@ -1245,6 +1302,38 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
     return 0;
 }
 
+int abacus_hod_set_ngal_bins(abacus_hod_state *st, const uint8_t *bins4, const double *centres, int nbin) {
+    ABACUS_TRY(ensure_init());
+    if (!st || !bins4 || !centres) return fail("abacus_hod_set_ngal_bins: null argument");
+    if (nbin < 1 || nbin > 254) return fail("abacus_hod_set_ngal_bins: nbin must be in [1, 254]");
+    ABACUS_TRY(st->ngal_bins.reserve((size_t)(st->nh > 0 ? st->nh : 1) * 4));
+    ABACUS_TRY(st->ngal_tables.reserve((size_t)4 * nbin * sizeof(double)));
+    ABACUS_TRY(st->ngal_out.reserve(8 * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(st->ngal_bins.p, bins4, (size_t)st->nh * 4, hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemcpyAsync(st->ngal_tables.p, centres, (size_t)4 * nbin * sizeof(double), hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    st->ngal_nbin = nbin;
+    return 0;
+}
+
+int abacus_hod_ngal(abacus_hod_state *st, const abacus_hod_params *p, double out[6]) {
+    ABACUS_TRY(ensure_init());
+    if (!st || !p || !out) return fail("abacus_hod_ngal: null argument");
+    if (!st->ngal_nbin) return fail("abacus_hod_ngal: the histogram cells have not been set (abacus_hod_set_ngal_bins)");
+    HIP_TRY(hipMemsetAsync(st->ngal_out.p, 0, 6 * sizeof(double), stream()));
+    if (st->nh > 0) {
+        NgalTables tb;
+        const double *c = st->ngal_tables.as<double>();
+        tb.Mh = c, tb.deltac = c + st->ngal_nbin, tb.fenv = c + 2 * st->ngal_nbin, tb.shear = c + 3 * st->ngal_nbin;
+        const int grid = (int)std::min<int64_t>(ceil_div(st->nh, 256), 256 * 8);
+        ABACUS_LAUNCH("hod_ngal", hod_ngal, dim3(grid), dim3(256), 0, st->nh, (const uchar4 *)st->ngal_bins.p,
+                      (const double *)st->hmultis, tb, *p, st->ngal_out.as<double>());
+    }
+    HIP_TRY(hipMemcpyAsync(out, st->ngal_out.p, 6 * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
 int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) {
     ABACUS_TRY(ensure_init());
     if (!st || !p) return fail("abacus_hod_populate: null argument");
@@ -1384,6 +1473,7 @@ int abacus_hod_free(abacus_hod_state *st) {
     if (st->owns_sigma && st->hsigma3d) (void)hipFree(st->hsigma3d);
     if (st->hc) (void)hipFree(st->hc);
     if (st->hrvir) (void)hipFree(st->hrvir);
+    (void)st->ngal_bins.release(), (void)st->ngal_tables.release(), (void)st->ngal_out.release();
     (void)st->nfw_counts.release(), (void)st->nfw_offsets.release(), (void)st->nfw_draw.release(), (void)st->nfw_scan.release();
     if (st->h_totals) (void)hipHostFree(st->h_totals);
     for (int t = 0; t < 3; t++) (void)st->out[t].release();

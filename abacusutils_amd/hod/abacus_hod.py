@@ -5,7 +5,7 @@ Same constructor, attributes and method signatures for the calls on the hot path
     run_hod            (:706-859)   -> gen_gal_cat on the device-resident subsample (csrc/hod.hip)
     compute_power      (:1338-1472) -> calc_power (csrc/tsc.hip, power.hip)
     compute_xirppi / compute_wp / compute_multipole / compute_clustering  (:1181-1336, :1826-1885) -> csrc/pairs.hip
-    compute_ngal       (:861-1179)  host-side NumPy evaluation of the same sums ("next" row of SURVEY.md 8f)
+    compute_ngal       (:861-1179)  the same sums as one pass over the staged halos on the device (abacus_hod_ngal)
 
 The halo/particle subsample is uploaded to HBM on the first `run_hod` and stays there (the reference keeps it in
 host RAM across calls, :193-197); `reseed` rewrites the three random arrays in HBM with the device Philox generator
@@ -374,61 +374,52 @@ class AbacusHOD:
         return mock_dict
 
     # ------------------------------------------------------------------------------------------------------
+    def _ngal_cells(self):
+        """np.histogramdd's cell of every halo in the (logM, deltac, fenv, shear) histogram (:199-251): uint8 (N, 4),
+        255 = outside the range (histogramdd drops those), plus the [4][100] table of cell centres"""
+        hd = self.halo_data
+        n = len(hd['hmass'])
+        cols = (np.log10(hd['hmass']), hd.get('hdeltac', np.zeros(n)), hd.get('hfenv', np.zeros(n)),
+                hd.get('hshear', np.zeros(n)))
+        edges = (self.logMbins, self.deltacbins, self.fenvbins, self.shearbins)
+        bins = np.empty((n, 4), dtype=np.uint8)
+        for d, (x, e) in enumerate(zip(cols, edges)):
+            idx = np.searchsorted(e, x, side='right') - 1
+            idx[x == e[-1]] = len(e) - 2           # the last bin is closed on the right
+            idx[(idx < 0) | (idx > len(e) - 2)] = 255
+            bins[:, d] = idx
+        centres = np.empty((4, len(self.logMbins) - 1))
+        centres[0] = 10 ** (0.5 * (self.logMbins[1:] + self.logMbins[:-1]))   # Mh_temp = 10**logMs[i] (:1009)
+        for d, e in enumerate(edges[1:], start=1):
+            centres[d] = 0.5 * (e[1:] + e[:-1])
+        return bins, centres
+
     def compute_ngal(self, tracers=None, Nthread=16):
         """Expected number of each tracer and its satellite fraction from the weighted halo histogram
-        (hod/abacus_hod.py:861-1179).  Host-side NumPy evaluation of the reference's triple/quadruple sums."""
+        (hod/abacus_hod.py:861-1179), evaluated on the device as the identical sum over halos (abacus_hod_ngal)."""
+        import ctypes as C
+
+        from .. import _lib
+        from .GRAND_HOD import TRACERS, marshal_params
         if tracers is None:
             tracers = self.tracers
+        st = self._device_catalog()
+        if not getattr(st, '_ngal_set', False):
+            bins, centres = self._ngal_cells()
+            _lib.check(_lib.lib().abacus_hod_set_ngal_bins(st._h, _lib.ptr(np.ascontiguousarray(bins)),
+                                                           _lib.ptr(np.ascontiguousarray(centres)), centres.shape[1]))
+            st._ngal_set = True
+        known = {t: dict(tracers[t]) for t in tracers if t in TRACERS}
+        for hod in known.values():               # keys gen_gals requires but compute_ngal never reads (:884-976)
+            for k in ('alpha_c', 'alpha_s', 's', 's_v', 's_p', 's_r'):
+                hod.setdefault(k, 0.0)
+        p = marshal_params(known, dict(self.params, z=self.z_mock), False, True)
+        out = (C.c_double * 6)()
+        _lib.check(_lib.lib().abacus_hod_ngal(st._h, C.byref(p), out))
         ngal_dict, fsat_dict = {}, {}
-        erfc = np.vectorize(math.erfc)
-        erf = np.vectorize(math.erf)
-        logMs = 0.5 * (self.logMbins[1:] + self.logMbins[:-1])
-        deltacs = 0.5 * (self.deltacbins[1:] + self.deltacbins[:-1])
-        fenvs = 0.5 * (self.fenvbins[1:] + self.fenvbins[:-1])
-        shears = 0.5 * (self.shearbins[1:] + self.shearbins[:-1])
-        for etracer, hod in tracers.items():
-            Delta_a = 1.0 / (1 + self.z_mock) - 1.0 / (1 + hod.get('z_pivot', self.z_mock))
-            logM_cut = hod['logM_cut'] + hod.get('logM_cut_pr', 0) * Delta_a
-            logM1 = hod['logM1'] + hod.get('logM1_pr', 0) * Delta_a
-            Ac, As, Bc, Bs = (hod.get(k, 0) for k in ('Acent', 'Asat', 'Bcent', 'Bsat'))
-            ic = hod.get('ic', 1)
-            Mh = (10 ** logMs)[:, None, None]
-            lc = logM_cut + Ac * deltacs[None, :, None] + Bc * fenvs[None, None, :]
-            M1 = 10 ** (logM1 + As * deltacs[None, :, None] + Bs * fenvs[None, None, :])
-            if etracer == 'LRG':
-                ncent = 0.5 * erfc((lc - np.log10(Mh)) / (1.41421356 * hod['sigma']))
-                base = Mh - hod['kappa'] * 10**lc
-                nsat = np.where(base < 0, 0.0, (np.maximum(base, 0) / M1) ** hod['alpha'] * ncent)
-                ngal_cent = np.sum(self.halo_mass_func * ncent * ic)
-                ngal_sat = np.sum(self.halo_mass_func * nsat * ic)
-            elif etracer == 'QSO':
-                ncent = 0.5 * (1 + erf((np.log10(Mh) - lc) / 1.41421356 / hod['sigma']))
-                base = Mh - hod['kappa'] * 10**lc
-                nsat = np.where(base < 0, 0.0, (np.maximum(base, 0) / M1) ** hod['alpha'])
-                ngal_cent = np.sum(self.halo_mass_func * ncent * ic)
-                ngal_sat = np.sum(self.halo_mass_func * nsat * ic)
-            elif etracer == 'ELG':
-                Cc, Cs = hod.get('Ccent', 0), hod.get('Csat', 0)
-                A_s = hod.get('A_s', 1)
-                logM1_EE, alpha_EE = hod.get('logM1_EE', hod['logM1']), hod.get('alpha_EE', hod['alpha'])
-                ngal_cent = ngal_sat = 0.0
-                hmf = self.halo_mass_func_wshear
-                logMh = np.log10(Mh)
-                for el, sh in enumerate(shears):  # one shear slice at a time keeps the temporaries at 100^3
-                    lce = lc + Cc * sh
-                    M1e = 10 ** (logM1 + As * deltacs[None, :, None] + Bs * fenvs[None, None, :] + Cs * sh)
-                    phi = 0.3989422804014327 / hod['sigma'] * np.exp(-((logMh - lce) ** 2) / 2 / hod['sigma'] ** 2)
-                    Phi = 0.5 * (1 + erf(hod['gamma'] * (logMh - lce) / hod['sigma'] / np.sqrt(2)))
-                    ncent = 2.0 * (hod['p_max'] - 1.0 / hod['Q']) * phi * Phi * ic
-                    base = Mh - hod['kappa'] * 10**lce
-                    nsat = np.where(base < 0, 0.0, A_s * (np.maximum(base, 0) / M1e) ** hod['alpha']) * ic
-                    M1c = 10 ** (logM1_EE + As * deltacs[None, :, None] + Bs * fenvs[None, None, :] + Cs * sh)
-                    nconf = np.where(base < 0, 0.0, A_s * (np.maximum(base, 0) / M1c) ** alpha_EE) * ic
-                    w = hmf[:, :, :, el]
-                    ngal_cent += np.sum(w * ncent)
-                    ngal_sat += np.sum(w * (nsat * (1 - ncent) + nconf * ncent))
-            else:
-                continue
+        for etracer in known:
+            t = TRACERS.index(etracer)
+            ngal_cent, ngal_sat = out[t], out[3 + t]
             ngal_dict[etracer] = ngal_cent + ngal_sat
             fsat_dict[etracer] = ngal_sat / (ngal_cent + ngal_sat)
         return ngal_dict, fsat_dict

@@ -122,6 +122,15 @@ int abacus_hod_set_sigma3d(abacus_hod_state *st, const double *hsigma3d, int on_
 int abacus_hod_reseed(abacus_hod_state *st, uint64_t seed, int want_expvel, int64_t halo_index0, int64_t part_index0);
 int abacus_hod_fetch_field(abacus_hod_state *st, const char *field, double *host);
 
+/* `AbacusHOD.compute_ngal` (hod/abacus_hod.py:861-1179): expected numbers of centrals and satellites per tracer from the
+ * weighted halo histogram.  The reference's sum over the 100^3 / 100^4 histogram cells is evaluated as the identical
+ * sum over halos, sum_i multis[i] * n(centre of the cell of halo i).  bins4[i] = {logM, deltac, fenv, shear} cell of
+ * halo i under np.histogramdd's edge rule (255 = outside: dropped, as histogramdd drops it); centres = [4][nbin]:
+ * 10**logM centres, then the deltac, fenv and shear centres.  out = Ncent[3], Nsat[3] (LRG, ELG, QSO); `p` is the
+ * marshalled parameter struct (z-evolution applied). */
+int abacus_hod_set_ngal_bins(abacus_hod_state *st, const uint8_t *bins4, const double *centres, int nbin);
+int abacus_hod_ngal(abacus_hod_state *st, const abacus_hod_params *p, double out[6]);
+
 /* NFW satellites: `gen_gal_cat(..., nfw=True, NFW_draw=...)` (gen_sats_nfw, compute_fast_NFW, getPointsOnSphere,
  * hod/GRAND_HOD.py:417-822).  Centrals are decided exactly as on the particle path; satellites are Poisson(n_sat(M) ic)
  * per halo and tracer, placed isotropically at r = NFW_draw[k] / c * Rvir (k random with NFW_draw[k] <= c) around

@@ -463,3 +463,66 @@ def nfw_expected_counts(halo_data, tracers, params, keep_cent):
         lc = p.Q_logM_cut + p.Q_Acent * dc + p.Q_Bcent * fe
         out['QSO'] = n_sat_generic(m, 10 ** lc, p.Q_kappa, M1, p.Q_alpha) * p.Q_ic
     return out
+
+
+def compute_ngal_numpy(ball, tracers=None):
+    """AbacusHOD.compute_ngal (hod/abacus_hod.py:861-1179) restated in NumPy: the reference's triple / quadruple sums over
+    the weighted halo histograms `ball.halo_mass_func` (100^3) and `ball.halo_mass_func_wshear` (100^4), cell centres
+    as abscissae.  `ball`: any object with logMbins, deltacbins, fenvbins, shearbins, z_mock and the two histograms."""
+    import math
+    if tracers is None:
+        tracers = ball.tracers
+    ngal_dict, fsat_dict = {}, {}
+    erfc = np.vectorize(math.erfc)
+    erf = np.vectorize(math.erf)
+    logMs = 0.5 * (ball.logMbins[1:] + ball.logMbins[:-1])
+    deltacs = 0.5 * (ball.deltacbins[1:] + ball.deltacbins[:-1])
+    fenvs = 0.5 * (ball.fenvbins[1:] + ball.fenvbins[:-1])
+    shears = 0.5 * (ball.shearbins[1:] + ball.shearbins[:-1])
+    for etracer, hod in tracers.items():
+        Delta_a = 1.0 / (1 + ball.z_mock) - 1.0 / (1 + hod.get('z_pivot', ball.z_mock))
+        logM_cut = hod['logM_cut'] + hod.get('logM_cut_pr', 0) * Delta_a
+        logM1 = hod['logM1'] + hod.get('logM1_pr', 0) * Delta_a
+        Ac, As, Bc, Bs = (hod.get(k, 0) for k in ('Acent', 'Asat', 'Bcent', 'Bsat'))
+        ic = hod.get('ic', 1)
+        Mh = (10 ** logMs)[:, None, None]
+        lc = logM_cut + Ac * deltacs[None, :, None] + Bc * fenvs[None, None, :]
+        M1 = 10 ** (logM1 + As * deltacs[None, :, None] + Bs * fenvs[None, None, :])
+        if etracer == 'LRG':
+            ncent = 0.5 * erfc((lc - np.log10(Mh)) / (1.41421356 * hod['sigma']))
+            base = Mh - hod['kappa'] * 10**lc
+            nsat = np.where(base < 0, 0.0, (np.maximum(base, 0) / M1) ** hod['alpha'] * ncent)
+            ngal_cent = np.sum(ball.halo_mass_func * ncent * ic)
+            ngal_sat = np.sum(ball.halo_mass_func * nsat * ic)
+        elif etracer == 'QSO':
+            ncent = 0.5 * (1 + erf((np.log10(Mh) - lc) / 1.41421356 / hod['sigma']))
+            base = Mh - hod['kappa'] * 10**lc
+            nsat = np.where(base < 0, 0.0, (np.maximum(base, 0) / M1) ** hod['alpha'])
+            ngal_cent = np.sum(ball.halo_mass_func * ncent * ic)
+            ngal_sat = np.sum(ball.halo_mass_func * nsat * ic)
+        elif etracer == 'ELG':
+            Cc, Cs = hod.get('Ccent', 0), hod.get('Csat', 0)
+            A_s = hod.get('A_s', 1)
+            logM1_EE, alpha_EE = hod.get('logM1_EE', hod['logM1']), hod.get('alpha_EE', hod['alpha'])
+            ngal_cent = ngal_sat = 0.0
+            hmf = ball.halo_mass_func_wshear
+            logMh = np.log10(Mh)
+            for el, sh in enumerate(shears):  # one shear slice at a time keeps the temporaries at 100^3
+                lce = lc + Cc * sh
+                M1e = 10 ** (logM1 + As * deltacs[None, :, None] + Bs * fenvs[None, None, :] + Cs * sh)
+                phi = 0.3989422804014327 / hod['sigma'] * np.exp(-((logMh - lce) ** 2) / 2 / hod['sigma'] ** 2)
+                Phi = 0.5 * (1 + erf(hod['gamma'] * (logMh - lce) / hod['sigma'] / np.sqrt(2)))
+                ncent = 2.0 * (hod['p_max'] - 1.0 / hod['Q']) * phi * Phi * ic
+                base = Mh - hod['kappa'] * 10**lce
+                nsat = np.where(base < 0, 0.0, A_s * (np.maximum(base, 0) / M1e) ** hod['alpha']) * ic
+                M1c = 10 ** (logM1_EE + As * deltacs[None, :, None] + Bs * fenvs[None, None, :] + Cs * sh)
+                nconf = np.where(base < 0, 0.0, A_s * (np.maximum(base, 0) / M1c) ** alpha_EE) * ic
+                w = hmf[:, :, :, el]
+                ngal_cent += np.sum(w * ncent)
+                ngal_sat += np.sum(w * (nsat * (1 - ncent) + nconf * ncent))
+        else:
+            continue
+        ngal_dict[etracer] = ngal_cent + ngal_sat
+        fsat_dict[etracer] = ngal_sat / (ngal_cent + ngal_sat)
+    return ngal_dict, fsat_dict
+
