@@ -224,7 +224,8 @@ class SlabComm:
         cnt = torch.from_numpy(raw[: n_u64 * 8].view(np.int64).copy())
         val = torch.from_numpy(raw[n_u64 * 8:].view(np.float64).copy())
         self.dist.all_reduce(cnt, group=self.group)
-        self.dist.all_reduce(val, group=self.group)
+        if val.numel():
+            self.dist.all_reduce(val, group=self.group)
         out = np.empty_like(raw)
         out[: n_u64 * 8] = cnt.numpy().view(np.uint8)
         out[n_u64 * 8:] = val.numpy().view(np.uint8)
