@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--workload', default='hod', choices=['hod', 'pk'])
     ap.add_argument('--nhalo', type=int, default=10_000_000)
     ap.add_argument('--npart', type=int, default=10_000_000)
-    ap.add_argument('--nmesh', type=int, default=1024)
+    ap.add_argument('--nmesh', type=int, default=2048)
     ap.add_argument('--npk', type=int, default=100_000_000, help='particles for the P(k) workload')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-pk', action='store_true', help='skip the secondary P(k) measurement')
