@@ -26,7 +26,8 @@ def pmc_traffic(workload, kernel):
         except (OSError, ValueError):
             continue
         for k, e in tab.items():
-            if k.split('<')[0] == kernel:
+            base = k.split('<')[0]
+            if kernel == base or kernel.startswith(base + '_'):
                 return e['hbm_bytes_per_launch']
     return None
 
