@@ -27,7 +27,7 @@ def pmc_traffic(workload, kernel):
             continue
         for k, e in tab.items():
             base = k.split('<')[0]
-            if kernel == base or kernel.startswith(base + '_'):
+            if kernel == base or kernel.startswith(base + '_') or base.startswith(kernel + '_'):
                 return e['hbm_bytes_per_launch']
     return None
 
