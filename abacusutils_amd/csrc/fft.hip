@@ -171,7 +171,13 @@ constexpr int colpitch_of() { return N + (N >> PADSHIFT) + 1; }   // odd: adjace
 // "loads of t+1, then stores of t": the compiler then waits with a counted vmcnt that leaves the stores in flight
 // (with the staging at the top of the loop the prologue path merges in and every wait degenerates to "all stores
 // done", which exposes the full store latency once per tile).
-template <int N, int B>
+// FUSE (B = 4, full n^3 mesh): a tile is the four rows (x, y), (x, y+n/2), (x+n/2, y), (x+n/2, y+n/2); after their z
+// transforms the first radix-2 DIF stage of the y AND of the x transform is applied across them on the way out
+// (a = u + v, b = (u - v) W^y, likewise along x).  The y and x passes are then two independent n/2-point column
+// transforms each, over rows [0, n/2) and [n/2, n): half the rows per LDS tile, twice the columns - 128-B row
+// segments at n = 2048, which the memory system serves at the in-place floor instead of 3.4 TB/s.
+// Row r of either half then holds frequency 2 (r mod n/2) + (r div n/2) along that axis.
+template <int N, int B, bool FUSE>
 __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
                                                          const float2 *__restrict__ twN, const float2 *__restrict__ tw2N,
                                                          int dbg) {
@@ -184,17 +190,24 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
     const int tid = threadIdx.x;
     for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
     for (int q = tid; q <= N; q += FFT_THREADS) tw2[q] = tw2N[q];
-    const int64_t ntiles = (nrows + B - 1) / B;
+    static_assert(!FUSE || B == 4, "the fused first stages work on 2 x 2 rows");
+    constexpr int NF = 2 * N;                               // mesh size n
+    const int64_t ntiles = FUSE ? (int64_t)N * N : (nrows + B - 1) / B;
+    // first row of a tile, and the row of its r-th member
+    auto row_of = [&](int64_t tile, int r) -> int64_t {
+        if (!FUSE) return tile * B + r;
+        const int64_t x = tile / N, y = tile % N;
+        return (x + (r >> 1) * N) * NF + y + (r & 1) * N;
+    };
     const int pitch_c = pitch_r / 2;
     v4f regs[NLD];
     auto prefetch = [&](int64_t tile) {
-        const int64_t row0 = tile * B;
-        const int nb = (int)min((int64_t)B, nrows - row0);
+        const int nb = FUSE ? B : (int)min((int64_t)B, nrows - tile * B);
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int e = q * FFT_THREADS + tid;
             const int r = min(e / (N / 2), nb - 1), m = (e % (N / 2)) * 2;   // rows past the end re-read the last row
-            gload16_async(regs[q], mesh + (row0 + r) * pitch_r + 2 * m);
+            gload16_async(regs[q], mesh + row_of(tile, r) * pitch_r + 2 * m);
         }
     };
     auto stage = [&]() {   // registers -> LDS: two complex (= four consecutive reals) per 16-B load
@@ -217,19 +230,19 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
     wait_vmcnt<0>();
     stage();
     // stores every thread issues per full tile (threads with one more only wait longer): vmcnt(that) = loads landed
-    const int stores_min = (B * (pitch_c / 2)) / FFT_THREADS;
+    const int stores_min = FUSE ? 4 * ((pitch_c / 2) / FFT_THREADS) : (B * (pitch_c / 2)) / FFT_THREADS;
     for (;;) {
         __syncthreads();
         const int64_t next = tile + gridDim.x;
         const bool has_next = next < ntiles;
         if (has_next) prefetch(next);   // in flight during the transform and the write-back below
         const int64_t row0 = tile * B;
-        const int nb = (int)min((int64_t)B, nrows - row0);
+        const int nb = FUSE ? B : (int)min((int64_t)B, nrows - row0);
         if (!(dbg & 1)) Passes<N, N>::run(lds, CP, nb, tw);
         // even/odd split: X_k = E + (-i W_2N^k) O with E = (Z_k + conj Z_{N-k})/2, O = (Z_k - conj Z_{N-k})/2, k = 0..N.
         // A thread forms two adjacent outputs (one 16-B store); the row is written over its whole pitch (zeros behind
         // k = N) so that no partial 128-B line is ever written.
-        if (!(dbg & 2))
+        if (!(dbg & 2) && !FUSE)
             for (int e = tid; e < nb * (pitch_c / 2); e += FFT_THREADS) {
                 const int r = e / (pitch_c / 2), k0 = (e % (pitch_c / 2)) * 2;
                 const float2 *c = lds + r * CP;
@@ -251,6 +264,47 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
                 *reinterpret_cast<float4 *>(mesh + (row0 + r) * pitch_r + 2 * k0) =
                     make_float4(X[0].x, X[0].y, X[1].x, X[1].y);
             }
+        if (!(dbg & 2) && FUSE) {
+            const int x = (int)(tile / N), y = (int)(tile % N);
+            float sy, cy, sx, cx;
+            sincospif((float)y / (float)N, &sy, &cy);        // W_n^y = exp(-2 pi i y / n), n = 2N
+            sincospif((float)x / (float)N, &sx, &cx);
+            const float2 Wy = make_float2(cy, -sy), Wx = make_float2(cx, -sx);
+            for (int k2 = tid; k2 < pitch_c / 2; k2 += FFT_THREADS) {
+                const int k0 = k2 * 2;
+                float2 X[4][2];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float2 *c = lds + r * CP;
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int k = k0 + u;
+                        X[r][u] = make_float2(0.f, 0.f);
+                        if (k <= N) {
+                            const float2 zk = c[padq(revpos<N>(k & (N - 1)))];
+                            const float2 zn = c[padq(revpos<N>((N - k) & (N - 1)))];
+                            const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+                            const float2 O = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
+                            const float2 w = tw2[k];
+                            X[r][u] = cadd(E, cmul(make_float2(w.y, -w.x), O));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {   // rows: 0 = (x, y), 1 = (x, y+H), 2 = (x+H, y), 3 = (x+H, y+H)
+                    const float2 A = cadd(X[0][u], X[1][u]), Bv = cmul(csub(X[0][u], X[1][u]), Wy);
+                    const float2 Cv = cadd(X[2][u], X[3][u]), D = cmul(csub(X[2][u], X[3][u]), Wy);
+                    X[0][u] = cadd(A, Cv);
+                    X[2][u] = cmul(csub(A, Cv), Wx);
+                    X[1][u] = cadd(Bv, D);
+                    X[3][u] = cmul(csub(Bv, D), Wx);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    *reinterpret_cast<float4 *>(mesh + row_of(tile, r) * pitch_r + 2 * k0) =
+                        make_float4(X[r][0].x, X[r][0].y, X[r][1].x, X[r][1].y);
+            }
+        }
         if (!has_next) break;
         __syncthreads();   // every LDS read of this tile is done
         wait_vmcnt_upto8((dbg & 2) || nb < B ? 0 : stores_min);
@@ -264,8 +318,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
 // Persistent workgroups with the next tile prefetched into registers, as above.
 template <int N, int C>
 __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ data, int64_t S, int ntile_c,
-                                                        int64_t ntiles, int64_t outer_stride,
-                                                        const float2 *__restrict__ twN, int dbg) {
+                                                        int64_t ntiles, int64_t outer_stride, int64_t outer_mod,
+                                                        int64_t outer_stride2, const float2 *__restrict__ twN, int dbg) {
     constexpr int CP = colpitch_of<N>();
     constexpr int NLD = (N * (C / 2) + FFT_THREADS - 1) / FFT_THREADS;
     constexpr bool WHOLE = (N * (C / 2)) % FFT_THREADS == 0;
@@ -275,7 +329,11 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
     const int tid = threadIdx.x;
     for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
     v4f regs[NLD];
-    auto tile_base = [&](int64_t t) { return data + (t / ntile_c) * outer_stride + (t % ntile_c) * C; };
+    // outer index o = t / ntile_c -> (o % outer_mod) * outer_stride + (o / outer_mod) * outer_stride2
+    auto tile_base = [&](int64_t t) {
+        const int64_t o = t / ntile_c;
+        return data + (o % outer_mod) * outer_stride + (o / outer_mod) * outer_stride2 + (t % ntile_c) * C;
+    };
     auto prefetch = [&](int64_t t) {
         const float2 *g = tile_base(t);
         // lanes walk the C columns of one row first (C*8 B contiguous), two columns per 16-B load
@@ -372,22 +430,23 @@ int get_tables(int n, Tables **out) {
     return 0;
 }
 
-template <int N, int B>
+template <int N, int B, bool FUSE = false>
 int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
     const size_t lds = (size_t)(2 * N + 2 + B * colpitch_of<N>()) * sizeof(float2);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_z_r2c<N, B>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_z_r2c<N, B, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    const int64_t ntiles = ceil_div(nrows, B);
+    const int64_t ntiles = FUSE ? (int64_t)N * N : ceil_div(nrows, B);
     int per_cu = 1;   // persistent grid = exactly the resident workgroups (a larger grid would run in two uneven waves)
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_z_r2c<N, B>, FFT_THREADS, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_z_r2c<N, B, FUSE>, FFT_THREADS, lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
-    ABACUS_LAUNCH("fft_z_r2c", (fft_z_r2c<N, B>), dim3(grid), dim3(FFT_THREADS), lds, mesh, nrows,
+    ABACUS_LAUNCH("fft_z_r2c", (fft_z_r2c<N, B, FUSE>), dim3(grid), dim3(FFT_THREADS), lds, mesh, nrows,
                   pitch_r, t->twHalf.as<float2>(), t->tw2.as<float2>(), getenv("ABACUS_DBG_FFT") ? atoi(getenv("ABACUS_DBG_FFT")) : 0);
     return 0;
 }
 
 template <int N, int C>
-int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t outer, int64_t outer_stride, Tables *t) {
+int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t outer, int64_t outer_stride, const float2 *tw,
+                int64_t outer_mod = (int64_t)1 << 40, int64_t outer_stride2 = 0) {
     const size_t lds = (size_t)(N + C * colpitch_of<N>()) * sizeof(float2);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
@@ -396,7 +455,7 @@ int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t 
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_cols<N, C>, FFT_THREADS, lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
     ABACUS_LAUNCH(name, (fft_cols<N, C>), dim3(grid), dim3(FFT_THREADS), lds, data, S, ntile_c, ntiles,
-                  outer_stride, t->twN.as<float2>(), getenv("ABACUS_DBG_FFT") ? atoi(getenv("ABACUS_DBG_FFT")) : 0);
+                  outer_stride, outer_mod, outer_stride2, tw, getenv("ABACUS_DBG_FFT") ? atoi(getenv("ABACUS_DBG_FFT")) : 0);
     return 0;
 }
 
@@ -409,7 +468,7 @@ int fft3d(float *mesh, int pitch_r, Tables *t, int64_t nx_local) {
     // y: for every x-plane, columns along y (element stride pitch_c)
     const int ntile_c = (kzlen + C - 1) / C;   // the last tile reads into the row padding (pitch_c >= ntile_c*C)
     if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
-    return launch_cols<N, C>("fft_cols_y", data, pitch_c, ntile_c, nx_local, (int64_t)N * pitch_c, t);
+    return launch_cols<N, C>("fft_cols_y", data, pitch_c, ntile_c, nx_local, (int64_t)N * pitch_c, t->twN.as<float2>());
 }
 
 template <int N, int C>
@@ -417,7 +476,7 @@ int fft_x(float2 *data, int pitch_c, Tables *t, int64_t ny_local, int64_t x_stri
     // x: for every y, columns along x (element stride x_stride)
     const int ntile_c = (N / 2 + 1 + C - 1) / C;
     if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
-    return launch_cols<N, C>("fft_cols_x", data, x_stride, ntile_c, ny_local, y_stride, t);
+    return launch_cols<N, C>("fft_cols_x", data, x_stride, ntile_c, ny_local, y_stride, t->twN.as<float2>());
 }
 
 }  // namespace
@@ -461,6 +520,40 @@ int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_st
 int fft_native_r2c_inplace(float *mesh, int n, int pitch_r) {
     ABACUS_TRY(fft_native_zy(mesh, n, pitch_r, n));
     return fft_native_x(mesh, n, pitch_r, n, (int64_t)n * (pitch_r / 2), pitch_r / 2);
+}
+
+// Full-mesh transform with the first radix-2 stage of y and x fused into the z pass (see fft_z_r2c<.., FUSE>): the y and
+// x passes are n/2-point column transforms with C columns.  Output rows are in the permuted order
+// f = 2 (r mod n/2) + (r div n/2) along x and y (power.hip's binning undoes it in its index arithmetic).
+template <int N, int C>
+int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th) {
+    constexpr int H = N / 2;
+    const int pitch_c = pitch_r / 2, kzlen = N / 2 + 1;
+    const int ntile_c = (kzlen + C - 1) / C;
+    if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
+    ABACUS_TRY((launch_z<N / 2, 4, true>(mesh, (int64_t)N * N, pitch_r, t)));
+    float2 *data = reinterpret_cast<float2 *>(mesh);
+    // y: 2 N half-planes of H rows each, contiguous in memory
+    ABACUS_TRY((launch_cols<H, C>("fft_cols_y", data, pitch_c, ntile_c, 2 * (int64_t)N, (int64_t)H * pitch_c,
+                                  th->twN.as<float2>())));
+    // x: for every y and either half of x, H planes apart by N * pitch_c
+    const int64_t S = (int64_t)N * pitch_c;
+    return launch_cols<H, C>("fft_cols_x", data, S, ntile_c, 2 * (int64_t)N, pitch_c, th->twN.as<float2>(), N, (int64_t)H * S);
+}
+
+// n = 256 only on request (tests against the CPU oracle): small meshes gain nothing from the fused form
+int fft_native_fused_supported(int n) { return n == 2048 || n == 1024 || (n == 256 && getenv("ABACUS_FFT_FUSE_SMALL")); }
+
+int fft_native_r2c_fused(float *mesh, int n, int pitch_r) {
+    Tables *t, *th;
+    ABACUS_TRY(get_tables(n, &t));
+    ABACUS_TRY(get_tables(n / 2, &th));
+    switch (n) {
+        case 256: return fft3d_fused<256, 16>(mesh, pitch_r, t, th);
+        case 1024: return fft3d_fused<1024, 16>(mesh, pitch_r, t, th);
+        case 2048: return fft3d_fused<2048, 16>(mesh, pitch_r, t, th);
+    }
+    return fail("fft: the fused transform supports n = 1024 and 2048");
 }
 
 int fft_native_release() {

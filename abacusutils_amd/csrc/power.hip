@@ -46,6 +46,8 @@ int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_st
 int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
                          int64_t zstride, double box, double offset, int wrap, double norm, int cic);
 int fft_native_release();
+int fft_native_fused_supported(int n);
+int fft_native_r2c_fused(float *mesh, int n, int pitch_r);   // rows come out in the permuted order of fft.hip's fused form
 }  // namespace abacus
 
 namespace {
@@ -56,6 +58,8 @@ constexpr int BIN_THREADS = 1024;
 struct SpecArgs {
     int n, kzlen, pitch;      // pitch: complex elements per (kx, ky) row in memory (>= kzlen)
     int rowmode, y0;          // 0: row = kx*n + ky (full spectrum); 1: row = ky_local*n + kx, ky = y0 + ky_local (y-slab)
+    int permshift;            // > 0: rows are in the order of the fused transform: index r of x and y holds frequency
+                              // 2 (r mod n/2) + (r div n/2); permshift = log2(n/2)
     int64_t nrows;            // rows held in memory (n*n, or ny_local*n for a y-slab)
     int mode;                 // 0: raw fields (deltak API), 1: FFT output needing scale/interlace/compensation
     int interlaced, compensated, cross;
@@ -70,6 +74,11 @@ __device__ __forceinline__ int fold(int i, int n) { return i < n / 2 ? i : i - n
 __device__ __forceinline__ void row_ij(const SpecArgs &s, int64_t row, int &i, int &j) {
     if (s.rowmode == 0) {
         j = (int)(row % s.n), i = (int)(row / s.n);
+        if (s.permshift) {
+            const int hm = (1 << s.permshift) - 1;
+            i = ((i & hm) << 1) | (i >> s.permshift);
+            j = ((j & hm) << 1) | (j >> s.permshift);
+        }
     } else {
         i = (int)(row % s.n), j = s.y0 + (int)(row / s.n);
     }
@@ -488,7 +497,14 @@ int ensure_phase(int n) {
 }
 
 // deposit + FFT of one particle set into mesh slots [slot] (and [slot+1] when interlaced); device particle arrays
-int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, int paste, int interlaced, int slot) {
+// `fused`: use fft.hip's fused form (permuted row order; the caller sets SpecArgs::permshift)
+bool use_fused_fft(int nmesh) {
+    return fft_native_supported(nmesh) && !getenv("ABACUS_FFT_HIPFFT") && !getenv("ABACUS_FFT_NOFUSE") &&
+           fft_native_fused_supported(nmesh);
+}
+
+int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, int paste, int interlaced, int slot,
+                  bool fused = false) {
     if (n <= 0) return fail("power: empty particle set");
     const bool native = fft_native_supported(nmesh) && !getenv("ABACUS_FFT_HIPFFT");
     hipfftHandle plan = 0;
@@ -502,7 +518,9 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
         float *mesh = g_ctx.mesh[slot + s].as<float>();
         // tsc_parallel wraps pos in place on the first call (tsc.py:171-173); the shifted deposit sees wrapped pos
         ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste));
-        if (native) {
+        if (native && fused) {
+            ABACUS_TRY(fft_native_r2c_fused(mesh, nmesh, (int)zstride));
+        } else if (native) {
             ABACUS_TRY(fft_native_r2c_inplace(mesh, nmesh, (int)zstride));   // fft.hip: three passes, one per axis
         } else {
             prof_begin("hipfft_r2c");
@@ -520,6 +538,7 @@ void fill_spec(SpecArgs &s, int nmesh, int mode, int interlaced, const float *W_
     s.pitch = mode == 1 ? pitch_r(nmesh) / 2 : nmesh / 2 + 1;   // caller-supplied spectra (mode 0) are contiguous
     s.rowmode = 0;
     s.y0 = 0;
+    s.permshift = 0;
     s.nrows = (int64_t)nmesh * nmesh;
     s.mode = mode;
     s.interlaced = interlaced;
@@ -687,11 +706,16 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
     ABACUS_TRY(ensure_phase(nmesh));
     const float *W_dev;
     ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
-    ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0));
+    const bool fused = use_fused_fft(nmesh);
+    ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, fused));
     const bool cross = pos2 != nullptr;
-    if (cross) ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, interlaced, 2));
+    if (cross) ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, interlaced, 2, fused));
     SpecArgs s;
     fill_spec(s, nmesh, 1, interlaced, W_dev, cross);
+    if (fused) {
+        s.permshift = 0;
+        while ((2 << s.permshift) < nmesh) s.permshift++;   // log2(nmesh / 2)
+    }
     s.a = g_ctx.mesh[0].as<float2>();
     s.as = interlaced ? g_ctx.mesh[1].as<float2>() : nullptr;
     s.b = cross ? g_ctx.mesh[2].as<float2>() : nullptr;

@@ -162,3 +162,33 @@ def test_native_fft_sizes(nmesh):
     tab = calc_power(pos.copy(), box, **kw)
     ref = oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw)
     _check_oracle(tab, ref)
+
+
+def test_fused_fft_against_oracle(monkeypatch):
+    """fft.hip's fused form (first radix-2 stage of y and x inside the z pass, permuted row order undone by the binning)
+    on a 256^3 mesh against the CPU oracle: auto and cross spectra, interlaced + compensated, multipoles"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    monkeypatch.setenv('ABACUS_FFT_FUSE_SMALL', '1')
+    n, box = 600_000, 1000.0
+    pos = synth.synth_positions(n, box, seed=79, clustered=True)
+    pos2 = synth.synth_positions(n // 2, box, seed=80, clustered=True)
+    for extra in (dict(), dict(pos2=pos2.copy())):
+        kw = dict(kbins=40, mubins=4, paste='TSC', nmesh=256, compensated=True, interlaced=True, poles=[0, 2, 4], **extra)
+        tab = calc_power(pos.copy(), box, **kw)
+        ref = oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw)
+        _check_oracle(tab, ref)
+
+
+@pytest.mark.parametrize('nmesh', [1024])
+def test_fused_fft_matches_three_pass(monkeypatch, nmesh):
+    """production sizes of the fused form against the plain three-pass transform on the same particles"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    pos = synth.synth_positions(3_000_000, 1000.0, seed=81, clustered=True)
+    kw = dict(kbins=64, mubins=4, paste='TSC', nmesh=nmesh, compensated=False, interlaced=True, poles=[0, 2, 4])
+    a = calc_power(pos.copy(), 1000.0, **kw)
+    monkeypatch.setenv('ABACUS_FFT_NOFUSE', '1')
+    b = calc_power(pos.copy(), 1000.0, **kw)
+    np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
+    np.testing.assert_allclose(a['power'], b['power'], rtol=2e-5, atol=1e-6 * np.abs(b['power']).max())
+    np.testing.assert_allclose(a['poles'], b['poles'], rtol=2e-5, atol=1e-6 * np.abs(b['power']).max())
