@@ -140,7 +140,11 @@ def finalize_raw(raw, Lbox, Nk, Nmu, poles):
 class SlabComm:
     """ring send/recv, all-to-all and all-reduce over torch.distributed (or trivially for a single rank)"""
 
-    def __init__(self, device_collectives=False, group=None):
+    def __init__(self, device_collectives=False, group=None, force_collectives=False):
+        """device_collectives: mesh-sized exchanges run on device tensors (RCCL; the process group must be `nccl`) instead
+        of being staged through the host.  Small host-side messages (histograms, counts, particle routing) always go
+        through a gloo group, created here when the default backend cannot move CPU tensors.
+        force_collectives: run the collectives even with a single rank (tests of the transport on one GPU)."""
         self.dist = None
         self.rank, self.world = 0, 1
         try:
@@ -151,7 +155,11 @@ class SlabComm:
         except ImportError:
             pass
         self.group = group
-        self.device = bool(device_collectives) and self.world > 1
+        self.hgroup = group
+        self.collective = self.dist is not None and (self.world > 1 or bool(force_collectives))
+        self.device = bool(device_collectives) and self.collective
+        if self.collective and self.dist.get_backend(group) != 'gloo':
+            self.hgroup = self.dist.new_group(backend='gloo')   # collective call: every rank constructs its SlabComm
 
     def _tensor(self, buf, off, n):
         import torch
@@ -163,8 +171,8 @@ class SlabComm:
     def ring_exchange(self, backend, buf, left_off, right_off, recv, n):
         """send buf[left_off:+n] to rank-1 and buf[right_off:+n] to rank+1;
         recv[0:n] <- what rank+1 sent left, recv[n:2n] <- what rank-1 sent right"""
-        if self.world == 1:   # the ring neighbour is this rank (periodic box): callers add the ghosts in place
-            raise RuntimeError('ring_exchange needs more than one rank')
+        if not self.collective:   # the ring neighbour is this rank (periodic box): callers add the ghosts in place
+            raise RuntimeError('ring_exchange needs an initialised process group')
         import torch
         backend.sync()
         left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
@@ -175,11 +183,16 @@ class SlabComm:
         else:
             r_from_right = torch.empty(n, dtype=torch.float32)
             r_from_left = torch.empty(n, dtype=torch.float32)
-        ops = [self.dist.P2POp(self.dist.isend, s_l, left, self.group), self.dist.P2POp(self.dist.isend, s_r, right, self.group),
-               self.dist.P2POp(self.dist.irecv, r_from_right, right, self.group),
-               self.dist.P2POp(self.dist.irecv, r_from_left, left, self.group)]
-        for req in self.dist.batch_isend_irecv(ops):
-            req.wait()
+        if left == self.rank:   # one rank: its own ghosts come back (no transport can send to itself portably)
+            r_from_right.copy_(s_l)
+            r_from_left.copy_(s_r)
+        else:
+            ops = [self.dist.P2POp(self.dist.isend, s_l, left, self.group),
+                   self.dist.P2POp(self.dist.isend, s_r, right, self.group),
+                   self.dist.P2POp(self.dist.irecv, r_from_right, right, self.group),
+                   self.dist.P2POp(self.dist.irecv, r_from_left, left, self.group)]
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
         if self.device:
             torch.cuda.synchronize()
         else:
@@ -187,8 +200,8 @@ class SlabComm:
             recv.set(n, r_from_left.numpy())
 
     def all_to_all(self, backend, send, recv, n_total):
-        if self.world == 1:   # callers unpack straight from the send buffer
-            raise RuntimeError('all_to_all needs more than one rank')
+        if not self.collective:   # callers unpack straight from the send buffer
+            raise RuntimeError('all_to_all needs an initialised process group')
         import torch
         backend.sync()
         s, _ = self._tensor(send, 0, n_total)
@@ -218,45 +231,45 @@ class SlabComm:
 
     def all_reduce_raw(self, raw, n_u64):
         """sum the raw histogram over ranks: first n_u64 entries are uint64 counts, the rest float64"""
-        if self.world == 1:
+        if not self.collective:
             return raw
         import torch
         cnt = torch.from_numpy(raw[: n_u64 * 8].view(np.int64).copy())
         val = torch.from_numpy(raw[n_u64 * 8:].view(np.float64).copy())
-        self.dist.all_reduce(cnt, group=self.group)
+        self.dist.all_reduce(cnt, group=self.hgroup)
         if val.numel():
-            self.dist.all_reduce(val, group=self.group)
+            self.dist.all_reduce(val, group=self.hgroup)
         out = np.empty_like(raw)
         out[: n_u64 * 8] = cnt.numpy().view(np.uint8)
         out[n_u64 * 8:] = val.numpy().view(np.uint8)
         return out
 
     def all_reduce_int(self, v):
-        if self.world == 1:
+        if not self.collective:
             return int(v)
         import torch
         t = torch.tensor([int(v)], dtype=torch.int64)
-        self.dist.all_reduce(t, group=self.group)
+        self.dist.all_reduce(t, group=self.hgroup)
         return int(t[0])
 
     def all_reduce_float(self, v):
-        if self.world == 1:
+        if not self.collective:
             return float(v)
         import torch
         t = torch.tensor([float(v)], dtype=torch.float64)
-        self.dist.all_reduce(t, group=self.group)
+        self.dist.all_reduce(t, group=self.hgroup)
         return float(t[0])
 
     def all_to_all_host(self, arrays):
         """variable-size host all-to-all of float32 arrays (particle routing): arrays[p] goes to rank p"""
-        if self.world == 1:
+        if not self.collective:
             return [arrays[0]]
         import torch
         sizes = torch.tensor([a.size for a in arrays], dtype=torch.int64)
         rsizes = torch.empty(self.world, dtype=torch.int64)
         reqs = []
         all_sizes = [torch.empty(self.world, dtype=torch.int64) for _ in range(self.world)]
-        self.dist.all_gather(all_sizes, sizes, group=self.group)
+        self.dist.all_gather(all_sizes, sizes, group=self.hgroup)
         for p in range(self.world):
             rsizes[p] = all_sizes[p][self.rank]
         outs = [np.empty(int(rsizes[p]), dtype=np.float32) for p in range(self.world)]
@@ -265,9 +278,9 @@ class SlabComm:
                 outs[p][:] = arrays[p].ravel()
             else:
                 if arrays[p].size:
-                    reqs.append(self.dist.isend(torch.from_numpy(np.ascontiguousarray(arrays[p].ravel())), p, group=self.group))
+                    reqs.append(self.dist.isend(torch.from_numpy(np.ascontiguousarray(arrays[p].ravel())), p, group=self.hgroup))
                 if outs[p].size:
-                    reqs.append(self.dist.irecv(torch.from_numpy(outs[p]), p, group=self.group))
+                    reqs.append(self.dist.irecv(torch.from_numpy(outs[p]), p, group=self.hgroup))
         for q in reqs:
             q.wait()
         return outs
@@ -333,7 +346,7 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         norm = float(np.float32(float(nmesh) ** 3 / float(ntot)))   # dtype(field.size / tot_weight) (:856,894)
         backend.deposit(particles, mesh, nmesh, (x0 - GHOST) % nmesh, nxl + 2 * GHOST, Lbox, offset, norm, code)
         # left ghost block -> left neighbour, right ghost block -> right neighbour
-        if W > 1:
+        if comm.collective:
             comm.ring_exchange(backend, mesh, 0, (GHOST + nxl) * plane, ghost, g)
             # ghost[0:g]  came from the right neighbour (its left ghosts)  = my last GHOST owned planes
             # ghost[g:2g] came from the left neighbour (its right ghosts)  = my first GHOST owned planes
@@ -345,9 +358,9 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         backend.axpy(mesh, GHOST * plane, None, 0, nxl * plane, -1.0)          # delta = rho*norm - 1 on the owned planes
         backend.fft_zy(mesh, GHOST * plane, nmesh, nxl)
         backend.pack(mesh, GHOST * plane, send, nmesh, nxl, W)
-        if W > 1:
+        if comm.collective:
             comm.all_to_all(backend, send, recv, nxl * plane)
-        backend.unpack(recv if W > 1 else send, mesh, GHOST * plane, nmesh, nxl, W)   # mesh now holds (y_local, x, k)
+        backend.unpack(recv if comm.collective else send, mesh, GHOST * plane, nmesh, nxl, W)   # mesh now holds (y_local, x, k)
         backend.fft_x(mesh, GHOST * plane, nmesh, nxl)
         return (mesh, GHOST * plane)
 

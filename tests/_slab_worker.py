@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--backend', default='numpy')
     ap.add_argument('--device-collectives', action='store_true')
+    ap.add_argument('--force-collectives', action='store_true')
     ap.add_argument('--nmesh', type=int, default=64)
     ap.add_argument('--n', type=int, default=20000)
     ap.add_argument('--interlaced', type=int, default=1)
@@ -25,13 +26,13 @@ def main():
     import torch  # noqa: F401  (before the HIP library: one HIP runtime per process)
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
+    if world > 1 or a.force_collectives:
         if a.device_collectives:
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
         dist.init_process_group('nccl' if a.device_collectives else 'gloo')
     from abacusutils_amd.analysis import slab_power as sp
     from abacusutils_amd.synth import synth_positions
-    comm = sp.SlabComm(device_collectives=a.device_collectives)
+    comm = sp.SlabComm(device_collectives=a.device_collectives, force_collectives=a.force_collectives)
     L = 500.0
     # every rank draws the same catalogue and keeps an arbitrary half: route_particles moves them to their slabs
     pos = synth_positions(a.n, L, seed=11)
@@ -52,7 +53,7 @@ def main():
         extra = dict(pos2=p2)
     t = sp.calc_power_slab(p1, L, comm=comm, backend=backend, w=w1, **kw, **extra)
     np.savez(f'{a.out}.rank{comm.rank}.npz', n_local=len(p1), **{k: np.asarray(t[k]) for k in t.keys()})
-    if world > 1:
+    if world > 1 or a.force_collectives:
         dist.barrier()
         dist.destroy_process_group()
 

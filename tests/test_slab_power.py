@@ -15,11 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 L = 500.0
 
 
-def run_ranks(tmp_path, world, backend, port, **kw):
+def run_ranks(tmp_path, world, backend, port, flags=(), **kw):
     out = str(tmp_path / f'slab_{backend}_{world}')
-    args = [f'--{k.replace("_", "-")}={v}' for k, v in kw.items()]
+    args = [f'--{k.replace("_", "-")}={v}' for k, v in kw.items()] + list(flags)
     worker = os.path.join(HERE, '_slab_worker.py')
-    if world == 1:
+    if world == 1 and not flags:
         cmd = [sys.executable, worker, '--backend', backend, '--out', out] + args
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
@@ -84,3 +84,16 @@ def test_slab_hip_matches_single_gpu_path(tmp_path):
     np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
     np.testing.assert_allclose(b['power'], a['power'], rtol=2e-5, atol=1e-6 * np.abs(a['power']).max())
     np.testing.assert_allclose(b['poles'], a['poles'], rtol=2e-5, atol=1e-6 * np.abs(a['power']).max())
+
+
+@pytest.mark.gpu
+def test_slab_hip_device_collectives_single_rank(tmp_path):
+    """the RCCL transport on one GPU: a one-rank `nccl` group with the collectives forced, so the zero-copy torch views
+    of the library's own allocations, the ring send/recv, all_to_all_single and the gloo side group all execute"""
+    res = run_ranks(tmp_path, 1, 'hip', 29641, flags=('--device-collectives', '--force-collectives'))
+    check(res, reference(), 1, 20000)
+
+
+def test_slab_forced_collectives_gloo_cpu(tmp_path):
+    res = run_ranks(tmp_path, 1, 'numpy', 29642, flags=('--force-collectives',))
+    check(res, reference(), 1, 20000)
