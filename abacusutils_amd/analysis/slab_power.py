@@ -73,13 +73,32 @@ class HipSlabBackend:
     def pitch(self, nmesh):
         return int(_lib.lib().abacus_slab_pitch(int(nmesh)))
 
+    def __init__(self, keep_buffers=False):
+        """keep_buffers: released work buffers are kept for the next call of the same shape (repeated spectra)"""
+        self.keep = bool(keep_buffers)
+        self._free = {}
+
     def new_buffer(self, nfloat):
-        return HipBuf(nfloat)
+        pool = self._free.get(int(nfloat))
+        return pool.pop() if pool else HipBuf(nfloat)
+
+    def release(self, buf):
+        if self.keep:
+            self._free.setdefault(buf.n, []).append(buf)
+        else:
+            buf.free()
+
+    def drop_buffers(self):
+        for pool in self._free.values():
+            for b in pool:
+                b.free()
+        self._free = {}
 
     def upload_particles(self, pos, w):
-        self._pos = _lib.DeviceArray(np.ascontiguousarray(pos, dtype=np.float32))
-        self._w = None if w is None else _lib.DeviceArray(np.ascontiguousarray(w, dtype=np.float32))
-        return self._pos, self._w
+        """host arrays are copied to HBM for this call; `_lib.DeviceArray`s (float32, resident) are used as they are"""
+        dpos = pos if isinstance(pos, _lib.DeviceArray) else _lib.DeviceArray(np.ascontiguousarray(pos, dtype=np.float32))
+        dw = w if (w is None or isinstance(w, _lib.DeviceArray)) else _lib.DeviceArray(np.ascontiguousarray(w, dtype=np.float32))
+        return dpos, dw
 
     def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste):
         pos, w = particles
@@ -140,7 +159,7 @@ def finalize_raw(raw, Lbox, Nk, Nmu, poles):
 class SlabComm:
     """ring send/recv, all-to-all and all-reduce over torch.distributed (or trivially for a single rank)"""
 
-    def __init__(self, device_collectives=False, group=None, force_collectives=False):
+    def __init__(self, device_collectives=False, group=None, force_collectives=False, host_group=None):
         """device_collectives: mesh-sized exchanges run on device tensors (RCCL; the process group must be `nccl`) instead
         of being staged through the host.  Small host-side messages (histograms, counts, particle routing) always go
         through a gloo group, created here when the default backend cannot move CPU tensors.
@@ -155,10 +174,10 @@ class SlabComm:
         except ImportError:
             pass
         self.group = group
-        self.hgroup = group
+        self.hgroup = host_group if host_group is not None else group
         self.collective = self.dist is not None and (self.world > 1 or bool(force_collectives))
         self.device = bool(device_collectives) and self.collective
-        if self.collective and self.dist.get_backend(group) != 'gloo':
+        if self.collective and host_group is None and self.dist.get_backend(group) != 'gloo':
             self.hgroup = self.dist.new_group(backend='gloo')   # collective call: every rank constructs its SlabComm
 
     def _tensor(self, buf, off, n):
@@ -368,7 +387,7 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     fields = []
     mi = 0
     for p_, w_, nt in sets:
-        ntot = nt if nt is not None else comm.all_reduce_int(len(p_))   # tot_weight = len(pos), also with weights (:1021)
+        ntot = nt if nt is not None else comm.all_reduce_int(p_.shape[0])   # tot_weight = len(pos), also with weights (:1021)
         particles = backend.upload_particles(p_, w_)
         fields.append(spectrum(particles, ntot, 0.0, meshes[mi]))
         mi += 1
@@ -383,7 +402,9 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     raw = comm.all_reduce_raw(raw, (len(ke) - 1) * (len(me) - 1))
     power, N_mode, bp, Nmp, k_avg = backend.finalize(raw, Lbox, len(ke) - 1, len(me) - 1, poles_arr)
     for b in meshes + [send, recv, ghost]:
-        if hasattr(b, 'free'):
+        if hasattr(backend, 'release'):
+            backend.release(b)
+        elif hasattr(b, 'free'):
             b.free()
     if squeeze_mu_axis and len(me) == 2:
         power, N_mode, k_avg = power[:, 0], N_mode[:, 0], k_avg[:, 0]

@@ -41,6 +41,8 @@ def parse():
     ap.add_argument('--npk', type=int, default=100_000_000, help='particles for the P(k) workload')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-pk', action='store_true', help='skip the secondary P(k) measurement')
+    ap.add_argument('--no-slab', action='store_true', help='N > 1: skip the slab-decomposed P(k) leg (RCCL all-to-all)')
+    ap.add_argument('--slab-timeout', type=float, default=240.0, help='seconds before the slab leg is abandoned')
     return ap.parse_args()
 
 
@@ -228,8 +230,30 @@ def main():
     else:
         from bench_pk import bench_pk
         out = bench_pk(args, dist, headline=True)
+    if dist.world > 1 and not args.no_slab and not args.no_pk:
+        # One nmesh^3 mesh decomposed over the N GPUs (BASELINE config 4): ghost exchange, all-to-all pencil transpose
+        # and histogram all-reduce over RCCL.  The headline above is complete at this point; a watchdog prints it and
+        # ends the process if this leg does not finish, so a stuck collective cannot take the bench line down.
+        import threading
+
+        def give_up():
+            if dist.rank == 0:
+                out['pk_slab'] = {'error': f'abandoned after {args.slab_timeout:.0f} s'}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        guard = threading.Timer(args.slab_timeout, give_up)
+        guard.daemon = True
+        guard.start()
+        try:
+            from bench_pk import bench_pk_slab
+            res = bench_pk_slab(args, dist)
+        except Exception as e:
+            res = {'error': repr(e)}
+        guard.cancel()
+        if dist.rank == 0:
+            out['pk_slab'] = res
     if dist.rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     dist.finish()
 
 

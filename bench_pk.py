@@ -153,3 +153,50 @@ def cpu_baseline_pk(L):
             'sample': f'nmesh {nmesh}, {n} particles (same particles per cell as the GPU workload), '
                       f'{min(ts) * 1e3:.0f} ms per calc_power, min of 2 after 1 warm-up',
             'ms': min(ts) * 1e3}
+
+
+def bench_pk_slab(args, dist):
+    """strong scaling of ONE nmesh^3 P(k) over the N GPUs: x-slab deposit with ghost planes, ring exchange, z/y passes,
+    all-to-all pencil transpose, x pass, y-slab binning, all-reduce (abacusutils_amd/analysis/slab_power.py).  Particles
+    (args.npk in total, uniform, generated inside each rank's slab) are resident in HBM; device collectives over RCCL."""
+    import torch
+    import torch.distributed as td
+
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis import slab_power as sp
+    nmesh, ntot = args.nmesh, args.npk
+    L = 2000.0
+    W, r = dist.world, dist.rank
+    ndev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dist.local_rank % ndev)
+    nccl = td.new_group(backend='nccl')
+    comm = sp.SlabComm(device_collectives=True, group=nccl, host_group=td.group.WORLD)
+    backend = sp.HipSlabBackend(keep_buffers=True)
+    n_local = ntot // W
+    rng = np.random.default_rng(300 + r)
+    pos = rng.random((n_local, 3), dtype=np.float32)
+    pos[:, 0] = (pos[:, 0] + np.float32(r)) * np.float32(L / W)
+    pos[:, 1:] *= np.float32(L)
+    np.minimum(pos[:, 0], np.nextafter(np.float32((r + 1) * L / W), np.float32(0)), out=pos[:, 0])
+    dpos = _lib.DeviceArray(pos)
+    kw = dict(kbins=min(512, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste='TSC', nmesh=nmesh,
+              compensated=False, interlaced=False, poles=[0, 2, 4], n_total=n_local * W)
+    steps = max(1, min(args.steps, 5))
+    tab = sp.calc_power_slab(dpos, L, comm=comm, backend=backend, **kw)   # warm-up: allocations, plans, RCCL channels
+    dist.barrier()
+    _lib.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tab = sp.calc_power_slab(dpos, L, comm=comm, backend=backend, **kw)
+    _lib.sync()
+    dist.barrier()
+    dt = dist.max(time.perf_counter() - t0) / steps
+    power = np.asarray(tab['power'])
+    shot = L**3 / (n_local * W)
+    backend.drop_buffers()
+    dpos.free()
+    return {'metric': f'wall-clock of one {nmesh}^3 TSC+FFT P(k) slab-decomposed over {W} GPUs', 'value': dt * 1e3,
+            'unit': 'ms', 'n_gpus': W, 'steps': steps, 'scaling': 'strong',
+            'config': {'workload': f'{n_local * W:.0e} uniform particles in x-slabs, nmesh {nmesh}, TSC, non-interlaced, '
+                                   'device collectives (RCCL all-to-all + ring send/recv + all-reduce)'},
+            'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot)}
