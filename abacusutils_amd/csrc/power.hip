@@ -152,7 +152,7 @@ __device__ __noinline__ int lower_bin(const float *edges, int N, float v) {
 // Registers hold the next tile of every field that is read (1, 2 or 4 fields): 16 per thread, 8 when all four are live.
 template <bool INTER, bool CROSS>
 struct BinCfg {
-    static constexpr int EPT = (INTER && CROSS) ? 8 : 16;
+    static constexpr int EPT = (INTER && CROSS) ? 4 : ((INTER || CROSS) ? 8 : 16);   // 2 or 4 fields in flight: shorter runs keep the prefetch in registers
     static constexpr int TILE_MODES = BIN_THREADS * EPT;
     static constexpr int LOADS = EPT / 2;                   // float4 loads per thread per field and tile
 };
@@ -278,70 +278,72 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
         if (!(b.dbg & 2)) tile_store<INTER, CROSS>(s, base, total, regs, tile);
         __syncthreads();
         if (t + gridDim.x < ntiles) tile_load<INTER, CROSS>(s, (t + gridDim.x) * BIN_TILE, total, regs);
-        // ---- bin: every thread walks EPT consecutive elements (a run may cross into the next row).  One pass, one
-        //      flush site: the target bin `tb` of each element is found first (-1 = not binned), a change of `tb`
-        //      flushes the register accumulators of the finished run into the LDS histogram ----
+        // ---- bin: every thread walks EPT consecutive elements: at most two row segments.  Along a row |k| and mu only
+        //      grow with kz, so a segment is located once (binary searches at its first binned mode) and the inner loop
+        //      only advances: bins change by `while` steps, a change of the target bin flushes the register accumulators
+        //      of the finished run into the LDS histogram (one flush site in the loop, one behind it) ----
         const int e0 = tid * BIN_EPT;
         const int64_t idx0 = base + e0;
         if (idx0 < total && !(b.dbg & 1)) {
             int64_t row = idx0 / pitch;
             int k = (int)(idx0 - row * pitch);
-            int r2 = 0;                               // i'^2 + j'^2 <= 2*(n/2)^2 < 2^30 for n <= 32767
-            {
-                int ii, jj;
-                row_ij(s, row, ii, jj);
-                ii = fold(ii, n), jj = fold(jj, n);
-                r2 = ii * ii + jj * jj;
-            }
-            int cur = -1, cur_bk = 0, bk = 0, bmu = 0;
-            bool located = false;                     // bk, bmu and the cached edges are valid for this row
-            float ke_hi = 0.f, me_lo = 0.f, me_hi = 0.f;
-            int cnt = 0;
+            int cur = -1, cur_bk = 0, cnt = 0;
             float sp = 0.f, sk = 0.f, spole[NPC];
 #pragma unroll
             for (int q = 0; q < NPC; q++) spole[q] = 0.f;
+            auto flush = [&]() {
+                if (cnt) {
+                    atomicAdd(&h_cnt[cur], (unsigned int)cnt);
+                    atomicAdd(&h_sum[cur], (double)sp);
+                    atomicAdd(&h_ksum[cur], (double)sk);
+#pragma unroll
+                    for (int q = 0; q < NPC; q++)
+                        if (q < np) atomicAdd(&h_pole[q * b.Nk + cur_bk], (double)spole[q]);
+                }
+                cnt = 0;
+                sp = sk = 0.f;
+#pragma unroll
+                for (int q = 0; q < NPC; q++) spole[q] = 0.f;
+            };
+            const float *trun = tile + tpad<BIN_EPT>(e0);   // the run is contiguous in the padded tile
+            int left = BIN_EPT, epos = 0;
 #pragma unroll 1
-            for (int e = 0; e <= BIN_EPT; e++, k++) {
-                int tb = -1;
-                float p = 0.f, mu2 = 0.f, kmag2 = 0.f;
-                if (e < BIN_EPT) {
-                    if (k == pitch) {                 // next (kx, ky) row
-                        k = 0;
-                        row++;
-                        int ii, jj;
-                        row_ij(s, row, ii, jj);
-                        ii = fold(ii, n), jj = fold(jj, n);
-                        r2 = ii * ii + jj * jj;
-                        located = false;
-                    }
-                    const int k2 = k * k;
-                    kmag2 = (float)(r2 + k2);         // dtype(i2 + j2 + k**2) (:239); exact integer below 2^24
-                    // `continue` below the first edge (:246), `break` from the last edge on (:249), padding, array end
-                    const bool inrange = k < kzlen && row < s.nrows && kmag2 >= klo && kmag2 < khi;
-                    if (inrange) {
+            while (left > 0 && row < s.nrows) {
+                const int seg = min(left, pitch - k);
+                int r2;                               // i'^2 + j'^2 <= 2*(n/2)^2 < 2^30 for n <= 32767
+                {
+                    int ii, jj;
+                    row_ij(s, row, ii, jj);
+                    ii = fold(ii, n), jj = fold(jj, n);
+                    r2 = ii * ii + jj * jj;
+                }
+                int ka = k;
+                const int kb = min(k + seg, kzlen);
+                while (ka < kb && (float)(r2 + ka * ka) < klo) ka++;   // `continue` below the first edge (:246)
+                if (ka < kb && (float)(r2 + ka * ka) < khi) {
+                    // locate the first binned mode of the segment exactly as the reference's running search would
+                    const float kmag2a = (float)(r2 + ka * ka);
+                    int bk = lower_bin(ke, b.Nk - 1, kmag2a);
+                    float ke_hi = ke[bk + 1];
+                    const float mu2a = kmag2a > 0.f ? (float)(ka * ka) * (1.0f / kmag2a) : 0.f;   // IEEE division
+                    int bmu = lower_bin(me, b.Nmu - 1, mu2a);
+                    float me_lo = me[bmu], me_hi = me[bmu + 1];
+#pragma unroll 1
+                    for (int kk = ka; kk < kb; kk++) {
+                        const int k2 = kk * kk;
+                        const float kmag2 = (float)(r2 + k2);   // dtype(i2 + j2 + k**2) (:239); exact integer below 2^24
+                        if (kmag2 >= khi) break;                // `break` from the last edge on (:249)
+                        while (kmag2 > ke_hi) {                 // (:252-253)
+                            bk++;
+                            ke_hi = ke[bk + 1];
+                        }
                         // mu^2 = f32(k^2) * (1/kmag2) (:240-244).  The hardware reciprocal (1 ulp) picks the bin unless
                         // mu^2 lands within a few ulp of an edge; only then the correctly rounded value is formed.
                         const float k2f = (float)k2;
-                        mu2 = kmag2 > 0.f ? k2f * __builtin_amdgcn_rcpf(kmag2) : 0.f;
-                        bool moved = !located;
-                        if (!located) {
-                            bk = lower_bin(ke, b.Nk - 1, kmag2);
-                            bmu = lower_bin(me, b.Nmu - 1, mu2);
-                            located = true;
-                        } else {
-                            while (kmag2 > ke_hi) {   // (:252-253)
-                                bk++;
-                                ke_hi = ke[bk + 1];
-                            }
-                            while (bmu + 1 < b.Nmu && mu2 > me_hi) {   // (:255-256)
-                                bmu++;
-                                me_hi = me[bmu + 1];
-                                moved = true;
-                            }
-                        }
-                        if (moved) {
-                            ke_hi = ke[bk + 1];
-                            me_lo = me[bmu];
+                        float mu2 = kmag2 > 0.f ? k2f * __builtin_amdgcn_rcpf(kmag2) : 0.f;
+                        while (bmu + 1 < b.Nmu && mu2 > me_hi) {   // (:255-256)
+                            bmu++;
+                            me_lo = me_hi;
                             me_hi = me[bmu + 1];
                         }
                         const float tol = 6e-7f * mu2;
@@ -351,46 +353,34 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
                             me_lo = me[bmu];
                             me_hi = me[bmu + 1];
                         }
-                        tb = bk * b.Nmu + bmu;
-                        p = tile[tpad<BIN_EPT>(e0 + e)];
-                    } else {
-                        if (kmag2 < klo) located = false;   // re-locate when the row enters the binned range
-                    }
-                }
-                if (tb != cur) {                      // the one flush site
-                    if (cnt && !(b.dbg & 4)) {
-                        atomicAdd(&h_sum[cur], (double)sp);
-                        if (!(b.dbg & 8)) {
-                        atomicAdd(&h_cnt[cur], (unsigned int)cnt);
-                        atomicAdd(&h_ksum[cur], (double)sk);
+                        const int tb = bk * b.Nmu + bmu;
+                        if (tb != cur) {
+                            flush();
+                            cur = tb;
+                            cur_bk = bk;
+                        }
+                        const float p = trun[epos + (kk - k)];
+                        const float wgt = kk == 0 ? 1.f : 2.f;
+                        cnt += kk == 0 ? 1 : 2;
+                        const float wp = wgt * p;
+                        sp += wp;
+                        sk += wgt * __builtin_amdgcn_sqrtf(kmag2);
 #pragma unroll
                         for (int q = 0; q < NPC; q++)
-                            if (q < np) atomicAdd(&h_pole[q * b.Nk + cur_bk], (double)spole[q]);
-                        }
+                            if (q < np) {
+                                const float *c = b.polecoef[q];
+                                float Lq = c[b.poledeg[q]];
+                                for (int m = b.poledeg[q] - 1; m >= 0; m--) Lq = Lq * mu2 + c[m];
+                                spole[q] += wp * Lq;
+                            }
                     }
-                    cnt = 0;
-                    sp = sk = 0.f;
-#pragma unroll
-                    for (int q = 0; q < NPC; q++) spole[q] = 0.f;
-                    cur = tb;
-                    cur_bk = bk;
                 }
-                if (tb >= 0) {
-                    const float wgt = k == 0 ? 1.f : 2.f;
-                    cnt += k == 0 ? 1 : 2;
-                    const float wp = wgt * p;
-                    sp += wp;
-                    sk += wgt * __builtin_amdgcn_sqrtf(kmag2);
-#pragma unroll
-                    for (int q = 0; q < NPC; q++)
-                        if (q < np) {
-                            const float *c = b.polecoef[q];
-                            float Lq = c[b.poledeg[q]];
-                            for (int m = b.poledeg[q] - 1; m >= 0; m--) Lq = Lq * mu2 + c[m];
-                            spole[q] += wp * Lq;
-                        }
-                }
+                left -= seg;
+                epos += seg;
+                k = 0;
+                row++;
             }
+            flush();
         }
         __syncthreads();
     }
@@ -641,7 +631,7 @@ int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const 
     const size_t hist_bytes = nb * (8 + 8 + 4) + npk * 8 + (size_t)(Nk + 1 + Nmu + 1) * 4 + 64;
     const size_t lds_max = 160 * 1024;
     const bool inter = s.mode == 1 && s.interlaced, cross = s.cross != 0;
-    const int ept = (inter && cross) ? 8 : 16;
+    const int ept = (inter && cross) ? 4 : ((inter || cross) ? 8 : 16);
     const int64_t tile_modes = (int64_t)BIN_THREADS * ept;
     const size_t tile_bytes = (size_t)(tile_modes + BIN_THREADS + 16) * 4;
     if (hist_bytes + tile_bytes > lds_max)
