@@ -1,6 +1,7 @@
 """No-GPU checks: the C-ABI library loads and exports every symbol include/abacus_hip.h declares; host-side logic
 (parameter marshalling, bin edges, argument validation); compute entry points fail loudly without a GPU."""
 import ctypes
+import os
 import re
 from pathlib import Path
 
@@ -95,3 +96,32 @@ def test_no_cpu_fallback():
         gen_gal_cat(hd, pd, {'LRG': synth.LRG_PARAMS}, params)
     with pytest.raises(_lib.AbacusHipError, match='no HIP device'):
         calc_power(np.zeros((10, 3), dtype='f4'), 10.0, nmesh=8)
+
+
+def test_async_load_kernels_do_not_spill(tmp_path):
+    """fft.hip and tsc.hip prefetch with untracked asynchronous loads (inline-asm global_load + hand-counted vmcnt): the
+    compiler does not know those registers are pending, so it must never spill or copy them.  With zero spills and the
+    `touch` barriers in the source that holds; this test pins the zero (it cross-compiles, no GPU needed)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    csrc = os.path.join(str(REPO), 'abacusutils_amd', 'csrc')
+    for src, names in (('fft.hip', ('fft_z_r2c', 'fft_cols')), ('tsc.hip', ('tsc_tile_deposit_p',))):
+        obj = tmp_path / (src + '.o')
+        r = subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-munsafe-fp-atomics',
+                            '-c', os.path.join(csrc, src), '-o', str(obj), '-save-temps=obj'], capture_output=True,
+                           text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm = [f for f in os.listdir(tmp_path) if f.startswith(src.split('.')[0]) and f.endswith('gfx950.s')]
+        assert asm, os.listdir(tmp_path)
+        text = open(tmp_path / asm[0]).read()
+        found = 0
+        for m in re.finditer(r'\.name:\s+(\S+)(.*?)\.vgpr_spill_count:\s+(\d+)', text, re.S):
+            name, spills = m.group(1), int(m.group(3))
+            if any(n in name for n in names):
+                found += 1
+                assert spills == 0, (name, spills)
+        assert found >= len(names)
