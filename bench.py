@@ -181,7 +181,7 @@ def bench_hod(args, dist):
                            'whole_step_GBs': (24.0 * nh + 24.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9,
                            'whole_step_frac': (24.0 * nh + 24.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
     st.free()
-    if dist.rank == 0 and not args.no_cpu:
+    if dist.rank == 0 and dist.world == 1 and not args.no_cpu:   # CPU baseline: rank 0 at N = 1 only
         out['cpu_baseline'] = cpu_baseline_hod(hd, pd, params, tracers, nh)
     return out
 

@@ -127,7 +127,7 @@ def bench_pk(args, dist, headline):
         out['interlaced_compensated'] = {'error': repr(e)}
     dpos.free()
     lib.abacus_power_release()
-    if dist.rank == 0 and not args.no_cpu:
+    if dist.rank == 0 and dist.world == 1 and not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline_pk(L)
     return out
 
