@@ -173,87 +173,141 @@ __global__ __launch_bounds__(PB) void pair_count(PairArgs a, const int *__restri
 // the periodic image of a neighbour cell is known per cell: d = (xi - xj) + shift with shift in {0, +-L} is the very
 // expression the per-pair minimum image evaluates, without its compares.  Accepted pairs (15 % of the candidates)
 // search their bin from the top - most of the volume is in the outer bins - and bump the LDS histogram.
-template <int MODE>
-__global__ __launch_bounds__(PB) void pair_count2(PairArgs a, const int *__restrict__ work_cell,
-                                                  const int *__restrict__ work_off) {
+// AGG = false (dense catalogues): one staging round per neighbour cell chunk, the periodic shift and the self-pair
+// test are uniform per round.  AGG = true (a few points per cell): the points of all 27 neighbour cells are appended
+// to one 256-slot staging buffer with their shifts and indices, one round per slice instead of 27.
+template <int MODE, bool AGG>
+__global__ __launch_bounds__(PB) void pair_count2(PairArgs a, const int *__restrict__ outside, int ncell) {
     __shared__ float ix[PB], iy[PB], iz[PB];
     __shared__ float jx[PB], jy[PB], jz[PB];
-    __shared__ unsigned int hist[MAX_HIST];
+    __shared__ float jsx[AGG ? PB : 1], jsy[AGG ? PB : 1], jsz[AGG ? PB : 1];   // per-point periodic shifts
+    __shared__ int jg[AGG ? PB : 1];                                               // index in the sorted array
+    extern __shared__ unsigned int hist[];   // nbins * nsub counters: small histograms leave room for 8 workgroups per CU
     __shared__ float e2[64];
+    __shared__ int64_t nb_j0[27], nb_j1[27];   // ranges and shifts of the neighbour cells, fetched in ONE round trip
+    __shared__ float nb_sh[27][3];
     const int tid = threadIdx.x;
     const int nh = a.nbins * a.nsub;
+    // persistent workgroups over the cells of set 1 (no host-built work list, no host synchronisation before the
+    // launch): the LDS histogram lives across cells and is flushed once - per-cell flushes of a sparse catalogue are
+    // millions of global atomics on a dozen addresses.  A cell with more than 256 points is walked in slices.
     for (int q = tid; q < nh; q += PB) hist[q] = 0u;
     if (tid <= a.nbins) e2[tid] = a.edges2[tid];
-    const int c1 = work_cell[blockIdx.x];
-    const int64_t i0 = a.start1[c1] + work_off[blockIdx.x];
-    const int ni = (int)min((int64_t)PB, a.start1[c1 + 1] - i0);
-    if (tid < ni) ix[tid] = a.x1[i0 + tid], iy[tid] = a.y1[i0 + tid], iz[tid] = a.z1[i0 + tid];
-    __syncthreads();
-    const float lo2 = e2[0], hi2 = e2[a.nbins];
+    const bool in_box = *outside == 0;
+    for (int c1 = blockIdx.x; c1 < ncell; c1 += gridDim.x) {
+    const int64_t cbeg = a.start1[c1], cend = a.start1[c1 + 1];
+    if (cbeg == cend) continue;
+    __syncthreads();   // the previous cell's reads of the neighbour tables are done
     const int cz = c1 % a.g.ncz, cy = (c1 / a.g.ncz) % a.g.ncy, cx = c1 / (a.g.ncz * a.g.ncy);
     const int rx = a.g.ncx >= 3 ? 1 : 0, ry = a.g.ncy >= 3 ? 1 : 0, rz = a.g.ncz >= 3 ? 1 : 0;
+    const int wx = 2 * rx + 1, wy = 2 * ry + 1, wz = 2 * rz + 1, nnb = wx * wy * wz;
+    if (tid < nnb) {
+        int nx = cx + tid / (wy * wz) - rx, ny = cy + (tid / wz) % wy - ry, nz = cz + tid % wz - rz;
+        float shx = 0.f, shy = 0.f, shz = 0.f;   // xi - xj is about -L when c2 wrapped below 0: add L
+        if (nx < 0) nx += a.g.ncx, shx = a.g.box;
+        else if (nx >= a.g.ncx) nx -= a.g.ncx, shx = -a.g.box;
+        if (ny < 0) ny += a.g.ncy, shy = a.g.box;
+        else if (ny >= a.g.ncy) ny -= a.g.ncy, shy = -a.g.box;
+        if (nz < 0) nz += a.g.ncz, shz = a.g.box;
+        else if (nz >= a.g.ncz) nz -= a.g.ncz, shz = -a.g.box;
+        const int c2 = (nx * a.g.ncy + ny) * a.g.ncz + nz;
+        nb_j0[tid] = a.start2[c2], nb_j1[tid] = a.start2[c2 + 1];
+        nb_sh[tid][0] = shx, nb_sh[tid][1] = shy, nb_sh[tid][2] = shz;
+    }
+    __syncthreads();
+    const float lo2 = e2[0], hi2 = e2[a.nbins];
     // per-cell periodic shifts need |d| of an unwrapped neighbour pair (< 2 cells) to stay below half the box
-    const bool fast = a.in_box && a.g.ncx >= 5 && a.g.ncy >= 5 && a.g.ncz >= 5;
-    for (int ox = -rx; ox <= rx; ox++)
-        for (int oy = -ry; oy <= ry; oy++)
-            for (int oz = -rz; oz <= rz; oz++) {
-                int nx = cx + ox, ny = cy + oy, nz = cz + oz;
-                float shx = 0.f, shy = 0.f, shz = 0.f;   // xi - xj is about +L when c2 wrapped below 0: subtract L
-                if (nx < 0) nx += a.g.ncx, shx = a.g.box;
-                else if (nx >= a.g.ncx) nx -= a.g.ncx, shx = -a.g.box;
-                if (ny < 0) ny += a.g.ncy, shy = a.g.box;
-                else if (ny >= a.g.ncy) ny -= a.g.ncy, shy = -a.g.box;
-                if (nz < 0) nz += a.g.ncz, shz = a.g.box;
-                else if (nz >= a.g.ncz) nz -= a.g.ncz, shz = -a.g.box;
-                // c1 at the low edge (cx = 0) with ox = -1: c2 = ncx - 1, xj ~ L, xi ~ 0: xi - xj ~ -L -> add L
-                const int c2 = (nx * a.g.ncy + ny) * a.g.ncz + nz;
-                const int64_t j0 = a.start2[c2], j1 = a.start2[c2 + 1];
-                for (int64_t jb = j0; jb < j1; jb += PB) {
-                    const int m = (int)min((int64_t)PB, j1 - jb);
-                    __syncthreads();
-                    if (tid < m) jx[tid] = a.x2[jb + tid], jy[tid] = a.y2[jb + tid], jz[tid] = a.z2[jb + tid];
-                    __syncthreads();
-                    const int total = ni * m;
-                    const float inv_m = 1.0f / (float)m;
-                    const bool self_chunk = a.autocorr && jb < i0 + ni && jb + m > i0;   // the chunks overlap in the array
-                    for (int p = tid; p < total; p += PB) {
-                        const int i = (int)(((float)p + 0.5f) * inv_m);   // exact: p < 2^16, m <= 2^8
-                        const int j = p - i * m;
-                        if (self_chunk && jb + j == i0 + i) continue;      // the same point
-                        float dx = ix[i] - jx[j], dy = iy[i] - jy[j], dz = iz[i] - jz[j];
-                        if (fast) {
-                            dx += shx, dy += shy, dz += shz;
-                        } else {
-                            dx = min_image(dx, a.half, a.g.box);
-                            dy = min_image(dy, a.half, a.g.box);
-                            dz = min_image(dz, a.half, a.g.box);
-                        }
-                        float r2;
-                        int sub = 0;
-                        if (MODE == 1) {
-                            const float adz = fabsf(dz);
-                            if (adz >= a.pimax) continue;
-                            r2 = dx * dx + dy * dy;
-                            if (r2 < lo2 || r2 >= hi2) continue;
-                            sub = (int)(adz / a.dpi);
-                            if (sub >= a.nsub) continue;
-                        } else {
-                            r2 = dx * dx + dy * dy + dz * dz;
-                            if (r2 < lo2 || r2 >= hi2) continue;
-                        }
-                        int b = a.nbins - 1;
-                        while (r2 < e2[b]) b--;
-                        if (MODE == 2) {
-                            const float sr = sqrtf(r2);
-                            const float mu = sr > 0.f ? fabsf(dz) / sr : 0.f;
-                            if (mu >= a.mu_max) continue;
-                            sub = (int)(mu * a.inv_dmu);
-                            if (sub >= a.nsub) continue;
-                        }
-                        atomicAdd(&hist[b * a.nsub + sub], 1u);
+    const bool fast = in_box && a.g.ncx >= 5 && a.g.ncy >= 5 && a.g.ncz >= 5;
+
+    // all pairs (slice of c1) x (the `fill` staged neighbour points); !AGG: uniform shift (ux, uy, uz), the staged chunk
+    // starts at sorted index jbase (self pairs only when `self_chunk`)
+    auto process = [&](int64_t i0, int ni, int fill, float ux, float uy, float uz, int64_t jbase, bool self_chunk) {
+        const int total = ni * fill;
+        const float inv_m = 1.0f / (float)fill;
+        for (int p = tid; p < total; p += PB) {
+            const int i = (int)(((float)p + 0.5f) * inv_m);   // exact: p < 2^16, fill <= 2^8
+            const int j = p - i * fill;
+            if (AGG) {
+                if (a.autocorr && (int64_t)jg[j] == i0 + i) continue;   // the same point
+            } else {
+                if (self_chunk && jbase + j == i0 + i) continue;
+            }
+            float dx = ix[i] - jx[j], dy = iy[i] - jy[j], dz = iz[i] - jz[j];
+            if (fast) {
+                if (AGG) dx += jsx[j], dy += jsy[j], dz += jsz[j];
+                else dx += ux, dy += uy, dz += uz;
+            } else {
+                dx = min_image(dx, a.half, a.g.box);
+                dy = min_image(dy, a.half, a.g.box);
+                dz = min_image(dz, a.half, a.g.box);
+            }
+            float r2;
+            int sub = 0;
+            if (MODE == 1) {
+                const float adz = fabsf(dz);
+                if (adz >= a.pimax) continue;
+                r2 = dx * dx + dy * dy;
+                if (r2 < lo2 || r2 >= hi2) continue;
+                sub = (int)(adz / a.dpi);
+                if (sub >= a.nsub) continue;
+            } else {
+                r2 = dx * dx + dy * dy + dz * dz;
+                if (r2 < lo2 || r2 >= hi2) continue;
+            }
+            int b = a.nbins - 1;
+            while (r2 < e2[b]) b--;
+            if (MODE == 2) {
+                const float sr = sqrtf(r2);
+                const float mu = sr > 0.f ? fabsf(dz) / sr : 0.f;
+                if (mu >= a.mu_max) continue;
+                sub = (int)(mu * a.inv_dmu);
+                if (sub >= a.nsub) continue;
+            }
+            atomicAdd(&hist[b * a.nsub + sub], 1u);
+        }
+    };
+
+    for (int64_t i0 = cbeg; i0 < cend; i0 += PB) {
+        const int ni = (int)min((int64_t)PB, cend - i0);
+        __syncthreads();   // the previous slice's reads of ix/iy/iz (and of the staging buffer) are done
+        if (tid < ni) ix[tid] = a.x1[i0 + tid], iy[tid] = a.y1[i0 + tid], iz[tid] = a.z1[i0 + tid];
+        int fill = 0;
+        for (int nb = 0; nb < nnb; nb++) {
+            int64_t jb = nb_j0[nb];
+            const int64_t j1 = nb_j1[nb];
+            const float shx = nb_sh[nb][0], shy = nb_sh[nb][1], shz = nb_sh[nb][2];
+            while (jb < j1) {
+                const int take = (int)min((int64_t)(PB - fill), j1 - jb);
+                if (!AGG) __syncthreads();   // the previous round's reads of the staging buffer are done
+                if (tid < take) {
+                    const int q = fill + tid;
+                    jx[q] = a.x2[jb + tid], jy[q] = a.y2[jb + tid], jz[q] = a.z2[jb + tid];
+                    if (AGG) {
+                        jsx[q] = shx, jsy[q] = shy, jsz[q] = shz;
+                        jg[q] = (int)(jb + tid);
                     }
                 }
+                if (AGG) {
+                    fill += take;
+                    if (fill == PB) {
+                        __syncthreads();
+                        process(i0, ni, fill, 0.f, 0.f, 0.f, 0, false);
+                        __syncthreads();
+                        fill = 0;
+                    }
+                } else {
+                    __syncthreads();
+                    process(i0, ni, take, shx, shy, shz, jb, a.autocorr && jb < i0 + ni && jb + take > i0);
+                }
+                jb += take;
             }
+        }
+        if (AGG && fill) {
+            __syncthreads();
+            process(i0, ni, fill, 0.f, 0.f, 0.f, 0, false);
+        }
+    }
+    }   // cells
     __syncthreads();
     for (int q = tid; q < nh; q += PB)
         if (hist[q]) atomicAdd(&a.npairs[q], (unsigned long long)hist[q]);
@@ -340,25 +394,23 @@ extern "C" int abacus_paircount(int mode, const float *x1, const float *y1, cons
     if (!autocorr) ABACUS_TRY(sort_into_cells(x2, y2, z2, n2, g, S2, scratch, d_flag.as<int>()));
     SortedSet &T = autocorr ? S1 : S2;
 
-    // work list: one workgroup per 256 points of every non-empty cell of set 1 (host side: ncell <= 2M)
-    std::vector<int64_t> start1((size_t)ncell + 1);
+    const bool v1 = getenv("ABACUS_PAIRS_V1") != nullptr;
+    int nwork = 0, *d_wc = nullptr, *d_wo = nullptr;
     int h_outside = 0;
-    HIP_TRY(hipMemcpyAsync(start1.data(), S1.start.p, (size_t)(ncell + 1) * 8, hipMemcpyDeviceToHost, stream()));
-    HIP_TRY(hipMemcpyAsync(&h_outside, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    HIP_TRY(hipStreamSynchronize(stream()));
-    std::vector<int> work;
-    for (int64_t c = 0; c < ncell; c++)
-        for (int64_t o = 0; o < start1[c + 1] - start1[c]; o += PB) {
-            work.push_back((int)c);
-            work.push_back((int)o);
-        }
-    const int nwork = (int)(work.size() / 2);
-    std::vector<int> wc(nwork), wo(nwork);
-    for (int q = 0; q < nwork; q++) wc[q] = work[2 * q], wo[q] = work[2 * q + 1];
-    ABACUS_TRY(d_work.reserve((size_t)std::max(nwork, 1) * 8));
-    int *d_wc = d_work.as<int>(), *d_wo = d_wc + std::max(nwork, 1);
-    HIP_TRY(hipMemcpyAsync(d_wc, wc.data(), (size_t)nwork * 4, hipMemcpyHostToDevice, stream()));
-    HIP_TRY(hipMemcpyAsync(d_wo, wo.data(), (size_t)nwork * 4, hipMemcpyHostToDevice, stream()));
+    if (v1) {   // first-generation kernel: host-built work list, one workgroup per 256 points of a non-empty cell
+        std::vector<int64_t> start1((size_t)ncell + 1);
+        HIP_TRY(hipMemcpyAsync(start1.data(), S1.start.p, (size_t)(ncell + 1) * 8, hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        std::vector<int> wc, wo;
+        for (int64_t c = 0; c < ncell; c++)
+            for (int64_t o = 0; o < start1[c + 1] - start1[c]; o += PB) wc.push_back((int)c), wo.push_back((int)o);
+        nwork = (int)wc.size();
+        ABACUS_TRY(d_work.reserve((size_t)std::max(nwork, 1) * 8));
+        d_wc = d_work.as<int>(), d_wo = d_wc + std::max(nwork, 1);
+        HIP_TRY(hipMemcpyAsync(d_wc, wc.data(), (size_t)nwork * 4, hipMemcpyHostToDevice, stream()));
+        HIP_TRY(hipMemcpyAsync(d_wo, wo.data(), (size_t)nwork * 4, hipMemcpyHostToDevice, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+    }
 
     std::vector<float> e2(nbins + 1);
     for (int b = 0; b <= nbins; b++) e2[b] = bins[b] * bins[b];
@@ -370,7 +422,7 @@ extern "C" int abacus_paircount(int mode, const float *x1, const float *y1, cons
     PairArgs a;
     a.mode = mode;
     a.autocorr = autocorr;
-    a.in_box = !h_outside;
+    a.in_box = !h_outside;   // (first-generation kernel does not use it)
     a.g = g;
     a.nbins = nbins;
     a.nsub = nsub;
@@ -385,11 +437,26 @@ extern "C" int abacus_paircount(int mode, const float *x1, const float *y1, cons
     a.start1 = S1.start.as<int64_t>();
     a.start2 = T.start.as<int64_t>();
     a.npairs = d_npairs.as<unsigned long long>();
-    if (nwork > 0) {
-        if (getenv("ABACUS_PAIRS_V1")) ABACUS_LAUNCH("pair_count", pair_count, dim3(nwork), dim3(PB), 0, a, d_wc, d_wo);
-        else if (mode == 0) ABACUS_LAUNCH("pair_count", (pair_count2<0>), dim3(nwork), dim3(PB), 0, a, d_wc, d_wo);
-        else if (mode == 1) ABACUS_LAUNCH("pair_count", (pair_count2<1>), dim3(nwork), dim3(PB), 0, a, d_wc, d_wo);
-        else ABACUS_LAUNCH("pair_count", (pair_count2<2>), dim3(nwork), dim3(PB), 0, a, d_wc, d_wo);
+    if (v1) {
+        if (nwork > 0) ABACUS_LAUNCH("pair_count", pair_count, dim3(nwork), dim3(PB), 0, a, d_wc, d_wo);
+    } else {
+        int dev = 0, ncu = 256;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        const dim3 grid((unsigned int)std::min<int64_t>(ncell, (int64_t)ncu * 8));
+        const size_t hist_bytes = ntot * sizeof(unsigned int);
+        const int *flag = d_flag.as<int>();
+        // a few points per cell: stage all neighbour cells together (one round per slice instead of 27)
+        const bool agg = (double)T.n / (double)ncell < 12.0;
+#define LAUNCH_PC(M)                                                                                         \
+    do {                                                                                                     \
+        if (agg) ABACUS_LAUNCH("pair_count", (pair_count2<M, true>), grid, dim3(PB), hist_bytes, a, flag, (int)ncell);  \
+        else ABACUS_LAUNCH("pair_count", (pair_count2<M, false>), grid, dim3(PB), hist_bytes, a, flag, (int)ncell); \
+    } while (0)
+        if (mode == 0) LAUNCH_PC(0);
+        else if (mode == 1) LAUNCH_PC(1);
+        else LAUNCH_PC(2);
+#undef LAUNCH_PC
     }
     HIP_TRY(hipMemcpyAsync(npairs, d_npairs.p, ntot * 8, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));

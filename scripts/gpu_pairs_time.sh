@@ -18,3 +18,4 @@ for n in (1_000_000, 10_000_000):
             cand = n*(n/L**3)*27*30.0**3
             print(f'n={n:.0e} shift={shift} mode={mode} {dt*1e3:.1f} ms  pairs {int(c.sum()):.3e}  candidates {cand:.2e} -> {cand/dt:.2e}/s')
 PY
+bash scripts/gpu_pairs_prof.sh
