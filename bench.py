@@ -227,6 +227,11 @@ def main():
                 out['pk'] = bench_pk(args, dist, headline=False)
             except Exception as e:  # the secondary measurement must not take the headline down
                 out['pk'] = {'error': repr(e)}
+            try:
+                from bench_pk import bench_pairs
+                out['pairs'] = bench_pairs(args, dist)
+            except Exception as e:
+                out['pairs'] = {'error': repr(e)}
     else:
         from bench_pk import bench_pk
         out = bench_pk(args, dist, headline=True)

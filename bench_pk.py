@@ -200,3 +200,44 @@ def bench_pk_slab(args, dist):
             'config': {'workload': f'{n_local * W:.0e} uniform particles in x-slabs, nmesh {nmesh}, TSC, non-interlaced, '
                                    'device collectives (RCCL all-to-all + ring send/recv + all-reduce)'},
             'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot)}
+
+
+def bench_pairs(args, dist):
+    """pair-counting leg (BASELINE config 5): DD(r) of 1e7 uniform points, 13 log bins 0.1-30 Mpc/h in the 2 Gpc/h box
+    (the shape of scripts/emulator/generate_cfs/generate_cf.py:63-74), host arrays in / counts out like the Corrfunc
+    call it replaces.  Unit: candidate pair separations evaluated per second (N * nbar * 27 * cell^3)."""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.tpcf_corrfunc import _paircount
+    n, L = 10_000_000, 2000.0
+    rng = np.random.default_rng(500 + dist.rank)
+    p = rng.random((n, 3), dtype=np.float32) * np.float32(L)
+    x, y, z = (np.ascontiguousarray(p[:, i]) for i in range(3))
+    bins = np.geomspace(0.1, 30.0, 14).astype(np.float32)
+    _paircount(0, x, y, z, L, bins)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    dist.barrier()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        c = _paircount(0, x, y, z, L, bins)
+    dist.barrier()
+    dt = dist.max(time.perf_counter() - t0) / reps
+    _lib.profile_enable(False)
+    kern = {k: ms / cnt for k, (ms, cnt) in _lib.profile_get().items() if cnt}
+    ncell = int(np.floor(L / 30.0 * 0.9999))
+    cand = float(n) * (n / L**3) * 27 * (L / ncell) ** 3
+    out = {'metric': 'candidate pair separations per second, DD(r) to 30 Mpc/h', 'value': cand * dist.world / dt,
+           'unit': 'pairs/s', 'n_gpus': dist.world, 'ms_per_call': dt * 1e3, 'n_points': n, 'pairs_counted': int(c.sum()),
+           'kernels_ms': {k: round(v, 4) for k, v in kern.items()}, 'dtype': 'f32',
+           'note': 'VALU/LDS-bound kernel (about 30 lane-operations per candidate pair), not HBM-bound'}
+    if dist.rank == 0 and dist.world == 1 and not args.no_cpu:
+        from oracle import oracle
+        m = 50_000
+        cores = len(os.sched_getaffinity(0))
+        t = time.perf_counter()
+        oracle.paircount_brute('r', x[:m], y[:m], z[:m], L, bins, nthread=cores)
+        tc = time.perf_counter() - t
+        out['cpu_baseline'] = {'value': float(m) * m / tc, 'unit': 'pair separations/s (brute force, all N^2 pairs)',
+                               'cores': cores, 'kind': 'port', 'sample': f'{m} of the points, {tc * 1e3:.0f} ms'}
+    return out

@@ -4,9 +4,10 @@ PMC traffic table.
 
 PMC correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB, collected in
 separate passes; on gfx950 FETCH_SIZE tallies a 128-B request at 64 B, so wide streaming reads are doubled.  Kernels whose
-reads are 64-B segments (the strided column FFT passes: 8 complex columns per row) issue 64-B requests that are
-tallied exactly -- calibrated here against the known byte count (raw FETCH_SIZE of fft_cols == 4M bytes of the
-half-spectrum to 0.5 %), so they take factor 1."""
+reads are 64-B segments (the 2048-point column pass of the plain three-pass FFT: 8 complex columns per row) issue 64-B
+requests that are tallied exactly -- calibrated against the known byte count (raw FETCH_SIZE == 4M bytes of the
+half-spectrum to 0.5 %), so that kernel takes factor 1; the 16-column passes read 128-B runs and take factor 2 (their
+raw FETCH_SIZE is half the known byte count)."""
 import glob
 import json
 import os
@@ -17,7 +18,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 src = 'gpurun_out/round'
 dst = os.path.join('profiles', rnd)
 os.makedirs(dst, exist_ok=True)
-FETCH_FACTOR = {'fft_cols': 1.0}
+FETCH_FACTOR = {'fft_cols<2048, 8>': 1.0}   # 64-B row segments; every other kernel reads >= 128-B runs
 
 for d in ('prof_hod', 'prof_pk1024', 'prof_pk2048'):
     for f in glob.glob(os.path.join(src, d, '**', '*kernel_stats.csv'), recursive=True):
@@ -38,8 +39,7 @@ if os.path.exists(p):
         for k, e in ks.items():
             if 'FETCH_SIZE_KiB_per_launch_raw' not in e or 'WRITE_SIZE_KiB_per_launch_raw' not in e:
                 continue
-            base = k.split('<')[0]
-            fac = FETCH_FACTOR.get(base, 2.0)
+            fac = FETCH_FACTOR.get(k, 2.0)
             rd = e['FETCH_SIZE_KiB_per_launch_raw'] * 1024 * fac
             wr = e['WRITE_SIZE_KiB_per_launch_raw'] * 1024
             out.setdefault(wl, {})[k] = {'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
