@@ -492,10 +492,8 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
                                                          float *__restrict__ grid, int zero_grid, float norm, float sub,
                                                          int dbg) {
     constexpr int NPRE = 2;                                // prefetched entries per thread
-    constexpr int CPS = 16 / (int)sizeof(ACC);             // cells per flush step: one 16-B LDS read (2 f64 / 4 f32)
-    constexpr int ZP = TZS / CPS;
-    constexpr int FL = TXS * TYS * ZP / NT;                // flush stores per thread of a full tile
-    static_assert((TXS * TYS * ZP) % NT == 0 && 2 * FL + NPRE <= 60, "whole flush stores per thread");
+    constexpr int FL = TXS * TYS * (TZS / 4) / NT;         // flush stores (16 B) per thread of a full tile
+    static_assert((TXS * TYS * (TZS / 4)) % NT == 0 && 2 * FL + NPRE <= 60, "whole flush stores per thread");
     __shared__ __align__(16) ACC tile[TXS * TYS * TZS];
     __shared__ unsigned int bnd[TP_RANGE + 1];             // list bounds of the range, relative to its first entry
     const int tid = threadIdx.x;
@@ -547,26 +545,37 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
             if (more) issue(cur, tt + 2);                  // BEFORE this tile's stores
             const bool full = dx == TXS && dy == TYS && dz == TZS;
             if (full) {
+                // four cells (one 16-B store) per thread and step; a thread keeps its (y, z) and walks x, so the LDS
+                // and mesh addresses advance by constants - the flush is instruction-bound at two waves per SIMD
                 static_assert((TZS & (TZS - 1)) == 0 && (TYS & (TYS - 1)) == 0, "tile dims must be powers of two");
-#pragma unroll 4
-                for (int q = tid; q < TXS * TYS * ZP; q += NT) {
-                    const int zp = q & (ZP - 1), y = (q / ZP) & (TYS - 1), x = q / (ZP * TYS);
-                    float4 *cell = reinterpret_cast<float4 *>(&tile[(x * TYS + y) * TZS + CPS * zp]);
-                    const float4 raw = *cell;
-                    *cell = make_float4(0.f, 0.f, 0.f, 0.f);   // the tile is zero again for the next one
-                    float *dst = grid + ((int64_t)(ox + x) * g.gy + (oy + y)) * g.zstride + oz + CPS * zp;
-                    float v[CPS];
+                constexpr int ZQ = TZS / 4;                       // quads per row
+                constexpr int ROWS = NT / ZQ;                     // (x, y) rows covered per step
+                static_assert(NT % ZQ == 0 && ROWS % TYS == 0 && (TXS * TYS) % ROWS == 0, "flush mapping");
+                constexpr int XSTEP = ROWS / TYS, STEPS = TXS / XSTEP;
+                const int zq = tid & (ZQ - 1), yy = (tid / ZQ) & (TYS - 1), x0 = tid / (ZQ * TYS);
+                ACC *cell = &tile[(x0 * TYS + yy) * TZS + 4 * zq];
+                float *dst = grid + ((int64_t)(ox + x0) * g.gy + (oy + yy)) * g.zstride + oz + 4 * zq;
+                const int64_t dstep = (int64_t)XSTEP * g.gy * g.zstride;
+#pragma unroll
+                for (int st = 0; st < STEPS; st++, cell += XSTEP * TYS * TZS, dst += dstep) {
+                    float v[4];
                     if constexpr (sizeof(ACC) == 8) {
-                        double a0 = __hiloint2double(__float_as_int(raw.y), __float_as_int(raw.x));
-                        double a1 = __hiloint2double(__float_as_int(raw.w), __float_as_int(raw.z));
+                        double2 *c2 = reinterpret_cast<double2 *>(cell);
+                        const double2 a01 = c2[0], a23 = c2[1];
+                        c2[0] = make_double2(0.0, 0.0);       // the tile is zero again for the next one
+                        c2[1] = make_double2(0.0, 0.0);
+                        double a[4] = {a01.x, a01.y, a23.x, a23.y};
                         if (!zero_grid) {
-                            const float2 old = *reinterpret_cast<const float2 *>(dst);
-                            a0 += (double)old.x;
-                            a1 += (double)old.y;
+                            const float4 old = *reinterpret_cast<const float4 *>(dst);
+                            a[0] += (double)old.x, a[1] += (double)old.y, a[2] += (double)old.z, a[3] += (double)old.w;
                         }
-                        v[0] = (float)a0, v[1] = (float)a1;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) v[c] = (float)a[c];
                     } else {
-                        v[0] = raw.x, v[1] = raw.y, v[2] = raw.z, v[3] = raw.w;
+                        float4 *c4 = reinterpret_cast<float4 *>(cell);
+                        const float4 r = *c4;
+                        *c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[0] = r.x, v[1] = r.y, v[2] = r.z, v[3] = r.w;
                         if (!zero_grid) {
                             const float4 old = *reinterpret_cast<const float4 *>(dst);
                             v[0] += old.x, v[1] += old.y, v[2] += old.z, v[3] += old.w;
@@ -574,12 +583,9 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
                     }
                     if (norm != 0.f) {
 #pragma unroll
-                        for (int c = 0; c < CPS; c++) v[c] = v[c] * norm - sub;
+                        for (int c = 0; c < 4; c++) v[c] = v[c] * norm - sub;
                     }
-                    if (!(dbg & 2)) {
-                        if constexpr (CPS == 2) *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[1]);
-                        else *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
+                    if (!(dbg & 2)) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             } else {
                 for (int q = tid; q < TXS * TYS * TZS; q += NT) {
