@@ -1439,6 +1439,20 @@ int abacus_hod_fetch(abacus_hod_state *st, int tracer, double *x, double *y, dou
     return 0;
 }
 
+int abacus_hod_fetch_block(abacus_hod_state *st, int tracer, void *out8, int64_t n_expected) {
+    if (tracer < 0 || tracer > 2) return fail("abacus_hod_fetch_block: tracer %d out of range", tracer);
+    if (!out8) return fail("abacus_hod_fetch_block: null output");
+    ABACUS_TRY(abacus_hod_counts(st, nullptr));
+    const int64_t n = st->counts[tracer] + st->counts[3 + tracer];
+    if (n != n_expected) return fail("abacus_hod_fetch_block: the catalogue has %lld rows, the buffer %lld", (long long)n, (long long)n_expected);
+    if (n == 0) return 0;
+    // the 8 columns of a tracer are rows of one device allocation, `cap` elements apart: one 2-D copy
+    HIP_TRY(hipMemcpy2DAsync(out8, (size_t)n * 8, st->out[tracer].p, (size_t)st->cap[tracer] * 8, (size_t)n * 8, 8,
+                             hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
 int abacus_hod_device_columns(abacus_hod_state *st, int tracer, void *cols[8]) {
     if (tracer < 0 || tracer > 2) return fail("abacus_hod_device_columns: tracer %d out of range", tracer);
     ABACUS_TRY(abacus_hod_counts(st, nullptr));

@@ -183,9 +183,10 @@ class StagedCatalog:
         """device -> host copy of one tracer's catalog, in the reference's dict form (:1573-1589)"""
         t = TRACERS.index(tracer)
         n = int(self.counts[t] + self.counts[3 + t])
-        cols = {c: np.empty(n, dtype=np.float64) for c in COLS}
-        ids = np.empty(n, dtype=np.int64)
-        check(_lib.lib().abacus_hod_fetch(self._h, t, *[ptr(cols[c]) for c in COLS], ptr(ids)))
+        block = np.empty((8, n), dtype=np.float64)   # one transfer; the columns below are views of it
+        check(_lib.lib().abacus_hod_fetch_block(self._h, t, ptr(block), C.c_int64(n)))
+        cols = {c: block[q] for q, c in enumerate(COLS)}
+        ids = block[7].view(np.int64)
         d = {'Ncent': int(self.counts[t])}
         d.update(cols)
         d['id'] = ids

@@ -160,6 +160,9 @@ int abacus_hod_counts(abacus_hod_state *st, int64_t counts[6]); /* syncs; re-run
 /* copy tracer t's catalog (x,y,z,vx,vy,vz,mass: float64; id: int64), each of length Ncent+Nsat, to the host */
 int abacus_hod_fetch(abacus_hod_state *st, int tracer, double *x, double *y, double *z, double *vx, double *vy,
                      double *vz, double *mass, int64_t *id);
+/* the same catalogue as ONE device-to-host transfer: out8 = [8][n] (x, y, z, vx, vy, vz, mass as float64, id as int64),
+ * n = Ncent + Nsat of the tracer (checked against n_expected) */
+int abacus_hod_fetch_block(abacus_hod_state *st, int tracer, void *out8, int64_t n_expected);
 /* device pointers of tracer t's catalog columns (7 float64 + 1 int64), valid until the next populate */
 int abacus_hod_device_columns(abacus_hod_state *st, int tracer, void *cols[8]);
 /* the int8 masks gen_cent / gen_sats compute (hod/GRAND_HOD.py:210,954); either pointer may be NULL */
