@@ -132,11 +132,13 @@ def bench_hod(args, dist):
     dt_sync = time.perf_counter() - t1
 
     # PCIe-inclusive: catalog copied back to NumPy every step (what run_hod returns)
+    st.populate(p)
+    st.fetch('LRG')   # first transfer: one-time runtime set-up of the 2-D copy path
     t2 = time.perf_counter()
-    for _ in range(3):
+    for _ in range(10):
         st.populate(p)
         st.fetch('LRG')
-    dt_fetch = (time.perf_counter() - t2) / 3
+    dt_fetch = (time.perf_counter() - t2) / 10
 
     total_halos = dist.sum(float(nh)) * args.steps
     out = {
