@@ -108,17 +108,16 @@ def get_field(pos, Lbox, nmesh, paste, w=None, d=0.0, nthread=MAX_THREADS, dtype
     """Overdensity mesh of the particles (:808-857).  `pos` is wrapped in place for TSC, like the reference."""
     if w is not None:
         assert pos.shape[0] == len(w)
-    field = np.zeros((nmesh, nmesh, nmesh), dtype=dtype)
     paste_u = paste.upper()
-    if paste_u == 'TSC':
-        tsc_parallel(pos, field, Lbox, weights=w, nthread=nthread, offset=d)
-    elif paste_u == 'CIC':
-        warnings.warn('Note that currently CIC pasting, unlike TSC, supports only a non-parallel implementation.')
-        cic_serial(pos + d if d != 0.0 else pos, field, Lbox, weights=w)
-    else:
+    if paste_u not in ('TSC', 'CIC'):
         raise ValueError(f'Unknown pasting method: {paste}')
-    normalize_field(field, inplace=True, tot_weight=len(pos), nthread=nthread)
-    return field
+    if paste_u == 'CIC':
+        warnings.warn('Note that currently CIC pasting, unlike TSC, supports only a non-parallel implementation.')
+    p4 = _pos_f4(pos)
+    field = np.empty((nmesh, nmesh, nmesh), dtype=np.float32)
+    check(_lib.lib().abacus_field(ptr(p4), C.c_int64(len(p4)), ptr(_f4(w)), C.c_double(Lbox), int(nmesh),
+                                  0 if paste_u == 'TSC' else 1, C.c_double(d), ptr(field)))
+    return field if np.dtype(dtype) == np.float32 else field.astype(dtype)
 
 
 def _f4(a):

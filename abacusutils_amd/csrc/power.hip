@@ -760,6 +760,26 @@ int abacus_power_from_particles(float *pos, int64_t n, const float *w, float *po
     return 0;
 }
 
+int abacus_field(float *pos, int64_t n, const float *w, double Lbox, int nmesh, int paste, double offset, float *field) {
+    ABACUS_TRY(ensure_init());
+    ABACUS_TRY(check_common(nmesh, paste));
+    if (n <= 0) return fail("power: empty particle set");
+    if (!field) return fail("abacus_field: null output");
+    float *pd, *wd;
+    ABACUS_TRY(stage_particles(pos, n, w, g_ctx.pos, g_ctx.w, &pd, &wd));
+    ABACUS_TRY(g_ctx.mesh[0].reserve(mesh_bytes(nmesh)));
+    float *mesh = g_ctx.mesh[0].as<float>();
+    const int64_t zstride = pitch_r(nmesh);
+    const double M = (double)nmesh * nmesh * nmesh;
+    const double norm = (double)(float)(M / (double)n);   // dtype(field.size / tot_weight), tot_weight = len(pos) (:856,894)
+    ABACUS_TRY(tsc_deposit_f32(pd, n, wd, mesh, nmesh, zstride, Lbox, offset, paste == 0, norm, paste));
+    HIP_TRY(hipMemcpy2DAsync(field, (size_t)nmesh * 4, mesh, (size_t)zstride * 4, (size_t)nmesh * 4, (size_t)nmesh * nmesh,
+                             hipMemcpyDeviceToHost, stream()));
+    if (paste == 0) HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 12, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
 int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nmesh, int paste, const float *W_host,
                      int interlaced, void *out_c64) {
     ABACUS_TRY(ensure_init());

@@ -205,6 +205,9 @@ int abacus_partition(const void *pos, int64_t n, const void *weights, int dtype,
  * pos (n,3) float32 host; w (n,) float32 or NULL; W (nmesh,) float32 window or NULL (= not compensated);
  * out: (nmesh, nmesh, nmesh/2+1) complex64 host.  paste: 0 TSC, 1 CIC.
  */
+/* get_field (analysis/power_spectrum.py:808-857): overdensity mesh delta = rho * f32(M / len(pos)) - 1 of the particles,
+ * deposit and normalisation fused on the device; field: (nmesh, nmesh, nmesh) float32 host array.  TSC wraps pos in place. */
+int abacus_field(float *pos, int64_t n, const float *w, double Lbox, int nmesh, int paste, double offset, float *field);
 int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nmesh, int paste, const float *W,
                      int interlaced, void *out_c64);
 /*

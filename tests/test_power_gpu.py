@@ -192,3 +192,20 @@ def test_fused_fft_matches_three_pass(monkeypatch, nmesh):
     np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
     np.testing.assert_allclose(a['power'], b['power'], rtol=2e-5, atol=1e-6 * np.abs(b['power']).max())
     np.testing.assert_allclose(a['poles'], b['poles'], rtol=2e-5, atol=1e-6 * np.abs(b['power']).max())
+
+
+@pytest.mark.parametrize('paste,d', [('TSC', 0.0), ('TSC', 3.9), ('CIC', 0.0)])
+def test_get_field(paste, d):
+    """get_field (analysis/power_spectrum.py:808-857): deposit + normalisation fused on the device"""
+    from abacusutils_amd.analysis.power_spectrum import get_field
+    from oracle import oracle
+    box, nmesh, n = 500.0, 64, 50_000
+    pos = synth.synth_positions(n, box, seed=91, clustered=True)
+    w = np.random.default_rng(2).random(n, dtype=np.float32) + np.float32(0.5)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        a = get_field(pos.copy(), box, nmesh, paste, w=w, d=d)
+    b = oracle.get_field(pos.copy(), box, nmesh, paste, w=w, d=d, nthread=2)
+    assert a.shape == (nmesh,) * 3 and a.dtype == np.float32
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5 * np.abs(b).max())
