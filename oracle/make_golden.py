@@ -21,7 +21,10 @@ What is captured
   power_cases.npz             calc_power for all paste x compensated x interlaced
         modes, cross spectra, poles, logk; bin_kmu / calc_pk_from_deltak.
 
-usage: python oracle/make_golden.py [hod] [tsc] [power]
+  power_helpers.npz           bin_kppi, project_3d_to_poles, pk_to_xi, expand_poles_to_3d, get_smoothing,
+        get_delta_mu2 on seeded 16^3 / 21^3 inputs.
+
+usage: python oracle/make_golden.py [hod] [tsc] [power] [helpers]
 """
 import ctypes
 import os
@@ -434,8 +437,49 @@ def gen_power(P):
     print('power_cases written')
 
 
+def gen_helpers(P):
+    """ZCV-facing spectrum helpers: bin_kppi, project_3d_to_poles, pk_to_xi, expand_poles_to_3d,
+    get_smoothing, get_delta_mu2 of the reference on seeded inputs (plain-Python loops under the shim: small meshes)"""
+    warnings.simplefilter('ignore')
+    L = 400.0
+    out = {'meta.L': np.float64(L)}
+    for n in (16, 21):
+        kz = n // 2 + 1
+        rng = np.random.default_rng(40 + n)
+        p3d = (rng.random((n, n, kz), dtype=np.float32) * 100).astype(np.float32)
+        out[f'n{n}.p3d'] = p3d
+        ke = np.linspace(0.0, np.pi * n / L * 0.9, 7)
+        out[f'n{n}.kedges'] = ke
+        # bin_kppi in Fourier space and in configuration space
+        # pimax beyond the largest kz: below it the reference indexes past its pi edges (unchecked under Numba) before it breaks
+        wc, c = P.bin_kppi(n, L, ke, pimax=np.pi * n / L * 1.01, Npi=5, weights=p3d, nthread=1)
+        out[f'n{n}.kppi.mean'], out[f'n{n}.kppi.counts'] = wc, c
+        xi = rng.standard_normal((n, n, n)).astype(np.float32)
+        re = np.linspace(0.0, L / 3, 6)
+        out[f'n{n}.xi'], out[f'n{n}.redges'] = xi, re
+        wc, c = P.bin_kppi(n, L, re, pimax=L / 2 * 1.01, Npi=4, weights=xi, fourier=False, nthread=1)
+        out[f'n{n}.rppi.mean'], out[f'n{n}.rppi.counts'] = wc, c
+        # multipoles of a 3-D power spectrum
+        bp, npo = P.project_3d_to_poles(ke, p3d, L, [0, 2, 4])
+        out[f'n{n}.p2poles.poles'], out[f'n{n}.p2poles.N'] = bp, npo
+        # correlation-function multipoles
+        rb, xp, nr = P.pk_to_xi(p3d.copy(), L, re, poles=[0, 2, 4])
+        out[f'n{n}.pk2xi.r'], out[f'n{n}.pk2xi.poles'], out[f'n{n}.pk2xi.N'] = rb, xp, nr
+        # multipoles -> 3-D grid
+        k_ell = np.linspace(0.01, 0.3, 12)
+        P_ell = (rng.random((3, 12)) * 1e3).astype(np.float64)
+        out[f'n{n}.expand.k_ell'], out[f'n{n}.expand.P_ell'] = k_ell, P_ell
+        out[f'n{n}.expand.Pk'] = P.expand_poles_to_3d(k_ell, P_ell, n, L, np.array([0, 2, 4]))
+        out[f'n{n}.smoothing'] = P.get_smoothing(n, L, 7.5)
+        d = (rng.standard_normal((n, n, kz)) + 1j * rng.standard_normal((n, n, kz))).astype(np.complex64)
+        out[f'n{n}.delta'] = d
+        out[f'n{n}.delta_mu2'] = P.get_delta_mu2(d, n)
+    np.savez_compressed(GOLD / 'power_helpers.npz', **out)
+    print('power_helpers written')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['hod', 'tsc', 'power']
+    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers']
     G, T, P, C = import_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
     if 'hod' in which:
@@ -444,3 +488,5 @@ if __name__ == '__main__':
         gen_tsc(T, C)
     if 'power' in which:
         gen_power(P)
+    if 'helpers' in which:
+        gen_helpers(P)

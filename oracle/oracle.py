@@ -526,3 +526,106 @@ def compute_ngal_numpy(ball, tracers=None):
         fsat_dict[etracer] = ngal_sat / (ngal_cent + ngal_sat)
     return ngal_dict, fsat_dict
 
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ZCV-facing spectrum helpers (analysis/power_spectrum.py:303-660), NumPy restatements pinned by
+# tests/golden/power_helpers.npz (outputs of the shimmed reference).
+def _fold2(n):
+    i = np.arange(n, dtype=np.int64)
+    return np.where(i < n // 2, i * i, (i - n) ** 2)
+
+
+def bin_kppi(n1d, L, kedges, pimax, Npi, weights, fourier=True):
+    """bin_kppi (:303-412): mean of `weights` and mode counts in (k_perp, pi) bins.  Quirks kept: for every i the j loop
+    BREAKS at the first j whose k_perp^2 reaches the last edge (the negative-frequency half behind it is never visited,
+    :383-384); k_perp bins are (lo, hi] with bin 0 closed below; the kz loop breaks at the last pi edge."""
+    kzlen = n1d // 2 + 1
+    Nk = len(kedges) - 1
+    dk = 2.0 * np.pi / L if fourier else L / n1d
+    ke2 = ((np.asarray(kedges) / dk) ** 2).astype(np.float32)
+    pe2 = ((np.linspace(0.0, pimax, Npi + 1) / dk) ** 2).astype(np.float32)
+    f2 = _fold2(n1d)
+    kp2 = (f2[:, None] + f2[None, :]).astype(np.float32)                 # (i, j)
+    over = kp2 >= ke2[-1]
+    visited = np.cumsum(over, axis=1) == 0                                # j before the first `break`
+    use = visited & (kp2 >= ke2[0])
+    bk = np.searchsorted(ke2[1:], kp2, side='left')                       # while kmag2 > kedges2[bk+1]: bk += 1
+    kz2 = (np.arange(kzlen, dtype=np.int64) ** 2).astype(np.float32)
+    zuse = kz2 < pe2[-1]
+    bpi = np.searchsorted(pe2[1:], kz2, side='left')
+    wz = np.where(np.arange(kzlen) == 0, 1, 2)
+    counts = np.zeros((Nk, Npi), dtype=np.int64)
+    wsum = np.zeros((Nk, Npi), dtype=np.float64)
+    w = np.asarray(weights)[:, :, :kzlen].astype(np.float64)
+    ii, jj = np.nonzero(use)
+    for kz in np.nonzero(zuse)[0]:
+        np.add.at(counts, (bk[ii, jj], bpi[kz]), wz[kz])
+        np.add.at(wsum, (bk[ii, jj], bpi[kz]), wz[kz] * w[ii, jj, kz])
+    mean = np.where(counts > 0, wsum / np.maximum(counts, 1), wsum)
+    return mean.astype(np.float32), counts
+
+
+def project_3d_to_poles(k_bin_edges, raw_p3d, Lbox, poles, nthread=1):
+    """(:415-448): bin_kmu of a caller-supplied 3-D power with one mu bin, times L^3"""
+    n = raw_p3d.shape[0]
+    r = bin_kmu(n, Lbox, np.asarray(k_bin_edges, dtype=np.float64), np.array([0.0, 1.0]),
+                np.ascontiguousarray(raw_p3d, dtype=np.float32), poles=np.asarray(poles, dtype=np.int64), accum64=True,
+                nthread=nthread)
+    return r[2] * np.float32(Lbox**3), r[3]
+
+
+def pk_to_xi(Pk, Lbox, r_bins, poles=(0, 2, 4), nthread=1):
+    """(:620-660): Xi = irfftn(Pk); multipoles of Xi in r bins (bin_kmu with fourier=False), times nmesh^3"""
+    from scipy.fft import irfftn
+    Xi = irfftn(Pk, workers=nthread).real
+    n = Xi.shape[0]
+    r_binc = (np.asarray(r_bins)[1:] + np.asarray(r_bins)[:-1]) * 0.5
+    r = bin_kmu(n, Lbox, np.asarray(r_bins, dtype=np.float64), np.array([0.0, 1.0]),
+                np.ascontiguousarray(Xi[:, :, : n // 2 + 1], dtype=np.float32), poles=np.asarray(poles, dtype=np.int64),
+                fourier=False, accum64=True, nthread=nthread)
+    return r_binc, r[2] * np.float32(n**3), r[3]
+
+
+def _mu2_kmag2(n1d):
+    f2 = _fold2(n1d)
+    kz = np.arange(n1d // 2 + 1, dtype=np.int64)
+    kmag2 = (f2[:, None, None] + f2[None, :, None] + (kz * kz)[None, None, :]).astype(np.float32)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        mu2 = np.where(kmag2 > 0, (kz * kz).astype(np.float32)[None, None, :] * (np.float32(1) / kmag2), np.float32(0))
+    return mu2.astype(np.float32), kmag2
+
+
+def get_delta_mu2(delta, n1d):
+    """(:580-617)"""
+    mu2, _ = _mu2_kmag2(n1d)
+    return (delta * mu2).astype(np.complex64)
+
+
+def get_smoothing(n1d, L, R):
+    """(:527-577): exp(-k^2 R^2 / 2) in float32"""
+    _, kmag2 = _mu2_kmag2(n1d)
+    dk2 = np.float32(np.float32(2.0 * np.pi / L) ** 2)
+    R2 = np.float32(R**2)
+    return np.exp(-kmag2 * dk2 * R2 / np.float32(2.0)).astype(np.float32)
+
+
+def expand_poles_to_3d(k_ell, P_ell, n1d, L, poles):
+    """(:451-505): sum_l interp(P_l)(|k|) * P_l(mu) on the fundamental modes; linear_interp (:508-537) clamps at the ends"""
+    from scipy.special import eval_legendre
+    mu2, kmag2 = _mu2_kmag2(n1d)
+    dk = np.float32(2.0 * np.pi / L)
+    k_ell = np.asarray(k_ell).astype(np.float32)
+    P_ell = np.asarray(P_ell).astype(np.float32)
+    kk = np.sqrt(kmag2) * dk
+    dx = k_ell[1] - k_ell[0]
+    f = (kk - k_ell[0]) / dx
+    fl = np.clip(f.astype(np.int64), 0, len(k_ell) - 2)
+    out = np.zeros_like(kmag2, dtype=np.float32)
+    mu = np.sqrt(mu2.astype(np.float64))
+    for ip, ell in enumerate(poles):
+        y = P_ell[ip]
+        yd = y[fl] + (f - fl) * (y[fl + 1] - y[fl])
+        yd = np.where(kk <= k_ell[0], y[0], np.where(kk >= k_ell[-1], y[-1], yd))
+        out += (yd * (1.0 if ell == 0 else eval_legendre(int(ell), mu))).astype(np.float32)
+    return out
