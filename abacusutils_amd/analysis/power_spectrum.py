@@ -229,3 +229,81 @@ def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste
                    mu_max=np.broadcast_to(mubins[1:], res['power'].shape),
                    mu_mid=np.broadcast_to(mu_binc, res['power'].shape))
     return Table(res, meta=meta)
+
+
+# ---- ZCV-facing helpers (analysis/power_spectrum.py:303-660 of the reference) ------------------------------------
+def _grid_f4(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 3 or a.shape[0] != a.shape[1]:
+        raise ValueError('expected an (n, n, n//2+1) or (n, n, n) grid')
+    return a
+
+
+def bin_kppi(n1d, L, kedges, pimax, Npi, weights, dtype=np.float32, fourier=True, nthread=MAX_THREADS):
+    """Mean and mode count in (k_perp, pi) bins of an rfft-layout grid (or, fourier=False, a real-space grid)
+    (:303-412) -> (weighted_counts (Nk, Npi) float32, counts (Nk, Npi) int64)"""
+    w = _grid_f4(weights)
+    ke = np.ascontiguousarray(kedges, dtype=np.float64)
+    Nk = len(ke) - 1
+    mean = np.zeros((Nk, Npi), dtype=np.float32)
+    counts = np.zeros((Nk, Npi), dtype=np.int64)
+    check(_lib.lib().abacus_bin_kppi(ptr(w), int(n1d), int(w.shape[2]), C.c_double(L), ptr(ke), Nk, C.c_double(pimax),
+                                     int(Npi), int(bool(fourier)), ptr(mean), ptr(counts)))
+    return mean.astype(dtype, copy=False), counts
+
+
+def project_3d_to_poles(k_bin_edges, raw_p3d, Lbox, poles):
+    """Multipoles of a 3-D power spectrum given on the rfftn grid (:415-448) -> (binned_poles (Np, Nk), Npoles (Nk,))"""
+    assert np.max(poles) <= 10, 'numba implementation works up to ell = 10'
+    w = _grid_f4(raw_p3d)
+    n = w.shape[0]
+    ke = np.ascontiguousarray(k_bin_edges, dtype=np.float64)
+    me = np.array([0.0, 1.0])
+    po = np.ascontiguousarray(poles, dtype=np.int64)
+    power, N_mode, bp, Nmp, k_avg = _alloc_outputs(len(ke) - 1, 1, len(po))
+    check(_lib.lib().abacus_bin_weights(ptr(w), n, int(w.shape[2]), C.c_double(Lbox), 1, ptr(ke), len(ke) - 1, ptr(me), 1,
+                                        ptr(po), len(po), C.c_double(float(Lbox) ** 3), ptr(power), ptr(N_mode), ptr(bp),
+                                        ptr(Nmp), ptr(k_avg)))
+    return bp, Nmp
+
+
+def pk_to_xi(Pk, Lbox, r_bins, poles=[0, 2, 4]):
+    """Correlation-function multipoles of a 3-D power spectrum (:620-660): irfftn on the device, then the multipoles of
+    Xi in r bins -> (r_binc, binned_poles (Np, Nr), Npoles (Nr,))"""
+    w = _grid_f4(Pk)
+    n = w.shape[0]
+    if w.shape[2] != n // 2 + 1:
+        raise ValueError('Pk must have the rfftn shape (n, n, n//2+1)')
+    rb = np.ascontiguousarray(r_bins, dtype=np.float64)
+    po = np.ascontiguousarray(poles, dtype=np.int64)
+    bp = np.zeros((len(po), len(rb) - 1), dtype=np.float32)
+    Nmp = np.zeros(len(rb) - 1, dtype=np.int64)
+    check(_lib.lib().abacus_pk_to_xi(ptr(w), n, C.c_double(Lbox), ptr(rb), len(rb) - 1, ptr(po), len(po), ptr(bp), ptr(Nmp)))
+    return (rb[1:] + rb[:-1]) * 0.5, bp, Nmp
+
+
+def expand_poles_to_3d(k_ell, P_ell, n1d, L, poles, dtype=np.float32):
+    """3-D power spectrum on the fundamental modes from its multipoles (:451-505) -> (n1d, n1d, n1d//2+1)"""
+    k_ell = np.ascontiguousarray(k_ell, dtype=np.float64)
+    P_ell = np.ascontiguousarray(P_ell, dtype=np.float64).reshape(len(poles), len(k_ell))
+    assert np.abs((k_ell[1] - k_ell[0]) - (k_ell[-1] - k_ell[-2])) < 1.0e-6
+    po = np.ascontiguousarray(poles, dtype=np.int64)
+    out = np.empty((n1d, n1d, n1d // 2 + 1), dtype=np.float32)
+    check(_lib.lib().abacus_expand_poles_to_3d(ptr(k_ell), ptr(P_ell), len(k_ell), int(n1d), C.c_double(L), ptr(po), len(po),
+                                               ptr(out)))
+    return out.astype(dtype, copy=False)
+
+
+def get_smoothing(n1d, L, R, dtype=np.float32):
+    """Gaussian kernel exp(-k^2 R^2 / 2) on the rfftn grid (:527-577)"""
+    out = np.empty((n1d, n1d, n1d // 2 + 1), dtype=np.float32)
+    check(_lib.lib().abacus_get_smoothing(int(n1d), C.c_double(L), C.c_double(R), ptr(out)))
+    return out.astype(dtype, copy=False)
+
+
+def get_delta_mu2(delta, n1d, dtype_c=np.complex64, dtype_f=np.float32):
+    """delta * mu^2 of a Fourier field on the rfftn grid (:580-617)"""
+    d = np.ascontiguousarray(delta, dtype=np.complex64)
+    out = np.empty_like(d)
+    check(_lib.lib().abacus_get_delta_mu2(ptr(d), int(n1d), ptr(out)))
+    return out.astype(dtype_c, copy=False)

@@ -63,6 +63,7 @@ struct SpecArgs {
     int64_t nrows;            // rows held in memory (n*n, or ny_local*n for a y-slab)
     int mode;                 // 0: raw fields (deltak API), 1: FFT output needing scale/interlace/compensation
     int interlaced, compensated, cross;
+    int linear;               // mode 0 only: the value binned is Re(a) (caller-supplied real weights), not |a|^2
     float inv_size;           // f32(1/M)            (:1058)
     float half_inv_size;      // f32(0.5/M)          (:934)
     const float2 *a, *as, *b, *bs;   // field 1 (+ shifted), field 2 (+ shifted); b == nullptr -> auto power
@@ -229,8 +230,8 @@ __device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int6
             p0 = va0.x * vb0.x + va0.y * vb0.y;   // Re(conj(a) b)  (:724)
             p1 = va1.x * vb1.x + va1.y * vb1.y;
         } else {
-            p0 = va0.x * va0.x + va0.y * va0.y;   // |a|^2          (:726)
-            p1 = va1.x * va1.x + va1.y * va1.y;
+            p0 = s.linear ? va0.x : va0.x * va0.x + va0.y * va0.y;   // |a|^2 (:726), or the caller's weight itself
+            p1 = s.linear ? va1.x : va1.x * va1.x + va1.y * va1.y;
         }
         tile[tpad<EPT>(e)] = p0;
         tile[tpad<EPT>(e + 1)] = p1;
@@ -438,11 +439,125 @@ __global__ void slab_unpack(const float4 *__restrict__ recv, float4 *__restrict_
     }
 }
 
+// ---- ZCV-facing helpers (analysis/power_spectrum.py:303-660): elementwise generators and (k_perp, pi) binning --------
+// real weights (n, n, zdim) -> complex (w, 0) rows of kzlen = n/2+1 (the binning kernel's caller-supplied layout)
+__global__ void helper_real_to_c64(const float *__restrict__ w, float2 *__restrict__ out, int n, int zdim, int kzlen,
+                                   float scale) {
+    const int64_t total = (int64_t)n * n * kzlen;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(q % kzlen);
+        const int64_t row = q / kzlen;
+        out[q] = make_float2(w[row * zdim + k] * scale, 0.f);
+    }
+}
+
+__device__ __forceinline__ void helper_mode(int64_t q, int n, int kzlen, int &i2j2, int &k) {
+    k = (int)(q % kzlen);
+    const int64_t row = q / kzlen;
+    const int j = fold((int)(row % n), n), i = fold((int)(row / n), n);
+    i2j2 = i * i + j * j;
+}
+
+// get_smoothing (:527-577): exp(-kmag2 * dk^2 * R^2 / 2) in float32
+__global__ void helper_smoothing(float *__restrict__ out, int n, float dk2, float R2) {
+    const int kzlen = n / 2 + 1;
+    const int64_t total = (int64_t)n * n * kzlen;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        int r2, k;
+        helper_mode(q, n, kzlen, r2, k);
+        const float kmag2 = (float)(r2 + k * k);
+        out[q] = expf(-kmag2 * dk2 * R2 / 2.0f);
+    }
+}
+
+// get_delta_mu2 (:580-617): delta * mu^2, mu^2 = f32(k^2) * kmag2**-1 (0 at k = 0)
+__global__ void helper_delta_mu2(const float2 *__restrict__ d, float2 *__restrict__ out, int n) {
+    const int kzlen = n / 2 + 1;
+    const int64_t total = (int64_t)n * n * kzlen;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        int r2, k;
+        helper_mode(q, n, kzlen, r2, k);
+        const float kmag2 = (float)(r2 + k * k);
+        const float mu2 = kmag2 > 0.f ? (float)(k * k) * (1.0f / kmag2) : 0.f;
+        out[q] = make_float2(d[q].x * mu2, d[q].y * mu2);
+    }
+}
+
+// expand_poles_to_3d (:451-505) with linear_interp (:508-537): Pk = sum_l interp(P_l)(|k|) * P_l(mu)
+__global__ void helper_expand_poles(float *__restrict__ out, int n, float dk, const float *__restrict__ k_ell,
+                                    const float *__restrict__ P_ell, int nk, BinArgs b, int np_all,
+                                    const int *__restrict__ pole_slot) {
+    const int kzlen = n / 2 + 1;
+    const int64_t total = (int64_t)n * n * kzlen;
+    const float x0 = k_ell[0], x1 = k_ell[nk - 1], dx = k_ell[1] - k_ell[0];
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        int r2, k;
+        helper_mode(q, n, kzlen, r2, k);
+        const float kmag2 = (float)(r2 + k * k);
+        const float mu2 = kmag2 > 0.f ? (float)(k * k) * (1.0f / kmag2) : 0.f;
+        const float xd = sqrtf(kmag2) * dk;
+        float acc = 0.f;
+        for (int ip = 0; ip < np_all; ip++) {
+            const float *y = P_ell + (int64_t)ip * nk;
+            float yd;
+            if (xd <= x0) yd = y[0];
+            else if (xd >= x1) yd = y[nk - 1];
+            else {
+                const float f = (xd - x0) / dx;
+                const int fl = (int)f;
+                yd = y[fl] + (f - (float)fl) * (y[fl + 1] - y[fl]);
+            }
+            const int sl = pole_slot[ip];
+            if (sl >= 0) {   // P_l(mu) from the (2l+1) P_l polynomial of the binning kernel
+                const float *c = b.polecoef[sl];
+                float Lq = c[b.poledeg[sl]];
+                for (int m = b.poledeg[sl] - 1; m >= 0; m--) Lq = Lq * mu2 + c[m];
+                yd *= Lq / (float)(4 * b.poledeg[sl] + 1);
+            }
+            acc += yd;
+        }
+        out[q] = acc;
+    }
+}
+
+// bin_kppi (:303-412): one workgroup per i; the j loop of the reference BREAKS at the first k_perp^2 >= last edge
+// (the rest of the row, negative frequencies included, is never visited), kz loop breaks at the last pi edge
+__global__ __launch_bounds__(256) void helper_bin_kppi(const float *__restrict__ w, int n, int zdim,
+                                                       const float *__restrict__ ke2, int Nk,
+                                                       const float *__restrict__ pe2, int Npi,
+                                                       unsigned long long *__restrict__ cnt, double *__restrict__ sum) {
+    __shared__ int jbreak;
+    const int i = blockIdx.x, kzlen = n / 2 + 1;
+    const int fi = fold(i, n), i2 = fi * fi;
+    if (threadIdx.x == 0) jbreak = n;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const int fj = fold(j, n);
+        if ((float)(i2 + fj * fj) >= ke2[Nk]) atomicMin(&jbreak, j);
+    }
+    __syncthreads();
+    const int jb = jbreak;
+    for (int q = threadIdx.x; q < jb * kzlen; q += 256) {
+        const int j = q / kzlen, k = q - j * kzlen;
+        const int fj = fold(j, n);
+        const float kp2 = (float)(i2 + fj * fj), kz2 = (float)(k * k);
+        if (kp2 < ke2[0] || kz2 >= pe2[Npi]) continue;
+        int bk = 0, bp = 0;
+        while (kp2 > ke2[bk + 1]) bk++;
+        while (kz2 > pe2[bp + 1]) bp++;
+        const double v = (double)w[((int64_t)i * n + j) * zdim + k];
+        atomicAdd(&cnt[bk * Npi + bp], k == 0 ? 1ull : 2ull);
+        atomicAdd(&sum[bk * Npi + bp], k == 0 ? v : 2.0 * v);
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 struct PowerCtx {
     std::map<int, hipfftHandle> plans;
     DevBuf mesh[4];       // field1, field1 shifted, field2, field2 shifted
     DevBuf W, phase, edges, accum, pos, pos2, w, w2;
+    DevBuf helper_in, helper_tab;          // staging of caller-supplied real grids / small tables (ZCV helpers)
+    std::map<int, hipfftHandle> c2r_plans;  // contiguous 3-D C2R (pk_to_xi)
     int phase_n = 0;
 };
 PowerCtx g_ctx;
@@ -529,6 +644,7 @@ void fill_spec(SpecArgs &s, int nmesh, int mode, int interlaced, const float *W_
     s.rowmode = 0;
     s.y0 = 0;
     s.permshift = 0;
+    s.linear = 0;
     s.nrows = (int64_t)nmesh * nmesh;
     s.mode = mode;
     s.interlaced = interlaced;
@@ -559,15 +675,16 @@ int pole_coefs(int l, float c[6]) {
 
 // normalisation of bin_kmu (:276-293) / calc_pk_from_deltak (:789-792) in float64 from the raw sums
 // raw layout: [cnt u64 Nk*Nmu][sum f64 Nk*Nmu][ksum f64 Nk*Nmu][pole f64 Np'*Nk], Np' = poles with l != 0 in order
+// dk: unit of |k| for k_avg (0: 2 pi / L); scale: factor on the means (0: L^3, calc_pk_from_deltak :789-792)
 int finalize_bins(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *poles, int Np_all, float *power,
-                  int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
+                  int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg, double dk_ = 0, double scale = 0) {
     const size_t nb = (size_t)Nk * Nmu;
     const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(raw);
     const double *sum = reinterpret_cast<const double *>(cnt + nb);
     const double *ksum = sum + nb;
     const double *pole = ksum + nb;
-    const double dk = 2.0 * M_PI / Lbox;
-    const double L3 = Lbox * Lbox * Lbox;
+    const double dk = dk_ > 0 ? dk_ : 2.0 * M_PI / Lbox;
+    const double L3 = scale > 0 ? scale : Lbox * Lbox * Lbox;
     int nz_index[MAX_POLES], nnz = 0;
     for (int q = 0; q < Np_all; q++) nz_index[q] = poles[q] != 0 ? nnz++ : -1;
     for (int i = 0; i < Nk; i++) {
@@ -593,10 +710,10 @@ int finalize_bins(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *
 
 int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu,
             const int64_t *poles, int Np_all, float *power, int64_t *N_mode, float *binned_poles,
-            int64_t *N_mode_poles, float *k_avg, void *raw_out = nullptr) {
+            int64_t *N_mode_poles, float *k_avg, void *raw_out = nullptr, double dk_ = 0, double scale = 0) {
     if (Nk < 1 || Nmu < 1) return fail("power: need at least one k bin and one mu bin");
     if (Np_all > MAX_POLES) return fail("power: more than %d multipoles requested", MAX_POLES);
-    const double dk = 2.0 * M_PI / Lbox;
+    const double dk = dk_ > 0 ? dk_ : 2.0 * M_PI / Lbox;
     BinArgs b;
     b.Nk = Nk;
     b.Nmu = Nmu;
@@ -670,7 +787,8 @@ int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const 
     std::vector<unsigned char> host(acc_bytes);
     HIP_TRY(hipMemcpyAsync(host.data(), g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
-    return finalize_bins(host.data(), Lbox, Nk, Nmu, poles, Np_all, power, N_mode, binned_poles, N_mode_poles, k_avg);
+    return finalize_bins(host.data(), Lbox, Nk, Nmu, poles, Np_all, power, N_mode, binned_poles, N_mode_poles, k_avg, dk,
+                         scale);
 }
 
 int upload_W(const float *W_host, int nmesh, const float **W_dev) {
@@ -907,9 +1025,180 @@ int abacus_bin_finalize(const void *raw, double Lbox, int Nk, int Nmu, const int
     return finalize_bins(raw, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
 }
 
+// ---- ZCV-facing helpers --------------------------------------------------------------------------------------
+namespace {
+int helper_grid(int64_t total) { return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(total, 256), 1), 256 * 32); }
+
+// bin a real (n, n, zdim) device grid like bin_kmu does a caller-supplied weights array
+int bin_real_grid(const float *d_w, int n, int zdim, float prescale, double Lbox, double dk, double scale,
+                  const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np, float *power,
+                  int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
+    const int kzlen = n / 2 + 1;
+    const int64_t total = (int64_t)n * n * kzlen;
+    ABACUS_TRY(g_ctx.mesh[1].reserve((size_t)total * 8));
+    ABACUS_LAUNCH("helper_real_to_c64", helper_real_to_c64, dim3(helper_grid(total)), dim3(256), 0, d_w,
+                  g_ctx.mesh[1].as<float2>(), n, zdim, kzlen, prescale);
+    SpecArgs s;
+    fill_spec(s, n, 0, 0, nullptr, false);
+    s.linear = 1;
+    s.a = g_ctx.mesh[1].as<float2>();
+    s.as = s.b = s.bs = nullptr;
+    return run_bin(s, Lbox, kedges, Nk, muedges, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
+                   dk, scale);
+}
+}  // namespace
+
+int abacus_bin_weights(const float *weights, int n1d, int zdim, double Lbox, int fourier, const double *kedges, int Nk,
+                       const double *muedges, int Nmu, const int64_t *poles, int Np, double scale, float *power,
+                       int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
+    ABACUS_TRY(ensure_init());
+    if (!weights || n1d < 2 || n1d > 32767 || zdim < n1d / 2 + 1) return fail("abacus_bin_weights: bad grid shape");
+    const size_t bytes = (size_t)n1d * n1d * zdim * 4;
+    ABACUS_TRY(g_ctx.helper_in.reserve(bytes));
+    HIP_TRY(hipMemcpyAsync(g_ctx.helper_in.p, weights, bytes, hipMemcpyHostToDevice, stream()));
+    const double dk = fourier ? 2.0 * M_PI / Lbox : Lbox / n1d;   // (:210-213)
+    return bin_real_grid(g_ctx.helper_in.as<float>(), n1d, zdim, 1.0f, Lbox, dk, scale > 0 ? scale : 1.0, kedges, Nk, muedges,
+                         Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
+}
+
+int abacus_pk_to_xi(const float *Pk, int n, double Lbox, const double *redges, int Nr, const int64_t *poles, int Np,
+                    float *binned_poles, int64_t *N_poles) {
+    ABACUS_TRY(ensure_init());
+    if (!Pk || n < 2 || n > 4096) return fail("abacus_pk_to_xi: bad grid size");
+    const int kzlen = n / 2 + 1;
+    // scipy's irfftn without `s` returns 2 (kzlen - 1) points along z: n for even n, n - 1 for odd n (:645); the
+    // reference then bins that (n, n, nz) grid with nmesh = n
+    const int nz = 2 * (kzlen - 1);
+    const int64_t nc = (int64_t)n * n * kzlen, nr = (int64_t)n * n * nz;
+    ABACUS_TRY(g_ctx.helper_in.reserve((size_t)nc * 4));
+    ABACUS_TRY(g_ctx.mesh[0].reserve((size_t)nc * 8));
+    ABACUS_TRY(g_ctx.mesh[2].reserve((size_t)nr * 4));
+    HIP_TRY(hipMemcpyAsync(g_ctx.helper_in.p, Pk, (size_t)nc * 4, hipMemcpyHostToDevice, stream()));
+    ABACUS_LAUNCH("helper_real_to_c64", helper_real_to_c64, dim3(helper_grid(nc)), dim3(256), 0, g_ctx.helper_in.as<float>(),
+                  g_ctx.mesh[0].as<float2>(), n, kzlen, kzlen, 1.0f);
+    auto it = g_ctx.c2r_plans.find(n);
+    if (it == g_ctx.c2r_plans.end()) {
+        hipfftHandle h;
+        ABACUS_TRY(fft_check(hipfftPlan3d(&h, n, n, nz, HIPFFT_C2R), "hipfftPlan3d(C2R)"));
+        it = g_ctx.c2r_plans.emplace(n, h).first;
+    }
+    ABACUS_TRY(fft_check(hipfftSetStream(it->second, stream()), "hipfftSetStream"));
+    prof_begin("hipfft_c2r");
+    const hipfftResult r = hipfftExecC2R(it->second, (hipfftComplex *)g_ctx.mesh[0].p, (hipfftReal *)g_ctx.mesh[2].p);
+    prof_end("hipfft_c2r");
+    ABACUS_TRY(fft_check(r, "hipfftExecC2R"));
+    // Xi = irfftn(Pk) (scipy normalises by the number of output points); multipoles in r bins, times nmesh^3 (:655-659)
+    std::vector<float> power(Nr), k_avg(Nr);
+    std::vector<int64_t> N_mode(Nr);
+    const double mu01[2] = {0.0, 1.0};
+    return bin_real_grid(g_ctx.mesh[2].as<float>(), n, nz, (float)(1.0 / ((double)n * n * nz)), Lbox, Lbox / n,
+                         (double)n * n * n, redges, Nr, mu01, 1, poles, Np, power.data(), N_mode.data(), binned_poles, N_poles,
+                         k_avg.data());
+}
+
+int abacus_bin_kppi(const float *weights, int n1d, int zdim, double Lbox, const double *kedges, int Nk, double pimax, int Npi,
+                    int fourier, float *mean, int64_t *counts) {
+    ABACUS_TRY(ensure_init());
+    if (!weights || n1d < 2 || zdim < n1d / 2 + 1 || Nk < 1 || Npi < 1) return fail("abacus_bin_kppi: bad arguments");
+    const double dk = fourier ? 2.0 * M_PI / Lbox : Lbox / n1d;
+    std::vector<float> e((size_t)Nk + 1 + Npi + 1);
+    for (int q = 0; q <= Nk; q++) e[q] = (float)((kedges[q] / dk) * (kedges[q] / dk));
+    for (int q = 0; q <= Npi; q++) {   // np.linspace(0, pimax, Npi + 1) / dk, squared, float32 (:370)
+        const double pe = (q == Npi ? pimax : pimax * ((double)q / Npi)) / dk;
+        e[Nk + 1 + q] = (float)(pe * pe);
+    }
+    const size_t bytes = (size_t)n1d * n1d * zdim * 4, nb = (size_t)Nk * Npi;
+    ABACUS_TRY(g_ctx.helper_in.reserve(bytes));
+    ABACUS_TRY(g_ctx.helper_tab.reserve(e.size() * 4));
+    ABACUS_TRY(g_ctx.accum.reserve(nb * 16));
+    HIP_TRY(hipMemcpyAsync(g_ctx.helper_in.p, weights, bytes, hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemcpyAsync(g_ctx.helper_tab.p, e.data(), e.size() * 4, hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemsetAsync(g_ctx.accum.p, 0, nb * 16, stream()));
+    unsigned long long *d_cnt = g_ctx.accum.as<unsigned long long>();
+    double *d_sum = reinterpret_cast<double *>(d_cnt + nb);
+    ABACUS_LAUNCH("helper_bin_kppi", helper_bin_kppi, dim3(n1d), dim3(256), 0, g_ctx.helper_in.as<float>(), n1d, zdim,
+                  g_ctx.helper_tab.as<float>(), Nk, g_ctx.helper_tab.as<float>() + Nk + 1, Npi, d_cnt, d_sum);
+    std::vector<unsigned long long> h_cnt(nb);
+    std::vector<double> h_sum(nb);
+    HIP_TRY(hipMemcpyAsync(h_cnt.data(), d_cnt, nb * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemcpyAsync(h_sum.data(), d_sum, nb * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    for (size_t q = 0; q < nb; q++) {
+        counts[q] = (int64_t)h_cnt[q];
+        mean[q] = (float)(h_cnt[q] ? h_sum[q] / (double)h_cnt[q] : h_sum[q]);
+    }
+    return 0;
+}
+
+int abacus_get_smoothing(int n1d, double Lbox, double R, float *out) {
+    ABACUS_TRY(ensure_init());
+    if (!out || n1d < 2) return fail("abacus_get_smoothing: bad arguments");
+    const int64_t total = (int64_t)n1d * n1d * (n1d / 2 + 1);
+    ABACUS_TRY(g_ctx.helper_in.reserve((size_t)total * 4));
+    const float dk = (float)(2.0 * M_PI / Lbox);
+    ABACUS_LAUNCH("helper_smoothing", helper_smoothing, dim3(helper_grid(total)), dim3(256), 0, g_ctx.helper_in.as<float>(),
+                  n1d, dk * dk, (float)(R * R));
+    HIP_TRY(hipMemcpyAsync(out, g_ctx.helper_in.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_get_delta_mu2(const void *delta_c64, int n1d, void *out_c64) {
+    ABACUS_TRY(ensure_init());
+    if (!delta_c64 || !out_c64 || n1d < 2) return fail("abacus_get_delta_mu2: bad arguments");
+    const int64_t total = (int64_t)n1d * n1d * (n1d / 2 + 1);
+    ABACUS_TRY(g_ctx.mesh[0].reserve((size_t)total * 8));
+    ABACUS_TRY(g_ctx.mesh[1].reserve((size_t)total * 8));
+    HIP_TRY(hipMemcpyAsync(g_ctx.mesh[0].p, delta_c64, (size_t)total * 8, hipMemcpyHostToDevice, stream()));
+    ABACUS_LAUNCH("helper_delta_mu2", helper_delta_mu2, dim3(helper_grid(total)), dim3(256), 0, g_ctx.mesh[0].as<float2>(),
+                  g_ctx.mesh[1].as<float2>(), n1d);
+    HIP_TRY(hipMemcpyAsync(out_c64, g_ctx.mesh[1].p, (size_t)total * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_expand_poles_to_3d(const double *k_ell, const double *P_ell, int nk, int n1d, double Lbox, const int64_t *poles,
+                              int Np, float *out) {
+    ABACUS_TRY(ensure_init());
+    if (!k_ell || !P_ell || !poles || !out || nk < 2 || n1d < 2 || Np < 1 || Np > MAX_POLES)
+        return fail("abacus_expand_poles_to_3d: bad arguments");
+    if (std::fabs((k_ell[1] - k_ell[0]) - (k_ell[nk - 1] - k_ell[nk - 2])) >= 1.0e-6)
+        return fail("abacus_expand_poles_to_3d: k_ell must be equidistant (:475)");
+    BinArgs b;
+    memset(&b, 0, sizeof b);
+    std::vector<int> slot(Np, -1);
+    for (int q = 0; q < Np; q++)
+        if (poles[q] != 0) {
+            ABACUS_TRY(pole_coefs((int)poles[q], b.polecoef[b.Np]));
+            b.poledeg[b.Np] = (int)poles[q] / 2;
+            slot[q] = b.Np++;
+        }
+    std::vector<float> tab((size_t)nk * (Np + 1));
+    for (int m = 0; m < nk; m++) tab[m] = (float)k_ell[m];
+    for (int q = 0; q < Np; q++)
+        for (int m = 0; m < nk; m++) tab[(size_t)(q + 1) * nk + m] = (float)P_ell[(size_t)q * nk + m];
+    const int64_t total = (int64_t)n1d * n1d * (n1d / 2 + 1);
+    ABACUS_TRY(g_ctx.helper_in.reserve((size_t)total * 4));
+    ABACUS_TRY(g_ctx.helper_tab.reserve(tab.size() * 4 + (size_t)Np * 4 + 64));
+    float *d_tab = g_ctx.helper_tab.as<float>();
+    int *d_slot = reinterpret_cast<int *>(d_tab + tab.size());
+    HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemcpyAsync(d_slot, slot.data(), (size_t)Np * 4, hipMemcpyHostToDevice, stream()));
+    ABACUS_LAUNCH("helper_expand_poles", helper_expand_poles, dim3(helper_grid(total)), dim3(256), 0,
+                  g_ctx.helper_in.as<float>(), n1d, (float)(2.0 * M_PI / Lbox), (const float *)d_tab, (const float *)(d_tab + nk),
+                  nk, b, Np, (const int *)d_slot);
+    HIP_TRY(hipMemcpyAsync(out, g_ctx.helper_in.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
 int abacus_power_release(void) {
     for (auto &kv : g_ctx.plans) (void)hipfftDestroy(kv.second);
     g_ctx.plans.clear();
+    for (auto &kv : g_ctx.c2r_plans) (void)hipfftDestroy(kv.second);
+    g_ctx.c2r_plans.clear();
+    ABACUS_TRY(g_ctx.helper_in.release());
+    ABACUS_TRY(g_ctx.helper_tab.release());
     for (auto &m : g_ctx.mesh) ABACUS_TRY(m.release());
     for (DevBuf *b : {&g_ctx.W, &g_ctx.phase, &g_ctx.edges, &g_ctx.accum, &g_ctx.pos, &g_ctx.pos2, &g_ctx.w, &g_ctx.w2})
         ABACUS_TRY(b->release());

@@ -270,6 +270,30 @@ int64_t abacus_bin_raw_bytes(int Nk, int Nmu, const int64_t *poles, int Np);
 int abacus_bin_finalize(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *poles, int Np, float *power,
                         int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg);
 
+/* ---------------------------------------------------------------- ZCV-facing spectrum helpers ----------- */
+/*
+ * replaces the remaining Numba kernels of analysis/power_spectrum.py that the control-variates code calls
+ * (zcv/tools_cv.py:320,805-923, zcv/tracer_power.py:456).  Grids are host arrays in the rfftn layout (n, n, n/2+1)
+ * unless a z-extent `zdim` is given ((n, n, n) real-space grids: zdim = n, only k <= n/2 is read, like the reference).
+ */
+/* bin_kmu (:150-300) of a caller-supplied real grid: project_3d_to_poles (:415-448) with one mu bin and scale = L^3.
+ * fourier = 0 bins a configuration-space grid (dk = L/n, :212).  scale multiplies the means (<= 0: 1). */
+int abacus_bin_weights(const float *weights, int n1d, int zdim, double Lbox, int fourier, const double *kedges, int Nk,
+                       const double *muedges, int Nmu, const int64_t *poles, int Np, double scale, float *power,
+                       int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg);
+/* pk_to_xi (:620-660): Xi = irfftn(Pk) on the device (hipFFT C2R), multipoles of Xi in r bins, times nmesh^3 */
+int abacus_pk_to_xi(const float *Pk, int n, double Lbox, const double *redges, int Nr, const int64_t *poles, int Np,
+                    float *binned_poles, int64_t *N_poles);
+/* bin_kppi (:303-412): mean and mode count per (k_perp, pi) bin, pi edges linspace(0, pimax, Npi+1).  The reference's j
+ * loop breaks at the first k_perp beyond the last edge (the rest of that i row is never visited): kept. */
+int abacus_bin_kppi(const float *weights, int n1d, int zdim, double Lbox, const double *kedges, int Nk, double pimax, int Npi,
+                    int fourier, float *mean, int64_t *counts);
+/* get_smoothing (:527-577), get_delta_mu2 (:580-617), expand_poles_to_3d (:451-505) */
+int abacus_get_smoothing(int n1d, double Lbox, double R, float *out);
+int abacus_get_delta_mu2(const void *delta_c64, int n1d, void *out_c64);
+int abacus_expand_poles_to_3d(const double *k_ell, const double *P_ell, int nk, int n1d, double Lbox, const int64_t *poles,
+                              int Np, float *out);
+
 /* ---------------------------------------------------------------- pair counting ------------------------ */
 /*
  * replaces: Corrfunc.theory.DD / DDrppi / DDsmu as called at analysis/tpcf_corrfunc.py:144-156,164-179,

@@ -209,3 +209,56 @@ def test_get_field(paste, d):
     b = oracle.get_field(pos.copy(), box, nmesh, paste, w=w, d=d, nthread=2)
     assert a.shape == (nmesh,) * 3 and a.dtype == np.float32
     np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5 * np.abs(b).max())
+
+
+@pytest.mark.parametrize('n', [16, 21])
+def test_zcv_helpers_against_reference_goldens(n):
+    """bin_kppi, project_3d_to_poles, pk_to_xi, expand_poles_to_3d, get_smoothing, get_delta_mu2 on the device against the
+    outputs of the shimmed reference (tests/golden/power_helpers.npz)"""
+    from abacusutils_amd.analysis import power_spectrum as ps
+    g = load_golden('power_helpers')
+    L = float(g['meta.L'])
+    p3d, ke, xi, re = g[f'n{n}.p3d'], g[f'n{n}.kedges'], g[f'n{n}.xi'], g[f'n{n}.redges']
+    m, c = ps.bin_kppi(n, L, ke, np.pi * n / L * 1.01, 5, p3d)
+    np.testing.assert_array_equal(c, g[f'n{n}.kppi.counts'])
+    np.testing.assert_allclose(m, g[f'n{n}.kppi.mean'], rtol=2e-5)
+    m, c = ps.bin_kppi(n, L, re, L / 2 * 1.01, 4, xi, fourier=False)
+    np.testing.assert_array_equal(c, g[f'n{n}.rppi.counts'])
+    np.testing.assert_allclose(m, g[f'n{n}.rppi.mean'], rtol=2e-4, atol=2e-5)
+    bp, npo = ps.project_3d_to_poles(ke, p3d, L, [0, 2, 4])
+    np.testing.assert_array_equal(npo, g[f'n{n}.p2poles.N'])
+    np.testing.assert_allclose(bp, g[f'n{n}.p2poles.poles'], rtol=2e-5, atol=1e-5 * np.abs(g[f'n{n}.p2poles.poles']).max())
+    rb, xp, nr = ps.pk_to_xi(p3d.copy(), L, re, poles=[0, 2, 4])
+    np.testing.assert_allclose(rb, g[f'n{n}.pk2xi.r'])
+    np.testing.assert_array_equal(nr, g[f'n{n}.pk2xi.N'])
+    np.testing.assert_allclose(xp, g[f'n{n}.pk2xi.poles'], rtol=2e-4, atol=2e-5 * np.abs(g[f'n{n}.pk2xi.poles']).max())
+    np.testing.assert_allclose(ps.expand_poles_to_3d(g[f'n{n}.expand.k_ell'], g[f'n{n}.expand.P_ell'], n, L, [0, 2, 4]),
+                               g[f'n{n}.expand.Pk'], rtol=2e-5, atol=2e-4 * np.abs(g[f'n{n}.expand.Pk']).max())
+    np.testing.assert_allclose(ps.get_smoothing(n, L, 7.5), g[f'n{n}.smoothing'], rtol=3e-6)
+    np.testing.assert_allclose(ps.get_delta_mu2(g[f'n{n}.delta'], n), g[f'n{n}.delta_mu2'], rtol=2e-6, atol=1e-7)
+
+
+def test_zcv_helpers_larger_mesh_against_oracle():
+    from abacusutils_amd.analysis import power_spectrum as ps
+    from oracle import oracle
+    n, L = 96, 700.0
+    rng = np.random.default_rng(3)
+    p3d = (rng.random((n, n, n // 2 + 1), dtype=np.float32) * 50).astype(np.float32)
+    ke = np.linspace(0.0, np.pi * n / L, 25)
+    bp, npo = ps.project_3d_to_poles(ke, p3d, L, [0, 2, 4])
+    bo, no = oracle.project_3d_to_poles(ke, p3d, L, [0, 2, 4], nthread=4)
+    np.testing.assert_array_equal(npo, no)
+    np.testing.assert_allclose(bp, bo, rtol=2e-5, atol=1e-5 * np.abs(bo).max())
+    re = np.linspace(0.0, 150.0, 16)
+    _, xp, nr = ps.pk_to_xi(p3d.copy(), L, re)
+    _, xo, no = oracle.pk_to_xi(p3d.copy(), L, re, nthread=4)
+    np.testing.assert_array_equal(nr, no)
+    np.testing.assert_allclose(xp, xo, rtol=2e-4, atol=3e-5 * np.abs(xo).max())
+    m, c = ps.bin_kppi(n, L, ke, np.pi * n / L * 1.01, 12, p3d)
+    mo, co = oracle.bin_kppi(n, L, ke, np.pi * n / L * 1.01, 12, p3d)
+    np.testing.assert_array_equal(c, co)
+    np.testing.assert_allclose(m, mo, rtol=2e-5)
+    m, c = ps.bin_kppi(n, L, ke, 0.2, 6, p3d)            # pi range shorter than the grid: the kz loop breaks
+    mo, co = oracle.bin_kppi(n, L, ke, 0.2, 6, p3d)
+    np.testing.assert_array_equal(c, co)
+    np.testing.assert_allclose(m, mo, rtol=2e-5)
