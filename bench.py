@@ -42,14 +42,14 @@ def parse():
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-pk', action='store_true', help='skip the secondary P(k) measurement')
     ap.add_argument('--no-slab', action='store_true', help='N > 1: skip the slab-decomposed P(k) leg (RCCL all-to-all)')
-    ap.add_argument('--slab-timeout', type=float, default=240.0, help='seconds before the slab leg is abandoned')
+    ap.add_argument('--slab-timeout', type=float, default=150.0, help='seconds before one attempt of the slab leg is abandoned')
     return ap.parse_args()
 
 
 class Dist:
     """barrier / max-reduce across ranks; torch.distributed only when WORLD_SIZE > 1"""
 
-    def __init__(self):
+    def __init__(self, init_method=None):
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -58,7 +58,7 @@ class Dist:
             import torch  # noqa: F401  (imported BEFORE libabacus_hip.so so both share one HIP runtime)
             import torch.distributed as td
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            td.init_process_group(backend='gloo', rank=self.rank, world_size=self.world)
+            td.init_process_group(backend='gloo', rank=self.rank, world_size=self.world, init_method=init_method)
             self.td = td
 
     def barrier(self):
@@ -80,6 +80,14 @@ class Dist:
         t = torch.tensor([x], dtype=torch.float64)
         self.td.all_reduce(t, op=self.td.ReduceOp.SUM)
         return float(t[0])
+
+    def broadcast_int(self, x):
+        if not self.td:
+            return int(x)
+        import torch
+        t = torch.tensor([int(x)], dtype=torch.int64)
+        self.td.broadcast(t, src=0)
+        return int(t[0])
 
     def finish(self):
         if self.td:
@@ -215,6 +223,39 @@ def cpu_model():
     return 'unknown'
 
 
+def run_slab_children(args, dist, collectives):
+    """every rank starts `bench_pk.py --slab-child` (own rendezvous port, chosen by rank 0), waits for it with a
+    timeout and reports rank 0's result line; children are ended by exact PID on timeout"""
+    import socket
+    import subprocess
+    port = 0
+    if dist.rank == 0:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    port = dist.broadcast_int(port)
+    env = {k: v for k, v in os.environ.items() if not k.startswith('TORCHELASTIC')}
+    cmd = [sys.executable, os.path.join(REPO, 'bench_pk.py'), '--slab-child', '--store-port', str(port),
+           '--collectives', collectives, '--nmesh', str(args.nmesh), '--npk', str(args.npk), '--steps', str(min(args.steps, 5))]
+    res, ok = None, False
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.slab_timeout)
+        for line in r.stdout.splitlines():
+            if line.startswith('SLAB-RESULT '):
+                res = json.loads(line[len('SLAB-RESULT '):])
+        ok = r.returncode == 0
+        if dist.rank == 0:
+            if res is None:
+                res = {'error': f'child exit code {r.returncode}: ' + r.stderr[-400:]}
+            ok = ok and 'error' not in res
+    except subprocess.TimeoutExpired:
+        res = {'error': f'abandoned after {args.slab_timeout:.0f} s'}
+    bad = int(dist.sum(0.0 if ok else 1.0))          # collective: every rank takes the same retry decision
+    if bad and 'error' not in (res or {}):
+        res = {'error': f'{bad} rank(s) failed'}
+    return res or {}
+
+
 def main():
     args = parse()
     dist = Dist()
@@ -239,24 +280,13 @@ def main():
         out = bench_pk(args, dist, headline=True)
     if dist.world > 1 and not args.no_slab and not args.no_pk:
         # One nmesh^3 mesh decomposed over the N GPUs (BASELINE config 4): ghost exchange, all-to-all pencil transpose
-        # and histogram all-reduce over RCCL.  The headline above is complete at this point; a watchdog prints it and
-        # ends the process if this leg does not finish, so a stuck collective cannot take the bench line down.
-        import threading
-
-        def give_up():
-            if dist.rank == 0:
-                out['pk_slab'] = {'error': f'abandoned after {args.slab_timeout:.0f} s'}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        guard = threading.Timer(args.slab_timeout, give_up)
-        guard.daemon = True
-        guard.start()
-        try:
-            from bench_pk import bench_pk_slab
-            res = bench_pk_slab(args, dist)
-        except Exception as e:
-            res = {'error': repr(e)}
-        guard.cancel()
+        # and histogram all-reduce over RCCL.  Runs in a child process per rank: the headline above is complete, and a
+        # fault or a stuck collective in this leg must not take the bench line down with it.
+        res = run_slab_children(args, dist, 'device')
+        if 'error' in res:
+            first = res
+            res = run_slab_children(args, dist, 'host')
+            res['device_collectives_error'] = first['error']
         if dist.rank == 0:
             out['pk_slab'] = res
     if dist.rank == 0:

@@ -5,6 +5,7 @@ protocol): N = 1e8 particles on a 1024^3 mesh by default; `--nmesh 2048` is the 
 A step = one full calc_power chain (non-interlaced, uncompensated like scripts/power/bench.py:31) with particles
 already resident in HBM; the spectrum never leaves the device.
 """
+import json
 import os
 import time
 
@@ -169,8 +170,12 @@ def bench_pk_slab(args, dist):
     W, r = dist.world, dist.rank
     ndev = max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dist.local_rank % ndev)
-    nccl = td.new_group(backend='nccl')
-    comm = sp.SlabComm(device_collectives=True, group=nccl, host_group=td.group.WORLD)
+    device = getattr(args, 'collectives', 'device') == 'device'
+    if device:
+        nccl = td.new_group(backend='nccl')
+        comm = sp.SlabComm(device_collectives=True, group=nccl, host_group=td.group.WORLD)
+    else:       # transposes and ghost planes staged through the host over gloo (also what runs 2 ranks on ONE GPU)
+        comm = sp.SlabComm(device_collectives=False, group=td.group.WORLD)
     backend = sp.HipSlabBackend(keep_buffers=True)
     n_local = ntot // W
     rng = np.random.default_rng(300 + r)
@@ -197,8 +202,9 @@ def bench_pk_slab(args, dist):
     dpos.free()
     return {'metric': f'wall-clock of one {nmesh}^3 TSC+FFT P(k) slab-decomposed over {W} GPUs', 'value': dt * 1e3,
             'unit': 'ms', 'n_gpus': W, 'steps': steps, 'scaling': 'strong',
-            'config': {'workload': f'{n_local * W:.0e} uniform particles in x-slabs, nmesh {nmesh}, TSC, non-interlaced, '
-                                   'device collectives (RCCL all-to-all + ring send/recv + all-reduce)'},
+            'config': {'workload': f'{n_local * W:.0e} uniform particles in x-slabs, nmesh {nmesh}, TSC, non-interlaced, ' +
+                                   ('device collectives (RCCL all-to-all + ring send/recv + all-reduce)' if device else
+                                    'collectives staged through the host (gloo)')},
             'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot)}
 
 
@@ -241,3 +247,34 @@ def bench_pairs(args, dist):
         out['cpu_baseline'] = {'value': float(m) * m / tc, 'unit': 'pair separations/s (brute force, all N^2 pairs)',
                                'cores': cores, 'kind': 'port', 'sample': f'{m} of the points, {tc * 1e3:.0f} ms'}
     return out
+
+
+def slab_child_main():
+    """`python bench_pk.py --slab-child --store-port P ...`: the slab-decomposed leg as a process of its own, one per
+    rank, started by bench.py AFTER the headline is measured - a fault inside a collective then ends this process, not
+    the one that prints the bench line.  Rendezvous on 127.0.0.1:P (own TCP store, not torchrun's agent store)."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--slab-child', action='store_true')
+    ap.add_argument('--store-port', type=int, required=True)
+    ap.add_argument('--collectives', default='device', choices=['device', 'host'])
+    ap.add_argument('--nmesh', type=int, default=2048)
+    ap.add_argument('--npk', type=int, default=100_000_000)
+    ap.add_argument('--steps', type=int, default=3)
+    args = ap.parse_args()
+    import torch  # noqa: F401  (before libabacus_hip.so)
+    from bench import Dist
+    from abacusutils_amd import _lib
+    dist = Dist(init_method=f'tcp://127.0.0.1:{args.store_port}')
+    _lib.set_device(dist.local_rank % max(_lib.device_count(), 1))
+    try:
+        res = bench_pk_slab(args, dist)
+    except Exception as e:
+        res = {'error': repr(e)}
+    if dist.rank == 0:
+        print('SLAB-RESULT ' + json.dumps(res), flush=True)
+    dist.finish()
+
+
+if __name__ == '__main__':
+    slab_child_main()

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 2 --steps 3 --warmup 1 --nhalo 1000000 --npart 1000000 --nmesh 256 --npk 2000000 --no-cpu --slab-timeout 40 > gpurun_out/bench2.json 2> gpurun_out/bench2.err
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 2 --steps 3 --warmup 1 --nhalo 1000000 --npart 1000000 --nmesh 256 --npk 2000000 --no-cpu --slab-timeout 90 > gpurun_out/bench2.json 2> gpurun_out/bench2.err
 echo "rc=$?"; python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/bench2.json').read().strip().splitlines()[-1])
