@@ -1,0 +1,423 @@
+// Catalogue-side kernels upstream of the HOD: the bit-unpacking of Abacus particle subsamples
+// and the local mass environment that prepare_sim ranks halos by.  gfx950 only; all three are streaming / cell-list
+// kernels bounded by HBM bandwidth and latency, no matrix work.
+//
+//   unpack_rvint_k   rvint (3 x int32: 20-bit position | 12-bit velocity) -> pos, vel          (bitpacked.py:32-116)
+//   unpack_pids_k    64-bit aux word -> pid, lagr_idx, lagr_pos, tagged, density               (bitpacked.py:118-330)
+//   menv_*           M(< r_outer) - M(< r_inner) of neighbour halo mass around every halo above mcut (hod/menv.py:19-87;
+//                    the reference's KD-tree ball query + gather-sum becomes a cell list with cells >= max r_outer)
+//
+// Arithmetic follows the reference's typing: the products are formed in float64 and rounded once into the output
+// dtype (int64 * float64 for rvint; uint64 * float32 -> float64 for lagr_pos), so float32 outputs are bit-equal.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/abacus_hip.h"
+#include "common.hpp"
+
+namespace abacus {
+int exclusive_scan_u32(unsigned int *counters, int64_t n, int64_t *out, DevBuf &scratch, int zero_counters);
+}
+
+using namespace abacus;
+
+namespace {
+
+bool on_device(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // plain host memory: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+// input staging: device pointers are used in place, host buffers are copied into `buf`
+template <class T>
+int stage_in(const T *src, size_t count, DevBuf &buf, const T **out) {
+    if (!src || on_device(src)) {
+        *out = src;
+        return 0;
+    }
+    ABACUS_TRY(buf.reserve(std::max<size_t>(count, 1) * sizeof(T)));
+    HIP_TRY(hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, stream()));
+    *out = buf.as<T>();
+    return 0;
+}
+// output staging: a device destination is written directly; for a host destination the kernel writes `buf`
+struct OutStage {
+    void *host = nullptr, *dev = nullptr;
+    size_t bytes = 0;
+    int prepare(void *dst, size_t nbytes, DevBuf &buf) {
+        host = dev = nullptr;
+        bytes = nbytes;
+        if (!dst) return 0;
+        if (on_device(dst)) {
+            dev = dst;
+            return 0;
+        }
+        ABACUS_TRY(buf.reserve(std::max<size_t>(nbytes, 16)));
+        dev = buf.p;
+        host = dst;
+        return 0;
+    }
+    int finish() {
+        if (host && bytes) HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream()));
+        return 0;
+    }
+};
+
+constexpr int UB = 256;
+
+// ---- rvint: element-wise over the flat (3N) array, 4 elements (16 B) per thread -------------------------------------
+// pos = (x >> 12) * (boxsize / 1e6)  [arithmetic shift], vel = ((x & 0xFFF) - 2048) * (6000 / 2048); both in float64
+template <class F>
+__global__ __launch_bounds__(UB) void unpack_rvint_k(const int *__restrict__ in, int64_t n3, double posscale,
+                                                     double velscale, F *__restrict__ pos, F *__restrict__ vel) {
+    const int64_t nvec = n3 / 4;
+    for (int64_t v = (int64_t)blockIdx.x * UB + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * UB) {
+        const int4 x = reinterpret_cast<const int4 *>(in)[v];
+        const int e[4] = {x.x, x.y, x.z, x.w};
+        F p[4], u[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            p[q] = (F)((double)(e[q] >> 12) * posscale);
+            u[q] = (F)((double)((e[q] & 0xFFF) - 2048) * velscale);
+        }
+        if (pos) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) pos[4 * v + q] = p[q];   // contiguous per thread: merged into 16/32-B stores
+        }
+        if (vel) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) vel[4 * v + q] = u[q];
+        }
+    }
+    // tail (n3 mod 4 elements)
+    const int64_t t = nvec * 4 + (int64_t)blockIdx.x * UB + threadIdx.x;
+    if (t < n3) {
+        const int e = in[t];
+        if (pos) pos[t] = (F)((double)(e >> 12) * posscale);
+        if (vel) vel[t] = (F)((double)((e & 0xFFF) - 2048) * velscale);
+    }
+}
+
+// ---- packed PIDs: one particle per thread -----------------------------------------------------------------------------
+constexpr unsigned long long AUXX = 0x7FFFull, AUXY = 0x7FFF0000ull, AUXZ = 0x7FFF00000000ull;
+constexpr unsigned long long AUXDENS = 0x07FE000000000000ull;
+
+template <class F>
+__global__ __launch_bounds__(UB) void unpack_pids_k(const unsigned long long *__restrict__ packed, int64_t n,
+                                                    double inv_ppd, double half, long long *__restrict__ pid,
+                                                    F *__restrict__ lagr_pos, short *__restrict__ lagr_idx,
+                                                    unsigned char *__restrict__ tagged, F *__restrict__ density) {
+    for (int64_t i = (int64_t)blockIdx.x * UB + threadIdx.x; i < n; i += (int64_t)gridDim.x * UB) {
+        const unsigned long long a = packed[i];
+        const unsigned long long ix = a & AUXX, iy = (a & AUXY) >> 16, iz = (a & AUXZ) >> 32;
+        if (pid) pid[i] = (long long)(a & (AUXX | AUXY | AUXZ));
+        if (lagr_idx) {
+            lagr_idx[3 * i + 0] = (short)ix;
+            lagr_idx[3 * i + 1] = (short)iy;
+            lagr_idx[3 * i + 2] = (short)iz;
+        }
+        if (lagr_pos) {   // uint64 * float32 is float64 arithmetic in the reference (:312-314); one rounding on store
+            lagr_pos[3 * i + 0] = (F)((double)ix * inv_ppd - half);
+            lagr_pos[3 * i + 1] = (F)((double)iy * inv_ppd - half);
+            lagr_pos[3 * i + 2] = (F)((double)iz * inv_ppd - half);
+        }
+        if (tagged) tagged[i] = (unsigned char)((a >> 48) & 1ull);
+        if (density) {
+            const unsigned long long d = (a & AUXDENS) >> 49;
+            density[i] = (F)(d * d);
+        }
+    }
+}
+
+// ---- local mass environment --------------------------------------------------------------------------------------------
+struct MenvGrid {
+    int nc[3];
+    int periodic;
+    double lo[3], inv_cell[3], box;
+};
+
+// the reference's `pos = (pos + Lbox / 2.0) % Lbox` (menv.py:39) in the dtype of pos, with NumPy's remainder:
+// fmod, then + Lbox when the sign differs from the divisor's, +0 for an exact multiple
+template <class P>
+__device__ __forceinline__ P menv_wrap(P v, double box) {
+    const P L = (P)box, h = (P)(box / 2.0);
+    const P a = v + h;
+    P m = sizeof(P) == 4 ? (P)fmodf((float)a, (float)L) : (P)fmod((double)a, (double)L);
+    if (m != (P)0) {
+        if (m < (P)0) m += L;
+    } else {
+        m = (P)0;
+    }
+    return m;
+}
+
+template <class P>
+__device__ __forceinline__ int menv_cell(const MenvGrid &g, const P *pos, int64_t i, double (&x)[3]) {
+    int c[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        x[d] = (double)(g.periodic ? menv_wrap(pos[3 * i + d], g.box) : pos[3 * i + d]);
+        int q = (int)floor((x[d] - g.lo[d]) * g.inv_cell[d]);
+        c[d] = q < 0 ? 0 : (q >= g.nc[d] ? g.nc[d] - 1 : q);
+    }
+    return (c[0] * g.nc[1] + c[1]) * g.nc[2] + c[2];
+}
+
+template <class P>
+__global__ __launch_bounds__(UB) void menv_count(const P *__restrict__ pos, int64_t n, MenvGrid g,
+                                                 unsigned int *__restrict__ counts, unsigned int *__restrict__ cellid) {
+    for (int64_t i = (int64_t)blockIdx.x * UB + threadIdx.x; i < n; i += (int64_t)gridDim.x * UB) {
+        double x[3];
+        const int c = menv_cell(g, pos, i, x);
+        cellid[i] = (unsigned int)c;
+        atomicAdd(&counts[c], 1u);
+    }
+}
+
+// sorted record: x, y, z, mass (float64) + original index
+template <class P, class M>
+__global__ __launch_bounds__(UB) void menv_fill(const P *__restrict__ pos, const M *__restrict__ mass, int64_t n,
+                                                const unsigned int *__restrict__ cellid,
+                                                const int64_t *__restrict__ start, unsigned int *__restrict__ cursor,
+                                                double4 *__restrict__ rec, int *__restrict__ orig, int periodic,
+                                                double box) {
+    for (int64_t i = (int64_t)blockIdx.x * UB + threadIdx.x; i < n; i += (int64_t)gridDim.x * UB) {
+        const unsigned int c = cellid[i];
+        const int64_t s = start[c] + atomicAdd(&cursor[c], 1u);
+        P x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+        if (periodic) x = menv_wrap(x, box), y = menv_wrap(y, box), z = menv_wrap(z, box);
+        rec[s] = make_double4((double)x, (double)y, (double)z, (double)mass[i]);
+        orig[s] = (int)i;
+    }
+}
+
+// one thread per halo in cell order; halos at or below mcut return 0 (menv.py:43,84-85)
+template <class R>
+__global__ __launch_bounds__(UB) void menv_sum(const double4 *__restrict__ rec, const int *__restrict__ orig, int64_t n,
+                                               MenvGrid g, const int64_t *__restrict__ start,
+                                               const R *__restrict__ r_inner, int inner_is_array,
+                                               const R *__restrict__ r_outer, int outer_is_array, double mcut,
+                                               double *__restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * UB + threadIdx.x;
+    if (s >= n) return;
+    const double4 me = rec[s];
+    const int io = orig[s];
+    if (!(me.w > mcut)) {
+        out[io] = 0.0;
+        return;
+    }
+    const double ri = (double)r_inner[inner_is_array ? io : 0], ro = (double)r_outer[outer_is_array ? io : 0];
+    const double ri2 = ri * ri, ro2 = ro * ro;
+    const bool has_inner = ri >= 0.0, has_outer = ro >= 0.0;   // a negative radius matches nothing, like the tree query
+    int c[3];
+    {
+        const double x[3] = {me.x, me.y, me.z};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            int q = (int)floor((x[d] - g.lo[d]) * g.inv_cell[d]);
+            c[d] = q < 0 ? 0 : (q >= g.nc[d] ? g.nc[d] - 1 : q);
+        }
+    }
+    const double hb = 0.5 * g.box;
+    double so = 0.0, si = 0.0;
+    // neighbour range per dimension: the 3-cell stencil, or every cell when a periodic dimension has fewer than 3
+    int lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        if (g.periodic && g.nc[d] < 3) lo[d] = 0, hi[d] = g.nc[d] - 1;
+        else if (g.periodic) lo[d] = c[d] - 1, hi[d] = c[d] + 1;
+        else lo[d] = max(c[d] - 1, 0), hi[d] = min(c[d] + 1, g.nc[d] - 1);
+    }
+    for (int ax = lo[0]; ax <= hi[0]; ax++) {
+        const int cx = ax < 0 ? ax + g.nc[0] : (ax >= g.nc[0] ? ax - g.nc[0] : ax);
+        for (int ay = lo[1]; ay <= hi[1]; ay++) {
+            const int cy = ay < 0 ? ay + g.nc[1] : (ay >= g.nc[1] ? ay - g.nc[1] : ay);
+            // the z neighbours are adjacent cells in memory except across the periodic wrap: walk them one by one
+            for (int az = lo[2]; az <= hi[2]; az++) {
+                const int cz = az < 0 ? az + g.nc[2] : (az >= g.nc[2] ? az - g.nc[2] : az);
+                const int64_t cc = ((int64_t)cx * g.nc[1] + cy) * g.nc[2] + cz;
+                const int64_t j0 = start[cc], j1 = start[cc + 1];
+                for (int64_t j = j0; j < j1; j++) {
+                    const double4 o = rec[j];
+                    double dx = fabs(me.x - o.x), dy = fabs(me.y - o.y), dz = fabs(me.z - o.z);
+                    if (g.periodic) {
+                        if (dx > hb) dx = g.box - dx;
+                        if (dy > hb) dy = g.box - dy;
+                        if (dz > hb) dz = g.box - dz;
+                    }
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    if (has_outer && d2 <= ro2) so += o.w;
+                    if (has_inner && d2 <= ri2) si += o.w;
+                }
+            }
+        }
+    }
+    out[io] = so - si;
+}
+
+int grid_for(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, UB), 1), 8192); }
+
+}  // namespace
+
+extern "C" int abacus_unpack_rvint(const int32_t *intdata, int64_t n, double boxsize, int out_f64, void *posout,
+                                   void *velout) {
+    ABACUS_TRY(ensure_init());
+    if (n < 0 || (n > 0 && !intdata)) return fail("abacus_unpack_rvint: null input");
+    if (n == 0 || (!posout && !velout)) return 0;
+    static DevBuf b_in, b_pos, b_vel;
+    const int64_t n3 = 3 * n;
+    const size_t fs = out_f64 ? 8 : 4;
+    const int32_t *d_in;
+    ABACUS_TRY(stage_in(intdata, (size_t)n3, b_in, &d_in));
+    if (((uintptr_t)d_in & 15) != 0) return fail("abacus_unpack_rvint: device input must be 16-byte aligned");
+    OutStage op, ov;
+    ABACUS_TRY(op.prepare(posout, (size_t)n3 * fs, b_pos));
+    ABACUS_TRY(ov.prepare(velout, (size_t)n3 * fs, b_vel));
+    const double posscale = boxsize / 1e6, velscale = 6000.0 / 2048;   // (:104-105)
+    const int grid = grid_for(n3 / 4 + 4);
+    if (out_f64)
+        ABACUS_LAUNCH("unpack_rvint", unpack_rvint_k<double>, dim3(grid), dim3(UB), 0, d_in, n3, posscale, velscale,
+                      static_cast<double *>(op.dev), static_cast<double *>(ov.dev));
+    else
+        ABACUS_LAUNCH("unpack_rvint", unpack_rvint_k<float>, dim3(grid), dim3(UB), 0, d_in, n3, posscale, velscale,
+                      static_cast<float *>(op.dev), static_cast<float *>(ov.dev));
+    ABACUS_TRY(op.finish());
+    ABACUS_TRY(ov.finish());
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+extern "C" int abacus_unpack_pids(const uint64_t *packed, int64_t n, double box, int64_t ppd, int out_f64, int64_t *pid,
+                                  void *lagr_pos, int16_t *lagr_idx, uint8_t *tagged, void *density) {
+    ABACUS_TRY(ensure_init());
+    if (n < 0 || (n > 0 && !packed)) return fail("abacus_unpack_pids: null input");
+    if (ppd < 1) return fail("abacus_unpack_pids: ppd must be a positive integer");
+    if (n == 0) return 0;
+    static DevBuf b_in, b_pid, b_pos, b_idx, b_tag, b_den;
+    const size_t fs = out_f64 ? 8 : 4;
+    const uint64_t *d_in;
+    ABACUS_TRY(stage_in(packed, (size_t)n, b_in, &d_in));
+    OutStage o_pid, o_pos, o_idx, o_tag, o_den;
+    ABACUS_TRY(o_pid.prepare(pid, (size_t)n * 8, b_pid));
+    ABACUS_TRY(o_pos.prepare(lagr_pos, (size_t)n * 3 * fs, b_pos));
+    ABACUS_TRY(o_idx.prepare(lagr_idx, (size_t)n * 6, b_idx));
+    ABACUS_TRY(o_tag.prepare(tagged, (size_t)n, b_tag));
+    ABACUS_TRY(o_den.prepare(density, (size_t)n * fs, b_den));
+    // inv_ppd = float_dtype(box / ppd), half = float_dtype(box / 2) (:298-299), then float64 arithmetic
+    const double q = box / (double)ppd, h = box / 2;
+    const double inv_ppd = out_f64 ? q : (double)(float)q, half = out_f64 ? h : (double)(float)h;
+    const int grid = grid_for(n);
+    const unsigned long long *din = reinterpret_cast<const unsigned long long *>(d_in);
+    if (out_f64)
+        ABACUS_LAUNCH("unpack_pids", unpack_pids_k<double>, dim3(grid), dim3(UB), 0, din, n, inv_ppd, half,
+                      static_cast<long long *>(o_pid.dev), static_cast<double *>(o_pos.dev),
+                      static_cast<short *>(o_idx.dev), static_cast<unsigned char *>(o_tag.dev),
+                      static_cast<double *>(o_den.dev));
+    else
+        ABACUS_LAUNCH("unpack_pids", unpack_pids_k<float>, dim3(grid), dim3(UB), 0, din, n, inv_ppd, half,
+                      static_cast<long long *>(o_pid.dev), static_cast<float *>(o_pos.dev),
+                      static_cast<short *>(o_idx.dev), static_cast<unsigned char *>(o_tag.dev),
+                      static_cast<float *>(o_den.dev));
+    ABACUS_TRY(o_pid.finish());
+    ABACUS_TRY(o_pos.finish());
+    ABACUS_TRY(o_idx.finish());
+    ABACUS_TRY(o_tag.finish());
+    ABACUS_TRY(o_den.finish());
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+namespace {
+
+template <class P, class M, class R>
+int menv_run(const P *pos, const M *mass, int64_t n, const R *r_inner, int inner_n, const R *r_outer, int outer_n,
+             const MenvGrid &g, double mcut, double *out_host_or_dev) {
+    static DevBuf b_pos, b_mass, b_ri, b_ro, b_counts, b_cellid, b_start, b_rec, b_orig, b_out, scratch;
+    const P *d_pos;
+    const M *d_mass;
+    const R *d_ri, *d_ro;
+    ABACUS_TRY(stage_in(pos, (size_t)n * 3, b_pos, &d_pos));
+    ABACUS_TRY(stage_in(mass, (size_t)n, b_mass, &d_mass));
+    ABACUS_TRY(stage_in(r_inner, (size_t)inner_n, b_ri, &d_ri));
+    ABACUS_TRY(stage_in(r_outer, (size_t)outer_n, b_ro, &d_ro));
+    const int64_t ncell = (int64_t)g.nc[0] * g.nc[1] * g.nc[2];
+    ABACUS_TRY(b_counts.reserve((size_t)(ncell + 1) * 4));
+    ABACUS_TRY(b_cellid.reserve((size_t)n * 4));
+    ABACUS_TRY(b_start.reserve((size_t)(ncell + 1) * 8));
+    ABACUS_TRY(b_rec.reserve((size_t)n * sizeof(double4)));
+    ABACUS_TRY(b_orig.reserve((size_t)n * 4));
+    OutStage o;
+    ABACUS_TRY(o.prepare(out_host_or_dev, (size_t)n * 8, b_out));
+    HIP_TRY(hipMemsetAsync(b_counts.p, 0, (size_t)(ncell + 1) * 4, stream()));
+    const int grid = grid_for(n);
+    ABACUS_LAUNCH("menv_count", (menv_count<P>), dim3(grid), dim3(UB), 0, d_pos, n, g, b_counts.as<unsigned int>(),
+                  b_cellid.as<unsigned int>());
+    ABACUS_TRY(exclusive_scan_u32(b_counts.as<unsigned int>(), ncell, b_start.as<int64_t>(), scratch, 1));
+    ABACUS_LAUNCH("menv_fill", (menv_fill<P, M>), dim3(grid), dim3(UB), 0, d_pos, d_mass, n, b_cellid.as<unsigned int>(),
+                  b_start.as<int64_t>(), b_counts.as<unsigned int>(), b_rec.as<double4>(), b_orig.as<int>(), g.periodic, g.box);
+    ABACUS_LAUNCH("menv_sum", (menv_sum<R>), dim3((unsigned int)ceil_div(n, UB)), dim3(UB), 0, b_rec.as<double4>(),
+                  b_orig.as<int>(), n, g, b_start.as<int64_t>(), d_ri, inner_n != 1, d_ro, outer_n != 1, mcut,
+                  static_cast<double *>(o.dev));
+    ABACUS_TRY(o.finish());
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+}  // namespace
+
+// pos: (n,3) positions as the caller has them; when periodic the kernels apply the reference's shift into [0, Lbox)
+// (menv.py:36-40, NumPy remainder in the dtype of pos).  r_inner / r_outer: one
+// value (count 1) or one per halo (count n), in the `r_f64` precision.  Menv: (n) float64.
+extern "C" int abacus_menv(const void *pos, int pos_f64, const void *mass, int mass_f64, int64_t n, const void *r_inner,
+                           int64_t n_inner, const void *r_outer, int64_t n_outer, int r_f64, double r_outer_max,
+                           double Lbox, int periodic, const double *lo, const double *hi, double mcut, double *Menv) {
+    ABACUS_TRY(ensure_init());
+    if (n < 0) return fail("abacus_menv: negative count");
+    if (n == 0) return 0;
+    if (!pos || !mass || !r_inner || !r_outer || !Menv) return fail("abacus_menv: null argument");
+    if (n >= ((int64_t)1 << 31)) return fail("abacus_menv: too many halos");
+    if ((n_inner != 1 && n_inner != n) || (n_outer != 1 && n_outer != n))
+        return fail("abacus_menv: radii must be scalars or one per halo");
+    if (periodic && !(Lbox > 0)) return fail("abacus_menv: periodic box needs Lbox > 0");
+    if (!periodic && (!lo || !hi)) return fail("abacus_menv: open geometry needs the bounding box");
+    if (periodic && r_outer_max > 0.5 * Lbox) return fail("abacus_menv: r_outer exceeds half the box");
+    MenvGrid g;
+    g.periodic = periodic ? 1 : 0;
+    g.box = periodic ? Lbox : 0.0;
+    for (int d = 0; d < 3; d++) {
+        const double a = periodic ? 0.0 : lo[d], b = periodic ? Lbox : hi[d];
+        const double ext = std::max(b - a, 0.0);
+        int nc = 1;
+        if (r_outer_max > 0 && ext > 0) nc = (int)std::min(std::floor(ext / r_outer_max * 0.9999), 256.0);   // cell >= r_outer
+        if (nc < 1) nc = 1;
+        g.nc[d] = nc;
+        g.lo[d] = a;
+        g.inv_cell[d] = ext > 0 ? nc / ext : 0.0;
+    }
+    const int in_arr = (int)n_inner, out_arr = (int)n_outer;
+#define MENV_CALL(P, M, R)                                                                                          \
+    return menv_run<P, M, R>(static_cast<const P *>(pos), static_cast<const M *>(mass), n,                          \
+                             static_cast<const R *>(r_inner), in_arr, static_cast<const R *>(r_outer), out_arr, g,  \
+                             mcut, Menv)
+    if (pos_f64) {
+        if (mass_f64) {
+            if (r_f64) MENV_CALL(double, double, double);
+            MENV_CALL(double, double, float);
+        }
+        if (r_f64) MENV_CALL(double, float, double);
+        MENV_CALL(double, float, float);
+    }
+    if (mass_f64) {
+        if (r_f64) MENV_CALL(float, double, double);
+        MENV_CALL(float, double, float);
+    }
+    if (r_f64) MENV_CALL(float, float, double);
+    MENV_CALL(float, float, float);
+#undef MENV_CALL
+}

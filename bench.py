@@ -275,6 +275,11 @@ def main():
                 out['pairs'] = bench_pairs(args, dist)
             except Exception as e:
                 out['pairs'] = {'error': repr(e)}
+            try:
+                from bench_pk import bench_catalog
+                out['catalog'] = bench_catalog(args, dist)
+            except Exception as e:
+                out['catalog'] = {'error': repr(e)}
     else:
         from bench_pk import bench_pk
         out = bench_pk(args, dist, headline=True)

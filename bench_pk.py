@@ -249,6 +249,79 @@ def bench_pairs(args, dist):
     return out
 
 
+def bench_catalog(args, dist):
+    """catalogue-side kernels: rvint and packed-PID unpacking of 5e7 particles, device-resident
+    (GB/s of algorithmic bytes: 12 B in + 24 B out, 8 B in + 31 B out), and the local mass environment of 1e7 halos in
+    the 2 Gpc/h box (r_outer 5 Mpc/h, r_inner per halo; host arrays in / out like the reference call)."""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.data import bitpacked
+    from abacusutils_amd.hod.menv import do_Menv_from_tree
+    n = 50_000_000
+    rng = np.random.default_rng(700 + dist.rank)
+    rv = rng.integers(-2**31, 2**31, size=(n, 3), dtype=np.int64).astype(np.int32)
+    d_in = _lib.DeviceArray(rv)
+    d_pos = _lib.DeviceArray(nbytes=n * 12, dtype=np.float32, shape=(n, 3))
+    d_vel = _lib.DeviceArray(nbytes=n * 12, dtype=np.float32, shape=(n, 3))
+    pk = rng.integers(0, 2**63, size=n, dtype=np.int64).astype(np.uint64)
+    d_pk = _lib.DeviceArray(pk)
+    outs = {'pid': _lib.DeviceArray(nbytes=n * 8, dtype=np.int64, shape=(n,)),
+            'lagr_pos': _lib.DeviceArray(nbytes=n * 12, dtype=np.float32, shape=(n, 3)),
+            'lagr_idx': _lib.DeviceArray(nbytes=n * 6, dtype=np.int16, shape=(n, 3)),
+            'tagged': _lib.DeviceArray(nbytes=n, dtype=np.uint8, shape=(n,)),
+            'density': _lib.DeviceArray(nbytes=n * 4, dtype=np.float32, shape=(n,))}
+    L = _lib.lib()
+    import ctypes as C
+
+    def pids():
+        _lib.check(L.abacus_unpack_pids(d_pk.ptr, C.c_int64(n), C.c_double(2000.0), C.c_int64(6912), 0, outs['pid'].ptr,
+                                        outs['lagr_pos'].ptr, outs['lagr_idx'].ptr, outs['tagged'].ptr,
+                                        outs['density'].ptr))
+    bitpacked.unpack_rvint(d_in, 2000.0, posout=d_pos, velout=d_vel)
+    pids()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    reps = 5
+    for _ in range(reps):
+        bitpacked.unpack_rvint(d_in, 2000.0, posout=d_pos, velout=d_vel)
+        pids()
+    _lib.profile_enable(False)
+    kern = {k: ms / cnt for k, (ms, cnt) in _lib.profile_get().items() if cnt}
+    out = {'n_particles': n,
+           'unpack_rvint': {'ms': kern['unpack_rvint'], 'GB/s': n * 36 / kern['unpack_rvint'] / 1e6,
+                            'particles/s': n / kern['unpack_rvint'] * 1e3},
+           'unpack_pids': {'ms': kern['unpack_pids'], 'GB/s': n * 39 / kern['unpack_pids'] / 1e6,
+                           'particles/s': n / kern['unpack_pids'] * 1e3}}
+    for a in (d_in, d_pos, d_vel, d_pk, *outs.values()):
+        a.free()
+    nh, box = 10_000_000, 2000.0
+    hpos = (rng.random((nh, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(box)
+    hmass = 10 ** (10.5 + rng.exponential(0.45, nh))
+    rin = (0.1 + 0.4 * rng.random(nh)).astype(np.float32)
+    do_Menv_from_tree(hpos, hmass, rin, 5.0, False, box, mcut=1e11)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    menv = do_Menv_from_tree(hpos, hmass, rin, 5.0, False, box, mcut=1e11)
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    kern = {k: ms / cnt for k, (ms, cnt) in _lib.profile_get().items() if cnt}
+    out['menv'] = {'n_halos': nh, 'centres': int((hmass > 1e11).sum()), 'ms_per_call_host_arrays': dt * 1e3,
+                   'kernels_ms': {k: round(v, 4) for k, v in kern.items() if k.startswith('menv')},
+                   'halos/s': nh / dt, 'mean_Menv': float(menv.mean())}
+    if dist.rank == 0 and dist.world == 1 and not args.no_cpu:
+        from oracle import oracle
+        m = 5_000_000
+        t = time.perf_counter()
+        oracle.unpack_rvint(rv[:m], 2000.0)
+        tr = time.perf_counter() - t
+        t = time.perf_counter()
+        oracle.unpack_pids(pk[:m], box=2000.0, ppd=6912)
+        tp = time.perf_counter() - t
+        out['cpu_baseline'] = {'unpack_rvint particles/s': m / tr, 'unpack_pids particles/s': m / tp, 'cores': 1,
+                               'kind': 'port', 'sample': f'{m} particles, NumPy restatement'}
+    return out
+
+
 def slab_child_main():
     """`python bench_pk.py --slab-child --store-port P ...`: the slab-decomposed leg as a process of its own, one per
     rank, started by bench.py AFTER the headline is measured - a fault inside a collective then ends this process, not

@@ -306,6 +306,34 @@ int abacus_paircount(int mode, const float *x1, const float *y1, const float *z1
                      const float *y2, const float *z2, int64_t n2, float boxsize, const float *bins, int nbins,
                      float pimax, int npibins, float mu_max, int nmubins, uint64_t *npairs);
 
+/* ---------------------------------------------------------------- catalogue side (upstream of the HOD) ---- */
+/*
+ * replaces: abacusnbody/data/bitpacked.py:32-116 `unpack_rvint` / `_unpack_rvint`.  intdata: (n,3) int32, 20-bit
+ * position | 12-bit velocity per word.  pos = (x >> 12) * (boxsize / 1e6), vel = ((x & 0xFFF) - 2048) * 6000 / 2048,
+ * formed in float64 and rounded once into float32 (out_f64 = 0) or kept float64 (out_f64 = 1).  posout / velout:
+ * (n,3) or NULL (skip, the reference's `False`).  Every pointer of this block may be host or device memory.
+ */
+int abacus_unpack_rvint(const int32_t *intdata, int64_t n, double boxsize, int out_f64, void *posout, void *velout);
+/*
+ * replaces: abacusnbody/data/bitpacked.py:118-330 `unpack_pids` / `_unpack_pids`.  packed: (n) uint64 aux words.
+ * Outputs (each may be NULL): pid (n) int64 = packed & 0x7FFF7FFF7FFF; lagr_idx (n,3) int16; lagr_pos (n,3) =
+ * idx * float_dtype(box / ppd) - float_dtype(box / 2); tagged (n) uint8 = bit 48; density (n) = (bits 49..58)^2.
+ */
+int abacus_unpack_pids(const uint64_t *packed, int64_t n, double box, int64_t ppd, int out_f64, int64_t *pid,
+                       void *lagr_pos, int16_t *lagr_idx, uint8_t *tagged, void *density);
+/*
+ * replaces: abacusnbody/hod/menv.py:19-87 `do_Menv_from_tree` (scipy KDTree ball queries + gather sums; callers
+ * hod/prepare_sim.py:603-612,728-737).  Menv[i] = sum of mass within r_outer of halo i minus the sum within r_inner,
+ * over ALL halos (itself included in both), for halos with mass > mcut; 0 for the others.  pos: (n,3) in [-Lbox/2,
+ * Lbox/2) or wherever the caller has them: when periodic the kernels apply menv.py:39 `(pos + Lbox/2) % Lbox` in the
+ * dtype of pos (NumPy remainder), so the distances are formed from the values the reference's tree sees.
+ * r_inner / r_outer: n_inner / n_outer = 1 (scalar) or n values of precision r_f64; r_outer_max = their maximum (sets the
+ * cell size).  periodic = 0: open geometry (`halo_lc`), lo / hi = bounding box of pos.  Menv: (n) float64.
+ */
+int abacus_menv(const void *pos, int pos_f64, const void *mass, int mass_f64, int64_t n, const void *r_inner,
+                int64_t n_inner, const void *r_outer, int64_t n_outer, int r_f64, double r_outer_max, double Lbox,
+                int periodic, const double *lo, const double *hi, double mcut, double *Menv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,7 +109,7 @@ def read_asdf_blsc(fn, key):
     shape = [int(s) for s in re.search(r'shape: \[([\d, ]+)\]', body).group(1).split(',')]
     dt = re.search(r'datatype: (\w+)', body).group(1)
     bo = re.search(r'byteorder: (\w+)', body).group(1)
-    dtype = np.dtype({'float32': 'f4', 'float64': 'f8'}[dt]).newbyteorder('<' if bo == 'little' else '>')
+    dtype = np.dtype({'float32': 'f4', 'float64': 'f8', 'int32': 'i4', 'uint64': 'u8', 'int64': 'i8', 'uint32': 'u4'}[dt]).newbyteorder('<' if bo == 'little' else '>')
     p = raw.index(b'\xd3BLK') + 4
     (hsize,) = struct.unpack('>H', raw[p : p + 2])
     flags, comp, alloc, used, dsize = struct.unpack('>I4sQQQ', raw[p + 2 : p + 2 + 32])
@@ -478,8 +478,68 @@ def gen_helpers(P):
     print('power_helpers written')
 
 
+def gen_catalog():
+    """Catalogue side: the reference's unpack_rvint / unpack_pids on the Mini_N64_L32 subsample
+    files (tests/Mini_N64_L32/halos/z0.000/{halo,field}_{rv,pid}_A) and do_Menv_from_tree on the Mini halos and on
+    seeded synthetic halos (periodic and open geometry)."""
+    # abacusnbody/data/__init__.py configures astropy's IERS tables at import: bypass it with a bare package object
+    dpkg = types.ModuleType('abacusnbody.data')
+    dpkg.__path__ = [str(REF / 'abacusnbody' / 'data')]
+    sys.modules['abacusnbody.data'] = dpkg
+    import abacusnbody.data.bitpacked as B
+    import abacusnbody.hod.menv as M
+    base = REF / 'tests' / 'Mini_N64_L32' / 'halos' / 'z0.000'
+    out = {}
+    rv = np.concatenate([read_asdf_blsc(base / f'{k}_rv_A' / f'{k}_rv_A_{i:03d}.asdf', 'rvint')
+                         for k in ('halo', 'field') for i in range(3)])
+    # a few extreme words: sign bit set (negative positions), all-ones / all-zeros velocity fields
+    rv = np.concatenate([rv, np.array([[-2147483648, 2147483647, -1], [0, 4095, -4096]], dtype=np.int32)])
+    out['rvint.in'] = rv
+    for ft, tag in ((np.float32, 'f4'), (np.float64, 'f8')):
+        pos, vel = B.unpack_rvint(rv.copy(), 32.0, float_dtype=ft)
+        out[f'rvint.pos.{tag}'], out[f'rvint.vel.{tag}'] = pos, vel
+    pid = np.concatenate([read_asdf_blsc(base / f'{k}_pid_A' / f'{k}_pid_A_{i:03d}.asdf', 'packedpid')
+                          for k in ('halo', 'field') for i in range(3)])
+    pid = np.concatenate([pid, np.array([0xFFFFFFFFFFFFFFFF, 0, 0x07FE000000000000, 1 << 48], dtype=np.uint64)])
+    out['pids.in'] = pid
+    for ft, tag in ((np.float32, 'f4'), (np.float64, 'f8')):
+        r = B.unpack_pids(pid.copy(), box=32.0, ppd=64, pid=True, lagr_pos=True, tagged=True, density=True,
+                          lagr_idx=True, float_dtype=ft)
+        for k, v in r.items():
+            out[f'pids.{k}.{tag}'] = v
+    print('rvint', rv.shape, 'pids', pid.shape)
+    # local mass environment: the Mini halos as prepare_sim passes them (x_L2com f32, N * Mpart, r98 f32; :603-612)
+    sub = REF / 'tests' / 'ref_hod' / 'Mini_N64_L32' / 'z0.000'
+    H = np.concatenate([read_h5(sub / f'halos_xcom_{i}_seed600_abacushod_oldfenv_MT_new.h5', 'halos') for i in range(3)])
+    Mpart = 1.088239739e10
+    cases = {'mini': dict(pos=np.ascontiguousarray(H['x_L2com']), mass=H['N'] * Mpart, r_inner=np.ascontiguousarray(H['r98_L2com']),
+                          r_outer=5.0, halo_lc=False, Lbox=32.0, mcut=1e11)}
+    rng = np.random.default_rng(77)
+    n = 4000
+    cen = rng.random((40, 3)) * 300 - 150
+    p = (cen[rng.integers(0, 40, n)] + rng.standard_normal((n, 3)) * 6).astype(np.float32)
+    p = ((p + 150) % 300 - 150).astype(np.float32)
+    m = 10 ** (10.5 + rng.exponential(0.5, n))
+    cases['synth_periodic'] = dict(pos=p, mass=m, r_inner=(0.2 + rng.random(n)).astype(np.float32), r_outer=5.0,
+                                   halo_lc=False, Lbox=300.0, mcut=1e11)
+    cases['synth_router_array'] = dict(pos=p.astype(np.float64), mass=m.astype(np.float32), r_inner=0.5,
+                                       r_outer=3.0 + 4 * rng.random(n), halo_lc=False, Lbox=300.0, mcut=3e10)
+    cases['synth_lightcone'] = dict(pos=(p * np.float32(3) + np.float32(500)).astype(np.float32), mass=m,
+                                    r_inner=(0.2 + rng.random(n)).astype(np.float32), r_outer=12.0, halo_lc=True,
+                                    Lbox=2000.0, mcut=1e11)
+    for name, c in cases.items():
+        got = M.do_Menv_from_tree(c['pos'], c['mass'], r_inner=c['r_inner'], r_outer=c['r_outer'], halo_lc=c['halo_lc'],
+                                  Lbox=c['Lbox'], nthread=1, mcut=c['mcut'])
+        for k, v in c.items():
+            out[f'menv.{name}.{k}'] = np.asarray(v)
+        out[f'menv.{name}.Menv'] = got
+        print('menv', name, 'centres', int((c['mass'] > c['mcut']).sum()), 'nonzero', int((got != 0).sum()), got.dtype)
+    np.savez_compressed(GOLD / 'catalog_cases.npz', **out)
+    print('catalog_cases written')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers']
+    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'catalog']
     G, T, P, C = import_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
     if 'hod' in which:
@@ -490,3 +550,5 @@ if __name__ == '__main__':
         gen_power(P)
     if 'helpers' in which:
         gen_helpers(P)
+    if 'catalog' in which:
+        gen_catalog()

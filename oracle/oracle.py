@@ -629,3 +629,58 @@ def expand_poles_to_3d(k_ell, P_ell, n1d, L, poles):
         yd = np.where(kk <= k_ell[0], y[0], np.where(kk >= k_ell[-1], y[-1], yd))
         out += (yd * (1.0 if ell == 0 else eval_legendre(int(ell), mu))).astype(np.float32)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# catalogue side: bit-unpacking and the local mass environment
+# ---------------------------------------------------------------------------------------------------------------------
+def unpack_rvint(intdata, boxsize, float_dtype=np.float32):
+    """`_unpack_rvint` (abacusnbody/data/bitpacked.py:100-116): pos = (x >> 12) * (boxsize / 1e6), vel = ((x & 0xFFF) -
+    2048) * (6000 / 2048); the shift is arithmetic (int32), products are int64 * float64, rounded once on store."""
+    x = np.asarray(intdata, dtype=np.int32).reshape(-1, 3).astype(np.int64)
+    pos = ((x >> 12).astype(np.float64) * (float(boxsize) / 1e6)).astype(float_dtype)
+    vel = (((x & 0xFFF) - 2048).astype(np.float64) * (6000.0 / 2048)).astype(float_dtype)
+    return pos, vel
+
+
+def unpack_pids(packed, box=1.0, ppd=1, float_dtype=np.float32):
+    """`_unpack_pids` (bitpacked.py:274-330), every field.  lagr_pos: uint64 * float_dtype(box / ppd) is float64
+    arithmetic under both NumPy and Numba promotion; one rounding on store."""
+    a = np.asarray(packed, dtype=np.uint64)
+    ft = np.dtype(float_dtype).type
+    inv_ppd, half = np.float64(ft(float(box) / ppd)), np.float64(ft(float(box) / 2))
+    idx = np.stack([a & np.uint64(0x7FFF), (a & np.uint64(0x7FFF0000)) >> np.uint64(16),
+                    (a & np.uint64(0x7FFF00000000)) >> np.uint64(32)], axis=1)
+    d = ((a & np.uint64(0x07FE000000000000)) >> np.uint64(49)).astype(np.int64)
+    return {'pid': (a & np.uint64(0x7FFF7FFF7FFF)).astype(np.int64),
+            'lagr_idx': idx.astype(np.int16),
+            'lagr_pos': (idx.astype(np.float64) * inv_ppd - half).astype(float_dtype),
+            'tagged': ((a >> np.uint64(48)) & np.uint64(1)).astype(np.uint8),
+            'density': (d * d).astype(float_dtype)}
+
+
+def menv_brute(pos, mass, r_inner, r_outer, halo_lc, Lbox, mcut=1e11, chunk=512):
+    """`do_Menv_from_tree` (abacusnbody/hod/menv.py:19-87) without the tree: all-pairs float64 distances (minimum image
+    when periodic, like KDTree(boxsize=Lbox)), neighbours with d <= r, masses summed in float64."""
+    pos = np.asarray(pos)
+    mass = np.asarray(mass)
+    if not halo_lc:
+        pos = (pos + Lbox / 2.0) % Lbox
+    p = pos.astype(np.float64)
+    m = mass.astype(np.float64)
+    n = len(p)
+    ri = np.broadcast_to(np.asarray(r_inner, dtype=np.float64), (n,))
+    ro = np.broadcast_to(np.asarray(r_outer, dtype=np.float64), (n,))
+    out = np.zeros(n, dtype=np.float64)
+    cen = np.nonzero(mass > mcut)[0]
+    for s in range(0, len(cen), chunk):
+        c = cen[s:s + chunk]
+        d = np.abs(p[c, None, :] - p[None, :, :])
+        if not halo_lc:
+            d = np.where(d > 0.5 * Lbox, Lbox - d, d)
+        d2 = (d * d).sum(axis=2)
+        out[c] = ((d2 <= (ro[c] ** 2)[:, None]) * m[None, :]).sum(axis=1) - \
+                 ((d2 <= (ri[c] ** 2)[:, None]) * m[None, :]).sum(axis=1)
+    res = np.zeros_like(mass)
+    res[cen] = out[cen]
+    return res
