@@ -135,6 +135,167 @@ __global__ __launch_bounds__(UB) void unpack_pids_k(const unsigned long long *__
     }
 }
 
+// ---- pack9: 9-byte records, a cell header (first byte 0xFF) governs the particles that follow it ----------------------
+// The reference walks the records serially (pack9.py:58-123).  Here a chunk of P9_CH records is a workgroup: pass 1
+// counts the particles and notes the last header of every chunk, a scan turns the counts into output offsets, pass 2
+// stages the chunk in LDS, finds every record's governing header and output slot with workgroup scans (each thread owns
+// P9_PER consecutive records), decodes, and writes the compacted positions / velocities through LDS in coalesced rows.
+// Typing as Numba compiles the reference (pinned by tests/ref_data/test_pack9.asdf): invcpd, the cell centres and
+// pscale are float64 expressions rounded to the output dtype; the per-particle `short * scale + centre` is arithmetic in
+// the output dtype.
+constexpr int P9_NT = 256, P9_PER = 6, P9_CH = P9_NT * P9_PER;   // 13.5 KB of records + <= 36 KB of staged output in LDS
+
+__device__ __forceinline__ void p9_shorts(const unsigned char *c, int (&s)[6]) {
+    s[0] = ((c[1] & 0x0F) | (c[0] << 4)) - 2048;
+    s[1] = (((c[1] & 0xF0) << 4) | c[2]) - 2048;
+    s[2] = ((c[4] & 0x0F) | (c[3] << 4)) - 2048;
+    s[3] = (((c[4] & 0xF0) << 4) | c[5]) - 2048;
+    s[4] = ((c[7] & 0x0F) | (c[6] << 4)) - 2048;
+    s[5] = (((c[7] & 0xF0) << 4) | c[8]) - 2048;
+}
+
+template <class F>
+struct P9Cell {
+    F pscale, vscale, c[3];
+};
+
+template <class F>
+__device__ __forceinline__ P9Cell<F> p9_header(const unsigned char *rec, F boxsize, F velz) {
+    P9Cell<F> h;
+    if (!rec) {   // no header yet: the reference's state is NaN (:66-71)
+        h.pscale = h.vscale = h.c[0] = h.c[1] = h.c[2] = (F)NAN;
+        return h;
+    }
+    int s[6];
+    p9_shorts(rec, s);
+    const F invcpd = (F)(1.0 / (double)(s[1] + 2000));
+    const F csize = boxsize * invcpd;
+    const double halfbox = (double)boxsize / 2.0;
+    h.vscale = (F)((double)(s[2] + 2000) * 0.0005) * invcpd * velz;
+#pragma unroll
+    for (int d = 0; d < 3; d++) h.c[d] = (F)(((double)s[3 + d] + 2000.5) * (double)csize - halfbox);
+    h.pscale = (F)(0.0005 * (double)csize);
+    return h;
+}
+
+__device__ __forceinline__ void p9_stage(const unsigned char *__restrict__ data, int64_t rec0, int nrec_chunk,
+                                         unsigned int *lds_words) {
+    // the chunk starts at a multiple of 9 * P9_CH bytes: dword loads are aligned; the tail is read bytewise
+    const int64_t byte0 = rec0 * 9;
+    const int nbytes = nrec_chunk * 9, nwords = nbytes / 4;
+    const unsigned int *g = reinterpret_cast<const unsigned int *>(data + byte0);
+    for (int q = threadIdx.x; q < nwords; q += P9_NT) lds_words[q] = g[q];
+    unsigned char *lb = reinterpret_cast<unsigned char *>(lds_words);
+    for (int q = nwords * 4 + threadIdx.x; q < nbytes; q += P9_NT) lb[q] = data[byte0 + q];
+}
+
+__global__ __launch_bounds__(P9_NT) void pack9_count(const unsigned char *__restrict__ data, int64_t nrec,
+                                                     unsigned int *__restrict__ counts, int *__restrict__ last_hdr) {
+    __shared__ unsigned int sm_cnt;
+    __shared__ int sm_last;
+    if (threadIdx.x == 0) sm_cnt = 0u, sm_last = -1;
+    __syncthreads();
+    const int64_t rec0 = (int64_t)blockIdx.x * P9_CH;
+    const int m = (int)min((int64_t)P9_CH, nrec - rec0);
+    unsigned int cnt = 0;
+    int last = -1;
+    for (int r = threadIdx.x; r < m; r += P9_NT) {
+        if (data[(rec0 + r) * 9] == 0xFF) last = r;
+        else cnt++;
+    }
+    atomicAdd(&sm_cnt, cnt);
+    atomicMax(&sm_last, last);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = sm_cnt, last_hdr[blockIdx.x] = sm_last;
+}
+
+template <class F>
+__global__ __launch_bounds__(P9_NT) void pack9_emit(const unsigned char *__restrict__ data, int64_t nrec, F boxsize, F velz,
+                                                    const int64_t *__restrict__ chunk_off,
+                                                    const int *__restrict__ last_hdr, F *__restrict__ pos,
+                                                    F *__restrict__ vel) {
+    __shared__ unsigned int recs[P9_CH * 9 / 4 + 4];
+    __shared__ __align__(8) unsigned char stage_raw[P9_CH * 3 * sizeof(F)];
+    __shared__ int wave_cnt[P9_NT / 64], wave_hdr[P9_NT / 64];
+    __shared__ unsigned char carry_rec[12];
+    __shared__ int carry_ok;
+    F *stage = reinterpret_cast<F *>(stage_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rec0 = (int64_t)blockIdx.x * P9_CH;
+    const int m = (int)min((int64_t)P9_CH, nrec - rec0);
+    p9_stage(data, rec0, m, recs);
+    if (tid == 0) {   // the header in force at the start of this chunk: the last one of the nearest earlier chunk that has any
+        int64_t c = (int64_t)blockIdx.x - 1;
+        while (c >= 0 && last_hdr[c] < 0) c--;
+        carry_ok = c >= 0;
+        if (c >= 0) {
+            const unsigned char *h = data + (c * P9_CH + last_hdr[c]) * 9;
+            for (int q = 0; q < 9; q++) carry_rec[q] = h[q];
+        }
+    }
+    __syncthreads();
+    const unsigned char *lb = reinterpret_cast<const unsigned char *>(recs);
+    // per-thread run of P9_PER consecutive records
+    const int r0 = tid * P9_PER;
+    int cnt = 0, lasth = -1;
+#pragma unroll
+    for (int q = 0; q < P9_PER; q++) {
+        const int r = r0 + q;
+        if (r < m) {
+            if (lb[r * 9] == 0xFF) lasth = r;
+            else cnt++;
+        }
+    }
+    // workgroup scans: exclusive sum of cnt, exclusive running max of lasth
+    int incl = cnt, hmax = lasth;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int a = __shfl_up(incl, off, 64), b = __shfl_up(hmax, off, 64);
+        if (lane >= off) incl += a, hmax = max(hmax, b);
+    }
+    if (lane == 63) wave_cnt[wave] = incl, wave_hdr[wave] = hmax;
+    __syncthreads();
+    int base = 0, hprev = -1;
+    for (int w = 0; w < wave; w++) base += wave_cnt[w], hprev = max(hprev, wave_hdr[w]);
+    int total = 0;
+    for (int w = 0; w < P9_NT / 64; w++) total += wave_cnt[w];
+    const int excl = base + incl - cnt;
+    int hbefore = __shfl_up(hmax, 1, 64);
+    if (lane == 0) hbefore = -1;
+    int cur_h = max(hprev, hbefore);   // header governing this thread's first record (chunk-local index, -1 = carried in)
+    const int64_t out0 = chunk_off[blockIdx.x];
+
+    for (int pass = 0; pass < 2; pass++) {   // 0: positions, 1: velocities (one LDS staging buffer)
+        F *dst = pass == 0 ? pos : vel;
+        if (!dst) continue;
+        int h = cur_h, w = excl;
+        P9Cell<F> cell = p9_header<F>(h >= 0 ? lb + h * 9 : (carry_ok ? carry_rec : nullptr), boxsize, velz);
+#pragma unroll
+        for (int q = 0; q < P9_PER; q++) {
+            const int r = r0 + q;
+            if (r >= m) break;
+            const unsigned char *c = lb + r * 9;
+            if (c[0] == 0xFF) {
+                cell = p9_header<F>(c, boxsize, velz);
+                continue;
+            }
+            int s[6];
+            p9_shorts(c, s);
+            if (pass == 0) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) stage[w * 3 + d] = (F)s[d] * cell.pscale + cell.c[d];
+            } else {
+#pragma unroll
+                for (int d = 0; d < 3; d++) stage[w * 3 + d] = (F)s[3 + d] * cell.vscale;
+            }
+            w++;
+        }
+        __syncthreads();
+        for (int q = tid; q < total * 3; q += P9_NT) dst[out0 * 3 + q] = stage[q];
+        __syncthreads();
+    }
+}
+
 // ---- local mass environment --------------------------------------------------------------------------------------------
 struct MenvGrid {
     int nc[3];
@@ -329,6 +490,50 @@ extern "C" int abacus_unpack_pids(const uint64_t *packed, int64_t n, double box,
     ABACUS_TRY(o_idx.finish());
     ABACUS_TRY(o_tag.finish());
     ABACUS_TRY(o_den.finish());
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+extern "C" int abacus_unpack_pack9(const uint8_t *data, int64_t nrec, double boxsize, double velzspace_to_kms, int out_f64,
+                                   void *posout, void *velout, int64_t *npart) {
+    ABACUS_TRY(ensure_init());
+    if (nrec < 0 || (nrec > 0 && !data) || !npart) return fail("abacus_unpack_pack9: null argument");
+    *npart = 0;
+    if (nrec == 0) return 0;
+    static DevBuf b_in, b_pos, b_vel, b_counts, b_last, b_off, scratch;
+    const size_t fs = out_f64 ? 8 : 4;
+    const uint8_t *d_in;
+    ABACUS_TRY(stage_in(data, (size_t)nrec * 9, b_in, &d_in));
+    if (((uintptr_t)d_in & 3) != 0) return fail("abacus_unpack_pack9: device input must be 4-byte aligned");
+    OutStage op, ov;
+    ABACUS_TRY(op.prepare(posout, (size_t)nrec * 3 * fs, b_pos));
+    ABACUS_TRY(ov.prepare(velout, (size_t)nrec * 3 * fs, b_vel));
+    const int64_t nchunk = ceil_div(nrec, P9_CH);
+    if (nchunk >= ((int64_t)1 << 31)) return fail("abacus_unpack_pack9: too many records");
+    ABACUS_TRY(b_counts.reserve((size_t)(nchunk + 1) * 4));
+    ABACUS_TRY(b_last.reserve((size_t)nchunk * 4));
+    ABACUS_TRY(b_off.reserve((size_t)(nchunk + 1) * 8));
+    ABACUS_LAUNCH("pack9_count", pack9_count, dim3((unsigned int)nchunk), dim3(P9_NT), 0, d_in, nrec,
+                  b_counts.as<unsigned int>(), b_last.as<int>());
+    ABACUS_TRY(exclusive_scan_u32(b_counts.as<unsigned int>(), nchunk, b_off.as<int64_t>(), scratch, 0));
+    if (op.dev || ov.dev) {
+        if (out_f64)
+            ABACUS_LAUNCH("pack9_emit", pack9_emit<double>, dim3((unsigned int)nchunk), dim3(P9_NT), 0, d_in, nrec, boxsize,
+                          velzspace_to_kms, b_off.as<int64_t>(), b_last.as<int>(), static_cast<double *>(op.dev),
+                          static_cast<double *>(ov.dev));
+        else
+            ABACUS_LAUNCH("pack9_emit", pack9_emit<float>, dim3((unsigned int)nchunk), dim3(P9_NT), 0, d_in, nrec,
+                          (float)boxsize, (float)velzspace_to_kms, b_off.as<int64_t>(), b_last.as<int>(),
+                          static_cast<float *>(op.dev), static_cast<float *>(ov.dev));
+    }
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, b_off.as<int64_t>() + nchunk, 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    *npart = total;
+    // only the first npart rows are defined (the reference returns views of them)
+    op.bytes = ov.bytes = (size_t)total * 3 * fs;
+    ABACUS_TRY(op.finish());
+    ABACUS_TRY(ov.finish());
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;
 }

@@ -291,7 +291,26 @@ def bench_catalog(args, dist):
                             'particles/s': n / kern['unpack_rvint'] * 1e3},
            'unpack_pids': {'ms': kern['unpack_pids'], 'GB/s': n * 39 / kern['unpack_pids'] / 1e6,
                            'particles/s': n / kern['unpack_pids'] * 1e3}}
-    for a in (d_in, d_pos, d_vel, d_pk, *outs.values()):
+    # pack9: 5e7 records, a cell header every ~85 records like the Mini_N64_L32 slices (9 B in, 24 B out per particle)
+    p9 = rng.integers(0, 255, size=(n, 9), dtype=np.int64).astype(np.uint8)     # first byte never 0xFF ...
+    p9[::85, 0] = 0xFF                                                           # ... except at the headers
+    d_p9 = _lib.DeviceArray(p9)
+    npart = C.c_int64(0)
+
+    def pack9():
+        _lib.check(L.abacus_unpack_pack9(d_p9.ptr, C.c_int64(n), C.c_double(2000.0), C.c_double(208774.9), 0, d_pos.ptr,
+                                         d_vel.ptr, C.byref(npart)))
+    pack9()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    for _ in range(reps):
+        pack9()
+    _lib.profile_enable(False)
+    kern = {k: ms / cnt for k, (ms, cnt) in _lib.profile_get().items() if cnt}
+    t9 = kern['pack9_count'] + kern['pack9_emit']
+    out['unpack_pack9'] = {'ms': t9, 'kernels_ms': {k: round(v, 4) for k, v in kern.items() if k.startswith('pack9')},
+                           'GB/s': (n * 9 + npart.value * 24) / t9 / 1e6, 'particles/s': npart.value / t9 * 1e3}
+    for a in (d_in, d_pos, d_vel, d_pk, d_p9, *outs.values()):
         a.free()
     nh, box = 10_000_000, 2000.0
     hpos = (rng.random((nh, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(box)

@@ -322,6 +322,13 @@ int abacus_unpack_rvint(const int32_t *intdata, int64_t n, double boxsize, int o
 int abacus_unpack_pids(const uint64_t *packed, int64_t n, double box, int64_t ppd, int out_f64, int64_t *pid,
                        void *lagr_pos, int16_t *lagr_idx, uint8_t *tagged, void *density);
 /*
+ * replaces: abacusnbody/data/pack9.py:16-123 `unpack_pack9` / `_unpack_pack9`.  data: (nrec, 9) bytes; a record whose
+ * first byte is 0xFF is a cell header for the particles after it.  posout / velout: (nrec, 3) or NULL; the first
+ * *npart rows are written (records before the first header decode to NaN, like the reference's initial state).
+ */
+int abacus_unpack_pack9(const uint8_t *data, int64_t nrec, double boxsize, double velzspace_to_kms, int out_f64,
+                        void *posout, void *velout, int64_t *npart);
+/*
  * replaces: abacusnbody/hod/menv.py:19-87 `do_Menv_from_tree` (scipy KDTree ball queries + gather sums; callers
  * hod/prepare_sim.py:603-612,728-737).  Menv[i] = sum of mass within r_outer of halo i minus the sum within r_inner,
  * over ALL halos (itself included in both), for halos with mass > mcut; 0 for the others.  pos: (n,3) in [-Lbox/2,

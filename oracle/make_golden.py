@@ -96,43 +96,71 @@ def read_ecsv(fn):
     return cols, ncent
 
 
-def read_asdf_blsc(fn, key):
-    """First binary block of an ASDF file compressed with the reference's 'blsc'
-    extension (abacusnbody/data/asdf.py:81-93,128-181): block header, then chunks
-    of [!I nbytes][blosc frame]."""
-    raw = open(fn, 'rb').read()
-    # yaml tree: dtype/shape of `key`
-    tree = raw[: raw.index(b'\xd3BLK')].decode('latin1')
-    import re
-    m = re.search(key + r': !core/ndarray-[\d.]+\s*\n((?:\s+.*\n)+)', tree)
-    body = m.group(1)
-    shape = [int(s) for s in re.search(r'shape: \[([\d, ]+)\]', body).group(1).split(',')]
-    dt = re.search(r'datatype: (\w+)', body).group(1)
-    bo = re.search(r'byteorder: (\w+)', body).group(1)
-    dtype = np.dtype({'float32': 'f4', 'float64': 'f8', 'int32': 'i4', 'uint64': 'u8', 'int64': 'i8', 'uint32': 'u4'}[dt]).newbyteorder('<' if bo == 'little' else '>')
-    p = raw.index(b'\xd3BLK') + 4
-    (hsize,) = struct.unpack('>H', raw[p : p + 2])
-    flags, comp, alloc, used, dsize = struct.unpack('>I4sQQQ', raw[p + 2 : p + 2 + 32])
-    assert comp == b'blsc', comp
-    p = p + 2 + hsize
-    end = p + used
+_ASDF_DT = {'float32': 'f4', 'float64': 'f8', 'int32': 'i4', 'uint64': 'u8', 'int64': 'i8', 'uint32': 'u4',
+            'int16': 'i2', 'int8': 'i1', 'uint8': 'u1', 'bool8': 'u1'}
+
+
+def _asdf_blocks(raw):
+    """decompressed bytes of every binary block of an ASDF file written with the reference's 'blsc' extension
+    (abacusnbody/data/asdf.py:81-93,128-181): block header, then chunks of [!I nbytes][blosc frame]; plain blocks too"""
     lib = ctypes.CDLL(LIBBLOSC)
-    out = bytearray()
-    while p < end:
-        (n,) = struct.unpack('!I', raw[p : p + 4])
+    blocks = []
+    p = raw.find(b'\xd3BLK')
+    while p >= 0 and raw[p:p + 4] == b'\xd3BLK':
         p += 4
-        frame = raw[p : p + n]
-        p += n
-        nbytes = ctypes.c_size_t()
-        cbytes = ctypes.c_size_t()
-        bs = ctypes.c_size_t()
-        lib.blosc_cbuffer_sizes(frame, ctypes.byref(nbytes), ctypes.byref(cbytes), ctypes.byref(bs))
-        buf = ctypes.create_string_buffer(nbytes.value)
-        r = lib.blosc_decompress(frame, buf, ctypes.c_size_t(nbytes.value))
-        assert r == nbytes.value
-        out += buf.raw
-    assert len(out) == dsize
-    return np.frombuffer(bytes(out), dtype=dtype).reshape(shape).astype(dtype.newbyteorder('='))
+        (hsize,) = struct.unpack('>H', raw[p:p + 2])
+        flags, comp, alloc, used, dsize = struct.unpack('>I4sQQQ', raw[p + 2:p + 2 + 32])
+        p = p + 2 + hsize
+        end = p + used
+        if comp == b'blsc':
+            out = bytearray()
+            q = p
+            while q < end:
+                (n,) = struct.unpack('!I', raw[q:q + 4])
+                q += 4
+                frame = raw[q:q + n]
+                q += n
+                nbytes, cbytes, bs = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+                lib.blosc_cbuffer_sizes(frame, ctypes.byref(nbytes), ctypes.byref(cbytes), ctypes.byref(bs))
+                buf = ctypes.create_string_buffer(nbytes.value)
+                r = lib.blosc_decompress(frame, buf, ctypes.c_size_t(nbytes.value))
+                assert r == nbytes.value
+                out += buf.raw
+            assert len(out) == dsize
+            blocks.append(bytes(out))
+        else:
+            assert comp == b'\0\0\0\0', comp
+            blocks.append(raw[p:p + dsize])
+        p = p + alloc
+    return blocks
+
+
+def read_asdf_arrays(fn):
+    """{name: ndarray} of every ndarray in the YAML tree of an ASDF file (key name, or the column `name:` of a table)"""
+    raw = open(fn, 'rb').read()
+    tree = raw[: raw.index(b'\xd3BLK')].decode('latin1')
+    blocks = _asdf_blocks(raw)
+    out = {}
+    for m in re.finditer(r'(\w+): !core/ndarray-[\d.]+\s*\n((?:[ \t]+\w+: .*\n)+)', tree):
+        body = m.group(2)
+        src = int(re.search(r'source: (\d+)', body).group(1))
+        shape = [int(x) for x in re.search(r'shape: \[([\d, ]+)\]', body).group(1).split(',')]
+        dt = re.search(r'datatype: (\w+)', body).group(1)
+        bo = re.search(r'byteorder: (\w+)', body).group(1)
+        nm = re.search(r'\n\s+name: (\w+)', '\n' + body) or re.search(r'^\s+name: (\w+)', tree[m.end():m.end() + 80])
+        name = m.group(1) if m.group(1) != 'data' or nm is None else nm.group(1)
+        dtype = np.dtype(_ASDF_DT[dt]).newbyteorder('<' if bo == 'little' else '>')
+        off = re.search(r'offset: (\d+)', body)
+        off = int(off.group(1)) if off else 0
+        cnt = int(np.prod(shape))      # a view of a larger base array is stored as the base block + offset
+        assert 'strides' not in body
+        out[name] = np.frombuffer(blocks[src], dtype=dtype, count=cnt, offset=off).reshape(shape).astype(dtype.newbyteorder('='))
+    return out
+
+
+def read_asdf_blsc(fn, key):
+    """one named array of an ASDF file (see read_asdf_arrays)"""
+    return read_asdf_arrays(fn)[key]
 
 
 # ----------------------------------------------------------------------------
@@ -534,6 +562,33 @@ def gen_catalog():
             out[f'menv.{name}.{k}'] = np.asarray(v)
         out[f'menv.{name}.Menv'] = got
         print('menv', name, 'centres', int((c['mass'] > c['mcut']).sum()), 'nonzero', int((got != 0).sum()), got.dtype)
+    # ---- outputs of the REAL (Numba-compiled) reference held by its own tests (tests/test_data.py:258-326):
+    #      read_asdf of field_rv_A_000 / field_pid_A_000 -> ref_data/test_read_asdf.asdf; of L0_pack9/slab000 and
+    #      L0_pack9_pid/slab000 -> ref_data/test_pack9.asdf, test_pack9_pid.asdf.  Inputs and expected outputs are copied
+    #      into the fixture file; BoxSize 32, ppd 64, VelZSpace_to_kms 3200 from the file headers.
+    T = REF / 'tests'
+    real = read_asdf_arrays(T / 'ref_data' / 'test_read_asdf.asdf')
+    out['real.rvint.in'] = read_asdf_arrays(base / 'field_rv_A' / 'field_rv_A_000.asdf')['rvint']
+    out['real.rvint.pos'], out['real.rvint.vel'] = real['pos'], real['vel']
+    out['real.pids.in'] = read_asdf_arrays(base / 'field_pid_A' / 'field_pid_A_000.asdf')['packedpid']
+    assert np.array_equal(out['real.pids.in'], real['aux'])
+    for k in ('pid', 'lagr_pos', 'lagr_idx', 'tagged', 'density'):
+        out[f'real.pids.{k}'] = real[k]
+    sl = T / 'Mini_N64_L32' / 'slices' / 'z0.000'
+    p9 = read_asdf_arrays(sl / 'L0_pack9' / 'slab000.L0.pack9.asdf')['pack9'].view(np.uint8)
+    r9 = read_asdf_arrays(T / 'ref_data' / 'test_pack9.asdf')
+    out['real.pack9.in'], out['real.pack9.pos'], out['real.pack9.vel'] = p9, r9['pos'], r9['vel']
+    hdr = open(sl / 'L0_pack9' / 'slab000.L0.pack9.asdf', 'rb').read(20000).decode('latin1')
+    out['real.pack9.box'] = np.float64(re.search(r'BoxSize: ([\d.eE+-]+)', hdr).group(1))
+    out['real.pack9.velz'] = np.float64(re.search(r'VelZSpace_to_kms: ([\d.eE+-]+)', hdr).group(1))
+    rp = read_asdf_arrays(T / 'ref_data' / 'test_pack9_pid.asdf')
+    out['real.pack9pid.in'] = rp['aux']
+    for k in ('pid', 'lagr_pos', 'lagr_idx', 'tagged', 'density'):
+        out[f'real.pack9pid.{k}'] = rp[k]
+    # pack9 cannot run under the identity shim: `c[0] << 4` on NumPy uint8 scalars wraps, where Numba widens to 64 bit
+    # (pack9.py:128-130) - so float64 pack9 has no golden; a second input file is kept for HIP-vs-oracle comparisons
+    out['pack9.field.in'] = read_asdf_arrays(sl / 'field_pack9' / 'slab002.field.pack9.asdf')['pack9'].view(np.uint8)
+    print('pack9 real', p9.shape, '->', r9['pos'].shape)
     np.savez_compressed(GOLD / 'catalog_cases.npz', **out)
     print('catalog_cases written')
 

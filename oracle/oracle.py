@@ -684,3 +684,34 @@ def menv_brute(pos, mass, r_inner, r_outer, halo_lc, Lbox, mcut=1e11, chunk=512)
     res = np.zeros_like(mass)
     res[cen] = out[cen]
     return res
+
+
+def unpack_pack9(data, boxsize, velzspace_to_kms, float_dtype=np.float32):
+    """`_unpack_pack9` (abacusnbody/data/pack9.py:59-123), vectorised: every record takes the state of the last header at
+    or before it.  Typing as Numba compiles it (pinned by the reference's tests/ref_data/test_pack9.asdf): invcpd, the
+    cell centres and pscale are float64 expressions rounded to `float_dtype`; `short * pscale + centre` and
+    `short * vscale` are `float_dtype` arithmetic.  Records ahead of the first header decode to NaN."""
+    F = np.dtype(float_dtype).type
+    d = np.asarray(data, dtype=np.uint8).reshape(-1, 9)
+    c = d.astype(np.int64)
+    sh = np.stack([(c[:, 1] & 0x0F) | (c[:, 0] << 4), ((c[:, 1] & 0xF0) << 4) | c[:, 2],
+                   (c[:, 4] & 0x0F) | (c[:, 3] << 4), ((c[:, 4] & 0xF0) << 4) | c[:, 5],
+                   (c[:, 7] & 0x0F) | (c[:, 6] << 4), ((c[:, 7] & 0xF0) << 4) | c[:, 8]], axis=1) - 2048
+    hdr = d[:, 0] == 0xFF
+    hidx = np.maximum.accumulate(np.where(hdr, np.arange(len(d)), -1))
+    H = sh[np.maximum(hidx, 0)]
+    box, velz = F(boxsize), F(velzspace_to_kms)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        invcpd = (1.0 / (H[:, 1] + 2000)).astype(F)
+        csize = box * invcpd
+        halfbox = np.float64(box) / 2
+        vscale = ((H[:, 2] + 2000) * 0.0005).astype(F) * invcpd * velz
+        cell = [(((H[:, 3 + k] + 2000.5) * csize.astype(np.float64)) - halfbox).astype(F) for k in range(3)]
+        pscale = (0.0005 * csize.astype(np.float64)).astype(F)
+        nohdr = hidx < 0
+        for a in (vscale, pscale, *cell):
+            a[nohdr] = np.nan
+        pos = np.stack([sh[:, k].astype(F) * pscale + cell[k] for k in range(3)], axis=1)
+        vel = np.stack([sh[:, 3 + k].astype(F) * vscale for k in range(3)], axis=1)
+    part = ~hdr
+    return pos[part], vel[part]

@@ -126,3 +126,55 @@ def test_menv_large_uniform_and_tiny_boxes():
     # empty input and no centres
     assert len(do_Menv_from_tree(np.zeros((0, 3)), np.zeros(0), 1.0, 2.0, False, 10.0)) == 0
     assert not do_Menv_from_tree(pos2, m2, 0.3, 5.0, False, 11.0, mcut=1e20).any()
+
+
+def test_against_the_numba_compiled_reference():
+    """the reference's own stored outputs (ref_data/test_read_asdf.asdf, test_pack9.asdf, test_pack9_pid.asdf)"""
+    from abacusutils_amd.data.pack9 import unpack_pack9
+    pos, vel = bitpacked.unpack_rvint(G['real.rvint.in'], 32.0)
+    assert np.array_equal(pos, G['real.rvint.pos']) and np.array_equal(vel, G['real.rvint.vel'])
+    for case in ('pids', 'pack9pid'):
+        r = bitpacked.unpack_pids(G[f'real.{case}.in'], box=32.0, ppd=64, pid=True, lagr_pos=True, tagged=True,
+                                  density=True, lagr_idx=True)
+        for k, v in r.items():
+            want = G[f'real.{case}.{k}']
+            assert v.dtype == want.dtype and np.array_equal(v, want), (case, k)
+    pos, vel = unpack_pack9(G['real.pack9.in'], float(G['real.pack9.box']), float(G['real.pack9.velz']))
+    assert pos.dtype == np.float32 and pos.shape == G['real.pack9.pos'].shape
+    assert np.array_equal(pos, G['real.pack9.pos']) and np.array_equal(vel, G['real.pack9.vel'])
+
+
+def test_pack9_float64_protocol_and_edges():
+    from abacusutils_amd.data.pack9 import unpack_pack9
+    d8, velz = G['pack9.field.in'], float(G['real.pack9.velz'])
+    for ft in (np.float32, np.float64):
+        pos, vel = unpack_pack9(d8, 32.0, velz, float_dtype=ft)
+        wp, wv = oracle.unpack_pack9(d8, 32.0, velz, ft)
+        assert pos.dtype == ft and np.array_equal(pos, wp) and np.array_equal(vel, wv)
+    # caller-provided / skipped outputs (pack9.py:24-56)
+    buf = np.full((len(d8), 3), -7.0)
+    r = unpack_pack9(d8, 32.0, velz, float_dtype=np.float64, posout=False, velout=buf)
+    assert r == (0, len(pos)) and np.array_equal(buf[:len(pos)], vel) and (buf[len(pos):] == -7.0).all()
+    # chunk boundaries, headers as the last / first record of a chunk, no header at all, empty input
+    d = G['real.pack9.in']
+    rng = np.random.default_rng(9)
+    hdrs = np.nonzero(d[:, 0] == 0xFF)[0]
+    for n in (1, 2, 1535, 1536, 1537, 3072, 3073, 20000):
+        for start in (0, int(hdrs[3]), int(hdrs[3]) + 1):
+            sub = d[start:start + n]
+            gp, gv = unpack_pack9(sub, 32.0, 3200.0)
+            wp, wv = oracle.unpack_pack9(sub, 32.0, 3200.0)
+            assert gp.shape == wp.shape and np.array_equal(gp, wp, equal_nan=True) and np.array_equal(gv, wv, equal_nan=True)
+    parts = d[d[:, 0] != 0xFF][:5000]           # 5000 particles, no header: more than three chunks of NaN state
+    gp, gv = unpack_pack9(parts, 32.0, 3200.0)
+    assert gp.shape == (5000, 3) and np.isnan(gp).all() and np.isnan(gv).all()
+    big = np.concatenate([d[hdrs[0]:hdrs[0] + 1], parts, d[hdrs[1]:hdrs[1] + 1], parts[:7]])   # one header governs 3+ chunks
+    gp, gv = unpack_pack9(big, 32.0, 3200.0)
+    wp, wv = oracle.unpack_pack9(big, 32.0, 3200.0)
+    assert np.array_equal(gp, wp) and np.array_equal(gv, wv)
+    gp, gv = unpack_pack9(np.zeros((0, 9), dtype=np.uint8), 32.0, 3200.0)
+    assert gp.shape == (0, 3) and gv.shape == (0, 3)
+    rnd = rng.integers(0, 256, size=(100000, 9), dtype=np.int64).astype(np.uint8)   # random bytes: ~1/256 are headers
+    gp, gv = unpack_pack9(rnd, 2000.0, 208774.9, float_dtype=np.float64)
+    wp, wv = oracle.unpack_pack9(rnd, 2000.0, 208774.9, np.float64)
+    assert np.array_equal(gp, wp, equal_nan=True) and np.array_equal(gv, wv, equal_nan=True)

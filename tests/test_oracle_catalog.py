@@ -41,3 +41,33 @@ def test_menv(name):
     tol = 1e-12 if c['mass'].dtype == np.float64 else 3e-6
     assert np.abs(got - want).max() <= tol * scale
     assert np.array_equal(got == 0, want == 0) or tol > 1e-9
+
+
+def test_against_the_numba_compiled_reference():
+    """outputs of the real (Numba) reference kept by its own tests (ref_data/test_read_asdf.asdf, test_pack9.asdf,
+    test_pack9_pid.asdf): bit-equal, which also settles the mixed int/float32/float64 typing of the loops"""
+    pos, vel = oracle.unpack_rvint(G['real.rvint.in'], 32.0)
+    assert np.array_equal(pos, G['real.rvint.pos']) and np.array_equal(vel, G['real.rvint.vel'])
+    for case in ('pids', 'pack9pid'):
+        r = oracle.unpack_pids(G[f'real.{case}.in'], box=32.0, ppd=64)
+        for k in ('pid', 'lagr_pos', 'lagr_idx', 'tagged', 'density'):
+            want = G[f'real.{case}.{k}']
+            assert r[k].dtype == want.dtype and np.array_equal(r[k], want), (case, k)
+    pos, vel = oracle.unpack_pack9(G['real.pack9.in'], float(G['real.pack9.box']), float(G['real.pack9.velz']))
+    assert pos.dtype == np.float32 and np.array_equal(pos, G['real.pack9.pos'])
+    assert np.array_equal(vel, G['real.pack9.vel'])
+
+
+def test_pack9_float64_and_headerless_prefix():
+    # float64: no golden exists (the shim cannot run pack9, see oracle/make_golden.py); float32 rounding of the float64
+    # result must land within one ulp of the pinned float32 path
+    pos, vel = oracle.unpack_pack9(G['real.pack9.in'], 32.0, 3200.0, np.float64)
+    assert pos.dtype == np.float64
+    np.testing.assert_allclose(pos, G['real.pack9.pos'], rtol=0, atol=4e-6)
+    np.testing.assert_allclose(vel, G['real.pack9.vel'], rtol=3e-7, atol=0)
+    # particles ahead of the first header: NaN state of the reference (pack9.py:66-71)
+    d = G['real.pack9.in']
+    first = int(np.nonzero(d[:, 0] == 0xFF)[0][0])
+    tail = np.concatenate([d[first + 1:first + 4], d[first:]])
+    pos, vel = oracle.unpack_pack9(tail, 32.0, 3200.0)
+    assert np.isnan(pos[:3]).all() and np.isnan(vel[:3]).all() and not np.isnan(pos[3:]).any()
