@@ -428,7 +428,7 @@ int grid_for(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(ceil_d
 
 extern "C" int abacus_unpack_rvint(const int32_t *intdata, int64_t n, double boxsize, int out_f64, void *posout,
                                    void *velout) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (n < 0 || (n > 0 && !intdata)) return fail("abacus_unpack_rvint: null input");
     if (n == 0 || (!posout && !velout)) return 0;
     static DevBuf b_in, b_pos, b_vel;
@@ -456,7 +456,7 @@ extern "C" int abacus_unpack_rvint(const int32_t *intdata, int64_t n, double box
 
 extern "C" int abacus_unpack_pids(const uint64_t *packed, int64_t n, double box, int64_t ppd, int out_f64, int64_t *pid,
                                   void *lagr_pos, int16_t *lagr_idx, uint8_t *tagged, void *density) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (n < 0 || (n > 0 && !packed)) return fail("abacus_unpack_pids: null input");
     if (ppd < 1) return fail("abacus_unpack_pids: ppd must be a positive integer");
     if (n == 0) return 0;
@@ -496,7 +496,7 @@ extern "C" int abacus_unpack_pids(const uint64_t *packed, int64_t n, double box,
 
 extern "C" int abacus_unpack_pack9(const uint8_t *data, int64_t nrec, double boxsize, double velzspace_to_kms, int out_f64,
                                    void *posout, void *velout, int64_t *npart) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (nrec < 0 || (nrec > 0 && !data) || !npart) return fail("abacus_unpack_pack9: null argument");
     *npart = 0;
     if (nrec == 0) return 0;
@@ -582,7 +582,7 @@ int menv_run(const P *pos, const M *mass, int64_t n, const R *r_inner, int inner
 extern "C" int abacus_menv(const void *pos, int pos_f64, const void *mass, int mass_f64, int64_t n, const void *r_inner,
                            int64_t n_inner, const void *r_outer, int64_t n_outer, int r_f64, double r_outer_max,
                            double Lbox, int periodic, const double *lo, const double *hi, double mcut, double *Menv) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (n < 0) return fail("abacus_menv: negative count");
     if (n == 0) return 0;
     if (!pos || !mass || !r_inner || !r_outer || !Menv) return fail("abacus_menv: null argument");

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 namespace abacus {
@@ -20,6 +21,13 @@ hipStream_t stream();
         if (e_ != hipSuccess)                                                                               \
             return ::abacus::fail("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);      \
     } while (0)
+
+// Every extern "C" entry point starts with ABACUS_ENTER(): the library keeps one stream and reusable scratch
+// allocations, so concurrent callers (ctypes releases the GIL) are serialised here; nested entry points re-enter.
+std::recursive_mutex &api_mutex();
+#define ABACUS_ENTER()                                                              \
+    std::lock_guard<std::recursive_mutex> abacus_api_guard_(::abacus::api_mutex()); \
+    ABACUS_TRY(::abacus::ensure_init())
 
 #define ABACUS_TRY(expr)        \
     do {                        \

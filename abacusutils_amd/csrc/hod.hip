@@ -1096,7 +1096,7 @@ int launch_emit(abacus_hod_state *st) {
 extern "C" {
 
 int abacus_hod_stage(const abacus_hod_arrays *a, int on_device, abacus_hod_state **out) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!a || !out) return fail("abacus_hod_stage: null argument");
     if (a->n_halo < 0 || a->n_part < 0) return fail("abacus_hod_stage: negative length");
     if (a->n_halo > 0 && (!a->hpos || !a->hvel || !a->hmass || !a->hid || !a->hmultis || !a->hrandoms || !a->hveldev))
@@ -1155,7 +1155,7 @@ int abacus_hod_update(abacus_hod_state *st, const char *field, const double *hos
 }
 
 int abacus_hod_set_sigma3d(abacus_hod_state *st, const double *sigma3d, int on_device) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!st || !sigma3d) return fail("abacus_hod_set_sigma3d: null argument");
     if (st->owns_sigma && st->hsigma3d) HIP_TRY(hipFree(st->hsigma3d));
     st->hsigma3d = nullptr;
@@ -1172,7 +1172,7 @@ int abacus_hod_set_sigma3d(abacus_hod_state *st, const double *sigma3d, int on_d
 }
 
 int abacus_hod_reseed(abacus_hod_state *st, uint64_t seed, int want_expvel, int64_t halo_index0, int64_t part_index0) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!st) return fail("abacus_hod_reseed: null handle");
     if (!st->owns) return fail("abacus_hod_reseed: the catalogue was staged from caller-owned device arrays (read-only)");
     if (st->nh > 0 && !st->hsigma3d) return fail("abacus_hod_reseed: hsigma3d has not been set (abacus_hod_set_sigma3d)");
@@ -1205,7 +1205,7 @@ int abacus_hod_fetch_field(abacus_hod_state *st, const char *field, double *host
 }
 
 int abacus_hod_set_profile(abacus_hod_state *st, const double *hc, const double *hrvir) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!st || !hc || !hrvir) return fail("abacus_hod_set_profile: null argument");
     const size_t bytes = (size_t)(st->nh > 0 ? st->nh : 1) * sizeof(double);
     if (!st->hc) HIP_TRY(hipMalloc((void **)&st->hc, bytes));
@@ -1218,7 +1218,7 @@ int abacus_hod_set_profile(abacus_hod_state *st, const double *hc, const double 
 
 int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, const abacus_nfw_params *nfw,
                             const double *NFW_draw, int64_t n_draw, int64_t counts[6]) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!st || !p || !nfw) return fail("abacus_hod_populate_nfw: null argument");
     if (p->has_origin) return fail("abacus_hod_populate_nfw: the NFW path does not support light cones (hod/GRAND_HOD.py:551)");
     if (st->nh > 0 && (!st->hsigma3d || !st->hc || !st->hrvir))
@@ -1303,7 +1303,7 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
 }
 
 int abacus_hod_set_ngal_bins(abacus_hod_state *st, const uint8_t *bins4, const double *centres, int nbin) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!st || !bins4 || !centres) return fail("abacus_hod_set_ngal_bins: null argument");
     if (nbin < 1 || nbin > 254) return fail("abacus_hod_set_ngal_bins: nbin must be in [1, 254]");
     ABACUS_TRY(st->ngal_bins.reserve((size_t)(st->nh > 0 ? st->nh : 1) * 4));
@@ -1317,7 +1317,7 @@ int abacus_hod_set_ngal_bins(abacus_hod_state *st, const uint8_t *bins4, const d
 }
 
 int abacus_hod_ngal(abacus_hod_state *st, const abacus_hod_params *p, double out[6]) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!st || !p || !out) return fail("abacus_hod_ngal: null argument");
     if (!st->ngal_nbin) return fail("abacus_hod_ngal: the histogram cells have not been set (abacus_hod_set_ngal_bins)");
     HIP_TRY(hipMemsetAsync(st->ngal_out.p, 0, 6 * sizeof(double), stream()));
@@ -1335,7 +1335,7 @@ int abacus_hod_ngal(abacus_hod_state *st, const abacus_hod_params *p, double out
 }
 
 int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!st || !p) return fail("abacus_hod_populate: null argument");
     if (p->enable_ranks && st->np > 0 && (!st->pranks || !st->pranksv || !st->pranksp || !st->pranksr))
         return fail("abacus_hod_populate: enable_ranks set but the rank arrays were not staged");

@@ -354,7 +354,7 @@ extern "C" int abacus_paircount(int mode, const float *x1, const float *y1, cons
                                 const float *x2, const float *y2, const float *z2, int64_t n2, float boxsize,
                                 const float *bins, int nbins, float pimax, int npibins, float mu_max, int nmubins,
                                 uint64_t *npairs) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (mode < 0 || mode > 2) return fail("abacus_paircount: unknown mode %d", mode);
     if (!x1 || !y1 || !z1 || !bins || !npairs || nbins < 1) return fail("abacus_paircount: null/empty argument");
     if (nbins > 63) return fail("abacus_paircount: more than 63 separation bins");

@@ -42,7 +42,7 @@ __global__ void part_gather(const PT *__restrict__ pos, const PT *__restrict__ w
 template <typename PT>
 int partition_impl(const void *pos_, int64_t n, const void *w_, int npartition, double box, int coord, void *psort_,
                    int64_t *starts, void *wsort_) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (npartition < 1) return fail("abacus_partition: npartition < 1");
     if (coord < 0 || coord > 2) return fail("abacus_partition: coord out of range");
     if (n >= (int64_t)1 << 32) return fail("abacus_partition: more than 2^32 particles");

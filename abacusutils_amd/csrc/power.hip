@@ -854,7 +854,7 @@ int abacus_power_from_particles_dev(float *pos, int64_t n, const float *w, float
                                     const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
                                     int Np, float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles,
                                     float *k_avg) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     return power_dev(pos, n, w, pos2, n2, w2, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu, poles,
                      Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
 }
@@ -864,7 +864,7 @@ int abacus_power_from_particles(float *pos, int64_t n, const float *w, float *po
                                 const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
                                 int Np, float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles,
                                 float *k_avg) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     float *pd, *wd, *pd2 = nullptr, *wd2 = nullptr;
     ABACUS_TRY(stage_particles(pos, n, w, g_ctx.pos, g_ctx.w, &pd, &wd));
     if (pos2) ABACUS_TRY(stage_particles(pos2, n2, w2, g_ctx.pos2, g_ctx.w2, &pd2, &wd2));
@@ -879,7 +879,7 @@ int abacus_power_from_particles(float *pos, int64_t n, const float *w, float *po
 }
 
 int abacus_field(float *pos, int64_t n, const float *w, double Lbox, int nmesh, int paste, double offset, float *field) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     ABACUS_TRY(check_common(nmesh, paste));
     if (n <= 0) return fail("power: empty particle set");
     if (!field) return fail("abacus_field: null output");
@@ -900,7 +900,7 @@ int abacus_field(float *pos, int64_t n, const float *w, double Lbox, int nmesh, 
 
 int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nmesh, int paste, const float *W_host,
                      int interlaced, void *out_c64) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     ABACUS_TRY(check_common(nmesh, paste));
     ABACUS_TRY(ensure_phase(nmesh));
     const float *W_dev;
@@ -927,7 +927,7 @@ int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nme
 int abacus_pk_from_deltak(const void *field, const void *field2, int nmesh, double Lbox, const double *kedges, int Nk,
                           const double *muedges, int Nmu, const int64_t *poles, int Np, float *power, int64_t *N_mode,
                           float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!field) return fail("abacus_pk_from_deltak: null field");
     if (nmesh < 2 || nmesh > 32767) return fail("power: nmesh %d out of range", nmesh);
     const size_t bytes = (size_t)nmesh * nmesh * (nmesh / 2 + 1) * 8;
@@ -950,7 +950,7 @@ int abacus_slab_pitch(int nmesh) { return pitch_r(nmesh); }
 
 int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int nx_local,
                             double Lbox, double offset, double norm, int paste) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     ABACUS_TRY(check_common(nmesh, paste));
     if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
     return tsc_deposit_slab_f32(pos, n, w, mesh, nmesh, xoff, nx_local, pitch_r(nmesh), Lbox, offset, paste == 0, norm,
@@ -958,7 +958,7 @@ int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, 
 }
 
 int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (nfloat % 4) return fail("abacus_slab_axpy_dev: length must be a multiple of 4");
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(nfloat / 4, 256), 1), 256 * 32);
     ABACUS_LAUNCH("slab_axpy", slab_axpy, dim3(grid), dim3(256), 0, dst, src, nfloat / 4, add);
@@ -966,13 +966,13 @@ int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add
 }
 
 int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
     return fft_native_zy(mesh, nmesh, pitch_r(nmesh), nx_local);
 }
 
 int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
     const int nyl = nmesh / world, pitch4 = pitch_r(nmesh) / 4;
     const int grid = (int)std::min<int64_t>((int64_t)world * nx_local * nyl, 256 * 32);
@@ -982,7 +982,7 @@ int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, 
 }
 
 int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int nx_local, int world) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
     const int nyl = nmesh / world, pitch4 = pitch_r(nmesh) / 4;
     const int grid = (int)std::min<int64_t>((int64_t)world * nx_local * nyl, 256 * 32);
@@ -992,7 +992,7 @@ int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int nx_local,
 }
 
 int abacus_slab_fft_x_dev(float *data, int nmesh, int ny_local) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
     const int pc = pitch_r(nmesh) / 2;
     return fft_native_x(data, nmesh, pitch_r(nmesh), ny_local, pc, (int64_t)nmesh * pc);   // layout (y_local, x, k)
@@ -1001,7 +1001,7 @@ int abacus_slab_fft_x_dev(float *data, int nmesh, int ny_local) {
 int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void *bs, int nmesh, int y0, int ny_local,
                         double Lbox, const float *W_host, int interlaced, const double *kedges, int Nk,
                         const double *muedges, int Nmu, const int64_t *poles, int Np, void *raw_out) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     ABACUS_TRY(ensure_phase(nmesh));
     const float *W_dev;
     ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
@@ -1051,7 +1051,7 @@ int bin_real_grid(const float *d_w, int n, int zdim, float prescale, double Lbox
 int abacus_bin_weights(const float *weights, int n1d, int zdim, double Lbox, int fourier, const double *kedges, int Nk,
                        const double *muedges, int Nmu, const int64_t *poles, int Np, double scale, float *power,
                        int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!weights || n1d < 2 || n1d > 32767 || zdim < n1d / 2 + 1) return fail("abacus_bin_weights: bad grid shape");
     const size_t bytes = (size_t)n1d * n1d * zdim * 4;
     ABACUS_TRY(g_ctx.helper_in.reserve(bytes));
@@ -1063,7 +1063,7 @@ int abacus_bin_weights(const float *weights, int n1d, int zdim, double Lbox, int
 
 int abacus_pk_to_xi(const float *Pk, int n, double Lbox, const double *redges, int Nr, const int64_t *poles, int Np,
                     float *binned_poles, int64_t *N_poles) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!Pk || n < 2 || n > 4096) return fail("abacus_pk_to_xi: bad grid size");
     const int kzlen = n / 2 + 1;
     // scipy's irfftn without `s` returns 2 (kzlen - 1) points along z: n for even n, n - 1 for odd n (:645); the
@@ -1098,7 +1098,7 @@ int abacus_pk_to_xi(const float *Pk, int n, double Lbox, const double *redges, i
 
 int abacus_bin_kppi(const float *weights, int n1d, int zdim, double Lbox, const double *kedges, int Nk, double pimax, int Npi,
                     int fourier, float *mean, int64_t *counts) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!weights || n1d < 2 || zdim < n1d / 2 + 1 || Nk < 1 || Npi < 1) return fail("abacus_bin_kppi: bad arguments");
     const double dk = fourier ? 2.0 * M_PI / Lbox : Lbox / n1d;
     std::vector<float> e((size_t)Nk + 1 + Npi + 1);
@@ -1131,7 +1131,7 @@ int abacus_bin_kppi(const float *weights, int n1d, int zdim, double Lbox, const 
 }
 
 int abacus_get_smoothing(int n1d, double Lbox, double R, float *out) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!out || n1d < 2) return fail("abacus_get_smoothing: bad arguments");
     const int64_t total = (int64_t)n1d * n1d * (n1d / 2 + 1);
     ABACUS_TRY(g_ctx.helper_in.reserve((size_t)total * 4));
@@ -1144,7 +1144,7 @@ int abacus_get_smoothing(int n1d, double Lbox, double R, float *out) {
 }
 
 int abacus_get_delta_mu2(const void *delta_c64, int n1d, void *out_c64) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!delta_c64 || !out_c64 || n1d < 2) return fail("abacus_get_delta_mu2: bad arguments");
     const int64_t total = (int64_t)n1d * n1d * (n1d / 2 + 1);
     ABACUS_TRY(g_ctx.mesh[0].reserve((size_t)total * 8));
@@ -1159,7 +1159,7 @@ int abacus_get_delta_mu2(const void *delta_c64, int n1d, void *out_c64) {
 
 int abacus_expand_poles_to_3d(const double *k_ell, const double *P_ell, int nk, int n1d, double Lbox, const int64_t *poles,
                               int Np, float *out) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!k_ell || !P_ell || !poles || !out || nk < 2 || n1d < 2 || Np < 1 || Np > MAX_POLES)
         return fail("abacus_expand_poles_to_3d: bad arguments");
     if (std::fabs((k_ell[1] - k_ell[0]) - (k_ell[nk - 1] - k_ell[nk - 2])) >= 1.0e-6)

@@ -27,6 +27,11 @@ int fail(const char *fmt, ...) {
     return -1;
 }
 
+std::recursive_mutex &api_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
 int ensure_init() {
     if (g_inited) return 0;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -120,7 +125,7 @@ int abacus_set_device(int device) {
 }
 
 int abacus_device_name(char *buf, int len) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, g_device));
     snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
@@ -128,7 +133,7 @@ int abacus_device_name(char *buf, int len) {
 }
 
 int abacus_device_sync(void) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     HIP_TRY(hipStreamSynchronize(g_stream));
     return 0;
 }
@@ -149,7 +154,7 @@ int abacus_set_stream(void *s) {
 }
 
 int abacus_malloc(void **dptr, uint64_t nbytes) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     HIP_TRY(hipMalloc(dptr, nbytes ? nbytes : 1));
     return 0;
 }
@@ -158,25 +163,25 @@ int abacus_free(void *dptr) {
     return 0;
 }
 int abacus_memcpy_h2d(void *dst, const void *src, uint64_t nbytes) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     return 0;
 }
 int abacus_memcpy_d2h(void *dst, const void *src, uint64_t nbytes) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     return 0;
 }
 int abacus_memset(void *dptr, int value, uint64_t nbytes) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     HIP_TRY(hipMemsetAsync(dptr, value, nbytes, g_stream));
     return 0;
 }
 
 int abacus_event_create(void **ev) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     *ev = (void *)e;
@@ -197,7 +202,7 @@ int abacus_event_destroy(void *ev) {
 }
 
 int abacus_profile_enable(int on) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (!on && g_prof) prof_drain();
     g_prof = on != 0;
     return 0;

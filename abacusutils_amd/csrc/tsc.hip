@@ -762,7 +762,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
 template <typename PT, typename GT, bool CIC>
 int deposit_host(void *pos_, int64_t n, const void *weights_, void *grid_, int gx, int gy, int gz, double box,
                  double offset, int wrap) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     const size_t cells = (size_t)gx * gy * gz;
     PT *dpos = nullptr, *dw = nullptr;
     GT *dgrid = nullptr;
@@ -847,7 +847,7 @@ int abacus_tsc_deposit(void *pos, int64_t n, const void *weights, int pos_dtype,
 
 int abacus_tsc_deposit_dev(float *pos, int64_t n, const float *weights, float *grid, int gx, int gy, int gz,
                            double box, double offset, int wrap, int zero_grid, int cic) {
-    ABACUS_TRY(ensure_init());
+    ABACUS_ENTER();
     if (cic)
         return deposit_dev<float, float, true>(pos, n, weights, grid, gx, gy, gz, gz, box, offset, 0, zero_grid, 0.0,
                                                nullptr);

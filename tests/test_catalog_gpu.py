@@ -178,3 +178,37 @@ def test_pack9_float64_protocol_and_edges():
     gp, gv = unpack_pack9(rnd, 2000.0, 208774.9, float_dtype=np.float64)
     wp, wv = oracle.unpack_pack9(rnd, 2000.0, 208774.9, np.float64)
     assert np.array_equal(gp, wp, equal_nan=True) and np.array_equal(gv, wv, equal_nan=True)
+
+
+def test_concurrent_callers_are_serialised():
+    """ctypes releases the GIL: entry points share one stream and scratch buffers, so they lock (ABACUS_ENTER)"""
+    import threading
+    from abacusutils_amd.analysis.tpcf_corrfunc import _paircount
+    rng = np.random.default_rng(21)
+    rv = rng.integers(-2**31, 2**31, size=(300000, 3), dtype=np.int64).astype(np.int32)
+    want_rv = oracle.unpack_rvint(rv, 100.0)
+    pts = (rng.random((3, 40000), dtype=np.float32) * np.float32(200.0))
+    bins = np.linspace(0.5, 10, 8).astype(np.float32)
+    want_dd = _paircount(0, pts[0], pts[1], pts[2], 200.0, bins)
+    pos = (rng.random((30000, 3)) * 100 - 50).astype(np.float32)
+    mass = 10 ** (11 + rng.random(30000))
+    want_me = do_Menv_from_tree(pos, mass, 0.4, 4.0, False, 100.0)
+    bad = []
+
+    def work(kind):
+        for _ in range(20):
+            if kind == 0:
+                p, v = bitpacked.unpack_rvint(rv, 100.0)
+                ok = np.array_equal(p, want_rv[0]) and np.array_equal(v, want_rv[1])
+            elif kind == 1:
+                ok = np.array_equal(_paircount(0, pts[0], pts[1], pts[2], 200.0, bins), want_dd)
+            else:
+                ok = np.allclose(do_Menv_from_tree(pos, mass, 0.4, 4.0, False, 100.0), want_me, rtol=1e-12, atol=0)
+            if not ok:
+                bad.append(kind)
+    ts = [threading.Thread(target=work, args=(k % 3,)) for k in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad
