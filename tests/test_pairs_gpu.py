@@ -92,3 +92,22 @@ def test_cross_symmetry_and_scale():
     ba = T.DD(0, 1, bins, *b, X2=a[0], Y2=a[1], Z2=a[2], periodic=True, boxsize=box)['npairs']
     np.testing.assert_array_equal(ab, ba)
     assert ab.sum() > 0
+
+
+def test_full_size_c5_properties(monkeypatch):
+    """BASELINE config 5 size (1e7 points, 2 Gpc/h box, 13 log bins to 30 Mpc/h): the persistent kernel and the
+    first-generation one-workgroup-per-cell kernel count exactly the same pairs, and uniform randoms give the analytic
+    expectation N (N-1) V_shell / V within 5 sigma of the Poisson error in every bin"""
+    from abacusutils_amd.analysis import tpcf_corrfunc as T
+    n, box = 10_000_000, 2000.0
+    rng = np.random.default_rng(500)
+    p = rng.random((3, n), dtype=np.float32) * np.float32(box)
+    bins = np.geomspace(0.1, 30.0, 14)
+    got = T.DD(1, 1, bins, p[0], p[1], p[2], periodic=True, boxsize=box)['npairs']
+    monkeypatch.setenv('ABACUS_PAIRS_V1', '1')
+    old = T.DD(1, 1, bins, p[0], p[1], p[2], periodic=True, boxsize=box)['npairs']
+    np.testing.assert_array_equal(got, old)
+    b32 = bins.astype(np.float32).astype(np.float64)
+    expect = float(n) * (n - 1) * 4 / 3 * np.pi * (b32[1:] ** 3 - b32[:-1] ** 3) / box**3
+    # ordered pairs: each unordered pair is counted twice, so the variance is 2 * expect
+    assert np.all(np.abs(got - expect) < 5 * np.sqrt(2 * expect) + 2), (got, expect)
