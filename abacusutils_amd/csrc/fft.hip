@@ -24,7 +24,8 @@ using namespace abacus;
 
 namespace {
 
-constexpr int FFT_THREADS = 512;
+constexpr int FFT_THREADS = 512;   // column passes
+constexpr int Z_THREADS = 256;     // z pass: small tiles (4 rows), several workgroups per CU
 constexpr int PADSHIFT = 4;   // one pad element per 16: de-conflicts the stride-R accesses of the late passes
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -147,18 +148,149 @@ __device__ __forceinline__ void dif_pass(float2 *lds, int colpitch, int ncol, co
     __syncthreads();
 }
 
-template <int N, int L, int NT = FFT_THREADS>
+// frequency held at position `pos` after the in-place DIF passes (inverse of revpos)
+template <int N>
+__device__ __forceinline__ int freq_of_pos(int pos) {
+    int f = 0, L = N, w = 1;
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        if (L == 1) break;
+        const int R = radix_of(L);
+        const int d = pos / (L / R);
+        pos -= d * (L / R);
+        f += d * w;
+        w *= R;
+        L /= R;
+    }
+    return f;
+}
+
+// The last pass (L == R, no twiddles), writing NATURAL order: every butterfly of the workgroup is loaded and transformed
+// into registers first, then - behind a barrier, the writes land on other threads' inputs - element f goes to position
+// f.  The write-backs then read consecutive positions: conflict-free, where digit-reversed reads of consecutive
+// frequencies land 4 (z pass) or 2 (column passes) lanes on every bank pair.
+template <int N, int R, int NT, int MAXCOL>
+__device__ __forceinline__ void dif_last_natural(float2 *lds, int colpitch, int ncol) {
+    constexpr int BPC = N / R;
+    constexpr int MAXIT = (MAXCOL * BPC + NT - 1) / NT;
+    const int total = ncol * BPC;
+    float2 a[MAXIT][R];
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+        const int b = it * NT + threadIdx.x;
+        if (b < total) {
+            const int col = b / BPC, t = b % BPC;
+            const float2 *c = lds + col * colpitch;
+#pragma unroll
+            for (int r = 0; r < R; r++) a[it][r] = c[padq(t * R + r)];
+            dft<R>(a[it]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+        const int b = it * NT + threadIdx.x;
+        if (b < total) {
+            const int col = b / BPC, t = b % BPC;
+            float2 *c = lds + col * colpitch;
+            const int f0 = freq_of_pos<N>(t * R);          // position t*R + r holds frequency f0 + r * (N / R)
+#pragma unroll
+            for (int r = 0; r < R; r++) c[padq(f0 + r * (N / R))] = a[it][r];
+        }
+    }
+    __syncthreads();
+}
+
+// MAXCOL > 0: the last pass leaves natural order (dif_last_natural, MAXCOL = most columns a tile can hold);
+// MAXCOL = 0: every pass in place, frequency f at revpos(f) - the column passes at N = 1024 x 16 columns would need
+// 32 more complex registers per thread next to the 64 prefetch registers and spill.
+template <int N, int L, int NT = FFT_THREADS, int MAXCOL = 0>
 struct Passes {
     static __device__ __forceinline__ void run(float2 *lds, int colpitch, int ncol, const float2 *tw) {
         constexpr int R = radix_of(L);
-        dif_pass<N, L, R, NT>(lds, colpitch, ncol, tw);
-        Passes<N, L / R, NT>::run(lds, colpitch, ncol, tw);
+        if constexpr (L == R && MAXCOL > 0) {
+            dif_last_natural<N, R, NT, MAXCOL>(lds, colpitch, ncol);
+        } else {
+            dif_pass<N, L, R, NT>(lds, colpitch, ncol, tw);
+            if constexpr (L > R) Passes<N, L / R, NT, MAXCOL>::run(lds, colpitch, ncol, tw);
+        }
     }
 };
-template <int N, int NT>
-struct Passes<N, 1, NT> {
-    static __device__ __forceinline__ void run(float2 *, int, int, const float2 *) {}
+
+// ---- wave-local transforms: one 64-lane wave owns a whole column (N >= 512: at least 64 butterflies per pass) --------
+// A column's passes then need no workgroup barrier at all - LDS executes one wave's instructions in order, so a wave-level
+// fence between the passes is enough - and the waves of a workgroup drift apart, hiding each other's LDS latency.  The
+// last pass holds only N/64 complex values per lane, so it can always leave natural order.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N, int L, int R>
+__device__ __forceinline__ void butterfly_w(float2 *c, const float2 *tw, int t) {
+    constexpr int LR = L / R;
+    const int blk = t / LR, j = t % LR;
+    const int base = blk * L + j;
+    float2 a[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) a[r] = c[padq(base + r * LR)];
+    dft<R>(a);
+#pragma unroll
+    for (int r = 1; r < R; r++) a[r] = cmul(a[r], tw[j * r * (N / L)]);
+#pragma unroll
+    for (int r = 0; r < R; r++) c[padq(base + r * LR)] = a[r];
+}
+
+// UNR: unroll the butterflies of one lane (more LDS reads in flight; the column pass at N = 1024 has no registers to spare)
+template <int N, int L, int R, bool UNR>
+__device__ __forceinline__ void dif_pass_w(float2 *c, const float2 *tw, int lane) {
+    constexpr int BPC = N / R;
+    static_assert(BPC % 64 == 0, "wave-local passes need a multiple of 64 butterflies per column");
+    if constexpr (UNR) {
+#pragma unroll
+        for (int t0 = 0; t0 < BPC; t0 += 64) butterfly_w<N, L, R>(c, tw, t0 + lane);
+    } else {
+#pragma unroll 1
+        for (int t0 = 0; t0 < BPC; t0 += 64) butterfly_w<N, L, R>(c, tw, t0 + lane);
+    }
+    wave_sync();
+}
+
+template <int N, int R>
+__device__ __forceinline__ void dif_last_w(float2 *c, int lane) {
+    constexpr int BPC = N / R, IT = BPC / 64;
+    static_assert(BPC % 64 == 0, "wave-local passes need a multiple of 64 butterflies per column");
+    float2 a[IT][R];
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int t = it * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < R; r++) a[it][r] = c[padq(t * R + r)];
+        dft<R>(a[it]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int f0 = freq_of_pos<N>((it * 64 + lane) * R);
+#pragma unroll
+        for (int r = 0; r < R; r++) c[padq(f0 + r * (N / R))] = a[it][r];
+    }
+}
+
+template <int N, int L, bool UNR = false>
+struct PassesW {
+    static __device__ __forceinline__ void run(float2 *c, const float2 *tw, int lane) {
+        constexpr int R = radix_of(L);
+        if constexpr (L == R) {
+            dif_last_w<N, R>(c, lane);
+        } else {
+            dif_pass_w<N, L, R, UNR>(c, tw, lane);
+            PassesW<N, L / R, UNR>::run(c, tw, lane);
+        }
+    }
 };
+constexpr bool wave_local(int N) { return N == 512 || N == 1024; }   // the production sizes (n = 1024, 2048)
 
 template <int N>
 constexpr int colpitch_of() { return N + (N >> PADSHIFT) + 1; }   // odd: adjacent columns fall into different banks
@@ -178,18 +310,18 @@ constexpr int colpitch_of() { return N + (N >> PADSHIFT) + 1; }   // odd: adjace
 // segments at n = 2048, which the memory system serves at the in-place floor instead of 3.4 TB/s.
 // Row r of either half then holds frequency 2 (r mod n/2) + (r div n/2) along that axis.
 template <int N, int B, bool FUSE>
-__global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
+__global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
                                                          const float2 *__restrict__ twN, const float2 *__restrict__ tw2N,
                                                          int dbg) {
     constexpr int CP = colpitch_of<N>();
-    constexpr int NLD = (B * (N / 2) + FFT_THREADS - 1) / FFT_THREADS;   // 16-B loads per thread and tile
+    constexpr int NLD = (B * (N / 2) + Z_THREADS - 1) / Z_THREADS;   // 16-B loads per thread and tile
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float2 *tw2 = tw + N;            // exp(-2 pi i k / 2N), k = 0..N (kept in LDS: a global load inside the loop would
     float2 *lds = tw2 + N + 2;       //  make the compiler drain the prefetch with vmcnt(0))
     const int tid = threadIdx.x;
-    for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
-    for (int q = tid; q <= N; q += FFT_THREADS) tw2[q] = tw2N[q];
+    for (int q = tid; q < N; q += Z_THREADS) tw[q] = twN[q];
+    for (int q = tid; q <= N; q += Z_THREADS) tw2[q] = tw2N[q];
     static_assert(!FUSE || B == 4, "the fused first stages work on 2 x 2 rows");
     constexpr int NF = 2 * N;                               // mesh size n
     const int64_t ntiles = FUSE ? (int64_t)N * N : (nrows + B - 1) / B;
@@ -205,7 +337,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
         const int nb = FUSE ? B : (int)min((int64_t)B, nrows - tile * B);
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
-            const int e = q * FFT_THREADS + tid;
+            const int e = q * Z_THREADS + tid;
             const int r = min(e / (N / 2), nb - 1), m = (e % (N / 2)) * 2;   // rows past the end re-read the last row
             gload16_async(regs[q], mesh + row_of(tile, r) * pitch_r + 2 * m);
         }
@@ -215,9 +347,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
         for (int q = 0; q < NLD; q++) touch(regs[q]);
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
-            const int e = q * FFT_THREADS + tid;
+            const int e = q * Z_THREADS + tid;
             const int r = e / (N / 2), m = (e % (N / 2)) * 2;
-            if ((B * (N / 2)) % FFT_THREADS == 0 || r < B) {
+            if ((B * (N / 2)) % Z_THREADS == 0 || r < B) {
                 float2 *c = lds + r * CP;
                 c[padq(m)] = make_float2(regs[q].x, regs[q].y);
                 c[padq(m + 1)] = make_float2(regs[q].z, regs[q].w);
@@ -230,7 +362,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
     wait_vmcnt<0>();
     stage();
     // stores every thread issues per full tile (threads with one more only wait longer): vmcnt(that) = loads landed
-    const int stores_min = FUSE ? 4 * ((pitch_c / 2) / FFT_THREADS) : (B * (pitch_c / 2)) / FFT_THREADS;
+    const int stores_min = FUSE ? 4 * ((pitch_c / 2) / Z_THREADS) : (B * (pitch_c / 2)) / Z_THREADS;
     for (;;) {
         __syncthreads();
         const int64_t next = tile + gridDim.x;
@@ -238,12 +370,20 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
         if (has_next) prefetch(next);   // in flight during the transform and the write-back below
         const int64_t row0 = tile * B;
         const int nb = FUSE ? B : (int)min((int64_t)B, nrows - row0);
-        if (!(dbg & 1)) Passes<N, N>::run(lds, CP, nb, tw);
+        if (!(dbg & 1)) {
+            if constexpr (wave_local(N)) {   // one row per wave at a time; the write-back below reads across rows
+#pragma unroll 1
+                for (int r = tid >> 6; r < nb; r += Z_THREADS / 64) PassesW<N, N>::run(lds + r * CP, tw, tid & 63);
+                __syncthreads();
+            } else {
+                Passes<N, N, Z_THREADS, B>::run(lds, CP, nb, tw);
+            }
+        }
         // even/odd split: X_k = E + (-i W_2N^k) O with E = (Z_k + conj Z_{N-k})/2, O = (Z_k - conj Z_{N-k})/2, k = 0..N.
         // A thread forms two adjacent outputs (one 16-B store); the row is written over its whole pitch (zeros behind
         // k = N) so that no partial 128-B line is ever written.
         if (!(dbg & 2) && !FUSE)
-            for (int e = tid; e < nb * (pitch_c / 2); e += FFT_THREADS) {
+            for (int e = tid; e < nb * (pitch_c / 2); e += Z_THREADS) {
                 const int r = e / (pitch_c / 2), k0 = (e % (pitch_c / 2)) * 2;
                 const float2 *c = lds + r * CP;
                 float2 X[2];
@@ -252,8 +392,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
                     const int k = k0 + u;
                     X[u] = make_float2(0.f, 0.f);
                     if (k <= N) {
-                        const float2 zk = c[padq(revpos<N>(k & (N - 1)))];
-                        const float2 zn = c[padq(revpos<N>((N - k) & (N - 1)))];
+                        const float2 zk = c[padq(k & (N - 1))];
+                        const float2 zn = c[padq((N - k) & (N - 1))];
                         const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
                         const float2 O = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
                         const float2 w = tw2[k];                             // exp(-2 pi i k / 2N) = (cos, -sin)
@@ -270,7 +410,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
             sincospif((float)y / (float)N, &sy, &cy);        // W_n^y = exp(-2 pi i y / n), n = 2N
             sincospif((float)x / (float)N, &sx, &cx);
             const float2 Wy = make_float2(cy, -sy), Wx = make_float2(cx, -sx);
-            for (int k2 = tid; k2 < pitch_c / 2; k2 += FFT_THREADS) {
+            for (int k2 = tid; k2 < pitch_c / 2; k2 += Z_THREADS) {
                 const int k0 = k2 * 2;
                 float2 X[4][2];
 #pragma unroll
@@ -281,8 +421,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_z_r2c(float *__restrict__ mes
                         const int k = k0 + u;
                         X[r][u] = make_float2(0.f, 0.f);
                         if (k <= N) {
-                            const float2 zk = c[padq(revpos<N>(k & (N - 1)))];
-                            const float2 zn = c[padq(revpos<N>((N - k) & (N - 1)))];
+                            const float2 zk = c[padq(k & (N - 1))];
+                            const float2 zn = c[padq((N - k) & (N - 1))];
                             const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
                             const float2 O = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
                             const float2 w = tw2[k];
@@ -367,7 +507,15 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
         const int64_t next = t + gridDim.x;
         const bool has_next = next < ntiles;
         if (has_next) prefetch(next);
-        if (!(dbg & 1)) Passes<N, N>::run(lds, CP, C, tw);
+        if (!(dbg & 1)) {
+            if constexpr (wave_local(N)) {
+#pragma unroll 1
+                for (int c = tid >> 6; c < C; c += FFT_THREADS / 64) PassesW<N, N>::run(lds + c * CP, tw, tid & 63);
+                __syncthreads();
+            } else {
+                Passes<N, N>::run(lds, CP, C, tw);
+            }
+        }
         if (!(dbg & 2)) {
             float2 *g = tile_base(t);
             // constant trip count: the compiler can then count these stores in its vmcnt bookkeeping
@@ -376,7 +524,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
                 const int e = q * FFT_THREADS + tid;
                 const int c2 = (e % (C / 2)) * 2, f = e / (C / 2);
                 if (WHOLE || f < N) {
-                    const int p = padq(revpos<N>(f));
+                    const int p = padq(wave_local(N) ? f : revpos<N>(f));
                     const float2 a = lds[c2 * CP + p], b = lds[(c2 + 1) * CP + p];
                     *reinterpret_cast<float4 *>(g + (int64_t)f * S + c2) = make_float4(a.x, a.y, b.x, b.y);
                 }
@@ -437,9 +585,9 @@ int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
                                 (int)lds));
     const int64_t ntiles = FUSE ? (int64_t)N * N : ceil_div(nrows, B);
     int per_cu = 1;   // persistent grid = exactly the resident workgroups (a larger grid would run in two uneven waves)
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_z_r2c<N, B, FUSE>, FFT_THREADS, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_z_r2c<N, B, FUSE>, Z_THREADS, lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
-    ABACUS_LAUNCH("fft_z_r2c", (fft_z_r2c<N, B, FUSE>), dim3(grid), dim3(FFT_THREADS), lds, mesh, nrows,
+    ABACUS_LAUNCH("fft_z_r2c", (fft_z_r2c<N, B, FUSE>), dim3(grid), dim3(Z_THREADS), lds, mesh, nrows,
                   pitch_r, t->twHalf.as<float2>(), t->tw2.as<float2>(), getenv("ABACUS_DBG_FFT") ? atoi(getenv("ABACUS_DBG_FFT")) : 0);
     return 0;
 }
