@@ -497,15 +497,27 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
             }
         }
     };
-    int64_t t = blockIdx.x;
-    if (t >= ntiles) return;
+    // Tile order.  Workgroups b and b + 8 share an XCD (round-robin dispatch; a speed assumption only): the 8 groups
+    // take whole outer indices (o = 8 * og + group), so the workgroups of one XCD walk the column tiles of the same few
+    // outer indices - for the x pass that is the same set of N pages (rows 17 MB apart at n = 2048) instead of every
+    // XCD touching the pages of every outer index in flight.  Falls back to the flat order when the grid or the outer
+    // count does not divide.
+    const int64_t n_outer = ntiles / ntile_c;
+    const bool xmap = (gridDim.x % 8 == 0) && (n_outer % 8 == 0) && !(dbg & 8);
+    const int64_t grp = xmap ? (blockIdx.x & 7) : 0, ostep = xmap ? 8 : 1;
+    const int64_t qstep = xmap ? (gridDim.x >> 3) : gridDim.x, nq = ntiles / ostep;
+    auto tile_of = [&](int64_t i) { return ((i / ntile_c) * ostep + grp) * ntile_c + i % ntile_c; };
+    int64_t qi = xmap ? (blockIdx.x >> 3) : blockIdx.x;
+    if (qi >= nq) return;
+    int64_t t = tile_of(qi);
     prefetch(t);
     wait_vmcnt<0>();
     stage();
     for (;;) {
         __syncthreads();
-        const int64_t next = t + gridDim.x;
-        const bool has_next = next < ntiles;
+        qi += qstep;
+        const bool has_next = qi < nq;
+        const int64_t next = has_next ? tile_of(qi) : 0;
         if (has_next) prefetch(next);
         if (!(dbg & 1)) {
             if constexpr (wave_local(N)) {
