@@ -75,4 +75,13 @@ struct DevBuf {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Orders the LDS traffic of ONE wave: its lanes' earlier LDS writes are visible to its lanes' later LDS reads (the LDS
+// executes a wave's instructions in order; the fences keep the compiler from moving accesses across).  Lets a wave that
+// owns a private LDS region work without workgroup barriers.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 }  // namespace abacus

@@ -221,12 +221,6 @@ struct Passes {
 // A column's passes then need no workgroup barrier at all - LDS executes one wave's instructions in order, so a wave-level
 // fence between the passes is enough - and the waves of a workgroup drift apart, hiding each other's LDS latency.  The
 // last pass holds only N/64 complex values per lane, so it can always leave natural order.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <int N, int L, int R>
 __device__ __forceinline__ void butterfly_w(float2 *c, const float2 *tw, int t) {
     constexpr int LR = L / R;

@@ -180,7 +180,8 @@ template <bool INTER, bool CROSS>
 __device__ __forceinline__ void tile_load(const SpecArgs &s, int64_t base, int64_t total, TileRegs<INTER, CROSS> &r) {
 #pragma unroll
     for (int q = 0; q < BinCfg<INTER, CROSS>::LOADS; q++) {
-        const int64_t idx = base + (int64_t)(q * BIN_THREADS + threadIdx.x) * 2;
+        // wave-local: wave w loads the modes [w * 64 * EPT, (w + 1) * 64 * EPT) its own lanes bin, 1 KB per load
+        const int64_t idx = base + (int64_t)(threadIdx.x >> 6) * (64 * BinCfg<INTER, CROSS>::EPT) + (q * 64 + (threadIdx.x & 63)) * 2;
         r.a[q] = ld4(s.a, idx, total);
         if (INTER) r.as[q] = ld4(s.as, idx, total);
         if (CROSS) r.b[q] = ld4(s.b, idx, total);
@@ -206,7 +207,7 @@ __device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int6
     }
 #pragma unroll
     for (int q = 0; q < BinCfg<INTER, CROSS>::LOADS; q++) {
-        const int e = (q * BIN_THREADS + threadIdx.x) * 2;
+        const int e = (threadIdx.x >> 6) * (64 * EPT) + (q * 64 + (threadIdx.x & 63)) * 2;
         int i = 0, j = 0, k = 0, i2 = 0, j2 = 0, k2 = 0;
         if (need_idx) {
             const unsigned int kk = (unsigned int)(k0 + e);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
         // ---- power of this tile's modes: registers -> LDS; then prefetch the next tile into the registers, so its
         //      HBM latency is covered by the binning below ----
         if (!(b.dbg & 2)) tile_store<INTER, CROSS>(s, base, total, regs, tile);
-        __syncthreads();
+        wave_sync();   // a wave stages and bins its own 64 * EPT modes: no workgroup barrier, the waves drift apart
         if (t + gridDim.x < ntiles) tile_load<INTER, CROSS>(s, (t + gridDim.x) * BIN_TILE, total, regs);
         // ---- bin: every thread walks EPT consecutive elements: at most two row segments.  Along a row |k| and mu only
         //      grow with kz, so a segment is located once (binary searches at its first binned mode) and the inner loop
@@ -383,8 +384,9 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
             }
             flush();
         }
-        __syncthreads();
+        wave_sync();   // this wave's part of the tile buffer is free for its next staging
     }
+    __syncthreads();
     // ---- flush the workgroup histogram ----
     for (int q = tid; q < nb; q += BIN_THREADS) {
         if (h_cnt[q]) {
