@@ -327,11 +327,13 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
     };
     const int pitch_c = pitch_r / 2;
     v4f regs[NLD];
+    // WLS: one row per wave - a wave loads, stages and transforms its own row; only the write-back crosses rows
+    constexpr bool WLS = wave_local(N) && B * 64 == Z_THREADS;
     auto prefetch = [&](int64_t tile) {
         const int nb = FUSE ? B : (int)min((int64_t)B, nrows - tile * B);
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
-            const int e = q * Z_THREADS + tid;
+            const int e = WLS ? (tid >> 6) * (N / 2) + q * 64 + (tid & 63) : q * Z_THREADS + tid;
             const int r = min(e / (N / 2), nb - 1), m = (e % (N / 2)) * 2;   // rows past the end re-read the last row
             gload16_async(regs[q], mesh + row_of(tile, r) * pitch_r + 2 * m);
         }
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
         for (int q = 0; q < NLD; q++) touch(regs[q]);
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
-            const int e = q * Z_THREADS + tid;
+            const int e = WLS ? (tid >> 6) * (N / 2) + q * 64 + (tid & 63) : q * Z_THREADS + tid;
             const int r = e / (N / 2), m = (e % (N / 2)) * 2;
             if ((B * (N / 2)) % Z_THREADS == 0 || r < B) {
                 float2 *c = lds + r * CP;
@@ -357,8 +359,10 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
     stage();
     // stores every thread issues per full tile (threads with one more only wait longer): vmcnt(that) = loads landed
     const int stores_min = FUSE ? 4 * ((pitch_c / 2) / Z_THREADS) : (B * (pitch_c / 2)) / Z_THREADS;
+    if constexpr (WLS) __syncthreads();   // the twiddle tables (written by all waves) before the first transform
     for (;;) {
-        __syncthreads();
+        if constexpr (WLS) wave_sync();   // the row staged by this wave is the row it transforms
+        else __syncthreads();
         const int64_t next = tile + gridDim.x;
         const bool has_next = next < ntiles;
         if (has_next) prefetch(next);   // in flight during the transform and the write-back below
