@@ -240,7 +240,10 @@ __device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int6
 }
 
 // NP: compile-time number of ell != 0 multipoles (0..3), or -1 for the generic loop over b.Np
-template <bool INTER, bool CROSS, int NP>
+// PD: degree (in mu^2) of the Horner evaluation of the Legendre weights, 2 (ell <= 4) or 5; the coefficients are
+// hoisted into registers, zero-padded above a pole's own degree (0 * mu^2 + c is c: bit-identical to starting at the
+// pole's degree) - indexing the kernel-argument arrays in the loop costs a scalar memory load + wait per mode
+template <bool INTER, bool CROSS, int NP, int PD>
 __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs b) {
     constexpr int BIN_EPT = BinCfg<INTER, CROSS>::EPT, BIN_TILE = BinCfg<INTER, CROSS>::TILE_MODES;
     constexpr int NPC = NP < 0 ? MAX_POLES : (NP > 0 ? NP : 1);
@@ -267,6 +270,11 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
     __syncthreads();
     const float klo = ke[0], khi = ke[b.Nk];
     const int n = s.n, kzlen = s.kzlen, pitch = s.pitch;
+    float pc[NPC][PD + 1];
+#pragma unroll
+    for (int q = 0; q < NPC; q++)
+#pragma unroll
+        for (int m = 0; m <= PD; m++) pc[q][m] = (q < np && m <= b.poledeg[q]) ? b.polecoef[q][m] : 0.f;
     const int64_t total = s.nrows * pitch;
     const int64_t ntiles = (total + BIN_TILE - 1) / BIN_TILE;
 
@@ -370,9 +378,9 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
 #pragma unroll
                         for (int q = 0; q < NPC; q++)
                             if (q < np) {
-                                const float *c = b.polecoef[q];
-                                float Lq = c[b.poledeg[q]];
-                                for (int m = b.poledeg[q] - 1; m >= 0; m--) Lq = Lq * mu2 + c[m];
+                                float Lq = pc[q][PD];
+#pragma unroll
+                                for (int m = PD - 1; m >= 0; m--) Lq = Lq * mu2 + pc[q][m];
                                 spole[q] += wp * Lq;
                             }
                     }
@@ -765,18 +773,21 @@ int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const 
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t ntiles = (s.nrows * s.pitch + tile_modes - 1) / tile_modes;
     const int grid = (int)std::min<int64_t>(ntiles, ncu);
-#define LAUNCH_BIN(I, C, P)                                                                                          \
+    int maxdeg = 0;
+    for (int q = 0; q < b.Np; q++) maxdeg = std::max(maxdeg, b.poledeg[q]);
+    if (maxdeg > 5) return fail("power: multipole order beyond the coefficient table");
+#define LAUNCH_BIN(I, C, P, D)                                                                                       \
     do {                                                                                                             \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spectrum_bin<I, C, P>),                           \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spectrum_bin<I, C, P, D>),                        \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-        ABACUS_LAUNCH("spectrum_bin", (spectrum_bin<I, C, P>), dim3(grid), dim3(BIN_THREADS), lds, s, b);            \
+        ABACUS_LAUNCH("spectrum_bin", (spectrum_bin<I, C, P, D>), dim3(grid), dim3(BIN_THREADS), lds, s, b);         \
     } while (0)
-#define LAUNCH_NP(I, C)                                 \
-    do {                                                \
-        if (b.Np == 0) LAUNCH_BIN(I, C, 0);             \
-        else if (b.Np == 1) LAUNCH_BIN(I, C, 1);        \
-        else if (b.Np == 2) LAUNCH_BIN(I, C, 2);        \
-        else LAUNCH_BIN(I, C, -1);                      \
+#define LAUNCH_NP(I, C)                                              \
+    do {                                                             \
+        if (b.Np == 0) LAUNCH_BIN(I, C, 0, 2);                       \
+        else if (b.Np == 1 && maxdeg <= 2) LAUNCH_BIN(I, C, 1, 2);   \
+        else if (b.Np == 2 && maxdeg <= 2) LAUNCH_BIN(I, C, 2, 2);   \
+        else LAUNCH_BIN(I, C, -1, 5);                                \
     } while (0)
     if (inter && cross) LAUNCH_NP(true, true);
     else if (inter) LAUNCH_NP(true, false);
