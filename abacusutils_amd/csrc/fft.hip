@@ -123,6 +123,14 @@ __device__ __forceinline__ int revpos(int f) {
     return pos;
 }
 
+// padded position of element base + r * LR: when LR is a multiple of the padding period the pad term is additive, so the
+// R addresses of a butterfly are one computed address plus compile-time offsets (immediate offsets of the LDS instructions)
+template <int LR>
+__device__ __forceinline__ int padq_strided(int base, int r) {
+    if constexpr (LR % (1 << PADSHIFT) == 0) return padq(base) + r * (LR + (LR >> PADSHIFT));
+    else return padq(base + r * LR);
+}
+
 // one DIF pass of sub-length L over `ncol` columns of N elements each (column c at lds + c*colpitch, padded index)
 template <int N, int L, int R, int NT = FFT_THREADS>
 __device__ __forceinline__ void dif_pass(float2 *lds, int colpitch, int ncol, const float2 *tw) {
@@ -136,14 +144,14 @@ __device__ __forceinline__ void dif_pass(float2 *lds, int colpitch, int ncol, co
         const int base = blk * L + j;
         float2 a[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) a[r] = c[padq(base + r * LR)];
+        for (int r = 0; r < R; r++) a[r] = c[padq_strided<LR>(base, r)];
         dft<R>(a);
         if (L > R) {   // the last pass has j = 0: all twiddles are one
 #pragma unroll
             for (int r = 1; r < R; r++) a[r] = cmul(a[r], tw[j * r * (N / L)]);
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) c[padq(base + r * LR)] = a[r];
+        for (int r = 0; r < R; r++) c[padq_strided<LR>(base, r)] = a[r];
     }
     __syncthreads();
 }
@@ -228,12 +236,12 @@ __device__ __forceinline__ void butterfly_w(float2 *c, const float2 *tw, int t) 
     const int base = blk * L + j;
     float2 a[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) a[r] = c[padq(base + r * LR)];
+    for (int r = 0; r < R; r++) a[r] = c[padq_strided<LR>(base, r)];
     dft<R>(a);
 #pragma unroll
     for (int r = 1; r < R; r++) a[r] = cmul(a[r], tw[j * r * (N / L)]);
 #pragma unroll
-    for (int r = 0; r < R; r++) c[padq(base + r * LR)] = a[r];
+    for (int r = 0; r < R; r++) c[padq_strided<LR>(base, r)] = a[r];
 }
 
 // UNR: unroll the butterflies of one lane (more LDS reads in flight; the column pass at N = 1024 has no registers to spare)
