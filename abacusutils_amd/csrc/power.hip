@@ -69,6 +69,7 @@ struct SpecArgs {
     const float2 *a, *as, *b, *bs;   // field 1 (+ shifted), field 2 (+ shifted); b == nullptr -> auto power
     const float *W;           // (n,) window or nullptr
     const float2 *phase;      // (2n,) e^{i*pi*m/n}
+    int lds_tables;           // spectrum_bin: W and phase are copied into LDS behind the tile buffer (they fit)
 };
 
 __device__ __forceinline__ int fold(int i, int n) { return i < n / 2 ? i : i - n; }   // (:234,237,940-942)
@@ -87,15 +88,17 @@ __device__ __forceinline__ void row_ij(const SpecArgs &s, int64_t row, int &i, i
 
 // final delta_k of one field at (i, j, k) from the raw FFT output v (and the shifted field's w): what get_field_fft
 // returns (:1046-1070)
-__device__ __forceinline__ float2 finish_value(const SpecArgs &s, float2 v, float2 w, int i, int j, int k) {
+// W / phase: the tables of SpecArgs, or copies of them in LDS (spectrum_bin)
+__device__ __forceinline__ float2 finish_value(const SpecArgs &s, float2 v, float2 w, int i, int j, int k, const float *W,
+                                               const float2 *phase) {
     if (s.mode == 0) return v;
     if (s.interlaced) {
         // (delta_k + delta'_k * exp(i*(d/2)*(kx+ky+kz))) * f32(0.5/M); (d/2)*dk = pi/n, so the phase only depends
-        // on m = i' + j' + k (mod 2n): taken from a table of exact angles
+        // on m = i' + j' + k (mod 2n): taken from a table of exact angles.  |i'|, |j'| <= n/2 and 0 <= k < n: m lies in
+        // (-2n, 2n), one conditional add replaces the modulo
         int m = fold(i, s.n) + fold(j, s.n) + k;
-        m %= 2 * s.n;
         if (m < 0) m += 2 * s.n;
-        const float2 ph = s.phase[m];
+        const float2 ph = phase[m];
         const float re = w.x * ph.x - w.y * ph.y, im = w.x * ph.y + w.y * ph.x;
         v.x = (v.x + re) * s.half_inv_size;
         v.y = (v.y + im) * s.half_inv_size;
@@ -104,7 +107,7 @@ __device__ __forceinline__ float2 finish_value(const SpecArgs &s, float2 v, floa
         v.y *= s.inv_size;
     }
     if (s.compensated) {
-        const float wgt = (s.W[i] * s.W[j]) * s.W[k];   // (:1065-1069), NumPy divides complex by real as *(1/w)
+        const float wgt = (W[i] * W[j]) * W[k];   // (:1065-1069), NumPy divides complex by real as *(1/w)
         const float scl = 1.0f / wgt;
         v.x *= scl;
         v.y *= scl;
@@ -122,7 +125,7 @@ __global__ void spectrum_apply(SpecArgs s, float2 *out) {
         row_ij(s, row, i, j);
         const int64_t idx = row * s.pitch + k;
         const float2 w = s.interlaced ? s.as[idx] : make_float2(0.f, 0.f);
-        out[idx] = finish_value(s, s.a[idx], w, i, j, k);
+        out[idx] = finish_value(s, s.a[idx], w, i, j, k, s.W, s.phase);
     }
 }
 
@@ -195,39 +198,59 @@ __device__ __forceinline__ int tpad(int e) { return e + e / EPT; }
 
 template <bool INTER, bool CROSS>
 __device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int64_t total,
-                                           const TileRegs<INTER, CROSS> &r, float *tile) {
+                                           const TileRegs<INTER, CROSS> &r, float *tile, const float *W,
+                                           const float2 *phase) {
     constexpr int EPT = BinCfg<INTER, CROSS>::EPT;
     const bool need_idx = s.mode == 1 && (INTER || s.compensated);
-    // (row, k) of the tile's first element, once per thread; the per-load offsets are < 2^16
-    int64_t row0 = 0;
-    int k0 = 0;
+    // (row, k) and the row's two slow indices (hi = row / n, lo = row % n) of this lane's first pair: the only 64-bit
+    // divisions, once per thread and tile; the lane's later pairs are 128 elements apart and advance by carries
+    const int e_first = (threadIdx.x >> 6) * (64 * EPT) + (threadIdx.x & 63) * 2;
+    int64_t row = 0;
+    int k = 0, hi = 0, lo = 0;
     if (need_idx) {
-        row0 = base / s.pitch;
-        k0 = (int)(base - row0 * s.pitch);
+        const int64_t idx = base + e_first;
+        row = idx / s.pitch;
+        k = (int)(idx - row * s.pitch);
+        hi = (int)(row / s.n);
+        lo = (int)(row - (int64_t)hi * s.n);
     }
 #pragma unroll
     for (int q = 0; q < BinCfg<INTER, CROSS>::LOADS; q++) {
-        const int e = (threadIdx.x >> 6) * (64 * EPT) + (q * 64 + (threadIdx.x & 63)) * 2;
-        int i = 0, j = 0, k = 0, i2 = 0, j2 = 0, k2 = 0;
+        const int e = e_first + q * 128;
+        int i = 0, j = 0, kc = 0;
         if (need_idx) {
-            const unsigned int kk = (unsigned int)(k0 + e);
-            const unsigned int dr = kk / (unsigned int)s.pitch;
-            k = (int)(kk - dr * (unsigned int)s.pitch);
-            const int64_t row = row0 + dr;
-            row_ij(s, row < s.nrows ? row : 0, i, j);
-            k2 = k + 1, j2 = j, i2 = i;   // pitch is even and e is even: the pair never straddles two rows
-            // padding elements (k >= kzlen) and rows past the end are never binned: clamp their indices
-            if (k >= s.kzlen || row >= s.nrows) i = j = k = i2 = j2 = k2 = 0;
-            if (k2 >= s.kzlen) i2 = j2 = k2 = 0;
+            if (row < s.nrows) {      // rows past the end (last tile) are never binned: indices stay 0
+                int a = hi, b = lo;   // row_ij without the divisions
+                if (s.rowmode == 0) {
+                    if (s.permshift) {
+                        const int hm = (1 << s.permshift) - 1;
+                        a = ((a & hm) << 1) | (a >> s.permshift);
+                        b = ((b & hm) << 1) | (b >> s.permshift);
+                    }
+                    i = a, j = b;
+                } else {
+                    i = b, j = s.y0 + a;
+                }
+                kc = k;
+            }
+            k += 128;                 // next pair of this lane
+            while (k >= s.pitch) {
+                k -= s.pitch;
+                row++;
+                if (++lo == s.n) lo = 0, hi++;
+            }
         }
         const float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 ras = INTER ? r.as[q] : zs, rbs = (INTER && CROSS) ? r.bs[q] : zs;
-        const float2 va0 = finish_value(s, make_float2(r.a[q].x, r.a[q].y), make_float2(ras.x, ras.y), i, j, k);
-        const float2 va1 = finish_value(s, make_float2(r.a[q].z, r.a[q].w), make_float2(ras.z, ras.w), i2, j2, k2);
+        // pitch is even and e is even: the pair (kc, kc + 1) never straddles two rows; the row padding (k >= kzlen) is
+        // never binned, its table indices are clamped
+        const int k0 = kc < s.kzlen ? kc : 0, k1 = kc + 1 < s.kzlen ? kc + 1 : 0;
+        const float2 va0 = finish_value(s, make_float2(r.a[q].x, r.a[q].y), make_float2(ras.x, ras.y), i, j, k0, W, phase);
+        const float2 va1 = finish_value(s, make_float2(r.a[q].z, r.a[q].w), make_float2(ras.z, ras.w), i, j, k1, W, phase);
         float p0, p1;
         if (CROSS) {
-            const float2 vb0 = finish_value(s, make_float2(r.b[q].x, r.b[q].y), make_float2(rbs.x, rbs.y), i, j, k);
-            const float2 vb1 = finish_value(s, make_float2(r.b[q].z, r.b[q].w), make_float2(rbs.z, rbs.w), i2, j2, k2);
+            const float2 vb0 = finish_value(s, make_float2(r.b[q].x, r.b[q].y), make_float2(rbs.x, rbs.y), i, j, k0, W, phase);
+            const float2 vb1 = finish_value(s, make_float2(r.b[q].z, r.b[q].w), make_float2(rbs.z, rbs.w), i, j, k1, W, phase);
             p0 = va0.x * vb0.x + va0.y * vb0.y;   // Re(conj(a) b)  (:724)
             p1 = va1.x * vb1.x + va1.y * vb1.y;
         } else {
@@ -267,6 +290,18 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
     for (int q = tid; q < b.Np * b.Nk; q += BIN_THREADS) h_pole[q] = 0.0;
     for (int q = tid; q <= b.Nk; q += BIN_THREADS) ke[q] = b.kedges2[q];
     for (int q = tid; q <= b.Nmu; q += BIN_THREADS) me[q] = b.muedges2[q];
+    // window and interlacing-phase tables: gathered per mode in the staging, from LDS when they fit
+    const float *Wt = s.W;
+    const float2 *pht = s.phase;
+    if (s.lds_tables) {
+        float2 *phl = reinterpret_cast<float2 *>(tile + (BIN_TILE + BIN_THREADS + 16));   // 8-B aligned: even float count
+        float *Wl = reinterpret_cast<float *>(phl + (INTER ? 2 * s.n : 0));
+        if (INTER)
+            for (int q = tid; q < 2 * s.n; q += BIN_THREADS) phl[q] = s.phase[q];
+        if (s.compensated)
+            for (int q = tid; q < s.n; q += BIN_THREADS) Wl[q] = s.W[q];
+        Wt = Wl, pht = phl;
+    }
     __syncthreads();
     const float klo = ke[0], khi = ke[b.Nk];
     const int n = s.n, kzlen = s.kzlen, pitch = s.pitch;
@@ -285,7 +320,7 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
         const int64_t base = t * BIN_TILE;
         // ---- power of this tile's modes: registers -> LDS; then prefetch the next tile into the registers, so its
         //      HBM latency is covered by the binning below ----
-        if (!(b.dbg & 2)) tile_store<INTER, CROSS>(s, base, total, regs, tile);
+        if (!(b.dbg & 2)) tile_store<INTER, CROSS>(s, base, total, regs, tile, Wt, pht);
         wave_sync();   // a wave stages and bins its own 64 * EPT modes: no workgroup barrier, the waves drift apart
         if (t + gridDim.x < ntiles) tile_load<INTER, CROSS>(s, (t + gridDim.x) * BIN_TILE, total, regs);
         // ---- bin: every thread walks EPT consecutive elements: at most two row segments.  Along a row |k| and mu only
@@ -722,9 +757,11 @@ int finalize_bins(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *
     return 0;
 }
 
-int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu,
+int run_bin(const SpecArgs &s_in, double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu,
             const int64_t *poles, int Np_all, float *power, int64_t *N_mode, float *binned_poles,
             int64_t *N_mode_poles, float *k_avg, void *raw_out = nullptr, double dk_ = 0, double scale = 0) {
+    SpecArgs s = s_in;
+    s.lds_tables = 0;
     if (Nk < 1 || Nmu < 1) return fail("power: need at least one k bin and one mu bin");
     if (Np_all > MAX_POLES) return fail("power: more than %d multipoles requested", MAX_POLES);
     const double dk = dk_ > 0 ? dk_ : 2.0 * M_PI / Lbox;
@@ -767,7 +804,10 @@ int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const 
     const size_t tile_bytes = (size_t)(tile_modes + BIN_THREADS + 16) * 4;
     if (hist_bytes + tile_bytes > lds_max)
         return fail("power: %d x %d bins with %d multipoles do not fit the 160 KiB LDS histogram", Nk, Nmu, b.Np);
-    const size_t lds = hist_bytes + tile_bytes;
+    size_t table_bytes = 0;
+    if (s.mode == 1) table_bytes = (inter ? (size_t)2 * s.n * 8 : 0) + (s.compensated ? (size_t)s.n * 4 : 0);
+    s.lds_tables = table_bytes > 0 && hist_bytes + tile_bytes + table_bytes + 16 <= lds_max;
+    const size_t lds = hist_bytes + tile_bytes + (s.lds_tables ? table_bytes + 16 : 0);
     int dev = 0, ncu = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
