@@ -86,6 +86,29 @@ __device__ __forceinline__ void row_ij(const SpecArgs &s, int64_t row, int &i, i
     }
 }
 
+// x / d and x % d for 0 <= x < 2^53, 0 < d < 2^31 without the 64-bit integer division (about a hundred instructions on
+// this hardware): one float64 multiply by 1/d, exact product, remainder fixed up by at most one step
+__device__ __forceinline__ void divmod_inv(int64_t x, int d, double inv_d, int64_t &q, int &r) {
+    q = (int64_t)((double)x * inv_d);
+    int64_t rem = x - q * d;
+    if (rem < 0) q--, rem += d;
+    else if (rem >= d) q++, rem -= d;
+    r = (int)rem;
+}
+// (i, j) of the row whose slow / fast row digits are (hi, lo) = (row / n, row % n): row_ij without the divisions
+__device__ __forceinline__ void hilo_ij(const SpecArgs &s, int hi, int lo, int &i, int &j) {
+    if (s.rowmode == 0) {
+        if (s.permshift) {
+            const int hm = (1 << s.permshift) - 1;
+            hi = ((hi & hm) << 1) | (hi >> s.permshift);
+            lo = ((lo & hm) << 1) | (lo >> s.permshift);
+        }
+        i = hi, j = lo;
+    } else {
+        i = lo, j = s.y0 + hi;
+    }
+}
+
 // final delta_k of one field at (i, j, k) from the raw FFT output v (and the shifted field's w): what get_field_fft
 // returns (:1046-1070)
 // W / phase: the tables of SpecArgs, or copies of them in LDS (spectrum_bin)
@@ -199,7 +222,7 @@ __device__ __forceinline__ int tpad(int e) { return e + e / EPT; }
 template <bool INTER, bool CROSS>
 __device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int64_t total,
                                            const TileRegs<INTER, CROSS> &r, float *tile, const float *W,
-                                           const float2 *phase) {
+                                           const float2 *phase, double inv_pitch, double inv_n) {
     constexpr int EPT = BinCfg<INTER, CROSS>::EPT;
     const bool need_idx = s.mode == 1 && (INTER || s.compensated);
     // (row, k) and the row's two slow indices (hi = row / n, lo = row % n) of this lane's first pair: the only 64-bit
@@ -208,11 +231,10 @@ __device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int6
     int64_t row = 0;
     int k = 0, hi = 0, lo = 0;
     if (need_idx) {
-        const int64_t idx = base + e_first;
-        row = idx / s.pitch;
-        k = (int)(idx - row * s.pitch);
-        hi = (int)(row / s.n);
-        lo = (int)(row - (int64_t)hi * s.n);
+        int64_t h64;
+        divmod_inv(base + e_first, s.pitch, inv_pitch, row, k);
+        divmod_inv(row, s.n, inv_n, h64, lo);
+        hi = (int)h64;
     }
 #pragma unroll
     for (int q = 0; q < BinCfg<INTER, CROSS>::LOADS; q++) {
@@ -220,17 +242,7 @@ __device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int6
         int i = 0, j = 0, kc = 0;
         if (need_idx) {
             if (row < s.nrows) {      // rows past the end (last tile) are never binned: indices stay 0
-                int a = hi, b = lo;   // row_ij without the divisions
-                if (s.rowmode == 0) {
-                    if (s.permshift) {
-                        const int hm = (1 << s.permshift) - 1;
-                        a = ((a & hm) << 1) | (a >> s.permshift);
-                        b = ((b & hm) << 1) | (b >> s.permshift);
-                    }
-                    i = a, j = b;
-                } else {
-                    i = b, j = s.y0 + a;
-                }
+                hilo_ij(s, hi, lo, i, j);
                 kc = k;
             }
             k += 128;                 // next pair of this lane
@@ -305,6 +317,7 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
     __syncthreads();
     const float klo = ke[0], khi = ke[b.Nk];
     const int n = s.n, kzlen = s.kzlen, pitch = s.pitch;
+    const double inv_pitch = 1.0 / (double)pitch, inv_n = 1.0 / (double)n;
     float pc[NPC][PD + 1];
 #pragma unroll
     for (int q = 0; q < NPC; q++)
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
         const int64_t base = t * BIN_TILE;
         // ---- power of this tile's modes: registers -> LDS; then prefetch the next tile into the registers, so its
         //      HBM latency is covered by the binning below ----
-        if (!(b.dbg & 2)) tile_store<INTER, CROSS>(s, base, total, regs, tile, Wt, pht);
+        if (!(b.dbg & 2)) tile_store<INTER, CROSS>(s, base, total, regs, tile, Wt, pht, inv_pitch, inv_n);
         wave_sync();   // a wave stages and bins its own 64 * EPT modes: no workgroup barrier, the waves drift apart
         if (t + gridDim.x < ntiles) tile_load<INTER, CROSS>(s, (t + gridDim.x) * BIN_TILE, total, regs);
         // ---- bin: every thread walks EPT consecutive elements: at most two row segments.  Along a row |k| and mu only
@@ -330,8 +343,11 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
         const int e0 = tid * BIN_EPT;
         const int64_t idx0 = base + e0;
         if (idx0 < total && !(b.dbg & 1)) {
-            int64_t row = idx0 / pitch;
-            int k = (int)(idx0 - row * pitch);
+            int64_t row, h64;
+            int k, hi, lo;
+            divmod_inv(idx0, pitch, inv_pitch, row, k);
+            divmod_inv(row, n, inv_n, h64, lo);
+            hi = (int)h64;
             int cur = -1, cur_bk = 0, cnt = 0;
             float sp = 0.f, sk = 0.f, spole[NPC];
 #pragma unroll
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
                 int r2;                               // i'^2 + j'^2 <= 2*(n/2)^2 < 2^30 for n <= 32767
                 {
                     int ii, jj;
-                    row_ij(s, row, ii, jj);
+                    hilo_ij(s, hi, lo, ii, jj);
                     ii = fold(ii, n), jj = fold(jj, n);
                     r2 = ii * ii + jj * jj;
                 }
@@ -424,6 +440,7 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
                 epos += seg;
                 k = 0;
                 row++;
+                if (++lo == n) lo = 0, hi++;
             }
             flush();
         }
