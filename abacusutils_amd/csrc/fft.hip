@@ -475,13 +475,21 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
     const int tid = threadIdx.x;
     for (int q = tid; q < N; q += FFT_THREADS) tw[q] = twN[q];
     v4f regs[NLD];
-    // outer index o = t / ntile_c -> (o % outer_mod) * outer_stride + (o / outer_mod) * outer_stride2
-    auto tile_base = [&](int64_t t) {
-        const int64_t o = t / ntile_c;
-        return data + (o % outer_mod) * outer_stride + (o / outer_mod) * outer_stride2 + (t % ntile_c) * C;
+    // tile (outer index o, column tile ct) -> o splits as (o % outer_mod) * outer_stride + (o / outer_mod) * outer_stride2.
+    // Tile counts fit 32 bits: all index arithmetic is 32-bit (a 64-bit division costs ~100 VALU instructions and this
+    // runs per tile in every lane), only the final element offset is 64-bit
+    const int n_outer = (int)(ntiles / ntile_c);
+    const bool two_level = outer_mod < (int64_t)n_outer;
+    const unsigned int omod = two_level ? (unsigned int)outer_mod : 1u;
+    auto tile_ptr = [&](int o, int ct) {
+        unsigned int a = (unsigned int)o, b = 0;
+        if (two_level) {
+            b = a / omod;
+            a -= b * omod;
+        }
+        return data + (int64_t)a * outer_stride + (int64_t)b * outer_stride2 + ct * C;
     };
-    auto prefetch = [&](int64_t t) {
-        const float2 *g = tile_base(t);
+    auto prefetch = [&](const float2 *g) {
         // lanes walk the C columns of one row first (C*8 B contiguous), two columns per 16-B load
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
@@ -508,23 +516,24 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
     // outer indices - for the x pass that is the same set of N pages (rows 17 MB apart at n = 2048) instead of every
     // XCD touching the pages of every outer index in flight.  Falls back to the flat order when the grid or the outer
     // count does not divide.
-    const int64_t n_outer = ntiles / ntile_c;
     const bool xmap = (gridDim.x % 8 == 0) && (n_outer % 8 == 0) && !(dbg & 8);
-    const int64_t grp = xmap ? (blockIdx.x & 7) : 0, ostep = xmap ? 8 : 1;
-    const int64_t qstep = xmap ? (gridDim.x >> 3) : gridDim.x, nq = ntiles / ostep;
-    auto tile_of = [&](int64_t i) { return ((i / ntile_c) * ostep + grp) * ntile_c + i % ntile_c; };
-    int64_t qi = xmap ? (blockIdx.x >> 3) : blockIdx.x;
-    if (qi >= nq) return;
-    int64_t t = tile_of(qi);
-    prefetch(t);
+    const int grp = xmap ? (int)(blockIdx.x & 7) : 0, ostep = xmap ? 8 : 1;
+    const unsigned int qstep = xmap ? (gridDim.x >> 3) : gridDim.x, q0 = xmap ? (blockIdx.x >> 3) : blockIdx.x;
+    const int n_og = n_outer / ostep;                       // outer indices of this group
+    const int dg = (int)(qstep / (unsigned int)ntile_c), dc = (int)(qstep % (unsigned int)ntile_c);
+    int og = (int)(q0 / (unsigned int)ntile_c), ct = (int)(q0 % (unsigned int)ntile_c);   // the q-th tile of the group
+    if (og >= n_og) return;
+    float2 *gcur = tile_ptr(og * ostep + grp, ct);
+    prefetch(gcur);
     wait_vmcnt<0>();
     stage();
     for (;;) {
         __syncthreads();
-        qi += qstep;
-        const bool has_next = qi < nq;
-        const int64_t next = has_next ? tile_of(qi) : 0;
-        if (has_next) prefetch(next);
+        og += dg, ct += dc;
+        if (ct >= ntile_c) ct -= ntile_c, og++;
+        const bool has_next = og < n_og;
+        float2 *gnext = has_next ? tile_ptr(og * ostep + grp, ct) : gcur;
+        if (has_next) prefetch(gnext);
         if (!(dbg & 1)) {
             if constexpr (wave_local(N)) {
 #pragma unroll 1
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
             }
         }
         if (!(dbg & 2)) {
-            float2 *g = tile_base(t);
+            float2 *g = gcur;
             // constant trip count: the compiler can then count these stores in its vmcnt bookkeeping
 #pragma unroll
             for (int q = 0; q < NLD; q++) {
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
         if (dbg & 2) wait_vmcnt<0>();
         else wait_vmcnt<(NLD < 60 ? NLD : 0)>();
         stage();
-        t = next;
+        gcur = gnext;
     }
 }
 
