@@ -37,7 +37,7 @@ using namespace abacus;
 
 namespace abacus {
 int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
-                    double offset, int wrap, double norm, int cic);
+                    double offset, int wrap, double norm, int cic, int list_mode = 0);
 int tsc_release_work();
 bool fft_native_supported(int n);
 int fft_native_r2c_inplace(float *mesh, int n, int pitch_r);
@@ -688,7 +688,9 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
         ABACUS_TRY(g_ctx.mesh[slot + s].reserve(mesh_bytes(nmesh)));
         float *mesh = g_ctx.mesh[slot + s].as<float>();
         // tsc_parallel wraps pos in place on the first call (tsc.py:171-173); the shifted deposit sees wrapped pos
-        ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste));
+        // interlaced: the lists of the first deposit are built to cover the half-cell-shifted one as well
+        ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste,
+                                   interlaced ? (s == 0 ? 1 : 2) : 0));
         if (native && fused) {
             ABACUS_TRY(fft_native_r2c_fused(mesh, nmesh, (int)zstride));
         } else if (native) {

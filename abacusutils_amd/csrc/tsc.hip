@@ -147,6 +147,31 @@ __device__ __forceinline__ int tiles_1d(int i, int g, int t, int sh, int out[3])
     return n;
 }
 
+// the same with the cell range i-1 .. i+1+ext: ext = 1 covers the clouds of BOTH deposits of an interlaced pair (offset 0
+// and half a cell: the nearest cell moves by 0 or +1), so one set of lists serves both
+__device__ __forceinline__ int tiles_1d_x_ext(int i, const TileGeom &g, int ext, int out[4]) {
+    int n = 0;
+    for (int a = -1; a <= 1 + ext; a++) {
+        const int l = xloc(i + a, g);
+        if (l < 0) continue;
+        const int t = tile_of_cell(l, g.tx, g.shx);
+        bool dup = false;
+        for (int q = 0; q < n; q++) dup = dup || out[q] == t;
+        if (!dup) out[n++] = t;
+    }
+    return n;
+}
+__device__ __forceinline__ int tiles_1d_ext(int i, int g, int t, int sh, int ext, int out[4]) {
+    int n = 0;
+    for (int a = -1; a <= 1 + ext; a++) {
+        const int tt = tile_of_cell(wrapcell(i + a, g), t, sh);
+        bool dup = false;
+        for (int q = 0; q < n; q++) dup = dup || out[q] == tt;
+        if (!dup) out[n++] = tt;
+    }
+    return n;
+}
+
 template <typename PT>
 struct Entry {
     PT x, y, z, w;
@@ -228,7 +253,7 @@ constexpr int MS_BINS = 1024;
 
 template <typename PT, bool CIC, typename F>
 __device__ __forceinline__ void for_each_tile(PT x, PT y, PT z, const TileGeom &g, double box, PT offset, PT ihx, PT ihy,
-                                              PT ihz, F f) {
+                                              PT ihz, int ext, F f) {
     int ci[3];
     if (CIC) {
         Cloud<double> c;
@@ -239,9 +264,14 @@ __device__ __forceinline__ void for_each_tile(PT x, PT y, PT z, const TileGeom &
         tsc_cloud<PT>(x, y, z, offset, ihx, ihy, ihz, c);
         ci[0] = c.i[0], ci[1] = c.i[1], ci[2] = c.i[2];
     }
-    int ax[3], ay[3], az[3];
-    const int nx = tiles_1d_x(ci[0], g, ax), ny = tiles_1d(ci[1], g.gy, g.ty, g.shy, ay),
-              nz = tiles_1d(ci[2], g.gz, g.tz, g.shz, az);
+    int ax[4], ay[4], az[4];
+    int nx, ny, nz;
+    if (ext) {
+        nx = tiles_1d_x_ext(ci[0], g, ext, ax), ny = tiles_1d_ext(ci[1], g.gy, g.ty, g.shy, ext, ay),
+        nz = tiles_1d_ext(ci[2], g.gz, g.tz, g.shz, ext, az);
+    } else {
+        nx = tiles_1d_x(ci[0], g, ax), ny = tiles_1d(ci[1], g.gy, g.ty, g.shy, ay), nz = tiles_1d(ci[2], g.gz, g.tz, g.shz, az);
+    }
     for (int a = 0; a < nx; a++)
         for (int b = 0; b < ny; b++)
             for (int c = 0; c < nz; c++) f((unsigned int)((ax[a] * g.nty + ay[b]) * g.ntz + az[c]));
@@ -255,7 +285,8 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
                                                       int ncoarse, unsigned int *__restrict__ gcount,
                                                       const int64_t *__restrict__ gstart,
                                                       Entry<PT> *__restrict__ stage_entry,
-                                                      unsigned int *__restrict__ stage_key, int *__restrict__ wrapped_flag) {
+                                                      unsigned int *__restrict__ stage_key, int *__restrict__ wrapped_flag,
+                                                      int ext) {
     __shared__ unsigned int hist[MS_BINS];
     __shared__ int64_t base[MS_BINS];
     const int tid = threadIdx.x;
@@ -279,7 +310,7 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
                 any_changed = true;
             }
         }
-        for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz,
+        for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, ext,
                                [&](unsigned int tile) { atomicAdd(&hist[tile >> cshift], 1u); });
     }
     if (!SCATTER && any_changed) *wrapped_flag = 1;
@@ -299,7 +330,7 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
     for (int64_t p = p0 + tid; p < p1; p += MS_BLOCK) {
         const PT x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
         const PT w = weights ? weights[p] : (PT)1;
-        for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, [&](unsigned int tile) {
+        for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, ext, [&](unsigned int tile) {
             const unsigned int b = tile >> cshift;
             const int64_t dst = base[b] + atomicAdd(&hist[b], 1u);
             stage_entry[dst] = Entry<PT>{x, y, z, w};
@@ -636,6 +667,18 @@ struct TscWork {
 };
 TscWork g_work;
 
+// Lists kept from a `list_mode = 1` build (extended clouds): a following `list_mode = 2` deposit of the same particles on
+// the same mesh (the half-cell-shifted deposit of an interlaced pair) reuses them instead of sorting again.
+struct ListCache {
+    bool valid = false;
+    const void *pos = nullptr;
+    int64_t n = 0, zstride = 0, nentries = 0;
+    int gx = 0, gy = 0, gz = 0, gxg = 0, xoff = 0, cic = 0;
+    double box = 0;
+    void *entries = nullptr;
+};
+ListCache g_lists;
+
 TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int TZ, int gxg, int xoff) {
     TileGeom g;
     g.gx = gx, g.gy = gy, g.gz = gz;
@@ -655,7 +698,7 @@ TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int 
 template <typename PT, typename GT, bool CIC>
 int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy, int gz, int64_t zstride, double box,
                 double offset, int wrap, int zero_grid, double norm, int *wrapped_out, int gxg = -1, int xoff = 0,
-                double sub = 1.0) {
+                double sub = 1.0, int list_mode = 0) {
     if (gxg < 0) gxg = gx;
     if (gx < 1 || gy < 1 || gz < 1) return fail("tsc: empty mesh");
     if (gxg > 32767 || gy > 32767 || gz > 32767) return fail("tsc: mesh dimension > 32767 (int16 cell index of the reference)");
@@ -676,7 +719,23 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     while (((int64_t)ntiles + (1 << cshift) - 1) >> cshift > MS_BINS) cshift++;
     const bool multisplit = n >= 2000000 && cshift <= 10 && !getenv("ABACUS_TSC_ATOMIC");
     int64_t nentries_total = 0;
-    if (multisplit) {
+    // list sharing (multisplit path only): mode 1 builds lists that also cover a deposit shifted by up to half a cell,
+    // mode 2 reuses them when nothing about the particles or the mesh changed
+    const bool share = multisplit && list_mode != 0 && !getenv("ABACUS_TSC_NOSHARE");
+    if (share && list_mode == 1 && offset != 0.0) return fail("tsc: shared lists are built at offset 0");
+    if (share && list_mode == 2 && (offset < 0.0 || offset > 0.5 * box / gxg * 1.0000001))
+        return fail("tsc: shared lists cover offsets up to half a cell");
+    const int ext = share ? 1 : 0;
+    const bool reuse = share && list_mode == 2 && g_lists.valid && g_lists.pos == (const void *)pos && g_lists.n == n &&
+                       g_lists.zstride == zstride && g_lists.gx == gx && g_lists.gy == gy && g_lists.gz == gz &&
+                       g_lists.gxg == gxg && g_lists.xoff == xoff && g_lists.cic == (CIC ? 1 : 0) && g_lists.box == box &&
+                       sizeof(PT) == 4;
+    if (!reuse) g_lists.valid = false;   // every build below overwrites the buffers the cache points into
+    if (reuse) {
+        entries = static_cast<Entry<PT> *>(g_lists.entries);
+        nentries_total = g_lists.nentries;
+        if (wrapped_out) *wrapped_out = 0;
+    } else if (multisplit) {
         const int ncoarse = (int)(((int64_t)ntiles + (1 << cshift) - 1) >> cshift);
         ABACUS_TRY(g_work.gcount.reserve((size_t)(MS_BINS + 1) * sizeof(unsigned int)));
         ABACUS_TRY(g_work.gstart.reserve((size_t)(MS_BINS + 1) * sizeof(int64_t)));
@@ -686,7 +745,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         const int cgrid = (int)ceil_div(n, MS_CHUNK);
         ABACUS_LAUNCH("tsc_ms_coarse_count", (ms_coarse<PT, CIC, false>), dim3(cgrid), dim3(MS_BLOCK), 0, pos, n, weights, g,
                       box, offset, wrap, cshift, ncoarse, gcount, (const int64_t *)nullptr, (Entry<PT> *)nullptr,
-                      (unsigned int *)nullptr, flag);
+                      (unsigned int *)nullptr, flag, ext);
         ABACUS_TRY(exclusive_scan_u32(gcount, ncoarse, gstart, g_work.scan, 1));   // counters re-zeroed: cursors
         std::vector<int64_t> h_start((size_t)ncoarse + 1);
         int h_flag = 0;
@@ -705,7 +764,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         Entry<PT> *stage_entry = g_work.stage_entry.as<Entry<PT>>();
         unsigned int *stage_key = g_work.stage_key.as<unsigned int>();
         ABACUS_LAUNCH("tsc_ms_coarse_scatter", (ms_coarse<PT, CIC, true>), dim3(cgrid), dim3(MS_BLOCK), 0, pos, n, weights,
-                      g, box, offset, 0, cshift, ncoarse, gcount, (const int64_t *)gstart, stage_entry, stage_key, flag);
+                      g, box, offset, 0, cshift, ncoarse, gcount, (const int64_t *)gstart, stage_entry, stage_key, flag, ext);
         if (cshift == 0) {   // every bucket is a tile already
             HIP_TRY(hipMemcpyAsync(tile_start, gstart, (size_t)(ntiles + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice,
                                    stream()));
@@ -744,6 +803,12 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         if (n > 0)
             ABACUS_LAUNCH("tsc_bin_fill", (tsc_bin<PT, true, CIC>), dim3(nblk), dim3(TSC_BLOCK), 0, pos, n, weights, g, box,
                           offset, 0, tile_count, (const int64_t *)tile_start, entries, flag);
+    }
+    if (share && list_mode == 1 && !reuse) {
+        g_lists.valid = true;
+        g_lists.pos = pos, g_lists.n = n, g_lists.zstride = zstride, g_lists.nentries = nentries_total;
+        g_lists.gx = gx, g_lists.gy = gy, g_lists.gz = gz, g_lists.gxg = gxg, g_lists.xoff = xoff, g_lists.cic = CIC ? 1 : 0;
+        g_lists.box = box, g_lists.entries = entries;
     }
     const int dbg = getenv("ABACUS_DBG_TSC") ? atoi(getenv("ABACUS_DBG_TSC")) : 0;
     if constexpr (std::is_same<PT, float>::value && std::is_same<GT, float>::value) {
@@ -813,13 +878,15 @@ int deposit_host(void *pos_, int64_t n, const void *weights_, void *grid_, int g
 
 namespace abacus {
 // used by power.hip: float32 deposit into a (possibly padded) device mesh with fused normalisation
+// list_mode: 0 = lists for this deposit only; 1 = build lists that a following deposit of the same particles shifted by
+// up to half a cell can reuse (call with offset 0); 2 = reuse them (rebuilds when anything changed)
 int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
-                    double offset, int wrap, double norm, int cic) {
+                    double offset, int wrap, double norm, int cic, int list_mode) {
     if (cic)
         return deposit_dev<float, float, true>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, 0, 1, norm,
-                                               nullptr);
+                                               nullptr, -1, 0, 1.0, list_mode);
     return deposit_dev<float, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
-                                            nullptr);
+                                            nullptr, -1, 0, 1.0, list_mode);
 }
 // x-slab variant: `grid` holds planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh, ghosts included;
 // written as rho*norm (no "-1": ghost planes are added to their owners first)
@@ -832,6 +899,7 @@ int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int
                                             nullptr, nmesh, xoff, 0.0);
 }
 int tsc_release_work() {
+    g_lists.valid = false;
     ABACUS_TRY(g_work.tile_count.release());
     ABACUS_TRY(g_work.tile_start.release());
     ABACUS_TRY(g_work.entries.release());
