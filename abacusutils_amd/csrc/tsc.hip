@@ -48,6 +48,8 @@ struct TileGeom {
                           // gxg == gx, xoff == 0 for a full mesh
     int shx, shy, shz;    // log2 of the tile shape where it is a power of two (the usual 16 x 16 x 32), else -1:
                           // cell -> tile by a shift instead of a runtime integer division (nine per particle and pass)
+    int f4x, f4y, f4z;    // four consecutive (periodically wrapped) cells always lie in at most two tiles of this
+                          // dimension: tiles of >= 4 cells, the last one included (x: full meshes only, not x-slabs)
 };
 
 __device__ __forceinline__ int tile_of_cell(int c, int t, int sh) { return sh >= 0 ? c >> sh : c / t; }
@@ -150,6 +152,11 @@ __device__ __forceinline__ int tiles_1d(int i, int g, int t, int sh, int out[3])
 // the same with the cell range i-1 .. i+1+ext: ext = 1 covers the clouds of BOTH deposits of an interlaced pair (offset 0
 // and half a cell: the nearest cell moves by 0 or +1), so one set of lists serves both
 __device__ __forceinline__ int tiles_1d_x_ext(int i, const TileGeom &g, int ext, int out[4]) {
+    if (g.f4x) {   // the end cells decide
+        const int a = tile_of_cell(wrapcell(i - 1, g.gx), g.tx, g.shx), b = tile_of_cell(wrapcell(i + 1 + ext, g.gx), g.tx, g.shx);
+        out[0] = a, out[1] = b;
+        return a == b ? 1 : 2;
+    }
     int n = 0;
     for (int a = -1; a <= 1 + ext; a++) {
         const int l = xloc(i + a, g);
@@ -161,7 +168,12 @@ __device__ __forceinline__ int tiles_1d_x_ext(int i, const TileGeom &g, int ext,
     }
     return n;
 }
-__device__ __forceinline__ int tiles_1d_ext(int i, int g, int t, int sh, int ext, int out[4]) {
+__device__ __forceinline__ int tiles_1d_ext(int i, int g, int t, int sh, int ext, int f4, int out[4]) {
+    if (f4) {
+        const int a = tile_of_cell(wrapcell(i - 1, g), t, sh), b = tile_of_cell(wrapcell(i + 1 + ext, g), t, sh);
+        out[0] = a, out[1] = b;
+        return a == b ? 1 : 2;
+    }
     int n = 0;
     for (int a = -1; a <= 1 + ext; a++) {
         const int tt = tile_of_cell(wrapcell(i + a, g), t, sh);
@@ -267,8 +279,8 @@ __device__ __forceinline__ void for_each_tile(PT x, PT y, PT z, const TileGeom &
     int ax[4], ay[4], az[4];
     int nx, ny, nz;
     if (ext) {
-        nx = tiles_1d_x_ext(ci[0], g, ext, ax), ny = tiles_1d_ext(ci[1], g.gy, g.ty, g.shy, ext, ay),
-        nz = tiles_1d_ext(ci[2], g.gz, g.tz, g.shz, ext, az);
+        nx = tiles_1d_x_ext(ci[0], g, ext, ax), ny = tiles_1d_ext(ci[1], g.gy, g.ty, g.shy, ext, g.f4y, ay),
+        nz = tiles_1d_ext(ci[2], g.gz, g.tz, g.shz, ext, g.f4z, az);
     } else {
         nx = tiles_1d_x(ci[0], g, ax), ny = tiles_1d(ci[1], g.gy, g.ty, g.shy, ay), nz = tiles_1d(ci[2], g.gz, g.tz, g.shz, az);
     }
@@ -691,6 +703,8 @@ TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int 
         return (1 << sh) == v ? sh : -1;
     };
     g.shx = lg(g.tx), g.shy = lg(g.ty), g.shz = lg(g.tz);
+    auto four = [](int cells, int t) { return t >= 4 && (cells % t == 0 || cells % t >= 4) ? 1 : 0; };
+    g.f4x = (gxg == gx && xoff == 0) ? four(gx, g.tx) : 0, g.f4y = four(gy, g.ty), g.f4z = four(gz, g.tz);
     g.zstride = zstride;
     return g;
 }
