@@ -304,3 +304,22 @@ def test_full_size_2048_properties(monkeypatch):
     shot = box**3 / n
     assert abs(np.mean(p0[32:224]) / shot - 1) < 2e-3
     assert np.all(np.abs(p0[64:224] / shot - 1) < 0.02)
+
+
+@pytest.mark.parametrize('paste,nmesh', [('CIC', 256), ('TSC', 98), ('CIC', 98), ('TSC', 130)])
+def test_interlaced_shared_lists(paste, nmesh, monkeypatch):
+    """>= 2e6 particles: the two deposits of an interlaced pair share one list build (tsc.hip `list_mode`, lists for the
+    4-cell union of both clouds).  CIC and meshes whose last tile has fewer than 4 cells (generic tile enumeration)
+    against the oracle, and against the same call with the sharing switched off"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    n, box = 2_500_000, 1000.0
+    pos = synth.synth_positions(n, box, seed=91, clustered=True)
+    kw = dict(kbins=24, mubins=3, paste=paste, nmesh=nmesh, compensated=True, interlaced=True, poles=[0, 2, 4])
+    tab = calc_power(pos.copy(), box, **kw)
+    ref = oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw)
+    _check_oracle(tab, ref)
+    monkeypatch.setenv('ABACUS_TSC_NOSHARE', '1')
+    tab2 = calc_power(pos.copy(), box, **kw)
+    np.testing.assert_array_equal(tab['N_mode'], tab2['N_mode'])
+    np.testing.assert_allclose(tab['power'], tab2['power'], rtol=1e-6, atol=1e-9 * np.abs(np.asarray(tab2['power'])).max())
