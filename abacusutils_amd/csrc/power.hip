@@ -275,7 +275,7 @@ __device__ __forceinline__ void tile_store(const SpecArgs &s, int64_t base, int6
 }
 
 // NP: compile-time number of ell != 0 multipoles (0..3), or -1 for the generic loop over b.Np
-// PD: degree (in mu^2) of the Horner evaluation of the Legendre weights, 2 (ell <= 4) or 5; the coefficients are
+// PD: degree (in mu^2) of the Horner evaluation of the Legendre weights: 2 (ell <= 4; -1 with the generic NP); the coefficients are
 // hoisted into registers, zero-padded above a pole's own degree (0 * mu^2 + c is c: bit-identical to starting at the
 // pole's degree) - indexing the kernel-argument arrays in the loop costs a scalar memory load + wait per mode
 template <bool INTER, bool CROSS, int NP, int PD>
@@ -318,11 +318,14 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
     const float klo = ke[0], khi = ke[b.Nk];
     const int n = s.n, kzlen = s.kzlen, pitch = s.pitch;
     const double inv_pitch = 1.0 / (double)pitch, inv_n = 1.0 / (double)n;
-    float pc[NPC][PD + 1];
+    constexpr int PDC = PD < 0 ? 0 : PD;      // PD < 0 (generic pole count): coefficients stay in the kernel arguments
+    float pc[PD < 0 ? 1 : NPC][PDC + 1];
+    if constexpr (PD >= 0) {
 #pragma unroll
-    for (int q = 0; q < NPC; q++)
+        for (int q = 0; q < NPC; q++)
 #pragma unroll
-        for (int m = 0; m <= PD; m++) pc[q][m] = (q < np && m <= b.poledeg[q]) ? b.polecoef[q][m] : 0.f;
+            for (int m = 0; m <= PDC; m++) pc[q][m] = (q < np && m <= b.poledeg[q]) ? b.polecoef[q][m] : 0.f;
+    }
     const int64_t total = s.nrows * pitch;
     const int64_t ntiles = (total + BIN_TILE - 1) / BIN_TILE;
 
@@ -429,9 +432,16 @@ __global__ __launch_bounds__(BIN_THREADS) void spectrum_bin(SpecArgs s, BinArgs 
 #pragma unroll
                         for (int q = 0; q < NPC; q++)
                             if (q < np) {
-                                float Lq = pc[q][PD];
+                                float Lq;
+                                if constexpr (PD >= 0) {
+                                    Lq = pc[q][PDC];
 #pragma unroll
-                                for (int m = PD - 1; m >= 0; m--) Lq = Lq * mu2 + pc[q][m];
+                                    for (int m = PDC - 1; m >= 0; m--) Lq = Lq * mu2 + pc[q][m];
+                                } else {
+                                    const float *c = b.polecoef[q];
+                                    Lq = c[b.poledeg[q]];
+                                    for (int m = b.poledeg[q] - 1; m >= 0; m--) Lq = Lq * mu2 + c[m];
+                                }
                                 spole[q] += wp * Lq;
                             }
                     }
@@ -846,7 +856,7 @@ int run_bin(const SpecArgs &s_in, double Lbox, const double *kedges, int Nk, con
         if (b.Np == 0) LAUNCH_BIN(I, C, 0, 2);                       \
         else if (b.Np == 1 && maxdeg <= 2) LAUNCH_BIN(I, C, 1, 2);   \
         else if (b.Np == 2 && maxdeg <= 2) LAUNCH_BIN(I, C, 2, 2);   \
-        else LAUNCH_BIN(I, C, -1, 5);                                \
+        else LAUNCH_BIN(I, C, -1, -1);                               \
     } while (0)
     if (inter && cross) LAUNCH_NP(true, true);
     else if (inter) LAUNCH_NP(true, false);

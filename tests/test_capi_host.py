@@ -101,7 +101,8 @@ def test_no_cpu_fallback():
 def test_async_load_kernels_do_not_spill(tmp_path):
     """fft.hip and tsc.hip prefetch with untracked asynchronous loads (inline-asm global_load + hand-counted vmcnt): the
     compiler does not know those registers are pending, so it must never spill or copy them.  With zero spills and the
-    `touch` barriers in the source that holds; this test pins the zero (it cross-compiles, no GPU needed)."""
+    `touch` barriers in the source that holds; this test pins the zero (it cross-compiles, no GPU needed).  The binning
+    and HOD kernels are held to zero spills as well (scratch traffic in their hot loops is a silent 2x)."""
     import re
     import shutil
     import subprocess
@@ -109,7 +110,8 @@ def test_async_load_kernels_do_not_spill(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available')
     csrc = os.path.join(str(REPO), 'abacusutils_amd', 'csrc')
-    for src, names in (('fft.hip', ('fft_z_r2c', 'fft_cols')), ('tsc.hip', ('tsc_tile_deposit_p',))):
+    for src, names in (('fft.hip', ('fft_z_r2c', 'fft_cols')), ('tsc.hip', ('tsc_tile_deposit_p',)),
+                       ('power.hip', ('spectrum_bin',)), ('hod.hip', ('hod_filter', 'hod_exact', 'hod_emit'))):
         obj = tmp_path / (src + '.o')
         r = subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-munsafe-fp-atomics',
                             '-c', os.path.join(csrc, src), '-o', str(obj), '-save-temps=obj'], capture_output=True,
