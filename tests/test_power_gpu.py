@@ -323,3 +323,15 @@ def test_interlaced_shared_lists(paste, nmesh, monkeypatch):
     tab2 = calc_power(pos.copy(), box, **kw)
     np.testing.assert_array_equal(tab['N_mode'], tab2['N_mode'])
     np.testing.assert_allclose(tab['power'], tab2['power'], rtol=1e-6, atol=1e-9 * np.abs(np.asarray(tab2['power'])).max())
+
+
+def test_many_multipoles_generic_path():
+    """three or more ell != 0 multipoles (or ell > 4) take the binning kernel's generic pole loop"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    pos = synth.synth_positions(300_000, 1000.0, seed=93, clustered=True)
+    for poles in ([0, 2, 4, 6], [2, 6], [0, 8, 4, 2, 6]):
+        kw = dict(kbins=20, mubins=3, paste='TSC', nmesh=96, compensated=True, interlaced=True, poles=poles)
+        tab = calc_power(pos.copy(), 1000.0, **kw)
+        ref = oracle.calc_power(pos.copy(), 1000.0, nthread=oracle.max_threads(), accum64=True, **kw)
+        _check_oracle(tab, ref)
