@@ -836,8 +836,8 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
             const int grid_p = (int)std::min<int64_t>(nranges, (int64_t)ncu * 2);
             // dense lists: more threads per tile shorten the accumulation; sparse ones are flush-bound
             const bool dense = nentries_total / std::max<int64_t>(ntiles, 1) > 400;
-            // ACC = float (32-KiB tiles, 4 workgroups per CU) was measured 1.6-4.5x SLOWER: float LDS atomics compile to
-            // a compare-and-swap loop under the default denormal mode, float64 ones to native ds_add_f64
+            // ACC = float (32-KiB tiles, 4 workgroups per CU) was measured 1.6-4.5x SLOWER (16.3 vs 9.3 ms at 2048^3, both
+            // compile to native ds_add_f32 / ds_add_f64): kept float64, which also makes the mesh reproducible run to run
 #define LAUNCH_P(NTP, ACC, GRID)                                                                                      \
     ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit_p<TX, TY, TZ, CIC, NTP, ACC>), dim3(GRID), dim3(NTP), 0,      \
                   (const Entry<float> *)entries, (int64_t)nentries_total, (const int64_t *)tile_start, (int)ntiles,   \
