@@ -506,6 +506,38 @@ def gen_helpers(P):
     print('power_helpers written')
 
 
+def mock_digest(mock):
+    """{tracer: (N, Ncent, sha256 of the eight columns' bytes)} of a gen_gal_cat result"""
+    import hashlib
+    out = {}
+    for tr, cols in mock.items():
+        h = hashlib.sha256()
+        for c in ('x', 'y', 'z', 'vx', 'vy', 'vz', 'mass'):
+            h.update(np.ascontiguousarray(cols[c], dtype=np.float64).tobytes())
+        h.update(np.ascontiguousarray(cols['id'], dtype=np.int64).tobytes())
+        out[tr] = (len(cols['x']), int(cols['Ncent']), np.frombuffer(h.digest(), dtype=np.uint8).copy())
+    return out
+
+
+def gen_sweep(G):
+    """40 seeded random parameter sets (tests/sweep.py: assembly bias, conformity, ranks, velocity bias, tracer subsets,
+    light-cone RSD) through the shimmed reference; the catalogues are kept as digests (counts + SHA-256 of the columns),
+    the inputs are regenerated from the seeds by the tests."""
+    sys.path.insert(0, str(REPO / 'tests'))
+    from sweep import sweep_case
+    out = {}
+    for seed in range(40):
+        hd, pd, params, tracers, ranks, rsd = sweep_case(seed)
+        out[f'case{seed}.checksum'] = np.float64(checksum(hd, pd))
+        mock = G.gen_gal_cat({k: v.copy() for k, v in hd.items()}, {k: v.copy() for k, v in pd.items()}, tracers, params,
+                             Nthread=1, enable_ranks=ranks, rsd=rsd, write_to_disk=False)
+        for tr, (n, nc, sha) in mock_digest(mock).items():
+            out[f'case{seed}.{tr}.n'], out[f'case{seed}.{tr}.ncent'], out[f'case{seed}.{tr}.sha'] = np.int64(n), np.int64(nc), sha
+        print('sweep', seed, {tr: (len(m['x']), m['Ncent']) for tr, m in mock.items()})
+    np.savez_compressed(GOLD / 'hod_sweep.npz', **out)
+    print('hod_sweep written')
+
+
 def gen_catalog():
     """Catalogue side: the reference's unpack_rvint / unpack_pids on the Mini_N64_L32 subsample
     files (tests/Mini_N64_L32/halos/z0.000/{halo,field}_{rv,pid}_A) and do_Menv_from_tree on the Mini halos and on
@@ -594,7 +626,7 @@ def gen_catalog():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'catalog']
+    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'catalog', 'sweep']
     G, T, P, C = import_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
     if 'hod' in which:
@@ -607,3 +639,5 @@ if __name__ == '__main__':
         gen_helpers(P)
     if 'catalog' in which:
         gen_catalog()
+    if 'sweep' in which:
+        gen_sweep(G)

@@ -197,3 +197,23 @@ def test_reseed_is_sharding_invariant_and_feeds_populate():
         for k in ('x', 'y', 'z', 'vx', 'vy', 'vz', 'mass', 'id'):
             np.testing.assert_array_equal(got[tr][k], ref[tr][k])
     st.free()
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_random_parameter_sweep_bit_exact(G, seed):
+    """seeded random HOD parameters over the ranges an MCMC explores (incl. assembly bias, conformity, velocity bias,
+    rank parameters, incompleteness, tracer subsets, light-cone RSD; tests/sweep.py): catalogues and keep masks
+    bit-equal to the oracle (which tests/test_oracle_hod.py holds to the shimmed reference on the same cases)"""
+    from oracle import oracle
+    from sweep import sweep_case
+    hd, pd, params, tracers, ranks, rsd = sweep_case(seed)
+    st = G.StagedCatalog(hd, pd)
+    st.populate(G.marshal_params(tracers, params, ranks, rsd))
+    kc, ks = st.fetch_keep()
+    mock = {tr: st.fetch(tr) for tr in tracers}
+    want, wkc, wks = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=4, enable_ranks=ranks, rsd=rsd, return_keep=True)
+    np.testing.assert_array_equal(kc, wkc)
+    np.testing.assert_array_equal(ks, wks)
+    assert sum(len(m['x']) for m in want.values()) > 0
+    assert_mock_equal(mock, want, exact=True)
+    st.free()
