@@ -111,3 +111,44 @@ def test_full_size_c5_properties(monkeypatch):
     expect = float(n) * (n - 1) * 4 / 3 * np.pi * (b32[1:] ** 3 - b32[:-1] ** 3) / box**3
     # ordered pairs: each unordered pair is counted twice, so the variance is 2 * expect
     assert np.all(np.abs(got - expect) < 5 * np.sqrt(2 * expect) + 2), (got, expect)
+
+
+@pytest.mark.parametrize('seed', range(18))
+def test_random_configuration_sweep(seed):
+    """seeded random pair-count calls (mode, auto / cross, point counts from a handful to 6000, box, reach up to L/2,
+    bin layout, pimax / mu bins, coordinates inside [0, L) or centred or partly outside) against the brute-force counter"""
+    from abacusutils_amd.analysis import tpcf_corrfunc as T
+    from oracle import oracle
+    rng = np.random.default_rng(7000 + seed)
+    mode = ['r', 'rppi', 'smu'][seed % 3]
+    box = float(rng.choice([50.0, 200.0, 1000.0]))
+    n1, n2 = int(rng.integers(5, 6000)), int(rng.integers(5, 5000))
+    auto = bool(rng.integers(2))
+    place = seed % 4                       # 0: [0, L), 1: centred, 2: a few points outside the box, 3: clustered in a corner
+    x1, y1, z1 = _points(n1, box, 100 + seed, centered=place == 1, clustered=bool(rng.integers(2)))
+    x2, y2, z2 = (None, None, None) if auto else _points(n2, box, 200 + seed, centered=place == 1, clustered=True)
+    if place == 2:
+        x1[:3] += box
+        z1[-2:] -= box
+    if place == 3:
+        x1, y1, z1 = x1 * 0.05, y1 * 0.05, z1 * 0.05
+    rmax = float(box * rng.uniform(0.02, 0.49))
+    nb = int(rng.integers(1, 20))
+    bins = np.geomspace(rmax * 1e-3, rmax, nb + 1) if rng.integers(2) else np.linspace(0.0, rmax, nb + 1)
+    if mode == 'rppi':
+        pimax = float(int(min(rmax, 40.0)) or 1)
+        kw = dict(pimax=pimax, npibins=int(pimax))
+    elif mode == 'smu':
+        kw = dict(mu_max=float(rng.choice([1.0, 0.7])), nmubins=int(rng.integers(1, 30)))
+    else:
+        kw = {}
+    want = oracle.paircount_brute(mode, x1, y1, z1, box, bins, x2, y2, z2, **kw)
+    if mode == 'r':
+        got = T.DD(int(auto), 4, bins, x1, y1, z1, X2=x2, Y2=y2, Z2=z2, periodic=True, boxsize=box)['npairs']
+    elif mode == 'rppi':
+        got = T.DDrppi(int(auto), 4, binfile=bins, pimax=kw['pimax'], X1=x1, Y1=y1, Z1=z1, X2=x2, Y2=y2, Z2=z2,
+                       periodic=True, boxsize=box)['npairs']
+    else:
+        got = T.DDsmu(int(auto), 4, bins, kw['mu_max'], kw['nmubins'], x1, y1, z1, X2=x2, Y2=y2, Z2=z2, periodic=True,
+                      boxsize=box)['npairs']
+    np.testing.assert_array_equal(got, want)
