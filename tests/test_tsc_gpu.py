@@ -178,3 +178,32 @@ def test_full_size_properties(monkeypatch):
     b = tsc_parallel(pos, ng, box, weights=w)
     # mean cell holds ~0.09 particles' weight spread over 27 cells: float32 sums of a few terms
     assert np.abs(a - b).max() <= 4e-6 * max(a.max(), 1.0)
+
+
+@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.filterwarnings('ignore:.*dtype')
+def test_random_option_sweep(seed):
+    """seeded random tsc_parallel calls (float32 / float64 positions, weights or none, offset, wrap, user mesh vs
+    allocated, cubic and anisotropic meshes from 2 cells up, particle counts around the list-builder switch) against the
+    oracle's stripe-partitioned scatter"""
+    from abacusutils_amd.analysis.tsc import tsc_parallel
+    from oracle import oracle
+    rng = np.random.default_rng(9000 + seed)
+    dt = ['f4', 'f8'][seed % 2]
+    box = float(rng.choice([1.0, 123.0, 2000.0]))
+    n = int(rng.choice([0, 1, 7, 3000, 50000, 400000, 2100000]))
+    if rng.random() < 0.35:
+        shape = tuple(int(v) for v in rng.integers(2, 70, 3))            # anisotropic
+    else:
+        shape = (int(rng.choice([2, 3, 5, 16, 31, 32, 33, 64, 100])),) * 3
+    pos = ((rng.random((n, 3)) * 1.3 - 0.15) * box).astype(dt)            # some outside the box
+    w = rng.uniform(0.2, 2.0, n).astype(dt) if rng.random() < 0.6 else None
+    offset = float(rng.choice([0.0, 0.5 * box / shape[0], -0.3 * box / shape[0], 0.123]))
+    wrap = bool(rng.integers(2)) or True    # positions outside the box need the wrap (tsc.py:45-50)
+    grid0 = (rng.random(shape) * 0.1).astype(np.float32)
+    ga, gb, p1, p2 = grid0.copy(), grid0.copy(), pos.copy(), pos.copy()
+    assert tsc_parallel(p1, ga, box, weights=w, wrap=wrap, offset=offset) is None
+    oracle.tsc_parallel(p2, gb, box, weights=w, nthread=1, wrap=wrap, offset=offset)
+    np.testing.assert_array_equal(p1, p2)
+    scale = max(float(np.abs(gb).max()), 1e-30)
+    np.testing.assert_allclose(ga, gb, rtol=2e-5, atol=3e-6 * scale)
