@@ -208,9 +208,12 @@ __device__ __forceinline__ float half_erfc_ub(float num, float dnum, float inv_s
     return 0.5f * __expf(-(tl * tl) * 0.9999f) * 1.0002f;
 }
 
-__device__ __forceinline__ bool cent_reject(const abacus_hod_params &p, const Filt &F, double mass, double multis,
-                                            double randoms, double deltac, double fenv, double shear) {
-    if (!(multis >= 0.0)) return false;
+// T = double: the staged float64 columns; T = float: their float32 shadows (mass rounded up, randoms rounded down,
+// the rest to nearest - the slack terms below already cover one float32 rounding of every operand)
+template <class T>
+__device__ __forceinline__ bool cent_reject(const abacus_hod_params &p, const Filt &F, T mass, T multis, T randoms,
+                                            T deltac, T fenv, T shear) {
+    if (!(multis >= (T)0)) return false;
     const float lM = __log10f((float)mass);   // v_log_f32 (1 ulp); its error is inside `dn` below
     const float mu = (float)multis * 1.00001f;
     const float d = (float)deltac, f = (float)fenv, sh = (float)shear;
@@ -235,26 +238,27 @@ __device__ __forceinline__ bool cent_reject(const abacus_hod_params &p, const Fi
         const float dn = 1e-6f * (fabsf(F.Q_lc) + fabsf(a1) + fabsf(a2) + fabsf(lM) + 4.f);
         U += half_erfc_ub(lc - lM, dn, F.Q_inv_s) * F.Q_ic * mu;
     }
-    return randoms > (double)(U * 1.001f);
+    return randoms > (T)(U * 1.001f);
 }
 
 __device__ __forceinline__ float pow_ub(float x, float alpha) {   // upper bound of x_true**alpha, x within 1e-6
     if (alpha == 1.0f) return x * 1.00001f;
     return powf(x, alpha) * (1.0002f + fabsf(alpha) * 4e-6f);
 }
-__device__ __forceinline__ float dec_ub(const float s[4], double r, double rv, double rp, double rr) {
+template <class T>
+__device__ __forceinline__ float dec_ub(const float s[4], T r, T rv, T rp, T rr) {
     return (1.f + fabsf(s[0] * (float)r) + fabsf(s[1] * (float)rv) + fabsf(s[2] * (float)rp) + fabsf(s[3] * (float)rr)) *
            1.00001f;
 }
 
-__device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Filt &F, double hmass, double weights,
-                                           double randoms, double r, double rv, double rp, double rr,
-                                           int8_t keep_cent) {
-    if (!(weights >= 0.0)) return false;
+template <class T>
+__device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Filt &F, T hmass, T weights, T randoms, T r,
+                                           T rv, T rp, T rr, int8_t keep_cent) {
+    if (!(weights >= (T)0)) return false;
     const float w = (float)weights * 1.00001f;
     float U = 0.f;
     if (p.want_LRG) {
-        const double xd = hmass - F.L_kMcut;   // the exact FP64 test of n_sat_LRG_modified (:28)
+        const double xd = (double)hmass - F.L_kMcut;   // the exact FP64 test of n_sat_LRG_modified (:28); a shadow mass is >= the true one
         if (!(xd < 0)) {
             const float lM = __log10f((float)hmass);
             const float dn = 1e-6f * (fabsf(F.L_lc) + fabsf(lM) + 4.f);
@@ -264,7 +268,7 @@ __device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Fil
         }
     }
     if (p.want_ELG) {
-        const double xd = hmass - F.E_kMcut;
+        const double xd = (double)hmass - F.E_kMcut;
         if (!(xd < 0)) {
             const int v = keep_cent == 1 ? 1 : (keep_cent == 2 ? 2 : 0);
             float term = F.E_As * pow_ub((float)xd * F.E_invM1[v], F.E_alpha[v]) * w * F.E_ic;
@@ -273,14 +277,14 @@ __device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Fil
         }
     }
     if (p.want_QSO) {
-        const double xd = hmass - F.Q_kMcut;
+        const double xd = (double)hmass - F.Q_kMcut;
         if (!(xd < 0)) {
             float term = pow_ub((float)xd * F.Q_invM1, F.Q_alpha) * w * F.Q_ic;
             if (p.enable_ranks) term *= dec_ub(F.Q_s, r, rv, rp, rr);
             U += term;
         }
     }
-    return randoms > (double)(U * 1.001f);
+    return randoms > (T)(U * 1.001f);
 }
 
 // Decide = two launches per object kind:
@@ -392,6 +396,111 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter(HodPtrs a, int first_tile, 
     }
     __syncthreads();
     // the tile's survivors go to the tile's own slice of the queue: no global atomics anywhere
+    const int cnt = nq;
+    if (tid == 0) a.q_count[g] = cnt;
+    unsigned short *queue = sat ? a.queue_s : a.queue_c;
+    for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
+}
+
+// ---- float32 shadows of the columns the filter streams ----------------------------------------------------------------
+// The filter only ever uses float32 casts of its inputs (every bound carries slack for that rounding), so for a catalogue
+// the library owns it streams float32 SHADOW columns built once at staging: 12 B per object instead of 24 (20 instead of
+// 40 with assembly bias).  Rounding modes keep every bound an upper bound: masses round UP (the exact test
+// `M - kappa M_cut < 0` of the satellite occupations then never fires for a particle the exact path keeps, and n(M) only
+// grows with M), randoms round DOWN (`r32 > U` implies `r > U`), the other columns to nearest (covered by the slack).
+// Shadows are padded to a multiple of four with values that always reject, so the filter loads whole float4s.
+template <int MODE>   // 0: nearest, 1: up, 2: down
+__global__ void hod_shadow(const double *__restrict__ src, float *__restrict__ dst, int64_t n, int64_t npad, float fill) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += (int64_t)gridDim.x * blockDim.x) {
+        float f = fill;
+        if (i < n) {
+            const double x = src[i];
+            f = (float)x;
+            if (MODE == 1 && (double)f < x) f = nextafterf(f, INFINITY);
+            if (MODE == 2 && (double)f > x) f = nextafterf(f, -INFINITY);
+        }
+        dst[i] = f;
+    }
+}
+
+struct FiltCols {
+    const float *hmass, *hmultis, *hrandoms, *hdeltac, *hfenv, *hshear;
+    const float *phmass, *pweights, *prandoms, *pranks, *pranksv, *pranksp, *pranksr;
+};
+
+__device__ __forceinline__ void load4f(const float *a, int64_t i, float fill, float (&v)[4]) {
+    if (a == nullptr) {
+        v[0] = v[1] = v[2] = v[3] = fill;
+    } else {
+        const float4 t = *reinterpret_cast<const float4 *>(a + i);
+        v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+    }
+}
+
+// hod_filter on the shadow columns: four consecutive objects per thread and step (one float4 per column)
+__global__ __launch_bounds__(FBLOCK) void hod_filter32(HodPtrs a, FiltCols c, int first_tile, int want_LRG, int want_ELG,
+                                                       int want_QSO, int enable_ranks, int need_env, int need_shear,
+                                                       Filt F) {
+    __shared__ int nq;
+    __shared__ unsigned short q[TILE];
+    const int tid = threadIdx.x;
+    if (tid == 0) nq = 0;
+    __syncthreads();
+    const int g = (int)blockIdx.x + first_tile;
+    const bool sat = g >= a.ntile_c;
+    const int T = sat ? g - a.ntile_c : g;
+    const int64_t n = sat ? a.np : a.nh;
+    const int64_t tile0 = (int64_t)T * TILE;
+    int8_t *keep = sat ? a.keep_s : a.keep_c;
+    abacus_hod_params pw;
+    pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO, pw.enable_ranks = enable_ranks;
+    const bool need_conf = sat && want_ELG && a.pinds != nullptr;
+#pragma unroll 2
+    for (int k = 0; k < PER_THREAD / 4; k++) {
+        const int loc = k * (4 * FBLOCK) + 4 * tid;
+        const int64_t i = tile0 + loc;
+        if (i >= n) continue;
+        bool need[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) need[u] = i + u < n;
+        if (!sat && F.cent_ok) {
+            float m[4], mu[4], r[4], d[4], f[4], s[4];
+            load4f(c.hmass, i, 1.f, m);
+            load4f(c.hmultis, i, 0.f, mu);
+            load4f(c.hrandoms, i, 2.f, r);
+            load4f(need_env ? c.hdeltac : nullptr, i, 0.f, d);
+            load4f(need_env ? c.hfenv : nullptr, i, 0.f, f);
+            load4f(need_shear ? c.hshear : nullptr, i, 0.f, s);
+#pragma unroll
+            for (int u = 0; u < 4; u++) need[u] = need[u] && !cent_reject<float>(pw, F, m[u], mu[u], r[u], d[u], f[u], s[u]);
+        } else if (sat && F.sat_ok) {
+            float m[4], w[4], r[4], r0[4], r1[4], r2[4], r3[4];
+            load4f(c.phmass, i, 1.f, m);
+            load4f(c.pweights, i, 0.f, w);
+            load4f(c.prandoms, i, 2.f, r);
+            load4f(enable_ranks ? c.pranks : nullptr, i, 1.f, r0);
+            load4f(enable_ranks ? c.pranksv : nullptr, i, 1.f, r1);
+            load4f(enable_ranks ? c.pranksp : nullptr, i, 1.f, r2);
+            load4f(enable_ranks ? c.pranksr : nullptr, i, 1.f, r3);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int8_t kc = 0;
+                if (need_conf && need[u]) kc = a.keep_c[a.pinds[i + u]];
+                need[u] = need[u] && !sat_reject<float>(pw, F, m[u], w[u], r[u], r0[u], r1[u], r2[u], r3[u], kc);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (need[u]) q[atomicAdd(&nq, 1)] = (unsigned short)(loc + u);
+    }
+    {   // zero this tile's mask: 8 consecutive bytes per thread
+        const int64_t o = tile0 + (int64_t)tid * 8;
+        if (o + 8 <= n) *reinterpret_cast<unsigned long long *>(keep + o) = 0ull;
+        else
+            for (int q8 = 0; q8 < 8; q8++)
+                if (o + q8 < n) keep[o + q8] = 0;
+    }
+    __syncthreads();
     const int cnt = nq;
     if (tid == 0) a.q_count[g] = cnt;
     unsigned short *queue = sat ? a.queue_s : a.queue_c;
@@ -985,6 +1094,10 @@ struct abacus_hod_state {
     int64_t counts[6] = {0, 0, 0, 0, 0, 0};
     abacus_hod_params params;
     bool have_run = false, counts_valid = false;
+    // float32 shadows of the columns the filter streams (owned catalogues only; see hod_shadow)
+    DevBuf shadow;
+    FiltCols fc = {};
+    bool shadow_ok = false, shadow_rand_ok = false;
 };
 
 namespace {
@@ -1091,6 +1204,51 @@ int launch_emit(abacus_hod_state *st) {
     return 0;
 }
 
+// (re)build the float32 shadow columns of an owned catalogue; `rand_only`: just the two random columns (after a reseed
+// or an update of the randoms)
+int build_shadows(abacus_hod_state *st, bool rand_only) {
+    const int64_t nh = st->nh, np = st->np;
+    const int64_t ph = (nh + 3) / 4 * 4 + 4, pp = (np + 3) / 4 * 4 + 4;
+    if (!rand_only) {
+        const int ncol_h = 3 + (st->hdeltac ? 1 : 0) + (st->hfenv ? 1 : 0) + (st->hshear ? 1 : 0);
+        const int ncol_p = 3 + (st->pranks ? 1 : 0) + (st->pranksv ? 1 : 0) + (st->pranksp ? 1 : 0) + (st->pranksr ? 1 : 0);
+        ABACUS_TRY(st->shadow.reserve(((size_t)ncol_h * ph + (size_t)ncol_p * pp) * sizeof(float)));
+    }
+    float *cur = st->shadow.as<float>();
+    auto col = [&](const double *src, int64_t n, int64_t npad, int mode, float fill, const float **slot, bool is_rand) -> int {
+        if (!src) {
+            *slot = nullptr;
+            return 0;
+        }
+        float *dst = cur;
+        cur += npad;
+        *slot = dst;
+        if (rand_only && !is_rand) return 0;
+        const int grid = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(npad, 256), 1), 8192);
+        if (mode == 0) ABACUS_LAUNCH("hod_shadow", hod_shadow<0>, dim3(grid), dim3(256), 0, src, dst, n, npad, fill);
+        else if (mode == 1) ABACUS_LAUNCH("hod_shadow", hod_shadow<1>, dim3(grid), dim3(256), 0, src, dst, n, npad, fill);
+        else ABACUS_LAUNCH("hod_shadow", hod_shadow<2>, dim3(grid), dim3(256), 0, src, dst, n, npad, fill);
+        return 0;
+    };
+    FiltCols &c = st->fc;
+    // padding values: randoms 2 (> any bound) reject; the objects behind n are masked in the kernel anyway
+    ABACUS_TRY(col(st->hmass, nh, ph, 1, 1.f, &c.hmass, false));
+    ABACUS_TRY(col(st->hmultis, nh, ph, 0, 0.f, &c.hmultis, false));
+    ABACUS_TRY(col(st->hrandoms, nh, ph, 2, 2.f, &c.hrandoms, true));
+    ABACUS_TRY(col(st->hdeltac, nh, ph, 0, 0.f, &c.hdeltac, false));
+    ABACUS_TRY(col(st->hfenv, nh, ph, 0, 0.f, &c.hfenv, false));
+    ABACUS_TRY(col(st->hshear, nh, ph, 0, 0.f, &c.hshear, false));
+    ABACUS_TRY(col(st->phmass, np, pp, 1, 1.f, &c.phmass, false));
+    ABACUS_TRY(col(st->pweights, np, pp, 0, 0.f, &c.pweights, false));
+    ABACUS_TRY(col(st->prandoms, np, pp, 2, 2.f, &c.prandoms, true));
+    ABACUS_TRY(col(st->pranks, np, pp, 0, 1.f, &c.pranks, false));
+    ABACUS_TRY(col(st->pranksv, np, pp, 0, 1.f, &c.pranksv, false));
+    ABACUS_TRY(col(st->pranksp, np, pp, 0, 1.f, &c.pranksp, false));
+    ABACUS_TRY(col(st->pranksr, np, pp, 0, 1.f, &c.pranksr, false));
+    st->shadow_ok = st->shadow_rand_ok = true;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1151,6 +1309,7 @@ int abacus_hod_update(abacus_hod_state *st, const char *field, const double *hos
     if (n == 0) return 0;
     HIP_TRY(hipMemcpyAsync(dst, host, n * sizeof(double), hipMemcpyHostToDevice, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
+    st->shadow_rand_ok = false;   // the float32 shadows of the randoms are rebuilt by the next populate
     return 0;
 }
 
@@ -1187,6 +1346,7 @@ int abacus_hod_reseed(abacus_hod_state *st, uint64_t seed, int want_expvel, int6
         ABACUS_LAUNCH("hod_reseed_particles", hod_reseed_particles, dim3(grid), dim3(256), 0, st->np, part_index0,
                       (unsigned long long)seed, st->prandoms);
     }
+    st->shadow_rand_ok = false;
     return 0;
 }
 
@@ -1370,19 +1530,31 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     const int need_shear = p->want_ELG && p->E_Ccent != 0 && st->hshear != nullptr;
     const bool conf = p->want_ELG && st->pinds != nullptr && st->ntile_s > 0;   // satellites read keep_cent[pinds]
     const int ntile = st->ntile_c + st->ntile_s, nsb = st->nsb_c + st->nsb_s;
+    // owned catalogues: the filter streams the float32 shadow columns (half the bytes); caller-owned device arrays can
+    // change behind the library's back, so they are streamed as they are
+    static const bool force64 = getenv("ABACUS_HOD_F64FILTER") != nullptr;
+    const bool use32 = st->owns && !force64;
+    if (use32 && !st->shadow_ok) ABACUS_TRY(build_shadows(st, false));
+    else if (use32 && !st->shadow_rand_ok) ABACUS_TRY(build_shadows(st, true));
+    const FiltCols fc = st->fc;
 #define FILTER(first, count)                                                                                         \
-    if ((count) > 0)                                                                                                 \
-    ABACUS_LAUNCH("hod_filter", hod_filter, dim3(count), dim3(FBLOCK), 0, a, first, p->want_LRG, p->want_ELG,        \
-                  p->want_QSO, p->enable_ranks, need_env, need_shear, F)
+    if ((count) > 0) {                                                                                               \
+        if (use32)                                                                                                   \
+            ABACUS_LAUNCH("hod_filter", hod_filter32, dim3(count), dim3(FBLOCK), 0, a, fc, first, p->want_LRG,       \
+                          p->want_ELG, p->want_QSO, p->enable_ranks, need_env, need_shear, F);                       \
+        else                                                                                                         \
+            ABACUS_LAUNCH("hod_filter", hod_filter, dim3(count), dim3(FBLOCK), 0, a, first, p->want_LRG, p->want_ELG, \
+                          p->want_QSO, p->enable_ranks, need_env, need_shear, F);                                    \
+    }
 #define EXACT(first, count) \
     if ((count) > 0) ABACUS_LAUNCH("hod_exact", hod_exact, dim3(count), dim3(FBLOCK), 0, a, first, *p, pre)
     if (!conf) {
-        FILTER(0, ntile);
+        FILTER(0, ntile)
         EXACT(0, nsb);
     } else {
-        FILTER(0, st->ntile_c);
+        FILTER(0, st->ntile_c)
         EXACT(0, st->nsb_c);
-        FILTER(st->ntile_c, st->ntile_s);
+        FILTER(st->ntile_c, st->ntile_s)
         EXACT(st->nsb_c, st->nsb_s);
     }
 #undef FILTER
@@ -1491,6 +1663,7 @@ int abacus_hod_free(abacus_hod_state *st) {
     (void)st->nfw_counts.release(), (void)st->nfw_offsets.release(), (void)st->nfw_draw.release(), (void)st->nfw_scan.release();
     if (st->h_totals) (void)hipHostFree(st->h_totals);
     for (int t = 0; t < 3; t++) (void)st->out[t].release();
+    (void)st->shadow.release();
     delete st;
     return 0;
 }

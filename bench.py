@@ -173,9 +173,10 @@ def bench_hod(args, dist):
     # roofline of the dominant kernel: algorithmic bytes / HIP-event duration
     alg_bytes = {
         # one fused launch over the central and the satellite tiles: mass, multis, randoms per halo and hmass, weights,
-        # randoms per particle (the LRG HOD of the test yaml has Acent = Bcent = 0, so deltac / fenv enter as 0 * x and
-        # are not streamed: 24 B, not SURVEY's 40 B, per object -- the smaller, honest numerator)
-        'hod_filter': 24.0 * nh + 24.0 * npart,
+        # randoms per particle, streamed from the float32 SHADOW columns the library keeps for a catalogue it owns
+        # (12 B per object; the float64 originals would be 24 B, SURVEY's 40 B count deltac / fenv, which the LRG HOD of
+        # the test yaml multiplies by Acent = Bcent = 0 and the filter does not read) -- the smallest, honest numerator
+        'hod_filter': 12.0 * nh + 12.0 * npart,
         'hod_emit': 1.0 * (nh + npart) + 152.0 * ngal,   # mask + gather 88 B + write 64 B per galaxy
     }
     kern = dict(warm)
@@ -188,8 +189,9 @@ def bench_hod(args, dist):
                            'frac': ach / HBM_PEAK_GBS,
                            'traffic': pmc_traffic('hod', dom) if (nh, npart) == (10_000_000, 10_000_000) else None,
                            'algorithmic_bytes': alg_bytes[dom],
-                           'whole_step_GBs': (24.0 * nh + 24.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9,
-                           'whole_step_frac': (24.0 * nh + 24.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
+                           'whole_step_GBs': (12.0 * nh + 12.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9,
+                           'whole_step_frac': (12.0 * nh + 12.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                           'reference_layout_GBs': (24.0 * nh + 24.0 * npart) / (kern[dom] * 1e-3) / 1e9}
     st.free()
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu:   # CPU baseline: rank 0 at N = 1 only
         out['cpu_baseline'] = cpu_baseline_hod(hd, pd, params, tracers, nh)
