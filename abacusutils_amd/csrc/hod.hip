@@ -455,7 +455,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter32(HodPtrs a, FiltCols c, in
     abacus_hod_params pw;
     pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO, pw.enable_ranks = enable_ranks;
     const bool need_conf = sat && want_ELG && a.pinds != nullptr;
-#pragma unroll 2
+#pragma unroll 1
     for (int k = 0; k < PER_THREAD / 4; k++) {
         const int loc = k * (4 * FBLOCK) + 4 * tid;
         const int64_t i = tile0 + loc;
