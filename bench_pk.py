@@ -28,7 +28,8 @@ def pmc_traffic(workload, kernel):
             continue
         for k, e in tab.items():
             base = k.split('<')[0]
-            if kernel == base or kernel.startswith(base + '_') or base.startswith(kernel + '_'):
+            # profiler labels vs kernel symbols: fft_cols_x <-> fft_cols, hod_filter <-> hod_filter32 (float32 shadows)
+            if kernel == base or kernel.startswith(base + '_') or base.startswith(kernel + '_') or base == kernel + '32':
                 return e['hbm_bytes_per_launch']
     return None
 
