@@ -437,61 +437,142 @@ __device__ __forceinline__ void load4f(const float *a, int64_t i, float fill, fl
     }
 }
 
-// hod_filter on the shadow columns: four consecutive objects per thread and step (one float4 per column)
+// ---- two-stage filter: a table bound in the streaming loop, the arithmetic bound only for its survivors ---------------
+// Where the summed occupation of the wanted tracers is non-decreasing in mass (centrals: LRG / QSO erfc forms without
+// assembly bias; satellites: every power-law form the filter covers), the bound of a whole mass BIN is the bound at its
+// upper edge.  Bins follow the float32 representation (exponent and top three mantissa bits: 8 per octave, 2^33..2^54),
+// so the bin of a shadow mass (rounded up) is a shift and a subtraction; the table holds host-evaluated float64
+// occupations at the upper edges, rounded up, with a floor of 1e-30 (no bound ever underflows to "reject at r > 0").
+// Stage 1 (per object: one table look-up, two multiplies, one compare - no log10 / exp / pow) fills an LDS queue with
+// the few per cent that survive; stage 2 evaluates the arithmetic bound of hod_filter for those, all lanes busy, and
+// fills the tile's queue.  Conformity (keep_cent[pinds]) is only looked up in stage 2.
+constexpr int CH_SHIFT = 20, CH_BASE = (127 + 33) << 3, CH_NLEV = 21 * 8;
+struct Cheap {
+    int c_ok, s_ok;
+    float dec[4];             // max over the wanted tracers of |s|, |s_v|, |s_p|, |s_r| (rank modulation bound)
+    float Bc[CH_NLEV], Bs[CH_NLEV];
+};
+
+__device__ __forceinline__ float cheap_bound(const float *tab, float mass) {
+    const unsigned int lev = (__float_as_uint(mass) >> CH_SHIFT);   // negative / NaN masses land above the table
+    const int j = (int)lev - CH_BASE;
+    return j < 0 ? tab[0] : (j < CH_NLEV ? tab[j] : INFINITY);
+}
+
+// hod_filter on the shadow columns: four consecutive objects per thread and step (one float4 per column).  One
+// instantiation per (object kind, one- or two-stage): a launch carries only the code it runs - with all four paths in one
+// kernel body the same work took 68 instead of 59 us (instruction fetch).  `first_tile` counts from the first tile of
+// the kind.
+// KIND: 0 = central tiles, 1 = satellite tiles, 2 = both in one launch (first_tile is then a global tile id)
+template <int KIND, bool TWO_STAGE>
 __global__ __launch_bounds__(FBLOCK) void hod_filter32(HodPtrs a, FiltCols c, int first_tile, int want_LRG, int want_ELG,
                                                        int want_QSO, int enable_ranks, int need_env, int need_shear,
-                                                       Filt F) {
-    __shared__ int nq;
-    __shared__ unsigned short q[TILE];
+                                                       Filt F, Cheap ch) {
+    __shared__ int nq, nq1;
+    __shared__ unsigned short q[TILE], q1[TWO_STAGE ? TILE : 1];
+    __shared__ float tab[TWO_STAGE ? CH_NLEV : 1];
     const int tid = threadIdx.x;
-    if (tid == 0) nq = 0;
+    if (tid == 0) nq = 0, nq1 = 0;
+    const bool SAT = KIND == 2 ? (int)blockIdx.x + first_tile >= a.ntile_c : KIND == 1;
+    if (TWO_STAGE && tid < CH_NLEV) tab[tid] = SAT ? ch.Bs[tid] : ch.Bc[tid];
     __syncthreads();
-    const int g = (int)blockIdx.x + first_tile;
-    const bool sat = g >= a.ntile_c;
-    const int T = sat ? g - a.ntile_c : g;
-    const int64_t n = sat ? a.np : a.nh;
+    const int T = KIND == 2 ? (int)blockIdx.x + first_tile - (SAT ? a.ntile_c : 0) : (int)blockIdx.x + first_tile;
+    const int g = SAT ? T + a.ntile_c : T;          // global tile id (index of q_count)
+    const int64_t n = SAT ? a.np : a.nh;
     const int64_t tile0 = (int64_t)T * TILE;
-    int8_t *keep = sat ? a.keep_s : a.keep_c;
+    int8_t *keep = SAT ? a.keep_s : a.keep_c;
     abacus_hod_params pw;
     pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO, pw.enable_ranks = enable_ranks;
-    const bool need_conf = sat && want_ELG && a.pinds != nullptr;
+    const bool need_conf = SAT && want_ELG && a.pinds != nullptr;
+    if constexpr (TWO_STAGE) {
+        // ---- stage 1: table bound ----
 #pragma unroll 1
-    for (int k = 0; k < PER_THREAD / 4; k++) {
-        const int loc = k * (4 * FBLOCK) + 4 * tid;
-        const int64_t i = tile0 + loc;
-        if (i >= n) continue;
-        bool need[4];
+        for (int k = 0; k < PER_THREAD / 4; k++) {
+            const int loc = k * (4 * FBLOCK) + 4 * tid;
+            const int64_t i = tile0 + loc;
+            if (i >= n) continue;
+            float m[4], w[4], r[4], dec[4] = {1.f, 1.f, 1.f, 1.f};
+            load4f(SAT ? c.phmass : c.hmass, i, 1.f, m);
+            load4f(SAT ? c.pweights : c.hmultis, i, 0.f, w);
+            load4f(SAT ? c.prandoms : c.hrandoms, i, 2.f, r);
+            if (SAT && enable_ranks) {
+                float r0[4], r1[4], r2[4], r3[4];
+                load4f(c.pranks, i, 1.f, r0);
+                load4f(c.pranksv, i, 1.f, r1);
+                load4f(c.pranksp, i, 1.f, r2);
+                load4f(c.pranksr, i, 1.f, r3);
 #pragma unroll
-        for (int u = 0; u < 4; u++) need[u] = i + u < n;
-        if (!sat && F.cent_ok) {
-            float m[4], mu[4], r[4], d[4], f[4], s[4];
-            load4f(c.hmass, i, 1.f, m);
-            load4f(c.hmultis, i, 0.f, mu);
-            load4f(c.hrandoms, i, 2.f, r);
-            load4f(need_env ? c.hdeltac : nullptr, i, 0.f, d);
-            load4f(need_env ? c.hfenv : nullptr, i, 0.f, f);
-            load4f(need_shear ? c.hshear : nullptr, i, 0.f, s);
-#pragma unroll
-            for (int u = 0; u < 4; u++) need[u] = need[u] && !cent_reject<float>(pw, F, m[u], mu[u], r[u], d[u], f[u], s[u]);
-        } else if (sat && F.sat_ok) {
-            float m[4], w[4], r[4], r0[4], r1[4], r2[4], r3[4];
-            load4f(c.phmass, i, 1.f, m);
-            load4f(c.pweights, i, 0.f, w);
-            load4f(c.prandoms, i, 2.f, r);
-            load4f(enable_ranks ? c.pranks : nullptr, i, 1.f, r0);
-            load4f(enable_ranks ? c.pranksv : nullptr, i, 1.f, r1);
-            load4f(enable_ranks ? c.pranksp : nullptr, i, 1.f, r2);
-            load4f(enable_ranks ? c.pranksr : nullptr, i, 1.f, r3);
+                for (int u = 0; u < 4; u++) dec[u] = dec_ub<float>(ch.dec, r0[u], r1[u], r2[u], r3[u]);
+            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                int8_t kc = 0;
-                if (need_conf && need[u]) kc = a.keep_c[a.pinds[i + u]];
-                need[u] = need[u] && !sat_reject<float>(pw, F, m[u], w[u], r[u], r0[u], r1[u], r2[u], r3[u], kc);
+                if (i + u >= n) continue;
+                bool pass = true;                                  // negative / NaN multiplicities are never rejected
+                if (w[u] >= 0.f) {
+                    const float U = cheap_bound(tab, m[u]) * (w[u] * 1.00001f) * dec[u];
+                    pass = !(r[u] > U * 1.001f);
+                }
+                if (pass) q1[atomicAdd(&nq1, 1)] = (unsigned short)(loc + u);
             }
         }
+        __syncthreads();
+        // ---- stage 2: the arithmetic bound for the survivors ----
+        const int n1 = nq1;
+        for (int e = tid; e < n1; e += FBLOCK) {
+            const int loc = q1[e];
+            const int64_t i = tile0 + loc;
+            bool rej;
+            if (!SAT) {
+                rej = cent_reject<float>(pw, F, c.hmass[i], c.hmultis[i], c.hrandoms[i], 0.f, 0.f, 0.f);
+            } else {
+                int8_t kc = 0;
+                if (need_conf) kc = a.keep_c[a.pinds[i]];
+                const float r0 = enable_ranks ? c.pranks[i] : 1.f, r1 = enable_ranks ? c.pranksv[i] : 1.f,
+                            r2 = enable_ranks ? c.pranksp[i] : 1.f, r3 = enable_ranks ? c.pranksr[i] : 1.f;
+                rej = sat_reject<float>(pw, F, c.phmass[i], c.pweights[i], c.prandoms[i], r0, r1, r2, r3, kc);
+            }
+            if (!rej) q[atomicAdd(&nq, 1)] = (unsigned short)loc;
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < PER_THREAD / 4; k++) {
+            const int loc = k * (4 * FBLOCK) + 4 * tid;
+            const int64_t i = tile0 + loc;
+            if (i >= n) continue;
+            bool need[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (need[u]) q[atomicAdd(&nq, 1)] = (unsigned short)(loc + u);
+            for (int u = 0; u < 4; u++) need[u] = i + u < n;
+            if (!SAT && F.cent_ok) {
+                float m[4], mu[4], r[4], d[4], f[4], sh[4];
+                load4f(c.hmass, i, 1.f, m);
+                load4f(c.hmultis, i, 0.f, mu);
+                load4f(c.hrandoms, i, 2.f, r);
+                load4f(need_env ? c.hdeltac : nullptr, i, 0.f, d);
+                load4f(need_env ? c.hfenv : nullptr, i, 0.f, f);
+                load4f(need_shear ? c.hshear : nullptr, i, 0.f, sh);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    need[u] = need[u] && !cent_reject<float>(pw, F, m[u], mu[u], r[u], d[u], f[u], sh[u]);
+            } else if (SAT && F.sat_ok) {
+                float m[4], w[4], r[4], r0[4], r1[4], r2[4], r3[4];
+                load4f(c.phmass, i, 1.f, m);
+                load4f(c.pweights, i, 0.f, w);
+                load4f(c.prandoms, i, 2.f, r);
+                load4f(enable_ranks ? c.pranks : nullptr, i, 1.f, r0);
+                load4f(enable_ranks ? c.pranksv : nullptr, i, 1.f, r1);
+                load4f(enable_ranks ? c.pranksp : nullptr, i, 1.f, r2);
+                load4f(enable_ranks ? c.pranksr : nullptr, i, 1.f, r3);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int8_t kc = 0;
+                    if (need_conf && need[u]) kc = a.keep_c[a.pinds[i + u]];
+                    need[u] = need[u] && !sat_reject<float>(pw, F, m[u], w[u], r[u], r0[u], r1[u], r2[u], r3[u], kc);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (need[u]) q[atomicAdd(&nq, 1)] = (unsigned short)(loc + u);
+        }
     }
     {   // zero this tile's mask: 8 consecutive bytes per thread
         const int64_t o = tile0 + (int64_t)tid * 8;
@@ -503,7 +584,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter32(HodPtrs a, FiltCols c, in
     __syncthreads();
     const int cnt = nq;
     if (tid == 0) a.q_count[g] = cnt;
-    unsigned short *queue = sat ? a.queue_s : a.queue_c;
+    unsigned short *queue = SAT ? a.queue_s : a.queue_c;
     for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
 }
 
@@ -1156,6 +1237,57 @@ Filt make_filter(const abacus_hod_params &p, const SatPre &pre) {
     return F;
 }
 
+// host side of the two-stage filter: float64 occupations at the upper edge of every float32 mass bin
+Cheap make_cheap(const abacus_hod_params &p, const SatPre &pre, const Filt &F, int need_env) {
+    Cheap c;
+    memset(&c, 0, sizeof c);
+    // centrals: erfc forms without assembly bias; the ELG central occupation is not monotone in mass
+    c.c_ok = F.cent_ok && !p.want_ELG && !need_env && (p.want_LRG || p.want_QSO) && !getenv("ABACUS_HOD_ONE_STAGE");
+    // satellites: F.sat_ok already demands particle-independent M1 / M_cut, M1 > 0, alpha >= 0, A_s >= 0, ic >= 0
+    c.s_ok = F.sat_ok && !getenv("ABACUS_HOD_ONE_STAGE");
+    auto up = [](double v) { return std::max((float)(v * 1.00001), 1e-30f); };
+    const double Ls[4] = {p.L_s, p.L_s_v, p.L_s_p, p.L_s_r}, Es[4] = {p.E_s, p.E_s_v, p.E_s_p, p.E_s_r},
+                 Qs[4] = {p.Q_s, p.Q_s_v, p.Q_s_p, p.Q_s_r};
+    for (int q = 0; q < 4; q++) {
+        double m = 0;
+        if (p.want_LRG) m = std::max(m, std::fabs(Ls[q]));
+        if (p.want_ELG) m = std::max(m, std::fabs(Es[q]));
+        if (p.want_QSO) m = std::max(m, std::fabs(Qs[q]));
+        c.dec[q] = (float)(m * 1.000001);
+    }
+    auto ncen_L = [&](double M) { return 0.5 * std::erfc((p.L_logM_cut - std::log10(M)) / (1.41421356 * p.L_sigma)); };
+    auto ncen_Q = [&](double M) { return 0.5 * (1 + std::erf((std::log10(M) - p.Q_logM_cut) / 1.41421356 / p.Q_sigma)); };
+    auto powa = [](double x, double a) { return a == 1.0 ? x : std::pow(x, a); };
+    auto plaw = [&](double M, double kMcut, double M1, double alpha) {
+        return M - kMcut < 0 ? 0.0 : powa((M - kMcut) / M1, alpha);
+    };
+    for (int j = 0; j < CH_NLEV; j++) {
+        const uint32_t bits = (uint32_t)(CH_BASE + j + 1) << CH_SHIFT;   // upper edge of bin j (exclusive)
+        float Tf;
+        memcpy(&Tf, &bits, 4);
+        const double T = (double)Tf;
+        double bc = 0, bs = 0;
+        if (c.c_ok) {
+            if (p.want_LRG) bc += ncen_L(T) * p.L_ic;
+            if (p.want_QSO) bc += ncen_Q(T) * p.Q_ic;
+        }
+        if (c.s_ok) {
+            if (p.want_LRG) bs += plaw(T, p.L_kappa * pre.L_Mcut, pre.L_M1, p.L_alpha) * ncen_L(T) * p.L_ic;
+            if (p.want_ELG) {
+                const double k = p.E_kappa * pre.E_Mcut;   // conformity variants: the largest of the three
+                const double v = std::max(plaw(T, k, pre.E_M1, p.E_alpha),
+                                          std::max(plaw(T, k, pre.E_M1_EL, p.E_alpha_EL), plaw(T, k, pre.E_M1_EE, p.E_alpha_EE)));
+                bs += p.E_A_s * v * p.E_ic;
+            }
+            if (p.want_QSO) bs += plaw(T, p.Q_kappa * pre.Q_Mcut, pre.Q_M1, p.Q_alpha) * p.Q_ic;
+        }
+        if (!std::isfinite(bc)) c.c_ok = 0;
+        if (!std::isfinite(bs)) c.s_ok = 0;
+        c.Bc[j] = up(bc), c.Bs[j] = up(bs);
+    }
+    return c;
+}
+
 template <class T>
 int upload(T *&dst, const T *src, int64_t n, bool on_device) {
     if (src == nullptr) {
@@ -1537,11 +1669,34 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     if (use32 && !st->shadow_ok) ABACUS_TRY(build_shadows(st, false));
     else if (use32 && !st->shadow_rand_ok) ABACUS_TRY(build_shadows(st, true));
     const FiltCols fc = st->fc;
+    const Cheap cheap = make_cheap(*p, pre, F, need_env);
+    // `first`, `count` in global tile ids (centrals first): the shadow path launches the two kinds separately
+    auto filter32 = [&](int first, int count) -> int {
+        const int c0 = std::min(first, st->ntile_c), c1 = std::min(first + count, st->ntile_c);
+        const int s0 = std::max(first, st->ntile_c) - st->ntile_c, s1 = std::max(first + count, st->ntile_c) - st->ntile_c;
+#define F32(KIND, TWO, first_, count_)                                                                                \
+    ABACUS_LAUNCH("hod_filter", (hod_filter32<KIND, TWO>), dim3(count_), dim3(FBLOCK), 0, a, fc, first_, p->want_LRG, \
+                  p->want_ELG, p->want_QSO, p->enable_ranks, need_env, need_shear, F, cheap)
+        const bool c2 = F.cent_ok && cheap.c_ok, s2 = F.sat_ok && cheap.s_ok;
+        if (c1 > c0 && s1 > s0 && c2 == s2) {   // both kinds, same path: one launch
+            if (c2) F32(2, true, first, count);
+            else F32(2, false, first, count);
+            return 0;
+        }
+        if (c1 > c0) {
+            if (c2) F32(0, true, c0, c1 - c0);
+            else F32(0, false, c0, c1 - c0);
+        }
+        if (s1 > s0) {
+            if (s2) F32(1, true, s0, s1 - s0);
+            else F32(1, false, s0, s1 - s0);
+        }
+#undef F32
+        return 0;
+    };
 #define FILTER(first, count)                                                                                         \
     if ((count) > 0) {                                                                                               \
-        if (use32)                                                                                                   \
-            ABACUS_LAUNCH("hod_filter", hod_filter32, dim3(count), dim3(FBLOCK), 0, a, fc, first, p->want_LRG,       \
-                          p->want_ELG, p->want_QSO, p->enable_ranks, need_env, need_shear, F);                       \
+        if (use32) ABACUS_TRY(filter32(first, count));                                                               \
         else                                                                                                         \
             ABACUS_LAUNCH("hod_filter", hod_filter, dim3(count), dim3(FBLOCK), 0, a, first, p->want_LRG, p->want_ELG, \
                           p->want_QSO, p->enable_ranks, need_env, need_shear, F);                                    \
