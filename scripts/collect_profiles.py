@@ -21,8 +21,10 @@ os.makedirs(dst, exist_ok=True)
 FETCH_FACTOR = {'fft_cols<2048, 8>': 1.0}   # 64-B row segments; every other kernel reads >= 128-B runs
 
 for d in ('prof_hod', 'prof_pk1024', 'prof_pk2048'):
-    for f in glob.glob(os.path.join(src, d, '**', '*kernel_stats.csv'), recursive=True):
-        shutil.copy(f, os.path.join(dst, f'{d[5:]}_kernel_stats.csv'))
+    # gpurun MERGES its output into gpurun_out/: summaries of earlier calls are still there - take the newest
+    found = sorted(glob.glob(os.path.join(src, d, '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime)
+    if found:
+        shutil.copy(found[-1], os.path.join(dst, f'{d[5:]}_kernel_stats.csv'))
     log = os.path.join(src, d + '.log')
     if os.path.exists(log):   # the bench JSON line printed under the profiler
         lines = [ln for ln in open(log) if ln.startswith('{"metric"')]
