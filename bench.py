@@ -191,7 +191,10 @@ def bench_hod(args, dist):
                            'algorithmic_bytes': alg_bytes[dom],
                            'whole_step_GBs': (12.0 * nh + 12.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9,
                            'whole_step_frac': (12.0 * nh + 12.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                           'reference_layout_GBs': (24.0 * nh + 24.0 * npart) / (kern[dom] * 1e-3) / 1e9}
+                           # the same times in units of the float64 columns the reference streams (24 B per object):
+                           # what a kernel reading the reference layout would need to sustain - NOT bytes this path moves
+                           'reference_layout_GBs': (24.0 * nh + 24.0 * npart) / (kern[dom] * 1e-3) / 1e9,
+                           'reference_layout_whole_step_GBs': (24.0 * nh + 24.0 * npart + 152.0 * ngal) / (dt / args.steps) / 1e9}
     st.free()
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu:   # CPU baseline: rank 0 at N = 1 only
         out['cpu_baseline'] = cpu_baseline_hod(hd, pd, params, tracers, nh)
