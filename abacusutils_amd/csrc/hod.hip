@@ -296,7 +296,57 @@ __device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Fil
 constexpr int FBLOCK = 256;
 
 // All device pointers of the staged catalogue + work arrays, passed by value to the fused kernels
+// Emission records (owned catalogues): the rows hod_emit gathers for a kept object, packed next to each other at
+// staging - one TLB entry and one or two 64-B sectors per galaxy instead of five arrays (five pages, five lines).  Only
+// columns that never change after staging (not hveldev, which a reseed redraws).
+// The exact kernel reads its decision inputs (mass, multiplicity / weight, environment, ranks) from the same record, so
+// a kept object's record is already in the cache hierarchy when hod_emit comes for it.  Absent optional columns are
+// stored as the value the exact chain substitutes for them (0, ranks 1).
+struct __attribute__((aligned(32))) HaloRec {
+    double pos[3], vel[3], mass;
+    long long id;
+    double multis, deltac, fenv, shear;
+};
+struct __attribute__((aligned(32))) PartRec {
+    double pos[3], vel[3], hvel[3], mass;
+    long long id;
+    double weights, deltac, fenv, shear, ranks[4], pad;
+};
+static_assert(sizeof(HaloRec) == 96 && sizeof(PartRec) == 160, "record sizes");
+
+struct RecSrc {
+    const double *hpos, *hvel, *hmass, *hmultis, *hdeltac, *hfenv, *hshear;
+    const int64_t *hid;
+    const double *ppos, *pvel, *phvel, *phmass, *pweights, *pdeltac, *pfenv, *pshear, *pranks[4];
+    const int64_t *phid;
+};
+__global__ void hod_build_recs(int64_t nh, int64_t np, RecSrc c, HaloRec *__restrict__ hrec, PartRec *__restrict__ prec) {
+    const double *hpos = c.hpos, *hvel = c.hvel, *hmass = c.hmass, *ppos = c.ppos, *pvel = c.pvel, *phvel = c.phvel,
+                 *phmass = c.phmass;
+    const int64_t *hid = c.hid, *phid = c.phid;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < nh; i += stride) {
+        HaloRec r;
+        for (int d = 0; d < 3; d++) r.pos[d] = hpos[3 * i + d], r.vel[d] = hvel[3 * i + d];
+        r.mass = hmass[i], r.id = hid[i];
+        r.multis = c.hmultis[i];
+        r.deltac = c.hdeltac ? c.hdeltac[i] : 0.0, r.fenv = c.hfenv ? c.hfenv[i] : 0.0, r.shear = c.hshear ? c.hshear[i] : 0.0;
+        hrec[i] = r;
+    }
+    for (int64_t i = t0; i < np; i += stride) {
+        PartRec r;
+        for (int d = 0; d < 3; d++) r.pos[d] = ppos[3 * i + d], r.vel[d] = pvel[3 * i + d], r.hvel[d] = phvel[3 * i + d];
+        r.mass = phmass[i], r.id = phid[i], r.pad = 0.0;
+        r.weights = c.pweights[i];
+        r.deltac = c.pdeltac ? c.pdeltac[i] : 0.0, r.fenv = c.pfenv ? c.pfenv[i] : 0.0, r.shear = c.pshear ? c.pshear[i] : 0.0;
+        for (int q = 0; q < 4; q++) r.ranks[q] = c.pranks[q] ? c.pranks[q][i] : 1.0;
+        prec[i] = r;
+    }
+}
+
 struct HodPtrs {
+    const HaloRec *hrec = nullptr;   // packed per-object records (owned catalogues), or nullptr: gather from the columns
+    const PartRec *prec = nullptr;
     int64_t nh, np;
     int ntile_c, ntile_s, nsb_c, nsb_s;
     const double *hmass, *hmultis, *hrandoms, *hdeltac, *hfenv, *hshear;
@@ -641,8 +691,14 @@ __global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, aba
             const int64_t t0 = (int64_t)(tile_first + q) * TILE;
             const int loc = a.queue_c[t0 + (j - L.pre[q])];
             const int64_t i = t0 + loc;
-            const int8_t kk = cent_decide(p, a.hmass[i], a.hmultis[i], a.hrandoms[i], load1(a.hdeltac, i, 0.0),
-                                          load1(a.hfenv, i, 0.0), load1(sh_arr, i, 0.0));
+            int8_t kk;
+            if (a.hrec) {
+                const HaloRec &r = a.hrec[i];
+                kk = cent_decide(p, r.mass, r.multis, a.hrandoms[i], r.deltac, r.fenv, p.want_ELG ? r.shear : 0.0);
+            } else {
+                kk = cent_decide(p, a.hmass[i], a.hmultis[i], a.hrandoms[i], load1(a.hdeltac, i, 0.0),
+                                 load1(a.hfenv, i, 0.0), load1(sh_arr, i, 0.0));
+            }
             if (kk) {
                 a.keep_c[i] = kk;
                 const int ls = q * TILE + loc;
@@ -659,10 +715,18 @@ __global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, aba
             const int loc = a.queue_s[t0 + (j - L.pre[q])];
             const int64_t i = t0 + loc;
             const int8_t kc = need_conf ? a.keep_c[a.pinds[i]] : (int8_t)0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
-            const int8_t kk = sat_decide(p, pre, a.phmass[i], a.pweights[i], a.prandoms[i], load1(a.pdeltac, i, 0.0),
-                                         load1(a.pfenv, i, 0.0), load1(sh_arr, i, 0.0), need_ranks ? a.pranks[i] : 1.0,
-                                         need_ranks ? a.pranksv[i] : 1.0, need_ranks ? a.pranksp[i] : 1.0,
-                                         need_ranks ? a.pranksr[i] : 1.0, kc);
+            int8_t kk;
+            if (a.prec) {
+                const PartRec &r = a.prec[i];
+                kk = sat_decide(p, pre, r.mass, r.weights, a.prandoms[i], r.deltac, r.fenv, p.want_ELG ? r.shear : 0.0,
+                                need_ranks ? r.ranks[0] : 1.0, need_ranks ? r.ranks[1] : 1.0, need_ranks ? r.ranks[2] : 1.0,
+                                need_ranks ? r.ranks[3] : 1.0, kc);
+            } else {
+                kk = sat_decide(p, pre, a.phmass[i], a.pweights[i], a.prandoms[i], load1(a.pdeltac, i, 0.0),
+                                load1(a.pfenv, i, 0.0), load1(sh_arr, i, 0.0), need_ranks ? a.pranks[i] : 1.0,
+                                need_ranks ? a.pranksv[i] : 1.0, need_ranks ? a.pranksp[i] : 1.0,
+                                need_ranks ? a.pranksr[i] : 1.0, kc);
+            }
             if (kk) {
                 a.keep_s[i] = kk;
                 const int ls = q * TILE + loc;
@@ -769,6 +833,8 @@ __device__ __forceinline__ int64_t wave_sum(int64_t v) {
 struct EmitPtrs {
     const double *hpos, *hvel, *hvdev, *hmass, *ppos, *pvel, *phvel, *phmass;
     const int64_t *hid, *phid;
+    const HaloRec *hrec;   // nullptr: gather from the columns
+    const PartRec *prec;
 };
 
 __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const unsigned short *__restrict__ kept_c,
@@ -837,7 +903,21 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
         const double al = t == 0 ? a0 : (t == 1 ? a1 : a2);
         double x, y, z, vx, vy, vz, m;
         int64_t id;
-        if (!sat) {
+        if (!sat && in.hrec) {
+            const HaloRec r = in.hrec[i];
+            x = r.pos[0], y = r.pos[1], z = r.pos[2];
+            vx = r.vel[0] + al * in.hvdev[3 * i];
+            vy = r.vel[1] + al * in.hvdev[3 * i + 1];
+            vz = r.vel[2] + al * in.hvdev[3 * i + 2];
+            m = r.mass, id = r.id;
+        } else if (sat && in.prec) {
+            const PartRec r = in.prec[i];
+            x = r.pos[0], y = r.pos[1], z = r.pos[2];
+            vx = r.hvel[0] + al * (r.vel[0] - r.hvel[0]);
+            vy = r.hvel[1] + al * (r.vel[1] - r.hvel[1]);
+            vz = r.hvel[2] + al * (r.vel[2] - r.hvel[2]);
+            m = r.mass, id = r.id;
+        } else if (!sat) {
             x = in.hpos[3 * i], y = in.hpos[3 * i + 1], z = in.hpos[3 * i + 2];
             vx = in.hvel[3 * i] + al * in.hvdev[3 * i];  // velocity bias (:301-305)
             vy = in.hvel[3 * i + 1] + al * in.hvdev[3 * i + 1];
@@ -1179,6 +1259,8 @@ struct abacus_hod_state {
     DevBuf shadow;
     FiltCols fc = {};
     bool shadow_ok = false, shadow_rand_ok = false;
+    DevBuf hrec, prec;          // emission records (owned catalogues)
+    bool rec_ok = false;
 };
 
 namespace {
@@ -1322,6 +1404,25 @@ OutCols out_cols(abacus_hod_state *st) {
     return o;
 }
 
+// packed records of an owned catalogue (static columns only), built once
+int build_records(abacus_hod_state *st) {
+    static const bool norec = getenv("ABACUS_HOD_NOREC") != nullptr;
+    if (!st->owns || norec || st->rec_ok) return 0;
+    ABACUS_TRY(st->hrec.reserve((size_t)std::max<int64_t>(st->nh, 1) * sizeof(HaloRec)));
+    ABACUS_TRY(st->prec.reserve((size_t)std::max<int64_t>(st->np, 1) * sizeof(PartRec)));
+    RecSrc c;
+    c.hpos = st->hpos, c.hvel = st->hvel, c.hmass = st->hmass, c.hmultis = st->hmultis, c.hdeltac = st->hdeltac,
+    c.hfenv = st->hfenv, c.hshear = st->hshear, c.hid = st->hid;
+    c.ppos = st->ppos, c.pvel = st->pvel, c.phvel = st->phvel, c.phmass = st->phmass, c.pweights = st->pweights,
+    c.pdeltac = st->pdeltac, c.pfenv = st->pfenv, c.pshear = st->pshear, c.phid = st->phid;
+    c.pranks[0] = st->pranks, c.pranks[1] = st->pranksv, c.pranks[2] = st->pranksp, c.pranks[3] = st->pranksr;
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(std::max(st->nh, st->np), 256), 1), 8192);
+    ABACUS_LAUNCH("hod_build_recs", hod_build_recs, dim3(grid), dim3(256), 0, st->nh, st->np, c, st->hrec.as<HaloRec>(),
+                  st->prec.as<PartRec>());
+    st->rec_ok = true;
+    return 0;
+}
+
 int launch_emit(abacus_hod_state *st) {
     const int nemit = st->nsb_c + st->nsb_s;
     if (nemit == 0) {
@@ -1331,6 +1432,8 @@ int launch_emit(abacus_hod_state *st) {
     EmitPtrs in;
     in.hpos = st->hpos, in.hvel = st->hvel, in.hvdev = st->hveldev, in.hmass = st->hmass, in.hid = st->hid;
     in.ppos = st->ppos, in.pvel = st->pvel, in.phvel = st->phvel, in.phmass = st->phmass, in.phid = st->phid;
+    in.hrec = st->rec_ok ? st->hrec.as<HaloRec>() : nullptr;
+    in.prec = st->rec_ok ? st->prec.as<PartRec>() : nullptr;
     ABACUS_LAUNCH("hod_emit", hod_emit, dim3(nemit), dim3(EBLOCK), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s,
                   st->sb_counts, st->d_totals, in, st->params, out_cols(st));
     return 0;
@@ -1660,6 +1763,9 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
                          (p->want_ELG && (p->E_Acent != 0 || p->E_Bcent != 0)) ||
                          (p->want_QSO && (p->Q_Acent != 0 || p->Q_Bcent != 0));
     const int need_shear = p->want_ELG && p->E_Ccent != 0 && st->hshear != nullptr;
+    ABACUS_TRY(build_records(st));
+    a.hrec = st->rec_ok ? st->hrec.as<HaloRec>() : nullptr;
+    a.prec = st->rec_ok ? st->prec.as<PartRec>() : nullptr;
     const bool conf = p->want_ELG && st->pinds != nullptr && st->ntile_s > 0;   // satellites read keep_cent[pinds]
     const int ntile = st->ntile_c + st->ntile_s, nsb = st->nsb_c + st->nsb_s;
     // owned catalogues: the filter streams the float32 shadow columns (half the bytes); caller-owned device arrays can
@@ -1819,6 +1925,7 @@ int abacus_hod_free(abacus_hod_state *st) {
     if (st->h_totals) (void)hipHostFree(st->h_totals);
     for (int t = 0; t < 3; t++) (void)st->out[t].release();
     (void)st->shadow.release();
+    (void)st->hrec.release(), (void)st->prec.release();
     delete st;
     return 0;
 }
