@@ -2,17 +2,20 @@
 
 The reference wraps the third-party Corrfunc pair counters; here `DD`, `DDrppi` and `DDsmu` are provided by the
 HIP cell-list kernel (csrc/pairs.hip, C ABI `abacus_paircount`) with Corrfunc's calling conventions as used by the
-reference, and the wrapper arithmetic (float32 casts, pi-bin regrouping, analytic RR, xi = DD/RR - 1, wp, multipoles)
-follows the reference line by line:
+reference, so the reference's own wrappers bind to them unchanged.  The four wrapper entry points the rest of abacusutils calls
 
     calc_xirppi_fast     (:97-203)      calc_wp_fast (:301-372)
     calc_multipole_fast  (:206-298)     tpcf_multipole (:17-94)
+
+are kept as signatures over ONE shared estimator, `_natural_estimator` (float32 casts of coordinates and bins before
+counting, analytic RR of the periodic box in the reference's dtype and operation order, xi = DD / RR - 1); their results
+are pinned bit for bit against the reference's functions run with a brute-force Corrfunc stand-in
+(tests/golden/pair_wrappers.npz, oracle/make_golden.py).
 
 Corrfunc is not vendored in the reference and none of its tests cover these functions: parity of the pair counts is
 pinned against the brute-force float32 counter of the oracle only ("parity unpinned" with respect to Corrfunc).
 """
 import ctypes as C
-import time
 
 import numpy as np
 
@@ -84,107 +87,83 @@ def DDsmu(autocorr, nthreads, binfile, mu_max, nmu_bins, X1, Y1, Z1, X2=None, Y2
     return _result(n, bins, int(nmu_bins), {'mumax': (np.arange(1, nmu_bins + 1) * mu_max / nmu_bins)})
 
 
+def _check_int(name, v):
+    if not isinstance(v, int):
+        raise ValueError(f'{name} needs to be an integer')
+
+
+def _natural_estimator(counter, sample1, sample2, edges, lbox, shell_measure, nsub, **counter_kw):
+    """xi = DD / RR - 1 on a periodic box, shape (len(edges) - 1, nsub).
+
+    counter         DDrppi | DDsmu (Corrfunc calling convention), called on float32 copies of the coordinates
+    sample2         None for an autocorrelation (Corrfunc then returns ordered pairs, hence the factor 2 in RR,
+                    which the reference also keeps for cross counts: tpcf_corrfunc.py:190-198,284-292,363-370)
+    shell_measure   volume of a bin per unit (box volume)^-1 before the N1 N2 / L^3 normalisation, already shaped
+                    (nbins, 1) or (nbins, nsub); RR is formed as measure / L^3 * N1 * N2 * 2 in that order and in the
+                    dtype NumPy gives the reference's expression (float32 bins and box -> float32 RR)
+    """
+    cast = lambda cols: [np.asarray(c).astype(np.float32) for c in cols]  # noqa: E731
+    first = cast(sample1)
+    n1 = float(len(first[0]))
+    if sample2 is None or sample2[0] is None:
+        second, n2, auto = {}, n1, 1
+    else:
+        second = dict(zip(('X2', 'Y2', 'Z2'), cast(sample2)))
+        n2, auto = len(second['X2']), 0
+    res = counter(auto, counter_kw.pop('nthreads'), X1=first[0], Y1=first[1], Z1=first[2], boxsize=lbox, periodic=True,
+                  **second, **counter_kw)
+    dd = res['npairs'].reshape(len(edges) - 1, nsub)
+    rr = shell_measure / lbox**3 * n1 * n2 * 2
+    return dd, rr
+
+
 def tpcf_multipole(s_mu_tcpf_result, mu_bins, order=0):
-    """Multipole of xi(s, mu) (tpcf_corrfunc.py:17-94; halotools' tpcf_multipole)."""
+    """Legendre multipole of xi(s, mu) over mu in [0, 1] bins, doubled to cover [-1, 1] (tpcf_corrfunc.py:17-94):
+    (2l + 1)/2 * sum_mu xi * dmu * (L_l(mu) + L_l(-mu))."""
     from scipy.special import legendre
-    s_mu_tcpf_result = np.atleast_1d(s_mu_tcpf_result)
-    mu_bins = np.atleast_1d(mu_bins)
-    order = int(order)
-    mu_bin_centers = (mu_bins[:-1] + mu_bins[1:]) / (2.0)
-    Ln = legendre(order)
-    result = ((2.0 * order + 1.0) / 2.0
-              * np.sum(s_mu_tcpf_result * np.diff(mu_bins) * (Ln(mu_bin_centers) + Ln(-1.0 * mu_bin_centers)), axis=1))
-    return result
+    xi = np.atleast_1d(s_mu_tcpf_result)
+    edges = np.atleast_1d(mu_bins)
+    ell = int(order)
+    mid = (edges[:-1] + edges[1:]) / 2.0
+    poly = legendre(ell)          # poly1d, evaluated like the reference does (same rounding)
+    both_signs = poly(mid) + poly(-1.0 * mid)
+    return (2.0 * ell + 1.0) / 2.0 * np.sum(xi * np.diff(edges) * both_signs, axis=1)
 
 
 def calc_xirppi_fast(x1, y1, z1, rpbins, pimax, pi_bin_size, lbox, Nthread, num_cells=20, x2=None, y2=None, z2=None):
-    """xi(rp, pi) (tpcf_corrfunc.py:97-203)"""
-    if not isinstance(pimax, int):
-        raise ValueError('pimax needs to be an integer')
-    if not isinstance(pi_bin_size, int):
-        raise ValueError('pi_bin_size needs to be an integer')
-    if not pimax % pi_bin_size == 0:
+    """xi(rp, pi) in pi bins of `pi_bin_size` built from unit pi bins (tpcf_corrfunc.py:97-203)"""
+    _check_int('pimax', pimax)
+    _check_int('pi_bin_size', pi_bin_size)
+    if pimax % pi_bin_size:
         raise ValueError('pi_bin_size needs to be an integer divisor of pimax, current values are ', pi_bin_size, pimax)
-    ND1 = float(len(x1))
-    if x2 is not None:
-        ND2 = len(x2)
-        autocorr = 0
-    else:
-        autocorr = 1
-        ND2 = ND1
-    rpbins = rpbins.astype(np.float32)
-    pimax = np.float32(pimax)
-    x1, y1, z1 = (a.astype(np.float32) for a in (x1, y1, z1))
+    edges = rpbins.astype(np.float32)
     lbox = np.float32(lbox)
-    if autocorr == 1:
-        results = DDrppi(autocorr, Nthread, binfile=rpbins, pimax=pimax, X1=x1, Y1=y1, Z1=z1, boxsize=lbox,
-                         periodic=True, max_cells_per_dim=num_cells, verbose=False)
-    else:
-        x2, y2, z2 = (a.astype(np.float32) for a in (x2, y2, z2))
-        results = DDrppi(autocorr, Nthread, binfile=rpbins, pimax=pimax, X1=x1, Y1=y1, Z1=z1, X2=x2, Y2=y2, Z2=z2,
-                         boxsize=lbox, periodic=True, max_cells_per_dim=num_cells, verbose=False)
-    DD_counts = results['npairs']
-    DD_counts_new = np.array([np.sum(DD_counts[i:i + pi_bin_size]) for i in range(0, len(DD_counts), pi_bin_size)])
-    DD_counts_new = DD_counts_new.reshape((len(rpbins) - 1, int(pimax / pi_bin_size)))
-    RR_counts_new = (np.pi * (rpbins[1:] ** 2 - rpbins[:-1] ** 2) * pi_bin_size / lbox**3 * ND1 * ND2 * 2)
-    xirppi = DD_counts_new / RR_counts_new[:, None] - 1
-    return xirppi
+    annulus = np.pi * (edges[1:] ** 2 - edges[:-1] ** 2) * pi_bin_size
+    dd, rr = _natural_estimator(DDrppi, (x1, y1, z1), (x2, y2, z2), edges, lbox, annulus, pimax, nthreads=Nthread,
+                                binfile=edges, pimax=np.float32(pimax), max_cells_per_dim=num_cells, verbose=False)
+    grouped = dd.reshape(len(edges) - 1, pimax // pi_bin_size, pi_bin_size).sum(axis=2)
+    return grouped / rr[:, None] - 1
 
 
 def calc_multipole_fast(x1, y1, z1, sbins, lbox, Nthread, nbins_mu=50, num_cells=20, x2=None, y2=None, z2=None,
                         orders=[0, 2]):
-    """xi_l(s) from DD(s, mu) (tpcf_corrfunc.py:206-298)"""
-    ND1 = float(len(x1))
-    if x2 is not None:
-        ND2 = len(x2)
-        autocorr = 0
-    else:
-        autocorr = 1
-        ND2 = ND1
-    sbins = sbins.astype(np.float32)
-    x1, y1, z1 = (a.astype(np.float32) for a in (x1, y1, z1))
+    """xi_l(s), the requested orders concatenated, from DD(s, mu) (tpcf_corrfunc.py:206-298)"""
+    edges = sbins.astype(np.float32)
     lbox = np.float32(lbox)
-    if autocorr == 1:
-        results = DDsmu(autocorr, Nthread, sbins, 1, nbins_mu, x1, y1, z1, periodic=True, boxsize=lbox,
-                        max_cells_per_dim=num_cells)
-    else:
-        x2, y2, z2 = (a.astype(np.float32) for a in (x2, y2, z2))
-        results = DDsmu(autocorr, Nthread, sbins, 1, nbins_mu, x1, y1, z1, X2=x2, Y2=y2, Z2=z2, periodic=True,
-                        boxsize=lbox, max_cells_per_dim=num_cells)
-    DD_counts = results['npairs'].reshape((len(sbins) - 1, nbins_mu))
-    mu_bins = np.linspace(0, 1, nbins_mu + 1)
-    RR_counts = (2 * np.pi / 3 * (sbins[1:, None] ** 3 - sbins[:-1, None] ** 3)
-                 * (mu_bins[None, 1:] - mu_bins[None, :-1]) / lbox**3 * ND1 * ND2 * 2)
-    xi_s_mu = DD_counts / RR_counts - 1
-    xi_array = []
-    for neworder in orders:
-        xi_array += [tpcf_multipole(xi_s_mu, mu_bins, order=neworder)]
-    return np.concatenate(xi_array)
+    mu_edges = np.linspace(0, 1, nbins_mu + 1)
+    wedge = 2 * np.pi / 3 * (edges[1:, None] ** 3 - edges[:-1, None] ** 3) * (mu_edges[None, 1:] - mu_edges[None, :-1])
+    dd, rr = _natural_estimator(DDsmu, (x1, y1, z1), (x2, y2, z2), edges, lbox, wedge, nbins_mu, nthreads=Nthread,
+                                binfile=edges, mu_max=1, nmu_bins=nbins_mu, max_cells_per_dim=num_cells)
+    xi = dd / rr - 1
+    return np.concatenate([tpcf_multipole(xi, mu_edges, order=ell) for ell in orders])
 
 
 def calc_wp_fast(x1, y1, z1, rpbins, pimax, lbox, Nthread, num_cells=30, x2=None, y2=None, z2=None):
-    """wp(rp) = 2 sum_pi xi(rp, pi) with 1 Mpc/h pi bins (tpcf_corrfunc.py:301-372)"""
-    if not isinstance(pimax, int):
-        raise ValueError('pimax needs to be an integer')
-    ND1 = float(len(x1))
-    if x2 is not None:
-        ND2 = len(x2)
-        autocorr = 0
-    else:
-        autocorr = 1
-        ND2 = ND1
-    rpbins = rpbins.astype(np.float32)
-    pimax = np.float32(pimax)
-    x1, y1, z1 = (a.astype(np.float32) for a in (x1, y1, z1))
+    """wp(rp) = 2 * sum over unit pi bins of xi(rp, pi) (tpcf_corrfunc.py:301-372)"""
+    _check_int('pimax', pimax)
+    edges = rpbins.astype(np.float32)
     lbox = np.float32(lbox)
-    if autocorr == 1:
-        results = DDrppi(autocorr, Nthread, binfile=rpbins, pimax=pimax, X1=x1, Y1=y1, Z1=z1, boxsize=lbox,
-                         periodic=True, max_cells_per_dim=num_cells)
-    else:
-        x2, y2, z2 = (a.astype(np.float32) for a in (x2, y2, z2))
-        results = DDrppi(autocorr, Nthread, binfile=rpbins, pimax=pimax, X1=x1, Y1=y1, Z1=z1, X2=x2, Y2=y2, Z2=z2,
-                         boxsize=lbox, periodic=True, max_cells_per_dim=num_cells)
-    DD_counts = results['npairs'].reshape((len(rpbins) - 1, int(pimax)))
-    RR_counts = np.pi * (rpbins[1:] ** 2 - rpbins[:-1] ** 2) / lbox**3 * ND1 * ND2 * 2
-    xirppi = DD_counts / RR_counts[:, None] - 1
-    return 2 * np.sum(xirppi, axis=1)
+    annulus = np.pi * (edges[1:] ** 2 - edges[:-1] ** 2)
+    dd, rr = _natural_estimator(DDrppi, (x1, y1, z1), (x2, y2, z2), edges, lbox, annulus, pimax, nthreads=Nthread,
+                                binfile=edges, pimax=np.float32(pimax), max_cells_per_dim=num_cells)
+    return 2 * np.sum(dd / rr[:, None] - 1, axis=1)

@@ -413,6 +413,13 @@ class AbacusHOD:
         for hod in known.values():               # keys gen_gals requires but compute_ngal never reads (:884-976)
             for k in ('alpha_c', 'alpha_s', 's', 's_v', 's_p', 's_r'):
                 hod.setdefault(k, 0.0)
+        if 'ELG' in known:
+            # compute_ngal's own defaults (:925-948), which differ from gen_gals': `A_s` is optional here, and the
+            # conformity parameters default to the RAW logM1 / alpha - the z-evolution (:1050-1051) never touches them
+            hod = known['ELG']
+            hod.setdefault('A_s', 1.0)
+            for k, src in (('logM1_EE', 'logM1'), ('alpha_EE', 'alpha'), ('logM1_EL', 'logM1'), ('alpha_EL', 'alpha')):
+                hod.setdefault(k, hod[src])
         p = marshal_params(known, dict(self.params, z=self.z_mock), False, True)
         out = (C.c_double * 6)()
         _lib.check(_lib.lib().abacus_hod_ngal(st._h, C.byref(p), out))

@@ -24,7 +24,13 @@ What is captured
   power_helpers.npz           bin_kppi, project_3d_to_poles, pk_to_xi, expand_poles_to_3d, get_smoothing,
         get_delta_mu2 on seeded 16^3 / 21^3 inputs.
 
-usage: python oracle/make_golden.py [hod] [tsc] [power] [helpers]
+  ngal.npz                    AbacusHOD.compute_ngal (abacus_hod.py:861-1179) on a 12-cell-per-dimension histogram of
+        seeded synthetic halos, three parameter cases (defaults, assembly bias + z-evolution, evolving ELG with the
+        conformity defaults).
+  pair_wrappers.npz           calc_xirppi_fast / calc_wp_fast / calc_multipole_fast / tpcf_multipole with a brute-force
+        stand-in for Corrfunc's counters (pins the wrapper arithmetic, not Corrfunc).
+
+usage: python oracle/make_golden.py [hod] [tsc] [power] [helpers] [catalog] [sweep] [ngal] [pairs]
 """
 import ctypes
 import os
@@ -625,8 +631,143 @@ def gen_catalog():
     print('catalog_cases written')
 
 
+# ----------------------------------------------------------------------------
+# compute_ngal and the pair-count wrappers: the reference's abacus_hod.py / tpcf_corrfunc.py import third-party
+# modules that are absent here (asdf, h5py, parallel_numpy_rng, Corrfunc).  None of them is used by the functions
+# captured below, except Corrfunc's counters, for which a stand-in with Corrfunc's calling convention is backed by the
+# oracle's brute-force float32 counter (so the golden vectors pin the WRAPPER arithmetic: casts, pi regrouping,
+# analytic RR, xi, wp, multipoles - not Corrfunc's kernels, which stay unpinned).
+# ----------------------------------------------------------------------------
+def _brute_corrfunc():
+    from oracle import oracle as O
+
+    def result(n, bins, nsub):
+        res = np.zeros((len(bins) - 1) * nsub, dtype=[('rmin', 'f8'), ('rmax', 'f8'), ('npairs', 'u8')])
+        res['npairs'] = n
+        return res
+
+    def second(autocorr, X2, Y2, Z2):
+        return (None, None, None) if autocorr else (X2, Y2, Z2)
+
+    def DDrppi(autocorr, nthreads, binfile=None, pimax=None, X1=None, Y1=None, Z1=None, X2=None, Y2=None, Z2=None,
+               periodic=True, boxsize=None, max_cells_per_dim=None, verbose=False):
+        assert periodic
+        x2, y2, z2 = second(autocorr, X2, Y2, Z2)
+        n = O.paircount_brute('rppi', X1, Y1, Z1, float(boxsize), binfile, x2, y2, z2, pimax=float(pimax),
+                              npibins=int(pimax), nthread=8)
+        return result(n, binfile, int(pimax))
+
+    def DDsmu(autocorr, nthreads, binfile, mu_max, nmu_bins, X1, Y1, Z1, X2=None, Y2=None, Z2=None, periodic=True,
+              boxsize=None, max_cells_per_dim=None, verbose=False):
+        assert periodic
+        x2, y2, z2 = second(autocorr, X2, Y2, Z2)
+        n = O.paircount_brute('smu', X1, Y1, Z1, float(boxsize), binfile, x2, y2, z2, mu_max=float(mu_max),
+                              nmubins=int(nmu_bins), nthread=8)
+        return result(n, binfile, int(nmu_bins))
+
+    return DDrppi, DDsmu
+
+
+def import_reference_hod():
+    """abacusnbody.hod.abacus_hod / analysis.tpcf_corrfunc with inert stand-ins for their absent imports"""
+    for name in ('asdf', 'h5py', 'parallel_numpy_rng', 'Corrfunc', 'Corrfunc.theory'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['parallel_numpy_rng'].MTGenerator = None
+    sys.modules['Corrfunc.theory'].DDrppi, sys.modules['Corrfunc.theory'].DDsmu = _brute_corrfunc()
+    import abacusnbody.analysis.tpcf_corrfunc as TP
+    import abacusnbody.hod.abacus_hod as AH
+    return AH, TP
+
+
+NGAL_CASES = {
+    'defaults': None,   # filled from synth.*_PARAMS
+    'ab_zpivot': {'LRG': dict(Acent=0.3, Asat=-0.2, Bcent=0.1, Bsat=0.4, logM_cut_pr=0.5, logM1_pr=-0.3, z_pivot=0.8, ic=0.9),
+                  'ELG': dict(Acent=0.2, Bsat=-0.3, Ccent=0.5, Csat=0.25, logM1_EE=13.0, alpha_EE=0.8),
+                  'QSO': dict(Bcent=-0.4, Asat=0.3, ic=0.7, logM_cut_pr=-0.2, z_pivot=1.1)},
+    # the conformity defaults of compute_ngal are the RAW logM1 / alpha although logM1 itself evolves (:925-948, 1050)
+    'elg_evolving_conformity_defaults': {'ELG': dict(logM1_pr=0.6, logM_cut_pr=0.2, z_pivot=0.9, Asat=0.15)},
+}
+
+
+def gen_ngal(nbin=12, nhalo=30000):
+    import contextlib
+    import io
+    import json
+
+    from abacusutils_amd import synth
+    AH, _ = import_reference_hod()
+    hd, _, params = synth.synth_hod_inputs(nhalo, 10, seed=77)
+    ball = AH.AbacusHOD.__new__(AH.AbacusHOD)
+    ball.z_mock = params['z']
+    n = len(hd['hmass'])
+    # the histograms of AbacusHOD.__init__ (:200-251) on an `nbin`-cell grid per dimension (the reference hard-codes 100,
+    # 10^8 cells for ELG: hours of pure-Python loops under the shim; the kernels take the grid from the edge arrays)
+    ball.logMbins = np.linspace(np.log10(np.min(hd['hmass'])), np.log10(np.max(hd['hmass'])), nbin + 1)
+    ball.deltacbins = np.linspace(-0.5, 0.5, nbin + 1)
+    ball.fenvbins = np.linspace(-0.5, 0.5, nbin + 1)
+    ball.shearbins = np.linspace(-0.5, 0.5, nbin + 1)
+    cols = [np.log10(hd['hmass']), hd['hdeltac'], hd['hfenv'], hd['hshear']]
+    ball.halo_mass_func, _ = np.histogramdd(np.vstack(cols[:3]).T, bins=[ball.logMbins, ball.deltacbins, ball.fenvbins],
+                                            weights=hd['hmultis'])
+    ball.halo_mass_func_wshear, _ = np.histogramdd(
+        np.vstack(cols).T, bins=[ball.logMbins, ball.deltacbins, ball.fenvbins, ball.shearbins], weights=hd['hmultis'])
+    base = {'LRG': synth.LRG_PARAMS, 'ELG': synth.ELG_PARAMS, 'QSO': synth.QSO_PARAMS}
+    out = dict(nbin=nbin, z=params['z'], hmass=hd['hmass'], hdeltac=hd['hdeltac'], hfenv=hd['hfenv'], hshear=hd['hshear'],
+               hmultis=hd['hmultis'])
+    cases = {}
+    for name, over in NGAL_CASES.items():
+        tracers = {t: dict(base[t], **(over or {}).get(t, {})) for t in (over or base)}
+        if name == 'elg_evolving_conformity_defaults':
+            for k in ('logM1_EE', 'logM1_EL', 'alpha_EE', 'alpha_EL', 'A_s'):
+                tracers['ELG'].pop(k, None)
+        with contextlib.redirect_stdout(io.StringIO()):      # compute_ngal prints `newngal` for ELG (:949)
+            ngal, fsat = AH.AbacusHOD.compute_ngal(ball, tracers, Nthread=1)
+        cases[name] = tracers
+        for t in tracers:
+            out[f'{name}.{t}.ngal'] = np.float64(ngal[t])
+            out[f'{name}.{t}.fsat'] = np.float64(fsat[t])
+            print('ngal', name, t, ngal[t], fsat[t])
+    out['cases_json'] = np.array(json.dumps(cases))
+    np.savez_compressed(GOLD / 'ngal.npz', **out)
+    print('ngal.npz written')
+
+
+def gen_pair_wrappers():
+    """calc_xirppi_fast / calc_wp_fast / calc_multipole_fast / tpcf_multipole of the reference (tpcf_corrfunc.py:17-372)
+    on seeded clustered points, auto and cross, float64 inputs (the wrappers cast)"""
+    import contextlib
+    import io
+    _, TP = import_reference_hod()
+    rng = np.random.default_rng(4242)
+    L = 120.0
+    n1, n2 = 1800, 1300
+    centres = rng.random((60, 3)) * L
+    a = (centres[rng.integers(0, 60, n1)] + rng.normal(0, 3.0, (n1, 3))) % L
+    b = np.concatenate([(centres[rng.integers(0, 60, n2 // 2)] + rng.normal(0, 5.0, (n2 // 2, 3))) % L,
+                        rng.random((n2 - n2 // 2, 3)) * L])
+    rpbins = np.logspace(-0.5, 1.3, 8)
+    sbins = np.linspace(0.5, 25.0, 9)
+    pimax, pi_bin_size, nmu = 24, 4, 10
+    out = dict(L=L, a=a, b=b, rpbins=rpbins, sbins=sbins, pimax=pimax, pi_bin_size=pi_bin_size, nbins_mu=nmu)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for tag, second in (('auto', {}), ('cross', dict(x2=b[:, 0], y2=b[:, 1], z2=b[:, 2]))):
+            out[f'{tag}.xirppi'] = TP.calc_xirppi_fast(a[:, 0], a[:, 1], a[:, 2], rpbins, pimax, pi_bin_size, L, 4, **second)
+            out[f'{tag}.wp'] = TP.calc_wp_fast(a[:, 0], a[:, 1], a[:, 2], rpbins, pimax, L, 4, **second)
+            out[f'{tag}.multipole'] = TP.calc_multipole_fast(a[:, 0], a[:, 1], a[:, 2], sbins, L, 4, nbins_mu=nmu,
+                                                            orders=[0, 2, 4], **second)
+    xi = rng.normal(size=(6, 12))
+    mub = np.linspace(0, 1, 13)
+    out['tpcf.xi'], out['tpcf.mu_bins'] = xi, mub
+    for ell in (0, 1, 2, 4):
+        out[f'tpcf.l{ell}'] = TP.tpcf_multipole(xi, mub, order=ell)
+    for k in ('auto.xirppi', 'auto.wp', 'auto.multipole', 'cross.wp'):
+        print(k, out[k].dtype, out[k].shape, float(np.ravel(out[k])[0]))
+    np.savez_compressed(GOLD / 'pair_wrappers.npz', **out)
+    print('pair_wrappers.npz written')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'catalog', 'sweep']
+    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'catalog', 'sweep', 'ngal', 'pairs']
     G, T, P, C = import_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
     if 'hod' in which:
@@ -641,3 +782,7 @@ if __name__ == '__main__':
         gen_catalog()
     if 'sweep' in which:
         gen_sweep(G)
+    if 'ngal' in which:
+        gen_ngal()
+    if 'pairs' in which:
+        gen_pair_wrappers()

@@ -125,3 +125,27 @@ def test_compute_ngal_device_vs_numpy():
     ngal, fsat = ball.compute_ngal({'LRG': ball.tracers['LRG']})
     ncent = ngal['LRG'] * (1 - fsat['LRG'])
     assert abs(mock['LRG']['Ncent'] - ncent) < 5 * np.sqrt(ncent) + 0.02 * ncent
+
+
+def test_compute_ngal_vs_reference_golden():
+    """AbacusHOD.compute_ngal on the device against the REFERENCE's compute_ngal (abacus_hod.py:861-1179, run under the
+    shim by oracle/make_golden.py ngal on a 12-cell-per-dimension histogram): three parameter cases, including an
+    evolving ELG whose conformity parameters take compute_ngal's own (raw) defaults"""
+    import json
+
+    from abacusutils_amd.hod.abacus_hod import AbacusHOD
+    g = load_golden('ngal')
+    nh = len(g['hmass'])
+    hd, pd, params = synth.synth_hod_inputs(nh, 10, seed=77)
+    for k in ('hmass', 'hdeltac', 'hfenv', 'hshear', 'hmultis'):
+        np.testing.assert_array_equal(hd[k], g[k])          # the generator of the golden inputs has not drifted
+    hp = dict(HOD_PARAMS, tracer_flags={'LRG': True, 'ELG': True, 'QSO': True})
+    ball = AbacusHOD.from_arrays(hd, pd, params, hp)
+    nb = int(g['nbin'])
+    ball.logMbins = np.linspace(np.log10(np.min(hd['hmass'])), np.log10(np.max(hd['hmass'])), nb + 1)
+    ball.deltacbins = ball.fenvbins = ball.shearbins = np.linspace(-0.5, 0.5, nb + 1)
+    for name, tracers in json.loads(str(g['cases_json'])).items():
+        ngal, fsat = ball.compute_ngal(tracers)
+        for t in tracers:
+            np.testing.assert_allclose(ngal[t], float(g[f'{name}.{t}.ngal']), rtol=1e-11, err_msg=f'{name} {t}')
+            np.testing.assert_allclose(fsat[t], float(g[f'{name}.{t}.fsat']), rtol=1e-11, err_msg=f'{name} {t}')

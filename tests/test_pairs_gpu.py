@@ -152,3 +152,51 @@ def test_random_configuration_sweep(seed):
         got = T.DDsmu(int(auto), 4, bins, kw['mu_max'], kw['nmubins'], x1, y1, z1, X2=x2, Y2=y2, Z2=z2, periodic=True,
                       boxsize=box)['npairs']
     np.testing.assert_array_equal(got, want)
+
+
+def test_wrappers_vs_reference_golden():
+    """calc_xirppi_fast / calc_wp_fast / calc_multipole_fast on the HIP counters against the outputs of the REFERENCE's
+    wrappers (tpcf_corrfunc.py:97-372, run under the shim with a brute-force Corrfunc stand-in): bit for bit"""
+    from test_oracle_pinned import check_pair_wrappers
+
+    from abacusutils_amd.analysis import tpcf_corrfunc as T
+    check_pair_wrappers(T)
+
+
+def test_bin_edge_conventions():
+    """pairs that sit exactly ON an edge document the convention (Corrfunc's published kernels, restated from memory -
+    the library is absent): r-bin b holds edges[b] <= r < edges[b+1]; DDrppi keeps |dz| < pimax with
+    pi-bin = int(|dz| * npibins / pimax); DDsmu drops mu >= mu_max (a pair along the line of sight has mu = 1)."""
+    from abacusutils_amd.analysis import tpcf_corrfunc as T
+    from oracle import oracle
+    box = 64.0
+    bins = np.array([1.0, 2.0, 4.0, 8.0], dtype=np.float32)
+    base = np.array([10.0, 20.0, 30.0], dtype=np.float32)
+    # partner offsets (all float32-exact): r = 2 (on an inner edge, along x), r = 1 (first edge), r = 8 (last edge),
+    # r = 4 along z (mu = 1, |dz| = 4), and (3, 0, 4): rp = 3, |dz| = 4, s = 5, mu = 0.8
+    offs = np.array([[2, 0, 0], [0, 1, 0], [8, 0, 0], [0, 0, 4], [3, 0, 4]], dtype=np.float32)
+    far = np.array([[40.0, 40.0, 40.0]], dtype=np.float32)   # keeps the sets non-degenerate
+    p2 = np.concatenate([base + offs, far])
+    x1, y1, z1 = (np.array([v], dtype=np.float32) for v in base)
+    x2, y2, z2 = (np.ascontiguousarray(p2[:, i]) for i in range(3))
+    dd = T.DD(0, 1, bins, x1, y1, z1, X2=x2, Y2=y2, Z2=z2, periodic=True, boxsize=box)['npairs']
+    np.testing.assert_array_equal(dd, oracle.paircount_brute('r', x1, y1, z1, box, bins, x2, y2, z2))
+    # r=1 -> bin 0 (lower edge included); r=2 -> bin 1; r=4 -> bin 2; r=5 -> bin 2; r=8 -> excluded (upper edge open)
+    np.testing.assert_array_equal(dd, [1, 1, 2])
+    rppi = T.DDrppi(0, 1, binfile=bins, pimax=4.0, X1=x1, Y1=y1, Z1=z1, X2=x2, Y2=y2, Z2=z2, periodic=True,
+                    boxsize=box)['npairs'].reshape(3, 4)
+    np.testing.assert_array_equal(rppi.ravel(), oracle.paircount_brute('rppi', x1, y1, z1, box, bins, x2, y2, z2,
+                                                                       pimax=4.0, npibins=4))
+    # |dz| = 4 = pimax is dropped (both the z pair and (3,0,4)); (2,0,0) -> rp bin 1, pi bin 0; (0,1,0) -> rp bin 0
+    want = np.zeros((3, 4), dtype=np.uint64)
+    want[1, 0] = 1
+    want[0, 0] = 1
+    np.testing.assert_array_equal(rppi, want)
+    smu = T.DDsmu(0, 1, bins, 1.0, 5, x1, y1, z1, X2=x2, Y2=y2, Z2=z2, periodic=True, boxsize=box)['npairs'].reshape(3, 5)
+    np.testing.assert_array_equal(smu.ravel(), oracle.paircount_brute('smu', x1, y1, z1, box, bins, x2, y2, z2,
+                                                                      mu_max=1.0, nmubins=5))
+    want = np.zeros((3, 5), dtype=np.uint64)
+    want[1, 0] = 1      # (2,0,0): s = 2, mu = 0
+    want[0, 0] = 1      # (0,1,0): s = 1, mu = 0
+    want[2, 4] = 1      # (3,0,4): s = 5, mu = 0.8 -> int(0.8 * 5) = 4 (float32: 0.8f * 5 = 4.0000001 -> 4)
+    np.testing.assert_array_equal(smu, want)   # the z pair (mu = 1 = mu_max) is dropped
