@@ -1486,22 +1486,18 @@ int build_shadows(abacus_hod_state *st, bool rand_only) {
 
 }  // namespace
 
-extern "C" {
+__global__ void hod_check_pinds(const int64_t *__restrict__ pinds, int64_t np, int64_t nh, int *__restrict__ flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t h = pinds[i];
+        bad = bad || h < 0 || h >= nh;
+    }
+    if (bad) *flag = 1;
+}
 
-int abacus_hod_stage(const abacus_hod_arrays *a, int on_device, abacus_hod_state **out) {
-    ABACUS_ENTER();
-    if (!a || !out) return fail("abacus_hod_stage: null argument");
-    if (a->n_halo < 0 || a->n_part < 0) return fail("abacus_hod_stage: negative length");
-    if (a->n_halo > 0 && (!a->hpos || !a->hvel || !a->hmass || !a->hid || !a->hmultis || !a->hrandoms || !a->hveldev))
-        return fail("abacus_hod_stage: a required halo array is NULL");
-    if (a->n_part > 0 && (!a->ppos || !a->pvel || !a->phvel || !a->phmass || !a->phid || !a->pweights || !a->prandoms))
-        return fail("abacus_hod_stage: a required particle array is NULL");
-    if (a->n_halo >= ((int64_t)1 << 32) || a->n_part >= ((int64_t)1 << 32))
-        return fail("abacus_hod_stage: too many objects for one device");
-    auto *st = new abacus_hod_state();
-    st->nh = a->n_halo;
-    st->np = a->n_part;
-    st->owns = !on_device;
+// uploads / adopts the arrays and allocates the work buffers of a freshly constructed state; on failure the caller
+// frees whatever was allocated so far (abacus_hod_free is null-safe for every member)
+static int stage_fill(abacus_hod_state *st, const abacus_hod_arrays *a, int on_device) {
     const bool d = on_device != 0;
     const int64_t nh = st->nh, np = st->np;
 #define UP(field, n) ABACUS_TRY(upload(st->field, a->field, n, d))
@@ -1528,12 +1524,48 @@ int abacus_hod_stage(const abacus_hod_arrays *a, int on_device, abacus_hod_state
     HIP_TRY(hipHostMalloc((void **)&st->h_totals, 8 * sizeof(int64_t), hipHostMallocDefault));
     // first guess for the catalog buffers; grown on demand by abacus_hod_counts
     for (int t = 0; t < 3; t++) ABACUS_TRY(set_capacity(st, t, (nh + np) / 64));
+    if (st->pinds && st->np > 0) {   // keep_c[pinds[i]] is read unchecked by the kernels: reject a stale / out-of-range index here
+        int *flag = (int *)st->d_totals;   // scratch, rewritten by every populate
+        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), stream()));
+        ABACUS_LAUNCH("hod_check_pinds", hod_check_pinds, dim3((unsigned)std::min<int64_t>(ceil_div(st->np, 256), 4096)), dim3(256), 0,
+                      st->pinds, st->np, st->nh, flag);
+        int bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        if (bad) return fail("abacus_hod_stage: pinds holds a host index outside [0, %lld) (stale after sub-selecting the halos?)", (long long)st->nh);
+    }
     HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+extern "C" {
+
+int abacus_hod_stage(const abacus_hod_arrays *a, int on_device, abacus_hod_state **out) {
+    ABACUS_ENTER();
+    if (!a || !out) return fail("abacus_hod_stage: null argument");
+    if (a->n_halo < 0 || a->n_part < 0) return fail("abacus_hod_stage: negative length");
+    if (a->n_halo > 0 && (!a->hpos || !a->hvel || !a->hmass || !a->hid || !a->hmultis || !a->hrandoms || !a->hveldev))
+        return fail("abacus_hod_stage: a required halo array is NULL");
+    if (a->n_part > 0 && (!a->ppos || !a->pvel || !a->phvel || !a->phmass || !a->phid || !a->pweights || !a->prandoms))
+        return fail("abacus_hod_stage: a required particle array is NULL");
+    if (a->n_halo >= ((int64_t)1 << 32) || a->n_part >= ((int64_t)1 << 32))
+        return fail("abacus_hod_stage: too many objects for one device");
+    auto *st = new abacus_hod_state();
+    st->nh = a->n_halo;
+    st->np = a->n_part;
+    st->owns = !on_device;
+    const int rc = stage_fill(st, a, on_device);
+    if (rc != 0) {   // e.g. out of HBM half-way through: nothing of the partial state may leak (a retry with a smaller chunk must fit)
+        const std::string msg = abacus_last_error();
+        (void)abacus_hod_free(st);
+        return fail("%s", msg.c_str());
+    }
     *out = st;
     return 0;
 }
 
 int abacus_hod_update(abacus_hod_state *st, const char *field, const double *host) {
+    ABACUS_ENTER();
     if (!st || !field || !host) return fail("abacus_hod_update: null argument");
     double *dst = nullptr;
     int64_t n = 0;
@@ -1586,6 +1618,7 @@ int abacus_hod_reseed(abacus_hod_state *st, uint64_t seed, int want_expvel, int6
 }
 
 int abacus_hod_fetch_field(abacus_hod_state *st, const char *field, double *host) {
+    ABACUS_ENTER();
     if (!st || !field || !host) return fail("abacus_hod_fetch_field: null argument");
     const double *src = nullptr;
     int64_t n = 0;
@@ -1829,6 +1862,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
 }
 
 int abacus_hod_counts(abacus_hod_state *st, int64_t counts[6]) {
+    ABACUS_ENTER();
     if (!st || !st->have_run) return fail("abacus_hod_counts: populate has not been called");
     if (!st->counts_valid) {
         HIP_TRY(hipStreamSynchronize(stream()));
@@ -1853,12 +1887,14 @@ int abacus_hod_counts(abacus_hod_state *st, int64_t counts[6]) {
 }
 
 int abacus_hod_populate(abacus_hod_state *st, const abacus_hod_params *p, int64_t counts[6]) {
+    ABACUS_ENTER();
     ABACUS_TRY(abacus_hod_populate_async(st, p));
     return abacus_hod_counts(st, counts);
 }
 
 int abacus_hod_fetch(abacus_hod_state *st, int tracer, double *x, double *y, double *z, double *vx, double *vy,
                      double *vz, double *mass, int64_t *id) {
+    ABACUS_ENTER();
     if (tracer < 0 || tracer > 2) return fail("abacus_hod_fetch: tracer %d out of range", tracer);
     ABACUS_TRY(abacus_hod_counts(st, nullptr));
     const int64_t n = st->counts[tracer] + st->counts[3 + tracer];
@@ -1873,6 +1909,7 @@ int abacus_hod_fetch(abacus_hod_state *st, int tracer, double *x, double *y, dou
 }
 
 int abacus_hod_fetch_block(abacus_hod_state *st, int tracer, void *out8, int64_t n_expected) {
+    ABACUS_ENTER();
     if (tracer < 0 || tracer > 2) return fail("abacus_hod_fetch_block: tracer %d out of range", tracer);
     if (!out8) return fail("abacus_hod_fetch_block: null output");
     ABACUS_TRY(abacus_hod_counts(st, nullptr));
@@ -1887,6 +1924,7 @@ int abacus_hod_fetch_block(abacus_hod_state *st, int tracer, void *out8, int64_t
 }
 
 int abacus_hod_device_columns(abacus_hod_state *st, int tracer, void *cols[8]) {
+    ABACUS_ENTER();
     if (tracer < 0 || tracer > 2) return fail("abacus_hod_device_columns: tracer %d out of range", tracer);
     ABACUS_TRY(abacus_hod_counts(st, nullptr));
     OutCols o = out_cols(st);
@@ -1896,6 +1934,7 @@ int abacus_hod_device_columns(abacus_hod_state *st, int tracer, void *cols[8]) {
 }
 
 int abacus_hod_fetch_keep(abacus_hod_state *st, int8_t *keep_cent, int8_t *keep_sat) {
+    ABACUS_ENTER();
     if (!st || !st->have_run) return fail("abacus_hod_fetch_keep: populate has not been called");
     if (keep_cent && st->nh) HIP_TRY(hipMemcpyAsync(keep_cent, st->keep_c, st->nh, hipMemcpyDeviceToHost, stream()));
     if (keep_sat && st->np) HIP_TRY(hipMemcpyAsync(keep_sat, st->keep_s, st->np, hipMemcpyDeviceToHost, stream()));
@@ -1905,6 +1944,7 @@ int abacus_hod_fetch_keep(abacus_hod_state *st, int8_t *keep_cent, int8_t *keep_
 
 int abacus_hod_free(abacus_hod_state *st) {
     if (!st) return 0;
+    std::lock_guard<std::recursive_mutex> guard(::abacus::api_mutex());
     (void)hipStreamSynchronize(stream());
     if (st->owns) {
         void *ptrs[] = {st->hpos, st->hvel, st->hmass, st->hid, st->hmultis, st->hrandoms, st->hveldev, st->hdeltac,

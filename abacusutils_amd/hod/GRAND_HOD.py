@@ -89,9 +89,18 @@ class StagedCatalog:
         arrs = HodArrays()
         keep = []  # host copies must outlive the upload call
 
+        vec3 = ('hpos', 'hvel', 'hveldev', 'ppos', 'pvel', 'phvel')
+
         def put(name, src, dtype, required):
             if name in src and src[name] is not None:
                 a = _as(src[name], dtype)
+                n = self.n_halo if name.startswith('h') else self.n_part
+                if name == 'hveldev' and a.ndim == 1 and a.shape == (n,):
+                    a = np.ascontiguousarray(np.repeat(a[:, None], 3, axis=1))   # the scalar form `reseed` accepts (:826-829)
+                # a short array would be read past its end by the upload (the reference raises IndexError in its loops)
+                want = (n, 3) if name in vec3 else (n,)
+                if a.shape != want:
+                    raise ValueError(f'{name} has shape {a.shape}, expected {want} (n_halo={self.n_halo}, n_part={self.n_part})')
                 keep.append(a)
                 setattr(arrs, name, a.ctypes.data)
             elif required:
@@ -108,9 +117,6 @@ class StagedCatalog:
                 put(k, particle_data, np.int64 if k == 'phid' else np.float64, True)
             for k in _PART_OPT:
                 put(k, particle_data, np.int64 if k == 'pinds' else np.float64, False)
-        hv = halo_data['hveldev']
-        if np.ndim(hv) != 2:
-            raise ValueError('hveldev must have shape (N, 3)')
         check(_lib.lib().abacus_hod_stage(C.byref(arrs), 0, C.byref(self._h)))
         self.has_ranks = all(k in particle_data for k in ('pranks', 'pranksv', 'pranksp', 'pranksr'))
         self.counts = None

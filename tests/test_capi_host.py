@@ -127,3 +127,20 @@ def test_async_load_kernels_do_not_spill(tmp_path):
                 found += 1
                 assert spills == 0, (name, spills)
         assert found >= len(names)
+
+
+def test_staged_catalog_rejects_wrong_shapes():
+    """a short or mis-shaped array would be read past its end by the upload: StagedCatalog refuses it before any
+    library call (no GPU needed); a 1-D hveldev (the scalar form reseed accepts, hod/abacus_hod.py:826-829) is tiled"""
+    from abacusutils_amd import synth
+    from abacusutils_amd.hod.GRAND_HOD import StagedCatalog
+    hd, pd, _ = synth.synth_hod_inputs(50, 80, seed=3)
+    bad = dict(hd, hmultis=hd['hmultis'][:-1])
+    with pytest.raises(ValueError, match='hmultis has shape'):
+        StagedCatalog(bad, pd)
+    bad = dict(pd, ppos=pd['ppos'][:, :2])
+    with pytest.raises(ValueError, match='ppos has shape'):
+        StagedCatalog(hd, bad)
+    bad = dict(hd, hveldev=hd['hveldev'][:10, 0])
+    with pytest.raises(ValueError, match='hveldev has shape'):
+        StagedCatalog(bad, pd)

@@ -217,3 +217,20 @@ def test_random_parameter_sweep_bit_exact(G, seed):
     assert sum(len(m['x']) for m in want.values()) > 0
     assert_mock_equal(mock, want, exact=True)
     st.free()
+
+
+def test_stale_pinds_rejected_at_staging():
+    """keep_cent[pinds] is gathered on the device: an index outside [0, n_halo) (pinds kept after sub-selecting the
+    halos) is refused when the catalogue is staged, with nothing leaked (a second staging of the same size works)"""
+    from abacusutils_amd import _lib, synth
+    from abacusutils_amd.hod.GRAND_HOD import StagedCatalog
+    hd, pd, _ = synth.synth_hod_inputs(5000, 8000, seed=9)
+    bad = dict(pd, pinds=pd['pinds'].copy())
+    bad['pinds'][1234] = 5000
+    with pytest.raises(_lib.AbacusHipError, match='pinds'):
+        StagedCatalog(hd, bad)
+    bad['pinds'][1234] = -1
+    with pytest.raises(_lib.AbacusHipError, match='pinds'):
+        StagedCatalog(hd, bad)
+    st = StagedCatalog(hd, pd)
+    st.free()
