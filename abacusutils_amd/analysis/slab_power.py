@@ -17,10 +17,11 @@ slab (`route_particles` moves them there).  Per field:
     binning           raw (k, mu) / multipole sums of the y-slab                             [device]
     all-reduce        of the few-KB histogram, then bin_kmu's normalisation                  [RCCL all-reduce]
 
-Collectives go through torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests); the device
-buffers are exposed to torch through `__cuda_array_interface__`, so RCCL works on the library's own allocations
-without staging.  `SlabComm(..., device_collectives=False)` stages through host memory instead (gloo): used for
-tests, including two ranks sharing one GPU.
+Collectives: `abacusutils_amd.comm.RcclComm` - RCCL through the C ABI (abacus_comm_*), enqueued on the library stream
+between the kernels, no host synchronisation inside a spectrum; the pencil transpose is cut into chunks of x-planes and
+every chunk's all-to-all runs on the communicator's stream while the next chunk's z / y passes run.  `SlabComm` below is
+the host-staged stand-in with the same methods over torch.distributed gloo: TEST infrastructure (CPU container, or
+several ranks sharing one GPU), never the multi-GPU path.
 Restrictions: nmesh a power of two in [64, 2048] (hand-written FFT passes), nmesh % W == 0, nmesh/W >= GHOST.
 """
 import ctypes as C
@@ -51,16 +52,6 @@ class HipBuf:
     def set(self, off, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         _lib.check(_lib.lib().abacus_memcpy_h2d(self.ptr(off), _lib.ptr(arr), C.c_uint64(arr.nbytes)))
-
-    def torch_view(self, off, n):
-        import torch
-
-        class _View:
-            pass
-        v = _View()
-        v.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f4', 'data': (self.dev.ptr.value + 4 * int(off), False),
-                                      'version': 2, 'strides': None}
-        return torch.as_tensor(v, device='cuda')
 
     def free(self):
         self.dev.free()
@@ -114,8 +105,9 @@ class HipSlabBackend:
     def fft_zy(self, mesh, off, nmesh, nxl):
         _lib.check(_lib.lib().abacus_slab_fft_zy_dev(mesh.ptr(off), int(nmesh), int(nxl)))
 
-    def pack(self, mesh, off, send, nmesh, nxl, world):
-        _lib.check(_lib.lib().abacus_slab_pack_dev(mesh.ptr(off), send.ptr(0), int(nmesh), int(nxl), int(world)))
+    def pack(self, mesh, off, send, nmesh, nxl, world, x0=0, nxc=None):
+        _lib.check(_lib.lib().abacus_slab_pack_dev(mesh.ptr(off), send.ptr(0), int(nmesh), int(nxl), int(world), int(x0),
+                                                   int(nxl if nxc is None else nxc)))
 
     def unpack(self, recv, out, off, nmesh, nxl, world):
         _lib.check(_lib.lib().abacus_slab_unpack_dev(recv.ptr(0), out.ptr(off), int(nmesh), int(nxl), int(world)))
@@ -157,13 +149,13 @@ def finalize_raw(raw, Lbox, Nk, Nmu, poles):
 
 
 class SlabComm:
-    """ring send/recv, all-to-all and all-reduce over torch.distributed (or trivially for a single rank)"""
+    """HOST-STAGED stand-in for `abacusutils_amd.comm.RcclComm` over torch.distributed (gloo): the transport of the CPU
+    tests (world 2 / 4 with the NumPy device stand-in) and of several ranks sharing ONE GPU.  Same methods; mesh-sized
+    exchanges are copied to the host, exchanged and copied back."""
 
-    def __init__(self, device_collectives=False, group=None, force_collectives=False, host_group=None):
-        """device_collectives: mesh-sized exchanges run on device tensors (RCCL; the process group must be `nccl`) instead
-        of being staged through the host.  Small host-side messages (histograms, counts, particle routing) always go
-        through a gloo group, created here when the default backend cannot move CPU tensors.
-        force_collectives: run the collectives even with a single rank (tests of the transport on one GPU)."""
+    device = False
+
+    def __init__(self, group=None, force_collectives=False):
         self.dist = None
         self.rank, self.world = 0, 1
         try:
@@ -174,18 +166,21 @@ class SlabComm:
         except ImportError:
             pass
         self.group = group
-        self.hgroup = host_group if host_group is not None else group
         self.collective = self.dist is not None and (self.world > 1 or bool(force_collectives))
-        self.device = bool(device_collectives) and self.collective
-        if self.collective and host_group is None and self.dist.get_backend(group) != 'gloo':
-            self.hgroup = self.dist.new_group(backend='gloo')   # collective call: every rank constructs its SlabComm
 
-    def _tensor(self, buf, off, n):
-        import torch
-        if self.device:
-            return buf.torch_view(off, n), None
-        host = buf.get(off, n)
-        return torch.from_numpy(host), host
+    def _pairwise(self, ins, outs):
+        """ins[p] -> rank p, outs[p] <- rank p (host tensors; gloo has no all_to_all)"""
+        reqs = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                outs[peer].copy_(ins[peer])
+            else:
+                if ins[peer].numel():
+                    reqs.append(self.dist.isend(ins[peer].contiguous(), peer, group=self.group))
+                if outs[peer].numel():
+                    reqs.append(self.dist.irecv(outs[peer], peer, group=self.group))
+        for q in reqs:
+            q.wait()
 
     def ring_exchange(self, backend, buf, left_off, right_off, recv, n):
         """send buf[left_off:+n] to rank-1 and buf[right_off:+n] to rank+1;
@@ -195,14 +190,10 @@ class SlabComm:
         import torch
         backend.sync()
         left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
-        s_l, _ = self._tensor(buf, left_off, n)
-        s_r, _ = self._tensor(buf, right_off, n)
-        if self.device:
-            r_from_right, r_from_left = recv.torch_view(0, n), recv.torch_view(n, n)
-        else:
-            r_from_right = torch.empty(n, dtype=torch.float32)
-            r_from_left = torch.empty(n, dtype=torch.float32)
-        if left == self.rank:   # one rank: its own ghosts come back (no transport can send to itself portably)
+        s_l, s_r = torch.from_numpy(buf.get(left_off, n)), torch.from_numpy(buf.get(right_off, n))
+        r_from_right = torch.empty(n, dtype=torch.float32)
+        r_from_left = torch.empty(n, dtype=torch.float32)
+        if left == self.rank:   # one rank: its own ghosts come back
             r_from_right.copy_(s_l)
             r_from_left.copy_(s_r)
         else:
@@ -212,41 +203,28 @@ class SlabComm:
                    self.dist.P2POp(self.dist.irecv, r_from_left, left, self.group)]
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()
-        if self.device:
-            torch.cuda.synchronize()
-        else:
-            recv.set(0, r_from_right.numpy())
-            recv.set(n, r_from_left.numpy())
+        recv.set(0, r_from_right.numpy())
+        recv.set(n, r_from_left.numpy())
 
     def all_to_all(self, backend, send, recv, n_total):
+        self.all_to_all_piece(backend, send, recv, n_total // self.world, 0, n_total // self.world)
+
+    def all_to_all_piece(self, backend, send, recv, peer_stride, offset, n, overlap=False):
         if not self.collective:   # callers unpack straight from the send buffer
             raise RuntimeError('all_to_all needs an initialised process group')
         import torch
         backend.sync()
-        s, _ = self._tensor(send, 0, n_total)
-        if self.device:
-            r = recv.torch_view(0, n_total)
-            self.dist.all_to_all_single(r, s, group=self.group)
-            torch.cuda.synchronize()
-        else:
-            r = torch.empty(n_total, dtype=torch.float32)
-            if self.dist.get_backend(self.group) == 'gloo':
-                # gloo has no all_to_all_single: W scatter rounds of equal blocks
-                blk = n_total // self.world
-                outs = list(r.split(blk))
-                ins = list(s.split(blk))
-                reqs = []
-                for peer in range(self.world):
-                    if peer == self.rank:
-                        outs[peer].copy_(ins[peer])
-                    else:
-                        reqs.append(self.dist.isend(ins[peer].contiguous(), peer, group=self.group))
-                        reqs.append(self.dist.irecv(outs[peer], peer, group=self.group))
-                for q in reqs:
-                    q.wait()
-            else:
-                self.dist.all_to_all_single(r, s, group=self.group)
-            recv.set(0, r.numpy())
+        ins = [torch.from_numpy(send.get(p * peer_stride + offset, n)) for p in range(self.world)]
+        outs = [torch.empty(n, dtype=torch.float32) for _ in range(self.world)]
+        self._pairwise(ins, outs)
+        for p in range(self.world):
+            recv.set(p * peer_stride + offset, outs[p].numpy())
+
+    def join(self):
+        pass
+
+    def transpose_chunks(self, nxl):
+        return 2 if (self.collective and nxl % 2 == 0 and nxl >= 4) else 1   # the chunked code path, in the CPU tests too
 
     def all_reduce_raw(self, raw, n_u64):
         """sum the raw histogram over ranks: first n_u64 entries are uint64 counts, the rest float64"""
@@ -255,9 +233,9 @@ class SlabComm:
         import torch
         cnt = torch.from_numpy(raw[: n_u64 * 8].view(np.int64).copy())
         val = torch.from_numpy(raw[n_u64 * 8:].view(np.float64).copy())
-        self.dist.all_reduce(cnt, group=self.hgroup)
+        self.dist.all_reduce(cnt, group=self.group)
         if val.numel():
-            self.dist.all_reduce(val, group=self.hgroup)
+            self.dist.all_reduce(val, group=self.group)
         out = np.empty_like(raw)
         out[: n_u64 * 8] = cnt.numpy().view(np.uint8)
         out[n_u64 * 8:] = val.numpy().view(np.uint8)
@@ -268,16 +246,20 @@ class SlabComm:
             return int(v)
         import torch
         t = torch.tensor([int(v)], dtype=torch.int64)
-        self.dist.all_reduce(t, group=self.hgroup)
+        self.dist.all_reduce(t, group=self.group)
         return int(t[0])
 
-    def all_reduce_float(self, v):
+    def all_reduce_float(self, v, op='sum'):
         if not self.collective:
             return float(v)
         import torch
         t = torch.tensor([float(v)], dtype=torch.float64)
-        self.dist.all_reduce(t, group=self.hgroup)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == 'max' else self.dist.ReduceOp.SUM, group=self.group)
         return float(t[0])
+
+    def barrier(self):
+        if self.collective:
+            self.dist.barrier(group=self.group)
 
     def all_to_all_host(self, arrays):
         """variable-size host all-to-all of float32 arrays (particle routing): arrays[p] goes to rank p"""
@@ -285,29 +267,20 @@ class SlabComm:
             return [arrays[0]]
         import torch
         sizes = torch.tensor([a.size for a in arrays], dtype=torch.int64)
-        rsizes = torch.empty(self.world, dtype=torch.int64)
-        reqs = []
         all_sizes = [torch.empty(self.world, dtype=torch.int64) for _ in range(self.world)]
-        self.dist.all_gather(all_sizes, sizes, group=self.hgroup)
-        for p in range(self.world):
-            rsizes[p] = all_sizes[p][self.rank]
-        outs = [np.empty(int(rsizes[p]), dtype=np.float32) for p in range(self.world)]
-        for p in range(self.world):
-            if p == self.rank:
-                outs[p][:] = arrays[p].ravel()
-            else:
-                if arrays[p].size:
-                    reqs.append(self.dist.isend(torch.from_numpy(np.ascontiguousarray(arrays[p].ravel())), p, group=self.hgroup))
-                if outs[p].size:
-                    reqs.append(self.dist.irecv(torch.from_numpy(outs[p]), p, group=self.hgroup))
-        for q in reqs:
-            q.wait()
+        self.dist.all_gather(all_sizes, sizes, group=self.group)
+        outs = [np.empty(int(all_sizes[p][self.rank]), dtype=np.float32) for p in range(self.world)]
+        self._pairwise([torch.from_numpy(np.ascontiguousarray(a.ravel())) for a in arrays], [torch.from_numpy(o) for o in outs])
         return outs
 
 
 def route_particles(pos, w, Lbox, comm):
-    """send every particle to the rank that owns its x-slab (wrapped x in [r*L/W, (r+1)*L/W)); host-side, for
-    catalogs whose order is not slab-local (e.g. light-cone RSD moves galaxies across slabs)"""
+    """send every particle to the rank that owns its x-slab (wrapped x in [r*L/W, (r+1)*L/W)), for catalogs whose
+    order is not slab-local (e.g. light-cone RSD moves galaxies across slabs).  With the RCCL communicator
+    and `_lib.DeviceArray` inputs the particles never leave HBM (bucket sort + all-to-all-v on the device); host arrays
+    and the gloo stand-in take the NumPy route below."""
+    if getattr(comm, 'device', False) and isinstance(pos, _lib.DeviceArray):
+        return comm.route_particles(pos, w, Lbox)
     pos = np.ascontiguousarray(pos, dtype=np.float32)
     xw = pos[:, 0] - np.floor(pos[:, 0] / np.float32(Lbox)) * np.float32(Lbox)
     owner = np.minimum((xw * (comm.world / np.float32(Lbox))).astype(np.int64), comm.world - 1)
@@ -328,7 +301,13 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
                     squeeze_mu_axis=True, n_total=None, n_total2=None):
     """`calc_power` (abacusnbody/analysis/power_spectrum.py:1131-1319) over x-slabs.  `pos` / `pos2` are THIS rank's
     particles (already inside its x-slab, see `route_particles`); every rank returns the full Table."""
-    comm = comm or SlabComm()
+    if comm is None:   # launched with WORLD_SIZE > 1: RCCL; a single process needs no transport
+        import os
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            from ..comm import RcclComm
+            comm = RcclComm.from_env()
+        else:
+            comm = SlabComm()
     backend = backend or HipSlabBackend()
     W, r = comm.world, comm.rank
     if nmesh % W or nmesh // W < GHOST:
@@ -375,10 +354,19 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
             backend.axpy(mesh, nxl * plane, mesh, 0, g, 0.0)
             backend.axpy(mesh, GHOST * plane, mesh, (GHOST + nxl) * plane, g, 0.0)
         backend.axpy(mesh, GHOST * plane, None, 0, nxl * plane, -1.0)          # delta = rho*norm - 1 on the owned planes
-        backend.fft_zy(mesh, GHOST * plane, nmesh, nxl)
-        backend.pack(mesh, GHOST * plane, send, nmesh, nxl, W)
+        # z / y passes, pack and pencil transpose in chunks of x-planes: chunk c is on the links (the communicator's
+        # stream) while chunk c+1 is transformed
+        nchunk = comm.transpose_chunks(nxl) if comm.collective else 1
+        cx = nxl // nchunk
+        nyl = nmesh // W
+        for c in range(nchunk):
+            backend.fft_zy(mesh, (GHOST + c * cx) * plane, nmesh, cx)
+            backend.pack(mesh, GHOST * plane, send, nmesh, nxl, W, c * cx, cx)
+            if comm.collective:
+                comm.all_to_all_piece(backend, send, recv, nxl * nyl * pitch, c * cx * nyl * pitch, cx * nyl * pitch,
+                                      overlap=nchunk > 1)
         if comm.collective:
-            comm.all_to_all(backend, send, recv, nxl * plane)
+            comm.join()
         backend.unpack(recv if comm.collective else send, mesh, GHOST * plane, nmesh, nxl, W)   # mesh now holds (y_local, x, k)
         backend.fft_x(mesh, GHOST * plane, nmesh, nxl)
         return (mesh, GHOST * plane)

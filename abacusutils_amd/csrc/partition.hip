@@ -8,6 +8,8 @@
 // gather then writes the particles.  HBM-bound: ~3 passes over 8-B pairs + one 12-B gather.
 #include <hipcub/hipcub.hpp>
 
+#include <vector>
+
 #include "../../include/abacus_hip.h"
 #include "common.hpp"
 
@@ -107,7 +109,61 @@ int partition_impl(const void *pos_, int64_t n, const void *w_, int npartition, 
     return rc;
 }
 
+// owner of a particle in the x-slab decomposition of the mesh: wrapped x in [r L/W, (r+1) L/W), float32 like the deposit
+__global__ void route_keys(const float *__restrict__ pos, int64_t n, float box, float inv_width, int world,
+                           int *__restrict__ keys, unsigned int *__restrict__ idx, unsigned long long *__restrict__ hist) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = pos[3 * i];
+        const float xw = x - floorf(x / box) * box;
+        int k = (int)(xw * inv_width);
+        k = max(min(k, world - 1), 0);
+        keys[i] = k;
+        idx[i] = (unsigned int)i;
+        atomicAdd(&hist[k], 1ull);
+    }
+}
+
 }  // namespace
+
+// Particle routing of the slab P(k) on the device (no reference counterpart: the reference's mesh is single-process):
+// stable bucket sort of (pos, w) by owning rank; counts[world] on the host.  The variable-size blocks then travel with
+// abacus_comm_all_to_all_v.
+extern "C" int abacus_slab_route_dev(const float *pos, int64_t n, const float *w, double Lbox, int world, float *pos_out,
+                                     float *w_out, int64_t *counts) {
+    ABACUS_ENTER();
+    if (world < 1 || !counts || (n > 0 && (!pos || !pos_out)) || (w && !w_out)) return fail("abacus_slab_route_dev: bad argument");
+    if (n >= (int64_t)1 << 31) return fail("abacus_slab_route_dev: more than 2^31 particles per rank");
+    static DevBuf keys, keys2, idx, idx2, hist, tmp;   // library scratch, reused across calls (API mutex held)
+    const size_t n1 = (size_t)std::max<int64_t>(n, 1);
+    ABACUS_TRY(keys.reserve(n1 * 4));
+    ABACUS_TRY(keys2.reserve(n1 * 4));
+    ABACUS_TRY(idx.reserve(n1 * 4));
+    ABACUS_TRY(idx2.reserve(n1 * 4));
+    ABACUS_TRY(hist.reserve((size_t)world * 8));
+    HIP_TRY(hipMemsetAsync(hist.p, 0, (size_t)world * 8, stream()));
+    std::vector<unsigned long long> h((size_t)world, 0ull);
+    if (n > 0) {
+        const int nblk = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+        const float box = (float)Lbox;
+        ABACUS_LAUNCH("route_keys", route_keys, dim3(nblk), dim3(256), 0, pos, n, box, (float)world / box, world, keys.as<int>(),
+                      idx.as<unsigned int>(), hist.as<unsigned long long>());
+        int end_bit = 1;
+        while ((1ll << end_bit) < world) end_bit++;
+        size_t tmp_bytes = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<int>(), keys2.as<int>(), idx.as<unsigned int>(),
+                                                 idx2.as<unsigned int>(), (int)n, 0, end_bit, stream());
+        ABACUS_TRY(tmp.reserve(tmp_bytes));
+        if (hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<int>(), keys2.as<int>(), idx.as<unsigned int>(),
+                                               idx2.as<unsigned int>(), (int)n, 0, end_bit, stream()) != hipSuccess)
+            return fail("abacus_slab_route_dev: radix sort failed");
+        ABACUS_LAUNCH("route_gather", part_gather<float>, dim3(nblk), dim3(256), 0, pos, w, idx2.as<unsigned int>(), n, pos_out,
+                      w_out);
+    }
+    HIP_TRY(hipMemcpyAsync(h.data(), hist.p, (size_t)world * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    for (int k = 0; k < world; k++) counts[k] = (int64_t)h[k];
+    return 0;
+}
 
 extern "C" int abacus_partition(const void *pos, int64_t n, const void *weights, int dtype, int npartition,
                                 double box, int coord, void *psort, int64_t *starts, void *wsort) {

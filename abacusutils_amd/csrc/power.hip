@@ -488,14 +488,15 @@ __global__ void slab_axpy(float *__restrict__ dst, const float *__restrict__ src
     }
 }
 
-// send[p][xl][yl][k] = data[xl][p*nyl + yl][k]   (rows of `pitch` complex, copied as 16-B pieces)
+// send[p][xl][yl][k] = data[xl][p*nyl + yl][k] for the planes xl in [x0, x0 + nxc)   (rows of `pitch` complex, copied as
+// 16-B pieces); a chunk of planes at a time, so that the transpose of a chunk is on the links while the next is transformed
 __global__ void slab_pack(const float4 *__restrict__ data, float4 *__restrict__ send, int n, int nxl, int nyl, int world,
-                          int pitch4) {
-    const int64_t rows = (int64_t)world * nxl * nyl;
+                          int pitch4, int x0, int nxc) {
+    const int64_t rows = (int64_t)world * nxc * nyl;
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-        const int yl = (int)(r % nyl), xl = (int)((r / nyl) % nxl), p = (int)(r / ((int64_t)nyl * nxl));
+        const int yl = (int)(r % nyl), xl = x0 + (int)((r / nyl) % nxc), p = (int)(r / ((int64_t)nyl * nxc));
         const float4 *src = data + ((int64_t)xl * n + (p * nyl + yl)) * pitch4;
-        float4 *dst = send + r * pitch4;
+        float4 *dst = send + (((int64_t)p * nxl + xl) * nyl + yl) * pitch4;
         for (int q = threadIdx.x; q < pitch4; q += blockDim.x) dst[q] = src[q];
     }
 }
@@ -1057,13 +1058,14 @@ int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local) {
     return fft_native_zy(mesh, nmesh, pitch_r(nmesh), nx_local);
 }
 
-int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world) {
+int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world, int x_begin, int x_count) {
     ABACUS_ENTER();
     if (nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
+    if (x_begin < 0 || x_count < 1 || x_begin + x_count > nx_local) return fail("abacus_slab_pack_dev: planes [%d, +%d) of %d", x_begin, x_count, nx_local);
     const int nyl = nmesh / world, pitch4 = pitch_r(nmesh) / 4;
-    const int grid = (int)std::min<int64_t>((int64_t)world * nx_local * nyl, 256 * 32);
+    const int grid = (int)std::min<int64_t>((int64_t)world * x_count * nyl, 256 * 32);
     ABACUS_LAUNCH("slab_pack", slab_pack, dim3(grid), dim3(256), 0, (const float4 *)data, (float4 *)send, nmesh, nx_local,
-                  nyl, world, pitch4);
+                  nyl, world, pitch4, x_begin, x_count);
     return 0;
 }
 

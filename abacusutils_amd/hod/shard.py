@@ -68,11 +68,18 @@ def merge_catalogs(parts, tracers=None):
 
 
 class HodComm:
-    """control-plane collectives for the sharded HOD (torch.distributed when initialised, trivial otherwise)"""
+    """control-plane collectives of the sharded HOD: sums of per-tracer counts and the merge of the per-rank mocks.
 
-    def __init__(self, group=None):
-        self.dist, self.group = None, group
+    transport: an `abacusutils_amd.comm.RcclComm` (GPUs: RCCL through the C ABI), or None = torch.distributed when a
+    process group is initialised (the gloo CPU tests), else a single process."""
+
+    def __init__(self, transport=None, group=None):
+        self.rccl, self.dist, self.group = None, None, group
         self.rank, self.world = 0, 1
+        if transport is not None:
+            self.rccl = transport
+            self.rank, self.world = transport.rank, transport.world
+            return
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
@@ -85,7 +92,9 @@ class HodComm:
         """sum {tracer: (Ncent, Nsat)}-style integer dicts over ranks"""
         keys = sorted(counts)
         vals = np.array([np.atleast_1d(counts[k]) for k in keys], dtype=np.int64)
-        if self.dist is not None and self.world > 1:
+        if self.rccl is not None and self.world > 1:
+            vals = self.rccl.all_reduce_array(vals.copy()).reshape(vals.shape)
+        elif self.dist is not None and self.world > 1:
             import torch
             t = torch.from_numpy(vals.copy())
             self.dist.all_reduce(t, group=self.group)
@@ -95,8 +104,11 @@ class HodComm:
     def gather_catalog(self, local, dst=None):
         """merge the per-rank catalogues; on every rank (dst=None) or only on `dst` (others get None).  Host-side:
         a mock is ~1e-3 of the particle subsample it was drawn from"""
-        if self.dist is None or self.world == 1:
+        if self.world == 1 or (self.rccl is None and self.dist is None):
             return local
+        if self.rccl is not None:
+            objs = self.rccl.all_gather_object(local)
+            return merge_catalogs(objs) if dst is None or self.rank == dst else None
         objs = [None] * self.world
         if dst is None:
             self.dist.all_gather_object(objs, local, group=self.group)

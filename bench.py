@@ -11,8 +11,14 @@ stays in HBM (device-resident rate; the PCIe-inclusive rate is quoted in DESIGN.
 metric - wall-clock of the TSC + FFT + binning P(k) - is reported in the "pk" object of the same JSON line
 (`--workload pk` makes it the headline instead).
 
-N > 1: one process per GPU (torch.distributed.run); every rank populates its own 10^7-halo slab catalog
-(weak scaling, no data-path collective - halos are independent).
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N rank processes itself (abacusutils_amd/launch.py:
+the parent never touches the GPU; fresh children with RANK / LOCAL_RANK / WORLD_SIZE set; a stuck or crashed rank is
+ended by PID and the line is still printed, with an `error` field); under `python -m torch.distributed.run` every rank
+process starts only its own child.  Collectives are RCCL through the C ABI (abacusutils_amd/comm.py) - no torch in any
+of these processes.  Two legs per N: the headline, every rank populating its own 10^7-halo slab catalogue (weak scaling,
+no data-path collective - halos are independent; the reference's unit is the slab chunk,
+abacusnbody/hod/abacus_hod.py:301-312), and `pk_slab`: ONE nmesh^3 TSC + FFT P(k) decomposed over the N GPUs (strong
+scaling: ghost exchange, all-to-all pencil transpose, histogram all-reduce).
 """
 import argparse
 import json
@@ -42,56 +48,10 @@ def parse():
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-pk', action='store_true', help='skip the secondary P(k) measurement')
     ap.add_argument('--no-slab', action='store_true', help='N > 1: skip the slab-decomposed P(k) leg (RCCL all-to-all)')
-    ap.add_argument('--slab-timeout', type=float, default=150.0, help='seconds before one attempt of the slab leg is abandoned')
+    ap.add_argument('--slab-timeout', type=float, default=240.0, help='seconds before the slab leg is abandoned')
+    ap.add_argument('--hod-timeout', type=float, default=420.0, help='N > 1: seconds before the headline leg is abandoned')
+    ap.add_argument('--leg', default=None, choices=['hod', 'pk_slab'], help='internal: run one leg as a rank process')
     return ap.parse_args()
-
-
-class Dist:
-    """barrier / max-reduce across ranks; torch.distributed only when WORLD_SIZE > 1"""
-
-    def __init__(self, init_method=None):
-        self.world = int(os.environ.get('WORLD_SIZE', '1'))
-        self.rank = int(os.environ.get('RANK', '0'))
-        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-        self.td = None
-        if self.world > 1:
-            import torch  # noqa: F401  (imported BEFORE libabacus_hip.so so both share one HIP runtime)
-            import torch.distributed as td
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            td.init_process_group(backend='gloo', rank=self.rank, world_size=self.world, init_method=init_method)
-            self.td = td
-
-    def barrier(self):
-        if self.td:
-            self.td.barrier()
-
-    def max(self, x):
-        if not self.td:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
-        return float(t[0])
-
-    def sum(self, x):
-        if not self.td:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        self.td.all_reduce(t, op=self.td.ReduceOp.SUM)
-        return float(t[0])
-
-    def broadcast_int(self, x):
-        if not self.td:
-            return int(x)
-        import torch
-        t = torch.tensor([int(x)], dtype=torch.int64)
-        self.td.broadcast(t, src=0)
-        return int(t[0])
-
-    def finish(self):
-        if self.td:
-            self.td.destroy_process_group()
 
 
 def bench_hod(args, dist):
@@ -228,81 +188,94 @@ def cpu_model():
     return 'unknown'
 
 
-def run_slab_children(args, dist, collectives):
-    """every rank starts `bench_pk.py --slab-child` (own rendezvous port, chosen by rank 0), waits for it with a
-    timeout and reports rank 0's result line; children are ended by exact PID on timeout"""
-    import socket
-    import subprocess
-    port = 0
+def run_leg(args):
+    """a rank process of an N > 1 run (started by `orchestrate`): RCCL communicator from the environment, one leg"""
+    from abacusutils_amd.comm import Dist
+    dist = Dist.from_env()          # binds GPU LOCAL_RANK, file rendezvous, ncclCommInitRank; raises without a HIP device
+    if args.leg == 'hod':
+        out = bench_hod(args, dist)
+    else:
+        from bench_pk import bench_pk_slab
+        out = bench_pk_slab(args, dist)
+    if dist.comm is not None:
+        out['rccl'] = dist.comm.info()
     if dist.rank == 0:
-        with socket.socket() as sk:
-            sk.bind(('127.0.0.1', 0))
-            port = sk.getsockname()[1]
-    port = dist.broadcast_int(port)
+        print('BENCH-LEG ' + json.dumps(out), flush=True)
+    dist.finish()
+
+
+def orchestrate(args, under_launcher):
+    """N > 1.  This process never touches the GPU: it starts rank children per leg and assembles the line."""
+    from abacusutils_amd.launch import failure_summary, launch_ranks
+    if under_launcher:      # one orchestrator per rank already exists (torchrun): each starts its own child
+        world, ranks = int(os.environ['WORLD_SIZE']), [int(os.environ['RANK'])]
+        key0 = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"
+    else:
+        world, ranks = args.gpus, None
+        key0 = f'{os.getpid()}_{int(time.time() * 1e3)}'
     env = {k: v for k, v in os.environ.items() if not k.startswith('TORCHELASTIC')}
-    cmd = [sys.executable, os.path.join(REPO, 'bench_pk.py'), '--slab-child', '--store-port', str(port),
-           '--collectives', collectives, '--nmesh', str(args.nmesh), '--npk', str(args.npk), '--steps', str(min(args.steps, 5))]
-    res, ok = None, False
-    try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.slab_timeout)
-        for line in r.stdout.splitlines():
-            if line.startswith('SLAB-RESULT '):
-                res = json.loads(line[len('SLAB-RESULT '):])
-        ok = r.returncode == 0
-        if dist.rank == 0:
-            if res is None:
-                res = {'error': f'child exit code {r.returncode}: ' + r.stderr[-400:]}
-            ok = ok and 'error' not in res
-    except subprocess.TimeoutExpired:
-        res = {'error': f'abandoned after {args.slab_timeout:.0f} s'}
-    bad = int(dist.sum(0.0 if ok else 1.0))          # collective: every rank takes the same retry decision
-    if bad and 'error' not in (res or {}):
-        res = {'error': f'{bad} rank(s) failed'}
-    return res or {}
+    is_root = ranks is None or 0 in ranks
+    common = ['--gpus', str(world), '--steps', str(args.steps), '--warmup', str(args.warmup), '--nhalo', str(args.nhalo),
+              '--npart', str(args.npart), '--nmesh', str(args.nmesh), '--npk', str(args.npk), '--no-cpu']
+
+    def leg(name, timeout):
+        res = launch_ranks([sys.executable, os.path.abspath(__file__), '--leg', name] + common, world, ranks=ranks,
+                           timeout=timeout, tag='BENCH-LEG', key=f'{key0}_{name}', env=env)
+        ok = all(c == 0 for c in res['returncodes'].values())
+        return (res['results'].get(0) if is_root else None), ok, (None if ok else failure_summary(res))
+
+    out, ok, err = leg('hod', args.hod_timeout)
+    if out is None:
+        out = {'metric': 'halos/sec HOD populate', 'value': None, 'unit': 'halos/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f64', 'data': 'synthetic', 'config': {'workload': 'C2 per GPU (not measured)'}}
+    if err:
+        out['error'] = err
+    rc = 0 if ok else 1
+    if not args.no_slab and not args.no_pk:
+        slab, sok, serr = leg('pk_slab', args.slab_timeout)
+        slab = slab or {}
+        if serr:
+            slab['error'] = serr
+        out['pk_slab'] = slab
+    if is_root:
+        print(json.dumps(out), flush=True)
+    return rc
+
+
+def single(args):
+    """N = 1: everything in this process, no communicator"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.comm import Dist
+    dist = Dist(None)
+    _lib.set_device(0)
+    if args.workload == 'hod':
+        out = bench_hod(args, dist)
+        if not args.no_pk:
+            import bench_pk
+            for key, fn in (('pk', lambda: bench_pk.bench_pk(args, dist, headline=False)),
+                            ('pairs', lambda: bench_pk.bench_pairs(args, dist)),
+                            ('catalog', lambda: bench_pk.bench_catalog(args, dist))):
+                try:                    # a secondary measurement must not take the headline down
+                    out[key] = fn()
+                except Exception as e:
+                    out[key] = {'error': repr(e)}
+    else:
+        from bench_pk import bench_pk
+        out = bench_pk(args, dist, headline=True)
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 def main():
     args = parse()
-    dist = Dist()
-    from abacusutils_amd import _lib
-    ndev = max(_lib.device_count(), 1)
-    _lib.set_device(dist.local_rank % ndev)
-    if args.workload == 'hod':
-        out = bench_hod(args, dist)
-        if not args.no_pk:
-            try:
-                from bench_pk import bench_pk
-                out['pk'] = bench_pk(args, dist, headline=False)
-            except Exception as e:  # the secondary measurement must not take the headline down
-                out['pk'] = {'error': repr(e)}
-            try:
-                from bench_pk import bench_pairs
-                out['pairs'] = bench_pairs(args, dist)
-            except Exception as e:
-                out['pairs'] = {'error': repr(e)}
-            try:
-                from bench_pk import bench_catalog
-                out['catalog'] = bench_catalog(args, dist)
-            except Exception as e:
-                out['catalog'] = {'error': repr(e)}
-    else:
-        from bench_pk import bench_pk
-        out = bench_pk(args, dist, headline=True)
-    if dist.world > 1 and not args.no_slab and not args.no_pk:
-        # One nmesh^3 mesh decomposed over the N GPUs (BASELINE config 4): ghost exchange, all-to-all pencil transpose
-        # and histogram all-reduce over RCCL.  Runs in a child process per rank: the headline above is complete, and a
-        # fault or a stuck collective in this leg must not take the bench line down with it.
-        res = run_slab_children(args, dist, 'device')
-        if 'error' in res:
-            first = res
-            res = run_slab_children(args, dist, 'host')
-            res['device_collectives_error'] = first['error']
-        if dist.rank == 0:
-            out['pk_slab'] = res
-    if dist.rank == 0:
-        print(json.dumps(out), flush=True)
-    dist.finish()
+    if args.leg:
+        return run_leg(args)
+    under_launcher = 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1
+    if args.gpus > 1 or under_launcher:
+        return orchestrate(args, under_launcher)
+    return single(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

@@ -159,24 +159,15 @@ def cpu_baseline_pk(L):
 
 def bench_pk_slab(args, dist):
     """strong scaling of ONE nmesh^3 P(k) over the N GPUs: x-slab deposit with ghost planes, ring exchange, z/y passes,
-    all-to-all pencil transpose, x pass, y-slab binning, all-reduce (abacusutils_amd/analysis/slab_power.py).  Particles
-    (args.npk in total, uniform, generated inside each rank's slab) are resident in HBM; device collectives over RCCL."""
-    import torch
-    import torch.distributed as td
-
+    all-to-all pencil transpose (chunked, overlapping the passes), x pass, y-slab binning, all-reduce
+    (abacusutils_amd/analysis/slab_power.py).  Particles (args.npk in total, uniform, generated inside each rank's slab)
+    are resident in HBM; collectives are RCCL through the C ABI (dist.comm)."""
     from abacusutils_amd import _lib
     from abacusutils_amd.analysis import slab_power as sp
     nmesh, ntot = args.nmesh, args.npk
     L = 2000.0
     W, r = dist.world, dist.rank
-    ndev = max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dist.local_rank % ndev)
-    device = getattr(args, 'collectives', 'device') == 'device'
-    if device:
-        nccl = td.new_group(backend='nccl')
-        comm = sp.SlabComm(device_collectives=True, group=nccl, host_group=td.group.WORLD)
-    else:       # transposes and ghost planes staged through the host over gloo (also what runs 2 ranks on ONE GPU)
-        comm = sp.SlabComm(device_collectives=False, group=td.group.WORLD)
+    comm = dist.comm if dist.comm is not None else sp.SlabComm()
     backend = sp.HipSlabBackend(keep_buffers=True)
     n_local = ntot // W
     rng = np.random.default_rng(300 + r)
@@ -188,7 +179,8 @@ def bench_pk_slab(args, dist):
     kw = dict(kbins=min(512, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste='TSC', nmesh=nmesh,
               compensated=False, interlaced=False, poles=[0, 2, 4], n_total=n_local * W)
     steps = max(1, min(args.steps, 5))
-    tab = sp.calc_power_slab(dpos, L, comm=comm, backend=backend, **kw)   # warm-up: allocations, plans, RCCL channels
+    tab = sp.calc_power_slab(dpos, L, comm=comm, backend=backend, **kw)   # warm-up: allocations, tables, RCCL channels
+    sent0 = comm.info()['bytes_sent'] if dist.comm is not None else 0
     dist.barrier()
     _lib.sync()
     t0 = time.perf_counter()
@@ -197,16 +189,39 @@ def bench_pk_slab(args, dist):
     _lib.sync()
     dist.barrier()
     dt = dist.max(time.perf_counter() - t0) / steps
+    sent = (comm.info()['bytes_sent'] - sent0) / steps if dist.comm is not None else 0
     power = np.asarray(tab['power'])
     shot = L**3 / (n_local * W)
+    out = {'metric': f'wall-clock of one {nmesh}^3 TSC+FFT P(k) slab-decomposed over {W} GPUs', 'value': dt * 1e3,
+           'unit': 'ms', 'n_gpus': W, 'rccl_ranks': W if dist.comm is not None else 0, 'steps': steps, 'scaling': 'strong',
+           'higher_is_better': False, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'{n_local * W:.0e} uniform particles in x-slabs, nmesh {nmesh}, TSC, non-interlaced, '
+                                  'RCCL through the C ABI: ring send/recv of ghost planes, chunked all-to-all of the '
+                                  'pencil transpose (grouped ncclSend/ncclRecv), all-reduce of the histogram'},
+           'bytes_sent_per_rank_per_step': sent,
+           'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot)}
+    # the pencil transpose on its own: every rank sends 1/W of its slab to each peer at once (one xGMI link per peer)
+    if dist.comm is not None and W > 1:
+        pitch = backend.pitch(nmesh)
+        nfl = (nmesh // W) * nmesh * pitch
+        a, b = backend.new_buffer(nfl), backend.new_buffer(nfl)
+        comm.all_to_all(backend, a, b, nfl)
+        dist.barrier()
+        _lib.sync()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            comm.all_to_all(backend, a, b, nfl)
+        _lib.sync()
+        ta = dist.max(time.perf_counter() - t1) / reps
+        per_peer = 4.0 * nfl / W
+        out['all_to_all'] = {'ms': ta * 1e3, 'bytes_per_peer': per_peer, 'GBs_per_link': per_peer / ta / 1e9,
+                             'GBs_per_rank_out': per_peer * (W - 1) / ta / 1e9}
+        a.free()
+        b.free()
     backend.drop_buffers()
     dpos.free()
-    return {'metric': f'wall-clock of one {nmesh}^3 TSC+FFT P(k) slab-decomposed over {W} GPUs', 'value': dt * 1e3,
-            'unit': 'ms', 'n_gpus': W, 'steps': steps, 'scaling': 'strong',
-            'config': {'workload': f'{n_local * W:.0e} uniform particles in x-slabs, nmesh {nmesh}, TSC, non-interlaced, ' +
-                                   ('device collectives (RCCL all-to-all + ring send/recv + all-reduce)' if device else
-                                    'collectives staged through the host (gloo)')},
-            'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot)}
+    return out
 
 
 def bench_pairs(args, dist):
@@ -340,34 +355,3 @@ def bench_catalog(args, dist):
         out['cpu_baseline'] = {'unpack_rvint particles/s': m / tr, 'unpack_pids particles/s': m / tp, 'cores': 1,
                                'kind': 'port', 'sample': f'{m} particles, NumPy restatement'}
     return out
-
-
-def slab_child_main():
-    """`python bench_pk.py --slab-child --store-port P ...`: the slab-decomposed leg as a process of its own, one per
-    rank, started by bench.py AFTER the headline is measured - a fault inside a collective then ends this process, not
-    the one that prints the bench line.  Rendezvous on 127.0.0.1:P (own TCP store, not torchrun's agent store)."""
-    import argparse
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--slab-child', action='store_true')
-    ap.add_argument('--store-port', type=int, required=True)
-    ap.add_argument('--collectives', default='device', choices=['device', 'host'])
-    ap.add_argument('--nmesh', type=int, default=2048)
-    ap.add_argument('--npk', type=int, default=100_000_000)
-    ap.add_argument('--steps', type=int, default=3)
-    args = ap.parse_args()
-    import torch  # noqa: F401  (before libabacus_hip.so)
-    from bench import Dist
-    from abacusutils_amd import _lib
-    dist = Dist(init_method=f'tcp://127.0.0.1:{args.store_port}')
-    _lib.set_device(dist.local_rank % max(_lib.device_count(), 1))
-    try:
-        res = bench_pk_slab(args, dist)
-    except Exception as e:
-        res = {'error': repr(e)}
-    if dist.rank == 0:
-        print('SLAB-RESULT ' + json.dumps(res), flush=True)
-    dist.finish()
-
-
-if __name__ == '__main__':
-    slab_child_main()

@@ -242,8 +242,8 @@ int abacus_power_release(void);
 /*
  * The reference has no distributed mesh (docs/tutorials/analysis/tsc.ipynb:19); this is new functionality behind
  * calc_power: x-slab mesh decomposition, ghost-plane exchange-add, local z/y FFT passes, all-to-all pencil transpose,
- * x FFT pass and binning on y-slabs, all-reduce of the (k, mu) histogram.  The collectives are issued by
- * the host code (torch.distributed: RCCL on GPUs, gloo in tests); these entry points are the device-side pieces.
+ * x FFT pass and binning on y-slabs, all-reduce of the (k, mu) histogram.  The collectives are the
+ * abacus_comm_* entry points below (RCCL); these entry points are the device-side pieces.
  * All pointers are DEVICE pointers; nmesh must be a power of two in [64, 2048] and divisible by the number of ranks.
  * Mesh rows have abacus_slab_pitch(nmesh) floats (128-B aligned rows; complex rows of pitch/2).
  */
@@ -255,8 +255,9 @@ int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, 
 int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add);
 /* z and y passes of the 3-D R2C FFT on nx_local owned planes, in place */
 int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local);
-/* (x_local, y, k) -> send[p][x_local][y_local][k] and recv[r][x_local][y_local][k] -> (y_local, x, k) */
-int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world);
+/* (x_local, y, k) -> send[p][x_local][y_local][k] for the planes [x_begin, x_begin + x_count) of the slab (a chunk of
+ * the pencil transpose), and recv[r][x_local][y_local][k] -> (y_local, x, k) */
+int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world, int x_begin, int x_count);
 int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int nx_local, int world);
 /* x pass on a y-slab in the (y_local, x, k) layout, in place */
 int abacus_slab_fft_x_dev(float *data, int nmesh, int ny_local);
@@ -266,9 +267,52 @@ int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void
                         double Lbox, const float *W_host, int interlaced, const double *kedges, int Nk,
                         const double *muedges, int Nmu, const int64_t *poles, int Np, void *raw_out);
 int64_t abacus_bin_raw_bytes(int Nk, int Nmu, const int64_t *poles, int Np);
+/* particle routing on the device: stable bucket sort of (pos (n,3) float32, w or NULL) by the rank that owns the wrapped x
+ * (x-slabs of width Lbox / world); counts[world] on the host.  The blocks then travel with abacus_comm_all_to_all_v. */
+int abacus_slab_route_dev(const float *pos, int64_t n, const float *w, double Lbox, int world, float *pos_out, float *w_out,
+                          int64_t *counts);
 /* bin_kmu's normalisation (analysis/power_spectrum.py:276-293, 789-792) of reduced raw sums; host only */
 int abacus_bin_finalize(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *poles, int Np, float *power,
                         int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg);
+
+/* ---------------------------------------------------------------- multi-GPU communicator (RCCL) -------- */
+/*
+ * One process per GPU; the collectives of the slab-decomposed P(k), the sharded HOD and the slab pair counts
+ * (SURVEY.md 8e).  New functionality: the reference is single-node shared-memory (its unit of decomposition is the slab
+ * chunk, hod/abacus_hod.py:301-312).  librccl is opened on first use.  Rank 0 creates the 128-byte id and distributes it
+ * out of band (abacusutils_amd/comm.py: file rendezvous); abacus_comm_init = ncclCommInitRank on the device selected with
+ * abacus_set_device.  Device-buffer collectives are enqueued on the library stream and never synchronise with the host;
+ * `async` != 0 runs them on the communicator's own stream behind the kernels enqueued so far - abacus_comm_join puts the
+ * library stream behind them again (pencil-transpose chunks overlap the FFT passes of the next chunk).
+ * dtype codes: 0 int64, 1 float64, 2 float32, 3 uint64; op: 0 sum, 1 max.
+ */
+#define ABACUS_COMM_ID_BYTES 128
+typedef struct abacus_comm abacus_comm;
+int abacus_comm_unique_id(void *id, int len);
+int abacus_comm_init(int rank, int world, const void *id, int len, abacus_comm **out);
+int abacus_comm_info(const abacus_comm *c, int *rank, int *world, int *rccl_version, uint64_t *bytes_sent);
+int abacus_comm_free(abacus_comm *c);
+int abacus_comm_abort(abacus_comm *c);   /* ncclCommAbort: after a failed or abandoned collective */
+int abacus_comm_join(abacus_comm *c);
+/* block p of `send` (bytes_per_peer each) goes to rank p, block p of `recv` comes from rank p: ONE group of
+ * ncclSend / ncclRecv, every xGMI link busy at once */
+int abacus_comm_all_to_all(abacus_comm *c, const void *send, void *recv, uint64_t bytes_per_peer, int async);
+/* the same for the piece [offset, offset + bytes) of every peer block (blocks `peer_stride` bytes apart): chunks of the
+ * pencil transpose */
+int abacus_comm_all_to_all_strided(abacus_comm *c, const void *send, void *recv, uint64_t peer_stride, uint64_t offset,
+                                   uint64_t bytes, int async);
+/* variable blocks (device-side particle routing): byte counts and offsets per peer, host arrays of `world` entries */
+int abacus_comm_all_to_all_v(abacus_comm *c, const void *send, const uint64_t *send_bytes, const uint64_t *send_off, void *recv,
+                             const uint64_t *recv_bytes, const uint64_t *recv_off);
+/* ghost blocks: to_left -> rank-1, to_right -> rank+1; from_right <- what rank+1 sent left, from_left <- what rank-1 sent
+ * right (one rank: its own blocks come back, the periodic box) */
+int abacus_comm_ring_exchange(abacus_comm *c, const void *to_left, const void *to_right, void *from_right, void *from_left,
+                              uint64_t bytes);
+int abacus_comm_allreduce_dev(abacus_comm *c, void *buf, int64_t count, int dtype, int op);   /* in place, device buffer */
+/* host-buffer conveniences for the few-KB messages (histograms, counts, timings): staged through device scratch, blocking */
+int abacus_comm_allreduce_host(abacus_comm *c, void *buf, int64_t count, int dtype, int op);
+int abacus_comm_allgather_host(abacus_comm *c, const void *send, void *recv, uint64_t bytes);
+int abacus_comm_barrier(abacus_comm *c);
 
 /* ---------------------------------------------------------------- ZCV-facing spectrum helpers ----------- */
 /*

@@ -69,13 +69,14 @@ class NumpySlabBackend:
         c[:] = 0
         c[:, :, :nmesh // 2 + 1] = f.astype(np.complex64)
 
-    def pack(self, mesh, off, send, nmesh, nxl, world):
+    def pack(self, mesh, off, send, nmesh, nxl, world, x0=0, nxc=None):
         c = self._cplx(mesh, off, nmesh, nxl)
         nyl = nmesh // world
         pc = c.shape[2]
+        x1 = nxl if nxc is None else x0 + nxc
         s = send.a[:nxl * nmesh * pc * 2].view(np.complex64).reshape(world, nxl, nyl, pc)
         for p in range(world):
-            s[p] = c[:, p * nyl:(p + 1) * nyl, :]
+            s[p, x0:x1] = c[x0:x1, p * nyl:(p + 1) * nyl, :]
 
     def unpack(self, recv, out, off, nmesh, nxl, world):
         nyl = nmesh // world

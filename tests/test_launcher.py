@@ -1,0 +1,103 @@
+"""abacusutils_amd/launch.py (the one-process-per-GPU launcher behind `python bench.py --gpus N`) and bench.py's N > 1
+orchestration, on the CPU: rank environment, result collection, a crashed rank, a stuck rank, the rendezvous of
+abacusutils_amd/comm.py, and the bench line when no GPU exists."""
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+WORKER = [sys.executable, os.path.join(HERE, '_launch_worker.py')]
+
+
+def test_launch_two_ranks_gloo():
+    from abacusutils_amd.launch import launch_ranks
+    res = launch_ranks(WORKER, 2, timeout=240, key='unit_test_key')
+    assert res['returncodes'] == {0: 0, 1: 0} and not res['timed_out'], res
+    assert res['results'][0] == {'sum': 3, 'world': 2, 'key': 'unit_test_key'} and res['results'][1] is None
+
+
+def test_launch_reports_a_crashed_rank_and_ends_its_peers():
+    from abacusutils_amd.launch import failure_summary, launch_ranks
+    t0 = time.time()
+    res = launch_ranks(WORKER + ['--fail-rank', '1'], 2, timeout=240, grace=3.0)
+    assert res['returncodes'][1] == 3 and res['returncodes'][0] != 0      # rank 0 waited for its peer and was ended
+    assert time.time() - t0 < 120 and not res['timed_out']
+    assert 'rank 1: exit 3: boom from rank 1' in failure_summary(res)
+
+
+def test_launch_ends_a_stuck_rank_at_the_timeout():
+    from abacusutils_amd.launch import failure_summary, launch_ranks
+    res = launch_ranks(WORKER + ['--hang-rank', '0'], 2, timeout=8.0)
+    assert res['timed_out'] and all(c != 0 for c in res['returncodes'].values())
+    assert 'abandoned after' in failure_summary(res)
+
+
+def test_file_rendezvous(tmp_path):
+    """rank 0 publishes atomically, the others poll; a stale file (older than the reader by > 10 min) is ignored"""
+    from abacusutils_amd import comm
+    path = str(tmp_path / 'rdzv')
+    blob = bytes(range(128))
+    got = {}
+    th = threading.Thread(target=lambda: got.setdefault(1, comm.exchange_id(1, 2, None, path, timeout=30)))
+    th.start()
+    time.sleep(0.2)
+    assert comm.exchange_id(0, 2, lambda: blob, path) == blob
+    th.join()
+    assert got[1] == blob
+    os.utime(path, (time.time() - 3600, time.time() - 3600))
+    try:
+        comm.exchange_id(1, 2, None, path, timeout=0.3)
+        raise AssertionError('a stale id was accepted')
+    except TimeoutError:
+        pass
+
+
+def _last_json(stdout):
+    return json.loads([ln for ln in stdout.splitlines() if ln.startswith('{')][-1])
+
+
+def test_bench_gpus_2_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` in a container without a GPU: the parent starts two rank processes, both report
+    "no HIP device", the line is still printed (value null, error from both ranks) and the exit code is non-zero"""
+    from abacusutils_amd import _lib
+    if _lib.device_count() > 0:
+        import pytest
+        pytest.skip('a GPU is present')
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    line = _last_json(r.stdout)
+    assert line['n_gpus'] == 2 and line['value'] is None
+    assert 'rank 0' in line['error'] and 'rank 1' in line['error'] and line['error'].count('no HIP device') == 2
+    assert 'no HIP device' in line['pk_slab']['error']
+
+
+def test_bench_under_torchrun_fails_loudly_without_a_gpu():
+    """the driver's N > 1 command: one orchestrator per rank, each starts its own child; rank 0's prints the line"""
+    from abacusutils_amd import _lib
+    if _lib.device_count() > 0:
+        import pytest
+        pytest.skip('a GPU is present')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29671', os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-slab']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                      # ONE line, from rank 0's orchestrator
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and 'no HIP device' in line['error']
+
+
+def test_dist_without_ranks_is_trivial():
+    from abacusutils_amd.comm import Dist
+    d = Dist(None)
+    assert (d.rank, d.world) == (0, 1) and d.max(2.5) == 2.5 and d.sum(2.5) == 2.5
+    d.barrier()
+    d.finish()
+    assert np.isfinite(d.max(1.0))

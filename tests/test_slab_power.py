@@ -87,11 +87,13 @@ def test_slab_hip_matches_single_gpu_path(tmp_path):
 
 
 @pytest.mark.gpu
-def test_slab_hip_device_collectives_single_rank(tmp_path):
-    """the RCCL transport on one GPU: a one-rank `nccl` group with the collectives forced, so the zero-copy torch views
-    of the library's own allocations, the ring send/recv, all_to_all_single and the gloo side group all execute"""
-    res = run_ranks(tmp_path, 1, 'hip', 29641, flags=('--device-collectives', '--force-collectives'))
-    check(res, reference(), 1, 20000)
+@pytest.mark.parametrize('cross', [0, 1])
+def test_slab_hip_rccl_single_rank(tmp_path, cross):
+    """the product transport on the one GPU of the test box: a one-rank RCCL communicator created through the C ABI (file
+    rendezvous, ncclCommInitRank), with the device-side particle routing, ring exchange, chunk-wise all-to-all on the
+    communicator's stream, join and the histogram all-reduce all executing; no torch in the process"""
+    res = run_ranks(tmp_path, 1, 'hip', 29641, flags=('--rccl',), cross=cross, interlaced=1 - cross)
+    check(res, reference(cross=cross, interlaced=1 - cross), 1, 20000)
 
 
 def test_slab_forced_collectives_gloo_cpu(tmp_path):
