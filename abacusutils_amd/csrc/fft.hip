@@ -24,278 +24,7 @@ using namespace abacus;
 
 namespace {
 
-constexpr int FFT_THREADS = 512;   // column passes
-constexpr int Z_THREADS = 256;     // z pass: small tiles (4 rows), several workgroups per CU
-constexpr int PADSHIFT = 4;   // one pad element per 16: de-conflicts the stride-R accesses of the late passes
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ int padq(int q) { return q + (q >> PADSHIFT); }
-
-// Asynchronous 16-B global load the compiler does not track: the prefetch of the next tile stays in flight across the
-// transform AND the write-back of the current one.  hipcc's own vmcnt bookkeeping cannot express "wait for the loads
-// but not for the stores issued after them" once loop paths merge (it degenerates to waiting for every store, which
-// exposes the store latency once per tile), so the wait is written by hand: vmcnt retires in issue order on gfx9, so
-// after `prefetch; ...; K stores` a vmcnt(K) guarantees that every prefetch load has landed.
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gload16_async(v4f &dst, const void *p) {
-    v4f t;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(p) : "memory");
-    dst = t;
-}
-template <int K>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
-}
-__device__ __forceinline__ void wait_vmcnt_upto8(int k) {   // runtime count (uniform), immediate operand
-    switch (k) {
-        case 1: wait_vmcnt<1>(); break;
-        case 2: wait_vmcnt<2>(); break;
-        case 3: wait_vmcnt<3>(); break;
-        case 4: wait_vmcnt<4>(); break;
-        case 5: wait_vmcnt<5>(); break;
-        case 6: wait_vmcnt<6>(); break;
-        case 7: wait_vmcnt<7>(); break;
-        case 8: wait_vmcnt<8>(); break;
-        default: wait_vmcnt<0>(); break;
-    }
-}
-// ties registers to the wait above: their uses cannot be scheduled before it
-__device__ __forceinline__ void touch(v4f &a) {
-    v4f t = a;
-    asm volatile("" : "+v"(t));
-    a = t;
-}
-
-// forward DFTs of size R in registers, natural order in and out (W = exp(-2 pi i / R))
-template <int R>
-__device__ __forceinline__ void dft(float2 (&a)[R]);
-template <>
-__device__ __forceinline__ void dft<2>(float2 (&a)[2]) {
-    const float2 t = a[0];
-    a[0] = cadd(t, a[1]);
-    a[1] = csub(t, a[1]);
-}
-__device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
-    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
-    a0 = cadd(t0, t2);
-    a2 = csub(t0, t2);
-    a1 = make_float2(t1.x + t3.y, t1.y - t3.x);   // t1 - i t3
-    a3 = make_float2(t1.x - t3.y, t1.y + t3.x);   // t1 + i t3
-}
-template <>
-__device__ __forceinline__ void dft<4>(float2 (&a)[4]) { dft4(a[0], a[1], a[2], a[3]); }
-template <>
-__device__ __forceinline__ void dft<8>(float2 (&a)[8]) {
-    dft4(a[0], a[2], a[4], a[6]);   // even
-    dft4(a[1], a[3], a[5], a[7]);   // odd
-    const float h = 0.70710678118654752440f;
-    const float2 o0 = a[1];
-    const float2 o1 = make_float2(h * (a[3].x + a[3].y), h * (a[3].y - a[3].x));   // * (h, -h)
-    const float2 o2 = make_float2(a[5].y, -a[5].x);                                // * (-i)
-    const float2 o3 = make_float2(h * (a[7].y - a[7].x), -h * (a[7].x + a[7].y));  // * (-h, -h)
-    const float2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
-    a[0] = cadd(e0, o0);
-    a[4] = csub(e0, o0);
-    a[1] = cadd(e1, o1);
-    a[5] = csub(e1, o1);
-    a[2] = cadd(e2, o2);
-    a[6] = csub(e2, o2);
-    a[3] = cadd(e3, o3);
-    a[7] = csub(e3, o3);
-}
-
-constexpr int radix_of(int L) { return L >= 8 ? 8 : L; }   // greedy radix-8, then one radix-4 or radix-2 pass
-
-// position of frequency f after the in-place DIF passes (mixed-radix digit reversal)
-template <int N>
-__device__ __forceinline__ int revpos(int f) {
-    int pos = 0, L = N;
-#pragma unroll
-    for (int it = 0; it < 12; it++) {
-        if (L == 1) break;
-        const int R = radix_of(L);
-        pos += (f % R) * (L / R);
-        f /= R;
-        L /= R;
-    }
-    return pos;
-}
-
-// padded position of element base + r * LR: when LR is a multiple of the padding period the pad term is additive, so the
-// R addresses of a butterfly are one computed address plus compile-time offsets (immediate offsets of the LDS instructions)
-template <int LR>
-__device__ __forceinline__ int padq_strided(int base, int r) {
-    if constexpr (LR % (1 << PADSHIFT) == 0) return padq(base) + r * (LR + (LR >> PADSHIFT));
-    else return padq(base + r * LR);
-}
-
-// one DIF pass of sub-length L over `ncol` columns of N elements each (column c at lds + c*colpitch, padded index)
-template <int N, int L, int R, int NT = FFT_THREADS>
-__device__ __forceinline__ void dif_pass(float2 *lds, int colpitch, int ncol, const float2 *tw) {
-    constexpr int BPC = N / R;      // butterflies per column
-    constexpr int LR = L / R;
-    const int total = ncol * BPC;
-    for (int b = threadIdx.x; b < total; b += NT) {
-        const int col = b / BPC, t = b % BPC;
-        const int blk = t / LR, j = t % LR;
-        float2 *c = lds + col * colpitch;
-        const int base = blk * L + j;
-        float2 a[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) a[r] = c[padq_strided<LR>(base, r)];
-        dft<R>(a);
-        if (L > R) {   // the last pass has j = 0: all twiddles are one
-#pragma unroll
-            for (int r = 1; r < R; r++) a[r] = cmul(a[r], tw[j * r * (N / L)]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) c[padq_strided<LR>(base, r)] = a[r];
-    }
-    __syncthreads();
-}
-
-// frequency held at position `pos` after the in-place DIF passes (inverse of revpos)
-template <int N>
-__device__ __forceinline__ int freq_of_pos(int pos) {
-    int f = 0, L = N, w = 1;
-#pragma unroll
-    for (int it = 0; it < 12; it++) {
-        if (L == 1) break;
-        const int R = radix_of(L);
-        const int d = pos / (L / R);
-        pos -= d * (L / R);
-        f += d * w;
-        w *= R;
-        L /= R;
-    }
-    return f;
-}
-
-// The last pass (L == R, no twiddles), writing NATURAL order: every butterfly of the workgroup is loaded and transformed
-// into registers first, then - behind a barrier, the writes land on other threads' inputs - element f goes to position
-// f.  The write-backs then read consecutive positions: conflict-free, where digit-reversed reads of consecutive
-// frequencies land 4 (z pass) or 2 (column passes) lanes on every bank pair.
-template <int N, int R, int NT, int MAXCOL>
-__device__ __forceinline__ void dif_last_natural(float2 *lds, int colpitch, int ncol) {
-    constexpr int BPC = N / R;
-    constexpr int MAXIT = (MAXCOL * BPC + NT - 1) / NT;
-    const int total = ncol * BPC;
-    float2 a[MAXIT][R];
-#pragma unroll
-    for (int it = 0; it < MAXIT; it++) {
-        const int b = it * NT + threadIdx.x;
-        if (b < total) {
-            const int col = b / BPC, t = b % BPC;
-            const float2 *c = lds + col * colpitch;
-#pragma unroll
-            for (int r = 0; r < R; r++) a[it][r] = c[padq(t * R + r)];
-            dft<R>(a[it]);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < MAXIT; it++) {
-        const int b = it * NT + threadIdx.x;
-        if (b < total) {
-            const int col = b / BPC, t = b % BPC;
-            float2 *c = lds + col * colpitch;
-            const int f0 = freq_of_pos<N>(t * R);          // position t*R + r holds frequency f0 + r * (N / R)
-#pragma unroll
-            for (int r = 0; r < R; r++) c[padq(f0 + r * (N / R))] = a[it][r];
-        }
-    }
-    __syncthreads();
-}
-
-// MAXCOL > 0: the last pass leaves natural order (dif_last_natural, MAXCOL = most columns a tile can hold);
-// MAXCOL = 0: every pass in place, frequency f at revpos(f) - the column passes at N = 1024 x 16 columns would need
-// 32 more complex registers per thread next to the 64 prefetch registers and spill.
-template <int N, int L, int NT = FFT_THREADS, int MAXCOL = 0>
-struct Passes {
-    static __device__ __forceinline__ void run(float2 *lds, int colpitch, int ncol, const float2 *tw) {
-        constexpr int R = radix_of(L);
-        if constexpr (L == R && MAXCOL > 0) {
-            dif_last_natural<N, R, NT, MAXCOL>(lds, colpitch, ncol);
-        } else {
-            dif_pass<N, L, R, NT>(lds, colpitch, ncol, tw);
-            if constexpr (L > R) Passes<N, L / R, NT, MAXCOL>::run(lds, colpitch, ncol, tw);
-        }
-    }
-};
-
-// ---- wave-local transforms: one 64-lane wave owns a whole column (N >= 512: at least 64 butterflies per pass) --------
-// A column's passes then need no workgroup barrier at all - LDS executes one wave's instructions in order, so a wave-level
-// fence between the passes is enough - and the waves of a workgroup drift apart, hiding each other's LDS latency.  The
-// last pass holds only N/64 complex values per lane, so it can always leave natural order.
-template <int N, int L, int R>
-__device__ __forceinline__ void butterfly_w(float2 *c, const float2 *tw, int t) {
-    constexpr int LR = L / R;
-    const int blk = t / LR, j = t % LR;
-    const int base = blk * L + j;
-    float2 a[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) a[r] = c[padq_strided<LR>(base, r)];
-    dft<R>(a);
-#pragma unroll
-    for (int r = 1; r < R; r++) a[r] = cmul(a[r], tw[j * r * (N / L)]);
-#pragma unroll
-    for (int r = 0; r < R; r++) c[padq_strided<LR>(base, r)] = a[r];
-}
-
-// UNR: unroll the butterflies of one lane (more LDS reads in flight; the column pass at N = 1024 has no registers to spare)
-template <int N, int L, int R, bool UNR>
-__device__ __forceinline__ void dif_pass_w(float2 *c, const float2 *tw, int lane) {
-    constexpr int BPC = N / R;
-    static_assert(BPC % 64 == 0, "wave-local passes need a multiple of 64 butterflies per column");
-    if constexpr (UNR) {
-#pragma unroll
-        for (int t0 = 0; t0 < BPC; t0 += 64) butterfly_w<N, L, R>(c, tw, t0 + lane);
-    } else {
-#pragma unroll 1
-        for (int t0 = 0; t0 < BPC; t0 += 64) butterfly_w<N, L, R>(c, tw, t0 + lane);
-    }
-    wave_sync();
-}
-
-template <int N, int R>
-__device__ __forceinline__ void dif_last_w(float2 *c, int lane) {
-    constexpr int BPC = N / R, IT = BPC / 64;
-    static_assert(BPC % 64 == 0, "wave-local passes need a multiple of 64 butterflies per column");
-    float2 a[IT][R];
-#pragma unroll
-    for (int it = 0; it < IT; it++) {
-        const int t = it * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < R; r++) a[it][r] = c[padq(t * R + r)];
-        dft<R>(a[it]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int it = 0; it < IT; it++) {
-        const int f0 = freq_of_pos<N>((it * 64 + lane) * R);
-#pragma unroll
-        for (int r = 0; r < R; r++) c[padq(f0 + r * (N / R))] = a[it][r];
-    }
-}
-
-template <int N, int L, bool UNR = false>
-struct PassesW {
-    static __device__ __forceinline__ void run(float2 *c, const float2 *tw, int lane) {
-        constexpr int R = radix_of(L);
-        if constexpr (L == R) {
-            dif_last_w<N, R>(c, lane);
-        } else {
-            dif_pass_w<N, L, R, UNR>(c, tw, lane);
-            PassesW<N, L / R, UNR>::run(c, tw, lane);
-        }
-    }
-};
-constexpr bool wave_local(int N) { return N == 512 || N == 1024; }   // the production sizes (n = 1024, 2048)
-
-template <int N>
-constexpr int colpitch_of() { return N + (N >> PADSHIFT) + 1; }   // odd: adjacent columns fall into different banks
+#include "fft_device.hpp"
 
 // ---- z pass: real rows -> half-spectrum rows, in place ---------------------------------------------------------
 // N = n/2.  mesh rows have `pitch_r` floats; row r of the (n*n) rows starts at r*pitch_r.  Persistent workgroups:
@@ -697,11 +426,18 @@ int fft_native_r2c_inplace(float *mesh, int n, int pitch_r) {
     return fft_native_x(mesh, n, pitch_r, n, (int64_t)n * (pitch_r / 2), pitch_r / 2);
 }
 
+const float2 *fft_twiddles(int n) {
+    Tables *t;
+    if (get_tables(n, &t) != 0) return nullptr;
+    return t->twN.as<float2>();
+}
+int fft_num_cus() { return num_cus(); }
+
 // Full-mesh transform with the first radix-2 stage of y and x fused into the z pass (see fft_z_r2c<.., FUSE>): the y and
 // x passes are n/2-point column transforms with C columns.  Output rows are in the permuted order
 // f = 2 (r mod n/2) + (r div n/2) along x and y (power.hip's binning undoes it in its index arithmetic).
 template <int N, int C>
-int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th) {
+int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x) {
     constexpr int H = N / 2;
     const int pitch_c = pitch_r / 2, kzlen = N / 2 + 1;
     const int ntile_c = (kzlen + C - 1) / C;
@@ -711,6 +447,7 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th) {
     // y: 2 N half-planes of H rows each, contiguous in memory
     ABACUS_TRY((launch_cols<H, C>("fft_cols_y", data, pitch_c, ntile_c, 2 * (int64_t)N, (int64_t)H * pitch_c,
                                   th->twN.as<float2>())));
+    if (!with_x) return 0;   // the caller runs the last pass fused with the binning (xbin.hip)
     // x: for every y and either half of x, H planes apart by N * pitch_c
     const int64_t S = (int64_t)N * pitch_c;
     return launch_cols<H, C>("fft_cols_x", data, S, ntile_c, 2 * (int64_t)N, pitch_c, th->twN.as<float2>(), N, (int64_t)H * S);
@@ -719,17 +456,20 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th) {
 // n = 256 only on request (tests against the CPU oracle): small meshes gain nothing from the fused form
 int fft_native_fused_supported(int n) { return n == 2048 || n == 1024 || (n == 256 && getenv("ABACUS_FFT_FUSE_SMALL")); }
 
-int fft_native_r2c_fused(float *mesh, int n, int pitch_r) {
+static int fused_impl(float *mesh, int n, int pitch_r, bool with_x) {
     Tables *t, *th;
     ABACUS_TRY(get_tables(n, &t));
     ABACUS_TRY(get_tables(n / 2, &th));
     switch (n) {
-        case 256: return fft3d_fused<256, 16>(mesh, pitch_r, t, th);
-        case 1024: return fft3d_fused<1024, 16>(mesh, pitch_r, t, th);
-        case 2048: return fft3d_fused<2048, 16>(mesh, pitch_r, t, th);
+        case 256: return fft3d_fused<256, 16>(mesh, pitch_r, t, th, with_x);
+        case 1024: return fft3d_fused<1024, 16>(mesh, pitch_r, t, th, with_x);
+        case 2048: return fft3d_fused<2048, 16>(mesh, pitch_r, t, th, with_x);
     }
     return fail("fft: the fused transform supports n = 1024 and 2048");
 }
+int fft_native_r2c_fused(float *mesh, int n, int pitch_r) { return fused_impl(mesh, n, pitch_r, true); }
+// z and y passes only: the x pass is left to fft_x_bin_run (last pass fused with the binning)
+int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r) { return fused_impl(mesh, n, pitch_r, false); }
 
 int fft_native_release() {
     for (auto &kv : g_tables) {

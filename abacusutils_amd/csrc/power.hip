@@ -32,6 +32,7 @@
 
 #include "../../include/abacus_hip.h"
 #include "common.hpp"
+#include "bin_device.hpp"
 
 using namespace abacus;
 
@@ -48,11 +49,13 @@ int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int
 int fft_native_release();
 int fft_native_fused_supported(int n);
 int fft_native_r2c_fused(float *mesh, int n, int pitch_r);   // rows come out in the permuted order of fft.hip's fused form
+int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r);
+bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
+int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg);
 }  // namespace abacus
 
 namespace {
 
-constexpr int MAX_POLES = 8;     // requested multipoles
 constexpr int BIN_THREADS = 1024;
 
 struct SpecArgs {
@@ -150,29 +153,6 @@ __global__ void spectrum_apply(SpecArgs s, float2 *out) {
         const float2 w = s.interlaced ? s.as[idx] : make_float2(0.f, 0.f);
         out[idx] = finish_value(s, s.a[idx], w, i, j, k, s.W, s.phase);
     }
-}
-
-struct BinArgs {
-    int Nk, Nmu, Np;          // Np = number of requested poles with ell != 0 (ell = 0 comes from the wedges)
-    const float *kedges2;     // (Nk+1) f32((kedges/dk)^2)  (:217)
-    const float *muedges2;    // (Nmu+1) f32(muedges^2)     (:218)
-    float polecoef[MAX_POLES][6];   // (2l+1) * P_l as a polynomial in mu^2: sum_m c[m] * (mu^2)^m
-    int poledeg[MAX_POLES];         // l/2
-    int dbg;                        // ablation switches (ABACUS_DBG): 1 skip binning, 2 skip staging
-    unsigned long long *g_cnt;      // (Nk*Nmu)
-    double *g_sum, *g_ksum;         // (Nk*Nmu)
-    double *g_pole;                 // (Np*Nk)
-};
-
-// number of edges[1..N] strictly below v  ==  the bin the reference's `while v > edges[b+1]: b += 1` stops at
-__device__ __noinline__ int lower_bin(const float *edges, int N, float v) {
-    int lo = 0, hi = N;   // answer in [lo, hi]
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (v > edges[mid + 1]) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
 }
 
 // Tile geometry: a tile is a flat range of the (pitched) half-spectrum, EPT consecutive elements per thread.
@@ -682,7 +662,7 @@ bool use_fused_fft(int nmesh) {
 }
 
 int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, int paste, int interlaced, int slot,
-                  bool fused = false) {
+                  bool fused = false, bool skip_x = false) {
     if (n <= 0) return fail("power: empty particle set");
     const bool native = fft_native_supported(nmesh) && !getenv("ABACUS_FFT_HIPFFT");
     hipfftHandle plan = 0;
@@ -703,7 +683,7 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
         ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste,
                                    interlaced ? (s == 0 ? 1 : 2) : 0));
         if (native && fused) {
-            ABACUS_TRY(fft_native_r2c_fused(mesh, nmesh, (int)zstride));
+            ABACUS_TRY(skip_x ? fft_native_r2c_fused_zy(mesh, nmesh, (int)zstride) : fft_native_r2c_fused(mesh, nmesh, (int)zstride));
         } else if (native) {
             ABACUS_TRY(fft_native_r2c_inplace(mesh, nmesh, (int)zstride));   // fft.hip: three passes, one per axis
         } else {
@@ -787,44 +767,67 @@ int finalize_bins(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *
     return 0;
 }
 
-int run_bin(const SpecArgs &s_in, double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu,
-            const int64_t *poles, int Np_all, float *power, int64_t *N_mode, float *binned_poles,
-            int64_t *N_mode_poles, float *k_avg, void *raw_out = nullptr, double dk_ = 0, double scale = 0) {
-    SpecArgs s = s_in;
-    s.lds_tables = 0;
+// host side of a binning launch: pole coefficients, squared float32 edges (:217-218) and zeroed accumulators on the device
+int prepare_bins(double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np_all,
+                 double dk_, BinArgs &b, size_t &acc_bytes) {
     if (Nk < 1 || Nmu < 1) return fail("power: need at least one k bin and one mu bin");
     if (Np_all > MAX_POLES) return fail("power: more than %d multipoles requested", MAX_POLES);
     const double dk = dk_ > 0 ? dk_ : 2.0 * M_PI / Lbox;
-    BinArgs b;
     b.Nk = Nk;
     b.Nmu = Nmu;
     b.dbg = getenv("ABACUS_DBG") ? atoi(getenv("ABACUS_DBG")) : 0;
-    int nz_index[MAX_POLES];   // requested pole -> slot among the ell != 0 accumulators
     b.Np = 0;
-    for (int q = 0; q < Np_all; q++) {
-        nz_index[q] = -1;
-        if (poles[q] != 0) {
+    for (int q = 0; q < Np_all; q++)
+        if (poles[q] != 0) {   // requested pole -> slot among the ell != 0 accumulators, in order
             ABACUS_TRY(pole_coefs((int)poles[q], b.polecoef[b.Np]));
             b.poledeg[b.Np] = (int)poles[q] / 2;
-            nz_index[q] = b.Np++;
+            b.Np++;
         }
-    }
     // edges in units of dk, squared, float32 (:217-218)
     std::vector<float> e2((size_t)Nk + 1 + Nmu + 1);
     for (int q = 0; q <= Nk; q++) e2[q] = (float)((kedges[q] / dk) * (kedges[q] / dk));
     for (int q = 0; q <= Nmu; q++) e2[Nk + 1 + q] = (float)(muedges[q] * muedges[q]);
     ABACUS_TRY(g_ctx.edges.reserve(e2.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(g_ctx.edges.p, e2.data(), e2.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));   // e2 is a local
     b.kedges2 = g_ctx.edges.as<float>();
     b.muedges2 = b.kedges2 + Nk + 1;
     const size_t nb = (size_t)Nk * Nmu, npk = (size_t)b.Np * Nk;
-    const size_t acc_bytes = nb * 8 * 3 + npk * 8;
+    acc_bytes = nb * 8 * 3 + npk * 8;
     ABACUS_TRY(g_ctx.accum.reserve(acc_bytes));
     HIP_TRY(hipMemsetAsync(g_ctx.accum.p, 0, acc_bytes, stream()));
     b.g_cnt = g_ctx.accum.as<unsigned long long>();
     b.g_sum = reinterpret_cast<double *>(b.g_cnt + nb);
     b.g_ksum = b.g_sum + nb;
     b.g_pole = b.g_ksum + nb;
+    return 0;
+}
+
+// tiny read-back of the raw sums - counts (u64), sum P, sum k, pole sums (f64) - and bin_kmu's normalisation
+int collect_bins(size_t acc_bytes, double Lbox, int Nk, int Nmu, const int64_t *poles, int Np_all, float *power,
+                 int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg, void *raw_out, double dk, double scale) {
+    if (raw_out) {
+        HIP_TRY(hipMemcpyAsync(raw_out, g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        return 0;
+    }
+    std::vector<unsigned char> host(acc_bytes);
+    HIP_TRY(hipMemcpyAsync(host.data(), g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return finalize_bins(host.data(), Lbox, Nk, Nmu, poles, Np_all, power, N_mode, binned_poles, N_mode_poles, k_avg, dk,
+                         scale);
+}
+
+int run_bin(const SpecArgs &s_in, double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu,
+            const int64_t *poles, int Np_all, float *power, int64_t *N_mode, float *binned_poles,
+            int64_t *N_mode_poles, float *k_avg, void *raw_out = nullptr, double dk_ = 0, double scale = 0) {
+    SpecArgs s = s_in;
+    s.lds_tables = 0;
+    const double dk = dk_ > 0 ? dk_ : 2.0 * M_PI / Lbox;
+    BinArgs b;
+    size_t acc_bytes = 0;
+    ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np_all, dk_, b, acc_bytes));
+    const size_t nb = (size_t)Nk * Nmu, npk = (size_t)b.Np * Nk;
     // LDS budget: histogram + edges + tile
     const size_t hist_bytes = nb * (8 + 8 + 4) + npk * 8 + (size_t)(Nk + 1 + Nmu + 1) * 4 + 64;
     const size_t lds_max = 160 * 1024;
@@ -865,17 +868,8 @@ int run_bin(const SpecArgs &s_in, double Lbox, const double *kedges, int Nk, con
     else LAUNCH_NP(false, false);
 #undef LAUNCH_NP
 #undef LAUNCH_BIN
-    // tiny read-back of the raw sums: counts (u64), sum P, sum k, pole sums (f64)
-    if (raw_out) {
-        HIP_TRY(hipMemcpyAsync(raw_out, g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
-        HIP_TRY(hipStreamSynchronize(stream()));
-        return 0;
-    }
-    std::vector<unsigned char> host(acc_bytes);
-    HIP_TRY(hipMemcpyAsync(host.data(), g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
-    HIP_TRY(hipStreamSynchronize(stream()));
-    return finalize_bins(host.data(), Lbox, Nk, Nmu, poles, Np_all, power, N_mode, binned_poles, N_mode_poles, k_avg, dk,
-                         scale);
+    return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np_all, power, N_mode, binned_poles, N_mode_poles, k_avg, raw_out, dk,
+                        scale);
 }
 
 int upload_W(const float *W_host, int nmesh, const float **W_dev) {
@@ -902,8 +896,21 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
     const float *W_dev;
     ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
     const bool fused = use_fused_fft(nmesh);
-    ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, fused));
     const bool cross = pos2 != nullptr;
+    if (fused && !interlaced && !cross && !getenv("ABACUS_PK_NOXBIN")) {
+        // auto power of one field: the last FFT pass bins straight from LDS (xbin.hip) - no spectrum write + re-read
+        BinArgs b;
+        size_t acc_bytes = 0;
+        ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
+        if (xbin_supported(nmesh, Nk, Nmu, b, W_dev != nullptr)) {
+            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 0, 0, true, /*skip_x=*/true));
+            const double M = (double)nmesh * nmesh * nmesh;
+            ABACUS_TRY(fft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg));
+            return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
+                                2.0 * M_PI / Lbox, 0);
+        }
+    }
+    ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, fused));
     if (cross) ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, interlaced, 2, fused));
     SpecArgs s;
     fill_spec(s, nmesh, 1, interlaced, W_dev, cross);

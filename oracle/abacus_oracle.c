@@ -604,9 +604,59 @@ static float P_n_f32(float x, int n) {
  * accum64 = 1: float64 accumulators, OpenMP over kx planes (the yardstick for the GPU path).
  * Outputs: power[Nk*Nmu] f32, counts[Nk*Nmu] i64, poles[Np*Nk] f32, counts_poles[Nk] i64, kavg[Nk*Nmu] f32.
  */
+/* weight of mode (i, j, k) when the spectrum is known in closed form: |amp * sum_t X_t[i] Y_t[j] Z_t[k]|^2 /
+ * (cx[i] cy[j] cz[k])^2 - a sum of T separable complex terms (tabs: [T][3][n1d] complex128 as re, im pairs), an optional
+ * real separable divisor (comp: [3][n1d] or NULL).  Used for the analytic known answers of the full-size tests: the
+ * discrete Fourier transform of the TSC / CIC cloud of a handful of particles is such a sum (one term per particle). */
+typedef struct {
+    int T;
+    const double *tabs;
+    const double *comp;
+    double amp;
+} sep_spec;
+
+static inline float sep_weight(const sep_spec *sp, int n1d, int i, int j, int k) {
+    double re = 0, im = 0;
+    for (int t = 0; t < sp->T; t++) {
+        const double *X = sp->tabs + ((size_t)(t * 3 + 0) * n1d + i) * 2;
+        const double *Y = sp->tabs + ((size_t)(t * 3 + 1) * n1d + j) * 2;
+        const double *Z = sp->tabs + ((size_t)(t * 3 + 2) * n1d + k) * 2;
+        const double xr = X[0] * Y[0] - X[1] * Y[1], xi = X[0] * Y[1] + X[1] * Y[0];
+        re += xr * Z[0] - xi * Z[1];
+        im += xr * Z[1] + xi * Z[0];
+    }
+    re *= sp->amp, im *= sp->amp;
+    if (sp->comp) {
+        const double c = sp->comp[i] * sp->comp[n1d + j] * sp->comp[2 * (size_t)n1d + k];
+        re /= c, im /= c;
+    }
+    return (float)(re * re + im * im);
+}
+
+static int bin_kmu_core(int n1d, double L, const double *kedges, int Nk, const double *muedges, int Nmu,
+                        const float *weights, const sep_spec *sep, const int64_t *poles, int Np, int fourier, int accum64,
+                        int nthread, float *power, int64_t *counts, float *binned_poles, int64_t *counts_poles, float *kavg);
+
 int oracle_bin_kmu(int n1d, double L, const double *kedges, int Nk, const double *muedges, int Nmu,
                    const float *weights, const int64_t *poles, int Np, int fourier, int accum64, int nthread,
                    float *power, int64_t *counts, float *binned_poles, int64_t *counts_poles, float *kavg) {
+    return bin_kmu_core(n1d, L, kedges, Nk, muedges, Nmu, weights, NULL, poles, Np, fourier, accum64, nthread, power, counts,
+                        binned_poles, counts_poles, kavg);
+}
+
+/* bin_kmu (float64 accumulation) of a spectrum given as a sum of separable terms: nothing of mesh size is stored, so the
+ * 2048^3 known answers cost seconds on the host cores */
+int oracle_bin_kmu_separable(int n1d, double L, const double *kedges, int Nk, const double *muedges, int Nmu, int T,
+                             const double *tabs, const double *comp, double amp, const int64_t *poles, int Np, int nthread,
+                             float *power, int64_t *counts, float *binned_poles, int64_t *counts_poles, float *kavg) {
+    sep_spec sp = {T, tabs, comp, amp};
+    return bin_kmu_core(n1d, L, kedges, Nk, muedges, Nmu, NULL, &sp, poles, Np, 1, 1, nthread, power, counts, binned_poles,
+                        counts_poles, kavg);
+}
+
+static int bin_kmu_core(int n1d, double L, const double *kedges, int Nk, const double *muedges, int Nmu,
+                        const float *weights, const sep_spec *sep, const int64_t *poles, int Np, int fourier, int accum64,
+                        int nthread, float *power, int64_t *counts, float *binned_poles, int64_t *counts_poles, float *kavg) {
     const int kzlen = n1d / 2 + 1;
     const double dk = fourier ? 2.0 * M_PI / L : L / n1d;
     float *kedges2 = malloc((Nk + 1) * sizeof(float));
@@ -644,7 +694,7 @@ int oracle_bin_kmu(int n1d, double L, const double *kedges, int Nk, const double
                 if (kmag2 >= kedges2[Nk]) break;
                 while (kmag2 > kedges2[bk + 1]) bk++;
                 while (bmu + 1 < Nmu && mu2 > muedges2[bmu + 1]) bmu++;
-                float w = weights[((int64_t)i * n1d + j) * kzlen + k];
+                float w = weights ? weights[((int64_t)i * n1d + j) * kzlen + k] : sep_weight(sep, n1d, i, j, k);
                 size_t b = (size_t)bk * Nmu + bmu;
                 cnt[tid * nb + b] += k == 0 ? 1 : 2;
                 if (accum64) {

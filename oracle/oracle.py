@@ -353,6 +353,80 @@ def bin_kmu(n1d, L, kedges, muedges, weights, poles=np.empty(0, 'i8'), fourier=T
     return power, counts, bpoles, cpoles, kavg
 
 
+def particle_cloud_tables(pos, w, Lbox, nmesh, paste='TSC', offset=0.0):
+    """[P][3][nmesh] complex128: per particle and dimension, the discrete Fourier transform of its 1-D mass-assignment
+    cloud on the mesh, sum_s w_s exp(-2 pi i m c_s / n) for every integer frequency index m (the TSC / CIC weights of
+    analysis/tsc.py:424-436 / analysis/cic.py evaluated in float64; the particle weight multiplies the x table).  The 3-D
+    transform of the deposited mesh is sum_p X_p[i] Y_p[j] Z_p[k]: exact, aliasing included."""
+    pos = np.asarray(pos, dtype=np.float64)
+    P = len(pos)
+    w = np.ones(P) if w is None else np.asarray(w, dtype=np.float64)
+    m = np.arange(nmesh)
+    tabs = np.zeros((P, 3, nmesh), dtype=np.complex128)
+    for p in range(P):
+        for d in range(3):
+            x = (pos[p, d] + offset) * (nmesh / Lbox)
+            if paste.upper() == 'TSC':
+                c = np.rint(x)                      # round half to even, like the reference's round()
+                dd = c - x
+                cells = [(c - 1, 0.5 * (0.5 + dd) ** 2), (c, 0.75 - dd * dd), (c + 1, 0.5 * (0.5 - dd) ** 2)]
+            else:
+                c = np.floor(x)
+                f = x - c
+                cells = [(c, 1 - f), (c + 1, f)]
+            t = sum(ws * np.exp(-2j * np.pi * m * (cs % nmesh) / nmesh) for cs, ws in cells)
+            tabs[p, d] = t * (w[p] if d == 0 else 1.0)
+    return tabs
+
+
+def pk_of_particles_analytic(pos, w, Lbox, nmesh, kedges, muedges, poles, paste='TSC', compensated=False, interlaced=False,
+                             nthread=1):
+    """calc_power (analysis/power_spectrum.py:1131-1319) of a HANDFUL of particles in closed form: delta_k = (1/N) sum_p
+    [cloud transform], the interlaced combination (:904-948) as a second set of separable terms, the compensation window
+    (:1081-1128) as a separable divisor, then bin_kmu's rule with float64 sums - nothing of mesh size is allocated, so the
+    known answer at 2048^3 costs seconds.  Returns the columns of the Table as a dict."""
+    pos = np.asarray(pos, dtype=np.float64)
+    P = len(pos)
+    tabs = particle_cloud_tables(pos, w, Lbox, nmesh, paste)
+    amp = 1.0 / P                                 # rho * (M / len(pos)) / M; the -1 only touches k = 0
+    if interlaced:
+        d = Lbox / nmesh
+        sh = particle_cloud_tables(pos, w, Lbox, nmesh, paste, offset=0.5 * d)
+        m = np.arange(nmesh)
+        kk = np.where(m < nmesh // 2, m, m - nmesh)           # Nyquist takes the negative branch (:940-942)
+        phase = np.exp(1j * np.pi * kk / nmesh)               # exp(i (d/2) k), k = kk * 2 pi / L
+        sh = sh * phase[None, None, :]
+        tabs = np.concatenate([tabs, sh])
+        amp *= 0.5
+    comp = None
+    if compensated:
+        W = get_W_compensated(Lbox, nmesh, paste, interlaced).astype(np.float64)
+        comp = np.ascontiguousarray(np.stack([W, W, W]))
+    kedges, muedges = _f8(kedges), _f8(muedges)
+    poles_arr = np.ascontiguousarray(poles if poles is not None else [], dtype=np.int64)
+    Nk, Nmu, Np = len(kedges) - 1, len(muedges) - 1, len(poles_arr)
+    power = np.zeros((Nk, Nmu), dtype=np.float32)
+    counts = np.zeros((Nk, Nmu), dtype=np.int64)
+    bpoles = np.zeros((Np, Nk), dtype=np.float32)
+    cpoles = np.zeros(Nk, dtype=np.int64)
+    kavg = np.zeros((Nk, Nmu), dtype=np.float32)
+    tri = np.ascontiguousarray(np.stack([tabs.real, tabs.imag], axis=-1))      # [T][3][n][2]
+    lib().oracle_bin_kmu_separable(int(nmesh), _D(Lbox), _ptr(kedges), Nk, _ptr(muedges), Nmu, int(len(tabs)), _ptr(tri),
+                                   _ptr(comp), _D(amp), _ptr(poles_arr), Np, int(nthread), _ptr(power), _ptr(counts),
+                                   _ptr(bpoles), _ptr(cpoles), _ptr(kavg))
+    # the k = 0 mode carries sum(w)/N - 1, not sum(w)/N (the window is 1 there): correct the bin that holds it (it is
+    # binned iff kedges[0] <= 0); mu = 0 for the zero vector (:243)
+    if kedges[0] <= 0 and counts[0, 0] > 0:
+        d0 = (float(np.sum(w)) if w is not None else float(P)) / P
+        fix = (d0 - 1.0) ** 2 - d0 ** 2
+        power[0, 0] += np.float32(fix / counts[0, 0])
+        for ip, ell in enumerate(poles_arr):
+            pw = 1.0 if ell == 0 else (2 * ell + 1) * float(np.polynomial.legendre.legval(0.0, [0] * int(ell) + [1]))
+            bpoles[ip, 0] += np.float32(fix * pw / cpoles[0])
+    L3 = Lbox ** 3
+    return dict(power=power * np.float32(L3), N_mode=counts, poles=(bpoles * np.float32(L3)).T, N_mode_poles=cpoles, k_avg=kavg)
+
+
 def calc_pk_from_deltak(field_fft, Lbox, k_bin_edges, mu_bin_edges, field2_fft=None, poles=np.empty(0, 'i8'),
                         squeeze_mu_axis=True, nthread=1, accum64=False):
     """analysis/power_spectrum.py:730-805"""

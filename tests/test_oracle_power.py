@@ -116,3 +116,29 @@ def test_shot_noise_known_answer():
     tab = oracle.calc_power(pos, 1000.0, kbins=8, paste='TSC', nmesh=64, compensated=True, interlaced=True,
                             nthread=4, accum64=True)
     assert abs(np.mean(tab['power'][2:]) / (1000.0**3 / 200000) - 1) < 0.02
+
+
+@pytest.mark.parametrize('paste', ['TSC', 'CIC'])
+@pytest.mark.parametrize('comp,inter', [(False, False), (True, False), (False, True), (True, True)])
+def test_analytic_known_answer_matches_calc_power(paste, comp, inter):
+    """the closed-form evaluator behind the full-size known-answer tests (oracle.pk_of_particles_analytic: cloud
+    transforms of a handful of particles as separable terms, no mesh) against the oracle's calc_power - itself pinned to
+    the reference by the golden vectors - on a mesh small enough to build"""
+    from oracle import oracle
+    L, nmesh = 300.0, 48
+    rng = np.random.default_rng(17)
+    pos = (rng.random((6, 3)) * L).astype(np.float32)
+    pos[0] = (np.floor(pos[0] / (L / nmesh)) + 0.5) * (L / nmesh)   # one particle exactly half-way between cell centres
+    w = (rng.random(6) + 0.5).astype(np.float32)
+    kw = dict(kbins=12, mubins=3, k_max=np.pi * nmesh / L, paste=paste, nmesh=nmesh, compensated=comp, interlaced=inter,
+              poles=[0, 2, 4])
+    ref = oracle.calc_power(pos.copy(), L, w=w, nthread=2, accum64=True, **kw)
+    kedges = np.concatenate([ref['k_min'], ref['k_max'][-1:]])
+    muedges = np.linspace(0, 1, 4)
+    got = oracle.pk_of_particles_analytic(pos, w, L, nmesh, kedges, muedges, [0, 2, 4], paste=paste, compensated=comp,
+                                          interlaced=inter, nthread=2)
+    np.testing.assert_array_equal(got['N_mode'], ref['N_mode'])
+    scale = np.abs(ref['power']).max()
+    np.testing.assert_allclose(got['power'], ref['power'], rtol=5e-6, atol=5e-6 * scale)
+    np.testing.assert_allclose(got['poles'], ref['poles'], rtol=5e-6, atol=5e-6 * scale)
+    np.testing.assert_allclose(got['k_avg'], ref['k_avg'], rtol=1e-6)

@@ -375,3 +375,78 @@ def test_random_option_sweep(seed):
     _check_oracle(tab, ref, rtol=1e-5 if kw['paste'] == 'TSC' else 3e-5)
     if 'N_mode_poles' in ref:
         np.testing.assert_array_equal(np.asarray(tab['N_mode_poles']), ref['N_mode_poles'])
+
+
+def _kmu_edges(res, nmu):
+    return np.concatenate([np.asarray(res['k_min']), np.asarray(res['k_max'])[-1:]]), np.linspace(0, 1, nmu + 1)
+
+
+@pytest.mark.parametrize('comp,inter', [(False, False), (True, True), (True, False)])
+def test_full_size_2048_analytic_known_answer(comp, inter):
+    """nmesh 2048 against a closed form: a handful of weighted particles at generic positions; the
+    discrete transform of their TSC clouds is a sum of separable terms, evaluated in float64 and binned by bin_kmu's rule
+    without any mesh (oracle.pk_of_particles_analytic, itself held to the oracle's calc_power on a buildable mesh by
+    tests/test_oracle_power.py).  Every (k, mu) bin, the multipoles and k_avg to 1e-5; N_mode exact - over all 4.3e9
+    modes, through the fused last pass (non-interlaced) and through spectrum_bin (interlaced + compensated)."""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    box, nmesh = 2000.0, 2048
+    rng = np.random.default_rng(41)
+    pos = (rng.random((7, 3)) * box).astype(np.float32)
+    pos[0] = (np.floor(pos[0] / (box / nmesh)) + 0.5) * (box / nmesh)      # half-way between cell centres (round-half-even)
+    pos[1] = np.floor(pos[1] / (box / nmesh)) * (box / nmesh)              # exactly on a cell centre
+    w = (rng.random(7) + 0.5).astype(np.float32)
+    kw = dict(kbins=128, mubins=4, k_max=np.pi * nmesh / box, paste='TSC', nmesh=nmesh, poles=[0, 2, 4], compensated=comp,
+              interlaced=inter)
+    got = calc_power(pos.copy(), box, w=w, **kw)
+    kedges, muedges = _kmu_edges(got, 4)
+    want = oracle.pk_of_particles_analytic(pos, w, box, nmesh, kedges, muedges, [0, 2, 4], paste='TSC', compensated=comp,
+                                           interlaced=inter, nthread=oracle.max_threads())
+    np.testing.assert_array_equal(np.asarray(got['N_mode']), want['N_mode'])
+    np.testing.assert_array_equal(np.asarray(got['N_mode_poles']), want['N_mode_poles'])
+    scale = np.abs(want['power']).max()
+    np.testing.assert_allclose(np.asarray(got['power']), want['power'], rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(np.asarray(got['poles']), want['poles'], rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(np.asarray(got['k_avg']), want['k_avg'], rtol=1e-6)
+
+
+def test_c3_full_size_against_oracle():
+    """BASELINE config 3 at full size: 1e8 uniform particles (seed 300) -> 1024^3 TSC + FFT + binning,
+    HIP against the CPU oracle (float64 accumulation) on the same inputs: N_mode exact, P(k, mu), multipoles <= 1e-5"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    n, box, nmesh = 100_000_000, 2000.0, 1024
+    pos = np.random.default_rng(300).random((n, 3), dtype=np.float32) * np.float32(box)
+    kw = dict(kbins=512, mubins=4, k_max=np.pi * nmesh / box + 1e-6, paste='TSC', nmesh=nmesh, poles=[0, 2, 4],
+              compensated=False, interlaced=False)
+    a = calc_power(pos, box, **kw)
+    b = oracle.calc_power(pos, box, nthread=oracle.max_threads(), accum64=True, **kw)
+    np.testing.assert_array_equal(np.asarray(a['N_mode']), b['N_mode'])
+    ok = b['N_mode'] > 0
+    np.testing.assert_allclose(np.asarray(a['power'])[ok], b['power'][ok], rtol=1e-5)
+    scale = np.abs(b['power']).max()
+    np.testing.assert_allclose(np.asarray(a['poles']), b['poles'], rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(np.asarray(a['k_avg'])[ok], b['k_avg'][ok], rtol=1e-6)
+    shot = box**3 / n
+    assert abs(np.mean(np.asarray(a['poles'])[8:128, 0]) / shot - 1) < 5e-3    # flat shot noise below the window's reach
+
+
+@pytest.mark.parametrize('nmesh,comp', [(1024, False), (1024, True)])
+def test_fused_last_pass_matches_spectrum_bin(monkeypatch, nmesh, comp):
+    """fft_x_bin (last FFT pass + binning in one kernel, xbin.hip) against the x pass + spectrum_bin on the same particles:
+    identical |delta_k|^2 per mode, so the float64 sums agree to rounding"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    pos = synth.synth_positions(3_000_000, 1000.0, seed=83, clustered=True)
+    w = np.random.default_rng(3).random(len(pos), dtype=np.float32) + np.float32(0.5)
+    for kw in (dict(kbins=64, mubins=4, poles=[0, 2, 4]), dict(kbins=200, mubins=None, poles=[0, 2]),
+               dict(kbins=48, mubins=7, poles=[]), dict(kbins=32, mubins=3, poles=[4], logk=True, k_max=1.5)):
+        kw = dict(kw, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=False, w=w)
+        a = calc_power(pos.copy(), 1000.0, **kw)
+        monkeypatch.setenv('ABACUS_PK_NOXBIN', '1')
+        b = calc_power(pos.copy(), 1000.0, **kw)
+        monkeypatch.delenv('ABACUS_PK_NOXBIN')
+        np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
+        np.testing.assert_allclose(a['power'], b['power'], rtol=2e-6, atol=1e-7 * np.abs(b['power']).max())
+        np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)
+        if kw['poles']:
+            np.testing.assert_allclose(a['poles'], b['poles'], rtol=2e-6, atol=2e-7 * np.abs(b['power']).max())
