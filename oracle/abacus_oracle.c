@@ -299,6 +299,14 @@ int oracle_gen_sats(int64_t H, const double *ppos, const double *pvel, const dou
     return 0;
 }
 
+/* keep_cent[pinds] (hod/GRAND_HOD.py:1562: a NumPy fancy-index gather on the host); threaded here so that the
+ * CPU baseline of bench.py times compiled code only */
+void oracle_gather_i8(const int8_t *src, const int64_t *idx, int64_t n, int8_t *dst, int nthread) {
+    if (nthread < 1) nthread = 1;
+#pragma omp parallel for num_threads(nthread) schedule(static)
+    for (int64_t i = 0; i < n; i++) dst[i] = src[idx[i]];
+}
+
 /* ------------------------------------------------------------------------- */
 /* TSC / CIC / partition                                                      */
 /* ------------------------------------------------------------------------- */

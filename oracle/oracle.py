@@ -138,6 +138,49 @@ def gen_sats(particle_data, p, nthread, keep_cent_at_pinds):
     return _two_pass(lib().oracle_gen_sats, n, args, p, nthread)
 
 
+def time_gen_gals(halo_data, particle_data, tracers, params, nthread, reps=3, enable_ranks=False, rsd=True):
+    """CPU-baseline timing of the compiled kernels alone (bench.py `cpu_baseline`): arrays marshalled and output buffers
+    allocated outside the timed region; one repetition = gen_cent (pass 1 + pass 2), the keep_cent[pinds] gather
+    (hod/GRAND_HOD.py:1562), gen_sats (pass 1 + pass 2).  Returns (seconds per repetition [min], [mean], n_gal)."""
+    import time
+    p = marshal_params(tracers, params, enable_ranks, rsd)
+    h, s = halo_data, particle_data
+    nh, npart = len(h['hmass']), len(s['phmass'])
+    harr = [_f8(h['hpos']), _f8(h['hvel']), _f8(h['hmass']), np.ascontiguousarray(h['hid'], dtype=np.int64),
+            _f8(h['hmultis']), _f8(h['hrandoms']), _f8(h['hveldev'])]
+    hopt = [(_f8(h[k]) if k in h else None) for k in ('hdeltac', 'hfenv', 'hshear')]
+    parr = [_f8(s['ppos']), _f8(s['pvel']), _f8(s['phvel']), _f8(s['phmass']),
+            np.ascontiguousarray(s['phid'], dtype=np.int64), _f8(s['pweights']), _f8(s['prandoms'])]
+    popt = [(_f8(s[k]) if k in s else None) for k in ('pdeltac', 'pfenv', 'pshear')]
+    ranks = [_f8(s[k]) for k in ('pranks', 'pranksv', 'pranksp', 'pranksr')]
+    pinds = np.ascontiguousarray(s['pinds'], dtype=np.int64)
+    keep_c, keep_s, kc = np.empty(nh, np.int8), np.empty(npart, np.int8), np.empty(npart, np.int8)
+    cnt_c, cnt_s = np.zeros(3, np.int64), np.zeros(3, np.int64)
+    L = lib()
+    hargs = [C.c_int64(nh)] + [_ptr(a) for a in harr + hopt]
+    L.oracle_gen_cent(*hargs, C.byref(p), nthread, _ptr(keep_c), _ptr(cnt_c), None, None)     # sizing pass
+    L.oracle_gather_i8(_ptr(keep_c), _ptr(pinds), C.c_int64(npart), _ptr(kc), nthread)
+    pargs = [C.c_int64(npart)] + [_ptr(a) for a in parr + popt + ranks] + [_ptr(kc)]
+    L.oracle_gen_sats(*pargs, C.byref(p), nthread, _ptr(keep_s), _ptr(cnt_s), None, None)
+
+    def bufs(cnt):
+        outs = [[np.empty(cnt[t], np.float64) for _ in COLS] for t in range(3)]
+        ids = [np.empty(cnt[t], np.int64) for t in range(3)]
+        return outs, ids, (C.c_void_p * 21)(*[a.ctypes.data for t in range(3) for a in outs[t]]), \
+            (C.c_void_p * 3)(*[a.ctypes.data for a in ids])
+    oc, ic, ocp, icp = bufs(cnt_c)
+    os_, is_, osp, isp = bufs(cnt_s)
+    ts = []
+    for _ in range(reps + 1):          # first repetition = warm-up
+        t0 = time.perf_counter()
+        L.oracle_gen_cent(*hargs, C.byref(p), nthread, _ptr(keep_c), _ptr(cnt_c), ocp, icp)
+        L.oracle_gather_i8(_ptr(keep_c), _ptr(pinds), C.c_int64(npart), _ptr(kc), nthread)
+        L.oracle_gen_sats(*pargs, C.byref(p), nthread, _ptr(keep_s), _ptr(cnt_s), osp, isp)
+        ts.append(time.perf_counter() - t0)
+    ts = ts[1:]
+    return min(ts), sum(ts) / len(ts), int(cnt_c.sum() + cnt_s.sum())
+
+
 def gen_gal_cat(halo_data, particle_data, tracers, params, Nthread=16, enable_ranks=False, rsd=True,
                 return_keep=False):
     """gen_gal_cat -> gen_gals (hod/GRAND_HOD.py:1595-1724,1302-1592), particle-based path"""
@@ -355,22 +398,30 @@ def bin_kmu(n1d, L, kedges, muedges, weights, poles=np.empty(0, 'i8'), fourier=T
 
 def particle_cloud_tables(pos, w, Lbox, nmesh, paste='TSC', offset=0.0):
     """[P][3][nmesh] complex128: per particle and dimension, the discrete Fourier transform of its 1-D mass-assignment
-    cloud on the mesh, sum_s w_s exp(-2 pi i m c_s / n) for every integer frequency index m (the TSC / CIC weights of
-    analysis/tsc.py:424-436 / analysis/cic.py evaluated in float64; the particle weight multiplies the x table).  The 3-D
-    transform of the deposited mesh is sum_p X_p[i] Y_p[j] Z_p[k]: exact, aliasing included."""
-    pos = np.asarray(pos, dtype=np.float64)
+    cloud on the mesh, sum_s w_s exp(-2 pi i m c_s / n) for every integer frequency index m.  The TSC weights are
+    evaluated as _tsc_scatter does (analysis/tsc.py:400-451): in the DTYPE OF THE POSITIONS (`ftype`), with
+    `inv_h = ftype(g / box)`, `p = (x + ftype(offset)) * inv_h`, `d = ftype(round(p)) - p` - at nmesh 2048 a float32 grid
+    coordinate resolves 1.2e-4 of a cell, which moves single-particle window amplitudes at the 1e-4 level, so a float64
+    evaluation is NOT what the reference deposits.  CIC (analysis/cic.py:29-71) is float64 whatever the dtype.  The
+    particle weight multiplies the x table.  The 3-D transform of the deposited mesh is sum_p X_p[i] Y_p[j] Z_p[k]:
+    exact, aliasing included."""
+    pos = np.asarray(pos)
+    ft = pos.dtype.type if pos.dtype in (np.float32, np.float64) else np.float64
     P = len(pos)
     w = np.ones(P) if w is None else np.asarray(w, dtype=np.float64)
     m = np.arange(nmesh)
     tabs = np.zeros((P, 3, nmesh), dtype=np.complex128)
+    inv_h, off, HALF, P75 = ft(nmesh / Lbox), ft(offset), ft(0.5), ft(0.75)
     for p in range(P):
         for d in range(3):
-            x = (pos[p, d] + offset) * (nmesh / Lbox)
             if paste.upper() == 'TSC':
+                x = (ft(pos[p, d]) + off) * inv_h
                 c = np.rint(x)                      # round half to even, like the reference's round()
-                dd = c - x
-                cells = [(c - 1, 0.5 * (0.5 + dd) ** 2), (c, 0.75 - dd * dd), (c + 1, 0.5 * (0.5 - dd) ** 2)]
+                dd = ft(c) - x
+                tm, tp, c = HALF + dd, HALF - dd, float(c)
+                cells = [(c - 1, float(HALF * (tm * tm))), (c, float(P75 - dd * dd)), (c + 1, float(HALF * (tp * tp)))]
             else:
+                x = (float(pos[p, d]) + offset) / Lbox * nmesh
                 c = np.floor(x)
                 f = x - c
                 cells = [(c, 1 - f), (c + 1, f)]
@@ -385,7 +436,7 @@ def pk_of_particles_analytic(pos, w, Lbox, nmesh, kedges, muedges, poles, paste=
     [cloud transform], the interlaced combination (:904-948) as a second set of separable terms, the compensation window
     (:1081-1128) as a separable divisor, then bin_kmu's rule with float64 sums - nothing of mesh size is allocated, so the
     known answer at 2048^3 costs seconds.  Returns the columns of the Table as a dict."""
-    pos = np.asarray(pos, dtype=np.float64)
+    pos = np.asarray(pos)                         # dtype kept: the cloud weights are evaluated in it, as the reference does
     P = len(pos)
     tabs = particle_cloud_tables(pos, w, Lbox, nmesh, paste)
     amp = 1.0 / P                                 # rho * (M / len(pos)) / M; the -1 only touches k = 0

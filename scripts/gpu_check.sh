@@ -9,7 +9,7 @@ for w in "$@"; do
 case $w in
 tests)
   make -s -C oracle
-  timeout 2700 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee "$O/gpu_tests.log"
+  timeout 2700 python -m pytest tests -m gpu -q 2>&1 | tail -40 | tee "$O/gpu_tests.log"
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12 | tee "$O/smoke.log"
   ;;
 only:*)
