@@ -21,6 +21,7 @@
 // random within ~1e-16 of its marker.
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "../../include/abacus_hip.h"
 #include "common.hpp"
@@ -187,7 +188,8 @@ __device__ __forceinline__ double load1(const double *a, int64_t i, double fill)
 // (1e-4 relative) and for the propagated argument error of erfc; `filter` is switched off by the host for parameter
 // sets the bounds do not cover (negative ic / A_s / kappa-free cases, non-finite values).
 struct Filt {
-    int cent_ok, sat_ok;
+    int cent_ok, sat_ok;   // sat_ok: the arithmetic satellite bound applies (particle-independent M1 / M_cut)
+    int sat_basic, pad_;   // finite parameters, alpha >= 0, A_s >= 0, ic >= 0 (what the envelope table needs)
     float L_lc, L_Ac, L_Bc, L_inv_s, L_ic;                      // centrals + LRG satellites share lc, sigma
     float E_lc, E_Ac, E_Bc, E_Cc, E_c_phi, E_half_inv_s2, E_ic;  // c_phi = max(2(pmax-1/Q),0) * 0.39894/sigma
     float Q_lc, Q_Ac, Q_Bc, Q_inv_s, Q_ic;
@@ -270,8 +272,15 @@ __device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Fil
     if (p.want_ELG) {
         const double xd = (double)hmass - F.E_kMcut;
         if (!(xd < 0)) {
-            const int v = keep_cent == 1 ? 1 : (keep_cent == 2 ? 2 : 0);
-            float term = F.E_As * pow_ub((float)xd * F.E_invM1[v], F.E_alpha[v]) * w * F.E_ic;
+            float pw;
+            if (keep_cent < 0) {   // host decision not known yet (filter ahead of the central exact pass): largest variant
+                pw = fmaxf(pow_ub((float)xd * F.E_invM1[0], F.E_alpha[0]),
+                           fmaxf(pow_ub((float)xd * F.E_invM1[1], F.E_alpha[1]), pow_ub((float)xd * F.E_invM1[2], F.E_alpha[2])));
+            } else {
+                const int v = keep_cent == 1 ? 1 : (keep_cent == 2 ? 2 : 0);
+                pw = pow_ub((float)xd * F.E_invM1[v], F.E_alpha[v]);
+            }
+            float term = F.E_As * pw * w * F.E_ic;
             if (p.enable_ranks) term *= dec_ub(F.E_s, r, rv, rp, rr);
             U += term;
         }
@@ -499,7 +508,8 @@ __device__ __forceinline__ void load4f(const float *a, int64_t i, float fill, fl
 constexpr int CH_SHIFT = 20, CH_BASE = (127 + 33) << 3, CH_NLEV = 21 * 8;
 struct Cheap {
     int c_ok, s_ok;
-    float dec[4];             // max over the wanted tracers of |s|, |s_v|, |s_p|, |s_r| (rank modulation bound)
+    float dec_max;            // >= 1 + sum_q |s_q| |rank_q| for every wanted tracer and every staged rank value
+    float pad_;
     float Bc[CH_NLEV], Bs[CH_NLEV];
 };
 
@@ -535,52 +545,47 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter32(HodPtrs a, FiltCols c, in
     pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO, pw.enable_ranks = enable_ranks;
     const bool need_conf = SAT && want_ELG && a.pinds != nullptr;
     if constexpr (TWO_STAGE) {
-        // ---- stage 1: table bound ----
-#pragma unroll 1
+        // ---- stage 1: envelope table bound - three float4 loads per four objects whatever the HOD weights ----
+        const float dec = ch.dec_max;
+#pragma unroll
         for (int k = 0; k < PER_THREAD / 4; k++) {
             const int loc = k * (4 * FBLOCK) + 4 * tid;
             const int64_t i = tile0 + loc;
             if (i >= n) continue;
-            float m[4], w[4], r[4], dec[4] = {1.f, 1.f, 1.f, 1.f};
+            float m[4], w[4], r[4];
             load4f(SAT ? c.phmass : c.hmass, i, 1.f, m);
             load4f(SAT ? c.pweights : c.hmultis, i, 0.f, w);
             load4f(SAT ? c.prandoms : c.hrandoms, i, 2.f, r);
-            if (SAT && enable_ranks) {
-                float r0[4], r1[4], r2[4], r3[4];
-                load4f(c.pranks, i, 1.f, r0);
-                load4f(c.pranksv, i, 1.f, r1);
-                load4f(c.pranksp, i, 1.f, r2);
-                load4f(c.pranksr, i, 1.f, r3);
-#pragma unroll
-                for (int u = 0; u < 4; u++) dec[u] = dec_ub<float>(ch.dec, r0[u], r1[u], r2[u], r3[u]);
-            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (i + u >= n) continue;
                 bool pass = true;                                  // negative / NaN multiplicities are never rejected
                 if (w[u] >= 0.f) {
-                    const float U = cheap_bound(tab, m[u]) * (w[u] * 1.00001f) * dec[u];
+                    float U = cheap_bound(tab, m[u]) * (w[u] * 1.00001f);
+                    if (SAT) U *= dec;
                     pass = !(r[u] > U * 1.001f);
                 }
                 if (pass) q1[atomicAdd(&nq1, 1)] = (unsigned short)(loc + u);
             }
         }
         __syncthreads();
-        // ---- stage 2: the arithmetic bound for the survivors ----
+        // ---- stage 2: the arithmetic bound with the object's own environment / ranks, for the survivors ----
         const int n1 = nq1;
         for (int e = tid; e < n1; e += FBLOCK) {
             const int loc = q1[e];
             const int64_t i = tile0 + loc;
-            bool rej;
+            bool rej = false;
             if (!SAT) {
-                rej = cent_reject<float>(pw, F, c.hmass[i], c.hmultis[i], c.hrandoms[i], 0.f, 0.f, 0.f);
-            } else {
-                int8_t kc = 0;
-                if (need_conf) kc = a.keep_c[a.pinds[i]];
+                const float d = need_env && c.hdeltac ? c.hdeltac[i] : 0.f, f = need_env && c.hfenv ? c.hfenv[i] : 0.f,
+                            sh = need_shear && c.hshear ? c.hshear[i] : 0.f;
+                rej = cent_reject<float>(pw, F, c.hmass[i], c.hmultis[i], c.hrandoms[i], d, f, sh);
+            } else if (F.sat_ok) {
+                // conformity: the host's exact decision may not exist yet (one filter launch for both kinds) -> -1
                 const float r0 = enable_ranks ? c.pranks[i] : 1.f, r1 = enable_ranks ? c.pranksv[i] : 1.f,
                             r2 = enable_ranks ? c.pranksp[i] : 1.f, r3 = enable_ranks ? c.pranksr[i] : 1.f;
-                rej = sat_reject<float>(pw, F, c.phmass[i], c.pweights[i], c.prandoms[i], r0, r1, r2, r3, kc);
-            }
+                rej = sat_reject<float>(pw, F, c.phmass[i], c.pweights[i], c.prandoms[i], r0, r1, r2, r3,
+                                        need_conf ? (int8_t)-1 : (int8_t)0);
+            }   // satellites with assembly bias: the envelope's survivors go straight to the exact chain
             if (!rej) q[atomicAdd(&nq, 1)] = (unsigned short)loc;
         }
     } else {
@@ -1219,6 +1224,31 @@ __global__ __launch_bounds__(256) void hod_ngal(int64_t n, const uchar4 *__restr
     if (threadIdx.x < 6) atomicAdd(&out[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+struct ColRange {
+    double lo = 0, hi = 0;
+};
+struct HodRanges {
+    ColRange hdeltac, hfenv, hshear, pdeltac, pfenv, pshear, pranks[4];
+};
+
+// per-block minimum / maximum of a column, NaNs ignored (fmin / fmax); the host folds the partials
+__global__ __launch_bounds__(256) void hod_minmax(const double *__restrict__ src, int64_t n, double *__restrict__ part) {
+    double lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = src[i];
+        lo = fmin(lo, v), hi = fmax(hi, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lo = fmin(lo, __shfl_xor(lo, off, 64)), hi = fmax(hi, __shfl_xor(hi, off, 64));
+    __shared__ double red[4][2];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][0] = lo, red[threadIdx.x >> 6][1] = hi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0]));
+        part[2 * blockIdx.x + 1] = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
+    }
+}
+
 }  // namespace
 
 // ---- handle ---------------------------------------------------------------------------------------------
@@ -1261,6 +1291,8 @@ struct abacus_hod_state {
     bool shadow_ok = false, shadow_rand_ok = false;
     DevBuf hrec, prec;          // emission records (owned catalogues)
     bool rec_ok = false;
+    HodRanges ranges;           // value ranges of the environment / rank columns (envelope table of the two-stage filter)
+    bool ranges_ok = false;
 };
 
 namespace {
@@ -1290,19 +1322,23 @@ Filt make_filter(const abacus_hod_params &p, const SatPre &pre) {
     F.E_half_inv_s2 = (float)(0.5 / (p.E_sigma * p.E_sigma)), F.E_ic = up(p.E_ic);
     F.Q_lc = (float)p.Q_logM_cut, F.Q_Ac = (float)p.Q_Acent, F.Q_Bc = (float)p.Q_Bcent;
     F.Q_inv_s = (float)(1.0 / (1.41421356 * p.Q_sigma)), F.Q_ic = up(p.Q_ic);
-    // satellites: only when every wanted tracer has particle-independent M1 / M_cut, positive masses and alpha >= 0
-    bool sok = ok;
+    // satellites: the arithmetic bound only when every wanted tracer has particle-independent M1 / M_cut (`sok`); the
+    // envelope table of the two-stage filter needs just finite parameters, positive masses and alpha >= 0 (`sbasic`)
+    bool sok = ok, sbasic = ok;
     auto sat = [&](bool want, int is_const, double M1, double alpha, double kappa, double Mcut) {
         if (!want) return;
-        sok = sok && is_const && finite(M1) && M1 > 0 && finite(alpha) && alpha >= 0 && finite(kappa) && finite(Mcut);
+        const bool b = finite(M1) && M1 > 0 && finite(alpha) && alpha >= 0 && finite(kappa) && finite(Mcut);
+        sbasic = sbasic && b;
+        sok = sok && is_const && b;
     };
     sat(p.want_LRG, pre.L_const, pre.L_M1, p.L_alpha, p.L_kappa, pre.L_Mcut);
     sat(p.want_ELG, pre.E_const, pre.E_M1, p.E_alpha, p.E_kappa, pre.E_Mcut);
     sat(p.want_ELG, pre.E_const, pre.E_M1_EL, p.E_alpha_EL, p.E_kappa, pre.E_Mcut);
     sat(p.want_ELG, pre.E_const, pre.E_M1_EE, p.E_alpha_EE, p.E_kappa, pre.E_Mcut);
     sat(p.want_QSO, pre.Q_const, pre.Q_M1, p.Q_alpha, p.Q_kappa, pre.Q_Mcut);
-    if (p.want_ELG) sok = sok && finite(p.E_A_s) && p.E_A_s >= 0;
+    if (p.want_ELG) sok = sok && finite(p.E_A_s) && p.E_A_s >= 0, sbasic = sbasic && finite(p.E_A_s) && p.E_A_s >= 0;
     F.sat_ok = sok;
+    F.sat_basic = sbasic;
     F.L_invM1 = up(1.0 / pre.L_M1), F.L_alpha = (float)p.L_alpha;
     F.E_invM1[0] = up(1.0 / pre.E_M1), F.E_invM1[1] = up(1.0 / pre.E_M1_EL), F.E_invM1[2] = up(1.0 / pre.E_M1_EE);
     F.E_alpha[0] = (float)p.E_alpha, F.E_alpha[1] = (float)p.E_alpha_EL, F.E_alpha[2] = (float)p.E_alpha_EE;
@@ -1312,60 +1348,114 @@ Filt make_filter(const abacus_hod_params &p, const SatPre &pre) {
                  Qs[4] = {p.Q_s, p.Q_s_v, p.Q_s_p, p.Q_s_r};
     for (int q = 0; q < 4; q++) {
         F.L_s[q] = up(std::fabs(Ls[q])), F.E_s[q] = up(std::fabs(Es[q])), F.Q_s[q] = up(std::fabs(Qs[q]));
-        if (p.enable_ranks) F.sat_ok = F.sat_ok && finite(Ls[q]) && finite(Es[q]) && finite(Qs[q]);
+        if (p.enable_ranks) {
+            const bool b = finite(Ls[q]) && finite(Es[q]) && finite(Qs[q]);
+            F.sat_ok = F.sat_ok && b, F.sat_basic = F.sat_basic && b;
+        }
     }
     // kappa*M_cut exactly as n_sat_* forms it (FP64 product)
     F.L_kMcut = p.L_kappa * pre.L_Mcut, F.E_kMcut = p.E_kappa * pre.E_Mcut, F.Q_kMcut = p.Q_kappa * pre.Q_Mcut;
     return F;
 }
 
-// host side of the two-stage filter: float64 occupations at the upper edge of every float32 mass bin
-Cheap make_cheap(const abacus_hod_params &p, const SatPre &pre, const Filt &F, int need_env) {
+// Value ranges of the staged environment / rank columns (NaNs ignored), measured once per catalogue: the envelope
+// table bounds every object's occupation by the occupation at the most favourable environment in these ranges.
+inline void prod_range(double c, const ColRange &r, double &lo, double &hi) {   // range of c * x, x in r
+    const double a = c * r.lo, b = c * r.hi;
+    if (c == 0) return;   // the reference forms 0 * x: exactly 0 for finite x
+    lo += std::min(a, b), hi += std::max(a, b);
+}
+
+// host side of the two-stage filter: an ENVELOPE table - for every float32 mass bin an upper bound of the summed
+// occupation of the wanted tracers over the masses of the bin AND over the staged ranges of deltac / fenv / shear, so the
+// streaming loop reads mass, multiplicity / weight and random only (12 B per object) for any HOD:
+//   erfc forms (LRG / QSO centrals, the LRG satellites' n_cen factor): largest at the bin's upper edge and the smallest
+//   logM_cut + A d + B f of the range;  ELG centrals 2 (p_max - 1/Q) phi(x) Phi(gamma x), x = (logM - logM_cut') / sigma
+//   (not monotone): Gaussian at the smallest |logM - logM_cut'| the bin and the range admit, Phi at the largest gamma x;
+//   power laws ((M - kappa M_cut') / M1')^alpha: upper edge, smallest kappa M_cut' and smallest M1' of the range, the
+//   largest of the three conformity variants for ELG.  Rank modulation: 1 + sum |s_q| max |rank_q|.
+Cheap make_cheap(const abacus_hod_params &p, const Filt &F, const HodRanges &R) {
     Cheap c;
     memset(&c, 0, sizeof c);
-    // centrals: erfc forms without assembly bias; the ELG central occupation is not monotone in mass
-    c.c_ok = F.cent_ok && !p.want_ELG && !need_env && (p.want_LRG || p.want_QSO) && !getenv("ABACUS_HOD_ONE_STAGE");
-    // satellites: F.sat_ok already demands particle-independent M1 / M_cut, M1 > 0, alpha >= 0, A_s >= 0, ic >= 0
-    c.s_ok = F.sat_ok && !getenv("ABACUS_HOD_ONE_STAGE");
+    static const bool one_stage = getenv("ABACUS_HOD_ONE_STAGE") != nullptr;
+    c.c_ok = F.cent_ok && (p.want_LRG || p.want_ELG || p.want_QSO) && !one_stage;
+    c.s_ok = F.sat_basic && (p.want_LRG || p.want_ELG || p.want_QSO) && !one_stage;
     auto up = [](double v) { return std::max((float)(v * 1.00001), 1e-30f); };
-    const double Ls[4] = {p.L_s, p.L_s_v, p.L_s_p, p.L_s_r}, Es[4] = {p.E_s, p.E_s_v, p.E_s_p, p.E_s_r},
-                 Qs[4] = {p.Q_s, p.Q_s_v, p.Q_s_p, p.Q_s_r};
-    for (int q = 0; q < 4; q++) {
-        double m = 0;
-        if (p.want_LRG) m = std::max(m, std::fabs(Ls[q]));
-        if (p.want_ELG) m = std::max(m, std::fabs(Es[q]));
-        if (p.want_QSO) m = std::max(m, std::fabs(Qs[q]));
-        c.dec[q] = (float)(m * 1.000001);
-    }
-    auto ncen_L = [&](double M) { return 0.5 * std::erfc((p.L_logM_cut - std::log10(M)) / (1.41421356 * p.L_sigma)); };
-    auto ncen_Q = [&](double M) { return 0.5 * (1 + std::erf((std::log10(M) - p.Q_logM_cut) / 1.41421356 / p.Q_sigma)); };
-    auto powa = [](double x, double a) { return a == 1.0 ? x : std::pow(x, a); };
-    auto plaw = [&](double M, double kMcut, double M1, double alpha) {
-        return M - kMcut < 0 ? 0.0 : powa((M - kMcut) / M1, alpha);
+    // ranges of logM_cut' (centrals: halo columns; satellites: particle columns) and of logM1' per tracer / variant
+    struct LR {
+        double lo, hi;
     };
+    auto lin = [&](double base, double A, const ColRange &d, double B, const ColRange &f, double Cc, const ColRange &sh) {
+        LR r{base, base};
+        prod_range(A, d, r.lo, r.hi), prod_range(B, f, r.lo, r.hi), prod_range(Cc, sh, r.lo, r.hi);
+        return r;
+    };
+    const LR Lc_h = lin(p.L_logM_cut, p.L_Acent, R.hdeltac, p.L_Bcent, R.hfenv, 0, R.hshear);
+    const LR Ec_h = lin(p.E_logM_cut, p.E_Acent, R.hdeltac, p.E_Bcent, R.hfenv, p.E_Ccent, R.hshear);
+    const LR Qc_h = lin(p.Q_logM_cut, p.Q_Acent, R.hdeltac, p.Q_Bcent, R.hfenv, 0, R.hshear);
+    const LR Lc_p = lin(p.L_logM_cut, p.L_Acent, R.pdeltac, p.L_Bcent, R.pfenv, 0, R.pshear);
+    const LR Ec_p = lin(p.E_logM_cut, p.E_Acent, R.pdeltac, p.E_Bcent, R.pfenv, p.E_Ccent, R.pshear);
+    const LR Qc_p = lin(p.Q_logM_cut, p.Q_Acent, R.pdeltac, p.Q_Bcent, R.pfenv, 0, R.pshear);
+    const LR L1 = lin(p.L_logM1, p.L_Asat, R.pdeltac, p.L_Bsat, R.pfenv, 0, R.pshear);
+    const LR E1 = lin(p.E_logM1, p.E_Asat, R.pdeltac, p.E_Bsat, R.pfenv, p.E_Csat, R.pshear);
+    const LR E1L = lin(p.E_logM1_EL, p.E_Asat, R.pdeltac, p.E_Bsat, R.pfenv, 0, R.pshear);   // no Csat term (:1006-1035)
+    const LR E1E = lin(p.E_logM1_EE, p.E_Asat, R.pdeltac, p.E_Bsat, R.pfenv, 0, R.pshear);
+    const LR Q1 = lin(p.Q_logM1, p.Q_Asat, R.pdeltac, p.Q_Bsat, R.pfenv, 0, R.pshear);
+    double dec = 1.0;
+    if (p.enable_ranks) {
+        const double Ls[4] = {p.L_s, p.L_s_v, p.L_s_p, p.L_s_r}, Es[4] = {p.E_s, p.E_s_v, p.E_s_p, p.E_s_r},
+                     Qs[4] = {p.Q_s, p.Q_s_v, p.Q_s_p, p.Q_s_r};
+        for (int q = 0; q < 4; q++) {
+            double m = 0;
+            if (p.want_LRG) m = std::max(m, std::fabs(Ls[q]));
+            if (p.want_ELG) m = std::max(m, std::fabs(Es[q]));
+            if (p.want_QSO) m = std::max(m, std::fabs(Qs[q]));
+            dec += m * std::max(std::fabs(R.pranks[q].lo), std::fabs(R.pranks[q].hi));
+        }
+    }
+    if (!std::isfinite(dec)) c.s_ok = 0;
+    c.dec_max = (float)(dec * 1.0001);
+    auto half_erfc = [](double lM, double lc, double sigma) { return 0.5 * std::erfc((lc - lM) / (1.41421356 * sigma)); };
+    auto powa = [](double x, double a) { return a == 1.0 ? x : std::pow(x, a); };
+    // ((M - kappa M_cut') / M1')^alpha at its largest: smallest kappa * 10^lc and smallest 10^l1 of the ranges
+    auto plaw = [&](double M, double kappa, const LR &lc, const LR &l1, double alpha) {
+        const double kM = std::min(kappa * std::pow(10.0, lc.lo), kappa * std::pow(10.0, lc.hi));
+        const double x = M - kM;
+        return x < 0 ? 0.0 : powa(x / std::pow(10.0, l1.lo), alpha);
+    };
+    double lM_prev = -INFINITY;   // bin 0 also takes every smaller mass
     for (int j = 0; j < CH_NLEV; j++) {
         const uint32_t bits = (uint32_t)(CH_BASE + j + 1) << CH_SHIFT;   // upper edge of bin j (exclusive)
         float Tf;
         memcpy(&Tf, &bits, 4);
-        const double T = (double)Tf;
+        const double T = (double)Tf, lM = std::log10(T);
         double bc = 0, bs = 0;
         if (c.c_ok) {
-            if (p.want_LRG) bc += ncen_L(T) * p.L_ic;
-            if (p.want_QSO) bc += ncen_Q(T) * p.Q_ic;
+            if (p.want_LRG) bc += half_erfc(lM, Lc_h.lo, p.L_sigma) * p.L_ic;
+            if (p.want_QSO) bc += half_erfc(lM, Qc_h.lo, p.Q_sigma) * p.Q_ic;   // 0.5 (1 + erf(u)) = 0.5 erfc(-u)
+            if (p.want_ELG) {
+                // d = logM - logM_cut' over the bin (its lower edge widened by the round-up of the shadow mass) and the range
+                const double dl = (lM_prev - 1e-6) - Ec_h.hi, dh = lM - Ec_h.lo;
+                const double dmin = (dl <= 0 && dh >= 0) ? 0.0 : std::min(std::fabs(dl), std::fabs(dh));
+                const double phi = 0.3989422804014327 / p.E_sigma * std::exp(-(dmin * dmin) / 2 / (p.E_sigma * p.E_sigma));
+                const double xmax = std::max(p.E_gamma * dl / p.E_sigma, p.E_gamma * dh / p.E_sigma);
+                const double Phi = std::isfinite(xmax) ? 0.5 * (1 + std::erf(xmax / 1.4142135623730951)) : 1.0;
+                bc += std::max(2.0 * (p.E_p_max - 1.0 / p.E_Q), 0.0) * phi * Phi * p.E_ic;
+            }
         }
         if (c.s_ok) {
-            if (p.want_LRG) bs += plaw(T, p.L_kappa * pre.L_Mcut, pre.L_M1, p.L_alpha) * ncen_L(T) * p.L_ic;
+            if (p.want_LRG) bs += plaw(T, p.L_kappa, Lc_p, L1, p.L_alpha) * half_erfc(lM, Lc_p.lo, p.L_sigma) * p.L_ic;
             if (p.want_ELG) {
-                const double k = p.E_kappa * pre.E_Mcut;   // conformity variants: the largest of the three
-                const double v = std::max(plaw(T, k, pre.E_M1, p.E_alpha),
-                                          std::max(plaw(T, k, pre.E_M1_EL, p.E_alpha_EL), plaw(T, k, pre.E_M1_EE, p.E_alpha_EE)));
+                const double v = std::max(plaw(T, p.E_kappa, Ec_p, E1, p.E_alpha),
+                                          std::max(plaw(T, p.E_kappa, Ec_p, E1L, p.E_alpha_EL), plaw(T, p.E_kappa, Ec_p, E1E, p.E_alpha_EE)));
                 bs += p.E_A_s * v * p.E_ic;
             }
-            if (p.want_QSO) bs += plaw(T, p.Q_kappa * pre.Q_Mcut, pre.Q_M1, p.Q_alpha) * p.Q_ic;
+            if (p.want_QSO) bs += plaw(T, p.Q_kappa, Qc_p, Q1, p.Q_alpha) * p.Q_ic;
         }
         if (!std::isfinite(bc)) c.c_ok = 0;
         if (!std::isfinite(bs)) c.s_ok = 0;
         c.Bc[j] = up(bc), c.Bs[j] = up(bs);
+        lM_prev = lM;
     }
     return c;
 }
@@ -1436,6 +1526,45 @@ int launch_emit(abacus_hod_state *st) {
     in.prec = st->rec_ok ? st->prec.as<PartRec>() : nullptr;
     ABACUS_LAUNCH("hod_emit", hod_emit, dim3(nemit), dim3(EBLOCK), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s,
                   st->sb_counts, st->d_totals, in, st->params, out_cols(st));
+    return 0;
+}
+
+// value ranges of the environment / rank columns (once per catalogue; absent columns keep the value the exact chain
+// substitutes for them: 0, ranks 1)
+int compute_ranges(abacus_hod_state *st) {
+    if (st->ranges_ok) return 0;
+    constexpr int NB = 1024;
+    DevBuf part;
+    ABACUS_TRY(part.reserve((size_t)NB * 2 * sizeof(double)));
+    std::vector<double> hostv((size_t)NB * 2);
+    double *host = hostv.data();
+    auto col = [&](const double *src, int64_t n, double absent, ColRange &r) -> int {
+        r.lo = r.hi = absent;
+        if (!src || n <= 0) return 0;
+        const int grid = (int)std::min<int64_t>(ceil_div(n, 256), NB);
+        ABACUS_LAUNCH("hod_minmax", hod_minmax, dim3(grid), dim3(256), 0, src, n, part.as<double>());
+        HIP_TRY(hipMemcpyAsync(host, part.p, (size_t)grid * 2 * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        double lo = INFINITY, hi = -INFINITY;
+        for (int b = 0; b < grid; b++) lo = std::fmin(lo, host[2 * b]), hi = std::fmax(hi, host[2 * b + 1]);
+        if (lo <= hi) r.lo = lo, r.hi = hi;   // all-NaN column: the exact chain keeps nothing it weights; any range will do
+        return 0;
+    };
+    HodRanges &R = st->ranges;
+    int rc = 0;
+    rc = rc ? rc : col(st->hdeltac, st->nh, 0.0, R.hdeltac);
+    rc = rc ? rc : col(st->hfenv, st->nh, 0.0, R.hfenv);
+    rc = rc ? rc : col(st->hshear, st->nh, 0.0, R.hshear);
+    rc = rc ? rc : col(st->pdeltac, st->np, 0.0, R.pdeltac);
+    rc = rc ? rc : col(st->pfenv, st->np, 0.0, R.pfenv);
+    rc = rc ? rc : col(st->pshear, st->np, 0.0, R.pshear);
+    rc = rc ? rc : col(st->pranks, st->np, 1.0, R.pranks[0]);
+    rc = rc ? rc : col(st->pranksv, st->np, 1.0, R.pranks[1]);
+    rc = rc ? rc : col(st->pranksp, st->np, 1.0, R.pranks[2]);
+    rc = rc ? rc : col(st->pranksr, st->np, 1.0, R.pranks[3]);
+    (void)part.release();
+    if (rc) return rc;
+    st->ranges_ok = true;
     return 0;
 }
 
@@ -1808,7 +1937,8 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     if (use32 && !st->shadow_ok) ABACUS_TRY(build_shadows(st, false));
     else if (use32 && !st->shadow_rand_ok) ABACUS_TRY(build_shadows(st, true));
     const FiltCols fc = st->fc;
-    const Cheap cheap = make_cheap(*p, pre, F, need_env);
+    if (use32) ABACUS_TRY(compute_ranges(st));
+    const Cheap cheap = use32 ? make_cheap(*p, F, st->ranges) : Cheap{};
     // `first`, `count` in global tile ids (centrals first): the shadow path launches the two kinds separately
     auto filter32 = [&](int first, int count) -> int {
         const int c0 = std::min(first, st->ntile_c), c1 = std::min(first + count, st->ntile_c);
@@ -1816,7 +1946,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
 #define F32(KIND, TWO, first_, count_)                                                                                \
     ABACUS_LAUNCH("hod_filter", (hod_filter32<KIND, TWO>), dim3(count_), dim3(FBLOCK), 0, a, fc, first_, p->want_LRG, \
                   p->want_ELG, p->want_QSO, p->enable_ranks, need_env, need_shear, F, cheap)
-        const bool c2 = F.cent_ok && cheap.c_ok, s2 = F.sat_ok && cheap.s_ok;
+        const bool c2 = cheap.c_ok != 0, s2 = cheap.s_ok != 0;
         if (c1 > c0 && s1 > s0 && c2 == s2) {   // both kinds, same path: one launch
             if (c2) F32(2, true, first, count);
             else F32(2, false, first, count);
@@ -1842,9 +1972,16 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     }
 #define EXACT(first, count) \
     if ((count) > 0) ABACUS_LAUNCH("hod_exact", hod_exact, dim3(count), dim3(FBLOCK), 0, a, first, *p, pre)
+    // the two-stage satellite filter bounds the conformity variants by their largest, so it does not wait for the exact
+    // central decisions: one filter launch for both kinds, then the exact passes in order
+    const bool filter_first = conf && use32 && cheap.s_ok;
     if (!conf) {
         FILTER(0, ntile)
         EXACT(0, nsb);
+    } else if (filter_first) {
+        FILTER(0, ntile)
+        EXACT(0, st->nsb_c);
+        EXACT(st->nsb_c, st->nsb_s);
     } else {
         FILTER(0, st->ntile_c)
         EXACT(0, st->nsb_c);

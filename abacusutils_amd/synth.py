@@ -30,6 +30,20 @@ QSO_PARAMS = dict(
     Acent=0, Asat=0, Bcent=0, Bsat=0, ic=1.0,
 )
 
+# "production" multi-tracer mix of BASELINE config 5 (LRG + ELG + QSO on one catalogue): the yaml blocks above with
+# assembly bias, satellite rank modulation, velocity bias and ELG conformity switched on (the keys an MCMC samples,
+# docs/hod.rst; magnitudes typical of the AbacusSummit fits).  QSO incompleteness 0.05: the yaml's ic = 1 on the synthetic
+# mass function of synth_hod_inputs would put a quasar in 70 % of the halos.
+PRODUCTION_TRACERS = {
+    'LRG': dict(LRG_PARAMS, alpha_c=0.3, alpha_s=0.9, s=0.2, s_v=-0.1, s_p=0.1, s_r=-0.15,
+                Acent=-0.15, Asat=0.1, Bcent=0.08, Bsat=-0.12),
+    'ELG': dict(ELG_PARAMS, alpha_c=0.2, alpha_s=1.1, s=-0.2, s_v=0.1, s_p=-0.1, s_r=0.1,
+                Acent=0.1, Asat=-0.1, Bcent=-0.1, Bsat=0.15, Ccent=0.05, Csat=-0.05,
+                logM1_EE=13.2, alpha_EE=0.9, logM1_EL=13.8, alpha_EL=1.1),
+    'QSO': dict(QSO_PARAMS, alpha_c=0.4, alpha_s=1.0, s=0.1, s_v=0.1, s_p=-0.1, s_r=0.05,
+                Acent=0.1, Asat=0.05, Bcent=-0.05, Bsat=0.1, ic=0.05),
+}
+
 
 def _downfactor_lrg(m):
     """halo subsampling fraction, LRG-only branch (hod/prepare_sim.py:103-107)"""

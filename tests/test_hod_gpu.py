@@ -94,6 +94,31 @@ def test_full_size_c2_bit_exact(G):
     assert np.all((mock['LRG']['z'] >= -L / 2 - 1.0) & (mock['LRG']['z'] < L / 2 + 1.0))
 
 
+def test_full_size_c5_multi_tracer_bit_exact(G):
+    """BASELINE config 5's HOD at C2 size (the `hod_multi` leg of bench.py): 10^7 halos + 10^7 particles, LRG + ELG + QSO
+    with assembly bias, rank modulation, velocity bias and ELG conformity (synth.PRODUCTION_TRACERS) - the envelope
+    table of the two-stage filter, the conformity variants bounded ahead of the exact central pass - against the CPU
+    oracle: keep masks, counts and all eight columns of the three catalogues bit-equal"""
+    from oracle import oracle
+    n = 10_000_000
+    hd, pd, params = synth.synth_hod_inputs(n, n, seed=600, with_ranks=True)
+    tracers = synth.PRODUCTION_TRACERS
+    st = G.StagedCatalog(hd, pd)
+    p = G.marshal_params(tracers, params, True, True)
+    ncent, nsat = st.populate(p)
+    kc, ks = st.fetch_keep()
+    mock = {tr: st.fetch(tr) for tr in tracers}
+    st.free()
+    want, wkc, wks = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=oracle.max_threads(), enable_ranks=True,
+                                        rsd=True, return_keep=True)
+    np.testing.assert_array_equal(kc, wkc)
+    np.testing.assert_array_equal(ks, wks)
+    for t, tr in enumerate(('LRG', 'ELG', 'QSO')):
+        assert ncent[t] == want[tr]['Ncent'] and ncent[t] + nsat[t] == len(want[tr]['x'])
+        assert ncent[t] > 1000 and nsat[t] > 100     # every branch populated
+    assert_mock_equal(mock, want, exact=True)
+
+
 def test_capacity_growth_and_param_change(G):
     """first populate emits few galaxies, second many more than the catalog buffers hold: buffers grow, order kept"""
     from oracle import oracle

@@ -428,7 +428,9 @@ def test_c3_full_size_against_oracle():
     np.testing.assert_allclose(np.asarray(a['poles']), b['poles'], rtol=1e-5, atol=1e-5 * scale)
     np.testing.assert_allclose(np.asarray(a['k_avg'])[ok], b['k_avg'][ok], rtol=1e-6)
     shot = box**3 / n
-    assert abs(np.mean(np.asarray(a['poles'])[8:128, 0]) / shot - 1) < 5e-3    # flat shot noise below the window's reach
+    # flat shot noise where the (uncompensated) TSC window is still ~1: k <= k_Nyquist / 14 -> W^2 >= 0.99; the few thousand
+    # modes of these bins scatter at the per-cent level
+    assert abs(np.mean(np.asarray(a['poles'])[4:36, 0]) / shot - 1) < 2.5e-2
 
 
 @pytest.mark.parametrize('nmesh,comp', [(1024, False), (1024, True)])
