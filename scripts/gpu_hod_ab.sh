@@ -1,14 +1,27 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
+#!/bin/bash
+# HOD A/B on the GPU box: tests of the HOD path, then the bench legs with the fused exact+emit / interval classifier on and off
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=$GRAFT_REPO_ROOT/gpurun_out/hod_ab
+mkdir -p "$O"
 make -s -C oracle
-timeout 900 python -m pytest tests/test_hod_gpu.py tests/test_abacus_hod_gpu.py tests/test_hod_shard.py -m gpu -x -q 2>&1 | tail -15
-for v in ""; do
-  echo "== variant: $v"
-  env $v timeout 600 python bench.py --no-pk --no-cpu --steps 50 --warmup 3 > gpurun_out/bench_hod.json 2> gpurun_out/bench_hod.err
-  python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench_hod.json'))
-print({k:d[k] for k in ('value','ms_per_step','ms_per_step_host_sync','kernels_ms')}); print(d.get('roofline'))
+if [ "$1" != "notest" ]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q -k "hod" 2>&1 | tail -8 | tee "$O/tests.log"
+  grep -q "failed\|error" "$O/tests.log" && exit 1
+fi
+for mode in fused nocls nofuse; do
+  case $mode in
+    fused) env_=() ;;
+    nocls) env_=(ABACUS_HOD_NOCLS=1) ;;
+    nofuse) env_=(ABACUS_HOD_NOFUSE=1) ;;
+  esac
+  env "${env_[@]}" timeout 600 python bench.py --no-cpu --steps 20 --warmup 3 > "$O/bench_$mode.json" 2> "$O/bench_$mode.err" || { tail -5 "$O/bench_$mode.err"; exit 1; }
+  python - "$O/bench_$mode.json" "$mode" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for k in ('', 'hod_multi', 'hod_large'):
+    e = d[k] if k else d
+    if 'error' in e:
+        print(sys.argv[2], k, e['error']); continue
+    print(sys.argv[2], k or 'C2', 'ms/step %.4f' % e['ms_per_step'], 'halos/s %.3e' % e['value'], {a: round(b * 1e3, 1) for a, b in e['kernels_ms'].items() if a.startswith('hod_') and a not in ('hod_build_recs', 'hod_shadow', 'hod_minmax')})
 PY
-  tail -2 gpurun_out/bench_hod.err
 done
