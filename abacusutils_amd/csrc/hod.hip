@@ -542,7 +542,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter32(HodPtrs a, FiltCols c, in
     if constexpr (TWO_STAGE) {
         // ---- stage 1: envelope table bound - three float4 loads per four objects whatever the HOD weights ----
         const float dec = ch.dec_max;
-#pragma unroll
+#pragma unroll 1
         for (int k = 0; k < PER_THREAD / 4; k++) {
             const int loc = k * (4 * FBLOCK) + 4 * tid;
             const int64_t i = tile0 + loc;
@@ -638,6 +638,20 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter32(HodPtrs a, FiltCols c, in
     for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
 }
 
+// The reference's float64 chains as OUT-OF-LINE functions reading the parameters through a pointer (the workgroup's LDS
+// copy).  hod_exact settles its candidates with the float32 interval classifier (hod_classify.hpp: a decision is taken
+// from float32 enclosures of the markers unless the random lies inside a band) and calls these only for the undecided few
+// 1e-4; inlined, their ~190 registers (hoisted float64 constants of three tracers) set the occupancy of the whole kernel.
+__device__ __noinline__ int cent_decide_cold(const abacus_hod_params *p, double mass, double multis, double rnd, double dc,
+                                             double fe, double sh) {
+    return cent_decide(*p, mass, multis, rnd, dc, fe, sh);
+}
+__device__ __noinline__ int sat_decide_cold(const abacus_hod_params *p, const SatPre *pre, double mass, double w, double rnd,
+                                            double dc, double fe, double sh, double r0, double r1, double r2, double r3,
+                                            int kc) {
+    return sat_decide(*p, *pre, mass, w, rnd, dc, fe, sh, r0, r1, r2, r3, (int8_t)kc);
+}
+
 // Exact kernel: one workgroup per superblock (16 tiles = 32768 objects).  The tiles' queue lengths are prefix-summed
 // in LDS so the few hundred survivors of the superblock are processed as one dense list.  Kept objects set a bit in
 // one of three LDS bitmaps (one per tracer); a popcount scan of the bitmaps then yields every kept object's rank in
@@ -663,9 +677,17 @@ __device__ __forceinline__ int exact_find_tile(const ExactLds &L, int j) {   // 
 
 // One launch for the central superblocks (global superblock id < nsb_c) and the satellite ones; `first_sb` splits
 // it when the satellites depend on the exact central decisions (ELG conformity).
-__global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre) {
+__global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre,
+                                                    abacus_cls::ClsConst cc, int use_cls) {
     __shared__ ExactLds L;
+    __shared__ abacus_hod_params s_p;     // read by the out-of-line float64 chains
+    __shared__ SatPre s_pre;
     const int tid = threadIdx.x;
+    static_assert(sizeof(abacus_hod_params) % 8 == 0 && sizeof(SatPre) % 8 == 0, "copied as 8-byte words");
+    if (tid < (int)(sizeof(abacus_hod_params) / 8))
+        reinterpret_cast<unsigned long long *>(&s_p)[tid] = reinterpret_cast<const unsigned long long *>(&p)[tid];
+    if (tid < (int)(sizeof(SatPre) / 8))
+        reinterpret_cast<unsigned long long *>(&s_pre)[tid] = reinterpret_cast<const unsigned long long *>(&pre)[tid];
     const int g = (int)blockIdx.x + first_sb;
     const bool sat = g >= a.nsb_c;
     const int S = sat ? g - a.nsb_c : g;
@@ -684,54 +706,48 @@ __global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, aba
         for (int q = 1; q <= SB_TILES; q++) L.pre[q] += L.pre[q - 1];
     __syncthreads();
     const int total = L.pre[SB_TILES];
-    if (!sat) {
-        const double *sh_arr = p.want_ELG ? a.hshear : nullptr;
-        for (int j = tid; j < total; j += FBLOCK) {
-            const int q = exact_find_tile(L, j);
-            const int64_t t0 = (int64_t)(tile_first + q) * TILE;
-            const int loc = a.queue_c[t0 + (j - L.pre[q])];
-            const int64_t i = t0 + loc;
-            int8_t kk;
+    const bool need_conf = sat && p.want_ELG && a.pinds != nullptr;
+    const bool need_ranks = p.enable_ranks != 0;
+    for (int j = tid; j < total; j += FBLOCK) {
+        const int q = exact_find_tile(L, j);
+        const int64_t t0 = (int64_t)(tile_first + q) * TILE;
+        const int loc = (sat ? a.queue_s : a.queue_c)[t0 + (j - L.pre[q])];
+        const int64_t i = t0 + loc;
+        double mass, w, rnd, dc, fe, sh, r0 = 1.0, r1 = 1.0, r2 = 1.0, r3 = 1.0;
+        int kc = 0;
+        if (!sat) {
+            rnd = a.hrandoms[i];
             if (a.hrec) {
                 const HaloRec &r = a.hrec[i];
-                kk = cent_decide(p, r.mass, r.multis, a.hrandoms[i], r.deltac, r.fenv, p.want_ELG ? r.shear : 0.0);
+                mass = r.mass, w = r.multis, dc = r.deltac, fe = r.fenv, sh = p.want_ELG ? r.shear : 0.0;
             } else {
-                kk = cent_decide(p, a.hmass[i], a.hmultis[i], a.hrandoms[i], load1(a.hdeltac, i, 0.0),
-                                 load1(a.hfenv, i, 0.0), load1(sh_arr, i, 0.0));
+                mass = a.hmass[i], w = a.hmultis[i], dc = load1(a.hdeltac, i, 0.0), fe = load1(a.hfenv, i, 0.0),
+                sh = p.want_ELG ? load1(a.hshear, i, 0.0) : 0.0;
             }
-            if (kk) {
-                a.keep_c[i] = kk;
-                const int ls = q * TILE + loc;
-                atomicOr(&L.bm[kk - 1][ls >> 5], 1u << (ls & 31));
-            }
-        }
-    } else {
-        const double *sh_arr = p.want_ELG ? a.pshear : nullptr;
-        const bool need_conf = p.want_ELG && a.pinds != nullptr;
-        const bool need_ranks = p.enable_ranks != 0;
-        for (int j = tid; j < total; j += FBLOCK) {
-            const int q = exact_find_tile(L, j);
-            const int64_t t0 = (int64_t)(tile_first + q) * TILE;
-            const int loc = a.queue_s[t0 + (j - L.pre[q])];
-            const int64_t i = t0 + loc;
-            const int8_t kc = need_conf ? a.keep_c[a.pinds[i]] : (int8_t)0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
-            int8_t kk;
+        } else {
+            kc = need_conf ? a.keep_c[a.pinds[i]] : 0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
+            rnd = a.prandoms[i];
             if (a.prec) {
                 const PartRec &r = a.prec[i];
-                kk = sat_decide(p, pre, r.mass, r.weights, a.prandoms[i], r.deltac, r.fenv, p.want_ELG ? r.shear : 0.0,
-                                need_ranks ? r.ranks[0] : 1.0, need_ranks ? r.ranks[1] : 1.0, need_ranks ? r.ranks[2] : 1.0,
-                                need_ranks ? r.ranks[3] : 1.0, kc);
+                mass = r.mass, w = r.weights, dc = r.deltac, fe = r.fenv, sh = p.want_ELG ? r.shear : 0.0;
+                if (need_ranks) r0 = r.ranks[0], r1 = r.ranks[1], r2 = r.ranks[2], r3 = r.ranks[3];
             } else {
-                kk = sat_decide(p, pre, a.phmass[i], a.pweights[i], a.prandoms[i], load1(a.pdeltac, i, 0.0),
-                                load1(a.pfenv, i, 0.0), load1(sh_arr, i, 0.0), need_ranks ? a.pranks[i] : 1.0,
-                                need_ranks ? a.pranksv[i] : 1.0, need_ranks ? a.pranksp[i] : 1.0,
-                                need_ranks ? a.pranksr[i] : 1.0, kc);
+                mass = a.phmass[i], w = a.pweights[i], dc = load1(a.pdeltac, i, 0.0), fe = load1(a.pfenv, i, 0.0),
+                sh = p.want_ELG ? load1(a.pshear, i, 0.0) : 0.0;
+                if (need_ranks) r0 = a.pranks[i], r1 = a.pranksv[i], r2 = a.pranksp[i], r3 = a.pranksr[i];
             }
-            if (kk) {
-                a.keep_s[i] = kk;
-                const int ls = q * TILE + loc;
-                atomicOr(&L.bm[kk - 1][ls >> 5], 1u << (ls & 31));
-            }
+        }
+        int kk = -1;
+        if (use_cls)
+            kk = sat ? abacus_cls::sat_classify(cc, mass, w, rnd, dc, fe, sh, r0, r1, r2, r3, kc)
+                     : abacus_cls::cent_classify(cc, mass, w, rnd, dc, fe, sh);
+        if (kk < 0)   // the random lies inside a marker's band (or the classifier is off): the reference's float64 chain
+            kk = sat ? sat_decide_cold(&s_p, &s_pre, mass, w, rnd, dc, fe, sh, r0, r1, r2, r3, kc)
+                     : cent_decide_cold(&s_p, mass, w, rnd, dc, fe, sh);
+        if (kk) {
+            (sat ? a.keep_s : a.keep_c)[i] = (int8_t)kk;
+            const int ls = q * TILE + loc;
+            atomicOr(&L.bm[kk - 1][ls >> 5], 1u << (ls & 31));
         }
     }
     __syncthreads();
@@ -933,240 +949,6 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
             id = in.phid[i];
         }
         emit_one(p, o, t, j, x, y, z, vx, vy, vz, m, id);
-    }
-}
-
-// ---- fused exact + emit (owned catalogues) ---------------------------------------------------------------------------------
-// One launch replaces hod_exact + hod_emit: a workgroup decides the candidates of its superblock, publishes its three
-// counts, obtains its output offsets by looking back at the counts of the superblocks in front of it, and emits its kept
-// rows straight from the LDS bitmaps - no kept list and no counters travel through HBM between two launches, the rows
-// are gathered while the decision's records are still in cache, and one launch (with its drain / fill) disappears.
-//   * Superblocks are taken in TICKET order (an atomic counter), so a workgroup only ever waits for workgroups that
-//     started before it: no deadlock whatever the hardware's dispatch order or the grid size.
-//   * Counts + a ready bit are ONE 64-bit word per superblock, written and polled with agent-scope atomics.
-//   * ELG conformity: satellite superblocks wait for every central superblock's word, then (acquire fence) read
-//     keep_cent[pinds] - the central workgroups release-fence their keep bytes before publishing.
-//   * Decisions: the float32 interval classifier (hod_classify.hpp) settles all but the few 1e-4 of the candidates whose
-//     random lies inside a marker's band; those run the reference's float64 chain.  Bit-identical to deciding everything
-//     in float64 (tests/test_hod_classify.py holds the classifier to the oracle on the CPU).
-// the reference's float64 chains as out-of-line functions reading the parameters through a pointer (the workgroup's LDS
-// copy): they run for a few 1e-4 of the candidates only, and kept out of line their ~190 registers do not set the
-// occupancy of the whole kernel
-__device__ __noinline__ int cent_decide_cold(const abacus_hod_params *p, double mass, double multis, double rnd, double dc,
-                                             double fe, double sh) {
-    return cent_decide(*p, mass, multis, rnd, dc, fe, sh);
-}
-__device__ __noinline__ int sat_decide_cold(const abacus_hod_params *p, const SatPre *pre, double mass, double w, double rnd,
-                                            double dc, double fe, double sh, double r0, double r1, double r2, double r3,
-                                            int kc) {
-    return sat_decide(*p, *pre, mass, w, rnd, dc, fe, sh, r0, r1, r2, r3, (int8_t)kc);
-}
-
-struct FusedCtl {
-    unsigned int *ticket;            // [1]
-    unsigned long long *state;       // [nsb_c + nsb_s]: bit 63 ready, 3 x 17-bit counts
-    int64_t *totals;                 // [6]
-    int use_cls;
-};
-constexpr unsigned long long FUSED_READY = 1ull << 63;
-constexpr int FUSED_AMB = 1024;   // LDS list of candidates the interval classifier leaves undecided
-
-__device__ __forceinline__ unsigned long long fused_wait(const unsigned long long *w) {
-    unsigned long long v;
-    while (!((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & FUSED_READY)) __builtin_amdgcn_s_sleep(2);
-    return v;
-}
-
-__global__ __launch_bounds__(FBLOCK) void hod_fused(HodPtrs a, abacus_hod_params p, SatPre pre, abacus_cls::ClsConst cc,
-                                                    FusedCtl ctl, const double *__restrict__ hvdev, OutCols o) {
-    __shared__ ExactLds L;
-    __shared__ int s_ticket, s_namb;
-    __shared__ unsigned int s_amb[FUSED_AMB];
-    __shared__ int64_t red[FBLOCK / 64][6];
-    __shared__ abacus_hod_params s_p;     // read by the out-of-line float64 chains
-    __shared__ SatPre s_pre;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_ticket = (int)atomicAdd(ctl.ticket, 1u), s_namb = 0;
-    static_assert(sizeof(abacus_hod_params) % 8 == 0 && sizeof(SatPre) % 8 == 0, "copied as 8-byte words");
-    if (tid < (int)(sizeof(abacus_hod_params) / 8))
-        reinterpret_cast<unsigned long long *>(&s_p)[tid] = reinterpret_cast<const unsigned long long *>(&p)[tid];
-    if (tid < (int)(sizeof(SatPre) / 8))
-        reinterpret_cast<unsigned long long *>(&s_pre)[tid] = reinterpret_cast<const unsigned long long *>(&pre)[tid];
-#pragma unroll
-    for (int w = 0; w < 3 * WORDS_PER_THREAD; w++) (&L.bm[0][0])[w * FBLOCK + tid] = 0u;
-    __syncthreads();
-    const int g = s_ticket;
-    const bool sat = g >= a.nsb_c;
-    const int S = sat ? g - a.nsb_c : g;
-    const int ntile = sat ? a.ntile_s : a.ntile_c;
-    const int tile_first = S * SB_TILES;
-    const int *q_count = a.q_count + (sat ? a.ntile_c : 0);
-    if (tid < SB_TILES) {
-        const int t = tile_first + tid;
-        L.pre[tid + 1] = t < ntile ? q_count[t] : 0;
-    }
-    if (tid == 0) L.pre[0] = 0;
-    const bool need_conf = sat && p.want_ELG && a.pinds != nullptr;
-    if (need_conf) {   // every central decision must be final (and visible) before keep_cent[pinds] is read
-        for (int s = tid; s < a.nsb_c; s += FBLOCK) (void)fused_wait(&ctl.state[s]);
-        __threadfence();
-    }
-    __syncthreads();
-    if (tid == 0)
-        for (int q = 1; q <= SB_TILES; q++) L.pre[q] += L.pre[q - 1];
-    __syncthreads();
-    const int total = L.pre[SB_TILES];
-    const bool need_ranks = p.enable_ranks != 0;
-    // pass A: float32 interval classification of every candidate; the undecided ones (random inside a marker's band) are
-    // listed in LDS.  pass B: the reference's float64 chain for the listed ones.  Two loops so that the registers of the
-    // two evaluations never live together (one loop body needed 256 + 12 registers: one wave per SIMD).
-    auto settle = [&](int q, int loc, int64_t i, int kk) {
-        if (!kk) return;
-        (sat ? a.keep_s : a.keep_c)[i] = (int8_t)kk;
-        const int ls = q * TILE + loc;
-        atomicOr(&L.bm[kk - 1][ls >> 5], 1u << (ls & 31));
-    };
-    auto exact_one = [&](int64_t i) -> int {
-        if (!sat) {
-            const HaloRec &r = a.hrec[i];
-            return cent_decide_cold(&s_p, r.mass, r.multis, a.hrandoms[i], r.deltac, r.fenv, p.want_ELG ? r.shear : 0.0);
-        }
-        const int8_t kc = need_conf ? a.keep_c[a.pinds[i]] : (int8_t)0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
-        const PartRec &r = a.prec[i];
-        return sat_decide_cold(&s_p, &s_pre, r.mass, r.weights, a.prandoms[i], r.deltac, r.fenv, p.want_ELG ? r.shear : 0.0,
-                               need_ranks ? r.ranks[0] : 1.0, need_ranks ? r.ranks[1] : 1.0, need_ranks ? r.ranks[2] : 1.0,
-                               need_ranks ? r.ranks[3] : 1.0, kc);
-    };
-    for (int j = tid; j < total; j += FBLOCK) {
-        const int q = exact_find_tile(L, j);
-        const int64_t t0 = (int64_t)(tile_first + q) * TILE;
-        const int loc = (sat ? a.queue_s : a.queue_c)[t0 + (j - L.pre[q])];
-        const int64_t i = t0 + loc;
-        int kk = -1;
-        if (ctl.use_cls) {
-            if (!sat) {
-                const HaloRec &r = a.hrec[i];
-                kk = abacus_cls::cent_classify(cc, r.mass, r.multis, a.hrandoms[i], r.deltac, r.fenv,
-                                               p.want_ELG ? r.shear : 0.0);
-            } else {
-                const int8_t kc = need_conf ? a.keep_c[a.pinds[i]] : (int8_t)0;
-                const PartRec &r = a.prec[i];
-                kk = abacus_cls::sat_classify(cc, r.mass, r.weights, a.prandoms[i], r.deltac, r.fenv,
-                                              p.want_ELG ? r.shear : 0.0, need_ranks ? r.ranks[0] : 1.0,
-                                              need_ranks ? r.ranks[1] : 1.0, need_ranks ? r.ranks[2] : 1.0,
-                                              need_ranks ? r.ranks[3] : 1.0, kc);
-            }
-        }
-        if (kk < 0) {
-            const int slot = atomicAdd(&s_namb, 1);
-            if (slot < FUSED_AMB) s_amb[slot] = ((unsigned int)q << 16) | (unsigned int)loc;
-            else kk = exact_one(i);      // list full (only with use_cls off or pathological parameters): decide in place
-        }
-        if (kk > 0) settle(q, loc, i, kk);
-    }
-    __syncthreads();
-    {
-        const int namb = min(s_namb, FUSED_AMB);
-        for (int e = tid; e < namb; e += FBLOCK) {
-            const int q = (int)(s_amb[e] >> 16), loc = (int)(s_amb[e] & 0xffffu);
-            const int64_t i = (int64_t)(tile_first + q) * TILE + loc;
-            settle(q, loc, i, exact_one(i));
-        }
-    }
-    __syncthreads();
-    // ranks: thread t owns words [4t, 4t+4) of each bitmap; packed 3 x 21-bit exclusive scan over the workgroup
-    unsigned int wbits[3][WORDS_PER_THREAD];
-    unsigned long long mine = 0;
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        unsigned int c = 0;
-#pragma unroll
-        for (int w = 0; w < WORDS_PER_THREAD; w++) {
-            wbits[t][w] = L.bm[t][tid * WORDS_PER_THREAD + w];
-            c += __popc(wbits[t][w]);
-        }
-        mine |= (unsigned long long)c << (21 * t);
-    }
-    unsigned long long incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long v = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += v;
-    }
-    if (lane == 63) L.wave_tot[wv] = incl;
-    __syncthreads();
-    unsigned long long before = 0, all = 0;
-#pragma unroll
-    for (int w = 0; w < FBLOCK / 64; w++) {
-        if (w < wv) before += L.wave_tot[w];
-        all += L.wave_tot[w];
-    }
-    const unsigned long long excl = before + incl - mine;
-    const int T[3] = {(int)(all & 0x1fffff), (int)((all >> 21) & 0x1fffff), (int)((all >> 42) & 0x1fffff)};
-    if (tid == 0) {
-        // release: the keep bytes of this superblock become visible to the satellites' conformity look-ups
-        if (!sat && p.want_ELG) __threadfence();
-        const unsigned long long word = FUSED_READY | (unsigned long long)T[0] | ((unsigned long long)T[1] << 17) |
-                                        ((unsigned long long)T[2] << 34);
-        __hip_atomic_store(&ctl.state[g], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // look-back: v[0..2] = counts of the superblocks of my kind in front of me; v[3..5] = all central counts
-    int64_t v[6] = {0, 0, 0, 0, 0, 0};
-    const unsigned long long *mine_state = ctl.state + (sat ? a.nsb_c : 0);
-    for (int s = tid; s < S; s += FBLOCK) {
-        const unsigned long long w = fused_wait(&mine_state[s]);
-        v[0] += (int64_t)(w & 0x1ffff), v[1] += (int64_t)((w >> 17) & 0x1ffff), v[2] += (int64_t)((w >> 34) & 0x1ffff);
-    }
-    if (sat)
-        for (int s = tid; s < a.nsb_c; s += FBLOCK) {
-            const unsigned long long w = fused_wait(&ctl.state[s]);
-            v[3] += (int64_t)(w & 0x1ffff), v[4] += (int64_t)((w >> 17) & 0x1ffff), v[5] += (int64_t)((w >> 34) & 0x1ffff);
-        }
-#pragma unroll
-    for (int t = 0; t < 6; t++) v[t] = wave_sum(v[t]);
-    if (lane == 0)
-#pragma unroll
-        for (int t = 0; t < 6; t++) red[wv][t] = v[t];
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 6; t++) {
-        v[t] = 0;
-#pragma unroll
-        for (int w = 0; w < FBLOCK / 64; w++) v[t] += red[w][t];
-    }
-    if (g == a.nsb_c + a.nsb_s - 1 && tid == 0) {   // the last superblock knows every count in front of it: totals for the host
-        for (int t = 0; t < 3; t++) {
-            ctl.totals[t] = sat ? v[3 + t] : v[t] + T[t];
-            ctl.totals[3 + t] = sat ? v[t] + T[t] : 0;
-        }
-    }
-    if (T[0] + T[1] + T[2] == 0) return;
-    // emission (gen_cent pass 2 :295-381, gen_sats pass 2 :1131-1229): a thread emits the set bits of its own words in
-    // index order; satellites start after all centrals of their tracer (fast_concatenate never runs)
-    const double al[3] = {sat ? p.L_alpha_s : p.L_alpha_c, sat ? p.E_alpha_s : p.E_alpha_c, sat ? p.Q_alpha_s : p.Q_alpha_c};
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        int64_t j = v[t] + (sat ? v[3 + t] : 0) + (int64_t)((excl >> (21 * t)) & 0x1fffff);
-#pragma unroll
-        for (int w = 0; w < WORDS_PER_THREAD; w++) {
-            unsigned int bits = wbits[t][w];
-            while (bits) {
-                const int bpos = __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                const int64_t i = (int64_t)S * SB_OBJ + (tid * WORDS_PER_THREAD + w) * 32 + bpos;
-                if (!sat) {
-                    const HaloRec r = a.hrec[i];
-                    emit_one(p, o, t, j, r.pos[0], r.pos[1], r.pos[2], r.vel[0] + al[t] * hvdev[3 * i],
-                             r.vel[1] + al[t] * hvdev[3 * i + 1], r.vel[2] + al[t] * hvdev[3 * i + 2], r.mass, r.id);
-                } else {
-                    const PartRec r = a.prec[i];
-                    emit_one(p, o, t, j, r.pos[0], r.pos[1], r.pos[2], r.hvel[0] + al[t] * (r.vel[0] - r.hvel[0]),
-                             r.hvel[1] + al[t] * (r.vel[1] - r.hvel[1]), r.hvel[2] + al[t] * (r.vel[2] - r.hvel[2]), r.mass,
-                             r.id);
-                }
-                j++;
-            }
-        }
     }
 }
 
@@ -1522,8 +1304,6 @@ struct abacus_hod_state {
     bool rec_ok = false;
     HodRanges ranges;           // value ranges of the environment / rank columns (envelope table of the two-stage filter)
     bool ranges_ok = false;
-    DevBuf fused_ctl;           // hod_fused: [ticket (8 B)][one 64-bit word per superblock]
-    bool last_fused = false;    // the last populate ran the fused exact + emit (a capacity regrow repeats that launch)
 };
 
 namespace {
@@ -1774,30 +1554,7 @@ HodPtrs make_ptrs(const abacus_hod_state *st) {
     return a;
 }
 
-// the fused exact + emit launch for the parameters in st->params (queues of the last filter pass must be in place)
-int launch_fused(abacus_hod_state *st) {
-    const int nsb = st->nsb_c + st->nsb_s;
-    if (nsb == 0) {
-        HIP_TRY(hipMemsetAsync(st->d_totals, 0, 6 * sizeof(int64_t), stream()));
-        return 0;
-    }
-    static const bool nocls = getenv("ABACUS_HOD_NOCLS") != nullptr;
-    ABACUS_TRY(st->fused_ctl.reserve((size_t)(nsb + 1) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(st->fused_ctl.p, 0, (size_t)(nsb + 1) * sizeof(unsigned long long), stream()));
-    FusedCtl ctl;
-    ctl.ticket = st->fused_ctl.as<unsigned int>();
-    ctl.state = st->fused_ctl.as<unsigned long long>() + 1;
-    ctl.totals = st->d_totals;
-    ctl.use_cls = nocls ? 0 : 1;
-    abacus_cls::ClsConst cc;
-    abacus_cls::make_cls_const(st->params, make_pre(&st->params), cc);
-    ABACUS_LAUNCH("hod_fused", hod_fused, dim3(nsb), dim3(FBLOCK), 0, make_ptrs(st), st->params, make_pre(&st->params), cc,
-                  ctl, (const double *)st->hveldev, out_cols(st));
-    return 0;
-}
-
 int launch_emit(abacus_hod_state *st) {
-    if (st->last_fused) return launch_fused(st);
     const int nemit = st->nsb_c + st->nsb_s;
     if (nemit == 0) {
         HIP_TRY(hipMemsetAsync(st->d_totals, 0, 6 * sizeof(int64_t), stream()));
@@ -2066,7 +1823,6 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
         return fail("abacus_hod_populate_nfw: hsigma3d / hc / hrvir have not been staged (abacus_hod_set_sigma3d, _set_profile)");
     if (!NFW_draw || n_draw < 1) return fail("abacus_hod_populate_nfw: NFW_draw is empty");
     st->params = *p;
-    st->last_fused = false;   // this path decides and emits the centrals with hod_exact + hod_emit
     SatPre pre;
     memset(&pre, 0, sizeof pre);
     Filt F = make_filter(*p, pre);
@@ -2086,7 +1842,9 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
     if (st->ntile_c) {
         ABACUS_LAUNCH("hod_filter", hod_filter, dim3(st->ntile_c), dim3(FBLOCK), 0, a, 0, p->want_LRG, p->want_ELG,
                       p->want_QSO, p->enable_ranks, need_env, need_shear, F);
-        ABACUS_LAUNCH("hod_exact", hod_exact, dim3(st->nsb_c), dim3(FBLOCK), 0, a, 0, *p, pre);
+        abacus_cls::ClsConst cc;
+        abacus_cls::make_cls_const(*p, pre, cc);
+        ABACUS_LAUNCH("hod_exact", hod_exact, dim3(st->nsb_c), dim3(FBLOCK), 0, a, 0, *p, pre, cc, 1);
     }
     ABACUS_TRY(launch_emit(st));
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
@@ -2235,18 +1993,15 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
             ABACUS_LAUNCH("hod_filter", hod_filter, dim3(count), dim3(FBLOCK), 0, a, first, p->want_LRG, p->want_ELG, \
                           p->want_QSO, p->enable_ranks, need_env, need_shear, F);                                    \
     }
+    static const bool nocls = getenv("ABACUS_HOD_NOCLS") != nullptr;   // A/B: every candidate through the float64 chain
+    abacus_cls::ClsConst cc;
+    abacus_cls::make_cls_const(*p, pre, cc);
 #define EXACT(first, count) \
-    if ((count) > 0) ABACUS_LAUNCH("hod_exact", hod_exact, dim3(count), dim3(FBLOCK), 0, a, first, *p, pre)
+    if ((count) > 0) ABACUS_LAUNCH("hod_exact", hod_exact, dim3(count), dim3(FBLOCK), 0, a, first, *p, pre, cc, nocls ? 0 : 1)
     // the two-stage satellite filter bounds the conformity variants by their largest, so it does not wait for the exact
     // central decisions: one filter launch for both kinds, then the exact passes in order
     const bool filter_first = conf && use32 && cheap.s_ok;
-    // owned catalogues with packed records: exact decisions and emission in ONE launch (hod_fused) - needs a satellite
-    // filter that does not read keep_cent (always, unless conformity meets the one-stage fallback)
-    static const bool nofuse = getenv("ABACUS_HOD_NOFUSE") != nullptr;
-    st->last_fused = st->rec_ok && use32 && !nofuse && (!conf || filter_first);
-    if (st->last_fused) {
-        FILTER(0, ntile)
-    } else if (!conf) {
+    if (!conf) {
         FILTER(0, ntile)
         EXACT(0, nsb);
     } else if (filter_first) {

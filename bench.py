@@ -46,7 +46,8 @@ def parse():
     ap.add_argument('--nmesh', type=int, default=2048)
     ap.add_argument('--npk', type=int, default=100_000_000, help='particles for the P(k) workload')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--no-pk', action='store_true', help='skip the secondary P(k) measurement')
+    ap.add_argument('--no-pk', action='store_true', help='skip the secondary P(k) / pairs / catalogue measurements')
+    ap.add_argument('--no-hod-extra', action='store_true', help='skip the hod_multi and hod_large legs')
     ap.add_argument('--no-slab', action='store_true', help='N > 1: skip the slab-decomposed P(k) leg (RCCL all-to-all)')
     ap.add_argument('--slab-timeout', type=float, default=240.0, help='seconds before the slab leg is abandoned')
     ap.add_argument('--hod-timeout', type=float, default=420.0, help='N > 1: seconds before the headline leg is abandoned')
@@ -180,7 +181,7 @@ def bench_hod(args, dist):
     if single and not args.no_cpu:   # CPU baseline: rank 0 at N = 1 only
         out['cpu_baseline'] = cpu_baseline_hod(*inputs, {'LRG': synth.LRG_PARAMS}, nh)
     del inputs
-    if single and not args.no_pk:
+    if single and not args.no_hod_extra:
         for key, fn in (
             ('hod_multi', lambda: measure_hod(
                 args, dist, nh, npart, synth.PRODUCTION_TRACERS, True, True,

@@ -1,20 +1,19 @@
 #!/bin/bash
-# HOD A/B on the GPU box: tests of the HOD path, then the bench legs with the fused exact+emit / interval classifier on and off
+# HOD A/B on the GPU box: tests of the HOD path, then the bench legs with the interval classifier of hod_exact on and off
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/hod_ab
 mkdir -p "$O"
 make -s -C oracle
 if [ "$1" != "notest" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q -k "hod" 2>&1 | tail -8 | tee "$O/tests.log"
-  grep -q "failed\|error" "$O/tests.log" && exit 1
+  grep -qE "[0-9]+ (failed|error)" "$O/tests.log" && exit 1
 fi
-for mode in fused nocls nofuse; do
+for mode in cls nocls; do
   case $mode in
-    fused) env_=() ;;
+    cls) env_=() ;;
     nocls) env_=(ABACUS_HOD_NOCLS=1) ;;
-    nofuse) env_=(ABACUS_HOD_NOFUSE=1) ;;
   esac
-  env "${env_[@]}" timeout 600 python bench.py --no-cpu --steps 20 --warmup 3 > "$O/bench_$mode.json" 2> "$O/bench_$mode.err" || { tail -5 "$O/bench_$mode.err"; exit 1; }
+  env "${env_[@]}" timeout 600 python bench.py --no-cpu --no-pk --steps 20 --warmup 3 > "$O/bench_$mode.json" 2> "$O/bench_$mode.err" || { tail -5 "$O/bench_$mode.err"; exit 1; }
   python - "$O/bench_$mode.json" "$mode" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

@@ -19,7 +19,7 @@ bench)
   ;;
 prof)
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_hod" -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu --no-pk > "$O/prof_hod.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_hod" -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu --no-pk --no-hod-extra > "$O/prof_hod.log" 2>&1
   for NM in 1024 2048; do
     timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_pk$NM" -- python3 "$R/bench.py" --workload pk --nmesh $NM --steps 3 --warmup 1 --no-cpu > "$O/prof_pk$NM.log" 2>&1
   done
@@ -32,7 +32,7 @@ prof)
 pmc)
   cd /tmp
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/pmc_hod_$C" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu --no-pk > "$O/pmc_hod_$C.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/pmc_hod_$C" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu --no-pk --no-hod-extra > "$O/pmc_hod_$C.log" 2>&1
     timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/pmc_pk2048_$C" -- python3 "$R/bench.py" --workload pk --nmesh 2048 --steps 2 --warmup 1 --no-cpu > "$O/pmc_pk2048_$C.log" 2>&1
   done
   cd "$R"
