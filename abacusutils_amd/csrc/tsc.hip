@@ -289,33 +289,15 @@ __device__ __forceinline__ void for_each_tile(PT x, PT y, PT z, const TileGeom &
             for (int c = 0; c < nz; c++) f((unsigned int)((ax[a] * g.nty + ay[b]) * g.ntz + az[c]));
 }
 
-// the distinct coarse buckets (tile >> cshift) among the tiles a particle's cloud touches (at most 8 tiles)
-template <typename PT, bool CIC, typename F>
-__device__ __forceinline__ void for_each_bucket(PT x, PT y, PT z, const TileGeom &g, double box, PT offset, PT ihx, PT ihy,
-                                                PT ihz, int ext, int cshift, F f) {
-    unsigned int seen[8];
-    int ns = 0;
-    for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, ext, [&](unsigned int tile) {
-        const unsigned int b = tile >> cshift;
-        bool dup = false;
-        for (int q = 0; q < ns; q++) dup = dup || seen[q] == b;
-        if (!dup) {
-            if (ns < 8) seen[ns++] = b;
-            f(b);
-        }
-    });
-}
-
-// coarse pass over the particles: SCATTER=false counts copies per coarse bucket (and wraps in place), SCATTER=true
-// writes ONE copy of the particle per distinct coarse bucket of its tiles - no tile id travels with it: the fine pass
-// recomputes the tiles of the copy and keeps those of its own bucket (20 -> 16 bytes per staged entry, one scattered
-// store instead of two, and a particle whose tiles share a bucket is staged once)
+// coarse pass over the particles: SCATTER=false counts entries per coarse bucket (and wraps in place),
+// SCATTER=true writes (entry, tile id) grouped by coarse bucket
 template <typename PT, bool CIC, bool SCATTER>
 __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int64_t n, const PT *__restrict__ weights,
                                                       TileGeom g, double box, double offset_, int wrap, int cshift,
                                                       int ncoarse, unsigned int *__restrict__ gcount,
                                                       const int64_t *__restrict__ gstart,
-                                                      Entry<PT> *__restrict__ stage_entry, int *__restrict__ wrapped_flag,
+                                                      Entry<PT> *__restrict__ stage_entry,
+                                                      unsigned int *__restrict__ stage_key, int *__restrict__ wrapped_flag,
                                                       int ext) {
     __shared__ unsigned int hist[MS_BINS];
     __shared__ int64_t base[MS_BINS];
@@ -340,8 +322,8 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
                 any_changed = true;
             }
         }
-        for_each_bucket<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, ext, cshift,
-                                 [&](unsigned int b) { atomicAdd(&hist[b], 1u); });
+        for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, ext,
+                               [&](unsigned int tile) { atomicAdd(&hist[tile >> cshift], 1u); });
     }
     if (!SCATTER && any_changed) *wrapped_flag = 1;
     __syncthreads();
@@ -360,18 +342,21 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
     for (int64_t p = p0 + tid; p < p1; p += MS_BLOCK) {
         const PT x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
         const PT w = weights ? weights[p] : (PT)1;
-        for_each_bucket<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, ext, cshift, [&](unsigned int b) {
-            stage_entry[base[b] + atomicAdd(&hist[b], 1u)] = Entry<PT>{x, y, z, w};
+        for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, ext, [&](unsigned int tile) {
+            const unsigned int b = tile >> cshift;
+            const int64_t dst = base[b] + atomicAdd(&hist[b], 1u);
+            stage_entry[dst] = Entry<PT>{x, y, z, w};
+            stage_key[dst] = tile;
         });
     }
 }
 
-// fine pass inside coarse bucket blockIdx.y, chunk blockIdx.x of its staged copies: the tiles of a copy are recomputed
-// from its position, those of this bucket are counted (SCATTER=false) or receive the entry
-template <typename PT, bool CIC, bool SCATTER>
+// fine pass inside coarse bucket blockIdx.y, chunk blockIdx.x of its entries
+template <typename PT, bool SCATTER>
 __global__ __launch_bounds__(MS_BLOCK) void ms_fine(const int64_t *__restrict__ gstart, int cshift, int ntiles,
-                                                    const Entry<PT> *__restrict__ stage_entry, TileGeom g, double box,
-                                                    double offset_, int ext, unsigned int *__restrict__ tile_count,
+                                                    const Entry<PT> *__restrict__ stage_entry,
+                                                    const unsigned int *__restrict__ stage_key,
+                                                    unsigned int *__restrict__ tile_count,
                                                     const int64_t *__restrict__ tile_start,
                                                     Entry<PT> *__restrict__ entries) {
     __shared__ unsigned int hist[MS_BINS];
@@ -381,16 +366,9 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_fine(const int64_t *__restrict__ 
     if (e0 >= e1) return;
     const unsigned int tile0 = (unsigned int)B << cshift;
     const int nfine = min(1 << cshift, ntiles - (int)tile0);
-    const PT ihx = (PT)(g.gxg / box), ihy = (PT)(g.gy / box), ihz = (PT)(g.gz / box);
-    const PT offset = (PT)offset_;
     for (int f = tid; f < nfine; f += MS_BLOCK) hist[f] = 0u;
     __syncthreads();
-    for (int64_t e = e0 + tid; e < e1; e += MS_BLOCK) {
-        const Entry<PT> en = stage_entry[e];
-        for_each_tile<PT, CIC>(en.x, en.y, en.z, g, box, offset, ihx, ihy, ihz, ext, [&](unsigned int tile) {
-            if ((tile >> cshift) == (unsigned int)B) atomicAdd(&hist[tile - tile0], 1u);
-        });
-    }
+    for (int64_t e = e0 + tid; e < e1; e += MS_BLOCK) atomicAdd(&hist[stage_key[e] - tile0], 1u);
     __syncthreads();
     if (!SCATTER) {
         for (int f = tid; f < nfine; f += MS_BLOCK)
@@ -404,13 +382,8 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_fine(const int64_t *__restrict__ 
     }
     __syncthreads();
     for (int64_t e = e0 + tid; e < e1; e += MS_BLOCK) {
-        const Entry<PT> en = stage_entry[e];
-        for_each_tile<PT, CIC>(en.x, en.y, en.z, g, box, offset, ihx, ihy, ihz, ext, [&](unsigned int tile) {
-            if ((tile >> cshift) == (unsigned int)B) {
-                const unsigned int f = tile - tile0;
-                entries[base[f] + atomicAdd(&hist[f], 1u)] = en;
-            }
-        });
+        const unsigned int f = stage_key[e] - tile0;
+        entries[base[f] + atomicAdd(&hist[f], 1u)] = stage_entry[e];
     }
 }
 
@@ -702,7 +675,7 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
 
 // ---- host-side driver ------------------------------------------------------------------------------------
 struct TscWork {
-    DevBuf tile_count, tile_start, entries, flag, scan, gcount, gstart, stage_entry;
+    DevBuf tile_count, tile_start, entries, flag, scan, gcount, gstart, stage_entry, stage_key;
 };
 TscWork g_work;
 
@@ -785,7 +758,8 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         HIP_TRY(hipMemsetAsync(gcount, 0, (size_t)(MS_BINS + 1) * sizeof(unsigned int), stream()));
         const int cgrid = (int)ceil_div(n, MS_CHUNK);
         ABACUS_LAUNCH("tsc_ms_coarse_count", (ms_coarse<PT, CIC, false>), dim3(cgrid), dim3(MS_BLOCK), 0, pos, n, weights, g,
-                      box, offset, wrap, cshift, ncoarse, gcount, (const int64_t *)nullptr, (Entry<PT> *)nullptr, flag, ext);
+                      box, offset, wrap, cshift, ncoarse, gcount, (const int64_t *)nullptr, (Entry<PT> *)nullptr,
+                      (unsigned int *)nullptr, flag, ext);
         ABACUS_TRY(exclusive_scan_u32(gcount, ncoarse, gstart, g_work.scan, 1));   // counters re-zeroed: cursors
         std::vector<int64_t> h_start((size_t)ncoarse + 1);
         int h_flag = 0;
@@ -794,33 +768,32 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
         HIP_TRY(hipStreamSynchronize(stream()));
         if (wrapped_out) *wrapped_out = h_flag;
-        const int64_t total = h_start[ncoarse];   // staged copies: one per (particle, coarse bucket)
+        const int64_t total = h_start[ncoarse];
         nentries_total = total;
         int64_t maxbucket = 0;
         for (int b = 0; b < ncoarse; b++) maxbucket = std::max(maxbucket, h_start[b + 1] - h_start[b]);
         const size_t t1 = (size_t)std::max<int64_t>(total, 1);
         ABACUS_TRY(g_work.stage_entry.reserve(t1 * sizeof(Entry<PT>)));
+        ABACUS_TRY(g_work.stage_key.reserve(t1 * sizeof(unsigned int)));
         Entry<PT> *stage_entry = g_work.stage_entry.as<Entry<PT>>();
+        unsigned int *stage_key = g_work.stage_key.as<unsigned int>();
         ABACUS_LAUNCH("tsc_ms_coarse_scatter", (ms_coarse<PT, CIC, true>), dim3(cgrid), dim3(MS_BLOCK), 0, pos, n, weights,
-                      g, box, offset, 0, cshift, ncoarse, gcount, (const int64_t *)gstart, stage_entry, flag, ext);
+                      g, box, offset, 0, cshift, ncoarse, gcount, (const int64_t *)gstart, stage_entry, stage_key, flag, ext);
         if (cshift == 0) {   // every bucket is a tile already
             HIP_TRY(hipMemcpyAsync(tile_start, gstart, (size_t)(ntiles + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice,
                                    stream()));
             entries = stage_entry;
         } else {
+            ABACUS_TRY(g_work.entries.reserve(t1 * sizeof(Entry<PT>)));
+            entries = g_work.entries.as<Entry<PT>>();
             HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)(ntiles + 1) * sizeof(unsigned int), stream()));
             const dim3 fgrid((unsigned int)std::max<int64_t>(ceil_div(maxbucket, MS_FCHUNK), 1), (unsigned int)ncoarse);
-            ABACUS_LAUNCH("tsc_ms_fine_count", (ms_fine<PT, CIC, false>), fgrid, dim3(MS_BLOCK), 0, (const int64_t *)gstart,
-                          cshift, ntiles, (const Entry<PT> *)stage_entry, g, box, offset, ext, tile_count,
+            ABACUS_LAUNCH("tsc_ms_fine_count", (ms_fine<PT, false>), fgrid, dim3(MS_BLOCK), 0, (const int64_t *)gstart, cshift,
+                          ntiles, (const Entry<PT> *)stage_entry, (const unsigned int *)stage_key, tile_count,
                           (const int64_t *)nullptr, (Entry<PT> *)nullptr);
             ABACUS_TRY(exclusive_scan_u32(tile_count, ntiles, tile_start, g_work.scan, 1));
-            // list length: the copies expand to one entry per (particle, tile)
-            HIP_TRY(hipMemcpyAsync(&nentries_total, tile_start + ntiles, sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
-            HIP_TRY(hipStreamSynchronize(stream()));
-            ABACUS_TRY(g_work.entries.reserve((size_t)std::max<int64_t>(nentries_total, 1) * sizeof(Entry<PT>)));
-            entries = g_work.entries.as<Entry<PT>>();
-            ABACUS_LAUNCH("tsc_ms_fine_scatter", (ms_fine<PT, CIC, true>), fgrid, dim3(MS_BLOCK), 0, (const int64_t *)gstart,
-                          cshift, ntiles, (const Entry<PT> *)stage_entry, g, box, offset, ext, tile_count,
+            ABACUS_LAUNCH("tsc_ms_fine_scatter", (ms_fine<PT, true>), fgrid, dim3(MS_BLOCK), 0, (const int64_t *)gstart, cshift,
+                          ntiles, (const Entry<PT> *)stage_entry, (const unsigned int *)stage_key, tile_count,
                           (const int64_t *)tile_start, entries);
         }
     } else {
@@ -949,6 +922,7 @@ int tsc_release_work() {
     ABACUS_TRY(g_work.gcount.release());
     ABACUS_TRY(g_work.gstart.release());
     ABACUS_TRY(g_work.stage_entry.release());
+    ABACUS_TRY(g_work.stage_key.release());
     return 0;
 }
 }  // namespace abacus
