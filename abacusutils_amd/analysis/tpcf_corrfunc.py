@@ -29,11 +29,24 @@ def _f4(a):
 
 def _paircount(mode, X1, Y1, Z1, boxsize, bins, X2=None, Y2=None, Z2=None, pimax=0.0, npibins=0, mu_max=1.0,
                nmubins=0):
-    X1, Y1, Z1, X2, Y2, Z2 = map(_f4, (X1, Y1, Z1, X2, Y2, Z2))
+    """host arrays (cast to float32 like the reference, tpcf_corrfunc.py:134-139) or - all of them - `_lib.DeviceArray`
+    columns of float32 / float64 already in HBM (the HOD catalogue: `abacus_paircount_dev`, no PCIe round trip)"""
     bins = _f4(bins)
     nb = len(bins) - 1
     nsub = 1 if mode == 0 else (npibins if mode == 1 else nmubins)
     out = np.zeros(nb * nsub, dtype=np.uint64)
+    cols = [c for c in (X1, Y1, Z1, X2, Y2, Z2) if c is not None]
+    if any(isinstance(c, _lib.DeviceArray) for c in cols):
+        if not all(isinstance(c, _lib.DeviceArray) and c.dtype == cols[0].dtype for c in cols):
+            raise TypeError('device-resident coordinates: every column must be a DeviceArray of one dtype')
+        dt = {np.dtype(np.float32): 0, np.dtype(np.float64): 1}[cols[0].dtype]
+        dp = lambda c: None if c is None else c.ptr     # noqa: E731
+        check(_lib.lib().abacus_paircount_dev(
+            int(mode), dp(X1), dp(Y1), dp(Z1), C.c_int64(X1.shape[0]), dp(X2), dp(Y2), dp(Z2),
+            C.c_int64(0 if X2 is None else X2.shape[0]), dt, C.c_float(boxsize), ptr(bins), int(nb), C.c_float(pimax),
+            int(npibins), C.c_float(mu_max), int(nmubins), ptr(out)))
+        return out
+    X1, Y1, Z1, X2, Y2, Z2 = map(_f4, (X1, Y1, Z1, X2, Y2, Z2))
     check(_lib.lib().abacus_paircount(
         int(mode), ptr(X1), ptr(Y1), ptr(Z1), C.c_int64(len(X1)), ptr(X2), ptr(Y2), ptr(Z2),
         C.c_int64(0 if X2 is None else len(X2)), C.c_float(boxsize), ptr(bins), int(nb), C.c_float(pimax),

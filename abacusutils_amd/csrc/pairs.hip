@@ -45,18 +45,47 @@ __device__ __forceinline__ int cell_coord(float v, int nc, float inv_box) {
     return c >= nc ? nc - 1 : c;
 }
 
+// Coordinate frame of a catalogue: the smallest and the largest coordinate per dimension as order-preserving integer keys
+// (so that atomicMin / atomicMax work on floats).  Corrfunc accepts any coordinate range; galaxies from the HOD live in
+// [-L/2, L/2).  When every coordinate of both sets lies in ONE interval [a, a + L) the periodic image of a pair of cells
+// is known per cell pair (pair_count3); `outside` only says that the frame is not [0, L).
+struct Frame {
+    unsigned int mn[3], mx[3];
+};
+__device__ __forceinline__ unsigned int fkey(float v) {
+    const unsigned int u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float funkey(unsigned int k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 __global__ void cell_count(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
                            int64_t n, CellGrid g, unsigned int *__restrict__ counts, unsigned int *__restrict__ cellid,
-                           int *__restrict__ outside) {
+                           int *__restrict__ outside, Frame *__restrict__ frame) {
     bool out = false;
+    unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (cell_coord(x[i], g.ncx, g.inv_box) * g.ncy + cell_coord(y[i], g.ncy, g.inv_box)) * g.ncz +
-                      cell_coord(z[i], g.ncz, g.inv_box);
+        const float v[3] = {x[i], y[i], z[i]};
+        const int c = (cell_coord(v[0], g.ncx, g.inv_box) * g.ncy + cell_coord(v[1], g.ncy, g.inv_box)) * g.ncz +
+                      cell_coord(v[2], g.ncz, g.inv_box);
         cellid[i] = (unsigned int)c;
         atomicAdd(&counts[c], 1u);
-        out = out || !(x[i] >= 0.f && x[i] < g.box && y[i] >= 0.f && y[i] < g.box && z[i] >= 0.f && z[i] < g.box);
+        out = out || !(v[0] >= 0.f && v[0] < g.box && v[1] >= 0.f && v[1] < g.box && v[2] >= 0.f && v[2] < g.box);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const unsigned int k = fkey(v[d]);
+            mn[d] = min(mn[d], k), mx[d] = max(mx[d], k);
+        }
     }
-    if (out) *outside = 1;   // some coordinate is not in [0, L): the per-cell periodic image is not known
+    if (out) *outside = 1;   // some coordinate is not in [0, L)
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        unsigned int a = mn[d], b = mx[d];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a = min(a, (unsigned int)__shfl_xor((int)a, off, 64)), b = max(b, (unsigned int)__shfl_xor((int)b, off, 64));
+        if ((threadIdx.x & 63) == 0 && a <= b) atomicMin(&frame->mn[d], a), atomicMax(&frame->mx[d], b);
+    }
 }
 
 __global__ void cell_fill(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
@@ -313,34 +342,252 @@ __global__ __launch_bounds__(PB) void pair_count2(PairArgs a, const int *__restr
         if (hist[q]) atomicAdd(&a.npairs[q], (unsigned long long)hist[q]);
 }
 
+// Third-generation kernel: ONE WAVE per cell of set 1, cells of size reach / R (R = 1 or 2), and for an autocorrelation the
+// HALF stencil - every unordered pair is evaluated once and the histogram is doubled at the end (exact: dx -> -dx,
+// the minimum image and the per-cell shifts negate exactly, so r^2, |dz| and mu of (i, j) and (j, i) are bit-equal).
+// Against the workgroup-per-cell kernel with cells of the full reach: R = 2 evaluates 5^3 / 8 instead of 27 cell volumes
+// per point (x 1/1.7), the half stencil halves that again, and a wave needs no workgroup barrier - the staging buffers, the
+// segment table and the i-slice are wave-private LDS, the waves of a workgroup only share the histogram.
+//   * Neighbour cells along z are consecutive in the sorted arrays: the stencil is walked as (2R+1)^2 ROWS, each one
+//     contiguous range of points (two when the row wraps around the box in z).
+//   * Half stencil: rows (ox, oy) lexicographically after (0, 0) with all 2R+1 cells; of row (0, 0) the cells behind the
+//     own one, and the own cell with the test j > i (sorted indices).
+//   * Periodic images per segment: coordinates of both sets lie in one interval [a, a + L) (Frame), so a point's
+//     coordinate is L frac + const, raised by L when its fraction lies below frac(a); the true separation of a pair from
+//     cells (c1, c1 + o) is (xi - xj) - L (w + s(c1) - s(c2)) with w the index wrap and s(c) = [c below the cut cell] - the
+//     same single float addition of 0 or -+L the per-pair minimum image performs.  Segments touching the cut cell or its
+//     two neighbours (mixed cells, float rounding at the cut) take the per-pair minimum image instead.
+constexpr int P3_WAVES = 4, P3_JCAP = 128, P3_ICAP = 64, P3_SLOTS = 64;
+
+template <int MODE>
+__global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const Frame *__restrict__ frame, int ncell, int R,
+                                                              unsigned long long *__restrict__ evaluated) {
+    __shared__ float ix[P3_WAVES][P3_ICAP], iy[P3_WAVES][P3_ICAP], iz[P3_WAVES][P3_ICAP];
+    __shared__ float jx[P3_WAVES][P3_JCAP], jy[P3_WAVES][P3_JCAP], jz[P3_WAVES][P3_JCAP];
+    __shared__ int jg[P3_WAVES][P3_JCAP], jc[P3_WAVES][P3_JCAP];
+    __shared__ int64_t seg_j0[P3_WAVES][P3_SLOTS];
+    __shared__ int seg_len[P3_WAVES][P3_SLOTS], seg_code[P3_WAVES][P3_SLOTS];
+    __shared__ float e2[64];
+    __shared__ int s_cut[3], s_general[3], s_ok;
+    extern __shared__ unsigned int hist[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nh = a.nbins * a.nsub;
+    for (int q = tid; q < nh; q += P3_WAVES * 64) hist[q] = 0u;
+    if (tid <= a.nbins) e2[tid] = a.edges2[tid];
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    if (tid < 3) {
+        const float lo = funkey(frame->mn[tid]), hi = funkey(frame->mx[tid]);
+        const int nc = tid == 0 ? a.g.ncx : (tid == 1 ? a.g.ncy : a.g.ncz);
+        // one period holds everything?  (margin: the cut cells absorb rounding at the ends)
+        if (!((double)hi - (double)lo < (double)a.g.box)) s_ok = 0;
+        const bool std_frame = lo >= 0.f && hi < a.g.box;       // [0, L): no raised coordinates, the cut is the index wrap
+        s_general[tid] = std_frame ? 0 : 1;
+        s_cut[tid] = std_frame ? 0 : cell_coord(lo, nc, a.g.inv_box);
+    }
+    __syncthreads();
+    const float lo2 = e2[0], hi2 = e2[a.nbins];
+    const bool frame_ok = s_ok != 0;
+    const int ncx = a.g.ncx, ncy = a.g.ncy, ncz = a.g.ncz, W = 2 * R + 1;
+    const int nrow = a.autocorr ? (W * W - 1) / 2 + 1 : W * W;     // half stencil: rows after (0, 0), then row (0, 0)
+    const int nslot = 2 * nrow + (a.autocorr ? 1 : 0);
+    // s(c) - [c below the cut] - and the mixed set {cut-1, cut, cut+1} of a dimension
+    auto below = [&](int d, int c) { return s_general[d] && c < s_cut[d] ? 1 : 0; };
+    auto mixed1 = [&](int d, int c, int nc) {
+        if (!s_general[d]) return false;
+        int t = c - s_cut[d];
+        if (t < 0) t += nc;
+        return t == 0 || t == 1 || t == nc - 1;
+    };
+    unsigned long long n_eval = 0;   // candidate pairs this wave evaluated (uniform per wave; lane 0 reports)
+    for (int c1 = blockIdx.x * P3_WAVES + w; c1 < ncell; c1 += gridDim.x * P3_WAVES) {
+        const int64_t cbeg = a.start1[c1], cend = a.start1[c1 + 1];
+        if (cbeg == cend) continue;
+        const int cz = c1 % ncz, cy = (c1 / ncz) % ncy, cx = c1 / (ncz * ncy);
+        wave_sync();   // the previous cell's reads of the segment table are done
+        if (lane < nslot) {
+            int64_t j0 = 0;
+            int len = 0, code = 0;
+            int ox = 0, oy = 0, zlo = -R, zhi = R, filt = 0;
+            bool valid = true;
+            const int part = lane & 1;
+            if (a.autocorr && lane == 2 * nrow) {          // the own cell: pairs j > i
+                zlo = zhi = 0, filt = 1;
+                valid = true;
+            } else {
+                const int row = lane >> 1;
+                if (a.autocorr) {
+                    if (row == nrow - 1) zlo = 1;          // row (0, 0): the cells behind the own one
+                    else {
+                        const int t = row + (R * W + R) + 1;
+                        ox = t / W - R, oy = t % W - R;
+                    }
+                } else {
+                    ox = row / W - R, oy = row % W - R;
+                }
+            }
+            int nx = cx + ox, ny = cy + oy, wx = 0, wy = 0;
+            if (nx < 0) nx += ncx, wx = -1;
+            else if (nx >= ncx) nx -= ncx, wx = 1;
+            if (ny < 0) ny += ncy, wy = -1;
+            else if (ny >= ncy) ny -= ncy, wy = 1;
+            // z cells [cz + zlo, cz + zhi]: part 0 = the piece inside [0, ncz), part 1 = the piece that wraps
+            int za = cz + zlo, zb = cz + zhi, wz = 0;
+            if (filt) {
+                if (part) valid = false;     // (lane 2 nrow is even: never taken, kept for clarity)
+            } else if (zlo > zhi) {
+                valid = false;
+            } else if (!part) {
+                za = max(za, 0), zb = min(zb, ncz - 1);
+            } else if (za < 0) {
+                zb = min(zb, -1) + ncz, za = za + ncz, wz = -1;
+            } else if (zb >= ncz) {
+                za = max(za, ncz) - ncz, zb = zb - ncz, wz = 1;
+            } else {
+                valid = false;
+            }
+            if (valid && za <= zb) {
+                const int cA = (nx * ncy + ny) * ncz + za, cB = (nx * ncy + ny) * ncz + zb;
+                j0 = a.start2[cA];
+                len = (int)(a.start2[cB + 1] - j0);
+                const int kx = wx + below(0, cx) - below(0, nx), ky = wy + below(1, cy) - below(1, ny),
+                          kz = wz + below(2, cz) - below(2, za);
+                bool mixed = !frame_ok || mixed1(0, cx, ncx) || mixed1(0, nx, ncx) || mixed1(1, cy, ncy) || mixed1(1, ny, ncy) ||
+                             mixed1(2, cz, ncz);
+                for (int zc = za; zc <= zb; zc++) mixed = mixed || mixed1(2, zc, ncz);
+                code = (kx + 2) | ((ky + 2) << 3) | ((kz + 2) << 6) | (mixed ? 512 : 0) | (filt ? 1024 : 0);
+            }
+            seg_j0[w][lane] = j0, seg_len[w][lane] = len, seg_code[w][lane] = code;
+        }
+        wave_sync();
+        for (int64_t i0 = cbeg; i0 < cend; i0 += P3_ICAP) {
+            const int ni = (int)min((int64_t)P3_ICAP, cend - i0);
+            wave_sync();   // the previous slice's pairs are done with ix / iy / iz and the staging buffer
+            if (lane < ni) ix[w][lane] = a.x1[i0 + lane], iy[w][lane] = a.y1[i0 + lane], iz[w][lane] = a.z1[i0 + lane];
+            auto process = [&](int fill) {
+                const int total = ni * fill;
+                n_eval += (unsigned long long)total;
+                const float inv_m = 1.0f / (float)fill;
+                for (int p = lane; p < total; p += 64) {
+                    const int i = (int)(((float)p + 0.5f) * inv_m);   // exact: p < 2^13, fill <= 2^7
+                    const int j = p - i * fill;
+                    const int code = jc[w][j];
+                    if ((code & 1024) && (int64_t)jg[w][j] <= i0 + i) continue;   // own cell: every unordered pair once
+                    float dx = ix[w][i] - jx[w][j], dy = iy[w][i] - jy[w][j], dz = iz[w][i] - jz[w][j];
+                    if (code & 512) {
+                        dx = min_image(dx, a.half, a.g.box);
+                        dy = min_image(dy, a.half, a.g.box);
+                        dz = min_image(dz, a.half, a.g.box);
+                    } else {   // -k L with k in {-2 .. 2}: k = 0 adds +-0 (no change), otherwise the minimum image's own addition
+                        dx += (float)(2 - (code & 7)) * a.g.box;
+                        dy += (float)(2 - ((code >> 3) & 7)) * a.g.box;
+                        dz += (float)(2 - ((code >> 6) & 7)) * a.g.box;
+                    }
+                    float r2;
+                    int sub = 0;
+                    if (MODE == 1) {
+                        const float adz = fabsf(dz);
+                        if (adz >= a.pimax) continue;
+                        r2 = dx * dx + dy * dy;
+                        if (r2 < lo2 || r2 >= hi2) continue;
+                        sub = (int)(adz / a.dpi);
+                        if (sub >= a.nsub) continue;
+                    } else {
+                        r2 = dx * dx + dy * dy + dz * dz;
+                        if (r2 < lo2 || r2 >= hi2) continue;
+                    }
+                    int b = a.nbins - 1;
+                    while (r2 < e2[b]) b--;
+                    if (MODE == 2) {
+                        const float sr = sqrtf(r2);
+                        const float mu = sr > 0.f ? fabsf(dz) / sr : 0.f;
+                        if (mu >= a.mu_max) continue;
+                        sub = (int)(mu * a.inv_dmu);
+                        if (sub >= a.nsub) continue;
+                    }
+                    atomicAdd(&hist[b * a.nsub + sub], 1u);
+                }
+            };
+            int fill = 0;
+            for (int sl = 0; sl < nslot; sl++) {
+                const int len = seg_len[w][sl];
+                if (len == 0) continue;
+                const int64_t j0 = seg_j0[w][sl];
+                const int code = seg_code[w][sl];
+                int off = 0;
+                while (off < len) {
+                    const int take = min(len - off, P3_JCAP - fill);
+                    for (int q = lane; q < take; q += 64) {
+                        const int64_t jj = j0 + off + q;
+                        jx[w][fill + q] = a.x2[jj], jy[w][fill + q] = a.y2[jj], jz[w][fill + q] = a.z2[jj];
+                        jg[w][fill + q] = (int)jj, jc[w][fill + q] = code;
+                    }
+                    fill += take, off += take;
+                    if (fill == P3_JCAP) {
+                        wave_sync();
+                        process(fill);
+                        wave_sync();
+                        fill = 0;
+                    }
+                }
+            }
+            if (fill) {
+                wave_sync();
+                process(fill);
+            }
+        }
+    }
+    if (lane == 0 && n_eval) atomicAdd(evaluated, n_eval);
+    __syncthreads();
+    const unsigned long long mult = a.autocorr ? 2ull : 1ull;   // the half stencil evaluated every unordered pair once
+    for (int q = tid; q < nh; q += P3_WAVES * 64)
+        if (hist[q]) atomicAdd(&a.npairs[q], mult * (unsigned long long)hist[q]);
+}
+
 struct SortedSet {
     DevBuf raw, sorted, counts, cellid, start;
     float *sx, *sy, *sz;
     int64_t n;
 };
 
-int sort_into_cells(const float *hx, const float *hy, const float *hz, int64_t n, const CellGrid &g, SortedSet &s,
-                    DevBuf &scratch, int *d_outside) {
+// float64 device columns (the HOD catalogue) -> float32, as the reference casts before it calls Corrfunc
+// (analysis/tpcf_corrfunc.py:134-139: `.astype(np.float32)`, round to nearest)
+__global__ void cast_f64_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+
+// where = 0: host float32 arrays; 1: device float32; 2: device float64
+int sort_into_cells(const void *hx, const void *hy, const void *hz, int where, int64_t n, const CellGrid &g, SortedSet &s,
+                    DevBuf &scratch, int *d_outside, Frame *d_frame) {
     const int64_t ncell = (int64_t)g.ncx * g.ncy * g.ncz;
     const size_t n1 = (size_t)std::max<int64_t>(n, 1);
     s.n = n;
-    ABACUS_TRY(s.raw.reserve(3 * n1 * 4));
     ABACUS_TRY(s.sorted.reserve(3 * n1 * 4));
     ABACUS_TRY(s.counts.reserve((size_t)(ncell + 1) * 4));
     ABACUS_TRY(s.cellid.reserve(n1 * 4));
     ABACUS_TRY(s.start.reserve((size_t)(ncell + 1) * 8));
-    float *rx = s.raw.as<float>(), *ry = rx + n1, *rz = ry + n1;
+    const float *rx, *ry, *rz;
     s.sx = s.sorted.as<float>();
     s.sy = s.sx + n1;
     s.sz = s.sy + n1;
-    HIP_TRY(hipMemcpyAsync(rx, hx, n * 4, hipMemcpyHostToDevice, stream()));
-    HIP_TRY(hipMemcpyAsync(ry, hy, n * 4, hipMemcpyHostToDevice, stream()));
-    HIP_TRY(hipMemcpyAsync(rz, hz, n * 4, hipMemcpyHostToDevice, stream()));
-    HIP_TRY(hipMemsetAsync(s.counts.p, 0, (size_t)(ncell + 1) * 4, stream()));
     const int nblk = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 256), 1), 4096);
+    if (where == 1) {   // caller's device arrays, read in place
+        rx = (const float *)hx, ry = (const float *)hy, rz = (const float *)hz;
+    } else {
+        ABACUS_TRY(s.raw.reserve(3 * n1 * 4));
+        float *bx = s.raw.as<float>(), *by = bx + n1, *bz = by + n1;
+        const void *src[3] = {hx, hy, hz};
+        float *dst[3] = {bx, by, bz};
+        for (int d = 0; d < 3 && n > 0; d++) {
+            if (where == 0) HIP_TRY(hipMemcpyAsync(dst[d], src[d], n * 4, hipMemcpyHostToDevice, stream()));
+            else ABACUS_LAUNCH("pair_cast", cast_f64_f32, dim3(nblk), dim3(256), 0, (const double *)src[d], dst[d], n);
+        }
+        rx = bx, ry = by, rz = bz;
+    }
+    HIP_TRY(hipMemsetAsync(s.counts.p, 0, (size_t)(ncell + 1) * 4, stream()));
     if (n > 0)
         ABACUS_LAUNCH("pair_cell_count", cell_count, dim3(nblk), dim3(256), 0, rx, ry, rz, n, g,
-                      s.counts.as<unsigned int>(), s.cellid.as<unsigned int>(), d_outside);
+                      s.counts.as<unsigned int>(), s.cellid.as<unsigned int>(), d_outside, d_frame);
     ABACUS_TRY(exclusive_scan_u32(s.counts.as<unsigned int>(), ncell, s.start.as<int64_t>(), scratch, 1));
     if (n > 0)
         ABACUS_LAUNCH("pair_cell_fill", cell_fill, dim3(nblk), dim3(256), 0, rx, ry, rz, n,
@@ -350,10 +597,12 @@ int sort_into_cells(const float *hx, const float *hy, const float *hz, int64_t n
 
 }  // namespace
 
-extern "C" int abacus_paircount(int mode, const float *x1, const float *y1, const float *z1, int64_t n1,
-                                const float *x2, const float *y2, const float *z2, int64_t n2, float boxsize,
-                                const float *bins, int nbins, float pimax, int npibins, float mu_max, int nmubins,
-                                uint64_t *npairs) {
+static unsigned long long g_last_evaluated = 0;   // candidate pairs of the last call (wave-per-cell kernel only)
+static int g_last_cells[3] = {0, 0, 0};
+
+static int paircount_impl(int mode, const void *x1, const void *y1, const void *z1, int64_t n1, const void *x2, const void *y2,
+                          const void *z2, int64_t n2, int where, float boxsize, const float *bins, int nbins, float pimax,
+                          int npibins, float mu_max, int nmubins, uint64_t *npairs) {
     ABACUS_ENTER();
     if (mode < 0 || mode > 2) return fail("abacus_paircount: unknown mode %d", mode);
     if (!x1 || !y1 || !z1 || !bins || !npairs || nbins < 1) return fail("abacus_paircount: null/empty argument");
@@ -377,24 +626,43 @@ extern "C" int abacus_paircount(int mode, const float *x1, const float *y1, cons
     CellGrid g;
     g.box = boxsize;
     g.inv_box = 1.0f / boxsize;
-    auto ncells = [&](float reach) {
-        int nc = (int)floorf(boxsize / reach * 0.9999f);   // cell size strictly >= reach
-        nc = std::min(nc, 128);
+    // cells of size >= reach / R: R = 2 (125-cell stencil of cells an eighth the volume: 1.7x fewer candidate pairs) when
+    // the catalogue is dense enough to keep a wave busy with a small cell, else R = 1
+    static const int gen = getenv("ABACUS_PAIRS_GEN") ? atoi(getenv("ABACUS_PAIRS_GEN")) : 3;   // A/B: 1, 2: older kernels
+    auto ncells = [&](float reach, int R, int cap) {
+        int nc = (int)floorf(boxsize / reach * (float)R * 0.9999f);   // cell size strictly >= reach / R
+        nc = std::min(nc, cap);
         return nc < 3 ? 1 : nc;
     };
-    g.ncx = g.ncy = ncells(reach_xy);
-    g.ncz = ncells(reach_z);
+    int R = 1;
+    {
+        const double nmax = (double)std::max(n1, autocorr ? n1 : n2);
+        const double per_cell = nmax * ((double)reach_xy / boxsize) * ((double)reach_xy / boxsize) * ((double)reach_z / boxsize);
+        if (gen >= 3 && per_cell > 12.0 && ncells(reach_xy, 2, 192) >= 5 && ncells(reach_z, 2, 192) >= 5) R = 2;
+    }
+    g.ncx = g.ncy = ncells(reach_xy, R, R == 2 ? 192 : 128);
+    g.ncz = ncells(reach_z, R, R == 2 ? 192 : 128);
+    // the cap may leave cells larger than reach / R: still correct (a cell >= reach / R is all the stencil needs)
     const int64_t ncell = (int64_t)g.ncx * g.ncy * g.ncz;
+    const bool use3 = gen >= 3 && g.ncx >= 2 * R + 1 && g.ncy >= 2 * R + 1 && g.ncz >= 2 * R + 1;
 
     static SortedSet S1, S2;
     static DevBuf scratch, d_edges, d_npairs, d_work, d_flag;
     ABACUS_TRY(d_flag.reserve(64));
-    HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(int), stream()));
-    ABACUS_TRY(sort_into_cells(x1, y1, z1, n1, g, S1, scratch, d_flag.as<int>()));
-    if (!autocorr) ABACUS_TRY(sort_into_cells(x2, y2, z2, n2, g, S2, scratch, d_flag.as<int>()));
+    HIP_TRY(hipMemsetAsync(d_flag.p, 0, 64, stream()));
+    Frame *d_frame = reinterpret_cast<Frame *>(d_flag.as<int>() + 4);
+    unsigned long long *d_eval = reinterpret_cast<unsigned long long *>(d_flag.as<int>() + 12);   // byte 48
+    {
+        Frame f0;
+        for (int d = 0; d < 3; d++) f0.mn[d] = 0xffffffffu, f0.mx[d] = 0u;
+        HIP_TRY(hipMemcpyAsync(d_frame, &f0, sizeof f0, hipMemcpyHostToDevice, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));   // f0 is a stack object
+    }
+    ABACUS_TRY(sort_into_cells(x1, y1, z1, where, n1, g, S1, scratch, d_flag.as<int>(), d_frame));
+    if (!autocorr) ABACUS_TRY(sort_into_cells(x2, y2, z2, where, n2, g, S2, scratch, d_flag.as<int>(), d_frame));
     SortedSet &T = autocorr ? S1 : S2;
 
-    const bool v1 = getenv("ABACUS_PAIRS_V1") != nullptr;
+    const bool v1 = gen == 1 || getenv("ABACUS_PAIRS_V1") != nullptr;
     int nwork = 0, *d_wc = nullptr, *d_wo = nullptr;
     int h_outside = 0;
     if (v1) {   // first-generation kernel: host-built work list, one workgroup per 256 points of a non-empty cell
@@ -439,6 +707,15 @@ extern "C" int abacus_paircount(int mode, const float *x1, const float *y1, cons
     a.npairs = d_npairs.as<unsigned long long>();
     if (v1) {
         if (nwork > 0) ABACUS_LAUNCH("pair_count", pair_count, dim3(nwork), dim3(PB), 0, a, d_wc, d_wo);
+    } else if (use3) {
+        int dev = 0, ncu = 256;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        const dim3 grid((unsigned int)std::min<int64_t>(ceil_div(ncell, P3_WAVES), (int64_t)ncu * 8));
+        const size_t hist_bytes = ntot * sizeof(unsigned int);
+        if (mode == 0) ABACUS_LAUNCH("pair_count", pair_count3<0>, grid, dim3(P3_WAVES * 64), hist_bytes, a, d_frame, (int)ncell, R, d_eval);
+        else if (mode == 1) ABACUS_LAUNCH("pair_count", pair_count3<1>, grid, dim3(P3_WAVES * 64), hist_bytes, a, d_frame, (int)ncell, R, d_eval);
+        else ABACUS_LAUNCH("pair_count", pair_count3<2>, grid, dim3(P3_WAVES * 64), hist_bytes, a, d_frame, (int)ncell, R, d_eval);
     } else {
         int dev = 0, ncu = 256;
         HIP_TRY(hipGetDevice(&dev));
@@ -459,6 +736,33 @@ extern "C" int abacus_paircount(int mode, const float *x1, const float *y1, cons
 #undef LAUNCH_PC
     }
     HIP_TRY(hipMemcpyAsync(npairs, d_npairs.p, ntot * 8, hipMemcpyDeviceToHost, stream()));
+    g_last_evaluated = 0;
+    HIP_TRY(hipMemcpyAsync(&g_last_evaluated, d_eval, 8, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
+    g_last_cells[0] = g.ncx, g_last_cells[1] = g.ncz, g_last_cells[2] = use3 ? R : 0;
+    return 0;
+}
+
+extern "C" int abacus_paircount(int mode, const float *x1, const float *y1, const float *z1, int64_t n1,
+                                const float *x2, const float *y2, const float *z2, int64_t n2, float boxsize,
+                                const float *bins, int nbins, float pimax, int npibins, float mu_max, int nmubins,
+                                uint64_t *npairs) {
+    return paircount_impl(mode, x1, y1, z1, n1, x2, y2, z2, n2, 0, boxsize, bins, nbins, pimax, npibins, mu_max, nmubins, npairs);
+}
+
+extern "C" int abacus_paircount_dev(int mode, const void *x1, const void *y1, const void *z1, int64_t n1, const void *x2,
+                                    const void *y2, const void *z2, int64_t n2, int pos_dtype, float boxsize, const float *bins,
+                                    int nbins, float pimax, int npibins, float mu_max, int nmubins, uint64_t *npairs) {
+    if (pos_dtype != ABACUS_F32 && pos_dtype != ABACUS_F64) return fail("abacus_paircount_dev: pos_dtype must be ABACUS_F32 or ABACUS_F64");
+    return paircount_impl(mode, x1, y1, z1, n1, x2, y2, z2, n2, pos_dtype == ABACUS_F32 ? 1 : 2, boxsize, bins, nbins, pimax,
+                          npibins, mu_max, nmubins, npairs);
+}
+
+extern "C" int abacus_paircount_stats(uint64_t *candidates, int *ncell_xy, int *ncell_z, int *stencil_R) {
+    ABACUS_ENTER();
+    if (candidates) *candidates = g_last_evaluated;
+    if (ncell_xy) *ncell_xy = g_last_cells[0];
+    if (ncell_z) *ncell_z = g_last_cells[1];
+    if (stencil_R) *stencil_R = g_last_cells[2];
     return 0;
 }

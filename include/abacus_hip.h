@@ -349,6 +349,17 @@ int abacus_expand_poles_to_3d(const double *k_ell, const double *P_ell, int nk, 
 int abacus_paircount(int mode, const float *x1, const float *y1, const float *z1, int64_t n1, const float *x2,
                      const float *y2, const float *z2, int64_t n2, float boxsize, const float *bins, int nbins,
                      float pimax, int npibins, float mu_max, int nmubins, uint64_t *npairs);
+/* the same with the coordinate columns already in HBM (pos_dtype ABACUS_F32, or ABACUS_F64: cast to float32 on the
+ * device as analysis/tpcf_corrfunc.py:134-139 casts on the host) - e.g. the catalogue columns of
+ * abacus_hod_device_columns: the HOD -> clustering step of hod/abacus_hod.py:1181-1336 without a PCIe round trip.
+ * Coordinates may lie in any interval of one box length ([0, L), [-L/2, L/2), ...), as Corrfunc accepts them. */
+int abacus_paircount_dev(int mode, const void *x1, const void *y1, const void *z1, int64_t n1, const void *x2,
+                         const void *y2, const void *z2, int64_t n2, int pos_dtype, float boxsize, const float *bins,
+                         int nbins, float pimax, int npibins, float mu_max, int nmubins, uint64_t *npairs);
+
+/* bookkeeping of the last pair-count call (bench.py's roofline): candidate pair separations the kernel evaluated (0 when an
+ * older-generation kernel ran), cells per dimension in xy / z, stencil half-width in cells (1 or 2; 0: older kernel) */
+int abacus_paircount_stats(uint64_t *candidates, int *ncell_xy, int *ncell_z, int *stencil_R);
 
 /* ---------------------------------------------------------------- catalogue side (upstream of the HOD) ---- */
 /*

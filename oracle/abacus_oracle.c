@@ -871,6 +871,133 @@ int oracle_paircount_brute(int mode, int autocorr, const float *x1, const float 
     return 0;
 }
 
+/*
+ * The same counts from a CELL LIST (cells >= the reach, 27-cell stencil, OpenMP over the cells of set 1, per-thread
+ * histograms): the algorithm class of Corrfunc's kernels (without their AVX inner loops), used as the CPU baseline beside
+ * the HIP pair counter in bench.py and held to the brute-force counter above by tests/test_oracle_pinned.py.  The per-pair
+ * expressions are those of the brute-force loop, so the integers are identical.
+ */
+static inline int oracle_cell_of(float v, int nc, float inv_box) {
+    float f = v * inv_box;
+    f -= floorf(f);
+    int c = (int)(f * (float)nc);
+    return c >= nc ? nc - 1 : c;
+}
+
+int oracle_paircount_cells(int mode, int autocorr, const float *x1, const float *y1, const float *z1, int64_t n1,
+                           const float *x2, const float *y2, const float *z2, int64_t n2, float boxsize,
+                           const float *bins, int nbins, float pimax, int npibins, float mu_max, int nmubins,
+                           int nthread, uint64_t *npairs) {
+    if (autocorr) x2 = x1, y2 = y1, z2 = z1, n2 = n1;
+    const int nsub = mode == 0 ? 1 : (mode == 1 ? npibins : nmubins);
+    const size_t ntot = (size_t)nbins * nsub;
+    if (nthread < 1) nthread = 1;
+    const float rmax = bins[nbins], reach_z = mode == 1 ? pimax : rmax;
+    const float inv_box = 1.0f / boxsize;
+    int ncxy = (int)floorf(boxsize / rmax * 0.9999f), ncz = (int)floorf(boxsize / reach_z * 0.9999f);
+    if (ncxy > 256) ncxy = 256;
+    if (ncz > 256) ncz = 256;
+    if (ncxy < 3) ncxy = 1;
+    if (ncz < 3) ncz = 1;
+    const int64_t ncell = (int64_t)ncxy * ncxy * ncz;
+    /* counting sort of both sets into the cells */
+    int64_t *start[2];
+    float *sx[2], *sy[2], *sz[2];
+    const float *px[2] = {x1, x2}, *py[2] = {y1, y2}, *pz[2] = {z1, z2};
+    const int64_t pn[2] = {n1, n2};
+    const int nset = autocorr ? 1 : 2;
+    for (int s = 0; s < nset; s++) {
+        const int64_t n = pn[s];
+        start[s] = calloc((size_t)ncell + 1, sizeof(int64_t));
+        int *cid = malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+        sx[s] = malloc((size_t)(n > 0 ? n : 1) * 4), sy[s] = malloc((size_t)(n > 0 ? n : 1) * 4), sz[s] = malloc((size_t)(n > 0 ? n : 1) * 4);
+        for (int64_t i = 0; i < n; i++) {
+            cid[i] = (oracle_cell_of(px[s][i], ncxy, inv_box) * ncxy + oracle_cell_of(py[s][i], ncxy, inv_box)) * ncz +
+                     oracle_cell_of(pz[s][i], ncz, inv_box);
+            start[s][cid[i] + 1]++;
+        }
+        for (int64_t c = 0; c < ncell; c++) start[s][c + 1] += start[s][c];
+        int64_t *cur = malloc((size_t)ncell * sizeof(int64_t));
+        memcpy(cur, start[s], (size_t)ncell * sizeof(int64_t));
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t d = cur[cid[i]]++;
+            sx[s][d] = px[s][i], sy[s][d] = py[s][i], sz[s][d] = pz[s][i];
+        }
+        free(cur);
+        free(cid);
+    }
+    const int T = autocorr ? 0 : 1;
+    uint64_t *loc = calloc(ntot * nthread, sizeof(uint64_t));
+    float *b2 = malloc((nbins + 1) * sizeof(float));
+    for (int b = 0; b <= nbins; b++) b2[b] = bins[b] * bins[b];
+    const float half = boxsize * 0.5f;
+    const float dpi = npibins > 0 ? pimax / (float)npibins : 1.0f;
+    const float inv_dmu = nmubins > 0 ? (float)nmubins / mu_max : 1.0f;
+    const int rxy = ncxy >= 3 ? 1 : 0, rz = ncz >= 3 ? 1 : 0;
+#pragma omp parallel for num_threads(nthread) schedule(dynamic, 16)
+    for (int64_t c1 = 0; c1 < ncell; c1++) {
+#ifdef _OPENMP
+        uint64_t *h = loc + (size_t)omp_get_thread_num() * ntot;
+#else
+        uint64_t *h = loc;
+#endif
+        const int64_t i0 = start[0][c1], i1 = start[0][c1 + 1];
+        if (i0 == i1) continue;
+        const int cz = (int)(c1 % ncz), cy = (int)((c1 / ncz) % ncxy), cx = (int)(c1 / ((int64_t)ncz * ncxy));
+        for (int ox = -rxy; ox <= rxy; ox++)
+            for (int oy = -rxy; oy <= rxy; oy++)
+                for (int oz = -rz; oz <= rz; oz++) {
+                    const int nx = (cx + ox + ncxy) % ncxy, ny = (cy + oy + ncxy) % ncxy, nz = (cz + oz + ncz) % ncz;
+                    const int64_t c2 = ((int64_t)nx * ncxy + ny) * ncz + nz;
+                    const int64_t j0 = start[T][c2], j1 = start[T][c2 + 1];
+                    for (int64_t i = i0; i < i1; i++) {
+                        const float xi = sx[0][i], yi = sy[0][i], zi = sz[0][i];
+                        for (int64_t j = j0; j < j1; j++) {
+                            if (autocorr && i == j) continue;
+                            float dx = xi - sx[T][j], dy = yi - sy[T][j], dz = zi - sz[T][j];
+                            if (dx > half) dx -= boxsize;
+                            else if (dx < -half) dx += boxsize;
+                            if (dy > half) dy -= boxsize;
+                            else if (dy < -half) dy += boxsize;
+                            if (dz > half) dz -= boxsize;
+                            else if (dz < -half) dz += boxsize;
+                            float r2;
+                            int sub = 0;
+                            if (mode == 1) {
+                                float adz = fabsf(dz);
+                                if (adz >= pimax) continue;
+                                r2 = dx * dx + dy * dy;
+                                sub = (int)(adz / dpi);
+                                if (sub >= npibins) continue;
+                            } else {
+                                r2 = dx * dx + dy * dy + dz * dz;
+                            }
+                            if (r2 < b2[0] || r2 >= b2[nbins]) continue;
+                            int b = 0;
+                            while (r2 >= b2[b + 1]) b++;
+                            if (mode == 2) {
+                                float sq = sqrtf(r2);
+                                float mu = sq > 0 ? fabsf(dz) / sq : 0.0f;
+                                if (mu >= mu_max) continue;
+                                sub = (int)(mu * inv_dmu);
+                                if (sub >= nmubins) continue;
+                            }
+                            h[(size_t)b * nsub + sub]++;
+                        }
+                    }
+                }
+    }
+    for (size_t b = 0; b < ntot; b++) {
+        uint64_t s = 0;
+        for (int t = 0; t < nthread; t++) s += loc[(size_t)t * ntot + b];
+        npairs[b] = s;
+    }
+    free(loc);
+    free(b2);
+    for (int s = 0; s < nset; s++) free(start[s]), free(sx[s]), free(sy[s]), free(sz[s]);
+    return 0;
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -531,8 +531,15 @@ def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste
 # ---------------------------------------------------------------------------
 # pair counting (parity unpinned - Corrfunc is third party)
 # ---------------------------------------------------------------------------
-def paircount_brute(mode, x1, y1, z1, boxsize, bins, x2=None, y2=None, z2=None, pimax=0.0, npibins=0,
+def paircount_cells(mode, x1, y1, z1, boxsize, bins, x2=None, y2=None, z2=None, pimax=0.0, npibins=0,
                     mu_max=1.0, nmubins=0, nthread=-1):
+    """the counts of `paircount_brute` from a cell list (OpenMP over cells): the CPU baseline of bench.py's pair leg"""
+    return paircount_brute(mode, x1, y1, z1, boxsize, bins, x2, y2, z2, pimax, npibins, mu_max, nmubins, nthread,
+                           _fn='oracle_paircount_cells')
+
+
+def paircount_brute(mode, x1, y1, z1, boxsize, bins, x2=None, y2=None, z2=None, pimax=0.0, npibins=0,
+                    mu_max=1.0, nmubins=0, nthread=-1, _fn='oracle_paircount_brute'):
     """mode 'r' | 'rppi' | 'smu' ; float32 inputs as analysis/tpcf_corrfunc.py:134-139 casts them"""
     m = {'r': 0, 'rppi': 1, 'smu': 2}[mode]
     if nthread < 0:
@@ -544,7 +551,7 @@ def paircount_brute(mode, x1, y1, z1, boxsize, bins, x2=None, y2=None, z2=None, 
     nsub = 1 if m == 0 else (npibins if m == 1 else nmubins)
     out = np.zeros(nb * nsub, dtype=np.uint64)
     auto = x2 is None
-    lib().oracle_paircount_brute(m, int(auto), _ptr(x1), _ptr(y1), _ptr(z1), C.c_int64(len(x1)),
+    getattr(lib(), _fn)(m, int(auto), _ptr(x1), _ptr(y1), _ptr(z1), C.c_int64(len(x1)),
                                  _ptr(x2), _ptr(y2), _ptr(z2), C.c_int64(0 if auto else len(x2)),
                                  C.c_float(boxsize), _ptr(bins), nb, C.c_float(pimax), int(npibins),
                                  C.c_float(mu_max), int(nmubins), int(nthread), _ptr(out))

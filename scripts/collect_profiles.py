@@ -19,6 +19,10 @@ src = 'gpurun_out/round'
 dst = os.path.join('profiles', rnd)
 os.makedirs(dst, exist_ok=True)
 FETCH_FACTOR = {'fft_cols<2048, 8>': 1.0}   # 64-B row segments; every other kernel reads >= 128-B runs
+# the fused last pass at 2048^3 (fft_x_bin<1024, 8, ...>) also reads 64-B row segments (8 complex columns): factor 1 like
+# fft_cols<2048, 8>.  Its raw FETCH_SIZE is 0.78 of the known 4M-byte read (part of the 64-B segments pair up into 128-B
+# requests tallied at 64 B): the guide calls such widths uncalibrated - the entry carries `note`.
+FETCH_PREFIX = {'fft_x_bin<1024, 8': (1.0, 'uncalibrated width (64-B row segments): raw FETCH_SIZE, known read = 4 B per mesh cell')}
 
 for d in ('prof_hod', 'prof_pk1024', 'prof_pk2048'):
     # gpurun MERGES its output into gpurun_out/: summaries of earlier calls are still there - take the newest
@@ -41,11 +45,16 @@ if os.path.exists(p):
         for k, e in ks.items():
             if 'FETCH_SIZE_KiB_per_launch_raw' not in e or 'WRITE_SIZE_KiB_per_launch_raw' not in e:
                 continue
-            fac = FETCH_FACTOR.get(k, 2.0)
+            fac, note = FETCH_FACTOR.get(k, 2.0), None
+            for pre, (f, nt) in FETCH_PREFIX.items():
+                if k.startswith(pre):
+                    fac, note = f, nt
             rd = e['FETCH_SIZE_KiB_per_launch_raw'] * 1024 * fac
             wr = e['WRITE_SIZE_KiB_per_launch_raw'] * 1024
             out.setdefault(wl, {})[k] = {'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
                                          'hbm_bytes_per_launch': rd + wr, 'fetch_factor': fac,
                                          'launches': e.get('launches_FETCH_SIZE')}
+            if note:
+                out[wl][k]['note'] = note
     json.dump(out, open(os.path.join(dst, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
 print(sorted(os.listdir(dst)))

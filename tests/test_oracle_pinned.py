@@ -99,3 +99,22 @@ def test_pair_wrapper_argument_errors():
         T.calc_xirppi_fast(x, x, x, bins, 30, 7, 100.0, 1)
     with pytest.raises(ValueError, match='pimax needs to be an integer'):
         T.calc_wp_fast(x, x, x, bins, 30.0, 100.0, 1)
+
+
+def test_cell_list_counter_equals_brute_force():
+    """oracle.paircount_cells (the CPU baseline of bench.py's pair leg) against the brute-force counter, the checker of the
+    HIP kernels: identical integers in all three modes, auto and cross, coordinates in [0, L) and in [-L/2, L/2)"""
+    from oracle import oracle
+    rng = np.random.default_rng(1)
+    box = 200.0
+    bins = np.logspace(-1, np.log10(30), 14)
+    for centered in (False, True):
+        p = rng.random((4000, 3)) * box - (box / 2 if centered else 0)
+        q = rng.random((3000, 3)) * box - (box / 2 if centered else 0)
+        for mode, kw in (('r', {}), ('rppi', dict(pimax=30.0, npibins=30)), ('smu', dict(mu_max=1.0, nmubins=20))):
+            a = oracle.paircount_brute(mode, p[:, 0], p[:, 1], p[:, 2], box, bins, nthread=4, **kw)
+            b = oracle.paircount_cells(mode, p[:, 0], p[:, 1], p[:, 2], box, bins, nthread=4, **kw)
+            np.testing.assert_array_equal(a, b)
+            a = oracle.paircount_brute(mode, p[:, 0], p[:, 1], p[:, 2], box, bins, q[:, 0], q[:, 1], q[:, 2], nthread=4, **kw)
+            b = oracle.paircount_cells(mode, p[:, 0], p[:, 1], p[:, 2], box, bins, q[:, 0], q[:, 1], q[:, 2], nthread=4, **kw)
+            np.testing.assert_array_equal(a, b)

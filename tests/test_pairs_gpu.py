@@ -46,6 +46,60 @@ def test_vs_bruteforce(mode, auto, centered):
         assert np.all(got % 2 == 0)   # ordered pairs
 
 
+@pytest.mark.parametrize('mode', ['r', 'rppi', 'smu'])
+@pytest.mark.parametrize('auto', [True, False])
+@pytest.mark.parametrize('frame', [0.0, -100.0, 37.3, -1234.5, 'unwrapped'])
+def test_dense_half_stencil_any_frame(mode, auto, frame):
+    """dense catalogue (67 points per r_max-cell: the wave-per-cell kernel with cells of r_max / 2, 125-cell stencil, half
+    stencil for the autocorrelation) with the coordinates in [a, a + L) for several a - Corrfunc takes any range; the
+    periodic image per pair of cells follows from the frame - and 'unwrapped' (coordinates spilling over both box edges:
+    no single period holds them, every pair takes the per-pair minimum image) against the brute-force counter"""
+    from abacusutils_amd.analysis.tpcf_corrfunc import _paircount
+    from oracle import oracle
+    box = 200.0
+    x1, y1, z1 = _points(20000, box, 11)
+    x2, y2, z2 = (None, None, None) if auto else _points(15000, box, 12)
+    if frame == 'unwrapped':
+        sh = lambda v, s: v + np.where(np.random.default_rng(s).random(len(v)) < 0.1, box, 0.0) - 20.0   # noqa: E731
+        x1, y1, z1 = sh(x1, 1), sh(y1, 2), sh(z1, 3)
+        if not auto:
+            x2, y2, z2 = sh(x2, 4), sh(y2, 5), sh(z2, 6)
+    else:
+        x1, y1, z1 = x1 + frame, y1 + frame, z1 + frame
+        if not auto:
+            x2, y2, z2 = x2 + frame, y2 + frame, z2 + frame
+    bins = np.logspace(-1, np.log10(30.0), 14)
+    kw = dict(pimax=30.0, npibins=30) if mode == 'rppi' else (dict(mu_max=1.0, nmubins=20) if mode == 'smu' else {})
+    want = oracle.paircount_brute(mode, x1, y1, z1, box, bins, x2, y2, z2, nthread=oracle.max_threads(), **kw)
+    got = _paircount({'r': 0, 'rppi': 1, 'smu': 2}[mode], x1, y1, z1, box, bins, x2, y2, z2, **kw)
+    assert want.sum() > 0
+    np.testing.assert_array_equal(got, want.ravel())
+
+
+def test_device_resident_columns_match_host_call():
+    """abacus_paircount_dev on float64 / float32 columns already in HBM (the HOD catalogue's layout and frame) == the
+    host-array call on the same values"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.tpcf_corrfunc import _paircount
+    box = 500.0
+    rng = np.random.default_rng(3)
+    p1 = (rng.random((40000, 3)) - 0.5) * box          # float64 in [-L/2, L/2) like the galaxy columns
+    p2 = (rng.random((30000, 3)) - 0.5) * box
+    bins = np.linspace(0.5, 20.0, 11)
+    for dt in (np.float64, np.float32):
+        d1 = [_lib.DeviceArray(np.ascontiguousarray(p1[:, i], dtype=dt)) for i in range(3)]
+        d2 = [_lib.DeviceArray(np.ascontiguousarray(p2[:, i], dtype=dt)) for i in range(3)]
+        for mode, kw in ((0, {}), (1, dict(pimax=20.0, npibins=20)), (2, dict(mu_max=1.0, nmubins=10))):
+            want = _paircount(mode, p1[:, 0], p1[:, 1], p1[:, 2], box, bins, **kw)
+            got = _paircount(mode, *d1, box, bins, **kw)
+            np.testing.assert_array_equal(got, want)
+            wantx = _paircount(mode, p1[:, 0], p1[:, 1], p1[:, 2], box, bins, p2[:, 0], p2[:, 1], p2[:, 2], **kw)
+            gotx = _paircount(mode, *d1, box, bins, *d2, **kw)
+            np.testing.assert_array_equal(gotx, wantx)
+        for a in d1 + d2:
+            a.free()
+
+
 def test_large_reach_few_cells():
     """r_max close to L/2: fewer than 3 cells per dimension, every cell is its own neighbour"""
     from abacusutils_amd.analysis import tpcf_corrfunc as T
