@@ -366,7 +366,7 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
     __shared__ float jx[P3_WAVES][P3_JCAP], jy[P3_WAVES][P3_JCAP], jz[P3_WAVES][P3_JCAP];
     __shared__ int jg[P3_WAVES][P3_JCAP], jc[P3_WAVES][P3_JCAP];
     __shared__ int64_t seg_j0[P3_WAVES][P3_SLOTS];
-    __shared__ int seg_len[P3_WAVES][P3_SLOTS], seg_code[P3_WAVES][P3_SLOTS];
+    __shared__ int seg_pre[P3_WAVES][P3_SLOTS + 1], seg_code[P3_WAVES][P3_SLOTS];   // exclusive prefix of the segment lengths
     __shared__ float e2[64];
     __shared__ int s_cut[3], s_general[3], s_ok;
     extern __shared__ unsigned int hist[];
@@ -405,9 +405,9 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
         if (cbeg == cend) continue;
         const int cz = c1 % ncz, cy = (c1 / ncz) % ncy, cx = c1 / (ncz * ncy);
         wave_sync();   // the previous cell's reads of the segment table are done
+        int64_t j0 = 0;
+        int len = 0, code = 0;
         if (lane < nslot) {
-            int64_t j0 = 0;
-            int len = 0, code = 0;
             int ox = 0, oy = 0, zlo = -R, zhi = R, filt = 0;
             bool valid = true;
             const int part = lane & 1;
@@ -457,8 +457,19 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
                 for (int zc = za; zc <= zb; zc++) mixed = mixed || mixed1(2, zc, ncz);
                 code = (kx + 2) | ((ky + 2) << 3) | ((kz + 2) << 6) | (mixed ? 512 : 0) | (filt ? 1024 : 0);
             }
-            seg_j0[w][lane] = j0, seg_len[w][lane] = len, seg_code[w][lane] = code;
         }
+        // exclusive prefix of the segment lengths over the wave: the neighbour points of the cell form ONE virtual list, which
+        // is staged 128 at a time by all lanes at once (a segment at a time was one memory round trip per segment: 27 to 51
+        // dependent round trips per cell, 40 us - the kernel was latency-bound at 18 % of its instruction rate)
+        int incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        const int M = __shfl(incl, 63, 64);
+        seg_j0[w][lane] = j0, seg_pre[w][lane] = incl - len, seg_code[w][lane] = code;
+        if (lane == 63) seg_pre[w][64] = M;
         wave_sync();
         for (int64_t i0 = cbeg; i0 < cend; i0 += P3_ICAP) {
             const int ni = (int)min((int64_t)P3_ICAP, cend - i0);
@@ -508,32 +519,36 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
                     atomicAdd(&hist[b * a.nsub + sub], 1u);
                 }
             };
-            int fill = 0;
-            for (int sl = 0; sl < nslot; sl++) {
-                const int len = seg_len[w][sl];
-                if (len == 0) continue;
-                const int64_t j0 = seg_j0[w][sl];
-                const int code = seg_code[w][sl];
-                int off = 0;
-                while (off < len) {
-                    const int take = min(len - off, P3_JCAP - fill);
-                    for (int q = lane; q < take; q += 64) {
-                        const int64_t jj = j0 + off + q;
-                        jx[w][fill + q] = a.x2[jj], jy[w][fill + q] = a.y2[jj], jz[w][fill + q] = a.z2[jj];
-                        jg[w][fill + q] = (int)jj, jc[w][fill + q] = code;
-                    }
-                    fill += take, off += take;
-                    if (fill == P3_JCAP) {
-                        wave_sync();
-                        process(fill);
-                        wave_sync();
-                        fill = 0;
+            for (int base = 0; base < M; base += P3_JCAP) {
+                const int cnt = min(P3_JCAP, M - base);
+                // every lane fetches its points of this round first (all loads in flight together), then stages them
+                float tx[P3_JCAP / 64], ty[P3_JCAP / 64], tz[P3_JCAP / 64];
+                int tg[P3_JCAP / 64], tc[P3_JCAP / 64];
+#pragma unroll
+                for (int u = 0; u < P3_JCAP / 64; u++) {
+                    const int q = u * 64 + lane;
+                    tg[u] = -1;
+                    if (q < cnt) {
+                        const int v = base + q;
+                        int lo = 0, hi = 63;             // largest slot with seg_pre <= v (empty slots repeat the prefix:
+                        while (lo < hi) {                //  the LAST of equal prefixes is the non-empty one)
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (seg_pre[w][mid] <= v) lo = mid;
+                            else hi = mid - 1;
+                        }
+                        const int64_t jj = seg_j0[w][lo] + (v - seg_pre[w][lo]);
+                        tx[u] = a.x2[jj], ty[u] = a.y2[jj], tz[u] = a.z2[jj];
+                        tg[u] = (int)jj, tc[u] = seg_code[w][lo];
                     }
                 }
-            }
-            if (fill) {
+#pragma unroll
+                for (int u = 0; u < P3_JCAP / 64; u++) {
+                    const int q = u * 64 + lane;
+                    if (tg[u] >= 0) jx[w][q] = tx[u], jy[w][q] = ty[u], jz[w][q] = tz[u], jg[w][q] = tg[u], jc[w][q] = tc[u];
+                }
                 wave_sync();
-                process(fill);
+                process(cnt);
+                wave_sync();
             }
         }
     }
@@ -634,8 +649,9 @@ static int paircount_impl(int mode, const void *x1, const void *y1, const void *
         nc = std::min(nc, cap);
         return nc < 3 ? 1 : nc;
     };
+    const bool v1 = gen == 1 || getenv("ABACUS_PAIRS_V1") != nullptr;   // first-generation kernel (comparator of the tests)
     int R = 1;
-    {
+    if (!v1) {
         const double nmax = (double)std::max(n1, autocorr ? n1 : n2);
         const double per_cell = nmax * ((double)reach_xy / boxsize) * ((double)reach_xy / boxsize) * ((double)reach_z / boxsize);
         if (gen >= 3 && per_cell > 12.0 && ncells(reach_xy, 2, 192) >= 5 && ncells(reach_z, 2, 192) >= 5) R = 2;
@@ -644,7 +660,7 @@ static int paircount_impl(int mode, const void *x1, const void *y1, const void *
     g.ncz = ncells(reach_z, R, R == 2 ? 192 : 128);
     // the cap may leave cells larger than reach / R: still correct (a cell >= reach / R is all the stencil needs)
     const int64_t ncell = (int64_t)g.ncx * g.ncy * g.ncz;
-    const bool use3 = gen >= 3 && g.ncx >= 2 * R + 1 && g.ncy >= 2 * R + 1 && g.ncz >= 2 * R + 1;
+    const bool use3 = !v1 && gen >= 3 && g.ncx >= 2 * R + 1 && g.ncy >= 2 * R + 1 && g.ncz >= 2 * R + 1;
 
     static SortedSet S1, S2;
     static DevBuf scratch, d_edges, d_npairs, d_work, d_flag;
@@ -662,7 +678,6 @@ static int paircount_impl(int mode, const void *x1, const void *y1, const void *
     if (!autocorr) ABACUS_TRY(sort_into_cells(x2, y2, z2, where, n2, g, S2, scratch, d_flag.as<int>(), d_frame));
     SortedSet &T = autocorr ? S1 : S2;
 
-    const bool v1 = gen == 1 || getenv("ABACUS_PAIRS_V1") != nullptr;
     int nwork = 0, *d_wc = nullptr, *d_wo = nullptr;
     int h_outside = 0;
     if (v1) {   // first-generation kernel: host-built work list, one workgroup per 256 points of a non-empty cell
@@ -711,8 +726,11 @@ static int paircount_impl(int mode, const void *x1, const void *y1, const void *
         int dev = 0, ncu = 256;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        const dim3 grid((unsigned int)std::min<int64_t>(ceil_div(ncell, P3_WAVES), (int64_t)ncu * 8));
         const size_t hist_bytes = ntot * sizeof(unsigned int);
+        int per_cu = 4;   // persistent waves: as many workgroups as are resident at once
+        const void *fn = mode == 0 ? (const void *)pair_count3<0> : (mode == 1 ? (const void *)pair_count3<1> : (const void *)pair_count3<2>);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P3_WAVES * 64, hist_bytes));
+        const dim3 grid((unsigned int)std::min<int64_t>(ceil_div(ncell, P3_WAVES), (int64_t)ncu * std::max(per_cu, 1)));
         if (mode == 0) ABACUS_LAUNCH("pair_count", pair_count3<0>, grid, dim3(P3_WAVES * 64), hist_bytes, a, d_frame, (int)ncell, R, d_eval);
         else if (mode == 1) ABACUS_LAUNCH("pair_count", pair_count3<1>, grid, dim3(P3_WAVES * 64), hist_bytes, a, d_frame, (int)ncell, R, d_eval);
         else ABACUS_LAUNCH("pair_count", pair_count3<2>, grid, dim3(P3_WAVES * 64), hist_bytes, a, d_frame, (int)ncell, R, d_eval);
