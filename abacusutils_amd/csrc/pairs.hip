@@ -357,13 +357,14 @@ __global__ __launch_bounds__(PB) void pair_count2(PairArgs a, const int *__restr
 //     cells (c1, c1 + o) is (xi - xj) - L (w + s(c1) - s(c2)) with w the index wrap and s(c) = [c below the cut cell] - the
 //     same single float addition of 0 or -+L the per-pair minimum image performs.  Segments touching the cut cell or its
 //     two neighbours (mixed cells, float rounding at the cut) take the per-pair minimum image instead.
-constexpr int P3_WAVES = 4, P3_JCAP = 128, P3_ICAP = 64, P3_SLOTS = 64;
+constexpr int P3_WAVES = 4, P3_JCAP = 256, P3_ICAP = 64, P3_SLOTS = 64;
 
 template <int MODE>
 __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const Frame *__restrict__ frame, int ncell, int R,
                                                               unsigned long long *__restrict__ evaluated) {
     __shared__ float ix[P3_WAVES][P3_ICAP], iy[P3_WAVES][P3_ICAP], iz[P3_WAVES][P3_ICAP];
     __shared__ float jx[P3_WAVES][P3_JCAP], jy[P3_WAVES][P3_JCAP], jz[P3_WAVES][P3_JCAP];
+    __shared__ float jsx[P3_WAVES][P3_JCAP], jsy[P3_WAVES][P3_JCAP], jsz[P3_WAVES][P3_JCAP];   // per-point image shifts
     __shared__ int jg[P3_WAVES][P3_JCAP], jc[P3_WAVES][P3_JCAP];
     __shared__ int64_t seg_j0[P3_WAVES][P3_SLOTS];
     __shared__ int seg_pre[P3_WAVES][P3_SLOTS + 1], seg_code[P3_WAVES][P3_SLOTS];   // exclusive prefix of the segment lengths
@@ -400,27 +401,29 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
         return t == 0 || t == 1 || t == nc - 1;
     };
     unsigned long long n_eval = 0;   // candidate pairs this wave evaluated (uniform per wave; lane 0 reports)
-    for (int c1 = blockIdx.x * P3_WAVES + w; c1 < ncell; c1 += gridDim.x * P3_WAVES) {
-        const int64_t cbeg = a.start1[c1], cend = a.start1[c1 + 1];
-        if (cbeg == cend) continue;
+    // the global loads of a cell's table (its own range, the ranges of its segments): issued ONE CELL AHEAD, so that
+    // their round trip runs under the pair loop of the cell before
+    struct Table {
+        int64_t cbeg, cend, j0;
+        int len, code;
+    };
+    auto fetch = [&](int c1) {
+        Table t;
+        t.cbeg = a.start1[c1], t.cend = a.start1[c1 + 1], t.j0 = 0, t.len = 0, t.code = 0;
         const int cz = c1 % ncz, cy = (c1 / ncz) % ncy, cx = c1 / (ncz * ncy);
-        wave_sync();   // the previous cell's reads of the segment table are done
-        int64_t j0 = 0;
-        int len = 0, code = 0;
         if (lane < nslot) {
             int ox = 0, oy = 0, zlo = -R, zhi = R, filt = 0;
             bool valid = true;
             const int part = lane & 1;
             if (a.autocorr && lane == 2 * nrow) {          // the own cell: pairs j > i
                 zlo = zhi = 0, filt = 1;
-                valid = true;
             } else {
                 const int row = lane >> 1;
                 if (a.autocorr) {
                     if (row == nrow - 1) zlo = 1;          // row (0, 0): the cells behind the own one
                     else {
-                        const int t = row + (R * W + R) + 1;
-                        ox = t / W - R, oy = t % W - R;
+                        const int t2 = row + (R * W + R) + 1;
+                        ox = t2 / W - R, oy = t2 % W - R;
                     }
                 } else {
                     ox = row / W - R, oy = row % W - R;
@@ -448,16 +451,30 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
             }
             if (valid && za <= zb) {
                 const int cA = (nx * ncy + ny) * ncz + za, cB = (nx * ncy + ny) * ncz + zb;
-                j0 = a.start2[cA];
-                len = (int)(a.start2[cB + 1] - j0);
+                t.j0 = a.start2[cA];
+                t.len = (int)(a.start2[cB + 1] - t.j0);
                 const int kx = wx + below(0, cx) - below(0, nx), ky = wy + below(1, cy) - below(1, ny),
                           kz = wz + below(2, cz) - below(2, za);
                 bool mixed = !frame_ok || mixed1(0, cx, ncx) || mixed1(0, nx, ncx) || mixed1(1, cy, ncy) || mixed1(1, ny, ncy) ||
                              mixed1(2, cz, ncz);
                 for (int zc = za; zc <= zb; zc++) mixed = mixed || mixed1(2, zc, ncz);
-                code = (kx + 2) | ((ky + 2) << 3) | ((kz + 2) << 6) | (mixed ? 512 : 0) | (filt ? 1024 : 0);
+                t.code = (kx + 2) | ((ky + 2) << 3) | ((kz + 2) << 6) | (mixed ? 512 : 0) | (filt ? 1024 : 0);
             }
         }
+        return t;
+    };
+    const int cstride = gridDim.x * P3_WAVES;
+    int c1 = blockIdx.x * P3_WAVES + w;
+    Table nxt;
+    if (c1 < ncell) nxt = fetch(c1);
+    for (; c1 < ncell; c1 += cstride) {
+        const Table cur = nxt;
+        if (c1 + cstride < ncell) nxt = fetch(c1 + cstride);
+        const int64_t cbeg = cur.cbeg, cend = cur.cend;
+        if (cbeg == cend) continue;
+        wave_sync();   // the previous cell's reads of the segment table are done
+        const int64_t j0 = cur.j0;
+        const int len = cur.len, code = cur.code;
         // exclusive prefix of the segment lengths over the wave: the neighbour points of the cell form ONE virtual list, which
         // is staged 128 at a time by all lanes at once (a segment at a time was one memory round trip per segment: 27 to 51
         // dependent round trips per cell, 40 us - the kernel was latency-bound at 18 % of its instruction rate)
@@ -475,48 +492,54 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
             const int ni = (int)min((int64_t)P3_ICAP, cend - i0);
             wave_sync();   // the previous slice's pairs are done with ix / iy / iz and the staging buffer
             if (lane < ni) ix[w][lane] = a.x1[i0 + lane], iy[w][lane] = a.y1[i0 + lane], iz[w][lane] = a.z1[i0 + lane];
+            // a lane OWNS staged neighbour points (its registers hold their coordinates, image shifts and flags) and walks
+            // the few points of the cell's slice, read from LDS at a wave-uniform address: no index arithmetic per pair,
+            // three LDS reads per pair instead of eight
+            const int i0i = (int)i0;
             auto process = [&](int fill) {
-                const int total = ni * fill;
-                n_eval += (unsigned long long)total;
-                const float inv_m = 1.0f / (float)fill;
-                for (int p = lane; p < total; p += 64) {
-                    const int i = (int)(((float)p + 0.5f) * inv_m);   // exact: p < 2^13, fill <= 2^7
-                    const int j = p - i * fill;
-                    const int code = jc[w][j];
-                    if ((code & 1024) && (int64_t)jg[w][j] <= i0 + i) continue;   // own cell: every unordered pair once
-                    float dx = ix[w][i] - jx[w][j], dy = iy[w][i] - jy[w][j], dz = iz[w][i] - jz[w][j];
-                    if (code & 512) {
-                        dx = min_image(dx, a.half, a.g.box);
-                        dy = min_image(dy, a.half, a.g.box);
-                        dz = min_image(dz, a.half, a.g.box);
-                    } else {   // -k L with k in {-2 .. 2}: k = 0 adds +-0 (no change), otherwise the minimum image's own addition
-                        dx += (float)(2 - (code & 7)) * a.g.box;
-                        dy += (float)(2 - ((code >> 3) & 7)) * a.g.box;
-                        dz += (float)(2 - ((code >> 6) & 7)) * a.g.box;
+                n_eval += (unsigned long long)ni * (unsigned long long)fill;
+                for (int jb = 0; jb < fill; jb += 64) {
+                    const int j = jb + lane;
+                    if (j >= fill) continue;
+                    const float xj = jx[w][j], yj = jy[w][j], zj = jz[w][j];
+                    const float sx = jsx[w][j], sy = jsy[w][j], sz = jsz[w][j];
+                    const int flags = jc[w][j];
+                    const int jself = (flags & 1024) ? jg[w][j] - i0i : 0x7fffffff;   // own cell: pairs with i < j - i0 only
+                    const bool mixed = (flags & 512) != 0;
+                    for (int i = 0; i < ni; i++) {
+                        if (i >= jself) break;    // every unordered pair of the own cell once (i ascending)
+                        float dx = ix[w][i] - xj, dy = iy[w][i] - yj, dz = iz[w][i] - zj;
+                        if (mixed) {
+                            dx = min_image(dx, a.half, a.g.box);
+                            dy = min_image(dy, a.half, a.g.box);
+                            dz = min_image(dz, a.half, a.g.box);
+                        } else {   // 0 or -+L (or -+2L): the minimum image's own single addition
+                            dx += sx, dy += sy, dz += sz;
+                        }
+                        float r2;
+                        int sub = 0;
+                        if (MODE == 1) {
+                            const float adz = fabsf(dz);
+                            if (adz >= a.pimax) continue;
+                            r2 = dx * dx + dy * dy;
+                            if (r2 < lo2 || r2 >= hi2) continue;
+                            sub = (int)(adz / a.dpi);
+                            if (sub >= a.nsub) continue;
+                        } else {
+                            r2 = dx * dx + dy * dy + dz * dz;
+                            if (r2 < lo2 || r2 >= hi2) continue;
+                        }
+                        int b = a.nbins - 1;
+                        while (r2 < e2[b]) b--;
+                        if (MODE == 2) {
+                            const float sr = sqrtf(r2);
+                            const float mu = sr > 0.f ? fabsf(dz) / sr : 0.f;
+                            if (mu >= a.mu_max) continue;
+                            sub = (int)(mu * a.inv_dmu);
+                            if (sub >= a.nsub) continue;
+                        }
+                        atomicAdd(&hist[b * a.nsub + sub], 1u);
                     }
-                    float r2;
-                    int sub = 0;
-                    if (MODE == 1) {
-                        const float adz = fabsf(dz);
-                        if (adz >= a.pimax) continue;
-                        r2 = dx * dx + dy * dy;
-                        if (r2 < lo2 || r2 >= hi2) continue;
-                        sub = (int)(adz / a.dpi);
-                        if (sub >= a.nsub) continue;
-                    } else {
-                        r2 = dx * dx + dy * dy + dz * dz;
-                        if (r2 < lo2 || r2 >= hi2) continue;
-                    }
-                    int b = a.nbins - 1;
-                    while (r2 < e2[b]) b--;
-                    if (MODE == 2) {
-                        const float sr = sqrtf(r2);
-                        const float mu = sr > 0.f ? fabsf(dz) / sr : 0.f;
-                        if (mu >= a.mu_max) continue;
-                        sub = (int)(mu * a.inv_dmu);
-                        if (sub >= a.nsub) continue;
-                    }
-                    atomicAdd(&hist[b * a.nsub + sub], 1u);
                 }
             };
             for (int base = 0; base < M; base += P3_JCAP) {
@@ -544,7 +567,12 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
 #pragma unroll
                 for (int u = 0; u < P3_JCAP / 64; u++) {
                     const int q = u * 64 + lane;
-                    if (tg[u] >= 0) jx[w][q] = tx[u], jy[w][q] = ty[u], jz[w][q] = tz[u], jg[w][q] = tg[u], jc[w][q] = tc[u];
+                    if (tg[u] >= 0) {
+                        jx[w][q] = tx[u], jy[w][q] = ty[u], jz[w][q] = tz[u], jg[w][q] = tg[u], jc[w][q] = tc[u];
+                        jsx[w][q] = (float)(2 - (tc[u] & 7)) * a.g.box;          // -k L, k in {-2 .. 2}
+                        jsy[w][q] = (float)(2 - ((tc[u] >> 3) & 7)) * a.g.box;
+                        jsz[w][q] = (float)(2 - ((tc[u] >> 6) & 7)) * a.g.box;
+                    }
                 }
                 wave_sync();
                 process(cnt);
