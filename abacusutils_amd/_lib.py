@@ -131,6 +131,20 @@ class DeviceArray:
         if host is not None and self.nbytes:
             check(lib().abacus_memcpy_h2d(self.ptr, ptr(host), C.c_uint64(self.nbytes)))
 
+    @classmethod
+    def view(cls, ptr_, dtype, shape):
+        """a NON-OWNING view of device memory the library manages (e.g. a column of a staged catalogue): free() is a
+        no-op, the caller must not use it after the owner rewrote or released the memory"""
+        self = cls.__new__(cls)
+        self.ptr = C.c_void_p(ptr_ if isinstance(ptr_, int) else ptr_.value)
+        self.dtype, self.shape = np.dtype(dtype), tuple(shape)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._view = True
+        return self
+
+    def __len__(self):
+        return self.shape[0]
+
     def get(self):
         out = np.empty(self.shape, dtype=self.dtype)
         if self.nbytes:
@@ -143,6 +157,9 @@ class DeviceArray:
         check(lib().abacus_memcpy_h2d(self.ptr, ptr(host), C.c_uint64(self.nbytes)))
 
     def free(self):
+        if getattr(self, '_view', False):
+            self.ptr = C.c_void_p()
+            return
         if self.ptr:
             lib().abacus_free(self.ptr)
             self.ptr = C.c_void_p()

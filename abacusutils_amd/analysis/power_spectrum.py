@@ -203,11 +203,7 @@ def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste
         meta['is_weighted2'] = w2 is not None
 
     code = _paste_code(paste, '')
-    W = get_W_compensated(Lbox, nmesh, paste, interlaced) if compensated else None
-    poles_arr = np.asarray(poles or [], dtype=np.int64)
-    kbins, mubins = get_k_mu_edges(Lbox, k_max, kbins, mubins, logk)
-    ke = np.ascontiguousarray(kbins, dtype=np.float64)
-    me = np.ascontiguousarray(mubins, dtype=np.float64)
+    W, poles_arr, kbins, mubins, ke, me = _power_setup(Lbox, nmesh, paste, compensated, interlaced, poles, k_max, kbins, mubins, logk)
 
     p1 = _pos_f4(pos)
     p2 = None if pos2 is None else _pos_f4(pos2)
@@ -216,8 +212,20 @@ def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste
         ptr(p1), C.c_int64(len(p1)), ptr(_f4(w)), ptr(p2), C.c_int64(0 if p2 is None else len(p2)), ptr(_f4(w2)),
         C.c_double(Lbox), int(nmesh), code, ptr(_f4(W)), int(bool(interlaced)), ptr(ke), len(ke) - 1, ptr(me),
         len(me) - 1, ptr(poles_arr), len(poles_arr), *[ptr(o) for o in outs]))
-    P = _pack(*outs, me, squeeze_mu_axis)
+    return _power_table(outs, me, kbins, mubins, poles_arr, squeeze_mu_axis, return_mubins, meta)
 
+
+def _power_setup(Lbox, nmesh, paste, compensated, interlaced, poles, k_max, kbins, mubins, logk):
+    W = get_W_compensated(Lbox, nmesh, paste, interlaced) if compensated else None
+    poles_arr = np.asarray(poles or [], dtype=np.int64)
+    kbins, mubins = get_k_mu_edges(Lbox, k_max, kbins, mubins, logk)
+    ke = np.ascontiguousarray(kbins, dtype=np.float64)
+    me = np.ascontiguousarray(mubins, dtype=np.float64)
+    return W, poles_arr, kbins, mubins, ke, me
+
+
+def _power_table(outs, me, kbins, mubins, poles_arr, squeeze_mu_axis, return_mubins, meta):
+    P = _pack(*outs, me, squeeze_mu_axis)
     k_binc = (kbins[1:] + kbins[:-1]) * 0.5
     mu_binc = (mubins[1:] + mubins[:-1]) * 0.5
     res = dict(k_min=kbins[:-1], k_max=kbins[1:], k_mid=k_binc, k_avg=P['k_avg'], power=P['power'],
@@ -229,6 +237,48 @@ def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste
                    mu_max=np.broadcast_to(mubins[1:], res['power'].shape),
                    mu_mid=np.broadcast_to(mu_binc, res['power'].shape))
     return Table(res, meta=meta)
+
+
+def calc_power_multi(columns, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste='TSC', nmesh=128,
+                     compensated=True, interlaced=True, poles=None, squeeze_mu_axis=True):
+    """Every auto and cross spectrum of several tracers whose galaxy columns are already in HBM - the loop of
+    `AbacusHOD.compute_power` (abacusnbody/hod/abacus_hod.py:1400-1470) without its repeated work: each tracer's field is
+    deposited and transformed ONCE (LRG x ELG: 2 deposits + FFTs instead of 4) and nothing crosses PCIe but the binned
+    spectra.  `columns`: {tracer: (x, y, z)} of float64 `_lib.DeviceArray`s (`MockDict.device_xyz`); unweighted.
+    Returns {(tracer_a, tracer_b): Table} for a <= b in dict order, each Table what
+    `calc_power(pos_a, ..., pos2=pos_b)` returns."""
+    if kbins is None:
+        kbins = nmesh
+    if k_max is None:
+        k_max = np.pi * nmesh / Lbox
+    return_mubins = mubins is not None
+    if mubins is None:
+        mubins = 1
+    names = list(columns)
+    if len(names) > 8:
+        raise ValueError('calc_power_multi: at most 8 tracers')
+    code = _paste_code(paste, '')
+    W, poles_arr, kbins, mubins, ke, me = _power_setup(Lbox, nmesh, paste, compensated, interlaced, poles, k_max, kbins, mubins, logk)
+    L = _lib.lib()
+    for slot, tr in enumerate(names):
+        x, y, z = columns[tr]
+        check(L.abacus_power_field_soa64(slot, x.ptr, y.ptr, z.ptr, C.c_int64(len(x)), C.c_double(Lbox), int(nmesh), code,
+                                         int(bool(interlaced))))
+    out = {}
+    for ia, ta in enumerate(names):
+        for ib in range(ia, len(names)):
+            tb = names[ib]
+            outs = _alloc_outputs(len(ke) - 1, len(me) - 1, len(poles_arr))
+            check(L.abacus_power_from_fields(ia, ib, ptr(_f4(W)), ptr(ke), len(ke) - 1, ptr(me), len(me) - 1, ptr(poles_arr),
+                                             len(poles_arr), *[ptr(o) for o in outs]))
+            meta = dict(Lbox=Lbox, logk=logk, paste=paste, nmesh=nmesh, compensated=compensated, interlaced=interlaced,
+                        poles=poles, N_pos=len(columns[ta][0]), is_weighted=False, field_dtype=np.float32,
+                        squeeze_mu_axis=squeeze_mu_axis)
+            if ib != ia:
+                meta.update(N_pos2=len(columns[tb][0]), is_weighted2=False)
+            out[(ta, tb)] = _power_table(outs, me, kbins, mubins, poles_arr, squeeze_mu_axis, return_mubins, meta)
+    check(L.abacus_power_fields_release())
+    return out
 
 
 # ---- ZCV-facing helpers (analysis/power_spectrum.py:303-660 of the reference) ------------------------------------

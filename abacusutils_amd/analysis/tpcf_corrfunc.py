@@ -115,7 +115,8 @@ def _natural_estimator(counter, sample1, sample2, edges, lbox, shell_measure, ns
                     (nbins, 1) or (nbins, nsub); RR is formed as measure / L^3 * N1 * N2 * 2 in that order and in the
                     dtype NumPy gives the reference's expression (float32 bins and box -> float32 RR)
     """
-    cast = lambda cols: [np.asarray(c).astype(np.float32) for c in cols]  # noqa: E731
+    # device-resident columns (the HOD catalogue in HBM) are cast to float32 on the device by abacus_paircount_dev
+    cast = lambda cols: [c if isinstance(c, _lib.DeviceArray) else np.asarray(c).astype(np.float32) for c in cols]  # noqa: E731
     first = cast(sample1)
     n1 = float(len(first[0]))
     if sample2 is None or sample2[0] is None:

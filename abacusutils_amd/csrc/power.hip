@@ -612,6 +612,14 @@ struct PowerCtx {
     DevBuf helper_in, helper_tab;          // staging of caller-supplied real grids / small tables (ZCV helpers)
     std::map<int, hipfftHandle> c2r_plans;  // contiguous 3-D C2R (pk_to_xi)
     int phase_n = 0;
+    // multi-tracer spectra: delta_k of every tracer kept in HBM (abacus_power_field_* / abacus_power_from_fields)
+    static constexpr int NFIELD = 8;
+    DevBuf field[NFIELD][2];                // [slot][unshifted, half-cell shifted]
+    struct FieldInfo {
+        int nmesh = 0, paste = 0, interlaced = 0, fused = 0;
+        double Lbox = 0;
+        int64_t n = 0;
+    } finfo[NFIELD];
 };
 PowerCtx g_ctx;
 
@@ -662,7 +670,8 @@ bool use_fused_fft(int nmesh) {
 }
 
 int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, int paste, int interlaced, int slot,
-                  bool fused = false, bool skip_x = false) {
+                  bool fused = false, bool skip_x = false, DevBuf *dest = nullptr) {
+    if (!dest) dest = &g_ctx.mesh[slot];
     if (n <= 0) return fail("power: empty particle set");
     const bool native = fft_native_supported(nmesh) && !getenv("ABACUS_FFT_HIPFFT");
     hipfftHandle plan = 0;
@@ -676,8 +685,8 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
     const double norm = (double)(float)(M / (double)n);   // dtype(field.size / tot_weight), tot_weight = len(pos) (:856,894)
     const double d = L / nmesh;
     for (int s = 0; s < (interlaced ? 2 : 1); s++) {
-        ABACUS_TRY(g_ctx.mesh[slot + s].reserve(mesh_bytes(nmesh)));
-        float *mesh = g_ctx.mesh[slot + s].as<float>();
+        ABACUS_TRY(dest[s].reserve(mesh_bytes(nmesh)));
+        float *mesh = dest[s].as<float>();
         // tsc_parallel wraps pos in place on the first call (tsc.py:171-173); the shifted deposit sees wrapped pos
         // interlaced: the lists of the first deposit are built to cover the half-cell-shifted one as well
         ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste,
@@ -925,6 +934,17 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
     return run_bin(s, Lbox, kedges, Nk, muedges, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
 }
 
+// the galaxy columns of the HOD (float64 x | y | z in HBM) as the (n, 3) float32 array calc_power works on: the cast
+// `np.stack((x, y, z), axis=1)` + float32 conversion of hod/abacus_hod.py:1405-1409 / analysis/power_spectrum.py
+__global__ void pack_pos_soa64(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                               int64_t n, float *__restrict__ pos) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        pos[3 * i] = (float)x[i];
+        pos[3 * i + 1] = (float)y[i];
+        pos[3 * i + 2] = (float)z[i];
+    }
+}
+
 // upload a host particle set into the context buffers; wrapped positions are copied back like the reference mutates them
 int stage_particles(float *pos, int64_t n, const float *w, DevBuf &dpos, DevBuf &dw, float **pd, float **wd) {
     ABACUS_TRY(dpos.reserve((size_t)std::max<int64_t>(n, 1) * 12));
@@ -951,6 +971,60 @@ int abacus_power_from_particles_dev(float *pos, int64_t n, const float *w, float
     ABACUS_ENTER();
     return power_dev(pos, n, w, pos2, n2, w2, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu, poles,
                      Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
+}
+
+int abacus_power_field_soa64(int slot, const double *x, const double *y, const double *z, int64_t n, double Lbox, int nmesh,
+                             int paste, int interlaced) {
+    ABACUS_ENTER();
+    if (slot < 0 || slot >= PowerCtx::NFIELD) return fail("abacus_power_field_soa64: slot %d out of range [0, %d)", slot, PowerCtx::NFIELD);
+    if (!x || !y || !z || n <= 0) return fail("abacus_power_field_soa64: empty catalogue");
+    ABACUS_TRY(check_common(nmesh, paste));
+    ABACUS_TRY(g_ctx.pos.reserve((size_t)n * 12));
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 256), 1), 256 * 32);
+    ABACUS_LAUNCH("pack_pos", pack_pos_soa64, dim3(grid), dim3(256), 0, x, y, z, n, g_ctx.pos.as<float>());
+    const bool fused = use_fused_fft(nmesh);
+    ABACUS_TRY(field_fft_dev(g_ctx.pos.as<float>(), n, nullptr, Lbox, nmesh, paste, interlaced, 0, fused, false, g_ctx.field[slot]));
+    PowerCtx::FieldInfo &f = g_ctx.finfo[slot];
+    f.nmesh = nmesh, f.paste = paste, f.interlaced = interlaced, f.fused = fused ? 1 : 0, f.Lbox = Lbox, f.n = n;
+    return 0;
+}
+
+int abacus_power_from_fields(int slot_a, int slot_b, const float *W_host, const double *kedges, int Nk, const double *muedges,
+                             int Nmu, const int64_t *poles, int Np, float *power, int64_t *N_mode, float *binned_poles,
+                             int64_t *N_mode_poles, float *k_avg) {
+    ABACUS_ENTER();
+    if (slot_a < 0 || slot_a >= PowerCtx::NFIELD || slot_b < 0 || slot_b >= PowerCtx::NFIELD)
+        return fail("abacus_power_from_fields: slot out of range");
+    const PowerCtx::FieldInfo &fa = g_ctx.finfo[slot_a], &fb = g_ctx.finfo[slot_b];
+    if (!fa.nmesh || !fb.nmesh) return fail("abacus_power_from_fields: a field slot is empty (abacus_power_field_soa64 first)");
+    if (fa.nmesh != fb.nmesh || fa.interlaced != fb.interlaced || fa.fused != fb.fused || fa.Lbox != fb.Lbox || fa.paste != fb.paste)
+        return fail("abacus_power_from_fields: the two fields were built with different mesh settings");
+    const int nmesh = fa.nmesh;
+    ABACUS_TRY(ensure_phase(nmesh));
+    const float *W_dev;
+    ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
+    const bool cross = slot_a != slot_b;
+    SpecArgs s;
+    fill_spec(s, nmesh, 1, fa.interlaced, W_dev, cross);
+    if (fa.fused) {
+        s.permshift = 0;
+        while ((2 << s.permshift) < nmesh) s.permshift++;   // log2(nmesh / 2)
+    }
+    s.a = g_ctx.field[slot_a][0].as<float2>();
+    s.as = fa.interlaced ? g_ctx.field[slot_a][1].as<float2>() : nullptr;
+    s.b = cross ? g_ctx.field[slot_b][0].as<float2>() : nullptr;
+    s.bs = cross && fa.interlaced ? g_ctx.field[slot_b][1].as<float2>() : nullptr;
+    return run_bin(s, fa.Lbox, kedges, Nk, muedges, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
+}
+
+int abacus_power_fields_release(void) {
+    ABACUS_ENTER();
+    for (int q = 0; q < PowerCtx::NFIELD; q++) {
+        ABACUS_TRY(g_ctx.field[q][0].release());
+        ABACUS_TRY(g_ctx.field[q][1].release());
+        g_ctx.finfo[q] = PowerCtx::FieldInfo();
+    }
+    return 0;
 }
 
 int abacus_power_from_particles(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, const float *w2,
@@ -1295,6 +1369,11 @@ int abacus_power_release(void) {
     ABACUS_TRY(g_ctx.helper_in.release());
     ABACUS_TRY(g_ctx.helper_tab.release());
     for (auto &m : g_ctx.mesh) ABACUS_TRY(m.release());
+    for (int q = 0; q < PowerCtx::NFIELD; q++) {
+        ABACUS_TRY(g_ctx.field[q][0].release());
+        ABACUS_TRY(g_ctx.field[q][1].release());
+        g_ctx.finfo[q] = PowerCtx::FieldInfo();
+    }
     for (DevBuf *b : {&g_ctx.W, &g_ctx.phase, &g_ctx.edges, &g_ctx.accum, &g_ctx.pos, &g_ctx.pos2, &g_ctx.w, &g_ctx.w2})
         ABACUS_TRY(b->release());
     g_ctx.phase_n = 0;

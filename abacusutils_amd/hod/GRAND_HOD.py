@@ -145,8 +145,11 @@ class StagedCatalog:
         check(_lib.lib().abacus_hod_fetch_field(self._h, field.encode(), ptr(out)))
         return out.reshape(-1, 3) if field == 'hveldev' else out
 
+    generation = 0    # bumped by every populate: the catalogue columns in HBM belong to the latest one only
+
     def populate(self, p):
         """decide + emit on the device; returns (Ncent[3], Nsat[3])"""
+        self.generation += 1
         counts = (C.c_int64 * 6)()
         check(_lib.lib().abacus_hod_populate(self._h, C.byref(p), counts))
         self.counts = np.array(counts[:], dtype=np.int64)
@@ -161,6 +164,7 @@ class StagedCatalog:
             check(_lib.lib().abacus_hod_set_profile(self._h, ptr(_as(halo_data['hc'], np.float64)),
                                                     ptr(_as(halo_data['hrvir'], np.float64))))
             self._profile_set = True
+        self.generation += 1
         nf = _lib.NfwParams()
         nf.seed = int(seed) & (2**64 - 1)
         for t, tr in enumerate(TRACERS):   # f_sigv defaults to 0 (hod/GRAND_HOD.py:1376,1418,1457)
@@ -177,6 +181,7 @@ class StagedCatalog:
 
     def populate_async(self, p):
         """enqueue only (bench): no host synchronisation, no result copy"""
+        self.generation += 1
         check(_lib.lib().abacus_hod_populate_async(self._h, C.byref(p)))
 
     def wait_counts(self):
@@ -222,6 +227,48 @@ class StagedCatalog:
             pass
 
 
+class MockDict(dict):
+    """The `mock_dict` of run_hod / gen_gal_cat - a plain dict of NumPy columns, exactly the reference's - that also
+    remembers where the same columns still sit in HBM, so that the clustering step (compute_power, compute_xirppi, ...)
+    can start from there instead of uploading them again.  `device_xyz(tracer)` returns None as soon as that is no
+    longer safe: a later populate rewrote the device catalogue, the staged catalogue was freed, or the host columns were
+    replaced / modified (a strided sample of x, y, z is compared with the values at creation)."""
+    _SAMPLE = 16
+
+    def _bind(self, staged):
+        import weakref
+        self._staged = weakref.ref(staged)
+        self._generation = staged.generation
+        self._fingerprint = {tr: self._sample(tr) for tr in self}
+        return self
+
+    def _sample(self, tr):
+        d = self[tr]
+        out = []
+        for c in ('x', 'y', 'z'):
+            a = d[c]
+            step = max(1, len(a) // self._SAMPLE)
+            out.append((id(a), len(a), np.array(a[::step][: self._SAMPLE], copy=True)))
+        return out
+
+    def device_xyz(self, tracer):
+        st = getattr(self, '_staged', lambda: None)()
+        if st is None or not st._h or st.generation != self._generation or tracer not in self._fingerprint or tracer not in self:
+            return None
+        try:
+            now = self._sample(tracer)
+        except (KeyError, TypeError):
+            return None
+        for (i0, n0, s0), (i1, n1, s1) in zip(self._fingerprint[tracer], now):
+            if i0 != i1 or n0 != n1 or not np.array_equal(s0, s1):
+                return None
+        n = len(self[tracer]['x'])
+        if n == 0:
+            return None
+        cols = st.device_columns(tracer)
+        return [_lib.DeviceArray.view(cols[q], np.float64, (n,)) for q in range(3)]
+
+
 def gen_gals(halos_array, subsample, tracers, params, Nthread, enable_ranks, rsd, verbose, nfw, NFW_draw=None,
              staged=None):
     """hod/GRAND_HOD.py:1302-1592.  `staged`: a StagedCatalog to reuse (extension); otherwise the arrays are
@@ -257,6 +304,8 @@ def gen_gals(halos_array, subsample, tracers, params, Nthread, enable_ranks, rsd
                 n = len(HOD_dict[tracer]['x'])
                 print(tracer, 'number of galaxies ', n)
                 print('satellite fraction ', (n - HOD_dict[tracer]['Ncent']) / n if n else 0.0)
+        if not own:   # the catalogue stays in HBM behind a resident StagedCatalog: let the clustering step find it there
+            HOD_dict = MockDict(HOD_dict)._bind(staged)
     finally:
         if own:
             staged.free()

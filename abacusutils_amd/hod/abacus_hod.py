@@ -442,17 +442,29 @@ class AbacusHOD:
             return self.compute_multipole(mock_dict, *args, **kwargs)
         raise ValueError('clustering_type not implemented or not specified, use xirppi, wp, multipole')
 
+    @staticmethod
+    def _xyz(mock_dict, tracer):
+        """the tracer's coordinate columns: still in HBM behind this object's staged catalogue when `mock_dict` is the
+        untouched result of the latest run_hod (GRAND_HOD.MockDict.device_xyz), else the host arrays"""
+        dev = mock_dict.device_xyz(tracer) if hasattr(mock_dict, 'device_xyz') else None
+        if dev is not None:
+            return dev
+        return mock_dict[tracer]['x'], mock_dict[tracer]['y'], mock_dict[tracer]['z']
+
     def _pairs(self, mock_dict, fn):
         clustering = {}
         for i1, tr1 in enumerate(mock_dict.keys()):
-            x1, y1, z1 = mock_dict[tr1]['x'], mock_dict[tr1]['y'], mock_dict[tr1]['z']
+            x1, y1, z1 = self._xyz(mock_dict, tr1)
             for i2, tr2 in enumerate(mock_dict.keys()):
                 if i1 > i2:
                     continue  # cross-correlations are symmetric
                 if i1 == i2:
                     clustering[tr1 + '_' + tr2] = fn(x1, y1, z1, None, None, None)
                 else:
-                    x2, y2, z2 = mock_dict[tr2]['x'], mock_dict[tr2]['y'], mock_dict[tr2]['z']
+                    x2, y2, z2 = self._xyz(mock_dict, tr2)
+                    if isinstance(x1, np.ndarray) != isinstance(x2, np.ndarray):   # one side only in HBM: both from the host
+                        x1, y1, z1 = (mock_dict[tr1][c] for c in 'xyz')
+                        x2, y2, z2 = (mock_dict[tr2][c] for c in 'xyz')
                     clustering[tr1 + '_' + tr2] = fn(x1, y1, z1, x2, y2, z2)
                     clustering[tr2 + '_' + tr1] = clustering[tr1 + '_' + tr2]
         return clustering
@@ -483,6 +495,26 @@ class AbacusHOD:
         '..._ell', '..._ell_modes', 'k_binc', 'mu_binc'."""
         Lbox = self.lbox
         clustering = {}
+        # the untouched result of the latest run_hod, unweighted: every tracer's field from its columns in HBM, deposited
+        # and transformed once, all pairs binned on the device (analysis.power_spectrum.calc_power_multi)
+        dev = {tr: (mock_dict.device_xyz(tr) if hasattr(mock_dict, 'device_xyz') and 'w' not in mock_dict[tr] else None)
+               for tr in mock_dict.keys()}
+        if dev and all(v is not None for v in dev.values()) and len(dev) <= 8:
+            from ..analysis.power_spectrum import calc_power_multi
+            tabs = calc_power_multi(dev, Lbox, nbins_k, nbins_mu, k_hMpc_max, logk, paste, num_cells, compensated,
+                                    interlaced, poles=poles)
+            for (tr1, tr2), power in tabs.items():
+                key = tr1 + '_' + tr2
+                clustering[key] = power['power']
+                clustering[key + '_modes'] = power['N_mode']
+                clustering[key + '_ell'] = power['poles']
+                clustering[key + '_ell_modes'] = power['N_mode_poles']
+                if tr1 != tr2:
+                    for suffix in ('', '_modes', '_ell', '_ell_modes'):
+                        clustering[tr2 + '_' + tr1 + suffix] = clustering[key + suffix]
+            clustering['k_binc'] = power['k_mid']
+            clustering['mu_binc'] = power['mu_mid'][0]
+            return clustering
         for i1, tr1 in enumerate(mock_dict.keys()):
             pos1 = np.stack((mock_dict[tr1]['x'], mock_dict[tr1]['y'], mock_dict[tr1]['z']), axis=1)
             w1 = mock_dict[tr1].get('w', None)

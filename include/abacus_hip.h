@@ -234,6 +234,18 @@ int abacus_power_from_particles_dev(float *pos, int64_t n, const float *w, float
                                     int interlaced, const double *kedges, int Nk, const double *muedges, int Nmu,
                                     const int64_t *poles, int Np, float *power, int64_t *N_mode,
                                     float *binned_poles, int64_t *N_mode_poles, float *k_avg);
+
+/* Multi-tracer spectra (hod/abacus_hod.py:1338-1472 `compute_power`: every auto and cross pair of the tracers) without
+ * repeated work and without leaving HBM: `abacus_power_field_soa64` deposits + transforms ONE tracer's galaxies - given as
+ * the float64 x | y | z columns of abacus_hod_device_columns, cast to float32 and wrapped like calc_power does - into field
+ * slot `slot` (< 8), which stays resident; `abacus_power_from_fields` bins the auto (slot_a == slot_b) or cross spectrum of
+ * two resident fields.  LRG x ELG: 2 deposits + FFTs instead of the 4 of three calc_power calls. */
+int abacus_power_field_soa64(int slot, const double *x, const double *y, const double *z, int64_t n, double Lbox, int nmesh,
+                             int paste, int interlaced);
+int abacus_power_from_fields(int slot_a, int slot_b, const float *W_host, const double *kedges, int Nk, const double *muedges,
+                             int Nmu, const int64_t *poles, int Np, float *power, int64_t *N_mode, float *binned_poles,
+                             int64_t *N_mode_poles, float *k_avg);
+int abacus_power_fields_release(void);
 /* releases cached FFT plans / work meshes */
 int abacus_power_release(void);
 

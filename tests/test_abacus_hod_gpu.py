@@ -100,6 +100,44 @@ def test_compute_power_and_clustering():
     assert abs(ngal['LRG'] / n_lrg - 1) < 0.15 and 0 <= fsat['LRG'] <= 1
 
 
+def test_clustering_from_the_catalogue_in_hbm_matches_the_host_path():
+    """run_hod's mock_dict remembers its columns in HBM (GRAND_HOD.MockDict): compute_power (every field deposited and
+    transformed once, all pairs binned on the device), compute_xirppi / compute_wp / compute_multipole (abacus_paircount_dev
+    on the float64 columns) give what the same calls give on plain host dicts; the device path is dropped as soon as the
+    catalogue is stale (a later run_hod) or the host columns were touched"""
+    from abacusutils_amd.hod.abacus_hod import AbacusHOD
+    hd, pd, params = synth.synth_hod_inputs(300000, 300000, seed=19, lbox=1000.0)
+    hod = dict(HOD_PARAMS, LRG_params=dict(synth.LRG_PARAMS, logM_cut=12.3, logM1=13.3), ELG_params=dict(synth.ELG_PARAMS))
+    ball = AbacusHOD.from_arrays(hd, pd, params, hod, CLUSTERING)
+    mock = ball.run_hod()
+    assert all(mock.device_xyz(tr) is not None for tr in mock)
+    plain = {tr: dict(mock[tr]) for tr in mock}                      # a plain dict: the host path
+    sbins = np.linspace(0.5, 30.0, 8)
+    got = dict(power=ball.compute_power(mock, 8, 2, 0.2, False, poles=[0, 2], num_cells=64, compensated=True, interlaced=True),
+               xirppi=ball.compute_xirppi(mock, ball.rpbins, ball.pimax, ball.pi_bin_size),
+               wp=ball.compute_wp(mock, ball.rpbins, ball.pimax, ball.pi_bin_size),
+               multi=ball.compute_multipole(mock, ball.rpbins, ball.pimax, sbins, 10))
+    want = dict(power=ball.compute_power(plain, 8, 2, 0.2, False, poles=[0, 2], num_cells=64, compensated=True, interlaced=True),
+                xirppi=ball.compute_xirppi(plain, ball.rpbins, ball.pimax, ball.pi_bin_size),
+                wp=ball.compute_wp(plain, ball.rpbins, ball.pimax, ball.pi_bin_size),
+                multi=ball.compute_multipole(plain, ball.rpbins, ball.pimax, sbins, 10))
+    for stat in ('xirppi', 'wp', 'multi'):                           # integer pair counts: identical
+        assert set(got[stat]) == set(want[stat])
+        for k in want[stat]:
+            np.testing.assert_array_equal(got[stat][k], want[stat][k], err_msg=f'{stat} {k}')
+    assert set(got['power']) == set(want['power'])
+    for k in want['power']:
+        if k.endswith('modes'):
+            np.testing.assert_array_equal(got['power'][k], want['power'][k])
+        else:
+            np.testing.assert_allclose(got['power'][k], want['power'][k], rtol=2e-6, atol=1e-6 * np.abs(want['power'][k]).max(), err_msg=k)
+    # staleness
+    mock['LRG']['x'][:] += 1.0
+    assert mock.device_xyz('LRG') is None and mock.device_xyz('ELG') is not None
+    mock2 = ball.run_hod()
+    assert mock.device_xyz('ELG') is None and mock2.device_xyz('ELG') is not None
+
+
 def test_compute_ngal_device_vs_numpy():
     """AbacusHOD.compute_ngal on the device (sum over halos) against the oracle's NumPy restatement of the reference's
     sums over the 100^3 / 100^4 histograms (hod/abacus_hod.py:861-1179)"""
