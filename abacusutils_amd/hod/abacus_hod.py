@@ -44,20 +44,43 @@ def _read_asdf_header(fn):
     return tree['header']
 
 
+def _i8(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
 def _searchsorted(a, b):
-    return np.searchsorted(a, b).astype(np.int64)
+    """`_searchsorted_parallel` (:588): np.searchsorted(a, b) on the device (abacus_searchsorted_i64)"""
+    import ctypes as C
+
+    from .. import _lib
+    a, b = _i8(a), _i8(b)
+    out = np.empty(len(b), dtype=np.int64)
+    _lib.check(_lib.lib().abacus_searchsorted_i64(_lib.ptr(a), C.c_int64(len(a)), _lib.ptr(b), C.c_int64(len(b)), _lib.ptr(out)))
+    return out
+
+
+def _argsort_ids(ids):
+    """the halo sort by id (:566-585) on the device (abacus_argsort_i64: stable radix sort)"""
+    import ctypes as C
+
+    from .. import _lib
+    ids = _i8(ids)
+    out = np.empty(len(ids), dtype=np.int64)
+    _lib.check(_lib.lib().abacus_argsort_i64(_lib.ptr(ids), C.c_int64(len(ids)), _lib.ptr(out)))
+    return out
 
 
 def calc_fenv_opt(Menv, mbins, halosM):
-    """global environment rank per mass bin (:1961-1970)"""
-    fenv_rank = np.zeros(len(Menv))
-    for ibin in range(len(mbins) - 1):
-        mmask = (halosM > mbins[ibin]) & (halosM < mbins[ibin + 1])
-        Nmask = np.sum(mmask)
-        if Nmask > 1:
-            new_fenv_rank = Menv[mmask].argsort().argsort()
-            fenv_rank[mmask] = new_fenv_rank / (Nmask - 1) - 0.5
-    return fenv_rank
+    """global environment rank per mass bin (:1961-1970) on the device (abacus_fenv_rank)"""
+    import ctypes as C
+
+    from .. import _lib
+    f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)   # noqa: E731
+    Menv, mbins, halosM = f8(Menv), f8(mbins), f8(halosM)
+    out = np.empty(len(Menv), dtype=np.float64)
+    _lib.check(_lib.lib().abacus_fenv_rank(_lib.ptr(Menv), _lib.ptr(halosM), C.c_int64(len(Menv)), _lib.ptr(mbins), len(mbins),
+                                         _lib.ptr(out)))
+    return out
 
 
 class AbacusHOD:
@@ -269,7 +292,7 @@ class AbacusHOD:
         # sort halos by id, important for conformity (:566-585)
         if not np.all(hid[:-1] <= hid[1:]):
             self.logger.info('Sorting halos for conformity calculation.')
-            s = np.argsort(hid)
+            s = _argsort_ids(hid)
             hpos, hvel, hmass, hid, hmultis, hrandoms, hveldev, hsigma3d, hc, hrvir = (
                 a[s] for a in (hpos, hvel, hmass, hid, hmultis, hrandoms, hveldev, hsigma3d, hc, hrvir))
             if self.want_AB:
@@ -297,7 +320,7 @@ class AbacusHOD:
             env_id, env_mass, env_Menv = np.concatenate(ids), np.concatenate(masses), np.concatenate(menvs)
             mbins_env = np.logspace(np.log10(mcut_env), 15.5, nbins_env + 1)
             hfenv_full = calc_fenv_opt(env_Menv, mbins_env, env_mass)
-            env_sort = np.argsort(env_id)
+            env_sort = _argsort_ids(env_id)
             env_id, hfenv_full = env_id[env_sort], hfenv_full[env_sort]
             hmatch = _searchsorted(env_id, hid)
             if not np.all(env_id[hmatch] == hid):

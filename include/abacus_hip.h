@@ -373,6 +373,18 @@ int abacus_paircount_dev(int mode, const void *x1, const void *y1, const void *z
  * older-generation kernel ran), cells per dimension in xy / z, stencil half-width in cells (1 or 2; 0: older kernel) */
 int abacus_paircount_stats(uint64_t *candidates, int *ncell_xy, int *ncell_z, int *stencil_R);
 
+/* ---------------------------------------------------------------- staging (the step in front of the HOD) ---- */
+/*
+ * Data-parallel pieces of AbacusHOD.staging() (hod/abacus_hod.py:253-704); host arrays in and out, staging runs once.
+ * abacus_argsort_i64: stable ascending argsort (replaces `np.argsort(hid)` of the halo sort, :566-585).
+ * abacus_searchsorted_i64: np.searchsorted(sorted, query, side='left') (replaces `_searchsorted_parallel`, :588).
+ * abacus_fenv_rank: `calc_fenv_opt` (:1961-1970): out[i] = rank of Menv[i] among the halos with
+ *   mbins[b] < halosM < mbins[b+1] of i's bin, / (N_bin - 1) - 0.5; 0 for halos in no bin or alone in theirs.
+ */
+int abacus_argsort_i64(const int64_t *keys, int64_t n, int64_t *order);
+int abacus_searchsorted_i64(const int64_t *sorted, int64_t n, const int64_t *query, int64_t m, int64_t *out);
+int abacus_fenv_rank(const double *Menv, const double *halosM, int64_t n, const double *mbins, int n_edges, double *out);
+
 /* ---------------------------------------------------------------- catalogue side (upstream of the HOD) ---- */
 /*
  * replaces: abacusnbody/data/bitpacked.py:32-116 `unpack_rvint` / `_unpack_rvint`.  intdata: (n,3) int32, 20-bit

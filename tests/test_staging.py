@@ -1,4 +1,4 @@
-"""`AbacusHOD.staging()` (host side, reference abacusnbody/hod/abacus_hod.py:263-702) against the staged arrays of
+"""`AbacusHOD.staging()` (file plumbing, reference abacusnbody/hod/abacus_hod.py:263-702) against the staged arrays of
 tests/golden/hod_mini.npz, which oracle/make_golden.py built from the same prepare_sim HDF5 fixtures with its own
 HDF5 reader.  Needs h5py and the reference's Mini_N64_L32 fixtures, so it only runs in the build container (an
 interpreter with h5py is looked up; the main one has none) and is skipped elsewhere."""
@@ -17,7 +17,22 @@ _SCRIPT = r'''
 import sys, yaml, numpy as np, h5py
 from pathlib import Path
 sys.path.insert(0, sys.argv[1])
+from abacusutils_amd.hod import abacus_hod
 from abacusutils_amd.hod.abacus_hod import AbacusHOD
+if sys.argv[4] == 'numpy-standins':
+    # no GPU in the build container: the three device helpers of staging() (abacus_argsort_i64, abacus_searchsorted_i64,
+    # abacus_fenv_rank) are replaced by the NumPy expressions of the reference (abacus_hod.py:566-588,1961-1970) so that the
+    # file plumbing can be held to the golden arrays here; tests/test_staging_gpu.py runs the real helpers
+    def _fenv(Menv, mbins, halosM):
+        out = np.zeros(len(Menv))
+        for ib in range(len(mbins) - 1):
+            m = (halosM > mbins[ib]) & (halosM < mbins[ib + 1])
+            if m.sum() > 1:
+                out[m] = Menv[m].argsort(kind='stable').argsort(kind='stable') / (m.sum() - 1) - 0.5
+        return out
+    abacus_hod._searchsorted = lambda a, b: np.searchsorted(a, b).astype(np.int64)
+    abacus_hod._argsort_ids = lambda a: np.argsort(a, kind='stable')
+    abacus_hod.calc_fenv_opt = _fenv
 ref, tmp = Path(sys.argv[2]), Path(sys.argv[3])
 cfg = yaml.safe_load(open(ref / 'abacus_hod.yaml'))
 cfg['sim_params'].update(sim_dir=str(ref) + '/', subsample_dir=str(ref / 'ref_hod') + '/', output_dir=str(tmp / 'out'))
@@ -103,6 +118,6 @@ def test_staging_matches_golden(tmp_path):
     exe = _python_with_h5py()
     if exe is None:
         pytest.skip('no interpreter with h5py')
-    r = subprocess.run([exe, '-c', _SCRIPT, str(ROOT), str(REF_TESTS), str(tmp_path)], capture_output=True, text=True,
+    r = subprocess.run([exe, '-c', _SCRIPT, str(ROOT), str(REF_TESTS), str(tmp_path), 'numpy-standins'], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and 'STAGING-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
