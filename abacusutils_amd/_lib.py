@@ -191,6 +191,11 @@ class Event:
             pass
 
 
+def set_option(name, value=1):
+    """diagnostic option of the library (abacus_set_option): comparator paths for tests / A-B timing"""
+    check(lib().abacus_set_option(name.encode(), int(value)))
+
+
 def profile_enable(on=True):
     check(lib().abacus_profile_enable(int(on)))
 

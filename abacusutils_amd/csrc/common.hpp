@@ -35,6 +35,10 @@ std::recursive_mutex &api_mutex();
         if (r_ != 0) return r_; \
     } while (0)
 
+// Diagnostic options (abacus_set_option, include/abacus_hip.h): comparator paths the parity tests and the A/B scripts
+// switch on explicitly - nothing in the library reads the environment.  0 when never set.
+int option(const char *name);
+
 // profiler hooks: no-ops unless abacus_profile_enable(1)
 void prof_begin(const char *name);
 void prof_end(const char *name);

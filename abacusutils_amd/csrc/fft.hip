@@ -344,7 +344,7 @@ int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_z_r2c<N, B, FUSE>, Z_THREADS, lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
     ABACUS_LAUNCH("fft_z_r2c", (fft_z_r2c<N, B, FUSE>), dim3(grid), dim3(Z_THREADS), lds, mesh, nrows,
-                  pitch_r, t->twHalf.as<float2>(), t->tw2.as<float2>(), getenv("ABACUS_DBG_FFT") ? atoi(getenv("ABACUS_DBG_FFT")) : 0);
+                  pitch_r, t->twHalf.as<float2>(), t->tw2.as<float2>(), option("dbg_fft"));
     return 0;
 }
 
@@ -359,7 +359,7 @@ int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t 
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_cols<N, C>, FFT_THREADS, lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
     ABACUS_LAUNCH(name, (fft_cols<N, C>), dim3(grid), dim3(FFT_THREADS), lds, data, S, ntile_c, ntiles,
-                  outer_stride, outer_mod, outer_stride2, tw, getenv("ABACUS_DBG_FFT") ? atoi(getenv("ABACUS_DBG_FFT")) : 0);
+                  outer_stride, outer_mod, outer_stride2, tw, option("dbg_fft"));
     return 0;
 }
 
@@ -454,7 +454,7 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x) {
 }
 
 // n = 256 only on request (tests against the CPU oracle): small meshes gain nothing from the fused form
-int fft_native_fused_supported(int n) { return n == 2048 || n == 1024 || (n == 256 && getenv("ABACUS_FFT_FUSE_SMALL")); }
+int fft_native_fused_supported(int n) { return n == 2048 || n == 1024 || (n == 256 && option("fft_fuse_small")); }
 
 static int fused_impl(float *mesh, int n, int pitch_r, bool with_x) {
     Tables *t, *th;

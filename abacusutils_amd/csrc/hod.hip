@@ -1388,7 +1388,7 @@ inline void prod_range(double c, const ColRange &r, double &lo, double &hi) {   
 Cheap make_cheap(const abacus_hod_params &p, const Filt &F, const HodRanges &R) {
     Cheap c;
     memset(&c, 0, sizeof c);
-    static const bool one_stage = getenv("ABACUS_HOD_ONE_STAGE") != nullptr;
+    const bool one_stage = option("hod_one_stage") != 0;
     c.c_ok = F.cent_ok && (p.want_LRG || p.want_ELG || p.want_QSO) && !one_stage;
     c.s_ok = F.sat_basic && (p.want_LRG || p.want_ELG || p.want_QSO) && !one_stage;
     auto up = [](double v) { return std::max((float)(v * 1.00001), 1e-30f); };
@@ -1507,7 +1507,7 @@ OutCols out_cols(abacus_hod_state *st) {
 
 // packed records of an owned catalogue (static columns only), built once
 int build_records(abacus_hod_state *st) {
-    static const bool norec = getenv("ABACUS_HOD_NOREC") != nullptr;
+    const bool norec = option("hod_norec") != 0;
     if (!st->owns || norec || st->rec_ok) return 0;
     ABACUS_TRY(st->hrec.reserve((size_t)std::max<int64_t>(st->nh, 1) * sizeof(HaloRec)));
     ABACUS_TRY(st->prec.reserve((size_t)std::max<int64_t>(st->np, 1) * sizeof(PartRec)));
@@ -1955,7 +1955,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     const int ntile = st->ntile_c + st->ntile_s, nsb = st->nsb_c + st->nsb_s;
     // owned catalogues: the filter streams the float32 shadow columns (half the bytes); caller-owned device arrays can
     // change behind the library's back, so they are streamed as they are
-    static const bool force64 = getenv("ABACUS_HOD_F64FILTER") != nullptr;
+    const bool force64 = option("hod_f64filter") != 0;
     const bool use32 = st->owns && !force64;
     if (use32 && !st->shadow_ok) ABACUS_TRY(build_shadows(st, false));
     else if (use32 && !st->shadow_rand_ok) ABACUS_TRY(build_shadows(st, true));
@@ -1993,7 +1993,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
             ABACUS_LAUNCH("hod_filter", hod_filter, dim3(count), dim3(FBLOCK), 0, a, first, p->want_LRG, p->want_ELG, \
                           p->want_QSO, p->enable_ranks, need_env, need_shear, F);                                    \
     }
-    static const bool nocls = getenv("ABACUS_HOD_NOCLS") != nullptr;   // A/B: every candidate through the float64 chain
+    const bool nocls = option("hod_nocls") != 0;   // A/B: every candidate through the float64 chain
     abacus_cls::ClsConst cc;
     abacus_cls::make_cls_const(*p, pre, cc);
 #define EXACT(first, count) \

@@ -671,13 +671,13 @@ static int paircount_impl(int mode, const void *x1, const void *y1, const void *
     g.inv_box = 1.0f / boxsize;
     // cells of size >= reach / R: R = 2 (125-cell stencil of cells an eighth the volume: 1.7x fewer candidate pairs) when
     // the catalogue is dense enough to keep a wave busy with a small cell, else R = 1
-    static const int gen = getenv("ABACUS_PAIRS_GEN") ? atoi(getenv("ABACUS_PAIRS_GEN")) : 3;   // A/B: 1, 2: older kernels
+    const int gen = option("pairs_gen") ? option("pairs_gen") : 3;   // comparators: 1, 2 = the older kernels
     auto ncells = [&](float reach, int R, int cap) {
         int nc = (int)floorf(boxsize / reach * (float)R * 0.9999f);   // cell size strictly >= reach / R
         nc = std::min(nc, cap);
         return nc < 3 ? 1 : nc;
     };
-    const bool v1 = gen == 1 || getenv("ABACUS_PAIRS_V1") != nullptr;   // first-generation kernel (comparator of the tests)
+    const bool v1 = gen == 1;   // first-generation kernel (comparator of the tests)
     int R = 1;
     if (!v1) {
         const double nmax = (double)std::max(n1, autocorr ? n1 : n2);

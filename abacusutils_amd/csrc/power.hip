@@ -665,7 +665,7 @@ int ensure_phase(int n) {
 // deposit + FFT of one particle set into mesh slots [slot] (and [slot+1] when interlaced); device particle arrays
 // `fused`: use fft.hip's fused form (permuted row order; the caller sets SpecArgs::permshift)
 bool use_fused_fft(int nmesh) {
-    return fft_native_supported(nmesh) && !getenv("ABACUS_FFT_HIPFFT") && !getenv("ABACUS_FFT_NOFUSE") &&
+    return fft_native_supported(nmesh) && !option("fft_hipfft") && !option("fft_nofuse") &&
            fft_native_fused_supported(nmesh);
 }
 
@@ -673,7 +673,7 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
                   bool fused = false, bool skip_x = false, DevBuf *dest = nullptr) {
     if (!dest) dest = &g_ctx.mesh[slot];
     if (n <= 0) return fail("power: empty particle set");
-    const bool native = fft_native_supported(nmesh) && !getenv("ABACUS_FFT_HIPFFT");
+    const bool native = fft_native_supported(nmesh) && !option("fft_hipfft");
     hipfftHandle plan = 0;
     // hipFFT (ROCm 7.2) returns a wrong spectrum for the padded in-place 2048^3 R2C (shot-noise test: 0.94 of the known
     // answer, where 1296^3..2016^3 give 1.0000); production never sends a power of two there, the debug switch must not
@@ -784,7 +784,7 @@ int prepare_bins(double Lbox, const double *kedges, int Nk, const double *muedge
     const double dk = dk_ > 0 ? dk_ : 2.0 * M_PI / Lbox;
     b.Nk = Nk;
     b.Nmu = Nmu;
-    b.dbg = getenv("ABACUS_DBG") ? atoi(getenv("ABACUS_DBG")) : 0;
+    b.dbg = option("dbg");
     b.Np = 0;
     for (int q = 0; q < Np_all; q++)
         if (poles[q] != 0) {   // requested pole -> slot among the ell != 0 accumulators, in order
@@ -906,7 +906,7 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
     ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
     const bool fused = use_fused_fft(nmesh);
     const bool cross = pos2 != nullptr;
-    if (fused && !interlaced && !cross && !getenv("ABACUS_PK_NOXBIN")) {
+    if (fused && !interlaced && !cross && !option("pk_noxbin")) {
         // auto power of one field: the last FFT pass bins straight from LDS (xbin.hip) - no spectrum write + re-read
         BinArgs b;
         size_t acc_bytes = 0;

@@ -2,6 +2,7 @@
 // HIP-event timers and the per-kernel profiler.
 #include <cstring>
 #include <map>
+#include <string>
 #include <mutex>
 #include <vector>
 
@@ -105,11 +106,39 @@ static void prof_drain() {
     }
 }
 
+namespace {
+std::map<std::string, int> &option_table() {
+    static std::map<std::string, int> t;
+    return t;
+}
+}  // namespace
+
+int option(const char *name) {
+    std::lock_guard<std::recursive_mutex> guard(api_mutex());
+    auto it = option_table().find(name);
+    return it == option_table().end() ? 0 : it->second;
+}
+
 }  // namespace abacus
 
 using namespace abacus;
 
 extern "C" {
+
+int abacus_set_option(const char *name, int value) {
+    if (!name) return abacus::fail("abacus_set_option: null name");
+    static const char *known[] = {"dbg", "dbg_fft", "dbg_tsc", "fft_fuse_small", "fft_hipfft", "fft_nofuse", "hod_f64filter",
+                                  "hod_nocls", "hod_norec", "hod_one_stage", "pairs_gen", "pk_noxbin", "tsc_atomic", "tsc_noshare"};
+    bool ok = false;
+    for (const char *k : known) ok = ok || !strcmp(k, name);
+    if (!ok) return abacus::fail("abacus_set_option: unknown option '%s'", name);
+    std::lock_guard<std::recursive_mutex> guard(abacus::api_mutex());
+    abacus::option_table()[name] = value;
+    return 0;
+}
+
+int abacus_get_option(const char *name) { return name ? abacus::option(name) : 0; }
+
 
 const char *abacus_last_error(void) { return g_err.c_str(); }
 

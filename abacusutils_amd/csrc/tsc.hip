@@ -778,11 +778,11 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     Entry<PT> *entries = nullptr;
     int cshift = 0;
     while (((int64_t)ntiles + (1 << cshift) - 1) >> cshift > MS_BINS) cshift++;
-    const bool multisplit = n >= 2000000 && cshift <= 10 && !getenv("ABACUS_TSC_ATOMIC");
+    const bool multisplit = n >= 2000000 && cshift <= 10 && !option("tsc_atomic");
     int64_t nentries_total = 0;
     // list sharing (multisplit path only): mode 1 builds lists that also cover a deposit shifted by up to half a cell,
     // mode 2 reuses them when nothing about the particles or the mesh changed
-    const bool share = multisplit && list_mode != 0 && !getenv("ABACUS_TSC_NOSHARE");
+    const bool share = multisplit && list_mode != 0 && !option("tsc_noshare");
     if (share && list_mode == 1 && offset != 0.0) return fail("tsc: shared lists are built at offset 0");
     if (share && list_mode == 2 && (offset < 0.0 || offset > 0.5 * box / gxg * 1.0000001))
         return fail("tsc: shared lists cover offsets up to half a cell");
@@ -879,7 +879,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         g_lists.gx = gx, g_lists.gy = gy, g_lists.gz = gz, g_lists.gxg = gxg, g_lists.xoff = xoff, g_lists.cic = CIC ? 1 : 0;
         g_lists.box = box, g_lists.entries = entries;
     }
-    const int dbg = getenv("ABACUS_DBG_TSC") ? atoi(getenv("ABACUS_DBG_TSC")) : 0;
+    const int dbg = option("dbg_tsc");
     if constexpr (std::is_same<PT, float>::value && std::is_same<GT, float>::value) {
         if (!(dbg & 4) && ntiles >= 4096) {   // persistent workgroups: two 64-KiB tiles per CU
             int dev = 0, ncu = 256;

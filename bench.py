@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--no-slab', action='store_true', help='N > 1: skip the slab-decomposed P(k) leg (RCCL all-to-all)')
     ap.add_argument('--slab-timeout', type=float, default=240.0, help='seconds before the slab leg is abandoned')
     ap.add_argument('--hod-timeout', type=float, default=420.0, help='N > 1: seconds before the headline leg is abandoned')
+    ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE',
+                    help='diagnostic option of the library (abacus_set_option), e.g. hod_nocls=1: A/B timing of a comparator path')
     ap.add_argument('--leg', default=None, choices=['hod', 'pk_slab'], help='internal: run one leg as a rank process')
     return ap.parse_args()
 
@@ -293,6 +295,9 @@ def single(args):
     from abacusutils_amd.comm import Dist
     dist = Dist(None)
     _lib.set_device(0)
+    for kv in args.option:
+        name, _, val = kv.partition('=')
+        _lib.set_option(name, int(val or 1))
     if args.workload == 'hod':
         out = bench_hod(args, dist)
         if not args.no_pk:

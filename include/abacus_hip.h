@@ -56,6 +56,13 @@ int abacus_profile_select(const char *name);
 /* writes up to `cap` entries; returns the number of distinct kernels (names are static strings) */
 int abacus_profile_get(const char **names, double *total_ms, int64_t *launches, int cap);
 
+/* Diagnostic options: comparator code paths that the parity tests and the A/B scripts switch on (the library reads no
+ * environment variables).  Names: fft_nofuse (plain three-pass FFT), fft_hipfft, fft_fuse_small, pk_noxbin (separate last
+ * pass + spectrum_bin), tsc_atomic, tsc_noshare, pairs_gen (1 / 2: older pair kernels), hod_nocls, hod_one_stage,
+ * hod_f64filter, hod_norec, dbg / dbg_fft / dbg_tsc (ablation bit masks).  Default 0 = the production path. */
+int abacus_set_option(const char *name, int value);
+int abacus_get_option(const char *name);
+
 /* ---------------------------------------------------------------- HOD ---------------------------------- */
 /*
  * Flat form of the three numba typed dicts gen_gals builds (hod/GRAND_HOD.py:1342-1468) plus the scalars it

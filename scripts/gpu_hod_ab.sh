@@ -10,10 +10,10 @@ if [ "$1" != "notest" ]; then
 fi
 for mode in cls nocls; do
   case $mode in
-    cls) env_=() ;;
-    nocls) env_=(ABACUS_HOD_NOCLS=1) ;;
+    cls) opt_=() ;;
+    nocls) opt_=(--option hod_nocls=1) ;;
   esac
-  env "${env_[@]}" timeout 600 python bench.py --no-cpu --no-pk --steps 20 --warmup 3 > "$O/bench_$mode.json" 2> "$O/bench_$mode.err" || { tail -5 "$O/bench_$mode.err"; exit 1; }
+  timeout 600 python bench.py --no-cpu --no-pk --steps 20 --warmup 3 "${opt_[@]}" > "$O/bench_$mode.json" 2> "$O/bench_$mode.err" || { tail -5 "$O/bench_$mode.err"; exit 1; }
   python - "$O/bench_$mode.json" "$mode" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

@@ -73,3 +73,27 @@ def assert_mock_equal(got, want, exact=True, rtol=0.0):
 
 
 SYNTH_CASES = ['lrg', 'all_rich', 'all_rich_ranks', 'all_rich_norsd', 'all_rich_lc', 'elg_only', 'qso_only', 'lrg_qso']
+
+
+class _Options:
+    def __init__(self):
+        self._set = set()
+
+    def set(self, name, value=1):
+        from abacusutils_amd import _lib
+        _lib.set_option(name, value)
+        self._set.add(name)
+
+    def reset(self):
+        from abacusutils_amd import _lib
+        for name in self._set:
+            _lib.set_option(name, 0)
+        self._set.clear()
+
+
+@pytest.fixture
+def options():
+    """diagnostic options of the library (comparator code paths), back to the production defaults after the test"""
+    o = _Options()
+    yield o
+    o.reset()

@@ -148,7 +148,7 @@ def test_cross_symmetry_and_scale():
     assert ab.sum() > 0
 
 
-def test_full_size_c5_properties(monkeypatch):
+def test_full_size_c5_properties(options):
     """BASELINE config 5 size (1e7 points, 2 Gpc/h box, 13 log bins to 30 Mpc/h): the persistent kernel and the
     first-generation one-workgroup-per-cell kernel count exactly the same pairs, and uniform randoms give the analytic
     expectation N (N-1) V_shell / V within 5 sigma of the Poisson error in every bin"""
@@ -158,7 +158,7 @@ def test_full_size_c5_properties(monkeypatch):
     p = rng.random((3, n), dtype=np.float32) * np.float32(box)
     bins = np.geomspace(0.1, 30.0, 14)
     got = T.DD(1, 1, bins, p[0], p[1], p[2], periodic=True, boxsize=box)['npairs']
-    monkeypatch.setenv('ABACUS_PAIRS_V1', '1')
+    options.set('pairs_gen', 1)
     old = T.DD(1, 1, bins, p[0], p[1], p[2], periodic=True, boxsize=box)['npairs']
     np.testing.assert_array_equal(got, old)
     b32 = bins.astype(np.float32).astype(np.float64)

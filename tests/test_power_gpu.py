@@ -164,12 +164,12 @@ def test_native_fft_sizes(nmesh):
     _check_oracle(tab, ref)
 
 
-def test_fused_fft_against_oracle(monkeypatch):
+def test_fused_fft_against_oracle(options):
     """fft.hip's fused form (first radix-2 stage of y and x inside the z pass, permuted row order undone by the binning)
     on a 256^3 mesh against the CPU oracle: auto and cross spectra, interlaced + compensated, multipoles"""
     from abacusutils_amd.analysis.power_spectrum import calc_power
     from oracle import oracle
-    monkeypatch.setenv('ABACUS_FFT_FUSE_SMALL', '1')
+    options.set('fft_fuse_small', 1)
     n, box = 600_000, 1000.0
     pos = synth.synth_positions(n, box, seed=79, clustered=True)
     pos2 = synth.synth_positions(n // 2, box, seed=80, clustered=True)
@@ -181,13 +181,13 @@ def test_fused_fft_against_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize('nmesh', [1024])
-def test_fused_fft_matches_three_pass(monkeypatch, nmesh):
+def test_fused_fft_matches_three_pass(options, nmesh):
     """production sizes of the fused form against the plain three-pass transform on the same particles"""
     from abacusutils_amd.analysis.power_spectrum import calc_power
     pos = synth.synth_positions(3_000_000, 1000.0, seed=81, clustered=True)
     kw = dict(kbins=64, mubins=4, paste='TSC', nmesh=nmesh, compensated=False, interlaced=True, poles=[0, 2, 4])
     a = calc_power(pos.copy(), 1000.0, **kw)
-    monkeypatch.setenv('ABACUS_FFT_NOFUSE', '1')
+    options.set('fft_nofuse', 1)
     b = calc_power(pos.copy(), 1000.0, **kw)
     np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
     np.testing.assert_allclose(a['power'], b['power'], rtol=2e-5, atol=1e-6 * np.abs(b['power']).max())
@@ -264,7 +264,7 @@ def test_zcv_helpers_larger_mesh_against_oracle():
     np.testing.assert_allclose(m, mo, rtol=2e-5)
 
 
-def test_full_size_2048_properties(monkeypatch):
+def test_full_size_2048_properties(options):
     """BASELINE size (nmesh 2048, 1e8 particles), size-independent properties: (1) the fused form of the hand-written
     FFT and its plain three-pass form give the same binned spectrum (hipFFT is no comparator here: its padded in-place
     2048^3 R2C is wrong on ROCm 7.2 - 0.94 of the shot-noise answer - and the library refuses it); (2) uniform randoms -> P0(k) = L^3/N (known answer) with
@@ -275,13 +275,13 @@ def test_full_size_2048_properties(monkeypatch):
     pos = rng.random((n, 3), dtype=np.float32) * np.float32(box)
     kw = dict(kbins=256, mubins=4, k_max=np.pi * nmesh / box, paste='TSC', nmesh=nmesh, poles=[0, 2, 4])
     a = calc_power(pos, box, compensated=False, interlaced=False, **kw)
-    monkeypatch.setenv('ABACUS_FFT_NOFUSE', '1')
+    options.set('fft_nofuse', 1)
     b = calc_power(pos, box, compensated=False, interlaced=False, **kw)
-    monkeypatch.delenv('ABACUS_FFT_NOFUSE')
-    monkeypatch.setenv('ABACUS_FFT_HIPFFT', '1')
+    options.set('fft_nofuse', 0)
+    options.set('fft_hipfft', 1)
     with pytest.raises(Exception, match='not usable'):
         calc_power(pos, box, compensated=False, interlaced=False, **kw)
-    monkeypatch.delenv('ABACUS_FFT_HIPFFT')
+    options.set('fft_hipfft', 0)
     np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
     np.testing.assert_allclose(a['power'], b['power'], rtol=2e-5)
     np.testing.assert_allclose(np.asarray(a['poles'])[:, 0], np.asarray(b['poles'])[:, 0], rtol=2e-5)
@@ -307,7 +307,7 @@ def test_full_size_2048_properties(monkeypatch):
 
 
 @pytest.mark.parametrize('paste,nmesh', [('CIC', 256), ('TSC', 98), ('CIC', 98), ('TSC', 130)])
-def test_interlaced_shared_lists(paste, nmesh, monkeypatch):
+def test_interlaced_shared_lists(paste, nmesh, options):
     """>= 2e6 particles: the two deposits of an interlaced pair share one list build (tsc.hip `list_mode`, lists for the
     4-cell union of both clouds).  CIC and meshes whose last tile has fewer than 4 cells (generic tile enumeration)
     against the oracle, and against the same call with the sharing switched off"""
@@ -319,7 +319,7 @@ def test_interlaced_shared_lists(paste, nmesh, monkeypatch):
     tab = calc_power(pos.copy(), box, **kw)
     ref = oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw)
     _check_oracle(tab, ref)
-    monkeypatch.setenv('ABACUS_TSC_NOSHARE', '1')
+    options.set('tsc_noshare', 1)
     tab2 = calc_power(pos.copy(), box, **kw)
     np.testing.assert_array_equal(tab['N_mode'], tab2['N_mode'])
     np.testing.assert_allclose(tab['power'], tab2['power'], rtol=1e-6, atol=1e-9 * np.abs(np.asarray(tab2['power'])).max())
@@ -434,7 +434,7 @@ def test_c3_full_size_against_oracle():
 
 
 @pytest.mark.parametrize('nmesh,comp', [(1024, False), (1024, True)])
-def test_fused_last_pass_matches_spectrum_bin(monkeypatch, nmesh, comp):
+def test_fused_last_pass_matches_spectrum_bin(options, nmesh, comp):
     """fft_x_bin (last FFT pass + binning in one kernel, xbin.hip) against the x pass + spectrum_bin on the same particles:
     identical |delta_k|^2 per mode, so the float64 sums agree to rounding"""
     from abacusutils_amd.analysis.power_spectrum import calc_power
@@ -444,9 +444,9 @@ def test_fused_last_pass_matches_spectrum_bin(monkeypatch, nmesh, comp):
                dict(kbins=48, mubins=7, poles=[]), dict(kbins=32, mubins=3, poles=[4], logk=True, k_max=1.5)):
         kw = dict(kw, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=False, w=w)
         a = calc_power(pos.copy(), 1000.0, **kw)
-        monkeypatch.setenv('ABACUS_PK_NOXBIN', '1')
+        options.set('pk_noxbin', 1)
         b = calc_power(pos.copy(), 1000.0, **kw)
-        monkeypatch.delenv('ABACUS_PK_NOXBIN')
+        options.set('pk_noxbin', 0)
         np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
         np.testing.assert_allclose(a['power'], b['power'], rtol=2e-6, atol=1e-7 * np.abs(b['power']).max())
         np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)

@@ -160,10 +160,10 @@ def test_vs_oracle_sizes(n, ngrid):
     assert np.isclose(a.sum(dtype='f8'), w.sum(dtype='f8'), rtol=1e-6)
 
 
-def test_full_size_properties(monkeypatch):
+def test_full_size_properties(options):
     """BASELINE config 3 size (1e8 particles, 1024^3 mesh): mass conservation (sum of the mesh = sum of the weights),
     every cell non-negative, and the two list builders (two-level multisplit vs single-level lists with per-tile atomic
-    cursors, `ABACUS_TSC_ATOMIC`) feeding the tile deposit give the same mesh to float32 rounding of the cell sums"""
+    cursors, option `tsc_atomic`) feeding the tile deposit give the same mesh to float32 rounding of the cell sums"""
     from abacusutils_amd.analysis.tsc import tsc_parallel
     n, box, ng = 100_000_000, 2000.0, 1024
     rng = np.random.default_rng(300)
@@ -174,7 +174,7 @@ def test_full_size_properties(monkeypatch):
     tot = float(a.sum(dtype=np.float64))
     assert abs(tot / float(w.sum(dtype=np.float64)) - 1) < 1e-6
     assert a.min() >= 0
-    monkeypatch.setenv('ABACUS_TSC_ATOMIC', '1')
+    options.set('tsc_atomic', 1)
     b = tsc_parallel(pos, ng, box, weights=w)
     # mean cell holds ~0.09 particles' weight spread over 27 cells: float32 sums of a few terms
     assert np.abs(a - b).max() <= 4e-6 * max(a.max(), 1.0)
