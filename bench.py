@@ -58,13 +58,14 @@ def parse():
 
 
 def filter_bytes_per_object(tracers, enable_ranks, two_stage=True):
-    """algorithmic bytes the rejection filter streams per halo / per particle, in the layout it actually reads (float32
-    shadow columns of a catalogue the library owns).  Two-stage (envelope table) filter: mass,
-    multiplicity / weight, random = 12 B per object for ANY HOD - environment and rank columns are only gathered for
-    the few per cent that survive the table.  One-stage fallback: + deltac, fenv (+ shear) per halo when weighted,
-    + four rank columns per particle."""
+    """algorithmic bytes the rejection filter streams per halo / per particle, in the layout it actually reads
+    (DESIGN.md section 4).  Two-stage filter: ONE packed 32-bit key per object (mass bin + a float lower bound of
+    random / weight, built at staging and after a reseed) - 4 B per object for ANY HOD; environment, rank and float32
+    shadow columns are only gathered for the few per cent that survive the table.  One-stage fallback (parameter sets
+    the envelope table cannot bound): float32 shadow columns, 12 B + deltac, fenv (+ shear) per halo when weighted,
+    12 B + four rank columns per particle."""
     if two_stage:
-        return 12.0, 12.0
+        return 4.0, 4.0
     env = any(t.get('Acent', 0) != 0 or t.get('Bcent', 0) != 0 for t in tracers.values())
     shear = 'ELG' in tracers and tracers['ELG'].get('Ccent', 0) != 0
     return 12.0 + (8.0 if env else 0.0) + (4.0 if shear else 0.0), 12.0 + (16.0 if enable_ranks else 0.0)
@@ -91,7 +92,7 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     warm = {k: ms / n for k, (ms, n) in _lib.profile_get().items() if n}
     calls = {k: n for k, (ms, n) in _lib.profile_get().items() if n}
     # one-off staging work outside the timed region: float32 shadows, packed records, column ranges (whole durations)
-    stage_ms = sum(warm[k] * calls[k] for k in warm if k in ('hod_shadow', 'hod_build_recs', 'hod_minmax', 'hod_check_pinds'))
+    stage_ms = sum(warm[k] * calls[k] for k in warm if k in ('hod_shadow', 'hod_build_recs', 'hod_build_keys', 'hod_minmax', 'hod_check_pinds'))
 
     # timed region: HIP events only around the dominant kernel (a pair of event records per launch costs a few
     # microseconds, which is not negligible against a 0.1-ms step); the other kernels' durations are the warm-up's
@@ -160,10 +161,10 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
                            'frac': ach / HBM_PEAK_GBS,
                            'traffic': pmc_traffic('hod', dom_name) if c2 else None,
                            'algorithmic_bytes': fbytes,
-                           'layout': f'float32 shadow columns built at staging ({bh:.0f} B per halo + {bp:.0f} B per particle: '
-                                     'mass, multiplicity / weight, random); the float64 reference layout (SURVEY.md 8d: 40 B '
-                                     'per object) is read only for the candidates; building the shadows + packed records is '
-                                     '`stage_ms`, once per catalogue, outside the timed region',
+                           'layout': f'packed filter keys built at staging ({bh:.0f} B per halo + {bp:.0f} B per particle: mass bin + a lower '
+                                     'bound of random / weight); the float64 reference layout (SURVEY.md 8d: 40 B per object) is read '
+                                     'only for the candidates; keys, float32 shadows and packed records are built once per catalogue '
+                                     '(`stage_ms`, outside the timed region), the keys again after a reseed',
                            'whole_step_GBs': step_bytes / (dt / args.steps) / 1e9,
                            'whole_step_frac': step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
     st.free()

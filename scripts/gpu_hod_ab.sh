@@ -8,10 +8,10 @@ if [ "$1" != "notest" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q -k "hod" 2>&1 | tail -8 | tee "$O/tests.log"
   grep -qE "[0-9]+ (failed|error)" "$O/tests.log" && exit 1
 fi
-for mode in cls nocls; do
+for mode in keys nokeys; do
   case $mode in
-    cls) opt_=() ;;
-    nocls) opt_=(--option hod_nocls=1) ;;
+    keys) opt_=() ;;
+    nokeys) opt_=(--option hod_nokeys=1) ;;
   esac
   timeout 600 python bench.py --no-cpu --no-pk --steps 20 --warmup 3 "${opt_[@]}" > "$O/bench_$mode.json" 2> "$O/bench_$mode.err" || { tail -5 "$O/bench_$mode.err"; exit 1; }
   python - "$O/bench_$mode.json" "$mode" <<'PY'
