@@ -683,8 +683,11 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
                                                          const unsigned int *__restrict__ pkeys, int ngroup_c, int want_LRG,
                                                          int want_ELG, int want_QSO, int enable_ranks, int need_env, int need_shear,
                                                          Filt F, Cheap ch) {
-    __shared__ int nq, nq1;
-    __shared__ unsigned short q[TILE], q1[TILE];
+    // survivors of the table bound of ALL the workgroup's tiles go to one list (tile << 11 | index in tile), so that the
+    // arithmetic bound of stage 2 - gathers from the float32 shadows: one memory round trip - runs once per workgroup and not
+    // once per tile (per tile it was four dependent round trips: 38 us at 1e7 + 1e7, latency-bound at 2.6 TB/s)
+    __shared__ int nq1, nq[KEY_TILES];
+    __shared__ unsigned short q1[KEY_TILES * TILE], q[KEY_TILES][TILE];
     __shared__ float tab[256];
     const int tid = threadIdx.x;
     const bool SAT = KIND == 2 ? (int)blockIdx.x >= ngroup_c : KIND == 1;
@@ -694,6 +697,8 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
         const float v = tid < CH_NLEV ? (SAT ? ch.Bs[tid] : ch.Bc[tid]) * dec * 1.0001f : INFINITY;
         tab[tid] = v;
     }
+    if (tid == 0) nq1 = 0;
+    if (tid < KEY_TILES) nq[tid] = 0;
     const int ntile = SAT ? a.ntile_s : a.ntile_c;
     const int64_t n = SAT ? a.np : a.nh;
     const unsigned int *keys = SAT ? pkeys : hkeys;
@@ -701,68 +706,74 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
     abacus_hod_params pw;
     pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO, pw.enable_ranks = enable_ranks;
     const bool need_conf = SAT && want_ELG && a.pinds != nullptr;
-    // all key loads of the workgroup's tiles first: 2 x 16 B per thread and tile (the key array is padded past the last tile)
+    // all key loads of the workgroup's tiles first: 2 x 16 B per thread and tile (the key array is padded to whole tiles)
     uint4 k[KEY_TILES][2];
     const int t_first = G * KEY_TILES;
+    const int64_t base0 = (int64_t)t_first * TILE;
 #pragma unroll
     for (int t = 0; t < KEY_TILES; t++) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int64_t i = ((int64_t)(t_first + t) * TILE) + h * (4 * FBLOCK) + 4 * tid;
+            const int64_t i = base0 + (int64_t)t * TILE + h * (4 * FBLOCK) + 4 * tid;
             k[t][h] = (t_first + t < ntile) ? *reinterpret_cast<const uint4 *>(keys + i) : make_uint4(0u, 0u, 0u, 0u);
         }
     }
+    __syncthreads();            // the table and the zeroed counters
+    // ---- stage 1: one LDS table look-up and one compare per object ----
 #pragma unroll
     for (int t = 0; t < KEY_TILES; t++) {
-        const int T = t_first + t;
-        if (T >= ntile) break;      // uniform
-        if (tid == 0) nq = 0, nq1 = 0;
-        __syncthreads();            // also: the table (first round), the previous tile's queues
-        const int64_t tile0 = (int64_t)T * TILE;
+        if (t_first + t >= ntile) break;      // uniform
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int loc = h * (4 * FBLOCK) + 4 * tid;
             const unsigned int kk[4] = {k[t][h].x, k[t][h].y, k[t][h].z, k[t][h].w};
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (tile0 + loc + u >= n) continue;
+                if (base0 + (int64_t)t * TILE + loc + u >= n) continue;
                 const float qv = __uint_as_float(kk[u] & 0xffffff00u);
-                if (!(qv > tab[kk[u] & 255u])) q1[atomicAdd(&nq1, 1)] = (unsigned short)(loc + u);
+                if (!(qv > tab[kk[u] & 255u])) q1[atomicAdd(&nq1, 1)] = (unsigned short)((t << 11) | (loc + u));
             }
         }
-        __syncthreads();
-        // ---- stage 2: the arithmetic bound with the object's own environment / ranks, for the survivors ----
-        const int n1 = nq1;
-        for (int e = tid; e < n1; e += FBLOCK) {
-            const int loc = q1[e];
-            const int64_t i = tile0 + loc;
-            bool rej = false;
-            if (!SAT) {
-                const float d = need_env && c.hdeltac ? c.hdeltac[i] : 0.f, f = need_env && c.hfenv ? c.hfenv[i] : 0.f,
-                            sh = need_shear && c.hshear ? c.hshear[i] : 0.f;
-                rej = cent_reject<float>(pw, F, c.hmass[i], c.hmultis[i], c.hrandoms[i], d, f, sh);
-            } else if (F.sat_ok) {
-                const float r0 = enable_ranks ? c.pranks[i] : 1.f, r1 = enable_ranks ? c.pranksv[i] : 1.f,
-                            r2 = enable_ranks ? c.pranksp[i] : 1.f, r3 = enable_ranks ? c.pranksr[i] : 1.f;
-                rej = sat_reject<float>(pw, F, c.phmass[i], c.pweights[i], c.prandoms[i], r0, r1, r2, r3,
-                                        need_conf ? (int8_t)-1 : (int8_t)0);
-            }
-            if (!rej) q[atomicAdd(&nq, 1)] = (unsigned short)loc;
-        }
-        {   // zero this tile's mask: 8 consecutive bytes per thread
-            const int64_t o = tile0 + (int64_t)tid * 8;
+    }
+    {   // zero the tiles' masks: 8 consecutive bytes per thread and tile
+#pragma unroll
+        for (int t = 0; t < KEY_TILES; t++) {
+            const int64_t o = base0 + (int64_t)t * TILE + (int64_t)tid * 8;
+            if (t_first + t >= ntile) break;
             if (o + 8 <= n) *reinterpret_cast<unsigned long long *>(keep + o) = 0ull;
             else
                 for (int q8 = 0; q8 < 8; q8++)
                     if (o + q8 < n) keep[o + q8] = 0;
         }
-        __syncthreads();
-        const int cnt = nq;
-        const int g = SAT ? T + a.ntile_c : T;          // global tile id (index of q_count)
-        if (tid == 0) a.q_count[g] = cnt;
-        unsigned short *queue = SAT ? a.queue_s : a.queue_c;
-        for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
-        __syncthreads();            // the queues and their counters are reused by the next tile
+    }
+    __syncthreads();
+    // ---- stage 2: the arithmetic bound with the object's own environment / ranks, for the survivors of all tiles ----
+    const int n1 = nq1;
+    for (int e = tid; e < n1; e += FBLOCK) {
+        const int code = q1[e], t = code >> 11, loc = code & (TILE - 1);
+        const int64_t i = base0 + (int64_t)t * TILE + loc;
+        bool rej = false;
+        if (!SAT) {
+            const float d = need_env && c.hdeltac ? c.hdeltac[i] : 0.f, f = need_env && c.hfenv ? c.hfenv[i] : 0.f,
+                        sh = need_shear && c.hshear ? c.hshear[i] : 0.f;
+            rej = cent_reject<float>(pw, F, c.hmass[i], c.hmultis[i], c.hrandoms[i], d, f, sh);
+        } else if (F.sat_ok) {
+            const float r0 = enable_ranks ? c.pranks[i] : 1.f, r1 = enable_ranks ? c.pranksv[i] : 1.f,
+                        r2 = enable_ranks ? c.pranksp[i] : 1.f, r3 = enable_ranks ? c.pranksr[i] : 1.f;
+            rej = sat_reject<float>(pw, F, c.phmass[i], c.pweights[i], c.prandoms[i], r0, r1, r2, r3,
+                                    need_conf ? (int8_t)-1 : (int8_t)0);
+        }
+        if (!rej) q[t][atomicAdd(&nq[t], 1)] = (unsigned short)loc;
+    }
+    __syncthreads();
+    unsigned short *queue = SAT ? a.queue_s : a.queue_c;
+#pragma unroll
+    for (int t = 0; t < KEY_TILES; t++) {
+        const int T = t_first + t;
+        if (T >= ntile) break;
+        const int cnt = nq[t];
+        if (tid == 0) a.q_count[SAT ? T + a.ntile_c : T] = cnt;    // global tile id
+        for (int j = tid; j < cnt; j += FBLOCK) queue[(int64_t)T * TILE + j] = q[t][j];
     }
 }
 
