@@ -676,6 +676,7 @@ __global__ __launch_bounds__(256) void hod_build_keys(const double *__restrict__
 }
 
 constexpr int KEY_TILES = 4;   // tiles per workgroup of the key filter
+constexpr int KEY_Q1 = 2048;   // stage-1 survivors a workgroup lists for stage 2 (~80 expected at 1 % survival)
 
 // KIND: 0 = central tile groups, 1 = satellite tile groups, 2 = both (central groups first)
 template <int KIND>
@@ -686,8 +687,11 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
     // survivors of the table bound of ALL the workgroup's tiles go to one list (tile << 11 | index in tile), so that the
     // arithmetic bound of stage 2 - gathers from the float32 shadows: one memory round trip - runs once per workgroup and not
     // once per tile (per tile it was four dependent round trips: 38 us at 1e7 + 1e7, latency-bound at 2.6 TB/s)
+    // The final survivors are written straight into the tiles' global queue slices (a few thousand 2-byte stores per
+    // launch); the stage-1 list holds KEY_Q1 entries, the rare overflow skips stage 2 (which only ever removes candidates):
+    // 5 KB of LDS per workgroup instead of 34 KB, so eight workgroups per CU hide each other's round trips.
     __shared__ int nq1, nq[KEY_TILES];
-    __shared__ unsigned short q1[KEY_TILES * TILE], q[KEY_TILES][TILE];
+    __shared__ unsigned short q1[KEY_Q1];
     __shared__ float tab[256];
     const int tid = threadIdx.x;
     const bool SAT = KIND == 2 ? (int)blockIdx.x >= ngroup_c : KIND == 1;
@@ -703,6 +707,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
     const int64_t n = SAT ? a.np : a.nh;
     const unsigned int *keys = SAT ? pkeys : hkeys;
     int8_t *keep = SAT ? a.keep_s : a.keep_c;
+    unsigned short *queue = SAT ? a.queue_s : a.queue_c;
     abacus_hod_params pw;
     pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO, pw.enable_ranks = enable_ranks;
     const bool need_conf = SAT && want_ELG && a.pinds != nullptr;
@@ -731,7 +736,11 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
             for (int u = 0; u < 4; u++) {
                 if (base0 + (int64_t)t * TILE + loc + u >= n) continue;
                 const float qv = __uint_as_float(kk[u] & 0xffffff00u);
-                if (!(qv > tab[kk[u] & 255u])) q1[atomicAdd(&nq1, 1)] = (unsigned short)((t << 11) | (loc + u));
+                if (!(qv > tab[kk[u] & 255u])) {
+                    const int slot = atomicAdd(&nq1, 1);
+                    if (slot < KEY_Q1) q1[slot] = (unsigned short)((t << 11) | (loc + u));
+                    else queue[base0 + (int64_t)t * TILE + atomicAdd(&nq[t], 1)] = (unsigned short)(loc + u);   // list full: unfiltered
+                }
             }
         }
     }
@@ -748,7 +757,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
     }
     __syncthreads();
     // ---- stage 2: the arithmetic bound with the object's own environment / ranks, for the survivors of all tiles ----
-    const int n1 = nq1;
+    const int n1 = min(nq1, KEY_Q1);
     for (int e = tid; e < n1; e += FBLOCK) {
         const int code = q1[e], t = code >> 11, loc = code & (TILE - 1);
         const int64_t i = base0 + (int64_t)t * TILE + loc;
@@ -763,18 +772,10 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
             rej = sat_reject<float>(pw, F, c.phmass[i], c.pweights[i], c.prandoms[i], r0, r1, r2, r3,
                                     need_conf ? (int8_t)-1 : (int8_t)0);
         }
-        if (!rej) q[t][atomicAdd(&nq[t], 1)] = (unsigned short)loc;
+        if (!rej) queue[base0 + (int64_t)t * TILE + atomicAdd(&nq[t], 1)] = (unsigned short)loc;
     }
     __syncthreads();
-    unsigned short *queue = SAT ? a.queue_s : a.queue_c;
-#pragma unroll
-    for (int t = 0; t < KEY_TILES; t++) {
-        const int T = t_first + t;
-        if (T >= ntile) break;
-        const int cnt = nq[t];
-        if (tid == 0) a.q_count[SAT ? T + a.ntile_c : T] = cnt;    // global tile id
-        for (int j = tid; j < cnt; j += FBLOCK) queue[(int64_t)T * TILE + j] = q[t][j];
-    }
+    if (tid < KEY_TILES && t_first + tid < ntile) a.q_count[(SAT ? a.ntile_c : 0) + t_first + tid] = nq[tid];   // global tile id
 }
 
 // The reference's float64 chains as OUT-OF-LINE functions reading the parameters through a pointer (the workgroup's LDS
