@@ -732,9 +732,10 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
         for (int h = 0; h < 2; h++) {
             const int loc = h * (4 * FBLOCK) + 4 * tid;
             const unsigned int kk[4] = {k[t][h].x, k[t][h].y, k[t][h].z, k[t][h].w};
+            const int lim = (int)min((int64_t)4, n - (base0 + (int64_t)t * TILE + loc));   // objects of this load inside the catalogue
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (base0 + (int64_t)t * TILE + loc + u >= n) continue;
+                if (u >= lim) continue;
                 const float qv = __uint_as_float(kk[u] & 0xffffff00u);
                 if (!(qv > tab[kk[u] & 255u])) {
                     const int slot = atomicAdd(&nq1, 1);
