@@ -37,7 +37,7 @@ namespace {
 constexpr int TILE = 2048;    // objects per workgroup
 constexpr int BLOCK = 256;    // threads per workgroup (4 waves)
 constexpr int PER_THREAD = TILE / BLOCK;
-constexpr int SB_TILES = 16;                       // decide tiles per superblock (one exact / emit workgroup)
+constexpr int SB_TILES = 8;                        // decide tiles per superblock (one exact / emit workgroup)
 constexpr int SB_OBJ = SB_TILES * TILE;            // 32768 objects: an in-superblock index fits uint16
 constexpr int SB_WORDS = SB_OBJ / 32;              // words of one tracer's keep bitmap
 
