@@ -300,50 +300,64 @@ __device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Fil
 constexpr int FBLOCK = 256;
 
 // All device pointers of the staged catalogue + work arrays, passed by value to the fused kernels
-// Emission records (owned catalogues): the rows hod_emit gathers for a kept object, packed next to each other at
-// staging - one TLB entry and one or two 64-B sectors per galaxy instead of five arrays (five pages, five lines).  Only
-// columns that never change after staging (not hveldev, which a reseed redraws).
-// The exact kernel reads its decision inputs (mass, multiplicity / weight, environment, ranks) from the same record, so
-// a kept object's record is already in the cache hierarchy when hod_emit comes for it.  Absent optional columns are
-// stored as the value the exact chain substitutes for them (0, ranks 1).
-struct __attribute__((aligned(32))) HaloRec {
-    double pos[3], vel[3], mass;
+// Packed per-object records (owned catalogues), laid out by 64-B LINE: line A holds exactly what hod_exact reads for a
+// candidate (mass, multiplicity / weight, the random, environment; for particles the first two ranks), the following
+// line(s) what only hod_emit needs (position, velocities, the halo's velocity deviate), so a candidate costs ONE line and
+// a galaxy two - five arrays in five pages otherwise (the column gathers were 27 + 26 us at C2, records 20 + 20; with the
+// random and hveldev in separate columns the dense multi-tracer mix still paid three to four lines per candidate).
+// The random and hveldev change with a reseed / update: those fields are rewritten then (hod_refresh_recs), the rest is
+// built once.  Absent optional columns are stored as the value the exact chain substitutes for them (0, ranks 1).
+struct __attribute__((aligned(128))) HaloRec {
+    double mass, multis, rnd, deltac, fenv, shear;   // line A
     long long id;
-    double multis, deltac, fenv, shear;
+    double pos0;
+    double pos1, pos2, vel[3], vdev[3];              // line B
 };
-struct __attribute__((aligned(32))) PartRec {
-    double pos[3], vel[3], hvel[3], mass;
+struct __attribute__((aligned(64))) PartRec {
+    double mass, weights, rnd, deltac, fenv, shear, rank0, rank1;   // line A
+    double rank2, rank3;                                            // line B
     long long id;
-    double weights, deltac, fenv, shear, ranks[4], pad;
+    double mass2, pos[3], vel0;
+    double vel1, vel2, hvel[3], pad[3];                             // line C
 };
-static_assert(sizeof(HaloRec) == 96 && sizeof(PartRec) == 160, "record sizes");
+static_assert(sizeof(HaloRec) == 128 && sizeof(PartRec) == 192, "record sizes");
 
 struct RecSrc {
-    const double *hpos, *hvel, *hmass, *hmultis, *hdeltac, *hfenv, *hshear;
+    const double *hpos, *hvel, *hvdev, *hmass, *hmultis, *hrandoms, *hdeltac, *hfenv, *hshear;
     const int64_t *hid;
-    const double *ppos, *pvel, *phvel, *phmass, *pweights, *pdeltac, *pfenv, *pshear, *pranks[4];
+    const double *ppos, *pvel, *phvel, *phmass, *pweights, *prandoms, *pdeltac, *pfenv, *pshear, *pranks[4];
     const int64_t *phid;
 };
+// RAND_ONLY: rewrite just the fields a reseed / update changes (the random; the halo's velocity deviate)
+template <bool RAND_ONLY>
 __global__ void hod_build_recs(int64_t nh, int64_t np, RecSrc c, HaloRec *__restrict__ hrec, PartRec *__restrict__ prec) {
-    const double *hpos = c.hpos, *hvel = c.hvel, *hmass = c.hmass, *ppos = c.ppos, *pvel = c.pvel, *phvel = c.phvel,
-                 *phmass = c.phmass;
-    const int64_t *hid = c.hid, *phid = c.phid;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = t0; i < nh; i += stride) {
+        if (RAND_ONLY) {
+            hrec[i].rnd = c.hrandoms[i];
+            for (int d = 0; d < 3; d++) hrec[i].vdev[d] = c.hvdev[3 * i + d];
+            continue;
+        }
         HaloRec r;
-        for (int d = 0; d < 3; d++) r.pos[d] = hpos[3 * i + d], r.vel[d] = hvel[3 * i + d];
-        r.mass = hmass[i], r.id = hid[i];
-        r.multis = c.hmultis[i];
+        r.mass = c.hmass[i], r.multis = c.hmultis[i], r.rnd = c.hrandoms[i], r.id = c.hid[i];
         r.deltac = c.hdeltac ? c.hdeltac[i] : 0.0, r.fenv = c.hfenv ? c.hfenv[i] : 0.0, r.shear = c.hshear ? c.hshear[i] : 0.0;
+        r.pos0 = c.hpos[3 * i], r.pos1 = c.hpos[3 * i + 1], r.pos2 = c.hpos[3 * i + 2];
+        for (int d = 0; d < 3; d++) r.vel[d] = c.hvel[3 * i + d], r.vdev[d] = c.hvdev[3 * i + d];
         hrec[i] = r;
     }
     for (int64_t i = t0; i < np; i += stride) {
+        if (RAND_ONLY) {
+            prec[i].rnd = c.prandoms[i];
+            continue;
+        }
         PartRec r;
-        for (int d = 0; d < 3; d++) r.pos[d] = ppos[3 * i + d], r.vel[d] = pvel[3 * i + d], r.hvel[d] = phvel[3 * i + d];
-        r.mass = phmass[i], r.id = phid[i], r.pad = 0.0;
-        r.weights = c.pweights[i];
+        r.mass = r.mass2 = c.phmass[i], r.weights = c.pweights[i], r.rnd = c.prandoms[i], r.id = c.phid[i];
         r.deltac = c.pdeltac ? c.pdeltac[i] : 0.0, r.fenv = c.pfenv ? c.pfenv[i] : 0.0, r.shear = c.pshear ? c.pshear[i] : 0.0;
-        for (int q = 0; q < 4; q++) r.ranks[q] = c.pranks[q] ? c.pranks[q][i] : 1.0;
+        r.rank0 = c.pranks[0] ? c.pranks[0][i] : 1.0, r.rank1 = c.pranks[1] ? c.pranks[1][i] : 1.0;
+        r.rank2 = c.pranks[2] ? c.pranks[2][i] : 1.0, r.rank3 = c.pranks[3] ? c.pranks[3][i] : 1.0;
+        for (int d = 0; d < 3; d++) r.pos[d] = c.ppos[3 * i + d], r.hvel[d] = c.phvel[3 * i + d];
+        r.vel0 = c.pvel[3 * i], r.vel1 = c.pvel[3 * i + 1], r.vel2 = c.pvel[3 * i + 2];
+        r.pad[0] = r.pad[1] = r.pad[2] = 0.0;
         prec[i] = r;
     }
 }
@@ -759,11 +773,15 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
     __syncthreads();
     // ---- stage 2: the arithmetic bound with the object's own environment / ranks, for the survivors of all tiles ----
     const int n1 = min(nq1, KEY_Q1);
+    const bool dense = nq1 > KEY_TILES * TILE / 8;
     for (int e = tid; e < n1; e += FBLOCK) {
         const int code = q1[e], t = code >> 11, loc = code & (TILE - 1);
         const int64_t i = base0 + (int64_t)t * TILE + loc;
         bool rej = false;
-        if (!SAT) {
+        if (dense) {
+            // more than an eighth of the objects survived the table: a dense tracer mix, where the arithmetic bound removes
+            // next to nothing (it bounds the same occupations) and its gathers cost more than the few extra exact evaluations
+        } else if (!SAT) {
             const float d = need_env && c.hdeltac ? c.hdeltac[i] : 0.f, f = need_env && c.hfenv ? c.hfenv[i] : 0.f,
                         sh = need_shear && c.hshear ? c.hshear[i] : 0.f;
             rej = cent_reject<float>(pw, F, c.hmass[i], c.hmultis[i], c.hrandoms[i], d, f, sh);
@@ -857,22 +875,22 @@ __global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, aba
         double mass, w, rnd, dc, fe, sh, r0 = 1.0, r1 = 1.0, r2 = 1.0, r3 = 1.0;
         int kc = 0;
         if (!sat) {
-            rnd = a.hrandoms[i];
             if (a.hrec) {
-                const HaloRec &r = a.hrec[i];
-                mass = r.mass, w = r.multis, dc = r.deltac, fe = r.fenv, sh = p.want_ELG ? r.shear : 0.0;
+                const HaloRec &r = a.hrec[i];   // line A only
+                mass = r.mass, w = r.multis, rnd = r.rnd, dc = r.deltac, fe = r.fenv, sh = p.want_ELG ? r.shear : 0.0;
             } else {
+                rnd = a.hrandoms[i];
                 mass = a.hmass[i], w = a.hmultis[i], dc = load1(a.hdeltac, i, 0.0), fe = load1(a.hfenv, i, 0.0),
                 sh = p.want_ELG ? load1(a.hshear, i, 0.0) : 0.0;
             }
         } else {
             kc = need_conf ? a.keep_c[a.pinds[i]] : 0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
-            rnd = a.prandoms[i];
             if (a.prec) {
-                const PartRec &r = a.prec[i];
-                mass = r.mass, w = r.weights, dc = r.deltac, fe = r.fenv, sh = p.want_ELG ? r.shear : 0.0;
-                if (need_ranks) r0 = r.ranks[0], r1 = r.ranks[1], r2 = r.ranks[2], r3 = r.ranks[3];
+                const PartRec &r = a.prec[i];   // line A (+ the head of line B with ranks)
+                mass = r.mass, w = r.weights, rnd = r.rnd, dc = r.deltac, fe = r.fenv, sh = p.want_ELG ? r.shear : 0.0;
+                if (need_ranks) r0 = r.rank0, r1 = r.rank1, r2 = r.rank2, r3 = r.rank3;
             } else {
+                rnd = a.prandoms[i];
                 mass = a.phmass[i], w = a.pweights[i], dc = load1(a.pdeltac, i, 0.0), fe = load1(a.pfenv, i, 0.0),
                 sh = p.want_ELG ? load1(a.pshear, i, 0.0) : 0.0;
                 if (need_ranks) r0 = a.pranks[i], r1 = a.pranksv[i], r2 = a.pranksp[i], r3 = a.pranksr[i];
@@ -1061,19 +1079,19 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
         double x, y, z, vx, vy, vz, m;
         int64_t id;
         if (!sat && in.hrec) {
-            const HaloRec r = in.hrec[i];
-            x = r.pos[0], y = r.pos[1], z = r.pos[2];
-            vx = r.vel[0] + al * in.hvdev[3 * i];
-            vy = r.vel[1] + al * in.hvdev[3 * i + 1];
-            vz = r.vel[2] + al * in.hvdev[3 * i + 2];
+            const HaloRec &r = in.hrec[i];   // both lines
+            x = r.pos0, y = r.pos1, z = r.pos2;
+            vx = r.vel[0] + al * r.vdev[0];
+            vy = r.vel[1] + al * r.vdev[1];
+            vz = r.vel[2] + al * r.vdev[2];
             m = r.mass, id = r.id;
         } else if (sat && in.prec) {
-            const PartRec r = in.prec[i];
+            const PartRec &r = in.prec[i];   // lines B and C
             x = r.pos[0], y = r.pos[1], z = r.pos[2];
-            vx = r.hvel[0] + al * (r.vel[0] - r.hvel[0]);
-            vy = r.hvel[1] + al * (r.vel[1] - r.hvel[1]);
-            vz = r.hvel[2] + al * (r.vel[2] - r.hvel[2]);
-            m = r.mass, id = r.id;
+            vx = r.hvel[0] + al * (r.vel0 - r.hvel[0]);
+            vy = r.hvel[1] + al * (r.vel1 - r.hvel[1]);
+            vz = r.hvel[2] + al * (r.vel2 - r.hvel[2]);
+            m = r.mass2, id = r.id;
         } else if (!sat) {
             x = in.hpos[3 * i], y = in.hpos[3 * i + 1], z = in.hpos[3 * i + 2];
             vx = in.hvel[3 * i] + al * in.hvdev[3 * i];  // velocity bias (:301-305)
@@ -1441,8 +1459,8 @@ struct abacus_hod_state {
     DevBuf shadow;
     FiltCols fc = {};
     bool shadow_ok = false, shadow_rand_ok = false;
-    DevBuf hrec, prec;          // emission records (owned catalogues)
-    bool rec_ok = false;
+    DevBuf hrec, prec;          // packed records (owned catalogues)
+    bool rec_ok = false, rec_rand_ok = false;   // rec_rand_ok: the records hold the current randoms / hveldev
     HodRanges ranges;           // value ranges of the environment / rank columns (envelope table of the two-stage filter)
     bool ranges_ok = false;
     DevBuf keys;                // packed filter keys (hod_build_keys): [ntile_c * TILE][ntile_s * TILE] uint32
@@ -1648,22 +1666,26 @@ OutCols out_cols(abacus_hod_state *st) {
     return o;
 }
 
-// packed records of an owned catalogue (static columns only), built once
+// packed records of an owned catalogue: built once; the random / hveldev fields rewritten after a reseed or an update
 int build_records(abacus_hod_state *st) {
     const bool norec = option("hod_norec") != 0;
-    if (!st->owns || norec || st->rec_ok) return 0;
+    if (!st->owns || norec || (st->rec_ok && st->rec_rand_ok)) return 0;
     ABACUS_TRY(st->hrec.reserve((size_t)std::max<int64_t>(st->nh, 1) * sizeof(HaloRec)));
     ABACUS_TRY(st->prec.reserve((size_t)std::max<int64_t>(st->np, 1) * sizeof(PartRec)));
     RecSrc c;
-    c.hpos = st->hpos, c.hvel = st->hvel, c.hmass = st->hmass, c.hmultis = st->hmultis, c.hdeltac = st->hdeltac,
-    c.hfenv = st->hfenv, c.hshear = st->hshear, c.hid = st->hid;
+    c.hpos = st->hpos, c.hvel = st->hvel, c.hvdev = st->hveldev, c.hmass = st->hmass, c.hmultis = st->hmultis,
+    c.hrandoms = st->hrandoms, c.hdeltac = st->hdeltac, c.hfenv = st->hfenv, c.hshear = st->hshear, c.hid = st->hid;
     c.ppos = st->ppos, c.pvel = st->pvel, c.phvel = st->phvel, c.phmass = st->phmass, c.pweights = st->pweights,
-    c.pdeltac = st->pdeltac, c.pfenv = st->pfenv, c.pshear = st->pshear, c.phid = st->phid;
+    c.prandoms = st->prandoms, c.pdeltac = st->pdeltac, c.pfenv = st->pfenv, c.pshear = st->pshear, c.phid = st->phid;
     c.pranks[0] = st->pranks, c.pranks[1] = st->pranksv, c.pranks[2] = st->pranksp, c.pranks[3] = st->pranksr;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(std::max(st->nh, st->np), 256), 1), 8192);
-    ABACUS_LAUNCH("hod_build_recs", hod_build_recs, dim3(grid), dim3(256), 0, st->nh, st->np, c, st->hrec.as<HaloRec>(),
-                  st->prec.as<PartRec>());
-    st->rec_ok = true;
+    if (!st->rec_ok)
+        ABACUS_LAUNCH("hod_build_recs", hod_build_recs<false>, dim3(grid), dim3(256), 0, st->nh, st->np, c, st->hrec.as<HaloRec>(),
+                      st->prec.as<PartRec>());
+    else
+        ABACUS_LAUNCH("hod_refresh_recs", hod_build_recs<true>, dim3(grid), dim3(256), 0, st->nh, st->np, c, st->hrec.as<HaloRec>(),
+                      st->prec.as<PartRec>());
+    st->rec_ok = st->rec_rand_ok = true;
     return 0;
 }
 
@@ -1692,8 +1714,9 @@ HodPtrs make_ptrs(const abacus_hod_state *st) {
     a.pranksp = st->pranksp, a.pranksr = st->pranksr, a.pinds = st->pinds;
     a.keep_c = st->keep_c, a.keep_s = st->keep_s, a.q_count = st->q_count, a.queue_c = st->queue_c,
     a.queue_s = st->queue_s, a.kept_c = st->kept_c, a.kept_s = st->kept_s, a.sb_counts = st->sb_counts;
-    a.hrec = st->rec_ok ? st->hrec.as<HaloRec>() : nullptr;
-    a.prec = st->rec_ok ? st->prec.as<PartRec>() : nullptr;
+    const bool rec = st->rec_ok && st->rec_rand_ok;   // stale randoms / hveldev in the records: gather from the columns
+    a.hrec = rec ? st->hrec.as<HaloRec>() : nullptr;
+    a.prec = rec ? st->prec.as<PartRec>() : nullptr;
     return a;
 }
 
@@ -1706,8 +1729,9 @@ int launch_emit(abacus_hod_state *st) {
     EmitPtrs in;
     in.hpos = st->hpos, in.hvel = st->hvel, in.hvdev = st->hveldev, in.hmass = st->hmass, in.hid = st->hid;
     in.ppos = st->ppos, in.pvel = st->pvel, in.phvel = st->phvel, in.phmass = st->phmass, in.phid = st->phid;
-    in.hrec = st->rec_ok ? st->hrec.as<HaloRec>() : nullptr;
-    in.prec = st->rec_ok ? st->prec.as<PartRec>() : nullptr;
+    const bool rec = st->rec_ok && st->rec_rand_ok;
+    in.hrec = rec ? st->hrec.as<HaloRec>() : nullptr;
+    in.prec = rec ? st->prec.as<PartRec>() : nullptr;
     ABACUS_LAUNCH("hod_emit", hod_emit, dim3(nemit), dim3(EBLOCK), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s,
                   st->sb_counts, st->d_totals, in, st->params, out_cols(st));
     return 0;
@@ -1905,6 +1929,7 @@ int abacus_hod_update(abacus_hod_state *st, const char *field, const double *hos
     HIP_TRY(hipStreamSynchronize(stream()));
     st->shadow_rand_ok = false;   // the float32 shadows of the randoms are rebuilt by the next populate
     st->keys_ok = false;          // ... and the packed filter keys
+    st->rec_rand_ok = false;      // ... and the random / hveldev fields of the packed records
     return 0;
 }
 
@@ -1943,6 +1968,7 @@ int abacus_hod_reseed(abacus_hod_state *st, uint64_t seed, int want_expvel, int6
     }
     st->shadow_rand_ok = false;
     st->keys_ok = false;
+    st->rec_rand_ok = false;
     return 0;
 }
 

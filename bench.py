@@ -89,7 +89,7 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     st.populate(p)
     _lib.profile_enable(False)
     stage_ms = sum(ms for k, (ms, n) in _lib.profile_get().items()
-                   if n and k in ('hod_shadow', 'hod_build_recs', 'hod_build_keys', 'hod_minmax', 'hod_check_pinds'))
+                   if n and k in ('hod_shadow', 'hod_build_recs', 'hod_refresh_recs', 'hod_build_keys', 'hod_minmax', 'hod_check_pinds'))
     _lib.profile_reset()
     _lib.profile_enable(True)
     for _ in range(max(args.warmup, 1)):  # steady-state kernel durations
