@@ -151,9 +151,10 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin(const float2 *__restrict
                 const int a0 = lane * RUN;
                 const int a1 = a0 + RUN + ((lane == 63 && xh == 0) ? 1 : 0);
                 int cur = -1, cur_bk = 0, cnt = 0;
-                float sp = 0.f, sk = 0.f, spole[NPC];
-#pragma unroll
-                for (int q = 0; q < NPC; q++) spole[q] = 0.f;
+                // the multipole sums of a run are kept as the MOMENTS sum w P, sum w P mu^2, sum w P mu^4; the Legendre
+                // combination (2l+1) P_l(mu) = c0 + c1 mu^2 + c2 mu^4 is formed once per flush instead of once per mode
+                // (four instructions per pair instead of twelve for two multipoles)
+                float sp = 0.f, sk = 0.f, s2 = 0.f, s4 = 0.f;
                 auto flush = [&]() {
                     if (cnt) {
                         atomicAdd(&h_cnt[cur], (unsigned int)cnt);
@@ -161,12 +162,12 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin(const float2 *__restrict
                         atomicAdd(&h_ksum[cur], (double)sk);
 #pragma unroll
                         for (int q = 0; q < NPC; q++)
-                            if (q < NP) atomicAdd(&h_pole[q * Nk + cur_bk], (double)spole[q]);
+                            if (q < NP)
+                                atomicAdd(&h_pole[q * Nk + cur_bk],
+                                          (double)pc[q][0] * (double)sp + (double)pc[q][1] * (double)s2 + (double)pc[q][2] * (double)s4);
                     }
                     cnt = 0;
-                    sp = sk = 0.f;
-#pragma unroll
-                    for (int q = 0; q < NPC; q++) spole[q] = 0.f;
+                    sp = sk = s2 = s4 = 0.f;
                 };
                 int a = a0;
                 int iabs = 2 * a + xh;
@@ -231,14 +232,11 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin(const float2 *__restrict
                         const float wp = wk * p;
                         sp += wp;
                         sk += (wk * (float)mult) * __builtin_amdgcn_sqrtf(kmag2);
-#pragma unroll
-                        for (int q = 0; q < NPC; q++)
-                            if (q < NP) {
-                                float Lq = pc[q][2];
-                                Lq = Lq * mu2 + pc[q][1];
-                                Lq = Lq * mu2 + pc[q][0];
-                                spole[q] += wp * Lq;
-                            }
+                        if (NP > 0) {
+                            const float m2 = wp * mu2;
+                            s2 += m2;
+                            s4 += m2 * mu2;
+                        }
                     }
                 }
                 flush();
