@@ -51,6 +51,29 @@ pos = (np.random.default_rng(2).random((5000, 3), dtype=np.float32) * 3 - 1) * n
 w = np.random.default_rng(3).random(5000, dtype=np.float32)
 rp, rw = c.route_particles(_lib.DeviceArray(pos), _lib.DeviceArray(w), 100.0)
 assert np.array_equal(rp.get(), pos) and np.array_equal(rw.get(), w)
+# the slab-decomposed P(k) through THIS communicator (device routing, ring exchange of the ghost planes, chunked
+# all-to-all on the communicator's stream, all-reduce of the histogram) against the single-GPU calc_power: the per-GPU
+# pipeline of BASELINE config 4, at 512^3 and at the full 2048^3 of the north star
+from abacusutils_amd.analysis.slab_power import HipSlabBackend, calc_power_slab
+from abacusutils_amd.analysis.power_spectrum import calc_power
+for nmesh, n in ((512, 3_000_000), (2048, 20_000_000)):
+    L = 2000.0
+    pos = np.random.default_rng(11).random((n, 3), dtype=np.float32) * np.float32(L)
+    pos[:, 0] -= np.float32(L / 2)                      # x outside [0, L): routing wraps it
+    kw = dict(kbins=min(256, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L, paste='TSC', nmesh=nmesh, compensated=True,
+              interlaced=(nmesh == 512), poles=[0, 2, 4])
+    dpos, _ = c.route_particles(_lib.DeviceArray(pos), None, L)
+    tab = calc_power_slab(dpos, L, comm=c, backend=HipSlabBackend(), n_total=n, **kw)
+    ref = calc_power(pos.copy(), L, **kw)
+    assert np.array_equal(np.asarray(tab['N_mode']), np.asarray(ref['N_mode'])), nmesh
+    ok = np.asarray(ref['N_mode']) > 0
+    rel = np.abs(np.asarray(tab['power'])[ok] / np.asarray(ref['power'])[ok] - 1).max()
+    scale = np.abs(np.asarray(ref['poles'])).max()
+    dpole = np.abs(np.asarray(tab['poles']) - np.asarray(ref['poles'])).max() / scale
+    assert rel < 1e-5 and dpole < 1e-5, (nmesh, rel, dpole)
+    dpos.free()
+    _lib.lib().abacus_power_release()
+    print('SLAB-OK', nmesh, rel, dpole)
 c.barrier()
 c.free()
 print('COMM-OK')
@@ -60,7 +83,7 @@ print('COMM-OK')
 def test_rccl_single_rank_collectives():
     import os
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', CODE % repo], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, '-c', CODE % repo], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'COMM-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 

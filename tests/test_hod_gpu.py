@@ -119,6 +119,28 @@ def test_full_size_c5_multi_tracer_bit_exact(G):
     assert_mock_equal(mock, want, exact=True)
 
 
+def test_c4_per_gpu_shard_bit_exact(G):
+    """BASELINE config 4 hands every GPU an eighth of 3e8 halos: 3.75e7 halos + 3.75e7 particles on ONE device (the keys,
+    queues, superblock counters and 64-bit offsets at that size; a filter stream of 0.3 GB), LRG + ELG with conformity,
+    against the CPU oracle: keep masks, counts and all columns bit-equal"""
+    from oracle import oracle
+    n = 37_500_000
+    hd, pd, params = synth.synth_hod_inputs(n, n, seed=604)
+    tracers = {'LRG': synth.LRG_PARAMS, 'ELG': dict(synth.ELG_PARAMS, logM1_EE=13.2, alpha_EE=0.9, logM1_EL=13.8, alpha_EL=1.1)}
+    st = G.StagedCatalog(hd, pd)
+    p = G.marshal_params(tracers, params, False, True)
+    ncent, nsat = st.populate(p)
+    kc, ks = st.fetch_keep()
+    mock = {tr: st.fetch(tr) for tr in tracers}
+    st.free()
+    want, wkc, wks = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=oracle.max_threads(), enable_ranks=False, rsd=True,
+                                        return_keep=True)
+    np.testing.assert_array_equal(kc, wkc)
+    np.testing.assert_array_equal(ks, wks)
+    assert ncent[0] > 100000 and ncent[1] > 1000000 and nsat[1] > 10000
+    assert_mock_equal(mock, want, exact=True)
+
+
 def test_capacity_growth_and_param_change(G):
     """first populate emits few galaxies, second many more than the catalog buffers hold: buffers grow, order kept"""
     from oracle import oracle
