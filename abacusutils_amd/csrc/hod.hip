@@ -21,6 +21,7 @@
 // random within ~1e-16 of its marker.
 #include <cmath>
 #include <cstring>
+#include <cstddef>
 #include <vector>
 
 #include "../../include/abacus_hip.h"
@@ -187,6 +188,7 @@ struct Filt {
     int sat_basic, pad_;   // finite parameters, alpha >= 0, A_s >= 0, ic >= 0 (what the envelope table needs)
     float L_lc, L_Ac, L_Bc, L_inv_s, L_ic;                      // centrals + LRG satellites share lc, sigma
     float E_lc, E_Ac, E_Bc, E_Cc, E_c_phi, E_half_inv_s2, E_ic;  // c_phi = max(2(pmax-1/Q),0) * 0.39894/sigma
+    float E_gs;                                                  // gamma / sigma / sqrt(2)
     float Q_lc, Q_Ac, Q_Bc, Q_inv_s, Q_ic;
     // satellites (only used when the tracer's 10**x values are particle independent, SatPre::*_const)
     float L_invM1, L_alpha, L_s[4];
@@ -195,14 +197,19 @@ struct Filt {
     double L_kMcut, E_kMcut, Q_kMcut;                            // kappa * M_cut
 };
 
-// upper bound of 0.5*erfc(t_true): t = num*inv_s with |num_true - num| <= dnum; erfc is decreasing
+// upper bound of 0.5*erfc(t_true): t = num*inv_s with |num_true - num| <= dnum; erfc is decreasing.
+// Abramowitz & Stegun 7.1.13, x >= 0:  1 / (x + sqrt(x^2 + 2)) < exp(x^2) int_x^inf exp(-t^2) dt <= 1 / (x + sqrt(x^2 + 4/pi)),
+// so 0.5 erfc(x) <= exp(-x^2) / (sqrt(pi) (x + sqrt(x^2 + 4/pi))) (exact at 0, 5 % high at 1, tighter further out) and
+// 0.5 erfc(-x) = 1 - 0.5 erfc(x) <= 1 - exp(-x^2) / (sqrt(pi) (x + sqrt(x^2 + 2))).  Hardware exp / sqrt / rcp (1 ulp) with slack.
 __device__ __forceinline__ float half_erfc_ub(float num, float dnum, float inv_s) {
     const float t = num * inv_s;
-    const float tl = t - (dnum * inv_s * 1.001f + fabsf(t) * 2e-6f);
-    // erfc(t) <= exp(-t^2) for t >= 0 and <= 2 always; hardware exp (v_exp_f32, 1 ulp) with slack
-    if (tl <= 0.f) return 1.0f;
-    if (tl >= 9.0f) return 4e-36f;   // 0.5*exp(-81) = 3.3e-36
-    return 0.5f * __expf(-(tl * tl) * 0.9999f) * 1.0002f;
+    const float tl = t - (dnum * fabsf(inv_s) * 1.001f + fabsf(t) * 2e-6f);
+    if (tl >= 9.0f) return 4e-36f;    // 0.5*exp(-81) / 32 = 1e-37
+    if (!(tl > -9.0f)) return 1.0f;   // also NaN
+    const float x = fabsf(tl), x2 = x * x;
+    if (tl >= 0.f)
+        return __expf(-x2 * 0.9999f) * (0.5641896f * 1.0003f) * __builtin_amdgcn_rcpf(x + __builtin_amdgcn_sqrtf(x2 + 1.2732395f));
+    return 1.0f - __expf(-x2 * 1.0001f) * (0.5641895f * 0.9997f) * __builtin_amdgcn_rcpf(x + __builtin_amdgcn_sqrtf(x2 + 2.0f));
 }
 
 // T = double: the staged float64 columns; T = float: their float32 shadows (mass rounded up, randoms rounded down,
@@ -227,7 +234,8 @@ __device__ __forceinline__ bool cent_reject(const abacus_hod_params &p, const Fi
         const float dn = 1e-6f * (fabsf(F.E_lc) + fabsf(a1) + fabsf(a2) + fabsf(a3) + fabsf(lM) + 4.f);
         const float dl = fmaxf(fabsf(lM - lc) - dn, 0.f);            // |logM - logM_cut| is at least this
         const float phi = F.E_c_phi * __expf(-(dl * dl) * F.E_half_inv_s2 * 0.9999f) * 1.0002f + 1e-37f;
-        U += phi * F.E_ic * mu;                                      // Phi <= 1
+        const float Phi = half_erfc_ub(lc - lM, dn, F.E_gs);         // 0.5 (1 + erf(y)) = 0.5 erfc(-y), y = gs (logM - logM_cut)
+        U += phi * Phi * F.E_ic * mu;
     }
     if (p.want_QSO) {  // 0.5*(1+erf(u)) = 0.5*erfc(-u)
         const float a1 = F.Q_Ac * d, a2 = F.Q_Bc * f;
@@ -242,12 +250,14 @@ __device__ __forceinline__ float pow_ub(float x, float alpha) {   // upper bound
     if (alpha == 1.0f) return x * 1.00001f;
     return powf(x, alpha) * (1.0002f + fabsf(alpha) * 4e-6f);
 }
+// upper bound of max(1 + s r + s_v r_v + s_p r_p + s_r r_r, 0): the value itself (float32 coefficients) plus its rounding
+// error; a negative factor makes the tracer's term negative, and the chain's largest marker is bounded by the positive terms
 template <class T>
 __device__ __forceinline__ float dec_ub(const float s[4], T r, T rv, T rp, T rr) {
-    return (1.f + fabsf(s[0] * (float)r) + fabsf(s[1] * (float)rv) + fabsf(s[2] * (float)rp) + fabsf(s[3] * (float)rr)) *
-           1.00001f;
+    const float t0 = s[0] * (float)r, t1 = s[1] * (float)rv, t2 = s[2] * (float)rp, t3 = s[3] * (float)rr;
+    const float v = (((1.f + t0) + t1) + t2) + t3;
+    return fmaxf(v + 2e-6f * (1.f + fabsf(t0) + fabsf(t1) + fabsf(t2) + fabsf(t3)), 0.f) * 1.00001f;
 }
-
 template <class T>
 __device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Filt &F, T hmass, T weights, T randoms, T r,
                                            T rv, T rp, T rr, int8_t keep_cent) {
@@ -300,33 +310,39 @@ __device__ __forceinline__ bool sat_reject(const abacus_hod_params &p, const Fil
 constexpr int FBLOCK = 256;
 
 // All device pointers of the staged catalogue + work arrays, passed by value to the fused kernels
-// Packed per-object records (owned catalogues), laid out by 64-B LINE: line A holds exactly what hod_exact reads for a
-// candidate (mass, multiplicity / weight, the random, environment; for particles the first two ranks), the following
-// line(s) what only hod_emit needs (position, velocities, the halo's velocity deviate), so a candidate costs ONE line and
-// a galaxy two - five arrays in five pages otherwise (the column gathers were 27 + 26 us at C2, records 20 + 20; with the
-// random and hveldev in separate columns the dense multi-tracer mix still paid three to four lines per candidate).
-// The random and hveldev change with a reseed / update: those fields are rewritten then (hod_refresh_recs), the rest is
-// built once.  Absent optional columns are stored as the value the exact chain substitutes for them (0, ranks 1).
+// Packed per-object records (owned catalogues), laid out by 128-B LINE - the granularity the memory system fetches at:
+// scripts/ubench/gather.hip reads 64 B or 128 B of a sparse, ascending subset of 128-B records at the same 4.7e10 records/s
+// (= 6 TB/s of whole lines) whatever the density, and 3.1e10 /s when a 128-B read straddles two lines.  The kernels of a
+// dense tracer mix are bound by exactly that - lines touched per candidate / galaxy:
+//   halo      one line: what hod_exact reads for a candidate (mass, multiplicity, the random, environment) AND what hod_emit
+//             reads for a galaxy (id, position, velocity, the halo's velocity deviate);
+//   particle  line 0 = everything hod_exact reads (host mass, weight, random, environment, the four ranks, and the host
+//             halo's index `pinds` for the conformity look-up), line 1 = everything hod_emit reads.
+// (With 64-B "lines" a particle was 192 B: 1.5 memory lines per candidate, 1.5 per galaxy, plus one for pinds[i]; five
+// arrays in five pages before that.)  The random and hveldev change with a reseed / update: those fields are rewritten
+// then (hod_refresh_recs), the rest is built once.  Absent optional columns are stored as the value the exact chain
+// substitutes for them (0, ranks 1, pinds -1).
 struct __attribute__((aligned(128))) HaloRec {
-    double mass, multis, rnd, deltac, fenv, shear;   // line A
+    double mass, multis, rnd, deltac, fenv, shear;
     long long id;
     double pos0;
-    double pos1, pos2, vel[3], vdev[3];              // line B
+    double pos1, pos2, vel[3], vdev[3];
 };
-struct __attribute__((aligned(64))) PartRec {
-    double mass, weights, rnd, deltac, fenv, shear, rank0, rank1;   // line A
-    double rank2, rank3;                                            // line B
-    long long id;
-    double mass2, pos[3], vel0;
-    double vel1, vel2, hvel[3], pad[3];                             // line C
+struct __attribute__((aligned(128))) PartRec {
+    double mass, weights, rnd, deltac, fenv, shear, rank0, rank1, rank2, rank3;   // line 0: decide
+    long long pinds;
+    double pad0[5];
+    long long id;                                                                 // line 1: emit
+    double mass2, pos[3], vel0, vel1, vel2, hvel[3];
+    double pad1[5];
 };
-static_assert(sizeof(HaloRec) == 128 && sizeof(PartRec) == 192, "record sizes");
+static_assert(sizeof(HaloRec) == 128 && sizeof(PartRec) == 256 && offsetof(PartRec, id) == 128, "record sizes");
 
 struct RecSrc {
     const double *hpos, *hvel, *hvdev, *hmass, *hmultis, *hrandoms, *hdeltac, *hfenv, *hshear;
     const int64_t *hid;
     const double *ppos, *pvel, *phvel, *phmass, *pweights, *prandoms, *pdeltac, *pfenv, *pshear, *pranks[4];
-    const int64_t *phid;
+    const int64_t *phid, *pinds;
 };
 // RAND_ONLY: rewrite just the fields a reseed / update changes (the random; the halo's velocity deviate)
 template <bool RAND_ONLY>
@@ -357,7 +373,8 @@ __global__ void hod_build_recs(int64_t nh, int64_t np, RecSrc c, HaloRec *__rest
         r.rank2 = c.pranks[2] ? c.pranks[2][i] : 1.0, r.rank3 = c.pranks[3] ? c.pranks[3][i] : 1.0;
         for (int d = 0; d < 3; d++) r.pos[d] = c.ppos[3 * i + d], r.hvel[d] = c.phvel[3 * i + d];
         r.vel0 = c.pvel[3 * i], r.vel1 = c.pvel[3 * i + 1], r.vel2 = c.pvel[3 * i + 2];
-        r.pad[0] = r.pad[1] = r.pad[2] = 0.0;
+        r.pinds = c.pinds ? c.pinds[i] : -1;
+        for (int d = 0; d < 5; d++) r.pad0[d] = r.pad1[d] = 0.0;
         prec[i] = r;
     }
 }
@@ -690,22 +707,18 @@ __global__ __launch_bounds__(256) void hod_build_keys(const double *__restrict__
 }
 
 constexpr int KEY_TILES = 4;   // tiles per workgroup of the key filter
-constexpr int KEY_Q1 = 2048;   // stage-1 survivors a workgroup lists for stage 2 (~80 expected at 1 % survival)
 
 // KIND: 0 = central tile groups, 1 = satellite tile groups, 2 = both (central groups first)
+// The table bound is the WHOLE filter here: its survivors go straight to the tiles' queue slices.  An arithmetic bound with
+// the object's own environment behind it (a second stage gathering the survivors' records) was measured and dropped: a
+// gather costs a 128-B line whatever it reads (scripts/ubench/gather.hip: 21 us per million lines), hod_exact pays the
+// same line plus ~35 us of classifier per million, so the second stage only wins where it removes more than 40 % of the
+// table's survivors - LRG alone: 2 % (56.3 vs 60.2 us per step without it); LRG + ELG + QSO with assembly bias: 42 % of the
+// halos, 53 % of the particles (354 vs 371 us).
 template <int KIND>
-__global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, const unsigned int *__restrict__ hkeys,
-                                                         const unsigned int *__restrict__ pkeys, int ngroup_c, int want_LRG,
-                                                         int want_ELG, int want_QSO, int enable_ranks, int need_env, int need_shear,
-                                                         Filt F, Cheap ch) {
-    // survivors of the table bound of ALL the workgroup's tiles go to one list (tile << 11 | index in tile), so that the
-    // arithmetic bound of stage 2 - gathers from the float32 shadows: one memory round trip - runs once per workgroup and not
-    // once per tile (per tile it was four dependent round trips: 38 us at 1e7 + 1e7, latency-bound at 2.6 TB/s)
-    // The final survivors are written straight into the tiles' global queue slices (a few thousand 2-byte stores per
-    // launch); the stage-1 list holds KEY_Q1 entries, the rare overflow skips stage 2 (which only ever removes candidates):
-    // 5 KB of LDS per workgroup instead of 34 KB, so eight workgroups per CU hide each other's round trips.
-    __shared__ int nq1, nq[KEY_TILES];
-    __shared__ unsigned short q1[KEY_Q1];
+__global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, const unsigned int *__restrict__ hkeys,
+                                                         const unsigned int *__restrict__ pkeys, int ngroup_c, Cheap ch) {
+    __shared__ int nq[KEY_TILES];
     __shared__ float tab[256];
     const int tid = threadIdx.x;
     const bool SAT = KIND == 2 ? (int)blockIdx.x >= ngroup_c : KIND == 1;
@@ -715,16 +728,12 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
         const float v = tid < CH_NLEV ? (SAT ? ch.Bs[tid] : ch.Bc[tid]) * dec * 1.0001f : INFINITY;
         tab[tid] = v;
     }
-    if (tid == 0) nq1 = 0;
     if (tid < KEY_TILES) nq[tid] = 0;
     const int ntile = SAT ? a.ntile_s : a.ntile_c;
     const int64_t n = SAT ? a.np : a.nh;
     const unsigned int *keys = SAT ? pkeys : hkeys;
     int8_t *keep = SAT ? a.keep_s : a.keep_c;
     unsigned short *queue = SAT ? a.queue_s : a.queue_c;
-    abacus_hod_params pw;
-    pw.want_LRG = want_LRG, pw.want_ELG = want_ELG, pw.want_QSO = want_QSO, pw.enable_ranks = enable_ranks;
-    const bool need_conf = SAT && want_ELG && a.pinds != nullptr;
     // all key loads of the workgroup's tiles first: 2 x 16 B per thread and tile (the key array is padded to whole tiles)
     uint4 k[KEY_TILES][2];
     const int t_first = G * KEY_TILES;
@@ -738,7 +747,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
         }
     }
     __syncthreads();            // the table and the zeroed counters
-    // ---- stage 1: one LDS table look-up and one compare per object ----
+    // one LDS table look-up and one compare per object
 #pragma unroll
     for (int t = 0; t < KEY_TILES; t++) {
         if (t_first + t >= ntile) break;      // uniform
@@ -751,11 +760,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
             for (int u = 0; u < 4; u++) {
                 if (u >= lim) continue;
                 const float qv = __uint_as_float(kk[u] & 0xffffff00u);
-                if (!(qv > tab[kk[u] & 255u])) {
-                    const int slot = atomicAdd(&nq1, 1);
-                    if (slot < KEY_Q1) q1[slot] = (unsigned short)((t << 11) | (loc + u));
-                    else queue[base0 + (int64_t)t * TILE + atomicAdd(&nq[t], 1)] = (unsigned short)(loc + u);   // list full: unfiltered
-                }
+                if (!(qv > tab[kk[u] & 255u])) queue[base0 + (int64_t)t * TILE + atomicAdd(&nq[t], 1)] = (unsigned short)(loc + u);
             }
         }
     }
@@ -769,29 +774,6 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, FiltCols c, 
                 for (int q8 = 0; q8 < 8; q8++)
                     if (o + q8 < n) keep[o + q8] = 0;
         }
-    }
-    __syncthreads();
-    // ---- stage 2: the arithmetic bound with the object's own environment / ranks, for the survivors of all tiles ----
-    const int n1 = min(nq1, KEY_Q1);
-    const bool dense = nq1 > KEY_TILES * TILE / 8;
-    for (int e = tid; e < n1; e += FBLOCK) {
-        const int code = q1[e], t = code >> 11, loc = code & (TILE - 1);
-        const int64_t i = base0 + (int64_t)t * TILE + loc;
-        bool rej = false;
-        if (dense) {
-            // more than an eighth of the objects survived the table: a dense tracer mix, where the arithmetic bound removes
-            // next to nothing (it bounds the same occupations) and its gathers cost more than the few extra exact evaluations
-        } else if (!SAT) {
-            const float d = need_env && c.hdeltac ? c.hdeltac[i] : 0.f, f = need_env && c.hfenv ? c.hfenv[i] : 0.f,
-                        sh = need_shear && c.hshear ? c.hshear[i] : 0.f;
-            rej = cent_reject<float>(pw, F, c.hmass[i], c.hmultis[i], c.hrandoms[i], d, f, sh);
-        } else if (F.sat_ok) {
-            const float r0 = enable_ranks ? c.pranks[i] : 1.f, r1 = enable_ranks ? c.pranksv[i] : 1.f,
-                        r2 = enable_ranks ? c.pranksp[i] : 1.f, r3 = enable_ranks ? c.pranksr[i] : 1.f;
-            rej = sat_reject<float>(pw, F, c.phmass[i], c.pweights[i], c.prandoms[i], r0, r1, r2, r3,
-                                    need_conf ? (int8_t)-1 : (int8_t)0);
-        }
-        if (!rej) queue[base0 + (int64_t)t * TILE + atomicAdd(&nq[t], 1)] = (unsigned short)loc;
     }
     __syncthreads();
     if (tid < KEY_TILES && t_first + tid < ntile) a.q_count[(SAT ? a.ntile_c : 0) + t_first + tid] = nq[tid];   // global tile id
@@ -819,10 +801,8 @@ __device__ __noinline__ int sat_decide_cold(const abacus_hod_params *p, const Sa
 struct ExactLds {
     int pre[SB_TILES + 1];
     unsigned int bm[3][SB_WORDS];
-    unsigned long long wave_tot[FBLOCK / 64];
+    unsigned long long wave_tot[8];
 };
-constexpr int WORDS_PER_THREAD = SB_WORDS / FBLOCK;   // 4
-static_assert(SB_WORDS % FBLOCK == 0, "bitmap words must divide over the workgroup");
 
 __device__ __forceinline__ int exact_find_tile(const ExactLds &L, int j) {   // largest q with pre[q] <= j
     int lo = 0, hi = SB_TILES - 1;
@@ -836,8 +816,41 @@ __device__ __forceinline__ int exact_find_tile(const ExactLds &L, int j) {   // 
 
 // One launch for the central superblocks (global superblock id < nsb_c) and the satellite ones; `first_sb` splits
 // it when the satellites depend on the exact central decisions (ELG conformity).
-__global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre,
-                                                    abacus_cls::ClsConst cc, int use_cls) {
+// PIPE (dense tracer mixes: thousands of candidates per superblock, a dozen per thread): the record of the thread's next
+// candidate and the queue entry of the one after it are requested before the current candidate is classified, so the
+// memory round trips (queue entry -> record line -> conformity byte) run under the classifier's ~1000 instructions instead
+// of in front of them.  It costs ~40 registers, which a sparse mix (LRG alone: less than one candidate per thread, twice
+// as many resident workgroups) would pay for nothing.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void aload16(v4u &dst, const void *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void aload_u16(unsigned int &dst, const void *p) {
+    asm volatile("global_load_ushort %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void aload_i8(int &dst, const void *p) {
+    asm volatile("global_load_sbyte %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int K>
+__device__ __forceinline__ void await_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
+}
+// tie registers to the wait above them: their uses cannot be scheduled before it
+__device__ __forceinline__ void touch4(v4u &a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void touch1(unsigned int &a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void touch1i(int &a) { asm volatile("" : "+v"(a)); }
+
+struct ExactCand {
+    double mass, w, rnd, dc, fe, sh, r0, r1, r2, r3;
+    long long pinds;
+    int q, loc;
+};
+
+template <int XB, bool PIPE>
+__global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre,
+                                                abacus_cls::ClsConst cc, int use_cls) {
+    constexpr int WORDS_PER_THREAD = SB_WORDS / XB;
+    static_assert(SB_WORDS % XB == 0 && XB <= 512, "bitmap words must divide over the workgroup");
     __shared__ ExactLds L;
     __shared__ abacus_hod_params s_p;     // read by the out-of-line float64 chains
     __shared__ SatPre s_pre;
@@ -859,7 +872,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, aba
     }
     if (tid == 0) L.pre[0] = 0;
 #pragma unroll
-    for (int w = 0; w < 3 * WORDS_PER_THREAD; w++) (&L.bm[0][0])[w * FBLOCK + tid] = 0u;
+    for (int w = 0; w < 3 * WORDS_PER_THREAD; w++) (&L.bm[0][0])[w * XB + tid] = 0u;
     __syncthreads();
     if (tid == 0)
         for (int q = 1; q <= SB_TILES; q++) L.pre[q] += L.pre[q - 1];
@@ -867,46 +880,154 @@ __global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, aba
     const int total = L.pre[SB_TILES];
     const bool need_conf = sat && p.want_ELG && a.pinds != nullptr;
     const bool need_ranks = p.enable_ranks != 0;
-    for (int j = tid; j < total; j += FBLOCK) {
-        const int q = exact_find_tile(L, j);
-        const int64_t t0 = (int64_t)(tile_first + q) * TILE;
-        const int loc = (sat ? a.queue_s : a.queue_c)[t0 + (j - L.pre[q])];
-        const int64_t i = t0 + loc;
-        double mass, w, rnd, dc, fe, sh, r0 = 1.0, r1 = 1.0, r2 = 1.0, r3 = 1.0;
-        int kc = 0;
+    const unsigned short *queue = sat ? a.queue_s : a.queue_c;
+    // tile and tile-local index of the superblock's j-th candidate
+    auto locate = [&](int j, int &q, int &loc) {
+        q = exact_find_tile(L, j);
+        loc = queue[(int64_t)(tile_first + q) * TILE + (j - L.pre[q])];
+    };
+    // the candidate's scalars: one record line, or the staged columns (caller-owned catalogues)
+    auto fetch = [&](int q, int loc, ExactCand &c) {
+        c.q = q, c.loc = loc;
+        const int64_t i = (int64_t)(tile_first + q) * TILE + loc;
+        c.r0 = c.r1 = c.r2 = c.r3 = 1.0;
+        c.pinds = 0;
         if (!sat) {
             if (a.hrec) {
-                const HaloRec &r = a.hrec[i];   // line A only
-                mass = r.mass, w = r.multis, rnd = r.rnd, dc = r.deltac, fe = r.fenv, sh = p.want_ELG ? r.shear : 0.0;
+                const HaloRec &r = a.hrec[i];
+                c.mass = r.mass, c.w = r.multis, c.rnd = r.rnd, c.dc = r.deltac, c.fe = r.fenv, c.sh = p.want_ELG ? r.shear : 0.0;
             } else {
-                rnd = a.hrandoms[i];
-                mass = a.hmass[i], w = a.hmultis[i], dc = load1(a.hdeltac, i, 0.0), fe = load1(a.hfenv, i, 0.0),
-                sh = p.want_ELG ? load1(a.hshear, i, 0.0) : 0.0;
+                c.rnd = a.hrandoms[i];
+                c.mass = a.hmass[i], c.w = a.hmultis[i], c.dc = load1(a.hdeltac, i, 0.0), c.fe = load1(a.hfenv, i, 0.0),
+                c.sh = p.want_ELG ? load1(a.hshear, i, 0.0) : 0.0;
             }
         } else {
-            kc = need_conf ? a.keep_c[a.pinds[i]] : 0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
             if (a.prec) {
-                const PartRec &r = a.prec[i];   // line A (+ the head of line B with ranks)
-                mass = r.mass, w = r.weights, rnd = r.rnd, dc = r.deltac, fe = r.fenv, sh = p.want_ELG ? r.shear : 0.0;
-                if (need_ranks) r0 = r.rank0, r1 = r.rank1, r2 = r.rank2, r3 = r.rank3;
+                const PartRec &r = a.prec[i];   // line 0
+                c.mass = r.mass, c.w = r.weights, c.rnd = r.rnd, c.dc = r.deltac, c.fe = r.fenv, c.sh = p.want_ELG ? r.shear : 0.0;
+                if (need_ranks) c.r0 = r.rank0, c.r1 = r.rank1, c.r2 = r.rank2, c.r3 = r.rank3;
+                if (need_conf) c.pinds = r.pinds;
             } else {
-                rnd = a.prandoms[i];
-                mass = a.phmass[i], w = a.pweights[i], dc = load1(a.pdeltac, i, 0.0), fe = load1(a.pfenv, i, 0.0),
-                sh = p.want_ELG ? load1(a.pshear, i, 0.0) : 0.0;
-                if (need_ranks) r0 = a.pranks[i], r1 = a.pranksv[i], r2 = a.pranksp[i], r3 = a.pranksr[i];
+                if (need_conf) c.pinds = a.pinds[i];
+                c.rnd = a.prandoms[i];
+                c.mass = a.phmass[i], c.w = a.pweights[i], c.dc = load1(a.pdeltac, i, 0.0), c.fe = load1(a.pfenv, i, 0.0),
+                c.sh = p.want_ELG ? load1(a.pshear, i, 0.0) : 0.0;
+                if (need_ranks) c.r0 = a.pranks[i], c.r1 = a.pranksv[i], c.r2 = a.pranksp[i], c.r3 = a.pranksr[i];
             }
         }
-        int kk = -1;
-        if (use_cls)
-            kk = sat ? abacus_cls::sat_classify(cc, mass, w, rnd, dc, fe, sh, r0, r1, r2, r3, kc)
-                     : abacus_cls::cent_classify(cc, mass, w, rnd, dc, fe, sh);
-        if (kk < 0)   // the random lies inside a marker's band (or the classifier is off): the reference's float64 chain
-            kk = sat ? sat_decide_cold(&s_p, &s_pre, mass, w, rnd, dc, fe, sh, r0, r1, r2, r3, kc)
-                     : cent_decide_cold(&s_p, mass, w, rnd, dc, fe, sh);
+    };
+    auto classify = [&](const ExactCand &c, int kc) {   // -1: the random lies inside a marker's band (or the classifier is off)
+        if (!use_cls) return -1;
+        return sat ? abacus_cls::sat_classify(cc, c.mass, c.w, c.rnd, c.dc, c.fe, c.sh, c.r0, c.r1, c.r2, c.r3, kc)
+                   : abacus_cls::cent_classify(cc, c.mass, c.w, c.rnd, c.dc, c.fe, c.sh);
+    };
+    auto exact_chain = [&](const ExactCand &c, int kc) {   // the reference's float64 chain (out of line)
+        return sat ? sat_decide_cold(&s_p, &s_pre, c.mass, c.w, c.rnd, c.dc, c.fe, c.sh, c.r0, c.r1, c.r2, c.r3, kc)
+                   : cent_decide_cold(&s_p, c.mass, c.w, c.rnd, c.dc, c.fe, c.sh);
+    };
+    auto record = [&](const ExactCand &c, int kk) {
         if (kk) {
-            (sat ? a.keep_s : a.keep_c)[i] = (int8_t)kk;
-            const int ls = q * TILE + loc;
+            (sat ? a.keep_s : a.keep_c)[(int64_t)(tile_first + c.q) * TILE + c.loc] = (int8_t)kk;
+            const int ls = c.q * TILE + c.loc;
             atomicOr(&L.bm[kk - 1][ls >> 5], 1u << (ls & 31));
+        }
+    };
+    if constexpr (!PIPE) {
+        for (int j = tid; j < total; j += XB) {
+            int q, loc;
+            locate(j, q, loc);
+            ExactCand c;
+            fetch(q, loc, c);
+            const int kc = need_conf ? a.keep_c[c.pinds] : 0;   // keep_cent[pinds[i]] (GRAND_HOD.py:1562)
+            int kk = classify(c, kc);
+            if (kk < 0) kk = exact_chain(c, kc);
+            record(c, kk);
+        }
+    } else {
+        // Records only (the host launches this variant for owned catalogues).  The loads of the pipeline are inline-asm loads
+        // the compiler does not track, waited for by hand: left to the compiler, the address arithmetic of the candidate after
+        // next was hoisted above the classification and with it a vmcnt(0) that drained the prefetch before it could overlap.
+        // Lanes past their last candidate keep loading the superblock's last candidate (valid addresses, no extra branches).
+        const char *rec = sat ? reinterpret_cast<const char *>(a.prec) : reinterpret_cast<const char *>(a.hrec);
+        const int64_t rb = sat ? (int64_t)sizeof(PartRec) : (int64_t)sizeof(HaloRec);
+        auto queue_addr = [&](int jj, int &q) {
+            jj = min(jj, total - 1);
+            q = exact_find_tile(L, jj);
+            return queue + ((int64_t)(tile_first + q) * TILE + (jj - L.pre[q]));
+        };
+        auto rec_addr = [&](int q, int loc) { return rec + ((int64_t)(tile_first + q) * TILE + loc) * rb; };
+        auto decode = [&](const v4u (&r)[6], int q, int loc, ExactCand &c) {
+            auto dbl = [](unsigned int lo, unsigned int hi) { return __hiloint2double((int)hi, (int)lo); };
+            c.q = q, c.loc = loc;
+            c.mass = dbl(r[0].x, r[0].y), c.w = dbl(r[0].z, r[0].w), c.rnd = dbl(r[1].x, r[1].y), c.dc = dbl(r[1].z, r[1].w);
+            c.fe = dbl(r[2].x, r[2].y), c.sh = p.want_ELG ? dbl(r[2].z, r[2].w) : 0.0;
+            c.r0 = c.r1 = c.r2 = c.r3 = 1.0;
+            c.pinds = 0;
+            if (sat) {
+                if (need_ranks) c.r0 = dbl(r[3].x, r[3].y), c.r1 = dbl(r[3].z, r[3].w), c.r2 = dbl(r[4].x, r[4].y), c.r3 = dbl(r[4].z, r[4].w);
+                c.pinds = (long long)(((unsigned long long)r[5].y << 32) | r[5].x);
+            }
+        };
+        if (total > 0) {   // uniform
+            int j = tid;
+            int q0, q1, q2;
+            unsigned int loc0, loc1, loc2 = 0;
+            v4u raw[6];
+            aload_u16(loc0, queue_addr(j, q0));
+            aload_u16(loc1, queue_addr(j + XB, q1));
+            await_vm<0>();
+            touch1(loc0), touch1(loc1);
+            {
+                const char *r0 = rec_addr(q0, (int)loc0);
+#pragma unroll
+                for (int l = 0; l < 6; l++)
+                    if (l < 3 || sat) aload16(raw[l], r0 + 16 * l);
+            }
+            await_vm<0>();
+#pragma unroll
+            for (int l = 0; l < 6; l++)
+                if (l < 3 || sat) touch4(raw[l]);
+            ExactCand cur;
+            decode(raw, q0, (int)loc0, cur);
+            int kc = 0;
+            if (need_conf) {
+                aload_i8(kc, a.keep_c + cur.pinds);
+                await_vm<0>();
+                touch1i(kc);
+            }
+#pragma unroll 1
+            for (; j < total; j += XB) {
+                {   // the next candidate's record and the queue entry of the one after it: in flight during decide()
+                    const char *r1 = rec_addr(q1, (int)loc1);
+#pragma unroll
+                    for (int l = 0; l < 6; l++)
+                        if (l < 3 || sat) aload16(raw[l], r1 + 16 * l);
+                    aload_u16(loc2, queue_addr(j + 2 * XB, q2));
+                }
+                int kk = classify(cur, kc);
+                if (kk < 0) {
+                    // a function call saves and restores live registers around it: the prefetch must have landed first
+                    await_vm<0>();
+#pragma unroll
+                    for (int l = 0; l < 6; l++)
+                        if (l < 3 || sat) touch4(raw[l]);
+                    touch1(loc2);
+                    kk = exact_chain(cur, kc);
+                }
+                record(cur, kk);
+                await_vm<0>();
+#pragma unroll
+                for (int l = 0; l < 6; l++)
+                    if (l < 3 || sat) touch4(raw[l]);
+                touch1(loc2);
+                decode(raw, q1, (int)loc1, cur);
+                if (need_conf) {   // keep_cent[pinds]: 10 MB, cache-resident
+                    aload_i8(kc, a.keep_c + cur.pinds);
+                    await_vm<0>();
+                    touch1i(kc);
+                }
+                q1 = q2, loc1 = loc2;
+            }
         }
     }
     __syncthreads();
@@ -934,7 +1055,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_exact(HodPtrs a, int first_sb, aba
     __syncthreads();
     unsigned long long before = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < FBLOCK / 64; w++) {
+    for (int w = 0; w < XB / 64; w++) {
         if (w < wv) before += L.wave_tot[w];
         all += L.wave_tot[w];
     }
@@ -997,7 +1118,6 @@ __device__ __forceinline__ void emit_one(const abacus_hod_params &p, const OutCo
 // centrals||satellites land concatenated and fast_concatenate never runs); the rank inside the superblock is the
 // position in the kept list hod_exact wrote.  All lanes gather and emit: the only inputs are the counters, the kept
 // list and the kept rows.  Workgroups [0, nsb_c) handle centrals, the rest satellites.
-constexpr int EBLOCK = 256;
 
 __device__ __forceinline__ int64_t wave_sum(int64_t v) {
 #pragma unroll
@@ -1012,6 +1132,7 @@ struct EmitPtrs {
     const PartRec *prec;
 };
 
+template <int EBLOCK>
 __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const unsigned short *__restrict__ kept_c,
                                                    const unsigned short *__restrict__ kept_s,
                                                    const int *__restrict__ sb_counts, int64_t *__restrict__ totals,
@@ -1079,14 +1200,14 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
         double x, y, z, vx, vy, vz, m;
         int64_t id;
         if (!sat && in.hrec) {
-            const HaloRec &r = in.hrec[i];   // both lines
+            const HaloRec &r = in.hrec[i];
             x = r.pos0, y = r.pos1, z = r.pos2;
             vx = r.vel[0] + al * r.vdev[0];
             vy = r.vel[1] + al * r.vdev[1];
             vz = r.vel[2] + al * r.vdev[2];
             m = r.mass, id = r.id;
         } else if (sat && in.prec) {
-            const PartRec &r = in.prec[i];   // lines B and C
+            const PartRec &r = in.prec[i];   // line 1
             x = r.pos[0], y = r.pos[1], z = r.pos[2];
             vx = r.hvel[0] + al * (r.vel0 - r.hvel[0]);
             vy = r.hvel[1] + al * (r.vel1 - r.hvel[1]);
@@ -1485,13 +1606,14 @@ Filt make_filter(const abacus_hod_params &p, const SatPre &pre) {
     tracer(p.want_LRG, p.L_logM_cut, p.L_Acent, p.L_Bcent, 0, p.L_sigma, p.L_ic);
     tracer(p.want_ELG, p.E_logM_cut, p.E_Acent, p.E_Bcent, p.E_Ccent, p.E_sigma, p.E_ic);
     tracer(p.want_QSO, p.Q_logM_cut, p.Q_Acent, p.Q_Bcent, 0, p.Q_sigma, p.Q_ic);
-    if (p.want_ELG) ok = ok && finite(p.E_p_max) && finite(p.E_Q) && p.E_Q != 0;
+    if (p.want_ELG) ok = ok && finite(p.E_p_max) && finite(p.E_Q) && p.E_Q != 0 && finite(p.E_gamma);
     F.cent_ok = ok;
     F.L_lc = (float)p.L_logM_cut, F.L_Ac = (float)p.L_Acent, F.L_Bc = (float)p.L_Bcent;
     F.L_inv_s = (float)(1.0 / (1.41421356 * p.L_sigma)), F.L_ic = up(p.L_ic);
     F.E_lc = (float)p.E_logM_cut, F.E_Ac = (float)p.E_Acent, F.E_Bc = (float)p.E_Bcent, F.E_Cc = (float)p.E_Ccent;
     F.E_c_phi = up(std::max(2.0 * (p.E_p_max - 1.0 / p.E_Q), 0.0) * 0.3989422804014327 / p.E_sigma);
     F.E_half_inv_s2 = (float)(0.5 / (p.E_sigma * p.E_sigma)), F.E_ic = up(p.E_ic);
+    F.E_gs = (float)(p.E_gamma / p.E_sigma / 1.4142135623730951);
     F.Q_lc = (float)p.Q_logM_cut, F.Q_Ac = (float)p.Q_Acent, F.Q_Bc = (float)p.Q_Bcent;
     F.Q_inv_s = (float)(1.0 / (1.41421356 * p.Q_sigma)), F.Q_ic = up(p.Q_ic);
     // satellites: the arithmetic bound only when every wanted tracer has particle-independent M1 / M_cut (`sok`); the
@@ -1519,7 +1641,7 @@ Filt make_filter(const abacus_hod_params &p, const SatPre &pre) {
     const double Ls[4] = {p.L_s, p.L_s_v, p.L_s_p, p.L_s_r}, Es[4] = {p.E_s, p.E_s_v, p.E_s_p, p.E_s_r},
                  Qs[4] = {p.Q_s, p.Q_s_v, p.Q_s_p, p.Q_s_r};
     for (int q = 0; q < 4; q++) {
-        F.L_s[q] = up(std::fabs(Ls[q])), F.E_s[q] = up(std::fabs(Es[q])), F.Q_s[q] = up(std::fabs(Qs[q]));
+        F.L_s[q] = (float)Ls[q], F.E_s[q] = (float)Es[q], F.Q_s[q] = (float)Qs[q];
         if (p.enable_ranks) {
             const bool b = finite(Ls[q]) && finite(Es[q]) && finite(Qs[q]);
             F.sat_ok = F.sat_ok && b, F.sat_basic = F.sat_basic && b;
@@ -1677,6 +1799,7 @@ int build_records(abacus_hod_state *st) {
     c.hrandoms = st->hrandoms, c.hdeltac = st->hdeltac, c.hfenv = st->hfenv, c.hshear = st->hshear, c.hid = st->hid;
     c.ppos = st->ppos, c.pvel = st->pvel, c.phvel = st->phvel, c.phmass = st->phmass, c.pweights = st->pweights,
     c.prandoms = st->prandoms, c.pdeltac = st->pdeltac, c.pfenv = st->pfenv, c.pshear = st->pshear, c.phid = st->phid;
+    c.pinds = st->pinds;
     c.pranks[0] = st->pranks, c.pranks[1] = st->pranksv, c.pranks[2] = st->pranksp, c.pranks[3] = st->pranksr;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(std::max(st->nh, st->np), 256), 1), 8192);
     if (!st->rec_ok)
@@ -1732,8 +1855,16 @@ int launch_emit(abacus_hod_state *st) {
     const bool rec = st->rec_ok && st->rec_rand_ok;
     in.hrec = rec ? st->hrec.as<HaloRec>() : nullptr;
     in.prec = rec ? st->prec.as<PartRec>() : nullptr;
-    ABACUS_LAUNCH("hod_emit", hod_emit, dim3(nemit), dim3(EBLOCK), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s,
-                  st->sb_counts, st->d_totals, in, st->params, out_cols(st));
+    // workgroup size: 512 threads per superblock for the dense mixes (ELG / QSO: thousands of galaxies per superblock, 106 vs
+    // 115 us at LRG + ELG + QSO on 1e7 + 1e7), 256 for LRG alone (12 vs 20 us: the larger workgroups only cost launch time)
+    int eb = option("hod_eblock");
+    if (eb != 256 && eb != 512) eb = (st->params.want_ELG || st->params.want_QSO) ? 512 : 256;
+#define EMIT(EB)                                                                                                      \
+    ABACUS_LAUNCH("hod_emit", hod_emit<EB>, dim3(nemit), dim3(EB), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s,   \
+                  st->sb_counts, st->d_totals, in, st->params, out_cols(st))
+    if (eb == 256) EMIT(256);
+    else EMIT(512);
+#undef EMIT
     return 0;
 }
 
@@ -2029,7 +2160,7 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
                       p->want_QSO, p->enable_ranks, need_env, need_shear, F);
         abacus_cls::ClsConst cc;
         abacus_cls::make_cls_const(*p, pre, cc);
-        ABACUS_LAUNCH("hod_exact", hod_exact, dim3(st->nsb_c), dim3(FBLOCK), 0, a, 0, *p, pre, cc, 1);
+        ABACUS_LAUNCH("hod_exact", (hod_exact<256, false>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1);
     }
     ABACUS_TRY(launch_emit(st));
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
@@ -2161,9 +2292,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
         const unsigned int *hk = st->keys.as<unsigned int>(), *pk = hk + (int64_t)std::max(st->ntile_c, 1) * TILE;
         const bool kc = keyed && c2 && c0 == 0 && c1 == st->ntile_c && c1 > c0, ks = keyed && s2 && s0 == 0 && s1 == st->ntile_s && s1 > s0;
         const int gc = (int)ceil_div(st->ntile_c, KEY_TILES), gs = (int)ceil_div(st->ntile_s, KEY_TILES);
-#define FKEY(KIND, grid_)                                                                                              \
-    ABACUS_LAUNCH("hod_filter", (hod_filter_key<KIND>), dim3(grid_), dim3(FBLOCK), 0, a, fc, hk, pk, gc, p->want_LRG,  \
-                  p->want_ELG, p->want_QSO, p->enable_ranks, need_env, need_shear, F, cheap)
+#define FKEY(KIND, grid_) ABACUS_LAUNCH("hod_filter", (hod_filter_key<KIND>), dim3(grid_), dim3(FBLOCK), 0, a, hk, pk, gc, cheap)
         if (kc && ks) {
             FKEY(2, gc + gs);
             return 0;
@@ -2211,8 +2340,14 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     const bool nocls = option("hod_nocls") != 0;   // A/B: every candidate through the float64 chain
     abacus_cls::ClsConst cc;
     abacus_cls::make_cls_const(*p, pre, cc);
-#define EXACT(first, count) \
-    if ((count) > 0) ABACUS_LAUNCH("hod_exact", hod_exact, dim3(count), dim3(FBLOCK), 0, a, first, *p, pre, cc, nocls ? 0 : 1)
+    // software-pipelined candidate loop for the dense mixes (see hod_exact); `hod_pipe` = 1 / 2 forces it off / on (A/B)
+    const int pipe_opt = option("hod_pipe");
+    const bool pipe = a.hrec && a.prec && (pipe_opt == 2 || (pipe_opt != 1 && (p->want_ELG || p->want_QSO)));
+#define EXACT(first, count)                                                                                              \
+    if ((count) > 0) {                                                                                                   \
+        if (pipe) ABACUS_LAUNCH("hod_exact", (hod_exact<256, true>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1); \
+        else ABACUS_LAUNCH("hod_exact", (hod_exact<256, false>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1); \
+    }
     // the two-stage satellite filter bounds the conformity variants by their largest, so it does not wait for the exact
     // central decisions: one filter launch for both kinds, then the exact passes in order
     const bool filter_first = conf && use32 && cheap.s_ok;
@@ -2261,6 +2396,18 @@ int abacus_hod_counts(abacus_hod_state *st, int64_t counts[6]) {
         st->counts_valid = true;
     }
     if (counts) memcpy(counts, st->counts, sizeof st->counts);
+    return 0;
+}
+
+int abacus_hod_candidates(abacus_hod_state *st, int64_t out[2]) {
+    ABACUS_ENTER();
+    if (!st || !st->have_run || !out) return fail("abacus_hod_candidates: populate has not been called");
+    const int nt = st->ntile_c + st->ntile_s;
+    std::vector<int> q((size_t)std::max(nt, 1));
+    HIP_TRY(hipMemcpyAsync(q.data(), st->q_count, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    out[0] = out[1] = 0;
+    for (int t = 0; t < nt; t++) out[t >= st->ntile_c] += q[t];
     return 0;
 }
 

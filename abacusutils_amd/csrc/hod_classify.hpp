@@ -12,6 +12,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/abacus_hip.h"
 
@@ -38,6 +39,22 @@ struct Iv {
 constexpr float CLS_R = 2.5e-7f;     // outward slack per float32 operation (one rounding is 6e-8)
 constexpr float CLS_F = 1e-5f;       // relative slack of erfcf / expf / exp10f / powf results
 constexpr float CLS_TINY = 1e-36f;
+
+// exp / exp10 / log10 / pow: on the device the hardware's exp2 and log2 (v_exp_f32, v_log_f32: 1 ulp) instead of the ocml
+// library functions (25 - 100 instructions each: two thirds of the satellite classifier).  Relative errors, all inside the
+// slack the enclosures already carry: exp10(x) |x| 2.3e-7 + 1 ulp (|x| <= 17: 4e-6 of the 2e-5 allotted); exp(-a) a 1e-7
+// (a <= 87: 9e-6 of 2e-5); log10 1.5e-7 |l| absolute (1e-6 |l| allotted); pow(y, a) a |log2 y| 9e-8 (a |log2 y| 6.9e-7 allotted).
+#if defined(__HIP_DEVICE_COMPILE__)
+CLS_HD float cls_exp10(float x) { return __builtin_amdgcn_exp2f(x * 3.3219281f); }
+CLS_HD float cls_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950f); }
+CLS_HD float cls_log10(float x) { return __builtin_amdgcn_logf(x) * 0.30103000f; }
+CLS_HD float cls_pow(float y, float a) { return __builtin_amdgcn_exp2f(a * __builtin_amdgcn_logf(y)); }
+#else
+CLS_HD float cls_exp10(float x) { return exp10f(x); }
+CLS_HD float cls_exp(float x) { return expf(x); }
+CLS_HD float cls_log10(float x) { return log10f(x); }
+CLS_HD float cls_pow(float y, float a) { return powf(y, a); }
+#endif
 
 CLS_HD Iv iv(float lo, float hi) {
     Iv r;
@@ -67,18 +84,35 @@ CLS_HD Iv affine(float b, float A, double d, float B, double f, float C, double 
     return iv(v - e, v + e);
 }
 CLS_HD Iv ilog10(double M) {   // log10 of a positive float64; non-positive / NaN masses give a NaN band (-> exact path)
-    const float l = log10f((float)M);
+    const float l = cls_log10((float)M);
     const float e = fabsf(l) * 1e-6f + 2e-7f;
     return iv(l - e, l + e);
 }
+// The transcendental of an enclosure is evaluated ONCE, at the end that gives the upper value; the lower value follows
+// from a derivative bound over the (1e-6-wide) argument band - half the erfcf / exp10f / expf / powf calls, which are
+// most of the classifier's instructions.
+//
 // 0.5 * erfc(t), decreasing in t; `abs_slack`: absolute error of the reference's own float64 evaluation
-// (0 for the erfc form, 3e-16 for 0.5 * (1 + erf(u)))
+// (0 for the erfc form, 3e-16 for 0.5 * (1 + erf(u))).  Lower end: erfc(t.lo) - erfc(t.hi) = |erfc'(x)| (t.hi - t.lo)
+// for some x in the band, and |erfc'(x)| = 2/sqrt(pi) exp(-x^2) <= erfc(x) (2 max(x, 0) + 1.5) <= erfc(t.lo) (2 max(t.hi, 0) + 1.5)
+// (x >= 0: the Mills-ratio bound erfc(x) > 2/sqrt(pi) exp(-x^2) / (x + sqrt(x^2 + 2)); x < 0: erfc >= 1, |erfc'| <= 1.13)
 CLS_HD Iv half_erfc(Iv t, float abs_slack) {
-    const float hi = 0.5f * erfcf(t.lo), lo = 0.5f * erfcf(t.hi);
+    const float hi = 0.5f * erfcf(t.lo);
+    const float w = (t.hi - t.lo) * (1.f + 1e-6f) + CLS_TINY;
+    const float lo = hi * fmaxf(1.f - w * (2.f * fmaxf(t.hi, 0.f) + 1.5f), 0.f);
     return iv(fmaxf(lo * (1.f - CLS_F) - abs_slack - CLS_TINY, 0.f), hi * (1.f + CLS_F) + abs_slack + CLS_TINY);
 }
+// 10**x: 10**x.lo = 10**x.hi * 10**-(x.hi - x.lo) >= 10**x.hi * (1 - ln(10) (x.hi - x.lo))
 CLS_HD Iv iexp10(Iv x) {
-    return iv(exp10f(x.lo) * (1.f - 2.f * CLS_F), exp10f(x.hi) * (1.f + 2.f * CLS_F) + CLS_TINY);
+    const float hi = cls_exp10(x.hi);
+    const float w = (x.hi - x.lo) * (1.f + 1e-6f) + CLS_TINY;
+    return iv(hi * fmaxf(1.f - 2.302586f * w, 0.f) * (1.f - 2.f * CLS_F), hi * (1.f + 2.f * CLS_F) + CLS_TINY);
+}
+// exp(-a): a in [alo, ahi], 0 <= alo; exp(-ahi) = exp(-alo) exp(-(ahi - alo)) >= exp(-alo) (1 - (ahi - alo))
+CLS_HD Iv iexp_neg(float alo, float ahi) {
+    const float hi = cls_exp(-alo);
+    const float w = (ahi - alo) * (1.f + 1e-6f) + CLS_TINY;
+    return iv(hi * fmaxf(1.f - w, 0.f) * (1.f - 2.f * CLS_F), hi * (1.f + 2.f * CLS_F) + CLS_TINY);
 }
 CLS_HD Iv fconst(float c) { return iv(c - fabsf(c) * CLS_R, c + fabsf(c) * CLS_R); }   // a host-converted float64 constant
 
@@ -154,8 +188,7 @@ CLS_HD int cent_classify(const ClsConst &c, double mass, double multis, double r
         const Iv d = isub(lM, lc);
         const float alo = (d.lo <= 0.f && d.hi >= 0.f) ? 0.f : fminf(fabsf(d.lo), fabsf(d.hi)), ahi = fmaxf(fabsf(d.lo), fabsf(d.hi));
         const float h = c.E_h;
-        const Iv phi = iv(expf(-(ahi * ahi) * h * (1.f + 4.f * CLS_R)) * (1.f - CLS_F),
-                          expf(-(alo * alo) * h * (1.f - 4.f * CLS_R)) * (1.f + CLS_F) + CLS_TINY);
+        const Iv phi = iexp_neg((alo * alo) * h * (1.f - 4.f * CLS_R), (ahi * ahi) * h * (1.f + 4.f * CLS_R));
         const Iv y = iscale(d, c.E_gs);                              // gamma (logM - logM_cut) / sigma / sqrt(2)
         const Iv Phi = half_erfc(iv(-y.hi, -y.lo), 3e-16f);          // 0.5 (1 + erf(y)) = 0.5 erfc(-y)
         m2 = iadd(m1, imul(iscale(imul(phi, Phi), c.E_K), mu));
@@ -180,9 +213,16 @@ CLS_HD Iv plaw_iv(Iv M, float kappa, Iv Mcut, Iv M1, float alpha, int alpha_is_o
         ok = false;
         return iv(0.f, 0.f);
     }
-    // powf of a value known to 3e-7 with an exponent known to 6e-8: relative error alpha * 3e-7 + |ln y| * 6e-8 * alpha
-    const float s = 2.f * CLS_F + alpha * 1e-6f * (1.f + fabsf(logf(fmaxf(yhi, 1e-30f))));
-    return iv(x.lo < 0.f ? 0.f : powf(ylo, alpha) * (1.f - s), powf(yhi, alpha) * (1.f + s) + CLS_TINY);
+    // powf of a value known to 3e-7 with an exponent known to 6e-8: relative error alpha * 3e-7 + |ln y| * 6e-8 * alpha,
+    // |ln y| <= ln(2) (|binary exponent of y| + 1).  One powf, at yhi: ylo^alpha = yhi^alpha (1 - u)^alpha with
+    // u = 1 - ylo / yhi in [0, 1], and (1 - u)^alpha >= 1 - max(alpha, 1) u (Bernoulli for alpha >= 1; (1 - u)^alpha >= 1 - u below)
+    int e2;
+    (void)frexpf(fmaxf(yhi, 1e-30f), &e2);
+    const float s = 2.f * CLS_F + alpha * 1e-6f * (1.f + 0.6932f * (float)(abs(e2) + 1));
+    const float v = cls_pow(yhi, alpha);
+    if (x.lo < 0.f) return iv(0.f, v * (1.f + s) + CLS_TINY);
+    const float u = (yhi - ylo) / yhi * (1.f + 1e-6f) + 1e-7f;
+    return iv(v * fmaxf(1.f - fmaxf(alpha, 1.f) * u, 0.f) * (1.f - s), v * (1.f + s) + CLS_TINY);
 }
 
 CLS_HD Iv dec_iv(const float s[4], double r, double rv, double rp, double rr) {

@@ -190,6 +190,12 @@ class StagedCatalog:
         self.counts = np.array(counts[:], dtype=np.int64)
         return self.counts
 
+    def candidates(self):
+        """diagnostic: (halos, particles) the last populate's filter handed to the exact float64 decision"""
+        out = (C.c_int64 * 2)()
+        check(_lib.lib().abacus_hod_candidates(self._h, out))
+        return int(out[0]), int(out[1])
+
     def fetch(self, tracer):
         """device -> host copy of one tracer's catalog, in the reference's dict form (:1573-1589)"""
         t = TRACERS.index(tracer)

@@ -98,6 +98,8 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     ngal = int(np.sum(counts))
     _lib.profile_enable(False)
     warm = {k: ms / n for k, (ms, n) in _lib.profile_get().items() if n}
+    launches = {k: n / max(args.warmup, 1) for k, (ms, n) in _lib.profile_get().items() if n}
+    cand = st.candidates()
 
     # timed region: HIP events only around the dominant kernel (a pair of event records per launch costs a few
     # microseconds, which is not negligible against a 0.1-ms step); the other kernels' durations are the warm-up's
@@ -156,7 +158,10 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     step_bytes = bh * nh + bp * npart + 152.0 * ngal     # + gather 88 B and write 64 B per galaxy
     kern = dict(warm)
     kern.update({k: (ms / n) for k, (ms, n) in prof.items() if n})
-    out['kernels_ms'] = {k: round(v, 5) for k, v in kern.items()}
+    out['kernels_ms'] = {k: round(v, 5) for k, v in kern.items()}   # per launch
+    out['launches_per_step'] = launches
+    out['filter_candidates'] = {'halos': cand[0], 'particles': cand[1]}
+    out['galaxies'] = {'centrals': [int(c) for c in counts[:3]], 'satellites': [int(c) for c in counts[3:]]}
     out['stage_ms'] = round(stage_ms, 4)
     if dom_name:
         fbytes = bh * nh + bp * npart

@@ -164,6 +164,9 @@ int abacus_hod_populate(abacus_hod_state *st, const abacus_hod_params *p, int64_
 /* as above but enqueue only (no host sync, counts stay on the device until abacus_hod_counts) */
 int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p);
 int abacus_hod_counts(abacus_hod_state *st, int64_t counts[6]); /* syncs; re-runs emission if buffers grew */
+/* diagnostic: how many halos (out[0]) and particles (out[1]) the last populate's filter passed on to the exact
+ * float64 decision (no reference counterpart: the reference evaluates every object, hod/GRAND_HOD.py:210,954) */
+int abacus_hod_candidates(abacus_hod_state *st, int64_t out[2]);
 /* copy tracer t's catalog (x,y,z,vx,vy,vz,mass: float64; id: int64), each of length Ncent+Nsat, to the host */
 int abacus_hod_fetch(abacus_hod_state *st, int tracer, double *x, double *y, double *z, double *vx, double *vy,
                      double *vz, double *mass, int64_t *id);

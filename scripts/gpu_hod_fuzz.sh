@@ -1,8 +1,9 @@
 # one-off fuzz: many more seeds of tests/sweep.py than the test-suite runs, HIP vs oracle, bit-exact
 cd $GRAFT_REPO_ROOT
 make -s -C oracle
-timeout 3000 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -15
-import sys, time, numpy as np, torch
+mkdir -p gpurun_out/fuzz
+timeout 1100 python - <<'PY' 2> gpurun_out/fuzz/hod_fuzz.err
+import sys, time, numpy as np
 sys.path.insert(0, 'tests')
 from sweep import sweep_case
 from abacusutils_amd.hod import GRAND_HOD as G
@@ -27,5 +28,7 @@ for seed in range(S0, S0 + NS):
         bad += 1
         print('MISMATCH seed', seed, list(tracers), ranks, rsd, int((kc != wkc).sum()), int((ks != wks).sum()), flush=True)
     st.free()
+    if (seed - S0) % 50 == 49:
+        print('progress', seed - S0 + 1, 'of', NS, 'mismatching', bad, 'galaxies', ngal, round(time.time() - t0, 1), 's', flush=True)
 print("cases", NS, 'mismatching', bad, 'galaxies compared', ngal, 'seconds', round(time.time() - t0, 1))
 PY
