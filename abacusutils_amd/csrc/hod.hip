@@ -38,7 +38,10 @@ namespace {
 constexpr int TILE = 2048;    // objects per workgroup
 constexpr int BLOCK = 256;    // threads per workgroup (4 waves)
 constexpr int PER_THREAD = TILE / BLOCK;
-constexpr int SB_TILES = 8;                        // decide tiles per superblock (one exact / emit workgroup)
+#ifndef ABACUS_SB_TILES
+#define ABACUS_SB_TILES 8   // 4 measured: LRG alone 63 vs 55 us per step, LRG + ELG + QSO 316 vs 317
+#endif
+constexpr int SB_TILES = ABACUS_SB_TILES;         // decide tiles per superblock (one exact / emit workgroup)
 constexpr int SB_OBJ = SB_TILES * TILE;            // 32768 objects: an in-superblock index fits uint16
 constexpr int SB_WORDS = SB_OBJ / 32;              // words of one tracer's keep bitmap
 
@@ -1136,7 +1139,7 @@ template <int EBLOCK>
 __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const unsigned short *__restrict__ kept_c,
                                                    const unsigned short *__restrict__ kept_s,
                                                    const int *__restrict__ sb_counts, int64_t *__restrict__ totals,
-                                                   EmitPtrs in, abacus_hod_params p, OutCols o) {
+                                                   EmitPtrs in, abacus_hod_params p, OutCols o, int dbg) {
     __shared__ int64_t red[EBLOCK / 64][6];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int g = blockIdx.x;
@@ -1192,6 +1195,68 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
     const unsigned short *kept = (sat ? kept_s : kept_c) + (int64_t)S * SB_OBJ;
     const double a0 = sat ? p.L_alpha_s : p.L_alpha_c, a1 = sat ? p.E_alpha_s : p.E_alpha_c,
                  a2 = sat ? p.Q_alpha_s : p.Q_alpha_c;
+    if (in.hrec && in.prec && !(dbg & 3)) {
+        // Records: software pipeline with untracked loads (see hod_exact).  Written plainly, an iteration was three dependent
+        // waits - the kept index, the record line, and (vmcnt counts in order) the eight column stores of the iteration
+        // before, which the wait for the kept index drained.  Here the stores of galaxy k are issued, then the record of
+        // k + 1 and the kept index of k + 2 are requested, and one wait covers all of them: 103 -> 95 us at LRG + ELG + QSO
+        // (1.8e6 galaxies).  What remains is bandwidth: gather alone 58 us, stores alone 38 us - 234 MB of record lines in
+        // and 117 MB of columns out share the memory system at ~4 TB/s.
+        const char *rec = sat ? reinterpret_cast<const char *>(in.prec) + offsetof(PartRec, id) : reinterpret_cast<const char *>(in.hrec);
+        const int64_t rb = sat ? (int64_t)sizeof(PartRec) : (int64_t)sizeof(HaloRec);
+        // 16-B pieces of the line: halo [mass, multis] [id, pos0] [pos1, pos2] [vel0, vel1] [vel2, vdev0] [vdev1, vdev2];
+        // particle (line 1) [id, mass] [pos0, pos1] [pos2, vel0] [vel1, vel2] [hvel0, hvel1] [hvel2, -]
+        const int o1 = sat ? 16 : 48, o2 = sat ? 32 : 64, o3 = sat ? 48 : 80, o4 = sat ? 64 : 96, o5 = sat ? 80 : 112;
+        auto issue = [&](unsigned int k, v4u (&r)[6]) {
+            const char *q = rec + ((int64_t)S * SB_OBJ + k) * rb;
+            aload16(r[0], q), aload16(r[1], q + o1), aload16(r[2], q + o2), aload16(r[3], q + o3), aload16(r[4], q + o4),
+                aload16(r[5], q + o5);
+        };
+        auto dbl = [](unsigned int lo, unsigned int hi) { return __hiloint2double((int)hi, (int)lo); };
+        int e = tid;
+        if (e >= total) return;
+        unsigned int k0, k1, k2 = 0;
+        v4u r[6];
+        aload_u16(k0, kept + e);
+        aload_u16(k1, kept + min(e + EBLOCK, total - 1));
+        await_vm<0>();
+        touch1(k0), touch1(k1);
+        issue(k0, r);
+        await_vm<0>();
+#pragma unroll 1
+        for (;;) {
+#pragma unroll
+            for (int l = 0; l < 6; l++) touch4(r[l]);
+            const int t = e < m0 ? 0 : (e < m0 + m1 ? 1 : 2);
+            const int64_t j = t == 0 ? off0 + e : (t == 1 ? off1 + (e - m0) : off2 + (e - m0 - m1));
+            const double al = t == 0 ? a0 : (t == 1 ? a1 : a2);
+            double x, y, z, vx, vy, vz, m;
+            int64_t id;
+            if (!sat) {
+                m = dbl(r[0].x, r[0].y), id = (int64_t)(((unsigned long long)r[1].y << 32) | r[1].x);
+                x = dbl(r[1].z, r[1].w), y = dbl(r[2].x, r[2].y), z = dbl(r[2].z, r[2].w);
+                vx = dbl(r[3].x, r[3].y) + al * dbl(r[4].z, r[4].w);   // velocity bias (:301-305)
+                vy = dbl(r[3].z, r[3].w) + al * dbl(r[5].x, r[5].y);
+                vz = dbl(r[4].x, r[4].y) + al * dbl(r[5].z, r[5].w);
+            } else {
+                id = (int64_t)(((unsigned long long)r[0].y << 32) | r[0].x), m = dbl(r[0].z, r[0].w);
+                x = dbl(r[1].x, r[1].y), y = dbl(r[1].z, r[1].w), z = dbl(r[2].x, r[2].y);
+                const double h0 = dbl(r[4].x, r[4].y), h1 = dbl(r[4].z, r[4].w), h2 = dbl(r[5].x, r[5].y);
+                vx = h0 + al * (dbl(r[2].z, r[2].w) - h0);   // (:1136-1146)
+                vy = h1 + al * (dbl(r[3].x, r[3].y) - h1);
+                vz = h2 + al * (dbl(r[3].z, r[3].w) - h2);
+            }
+            emit_one(p, o, t, j, x, y, z, vx, vy, vz, m, id);
+            e += EBLOCK;
+            if (e >= total) break;
+            issue(k1, r);
+            aload_u16(k2, kept + min(e + EBLOCK, total - 1));
+            await_vm<0>();
+            touch1(k2);
+            k1 = k2;
+        }
+        return;
+    }
     for (int e = tid; e < total; e += EBLOCK) {
         const int t = e < m0 ? 0 : (e < m0 + m1 ? 1 : 2);
         const int64_t j = t == 0 ? off0 + e : (t == 1 ? off1 + (e - m0) : off2 + (e - m0 - m1));
@@ -1199,7 +1264,10 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
         const double al = t == 0 ? a0 : (t == 1 ? a1 : a2);
         double x, y, z, vx, vy, vz, m;
         int64_t id;
-        if (!sat && in.hrec) {
+        if (dbg & 2) {   // ablation: no gather
+            x = y = z = vx = vy = vz = m = (double)i;
+            id = i;
+        } else if (!sat && in.hrec) {
             const HaloRec &r = in.hrec[i];
             x = r.pos0, y = r.pos1, z = r.pos2;
             vx = r.vel[0] + al * r.vdev[0];
@@ -1227,6 +1295,10 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
             vz = in.phvel[3 * i + 2] + al * (in.pvel[3 * i + 2] - in.phvel[3 * i + 2]);
             m = in.phmass[i];
             id = in.phid[i];
+        }
+        if (dbg & 1) {   // ablation: no column stores (one conditional store keeps the gather alive)
+            if (x + y + z + vx + vy + vz + m == 1.2345e300 && id == 77) o.c[t][0][j] = x;
+            continue;
         }
         emit_one(p, o, t, j, x, y, z, vx, vy, vz, m, id);
     }
@@ -1861,7 +1933,7 @@ int launch_emit(abacus_hod_state *st) {
     if (eb != 256 && eb != 512) eb = (st->params.want_ELG || st->params.want_QSO) ? 512 : 256;
 #define EMIT(EB)                                                                                                      \
     ABACUS_LAUNCH("hod_emit", hod_emit<EB>, dim3(nemit), dim3(EB), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s,   \
-                  st->sb_counts, st->d_totals, in, st->params, out_cols(st))
+                  st->sb_counts, st->d_totals, in, st->params, out_cols(st), option("dbg"))
     if (eb == 256) EMIT(256);
     else EMIT(512);
 #undef EMIT

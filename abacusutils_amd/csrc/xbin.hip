@@ -41,7 +41,7 @@ struct XBinGeom {
     int n, kzlen, pitch_c;      // mesh size, n/2 + 1, complex row pitch
     float inv_size;             // f32(1/M)
     const float *W;             // (n,) compensation window or nullptr
-    int dbg;                    // 1: skip the transform, 2: skip the binning (ablation)
+    int dbg;                    // ablation: 1 skip the transform, 2 skip the binning, 4 no histogram atomics, 8 no LDS reads in the binning
 };
 
 template <int H, int C, int NP, bool COMP>
@@ -54,13 +54,13 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin(const float2 *__restrict
     constexpr int RUN = (H / 2) / 64;                     // values of |i| per lane
     extern __shared__ __align__(16) unsigned char smem[];
     const int nb = b.Nk * b.Nmu;
-    // LDS: [twiddles H][tile C x CP][sum f64 nb][ksum f64 nb][pole f64 NP*Nk][cnt u32 nb][kedges2][muedges2][W n]
+    // LDS: [twiddles H][tile C x CP][sum f64 nb][ksum f64 nb][mu^2 and mu^4 moments f64 2*Nk][cnt u32 nb][kedges2][muedges2][W n]
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float2 *lds = tw + H;
     double *h_sum = reinterpret_cast<double *>(lds + C * CP + 1);   // CP odd, C even: +1 keeps 16-B alignment irrelevant, 8-B holds
     double *h_ksum = h_sum + nb;
-    double *h_pole = h_ksum + nb;
-    unsigned int *h_cnt = reinterpret_cast<unsigned int *>(h_pole + (size_t)NP * b.Nk);
+    double *h_m2 = h_ksum + nb, *h_m4 = h_m2 + b.Nk;   // per k bin: sum w P mu^2, sum w P mu^4 (NP > 0)
+    unsigned int *h_cnt = reinterpret_cast<unsigned int *>(h_m4 + b.Nk);
     float *ke = reinterpret_cast<float *>(h_cnt + nb);
     float *me = ke + (b.Nk + 1);
     float *Wl = me + (b.Nmu + 1);
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin(const float2 *__restrict
         h_ksum[q] = 0.0;
         h_cnt[q] = 0u;
     }
-    for (int q = tid; q < NP * b.Nk; q += XB_THREADS) h_pole[q] = 0.0;
+    for (int q = tid; q < 2 * b.Nk; q += XB_THREADS) h_m2[q] = 0.0;
     for (int q = tid; q <= b.Nk; q += XB_THREADS) ke[q] = b.kedges2[q];
     for (int q = tid; q <= b.Nmu; q += XB_THREADS) me[q] = b.muedges2[q];
     if (COMP)
@@ -151,20 +151,20 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin(const float2 *__restrict
                 const int a0 = lane * RUN;
                 const int a1 = a0 + RUN + ((lane == 63 && xh == 0) ? 1 : 0);
                 int cur = -1, cur_bk = 0, cnt = 0;
-                // the multipole sums of a run are kept as the MOMENTS sum w P, sum w P mu^2, sum w P mu^4; the Legendre
-                // combination (2l+1) P_l(mu) = c0 + c1 mu^2 + c2 mu^4 is formed once per flush instead of once per mode
-                // (four instructions per pair instead of twelve for two multipoles)
+                // the multipoles are accumulated as MOMENTS - sum w P mu^2 and sum w P mu^4 per k bin, in the run and in the
+                // LDS histogram alike; the Legendre combination (2l+1) P_l(mu) = c0 + c1 mu^2 + c2 mu^4 is linear in them and
+                // is formed once per workgroup at the end (the flush of a run is 3 + 2 atomics and no float64 arithmetic:
+                // its issue slots are paid by the whole wave whenever one lane changes bin)
                 float sp = 0.f, sk = 0.f, s2 = 0.f, s4 = 0.f;
                 auto flush = [&]() {
-                    if (cnt) {
+                    if (cnt && !(g.dbg & 4)) {   // 4: ablation, no histogram atomics
                         atomicAdd(&h_cnt[cur], (unsigned int)cnt);
                         atomicAdd(&h_sum[cur], (double)sp);
                         atomicAdd(&h_ksum[cur], (double)sk);
-#pragma unroll
-                        for (int q = 0; q < NPC; q++)
-                            if (q < NP)
-                                atomicAdd(&h_pole[q * Nk + cur_bk],
-                                          (double)pc[q][0] * (double)sp + (double)pc[q][1] * (double)s2 + (double)pc[q][2] * (double)s4);
+                        if (NP > 0) {
+                            atomicAdd(&h_m2[cur_bk], (double)s2);
+                            atomicAdd(&h_m4[cur_bk], (double)s4);
+                        }
                     }
                     cnt = 0;
                     sp = sk = s2 = s4 = 0.f;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin(const float2 *__restrict
                         // the two modes with this |i|: positions fA = a and its mirror fB (one mode for i = 0 and i = n/2)
                         const int fA = a;
                         const int fB = xh ? H - 1 - a : (H - a) & (H - 1);
-                        float2 vA = col[padq(fA)];
+                        float2 vA = (g.dbg & 8) ? make_float2(1.f, (float)a) : col[padq(fA)];   // 8: ablation, no LDS reads
                         vA.x *= g.inv_size, vA.y *= g.inv_size;                // _normalize (:1058-1060)
                         if (COMP) {
                             const float scl = 1.0f / ((Wl[2 * fA + xh] * Wl[j]) * Wl[k]);   // (:1065-1069)
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin(const float2 *__restrict
                         float p = vA.x * vA.x + vA.y * vA.y;                   // get_raw_power (:726)
                         int mult = 1;
                         if (fB != fA) {
-                            float2 vB = col[padq(fB)];
+                            float2 vB = (g.dbg & 8) ? make_float2(1.f, (float)a) : col[padq(fB)];
                             vB.x *= g.inv_size, vB.y *= g.inv_size;
                             if (COMP) {
                                 const float scl = 1.0f / ((Wl[2 * fB + xh] * Wl[j]) * Wl[k]);
@@ -254,14 +254,24 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin(const float2 *__restrict
             atomicAdd(&b.g_sum[q], h_sum[q]);
             atomicAdd(&b.g_ksum[q], h_ksum[q]);
         }
-    for (int q = tid; q < NP * Nk; q += XB_THREADS)
-        if (h_pole[q] != 0.0) atomicAdd(&b.g_pole[q], h_pole[q]);
+    if (NP > 0)
+        for (int bk = tid; bk < Nk; bk += XB_THREADS) {
+            double s0 = 0.0;   // sum w P of the k bin over its mu bins
+            for (int m = 0; m < Nmu; m++) s0 += h_sum[bk * Nmu + m];
+            const double m2 = h_m2[bk], m4 = h_m4[bk];
+#pragma unroll
+            for (int q = 0; q < NPC; q++)
+                if (q < NP) {
+                    const double v = (double)pc[q][0] * s0 + (double)pc[q][1] * m2 + (double)pc[q][2] * m4;
+                    if (v != 0.0) atomicAdd(&b.g_pole[q * Nk + bk], v);
+                }
+        }
 }
 
 template <int H, int C>
 size_t xbin_lds_bytes(int n, int Nk, int Nmu, int Np, bool comp) {
     const size_t nb = (size_t)Nk * Nmu;
-    return (size_t)(H + C * colpitch_of<H>() + 1) * sizeof(float2) + nb * (8 + 8 + 4) + (size_t)Np * Nk * 8 +
+    return (size_t)(H + C * colpitch_of<H>() + 1) * sizeof(float2) + nb * (8 + 8 + 4) + (size_t)2 * Nk * 8 +
            (size_t)(Nk + 1 + Nmu + 1) * 4 + (comp ? (size_t)n * 4 : 0) + 16;
 }
 
