@@ -709,7 +709,10 @@ __global__ __launch_bounds__(256) void hod_build_keys(const double *__restrict__
     }
 }
 
-constexpr int KEY_TILES = 4;   // tiles per workgroup of the key filter
+#ifndef ABACUS_KEY_TILES
+#define ABACUS_KEY_TILES 4
+#endif
+constexpr int KEY_TILES = ABACUS_KEY_TILES;   // tiles per workgroup of the key filter
 
 // KIND: 0 = central tile groups, 1 = satellite tile groups, 2 = both (central groups first)
 // The table bound is the WHOLE filter here: its survivors go straight to the tiles' queue slices.  An arithmetic bound with
