@@ -38,12 +38,12 @@ namespace {
 constexpr int TILE = 2048;    // objects per workgroup
 constexpr int BLOCK = 256;    // threads per workgroup (4 waves)
 constexpr int PER_THREAD = TILE / BLOCK;
-#ifndef ABACUS_SB_TILES
-#define ABACUS_SB_TILES 8   // 4 measured: LRG alone 63 vs 55 us per step, LRG + ELG + QSO 316 vs 317
-#endif
-constexpr int SB_TILES = ABACUS_SB_TILES;         // decide tiles per superblock (one exact / emit workgroup)
-constexpr int SB_OBJ = SB_TILES * TILE;            // 32768 objects: an in-superblock index fits uint16
-constexpr int SB_WORDS = SB_OBJ / 32;              // words of one tracer's keep bitmap
+// Superblock = the tiles one hod_exact / hod_emit workgroup owns.  Chosen per populate (template parameter SBT): 16 tiles
+// for LRG alone (a hundred candidates per superblock: fewer, fatter workgroups - 51.8 us per step at 1e7 + 1e7 against 55.2
+// with 8 tiles and 55.7 with 32), 8 for mixes with ELG / QSO (thousands per superblock: 308 us against 380 with 16 and 316
+// with 4).  An in-superblock index fits uint16.
+constexpr int SB_TILES_SPARSE = 16, SB_TILES_DENSE = 8;
+constexpr int SB_TILES_MIN = 8, SB_TILES_MAX = 16;
 
 // ---- occupation functions (hod/GRAND_HOD.py:23-136) ------------------------------------------------------
 __device__ __forceinline__ double n_cen_LRG(double M_h, double logM_cut, double sigma) {
@@ -804,14 +804,16 @@ __device__ __noinline__ int sat_decide_cold(const abacus_hod_params *p, const Sa
 // one of three LDS bitmaps (one per tracer); a popcount scan of the bitmaps then yields every kept object's rank in
 // index order, and the workgroup writes the superblock's kept list (uint16 in-superblock indices, tracer-major,
 // ascending) plus its three counts.  hod_emit needs nothing else: no mask re-read, no per-tile counters.
+template <int SBT>
 struct ExactLds {
-    int pre[SB_TILES + 1];
-    unsigned int bm[3][SB_WORDS];
+    int pre[SBT + 1];
+    unsigned int bm[3][SBT * TILE / 32];
     unsigned long long wave_tot[8];
 };
 
-__device__ __forceinline__ int exact_find_tile(const ExactLds &L, int j) {   // largest q with pre[q] <= j
-    int lo = 0, hi = SB_TILES - 1;
+template <int SBT>
+__device__ __forceinline__ int exact_find_tile(const ExactLds<SBT> &L, int j) {   // largest q with pre[q] <= j
+    int lo = 0, hi = SBT - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (L.pre[mid] <= j) lo = mid;
@@ -852,12 +854,13 @@ struct ExactCand {
     int q, loc;
 };
 
-template <int XB, bool PIPE>
+template <int XB, bool PIPE, int SBT>
 __global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre,
                                                 abacus_cls::ClsConst cc, int use_cls) {
+    constexpr int SB_TILES = SBT, SB_OBJ = SBT * TILE, SB_WORDS = SB_OBJ / 32;
     constexpr int WORDS_PER_THREAD = SB_WORDS / XB;
-    static_assert(SB_WORDS % XB == 0 && XB <= 512, "bitmap words must divide over the workgroup");
-    __shared__ ExactLds L;
+    static_assert(SB_WORDS % XB == 0 && XB <= 512 && SB_OBJ <= 65536, "bitmap words must divide over the workgroup");
+    __shared__ ExactLds<SBT> L;
     __shared__ abacus_hod_params s_p;     // read by the out-of-line float64 chains
     __shared__ SatPre s_pre;
     const int tid = threadIdx.x;
@@ -1138,11 +1141,12 @@ struct EmitPtrs {
     const PartRec *prec;
 };
 
-template <int EBLOCK>
+template <int EBLOCK, int SBT>
 __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const unsigned short *__restrict__ kept_c,
                                                    const unsigned short *__restrict__ kept_s,
                                                    const int *__restrict__ sb_counts, int64_t *__restrict__ totals,
                                                    EmitPtrs in, abacus_hod_params p, OutCols o, int dbg) {
+    constexpr int SB_OBJ = SBT * TILE;
     __shared__ int64_t red[EBLOCK / 64][6];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int g = blockIdx.x;
@@ -1642,7 +1646,8 @@ struct abacus_hod_state {
     int *q_count = nullptr;                                  // [ntile_c + ntile_s] survivors of the float32 filter
     unsigned short *queue_c = nullptr, *queue_s = nullptr;   // tile-local indices, one TILE-sized slice per tile
     unsigned short *kept_c = nullptr, *kept_s = nullptr;     // kept lists, one SB_OBJ-sized slice per superblock
-    int nsb_c = 0, nsb_s = 0;
+    int nsb_c = 0, nsb_s = 0;   // superblocks of the current populate (sb_tiles tiles each)
+    int sb_tiles = SB_TILES_DENSE;
     int64_t *d_totals = nullptr;  // 6
     int64_t *h_totals = nullptr;  // pinned, 6
     // outputs
@@ -1918,6 +1923,15 @@ HodPtrs make_ptrs(const abacus_hod_state *st) {
     return a;
 }
 
+// superblock size of a populate: 16 tiles for LRG alone, 8 for the dense mixes (see SB_TILES_*)
+void set_superblocks(abacus_hod_state *st, const abacus_hod_params *p) {
+    int sbt = option("hod_sbtiles");
+    if (sbt != SB_TILES_DENSE && sbt != SB_TILES_SPARSE) sbt = (p->want_ELG || p->want_QSO) ? SB_TILES_DENSE : SB_TILES_SPARSE;
+    st->sb_tiles = sbt;
+    st->nsb_c = (int)ceil_div(st->ntile_c, sbt);
+    st->nsb_s = (int)ceil_div(st->ntile_s, sbt);
+}
+
 int launch_emit(abacus_hod_state *st) {
     const int nemit = st->nsb_c + st->nsb_s;
     if (nemit == 0) {
@@ -1934,11 +1948,14 @@ int launch_emit(abacus_hod_state *st) {
     // 115 us at LRG + ELG + QSO on 1e7 + 1e7), 256 for LRG alone (12 vs 20 us: the larger workgroups only cost launch time)
     int eb = option("hod_eblock");
     if (eb != 256 && eb != 512) eb = (st->params.want_ELG || st->params.want_QSO) ? 512 : 256;
-#define EMIT(EB)                                                                                                      \
-    ABACUS_LAUNCH("hod_emit", hod_emit<EB>, dim3(nemit), dim3(EB), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s,   \
+#define EMIT(EB, SBT)                                                                                                       \
+    ABACUS_LAUNCH("hod_emit", (hod_emit<EB, SBT>), dim3(nemit), dim3(EB), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s, \
                   st->sb_counts, st->d_totals, in, st->params, out_cols(st), option("dbg"))
-    if (eb == 256) EMIT(256);
-    else EMIT(512);
+    const bool sparse = st->sb_tiles == SB_TILES_SPARSE;
+    if (eb == 256 && sparse) EMIT(256, SB_TILES_SPARSE);
+    else if (eb == 256) EMIT(256, SB_TILES_DENSE);
+    else if (sparse) EMIT(512, SB_TILES_SPARSE);
+    else EMIT(512, SB_TILES_DENSE);
 #undef EMIT
     return 0;
 }
@@ -2069,15 +2086,16 @@ static int stage_fill(abacus_hod_state *st, const abacus_hod_arrays *a, int on_d
     const int64_t ntiles = (int64_t)st->ntile_c + st->ntile_s;
     HIP_TRY(hipMalloc((void **)&st->keep_c, nh > 0 ? nh + 64 : 64));
     HIP_TRY(hipMalloc((void **)&st->keep_s, np > 0 ? np + 64 : 64));
-    st->nsb_c = (int)ceil_div(st->ntile_c, SB_TILES);
-    st->nsb_s = (int)ceil_div(st->ntile_s, SB_TILES);
+    // counters and kept lists sized for either superblock size (the populate picks one, set_superblocks)
+    st->nsb_c = (int)ceil_div(st->ntile_c, SB_TILES_MIN);
+    st->nsb_s = (int)ceil_div(st->ntile_s, SB_TILES_MIN);
     HIP_TRY(hipMalloc((void **)&st->sb_counts, (size_t)(st->nsb_c + st->nsb_s + 1) * 4 * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&st->d_totals, 8 * sizeof(int64_t)));
     HIP_TRY(hipMalloc((void **)&st->q_count, (size_t)(ntiles > 0 ? ntiles : 1) * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&st->queue_c, (size_t)(st->ntile_c > 0 ? st->ntile_c : 1) * TILE * sizeof(unsigned short)));
     HIP_TRY(hipMalloc((void **)&st->queue_s, (size_t)(st->ntile_s > 0 ? st->ntile_s : 1) * TILE * sizeof(unsigned short)));
-    HIP_TRY(hipMalloc((void **)&st->kept_c, (size_t)(st->nsb_c > 0 ? st->nsb_c : 1) * SB_OBJ * sizeof(unsigned short)));
-    HIP_TRY(hipMalloc((void **)&st->kept_s, (size_t)(st->nsb_s > 0 ? st->nsb_s : 1) * SB_OBJ * sizeof(unsigned short)));
+    HIP_TRY(hipMalloc((void **)&st->kept_c, (size_t)(st->ntile_c + SB_TILES_MAX) * TILE * sizeof(unsigned short)));
+    HIP_TRY(hipMalloc((void **)&st->kept_s, (size_t)(st->ntile_s + SB_TILES_MAX) * TILE * sizeof(unsigned short)));
     HIP_TRY(hipHostMalloc((void **)&st->h_totals, 8 * sizeof(int64_t), hipHostMallocDefault));
     // first guess for the catalog buffers; grown on demand by abacus_hod_counts
     for (int t = 0; t < 3; t++) ABACUS_TRY(set_capacity(st, t, (nh + np) / 64));
@@ -2219,6 +2237,7 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
     Filt F = make_filter(*p, pre);
     HodPtrs a;
     memset(&a, 0, sizeof a);
+    set_superblocks(st, p);
     a.nh = st->nh, a.np = 0, a.ntile_c = st->ntile_c, a.ntile_s = 0, a.nsb_c = st->nsb_c, a.nsb_s = 0;
     a.hmass = st->hmass, a.hmultis = st->hmultis, a.hrandoms = st->hrandoms, a.hdeltac = st->hdeltac,
     a.hfenv = st->hfenv, a.hshear = st->hshear;
@@ -2235,7 +2254,10 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
                       p->want_QSO, p->enable_ranks, need_env, need_shear, F);
         abacus_cls::ClsConst cc;
         abacus_cls::make_cls_const(*p, pre, cc);
-        ABACUS_LAUNCH("hod_exact", (hod_exact<256, false>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1);
+        if (st->sb_tiles == SB_TILES_SPARSE)
+            ABACUS_LAUNCH("hod_exact", (hod_exact<256, false, SB_TILES_SPARSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1);
+        else
+            ABACUS_LAUNCH("hod_exact", (hod_exact<256, false, SB_TILES_DENSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1);
     }
     ABACUS_TRY(launch_emit(st));
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
@@ -2341,6 +2363,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
                          (p->want_QSO && (p->Q_Acent != 0 || p->Q_Bcent != 0));
     const int need_shear = p->want_ELG && p->E_Ccent != 0 && st->hshear != nullptr;
     ABACUS_TRY(build_records(st));
+    set_superblocks(st, p);
     const HodPtrs a = make_ptrs(st);
     const bool conf = p->want_ELG && st->pinds != nullptr && st->ntile_s > 0;   // satellites read keep_cent[pinds]
     const int ntile = st->ntile_c + st->ntile_s, nsb = st->nsb_c + st->nsb_s;
@@ -2418,10 +2441,15 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     // software-pipelined candidate loop for the dense mixes (see hod_exact); `hod_pipe` = 1 / 2 forces it off / on (A/B)
     const int pipe_opt = option("hod_pipe");
     const bool pipe = a.hrec && a.prec && (pipe_opt == 2 || (pipe_opt != 1 && (p->want_ELG || p->want_QSO)));
-#define EXACT(first, count)                                                                                              \
-    if ((count) > 0) {                                                                                                   \
-        if (pipe) ABACUS_LAUNCH("hod_exact", (hod_exact<256, true>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1); \
-        else ABACUS_LAUNCH("hod_exact", (hod_exact<256, false>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1); \
+    const bool sparse_sb = st->sb_tiles == SB_TILES_SPARSE;
+#define EXACT_(PIPE, SBT, first, count) \
+    ABACUS_LAUNCH("hod_exact", (hod_exact<256, PIPE, SBT>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1)
+#define EXACT(first, count)                                                    \
+    if ((count) > 0) {                                                         \
+        if (pipe && sparse_sb) EXACT_(true, SB_TILES_SPARSE, first, count);    \
+        else if (pipe) EXACT_(true, SB_TILES_DENSE, first, count);             \
+        else if (sparse_sb) EXACT_(false, SB_TILES_SPARSE, first, count);      \
+        else EXACT_(false, SB_TILES_DENSE, first, count);                      \
     }
     // the two-stage satellite filter bounds the conformity variants by their largest, so it does not wait for the exact
     // central decisions: one filter launch for both kinds, then the exact passes in order
@@ -2441,6 +2469,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     }
 #undef FILTER
 #undef EXACT
+#undef EXACT_
     // speculative emission into the current buffers (writes past capacity are suppressed on the device)
     ABACUS_TRY(launch_emit(st));
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
