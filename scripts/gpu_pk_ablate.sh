@@ -11,7 +11,7 @@ for spec in "$@"; do
     IFS=, read -ra kv <<< "${spec#*:}"
     for o in "${kv[@]}"; do opt_+=(--option "$o"); done
   fi
-  timeout 300 python bench.py --workload pk --nmesh 2048 --steps 4 --warmup 1 --no-cpu "${opt_[@]}" > "$O/pk_$mode.json" 2> "$O/pk_$mode.err" || { tail -3 "$O/pk_$mode.err"; exit 1; }
+  timeout 300 python bench.py --workload pk --nmesh ${NMESH:-2048} --steps 4 --warmup 1 --no-cpu "${opt_[@]}" > "$O/pk_$mode.json" 2> "$O/pk_$mode.err" || { tail -3 "$O/pk_$mode.err"; exit 1; }
   python - "$O/pk_$mode.json" "$mode" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
