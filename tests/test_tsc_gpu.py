@@ -160,6 +160,28 @@ def test_vs_oracle_sizes(n, ngrid):
     assert np.isclose(a.sum(dtype='f8'), w.sum(dtype='f8'), rtol=1e-6)
 
 
+@pytest.mark.parametrize('dt', ['f4', 'f8'])
+def test_multisplit_tile_corner_pile_up(dt, options):
+    """every particle sits on a corner shared by eight 16 x 16 x 32-cell tiles, so each is listed eight times: a
+    sub-chunk of the LDS-sorted scatter passes then holds five times the entries its buffer has room for (the overflow
+    goes straight to its place in HBM).  Against the oracle, and against the single-level list builder"""
+    from abacusutils_amd.analysis.tsc import tsc_parallel
+    from oracle import oracle
+    n, ng, box = 2_200_000, 256, 256.0
+    rng = np.random.default_rng(77)
+    corner = np.stack([rng.integers(0, ng // 16, n) * 16, rng.integers(0, ng // 16, n) * 16, rng.integers(0, ng // 32, n) * 32], axis=1)
+    pos = ((corner + rng.uniform(-0.4, 0.4, (n, 3))) % ng).astype(dt)      # cell size 1: within half a cell of the corner
+    w = rng.uniform(0.5, 1.5, n).astype(dt)
+    p1, p2 = pos.copy(), pos.copy()
+    a = tsc_parallel(p1, ng, box, weights=w)
+    b = oracle.tsc_parallel(p2, ng, box, weights=w, nthread=1)
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * float(b.max()))
+    assert np.isclose(a.sum(dtype='f8'), w.sum(dtype='f8'), rtol=1e-6)
+    options.set('tsc_atomic', 1)
+    c = tsc_parallel(pos.copy(), ng, box, weights=w)
+    assert np.abs(a - c).max() <= 4e-6 * float(a.max())
+
+
 def test_full_size_properties(options):
     """BASELINE config 3 size (1e8 particles, 1024^3 mesh): mass conservation (sum of the mesh = sum of the weights),
     every cell non-negative, and the two list builders (two-level multisplit vs single-level lists with per-tile atomic
