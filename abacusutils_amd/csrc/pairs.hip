@@ -362,10 +362,6 @@ constexpr int P3_WAVES = 4, P3_JCAP = 256, P3_ICAP = 64, P3_SLOTS = 64;
 template <int MODE>
 __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const Frame *__restrict__ frame, int ncell, int R,
                                                               unsigned long long *__restrict__ evaluated) {
-    __shared__ float ix[P3_WAVES][P3_ICAP], iy[P3_WAVES][P3_ICAP], iz[P3_WAVES][P3_ICAP];
-    __shared__ float jx[P3_WAVES][P3_JCAP], jy[P3_WAVES][P3_JCAP], jz[P3_WAVES][P3_JCAP];
-    __shared__ float jsx[P3_WAVES][P3_JCAP], jsy[P3_WAVES][P3_JCAP], jsz[P3_WAVES][P3_JCAP];   // per-point image shifts
-    __shared__ int jg[P3_WAVES][P3_JCAP], jc[P3_WAVES][P3_JCAP];
     __shared__ int64_t seg_j0[P3_WAVES][P3_SLOTS];
     __shared__ int seg_pre[P3_WAVES][P3_SLOTS + 1], seg_code[P3_WAVES][P3_SLOTS];   // exclusive prefix of the segment lengths
     __shared__ float e2[64];
@@ -490,25 +486,56 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
         wave_sync();
         for (int64_t i0 = cbeg; i0 < cend; i0 += P3_ICAP) {
             const int ni = (int)min((int64_t)P3_ICAP, cend - i0);
-            wave_sync();   // the previous slice's pairs are done with ix / iy / iz and the staging buffer
-            if (lane < ni) ix[w][lane] = a.x1[i0 + lane], iy[w][lane] = a.y1[i0 + lane], iz[w][lane] = a.z1[i0 + lane];
-            // a lane OWNS staged neighbour points (its registers hold their coordinates, image shifts and flags) and walks
-            // the few points of the cell's slice, read from LDS at a wave-uniform address: no index arithmetic per pair,
-            // three LDS reads per pair instead of eight
+            // lane l holds point l of the cell's slice; the pair loop broadcasts point i to the wave with v_readlane (a scalar
+            // register: no LDS read, nothing to wait for - PMC had the waves of the LDS-staged form parked in s_waitcnt for
+            // 54 % of their cycles at 4 waves per SIMD).  A lane OWNS neighbour points - in the registers it fetched them
+            // into - and walks the few points of the slice: no index arithmetic per pair.
+            float vix = 0.f, viy = 0.f, viz = 0.f;
+            if (lane < ni) vix = a.x1[i0 + lane], viy = a.y1[i0 + lane], viz = a.z1[i0 + lane];
             const int i0i = (int)i0;
-            auto process = [&](int fill) {
-                n_eval += (unsigned long long)ni * (unsigned long long)fill;
-                for (int jb = 0; jb < fill; jb += 64) {
-                    const int j = jb + lane;
-                    if (j >= fill) continue;
-                    const float xj = jx[w][j], yj = jy[w][j], zj = jz[w][j];
-                    const float sx = jsx[w][j], sy = jsy[w][j], sz = jsz[w][j];
-                    const int flags = jc[w][j];
-                    const int jself = (flags & 1024) ? jg[w][j] - i0i : 0x7fffffff;   // own cell: pairs with i < j - i0 only
+            for (int base = 0; base < M; base += P3_JCAP) {
+                const int cnt = min(P3_JCAP, M - base);
+                // every lane fetches its points of this round first (all loads in flight together)
+                float tx[P3_JCAP / 64], ty[P3_JCAP / 64], tz[P3_JCAP / 64];
+                int tg[P3_JCAP / 64], tc[P3_JCAP / 64];
+#pragma unroll
+                for (int u = 0; u < P3_JCAP / 64; u++) {
+                    const int q = u * 64 + lane;
+                    tg[u] = -1;
+                    tc[u] = 0;
+                    tx[u] = ty[u] = tz[u] = 0.f;
+                    if (q < cnt) {
+                        const int v = base + q;
+                        int lo = 0, hi = 63;             // largest slot with seg_pre <= v (empty slots repeat the prefix:
+                        while (lo < hi) {                //  the LAST of equal prefixes is the non-empty one)
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (seg_pre[w][mid] <= v) lo = mid;
+                            else hi = mid - 1;
+                        }
+                        const int64_t jj = seg_j0[w][lo] + (v - seg_pre[w][lo]);
+                        tx[u] = a.x2[jj], ty[u] = a.y2[jj], tz[u] = a.z2[jj];
+                        tg[u] = (int)jj, tc[u] = seg_code[w][lo];
+                    }
+                }
+                n_eval += (unsigned long long)ni * (unsigned long long)cnt;
+#pragma unroll
+                for (int u = 0; u < P3_JCAP / 64; u++) {
+                    if (u * 64 >= cnt) break;   // uniform
+                    const bool have = tg[u] >= 0;
+                    const float xj = tx[u], yj = ty[u], zj = tz[u];
+                    const int flags = tc[u];
+                    const float sx = (float)(2 - (flags & 7)) * a.g.box;          // -k L, k in {-2 .. 2}
+                    const float sy = (float)(2 - ((flags >> 3) & 7)) * a.g.box;
+                    const float sz = (float)(2 - ((flags >> 6) & 7)) * a.g.box;
+                    // own cell: pairs with i < j - i0 only (every unordered pair once, i ascending); no point: no pairs
+                    const int ilim = !have ? 0 : ((flags & 1024) ? min(tg[u] - i0i, ni) : ni);
                     const bool mixed = (flags & 512) != 0;
-                    for (int i = 0; i < ni; i++) {
-                        if (i >= jself) break;    // every unordered pair of the own cell once (i ascending)
-                        float dx = ix[w][i] - xj, dy = iy[w][i] - yj, dz = iz[w][i] - zj;
+                    for (int i = 0; i < ni; i++) {   // uniform trip count: readlane needs a wave-uniform index
+                        const float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vix), i));
+                        const float yi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(viy), i));
+                        const float zi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(viz), i));
+                        if (i >= ilim) continue;
+                        float dx = xi - xj, dy = yi - yj, dz = zi - zj;
                         if (mixed) {
                             dx = min_image(dx, a.half, a.g.box);
                             dy = min_image(dy, a.half, a.g.box);
@@ -541,42 +568,6 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
                         atomicAdd(&hist[b * a.nsub + sub], 1u);
                     }
                 }
-            };
-            for (int base = 0; base < M; base += P3_JCAP) {
-                const int cnt = min(P3_JCAP, M - base);
-                // every lane fetches its points of this round first (all loads in flight together), then stages them
-                float tx[P3_JCAP / 64], ty[P3_JCAP / 64], tz[P3_JCAP / 64];
-                int tg[P3_JCAP / 64], tc[P3_JCAP / 64];
-#pragma unroll
-                for (int u = 0; u < P3_JCAP / 64; u++) {
-                    const int q = u * 64 + lane;
-                    tg[u] = -1;
-                    if (q < cnt) {
-                        const int v = base + q;
-                        int lo = 0, hi = 63;             // largest slot with seg_pre <= v (empty slots repeat the prefix:
-                        while (lo < hi) {                //  the LAST of equal prefixes is the non-empty one)
-                            const int mid = (lo + hi + 1) >> 1;
-                            if (seg_pre[w][mid] <= v) lo = mid;
-                            else hi = mid - 1;
-                        }
-                        const int64_t jj = seg_j0[w][lo] + (v - seg_pre[w][lo]);
-                        tx[u] = a.x2[jj], ty[u] = a.y2[jj], tz[u] = a.z2[jj];
-                        tg[u] = (int)jj, tc[u] = seg_code[w][lo];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < P3_JCAP / 64; u++) {
-                    const int q = u * 64 + lane;
-                    if (tg[u] >= 0) {
-                        jx[w][q] = tx[u], jy[w][q] = ty[u], jz[w][q] = tz[u], jg[w][q] = tg[u], jc[w][q] = tc[u];
-                        jsx[w][q] = (float)(2 - (tc[u] & 7)) * a.g.box;          // -k L, k in {-2 .. 2}
-                        jsy[w][q] = (float)(2 - ((tc[u] >> 3) & 7)) * a.g.box;
-                        jsz[w][q] = (float)(2 - ((tc[u] >> 6) & 7)) * a.g.box;
-                    }
-                }
-                wave_sync();
-                process(cnt);
-                wave_sync();
             }
         }
     }
