@@ -723,7 +723,7 @@ constexpr int KEY_TILES = ABACUS_KEY_TILES;   // tiles per workgroup of the key 
 // halos, 53 % of the particles (354 vs 371 us).
 template <int KIND>
 __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, const unsigned int *__restrict__ hkeys,
-                                                         const unsigned int *__restrict__ pkeys, int ngroup_c, Cheap ch) {
+                                                         const unsigned int *__restrict__ pkeys, int ngroup_c, Cheap ch, int nozero) {
     __shared__ int nq[KEY_TILES];
     __shared__ float tab[256];
     const int tid = threadIdx.x;
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, const unsign
             }
         }
     }
-    {   // zero the tiles' masks: 8 consecutive bytes per thread and tile
+    if (!nozero) {   // zero the tiles' masks: 8 consecutive bytes per thread and tile (unless hod_exact un-keeps, see there)
 #pragma unroll
         for (int t = 0; t < KEY_TILES; t++) {
             const int64_t o = base0 + (int64_t)t * TILE + (int64_t)tid * 8;
@@ -856,7 +856,7 @@ struct ExactCand {
 
 template <int XB, bool PIPE, int SBT>
 __global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre,
-                                                abacus_cls::ClsConst cc, int use_cls) {
+                                                abacus_cls::ClsConst cc, int use_cls, int clear_prev) {
     constexpr int SB_TILES = SBT, SB_OBJ = SBT * TILE, SB_WORDS = SB_OBJ / 32;
     constexpr int WORDS_PER_THREAD = SB_WORDS / XB;
     static_assert(SB_WORDS % XB == 0 && XB <= 512 && SB_OBJ <= 65536, "bitmap words must divide over the workgroup");
@@ -887,6 +887,18 @@ __global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_
         for (int q = 1; q <= SB_TILES; q++) L.pre[q] += L.pre[q - 1];
     __syncthreads();
     const int total = L.pre[SB_TILES];
+    if (clear_prev) {
+        // Lazy keep masks (sparse mixes): the filter did not zero the 1 B per object - 20 MB of the 100 MB it moves at 1e7 +
+        // 1e7 (23.8 -> 21.3 us; 83 -> 67 us at 4e7 + 4e7).  The only non-zero bytes are the objects the PREVIOUS populate
+        // kept, and this superblock's share of them is still listed in its kept slice (counts in sb_counts, overwritten at
+        // the end of this workgroup): un-keep those, then decide.  The host falls back to the zeroing filter whenever the
+        // lists do not describe the masks (first populate, another superblock size, the NFW path in between).
+        const int prev = a.sb_counts[(int64_t)g * 4] + a.sb_counts[(int64_t)g * 4 + 1] + a.sb_counts[(int64_t)g * 4 + 2];
+        const unsigned short *pk = (sat ? a.kept_s : a.kept_c) + (int64_t)S * SB_OBJ;
+        int8_t *keep = (sat ? a.keep_s : a.keep_c) + (int64_t)S * SB_OBJ;
+        for (int e = tid; e < prev; e += XB) keep[pk[e]] = 0;
+        __syncthreads();   // an object kept again is written again below, by whichever thread classifies it
+    }
     const bool need_conf = sat && p.want_ELG && a.pinds != nullptr;
     const bool need_ranks = p.enable_ranks != 0;
     const unsigned short *queue = sat ? a.queue_s : a.queue_c;
@@ -1648,6 +1660,8 @@ struct abacus_hod_state {
     unsigned short *kept_c = nullptr, *kept_s = nullptr;     // kept lists, one SB_OBJ-sized slice per superblock
     int nsb_c = 0, nsb_s = 0;   // superblocks of the current populate (sb_tiles tiles each)
     int sb_tiles = SB_TILES_DENSE;
+    bool kept_valid = false;    // the kept lists (superblocks of kept_sb_tiles tiles) name exactly the non-zero mask bytes
+    int kept_sb_tiles = 0;
     int64_t *d_totals = nullptr;  // 6
     int64_t *h_totals = nullptr;  // pinned, 6
     // outputs
@@ -2238,6 +2252,7 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
     HodPtrs a;
     memset(&a, 0, sizeof a);
     set_superblocks(st, p);
+    st->kept_valid = false;   // the particles' masks and kept lists are left as they are: no lazy masks after this path
     a.nh = st->nh, a.np = 0, a.ntile_c = st->ntile_c, a.ntile_s = 0, a.nsb_c = st->nsb_c, a.nsb_s = 0;
     a.hmass = st->hmass, a.hmultis = st->hmultis, a.hrandoms = st->hrandoms, a.hdeltac = st->hdeltac,
     a.hfenv = st->hfenv, a.hshear = st->hshear;
@@ -2255,9 +2270,9 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
         abacus_cls::ClsConst cc;
         abacus_cls::make_cls_const(*p, pre, cc);
         if (st->sb_tiles == SB_TILES_SPARSE)
-            ABACUS_LAUNCH("hod_exact", (hod_exact<256, false, SB_TILES_SPARSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1);
+            ABACUS_LAUNCH("hod_exact", (hod_exact<256, false, SB_TILES_SPARSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1, 0);
         else
-            ABACUS_LAUNCH("hod_exact", (hod_exact<256, false, SB_TILES_DENSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1);
+            ABACUS_LAUNCH("hod_exact", (hod_exact<256, false, SB_TILES_DENSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1, 0);
     }
     ABACUS_TRY(launch_emit(st));
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
@@ -2377,6 +2392,13 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     if (use32) ABACUS_TRY(compute_ranges(st));
     if (use32) ABACUS_TRY(build_keys(st));
     const Cheap cheap = use32 ? make_cheap(*p, F, st->ranges) : Cheap{};
+    // lazy keep masks (see hod_exact): only when one key-filter launch covers both kinds, the mix is sparse, and the kept
+    // lists of the previous populate describe the masks
+    const bool filter_first_ = conf && use32 && cheap.s_ok;
+    const bool lazy_masks = use32 && !option("hod_nokeys") && !option("hod_nolazy") && cheap.c_ok && cheap.s_ok && st->ntile_c > 0 &&
+                            st->ntile_s > 0 && (!conf || filter_first_) && st->sb_tiles == SB_TILES_SPARSE && st->kept_valid &&
+                            st->kept_sb_tiles == st->sb_tiles;
+    st->kept_valid = false;   // until this populate's launches are all enqueued
     // `first`, `count` in global tile ids (centrals first): the shadow path launches the two kinds separately
     auto filter32 = [&](int first, int count) -> int {
         const int c0 = std::min(first, st->ntile_c), c1 = std::min(first + count, st->ntile_c);
@@ -2390,7 +2412,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
         const unsigned int *hk = st->keys.as<unsigned int>(), *pk = hk + (int64_t)std::max(st->ntile_c, 1) * TILE;
         const bool kc = keyed && c2 && c0 == 0 && c1 == st->ntile_c && c1 > c0, ks = keyed && s2 && s0 == 0 && s1 == st->ntile_s && s1 > s0;
         const int gc = (int)ceil_div(st->ntile_c, KEY_TILES), gs = (int)ceil_div(st->ntile_s, KEY_TILES);
-#define FKEY(KIND, grid_) ABACUS_LAUNCH("hod_filter", (hod_filter_key<KIND>), dim3(grid_), dim3(FBLOCK), 0, a, hk, pk, gc, cheap)
+#define FKEY(KIND, grid_) ABACUS_LAUNCH("hod_filter", (hod_filter_key<KIND>), dim3(grid_), dim3(FBLOCK), 0, a, hk, pk, gc, cheap, lazy_masks ? 1 : 0)
         if (kc && ks) {
             FKEY(2, gc + gs);
             return 0;
@@ -2443,7 +2465,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     const bool pipe = a.hrec && a.prec && (pipe_opt == 2 || (pipe_opt != 1 && (p->want_ELG || p->want_QSO)));
     const bool sparse_sb = st->sb_tiles == SB_TILES_SPARSE;
 #define EXACT_(PIPE, SBT, first, count) \
-    ABACUS_LAUNCH("hod_exact", (hod_exact<256, PIPE, SBT>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1)
+    ABACUS_LAUNCH("hod_exact", (hod_exact<256, PIPE, SBT>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1, lazy_masks ? 1 : 0)
 #define EXACT(first, count)                                                    \
     if ((count) > 0) {                                                         \
         if (pipe && sparse_sb) EXACT_(true, SB_TILES_SPARSE, first, count);    \
@@ -2475,6 +2497,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
     st->have_run = true;
     st->counts_valid = false;
+    st->kept_valid = true, st->kept_sb_tiles = st->sb_tiles;   // every mask byte that is set is in a kept list
     return 0;
 }
 

@@ -156,6 +156,36 @@ def test_capacity_growth_and_param_change(G):
     st.free()
 
 
+def test_keep_masks_across_a_sequence_of_populates(G, options):
+    """one staged catalogue, many populates: the key filter of a sparse (LRG-only) mix leaves the keep masks alone and
+    hod_exact un-keeps what the populate before it kept; a change of the mix (other superblock size), a reseed, the NFW
+    path or the comparator filter in between must never leave a stale byte.  Masks and catalogues against the oracle after
+    every step"""
+    from oracle import oracle
+    hd, pd, params = synth.synth_hod_inputs(250_000, 350_000, seed=21, with_ranks=True)
+    st = G.StagedCatalog(hd, pd)
+    lrg = lambda lc: {'LRG': dict(synth.LRG_PARAMS, logM_cut=lc, logM1=lc + 0.9)}   # noqa: E731
+    steps = [('lrg', lrg(12.6), False), ('lrg', lrg(12.9), False), ('lrg', lrg(12.3), False), ('mix', synth.PRODUCTION_TRACERS, True),
+             ('lrg', lrg(12.7), False), ('lrg', lrg(12.7), False), ('nokeys', lrg(12.5), False), ('lrg', lrg(13.0), False),
+             ('reseed', lrg(12.8), False), ('lrg', lrg(12.4), False), ('nolazy', lrg(12.6), False), ('lrg', lrg(12.6), False)]
+    for what, tracers, ranks in steps:
+        options.set('hod_nokeys', 1 if what == 'nokeys' else 0)
+        options.set('hod_nolazy', 1 if what == 'nolazy' else 0)
+        if what == 'reseed':
+            st.reseed(1234, hsigma3d=hd['hsigma3d'])
+            hd = dict(hd, hrandoms=st.fetch_field('hrandoms'), hveldev=st.fetch_field('hveldev').reshape(-1, 3))
+            pd = dict(pd, prandoms=st.fetch_field('prandoms'))
+        p = G.marshal_params(tracers, params, ranks, True)
+        st.populate(p)
+        kc, ks = st.fetch_keep()
+        mock = {tr: st.fetch(tr) for tr in tracers}
+        want, wkc, wks = oracle.gen_gal_cat(hd, pd, tracers, params, Nthread=4, enable_ranks=ranks, rsd=True, return_keep=True)
+        np.testing.assert_array_equal(kc, wkc, err_msg=what)
+        np.testing.assert_array_equal(ks, wks, err_msg=what)
+        assert_mock_equal(mock, want, exact=True)
+    st.free()
+
+
 def test_errors(G):
     g = load_golden('hod_mini')
     hd, pd, params = unpack_inputs(g)
