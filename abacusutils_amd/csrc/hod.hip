@@ -672,28 +672,44 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter32(HodPtrs a, FiltCols c, in
     for (int j = tid; j < cnt; j += FBLOCK) queue[tile0 + j] = q[j];
 }
 
-// ---- packed filter keys: 4 bytes per object -------------------------------------------------------------------------------
-// Stage 1 of the two-stage filter compares `random > B[bin(mass)] * weight * dec`.  Everything on the object's side of that
-// inequality is fixed once the catalogue and its randoms are staged, so it is folded into ONE 32-bit key per object:
-//   low 8 bits   the mass bin of cheap_bound (float32-representation bins, 255 = above the table / not a mass: never rejected)
-//   high 24 bits a float32 q <= random / weight (rounded DOWN, low mantissa bits cleared: 16-bit mantissa), so that
-//                `q > B[bin] * dec` implies `random > B[bin] * weight * dec`; q = 0 (never rejected) where the division says
-//                nothing (weight < 0 or NaN, random <= 0 or NaN, weight = 0 with random <= 0), q = +inf for weight = 0 and a
-//                positive random (the marker is 0 * n = 0: never kept).
-// The streaming loop then reads 4 B per object instead of 12 (80 MB instead of 240 MB at 1e7 + 1e7), does one LDS table
-// look-up, one multiply and one compare per object, and a workgroup takes four tiles so that eight 16-B loads per thread are in
-// flight.  Keys are rebuilt (one pass) when the randoms change (reseed / update); the parameters never enter them.
+// ---- packed filter keys: 2 bytes per object -------------------------------------------------------------------------------
+// The filter compares `random > B[bin(mass)] * weight * dec`.  Everything on the object's side of that inequality is fixed
+// once the catalogue and its randoms are staged, so it is folded into ONE 16-bit key per object:
+//   low 7 bits   the mass bin: the float32-representation bins of cheap_bound (8 per octave), window 2^36 ... 2^51.9 - bin 0
+//                also takes every smaller mass (its bound is the largest of the levels it covers), bin 127 everything above
+//                and whatever is not a mass (never rejected);
+//   high 9 bits  a CODE of q <= random / weight: exponent and three mantissa bits of the float32 lower bound (its bits >> 20,
+//                offset so that code 0 is 2^-44 and below), i.e. q rounded down to eight steps per octave over 2^-44 ... 2^20.
+//                `code > code(B[bin] * dec)` implies `random > B[bin] * weight * dec`.  Code 0 is never rejected and also
+//                stands for "the division says nothing" (weight < 0 or NaN, random <= 0 or NaN): a bin whose bound lies below
+//                2^-44 sends the objects with a random / weight below that (float32 randoms: the zeros) to hod_exact.  Above
+//                2^20 codes and bounds saturate at 511: never rejected either; +inf (weight = 0 and a positive random: the
+//                marker is 0 * n = 0, never kept) too.
+// The coarse q costs candidates - objects whose q lies within a step (6 - 12 %) above the bound - and halves what the filter
+// streams: 2 B per object (40 MB at 1e7 + 1e7; 4-B keys with a 16-bit mantissa: 80 MB; float32 shadow columns: 240 MB), one
+// LDS table look-up and one integer compare per object, eight tiles per workgroup so that eight 16-B loads per thread are in
+// flight.  (Four steps per octave over 2^-100 ... 2^28: +10 % candidates; sixteen over 2^-24 ... 2^8: the satellites of
+// massive hosts, whose bound exceeds 2^8, all pass - 2.3e6 instead of 1.3e6 particles at LRG + ELG + QSO.)  Keys are
+// rebuilt (one pass) when the randoms change (reseed / update); the parameters never enter them.
+constexpr int K16_LEV0 = (36 - 33) * 8;            // CH level that is key bin 0: upper edge 2^36 * 9/8
+constexpr int K16_QSHIFT = 20, K16_QOFF = (127 - 44) << 3;   // (float bits >> 20) of 2^-44
+__host__ __device__ __forceinline__ int k16_code(float v) {   // v >= 0 or NaN / inf: monotone, saturating
+    unsigned int u;
+    memcpy(&u, &v, 4);
+    const int c = (int)((u & 0x7fffffffu) >> K16_QSHIFT) - K16_QOFF;
+    return c < 0 ? 0 : (c > 511 ? 511 : c);
+}
 __global__ __launch_bounds__(256) void hod_build_keys(const double *__restrict__ mass, const double *__restrict__ wgt,
                                                       const double *__restrict__ rnd, int64_t n, int64_t npad,
-                                                      unsigned int *__restrict__ keys) {
+                                                      unsigned short *__restrict__ keys) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npad; i += (int64_t)gridDim.x * 256) {
-        unsigned int key = 0x7f800000u | 255u;   // padding: q = +inf with the never-rejecting bin - masked by i < n anyway
+        unsigned int key = 127u;   // padding: never rejected - masked by i < n anyway
         if (i < n) {
             const double m = mass[i], w = wgt[i], r = rnd[i];
             float mf = (float)m;
             if ((double)mf < m) mf = nextafterf(mf, INFINITY);     // rounded up, like the shadow masses
-            const int j = (int)(__float_as_uint(mf) >> CH_SHIFT) - CH_BASE;   // negative / NaN masses: sign bit -> above the table
-            const unsigned int bin = (__float_as_uint(mf) >> 31) || !(mf == mf) ? 255u : (j < 0 ? 0u : (j < CH_NLEV ? (unsigned int)j : 255u));
+            const int j = (int)(__float_as_uint(mf) >> CH_SHIFT) - CH_BASE - K16_LEV0;   // negative / NaN masses: sign bit -> above
+            const unsigned int bin = (__float_as_uint(mf) >> 31) || !(mf == mf) ? 127u : (j < 0 ? 0u : (j < 127 ? (unsigned int)j : 127u));
             float q = 0.f;
             if (w > 0.0 && r > 0.0) {
                 const double qd = r / w * (1.0 - 1e-6);
@@ -703,14 +719,14 @@ __global__ __launch_bounds__(256) void hod_build_keys(const double *__restrict__
             } else if (w == 0.0 && r > 0.0) {
                 q = INFINITY;
             }
-            key = (__float_as_uint(q) & 0xffffff00u) | bin;
+            key = ((unsigned int)k16_code(q) << 7) | bin;
         }
-        keys[i] = key;
+        keys[i] = (unsigned short)key;
     }
 }
 
 #ifndef ABACUS_KEY_TILES
-#define ABACUS_KEY_TILES 4
+#define ABACUS_KEY_TILES 8
 #endif
 constexpr int KEY_TILES = ABACUS_KEY_TILES;   // tiles per workgroup of the key filter
 
@@ -722,52 +738,52 @@ constexpr int KEY_TILES = ABACUS_KEY_TILES;   // tiles per workgroup of the key 
 // table's survivors - LRG alone: 2 % (56.3 vs 60.2 us per step without it); LRG + ELG + QSO with assembly bias: 42 % of the
 // halos, 53 % of the particles (354 vs 371 us).
 template <int KIND>
-__global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, const unsigned int *__restrict__ hkeys,
-                                                         const unsigned int *__restrict__ pkeys, int ngroup_c, Cheap ch, int nozero) {
+__global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, const unsigned short *__restrict__ hkeys,
+                                                         const unsigned short *__restrict__ pkeys, int ngroup_c, Cheap ch, int nozero) {
     __shared__ int nq[KEY_TILES];
-    __shared__ float tab[256];
+    __shared__ int tc[128];       // per key bin: the largest q code that is NOT rejected
     const int tid = threadIdx.x;
     const bool SAT = KIND == 2 ? (int)blockIdx.x >= ngroup_c : KIND == 1;
     const int G = KIND == 2 && SAT ? (int)blockIdx.x - ngroup_c : (int)blockIdx.x;
-    {
-        const float dec = SAT ? ch.dec_max : 1.0f;   // folded into the table: one multiply less per object
-        const float v = tid < CH_NLEV ? (SAT ? ch.Bs[tid] : ch.Bc[tid]) * dec * 1.0001f : INFINITY;
-        tab[tid] = v;
+    if (tid < 128) {
+        const float dec = SAT ? ch.dec_max : 1.0f;   // folded into the table
+        const float *B = SAT ? ch.Bs : ch.Bc;
+        float v = INFINITY;                          // bin 127: never rejected
+        if (tid == 0) {                              // bin 0 and everything below it
+            v = 0.f;
+            for (int l = 0; l <= K16_LEV0; l++) v = fmaxf(v, B[l]);
+        } else if (tid < 127 && K16_LEV0 + tid < CH_NLEV) {
+            v = B[K16_LEV0 + tid];
+        }
+        tc[tid] = k16_code(v * dec * 1.0001f);       // NaN / inf saturate at 511: never rejected
     }
     if (tid < KEY_TILES) nq[tid] = 0;
     const int ntile = SAT ? a.ntile_s : a.ntile_c;
     const int64_t n = SAT ? a.np : a.nh;
-    const unsigned int *keys = SAT ? pkeys : hkeys;
+    const unsigned short *keys = SAT ? pkeys : hkeys;
     int8_t *keep = SAT ? a.keep_s : a.keep_c;
     unsigned short *queue = SAT ? a.queue_s : a.queue_c;
-    // all key loads of the workgroup's tiles first: 2 x 16 B per thread and tile (the key array is padded to whole tiles)
-    uint4 k[KEY_TILES][2];
+    // all key loads of the workgroup's tiles first: 16 B = eight keys per thread and tile (the key array is padded to whole tiles)
+    static_assert(TILE == 8 * FBLOCK, "one 16-B load per thread and tile");
+    uint4 k[KEY_TILES];
     const int t_first = G * KEY_TILES;
     const int64_t base0 = (int64_t)t_first * TILE;
 #pragma unroll
-    for (int t = 0; t < KEY_TILES; t++) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int64_t i = base0 + (int64_t)t * TILE + h * (4 * FBLOCK) + 4 * tid;
-            k[t][h] = (t_first + t < ntile) ? *reinterpret_cast<const uint4 *>(keys + i) : make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
+    for (int t = 0; t < KEY_TILES; t++)
+        k[t] = (t_first + t < ntile) ? *reinterpret_cast<const uint4 *>(keys + base0 + (int64_t)t * TILE + 8 * tid) : make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();            // the table and the zeroed counters
     // one LDS table look-up and one compare per object
 #pragma unroll
     for (int t = 0; t < KEY_TILES; t++) {
         if (t_first + t >= ntile) break;      // uniform
+        const int loc = 8 * tid;
+        const unsigned int kw[4] = {k[t].x, k[t].y, k[t].z, k[t].w};
+        const int lim = (int)min((int64_t)8, n - (base0 + (int64_t)t * TILE + loc));   // objects of this load inside the catalogue
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int loc = h * (4 * FBLOCK) + 4 * tid;
-            const unsigned int kk[4] = {k[t][h].x, k[t][h].y, k[t][h].z, k[t][h].w};
-            const int lim = (int)min((int64_t)4, n - (base0 + (int64_t)t * TILE + loc));   // objects of this load inside the catalogue
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (u >= lim) continue;
-                const float qv = __uint_as_float(kk[u] & 0xffffff00u);
-                if (!(qv > tab[kk[u] & 255u])) queue[base0 + (int64_t)t * TILE + atomicAdd(&nq[t], 1)] = (unsigned short)(loc + u);
-            }
+        for (int u = 0; u < 8; u++) {
+            if (u >= lim) continue;
+            const unsigned int key = (kw[u >> 1] >> ((u & 1) * 16)) & 0xffffu;
+            if ((int)(key >> 7) <= tc[key & 127u]) queue[base0 + (int64_t)t * TILE + atomicAdd(&nq[t], 1)] = (unsigned short)(loc + u);
         }
     }
     if (!nozero) {   // zero the tiles' masks: 8 consecutive bytes per thread and tile (unless hod_exact un-keeps, see there)
@@ -1978,8 +1994,8 @@ int launch_emit(abacus_hod_state *st) {
 int build_keys(abacus_hod_state *st) {
     if (st->keys_ok) return 0;
     const int64_t ph = (int64_t)std::max(st->ntile_c, 1) * TILE, pp = (int64_t)std::max(st->ntile_s, 1) * TILE;
-    ABACUS_TRY(st->keys.reserve((size_t)(ph + pp) * sizeof(unsigned int)));
-    unsigned int *hk = st->keys.as<unsigned int>(), *pk = hk + ph;
+    ABACUS_TRY(st->keys.reserve((size_t)(ph + pp) * sizeof(unsigned short)));
+    unsigned short *hk = st->keys.as<unsigned short>(), *pk = hk + ph;
     ABACUS_LAUNCH("hod_build_keys", hod_build_keys, dim3((unsigned)std::min<int64_t>(ceil_div(ph, 256), 8192)), dim3(256), 0,
                   (const double *)st->hmass, (const double *)st->hmultis, (const double *)st->hrandoms, st->nh, ph, hk);
     ABACUS_LAUNCH("hod_build_keys", hod_build_keys, dim3((unsigned)std::min<int64_t>(ceil_div(pp, 256), 8192)), dim3(256), 0,
@@ -2409,7 +2425,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
         const bool c2 = cheap.c_ok != 0, s2 = cheap.s_ok != 0;
         // two-stage kinds stream the packed keys (4 B per object), whole tile groups: only full-kind ranges take this path
         const bool keyed = !option("hod_nokeys");
-        const unsigned int *hk = st->keys.as<unsigned int>(), *pk = hk + (int64_t)std::max(st->ntile_c, 1) * TILE;
+        const unsigned short *hk = st->keys.as<unsigned short>(), *pk = hk + (int64_t)std::max(st->ntile_c, 1) * TILE;
         const bool kc = keyed && c2 && c0 == 0 && c1 == st->ntile_c && c1 > c0, ks = keyed && s2 && s0 == 0 && s1 == st->ntile_s && s1 > s0;
         const int gc = (int)ceil_div(st->ntile_c, KEY_TILES), gs = (int)ceil_div(st->ntile_s, KEY_TILES);
 #define FKEY(KIND, grid_) ABACUS_LAUNCH("hod_filter", (hod_filter_key<KIND>), dim3(grid_), dim3(FBLOCK), 0, a, hk, pk, gc, cheap, lazy_masks ? 1 : 0)

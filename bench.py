@@ -59,13 +59,15 @@ def parse():
 
 def filter_bytes_per_object(tracers, enable_ranks, two_stage=True):
     """algorithmic bytes the rejection filter streams per halo / per particle, in the layout it actually reads
-    (DESIGN.md section 4).  Two-stage filter: ONE packed 32-bit key per object (mass bin + a float lower bound of
-    random / weight, built at staging and after a reseed) - 4 B read (+ 1 B of keep mask written) per object for ANY HOD; environment, rank and float32
-    shadow columns are only gathered for the few per cent that survive the table.  One-stage fallback (parameter sets
-    the envelope table cannot bound): float32 shadow columns, 12 B + deltac, fenv (+ shear) per halo when weighted,
-    12 B + four rank columns per particle."""
+    (DESIGN.md section 4).  Key filter: ONE packed 16-bit key per object (mass bin + a 9-bit code of a lower bound of
+    random / weight, built at staging and after a reseed) - 2 B read per object for ANY HOD; mixes with ELG / QSO also zero
+    the 1-B keep mask in the same kernel (LRG alone: hod_exact un-keeps what the previous populate kept instead).  The
+    float64 columns are read only for the table's survivors.  One-stage fallback (parameter sets the envelope table cannot
+    bound): float32 shadow columns, 12 B + deltac, fenv (+ shear) per halo when weighted, 12 B + four rank columns per
+    particle."""
     if two_stage:
-        return 5.0, 5.0     # 4-B key read + 1 B of the int8 keep mask zeroed by the same kernel
+        m = 1.0 if ('ELG' in tracers or 'QSO' in tracers) else 0.0
+        return 2.0 + m, 2.0 + m
     env = any(t.get('Acent', 0) != 0 or t.get('Bcent', 0) != 0 for t in tracers.values())
     shear = 'ELG' in tracers and tracers['ELG'].get('Ccent', 0) != 0
     return 12.0 + (8.0 if env else 0.0) + (4.0 if shear else 0.0), 12.0 + (16.0 if enable_ranks else 0.0)
@@ -171,8 +173,8 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
                            'frac': ach / HBM_PEAK_GBS,
                            'traffic': pmc_traffic('hod', dom_name) if c2 else None,
                            'algorithmic_bytes': fbytes,
-                           'layout': f'packed filter keys built at staging ({bh:.0f} B per halo + {bp:.0f} B per particle: a 4-B key = mass bin + a '
-                                     'lower bound of random / weight, and 1 B of keep mask zeroed); the float64 reference layout (SURVEY.md 8d: 40 B per object) is read '
+                           'layout': f'packed filter keys built at staging ({bh:.0f} B per halo + {bp:.0f} B per particle: a 2-B key = mass bin + a '
+                                     '9-bit code of a lower bound of random / weight; + 1 B of keep mask zeroed for mixes with ELG / QSO); the float64 reference layout (SURVEY.md 8d: 40 B per object) is read '
                                      'only for the candidates; keys, float32 shadows and packed records are built once per catalogue '
                                      '(`stage_ms`, outside the timed region), the keys again after a reseed',
                            'whole_step_GBs': step_bytes / (dt / args.steps) / 1e9,
