@@ -737,26 +737,18 @@ constexpr int KEY_TILES = ABACUS_KEY_TILES;   // tiles per workgroup of the key 
 // same line plus ~35 us of classifier per million, so the second stage only wins where it removes more than 40 % of the
 // table's survivors - LRG alone: 2 % (56.3 vs 60.2 us per step without it); LRG + ELG + QSO with assembly bias: 42 % of the
 // halos, 53 % of the particles (354 vs 371 us).
+struct KeyTab {   // per key bin: the largest q code that is NOT rejected (host-built from the envelope table, make_keytab)
+    unsigned short c[128], s[128];
+};
 template <int KIND>
 __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, const unsigned short *__restrict__ hkeys,
-                                                         const unsigned short *__restrict__ pkeys, int ngroup_c, Cheap ch, int nozero) {
+                                                         const unsigned short *__restrict__ pkeys, int ngroup_c, KeyTab kt, int nozero) {
     __shared__ int nq[KEY_TILES];
-    __shared__ int tc[128];       // per key bin: the largest q code that is NOT rejected
+    __shared__ int tc[128];
     const int tid = threadIdx.x;
     const bool SAT = KIND == 2 ? (int)blockIdx.x >= ngroup_c : KIND == 1;
     const int G = KIND == 2 && SAT ? (int)blockIdx.x - ngroup_c : (int)blockIdx.x;
-    if (tid < 128) {
-        const float dec = SAT ? ch.dec_max : 1.0f;   // folded into the table
-        const float *B = SAT ? ch.Bs : ch.Bc;
-        float v = INFINITY;                          // bin 127: never rejected
-        if (tid == 0) {                              // bin 0 and everything below it
-            v = 0.f;
-            for (int l = 0; l <= K16_LEV0; l++) v = fmaxf(v, B[l]);
-        } else if (tid < 127 && K16_LEV0 + tid < CH_NLEV) {
-            v = B[K16_LEV0 + tid];
-        }
-        tc[tid] = k16_code(v * dec * 1.0001f);       // NaN / inf saturate at 511: never rejected
-    }
+    if (tid < 128) tc[tid] = SAT ? kt.s[tid] : kt.c[tid];
     if (tid < KEY_TILES) nq[tid] = 0;
     const int ntile = SAT ? a.ntile_s : a.ntile_c;
     const int64_t n = SAT ? a.np : a.nh;
@@ -1864,6 +1856,27 @@ Cheap make_cheap(const abacus_hod_params &p, const Filt &F, const HodRanges &R) 
     return c;
 }
 
+// threshold codes of the 16-bit key filter from the envelope table (see hod_build_keys): key bin b = table level
+// K16_LEV0 + b; bin 0 also covers every level below it, bin 127 is never rejected
+KeyTab make_keytab(const Cheap &ch) {
+    KeyTab kt;
+    for (int sat = 0; sat < 2; sat++) {
+        const float *B = sat ? ch.Bs : ch.Bc;
+        const float dec = sat ? ch.dec_max : 1.0f;   // folded into the table
+        for (int b = 0; b < 128; b++) {
+            float v = INFINITY;
+            if (b == 0) {
+                v = 0.f;
+                for (int l = 0; l <= K16_LEV0; l++) v = std::fmax(v, B[l]);
+            } else if (b < 127 && K16_LEV0 + b < CH_NLEV) {
+                v = B[K16_LEV0 + b];
+            }
+            (sat ? kt.s : kt.c)[b] = (unsigned short)k16_code(v * dec * 1.0001f);   // NaN / inf saturate at 511: never rejected
+        }
+    }
+    return kt;
+}
+
 template <class T>
 int upload(T *&dst, const T *src, int64_t n, bool on_device) {
     if (src == nullptr) {
@@ -2408,6 +2421,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     if (use32) ABACUS_TRY(compute_ranges(st));
     if (use32) ABACUS_TRY(build_keys(st));
     const Cheap cheap = use32 ? make_cheap(*p, F, st->ranges) : Cheap{};
+    const KeyTab keytab = use32 ? make_keytab(cheap) : KeyTab{};
     // lazy keep masks (see hod_exact): only when one key-filter launch covers both kinds, the mix is sparse, and the kept
     // lists of the previous populate describe the masks
     const bool filter_first_ = conf && use32 && cheap.s_ok;
@@ -2428,7 +2442,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
         const unsigned short *hk = st->keys.as<unsigned short>(), *pk = hk + (int64_t)std::max(st->ntile_c, 1) * TILE;
         const bool kc = keyed && c2 && c0 == 0 && c1 == st->ntile_c && c1 > c0, ks = keyed && s2 && s0 == 0 && s1 == st->ntile_s && s1 > s0;
         const int gc = (int)ceil_div(st->ntile_c, KEY_TILES), gs = (int)ceil_div(st->ntile_s, KEY_TILES);
-#define FKEY(KIND, grid_) ABACUS_LAUNCH("hod_filter", (hod_filter_key<KIND>), dim3(grid_), dim3(FBLOCK), 0, a, hk, pk, gc, cheap, lazy_masks ? 1 : 0)
+#define FKEY(KIND, grid_) ABACUS_LAUNCH("hod_filter", (hod_filter_key<KIND>), dim3(grid_), dim3(FBLOCK), 0, a, hk, pk, gc, keytab, lazy_masks ? 1 : 0)
         if (kc && ks) {
             FKEY(2, gc + gs);
             return 0;
