@@ -30,6 +30,8 @@
 
 namespace abacus {
 int exclusive_scan_u32(unsigned int *counters, int64_t n, int64_t *out, DevBuf &scratch, int zero_counters);
+int sort_pairs_u16(const unsigned short *keys_in, unsigned short *keys_out, const unsigned int *val_in, unsigned int *val_out,
+                   int64_t n, DevBuf &tmp);   // staging.hip
 }
 using namespace abacus;
 
@@ -793,6 +795,53 @@ __global__ __launch_bounds__(FBLOCK) void hod_filter_key(HodPtrs a, const unsign
     if (tid < KEY_TILES && t_first + tid < ntile) a.q_count[(SAT ? a.ntile_c : 0) + t_first + tid] = nq[tid];   // global tile id
 }
 
+// ---- mass-sorted key index (sparse mixes) ---------------------------------------------------------------------------
+// For LRG alone 95 % of the halos sit in mass bins whose bound lies below any positive random: streaming their keys only
+// to reject them is most of the filter's 17 us.  Once per catalogue (from its second populate with unchanged keys on) the
+// objects are sorted by (mass bin, q code); the candidates of a populate are then a PREFIX of every bin's segment - the
+// objects with code <= the bin's threshold code - whose length the host reads off a cumulative table without touching the
+// device.  hod_deal hands those indices to the tiles' queues (one global atomic per candidate: a hundred thousand at 1e7 +
+// 1e7); the candidate set is the key filter's, so everything behind it is unchanged.
+__global__ __launch_bounds__(256) void hod_index_keys(const unsigned short *__restrict__ keys, int64_t n,
+                                                      unsigned short *__restrict__ sk, unsigned int *__restrict__ idx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned int k = keys[i];
+        sk[i] = (unsigned short)(((k & 127u) << 9) | (k >> 7));   // bin-major
+        idx[i] = (unsigned int)i;
+    }
+}
+// last[v] = 1 + position of the last object with sort key v (0: none), from the sorted keys
+__global__ __launch_bounds__(256) void hod_index_last(const unsigned short *__restrict__ sk, int64_t n, unsigned int *__restrict__ last) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        if (i == n - 1 || sk[i] != sk[i + 1]) last[sk[i]] = (unsigned int)(i + 1);
+}
+struct DealTab {   // candidate segments of the sorted index: centrals first; pre = exclusive prefix of the lengths
+    int nseg, nseg_c;
+    unsigned int start[256], pre[257];
+};
+__global__ __launch_bounds__(256) void hod_deal(HodPtrs a, const unsigned int *__restrict__ idx_h, const unsigned int *__restrict__ idx_p,
+                                                DealTab tab) {
+    __shared__ unsigned int s_pre[257], s_start[256];
+    const int tid = threadIdx.x;
+    for (int q = tid; q <= tab.nseg; q += 256) s_pre[q] = tab.pre[q];
+    for (int q = tid; q < tab.nseg; q += 256) s_start[q] = tab.start[q];
+    __syncthreads();
+    const unsigned int j = blockIdx.x * 256u + tid;
+    if (j >= s_pre[tab.nseg]) return;
+    int lo = 0, hi = tab.nseg - 1;   // largest segment with pre <= j
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_pre[mid] <= j) lo = mid;
+        else hi = mid - 1;
+    }
+    const bool sat = lo >= tab.nseg_c;
+    const unsigned int i = (sat ? idx_p : idx_h)[s_start[lo] + (j - s_pre[lo])];
+    const unsigned int tile = i >> 11, loc = i & (TILE - 1);
+    static_assert(TILE == 2048, "tile index arithmetic");
+    const int slot = atomicAdd(&a.q_count[(sat ? a.ntile_c : 0) + (int)tile], 1);
+    (sat ? a.queue_s : a.queue_c)[(int64_t)tile * TILE + slot] = (unsigned short)loc;
+}
+
 // The reference's float64 chains as OUT-OF-LINE functions reading the parameters through a pointer (the workgroup's LDS
 // copy).  hod_exact settles its candidates with the float32 interval classifier (hod_classify.hpp: a decision is taken
 // from float32 enclosures of the markers unless the random lies inside a band) and calls these only for the undecided few
@@ -886,6 +935,7 @@ __global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_
     if (tid < SB_TILES) {
         const int t = tile_first + tid;
         L.pre[tid + 1] = t < ntile ? q_count[t] : 0;
+        if ((clear_prev & 2) && t < ntile) a.q_count[(sat ? a.ntile_c : 0) + t] = 0;   // the index path counts into zeroed counters
     }
     if (tid == 0) L.pre[0] = 0;
 #pragma unroll
@@ -895,7 +945,7 @@ __global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_
         for (int q = 1; q <= SB_TILES; q++) L.pre[q] += L.pre[q - 1];
     __syncthreads();
     const int total = L.pre[SB_TILES];
-    if (clear_prev) {
+    if (clear_prev & 1) {
         // Lazy keep masks (sparse mixes): the filter did not zero the 1 B per object - 20 MB of the 100 MB it moves at 1e7 +
         // 1e7 (23.8 -> 21.3 us; 83 -> 67 us at 4e7 + 4e7).  The only non-zero bytes are the objects the PREVIOUS populate
         // kept, and this superblock's share of them is still listed in its kept slice (counts in sb_counts, overwritten at
@@ -1668,6 +1718,13 @@ struct abacus_hod_state {
     unsigned short *kept_c = nullptr, *kept_s = nullptr;     // kept lists, one SB_OBJ-sized slice per superblock
     int nsb_c = 0, nsb_s = 0;   // superblocks of the current populate (sb_tiles tiles each)
     int sb_tiles = SB_TILES_DENSE;
+    // mass-sorted key index (sparse mixes; hod_deal)
+    DevBuf index_idx, index_scratch, index_tmp, index_last;
+    std::vector<unsigned int> upper_h, upper_p;   // host: number of objects with (bin << 9 | code) <= v
+    bool index_ok = false;
+    int key_uses = 0;           // populates since the keys were (re)built
+    bool q_zero = false;        // the per-tile candidate counters are known to be zero
+    int64_t last_cand[2] = {-1, -1};
     bool kept_valid = false;    // the kept lists (superblocks of kept_sb_tiles tiles) name exactly the non-zero mask bytes
     int kept_sb_tiles = 0;
     int64_t *d_totals = nullptr;  // 6
@@ -2014,6 +2071,44 @@ int build_keys(abacus_hod_state *st) {
     ABACUS_LAUNCH("hod_build_keys", hod_build_keys, dim3((unsigned)std::min<int64_t>(ceil_div(pp, 256), 8192)), dim3(256), 0,
                   (const double *)st->phmass, (const double *)st->pweights, (const double *)st->prandoms, st->np, pp, pk);
     st->keys_ok = true;
+    st->index_ok = false;   // the index sorts these keys
+    st->key_uses = 0;
+    return 0;
+}
+
+// sort the objects of both kinds by (mass bin, q code) and tabulate, on the host, how many lie at or below every sort key
+int build_index(abacus_hod_state *st) {
+    if (st->index_ok) return 0;
+    const int64_t nh = st->nh, np = st->np, nmax = std::max<int64_t>(std::max(nh, np), 1);
+    if (nh > 0x7fffffffll || np > 0x7fffffffll) return 0;   // 32-bit indices / sort sizes: larger catalogues keep streaming the keys
+    ABACUS_TRY(st->index_idx.reserve((size_t)std::max<int64_t>(nh + np, 1) * sizeof(unsigned int)));
+    ABACUS_TRY(st->index_scratch.reserve((size_t)nmax * (2 + 2 + 4)));
+    ABACUS_TRY(st->index_last.reserve(65536 * sizeof(unsigned int)));
+    unsigned short *sk_in = st->index_scratch.as<unsigned short>(), *sk_out = sk_in + nmax;
+    unsigned int *idx_in = reinterpret_cast<unsigned int *>(sk_out + nmax);
+    unsigned int *last = st->index_last.as<unsigned int>();
+    const unsigned short *hk = st->keys.as<unsigned short>(), *pk = hk + (int64_t)std::max(st->ntile_c, 1) * TILE;
+    std::vector<unsigned int> host(65536);
+    for (int kind = 0; kind < 2; kind++) {
+        const int64_t n = kind ? np : nh;
+        std::vector<unsigned int> &up = kind ? st->upper_p : st->upper_h;
+        up.assign(65536, 0u);
+        if (n == 0) continue;
+        unsigned int *idx_out = st->index_idx.as<unsigned int>() + (kind ? nh : 0);
+        const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 8192);
+        ABACUS_LAUNCH("hod_index_keys", hod_index_keys, dim3(grid), dim3(256), 0, kind ? pk : hk, n, sk_in, idx_in);
+        ABACUS_TRY(sort_pairs_u16(sk_in, sk_out, idx_in, idx_out, n, st->index_tmp));
+        HIP_TRY(hipMemsetAsync(last, 0, 65536 * sizeof(unsigned int), stream()));
+        ABACUS_LAUNCH("hod_index_last", hod_index_last, dim3(grid), dim3(256), 0, (const unsigned short *)sk_out, n, last);
+        HIP_TRY(hipMemcpyAsync(host.data(), last, 65536 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        unsigned int run = 0;
+        for (int v = 0; v < 65536; v++) {
+            if (host[v]) run = host[v];
+            up[v] = run;
+        }
+    }
+    st->index_ok = true;
     return 0;
 }
 
@@ -2282,6 +2377,7 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
     memset(&a, 0, sizeof a);
     set_superblocks(st, p);
     st->kept_valid = false;   // the particles' masks and kept lists are left as they are: no lazy masks after this path
+    st->q_zero = false, st->last_cand[0] = st->last_cand[1] = -1;
     a.nh = st->nh, a.np = 0, a.ntile_c = st->ntile_c, a.ntile_s = 0, a.nsb_c = st->nsb_c, a.nsb_s = 0;
     a.hmass = st->hmass, a.hmultis = st->hmultis, a.hrandoms = st->hrandoms, a.hdeltac = st->hdeltac,
     a.hfenv = st->hfenv, a.hshear = st->hshear;
@@ -2429,6 +2525,38 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
                             st->ntile_s > 0 && (!conf || filter_first_) && st->sb_tiles == SB_TILES_SPARSE && st->kept_valid &&
                             st->kept_sb_tiles == st->sb_tiles;
     st->kept_valid = false;   // until this populate's launches are all enqueued
+    // mass-sorted key index (see hod_deal): from the second populate on the same keys, for the mixes that run lazy masks
+    bool index_mode = false;
+    DealTab deal;
+    if (use32 && st->sb_tiles == SB_TILES_SPARSE && !option("hod_noindex") && !option("hod_nokeys")) {
+        st->key_uses++;
+        if (!st->index_ok && st->key_uses >= 2) ABACUS_TRY(build_index(st));
+        if (st->index_ok && lazy_masks) {
+            unsigned int pre = 0;
+            deal.nseg = 0;
+            int64_t cand[2] = {0, 0};
+            for (int kind = 0; kind < 2; kind++) {
+                const std::vector<unsigned int> &up = kind ? st->upper_p : st->upper_h;
+                const unsigned short *tcv = kind ? keytab.s : keytab.c;
+                for (int b = 0; b < 128; b++) {
+                    const unsigned int lo = b == 0 ? 0u : up[(b << 9) - 1], hi = up[(b << 9) | std::min<int>(tcv[b], 511)];
+                    if (hi > lo) {
+                        deal.start[deal.nseg] = lo, deal.pre[deal.nseg] = pre;
+                        pre += hi - lo, cand[kind] += hi - lo;
+                        deal.nseg++;
+                    }
+                }
+                if (kind == 0) deal.nseg_c = deal.nseg;
+            }
+            deal.pre[deal.nseg] = pre;
+            if ((int64_t)pre <= (st->nh + st->np) / 8) {   // a dense threshold set: stream the keys instead
+                index_mode = true;
+                st->last_cand[0] = cand[0], st->last_cand[1] = cand[1];
+            }
+        }
+    }
+    if (!index_mode) st->last_cand[0] = st->last_cand[1] = -1;
+    const int exact_flags = (lazy_masks ? 1 : 0) | (index_mode ? 2 : 0);
     // `first`, `count` in global tile ids (centrals first): the shadow path launches the two kinds separately
     auto filter32 = [&](int first, int count) -> int {
         const int c0 = std::min(first, st->ntile_c), c1 = std::min(first + count, st->ntile_c);
@@ -2482,7 +2610,14 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     };
 #define FILTER(first, count)                                                                                         \
     if ((count) > 0) {                                                                                               \
-        if (use32) ABACUS_TRY(filter32(first, count));                                                               \
+        if (index_mode) {                                                                                            \
+            if (!st->q_zero) HIP_TRY(hipMemsetAsync(st->q_count, 0, (size_t)ntile * sizeof(int), stream()));         \
+            st->q_zero = true;                                                                                       \
+            if (deal.pre[deal.nseg] > 0)                                                                             \
+                ABACUS_LAUNCH("hod_deal", hod_deal, dim3((deal.pre[deal.nseg] + 255u) / 256u), dim3(256), 0, a,       \
+                              (const unsigned int *)st->index_idx.as<unsigned int>(),                                \
+                              (const unsigned int *)(st->index_idx.as<unsigned int>() + st->nh), deal);             \
+        } else if (use32) ABACUS_TRY(filter32(first, count));                                                               \
         else                                                                                                         \
             ABACUS_LAUNCH("hod_filter", hod_filter, dim3(count), dim3(FBLOCK), 0, a, first, p->want_LRG, p->want_ELG, \
                           p->want_QSO, p->enable_ranks, need_env, need_shear, F);                                    \
@@ -2495,7 +2630,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     const bool pipe = a.hrec && a.prec && (pipe_opt == 2 || (pipe_opt != 1 && (p->want_ELG || p->want_QSO)));
     const bool sparse_sb = st->sb_tiles == SB_TILES_SPARSE;
 #define EXACT_(PIPE, SBT, first, count) \
-    ABACUS_LAUNCH("hod_exact", (hod_exact<256, PIPE, SBT>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1, lazy_masks ? 1 : 0)
+    ABACUS_LAUNCH("hod_exact", (hod_exact<256, PIPE, SBT>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1, exact_flags)
 #define EXACT(first, count)                                                    \
     if ((count) > 0) {                                                         \
         if (pipe && sparse_sb) EXACT_(true, SB_TILES_SPARSE, first, count);    \
@@ -2528,6 +2663,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     st->have_run = true;
     st->counts_valid = false;
     st->kept_valid = true, st->kept_sb_tiles = st->sb_tiles;   // every mask byte that is set is in a kept list
+    if (!index_mode) st->q_zero = false;                        // the streaming filter left its counts in q_count
     return 0;
 }
 
@@ -2559,6 +2695,10 @@ int abacus_hod_counts(abacus_hod_state *st, int64_t counts[6]) {
 int abacus_hod_candidates(abacus_hod_state *st, int64_t out[2]) {
     ABACUS_ENTER();
     if (!st || !st->have_run || !out) return fail("abacus_hod_candidates: populate has not been called");
+    if (st->last_cand[0] >= 0) {   // index path: the host dealt them out (the counters are zero again)
+        out[0] = st->last_cand[0], out[1] = st->last_cand[1];
+        return 0;
+    }
     const int nt = st->ntile_c + st->ntile_s;
     std::vector<int> q((size_t)std::max(nt, 1));
     HIP_TRY(hipMemcpyAsync(q.data(), st->q_count, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, stream()));
@@ -2648,6 +2788,7 @@ int abacus_hod_free(abacus_hod_state *st) {
     for (int t = 0; t < 3; t++) (void)st->out[t].release();
     (void)st->shadow.release();
     (void)st->keys.release();
+    (void)st->index_idx.release(), (void)st->index_scratch.release(), (void)st->index_tmp.release(), (void)st->index_last.release();
     (void)st->hrec.release(), (void)st->prec.release();
     delete st;
     return 0;

@@ -129,6 +129,23 @@ int sort_pairs(Tmp &t, const K *keys_in, K *keys_out, const unsigned int *val_in
 
 }  // namespace
 
+namespace abacus {
+// stable ascending sort of 16-bit keys carrying 32-bit values (the mass-bin index of the HOD filter keys, hod.hip)
+int sort_pairs_u16(const unsigned short *keys_in, unsigned short *keys_out, const unsigned int *val_in, unsigned int *val_out,
+                   int64_t n, DevBuf &tmp) {
+    if (n <= 0) return 0;
+    if (n > 0x7fffffff) return fail("sort_pairs_u16: too many elements");
+    size_t bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, val_in, val_out, (int)n, 0, 16, stream()));
+    ABACUS_TRY(tmp.reserve(std::max<size_t>(bytes, 16)));
+    prof_begin("hod_index_sort");
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, keys_in, keys_out, val_in, val_out, (int)n, 0, 16, stream());
+    prof_end("hod_index_sort");
+    HIP_TRY(e);
+    return 0;
+}
+}  // namespace abacus
+
 extern "C" {
 
 int abacus_argsort_i64(const int64_t *keys, int64_t n, int64_t *order) {

@@ -99,13 +99,21 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     counts = st.wait_counts()
     ngal = int(np.sum(counts))
     _lib.profile_enable(False)
-    warm = {k: ms / n for k, (ms, n) in _lib.profile_get().items() if n}
-    launches = {k: n / max(args.warmup, 1) for k, (ms, n) in _lib.profile_get().items() if n}
+    wprof = _lib.profile_get()
+    # one-off work that only happens from the second populate on (the mass-sorted key index of the sparse mixes) is staging too
+    index_names = ('hod_index_keys', 'hod_index_sort', 'hod_index_last')
+    stage_ms += sum(ms for k, (ms, n) in wprof.items() if n and k in index_names)
+    STEP = ('hod_filter', 'hod_deal', 'hod_exact', 'hod_emit')
+    warm = {k: ms / n for k, (ms, n) in wprof.items() if n and k not in index_names}
+    launches = {k: n / max(args.warmup, 1) for k, (ms, n) in wprof.items() if n and k not in index_names}
+    if 'hod_deal' in warm and 'hod_filter' in warm:   # the warm-up's first populate still streamed the keys
+        del warm['hod_filter'], launches['hod_filter']
+        launches['hod_deal'] = 1.0
     cand = st.candidates()
 
     # timed region: HIP events only around the dominant kernel (a pair of event records per launch costs a few
     # microseconds, which is not negligible against a 0.1-ms step); the other kernels' durations are the warm-up's
-    dom_name = max((k for k in warm if k.startswith('hod_filter')), key=lambda k: warm[k], default=None)
+    dom_name = max((k for k in warm if k in STEP), key=lambda k: warm[k] * launches.get(k, 1.0), default=None)
     _lib.profile_reset()
     _lib.profile_select(dom_name)
     _lib.profile_enable(True)
@@ -158,6 +166,8 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     # roofline of the dominant kernel: algorithmic bytes of the layout it streams / HIP-event duration
     bh, bp = filter_bytes_per_object(tracers, enable_ranks)
     step_bytes = bh * nh + bp * npart + 152.0 * ngal     # + gather 88 B and write 64 B per galaxy
+    if 'hod_deal' in warm:
+        step_bytes = 6.0 * (cand[0] + cand[1]) + 130.0 * (cand[0] + cand[1]) + 192.0 * ngal   # index path: no key stream
     kern = dict(warm)
     kern.update({k: (ms / n) for k, (ms, n) in prof.items() if n})
     out['kernels_ms'] = {k: round(v, 5) for k, v in kern.items()}   # per launch
@@ -166,17 +176,30 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     out['galaxies'] = {'centrals': [int(c) for c in counts[:3]], 'satellites': [int(c) for c in counts[3:]]}
     out['stage_ms'] = round(stage_ms, 4)
     if dom_name:
-        fbytes = bh * nh + bp * npart
+        # algorithmic bytes of one launch of the dominant kernel, in the layout it reads: the filter
+        # streams the keys (+ masks); hod_exact gathers one 128-B record line + a 2-B queue entry per candidate; hod_emit one
+        # record line per galaxy and writes its 64 B; hod_deal reads a 4-B index and writes a 2-B queue entry per candidate
+        ncand = float(cand[0] + cand[1])
+        per_launch = {'hod_filter': bh * nh + bp * npart, 'hod_deal': 6.0 * ncand,
+                      'hod_exact': 130.0 * ncand / max(launches.get('hod_exact', 1.0), 1.0), 'hod_emit': 192.0 * ngal}
+        fbytes = per_launch[dom_name]
         ach = fbytes / (kern[dom_name] * 1e-3) / 1e9
         c2 = (nh, npart) == (10_000_000, 10_000_000) and list(tracers) == ['LRG']
         out['roofline'] = {'bound': 'hbm', 'kernel': dom_name, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                            'frac': ach / HBM_PEAK_GBS,
                            'traffic': pmc_traffic('hod', dom_name) if c2 else None,
                            'algorithmic_bytes': fbytes,
-                           'layout': f'packed filter keys built at staging ({bh:.0f} B per halo + {bp:.0f} B per particle: a 2-B key = mass bin + a '
-                                     '9-bit code of a lower bound of random / weight; + 1 B of keep mask zeroed for mixes with ELG / QSO); the float64 reference layout (SURVEY.md 8d: 40 B per object) is read '
-                                     'only for the candidates; keys, float32 shadows and packed records are built once per catalogue '
-                                     '(`stage_ms`, outside the timed region), the keys again after a reseed',
+                           'layout': {
+                               'hod_filter': f'packed filter keys built at staging ({bh:.0f} B per halo + {bp:.0f} B per particle: a 2-B key = mass bin + a '
+                                             '9-bit code of a lower bound of random / weight; + 1 B of keep mask zeroed for mixes with ELG / QSO); the float64 '
+                                             'reference layout (SURVEY.md 8d: 40 B per object) is read only for the candidates',
+                               'hod_deal': 'mass-sorted key index: 4-B index read + 2-B queue entry written per candidate',
+                               'hod_exact': 'no key stream in the timed step (mass-sorted key index of the sparse mixes: the candidates are prefixes of '
+                                            'the index, dealt to the tiles by hod_deal): the dominant kernel gathers one 128-B packed record line + a 2-B '
+                                            'queue entry per candidate - a launch of a few hundred thousand dependent gathers, latency- not bandwidth-bound',
+                               'hod_emit': 'one 128-B packed record line gathered and 64 B of columns written per galaxy'}[dom_name] +
+                                         '; keys, index, float32 shadows and packed records are built once per catalogue (`stage_ms`, outside the timed '
+                                         'region), keys and index again after a reseed',
                            'whole_step_GBs': step_bytes / (dt / args.steps) / 1e9,
                            'whole_step_frac': step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
     st.free()
