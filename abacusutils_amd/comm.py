@@ -252,9 +252,60 @@ class RcclComm:
         return rpos, rw
 
 
+class FileComm:
+    """barrier and scalar all-reduce through files of the rendezvous directory: what a leg WITHOUT a data-path collective
+    (the sharded HOD: every rank populates its own shard) falls back to when the RCCL communicator cannot be created -
+    its throughput does not depend on the transport, only the start barrier and the max over the ranks' timings do.
+    Each call is one round: every rank writes `<key>.<round>.<rank>`, polls for the others, and reads their values."""
+
+    device = False
+
+    def __init__(self, rank, world, key=None, timeout=180.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        self._base = _rendezvous_path(key) + '.file'
+        self._round = 0
+
+    def _exchange(self, value):
+        self._round += 1
+        mine = f'{self._base}.{self._round}.{self.rank}'
+        tmp = mine + '.tmp'
+        with open(tmp, 'w') as f:
+            f.write(repr(float(value)))
+        os.replace(tmp, mine)
+        vals, t0 = [], time.time()
+        for r in range(self.world):
+            path = f'{self._base}.{self._round}.{r}'
+            while not os.path.exists(path):
+                if time.time() - t0 > self.timeout:
+                    raise TimeoutError(f'rank {self.rank}: rank {r} did not reach round {self._round} of the file barrier')
+                time.sleep(0.0005)
+            vals.append(float(open(path).read()))
+        return vals
+
+    def barrier(self):
+        self._exchange(0.0)
+
+    def all_reduce_float(self, x, op='sum'):
+        vals = self._exchange(x)
+        return max(vals) if op == 'max' else sum(vals)
+
+    def info(self):
+        return dict(rank=self.rank, world=self.world, transport='file barrier (no RCCL communicator)')
+
+    def free(self):
+        import glob
+        for f in glob.glob(f'{self._base}.*.{self.rank}'):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+
+
 class Dist:
     """what bench.py and the sharded drivers need from a process group: rank / world, barrier, max / sum of a scalar.
     world == 1: no communicator at all (no RCCL, no rendezvous)."""
+
+    rccl_error = None
 
     def __init__(self, comm=None):
         self.comm = comm
@@ -263,9 +314,18 @@ class Dist:
         self.local_rank = int(os.environ.get('LOCAL_RANK', str(self.rank)))
 
     @classmethod
-    def from_env(cls, **kw):
+    def from_env(cls, allow_file_fallback=False, **kw):
+        """`allow_file_fallback`: a leg without a data-path collective keeps going on a FileComm when RCCL cannot be
+        initialised (the error is kept in `self.rccl_error` and reported by the caller)"""
         if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-            return cls(RcclComm.from_env(**kw))
+            try:
+                return cls(RcclComm.from_env(**kw))
+            except Exception as e:   # noqa: BLE001 - whatever RCCL / the rendezvous raised
+                if not allow_file_fallback:
+                    raise
+                d = cls(FileComm(int(os.environ.get('RANK', '0')), int(os.environ['WORLD_SIZE']), key=kw.get('key')))
+                d.rccl_error = f'{type(e).__name__}: {e}'
+                return d
         return cls(None)
 
     def barrier(self):

@@ -273,7 +273,10 @@ def cpu_model():
 def run_leg(args):
     """a rank process of an N > 1 run (started by `orchestrate`): RCCL communicator from the environment, one leg"""
     from abacusutils_amd.comm import Dist
-    dist = Dist.from_env()          # binds GPU LOCAL_RANK, file rendezvous, ncclCommInitRank; raises without a HIP device
+    # binds GPU LOCAL_RANK, file rendezvous, ncclCommInitRank; raises without a HIP device.  The HOD leg has no data-path
+    # collective (every rank populates its own shard): if the RCCL communicator cannot be created it still runs, with the
+    # start barrier and the max over the ranks' timings through files, and says so in `rccl`
+    dist = Dist.from_env(allow_file_fallback=(args.leg == 'hod'))
     if args.leg == 'hod':
         out = bench_hod(args, dist)
     else:
@@ -281,6 +284,8 @@ def run_leg(args):
         out = bench_pk_slab(args, dist)
     if dist.comm is not None:
         out['rccl'] = dist.comm.info()
+        if dist.rccl_error:
+            out['rccl']['error'] = dist.rccl_error
     if dist.rank == 0:
         print('BENCH-LEG ' + json.dumps(out), flush=True)
     dist.finish()
