@@ -4,17 +4,26 @@
 // Data layout in HBM: the staged arrays keep the reference's layout (float64 SoA scalars, (N,3) C-order
 // pos/vel, int64 ids) and stay resident across populate calls (the MCMC use case of staging()).
 //
-// Kernels (all HBM-bound streaming, no MFMA - there is no contraction on this path):
-//   hod_filter   central + satellite tiles (2048 objects) in one launch: one pass over the per-halo / per-particle
-//        scalars (16-B coalesced loads); a float32 upper bound of the marker chain proves keep = 0 for the bulk of
-//        the objects, the rest is queued per tile.  Thousands of workgroups for the 256 CUs.
-//   hod_exact    one workgroup per superblock (16 tiles): exact FP64 occupation math (erfc, log10, pow) for the
-//        queued objects only; writes their int8 keep bytes, and - through per-tracer LDS bitmaps and a popcount scan -
-//        the superblock's kept list in index order plus its three counts.
-//   hod_emit     one workgroup per superblock: sums the counters of the superblocks in front of it (a few hundred
+// plus what the kernels actually read: a packed 16-bit filter key per object, packed records of whole 128-B memory lines
+// for the sparse phases, and for LRG-only runs a (mass bin, q code)-sorted key index.
+//
+// Kernels (no MFMA - there is no contraction on this path); a populate is filter | deal -> exact -> emit:
+//   hod_filter_key  streams the keys (2 B per object): `code > threshold[bin]` proves keep = 0 for the bulk of the objects
+//        (an envelope table bounds the marker chain over the bin's masses and the catalogue's environment ranges); the
+//        rest is queued per 2048-object tile.  hod_filter / hod_filter32 are the comparator and fallback filters
+//        (float64 columns of caller-owned catalogues, float32 shadow columns).
+//   hod_deal        LRG alone, from the second populate on: the candidates are prefixes of the sorted key index, found on
+//        the host without reading a key; the kernel hands their indices to the tile queues.
+//   hod_exact       one workgroup per superblock (16 tiles for LRG alone, 8 for mixes with ELG / QSO): a float32 interval
+//        classifier settles a candidate from one packed record line; the reference's float64 chain (erfc, log10, pow) runs
+//        only where the random lies inside a marker's band.  Writes the int8 keep bytes (for LRG alone it first un-keeps
+//        what the previous populate kept - the filter no longer zeroes the masks) and - through per-tracer LDS bitmaps and
+//        a popcount scan - the superblock's kept list in index order plus its three counts.
+//   hod_emit        one workgroup per superblock: sums the counters of the superblocks in front of it (a few hundred
 //        L2-resident ints) for its output offset - satellites start at Ncent, so centrals||satellites land
 //        concatenated (no fast_concatenate pass) - and gathers / writes the kept rows in input order (stable
 //        compaction = the reference's order for any Nthread).
+// What bounds them is in DESIGN.md section 4: the filter the key stream, the sparse phases the 128-B lines they gather.
 // All FP64 arithmetic that reaches an OUTPUT (velocity bias, RSD) is + - * / sqrt in the reference's order,
 // compiled with -ffp-contract=off, so outputs are bit-identical to the CPU; the keep decision compares
 // randoms against erfc/log10/pow-based markers whose last-ulp differences (ocml vs libm) only matter for a
