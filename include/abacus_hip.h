@@ -60,7 +60,8 @@ int abacus_profile_get(const char **names, double *total_ms, int64_t *launches, 
  * environment variables).  Names: fft_nofuse (plain three-pass FFT), fft_hipfft, fft_fuse_small, pk_noxbin (separate last
  * pass + spectrum_bin), tsc_atomic, tsc_noshare, pairs_gen (1 / 2: older pair kernels), hod_nocls, hod_one_stage,
  * hod_f64filter, hod_norec, hod_nokeys, hod_pipe (1 / 2: pipelined hod_exact off / on), hod_eblock (256 / 512 threads per
- * hod_emit workgroup), hod_sbtiles (8 / 16 tiles per superblock), dbg / dbg_fft / dbg_tsc (ablation bit masks).  Default 0 = the production path. */
+ * hod_emit workgroup), hod_sbtiles (8 / 16 tiles per superblock), hod_nolazy / hod_noindex (no lazy
+ * keep masks / no mass-sorted key index), dbg / dbg_fft / dbg_tsc (ablation bit masks).  Default 0 = the production path. */
 int abacus_set_option(const char *name, int value);
 int abacus_get_option(const char *name);
 
