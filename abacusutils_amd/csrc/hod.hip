@@ -848,7 +848,8 @@ __global__ __launch_bounds__(256) void hod_deal(HodPtrs a, const unsigned int *_
     const unsigned int tile = i >> 11, loc = i & (TILE - 1);
     static_assert(TILE == 2048, "tile index arithmetic");
     const int slot = atomicAdd(&a.q_count[(sat ? a.ntile_c : 0) + (int)tile], 1);
-    (sat ? a.queue_s : a.queue_c)[(int64_t)tile * TILE + slot] = (unsigned short)loc;
+    if (slot < TILE)   // always, when the counters started at zero (the host guarantees it; never write past a tile's slice)
+        (sat ? a.queue_s : a.queue_c)[(int64_t)tile * TILE + slot] = (unsigned short)loc;
 }
 
 // The reference's float64 chains as OUT-OF-LINE functions reading the parameters through a pointer (the workgroup's LDS
@@ -2621,7 +2622,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     if ((count) > 0) {                                                                                               \
         if (index_mode) {                                                                                            \
             if (!st->q_zero) HIP_TRY(hipMemsetAsync(st->q_count, 0, (size_t)ntile * sizeof(int), stream()));         \
-            st->q_zero = true;                                                                                       \
+            st->q_zero = false;   /* until hod_exact (which zeroes them again) is enqueued as well */               \
             if (deal.pre[deal.nseg] > 0)                                                                             \
                 ABACUS_LAUNCH("hod_deal", hod_deal, dim3((deal.pre[deal.nseg] + 255u) / 256u), dim3(256), 0, a,       \
                               (const unsigned int *)st->index_idx.as<unsigned int>(),                                \
@@ -2672,7 +2673,7 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     st->have_run = true;
     st->counts_valid = false;
     st->kept_valid = true, st->kept_sb_tiles = st->sb_tiles;   // every mask byte that is set is in a kept list
-    if (!index_mode) st->q_zero = false;                        // the streaming filter left its counts in q_count
+    st->q_zero = index_mode;   // index path: hod_exact zeroed the counters it read; streaming filter: its counts stay in q_count
     return 0;
 }
 
