@@ -78,6 +78,7 @@ def lib():
         L = C.CDLL(str(_SO))
         L.abacus_last_error.restype = C.c_char_p
         L.abacus_get_stream.restype = C.c_void_p
+        L.abacus_power_geometry_ms.restype = C.c_double
         _lib = L
     return _lib
 

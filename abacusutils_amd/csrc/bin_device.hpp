@@ -10,6 +10,7 @@ struct BinArgs {
     int Nk, Nmu, Np;          // Np = number of requested poles with ell != 0 (ell = 0 comes from the wedges)
     const float *kedges2;     // (Nk+1) f32((kedges/dk)^2)  (:217)
     const float *muedges2;    // (Nmu+1) f32(muedges^2)     (:218)
+    const float *h_edges2;    // HOST copy: kedges2 then muedges2 (key of fft_x_bin's cached geometry descriptor), or null
     float polecoef[MAX_POLES][6];   // (2l+1) * P_l as a polynomial in mu^2: sum_m c[m] * (mu^2)^m
     int poledeg[MAX_POLES];         // l/2
     int dbg;                        // ablation switches (ABACUS_DBG): 1 skip binning, 2 skip staging

@@ -86,7 +86,38 @@ __device__ __forceinline__ void dft<8>(float2 (&a)[8]) {
     a[7] = csub(e3, o3);
 }
 
+// 16 = 4 x 4: DFT-4 over n1 of x[4 n1 + n2], twiddles W16^(n2 k1), DFT-4 over n2; X[k1 + 4 k2] lands at 4 k1 + k2
+template <>
+__device__ __forceinline__ void dft<16>(float2 (&a)[16]) {
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft4(a[n2], a[4 + n2], a[8 + n2], a[12 + n2]);
+    const float h = 0.70710678118654752440f, c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
+    auto mul = [](float2 v, float wr, float wi) { return make_float2(v.x * wr - v.y * wi, v.x * wi + v.y * wr); };
+    // element (k1, n2) sits at 4 k1 + n2
+    a[5] = mul(a[5], c1, -s1);                               // W^1
+    a[6] = make_float2(h * (a[6].x + a[6].y), h * (a[6].y - a[6].x));       // W^2 = (h, -h)
+    a[7] = mul(a[7], s1, -c1);                               // W^3
+    a[9] = make_float2(h * (a[9].x + a[9].y), h * (a[9].y - a[9].x));       // W^2
+    a[10] = make_float2(a[10].y, -a[10].x);                  // W^4 = -i
+    a[11] = make_float2(h * (a[11].y - a[11].x), -h * (a[11].x + a[11].y)); // W^6 = (-h, -h)
+    a[13] = mul(a[13], s1, -c1);                             // W^3
+    a[14] = make_float2(h * (a[14].y - a[14].x), -h * (a[14].x + a[14].y)); // W^6
+    a[15] = mul(a[15], -c1, s1);                             // W^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) dft4(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
+    float2 t[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) t[k1 + 4 * k2] = a[4 * k1 + k2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = t[k];
+}
+
 constexpr int radix_of(int L) { return L >= 8 ? 8 : L; }   // greedy radix-8, then one radix-4 or radix-2 pass
+// pass schedule of an N-point transform: 1024 = 8 x 8 x 16 (three trips through LDS instead of the four of 8 x 8 x 8 x 2)
+template <int N>
+constexpr int radix_at(int L) { return (N == 1024 && L == 16) ? 16 : radix_of(L); }
 
 // position of frequency f after the in-place DIF passes (mixed-radix digit reversal)
 template <int N>
@@ -95,7 +126,7 @@ __device__ __forceinline__ int revpos(int f) {
 #pragma unroll
     for (int it = 0; it < 12; it++) {
         if (L == 1) break;
-        const int R = radix_of(L);
+        const int R = radix_at<N>(L);
         pos += (f % R) * (L / R);
         f /= R;
         L /= R;
@@ -143,7 +174,7 @@ __device__ __forceinline__ int freq_of_pos(int pos) {
 #pragma unroll
     for (int it = 0; it < 12; it++) {
         if (L == 1) break;
-        const int R = radix_of(L);
+        const int R = radix_at<N>(L);
         const int d = pos / (L / R);
         pos -= d * (L / R);
         f += d * w;
@@ -195,7 +226,7 @@ __device__ __forceinline__ void dif_last_natural(float2 *lds, int colpitch, int 
 template <int N, int L, int NT = FFT_THREADS, int MAXCOL = 0>
 struct Passes {
     static __device__ __forceinline__ void run(float2 *lds, int colpitch, int ncol, const float2 *tw) {
-        constexpr int R = radix_of(L);
+        constexpr int R = radix_at<N>(L);
         if constexpr (L == R && MAXCOL > 0) {
             dif_last_natural<N, R, NT, MAXCOL>(lds, colpitch, ncol);
         } else {
@@ -263,7 +294,7 @@ __device__ __forceinline__ void dif_last_w(float2 *c, int lane) {
 template <int N, int L, bool UNR = false>
 struct PassesW {
     static __device__ __forceinline__ void run(float2 *c, const float2 *tw, int lane) {
-        constexpr int R = radix_of(L);
+        constexpr int R = radix_at<N>(L);
         if constexpr (L == R) {
             dif_last_w<N, R>(c, lane);
         } else {

@@ -52,6 +52,9 @@ int fft_native_r2c_fused(float *mesh, int n, int pitch_r);   // rows come out in
 int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r);
 bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg);
+double xbin_last_build_ms();
+int xbin_last_gen();
+int xbin_release();
 }  // namespace abacus
 
 namespace {
@@ -612,6 +615,7 @@ struct PowerCtx {
     DevBuf helper_in, helper_tab;          // staging of caller-supplied real grids / small tables (ZCV helpers)
     std::map<int, hipfftHandle> c2r_plans;  // contiguous 3-D C2R (pk_to_xi)
     int phase_n = 0;
+    std::vector<float> edges_host;         // the float32 squared edges of the last prepare_bins (BinArgs::h_edges2)
     // multi-tracer spectra: delta_k of every tracer kept in HBM (abacus_power_field_* / abacus_power_from_fields)
     static constexpr int NFIELD = 8;
     DevBuf field[NFIELD][2];                // [slot][unshifted, half-cell shifted]
@@ -799,8 +803,10 @@ int prepare_bins(double Lbox, const double *kedges, int Nk, const double *muedge
     ABACUS_TRY(g_ctx.edges.reserve(e2.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(g_ctx.edges.p, e2.data(), e2.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));   // e2 is a local
+    g_ctx.edges_host.swap(e2);
     b.kedges2 = g_ctx.edges.as<float>();
     b.muedges2 = b.kedges2 + Nk + 1;
+    b.h_edges2 = g_ctx.edges_host.data();
     const size_t nb = (size_t)Nk * Nmu, npk = (size_t)b.Np * Nk;
     acc_bytes = nb * 8 * 3 + npk * 8;
     ABACUS_TRY(g_ctx.accum.reserve(acc_bytes));
@@ -1361,7 +1367,11 @@ int abacus_expand_poles_to_3d(const double *k_ell, const double *P_ell, int nk, 
     return 0;
 }
 
+double abacus_power_geometry_ms(void) { return xbin_last_build_ms(); }
+int abacus_power_xbin_generation(void) { return xbin_last_gen(); }
+
 int abacus_power_release(void) {
+    ABACUS_TRY(xbin_release());
     for (auto &kv : g_ctx.plans) (void)hipfftDestroy(kv.second);
     g_ctx.plans.clear();
     for (auto &kv : g_ctx.c2r_plans) (void)hipfftDestroy(kv.second);

@@ -18,8 +18,11 @@
 // x-frequency i = 2f + xh; the row yr holds y-frequency j = 2 (yr mod H) + (yr div H) (fft.hip's permuted order).
 // One wave owns a column through the butterfly passes AND its binning (no workgroup barrier between them); lane l
 // walks 8 (H = 1024) consecutive values of |i|, pairing position f with its mirror.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "common.hpp"
 #include "bin_device.hpp"
@@ -302,20 +305,579 @@ int dispatch_xbin(const float2 *data, const XBinGeom &g, const BinArgs &b, size_
     return fail("fft_x_bin: %d multipoles", b.Np);
 }
 
+
+// =====================================================================================================================
+// Second generation of the binning half: everything about a mode's bin that does not depend on the
+// data is taken out of the hot loop.  For a mesh n and a set of float32 edges (power_spectrum.py:217-218) the bin of a mode
+// is a function of two INTEGERS - kmag2 = i^2 + j^2 + k^2 (exact in float32 below 2^24) and k:
+//   * k bin: the reference's float tests `kmag2 < edges[0]`, `kmag2 >= edges[-1]`, `kmag2 > edges[b+1]` (:246-253) are
+//     tests of the integer against integer thresholds T[e] (floor / ceil of the edges): the extended bin
+//     eb = #{e in 0..Nk : kmag2 > T[e]} is 0 below the first edge, b + 1 in bin b, Nk + 1 beyond the last edge;
+//   * mu bin: mu2 = f32(k^2) * (1 / f32(kmag2)) is non-increasing in kmag2 for a fixed k, so `mu2 > muedges2[m]` (:255)
+//     holds for kmag2 <= U[k][m], one integer per (k, inner edge), found on the host by bisection with the same two
+//     float32 roundings.
+// eb comes from ONE LDS word per mode: the bit pattern of f32(kmag2), shifted, indexes 2^m cells per octave; a cell holds
+// the eb of its smallest integer and the threshold that ends that bin, `eb = word >> 22 + (kmag2 > (word & 0x3fffff))`,
+// exact when no cell spans two edges - checked per cell on the host, m = 6..10, and then for EVERY mode of the mesh
+// against the float tests by xbin_geometry on the device.  That kernel also yields N_mode and sum |k| of every bin, which
+// depend on (n, edges) alone: the descriptor is cached per (n, edges) and the hot kernel accumulates only w * P and its
+// two mu moments - no counts, no k sums, no square root, no walk along the edges.
+struct XDesc {
+    const unsigned int *lut;   // (ncell) eb << 22 | min(T[eb], 2^22 - 1)
+    const int *U;              // (kzlen, ustride): largest kmag2 with mu2 > muedges2[m + 1], m = 0 .. Nmu-2; -1: none
+    int ncell, sh, off, ustride;
+    int vtop;                  // T[Nk]: every kmag2 above it lies beyond the last edge
+    const unsigned long long *cnt;   // (Nk * Nmu) N_mode
+    const double *ksum;              // (Nk * Nmu) sum of w * sqrt(kmag2)
+};
+
+constexpr int XD_USTRIDE = 8;            // mu thresholds kept per kz (Nmu <= 8 on this path)
+constexpr int XD_TMASK = 0x3fffff;
+
+// vf1 = max(f32(kmag2), 1): kmag2 = 0 (the DC mode) shares the cell of kmag2 = 1; lut0 = lut - off; the table covers every
+// kmag2 of the mesh, so the index needs no clamp
+__device__ __forceinline__ int xd_eb(const unsigned int *lut0, int sh, int v, float vf1) {
+    const unsigned int w = lut0[__float_as_uint(vf1) >> sh];
+    return (int)(w >> 22) + (v > (int)(w & XD_TMASK) ? 1 : 0);
+}
+
+// N_mode, sum |k| and the validation of the descriptor: one wave per (j, k) column, lanes over |i| (both signs at once)
+__global__ __launch_bounds__(256) void xbin_geometry(int n, int Nk, int Nmu, const float *__restrict__ ke,
+                                                     const float *__restrict__ me, XDesc d,
+                                                     unsigned long long *__restrict__ cnt, double *__restrict__ ksum,
+                                                     int *__restrict__ flag) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int nb = Nk * Nmu;
+    double *hk = reinterpret_cast<double *>(smem);
+    unsigned int *hc = reinterpret_cast<unsigned int *>(hk + nb);
+    for (int q = threadIdx.x; q < nb; q += 256) hk[q] = 0.0, hc[q] = 0u;
+    __syncthreads();
+    const int kzlen = n / 2 + 1, lane = threadIdx.x & 63;
+    const int64_t ncol = (int64_t)n * kzlen;
+    const float klo = ke[0], khi = ke[Nk];
+    int bad = 0;
+    for (int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); col < ncol; col += (int64_t)gridDim.x * 4) {
+        const int j = (int)(col / kzlen), k = (int)(col - (int64_t)j * kzlen);
+        const int jj = j < n / 2 ? j : j - n;
+        const int r2 = jj * jj + k * k;
+        const float k2f = (float)(k * k);
+        const int ck = k == 0 ? 1 : 2;
+        for (int i = lane; i <= n / 2; i += 64) {
+            const int v = r2 + i * i;
+            const float vf = (float)v;
+            int tb = -1;
+            if (!(vf < klo) && !(vf >= khi)) {                       // (:246-250)
+                const int bk = lower_bin(ke, Nk - 1, vf);
+                const float mu2 = v > 0 ? k2f * (1.0f / vf) : 0.f;   // (:240-244)
+                tb = bk * Nmu + lower_bin(me, Nmu - 1, mu2);
+            }
+            const int eb = xd_eb(d.lut - d.off, d.sh, v, fmaxf(vf, 1.f));
+            int bm = 0;
+            for (int m = 0; m < Nmu - 1; m++) bm += v <= d.U[k * d.ustride + m] ? 1 : 0;
+            const int fast = (unsigned int)(eb - 1) < (unsigned int)Nk ? (eb - 1) * Nmu + bm : -1;
+            bad |= fast != tb;
+            if (tb >= 0) {
+                const int mult = (i == 0 || i == n / 2) ? 1 : 2;
+                atomicAdd(&hc[tb], (unsigned int)(ck * mult));
+                atomicAdd(&hk[tb], (double)((float)(ck * mult) * sqrtf(vf)));
+            }
+        }
+    }
+    if (bad) atomicOr(flag, 1);
+    __syncthreads();
+    for (int q = threadIdx.x; q < nb; q += 256)
+        if (hc[q]) {
+            atomicAdd(&cnt[q], (unsigned long long)hc[q]);
+            atomicAdd(&ksum[q], hk[q]);
+        }
+}
+
+// The hot kernel: the transform half is fft_x_bin's; the binning half reads the 16 values of a lane's 8 pairs, then per pair
+// ~25 vector instructions of |delta|^2, cell look-up and threshold compares.  RUNS: a lane keeps the sums of its current
+// bin in registers and adds them to the LDS histogram when the bin changes (fine bins: every step or two; coarse bins:
+// once per column); !RUNS: one LDS atomic per pair and accumulator.  LDS histogram rows eb = 0 and Nk + 1 take what
+// lies outside the edges and are never read.
+template <int H, int C, int NP, bool COMP, int MU, bool RUNS>
+__global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restrict__ data, XBinGeom g, BinArgs b, XDesc d,
+                                                          const float2 *__restrict__ twH) {
+    constexpr int CP = colpitch_of<H>();
+    constexpr int NLD = (H * (C / 2)) / XB_THREADS;
+    static_assert((H * (C / 2)) % XB_THREADS == 0 && wave_local(H), "tile shape");
+    constexpr int RUN = (H / 2) / 64;                     // values of |i| per lane (8, 4): a run shares its pad term
+    static_assert(RUN == 8 || RUN == 4, "run length");
+    constexpr int NPC = NP > 0 ? NP : 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int Nk = b.Nk, Nmu = b.Nmu;
+    const int nrow = Nk + 2, nbx = nrow * Nmu;
+    // LDS: [twiddles H][tile C x CP][sum f64 (Nk+2)*Nmu][mu^2, mu^4 moments f64 2*(Nk+2)][cell words ncell][U kzlen*(MU-1)][W n]
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float2 *lds = tw + H;
+    double *h_sum = reinterpret_cast<double *>(lds + C * CP + 1);
+    double *h_m2 = h_sum + nbx, *h_m4 = h_m2 + nrow;
+    unsigned int *lut = reinterpret_cast<unsigned int *>(h_m4 + nrow);
+    int *Ul = reinterpret_cast<int *>(lut + d.ncell);                 // (kzlen, MU - 1)
+    float *Wl = reinterpret_cast<float *>(Ul + g.kzlen * (MU - 1));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int q = tid; q < H; q += XB_THREADS) tw[q] = twH[q];
+    for (int q = tid; q < nbx; q += XB_THREADS) h_sum[q] = 0.0;
+    for (int q = tid; q < 2 * nrow; q += XB_THREADS) h_m2[q] = 0.0;
+    for (int q = tid; q < d.ncell; q += XB_THREADS) lut[q] = d.lut[q];
+    for (int q = tid; q < g.kzlen * (MU - 1); q += XB_THREADS) Ul[q] = d.U[(q / (MU > 1 ? MU - 1 : 1)) * XD_USTRIDE + q % (MU > 1 ? MU - 1 : 1)];
+    if (COMP)
+        for (int q = tid; q < g.n; q += XB_THREADS) Wl[q] = g.W[q];
+    const int n = g.n;
+    const int ntile_c = (g.kzlen + C - 1) / C;
+    const int64_t S = (int64_t)n * g.pitch_c;
+    const int n_outer = 2 * n;
+    const float inv2 = g.inv_size * g.inv_size;
+    const int sh = d.sh;
+    const unsigned int *lut0 = lut - d.off;
+
+    v4f regs[NLD];
+    auto tile_ptr = [&](int o, int ct) {
+        const int xh = o >= n ? 1 : 0, yr = o - xh * n;
+        return data + (int64_t)xh * H * S + (int64_t)yr * g.pitch_c + ct * C;
+    };
+    auto prefetch = [&](const float2 *p) {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int e = q * XB_THREADS + tid;
+            const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
+            gload16_async(regs[q], p + (int64_t)y * S + c2);
+        }
+    };
+    // registers -> LDS THROUGH the first radix-8 pass: load q of a thread is row tid / (C/2) + q * H/8 of its column pair,
+    // i.e. the eight loads are the inputs r = 0..7 of butterfly j = tid / (C/2) of the first DIF pass (sub-length H):
+    // the staged tile is never written raw and read back (one LDS round trip of the tile less)
+    static_assert(NLD == 8 && H / 8 == XB_THREADS / (C / 2), "the loads of a thread form one radix-8 butterfly per column");
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) touch(regs[q]);
+        const int c2 = (tid % (C / 2)) * 2, jb = tid / (C / 2);
+        float2 u[8], w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) u[q] = make_float2(regs[q].x, regs[q].y), w[q] = make_float2(regs[q].z, regs[q].w);
+        dft<8>(u);
+        dft<8>(w);
+#pragma unroll
+        for (int r = 1; r < 8; r++) {
+            const float2 t = tw[jb * r];
+            u[r] = cmul(u[r], t);
+            w[r] = cmul(w[r], t);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            lds[c2 * CP + padq_strided<H / 8>(jb, r)] = u[r];
+            lds[(c2 + 1) * CP + padq_strided<H / 8>(jb, r)] = w[r];
+        }
+    };
+    const bool xmap = (gridDim.x % 8 == 0) && (n_outer % 8 == 0);
+    const int grp = xmap ? (int)(blockIdx.x & 7) : 0, ostep = xmap ? 8 : 1;
+    const unsigned int qstep = xmap ? (gridDim.x >> 3) : gridDim.x, q0 = xmap ? (blockIdx.x >> 3) : blockIdx.x;
+    const int n_og = n_outer / ostep;
+    const int dg = (int)(qstep / (unsigned int)ntile_c), dc = (int)(qstep % (unsigned int)ntile_c);
+    int og = (int)(q0 / (unsigned int)ntile_c), ct = (int)(q0 % (unsigned int)ntile_c);
+    // lane-only LDS offsets of the RUN pairs (a = RUN lane + s and its mirror)
+    const int a0 = lane * RUN;
+    const int offA = padq(a0);
+    __syncthreads();
+    if (og < n_og) {
+        prefetch(tile_ptr(og * ostep + grp, ct));
+        wait_vmcnt<0>();
+        stage();
+        for (;;) {
+            __syncthreads();
+            const int o_cur = og * ostep + grp, ct_cur = ct;
+            og += dg, ct += dc;
+            if (ct >= ntile_c) ct -= ntile_c, og++;
+            const bool has_next = og < n_og;
+            if (has_next) prefetch(tile_ptr(og * ostep + grp, ct));
+            const int xh = o_cur >= n ? 1 : 0, yr = o_cur - xh * n;
+            const int j = ((yr & (H - 1)) << 1) | (yr >= H ? 1 : 0);
+            const int jj = j < n / 2 ? j : j - n;
+            // mirrors: xh = 1: H-1-a; xh = 0: H-a (a >= 1), a = 0 is its own mirror (i = 0, one mode)
+            const int offB = xh ? padq(H - 1 - a0) : padq(H - 1 - a0) + 1;      // minus s (xh = 0: s >= 1)
+            const int offB0 = xh ? offB : padq((H - a0) & (H - 1));
+            const float mB0 = (!xh && lane == 0) ? 0.f : 1.f;
+#pragma unroll 1
+            for (int c = wave; c < C; c += XB_THREADS / 64) {
+                float2 *col = lds + c * CP;
+                if (!(g.dbg & 1)) {
+                    PassesW<H, H / 8>::run(col, tw, lane);     // the passes behind the one stage() performed
+                    wave_sync();
+                }
+                const int k = ct_cur * C + c;
+                if (k >= g.kzlen || (g.dbg & 2)) continue;
+                const int r2 = jj * jj + k * k;
+                if (r2 > d.vtop) continue;                     // the whole column lies beyond the last edge
+                int Uk[MU > 1 ? MU - 1 : 1];
+#pragma unroll
+                for (int m = 0; m < MU - 1; m++) Uk[m] = Ul[k * (MU - 1) + m];
+                const float k2f = (float)(k * k);
+                const float scale = (k == 0 ? 1.f : 2.f) * inv2;   // weight (:258-262) times f32(1/M)^2 (:1058-1060)
+                float wjk = 1.f;
+                if (COMP) wjk = Wl[j] * Wl[k];
+                float2 vA[RUN], vB[RUN];
+                if (g.dbg & 8) {
+#pragma unroll
+                    for (int s = 0; s < RUN; s++) vA[s] = vB[s] = make_float2(1.f, (float)(a0 + s));
+                } else {
+#pragma unroll
+                    for (int s = 0; s < RUN; s++) vA[s] = col[offA + s];
+                    vB[0] = col[offB0];
+#pragma unroll
+                    for (int s = 1; s < RUN; s++) vB[s] = col[offB - s];
+                }
+                const int i0 = 2 * a0 + xh;
+                int v = r2 + i0 * i0, inc = 4 * i0 + 4;
+                int cur = 0, curk = 0;
+                float sp = 0.f, s2 = 0.f, s4 = 0.f;
+                auto flush = [&]() {
+                    if (!(g.dbg & 4)) {
+                        atomicAdd(&h_sum[cur], (double)sp);
+                        if (NP > 0) {
+                            atomicAdd(&h_m2[curk], (double)s2);
+                            atomicAdd(&h_m4[curk], (double)s4);
+                        }
+                    }
+                };
+                auto bin = [&](int vv, float p, bool first) {
+                    const float vf1 = fmaxf((float)vv, 1.f);            // kmag2 = 0: the cell of 1, mu2 = 0 (:243)
+                    const int eb = xd_eb(lut0, sh, vv, vf1);
+                    int bmu = 0;
+#pragma unroll
+                    for (int m = 0; m < MU - 1; m++) bmu += vv <= Uk[m] ? 1 : 0;
+                    const int tb = (int)__umul24(eb, Nmu) + bmu;
+                    const float pw = p * scale;
+                    float t2 = 0.f, t4 = 0.f;
+                    if (NP > 0) {
+                        const float mu2 = k2f * __builtin_amdgcn_rcpf(vf1);
+                        t2 = pw * mu2;
+                        t4 = t2 * mu2;
+                    }
+                    if (RUNS) {
+                        if (first) {
+                            cur = tb, curk = eb;
+                        } else if (tb != cur) {
+                            flush();
+                            cur = tb, curk = eb;
+                            sp = s2 = s4 = 0.f;
+                        }
+                        sp += pw, s2 += t2, s4 += t4;
+                    } else if ((unsigned int)(eb - 1) < (unsigned int)Nk && !(g.dbg & 4)) {
+                        atomicAdd(&h_sum[tb], (double)pw);
+                        if (NP > 0) {
+                            atomicAdd(&h_m2[eb], (double)t2);
+                            atomicAdd(&h_m4[eb], (double)t4);
+                        }
+                    }
+                };
+#pragma unroll
+                for (int s = 0; s < RUN; s++) {
+                    float pA = vA[s].x * vA[s].x + vA[s].y * vA[s].y;      // get_raw_power (:726)
+                    float pB = vB[s].x * vB[s].x + vB[s].y * vB[s].y;
+                    if (COMP) {                                            // (:1065-1069)
+                        const int fA = a0 + s, fB = xh ? H - 1 - fA : (H - fA) & (H - 1);
+                        const float sA = __builtin_amdgcn_rcpf(Wl[2 * fA + xh] * wjk), sB = __builtin_amdgcn_rcpf(Wl[2 * fB + xh] * wjk);
+                        pA *= sA * sA, pB *= sB * sB;
+                    }
+                    if (s == 0) pB *= mB0;
+                    bin(v, pA + pB, s == 0);
+                    v += inc, inc += 8;
+                }
+                if (!xh && lane == 63) {       // i = n/2 (a = H/2): one mode, last lane of the even half
+                    const float2 q = (g.dbg & 8) ? make_float2(1.f, 1.f) : col[padq(H / 2)];
+                    float p = q.x * q.x + q.y * q.y;
+                    if (COMP) {
+                        const float sc = __builtin_amdgcn_rcpf(Wl[H] * wjk);
+                        p *= sc * sc;
+                    }
+                    bin(r2 + H * H, p, false);
+                }
+                if (RUNS && (unsigned int)(curk - 1) < (unsigned int)Nk) flush();
+            }
+            if (!has_next) break;
+            __syncthreads();
+            wait_vmcnt<0>();
+            stage();
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < Nk * Nmu; q += XB_THREADS) {
+        const double s = h_sum[q + Nmu];           // row eb = bk + 1
+        if (s != 0.0) atomicAdd(&b.g_sum[q], s);
+        if (blockIdx.x == 0) b.g_cnt[q] = d.cnt[q], b.g_ksum[q] = d.ksum[q];
+    }
+    if (NP > 0) {
+        float pc[NPC][3];
+#pragma unroll
+        for (int q = 0; q < NPC; q++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) pc[q][m] = (q < NP && m <= b.poledeg[q]) ? b.polecoef[q][m] : 0.f;
+        for (int bk = tid; bk < Nk; bk += XB_THREADS) {
+            double s0 = 0.0;
+            for (int m = 0; m < Nmu; m++) s0 += h_sum[(bk + 1) * Nmu + m];
+            const double m2 = h_m2[bk + 1], m4 = h_m4[bk + 1];
+#pragma unroll
+            for (int q = 0; q < NPC; q++)
+                if (q < NP) {
+                    const double vq = (double)pc[q][0] * s0 + (double)pc[q][1] * m2 + (double)pc[q][2] * m4;
+                    if (vq != 0.0) atomicAdd(&b.g_pole[q * Nk + bk], vq);
+                }
+        }
+    }
+}
+
+template <int H, int C>
+size_t xbin2_lds_bytes(int n, int Nk, int Nmu, int ncell, bool comp) {
+    const int mu = Nmu <= 1 ? 1 : Nmu <= 4 ? 4 : 8;
+    return (size_t)(H + C * colpitch_of<H>() + 1) * sizeof(float2) + (size_t)(Nk + 2) * Nmu * 8 + (size_t)2 * (Nk + 2) * 8 +
+           (size_t)ncell * 4 + (size_t)(n / 2 + 1) * (mu - 1) * 4 + (comp ? (size_t)n * 4 : 0) + 16;
+}
+
+// ---- descriptor cache (host) ---------------------------------------------------------------------------------------
+struct XDescHost {
+    int n = 0, Nk = 0, Nmu = 0;
+    std::vector<float> e2;     // kedges2 (Nk+1) then muedges2 (Nmu+1)
+    bool ok = false;
+    int ncell = 0, sh = 0, off = 0, vtop = 0;
+    DevBuf buf;                // [cnt u64 nb][ksum f64 nb][lut u32 ncell][U int kzlen*XD_USTRIDE][flag int]
+    uint64_t stamp = 0;
+    double build_ms = 0;
+    XDesc dev() const {
+        XDesc d;
+        const size_t nb = (size_t)Nk * Nmu;
+        unsigned char *p = static_cast<unsigned char *>(buf.p);
+        d.cnt = reinterpret_cast<const unsigned long long *>(p);
+        d.ksum = reinterpret_cast<const double *>(p + nb * 8);
+        d.lut = reinterpret_cast<const unsigned int *>(p + nb * 16);
+        d.U = reinterpret_cast<const int *>(p + nb * 16 + (size_t)ncell * 4);
+        d.ncell = ncell, d.sh = sh, d.off = off, d.ustride = XD_USTRIDE, d.vtop = vtop;
+        return d;
+    }
+};
+std::vector<XDescHost *> g_desc;
+uint64_t g_desc_clock = 0;
+constexpr size_t XD_MAX_CACHED = 8;
+
+int float_bits(float f) {
+    int b;
+    memcpy(&b, &f, 4);
+    return b;
+}
+float bits_float(int b) {
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+// host half of the descriptor: thresholds, cell table, mu thresholds.  false: these edges do not fit the scheme
+bool xdesc_tables(int n, int Nk, int Nmu, const float *ke, const float *me, size_t lds_other, std::vector<unsigned int> &lut,
+                  std::vector<int> &U, int &sh, int &off, int &vtop) {
+    if (Nk + 1 > 1023 || Nmu > XD_USTRIDE || n > 2048) return false;
+    const int64_t vmax = (int64_t)3 * (n / 2) * (n / 2);
+    if (vmax >= XD_TMASK) return false;
+    for (int q = 0; q <= Nk; q++)
+        if (!(ke[q] == ke[q]) || (q && ke[q] < ke[q - 1])) return false;     // NaN or descending edges
+    for (int q = 0; q <= Nmu; q++)
+        if (!(me[q] == me[q])) return false;
+    auto clampi = [](double x) { return (int)std::min(std::max(x, -1.0), 1073741824.0); };
+    std::vector<int> T((size_t)Nk + 2);
+    T[0] = clampi(std::ceil((double)ke[0]) - 1.0);                              // kmag2 < edges[0]   <=> kmag2 <= T[0]
+    for (int e = 1; e < Nk; e++) T[e] = clampi(std::floor((double)ke[e]));      // kmag2 > edges[e]   <=> kmag2 >  T[e]
+    T[Nk] = clampi(std::ceil((double)ke[Nk]) - 1.0);                            // kmag2 >= edges[Nk] <=> kmag2 >  T[Nk]
+    T[Nk + 1] = 2147483647;
+    for (int e = 1; e <= Nk; e++) T[e] = std::max(T[e], T[e - 1]);
+    auto eb_true = [&](int64_t v) { return (int)(std::lower_bound(T.begin(), T.begin() + Nk + 1, (int)std::min<int64_t>(v, 2147483646)) - T.begin()); };
+    vtop = (int)std::min<int64_t>(T[Nk], vmax);
+    if (vtop < 0) vtop = 0;
+    bool found = false;
+    for (int m = 6; m <= 10 && !found; m++) {
+        sh = 23 - m, off = 127 << m;
+        const int ncell = (float_bits((float)vmax) >> sh) - off + 1;     // every kmag2 of the mesh has its cell: no clamp
+        if (lds_other + (size_t)ncell * 4 > 160 * 1024) break;
+        lut.assign(ncell, 0u);
+        bool good = true;
+        for (int c = 0; c < ncell && good; c++) {
+            int64_t vlo = c == 0 ? 0 : (int64_t)std::ceil((double)bits_float((c + off) << sh));
+            int64_t vhi = (int64_t)std::floor((double)bits_float((((c + off + 1) << sh)) - 1));
+            if (vlo > vhi) vhi = vlo;    // a cell without an integer: never looked up
+            const int e0 = eb_true(vlo), e1 = eb_true(vhi);
+            good = e1 - e0 <= 1;
+            lut[c] = ((unsigned int)e0 << 22) | (unsigned int)std::min(std::max(T[e0], 0), XD_TMASK);
+        }
+        found = good;
+    }
+    if (!found) return false;
+    const int kzlen = n / 2 + 1;
+    U.assign((size_t)kzlen * XD_USTRIDE, -1);
+    const int VMAX = 1 << 23;
+    for (int k = 0; k < kzlen; k++) {
+        const float k2f = (float)(k * k);
+        auto above = [&](int v, float edge) { return k2f * (1.0f / (float)v) > edge; };
+        for (int m = 0; m < Nmu - 1; m++) {
+            const float edge = me[m + 1];
+            int u;
+            if (0.f > edge) u = 2147483647;          // mu2 = 0 (kmag2 = 0 included) already lies above
+            else if (!above(1, edge)) u = -1;
+            else if (above(VMAX, edge)) u = 2147483647;
+            else {
+                int lo = 1, hi = VMAX;               // above(lo), !above(hi)
+                while (hi - lo > 1) {
+                    const int mid = lo + (hi - lo) / 2;
+                    (above(mid, edge) ? lo : hi) = mid;
+                }
+                u = lo;
+            }
+            U[(size_t)k * XD_USTRIDE + m] = u;
+        }
+    }
+    return true;
+}
+
+// descriptor of (n, edges): cached; built (tables + xbin_geometry over every mode) on first use
+int xdesc_get(int n, int Nk, int Nmu, const float *h_e2, const float *d_ke, const float *d_me, size_t lds_other, XDescHost **out) {
+    const size_t ne = (size_t)Nk + 1 + Nmu + 1;
+    for (XDescHost *x : g_desc)
+        if (x->n == n && x->Nk == Nk && x->Nmu == Nmu && !memcmp(x->e2.data(), h_e2, ne * 4)) {
+            x->stamp = ++g_desc_clock;
+            *out = x;
+            return 0;
+        }
+    if (g_desc.size() >= XD_MAX_CACHED) {
+        size_t old = 0;
+        for (size_t q = 1; q < g_desc.size(); q++)
+            if (g_desc[q]->stamp < g_desc[old]->stamp) old = q;
+        HIP_TRY(hipStreamSynchronize(stream()));
+        ABACUS_TRY(g_desc[old]->buf.release());
+        delete g_desc[old];
+        g_desc.erase(g_desc.begin() + old);
+    }
+    XDescHost *x = new XDescHost;
+    x->n = n, x->Nk = Nk, x->Nmu = Nmu, x->e2.assign(h_e2, h_e2 + ne), x->stamp = ++g_desc_clock;
+    g_desc.push_back(x);
+    *out = x;
+    std::vector<unsigned int> lut;
+    std::vector<int> U;
+    if (!xdesc_tables(n, Nk, Nmu, h_e2, h_e2 + Nk + 1, lds_other, lut, U, x->sh, x->off, x->vtop)) return 0;   // ok stays false
+    x->ncell = (int)lut.size();
+    const size_t nb = (size_t)Nk * Nmu;
+    if (nb * 12 > 96 * 1024) return 0;
+    const size_t bytes = nb * 16 + lut.size() * 4 + U.size() * 4 + 16;
+    ABACUS_TRY(x->buf.reserve(bytes));
+    unsigned char *p = static_cast<unsigned char *>(x->buf.p);
+    HIP_TRY(hipMemsetAsync(p, 0, bytes, stream()));
+    HIP_TRY(hipMemcpyAsync(p + nb * 16, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemcpyAsync(p + nb * 16 + lut.size() * 4, U.data(), U.size() * 4, hipMemcpyHostToDevice, stream()));
+    int *flag = reinterpret_cast<int *>(p + nb * 16 + lut.size() * 4 + U.size() * 4);
+    const XDesc d = x->dev();
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(xbin_geometry), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nb * 12)));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream()));
+    ABACUS_LAUNCH("xbin_geometry", xbin_geometry, dim3(fft_num_cus() * 4), dim3(256), nb * 12, n, Nk, Nmu, d_ke, d_me, d,
+                  const_cast<unsigned long long *>(d.cnt), const_cast<double *>(d.ksum), flag);
+    HIP_TRY(hipEventRecord(e1, stream()));
+    int bad = 1;
+    HIP_TRY(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));     // lut, U are locals
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(hipEventDestroy(e0));
+    HIP_TRY(hipEventDestroy(e1));
+    x->build_ms = ms;
+    x->ok = bad == 0;
+    return 0;
+}
+
+template <int H, int C, int NP, bool COMP, int MU>
+int launch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const XDesc &d, size_t lds) {
+    const bool runs = option("pk_xbin_pairs") == 0;
+    auto kern = runs ? fft_x_bin2<H, C, NP, COMP, MU, true> : fft_x_bin2<H, C, NP, COMP, MU, false>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 1;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, XB_THREADS, lds));
+    const int64_t ntiles = (int64_t)2 * g.n * ((g.kzlen + C - 1) / C);
+    const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)fft_num_cus() * std::max(per_cu, 1));
+    const float2 *tw = fft_twiddles(H);
+    if (!tw) return -1;
+    ABACUS_LAUNCH("fft_x_bin", kern, dim3(grid), dim3(XB_THREADS), lds, data, g, b, d, tw);
+    return 0;
+}
+
+template <int H, int C>
+int dispatch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const XDesc &d, size_t lds) {
+#define XB2(NP, MU)                                                                  \
+    (g.W ? launch_xbin2<H, C, NP, true, MU>(data, g, b, d, lds) : launch_xbin2<H, C, NP, false, MU>(data, g, b, d, lds))
+#define XB2_MU(NP) (b.Nmu <= 1 ? XB2(NP, 1) : b.Nmu <= 4 ? XB2(NP, 4) : XB2(NP, 8))
+    switch (b.Np) {
+        case 0: return XB2_MU(0);
+        case 1: return XB2_MU(1);
+        case 2: return XB2_MU(2);
+    }
+#undef XB2_MU
+#undef XB2
+    return fail("fft_x_bin: %d multipoles", b.Np);
+}
+
+size_t xbin2_lds_other(int n, int Nk, int Nmu, bool comp) {
+    return n == 2048 ? xbin2_lds_bytes<1024, 8>(n, Nk, Nmu, 0, comp) : xbin2_lds_bytes<512, 16>(n, Nk, Nmu, 0, comp);
+}
+
 }  // namespace
 
 namespace abacus {
 
 // can the fused last pass serve this mesh / histogram?  (n/2-point wave-local transforms: n = 1024, 2048; at most two
-// ell != 0 multipoles of degree <= 4; tile + histogram within the 160 KiB LDS)
-bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp) {
-    if (b.Np > 2) return false;
-    for (int q = 0; q < b.Np; q++)
-        if (b.poledeg[q] > 2) return false;
+// ell != 0 multipoles of degree <= 4; tile + histogram within the 160 KiB LDS).  Second generation (cached geometry
+// descriptor, <= 8 mu bins): builds the descriptor of (n, edges) on first use.
+static bool xbin1_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp) {
     const size_t cap = 160 * 1024;
     if (n == 2048) return xbin_lds_bytes<1024, 8>(n, Nk, Nmu, b.Np, comp) <= cap;
     if (n == 1024) return xbin_lds_bytes<512, 16>(n, Nk, Nmu, b.Np, comp) <= cap;
     return false;
+}
+
+static int xbin2_desc(int n, const BinArgs &b, bool comp, XDescHost **x) {
+    *x = nullptr;
+    if (option("pk_xbin_gen") == 1 || !b.h_edges2 || (n != 1024 && n != 2048) || b.Nmu > XD_USTRIDE) return 0;
+    const size_t other = xbin2_lds_other(n, b.Nk, b.Nmu, comp);
+    if (other + 64 * 4 > 160 * 1024) return 0;
+    ABACUS_TRY(xdesc_get(n, b.Nk, b.Nmu, b.h_edges2, b.kedges2, b.muedges2, other, x));
+    if (!(*x)->ok || other + (size_t)(*x)->ncell * 4 > 160 * 1024) *x = nullptr;
+    return 0;
+}
+
+bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp) {
+    if (b.Np > 2) return false;
+    for (int q = 0; q < b.Np; q++)
+        if (b.poledeg[q] > 2) return false;
+    if (n != 1024 && n != 2048) return false;
+    if (xbin1_supported(n, Nk, Nmu, b, comp)) return true;
+    XDescHost *x = nullptr;
+    return xbin2_desc(n, b, comp, &x) == 0 && x != nullptr;
+}
+
+// milliseconds the geometry pass of the most recently used descriptor took when it was built (bench.py reports it next to
+// the step time: it is paid once per (nmesh, edges))
+double xbin_last_build_ms() {
+    const XDescHost *best = nullptr;
+    for (const XDescHost *x : g_desc)
+        if (!best || x->stamp > best->stamp) best = x;
+    return best ? best->build_ms : 0.0;
+}
+
+static int g_last_gen = 0;
+int xbin_last_gen() { return g_last_gen; }
+
+int xbin_release() {
+    for (XDescHost *x : g_desc) {
+        ABACUS_TRY(x->buf.release());
+        delete x;
+    }
+    g_desc.clear();
+    return 0;
 }
 
 // `mesh` holds the fused transform after its z and y passes (fft_native_r2c_fused_zy); bins |delta_k|^2 of every mode
@@ -324,15 +886,21 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
     XBinGeom g;
     g.n = n, g.kzlen = n / 2 + 1, g.pitch_c = pitch_r / 2, g.inv_size = inv_size, g.W = W_dev, g.dbg = dbg;
     const float2 *data = reinterpret_cast<const float2 *>(mesh);
-    if (n == 2048) {
-        if (((g.kzlen + 7) / 8) * 8 > g.pitch_c) return fail("fft_x_bin: row pitch too small");
-        return dispatch_xbin<1024, 8>(data, g, b, xbin_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, b.Np, W_dev != nullptr));
+    if (n != 2048 && n != 1024) return fail("fft_x_bin: unsupported mesh %d", n);
+    const int C = n == 2048 ? 8 : 16;
+    if (((g.kzlen + C - 1) / C) * C > g.pitch_c) return fail("fft_x_bin: row pitch too small");
+    const bool comp = W_dev != nullptr;
+    XDescHost *x = nullptr;
+    ABACUS_TRY(xbin2_desc(n, b, comp, &x));
+    g_last_gen = x ? 2 : 1;
+    if (x) {
+        const XDesc d = x->dev();
+        if (n == 2048) return dispatch_xbin2<1024, 8>(data, g, b, d, xbin2_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, d.ncell, comp));
+        return dispatch_xbin2<512, 16>(data, g, b, d, xbin2_lds_bytes<512, 16>(n, b.Nk, b.Nmu, d.ncell, comp));
     }
-    if (n == 1024) {
-        if (((g.kzlen + 15) / 16) * 16 > g.pitch_c) return fail("fft_x_bin: row pitch too small");
-        return dispatch_xbin<512, 16>(data, g, b, xbin_lds_bytes<512, 16>(n, b.Nk, b.Nmu, b.Np, W_dev != nullptr));
-    }
-    return fail("fft_x_bin: unsupported mesh %d", n);
+    if (!xbin1_supported(n, b.Nk, b.Nmu, b, comp)) return fail("fft_x_bin: histogram does not fit");
+    if (n == 2048) return dispatch_xbin<1024, 8>(data, g, b, xbin_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, b.Np, comp));
+    return dispatch_xbin<512, 16>(data, g, b, xbin_lds_bytes<512, 16>(n, b.Nk, b.Nmu, b.Np, comp));
 }
 
 }  // namespace abacus

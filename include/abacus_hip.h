@@ -258,8 +258,15 @@ int abacus_power_from_fields(int slot_a, int slot_b, const float *W_host, const 
                              int Nmu, const int64_t *poles, int Np, float *power, int64_t *N_mode, float *binned_poles,
                              int64_t *N_mode_poles, float *k_avg);
 int abacus_power_fields_release(void);
-/* releases cached FFT plans / work meshes */
+/* releases cached FFT plans / work meshes / the cached binning geometry of fft_x_bin */
 int abacus_power_release(void);
+/* milliseconds of the one-off geometry pass behind the most recent fused last pass (abacus_power_from_particles[_dev],
+ * auto power, non-interlaced, nmesh 1024 / 2048): N_mode, k_avg and the (k, mu) bin of every mode depend on (nmesh, edges)
+ * alone (power_spectrum.py:233-256), so they are computed once per (nmesh, edges) and cached; 0 if none was built */
+double abacus_power_geometry_ms(void);
+/* which fused last pass served the most recent spectrum: 2 = cached-geometry kernel, 1 = first generation (bin walk in the
+ * kernel: more than 8 mu bins, edges the cell table cannot resolve, option pk_xbin_gen = 1), 0 = none yet */
+int abacus_power_xbin_generation(void);
 
 
 /* ---------------------------------------------------------------- multi-GPU slab building blocks ------- */

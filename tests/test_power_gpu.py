@@ -436,19 +436,34 @@ def test_c3_full_size_against_oracle():
 @pytest.mark.parametrize('nmesh,comp', [(1024, False), (1024, True)])
 def test_fused_last_pass_matches_spectrum_bin(options, nmesh, comp):
     """fft_x_bin (last FFT pass + binning in one kernel, xbin.hip) against the x pass + spectrum_bin on the same particles:
-    identical |delta_k|^2 per mode, so the float64 sums agree to rounding"""
+    identical |delta_k|^2 per mode, so the float64 sums agree to rounding.  Three forms of the fused pass: the
+    cached-geometry kernel with register runs (production) and with one LDS atomic per pair, and the first-generation
+    kernel that walks the edges itself (also what more than 8 mu bins fall back to)."""
+    from abacusutils_amd import _lib
     from abacusutils_amd.analysis.power_spectrum import calc_power
     pos = synth.synth_positions(3_000_000, 1000.0, seed=83, clustered=True)
     w = np.random.default_rng(3).random(len(pos), dtype=np.float32) + np.float32(0.5)
+    gen = _lib.lib().abacus_power_xbin_generation
     for kw in (dict(kbins=64, mubins=4, poles=[0, 2, 4]), dict(kbins=200, mubins=None, poles=[0, 2]),
-               dict(kbins=48, mubins=7, poles=[]), dict(kbins=32, mubins=3, poles=[4], logk=True, k_max=1.5)):
+               dict(kbins=48, mubins=7, poles=[]), dict(kbins=32, mubins=3, poles=[4], logk=True, k_max=1.5),
+               dict(kbins=500, mubins=2, poles=[0, 2, 4], k_max=np.pi * nmesh / 1000.0 + 1e-6),     # the bench's 2-dk bins
+               dict(kbins=np.array([0.02, 0.021, 0.0215, 0.3, 0.31, 2.0, 9.0]), mubins=np.array([0.0, 0.05, 0.5, 0.51, 1.0]),
+                    poles=[2]),                                                                     # ragged edges, past the corner
+               dict(kbins=40, mubins=12, poles=[0, 2])):                                            # > 8 mu bins: generation 1
         kw = dict(kw, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=False, w=w)
-        a = calc_power(pos.copy(), 1000.0, **kw)
         options.set('pk_noxbin', 1)
         b = calc_power(pos.copy(), 1000.0, **kw)
         options.set('pk_noxbin', 0)
-        np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
-        np.testing.assert_allclose(a['power'], b['power'], rtol=2e-6, atol=1e-7 * np.abs(b['power']).max())
-        np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)
-        if kw['poles']:
-            np.testing.assert_allclose(a['poles'], b['poles'], rtol=2e-6, atol=2e-7 * np.abs(b['power']).max())
+        nmu = np.asarray(b['N_mode']).shape[1] if np.asarray(b['N_mode']).ndim > 1 else 1
+        for name, opts, want_gen in (('runs', {}, 2), ('pairs', {'pk_xbin_pairs': 1}, 2), ('gen1', {'pk_xbin_gen': 1}, 1)):
+            for k, v in opts.items():
+                options.set(k, v)
+            a = calc_power(pos.copy(), 1000.0, **kw)
+            for k in opts:
+                options.set(k, 0)
+            assert gen() == (want_gen if nmu <= 8 else 1), (name, kw['kbins'] if np.isscalar(kw['kbins']) else 'edges')
+            np.testing.assert_array_equal(a['N_mode'], b['N_mode'], err_msg=name)
+            np.testing.assert_allclose(a['power'], b['power'], rtol=2e-6, atol=1e-7 * np.abs(b['power']).max(), err_msg=name)
+            np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6, err_msg=name)
+            if kw['poles']:
+                np.testing.assert_allclose(a['poles'], b['poles'], rtol=2e-6, atol=2e-7 * np.abs(b['power']).max(), err_msg=name)
