@@ -40,7 +40,7 @@ namespace {
 // transforms each, over rows [0, n/2) and [n/2, n): half the rows per LDS tile, twice the columns - 128-B row
 // segments at n = 2048, which the memory system serves at the in-place floor instead of 3.4 TB/s.
 // Row r of either half then holds frequency 2 (r mod n/2) + (r div n/2) along that axis.
-template <int N, int B, bool FUSE>
+template <int N, int B, bool FUSE, bool F1 = true>
 __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
                                                          const float2 *__restrict__ twN, const float2 *__restrict__ tw2N,
                                                          int dbg) {
@@ -75,9 +75,17 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
             gload16_async(regs[q], mesh + row_of(tile, r) * pitch_r + 2 * m);
         }
     };
+    // FUSE1: the eight 16-B loads of a lane are elements 2 lane (+1) + 128 q of its wave's row = two butterflies of the
+    // first radix-8 pass (stage_pass1); the passes that follow start at sub-length N/8
+    constexpr bool FUSE1 = F1 && WLS && N == 1024 && NLD == 8;
     auto stage = [&]() {   // registers -> LDS: two complex (= four consecutive reals) per 16-B load
 #pragma unroll
         for (int q = 0; q < NLD; q++) touch(regs[q]);
+        if constexpr (FUSE1) {
+            float2 *c = lds + (tid >> 6) * CP;
+            stage_pass1<N, NLD, N / 8>(regs, c, c, 2 * (tid & 63), 2 * (tid & 63) + 1, tw);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int e = WLS ? (tid >> 6) * (N / 2) + q * 64 + (tid & 63) : q * Z_THREADS + tid;
@@ -92,6 +100,7 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
     int64_t tile = blockIdx.x;
     if (tile >= ntiles) return;
     prefetch(tile);
+    __syncthreads();     // the twiddle table, which a fused first pass reads while staging
     wait_vmcnt<0>();
     stage();
     // stores every thread issues per full tile (threads with one more only wait longer): vmcnt(that) = loads landed
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
         if (!(dbg & 1)) {
             if constexpr (wave_local(N)) {   // one row per wave at a time; the write-back below reads across rows
 #pragma unroll 1
-                for (int r = tid >> 6; r < nb; r += Z_THREADS / 64) PassesW<N, N>::run(lds + r * CP, tw, tid & 63);
+                for (int r = tid >> 6; r < nb; r += Z_THREADS / 64) PassesW<N, FUSE1 ? N / 8 : N>::run(lds + r * CP, tw, tid & 63);
                 __syncthreads();
             } else {
                 Passes<N, N, Z_THREADS, B>::run(lds, CP, nb, tw);
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
 // ---- strided pass: C adjacent columns x N elements (element stride S complex), in place ----------------------
 // tile t -> (outer index o = t / ntile_c, column tile ct = t % ntile_c); first element at o*outer_stride + ct*C.
 // Persistent workgroups with the next tile prefetched into registers, as above.
-template <int N, int C>
+template <int N, int C, bool F1 = true>
 __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ data, int64_t S, int ntile_c,
                                                         int64_t ntiles, int64_t outer_stride, int64_t outer_mod,
                                                         int64_t outer_stride2, const float2 *__restrict__ twN, int dbg) {
@@ -227,9 +236,17 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
             gload16_async(regs[q], g + (int64_t)y * S + c2);
         }
     };
+    // FUSE1: load q of a thread is row tid / (C/2) + q * RS of its column pair: whole butterflies of the first radix-8 pass
+    constexpr int RS = FFT_THREADS / (C / 2);
+    constexpr bool FUSE1 = F1 && wave_local(N) && WHOLE && (RS == N / 8 || RS == N / 16) && NLD * RS == N;
     auto stage = [&]() {
 #pragma unroll
         for (int q = 0; q < NLD; q++) touch(regs[q]);
+        if constexpr (FUSE1) {
+            const int c2 = (tid % (C / 2)) * 2, j0 = tid / (C / 2);
+            stage_pass1<N, NLD, RS>(regs, lds + c2 * CP, lds + (c2 + 1) * CP, j0, j0, tw);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int e = q * FFT_THREADS + tid;
@@ -254,6 +271,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
     if (og >= n_og) return;
     float2 *gcur = tile_ptr(og * ostep + grp, ct);
     prefetch(gcur);
+    __syncthreads();     // the twiddle table, which a fused first pass reads while staging
     wait_vmcnt<0>();
     stage();
     for (;;) {
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
         if (!(dbg & 1)) {
             if constexpr (wave_local(N)) {
 #pragma unroll 1
-                for (int c = tid >> 6; c < C; c += FFT_THREADS / 64) PassesW<N, N>::run(lds + c * CP, tw, tid & 63);
+                for (int c = tid >> 6; c < C; c += FFT_THREADS / 64) PassesW<N, FUSE1 ? N / 8 : N>::run(lds + c * CP, tw, tid & 63);
                 __syncthreads();
             } else {
                 Passes<N, N>::run(lds, CP, C, tw);
@@ -334,33 +352,48 @@ int get_tables(int n, Tables **out) {
     return 0;
 }
 
-template <int N, int B, bool FUSE = false>
-int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
+template <int N, int B, bool FUSE, bool F1>
+int launch_z1(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
     const size_t lds = (size_t)(2 * N + 2 + B * colpitch_of<N>()) * sizeof(float2);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_z_r2c<N, B, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+    auto kern = fft_z_r2c<N, B, FUSE, F1>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t ntiles = FUSE ? (int64_t)N * N : ceil_div(nrows, B);
     int per_cu = 1;   // persistent grid = exactly the resident workgroups (a larger grid would run in two uneven waves)
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_z_r2c<N, B, FUSE>, Z_THREADS, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, Z_THREADS, lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
-    ABACUS_LAUNCH("fft_z_r2c", (fft_z_r2c<N, B, FUSE>), dim3(grid), dim3(Z_THREADS), lds, mesh, nrows,
-                  pitch_r, t->twHalf.as<float2>(), t->tw2.as<float2>(), option("dbg_fft"));
+    ABACUS_LAUNCH("fft_z_r2c", kern, dim3(grid), dim3(Z_THREADS), lds, mesh, nrows, pitch_r, t->twHalf.as<float2>(),
+                  t->tw2.as<float2>(), option("dbg_fft"));
     return 0;
 }
+// option fft_nofuse1 (A/B): 1 = z pass, 2 = column passes stage the raw tile and run every radix pass from LDS
+template <int N, int B, bool FUSE = false>
+int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
+    if constexpr (N == 1024)
+        if (option("fft_nofuse1") & 1) return launch_z1<N, B, FUSE, false>(mesh, nrows, pitch_r, t);
+    return launch_z1<N, B, FUSE, true>(mesh, nrows, pitch_r, t);
+}
 
+template <int N, int C, bool F1>
+int launch_cols1(const char *name, float2 *data, int64_t S, int ntile_c, int64_t outer, int64_t outer_stride, const float2 *tw,
+                 int64_t outer_mod, int64_t outer_stride2) {
+    const size_t lds = (size_t)(N + C * colpitch_of<N>()) * sizeof(float2);
+    auto kern = fft_cols<N, C, F1>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t ntiles = outer * ntile_c;
+    int per_cu = 1;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, FFT_THREADS, lds));
+    const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
+    ABACUS_LAUNCH(name, kern, dim3(grid), dim3(FFT_THREADS), lds, data, S, ntile_c, ntiles, outer_stride, outer_mod,
+                  outer_stride2, tw, option("dbg_fft"));
+    return 0;
+}
 template <int N, int C>
 int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t outer, int64_t outer_stride, const float2 *tw,
                 int64_t outer_mod = (int64_t)1 << 40, int64_t outer_stride2 = 0) {
-    const size_t lds = (size_t)(N + C * colpitch_of<N>()) * sizeof(float2);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    const int64_t ntiles = outer * ntile_c;
-    int per_cu = 1;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fft_cols<N, C>, FFT_THREADS, lds));
-    const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
-    ABACUS_LAUNCH(name, (fft_cols<N, C>), dim3(grid), dim3(FFT_THREADS), lds, data, S, ntile_c, ntiles,
-                  outer_stride, outer_mod, outer_stride2, tw, option("dbg_fft"));
-    return 0;
+    if constexpr (wave_local(N))
+        if (option("fft_nofuse1") & 2)
+            return launch_cols1<N, C, false>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2);
+    return launch_cols1<N, C, true>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2);
 }
 
 template <int N, int C, int BZ>

@@ -305,5 +305,38 @@ struct PassesW {
 };
 constexpr bool wave_local(int N) { return N == 512 || N == 1024; }   // the production sizes (n = 1024, 2048)
 
+// Registers -> LDS THROUGH the first radix-8 DIF pass (sub-length N): when load q of a thread is element j0 + q * RS of
+// its sequence (RS = N/8: one butterfly, 8 loads; RS = N/16: two butterflies, 16 loads, q = 2 r + b), the loads of a
+// thread ARE the inputs r = 0..7 of butterfly j = j0 + b * RS of that pass.  Each 16-B load carries two sequences
+// (.xy -> cA at index offset jA, .zw -> cB at jB: two columns of a column tile, or two adjacent elements of a row).
+// The tile is never staged raw and read back: one LDS round trip less; the remaining passes are PassesW<N, N/8>.
+template <int N, int NLD, int RS>
+__device__ __forceinline__ void stage_pass1(v4f (&regs)[NLD], float2 *cA, float2 *cB, int jA, int jB, const float2 *tw) {
+    constexpr int LR = N / 8, NB = LR / RS;
+    static_assert(NB * RS == LR && NLD == 8 * NB && (NB == 1 || NB == 2), "loads of a thread = whole radix-8 butterflies");
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        float2 u[8], w[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            u[r] = make_float2(regs[r * NB + b].x, regs[r * NB + b].y);
+            w[r] = make_float2(regs[r * NB + b].z, regs[r * NB + b].w);
+        }
+        dft<8>(u);
+        dft<8>(w);
+        const int ja = jA + b * RS, jb = jB + b * RS;
+#pragma unroll
+        for (int r = 1; r < 8; r++) {
+            u[r] = cmul(u[r], tw[ja * r]);
+            w[r] = cmul(w[r], tw[jb * r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            cA[padq_strided<LR>(ja, r)] = u[r];
+            cB[padq_strided<LR>(jb, r)] = w[r];
+        }
+    }
+}
+
 template <int N>
 constexpr int colpitch_of() { return N + (N >> PADSHIFT) + 1; }   // odd: adjacent columns fall into different banks
