@@ -40,7 +40,7 @@ namespace {
 // transforms each, over rows [0, n/2) and [n/2, n): half the rows per LDS tile, twice the columns - 128-B row
 // segments at n = 2048, which the memory system serves at the in-place floor instead of 3.4 TB/s.
 // Row r of either half then holds frequency 2 (r mod n/2) + (r div n/2) along that axis.
-template <int N, int B, bool FUSE, bool F1 = true>
+template <int N, int B, bool FUSE, int F1 = 1>
 __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
                                                          const float2 *__restrict__ twN, const float2 *__restrict__ tw2N,
                                                          int dbg) {
@@ -77,13 +77,25 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
     };
     // FUSE1: the eight 16-B loads of a lane are elements 2 lane (+1) + 128 q of its wave's row = two butterflies of the
     // first radix-8 pass (stage_pass1); the passes that follow start at sub-length N/8
-    constexpr bool FUSE1 = F1 && WLS && N == 1024 && NLD == 8;
+    constexpr bool FUSE1 = (F1 & 1) && WLS && N == 1024 && NLD == 8;
+    constexpr bool REGTW = (F1 & 2) && WLS && N == 1024;   // twiddles of the second (and a fused first) pass as lane constants
+    float2 tw1a[8], tw1b[8], tw2r[8];
+    if constexpr (REGTW) {
+#pragma unroll
+        for (int r = 1; r < 8; r++) {
+            tw1a[r] = twN[(2 * (tid & 63)) * r];
+            tw1b[r] = twN[(2 * (tid & 63) + 1) * r];
+            tw2r[r] = twN[((tid & 63) % (N >= 64 ? N / 64 : 1)) * r * 8];
+        }
+        tw1a[0] = tw1b[0] = tw2r[0] = make_float2(1.f, 0.f);
+    }
     auto stage = [&]() {   // registers -> LDS: two complex (= four consecutive reals) per 16-B load
 #pragma unroll
         for (int q = 0; q < NLD; q++) touch(regs[q]);
         if constexpr (FUSE1) {
             float2 *c = lds + (tid >> 6) * CP;
-            stage_pass1<N, NLD, N / 8>(regs, c, c, 2 * (tid & 63), 2 * (tid & 63) + 1, tw);
+            if constexpr (REGTW) stage_pass1_regtw<N>(regs, c, c, 2 * (tid & 63), 2 * (tid & 63) + 1, tw1a, tw1b);
+            else stage_pass1<N, NLD, N / 8>(regs, c, c, 2 * (tid & 63), 2 * (tid & 63) + 1, tw);
             return;
         }
 #pragma unroll
@@ -117,7 +129,16 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
         if (!(dbg & 1)) {
             if constexpr (wave_local(N)) {   // one row per wave at a time; the write-back below reads across rows
 #pragma unroll 1
-                for (int r = tid >> 6; r < nb; r += Z_THREADS / 64) PassesW<N, FUSE1 ? N / 8 : N>::run(lds + r * CP, tw, tid & 63);
+                for (int r = tid >> 6; r < nb; r += Z_THREADS / 64) {
+                    float2 *c = lds + r * CP;
+                    if constexpr (REGTW) {
+                        if constexpr (!FUSE1) dif_pass_w<N, N, 8, false>(c, tw, tid & 63);
+                        dif_pass_w_regtw<N, N / 8, 8>(c, tw2r, tid & 63);
+                        PassesW<N, N / 64>::run(c, tw, tid & 63);
+                    } else {
+                        PassesW<N, FUSE1 ? N / 8 : N>::run(c, tw, tid & 63);
+                    }
+                }
                 __syncthreads();
             } else {
                 Passes<N, N, Z_THREADS, B>::run(lds, CP, nb, tw);
@@ -352,7 +373,7 @@ int get_tables(int n, Tables **out) {
     return 0;
 }
 
-template <int N, int B, bool FUSE, bool F1>
+template <int N, int B, bool FUSE, int F1>
 int launch_z1(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
     const size_t lds = (size_t)(2 * N + 2 + B * colpitch_of<N>()) * sizeof(float2);
     auto kern = fft_z_r2c<N, B, FUSE, F1>;
@@ -365,12 +386,19 @@ int launch_z1(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
                   t->tw2.as<float2>(), option("dbg_fft"));
     return 0;
 }
-// option fft_nofuse1 (A/B): 1 = z pass, 2 = column passes stage the raw tile and run every radix pass from LDS
+// z pass at N = 1024, option fft_zmode (A/B): 0 = production; 1..4 = F1 bits + 1 (bit 0: first radix-8 pass fused with the
+// staging, bit 1: twiddles as lane constants)
 template <int N, int B, bool FUSE = false>
 int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
-    if constexpr (N == 1024)
-        if (option("fft_nofuse1") & 1) return launch_z1<N, B, FUSE, false>(mesh, nrows, pitch_r, t);
-    return launch_z1<N, B, FUSE, true>(mesh, nrows, pitch_r, t);
+    if constexpr (N == 1024) {
+        switch (option("fft_zmode")) {
+            case 1: return launch_z1<N, B, FUSE, 0>(mesh, nrows, pitch_r, t);
+            case 2: return launch_z1<N, B, FUSE, 1>(mesh, nrows, pitch_r, t);
+            case 3: return launch_z1<N, B, FUSE, 2>(mesh, nrows, pitch_r, t);
+            case 4: return launch_z1<N, B, FUSE, 3>(mesh, nrows, pitch_r, t);
+        }
+    }
+    return launch_z1<N, B, FUSE, 0>(mesh, nrows, pitch_r, t);
 }
 
 template <int N, int C, bool F1>
@@ -391,9 +419,9 @@ template <int N, int C>
 int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t outer, int64_t outer_stride, const float2 *tw,
                 int64_t outer_mod = (int64_t)1 << 40, int64_t outer_stride2 = 0) {
     if constexpr (wave_local(N))
-        if (option("fft_nofuse1") & 2)
-            return launch_cols1<N, C, false>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2);
-    return launch_cols1<N, C, true>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2);
+        if (option("fft_cmode") == 1)
+            return launch_cols1<N, C, true>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2);
+    return launch_cols1<N, C, false>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2);
 }
 
 template <int N, int C, int BZ>

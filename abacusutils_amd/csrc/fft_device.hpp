@@ -270,6 +270,28 @@ __device__ __forceinline__ void dif_pass_w(float2 *c, const float2 *tw, int lane
     wave_sync();
 }
 
+// a middle pass whose twiddles are lane constants: with LR = L/R <= 64 butterfly t = t0 + lane has j = lane % LR in every
+// trip, so its R - 1 twiddles exp(-2 pi i j r / L) live in registers for the whole kernel (twr[r], r >= 1) - no table reads
+template <int N, int L, int R>
+__device__ __forceinline__ void dif_pass_w_regtw(float2 *c, const float2 (&twr)[R], int lane) {
+    constexpr int BPC = N / R, LR = L / R;
+    static_assert(BPC % 64 == 0 && LR <= 64 && 64 % LR == 0, "twiddles constant per lane");
+#pragma unroll 1
+    for (int t0 = 0; t0 < BPC; t0 += 64) {
+        const int t = t0 + lane;
+        const int base = (t / LR) * L + t % LR;
+        float2 a[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) a[r] = c[padq_strided<LR>(base, r)];
+        dft<R>(a);
+#pragma unroll
+        for (int r = 1; r < R; r++) a[r] = cmul(a[r], twr[r]);
+#pragma unroll
+        for (int r = 0; r < R; r++) c[padq_strided<LR>(base, r)] = a[r];
+    }
+    wave_sync();
+}
+
 template <int N, int R>
 __device__ __forceinline__ void dif_last_w(float2 *c, int lane) {
     constexpr int BPC = N / R, IT = BPC / 64;
@@ -310,6 +332,22 @@ constexpr bool wave_local(int N) { return N == 512 || N == 1024; }   // the prod
 // thread ARE the inputs r = 0..7 of butterfly j = j0 + b * RS of that pass.  Each 16-B load carries two sequences
 // (.xy -> cA at index offset jA, .zw -> cB at jB: two columns of a column tile, or two adjacent elements of a row).
 // The tile is never staged raw and read back: one LDS round trip less; the remaining passes are PassesW<N, N/8>.
+// the same with the twiddles of the thread's two butterflies in registers (one butterfly per sequence: NLD = 8)
+template <int N>
+__device__ __forceinline__ void stage_pass1_regtw(v4f (&regs)[8], float2 *cA, float2 *cB, int jA, int jB,
+                                                  const float2 (&twA)[8], const float2 (&twB)[8]) {
+    constexpr int LR = N / 8;
+    float2 u[8], w[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) u[r] = make_float2(regs[r].x, regs[r].y), w[r] = make_float2(regs[r].z, regs[r].w);
+    dft<8>(u);
+    dft<8>(w);
+#pragma unroll
+    for (int r = 1; r < 8; r++) u[r] = cmul(u[r], twA[r]), w[r] = cmul(w[r], twB[r]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) cA[padq_strided<LR>(jA, r)] = u[r], cB[padq_strided<LR>(jB, r)] = w[r];
+}
+
 template <int N, int NLD, int RS>
 __device__ __forceinline__ void stage_pass1(v4f (&regs)[NLD], float2 *cA, float2 *cB, int jA, int jB, const float2 *tw) {
     constexpr int LR = N / 8, NB = LR / RS;

@@ -409,16 +409,22 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     extern __shared__ __align__(16) unsigned char smem[];
     const int Nk = b.Nk, Nmu = b.Nmu;
     const int nrow = Nk + 2, nbx = nrow * Nmu;
-    // LDS: [twiddles H][tile C x CP][sum f64 (Nk+2)*Nmu][mu^2, mu^4 moments f64 2*(Nk+2)][cell words ncell][U kzlen*(MU-1)][W n]
-    float2 *tw = reinterpret_cast<float2 *>(smem);
-    float2 *lds = tw + H;
+    // LDS: [tile C x CP][sum f64 (Nk+2)*Nmu][mu^2, mu^4 moments f64 2*(Nk+2)][cell words ncell][U kzlen*(MU-1)][W n]
+    float2 *lds = reinterpret_cast<float2 *>(smem);
     double *h_sum = reinterpret_cast<double *>(lds + C * CP + 1);
     double *h_m2 = h_sum + nbx, *h_m4 = h_m2 + nrow;
     unsigned int *lut = reinterpret_cast<unsigned int *>(h_m4 + nrow);
     int *Ul = reinterpret_cast<int *>(lut + d.ncell);                 // (kzlen, MU - 1)
     float *Wl = reinterpret_cast<float *>(Ul + g.kzlen * (MU - 1));
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int q = tid; q < H; q += XB_THREADS) tw[q] = twH[q];
+    // twiddles as lane constants: first pass (fused with the staging) j = tid / (C/2); second pass j = lane % (H/64)
+    float2 tw1[8], tw2[8];
+#pragma unroll
+    for (int r = 1; r < 8; r++) {
+        tw1[r] = twH[(tid / (C / 2)) * r];
+        tw2[r] = twH[(lane % (H / 64)) * r * 8];
+    }
+    tw1[0] = tw2[0] = make_float2(1.f, 0.f);
     for (int q = tid; q < nbx; q += XB_THREADS) h_sum[q] = 0.0;
     for (int q = tid; q < 2 * nrow; q += XB_THREADS) h_m2[q] = 0.0;
     for (int q = tid; q < d.ncell; q += XB_THREADS) lut[q] = d.lut[q];
@@ -461,9 +467,8 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
         dft<8>(w);
 #pragma unroll
         for (int r = 1; r < 8; r++) {
-            const float2 t = tw[jb * r];
-            u[r] = cmul(u[r], t);
-            w[r] = cmul(w[r], t);
+            u[r] = cmul(u[r], tw1[r]);
+            w[r] = cmul(w[r], tw1[r]);
         }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -503,7 +508,8 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
             for (int c = wave; c < C; c += XB_THREADS / 64) {
                 float2 *col = lds + c * CP;
                 if (!(g.dbg & 1)) {
-                    PassesW<H, H / 8>::run(col, tw, lane);     // the passes behind the one stage() performed
+                    dif_pass_w_regtw<H, H / 8, 8>(col, tw2, lane);          // the passes behind the one stage() performed
+                    PassesW<H, H / 64>::run(col, nullptr, lane);            // last pass: no twiddles
                     wave_sync();
                 }
                 const int k = ct_cur * C + c;
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
 template <int H, int C>
 size_t xbin2_lds_bytes(int n, int Nk, int Nmu, int ncell, bool comp) {
     const int mu = Nmu <= 1 ? 1 : Nmu <= 4 ? 4 : 8;
-    return (size_t)(H + C * colpitch_of<H>() + 1) * sizeof(float2) + (size_t)(Nk + 2) * Nmu * 8 + (size_t)2 * (Nk + 2) * 8 +
+    return (size_t)(C * colpitch_of<H>() + 1) * sizeof(float2) + (size_t)(Nk + 2) * Nmu * 8 + (size_t)2 * (Nk + 2) * 8 +
            (size_t)ncell * 4 + (size_t)(n / 2 + 1) * (mu - 1) * 4 + (comp ? (size_t)n * 4 : 0) + 16;
 }
 

@@ -343,7 +343,9 @@ def single(args):
         out = bench_hod(args, dist)
         if not args.no_pk:
             import bench_pk
-            for key, fn in (('pk', lambda: bench_pk.bench_pk(args, dist, headline=False)),
+            for key, fn in (('pk', lambda: bench_pk.bench_pk(args, dist, headline=False, cpu=False)),
+                            # BASELINE config 3 itself (1024^3, 1e8 particles), with the CPU oracle timed on the same workload
+                            ('pk_c3', lambda: bench_pk.bench_pk(args, dist, headline=False, nmesh=1024, variants=False)),
                             ('pairs', lambda: bench_pk.bench_pairs(args, dist)),
                             ('catalog', lambda: bench_pk.bench_catalog(args, dist))):
                 try:                    # a secondary measurement must not take the headline down

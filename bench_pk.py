@@ -34,12 +34,12 @@ def pmc_traffic(workload, kernel):
     return None
 
 
-def bench_pk(args, dist, headline):
+def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
     import ctypes as C
     from abacusutils_amd import _lib
     from abacusutils_amd.analysis import power_spectrum as ps
 
-    nmesh, n = args.nmesh, args.npk
+    nmesh, n = nmesh or args.nmesh, args.npk
     L = 2000.0
     rng = np.random.default_rng(300 + dist.rank)
     pos = rng.random((n, 3), dtype=np.float32)
@@ -61,6 +61,9 @@ def bench_pk(args, dist, headline):
     steps = max(1, min(args.steps, 10))
     for _ in range(max(1, min(args.warmup, 2))):
         step()
+    lib.abacus_power_geometry_ms.restype = C.c_double
+    geometry_ms = float(lib.abacus_power_geometry_ms())   # one-off pass of the first call (cached per (nmesh, edges))
+    xbin_gen = int(lib.abacus_power_xbin_generation())
     _lib.profile_reset()
     _lib.profile_enable(True)
     dist.barrier()
@@ -82,6 +85,7 @@ def bench_pk(args, dist, headline):
     alg = {
         'hipfft_r2c': 24.0 * M,            # three 1-D passes x (read + write) of the 4M-byte mesh/half-spectrum
         'fft_z_r2c': 8.0 * M, 'fft_cols_y': 8.0 * M, 'fft_cols_x': 8.0 * M,   # one pass each: read 4M + write 4M
+        'fft_x_bin': 4.0 * M,              # last pass fused with the binning: one read of the half-spectrum, nothing written
         'tsc_tile_deposit': 4.0 * M + 16.0 * 1.3 * n,
         'spectrum_bin': 4.0 * M,
         'tsc_bin_count': 12.0 * n,
@@ -102,39 +106,45 @@ def bench_pk(args, dist, headline):
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': f'C3-style: {n:.0e} uniform float32 particles (seed 300+rank), L=2000, nmesh={nmesh}, '
+        'config': {'workload': f'{"BASELINE config 3" if nmesh == 1024 else "C3-style"}: {n:.0e} uniform float32 particles (seed 300+rank), L=2000, nmesh={nmesh}, '
                                'TSC, non-interlaced, uncompensated, 4 mu bins, poles 0/2/4; particles resident in HBM',
                    'nmesh': nmesh, 'n_particles': n},
         'kernels_ms': {k: round(v, 4) for k, v in kern.items()},
+        'geometry_ms': round(geometry_ms, 3),
+        'geometry_note': 'N_mode, k_avg and the cell table of the (k, mu) bins depend on (nmesh, edges) alone: one pass over the '
+                         f'modes at the first spectrum of a mesh / edge set, cached (fused last pass generation {xbin_gen}); outside the timed steps',
         'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot),
         'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': ach / HBM_PEAK_GBS, 'algorithmic_bytes': alg[dom],
+                     'per_kernel_frac': {k: round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) for k in kern if k in alg},
                      'traffic': pmc_traffic('pk2048', dom) if (nmesh, n) == (2048, 100_000_000) else None,
                      'whole_step_GBs': alg_bytes_total / dt / 1e9,
                      'whole_step_frac': alg_bytes_total / dt / 1e9 / HBM_PEAK_GBS},
     }
     # interlaced + compensated variant (the calc_power defaults): 24 N + 80 M algorithmic bytes
-    try:
-        W = ps.get_W_compensated(L, nmesh, 'TSC', True).astype(np.float32)
-        step(1, W)
-        _lib.sync()
-        t1 = time.perf_counter()
-        for _ in range(max(1, steps // 2)):
+    if variants:
+        try:
+            W = ps.get_W_compensated(L, nmesh, 'TSC', True).astype(np.float32)
             step(1, W)
-        _lib.sync()
-        dti = (time.perf_counter() - t1) / max(1, steps // 2)
-        out['interlaced_compensated'] = {'ms_per_step': dti * 1e3,
-                                         'whole_step_GBs': (24.0 * n + 80.0 * M) / dti / 1e9}
-    except Exception as e:
-        out['interlaced_compensated'] = {'error': repr(e)}
+            _lib.sync()
+            t1 = time.perf_counter()
+            for _ in range(max(1, steps // 2)):
+                step(1, W)
+            _lib.sync()
+            dti = (time.perf_counter() - t1) / max(1, steps // 2)
+            out['interlaced_compensated'] = {'ms_per_step': dti * 1e3,
+                                             'whole_step_GBs': (24.0 * n + 80.0 * M) / dti / 1e9,
+                                             'whole_step_frac': (24.0 * n + 80.0 * M) / dti / 1e9 / HBM_PEAK_GBS}
+        except Exception as e:
+            out['interlaced_compensated'] = {'error': repr(e)}
     dpos.free()
     lib.abacus_power_release()
-    if dist.rank == 0 and dist.world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline_pk(L)
+    if cpu and dist.rank == 0 and dist.world == 1 and not args.no_cpu:
+        out['cpu_baseline'] = cpu_baseline_pk(L, out['ms_per_step'] if nmesh == 1024 else None)
     return out
 
 
-def cpu_baseline_pk(L):
+def cpu_baseline_pk(L, gpu_ms=None):
     """oracle (C+OpenMP stripe TSC, scipy pocketfft rfftn = the reference's FFT, OpenMP bin_kmu) on BASELINE config 3
     itself - 1e8 particles (seed 300) on a 1024^3 mesh, the largest of the reference's own benchmark meshes that the CPU
     finishes in seconds: one warm-up + one timed calc_power (about 10-20 s of CPU work on the box's cores)"""
@@ -153,7 +163,9 @@ def cpu_baseline_pk(L):
         ts.append(time.perf_counter() - t)
     return {'value': float(nmesh) ** 3 / ts[-1], 'unit': 'mesh cells/s', 'cores': cores, 'kind': 'port',
             'sample': f'BASELINE config 3: nmesh {nmesh}, {n} particles, {ts[-1] * 1e3:.0f} ms per calc_power (second of two '
-                      f'calls; first {ts[0] * 1e3:.0f} ms). The GPU takes 16.9 ms for the same workload (profiles/r02/pk1024_*)',
+                      f'calls; first {ts[0] * 1e3:.0f} ms)' +
+                      (f'. The GPU step of this same workload, measured in this run: {gpu_ms:.2f} ms' if gpu_ms else
+                       '. The GPU step of this same workload is the `pk_c3` leg of the line'),
             'ms': ts[-1] * 1e3}
 
 
