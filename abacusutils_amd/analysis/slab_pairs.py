@@ -11,7 +11,8 @@ Restriction: L/W >= r_max (the ghost layer reaches the direct neighbours only).
 """
 import numpy as np
 
-from .slab_power import SlabComm, route_particles
+from ..comm import default_comm
+from .slab_power import route_particles
 from .tpcf_corrfunc import _paircount
 
 MODES = {'r': 0, 'rppi': 1, 'smu': 2}
@@ -51,7 +52,7 @@ def paircount_slab(mode, pos1, boxsize, bins, comm=None, pos2=None, pimax=0.0, n
     mode: 'r' | 'rppi' | 'smu' (Corrfunc's DD / DDrppi / DDsmu as the reference calls them); pos1 / pos2: this rank's
     (N, 3) part of the catalogue(s), pos2 None = autocorrelation (ordered pairs, no self pairs).  Returns the uint64
     histogram [nbins * (1 | npibins | nmubins)] on every rank."""
-    comm = comm or SlabComm()
+    comm = comm or default_comm()
     counter = counter or _hip_counter
     m = MODES[mode]
     bins = np.asarray(bins, dtype=np.float32)

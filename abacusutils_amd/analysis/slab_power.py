@@ -19,9 +19,9 @@ slab (`route_particles` moves them there).  Per field:
 
 Collectives: `abacusutils_amd.comm.RcclComm` - RCCL through the C ABI (abacus_comm_*), enqueued on the library stream
 between the kernels, no host synchronisation inside a spectrum; the pencil transpose is cut into chunks of x-planes and
-every chunk's all-to-all runs on the communicator's stream while the next chunk's z / y passes run.  `SlabComm` below is
-the host-staged stand-in with the same methods over torch.distributed gloo: TEST infrastructure (CPU container, or
-several ranks sharing one GPU), never the multi-GPU path.
+every chunk's all-to-all runs on the communicator's stream while the next chunk's z / y passes run.  A single process
+needs no transport (`abacusutils_amd.comm.LocalComm`).  The host-staged stand-in with the same methods over
+torch.distributed gloo lives with the tests (tests/gloo_comm.py: CPU container, or several ranks sharing one GPU).
 Restrictions: nmesh a power of two in [64, 2048] (hand-written FFT passes), nmesh % W == 0, nmesh/W >= GHOST.
 """
 import ctypes as C
@@ -128,6 +128,19 @@ class HipSlabBackend:
                                                   len(poles), _lib.ptr(raw)))
         return raw
 
+    def xbin_raw(self, field, nmesh, y0, nyl, Lbox, W, ke, me, poles, put_geom):
+        """last x pass fused with the binning (auto power, one non-interlaced field, nmesh 1024 / 2048): raw sums, or None
+        when the library does not serve this mesh / histogram that way (then fft_x + bin_raw)"""
+        buf, off = field
+        raw = np.zeros(self.raw_bytes(len(ke) - 1, len(me) - 1, poles), dtype=np.uint8)
+        rc = _lib.lib().abacus_slab_xbin_dev(buf.ptr(off), int(nmesh), int(y0), int(nyl), C.c_double(Lbox),
+                                             None if W is None else _lib.ptr(W), _lib.ptr(ke), len(ke) - 1, _lib.ptr(me),
+                                             len(me) - 1, _lib.ptr(poles), len(poles), int(bool(put_geom)), _lib.ptr(raw))
+        if rc == 1:
+            return None
+        _lib.check(rc)
+        return raw
+
     def finalize(self, raw, Lbox, Nk, Nmu, poles):
         return finalize_raw(raw, Lbox, Nk, Nmu, poles)
 
@@ -146,132 +159,6 @@ def finalize_raw(raw, Lbox, Nk, Nmu, poles):
                                               len(poles), _lib.ptr(power), _lib.ptr(N_mode), _lib.ptr(bp), _lib.ptr(Nmp),
                                               _lib.ptr(k_avg)))
     return power, N_mode, bp, Nmp, k_avg
-
-
-class SlabComm:
-    """HOST-STAGED stand-in for `abacusutils_amd.comm.RcclComm` over torch.distributed (gloo): the transport of the CPU
-    tests (world 2 / 4 with the NumPy device stand-in) and of several ranks sharing ONE GPU.  Same methods; mesh-sized
-    exchanges are copied to the host, exchanged and copied back."""
-
-    device = False
-
-    def __init__(self, group=None, force_collectives=False):
-        self.dist = None
-        self.rank, self.world = 0, 1
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                self.dist = dist
-                self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        except ImportError:
-            pass
-        self.group = group
-        self.collective = self.dist is not None and (self.world > 1 or bool(force_collectives))
-
-    def _pairwise(self, ins, outs):
-        """ins[p] -> rank p, outs[p] <- rank p (host tensors; gloo has no all_to_all)"""
-        reqs = []
-        for peer in range(self.world):
-            if peer == self.rank:
-                outs[peer].copy_(ins[peer])
-            else:
-                if ins[peer].numel():
-                    reqs.append(self.dist.isend(ins[peer].contiguous(), peer, group=self.group))
-                if outs[peer].numel():
-                    reqs.append(self.dist.irecv(outs[peer], peer, group=self.group))
-        for q in reqs:
-            q.wait()
-
-    def ring_exchange(self, backend, buf, left_off, right_off, recv, n):
-        """send buf[left_off:+n] to rank-1 and buf[right_off:+n] to rank+1;
-        recv[0:n] <- what rank+1 sent left, recv[n:2n] <- what rank-1 sent right"""
-        if not self.collective:   # the ring neighbour is this rank (periodic box): callers add the ghosts in place
-            raise RuntimeError('ring_exchange needs an initialised process group')
-        import torch
-        backend.sync()
-        left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
-        s_l, s_r = torch.from_numpy(buf.get(left_off, n)), torch.from_numpy(buf.get(right_off, n))
-        r_from_right = torch.empty(n, dtype=torch.float32)
-        r_from_left = torch.empty(n, dtype=torch.float32)
-        if left == self.rank:   # one rank: its own ghosts come back
-            r_from_right.copy_(s_l)
-            r_from_left.copy_(s_r)
-        else:
-            ops = [self.dist.P2POp(self.dist.isend, s_l, left, self.group),
-                   self.dist.P2POp(self.dist.isend, s_r, right, self.group),
-                   self.dist.P2POp(self.dist.irecv, r_from_right, right, self.group),
-                   self.dist.P2POp(self.dist.irecv, r_from_left, left, self.group)]
-            for req in self.dist.batch_isend_irecv(ops):
-                req.wait()
-        recv.set(0, r_from_right.numpy())
-        recv.set(n, r_from_left.numpy())
-
-    def all_to_all(self, backend, send, recv, n_total):
-        self.all_to_all_piece(backend, send, recv, n_total // self.world, 0, n_total // self.world)
-
-    def all_to_all_piece(self, backend, send, recv, peer_stride, offset, n, overlap=False):
-        if not self.collective:   # callers unpack straight from the send buffer
-            raise RuntimeError('all_to_all needs an initialised process group')
-        import torch
-        backend.sync()
-        ins = [torch.from_numpy(send.get(p * peer_stride + offset, n)) for p in range(self.world)]
-        outs = [torch.empty(n, dtype=torch.float32) for _ in range(self.world)]
-        self._pairwise(ins, outs)
-        for p in range(self.world):
-            recv.set(p * peer_stride + offset, outs[p].numpy())
-
-    def join(self):
-        pass
-
-    def transpose_chunks(self, nxl):
-        return 2 if (self.collective and nxl % 2 == 0 and nxl >= 4) else 1   # the chunked code path, in the CPU tests too
-
-    def all_reduce_raw(self, raw, n_u64):
-        """sum the raw histogram over ranks: first n_u64 entries are uint64 counts, the rest float64"""
-        if not self.collective:
-            return raw
-        import torch
-        cnt = torch.from_numpy(raw[: n_u64 * 8].view(np.int64).copy())
-        val = torch.from_numpy(raw[n_u64 * 8:].view(np.float64).copy())
-        self.dist.all_reduce(cnt, group=self.group)
-        if val.numel():
-            self.dist.all_reduce(val, group=self.group)
-        out = np.empty_like(raw)
-        out[: n_u64 * 8] = cnt.numpy().view(np.uint8)
-        out[n_u64 * 8:] = val.numpy().view(np.uint8)
-        return out
-
-    def all_reduce_int(self, v):
-        if not self.collective:
-            return int(v)
-        import torch
-        t = torch.tensor([int(v)], dtype=torch.int64)
-        self.dist.all_reduce(t, group=self.group)
-        return int(t[0])
-
-    def all_reduce_float(self, v, op='sum'):
-        if not self.collective:
-            return float(v)
-        import torch
-        t = torch.tensor([float(v)], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == 'max' else self.dist.ReduceOp.SUM, group=self.group)
-        return float(t[0])
-
-    def barrier(self):
-        if self.collective:
-            self.dist.barrier(group=self.group)
-
-    def all_to_all_host(self, arrays):
-        """variable-size host all-to-all of float32 arrays (particle routing): arrays[p] goes to rank p"""
-        if not self.collective:
-            return [arrays[0]]
-        import torch
-        sizes = torch.tensor([a.size for a in arrays], dtype=torch.int64)
-        all_sizes = [torch.empty(self.world, dtype=torch.int64) for _ in range(self.world)]
-        self.dist.all_gather(all_sizes, sizes, group=self.group)
-        outs = [np.empty(int(all_sizes[p][self.rank]), dtype=np.float32) for p in range(self.world)]
-        self._pairwise([torch.from_numpy(np.ascontiguousarray(a.ravel())) for a in arrays], [torch.from_numpy(o) for o in outs])
-        return outs
 
 
 def route_particles(pos, w, Lbox, comm):
@@ -301,13 +188,9 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
                     squeeze_mu_axis=True, n_total=None, n_total2=None):
     """`calc_power` (abacusnbody/analysis/power_spectrum.py:1131-1319) over x-slabs.  `pos` / `pos2` are THIS rank's
     particles (already inside its x-slab, see `route_particles`); every rank returns the full Table."""
-    if comm is None:   # launched with WORLD_SIZE > 1: RCCL; a single process needs no transport
-        import os
-        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-            from ..comm import RcclComm
-            comm = RcclComm.from_env()
-        else:
-            comm = SlabComm()
+    if comm is None:   # launched with WORLD_SIZE > 1: RCCL (one communicator per process, reused); else no transport
+        from ..comm import default_comm
+        comm = default_comm()
     backend = backend or HipSlabBackend()
     W, r = comm.world, comm.rank
     if nmesh % W or nmesh // W < GHOST:
@@ -340,6 +223,9 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     ghost = backend.new_buffer(2 * g)
     x0 = r * nxl
 
+    # auto power of one non-interlaced field: the last x pass can bin straight from LDS (no spectrum write + re-read)
+    try_xbin = pos2 is None and not interlaced and hasattr(backend, 'xbin_raw')
+
     def spectrum(particles, ntot, offset, mesh):
         norm = float(np.float32(float(nmesh) ** 3 / float(ntot)))   # dtype(field.size / tot_weight) (:856,894)
         backend.deposit(particles, mesh, nmesh, (x0 - GHOST) % nmesh, nxl + 2 * GHOST, Lbox, offset, norm, code)
@@ -368,7 +254,8 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         if comm.collective:
             comm.join()
         backend.unpack(recv if comm.collective else send, mesh, GHOST * plane, nmesh, nxl, W)   # mesh now holds (y_local, x, k)
-        backend.fft_x(mesh, GHOST * plane, nmesh, nxl)
+        if not try_xbin:
+            backend.fft_x(mesh, GHOST * plane, nmesh, nxl)
         return (mesh, GHOST * plane)
 
     sets = [(pos, w, n_total)] + ([(pos2, w2, n_total2)] if pos2 is not None else [])
@@ -386,7 +273,11 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
             fields.append((None, 0))
     if pos2 is None:
         fields += [(None, 0), (None, 0)]
-    raw = backend.bin_raw(fields, nmesh, r * nxl, nxl, Lbox, Wk, interlaced, ke, me, poles_arr)
+    raw = backend.xbin_raw(fields[0], nmesh, r * nxl, nxl, Lbox, Wk, ke, me, poles_arr, r == 0) if try_xbin else None
+    if raw is None:
+        if try_xbin:
+            backend.fft_x(*fields[0], nmesh, nxl)
+        raw = backend.bin_raw(fields, nmesh, r * nxl, nxl, Lbox, Wk, interlaced, ke, me, poles_arr)
     raw = comm.all_reduce_raw(raw, (len(ke) - 1) * (len(me) - 1))
     power, N_mode, bp, Nmp, k_avg = backend.finalize(raw, Lbox, len(ke) - 1, len(me) - 1, poles_arr)
     for b in meshes + [send, recv, ghost]:

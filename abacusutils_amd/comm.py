@@ -8,7 +8,7 @@ own launcher, or anything else) `RcclComm.from_env()` is all a rank has to call.
 The reference has no distributed layer (its unit of decomposition is the slab chunk of one process,
 abacusnbody/hod/abacus_hod.py:301-312); this is the transport of the slab P(k) (analysis/slab_power.py), the sharded HOD
 (hod/shard.py) and the slab pair counts (analysis/slab_pairs.py).  The CPU tests use a host-staged stand-in with the same
-methods (`analysis.slab_power.SlabComm`, torch.distributed gloo) - test infrastructure, never the GPU path.
+methods (tests/gloo_comm.py, torch.distributed gloo) - test infrastructure, not part of this package.
 """
 import ctypes as C
 import os
@@ -28,18 +28,33 @@ def _rendezvous_path(key=None):
     global _seq
     if key is None:
         key = os.environ.get('ABACUS_RDZV_KEY')
-    if key is None:   # ranks of one launch share their parent (the launcher) and the rendezvous port
-        key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    if key is None:   # ranks of one launch share their parent (the launcher), the rendezvous port and the restart attempt
+        key = (f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_"
+               f"{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
     d = os.environ.get('ABACUS_RDZV_DIR', tempfile.gettempdir())
     path = os.path.join(d, f'abacus_rdzv_{key}_{_seq}')
     _seq += 1
     return path
 
 
+def _launch_time():
+    """when this launch began, if the launcher said so (abacusutils_amd/launch.py exports ABACUS_RDZV_T0): a rendezvous file
+    older than that belongs to an earlier launch with the same key"""
+    try:
+        return float(os.environ['ABACUS_RDZV_T0'])
+    except (KeyError, ValueError):
+        return None
+
+
 def exchange_id(rank, world, make_id, path, timeout=180.0):
-    """rank 0 publishes `make_id()` (bytes) at `path`; the others wait for it.  The file is written under a temporary
-    name and renamed, so a reader never sees a partial id; rank 0 removes it once every rank holds a communicator."""
+    """rank 0 publishes `make_id()` (bytes) at `path`; the others wait for it.  Rank 0 first removes whatever an earlier
+    launch left at `path`, writes under a temporary name and renames, so a reader never sees a stale or partial id; it
+    removes the file again once every rank holds a communicator."""
     if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
         blob = make_id()
         tmp = f'{path}.tmp{os.getpid()}'
         with open(tmp, 'wb') as f:
@@ -47,10 +62,13 @@ def exchange_id(rank, world, make_id, path, timeout=180.0):
         os.replace(tmp, path)
         return blob
     t0 = time.time()
+    launched = _launch_time()
+    # rank 0 may have written before this rank started, so "older than me" is no criterion; "older than the launch" is
+    # (when the launcher exported its start time), else anything older than ten minutes is a leftover
+    oldest = launched - 30.0 if launched is not None else t0 - 600.0
     while True:
         try:
-            # a file left behind by a crashed launch with the same key (PID reuse) is older than this process
-            if os.path.getmtime(path) > t0 - 600:
+            if os.path.getmtime(path) >= oldest:
                 with open(path, 'rb') as f:
                     blob = f.read()
                 if len(blob) == ID_BYTES:
@@ -252,11 +270,63 @@ class RcclComm:
         return rpos, rw
 
 
+class LocalComm:
+    """one process, no transport: what the slab estimator / slab pair counter / bench use when WORLD_SIZE is 1.  The
+    periodic neighbours of the only slab are the slab itself - callers handle `collective == False` in place."""
+
+    device = False
+    collective = False
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def join(self):
+        pass
+
+    def transpose_chunks(self, nxl):
+        return 1
+
+    def all_reduce_raw(self, raw, n_u64):
+        return raw
+
+    def all_reduce_int(self, v):
+        return int(v)
+
+    def all_reduce_float(self, v, op='sum'):
+        return float(v)
+
+    def all_to_all_host(self, arrays):
+        return [arrays[0]]
+
+    def info(self):
+        return dict(rank=0, world=1, transport='none (single process)')
+
+    def free(self):
+        pass
+
+
+_default = None
+
+
+def default_comm():
+    """the communicator of this process: an RcclComm from the launcher's environment when WORLD_SIZE > 1 (created once,
+    reused by every later call), else a LocalComm"""
+    global _default
+    if _default is None:
+        _default = RcclComm.from_env() if int(os.environ.get('WORLD_SIZE', '1')) > 1 else LocalComm()
+    return _default
+
+
 class FileComm:
     """barrier and scalar all-reduce through files of the rendezvous directory: what a leg WITHOUT a data-path collective
     (the sharded HOD: every rank populates its own shard) falls back to when the RCCL communicator cannot be created -
     its throughput does not depend on the transport, only the start barrier and the max over the ranks' timings do.
-    Each call is one round: every rank writes `<key>.<round>.<rank>`, polls for the others, and reads their values."""
+    Each call is one round: every rank writes `<key>.<round>.<rank>`, polls for the others, and reads their values.
+    File lifetime: a rank that has completed round r knows every rank has written round r, hence finished READING round
+    r - 1 - so it removes its own files up to r - 1 and nothing later.  `free()` is an acknowledged last round: every rank
+    writes a `done` marker; rank 0 waits for all markers and removes whatever is left (a peer still polling the last
+    round therefore always finds its files)."""
 
     device = False
 
@@ -265,21 +335,39 @@ class FileComm:
         self._base = _rendezvous_path(key) + '.file'
         self._round = 0
 
+    def _name(self, rnd, rank):
+        return f'{self._base}.{rnd}.{rank}'
+
+    @staticmethod
+    def _publish(path, text):
+        tmp = path + '.tmp'
+        with open(tmp, 'w') as f:
+            f.write(text)
+        os.replace(tmp, path)       # atomic: a reader sees the whole value or no file
+
+    def _read(self, path, what, t0):
+        while True:
+            try:
+                with open(path) as f:
+                    return f.read()
+            except OSError:
+                pass
+            if time.time() - t0 > self.timeout:
+                raise TimeoutError(f'rank {self.rank}: {what}')
+            time.sleep(0.0005)
+
     def _exchange(self, value):
         self._round += 1
-        mine = f'{self._base}.{self._round}.{self.rank}'
-        tmp = mine + '.tmp'
-        with open(tmp, 'w') as f:
-            f.write(repr(float(value)))
-        os.replace(tmp, mine)
-        vals, t0 = [], time.time()
-        for r in range(self.world):
-            path = f'{self._base}.{self._round}.{r}'
-            while not os.path.exists(path):
-                if time.time() - t0 > self.timeout:
-                    raise TimeoutError(f'rank {self.rank}: rank {r} did not reach round {self._round} of the file barrier')
-                time.sleep(0.0005)
-            vals.append(float(open(path).read()))
+        self._publish(self._name(self._round, self.rank), repr(float(value)))
+        t0 = time.time()
+        vals = [float(self._read(self._name(self._round, r),
+                                 f'rank {r} did not reach round {self._round} of the file barrier', t0))
+                for r in range(self.world)]
+        if self._round > 1:          # every rank has left round - 1 behind (see the class comment)
+            try:
+                os.unlink(self._name(self._round - 1, self.rank))
+            except OSError:
+                pass
         return vals
 
     def barrier(self):
@@ -294,11 +382,22 @@ class FileComm:
 
     def free(self):
         import glob
-        for f in glob.glob(f'{self._base}.*.{self.rank}'):
+        if self._round < 0:
+            return
+        self._publish(f'{self._base}.done.{self.rank}', str(self._round))
+        if self.rank == 0:           # the last one out removes the files: every marker means "I read my last round"
+            t0 = time.time()
             try:
-                os.unlink(f)
-            except OSError:
-                pass
+                for r in range(self.world):
+                    self._read(f'{self._base}.done.{r}', f'rank {r} did not finish (file barrier clean-up)', t0)
+            except TimeoutError:
+                pass                 # a crashed peer: clean up anyway
+            for f in glob.glob(f'{self._base}.*'):
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
+        self._round = -1
 
 
 class Dist:

@@ -119,13 +119,21 @@ int exchange(abacus_comm *c, const char *send, const uint64_t *sbytes, const uin
     if (sbytes[me]) HIP_TRY(hipMemcpyAsync(recv + roff[me], send + soff[me], sbytes[me], hipMemcpyDeviceToDevice, s));
     if (W == 1) return 0;
     NCCL_TRY(R.GroupStart());
-    for (int d = 1; d < W; d++) {   // peers in rotated order: rank r talks to r+d / r-d, every link pair busy in every round
+    // a failing Send / Recv must not leave the group open: every later RCCL call of this thread (the barrier or all-reduce
+    // that would report the failure included) would queue into it and never run.  Keep the first error, always close.
+    ncclResult_t bad = ncclSuccess;
+    const char *what = "";
+    for (int d = 1; d < W && bad == ncclSuccess; d++) {   // peers in rotated order: rank r talks to r+d / r-d, every link pair busy in every round
         const int to = (me + d) % W, from = (me - d + W) % W;
-        if (sbytes[to]) NCCL_TRY(R.Send(send + soff[to], sbytes[to], ncclUint8, to, c->nccl, s));
-        if (rbytes[from]) NCCL_TRY(R.Recv(recv + roff[from], rbytes[from], ncclUint8, from, c->nccl, s));
-        c->bytes_sent += sbytes[to];
+        if (sbytes[to] && (bad = R.Send(send + soff[to], sbytes[to], ncclUint8, to, c->nccl, s)) != ncclSuccess) what = "ncclSend";
+        if (bad == ncclSuccess && rbytes[from] &&
+            (bad = R.Recv(recv + roff[from], rbytes[from], ncclUint8, from, c->nccl, s)) != ncclSuccess)
+            what = "ncclRecv";
+        if (bad == ncclSuccess) c->bytes_sent += sbytes[to];
     }
-    NCCL_TRY(R.GroupEnd());
+    const ncclResult_t endr = R.GroupEnd();
+    if (bad != ncclSuccess) return fail("abacus_comm: %s: %s", what, R.GetErrorString(bad));
+    if (endr != ncclSuccess) return fail("abacus_comm: ncclGroupEnd: %s", R.GetErrorString(endr));
     return 0;
 }
 
@@ -253,11 +261,13 @@ int abacus_comm_ring_exchange(abacus_comm *c, const void *to_left, const void *t
     // W == 2: both neighbours are the same rank.  Messages between one pair are matched in issue order: the peer's first
     // send is ITS to_left block, which is what arrives here from the right - so the receive order below holds for W = 2 too
     NCCL_TRY(R.GroupStart());
-    NCCL_TRY(R.Send(to_left, bytes, ncclUint8, left, c->nccl, s));
-    NCCL_TRY(R.Send(to_right, bytes, ncclUint8, right, c->nccl, s));
-    NCCL_TRY(R.Recv(from_right, bytes, ncclUint8, right, c->nccl, s));
-    NCCL_TRY(R.Recv(from_left, bytes, ncclUint8, left, c->nccl, s));
-    NCCL_TRY(R.GroupEnd());
+    ncclResult_t bad = R.Send(to_left, bytes, ncclUint8, left, c->nccl, s);       // first error kept, the group always closed
+    if (bad == ncclSuccess) bad = R.Send(to_right, bytes, ncclUint8, right, c->nccl, s);
+    if (bad == ncclSuccess) bad = R.Recv(from_right, bytes, ncclUint8, right, c->nccl, s);
+    if (bad == ncclSuccess) bad = R.Recv(from_left, bytes, ncclUint8, left, c->nccl, s);
+    const ncclResult_t endr = R.GroupEnd();
+    if (bad != ncclSuccess) return fail("abacus_comm_ring_exchange: send / recv: %s", R.GetErrorString(bad));
+    if (endr != ncclSuccess) return fail("abacus_comm_ring_exchange: ncclGroupEnd: %s", R.GetErrorString(endr));
     c->bytes_sent += 2 * bytes;
     return 0;
 }

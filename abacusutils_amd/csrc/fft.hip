@@ -40,7 +40,7 @@ namespace {
 // transforms each, over rows [0, n/2) and [n/2, n): half the rows per LDS tile, twice the columns - 128-B row
 // segments at n = 2048, which the memory system serves at the in-place floor instead of 3.4 TB/s.
 // Row r of either half then holds frequency 2 (r mod n/2) + (r div n/2) along that axis.
-template <int N, int B, bool FUSE, int F1 = 1>
+template <int N, int B, int FUSE, int F1 = 0>
 __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
                                                          const float2 *__restrict__ twN, const float2 *__restrict__ tw2N,
                                                          int dbg) {
@@ -55,11 +55,14 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
     for (int q = tid; q <= N; q += Z_THREADS) tw2[q] = tw2N[q];
     static_assert(!FUSE || B == 4, "the fused first stages work on 2 x 2 rows");
     constexpr int NF = 2 * N;                               // mesh size n
-    const int64_t ntiles = FUSE ? (int64_t)N * N : (nrows + B - 1) / B;
+    // FUSE == 2 (x-slabs of a multi-GPU mesh: x + n/2 lives on another rank): only the y stage is fused; a tile is the rows
+    // (x, y), (x, y+n/2), (x+1, y), (x+1, y+n/2) of two adjacent planes, nrows = nx_local * n with nx_local even
+    const int64_t ntiles = FUSE == 1 ? (int64_t)N * N : FUSE == 2 ? nrows / 4 : (nrows + B - 1) / B;
     // first row of a tile, and the row of its r-th member
     auto row_of = [&](int64_t tile, int r) -> int64_t {
         if (!FUSE) return tile * B + r;
         const int64_t x = tile / N, y = tile % N;
+        if (FUSE == 2) return (2 * x + (r >> 1)) * NF + y + (r & 1) * N;
         return (x + (r >> 1) * N) * NF + y + (r & 1) * N;
     };
     const int pitch_c = pitch_r / 2;
@@ -199,6 +202,10 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
                 for (int u = 0; u < 2; u++) {   // rows: 0 = (x, y), 1 = (x, y+H), 2 = (x+H, y), 3 = (x+H, y+H)
                     const float2 A = cadd(X[0][u], X[1][u]), Bv = cmul(csub(X[0][u], X[1][u]), Wy);
                     const float2 Cv = cadd(X[2][u], X[3][u]), D = cmul(csub(X[2][u], X[3][u]), Wy);
+                    if (FUSE == 2) {            // rows 2, 3 belong to the next plane: no x stage here
+                        X[0][u] = A, X[1][u] = Bv, X[2][u] = Cv, X[3][u] = D;
+                        continue;
+                    }
                     X[0][u] = cadd(A, Cv);
                     X[2][u] = cmul(csub(A, Cv), Wx);
                     X[1][u] = cadd(Bv, D);
@@ -373,12 +380,12 @@ int get_tables(int n, Tables **out) {
     return 0;
 }
 
-template <int N, int B, bool FUSE, int F1>
+template <int N, int B, int FUSE, int F1>
 int launch_z1(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
     const size_t lds = (size_t)(2 * N + 2 + B * colpitch_of<N>()) * sizeof(float2);
     auto kern = fft_z_r2c<N, B, FUSE, F1>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t ntiles = FUSE ? (int64_t)N * N : ceil_div(nrows, B);
+    const int64_t ntiles = FUSE == 1 ? (int64_t)N * N : FUSE == 2 ? nrows / 4 : ceil_div(nrows, B);
     int per_cu = 1;   // persistent grid = exactly the resident workgroups (a larger grid would run in two uneven waves)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, Z_THREADS, lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
@@ -388,7 +395,7 @@ int launch_z1(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
 }
 // z pass at N = 1024, option fft_zmode (A/B): 0 = production; 1..4 = F1 bits + 1 (bit 0: first radix-8 pass fused with the
 // staging, bit 1: twiddles as lane constants)
-template <int N, int B, bool FUSE = false>
+template <int N, int B, int FUSE = 0>
 int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
     if constexpr (N == 1024) {
         switch (option("fft_zmode")) {
@@ -503,7 +510,7 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x) {
     const int pitch_c = pitch_r / 2, kzlen = N / 2 + 1;
     const int ntile_c = (kzlen + C - 1) / C;
     if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
-    ABACUS_TRY((launch_z<N / 2, 4, true>(mesh, (int64_t)N * N, pitch_r, t)));
+    ABACUS_TRY((launch_z<N / 2, 4, 1>(mesh, (int64_t)N * N, pitch_r, t)));
     float2 *data = reinterpret_cast<float2 *>(mesh);
     // y: 2 N half-planes of H rows each, contiguous in memory
     ABACUS_TRY((launch_cols<H, C>("fft_cols_y", data, pitch_c, ntile_c, 2 * (int64_t)N, (int64_t)H * pitch_c,
@@ -512,6 +519,50 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x) {
     // x: for every y and either half of x, H planes apart by N * pitch_c
     const int64_t S = (int64_t)N * pitch_c;
     return launch_cols<H, C>("fft_cols_x", data, S, ntile_c, 2 * (int64_t)N, pitch_c, th->twN.as<float2>(), N, (int64_t)H * S);
+}
+
+// The fused form on an x-slab (multi-GPU mesh): z pass with the first radix-2 stage of y only (x + n/2 lives on another
+// rank), y pass as two n/2-point transforms per plane with C columns; the first radix-2 stage of x is applied by the
+// unpack step behind the pencil transpose (power.hip slab_unpack_bfly), the x pass is then fft_native_fused_x_slab or the
+// fused last pass + binning (xbin.hip).  Row orders as in the single-GPU fused form.
+template <int N, int C>
+int fft3d_fused_zy_slab(float *mesh, int pitch_r, Tables *t, Tables *th, int64_t nx_local) {
+    constexpr int H = N / 2;
+    const int pitch_c = pitch_r / 2, ntile_c = (N / 2 + 1 + C - 1) / C;
+    if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
+    if (nx_local % 2) return fail("fft: the fused slab transform needs an even number of planes (got %lld)", (long long)nx_local);
+    ABACUS_TRY((launch_z<N / 2, 4, 2>(mesh, nx_local * N, pitch_r, t)));
+    return launch_cols<H, C>("fft_cols_y", reinterpret_cast<float2 *>(mesh), pitch_c, ntile_c, 2 * nx_local, (int64_t)H * pitch_c,
+                             th->twN.as<float2>());
+}
+template <int N, int C>
+int fft3d_fused_x_slab(float *mesh, int pitch_r, Tables *th, int64_t ny_local) {
+    constexpr int H = N / 2;
+    const int pitch_c = pitch_r / 2, ntile_c = (N / 2 + 1 + C - 1) / C;
+    // layout (y_local, x, k): the two halves of x of one y row are contiguous blocks of H rows
+    return launch_cols<H, C>("fft_cols_x", reinterpret_cast<float2 *>(mesh), pitch_c, ntile_c, 2 * ny_local, (int64_t)H * pitch_c,
+                             th->twN.as<float2>());
+}
+int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int64_t nx_local) {
+    Tables *t, *th;
+    ABACUS_TRY(get_tables(n, &t));
+    ABACUS_TRY(get_tables(n / 2, &th));
+    switch (n) {
+        case 256: return fft3d_fused_zy_slab<256, 16>(mesh, pitch_r, t, th, nx_local);
+        case 1024: return fft3d_fused_zy_slab<1024, 16>(mesh, pitch_r, t, th, nx_local);
+        case 2048: return fft3d_fused_zy_slab<2048, 16>(mesh, pitch_r, t, th, nx_local);
+    }
+    return fail("fft: the fused transform supports n = 1024 and 2048");
+}
+int fft_native_fused_x_slab(float *mesh, int n, int pitch_r, int64_t ny_local) {
+    Tables *th;
+    ABACUS_TRY(get_tables(n / 2, &th));
+    switch (n) {
+        case 256: return fft3d_fused_x_slab<256, 16>(mesh, pitch_r, th, ny_local);
+        case 1024: return fft3d_fused_x_slab<1024, 16>(mesh, pitch_r, th, ny_local);
+        case 2048: return fft3d_fused_x_slab<2048, 16>(mesh, pitch_r, th, ny_local);
+    }
+    return fail("fft: the fused transform supports n = 1024 and 2048");
 }
 
 // n = 256 only on request (tests against the CPU oracle): small meshes gain nothing from the fused form

@@ -51,7 +51,11 @@ int fft_native_fused_supported(int n);
 int fft_native_r2c_fused(float *mesh, int n, int pitch_r);   // rows come out in the permuted order of fft.hip's fused form
 int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r);
 bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
-int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg);
+int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
+                  int y0 = 0, int ny_local = 0, int put_geom = 1);
+bool xbin2_supported(int n, const BinArgs &b, bool comp);
+int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int64_t nx_local);
+int fft_native_fused_x_slab(float *mesh, int n, int pitch_r, int64_t ny_local);
 double xbin_last_build_ms();
 int xbin_last_gen();
 int xbin_release();
@@ -89,6 +93,11 @@ __device__ __forceinline__ void row_ij(const SpecArgs &s, int64_t row, int &i, i
         }
     } else {
         i = (int)(row % s.n), j = s.y0 + (int)(row / s.n);
+        if (s.permshift) {
+            const int hm = (1 << s.permshift) - 1;
+            i = ((i & hm) << 1) | (i >> s.permshift);
+            j = ((j & hm) << 1) | (j >> s.permshift);
+        }
     }
 }
 
@@ -112,6 +121,11 @@ __device__ __forceinline__ void hilo_ij(const SpecArgs &s, int hi, int lo, int &
         i = hi, j = lo;
     } else {
         i = lo, j = s.y0 + hi;
+        if (s.permshift) {
+            const int hm = (1 << s.permshift) - 1;
+            i = ((i & hm) << 1) | (i >> s.permshift);
+            j = ((j & hm) << 1) | (j >> s.permshift);
+        }
     }
 }
 
@@ -492,6 +506,28 @@ __global__ void slab_unpack(const float4 *__restrict__ recv, float4 *__restrict_
         const float4 *src = recv + r * pitch4;
         float4 *dst = out + ((int64_t)yl * n + (p * nxl + xl)) * pitch4;
         for (int q = threadIdx.x; q < pitch4; q += blockDim.x) dst[q] = src[q];
+    }
+}
+
+// the same with the first radix-2 DIF stage of the x transform applied on the way (fused slab form): for x < n/2
+// out[yl][x] = a(x) + a(x + n/2), out[yl][x + n/2] = (a(x) - a(x + n/2)) * exp(-2 pi i x / n) - after the pencil transpose
+// both planes are on this rank.  Rows [0, n/2) / [n/2, n) of x then feed two independent n/2-point transforms (fft.hip).
+__global__ void slab_unpack_bfly(const float4 *__restrict__ recv, float4 *__restrict__ out, int n, int nxl, int nyl, int pitch4) {
+    const int h = n / 2;
+    const int64_t rows = (int64_t)h * nyl;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int yl = (int)(r % nyl), x = (int)(r / nyl), x2 = x + h;
+        const float4 *sa = recv + (((int64_t)(x / nxl) * nxl + x % nxl) * nyl + yl) * pitch4;
+        const float4 *sb = recv + (((int64_t)(x2 / nxl) * nxl + x2 % nxl) * nyl + yl) * pitch4;
+        float4 *da = out + ((int64_t)yl * n + x) * pitch4, *db = out + ((int64_t)yl * n + x2) * pitch4;
+        float sn, cs;
+        sincospif((float)x / (float)h, &sn, &cs);     // W_n^x = (cs, -sn)
+        for (int q = threadIdx.x; q < pitch4; q += blockDim.x) {
+            const float4 a = sa[q], b = sb[q];
+            const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+            da[q] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            db[q] = make_float4(d.x * cs + d.y * sn, d.y * cs - d.x * sn, d.z * cs + d.w * sn, d.w * cs - d.z * sn);
+        }
     }
 }
 
@@ -1139,9 +1175,16 @@ int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add
     return 0;
 }
 
+// the slab path runs the fused form of the transform (fft.hip) wherever the single-GPU path does; `slab_nofuse` (A/B,
+// comparator of the tests) keeps the plain three-pass form.  zy, unpack, x and the binning decide alike.
+static bool slab_fused(int nmesh) { return use_fused_fft(nmesh) && !option("slab_nofuse"); }
+
+int abacus_slab_fused(int nmesh) { return slab_fused(nmesh) ? 1 : 0; }
+
 int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local) {
     ABACUS_ENTER();
     if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    if (slab_fused(nmesh)) return fft_native_fused_zy_slab(mesh, nmesh, pitch_r(nmesh), nx_local);
     return fft_native_zy(mesh, nmesh, pitch_r(nmesh), nx_local);
 }
 
@@ -1160,6 +1203,12 @@ int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int nx_local,
     ABACUS_ENTER();
     if (nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
     const int nyl = nmesh / world, pitch4 = pitch_r(nmesh) / 4;
+    if (slab_fused(nmesh)) {
+        const int grid = (int)std::min<int64_t>((int64_t)(nmesh / 2) * nyl, 256 * 32);
+        ABACUS_LAUNCH("slab_unpack", slab_unpack_bfly, dim3(grid), dim3(256), 0, (const float4 *)recv, (float4 *)out, nmesh,
+                      nx_local, nyl, pitch4);
+        return 0;
+    }
     const int grid = (int)std::min<int64_t>((int64_t)world * nx_local * nyl, 256 * 32);
     ABACUS_LAUNCH("slab_unpack", slab_unpack, dim3(grid), dim3(256), 0, (const float4 *)recv, (float4 *)out, nmesh,
                   nx_local, nyl, world, pitch4);
@@ -1169,6 +1218,7 @@ int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int nx_local,
 int abacus_slab_fft_x_dev(float *data, int nmesh, int ny_local) {
     ABACUS_ENTER();
     if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    if (slab_fused(nmesh)) return fft_native_fused_x_slab(data, nmesh, pitch_r(nmesh), ny_local);
     const int pc = pitch_r(nmesh) / 2;
     return fft_native_x(data, nmesh, pitch_r(nmesh), ny_local, pc, (int64_t)nmesh * pc);   // layout (y_local, x, k)
 }
@@ -1185,8 +1235,33 @@ int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void
     s.rowmode = 1;
     s.y0 = y0;
     s.nrows = (int64_t)ny_local * nmesh;
+    if (slab_fused(nmesh))
+        while ((2 << s.permshift) < nmesh) s.permshift++;   // rows of x and y in the fused form's order
     s.a = (const float2 *)a, s.as = (const float2 *)as, s.b = (const float2 *)b, s.bs = (const float2 *)bs;
     return run_bin(s, Lbox, kedges, Nk, muedges, Nmu, poles, Np, nullptr, nullptr, nullptr, nullptr, nullptr, raw_out);
+}
+
+// Last pass fused with the binning on a y-slab: `mesh` is the unpacked (y_local, x, k) block BEFORE its x pass (auto power
+// of one non-interlaced field).  Returns 0 with the raw sums in raw_out, 1 if this mesh / histogram is not served by the
+// fused last pass (the caller then runs abacus_slab_fft_x_dev + abacus_slab_bin_dev), < 0 on error.  put_geom: exactly one
+// rank passes 1 (the mesh-wide N_mode and sum |k| come from the cached geometry, not from the y-slab).
+int abacus_slab_xbin_dev(const void *mesh, int nmesh, int y0, int ny_local, double Lbox, const float *W_host,
+                         const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
+                         int put_geom, void *raw_out) {
+    ABACUS_ENTER();
+    if (!slab_fused(nmesh) || option("pk_noxbin") || (nmesh != 1024 && nmesh != 2048)) return 1;
+    const float *W_dev;
+    ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
+    BinArgs b;
+    size_t acc_bytes = 0;
+    ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
+    if (!xbin2_supported(nmesh, b, W_dev != nullptr)) return 1;
+    const double M = (double)nmesh * nmesh * nmesh;
+    ABACUS_TRY(fft_x_bin_run((const float *)mesh, nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, y0, ny_local,
+                             put_geom ? 1 : 0));
+    HIP_TRY(hipMemcpyAsync(raw_out, g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
 }
 
 int64_t abacus_bin_raw_bytes(int Nk, int Nmu, const int64_t *poles, int Np) {

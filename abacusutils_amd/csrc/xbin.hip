@@ -45,6 +45,12 @@ struct XBinGeom {
     float inv_size;             // f32(1/M)
     const float *W;             // (n,) compensation window or nullptr
     int dbg;                    // ablation: 1 skip the transform, 2 skip the binning, 4 no histogram atomics, 8 no LDS reads in the binning
+    // fft_x_bin2 only - where the rows live: element (x, y, k) at data[x * xs + (y - y0) * ys + k] for the ny rows
+    // y0 <= y < y0 + ny of this launch (full mesh: xs = n * pitch_c, ys = pitch_c, ny = n; y-slab of the multi-GPU
+    // transform, layout (y_local, x, k): xs = pitch_c, ys = n * pitch_c)
+    int64_t xs, ys;
+    int ny, y0;
+    int put_geom;               // copy the cached N_mode / sum |k| into the accumulators (one rank of a slab run does)
 };
 
 template <int H, int C, int NP, bool COMP>
@@ -433,16 +439,16 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
         for (int q = tid; q < g.n; q += XB_THREADS) Wl[q] = g.W[q];
     const int n = g.n;
     const int ntile_c = (g.kzlen + C - 1) / C;
-    const int64_t S = (int64_t)n * g.pitch_c;
-    const int n_outer = 2 * n;
+    const int64_t S = g.xs;
+    const int n_outer = 2 * g.ny;
     const float inv2 = g.inv_size * g.inv_size;
     const int sh = d.sh;
     const unsigned int *lut0 = lut - d.off;
 
     v4f regs[NLD];
     auto tile_ptr = [&](int o, int ct) {
-        const int xh = o >= n ? 1 : 0, yr = o - xh * n;
-        return data + (int64_t)xh * H * S + (int64_t)yr * g.pitch_c + ct * C;
+        const int xh = o >= g.ny ? 1 : 0, yr = o - xh * g.ny;
+        return data + (int64_t)xh * H * S + (int64_t)yr * g.ys + ct * C;
     };
     auto prefetch = [&](const float2 *p) {
 #pragma unroll
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
             if (ct >= ntile_c) ct -= ntile_c, og++;
             const bool has_next = og < n_og;
             if (has_next) prefetch(tile_ptr(og * ostep + grp, ct));
-            const int xh = o_cur >= n ? 1 : 0, yr = o_cur - xh * n;
+            const int xh = o_cur >= g.ny ? 1 : 0, yr = g.y0 + o_cur - xh * g.ny;
             const int j = ((yr & (H - 1)) << 1) | (yr >= H ? 1 : 0);
             const int jj = j < n / 2 ? j : j - n;
             // mirrors: xh = 1: H-1-a; xh = 0: H-a (a >= 1), a = 0 is its own mirror (i = 0, one mode)
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     for (int q = tid; q < Nk * Nmu; q += XB_THREADS) {
         const double s = h_sum[q + Nmu];           // row eb = bk + 1
         if (s != 0.0) atomicAdd(&b.g_sum[q], s);
-        if (blockIdx.x == 0) b.g_cnt[q] = d.cnt[q], b.g_ksum[q] = d.ksum[q];
+        if (blockIdx.x == 0 && g.put_geom) b.g_cnt[q] = d.cnt[q], b.g_ksum[q] = d.ksum[q];
     }
     if (NP > 0) {
         float pc[NPC][3];
@@ -804,7 +810,7 @@ int launch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const 
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, XB_THREADS, lds));
-    const int64_t ntiles = (int64_t)2 * g.n * ((g.kzlen + C - 1) / C);
+    const int64_t ntiles = (int64_t)2 * g.ny * ((g.kzlen + C - 1) / C);
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)fft_num_cus() * std::max(per_cu, 1));
     const float2 *tw = fft_twiddles(H);
     if (!tw) return -1;
@@ -887,10 +893,18 @@ int xbin_release() {
 }
 
 // `mesh` holds the fused transform after its z and y passes (fft_native_r2c_fused_zy); bins |delta_k|^2 of every mode
-// into the accumulators of `b` (zeroed by the caller)
-int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg) {
+// into the accumulators of `b` (zeroed by the caller).  ny_local > 0: `mesh` is the y-slab [y0, y0 + ny_local) of a
+// multi-GPU transform in the layout (y_local, x, k) behind the pencil transpose (slab_unpack_bfly has applied the first
+// radix-2 stage of x); only the cached-geometry kernel serves it, and `put_geom` says whether this rank contributes the
+// mesh-wide N_mode / sum |k| to the histogram that is all-reduced afterwards.
+int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
+                  int y0, int ny_local, int put_geom) {
     XBinGeom g;
     g.n = n, g.kzlen = n / 2 + 1, g.pitch_c = pitch_r / 2, g.inv_size = inv_size, g.W = W_dev, g.dbg = dbg;
+    const bool slab = ny_local > 0;
+    g.xs = slab ? g.pitch_c : (int64_t)n * g.pitch_c;
+    g.ys = slab ? (int64_t)n * g.pitch_c : g.pitch_c;
+    g.ny = slab ? ny_local : n, g.y0 = slab ? y0 : 0, g.put_geom = slab ? put_geom : 1;
     const float2 *data = reinterpret_cast<const float2 *>(mesh);
     if (n != 2048 && n != 1024) return fail("fft_x_bin: unsupported mesh %d", n);
     const int C = n == 2048 ? 8 : 16;
@@ -904,9 +918,19 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
         if (n == 2048) return dispatch_xbin2<1024, 8>(data, g, b, d, xbin2_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, d.ncell, comp));
         return dispatch_xbin2<512, 16>(data, g, b, d, xbin2_lds_bytes<512, 16>(n, b.Nk, b.Nmu, d.ncell, comp));
     }
+    if (slab) return fail("fft_x_bin: no geometry descriptor for this histogram (y-slab form)");
     if (!xbin1_supported(n, b.Nk, b.Nmu, b, comp)) return fail("fft_x_bin: histogram does not fit");
     if (n == 2048) return dispatch_xbin<1024, 8>(data, g, b, xbin_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, b.Np, comp));
     return dispatch_xbin<512, 16>(data, g, b, xbin_lds_bytes<512, 16>(n, b.Nk, b.Nmu, b.Np, comp));
+}
+
+// the cached-geometry kernel alone (what a y-slab needs)
+bool xbin2_supported(int n, const BinArgs &b, bool comp) {
+    if (b.Np > 2) return false;
+    for (int q = 0; q < b.Np; q++)
+        if (b.poledeg[q] > 2) return false;
+    XDescHost *x = nullptr;
+    return xbin2_desc(n, b, comp, &x) == 0 && x != nullptr;
 }
 
 }  // namespace abacus

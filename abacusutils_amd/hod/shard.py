@@ -70,60 +70,40 @@ def merge_catalogs(parts, tracers=None):
 class HodComm:
     """control-plane collectives of the sharded HOD: sums of per-tracer counts and the merge of the per-rank mocks.
 
-    transport: an `abacusutils_amd.comm.RcclComm` (GPUs: RCCL through the C ABI), or None = torch.distributed when a
-    process group is initialised (the gloo CPU tests), else a single process."""
+    transport: anything with `rank`, `world`, `all_reduce_array(int64 array)` and `all_gather_object(obj)` - an
+    `abacusutils_amd.comm.RcclComm` on the GPUs (RCCL through the C ABI); None = a single process.  (The CPU tests pass a
+    gloo transport of their own, tests/gloo_comm.py.)"""
 
-    def __init__(self, transport=None, group=None):
-        self.rccl, self.dist, self.group = None, None, group
-        self.rank, self.world = 0, 1
-        if transport is not None:
-            self.rccl = transport
-            self.rank, self.world = transport.rank, transport.world
-            return
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                self.dist = dist
-                self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        except ImportError:
-            pass
+    def __init__(self, transport=None):
+        self.transport = transport
+        self.rank = transport.rank if transport is not None else 0
+        self.world = transport.world if transport is not None else 1
 
     def all_reduce_counts(self, counts):
         """sum {tracer: (Ncent, Nsat)}-style integer dicts over ranks"""
         keys = sorted(counts)
         vals = np.array([np.atleast_1d(counts[k]) for k in keys], dtype=np.int64)
-        if self.rccl is not None and self.world > 1:
-            vals = self.rccl.all_reduce_array(vals.copy()).reshape(vals.shape)
-        elif self.dist is not None and self.world > 1:
-            import torch
-            t = torch.from_numpy(vals.copy())
-            self.dist.all_reduce(t, group=self.group)
-            vals = t.numpy()
+        if self.world > 1:
+            vals = np.asarray(self.transport.all_reduce_array(vals.copy())).reshape(vals.shape)
         return {k: tuple(int(x) for x in v) if np.ndim(counts[k]) else int(v[0]) for k, v in zip(keys, vals)}
 
     def gather_catalog(self, local, dst=None):
         """merge the per-rank catalogues; on every rank (dst=None) or only on `dst` (others get None).  Host-side:
         a mock is ~1e-3 of the particle subsample it was drawn from"""
-        if self.world == 1 or (self.rccl is None and self.dist is None):
+        if self.world == 1:
             return local
-        if self.rccl is not None:
-            objs = self.rccl.all_gather_object(local)
-            return merge_catalogs(objs) if dst is None or self.rank == dst else None
-        objs = [None] * self.world
-        if dst is None:
-            self.dist.all_gather_object(objs, local, group=self.group)
-        else:
-            self.dist.gather_object(local, objs if self.rank == dst else None, dst=dst, group=self.group)
-            if self.rank != dst:
-                return None
-        return merge_catalogs(objs)
+        objs = self.transport.all_gather_object(local)
+        return merge_catalogs(objs) if dst is None or self.rank == dst else None
 
 
 def run_hod_sharded(halo_data, particle_data, tracers, params, comm=None, populate=None, gather=True, **kw):
     """Populate this rank's shard of a (replicated or memory-mapped) staged catalogue and merge.
 
     `populate(halo_shard, particle_shard, tracers, params, **kw)` defaults to the HIP `gen_gal_cat`."""
-    comm = comm or HodComm()
+    if comm is None:   # launched with WORLD_SIZE > 1: the process's RCCL communicator; else a single process
+        from ..comm import LocalComm, default_comm
+        t = default_comm()
+        comm = HodComm(None if isinstance(t, LocalComm) else t)
     if populate is None:
         from .GRAND_HOD import gen_gal_cat as populate
     h, p = shard_catalog(halo_data, particle_data, comm.rank, comm.world)

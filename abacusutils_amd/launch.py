@@ -58,6 +58,7 @@ def launch_ranks(argv, world, ranks=None, timeout=600.0, tag='RESULT', key=None,
     base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL across processes needs it on this driver
     base['ABACUS_RDZV_KEY'] = key or f'{os.getpid()}_{int(time.time() * 1e3)}'
     base['WORLD_SIZE'] = str(world)
+    base.setdefault('ABACUS_RDZV_T0', repr(time.time()))   # rendezvous files older than this launch are leftovers (comm.py)
     procs, files = {}, {}
     t0 = time.time()
     for r in ranks:
@@ -68,19 +69,21 @@ def launch_ranks(argv, world, ranks=None, timeout=600.0, tag='RESULT', key=None,
         procs[r] = subprocess.Popen(list(argv), env=e, stdout=out, stderr=err, start_new_session=True)
     timed_out = False
     first_failure = None
-    while True:
-        codes = {r: p.poll() for r, p in procs.items()}
-        if all(c is not None for c in codes.values()):
-            break
-        now = time.time()
-        if first_failure is None and any(c not in (None, 0) for c in codes.values()):
-            first_failure = now           # a rank died: its peers will wait for it in the next collective
-        if now - t0 > timeout or (first_failure is not None and now - first_failure > grace):
-            timed_out = now - t0 > timeout
-            for p in procs.values():
-                _end(p)
-            break
-        time.sleep(0.05)
+    try:
+        while True:
+            codes = {r: p.poll() for r, p in procs.items()}
+            if all(c is not None for c in codes.values()):
+                break
+            now = time.time()
+            if first_failure is None and any(c not in (None, 0) for c in codes.values()):
+                first_failure = now           # a rank died: its peers will wait for it in the next collective
+            if now - t0 > timeout or (first_failure is not None and now - first_failure > grace):
+                timed_out = now - t0 > timeout
+                break
+            time.sleep(0.05)
+    finally:      # also when the caller is being terminated (an exception raised from its signal handler): no orphans
+        for p in procs.values():
+            _end(p)
     res = {'results': {}, 'returncodes': {}, 'stderr': {}, 'timed_out': timed_out, 'seconds': time.time() - t0}
     for r, p in procs.items():
         out, err = files[r]

@@ -50,7 +50,7 @@ def parse():
     ap.add_argument('--no-hod-extra', action='store_true', help='skip the hod_multi and hod_large legs')
     ap.add_argument('--no-slab', action='store_true', help='N > 1: skip the slab-decomposed P(k) leg (RCCL all-to-all)')
     ap.add_argument('--slab-timeout', type=float, default=240.0, help='seconds before the slab leg is abandoned')
-    ap.add_argument('--hod-timeout', type=float, default=420.0, help='N > 1: seconds before the headline leg is abandoned')
+    ap.add_argument('--hod-timeout', type=float, default=270.0, help='N > 1: seconds before the headline leg is abandoned')
     ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE',
                     help='diagnostic option of the library (abacus_set_option), e.g. hod_nocls=1: A/B timing of a comparator path')
     ap.add_argument('--leg', default=None, choices=['hod', 'pk_slab'], help='internal: run one leg as a rank process')
@@ -124,8 +124,9 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
         st.populate_async(p)
     st.wait_counts()
     _lib.sync()
-    dist.barrier()
-    dt = dist.max(time.perf_counter() - t0)
+    t1 = time.perf_counter()     # this rank's K steps, device idle again; the closing barrier's own latency (an all-reduce
+    dist.barrier()               # round trip, or a file poll on the fallback transport) is not part of the steps
+    dt = dist.max(t1 - t0)
     _lib.profile_enable(False)
     _lib.profile_select(None)
     prof = _lib.profile_get()
@@ -311,20 +312,38 @@ def orchestrate(args, under_launcher):
         ok = all(c == 0 for c in res['returncodes'].values())
         return (res['results'].get(0) if is_root else None), ok, (None if ok else failure_summary(res))
 
-    out, ok, err = leg('hod', args.hod_timeout)
-    if out is None:
-        out = {'metric': 'halos/sec HOD populate', 'value': None, 'unit': 'halos/s', 'n_gpus': world, 'steps': args.steps,
-               'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f64', 'data': 'synthetic', 'config': {'workload': 'C2 per GPU (not measured)'}}
-    if err:
-        out['error'] = err
-    rc = 0 if ok else 1
-    if not args.no_slab and not args.no_pk:
-        slab, sok, serr = leg('pk_slab', args.slab_timeout)
-        slab = slab or {}
-        if serr:
-            slab['error'] = serr
-        out['pk_slab'] = slab
+    class Terminated(Exception):
+        pass
+
+    def on_term(signum, frame):     # the launcher ends the surviving ranks when one fails: still print the line
+        raise Terminated()
+
+    import signal
+    signal.signal(signal.SIGTERM, on_term)
+    out, rc = None, 1
+    fallback = {'metric': 'halos/sec HOD populate', 'value': None, 'unit': 'halos/s', 'n_gpus': world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'f64', 'data': 'synthetic', 'config': {'workload': 'C2 per GPU (not measured)'}}
+    try:
+        out, ok, err = leg('hod', args.hod_timeout)
+        if out is None:
+            out = dict(fallback)
+        if err:
+            out['error'] = err
+        rc = 0 if ok else 1
+        if not ok and not is_root:
+            time.sleep(3.0)     # under a launcher that ends every rank at the first failure: rank 0 reports first
+        if not args.no_slab and not args.no_pk:
+            slab, sok, serr = leg('pk_slab', args.slab_timeout)
+            slab = slab or {}
+            if serr:
+                slab['error'] = serr
+            out['pk_slab'] = slab
+    except Terminated:
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        out = out or dict(fallback)
+        out.setdefault('error', 'terminated by the launcher before the leg finished (another rank failed first)')
+        rc = 1
     if is_root:
         print(json.dumps(out), flush=True)
     return rc

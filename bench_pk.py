@@ -72,8 +72,9 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
     for _ in range(steps):
         step()
     _lib.sync()
+    t1 = time.perf_counter()
     dist.barrier()
-    dt = dist.max(time.perf_counter() - t0) / steps
+    dt = dist.max(t1 - t0) / steps
     _lib.profile_enable(False)
     prof = _lib.profile_get()
     kern = {k: ms / c for k, (ms, c) in prof.items() if c}
@@ -179,7 +180,8 @@ def bench_pk_slab(args, dist):
     nmesh, ntot = args.nmesh, args.npk
     L = 2000.0
     W, r = dist.world, dist.rank
-    comm = dist.comm if dist.comm is not None else sp.SlabComm()
+    from abacusutils_amd.comm import LocalComm
+    comm = dist.comm if dist.comm is not None else LocalComm()
     backend = sp.HipSlabBackend(keep_buffers=True)
     n_local = ntot // W
     rng = np.random.default_rng(300 + r)
@@ -199,8 +201,9 @@ def bench_pk_slab(args, dist):
     for _ in range(steps):
         tab = sp.calc_power_slab(dpos, L, comm=comm, backend=backend, **kw)
     _lib.sync()
+    t1 = time.perf_counter()
     dist.barrier()
-    dt = dist.max(time.perf_counter() - t0) / steps
+    dt = dist.max(t1 - t0) / steps
     sent = (comm.info()['bytes_sent'] - sent0) / steps if dist.comm is not None else 0
     power = np.asarray(tab['power'])
     shot = L**3 / (n_local * W)

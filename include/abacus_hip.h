@@ -298,6 +298,18 @@ int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void
                         double Lbox, const float *W_host, int interlaced, const double *kedges, int Nk,
                         const double *muedges, int Nmu, const int64_t *poles, int Np, void *raw_out);
 int64_t abacus_bin_raw_bytes(int Nk, int Nmu, const int64_t *poles, int Np);
+/* 1 if the slab entry points above run the FUSED form of the transform for this mesh (nmesh 1024 / 2048, like the single-GPU
+ * path: first radix-2 stage of y inside the z pass, of x inside the unpack, n/2-point column passes with 128-B row
+ * segments; rows of x and y then come out in the order f = 2 (r mod n/2) + (r div n/2), which abacus_slab_bin_dev and
+ * abacus_slab_xbin_dev undo); needs an even number of planes per abacus_slab_fft_zy_dev call */
+int abacus_slab_fused(int nmesh);
+/* last x pass FUSED with the binning on the unpacked (y_local, x, k) block (auto power of one non-interlaced field):
+ * replaces abacus_slab_fft_x_dev + abacus_slab_bin_dev.  Returns 0 (raw sums in the host buffer raw_out), 1 when this mesh /
+ * histogram is not served (call the two-step form instead), < 0 on error.  put_geom = 1 on exactly one rank: N_mode and
+ * sum |k| are mesh-wide quantities taken from the cached geometry of (nmesh, edges), not from the y-slab */
+int abacus_slab_xbin_dev(const void *mesh, int nmesh, int y0, int ny_local, double Lbox, const float *W_host,
+                         const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
+                         int put_geom, void *raw_out);
 /* particle routing on the device: stable bucket sort of (pos (n,3) float32, w or NULL) by the rank that owns the wrapped x
  * (x-slabs of width Lbox / world); counts[world] on the host.  The blocks then travel with abacus_comm_all_to_all_v. */
 int abacus_slab_route_dev(const float *pos, int64_t n, const float *w, double Lbox, int world, float *pos_out, float *w_out,

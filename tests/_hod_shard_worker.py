@@ -6,6 +6,7 @@ import pickle
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -30,7 +31,8 @@ def main():
         populate = lambda h, p, t, pr, **kw: oracle.gen_gal_cat(h, p, t, pr, Nthread=2, **kw)  # noqa: E731
     else:
         populate = None
-    comm = shard.HodComm()
+    from gloo_comm import GlooHodTransport
+    comm = shard.HodComm(GlooHodTransport() if world > 1 else None)
     cat = shard.run_hod_sharded(hd, pd, tracers, params, comm=comm, populate=populate, rsd=True)
     counts = comm.all_reduce_counts({t: (c['Ncent'], len(c['x']) - c['Ncent']) for t, c in
                                      shard.run_hod_sharded(hd, pd, tracers, params, comm=comm, populate=populate,

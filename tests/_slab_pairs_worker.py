@@ -7,6 +7,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def catalogues(n=4000, L=100.0):
@@ -39,8 +40,8 @@ def main():
     if world > 1:
         dist.init_process_group('gloo')
     from abacusutils_amd.analysis import slab_pairs as sp
-    from abacusutils_amd.analysis.slab_power import SlabComm
-    comm = SlabComm()
+    from gloo_comm import GlooSlabComm
+    comm = GlooSlabComm()
     counter = None
     if a.backend == 'oracle':
         from oracle import oracle

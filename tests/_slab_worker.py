@@ -38,7 +38,8 @@ def main():
         import torch.distributed as dist
         if world > 1 or a.force_collectives:
             dist.init_process_group('gloo')
-        comm = sp.SlabComm(force_collectives=a.force_collectives)
+        from gloo_comm import GlooSlabComm
+        comm = GlooSlabComm(force_collectives=a.force_collectives)
     L = 500.0
     # every rank draws the same catalogue and keeps an arbitrary half: route_particles moves them to their slabs
     pos = synth_positions(a.n, L, seed=11)

@@ -10,10 +10,17 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
-def _rank(rank, world, key, tmpdir, q):
+def _rank(rank, world, key, tmpdir, q, slow_rank=-1):
     os.environ['ABACUS_RDZV_DIR'] = tmpdir
+    import time
     from abacusutils_amd.comm import Dist, FileComm
-    d = Dist(FileComm(rank, world, key=key, timeout=30.0))
+
+    class SlowReader(FileComm):      # a rank that is late reading its peers' files (a loaded box)
+        def _read(self, path, what, t0):
+            time.sleep(0.15)
+            return super()._read(path, what, t0)
+
+    d = Dist((SlowReader if rank == slow_rank else FileComm)(rank, world, key=key, timeout=30.0))
     d.barrier()
     mx = d.max(float(10 + rank))
     sm = d.sum(float(rank + 1))
@@ -22,11 +29,13 @@ def _rank(rank, world, key, tmpdir, q):
     d.finish()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_file_comm_barrier_max_sum(world, tmp_path):
+@pytest.mark.parametrize('world,slow_rank', [(2, -1), (3, -1), (3, 1), (3, 0), (2, 1)])
+def test_file_comm_barrier_max_sum(world, slow_rank, tmp_path):
+    """slow_rank >= 0: that rank reads every peer file late - its peers have long finished (and called free()) when it
+    reads the last round; nothing it still needs may have been removed (teardown race)"""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank, args=(r, world, f'k{world}', str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank, args=(r, world, f'k{world}', str(tmp_path), q, slow_rank)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=60) for _ in range(world))
@@ -36,4 +45,4 @@ def test_file_comm_barrier_max_sum(world, tmp_path):
     for r, (rank, mx, sm, transport) in enumerate(got):
         assert rank == r and mx == 10 + world - 1 and sm == world * (world + 1) / 2
         assert 'file barrier' in transport
-    assert not [f for f in os.listdir(tmp_path) if '.file.' in f]   # every rank removed its own files
+    assert not [f for f in os.listdir(tmp_path) if '.file.' in f]   # rank 0 removed what was left after every rank's `done`
