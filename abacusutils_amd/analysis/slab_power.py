@@ -91,12 +91,13 @@ class HipSlabBackend:
         dw = w if (w is None or isinstance(w, _lib.DeviceArray)) else _lib.DeviceArray(np.ascontiguousarray(w, dtype=np.float32))
         return dpos, dw
 
-    def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste):
+    def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste, sub=0.0):
+        """planes [xoff, xoff + nx_total) (mod nmesh) as rho * norm - sub"""
         pos, w = particles
         n = pos.shape[0]
         _lib.check(_lib.lib().abacus_slab_deposit_dev(pos.ptr, C.c_int64(n), None if w is None else w.ptr, mesh.ptr(0),
                                                       int(nmesh), int(xoff), int(nx_total), C.c_double(Lbox),
-                                                      C.c_double(offset), C.c_double(norm), int(paste)))
+                                                      C.c_double(offset), C.c_double(norm), int(paste), C.c_double(sub)))
 
     def axpy(self, dst, dst_off, src, src_off, nfloat, add):
         _lib.check(_lib.lib().abacus_slab_axpy_dev(dst.ptr(dst_off), None if src is None else src.ptr(src_off),
@@ -214,13 +215,14 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     nxl = nmesh // W
     pitch = backend.pitch(nmesh)
     plane = nmesh * pitch
-    g = GHOST * plane
+    G = GHOST if comm.collective else 0   # one rank without a transport: the periodic mesh has no ghost planes
+    g = G * plane
     d = Lbox / nmesh
     nfields = (2 if interlaced else 1) * (2 if pos2 is not None else 1)
-    meshes = [backend.new_buffer((nxl + 2 * GHOST) * plane) for _ in range(nfields)]
+    meshes = [backend.new_buffer((nxl + 2 * G) * plane) for _ in range(nfields)]
     send = backend.new_buffer(nxl * plane)
     recv = backend.new_buffer(nxl * plane)
-    ghost = backend.new_buffer(2 * g)
+    ghost = backend.new_buffer(max(2 * g, 4))
     x0 = r * nxl
 
     # auto power of one non-interlaced field: the last x pass can bin straight from LDS (no spectrum write + re-read)
@@ -228,35 +230,33 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
 
     def spectrum(particles, ntot, offset, mesh):
         norm = float(np.float32(float(nmesh) ** 3 / float(ntot)))   # dtype(field.size / tot_weight) (:856,894)
-        backend.deposit(particles, mesh, nmesh, (x0 - GHOST) % nmesh, nxl + 2 * GHOST, Lbox, offset, norm, code)
+        # every cell is written as rho * norm - 1 (the overdensity's "-1" costs no pass of its own); a ghost block holds
+        # contribution - 1, so its owner adds ghost + 1
+        backend.deposit(particles, mesh, nmesh, (x0 - G) % nmesh, nxl + 2 * G, Lbox, offset, norm, code, sub=1.0)
         # left ghost block -> left neighbour, right ghost block -> right neighbour
         if comm.collective:
-            comm.ring_exchange(backend, mesh, 0, (GHOST + nxl) * plane, ghost, g)
-            # ghost[0:g]  came from the right neighbour (its left ghosts)  = my last GHOST owned planes
-            # ghost[g:2g] came from the left neighbour (its right ghosts)  = my first GHOST owned planes
-            backend.axpy(mesh, nxl * plane, ghost, 0, g, 0.0)
-            backend.axpy(mesh, GHOST * plane, ghost, g, g, 0.0)
-        else:                                                                  # periodic box on one rank
-            backend.axpy(mesh, nxl * plane, mesh, 0, g, 0.0)
-            backend.axpy(mesh, GHOST * plane, mesh, (GHOST + nxl) * plane, g, 0.0)
-        backend.axpy(mesh, GHOST * plane, None, 0, nxl * plane, -1.0)          # delta = rho*norm - 1 on the owned planes
+            comm.ring_exchange(backend, mesh, 0, (G + nxl) * plane, ghost, g)
+            # ghost[0:g]  came from the right neighbour (its left ghosts)  = my last G owned planes
+            # ghost[g:2g] came from the left neighbour (its right ghosts)  = my first G owned planes
+            backend.axpy(mesh, nxl * plane, ghost, 0, g, 1.0)
+            backend.axpy(mesh, G * plane, ghost, g, g, 1.0)
         # z / y passes, pack and pencil transpose in chunks of x-planes: chunk c is on the links (the communicator's
         # stream) while chunk c+1 is transformed
         nchunk = comm.transpose_chunks(nxl) if comm.collective else 1
         cx = nxl // nchunk
         nyl = nmesh // W
         for c in range(nchunk):
-            backend.fft_zy(mesh, (GHOST + c * cx) * plane, nmesh, cx)
-            backend.pack(mesh, GHOST * plane, send, nmesh, nxl, W, c * cx, cx)
+            backend.fft_zy(mesh, (G + c * cx) * plane, nmesh, cx)
+            backend.pack(mesh, G * plane, send, nmesh, nxl, W, c * cx, cx)
             if comm.collective:
                 comm.all_to_all_piece(backend, send, recv, nxl * nyl * pitch, c * cx * nyl * pitch, cx * nyl * pitch,
                                       overlap=nchunk > 1)
         if comm.collective:
             comm.join()
-        backend.unpack(recv if comm.collective else send, mesh, GHOST * plane, nmesh, nxl, W)   # mesh now holds (y_local, x, k)
+        backend.unpack(recv if comm.collective else send, mesh, G * plane, nmesh, nxl, W)   # mesh now holds (y_local, x, k)
         if not try_xbin:
-            backend.fft_x(mesh, GHOST * plane, nmesh, nxl)
-        return (mesh, GHOST * plane)
+            backend.fft_x(mesh, G * plane, nmesh, nxl)
+        return (mesh, G * plane)
 
     sets = [(pos, w, n_total)] + ([(pos2, w2, n_total2)] if pos2 is not None else [])
     fields = []

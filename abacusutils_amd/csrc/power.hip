@@ -38,14 +38,14 @@ using namespace abacus;
 
 namespace abacus {
 int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
-                    double offset, int wrap, double norm, int cic, int list_mode = 0);
+                    double offset, int wrap, double norm, int cic, int list_mode = 0, double sub = 1.0);
 int tsc_release_work();
 bool fft_native_supported(int n);
 int fft_native_r2c_inplace(float *mesh, int n, int pitch_r);
 int fft_native_zy(float *mesh, int n, int pitch_r, int64_t nx_local);
 int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_stride, int64_t y_stride);
 int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
-                         int64_t zstride, double box, double offset, int wrap, double norm, int cic);
+                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub = 0.0);
 int fft_native_release();
 int fft_native_fused_supported(int n);
 int fft_native_r2c_fused(float *mesh, int n, int pitch_r);   // rows come out in the permuted order of fft.hip's fused form
@@ -1159,12 +1159,14 @@ int abacus_pk_from_deltak(const void *field, const void *field2, int nmesh, doub
 int abacus_slab_pitch(int nmesh) { return pitch_r(nmesh); }
 
 int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int nx_local,
-                            double Lbox, double offset, double norm, int paste) {
+                            double Lbox, double offset, double norm, int paste, double sub) {
     ABACUS_ENTER();
     ABACUS_TRY(check_common(nmesh, paste));
     if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    if (nx_local == nmesh && xoff == 0)   // the whole periodic mesh on one rank: the single-GPU deposit (fast list build)
+        return tsc_deposit_f32(pos, n, w, mesh, nmesh, pitch_r(nmesh), Lbox, offset, paste == 0, norm, paste, 0, sub);
     return tsc_deposit_slab_f32(pos, n, w, mesh, nmesh, xoff, nx_local, pitch_r(nmesh), Lbox, offset, paste == 0, norm,
-                                paste);
+                                paste, sub);
 }
 
 int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add) {

@@ -1076,22 +1076,23 @@ namespace abacus {
 // list_mode: 0 = lists for this deposit only; 1 = build lists that a following deposit of the same particles shifted by
 // up to half a cell can reuse (call with offset 0); 2 = reuse them (rebuilds when anything changed)
 int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
-                    double offset, int wrap, double norm, int cic, int list_mode) {
+                    double offset, int wrap, double norm, int cic, int list_mode, double sub) {
     if (cic)
         return deposit_dev<float, float, true>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, 0, 1, norm,
-                                               nullptr, -1, 0, 1.0, list_mode);
+                                               nullptr, -1, 0, sub, list_mode);
     return deposit_dev<float, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
-                                            nullptr, -1, 0, 1.0, list_mode);
+                                            nullptr, -1, 0, sub, list_mode);
 }
 // x-slab variant: `grid` holds planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh, ghosts included;
-// written as rho*norm (no "-1": ghost planes are added to their owners first)
+// written as rho*norm - sub (sub = 1: the overdensity's "-1" in every cell; a ghost block is then added to its owner as
+// ghost + 1)
 int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
-                         int64_t zstride, double box, double offset, int wrap, double norm, int cic) {
+                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub) {
     if (cic)
         return deposit_dev<float, float, true>(pos, n, w, grid, nx_local, nmesh, nmesh, zstride, box, offset, 0, 1, norm,
-                                               nullptr, nmesh, xoff, 0.0);
+                                               nullptr, nmesh, xoff, sub);
     return deposit_dev<float, float, false>(pos, n, w, grid, nx_local, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
-                                            nullptr, nmesh, xoff, 0.0);
+                                            nullptr, nmesh, xoff, sub);
 }
 int tsc_release_work() {
     g_lists.valid = false;

@@ -279,10 +279,13 @@ int abacus_power_xbin_generation(void);
  * Mesh rows have abacus_slab_pitch(nmesh) floats (128-B aligned rows; complex rows of pitch/2).
  */
 int abacus_slab_pitch(int nmesh);
-/* deposit into planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh as rho*norm (ghost planes included) */
+/* deposit into planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh as rho*norm - sub (ghost planes included).
+ * sub = 1: every cell already carries the "-1" of the overdensity (normalize_field, power_spectrum.py:860-901) - a ghost
+ * block is then added to its owner as `ghost + 1` (abacus_slab_axpy_dev with add = 1) and no pass over the mesh is spent
+ * on the subtraction; nx_local == nmesh with xoff == 0 is the whole periodic mesh (one rank: no ghosts at all) */
 int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int nx_local,
-                            double Lbox, double offset, double norm, int paste);
-/* dst[i] += src[i] + add  (ghost-plane accumulation; "-1" of the overdensity with src == NULL) */
+                            double Lbox, double offset, double norm, int paste, double sub);
+/* dst[i] += src[i] + add  (ghost-plane accumulation; a constant alone with src == NULL) */
 int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add);
 /* z and y passes of the 3-D R2C FFT on nx_local owned planes, in place */
 int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local);

@@ -22,6 +22,8 @@ def main():
     ap.add_argument('--interlaced', type=int, default=1)
     ap.add_argument('--compensated', type=int, default=1)
     ap.add_argument('--cross', type=int, default=0)
+    ap.add_argument('--kbins', type=int, default=16)
+    ap.add_argument('--option', action='append', default=[], help='library option name=value (abacus_set_option)')
     ap.add_argument('--out', required=True)
     a = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -50,13 +52,17 @@ def main():
                                     _lib.DeviceArray(np.ascontiguousarray(w[mine])), L, comm)
     else:
         p1, w1 = sp.route_particles(pos[mine], w[mine], L, comm)
-    kw = dict(kbins=16, mubins=4, paste='TSC', nmesh=a.nmesh, compensated=bool(a.compensated),
+    kw = dict(kbins=a.kbins, mubins=4, paste='TSC', nmesh=a.nmesh, compensated=bool(a.compensated),
               interlaced=bool(a.interlaced), poles=[0, 2, 4])
     if a.backend == 'numpy':
         from slab_numpy_backend import NumpySlabBackend
         backend = NumpySlabBackend()
     else:
         backend = sp.HipSlabBackend()
+        from abacusutils_amd import _lib as lib_
+        for kv in a.option:
+            name, _, val = kv.partition('=')
+            lib_.set_option(name, int(val or 1))
     extra = {}
     if a.cross:
         pos2 = synth_positions(a.n // 2, L, seed=12)

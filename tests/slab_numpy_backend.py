@@ -34,7 +34,7 @@ class NumpySlabBackend:
     def upload_particles(self, pos, w):
         return (np.array(pos, dtype=np.float32), None if w is None else np.asarray(w, dtype=np.float32))
 
-    def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste):
+    def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste, sub=0.0):
         assert paste == 0, 'CPU stand-in: TSC only'
         pos, w = particles
         full = np.zeros((nmesh,) * 3, dtype=np.float32)
@@ -44,8 +44,9 @@ class NumpySlabBackend:
             oracle.tsc_scatter(p, full, Lbox, weights=w, offset=offset)
         pitch = self.pitch(nmesh)
         win = np.zeros((nx_total, nmesh, pitch), dtype=np.float32)
+        win[:, :, :nmesh] = -np.float32(sub)           # window planes past one period receive no deposit: 0 * norm - sub
         for i in range(min(nx_total, nmesh)):          # plane i of the window = global plane (xoff + i) mod n
-            win[i, :, :nmesh] = full[(xoff + i) % nmesh] * np.float32(norm)
+            win[i, :, :nmesh] = full[(xoff + i) % nmesh] * np.float32(norm) - np.float32(sub)
         mesh.a[:win.size] = win.ravel()
 
     def axpy(self, dst, dst_off, src, src_off, n, add):

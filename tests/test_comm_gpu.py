@@ -56,14 +56,19 @@ assert np.array_equal(rp.get(), pos) and np.array_equal(rw.get(), w)
 # pipeline of BASELINE config 4, at 512^3 and at the full 2048^3 of the north star
 from abacusutils_amd.analysis.slab_power import HipSlabBackend, calc_power_slab
 from abacusutils_amd.analysis.power_spectrum import calc_power
-for nmesh, n in ((512, 3_000_000), (2048, 20_000_000)):
+# 512: plain three-pass form; 1024 / 2048: the fused form with the last pass binning straight from LDS (2048: compensated;
+# 1024 a second time with `slab_nofuse` = the plain form as comparator)
+for nmesh, n, nofuse in ((512, 3_000_000, 0), (1024, 5_000_000, 0), (1024, 5_000_000, 1), (2048, 20_000_000, 0)):
     L = 2000.0
     pos = np.random.default_rng(11).random((n, 3), dtype=np.float32) * np.float32(L)
     pos[:, 0] -= np.float32(L / 2)                      # x outside [0, L): routing wraps it
-    kw = dict(kbins=min(256, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L, paste='TSC', nmesh=nmesh, compensated=True,
+    kw = dict(kbins=min(256, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L, paste='TSC', nmesh=nmesh, compensated=nmesh != 1024,
               interlaced=(nmesh == 512), poles=[0, 2, 4])
     dpos, _ = c.route_particles(_lib.DeviceArray(pos), None, L)
+    _lib.set_option('slab_nofuse', nofuse)
+    assert _lib.lib().abacus_slab_fused(nmesh) == (1 if nmesh >= 1024 and not nofuse else 0)
     tab = calc_power_slab(dpos, L, comm=c, backend=HipSlabBackend(), n_total=n, **kw)
+    _lib.set_option('slab_nofuse', 0)
     ref = calc_power(pos.copy(), L, **kw)
     assert np.array_equal(np.asarray(tab['N_mode']), np.asarray(ref['N_mode'])), nmesh
     ok = np.asarray(ref['N_mode']) > 0

@@ -30,10 +30,10 @@ def run_ranks(tmp_path, world, backend, port, flags=(), **kw):
     return [np.load(f'{out}.rank{k}.npz') for k in range(world)]
 
 
-def reference(nmesh=64, n=20000, interlaced=1, compensated=1, cross=0):
+def reference(nmesh=64, n=20000, interlaced=1, compensated=1, cross=0, kbins=16):
     pos = synth_positions(n, L, seed=11)
     w = np.random.default_rng(5).random(n, dtype=np.float32) + np.float32(0.5)
-    kw = dict(kbins=16, mubins=4, paste='TSC', nmesh=nmesh, compensated=bool(compensated), interlaced=bool(interlaced),
+    kw = dict(kbins=kbins, mubins=4, paste='TSC', nmesh=nmesh, compensated=bool(compensated), interlaced=bool(interlaced),
               poles=[0, 2, 4], nthread=2, accum64=True)
     if cross:
         kw['pos2'] = synth_positions(n // 2, L, seed=12)
@@ -69,6 +69,36 @@ def test_slab_cross_cpu(tmp_path):
 def test_slab_hip(tmp_path, world, interlaced, compensated, cross):
     res = run_ranks(tmp_path, world, 'hip', 29631 + world, interlaced=interlaced, compensated=compensated, cross=cross)
     check(res, reference(interlaced=interlaced, compensated=compensated, cross=cross), world, 20000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,interlaced,cross', [(1, 0, 0), (2, 1, 0), (4, 0, 1), (4, 0, 0)])
+def test_slab_hip_fused_form_small(tmp_path, world, interlaced, cross):
+    """the FUSED slab transform (y stage inside the z pass, x stage inside the unpack, n/2-point column passes, permuted
+    rows undone by the binning) at a mesh the CPU oracle can check: nmesh 256 with `fft_fuse_small`, 1 / 2 / 4 ranks"""
+    res = run_ranks(tmp_path, world, 'hip', 29651 + world, flags=('--option', 'fft_fuse_small=1'), nmesh=256, kbins=40,
+                    interlaced=interlaced, compensated=1, cross=cross)
+    check(res, reference(nmesh=256, interlaced=interlaced, compensated=1, cross=cross, kbins=40), world, 20000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,compensated', [(2, 0), (4, 1)])
+def test_slab_hip_fused_last_pass_on_y_slabs(tmp_path, world, compensated):
+    """nmesh 1024, auto power of one non-interlaced field: after the pencil transpose every rank runs the last x pass fused
+    with the binning on its y-slab (abacus_slab_xbin_dev, y0 > 0 on ranks > 0, N_mode / k_avg from the cached geometry on
+    rank 0 only) - against the single-GPU calc_power on the same catalogue"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    res = run_ranks(tmp_path, world, 'hip', 29661 + world, nmesh=1024, kbins=128, interlaced=0, compensated=compensated)
+    pos = synth_positions(20000, L, seed=11)
+    w = np.random.default_rng(5).random(20000, dtype=np.float32) + np.float32(0.5)
+    ref = calc_power(pos, L, kbins=128, mubins=4, paste='TSC', nmesh=1024, compensated=bool(compensated), interlaced=False,
+                     poles=[0, 2, 4], w=w)
+    for r in res:
+        np.testing.assert_array_equal(r['N_mode'], np.asarray(ref['N_mode']))
+        scale = np.abs(np.asarray(ref['power'])).max()
+        np.testing.assert_allclose(r['power'], np.asarray(ref['power']), rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(r['poles'], np.asarray(ref['poles']), rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(r['k_avg'], np.asarray(ref['k_avg']), rtol=1e-6)
 
 
 @pytest.mark.gpu
