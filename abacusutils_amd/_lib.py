@@ -172,6 +172,71 @@ class DeviceArray:
             pass
 
 
+class _PinnedPool:
+    """page-locked host blocks (abacus_host_alloc) handed out as NumPy arrays and recycled: a block returns to the pool
+    when the last array viewing it is garbage-collected.  Device-to-host copies of the galaxy catalogues land in these
+    (one DMA, no page faults of a fresh allocation).  Blocks are power-of-two sized; at most `cap_bytes` stay pinned
+    (beyond that, or if pinning fails, plain NumPy memory is returned)."""
+
+    def __init__(self, cap_bytes=2 << 30):
+        self.free = {}          # size class -> [address]
+        self.total = 0
+        self.cap = cap_bytes
+
+    def _release(self, addr, size):
+        self.free.setdefault(size, []).append(addr)
+
+    def empty(self, shape, dtype):
+        import weakref
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        if nbytes == 0:
+            return np.empty(shape, dtype=dtype)
+        size = 1 << max(12, (nbytes - 1).bit_length())
+        pool = self.free.get(size)
+        if pool:
+            addr = pool.pop()
+        else:
+            if self.total + size > self.cap:
+                return np.empty(shape, dtype=dtype)
+            p = C.c_void_p()
+            if lib().abacus_host_alloc(C.byref(p), C.c_uint64(size)) != 0 or not p.value:
+                return np.empty(shape, dtype=dtype)
+            addr = p.value
+            self.total += size
+        buf = (C.c_char * size).from_address(addr)
+        weakref.finalize(buf, self._release, addr, size)     # the array below keeps `buf` alive through its base chain
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def drain(self):
+        for size, pool in self.free.items():
+            for addr in pool:
+                lib().abacus_host_free(C.c_void_p(addr))
+                self.total -= size
+        self.free = {}
+
+
+_pinned = _PinnedPool()
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """uninitialised array in page-locked host memory (recycled by the pool above), or plain memory as a fallback"""
+    return _pinned.empty(shape, dtype)
+
+
+def poshash_host(a):
+    """sum_i word[i] * (2 i + 1) mod 2^64 of a contiguous array of 8-byte values (the host side of abacus_poshash_u64)"""
+    w = np.ascontiguousarray(a).view(np.uint64).ravel()
+    with np.errstate(over='ignore'):
+        return int((w * (np.arange(w.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1))).sum(dtype=np.uint64))
+
+
+def poshash_device(dptr, n):
+    out = C.c_uint64(0)
+    check(lib().abacus_poshash_u64(dptr, C.c_int64(int(n)), C.byref(out)))
+    return int(out.value)
+
+
 class Event:
     def __init__(self):
         self.ev = C.c_void_p()

@@ -7,6 +7,8 @@
 #include <vector>
 
 #include "../../include/abacus_hip.h"
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace abacus {
@@ -206,6 +208,46 @@ int abacus_memcpy_d2h(void *dst, const void *src, uint64_t nbytes) {
 int abacus_memset(void *dptr, int value, uint64_t nbytes) {
     ABACUS_ENTER();
     HIP_TRY(hipMemsetAsync(dptr, value, nbytes, g_stream));
+    return 0;
+}
+
+// page-locked host memory: a device-to-host copy into it is one DMA at link speed (a pageable destination is copied
+// through a staging buffer, and a fresh NumPy allocation is page-faulted in on top of that)
+int abacus_host_alloc(void **hptr, uint64_t nbytes) {
+    ABACUS_ENTER();
+    HIP_TRY(hipHostMalloc(hptr, nbytes ? nbytes : 1, hipHostMallocDefault));
+    return 0;
+}
+int abacus_host_free(void *hptr) {
+    if (hptr) HIP_TRY(hipHostFree(hptr));
+    return 0;
+}
+
+namespace {
+// sum over i of word[i] * (2 i + 1) mod 2^64: a position-dependent checksum of a column of 8-byte values (any in-place
+// edit, a permutation of rows included, changes it)
+__global__ void poshash_u64(const unsigned long long *__restrict__ a, int64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += a[i] * (2ull * (unsigned long long)i + 1ull);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+DevBuf g_hash_scratch;
+}  // namespace
+
+int abacus_poshash_u64(const void *dptr, int64_t n, uint64_t *out) {
+    ABACUS_ENTER();
+    if (!out || (n > 0 && !dptr)) return fail("abacus_poshash_u64: null argument");
+    ABACUS_TRY(g_hash_scratch.reserve(8));
+    HIP_TRY(hipMemsetAsync(g_hash_scratch.p, 0, 8, g_stream));
+    if (n > 0) {
+        const int grid = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), 256 * 8);
+        ABACUS_LAUNCH("poshash", poshash_u64, dim3(grid), dim3(256), 0, (const unsigned long long *)dptr, n,
+                      g_hash_scratch.as<unsigned long long>());
+    }
+    HIP_TRY(hipMemcpyAsync(out, g_hash_scratch.p, 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
     return 0;
 }
 

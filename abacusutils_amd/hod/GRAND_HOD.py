@@ -200,13 +200,12 @@ class StagedCatalog:
         """device -> host copy of one tracer's catalog, in the reference's dict form (:1573-1589)"""
         t = TRACERS.index(tracer)
         n = int(self.counts[t] + self.counts[3 + t])
-        block = np.empty((8, n), dtype=np.float64)   # one transfer; the columns below are views of it
+        block = _lib.pinned_empty((8, n), np.float64)   # one transfer into page-locked memory; the columns are views of it
         check(_lib.lib().abacus_hod_fetch_block(self._h, t, ptr(block), C.c_int64(n)))
-        cols = {c: block[q] for q, c in enumerate(COLS)}
-        ids = block[7].view(np.int64)
         d = {'Ncent': int(self.counts[t])}
-        d.update(cols)
-        d['id'] = ids
+        for q, c in enumerate(COLS):
+            d[c] = block[q]
+        d['id'] = block[7].view(np.int64)
         return d
 
     def device_columns(self, tracer):
@@ -233,52 +232,130 @@ class StagedCatalog:
             pass
 
 
+class LazyTracer(dict):
+    """One tracer's catalogue with the reference's keys ('x' ... 'mass', 'id', 'Ncent') whose columns are still in HBM:
+    the device-to-host copy (all eight columns, one transfer) happens at the first access of any of them.  An MCMC step
+    that goes populate -> clustering on the device (`compute_power`, `compute_xirppi`, ...) never pays the copy.
+    Opt-in (`AbacusHOD.lazy_columns = True`): the columns can only be materialised until the NEXT populate of the same
+    staged catalogue rewrites them - accessing a stale, never-read catalogue raises instead of returning wrong galaxies.
+    Behaves like a dict once touched; pickles / copies as a plain dict."""
+
+    def __init__(self, staged, tracer, ncent):
+        super().__init__(Ncent=int(ncent))
+        import weakref
+        self._staged, self._generation, self._tracer = weakref.ref(staged), staged.generation, tracer
+        for c in COLS + ('id',):
+            dict.__setitem__(self, c, None)          # placeholders: the keys exist from the start
+
+    def _load(self):
+        ref = self.__dict__.pop('_staged', None)
+        if ref is None:
+            return
+        st = ref()
+        if st is None or not st._h or st.generation != self._generation:
+            self.__dict__['_staged'] = ref
+            raise RuntimeError(f'the {self._tracer} catalogue of this mock was never read and a later run_hod() has replaced '
+                               'it in HBM (AbacusHOD.lazy_columns = True): read the columns before the next run_hod(), or '
+                               'switch lazy_columns off')
+        full = st.fetch(self._tracer)
+        for k, v in full.items():
+            if k != 'Ncent':
+                dict.__setitem__(self, k, v)
+
+    def __getitem__(self, k):
+        if k != 'Ncent':
+            self._load()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        if k != 'Ncent':
+            self._load()
+        return dict.get(self, k, default)
+
+    def __iter__(self):            # overriding the iteration makes dict(self) / {**self} go through __getitem__
+        return dict.__iter__(self)
+
+    def keys(self):
+        return dict.keys(self)
+
+    def items(self):
+        self._load()
+        return dict.items(self)
+
+    def values(self):
+        self._load()
+        return dict.values(self)
+
+    def pop(self, k, *default):
+        if k != 'Ncent':
+            self._load()
+        return dict.pop(self, k, *default)
+
+    def copy(self):
+        self._load()
+        return dict(dict.items(self))
+
+    def __eq__(self, other):
+        self._load()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        if '_staged' in self.__dict__:
+            return f'<LazyTracer {self._tracer}: Ncent={dict.__getitem__(self, "Ncent")}, columns in HBM>'
+        return dict.__repr__(self)
+
+    def __reduce__(self):
+        self._load()
+        return (dict, (dict(dict.items(self)),))
+
+
 class MockDict(dict):
     """The `mock_dict` of run_hod / gen_gal_cat - a plain dict of NumPy columns, exactly the reference's - that also
     remembers where the same columns still sit in HBM, so that the clustering step (compute_power, compute_xirppi, ...)
     can start from there instead of uploading them again.  `device_xyz(tracer)` returns None as soon as that is no
     longer safe: a later populate rewrote the device catalogue, the staged catalogue was freed, or the host columns were
-    replaced / modified (a strided sample of x, y, z is compared with the values at creation)."""
-    _SAMPLE = 16
+    replaced or modified IN ANY ROW - a position-dependent checksum of the whole host column is compared with the same
+    checksum of the device column (one pass over 3 n values on either side, cheaper than the upload it saves; nothing is
+    computed when the mock is created).  Pickles and copies as a plain dict."""
 
     def _bind(self, staged):
         import weakref
         self._staged = weakref.ref(staged)
         self._generation = staged.generation
-        self._fingerprint = {tr: self._sample(tr) for tr in self}
         return self
 
-    def _sample(self, tr):
-        d = self[tr]
-        out = []
-        for c in ('x', 'y', 'z'):
-            a = d[c]
-            step = max(1, len(a) // self._SAMPLE)
-            out.append((id(a), len(a), np.array(a[::step][: self._SAMPLE], copy=True)))
-        return out
+    def __reduce__(self):
+        return (dict, ({k: (dict(v) if isinstance(v, dict) else v) for k, v in dict.items(self)},))
 
     def device_xyz(self, tracer):
         st = getattr(self, '_staged', lambda: None)()
-        if st is None or not st._h or st.generation != self._generation or tracer not in self._fingerprint or tracer not in self:
+        if st is None or not st._h or st.generation != self._generation or tracer not in self:
             return None
-        try:
-            now = self._sample(tracer)
-        except (KeyError, TypeError):
-            return None
-        for (i0, n0, s0), (i1, n1, s1) in zip(self._fingerprint[tracer], now):
-            if i0 != i1 or n0 != n1 or not np.array_equal(s0, s1):
-                return None
-        n = len(self[tracer]['x'])
+        d = self[tracer]
+        lazy = isinstance(d, LazyTracer) and '_staged' in d.__dict__     # never copied to the host: nothing to compare
+        n = int(st.counts[TRACERS.index(tracer)] + st.counts[3 + TRACERS.index(tracer)])
         if n == 0:
             return None
         cols = st.device_columns(tracer)
+        if not lazy:
+            try:
+                for q, c in enumerate(('x', 'y', 'z')):
+                    a = d[c]
+                    if not isinstance(a, np.ndarray) or a.shape != (n,) or a.dtype != np.float64:
+                        return None
+                    if _lib.poshash_host(a) != _lib.poshash_device(cols[q], n):
+                        return None
+            except (KeyError, TypeError):
+                return None
         return [_lib.DeviceArray.view(cols[q], np.float64, (n,)) for q in range(3)]
 
 
 def gen_gals(halos_array, subsample, tracers, params, Nthread, enable_ranks, rsd, verbose, nfw, NFW_draw=None,
-             staged=None):
+             staged=None, lazy=False):
     """hod/GRAND_HOD.py:1302-1592.  `staged`: a StagedCatalog to reuse (extension); otherwise the arrays are
-    uploaded for this call only."""
+    uploaded for this call only.  `lazy` (with `staged`): the columns stay in HBM until first read (LazyTracer)."""
     p = marshal_params(tracers, params, enable_ranks, rsd)
     own = staged is None
     if own:
@@ -305,7 +382,8 @@ def gen_gals(halos_array, subsample, tracers, params, Nthread, enable_ranks, rsd
         for tracer in tracers:
             if tracer not in TRACERS:
                 continue
-            HOD_dict[tracer] = staged.fetch(tracer)
+            t = TRACERS.index(tracer)
+            HOD_dict[tracer] = LazyTracer(staged, tracer, ncent[t]) if (lazy and not own and not verbose) else staged.fetch(tracer)
             if verbose:
                 n = len(HOD_dict[tracer]['x'])
                 print(tracer, 'number of galaxies ', n)
@@ -341,14 +419,14 @@ def _write_ecsv(path, cols, meta):
 
 
 def gen_gal_cat(halo_data, particle_data, tracers, params, Nthread=16, enable_ranks=False, rsd=True, nfw=False,
-                NFW_draw=None, write_to_disk=False, savedir='./', verbose=False, fn_ext=None, staged=None):
+                NFW_draw=None, write_to_disk=False, savedir='./', verbose=False, fn_ext=None, staged=None, lazy=False):
     """Drop-in for hod/GRAND_HOD.py:1595-1724: returns {tracer: {'x','y','z','vx','vy','vz','mass' (float64),
     'id' (int64), 'Ncent' (int)}} with centrals first; optionally writes `{tracer}s.dat` ECSV files."""
     if not isinstance(rsd, bool):
         raise ValueError('Error: rsd has to be a boolean')
 
     HOD_dict = gen_gals(halo_data, particle_data, tracers, params, Nthread, enable_ranks, rsd, verbose, nfw,
-                        NFW_draw, staged=staged)
+                        NFW_draw, staged=staged, lazy=lazy and not write_to_disk)
 
     if write_to_disk and tracers:
         rsd_string = '_rsd' if rsd else ''
@@ -357,6 +435,8 @@ def gen_gal_cat(halo_data, particle_data, tracers, params, Nthread=16, enable_ra
         os.makedirs(outdir, exist_ok=True)
 
     for tracer in tracers.keys():
+        if not (verbose or write_to_disk):
+            continue
         Ncent = HOD_dict[tracer]['Ncent']
         if verbose:
             n = len(HOD_dict[tracer]['x'])

@@ -86,6 +86,15 @@ def calc_fenv_opt(Menv, mbins, halosM):
 class AbacusHOD:
     """A multi-tracer HOD code for the AbacusSummit simulations (MI355X path)."""
 
+    # Extensions of the reference class (both off = the reference's behaviour):
+    # lazy_columns: run_hod() returns at once with the galaxy columns still in HBM; they are copied to NumPy at the first
+    #   read (GRAND_HOD.LazyTracer) and only until the next run_hod() - an MCMC step that feeds the mock straight into
+    #   compute_power / compute_xirppi / compute_wp / compute_multipole never pays the PCIe copy.
+    # reseed_sync_host: after `run_hod(reseed=...)` copy the redrawn random columns back into halo_data / particle_data
+    #   like the reference mutates them (True), or leave them on the device only (False).
+    lazy_columns = False
+    reseed_sync_host = True
+
     def __init__(self, sim_params, HOD_params, clustering_params=None, chunk=-1, n_chunks=1, skip_staging=False):
         self.logger = logging.getLogger('AbacusHOD')
         self.sim_name = sim_params['sim_name']
@@ -392,7 +401,7 @@ class AbacusHOD:
         mock_dict = gen_gal_cat(self.halo_data, self.particle_data, tracers, self.params, Nthread,
                                 enable_ranks=self.want_ranks, rsd=want_rsd, nfw=want_nfw, NFW_draw=NFW_draw,
                                 write_to_disk=write_to_disk, savedir=self.mock_dir, verbose=verbose, fn_ext=fn_ext,
-                                staged=self._device_catalog())
+                                staged=self._device_catalog(), lazy=getattr(self, 'lazy_columns', False))
         self.logger.info(f'HOD generated in elapsed time {time.time() - start:.2f} s.')
         return mock_dict
 

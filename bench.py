@@ -239,6 +239,59 @@ def bench_hod(args, dist):
     return out
 
 
+def bench_calls(args, dist):
+    """what a CALLER of the drop-in surface sees, per call, at BASELINE config 2 (1e7 halos + 1e7 particles, LRG): the loop
+    of the reference's scripts/hod/run_hod.py:40-73 - mutate a parameter, AbacusHOD.run_hod(), a clustering statistic"""
+    import numpy as np
+    from abacusutils_amd import synth
+    from abacusutils_amd.hod.abacus_hod import AbacusHOD
+    hod = dict(tracer_flags={'LRG': True, 'ELG': False, 'QSO': False}, want_ranks=False, want_AB=True, want_shear=False,
+               want_rsd=True, LRG_params=synth.LRG_PARAMS, ELG_params=synth.ELG_PARAMS, QSO_params=synth.QSO_PARAMS)
+    hd, pd, params = synth.synth_hod_inputs(args.nhalo, args.npart, seed=600)
+    ball = AbacusHOD.from_arrays(hd, pd, params, hod)
+    out = {'config': {'workload': f'AbacusHOD.run_hod() and clustering calls on the C2 catalogue ({args.nhalo:.0e} halos + '
+                                  f'{args.npart:.0e} particles, LRG), one parameter changed per call'}}
+
+    def loop(reps, body):
+        body(0)
+        t0 = time.perf_counter()
+        for i in range(reps):
+            body(i + 1)
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    state = {}
+
+    def run(i):
+        ball.tracers['LRG']['logM_cut'] = 13.3 + 0.001 * (i % 5)
+        state['m'] = ball.run_hod(ball.tracers, True, Nthread=16)
+
+    for lazy, key in ((False, 'run_hod_call_ms'), (True, 'run_hod_call_lazy_ms')):
+        ball.lazy_columns = lazy
+        loop(5, run)
+        out[key] = loop(100, run)
+    out['galaxies'] = int(len(state['m']['LRG']['x']))
+    out['run_hod_note'] = ('run_hod_call_ms: the eight columns returned as NumPy arrays every call (one device-to-host copy of '
+                           '64 B per galaxy into recycled page-locked memory); run_hod_call_lazy_ms: AbacusHOD.lazy_columns = True, '
+                           'columns left in HBM until read')
+    ball.lazy_columns = True
+    rp = np.geomspace(0.2, 30.0, 9)
+
+    def run_wp(i):
+        run(i)
+        state['wp'] = ball.compute_wp(state['m'], rp, 30, 1)
+
+    def run_pk(i):
+        run(i)
+        state['pk'] = ball.compute_power(state['m'], 32, 4, 0.5, False, poles=[0, 2], num_cells=512)
+
+    out['run_hod_plus_compute_wp_ms'] = loop(10, run_wp)
+    out['run_hod_plus_compute_power_ms'] = loop(10, run_pk)
+    out['compute_note'] = 'lazy mock fed to compute_wp (8 log bins to 30 Mpc/h, pimax 30) / compute_power (512^3 TSC, 32 x 4 bins, poles 0, 2): galaxies never leave HBM'
+    if ball._staged is not None:
+        ball._staged.free()
+    return out
+
+
 def cpu_baseline_hod(hd, pd, params, tracers, nh, enable_ranks=False):
     """the oracle's compiled kernels (C + OpenMP restatement of the reference's two-pass chunked algorithm) on the host
     cores: arrays marshalled and outputs allocated outside the timed region (oracle.time_gen_gals), thread counts swept
@@ -362,7 +415,8 @@ def single(args):
         out = bench_hod(args, dist)
         if not args.no_pk:
             import bench_pk
-            for key, fn in (('pk', lambda: bench_pk.bench_pk(args, dist, headline=False, cpu=False)),
+            for key, fn in (('calls', lambda: bench_calls(args, dist)),
+                            ('pk', lambda: bench_pk.bench_pk(args, dist, headline=False, cpu=False)),
                             # BASELINE config 3 itself (1024^3, 1e8 particles), with the CPU oracle timed on the same workload
                             ('pk_c3', lambda: bench_pk.bench_pk(args, dist, headline=False, nmesh=1024, variants=False)),
                             ('pairs', lambda: bench_pk.bench_pairs(args, dist)),

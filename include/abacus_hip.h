@@ -42,6 +42,13 @@ int abacus_free(void *dptr);
 int abacus_memcpy_h2d(void *dst, const void *src, uint64_t nbytes);
 int abacus_memcpy_d2h(void *dst, const void *src, uint64_t nbytes);
 int abacus_memset(void *dptr, int value, uint64_t nbytes);
+/* page-locked host memory (hipHostMalloc): device-to-host copies into it are single DMAs at link speed.  The Python side
+ * hands catalogue columns out as NumPy views of such blocks and recycles them (abacusutils_amd/_lib.py pinned_empty) */
+int abacus_host_alloc(void **hptr, uint64_t nbytes);
+int abacus_host_free(void *hptr);
+/* sum_i word[i] * (2 i + 1) mod 2^64 over n 8-byte words in HBM: position-dependent checksum of a device column (is a host
+ * copy of the column still what the device holds?) */
+int abacus_poshash_u64(const void *dptr, int64_t n, uint64_t *out);
 
 /* HIP-event timers on the library stream (bench.py: roofline.achieved) */
 int abacus_event_create(void **ev);

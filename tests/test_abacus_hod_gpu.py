@@ -131,11 +131,62 @@ def test_clustering_from_the_catalogue_in_hbm_matches_the_host_path():
             np.testing.assert_array_equal(got['power'][k], want['power'][k])
         else:
             np.testing.assert_allclose(got['power'][k], want['power'][k], rtol=2e-6, atol=1e-6 * np.abs(want['power'][k]).max(), err_msg=k)
-    # staleness
-    mock['LRG']['x'][:] += 1.0
+    # staleness: ANY in-place edit of a host column is seen (whole-column checksum against the device column), also one
+    # that touches a single row or swaps two rows
+    z = mock['LRG']['z']
+    z[len(z) // 3] += 1e-9
     assert mock.device_xyz('LRG') is None and mock.device_xyz('ELG') is not None
+    y = mock['ELG']['y']
+    y[[5, 7]] = y[[7, 5]]
+    assert mock.device_xyz('ELG') is None
+    y[[5, 7]] = y[[7, 5]]
+    assert mock.device_xyz('ELG') is not None
     mock2 = ball.run_hod()
     assert mock.device_xyz('ELG') is None and mock2.device_xyz('ELG') is not None
+    # a mock travels like the reference's plain dict: pickle (multiprocessing / emcee pools, np.save)
+    import pickle
+    back = pickle.loads(pickle.dumps(mock2))
+    assert type(back) is dict and set(back) == set(mock2)
+    for tr in mock2:
+        assert back[tr]['Ncent'] == mock2[tr]['Ncent']
+        for c in ('x', 'vz', 'mass', 'id'):
+            np.testing.assert_array_equal(back[tr][c], mock2[tr][c])
+
+
+def test_lazy_columns():
+    """AbacusHOD.lazy_columns: run_hod returns with the columns still in HBM; clustering runs from there; the first read
+    copies all eight columns and gives exactly what the eager call returns; a never-read mock refuses to be read after a
+    later run_hod replaced it"""
+    import pickle
+
+    from abacusutils_amd.hod.GRAND_HOD import LazyTracer
+    from abacusutils_amd.hod.abacus_hod import AbacusHOD
+    hd, pd, params = synth.synth_hod_inputs(300000, 300000, seed=19, lbox=1000.0)
+    hod = dict(HOD_PARAMS, LRG_params=dict(synth.LRG_PARAMS, logM_cut=12.3, logM1=13.3), ELG_params=dict(synth.ELG_PARAMS))
+    ball = AbacusHOD.from_arrays(hd, pd, params, hod, CLUSTERING)
+    eager = ball.run_hod()
+    wp_eager = ball.compute_wp(eager, ball.rpbins, ball.pimax, ball.pi_bin_size)
+    ball.lazy_columns = True
+    lazy = ball.run_hod()
+    assert all(isinstance(lazy[tr], LazyTracer) and '_staged' in lazy[tr].__dict__ for tr in lazy)   # nothing copied yet
+    assert lazy['LRG']['Ncent'] == eager['LRG']['Ncent'] and 'x' in lazy['LRG'] and set(lazy['LRG']) == set(eager['LRG'])
+    wp_lazy = ball.compute_wp(lazy, ball.rpbins, ball.pimax, ball.pi_bin_size)                        # from HBM
+    assert all('_staged' in lazy[tr].__dict__ for tr in lazy)
+    for k in wp_eager:
+        np.testing.assert_array_equal(wp_lazy[k], wp_eager[k])
+    for tr in eager:                                                                                  # first read
+        for c in ('x', 'y', 'z', 'vx', 'vy', 'vz', 'mass', 'id'):
+            np.testing.assert_array_equal(lazy[tr][c], eager[tr][c], err_msg=f'{tr} {c}')
+        assert dict(lazy[tr]).keys() == eager[tr].keys()
+    assert lazy.device_xyz('LRG') is not None
+    lazy2 = ball.run_hod()
+    back = pickle.loads(pickle.dumps(lazy2))                   # pickling reads the columns
+    np.testing.assert_array_equal(back['ELG']['x'], eager['ELG']['x'])
+    lazy3 = ball.run_hod()
+    ball.run_hod()
+    with pytest.raises(RuntimeError, match='never read'):
+        lazy3['LRG']['x']
+    np.testing.assert_array_equal(lazy2['LRG']['x'], eager['LRG']['x'])   # read in time: still whole
 
 
 def test_compute_ngal_device_vs_numpy():
