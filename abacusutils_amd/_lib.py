@@ -233,6 +233,7 @@ def poshash_host(a):
 
 def poshash_device(dptr, n):
     out = C.c_uint64(0)
+    dptr = dptr if isinstance(dptr, C.c_void_p) else C.c_void_p(dptr)    # a bare int would be passed as a 32-bit C int
     check(lib().abacus_poshash_u64(dptr, C.c_int64(int(n)), C.byref(out)))
     return int(out.value)
 

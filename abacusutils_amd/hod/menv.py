@@ -61,10 +61,15 @@ def do_Menv_from_tree(pos, mass, r_inner, r_outer, halo_lc, Lbox, nthread=1, mcu
         return np.ascontiguousarray(np.atleast_1d(r), dtype=r.dtype if r.dtype in (np.float32, np.float64) else np.float64)
 
     ri, ro = radius(r_inner, 'r_inner'), radius(r_outer, 'r_outer')
-    if ri.dtype != ro.dtype:     # one precision flag for both in the C ABI
-        if isinstance(ri, dev) or isinstance(ro, dev):
+    if ri.dtype != ro.dtype:     # one precision flag for both in the C ABI: a host scalar follows the other argument ...
+        if not isinstance(ri, dev) and len(ri) == 1 and float(ri.astype(ro.dtype)[0]) == float(ri[0]):
+            ri = ri.astype(ro.dtype)
+        elif not isinstance(ro, dev) and len(ro) == 1 and float(ro.astype(ri.dtype)[0]) == float(ro[0]):
+            ro = ro.astype(ri.dtype)
+        elif isinstance(ri, dev) or isinstance(ro, dev):
             raise TypeError('device r_inner / r_outer must share a dtype')
-        ri, ro = ri.astype(np.float64), ro.astype(np.float64)
+        else:                    # ... otherwise both are widened
+            ri, ro = ri.astype(np.float64), ro.astype(np.float64)
     # `mass > mcut` (:43) compares in the dtype of mass: a Python-float mcut is rounded to float32 for float32 masses
     mcut = float(np.asarray(mcut, dtype=massf.dtype)) if np.ndim(mcut) == 0 and isinstance(mcut, (int, float)) else float(mcut)
     # only centres' radii matter for the cell size (:48-54)

@@ -396,7 +396,7 @@ def bench_catalog(args, dist):
     dt = (time.perf_counter() - t0) / reps
     _lib.profile_enable(False)
     kern = {k: ms / cnt for k, (ms, cnt) in _lib.profile_get().items() if cnt}
-    assert np.array_equal(d_out.get(), menv)
+    assert np.allclose(d_out.get(), menv, rtol=1e-10, atol=1e-12 * float(hmass.max()))   # the order inside a cell is not fixed
     for a in (d_pos, d_mass, d_rin, d_out):
         a.free()
     out['menv'] = {'n_halos': nh, 'centres': int((hmass > 1e11).sum()), 'ms_per_call': dt * 1e3,
