@@ -998,6 +998,141 @@ int oracle_paircount_cells(int mode, int autocorr, const float *x1, const float 
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* reseed stream (hod/abacus_hod.py:775-839)                                  */
+/* ------------------------------------------------------------------------- */
+/* The reference redraws hrandoms / hveldev / prandoms from parallel_numpy_rng.MTGenerator(PCG64(seed)) (:778-823), a
+ * third-party generator that is not in the tree and not installed (parallel_numpy_rng >= 0.2.0, pyproject.toml:33): the
+ * REFERENCE's stream cannot be restated.  What is restated here is the stream the build draws instead - same
+ * distributions, dtypes and scalings as the reference (:780 float32 uniforms; :799-801 two-sided exponential of
+ * `want_expvel`; :803-818 float32 standard normals; :826-833 `r2 * hsigma3d / sqrt(3)`) - so that "device == CPU bit for
+ * bit" is a checked property (tests/test_reseed_gpu.py):
+ *   Philox4x32-10 (Salmon, Moraes, Dror & Shaw, SC'11; Random123), pinned by its published known-answer vectors
+ *   (tests/test_oracle_reseed.py); halo with global index g: a = Philox(ctr (g lo, g hi, 0, 0), key (seed lo, seed hi)),
+ *   b = Philox(ctr (g lo, g hi, 1, 0)); hrandoms = u(a0); normals by Box-Muller, (r0, r1) from (a1, a2), r2 from
+ *   (b0, b1); exponential deviates from a1, a2, a3; particle 4 q + d = word d of Philox(ctr (q lo, q hi, 2, 0)).
+ *   u(w) = (w >> 8) * 2^-24 in float32.  log / sin / cos are fixed float64 polynomial evaluations (+ - * / sqrt only,
+ *   compiled without FMA contraction), so the result does not depend on a math library. */
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1,
+                       n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u; /* golden ratio */
+        k1 += 0xBB67AE85u; /* sqrt(3) - 1 */
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+void oracle_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out) { philox4x32_10(ctr, key, out); }
+
+static float rs_u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+
+/* log of a positive finite double: x = m 2^e, m in [sqrt(1/2), sqrt 2); log m = 2 atanh((m-1)/(m+1)), series to s^15 */
+static double rs_log(double x) {
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    memcpy(&m, &bits, 8);
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        e += 1;
+    }
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    return 2.0 * s * p + (double)e * 0.6931471805599453;
+}
+/* sin, cos of 2 pi t for t in [0, 1): quadrant + Taylor series on [0, pi/2) */
+static void rs_sincos2pi(double t, double *sn, double *cs) {
+    const double t4 = 4.0 * t;
+    const int q = (int)t4;
+    const double a = (t4 - (double)q) * 1.5707963267948966, z = a * a;
+    double ps = -1.0 / 121645100408832000.0;
+    ps = ps * z + 1.0 / 355687428096000.0;
+    ps = ps * z - 1.0 / 1307674368000.0;
+    ps = ps * z + 1.0 / 6227020800.0;
+    ps = ps * z - 1.0 / 39916800.0;
+    ps = ps * z + 1.0 / 362880.0;
+    ps = ps * z - 1.0 / 5040.0;
+    ps = ps * z + 1.0 / 120.0;
+    ps = ps * z - 1.0 / 6.0;
+    ps = ps * z + 1.0;
+    const double s0 = a * ps;
+    double pc = 1.0 / 6402373705728000.0;
+    pc = pc * z - 1.0 / 20922789888000.0;
+    pc = pc * z + 1.0 / 87178291200.0;
+    pc = pc * z - 1.0 / 479001600.0;
+    pc = pc * z + 1.0 / 3628800.0;
+    pc = pc * z - 1.0 / 40320.0;
+    pc = pc * z + 1.0 / 720.0;
+    pc = pc * z - 1.0 / 24.0;
+    pc = pc * z + 0.5;
+    const double c0 = 1.0 - z * pc;
+    switch (q & 3) {
+        case 0: *sn = s0, *cs = c0; break;
+        case 1: *sn = c0, *cs = -s0; break;
+        case 2: *sn = -s0, *cs = -c0; break;
+        default: *sn = -c0, *cs = s0; break;
+    }
+}
+double oracle_rs_log(double x) { return rs_log(x); }
+void oracle_rs_sincos2pi(double t, double *sn, double *cs) { rs_sincos2pi(t, sn, cs); }
+
+static float rs_laplace(float rt) { /* (:799-801) */
+    return rt >= 0.5f ? (float)(-rs_log(2.0 * (1.0 - (double)rt))) : (float)rs_log(2.0 * (double)rt);
+}
+static float rs_max(float a, float b) { return a > b ? a : b; }
+
+/* halos [index0, index0 + n) of the global catalogue: hrandoms (n) float32 values as float64 (staging keeps float64
+ * columns), hveldev (n, 3) = float32 deviate * hsigma3d / sqrt(3) in float64 (:826-833) */
+void oracle_reseed_halos(int64_t n, int64_t index0, uint64_t seed, const double *sigma3d, int expvel, double *hrandoms,
+                         double *hveldev) {
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t g = (uint64_t)(index0 + i);
+        const uint32_t ca[4] = {(uint32_t)g, (uint32_t)(g >> 32), 0u, 0u}, cb[4] = {(uint32_t)g, (uint32_t)(g >> 32), 1u, 0u};
+        uint32_t a[4], b[4];
+        philox4x32_10(ca, key, a);
+        philox4x32_10(cb, key, b);
+        hrandoms[i] = (double)rs_u01(a[0]);
+        float r[3];
+        if (expvel) {
+            for (int d = 0; d < 3; d++) r[d] = rs_laplace(rs_max(rs_u01(a[1 + d]), 1e-30f));
+        } else {
+            const double m0 = sqrt(-2.0 * rs_log(1.0 - (double)rs_u01(a[1]))), m1 = sqrt(-2.0 * rs_log(1.0 - (double)rs_u01(b[0])));
+            double s0, c0, s1, c1;
+            rs_sincos2pi((double)rs_u01(a[2]), &s0, &c0);
+            rs_sincos2pi((double)rs_u01(b[1]), &s1, &c1);
+            r[0] = (float)(m0 * c0), r[1] = (float)(m0 * s0), r[2] = (float)(m1 * c1);
+        }
+        const double sg = sigma3d ? sigma3d[i] : 0.0;
+        for (int d = 0; d < 3; d++) hveldev[3 * i + d] = (double)r[d] * sg / 1.7320508075688772;
+    }
+}
+/* particles [index0, index0 + n): prandoms */
+void oracle_reseed_particles(int64_t n, int64_t index0, uint64_t seed, double *prandoms) {
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t g = (uint64_t)(index0 + i), q = g >> 2;
+        const uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), 2u, 0u};
+        uint32_t a[4];
+        philox4x32_10(c, key, a);
+        prandoms[i] = (double)rs_u01(a[g & 3]);
+    }
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -847,3 +847,49 @@ def unpack_pack9(data, boxsize, velzspace_to_kms, float_dtype=np.float32):
         vel = np.stack([sh[:, 3 + k].astype(F) * vscale for k in range(3)], axis=1)
     part = ~hdr
     return pos[part], vel[part]
+
+
+# ---- reseed stream (hod/abacus_hod.py:775-839): Philox4x32-10 + fixed float64 transforms --------------------------------
+def philox4x32_10(ctr, key):
+    """one block of Philox4x32-10 (C restatement); ctr (4,), key (2,) uint32 -> (4,) uint32"""
+    c = np.ascontiguousarray(ctr, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().oracle_philox4x32_10(_ptr(c), _ptr(k), _ptr(out))
+    return out
+
+
+def philox4x32_10_py(ctr, key):
+    """the same in pure Python straight from the published round function (Salmon et al. 2011, Random123): an
+    independent check of the C restatement on the known-answer vectors"""
+    c = [int(x) for x in ctr]
+    k = [int(x) for x in key]
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
+    return np.array(c, dtype=np.uint32)
+
+
+def rs_log(x):
+    lib().oracle_rs_log.restype = C.c_double
+    return float(lib().oracle_rs_log(C.c_double(float(x))))
+
+
+def rs_sincos2pi(t):
+    s, c = C.c_double(0), C.c_double(0)
+    lib().oracle_rs_sincos2pi(C.c_double(float(t)), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def reseed(seed, n_halo, n_part, hsigma3d=None, want_expvel=False, halo_index0=0, part_index0=0):
+    """the arrays `run_hod(reseed=seed)` rewrites (:824-835), as the build's generator draws them:
+    hrandoms (n_halo,), hveldev (n_halo, 3), prandoms (n_part,), all float64 holding float32-precision draws"""
+    hr = np.zeros(n_halo, dtype=np.float64)
+    hv = np.zeros((n_halo, 3), dtype=np.float64)
+    pr = np.zeros(n_part, dtype=np.float64)
+    sg = None if hsigma3d is None else _f8(hsigma3d)
+    lib().oracle_reseed_halos(C.c_int64(n_halo), C.c_int64(halo_index0), C.c_uint64(int(seed) & (2**64 - 1)), _ptr(sg),
+                              int(bool(want_expvel)), _ptr(hr), _ptr(hv))
+    lib().oracle_reseed_particles(C.c_int64(n_part), C.c_int64(part_index0), C.c_uint64(int(seed) & (2**64 - 1)), _ptr(pr))
+    return hr, hv, pr
