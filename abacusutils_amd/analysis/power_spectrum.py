@@ -132,6 +132,13 @@ def _pos_f4(pos):
     return np.ascontiguousarray(pos, dtype=np.float32).copy()
 
 
+def _pos_f8(pos):
+    """float64 C-contiguous positions are used (and wrapped) in place, anything else is converted to a float64 copy"""
+    if pos.dtype == np.float64 and pos.flags.c_contiguous and pos.flags.writeable:
+        return pos
+    return np.ascontiguousarray(pos, dtype=np.float64).copy()
+
+
 def get_field_fft(pos, Lbox, nmesh, paste, w, W, compensated, interlaced, nthread=MAX_THREADS, verbose=False,
                   dtype=np.float32):
     """delta_k of the particles as a complex64 (nmesh, nmesh, nmesh//2+1) array (:1001-1070)."""
@@ -193,7 +200,8 @@ def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste
     if mubins is None:
         mubins = 1
     if np.dtype(dtype) != np.float32:
-        raise NotImplementedError('the device path works on float32 meshes (the reference default)')
+        raise NotImplementedError('the device path works on float32 meshes (the reference default); float64 POSITIONS are '
+                                  'honoured (their cloud weights are evaluated in float64)')
 
     meta = dict(Lbox=Lbox, logk=logk, paste=paste, nmesh=nmesh, compensated=compensated, interlaced=interlaced,
                 poles=poles, nthread=nthread, N_pos=len(pos), is_weighted=w is not None, field_dtype=dtype,
@@ -205,11 +213,17 @@ def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste
     code = _paste_code(paste, '')
     W, poles_arr, kbins, mubins, ke, me = _power_setup(Lbox, nmesh, paste, compensated, interlaced, poles, k_max, kbins, mubins, logk)
 
-    p1 = _pos_f4(pos)
-    p2 = None if pos2 is None else _pos_f4(pos2)
+    # the cloud weights are evaluated in the dtype of the positions (analysis/tsc.py:400): float64 positions go through the
+    # float64 deposit (both sets then; the mesh and the transform are float32 either way)
+    f64 = pos.dtype == np.float64 or (pos2 is not None and pos2.dtype == np.float64)
+    cast = _pos_f8 if f64 else _pos_f4
+    wcast = (lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)) if f64 else _f4
+    p1 = cast(pos)
+    p2 = None if pos2 is None else cast(pos2)
     outs = _alloc_outputs(len(ke) - 1, len(me) - 1, len(poles_arr))
-    check(_lib.lib().abacus_power_from_particles(
-        ptr(p1), C.c_int64(len(p1)), ptr(_f4(w)), ptr(p2), C.c_int64(0 if p2 is None else len(p2)), ptr(_f4(w2)),
+    entry = _lib.lib().abacus_power_from_particles_f64 if f64 else _lib.lib().abacus_power_from_particles
+    check(entry(
+        ptr(p1), C.c_int64(len(p1)), ptr(wcast(w)), ptr(p2), C.c_int64(0 if p2 is None else len(p2)), ptr(wcast(w2)),
         C.c_double(Lbox), int(nmesh), code, ptr(_f4(W)), int(bool(interlaced)), ptr(ke), len(ke) - 1, ptr(me),
         len(me) - 1, ptr(poles_arr), len(poles_arr), *[ptr(o) for o in outs]))
     return _power_table(outs, me, kbins, mubins, poles_arr, squeeze_mu_axis, return_mubins, meta)

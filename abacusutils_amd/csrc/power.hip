@@ -39,6 +39,8 @@ using namespace abacus;
 namespace abacus {
 int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
                     double offset, int wrap, double norm, int cic, int list_mode = 0, double sub = 1.0);
+int tsc_deposit_f64pos(double *pos, int64_t n, const double *w, float *grid, int nmesh, int64_t zstride, double box,
+                       double offset, int wrap, double norm, int cic, double sub = 1.0);
 int tsc_release_work();
 bool fft_native_supported(int n);
 int fft_native_r2c_inplace(float *mesh, int n, int pitch_r);
@@ -709,8 +711,9 @@ bool use_fused_fft(int nmesh) {
            fft_native_fused_supported(nmesh);
 }
 
+// pf64: `pos` / `w` point to float64 values (cloud arithmetic in float64, analysis/tsc.py:400; float32 mesh)
 int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, int paste, int interlaced, int slot,
-                  bool fused = false, bool skip_x = false, DevBuf *dest = nullptr) {
+                  bool fused = false, bool skip_x = false, DevBuf *dest = nullptr, int pf64 = 0) {
     if (!dest) dest = &g_ctx.mesh[slot];
     if (n <= 0) return fail("power: empty particle set");
     const bool native = fft_native_supported(nmesh) && !option("fft_hipfft");
@@ -729,8 +732,12 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
         float *mesh = dest[s].as<float>();
         // tsc_parallel wraps pos in place on the first call (tsc.py:171-173); the shifted deposit sees wrapped pos
         // interlaced: the lists of the first deposit are built to cover the half-cell-shifted one as well
-        ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste,
-                                   interlaced ? (s == 0 ? 1 : 2) : 0));
+        if (pf64)
+            ABACUS_TRY(tsc_deposit_f64pos(reinterpret_cast<double *>(pos), n, reinterpret_cast<const double *>(w), mesh, nmesh,
+                                          zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste));
+        else
+            ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste,
+                                       interlaced ? (s == 0 ? 1 : 2) : 0));
         if (native && fused) {
             ABACUS_TRY(skip_x ? fft_native_r2c_fused_zy(mesh, nmesh, (int)zstride) : fft_native_r2c_fused(mesh, nmesh, (int)zstride));
         } else if (native) {
@@ -941,7 +948,7 @@ int check_common(int nmesh, int paste) {
 int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, const float *w2, double Lbox, int nmesh,
               int paste, const float *W_host, int interlaced, const double *kedges, int Nk, const double *muedges,
               int Nmu, const int64_t *poles, int Np, float *power, int64_t *N_mode, float *binned_poles,
-              int64_t *N_mode_poles, float *k_avg) {
+              int64_t *N_mode_poles, float *k_avg, int pf64 = 0) {
     ABACUS_TRY(check_common(nmesh, paste));
     ABACUS_TRY(ensure_phase(nmesh));
     const float *W_dev;
@@ -954,15 +961,15 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
         size_t acc_bytes = 0;
         ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
         if (xbin_supported(nmesh, Nk, Nmu, b, W_dev != nullptr)) {
-            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 0, 0, true, /*skip_x=*/true));
+            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 0, 0, true, /*skip_x=*/true, nullptr, pf64));
             const double M = (double)nmesh * nmesh * nmesh;
             ABACUS_TRY(fft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg));
             return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
                                 2.0 * M_PI / Lbox, 0);
         }
     }
-    ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, fused));
-    if (cross) ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, interlaced, 2, fused));
+    ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, fused, false, nullptr, pf64));
+    if (cross) ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, interlaced, 2, fused, false, nullptr, pf64));
     SpecArgs s;
     fill_spec(s, nmesh, 1, interlaced, W_dev, cross);
     if (fused) {
@@ -988,14 +995,15 @@ __global__ void pack_pos_soa64(const double *__restrict__ x, const double *__res
 }
 
 // upload a host particle set into the context buffers; wrapped positions are copied back like the reference mutates them
-int stage_particles(float *pos, int64_t n, const float *w, DevBuf &dpos, DevBuf &dw, float **pd, float **wd) {
-    ABACUS_TRY(dpos.reserve((size_t)std::max<int64_t>(n, 1) * 12));
-    HIP_TRY(hipMemcpyAsync(dpos.p, pos, (size_t)n * 12, hipMemcpyHostToDevice, stream()));
+int stage_particles(float *pos, int64_t n, const float *w, DevBuf &dpos, DevBuf &dw, float **pd, float **wd, size_t es = 4) {
+    // es: bytes per value (4 float32, 8 float64 - the pointers are then float64 arrays in disguise)
+    ABACUS_TRY(dpos.reserve((size_t)std::max<int64_t>(n, 1) * 3 * es));
+    HIP_TRY(hipMemcpyAsync(dpos.p, pos, (size_t)n * 3 * es, hipMemcpyHostToDevice, stream()));
     *pd = dpos.as<float>();
     *wd = nullptr;
     if (w) {
-        ABACUS_TRY(dw.reserve((size_t)std::max<int64_t>(n, 1) * 4));
-        HIP_TRY(hipMemcpyAsync(dw.p, w, (size_t)n * 4, hipMemcpyHostToDevice, stream()));
+        ABACUS_TRY(dw.reserve((size_t)std::max<int64_t>(n, 1) * es));
+        HIP_TRY(hipMemcpyAsync(dw.p, w, (size_t)n * es, hipMemcpyHostToDevice, stream()));
         *wd = dw.as<float>();
     }
     return 0;
@@ -1069,23 +1077,42 @@ int abacus_power_fields_release(void) {
     return 0;
 }
 
+static int power_from_host(void *pos, int64_t n, const void *w, void *pos2, int64_t n2, const void *w2, int pf64, double Lbox,
+                           int nmesh, int paste, const float *W_host, int interlaced, const double *kedges, int Nk,
+                           const double *muedges, int Nmu, const int64_t *poles, int Np, float *power, int64_t *N_mode,
+                           float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
+    const size_t es = pf64 ? 8 : 4;
+    float *pd, *wd, *pd2 = nullptr, *wd2 = nullptr;
+    ABACUS_TRY(stage_particles((float *)pos, n, (const float *)w, g_ctx.pos, g_ctx.w, &pd, &wd, es));
+    if (pos2) ABACUS_TRY(stage_particles((float *)pos2, n2, (const float *)w2, g_ctx.pos2, g_ctx.w2, &pd2, &wd2, es));
+    ABACUS_TRY(power_dev(pd, n, wd, pd2, n2, wd2, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu,
+                         poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, pf64));
+    if (paste == 0) {  // TSC wraps the caller's positions in place (tsc.py:171-173); CIC does not wrap (cic.py)
+        HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 3 * es, hipMemcpyDeviceToHost, stream()));
+        if (pos2) HIP_TRY(hipMemcpyAsync(pos2, pd2, (size_t)n2 * 3 * es, hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+    }
+    return 0;
+}
+
 int abacus_power_from_particles(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, const float *w2,
                                 double Lbox, int nmesh, int paste, const float *W_host, int interlaced,
                                 const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
                                 int Np, float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles,
                                 float *k_avg) {
     ABACUS_ENTER();
-    float *pd, *wd, *pd2 = nullptr, *wd2 = nullptr;
-    ABACUS_TRY(stage_particles(pos, n, w, g_ctx.pos, g_ctx.w, &pd, &wd));
-    if (pos2) ABACUS_TRY(stage_particles(pos2, n2, w2, g_ctx.pos2, g_ctx.w2, &pd2, &wd2));
-    ABACUS_TRY(power_dev(pd, n, wd, pd2, n2, wd2, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu,
-                         poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg));
-    if (paste == 0) {  // TSC wraps the caller's positions in place (tsc.py:171-173); CIC does not wrap (cic.py)
-        HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 12, hipMemcpyDeviceToHost, stream()));
-        if (pos2) HIP_TRY(hipMemcpyAsync(pos2, pd2, (size_t)n2 * 12, hipMemcpyDeviceToHost, stream()));
-        HIP_TRY(hipStreamSynchronize(stream()));
-    }
-    return 0;
+    return power_from_host(pos, n, w, pos2, n2, w2, 0, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu, poles,
+                           Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
+}
+
+int abacus_power_from_particles_f64(double *pos, int64_t n, const double *w, double *pos2, int64_t n2, const double *w2,
+                                    double Lbox, int nmesh, int paste, const float *W_host, int interlaced,
+                                    const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
+                                    int Np, float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles,
+                                    float *k_avg) {
+    ABACUS_ENTER();
+    return power_from_host(pos, n, w, pos2, n2, w2, 1, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu, poles,
+                           Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
 }
 
 int abacus_field(float *pos, int64_t n, const float *w, double Lbox, int nmesh, int paste, double offset, float *field) {

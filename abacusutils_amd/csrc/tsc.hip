@@ -1083,6 +1083,16 @@ int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmes
     return deposit_dev<float, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
                                             nullptr, -1, 0, sub, list_mode);
 }
+// float64 positions (and weights): the cloud weights are evaluated in the position dtype like the reference does
+// (analysis/tsc.py:400 `ftype = positions.dtype.type`), the mesh stays float32
+int tsc_deposit_f64pos(double *pos, int64_t n, const double *w, float *grid, int nmesh, int64_t zstride, double box,
+                       double offset, int wrap, double norm, int cic, double sub) {
+    if (cic)
+        return deposit_dev<double, float, true>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, 0, 1, norm,
+                                                nullptr, -1, 0, sub, 0);
+    return deposit_dev<double, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
+                                             nullptr, -1, 0, sub, 0);
+}
 // x-slab variant: `grid` holds planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh, ghosts included;
 // written as rho*norm - sub (sub = 1: the overdensity's "-1" in every cell; a ghost block is then added to its owner as
 // ghost + 1)

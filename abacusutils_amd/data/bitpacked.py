@@ -77,68 +77,51 @@ def unpack_rvint(intdata, boxsize, float_dtype=np.float32, posout=None, velout=N
     return tuple(ret)
 
 
+# field -> (dtype or None for the caller's float dtype, columns per particle); one table serves both allocators
+_FIELD_LAYOUT = {'pid': (np.int64, 1), 'lagr_pos': (None, 3), 'lagr_idx': (np.int16, 3), 'tagged': (np.uint8, 1),
+                 'density': (None, 1), 'packedpid': (np.uint64, 1)}
+
+
+def _alloc(N, fields, float_dtype):
+    out = {}
+    for name in _FIELD_LAYOUT:                       # the table's order, whatever order the caller listed
+        if name in fields:
+            dt, width = _FIELD_LAYOUT[name]
+            out[name] = np.empty(N if width == 1 else (N, width), dtype=float_dtype if dt is None else dt)
+    return out
+
+
 def empty_bitpacked_arrays(N, unpack_bits, float_dtype=np.float32):
-    """Empty arrays for the bit-packed fields (reference :224-271)"""
-    if type(unpack_bits) is str:
-        unpack_bits = [unpack_bits]
-    if unpack_bits is True:
-        unpack_bits = PID_FIELDS
-    elif unpack_bits is False:
-        unpack_bits = ['pid']
-    arr = {}
-    if 'pid' in unpack_bits:
-        arr['pid'] = np.empty(N, dtype=np.int64)
-    if 'lagr_pos' in unpack_bits:
-        arr['lagr_pos'] = np.empty((N, 3), dtype=float_dtype)
-    if 'lagr_idx' in unpack_bits:
-        arr['lagr_idx'] = np.empty((N, 3), dtype=np.int16)
-    if 'tagged' in unpack_bits:
-        arr['tagged'] = np.empty(N, dtype=np.uint8)
-    if 'density' in unpack_bits:
-        arr['density'] = np.empty(N, dtype=float_dtype)
-    if 'packedpid' in unpack_bits:
-        arr['packedpid'] = np.empty(N, dtype=np.uint64)
-    return arr
+    """Uninitialised output arrays for the bit-packed fields (reference :224-271): `unpack_bits` is True (every field of
+    PID_FIELDS), False (the pid alone), one field name or a list of names"""
+    wanted = PID_FIELDS if unpack_bits is True else ['pid'] if unpack_bits is False else np.atleast_1d(unpack_bits).tolist()
+    return _alloc(N, wanted, float_dtype)
 
 
 def unpack_pids(packed, box=None, ppd=None, pid=False, lagr_pos=False, tagged=False, density=False, lagr_idx=False,
                 float_dtype=np.float32):
-    """Extract fields from bit-packed PIDs (reference :118-221).  Returns a dict of the requested arrays."""
-    if not _is_dev(packed):
-        packed = np.ascontiguousarray(np.asanyarray(packed, dtype=np.uint64))
-    else:
+    """Extract fields from bit-packed PIDs (reference :118-221).  Returns a dict of the requested arrays (a field is
+    produced when its flag is exactly True, as in the reference)."""
+    if _is_dev(packed):
         assert packed.dtype == np.uint64
-    if lagr_pos is not False:
-        if box is None:
-            raise ValueError('Must supply `box` if requesting `lagr_pos`')
-        if ppd is None:
-            raise ValueError('Must supply `ppd` if requesting `lagr_pos`')
-    N = int(np.prod(packed.shape))
-    if ppd is not None:
+    else:
+        packed = np.ascontiguousarray(np.asanyarray(packed, dtype=np.uint64))
+    if lagr_pos is not False and (box is None or ppd is None):
+        raise ValueError('Must supply `box` if requesting `lagr_pos`' if box is None else
+                         'Must supply `ppd` if requesting `lagr_pos`')
+    if ppd is None:
+        ppd = 1
+    else:
         if not np.isclose(ppd, int(round(ppd))):
             raise ValueError(f'ppd "{ppd}" not valid int?')
         ppd = int(round(ppd))
-    else:
-        ppd = 1
-    if box is None:
-        box = 1.0
     float_dtype = np.dtype(float_dtype)
     if float_dtype not in (np.float32, np.float64):
         raise TypeError('float_dtype must be float32 or float64')
-    arr = {}
-    if pid is True:
-        arr['pid'] = np.empty(N, dtype=np.int64)
-    if lagr_pos is True:
-        arr['lagr_pos'] = np.empty((N, 3), dtype=float_dtype)
-    if lagr_idx is True:
-        arr['lagr_idx'] = np.empty((N, 3), dtype=np.int16)
-    if tagged is True:
-        arr['tagged'] = np.empty(N, dtype=np.uint8)
-    if density is True:
-        arr['density'] = np.empty(N, dtype=float_dtype)
+    N = int(np.prod(packed.shape))
+    flags = dict(pid=pid, lagr_pos=lagr_pos, lagr_idx=lagr_idx, tagged=tagged, density=density)
+    arr = _alloc(N, [k for k, v in flags.items() if v is True], float_dtype)
     if arr:
-        _lib.check(_lib.lib().abacus_unpack_pids(_p(packed), C.c_int64(N), C.c_double(float(box)), C.c_int64(ppd),
-                                                 int(float_dtype == np.float64), _p(arr.get('pid')),
-                                                 _p(arr.get('lagr_pos')), _p(arr.get('lagr_idx')),
-                                                 _p(arr.get('tagged')), _p(arr.get('density'))))
+        _lib.check(_lib.lib().abacus_unpack_pids(_p(packed), C.c_int64(N), C.c_double(1.0 if box is None else float(box)),
+                                                 C.c_int64(ppd), int(float_dtype == np.float64), *(_p(arr.get(k)) for k in flags)))
     return arr

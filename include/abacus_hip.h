@@ -247,6 +247,13 @@ int abacus_power_from_particles(float *pos, int64_t n, const float *w, float *po
                                 const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
                                 int Np, float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles,
                                 float *k_avg);
+/* the same for float64 positions (and weights): the cloud weights are evaluated in float64, as the reference computes them
+ * in the dtype of the positions (analysis/tsc.py:400 `ftype = positions.dtype.type`); the mesh and the transform stay float32 */
+int abacus_power_from_particles_f64(double *pos, int64_t n, const double *w, double *pos2, int64_t n2, const double *w2,
+                                    double Lbox, int nmesh, int paste, const float *W_host, int interlaced,
+                                    const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
+                                    int Np, float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles,
+                                    float *k_avg);
 /* same with DEVICE particle arrays (bench / HOD-to-P(k) without leaving HBM); outputs are host arrays */
 int abacus_power_from_particles_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2,
                                     const float *w2, double Lbox, int nmesh, int paste, const float *W_host,

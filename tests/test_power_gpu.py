@@ -180,6 +180,25 @@ def test_fused_fft_against_oracle(options):
         _check_oracle(tab, ref)
 
 
+@pytest.mark.parametrize('cross', [False, True])
+def test_float64_positions_use_float64_cloud_weights(cross):
+    """positions given in float64 (analysis/tsc.py:400: the cloud arithmetic follows the dtype of the positions; the mesh
+    stays float32): against the oracle, which deposits float64 positions in float64; in place wrapping of the caller's array"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    rng = np.random.default_rng(17)
+    n, box = 300_000, 2000.0
+    pos = (rng.random((n, 3)) * 1.2 - 0.1) * box                      # float64, some outside [0, L): wrapped in place
+    w = rng.random(n) + 0.5
+    extra = dict(pos2=(rng.random((n // 2, 3)) * box)) if cross else {}
+    kw = dict(kbins=24, mubins=3, paste='TSC', nmesh=128, compensated=True, interlaced=True, poles=[0, 2], w=w)
+    a_in = pos.copy()
+    tab = calc_power(a_in, box, **kw, **extra)
+    assert a_in.dtype == np.float64 and a_in.min() >= 0.0 and a_in.max() < box        # wrapped like tsc_parallel does
+    ref = oracle.calc_power(pos.copy(), box, nthread=4, accum64=True, **{k: (v.copy() if hasattr(v, 'copy') else v) for k, v in {**kw, **extra}.items()})
+    _check_oracle(tab, ref)
+
+
 @pytest.mark.parametrize('nmesh', [1024])
 def test_fused_fft_matches_three_pass(options, nmesh):
     """production sizes of the fused form against the plain three-pass transform on the same particles"""
