@@ -128,3 +128,49 @@ def synth_positions(n, lbox, seed=300, dtype=np.float32, clustered=False):
         pos -= np.floor(pos)
     pos = (pos * np.float32(lbox)).astype(dtype)
     return pos
+
+
+def synth_compaso_slabs(numslabs=3, n_halo=3000, seed=900, lbox=300.0, mpart=MPART_BASE, subsample_frac=0.03):
+    """`numslabs` CompaSO-like slabs of one periodic box, as `prepare_sim.prepare_slab` sees them after
+    `CompaSOHaloCatalog(..., subsamples=dict(A=True, rv=True))` (hod/prepare_sim.py:404-441): per slab a dict
+    `halos` - N (u4), x_L2com / v_L2com (n,3) f4, r25 / r90 / r98_L2com f4, npstartA / npoutA (i8: the halo's slice of
+    `parts`), id (u8, unique across slabs), sigmav3d_L2com f4 - and `parts` - pos / vel (m,3) f4, the subsample-A particles
+    of the slab's halos in halo order.  Halo x lies in the slab's x-range of [-L/2, L/2); masses follow a steep mass function
+    from 35 particles up, so every branch of subsample_halos / submask_particles (:83-174) is populated."""
+    out = []
+    dx = lbox / numslabs
+    for s in range(numslabs):
+        rng = np.random.default_rng(seed + s)
+        logm = np.minimum(10.9 + rng.exponential(0.55, n_halo), 15.3)
+        N = np.maximum((10 ** logm / mpart).astype(np.int64), 35).astype(np.uint32)
+        x = np.empty((n_halo, 3), dtype=np.float32)
+        x[:, 0] = (-0.5 * lbox + s * dx + rng.random(n_halo) * dx).astype(np.float32)
+        x[:, 1:] = ((rng.random((n_halo, 2)) - 0.5) * lbox).astype(np.float32)
+        np.clip(x, -0.5 * lbox, np.nextafter(np.float32(0.5 * lbox), np.float32(0)), out=x)
+        v = (rng.standard_normal((n_halo, 3)) * 300).astype(np.float32)
+        m = N.astype(np.float64) * mpart
+        r98 = (0.25 * (m / 1e13) ** (1.0 / 3.0) * (1 + 0.1 * rng.standard_normal(n_halo))).astype(np.float32)
+        r98 = np.maximum(r98, np.float32(0.02))
+        conc = (4.0 + 6.0 * rng.random(n_halo)).astype(np.float32)
+        r25 = (r98 / conc).astype(np.float32)
+        r90 = (r98 * np.float32(0.8)).astype(np.float32)
+        sig = (300.0 * (m / 1e13) ** (1.0 / 3.0)).astype(np.float32)
+        npout = rng.binomial(N.astype(np.int64), subsample_frac).astype(np.int64)
+        npout[rng.random(n_halo) < 0.02] = 0                      # halos without subsample particles (:868)
+        npstart = np.concatenate(([0], np.cumsum(npout)[:-1])).astype(np.int64)
+        host = np.repeat(np.arange(n_halo), npout)
+        nprt = len(host)
+        rr = (r98[host] * (0.02 + 0.98 * rng.random(nprt) ** 1.5))[:, None] * _unit_vectors(rng, nprt)   # never on the centre
+        pos = (x[host] + rr.astype(np.float32)).astype(np.float32)
+        vel = (v[host] + (rng.standard_normal((nprt, 3)) * sig[host][:, None] / np.sqrt(3.0)).astype(np.float32)).astype(np.float32)
+        halos = dict(N=N, x_L2com=x, v_L2com=v, r25_L2com=r25, r90_L2com=r90, r98_L2com=r98, npstartA=npstart, npoutA=npout,
+                     id=(np.uint64(s) * np.uint64(10**12) + np.arange(n_halo, dtype=np.uint64)), sigmav3d_L2com=sig)
+        out.append(dict(halos=halos, parts=dict(pos=pos, vel=vel)))
+    header = dict(BoxSizeHMpc=float(lbox), BoxSize=float(lbox), ParticleMassHMsun=float(mpart), H0=67.36,
+                  VelZSpace_to_kms=VELZSPACE_TO_KMS_BASE * lbox / LBOX_BASE)
+    return out, header
+
+
+def _unit_vectors(rng, n):
+    u = rng.standard_normal((n, 3))
+    return u / np.sqrt((u * u).sum(axis=1))[:, None]

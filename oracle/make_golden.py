@@ -30,7 +30,11 @@ What is captured
   pair_wrappers.npz           calc_xirppi_fast / calc_wp_fast / calc_multipole_fast / tpcf_multipole with a brute-force
         stand-in for Corrfunc's counters (pins the wrapper arithmetic, not Corrfunc).
 
-usage: python oracle/make_golden.py [hod] [tsc] [power] [helpers] [catalog] [sweep] [ngal] [pairs]
+  prepare_sim.npz             prepare_sim.prepare_slab (hod/prepare_sim.py:296-1052) on seeded synthetic slabs with stand-ins
+        for its file layer (CompaSOHaloCatalog -> synth tables, h5py -> capture): three configurations (MT / LRG-only,
+        ranks, assembly bias with the padded Menv, shear).
+
+usage: python oracle/make_golden.py [hod] [tsc] [power] [helpers] [catalog] [sweep] [ngal] [pairs] [prepare]
 """
 import ctypes
 import os
@@ -766,8 +770,96 @@ def gen_pair_wrappers():
     print('pair_wrappers.npz written')
 
 
+# ----------------------------------------------------------------------------
+# prepare_sim.prepare_slab (hod/prepare_sim.py:296-1052): the REFERENCE's function run on seeded synthetic slabs.  Its
+# file layer is replaced by stand-ins: a CompaSOHaloCatalog that hands over the tables of
+# abacusutils_amd.synth.synth_compaso_slabs (the CompaSO / ASDF readers are out of scope), an h5py that keeps what
+# create_dataset receives.  Everything between the loader and the writer - halo down-sampling, padded Menv, concentration /
+# shear ranks, per-halo particle selection, satellite ranks, host columns, random columns - is the reference's own code
+# consuming NumPy's global generator in its own order.
+# ----------------------------------------------------------------------------
+PREPARE_CASES = {
+    # name: (slab, MT, want_ranks, want_AB, want_shear)
+    'mt_ab': (1, True, False, True, False),            # the configuration of the reference's own fixture (tests/abacus_hod.yaml)
+    'lrg_ranks_ab': (0, False, True, True, False),
+    # (want_shear without want_AB fails in the reference itself: :784 touches deltac_rank, which only want_AB defines)
+    'mt_ranks_ab_shear': (2, True, True, True, True),
+}
+PREPARE_SYNTH = dict(numslabs=3, n_halo=1500, seed=900, lbox=300.0)
+
+
+def prepare_shearmark(ndim=16, seed=5):
+    return np.random.default_rng(seed).random((ndim, ndim, ndim))
+
+
+def gen_prepare():
+    from astropy.table import Table
+    from abacusutils_amd import synth
+    slabs, header = synth.synth_compaso_slabs(**PREPARE_SYNTH)
+    captured = {}
+
+    class FakeCat:
+        halo_lc = False
+
+        def __init__(self, slabname, subsamples=None, fields=None, cleaned=True, filter_func=None, **kw):
+            i = int(re.search(r'halo_info_(\d+)\.asdf', str(slabname)).group(1))
+            self.header = dict(header)
+            H = Table({k: v.copy() for k, v in slabs[i]['halos'].items()})
+            if filter_func is not None:
+                H = H[filter_func(H)]
+            self.halos = H
+            if subsamples:
+                self.subsamples = Table({k: v.copy() for k, v in slabs[i]['parts'].items()})
+
+    class FakeH5File:
+        def __init__(self, fn, mode='r'):
+            self.fn = str(fn)
+
+        def create_dataset(self, name, data=None):
+            captured[(os.path.basename(self.fn), name)] = {k: np.asarray(v) for k, v in data.items()} if isinstance(data, dict) else np.asarray(data)
+
+        def close(self):
+            pass
+
+    for name in ('asdf', 'h5py'):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules['h5py'].File = FakeH5File
+    dpkg = types.ModuleType('abacusnbody.data')
+    dpkg.__path__ = [str(REF / 'abacusnbody' / 'data')]
+    sys.modules['abacusnbody.data'] = dpkg
+    fake = types.ModuleType('abacusnbody.data.compaso_halo_catalog')
+    fake.CompaSOHaloCatalog = FakeCat
+    sys.modules['abacusnbody.data.compaso_halo_catalog'] = fake
+    ra = types.ModuleType('abacusnbody.data.read_abacus')
+    ra.read_asdf = None
+    sys.modules['abacusnbody.data.read_abacus'] = ra
+    import abacusnbody.hod.prepare_sim as PS
+    out = {'meta.header_json': np.array(__import__('json').dumps(header)), 'meta.synth_json': np.array(__import__('json').dumps(PREPARE_SYNTH))}
+    with tempfile.TemporaryDirectory() as td:
+        for case, (i, MT, want_ranks, want_AB, want_shear) in PREPARE_CASES.items():
+            captured.clear()
+            shear = prepare_shearmark() if want_shear else None
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                PS.prepare_slab(i, td, '/sim', 'Synth', 0.5, 'primary', {}, MT, want_ranks, want_AB, want_shear, shear, True, 600,
+                                halo_lc=False, nthread=1, overwrite=1, mcut=1e11, rad_outer=10, numslabs=PREPARE_SYNTH['numslabs'])
+            for (fn, dset), val in captured.items():
+                kind = 'env' if fn.startswith('env_') else dset
+                if isinstance(val, dict):
+                    for k, v in val.items():
+                        out[f'{case}.{kind}.{k}'] = v
+                else:
+                    out[f'{case}.{kind}.{dset}'] = val
+            nk = len(out[f'{case}.halos.id'])
+            print(case, 'halos kept', nk, 'particles kept', len(out[f'{case}.particles.pos']),
+                  'env' if f'{case}.env.Menv' in out else 'no env')
+    np.savez_compressed(GOLD / 'prepare_sim.npz', **out)
+    print('prepare_sim written', os.path.getsize(GOLD / 'prepare_sim.npz') // 1024, 'KiB')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'catalog', 'sweep', 'ngal', 'pairs']
+    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'catalog', 'sweep', 'ngal', 'pairs', 'prepare']
     G, T, P, C = import_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
     if 'hod' in which:
@@ -786,3 +878,5 @@ if __name__ == '__main__':
         gen_ngal()
     if 'pairs' in which:
         gen_pair_wrappers()
+    if 'prepare' in which:
+        gen_prepare()
