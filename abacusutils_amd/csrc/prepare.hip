@@ -1,0 +1,501 @@
+// Data-parallel core of prepare_sim.prepare_slab (abacusnbody/hod/prepare_sim.py:296-1052) on the device:
+//   abacus_prepare_halo_factors   subsample_halos (:83-108) + the halo mask (:449) + submask_particles' target count (:152-174)
+//   abacus_prepare_particles      per-halo particle selection (a random subset of `ntarget` of the halo's subsample particles:
+//                                 the reference's per-halo `np.random.choice(replace=False)` loop, :871-875), the new halo
+//                                 offsets (:895-897), the list of kept particles with their host halo and `Np`, and the five
+//                                 satellite rank columns (:899-977)
+// The concentration / environment / shear ranks per mass bin reuse abacus_fenv_rank (staging.hip), the environment masses
+// abacus_menv (catalog.hip).  File I/O and the CompaSO readers stay on the host side (out of scope).
+// Random numbers: the caller either passes the selection it drew itself (`submask`: abacusutils_amd/hod/prepare_sim.py draws it
+// from NumPy's legacy generator in the reference's order, which makes a run comparable with the reference value for value) or a
+// Philox seed - then every particle gets a counter-based 32-bit key and a halo keeps the `ntarget` smallest keys of its slice
+// (uniform over subsets; one stable radix sort of (halo, key) pairs for the whole slab, no per-halo serial work).
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <vector>
+
+#include "../../include/abacus_hip.h"
+#include "common.hpp"
+
+using namespace abacus;
+
+namespace {
+
+int grid_for(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 256), 1), 256 * 32); }
+
+struct Tmp {   // device allocations of one call, released on every exit path
+    std::vector<void *> p;
+    ~Tmp() {
+        for (void *q : p)
+            if (q) (void)hipFree(q);
+    }
+    template <class T>
+    int alloc(T **out, size_t count) {
+        void *q = nullptr;
+        HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+        p.push_back(q);
+        *out = static_cast<T *>(q);
+        return 0;
+    }
+    template <class T>
+    int upload(T **out, const T *host, size_t count) {
+        ABACUS_TRY(alloc(out, count));
+        if (count) HIP_TRY(hipMemcpyAsync(*out, host, count * sizeof(T), hipMemcpyHostToDevice, stream()));
+        return 0;
+    }
+};
+
+// ---- halos: kept fraction, mask, particle target --------------------------------------------------------------------------
+__global__ void prep_halo_factors(const unsigned int *__restrict__ N, int64_t n, double Mpart, int MT,
+                                  const double *__restrict__ u, const long long *__restrict__ pnum, double *__restrict__ p_out,
+                                  unsigned char *__restrict__ mask, int *__restrict__ ntarget) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double m = (double)N[i] * Mpart;
+        const double x = log10(m);
+        double f;
+        if (!MT) {                                             // LRG only (:103-108)
+            f = 1.0 / (1.0 + 0.1 * exp(-(x - 11.8) * 10));
+            if (x > 13.0) f = 1.0;
+        } else if (x < 11.4) {                                 // ELG-capable sample (:88-96)
+            f = 0.2 / (1.0 + 10 * exp(-(x - 11.2) * 25));
+        } else if (x < 11.6) {
+            f = 0.4 / (1.0 + 10 * exp(-(x - 11.3) * 25));
+        } else {
+            f = 1.0 / (1.0 + 0.1 * exp(-(x - 11.7) * 10));
+        }
+        p_out[i] = f;
+        if (mask) mask[i] = u[i] < f ? 1 : 0;                  // np.random.random(len(halos)) < p_halos (:449)
+        if (ntarget) {                                         // submask_particles (:152-174)
+            const long long n_in = pnum ? pnum[i] : 0;
+            long long t = 0;
+            if (MT) {
+                if (!(m < 1e11)) t = min(min(n_in, (long long)(1 + 1.5 * pow(10.0, x - 12.5))), 100ll);
+            } else {
+                if (!(pow(10.0, x) < 1e12)) t = min(n_in, (long long)(1 + 1.5 * pow(10.0, x - 13)));
+            }
+            ntarget[i] = (int)max(t, 0ll);
+        }
+    }
+}
+
+// ---- particle selection -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 prep_philox(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned int hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned int hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// one wave per halo: host index of the halo's particles; sort key (candidate rank << 32 | Philox word) of candidates
+__global__ __launch_bounds__(256) void prep_fill_host(const long long *__restrict__ pstart, const long long *__restrict__ pnum,
+                                                      const unsigned char *__restrict__ hmask, int64_t nh, int64_t npart,
+                                                      int *__restrict__ host, int *__restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < nh; j += (int64_t)gridDim.x * 4) {
+        if (!hmask[j] || pnum[j] <= 0) continue;
+        const long long a = pstart[j], b = a + pnum[j];
+        if (a < 0 || b > npart) {
+            if (lane == 0) atomicOr(bad, 1);
+            continue;
+        }
+        for (long long q = a + lane; q < b; q += 64) host[q] = (int)j;
+    }
+}
+__global__ void prep_keys(const int *__restrict__ host, const int *__restrict__ ntarget, const long long *__restrict__ pnum,
+                          int64_t npart, unsigned long long seed, long long part_index0, unsigned long long *__restrict__ key,
+                          unsigned int *__restrict__ idx, unsigned char *__restrict__ submask) {
+    const uint2 k2 = make_uint2((unsigned int)seed, (unsigned int)(seed >> 32));
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npart; q += (int64_t)gridDim.x * blockDim.x) {
+        const int j = host[q];
+        idx[q] = (unsigned int)q;
+        unsigned long long kq = ~0ull;                      // not a candidate: behind every candidate
+        unsigned char sel = 0;
+        if (j >= 0 && ntarget[j] > 0) {
+            if ((long long)ntarget[j] >= pnum[j]) sel = 1;  // the whole slice is kept: nothing to draw
+            else {
+                const unsigned long long g = (unsigned long long)(part_index0 + q);
+                const uint4 w = prep_philox(make_uint4((unsigned int)g, (unsigned int)(g >> 32), 3u, 0u), k2);   // stream 3
+                kq = ((unsigned long long)(unsigned int)j << 32) | w.x;
+            }
+        }
+        key[q] = kq;
+        submask[q] = sel;
+    }
+}
+// sorted position p holds candidate idx[p] of halo key >> 32; the halo's candidates start at cstart[halo]
+__global__ void prep_pick(const unsigned long long *__restrict__ key, const unsigned int *__restrict__ idx, int64_t npart,
+                          const long long *__restrict__ cstart, const int *__restrict__ ntarget, unsigned char *__restrict__ submask) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npart; p += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = key[p];
+        if (k == ~0ull) continue;
+        const int j = (int)(k >> 32);
+        if (p - cstart[j] < (long long)ntarget[j]) submask[idx[p]] = 1;
+    }
+}
+__global__ void prep_cand_count(const unsigned char *__restrict__ hmask, const long long *__restrict__ pnum, const int *__restrict__ ntarget,
+                                int64_t nh, long long *__restrict__ ccount) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nh; j += (int64_t)gridDim.x * blockDim.x)
+        ccount[j] = (hmask[j] && pnum[j] > 0 && ntarget[j] > 0 && (long long)ntarget[j] < pnum[j]) ? pnum[j] : 0;
+}
+
+// one wave per halo: kept particles of the halo
+__global__ __launch_bounds__(256) void prep_count(const long long *__restrict__ pstart, const long long *__restrict__ pnum,
+                                                  const unsigned char *__restrict__ hmask, const unsigned char *__restrict__ submask,
+                                                  int64_t nh, long long *__restrict__ kept) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < nh; j += (int64_t)gridDim.x * 4) {
+        long long c = 0;
+        if (hmask[j] && pnum[j] > 0)
+            for (long long q = pstart[j] + lane; q < pstart[j] + pnum[j]; q += 64) c += submask[q];
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (lane == 0) kept[j] = c;
+    }
+}
+__global__ void prep_halo_offsets(const unsigned char *__restrict__ hmask, const long long *__restrict__ pnum,
+                                  const long long *__restrict__ kept, const long long *__restrict__ kstart, int64_t nh,
+                                  double *__restrict__ pstart_new, double *__restrict__ pnum_new) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nh; j += (int64_t)gridDim.x * blockDim.x) {
+        const bool live = hmask[j] && pnum[j] > 0;            // (:868, :979-981)
+        pstart_new[j] = live ? (double)kstart[j] : -1.0;
+        pnum_new[j] = live ? (double)kept[j] : -1.0;
+    }
+}
+__global__ void prep_flags(const unsigned char *__restrict__ submask, const int *__restrict__ host, int64_t npart, long long *__restrict__ flag) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npart; q += (int64_t)gridDim.x * blockDim.x)
+        flag[q] = (submask[q] && host[q] >= 0) ? 1 : 0;
+}
+__global__ void prep_emit(const long long *__restrict__ flag, const long long *__restrict__ slot, const int *__restrict__ host,
+                          const long long *__restrict__ kept, int64_t npart, long long *__restrict__ sel_idx,
+                          long long *__restrict__ sel_host, double *__restrict__ sel_np) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npart; q += (int64_t)gridDim.x * blockDim.x)
+        if (flag[q]) {
+            const long long s = slot[q];
+            sel_idx[s] = q;
+            sel_host[s] = host[q];
+            sel_np[s] = (double)kept[host[q]];
+        }
+}
+
+// ---- satellite ranks (:899-977): one workgroup per halo with at least two kept particles -------------------------------------
+struct RankArgs {
+    const float *pos, *vel;              // (npart, 3)
+    const float *hpos, *hvel;            // (nh, 3)
+    const unsigned int *N;
+    const float *r25, *r98;
+    const long long *pstart, *pnum, *kept, *kstart;
+    const long long *sel_idx;            // kept particles in output order (ascending input index: halo after halo)
+    double Mpart, h;
+    double *ranks, *ranksv, *ranksp, *ranksr, *ranksc;   // (n_sel)
+    const int *work;                     // halos to rank
+    int kmax;
+};
+
+__device__ __forceinline__ bool key_before(double a, int ia, double b, int ib) {   // ascending, NaN last, ties by index
+    const bool na = a != a, nb = b != b;
+    if (na || nb) return (!na && nb) || (na && nb && ia < ib);
+    return a < b || (a == b && ia < ib);
+}
+
+__global__ __launch_bounds__(256) void prep_ranks(RankArgs A, int nwork) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const int j = A.work[wi];
+        const int k = (int)A.kept[j];
+        const long long o0 = A.kstart[j];
+        float *px = reinterpret_cast<float *>(smem);          // [3][k] positions of the kept particles
+        double *key = reinterpret_cast<double *>(smem + (size_t)((3 * k * 4 + 15) / 16) * 16);   // [5][k]
+        const float hx = A.hpos[3 * j], hy = A.hpos[3 * j + 1], hz = A.hpos[3 * j + 2];
+        const float hvx = A.hvel[3 * j], hvy = A.hvel[3 * j + 1], hvz = A.hvel[3 * j + 2];
+        const double m = (double)A.N[j] * A.Mpart / A.h;      // halos['N'][j] * Mpart / h (:934)
+        const float rs = A.r25[j];
+        const float c = A.r98[j] / rs;
+        const float onec = 1.f + c;
+        const float lc = (float)log((double)onec);            // np.log of a float32 scalar
+        const float t = lc - c / onec;
+        float a1 = 1.0f / t;
+        a1 = a1 * 2.f;
+        a1 = a1 * (float)6.67e-11;
+        __syncthreads();
+        for (int i = threadIdx.x; i < k; i += blockDim.x) {
+            const long long q = A.sel_idx[o0 + i];
+            const float x = A.pos[3 * q], y = A.pos[3 * q + 1], z = A.pos[3 * q + 2];
+            px[i] = x, px[k + i] = y, px[2 * k + i] = z;
+            const float rx = x - hx, ry = y - hy, rz = z - hz;
+            const float d2 = (rx * rx + ry * ry) + rz * rz;    // np.sum(r_rel**2, axis=1) in float32
+            const float vx = A.vel[3 * q] - hvx, vy = A.vel[3 * q + 1] - hvy, vz = A.vel[3 * q + 2] - hvz;
+            const float v2 = (vx * vx + vy * vy) + vz * vz;
+            const float r0 = __fsqrt_rn(d2);
+            const float nx = rx / r0, ny = ry / r0, nz = rz / r0;
+            const float vrad = (vx * nx + vy * ny) + vz * nz;
+            const float vrad2 = vrad * vrad, vtan2 = v2 - vrad2;
+            const float r0k = r0 * 1000.f;
+            double al = (double)a1 * m;
+            al = al * 2e30;
+            al = al / (double)r0k;
+            al = al / 3.086e19;
+            al = al / 1e6;
+            const float Af = vtan2 + vrad2;
+            float x2f = vtan2 / Af;
+            const float Bf = (float)log((double)(1.f + r0k / rs));
+            // first iteration: float32 until alpha (float64) enters (:958-965)
+            const float ox = __fsqrt_rn(x2f);
+            float lg = ox * r0k;
+            lg = lg / rs;
+            lg = 1.f + lg;
+            lg = (float)log((double)lg);
+            lg = lg / ox;
+            lg = lg - Bf;
+            double x2 = (double)vtan2 / ((double)Af + al * (double)lg);
+            for (int it = 1; it < 20; it++) {
+                const double od = sqrt(x2);
+                double w = od * (double)r0k;
+                w = w / (double)rs;
+                w = log(1.0 + w) / od - (double)Bf;
+                x2 = (double)vtan2 / ((double)Af + al * w);
+            }
+            if (x2 != x2) x2 = 1.0;
+            key[i] = (double)d2;
+            key[k + i] = (double)v2;
+            key[2 * k + i] = (double)(r0k * r0k) * x2;
+            key[3 * k + i] = (double)vrad;
+        }
+        __syncthreads();
+        // nearest other particle among ALL subsample particles of the halo (cKDTree.query(k=2)[0][:, 1], :912-913)
+        const long long a = A.pstart[j], n_in = A.pnum[j];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int i = wave; i < k; i += blockDim.x / 64) {
+            const long long self = A.sel_idx[o0 + i];
+            const double x = (double)px[i], y = (double)px[k + i], z = (double)px[2 * k + i];
+            double best = INFINITY;
+            for (long long q = a + lane; q < a + n_in; q += 64) {
+                if (q == self) continue;
+                const double dx = x - (double)A.pos[3 * q], dy = y - (double)A.pos[3 * q + 1], dz = z - (double)A.pos[3 * q + 2];
+                const double d = (dx * dx + dy * dy) + dz * dz;
+                best = d < best ? d : best;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_down(best, off, 64);
+                best = o < best ? o : best;
+            }
+            if (lane == 0) key[4 * k + i] = sqrt(best);
+        }
+        __syncthreads();
+        const double mean = 0.5 * (double)(k - 1);             // np.mean of the ranks 0 .. k-1
+        double *outs[5] = {A.ranks, A.ranksv, A.ranksp, A.ranksr, A.ranksc};
+        for (int e = threadIdx.x; e < 5 * k; e += blockDim.x) {
+            const int col = e / k, i = e - col * k;
+            const double *kc = key + (size_t)col * k;
+            const double v = kc[i];
+            int r = 0;
+            for (int q = 0; q < k; q++) r += key_before(kc[q], q, v, i) ? 1 : 0;
+            outs[col][o0 + i] = ((double)r - mean) / mean;     // (newranks - mean) / mean
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void prep_rank_work(const long long *__restrict__ kept, int64_t nh, int *__restrict__ work, int *__restrict__ nwork,
+                               int *__restrict__ kmax) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nh; j += (int64_t)gridDim.x * blockDim.x)
+        if (kept[j] >= 2) {
+            work[atomicAdd(nwork, 1)] = (int)j;
+            atomicMax(kmax, (int)min(kept[j], 0x7fffffffll));
+        }
+}
+__global__ void prep_rank_single(const long long *__restrict__ kept, const long long *__restrict__ kstart, int64_t nh,
+                                 double *r0, double *r1, double *r2, double *r3, double *r4) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nh; j += (int64_t)gridDim.x * blockDim.x)
+        if (kept[j] == 1) {                                   // a lone particle ranks 0 in every column (:889-895)
+            const long long s = kstart[j];
+            r0[s] = r1[s] = r2[s] = r3[s] = r4[s] = 0.0;
+        }
+}
+
+template <class T>
+int exclusive_sum(const T *in, T *out, int64_t n, Tmp &tmp) {
+    size_t bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, stream()));
+    void *ws;
+    ABACUS_TRY(tmp.alloc((unsigned char **)&ws, bytes));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws, bytes, in, out, (int)n, stream()));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int abacus_prepare_halo_factors(const uint32_t *N, int64_t n, double Mpart, int MT, const double *u, const int64_t *pnum,
+                                double *p_halos, uint8_t *mask, int32_t *ntarget) {
+    ABACUS_ENTER();
+    if (n < 0 || (n > 0 && (!N || !p_halos))) return fail("abacus_prepare_halo_factors: null argument");
+    if (mask && !u) return fail("abacus_prepare_halo_factors: the halo mask needs the uniform draws");
+    if (ntarget && !pnum) return fail("abacus_prepare_halo_factors: the particle targets need npoutA");
+    if (n == 0) return 0;
+    Tmp tmp;
+    unsigned int *dN;
+    double *du = nullptr, *dp;
+    long long *dnum = nullptr;
+    unsigned char *dm = nullptr;
+    int *dt = nullptr;
+    ABACUS_TRY(tmp.upload(&dN, (const unsigned int *)N, (size_t)n));
+    if (mask) ABACUS_TRY(tmp.upload(&du, u, (size_t)n));
+    if (ntarget) ABACUS_TRY(tmp.upload(&dnum, (const long long *)pnum, (size_t)n));
+    ABACUS_TRY(tmp.alloc(&dp, (size_t)n));
+    if (mask) ABACUS_TRY(tmp.alloc(&dm, (size_t)n));
+    if (ntarget) ABACUS_TRY(tmp.alloc(&dt, (size_t)n));
+    ABACUS_LAUNCH("prep_halo_factors", prep_halo_factors, dim3(grid_for(n)), dim3(256), 0, dN, n, Mpart, MT, du, dnum, dp, dm, dt);
+    HIP_TRY(hipMemcpyAsync(p_halos, dp, (size_t)n * 8, hipMemcpyDeviceToHost, stream()));
+    if (mask) HIP_TRY(hipMemcpyAsync(mask, dm, (size_t)n, hipMemcpyDeviceToHost, stream()));
+    if (ntarget) HIP_TRY(hipMemcpyAsync(ntarget, dt, (size_t)n * 4, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_prepare_particles(int64_t nh, const uint8_t *hmask, const int64_t *pstart, const int64_t *pnum, const uint32_t *N,
+                             const float *hpos, const float *hvel, const float *r25, const float *r98, int64_t npart,
+                             const float *pos, const float *vel, const uint8_t *submask_in, const int32_t *ntarget, uint64_t seed,
+                             int64_t part_index0, double Mpart, double h, int want_ranks, double *pstart_new, double *pnum_new,
+                             int64_t *n_sel, int64_t cap_sel, int64_t *sel_idx, int64_t *sel_host, double *sel_np, double *ranks,
+                             double *ranksv, double *ranksp, double *ranksr, double *ranksc, uint8_t *submask_out) {
+    ABACUS_ENTER();
+    if (nh < 0 || npart < 0 || !n_sel) return fail("abacus_prepare_particles: bad arguments");
+    if (nh > 0 && (!hmask || !pstart || !pnum || !pstart_new || !pnum_new)) return fail("abacus_prepare_particles: null halo column");
+    if (!submask_in && !ntarget) return fail("abacus_prepare_particles: pass either the selection (submask) or the per-halo targets");
+    if (want_ranks && (!N || !hpos || !hvel || !r25 || !r98 || !pos || !vel || !ranks || !ranksv || !ranksp || !ranksr || !ranksc))
+        return fail("abacus_prepare_particles: the rank columns need positions, velocities, N, r25, r98 and five outputs");
+    if (nh >= ((int64_t)1 << 31) || npart >= ((int64_t)1 << 31)) return fail("abacus_prepare_particles: slab too large for 32-bit indices");
+    *n_sel = 0;
+    if (nh == 0) return 0;
+    Tmp tmp;
+    unsigned char *d_hmask, *d_sub;
+    long long *d_pstart, *d_pnum, *d_kept, *d_kstart, *d_flag, *d_slot;
+    int *d_host, *d_bad, *d_nt = nullptr;
+    const size_t np1 = (size_t)std::max<int64_t>(npart, 1);
+    ABACUS_TRY(tmp.upload(&d_hmask, (const unsigned char *)hmask, (size_t)nh));
+    ABACUS_TRY(tmp.upload(&d_pstart, (const long long *)pstart, (size_t)nh));
+    ABACUS_TRY(tmp.upload(&d_pnum, (const long long *)pnum, (size_t)nh));
+    ABACUS_TRY(tmp.alloc(&d_host, np1));
+    ABACUS_TRY(tmp.alloc(&d_bad, 4));
+    ABACUS_TRY(tmp.alloc(&d_sub, np1));
+    HIP_TRY(hipMemsetAsync(d_host, 0xff, np1 * 4, stream()));
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 16, stream()));
+    ABACUS_LAUNCH("prep_fill_host", prep_fill_host, dim3((unsigned int)std::min<int64_t>(ceil_div(nh, 4), 256 * 32)), dim3(256), 0,
+                  d_pstart, d_pnum, d_hmask, nh, npart, d_host, d_bad);
+    if (submask_in) {
+        HIP_TRY(hipMemcpyAsync(d_sub, submask_in, (size_t)npart, hipMemcpyHostToDevice, stream()));
+    } else {
+        // Philox keys, one stable sort of (halo, key), the first ntarget of every halo's run
+        ABACUS_TRY(tmp.upload(&d_nt, (const int *)ntarget, (size_t)nh));
+        unsigned long long *k0, *k1;
+        unsigned int *i0, *i1;
+        long long *ccount, *cstart;
+        ABACUS_TRY(tmp.alloc(&k0, np1));
+        ABACUS_TRY(tmp.alloc(&k1, np1));
+        ABACUS_TRY(tmp.alloc(&i0, np1));
+        ABACUS_TRY(tmp.alloc(&i1, np1));
+        ABACUS_TRY(tmp.alloc(&ccount, (size_t)nh));
+        ABACUS_TRY(tmp.alloc(&cstart, (size_t)nh));
+        ABACUS_LAUNCH("prep_keys", prep_keys, dim3(grid_for(npart)), dim3(256), 0, d_host, d_nt, d_pnum, npart,
+                      (unsigned long long)seed, (long long)part_index0, k0, i0, d_sub);
+        ABACUS_LAUNCH("prep_cand_count", prep_cand_count, dim3(grid_for(nh)), dim3(256), 0, d_hmask, d_pnum, d_nt, nh, ccount);
+        ABACUS_TRY(exclusive_sum(ccount, cstart, nh, tmp));
+        if (npart > 0) {
+            size_t bytes = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, i0, i1, (int)npart, 0, 64, stream()));
+            void *ws;
+            ABACUS_TRY(tmp.alloc((unsigned char **)&ws, bytes));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ws, bytes, k0, k1, i0, i1, (int)npart, 0, 64, stream()));
+            ABACUS_LAUNCH("prep_pick", prep_pick, dim3(grid_for(npart)), dim3(256), 0, k1, i1, npart, cstart, d_nt, d_sub);
+        }
+    }
+    ABACUS_TRY(tmp.alloc(&d_kept, (size_t)nh));
+    ABACUS_TRY(tmp.alloc(&d_kstart, (size_t)nh));
+    ABACUS_LAUNCH("prep_count", prep_count, dim3((unsigned int)std::min<int64_t>(ceil_div(nh, 4), 256 * 32)), dim3(256), 0, d_pstart,
+                  d_pnum, d_hmask, d_sub, nh, d_kept);
+    ABACUS_TRY(exclusive_sum(d_kept, d_kstart, nh, tmp));
+    double *d_psn, *d_pnn;
+    ABACUS_TRY(tmp.alloc(&d_psn, (size_t)nh));
+    ABACUS_TRY(tmp.alloc(&d_pnn, (size_t)nh));
+    ABACUS_LAUNCH("prep_halo_offsets", prep_halo_offsets, dim3(grid_for(nh)), dim3(256), 0, d_hmask, d_pnum, d_kept, d_kstart, nh, d_psn, d_pnn);
+    HIP_TRY(hipMemcpyAsync(pstart_new, d_psn, (size_t)nh * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemcpyAsync(pnum_new, d_pnn, (size_t)nh * 8, hipMemcpyDeviceToHost, stream()));
+    long long last_start = 0, last_kept = 0;
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&last_start, d_kstart + (nh - 1), 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemcpyAsync(&last_kept, d_kept + (nh - 1), 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    if (bad) return fail("abacus_prepare_particles: a halo's [npstartA, npstartA + npoutA) lies outside the particle array");
+    const int64_t nsel = last_start + last_kept;
+    *n_sel = nsel;
+    if (submask_out && npart > 0) HIP_TRY(hipMemcpyAsync(submask_out, d_sub, (size_t)npart, hipMemcpyDeviceToHost, stream()));
+    if (nsel > cap_sel || !sel_idx) {      // size query (the count depends on the draw): the caller allocates and calls again
+        HIP_TRY(hipStreamSynchronize(stream()));
+        return 0;
+    }
+    if (nsel == 0) {
+        HIP_TRY(hipStreamSynchronize(stream()));
+        return 0;
+    }
+    long long *d_sidx, *d_shost;
+    double *d_snp;
+    ABACUS_TRY(tmp.alloc(&d_flag, np1));
+    ABACUS_TRY(tmp.alloc(&d_slot, np1));
+    ABACUS_TRY(tmp.alloc(&d_sidx, (size_t)nsel));
+    ABACUS_TRY(tmp.alloc(&d_shost, (size_t)nsel));
+    ABACUS_TRY(tmp.alloc(&d_snp, (size_t)nsel));
+    ABACUS_LAUNCH("prep_flags", prep_flags, dim3(grid_for(npart)), dim3(256), 0, d_sub, d_host, npart, d_flag);
+    ABACUS_TRY(exclusive_sum(d_flag, d_slot, npart, tmp));
+    ABACUS_LAUNCH("prep_emit", prep_emit, dim3(grid_for(npart)), dim3(256), 0, d_flag, d_slot, d_host, d_kept, npart, d_sidx, d_shost, d_snp);
+    HIP_TRY(hipMemcpyAsync(sel_idx, d_sidx, (size_t)nsel * 8, hipMemcpyDeviceToHost, stream()));
+    if (sel_host) HIP_TRY(hipMemcpyAsync(sel_host, d_shost, (size_t)nsel * 8, hipMemcpyDeviceToHost, stream()));
+    if (sel_np) HIP_TRY(hipMemcpyAsync(sel_np, d_snp, (size_t)nsel * 8, hipMemcpyDeviceToHost, stream()));
+    if (want_ranks) {
+        RankArgs A;
+        float *d_pos, *d_vel, *d_hpos, *d_hvel, *d_r25, *d_r98;
+        unsigned int *d_N;
+        double *d_r[5];
+        int *d_work, *d_cnt;
+        ABACUS_TRY(tmp.upload(&d_pos, pos, (size_t)npart * 3));
+        ABACUS_TRY(tmp.upload(&d_vel, vel, (size_t)npart * 3));
+        ABACUS_TRY(tmp.upload(&d_hpos, hpos, (size_t)nh * 3));
+        ABACUS_TRY(tmp.upload(&d_hvel, hvel, (size_t)nh * 3));
+        ABACUS_TRY(tmp.upload(&d_r25, r25, (size_t)nh));
+        ABACUS_TRY(tmp.upload(&d_r98, r98, (size_t)nh));
+        ABACUS_TRY(tmp.upload(&d_N, (const unsigned int *)N, (size_t)nh));
+        for (int c = 0; c < 5; c++) ABACUS_TRY(tmp.alloc(&d_r[c], (size_t)nsel));
+        ABACUS_TRY(tmp.alloc(&d_work, (size_t)nh));
+        ABACUS_TRY(tmp.alloc(&d_cnt, 4));
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, stream()));
+        ABACUS_LAUNCH("prep_rank_work", prep_rank_work, dim3(grid_for(nh)), dim3(256), 0, d_kept, nh, d_work, d_cnt, d_cnt + 1);
+        ABACUS_LAUNCH("prep_rank_single", prep_rank_single, dim3(grid_for(nh)), dim3(256), 0, d_kept, d_kstart, nh, d_r[0], d_r[1],
+                      d_r[2], d_r[3], d_r[4]);
+        int cnt[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        if (cnt[0] > 0) {
+            const size_t lds = (size_t)((3 * (size_t)cnt[1] * 4 + 15) / 16) * 16 + (size_t)5 * cnt[1] * 8;
+            if (lds > 160 * 1024) return fail("abacus_prepare_particles: %d kept particles in one halo exceed the rank kernel's LDS", cnt[1]);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(prep_ranks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            A.pos = d_pos, A.vel = d_vel, A.hpos = d_hpos, A.hvel = d_hvel, A.N = d_N, A.r25 = d_r25, A.r98 = d_r98;
+            A.pstart = d_pstart, A.pnum = d_pnum, A.kept = d_kept, A.kstart = d_kstart, A.sel_idx = d_sidx;
+            A.Mpart = Mpart, A.h = h;
+            A.ranks = d_r[0], A.ranksv = d_r[1], A.ranksp = d_r[2], A.ranksr = d_r[3], A.ranksc = d_r[4];
+            A.work = d_work, A.kmax = cnt[1];
+            ABACUS_LAUNCH("prep_ranks", prep_ranks, dim3((unsigned int)std::min(cnt[0], 256 * 8)), dim3(256), lds, A, cnt[0]);
+        }
+        double *dst[5] = {ranks, ranksv, ranksp, ranksr, ranksc};
+        for (int c = 0; c < 5; c++) HIP_TRY(hipMemcpyAsync(dst[c], d_r[c], (size_t)nsel * 8, hipMemcpyDeviceToHost, stream()));
+    }
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+}  // extern "C"

@@ -83,6 +83,17 @@ def calc_fenv_opt(Menv, mbins, halosM):
     return out
 
 
+def _concat_tables(tabs):
+    """rows of the slabs' subsample tables: HDF5 compound arrays or dicts of columns"""
+    if isinstance(tabs[0], dict):
+        return {k: np.concatenate([np.asarray(t[k]) for t in tabs]) for k in tabs[0]}
+    return np.concatenate(tabs)
+
+
+def _table_fields(tab):
+    return tab.keys() if isinstance(tab, dict) else tab.dtype.fields.keys()
+
+
 class AbacusHOD:
     """A multi-tracer HOD code for the AbacusSummit simulations (MI355X path)."""
 
@@ -170,6 +181,37 @@ class AbacusHOD:
             assert 'hdeltac' in self.halo_data.keys()
         if self.want_shear:
             assert 'hshear' in self.halo_data.keys()
+        self._build_mass_function()
+        return self
+
+    @classmethod
+    def from_prepared(cls, halo_tables, particle_tables, header, z_mock, HOD_params, clustering_params=None, env=None,
+                      mock_dir='./', halo_lc=False):
+        """Build the object straight from the subsample tables of prepare_sim (`prepare_slab_arrays` of
+        abacusutils_amd/hod/prepare_sim.py, one pair per slab) - what `staging()` reads back from the HDF5 files, without the
+        files.  header: BoxSize, ParticleMassHMsun, H0, VelZSpace_to_kms (+ LightConeOrigins) of the simulation; env: the
+        concatenated (id, mass, Menv) of `slab_environment` over ALL slabs of the box (needed with want_AB, :595-657)."""
+        self = cls.__new__(cls)
+        self.logger = logging.getLogger('AbacusHOD')
+        self.sim_name = self.sim_dir = self.subsample_dir = None
+        self.z_mock = z_mock
+        self.output_dir = str(mock_dir)
+        self.halo_lc = bool(halo_lc)
+        self.force_mt = False
+        self.local_env = {}
+        self.z_type = 'lightcone' if self.halo_lc else 'primary'
+        self._init_hod(HOD_params, clustering_params)
+        self.chunk, self.n_chunks = -1, 1
+        params = {'z': z_mock, 'h': header['H0'] / 100.0, 'Lbox': header['BoxSize'], 'Mpart': header['ParticleMassHMsun'],
+                  'velz2kms': header['VelZSpace_to_kms'] / header['BoxSize'], 'chunk': -1, 'numslabs': len(halo_tables),
+                  'origin': np.array(header['LightConeOrigins']).reshape(-1, 3)[0] if self.halo_lc else None}
+        if self.want_AB and not self.halo_lc and env is None:
+            raise ValueError('want_AB needs the environment masses of the whole box (prepare_sim.slab_environment per slab)')
+        self.halo_data, self.particle_data = self._assemble_staged(list(halo_tables), list(particle_tables), env, params, True)
+        self.params = params
+        self.mock_dir = Path(mock_dir)
+        self.lbox = params['Lbox']
+        self._staged = None
         self._build_mass_function()
         return self
 
@@ -262,7 +304,26 @@ class AbacusHOD:
             if with_parts:
                 with h5py.File(pfn, 'r') as f:
                     P.append(f['particles'][:])
-        Hc = np.concatenate(H)
+        env = None
+        if self.want_AB and (not self.halo_lc):
+            ids, masses, menvs = [], [], []
+            for eslab in range(len(halo_info_fns)):
+                envfilename = subsample_dir / f'env_xcom_{eslab}_abacushod_localenv_new.h5'
+                if not envfilename.exists():
+                    raise FileNotFoundError(f'Missing env sidecar: {envfilename}')
+                with h5py.File(envfilename, 'r') as fenv:
+                    ids.append(fenv['id'][:].astype(np.int64))
+                    masses.append(fenv['mass'][:])
+                    menvs.append(fenv['Menv'][:])
+            env = (np.concatenate(ids), np.concatenate(masses), np.concatenate(menvs))
+        halo_data, particle_data = self._assemble_staged(H, P, env, params, with_parts)
+        return halo_data, particle_data, params, mock_dir
+
+    def _assemble_staged(self, H, P, env, params, with_parts):
+        """the arrays of `halo_data` / `particle_data` from the subsample tables of the loaded slabs (:421-704).  H / P: one
+        table per slab (HDF5 compound arrays, or dicts of columns as prepare_sim.prepare_slab_arrays returns them); env: the
+        concatenated (id, mass, Menv) of the env sidecars of ALL slabs of the box, or None"""
+        Hc = _concat_tables(H)
         f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
         hpos, hvel = f8(Hc['x_L2com']), f8(Hc['v_L2com'])
         hmass = f8(Hc['N'] * params['Mpart'])
@@ -283,8 +344,8 @@ class AbacusHOD:
 
         particle_data = {}
         if with_parts:
-            Pc = np.concatenate(P)
-            fields = Pc.dtype.fields.keys()
+            Pc = _concat_tables(P)
+            fields = _table_fields(Pc)
             ppos, pvel, phvel = f8(Pc['pos']), f8(Pc['vel']), f8(Pc['halo_vel'])
             phmass = f8(Pc['halo_mass'])
             phid = Pc['halo_id'].astype(int)
@@ -317,16 +378,7 @@ class AbacusHOD:
         if self.want_AB and (not self.halo_lc):
             mcut_env = self.local_env.get('mcut', 1e11)
             nbins_env = self.local_env.get('nbins', 100)
-            ids, masses, menvs = [], [], []
-            for eslab in range(len(halo_info_fns)):
-                envfilename = subsample_dir / f'env_xcom_{eslab}_abacushod_localenv_new.h5'
-                if not envfilename.exists():
-                    raise FileNotFoundError(f'Missing env sidecar: {envfilename}')
-                with h5py.File(envfilename, 'r') as fenv:
-                    ids.append(fenv['id'][:].astype(np.int64))
-                    masses.append(fenv['mass'][:])
-                    menvs.append(fenv['Menv'][:])
-            env_id, env_mass, env_Menv = np.concatenate(ids), np.concatenate(masses), np.concatenate(menvs)
+            env_id, env_mass, env_Menv = env
             mbins_env = np.logspace(np.log10(mcut_env), 15.5, nbins_env + 1)
             hfenv_full = calc_fenv_opt(env_Menv, mbins_env, env_mass)
             env_sort = _argsort_ids(env_id)
@@ -359,7 +411,7 @@ class AbacusHOD:
             halo_data['hshear'] = hshear
             if with_parts:
                 particle_data['pshear'] = pshear
-        return halo_data, particle_data, params, mock_dir
+        return halo_data, particle_data
 
     # ------------------------------------------------------------------------------------------------------
     def restage(self):

@@ -1,0 +1,254 @@
+"""Subsample preparation on the MI355X: the data-parallel core of the reference's `prepare_sim.prepare_slab`
+(abacusnbody/hod/prepare_sim.py:296-1052), between "the CompaSO loader handed over the slab's `halos` and `parts` tables" and
+"the two HDF5 datasets are written".
+
+What runs where
+  device   subsample_halos + halo mask + particle targets (`abacus_prepare_halo_factors`); the per-halo particle selection,
+           new halo offsets, kept-particle list, Np and the five satellite rank columns (`abacus_prepare_particles`); the
+           concentration / shear / (light-cone) environment ranks per mass bin (`abacus_fenv_rank`); the environment masses
+           (`do_Menv_from_tree`).
+  host     drawing the random numbers, gathering the kept rows, file I/O (optional, needs h5py).  The CompaSO / ASDF readers
+           are out of scope: the caller passes the tables.
+
+Random numbers.  The reference consumes NumPy's global legacy generator in a fixed order (:349-350 seed, :449 halo mask,
+one `np.random.choice(replace=False)` per kept halo :163/:172, :984-996 halo randoms, :1029 particle randoms).
+`rng='numpy'` reproduces exactly that - including the serial per-halo `choice` loop, which stays on the host - so a run
+seeded like the reference agrees with it value for value (tests/test_prepare_gpu.py against the reference's own prepare_slab).
+`rng=<int seed>` is the scalable form: halo and particle columns from `np.random.Generator(np.random.Philox(seed))`, the
+per-halo selection on the device from counter-based Philox keys (no per-halo serial work); same distributions, another stream.
+
+The light-cone edge correction of the environment (:469-597, randoms through a KD-tree) is not built: `halo_lc=True` with
+`want_AB` raises if any halo lies in the edge region.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .menv import do_Menv_from_tree
+
+__all__ = ['subsample_halos', 'prepare_slab_arrays', 'slab_environment', 'rank_in_mass_bins', 'reference_seed', 'save_subsample']
+
+NBINS = 100          # mass bins of the rank columns (:454)
+RANK_COLUMNS = ('ranks', 'ranksv', 'ranksp', 'ranksr', 'ranksc')
+
+
+def reference_seed(newseed, i):
+    """seed NumPy's global generator like prepare_slab does for slab i (:349-351); returns the light-cone randoms seed"""
+    seeder = np.random.default_rng(newseed + i)
+    np.random.seed(seeder.integers(0, 2**32 - 1))
+    return seeder.integers(0, 2**32 - 1)
+
+
+def _halo_factors(N, Mpart, MT, u=None, pnum=None):
+    N = np.ascontiguousarray(N, dtype=np.uint32)
+    n = len(N)
+    p = np.empty(n, dtype=np.float64)
+    mask = np.empty(n, dtype=np.uint8) if u is not None else None
+    nt = np.empty(n, dtype=np.int32) if pnum is not None else None
+    u8 = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+    pn = None if pnum is None else np.ascontiguousarray(pnum, dtype=np.int64)
+    _lib.check(_lib.lib().abacus_prepare_halo_factors(_lib.ptr(N), C.c_int64(n), C.c_double(Mpart), int(bool(MT)), _lib.ptr(u8),
+                                                      _lib.ptr(pn), _lib.ptr(p), _lib.ptr(mask), _lib.ptr(nt)))
+    return p, (None if mask is None else mask.astype(bool)), nt
+
+
+def subsample_halos(m, MT, Mpart=None):
+    """fraction of halos kept as a function of mass (:83-108), evaluated on the device.  `m` are masses; halos are counted in
+    whole particles, so pass `Mpart` for exact agreement with `halos['N'] * Mpart` (else m is taken as the count times 1)"""
+    m = np.asarray(m, dtype=np.float64)
+    if Mpart is None:
+        Mpart, N = 1.0, m
+    else:
+        N = np.rint(m / Mpart)
+    return _halo_factors(N.astype(np.uint32), float(Mpart), MT)[0]
+
+
+def rank_in_mass_bins(values, masses, mbins):
+    """per mass bin (strictly inside both edges), the rank of `values` rescaled to [-0.5, 0.5]; halos alone in a bin or on an
+    edge get 0 (deltac_rank :762-773, shear_rank :776-796, calc_fenv_opt :283-293): abacus_fenv_rank on the device"""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    m = np.ascontiguousarray(masses, dtype=np.float64)
+    e = np.ascontiguousarray(mbins, dtype=np.float64)
+    out = np.zeros(len(v), dtype=np.float64)
+    if len(v):
+        _lib.check(_lib.lib().abacus_fenv_rank(_lib.ptr(v), _lib.ptr(m), C.c_int64(len(v)), _lib.ptr(e), len(e), _lib.ptr(out)))
+    return out
+
+
+def _periodic_dx(x, x0, Lbox):
+    return ((x - x0 + 0.5 * Lbox) % Lbox) - 0.5 * Lbox
+
+
+def slab_environment(i, central, neighbours, numslabs, Lbox, Mpart, rad_outer=10, mcut=1e11):
+    """raw environment masses of slab i's halos with the halos of the neighbouring slabs within `rad_outer` of its x-range
+    as padding (the periodic-box branch, :622-745).  central / neighbours: halo tables (dicts with x_L2com, N, r98_L2com, id);
+    `neighbours` lists the slabs (i - d) % numslabs and (i + d) % numslabs for d = 1 .. ceil(rad_outer / slab width), in any
+    order.  Returns (id, mass, Menv) of the central halos - the content of the reference's env sidecar file (:748-756)."""
+    cpos = np.asarray(central['x_L2com'])
+    cmass = central['N'] * Mpart
+    cid = np.asarray(central['id']).astype(np.int64)
+    if len(np.unique(cid)) != len(cid):
+        raise RuntimeError(f'Duplicate halo IDs found inside central slab {i}.')
+    dx_slab = Lbox / numslabs
+    x_center = -0.5 * Lbox + (i + 0.5) * dx_slab                       # unwrap_x_for_slab (:68-72)
+    xu = x_center + _periodic_dx(cpos[:, 0], x_center, Lbox)
+    edges = (xu.min(), xu.max())
+    pos, mass, rvir, ids = [cpos], [cmass], [np.asarray(central['r98_L2com'])], [cid]
+    for nb in neighbours:
+        x = np.asarray(nb['x_L2com'])[:, 0]
+        near = (np.abs(_periodic_dx(x, edges[0], Lbox)) <= rad_outer) | (np.abs(_periodic_dx(x, edges[1], Lbox)) <= rad_outer)
+        if near.any():
+            pos.append(np.asarray(nb['x_L2com'])[near])
+            mass.append((nb['N'] * Mpart)[near])
+            rvir.append(np.asarray(nb['r98_L2com'])[near])
+            ids.append(np.asarray(nb['id']).astype(np.int64)[near])
+    pos, mass, rvir, ids = np.concatenate(pos, axis=0), np.concatenate(mass), np.concatenate(rvir), np.concatenate(ids)
+    _, first = np.unique(ids, return_index=True)                        # a halo reached through both edges counts once (:712-718)
+    keep = np.sort(first)
+    Menv = do_Menv_from_tree(pos[keep], mass[keep], r_inner=rvir[keep], r_outer=rad_outer, halo_lc=False, Lbox=Lbox, mcut=mcut)
+    return cid, cmass, Menv[:len(cid)]
+
+
+def _targets_host(masses, pnum, MT):
+    """submask_particles' target count (:152-174) in the reference's own floating-point expressions (the host loop of
+    rng='numpy' must draw exactly what the reference draws)"""
+    out = np.zeros(len(masses), dtype=np.int64)
+    for j in np.nonzero(pnum > 0)[0]:
+        m_in, n_in = masses[j], int(pnum[j])
+        x = np.log10(m_in)
+        if MT:
+            if m_in < 1e11:
+                continue
+            out[j] = min(min(n_in, int(1 + 1.5 * 10 ** (x - 12.5))), 100)
+        elif not 10 ** x < 1e12:
+            out[j] = min(n_in, int(1 + 1.5 * 10 ** (x - 13)))
+    return out
+
+
+def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=True, Menv=None, shearmark=None, Lbox=None,
+                        mcut=1e11, halo_lc=False, rng='numpy', part_index0=0):
+    """halos: dict of columns N, x_L2com, v_L2com, r25_L2com, r90_L2com, r98_L2com, npstartA, npoutA, id, sigmav3d_L2com (what
+    CompaSOHaloCatalog loads for prepare_slab, :404-425); parts: dict with pos, vel of the slab's subsample-A particles in halo
+    order.  Returns (halo table of the kept halos, particle table of the kept particles, mask over the input halos): dicts with
+    the field names and dtypes of the reference's 'halos' / 'particles' datasets (:1001-1045)."""
+    nh = len(halos['N'])
+    N = np.ascontiguousarray(halos['N'], dtype=np.uint32)
+    masses = halos['N'] * Mpart
+    pstart = np.ascontiguousarray(halos['npstartA'], dtype=np.int64)
+    pnum = np.ascontiguousarray(halos['npoutA'], dtype=np.int64)
+    numpy_mode = isinstance(rng, str)
+    if numpy_mode and rng != 'numpy':
+        raise ValueError("rng must be 'numpy' (the reference's global generator) or an integer seed")
+    gen = None if numpy_mode else np.random.Generator(np.random.Philox(int(rng)))
+    u = np.random.random(nh) if numpy_mode else gen.random(nh)                       # (:449)
+    p_halos, mask_halos, ntarget = _halo_factors(N, Mpart, MT, u=u, pnum=pnum)
+    H = dict(halos)
+    H['mask_subsample'] = mask_halos
+    H['multi_halos'] = 1.0 / p_halos
+    mbins = np.logspace(np.log10(mcut), 15.5, NBINS + 1)
+    zeros = np.zeros(nh)
+    if want_AB:
+        if halo_lc:
+            if Menv is None:
+                raise ValueError('halo_lc with want_AB needs the environment masses (do_Menv_from_tree); the edge correction '
+                                 'with randoms (:469-597) is not built')
+            H['fenv_rank'] = rank_in_mass_bins(Menv, masses, mbins)                  # calc_fenv_opt (:618)
+        else:
+            H['fenv_rank'] = zeros.copy()         # ranked over the whole box later, by AbacusHOD.staging() (:758-759)
+        H['deltac_rank'] = rank_in_mass_bins(halos['r98_L2com'] / halos['r25_L2com'], masses, mbins)
+    else:
+        H['fenv_rank'], H['deltac_rank'] = zeros.copy(), zeros.copy()
+    if shearmark is not None:                                                        # (:776-796)
+        ndim = len(shearmark)
+        g = (np.asarray(halos['x_L2com']) / (Lbox / ndim)).astype(int) % ndim
+        H['shear_rank'] = rank_in_mass_bins(shearmark[g[:, 0], g[:, 1], g[:, 2]], masses, mbins)
+    else:
+        H['shear_rank'] = zeros.copy()
+
+    pos = np.ascontiguousarray(parts['pos'], dtype=np.float32)
+    vel = np.ascontiguousarray(parts['vel'], dtype=np.float32)
+    npart = len(pos)
+    submask = None
+    if numpy_mode:      # the reference's serial loop: one `choice` per kept halo with particles above the mass floor
+        tg = _targets_host(masses, np.where(mask_halos, pnum, 0), MT)
+        submask = np.zeros(npart, dtype=np.uint8)
+        for j in np.nonzero(tg > 0)[0]:
+            submask[pstart[j] + np.random.choice(int(pnum[j]), int(tg[j]), replace=False)] = 1
+
+    hmask8 = np.ascontiguousarray(mask_halos, dtype=np.uint8)
+    hpos = np.ascontiguousarray(halos['x_L2com'], dtype=np.float32)
+    hvel = np.ascontiguousarray(halos['v_L2com'], dtype=np.float32)
+    r25 = np.ascontiguousarray(halos['r25_L2com'], dtype=np.float32)
+    r98 = np.ascontiguousarray(halos['r98_L2com'], dtype=np.float32)
+    pstart_new, pnum_new = np.empty(nh), np.empty(nh)
+    nsel = C.c_int64(0)
+    seed = 0 if numpy_mode else int(gen.integers(0, 2**63 - 1))
+    L = _lib.lib()
+
+    def call(sub_in, cap, outs, sub_out):
+        _lib.check(L.abacus_prepare_particles(
+            C.c_int64(nh), _lib.ptr(hmask8), _lib.ptr(pstart), _lib.ptr(pnum), _lib.ptr(N), _lib.ptr(hpos), _lib.ptr(hvel),
+            _lib.ptr(r25), _lib.ptr(r98), C.c_int64(npart), _lib.ptr(pos), _lib.ptr(vel), _lib.ptr(sub_in),
+            None if sub_in is not None else _lib.ptr(ntarget), C.c_uint64(seed), C.c_int64(part_index0), C.c_double(Mpart),
+            C.c_double(h), int(bool(want_ranks)), _lib.ptr(pstart_new), _lib.ptr(pnum_new), C.byref(nsel), C.c_int64(cap),
+            *[_lib.ptr(o) for o in outs], _lib.ptr(sub_out)))
+
+    if submask is None:                          # device draw: size query first, then the same selection again
+        submask = np.zeros(max(npart, 1), dtype=np.uint8)[:npart]
+        call(None, 0, [None] * 8, submask)
+    else:
+        call(submask, 0, [None] * 8, None)
+    n = int(nsel.value)
+    sel_idx, sel_host = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+    sel_np = np.empty(n)
+    rk = [np.empty(n) for _ in RANK_COLUMNS] if want_ranks else [None] * 5
+    if n:
+        call(submask, n, [sel_idx, sel_host, sel_np] + rk, None)
+    H['npstartA'], H['npoutA'] = pstart_new, pnum_new
+    sig = np.repeat(halos['sigmav3d_L2com'], 3).reshape((-1, 3)) / np.sqrt(3)
+    if numpy_mode:                                                                   # (:984-996)
+        H['randoms'] = np.random.random(nh)
+        H['randoms_exp'] = (np.random.randint(0, 2, size=(nh, 3)) * 2 - 1) * np.random.exponential(scale=sig, size=(nh, 3))
+        H['randoms_gaus_vrms'] = np.random.normal(loc=0, scale=sig, size=(nh, 3))
+    else:
+        H['randoms'] = gen.random(nh)
+        H['randoms_exp'] = (gen.integers(0, 2, size=(nh, 3)) * 2 - 1) * gen.exponential(scale=sig, size=(nh, 3))
+        H['randoms_gaus_vrms'] = gen.normal(loc=0, scale=sig, size=(nh, 3))
+    Hk = {k: np.asarray(v)[mask_halos] for k, v in H.items()}
+
+    P = {'pos': pos[sel_idx], 'vel': vel[sel_idx]}
+    if want_ranks:
+        for name, col in zip(RANK_COLUMNS, rk):
+            P[name] = col
+    P['downsample_halo'] = p_halos[sel_host]
+    P['halo_vel'] = hvel[sel_host].astype(np.float64)
+    P['halo_mass'] = masses[sel_host].astype(np.float64)
+    P['Np'] = sel_np
+    P['halo_id'] = np.asarray(halos['id'])[sel_host].astype(np.int64)
+    P['randoms'] = np.random.random(n) if numpy_mode else gen.random(n)              # (:1029)
+    P['halo_deltac'] = H['deltac_rank'][sel_host]
+    P['halo_fenv'] = H['fenv_rank'][sel_host]
+    P['halo_shear'] = H['shear_rank'][sel_host]
+    return Hk, P, mask_halos
+
+
+def save_subsample(halo_table, particle_table, halo_fn, particle_fn):
+    """the two HDF5 files of a slab as the reference writes them (:1001-1045: one compound dataset each); needs h5py"""
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError('writing the prepare_sim HDF5 files needs h5py; the tables themselves can be handed to '
+                          'AbacusHOD.from_prepared without touching the disk') from e
+
+    def compound(tab):
+        n = len(next(iter(tab.values())))
+        dt = np.dtype([(k, v.dtype, v.shape[1:]) for k, v in tab.items()])
+        out = np.empty(n, dtype=dt)
+        for k, v in tab.items():
+            out[k] = v
+        return out
+
+    for fn, name, tab in ((halo_fn, 'halos', halo_table), (particle_fn, 'particles', particle_table)):
+        with h5py.File(fn, 'w') as f:
+            f.create_dataset(name, data=compound(tab))

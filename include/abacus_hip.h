@@ -433,6 +433,32 @@ int abacus_argsort_i64(const int64_t *keys, int64_t n, int64_t *order);
 int abacus_searchsorted_i64(const int64_t *sorted, int64_t n, const int64_t *query, int64_t m, int64_t *out);
 int abacus_fenv_rank(const double *Menv, const double *halosM, int64_t n, const double *mbins, int n_edges, double *out);
 
+/* ---------------------------------------------------------------- prepare_sim (subsample preparation) ---- */
+/*
+ * replaces the data-parallel core of abacusnbody/hod/prepare_sim.py `prepare_slab` (:296-1052); host arrays in and out
+ * (runs once per slab).  Host side and file layout: abacusutils_amd/hod/prepare_sim.py.
+ *
+ * abacus_prepare_halo_factors: p_halos[i] = subsample_halos(N[i] * Mpart, MT) (:83-108); mask[i] = u[i] < p_halos[i] (:449)
+ *   when `mask` / `u` are given; ntarget[i] = the number of subsample particles submask_particles keeps for a halo of that
+ *   mass with pnum[i] particles (:152-174) when `ntarget` / `pnum` are given.
+ * abacus_prepare_particles: for every kept halo (hmask) with pnum > 0, keep a subset of its particle slice
+ *   [pstart, pstart + pnum) - either the caller's `submask_in` (npart bytes, drawn on the host in the reference's order) or,
+ *   with submask_in == NULL, a uniformly random subset of ntarget[j] particles from counter-based Philox keys (seed, particle
+ *   index part_index0 + q).  Outputs: pstart_new / pnum_new per halo as the reference stores them (float64; -1 for dropped
+ *   halos and halos without particles, :895-897, :979-981); *n_sel kept particles; if cap_sel >= *n_sel also their input index
+ *   (ascending), host halo index, Np (:881) and, with want_ranks, the five rank columns ranks / ranksv / ranksp / ranksr /
+ *   ranksc (:899-977).  Call with cap_sel = 0 first to size the outputs (pass the returned `submask_out` as `submask_in` of the
+ *   second call, so that both calls see one draw).  Halo slices must be ordered like the halos (CompaSO's layout).
+ */
+int abacus_prepare_halo_factors(const uint32_t *N, int64_t n, double Mpart, int MT, const double *u, const int64_t *pnum,
+                                double *p_halos, uint8_t *mask, int32_t *ntarget);
+int abacus_prepare_particles(int64_t nh, const uint8_t *hmask, const int64_t *pstart, const int64_t *pnum, const uint32_t *N,
+                             const float *hpos, const float *hvel, const float *r25, const float *r98, int64_t npart,
+                             const float *pos, const float *vel, const uint8_t *submask_in, const int32_t *ntarget, uint64_t seed,
+                             int64_t part_index0, double Mpart, double h, int want_ranks, double *pstart_new, double *pnum_new,
+                             int64_t *n_sel, int64_t cap_sel, int64_t *sel_idx, int64_t *sel_host, double *sel_np, double *ranks,
+                             double *ranksv, double *ranksp, double *ranksr, double *ranksc, uint8_t *submask_out);
+
 /* ---------------------------------------------------------------- catalogue side (upstream of the HOD) ---- */
 /*
  * replaces: abacusnbody/data/bitpacked.py:32-116 `unpack_rvint` / `_unpack_rvint`.  intdata: (n,3) int32, 20-bit
