@@ -186,12 +186,12 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
     seed = 0 if numpy_mode else int(gen.integers(0, 2**63 - 1))
     L = _lib.lib()
 
-    def call(sub_in, cap, outs, sub_out):
+    def call(sub_in, cap, outs, sub_out, ranks=False):
         _lib.check(L.abacus_prepare_particles(
             C.c_int64(nh), _lib.ptr(hmask8), _lib.ptr(pstart), _lib.ptr(pnum), _lib.ptr(N), _lib.ptr(hpos), _lib.ptr(hvel),
             _lib.ptr(r25), _lib.ptr(r98), C.c_int64(npart), _lib.ptr(pos), _lib.ptr(vel), _lib.ptr(sub_in),
             None if sub_in is not None else _lib.ptr(ntarget), C.c_uint64(seed), C.c_int64(part_index0), C.c_double(Mpart),
-            C.c_double(h), int(bool(want_ranks)), _lib.ptr(pstart_new), _lib.ptr(pnum_new), C.byref(nsel), C.c_int64(cap),
+            C.c_double(h), int(bool(ranks)), _lib.ptr(pstart_new), _lib.ptr(pnum_new), C.byref(nsel), C.c_int64(cap),
             *[_lib.ptr(o) for o in outs], _lib.ptr(sub_out)))
 
     if submask is None:                          # device draw: size query first, then the same selection again
@@ -204,7 +204,7 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
     sel_np = np.empty(n)
     rk = [np.empty(n) for _ in RANK_COLUMNS] if want_ranks else [None] * 5
     if n:
-        call(submask, n, [sel_idx, sel_host, sel_np] + rk, None)
+        call(submask, n, [sel_idx, sel_host, sel_np] + rk, None, ranks=want_ranks)
     H['npstartA'], H['npoutA'] = pstart_new, pnum_new
     sig = np.repeat(halos['sigmav3d_L2com'], 3).reshape((-1, 3)) / np.sqrt(3)
     if numpy_mode:                                                                   # (:984-996)
