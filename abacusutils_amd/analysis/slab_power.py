@@ -129,14 +129,25 @@ class HipSlabBackend:
                                                   len(poles), _lib.ptr(raw)))
         return raw
 
-    def xbin_raw(self, field, nmesh, y0, nyl, Lbox, W, ke, me, poles, put_geom):
+    def fft_zy_pack(self, mesh, off, send, nmesh, nxl, world, x0, nxc):
+        """z / y passes of planes [x0, x0 + nxc) with the y pass writing the send buffer (no pack pass); False when the
+        library does not serve this mesh / rank count that way (then fft_zy + pack)"""
+        rc = _lib.lib().abacus_slab_fft_zy_pack_dev(mesh.ptr(off), send.ptr(0), int(nmesh), int(nxl), int(world), int(x0), int(nxc))
+        if rc == 1:
+            return False
+        _lib.check(rc)
+        return True
+
+    def xbin_raw(self, field, nmesh, y0, nyl, Lbox, W, ke, me, poles, put_geom, from_transpose=False):
         """last x pass fused with the binning (auto power, one non-interlaced field, nmesh 1024 / 2048): raw sums, or None
-        when the library does not serve this mesh / histogram that way (then fft_x + bin_raw)"""
+        when the library does not serve this mesh / histogram that way (then fft_x + bin_raw).  from_transpose: `field` is
+        the receive buffer of the pencil transpose, (x, y_local, k), not yet unpacked"""
         buf, off = field
         raw = np.zeros(self.raw_bytes(len(ke) - 1, len(me) - 1, poles), dtype=np.uint8)
         rc = _lib.lib().abacus_slab_xbin_dev(buf.ptr(off), int(nmesh), int(y0), int(nyl), C.c_double(Lbox),
                                              None if W is None else _lib.ptr(W), _lib.ptr(ke), len(ke) - 1, _lib.ptr(me),
-                                             len(me) - 1, _lib.ptr(poles), len(poles), int(bool(put_geom)), _lib.ptr(raw))
+                                             len(me) - 1, _lib.ptr(poles), len(poles), int(bool(put_geom)),
+                                             int(bool(from_transpose)), _lib.ptr(raw))
         if rc == 1:
             return None
         _lib.check(rc)
@@ -241,21 +252,32 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
             backend.axpy(mesh, nxl * plane, ghost, 0, g, 1.0)
             backend.axpy(mesh, G * plane, ghost, g, g, 1.0)
         # z / y passes, pack and pencil transpose in chunks of x-planes: chunk c is on the links (the communicator's
-        # stream) while chunk c+1 is transformed
+        # stream) while chunk c+1 is transformed.  Where the library offers it the y pass writes the send buffer itself (no
+        # pack pass), and - auto power of one non-interlaced field - the last x pass reads the receive buffer as it arrived,
+        # applies the x butterfly while staging and bins from LDS (no unpack pass, no x pass, no spectrum in HBM); one rank
+        # without a transport then needs neither buffer: its own slab is the "received" block.
         nchunk = comm.transpose_chunks(nxl) if comm.collective else 1
         cx = nxl // nchunk
         nyl = nmesh // W
+        direct = try_xbin and not comm.collective           # one rank, fused last pass: no transpose at all
         for c in range(nchunk):
-            backend.fft_zy(mesh, (G + c * cx) * plane, nmesh, cx)
-            backend.pack(mesh, G * plane, send, nmesh, nxl, W, c * cx, cx)
+            if direct:
+                backend.fft_zy(mesh, (G + c * cx) * plane, nmesh, cx)
+                continue
+            packed = comm.collective and hasattr(backend, 'fft_zy_pack') and \
+                backend.fft_zy_pack(mesh, G * plane, send, nmesh, nxl, W, c * cx, cx)
+            if not packed:
+                backend.fft_zy(mesh, (G + c * cx) * plane, nmesh, cx)
+                backend.pack(mesh, G * plane, send, nmesh, nxl, W, c * cx, cx)
             if comm.collective:
                 comm.all_to_all_piece(backend, send, recv, nxl * nyl * pitch, c * cx * nyl * pitch, cx * nyl * pitch,
                                       overlap=nchunk > 1)
         if comm.collective:
             comm.join()
+        if try_xbin:                                          # (x, y_local, k) as delivered: handed to the fused last pass
+            return (mesh, G * plane) if direct else (recv if comm.collective else send, 0)
         backend.unpack(recv if comm.collective else send, mesh, G * plane, nmesh, nxl, W)   # mesh now holds (y_local, x, k)
-        if not try_xbin:
-            backend.fft_x(mesh, G * plane, nmesh, nxl)
+        backend.fft_x(mesh, G * plane, nmesh, nxl)
         return (mesh, G * plane)
 
     sets = [(pos, w, n_total)] + ([(pos2, w2, n_total2)] if pos2 is not None else [])
@@ -273,10 +295,18 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
             fields.append((None, 0))
     if pos2 is None:
         fields += [(None, 0), (None, 0)]
-    raw = backend.xbin_raw(fields[0], nmesh, r * nxl, nxl, Lbox, Wk, ke, me, poles_arr, r == 0) if try_xbin else None
+    raw = None
+    if try_xbin:
+        raw = backend.xbin_raw(fields[0], nmesh, r * nxl, nxl, Lbox, Wk, ke, me, poles_arr, r == 0, from_transpose=True)
+        if raw is None:      # not served: unpack (with the x butterfly where the form is fused), x pass, binning
+            src, _ = fields[0]
+            if src is meshes[0]:                              # one rank went straight from its slab: it still has to be packed
+                backend.pack(meshes[0], G * plane, send, nmesh, nxl, W, 0, nxl)
+                src = send
+            backend.unpack(src, meshes[0], G * plane, nmesh, nxl, W)
+            backend.fft_x(meshes[0], G * plane, nmesh, nxl)
+            fields[0] = (meshes[0], G * plane)
     if raw is None:
-        if try_xbin:
-            backend.fft_x(*fields[0], nmesh, nxl)
         raw = backend.bin_raw(fields, nmesh, r * nxl, nxl, Lbox, Wk, interlaced, ke, me, poles_arr)
     raw = comm.all_reduce_raw(raw, (len(ke) - 1) * (len(me) - 1))
     power, N_mode, bp, Nmp, k_avg = backend.finalize(raw, Lbox, len(ke) - 1, len(me) - 1, poles_arr)

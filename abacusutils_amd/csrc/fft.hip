@@ -228,10 +228,20 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
 // ---- strided pass: C adjacent columns x N elements (element stride S complex), in place ----------------------
 // tile t -> (outer index o = t / ntile_c, column tile ct = t % ntile_c); first element at o*outer_stride + ct*C.
 // Persistent workgroups with the next tile prefetched into registers, as above.
-template <int N, int C, bool F1 = true>
+// PACK (y pass of an x-slab in the fused form, outer index o = 2 x + yhalf): the transformed rows are not written back in
+// place but straight into the send buffer of the pencil transpose, send[p][x][yl][k] with y-row yr = yhalf N + f,
+// p = yr / nyl, yl = yr % nyl - the separate pack pass (one read + one write of the slab) disappears
+struct ColsPack {
+    float2 *out;
+    int lg_nyl, x0;
+    int64_t peer_stride, x_stride;     // nxl * nyl * pitch_c, nyl * pitch_c (complex elements)
+};
+
+template <int N, int C, bool F1 = true, bool PACK = false>
 __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ data, int64_t S, int ntile_c,
                                                         int64_t ntiles, int64_t outer_stride, int64_t outer_mod,
-                                                        int64_t outer_stride2, const float2 *__restrict__ twN, int dbg) {
+                                                        int64_t outer_stride2, const float2 *__restrict__ twN, int dbg,
+                                                        ColsPack pk) {
     constexpr int CP = colpitch_of<N>();
     constexpr int NLD = (N * (C / 2) + FFT_THREADS - 1) / FFT_THREADS;
     constexpr bool WHOLE = (N * (C / 2)) % FFT_THREADS == 0;
@@ -297,7 +307,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
     const int dg = (int)(qstep / (unsigned int)ntile_c), dc = (int)(qstep % (unsigned int)ntile_c);
     int og = (int)(q0 / (unsigned int)ntile_c), ct = (int)(q0 % (unsigned int)ntile_c);   // the q-th tile of the group
     if (og >= n_og) return;
-    float2 *gcur = tile_ptr(og * ostep + grp, ct);
+    int o_cur = og * ostep + grp, ct_cur = ct;
+    float2 *gcur = tile_ptr(o_cur, ct);
     prefetch(gcur);
     __syncthreads();     // the twiddle table, which a fused first pass reads while staging
     wait_vmcnt<0>();
@@ -307,7 +318,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
         og += dg, ct += dc;
         if (ct >= ntile_c) ct -= ntile_c, og++;
         const bool has_next = og < n_og;
-        float2 *gnext = has_next ? tile_ptr(og * ostep + grp, ct) : gcur;
+        const int o_next = og * ostep + grp, ct_next = ct;
+        float2 *gnext = has_next ? tile_ptr(o_next, ct) : gcur;
         if (has_next) prefetch(gnext);
         if (!(dbg & 1)) {
             if constexpr (wave_local(N)) {
@@ -328,7 +340,13 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
                 if (WHOLE || f < N) {
                     const int p = padq(wave_local(N) ? f : revpos<N>(f));
                     const float2 a = lds[c2 * CP + p], b = lds[(c2 + 1) * CP + p];
-                    *reinterpret_cast<float4 *>(g + (int64_t)f * S + c2) = make_float4(a.x, a.y, b.x, b.y);
+                    float2 *dst = g + (int64_t)f * S + c2;
+                    if constexpr (PACK) {
+                        const int yr = (o_cur & 1) * N + f;
+                        dst = pk.out + (int64_t)(yr >> pk.lg_nyl) * pk.peer_stride + (int64_t)(pk.x0 + (o_cur >> 1)) * pk.x_stride +
+                              (int64_t)(yr & ((1 << pk.lg_nyl) - 1)) * S + ct_cur * C + c2;
+                    }
+                    *reinterpret_cast<float4 *>(dst) = make_float4(a.x, a.y, b.x, b.y);
                 }
             }
         }
@@ -338,7 +356,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
         if (dbg & 2) wait_vmcnt<0>();
         else wait_vmcnt<(NLD < 60 ? NLD : 0)>();
         stage();
-        gcur = gnext;
+        gcur = gnext, o_cur = o_next, ct_cur = ct_next;
     }
 }
 
@@ -408,18 +426,18 @@ int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
     return launch_z1<N, B, FUSE, 0>(mesh, nrows, pitch_r, t);
 }
 
-template <int N, int C, bool F1>
+template <int N, int C, bool F1, bool PACK = false>
 int launch_cols1(const char *name, float2 *data, int64_t S, int ntile_c, int64_t outer, int64_t outer_stride, const float2 *tw,
-                 int64_t outer_mod, int64_t outer_stride2) {
+                 int64_t outer_mod, int64_t outer_stride2, ColsPack pk = ColsPack()) {
     const size_t lds = (size_t)(N + C * colpitch_of<N>()) * sizeof(float2);
-    auto kern = fft_cols<N, C, F1>;
+    auto kern = fft_cols<N, C, F1, PACK>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t ntiles = outer * ntile_c;
     int per_cu = 1;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, FFT_THREADS, lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
     ABACUS_LAUNCH(name, kern, dim3(grid), dim3(FFT_THREADS), lds, data, S, ntile_c, ntiles, outer_stride, outer_mod,
-                  outer_stride2, tw, option("dbg_fft"));
+                  outer_stride2, tw, option("dbg_fft"), pk);
     return 0;
 }
 template <int N, int C>
@@ -525,15 +543,30 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x) {
 // rank), y pass as two n/2-point transforms per plane with C columns; the first radix-2 stage of x is applied by the
 // unpack step behind the pencil transpose (power.hip slab_unpack_bfly), the x pass is then fft_native_fused_x_slab or the
 // fused last pass + binning (xbin.hip).  Row orders as in the single-GPU fused form.
+// pack_out != nullptr: the y pass writes the send buffer of the pencil transpose (ColsPack); the planes given are planes
+// [x0, x0 + nx_local) of a slab of nxl_total planes decomposed over `world` ranks
 template <int N, int C>
-int fft3d_fused_zy_slab(float *mesh, int pitch_r, Tables *t, Tables *th, int64_t nx_local) {
+int fft3d_fused_zy_slab(float *mesh, int pitch_r, Tables *t, Tables *th, int64_t nx_local, float *pack_out = nullptr,
+                        int world = 1, int nxl_total = 0, int x0 = 0) {
     constexpr int H = N / 2;
     const int pitch_c = pitch_r / 2, ntile_c = (N / 2 + 1 + C - 1) / C;
     if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
     if (nx_local % 2) return fail("fft: the fused slab transform needs an even number of planes (got %lld)", (long long)nx_local);
     ABACUS_TRY((launch_z<N / 2, 4, 2>(mesh, nx_local * N, pitch_r, t)));
-    return launch_cols<H, C>("fft_cols_y", reinterpret_cast<float2 *>(mesh), pitch_c, ntile_c, 2 * nx_local, (int64_t)H * pitch_c,
-                             th->twN.as<float2>());
+    if (!pack_out)
+        return launch_cols<H, C>("fft_cols_y", reinterpret_cast<float2 *>(mesh), pitch_c, ntile_c, 2 * nx_local, (int64_t)H * pitch_c,
+                                 th->twN.as<float2>());
+    const int nyl = N / world;
+    ColsPack pk;
+    pk.out = reinterpret_cast<float2 *>(pack_out);
+    pk.lg_nyl = 0;
+    while ((1 << pk.lg_nyl) < nyl) pk.lg_nyl++;
+    if ((1 << pk.lg_nyl) != nyl || nyl > H) return fail("fft: packed y pass needs a power-of-two number of ranks >= 2 or one rank (nyl %d)", nyl);
+    pk.x0 = x0;
+    pk.x_stride = (int64_t)nyl * pitch_c;
+    pk.peer_stride = (int64_t)nxl_total * nyl * pitch_c;
+    return launch_cols1<H, C, false, true>("fft_cols_y", reinterpret_cast<float2 *>(mesh), pitch_c, ntile_c, 2 * nx_local,
+                                            (int64_t)H * pitch_c, th->twN.as<float2>(), (int64_t)1 << 40, 0, pk);
 }
 template <int N, int C>
 int fft3d_fused_x_slab(float *mesh, int pitch_r, Tables *th, int64_t ny_local) {
@@ -543,14 +576,15 @@ int fft3d_fused_x_slab(float *mesh, int pitch_r, Tables *th, int64_t ny_local) {
     return launch_cols<H, C>("fft_cols_x", reinterpret_cast<float2 *>(mesh), pitch_c, ntile_c, 2 * ny_local, (int64_t)H * pitch_c,
                              th->twN.as<float2>());
 }
-int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int64_t nx_local) {
+int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int64_t nx_local, float *pack_out, int world, int nxl_total,
+                             int x0) {
     Tables *t, *th;
     ABACUS_TRY(get_tables(n, &t));
     ABACUS_TRY(get_tables(n / 2, &th));
     switch (n) {
-        case 256: return fft3d_fused_zy_slab<256, 16>(mesh, pitch_r, t, th, nx_local);
-        case 1024: return fft3d_fused_zy_slab<1024, 16>(mesh, pitch_r, t, th, nx_local);
-        case 2048: return fft3d_fused_zy_slab<2048, 16>(mesh, pitch_r, t, th, nx_local);
+        case 256: return fft3d_fused_zy_slab<256, 16>(mesh, pitch_r, t, th, nx_local, pack_out, world, nxl_total, x0);
+        case 1024: return fft3d_fused_zy_slab<1024, 16>(mesh, pitch_r, t, th, nx_local, pack_out, world, nxl_total, x0);
+        case 2048: return fft3d_fused_zy_slab<2048, 16>(mesh, pitch_r, t, th, nx_local, pack_out, world, nxl_total, x0);
     }
     return fail("fft: the fused transform supports n = 1024 and 2048");
 }

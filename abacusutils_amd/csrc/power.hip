@@ -54,9 +54,10 @@ int fft_native_r2c_fused(float *mesh, int n, int pitch_r);   // rows come out in
 int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r);
 bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
-                  int y0 = 0, int ny_local = 0, int put_geom = 1);
+                  int y0 = 0, int ny_local = 0, int put_geom = 1, int layout = 0);
 bool xbin2_supported(int n, const BinArgs &b, bool comp);
-int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int64_t nx_local);
+int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int64_t nx_local, float *pack_out = nullptr, int world = 1,
+                             int nxl_total = 0, int x0 = 0);
 int fft_native_fused_x_slab(float *mesh, int n, int pitch_r, int64_t ny_local);
 double xbin_last_build_ms();
 int xbin_last_gen();
@@ -1217,6 +1218,23 @@ int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local) {
     return fft_native_zy(mesh, nmesh, pitch_r(nmesh), nx_local);
 }
 
+// z and y passes of planes [x_begin, x_begin + x_count) of the slab at `mesh` (plane 0 = first owned plane) with the y pass
+// writing the send buffer of the pencil transpose directly (fused form only): replaces abacus_slab_fft_zy_dev +
+// abacus_slab_pack_dev of that chunk.  Returns 1 when this mesh / rank count is not served that way (call the two).
+int abacus_slab_fft_zy_pack_dev(float *mesh, void *send, int nmesh, int nx_local, int world, int x_begin, int x_count) {
+    ABACUS_ENTER();
+    if (!slab_fused(nmesh) || option("slab_nopackfuse")) return 1;
+    if (world < 1 || nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
+    const int nyl = nmesh / world;
+    if ((nyl & (nyl - 1)) || nyl > nmesh / 2) {
+        if (world != 1) return 1;
+    }
+    if (world == 1) return 1;    // one rank: the transpose is the identity in this layout, no send buffer is needed at all
+    if (x_begin < 0 || x_count < 1 || x_begin + x_count > nx_local) return fail("abacus_slab_fft_zy_pack_dev: planes [%d, +%d) of %d", x_begin, x_count, nx_local);
+    return fft_native_fused_zy_slab(mesh + (size_t)x_begin * nmesh * pitch_r(nmesh), nmesh, pitch_r(nmesh), x_count, (float *)send,
+                                    world, nx_local, x_begin);
+}
+
 int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world, int x_begin, int x_count) {
     ABACUS_ENTER();
     if (nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
@@ -1276,9 +1294,10 @@ int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void
 // rank passes 1 (the mesh-wide N_mode and sum |k| come from the cached geometry, not from the y-slab).
 int abacus_slab_xbin_dev(const void *mesh, int nmesh, int y0, int ny_local, double Lbox, const float *W_host,
                          const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
-                         int put_geom, void *raw_out) {
+                         int put_geom, int from_transpose, void *raw_out) {
     ABACUS_ENTER();
     if (!slab_fused(nmesh) || option("pk_noxbin") || (nmesh != 1024 && nmesh != 2048)) return 1;
+    if (from_transpose && option("slab_nounpackfuse")) return 1;
     const float *W_dev;
     ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
     BinArgs b;
@@ -1287,7 +1306,7 @@ int abacus_slab_xbin_dev(const void *mesh, int nmesh, int y0, int ny_local, doub
     if (!xbin2_supported(nmesh, b, W_dev != nullptr)) return 1;
     const double M = (double)nmesh * nmesh * nmesh;
     ABACUS_TRY(fft_x_bin_run((const float *)mesh, nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, y0, ny_local,
-                             put_geom ? 1 : 0));
+                             put_geom ? 1 : 0, from_transpose ? 2 : 1));
     HIP_TRY(hipMemcpyAsync(raw_out, g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;

@@ -403,11 +403,15 @@ __global__ __launch_bounds__(256) void xbin_geometry(int n, int Nk, int Nmu, con
 // bin in registers and adds them to the LDS histogram when the bin changes (fine bins: every step or two; coarse bins:
 // once per column); !RUNS: one LDS atomic per pair and accumulator.  LDS histogram rows eb = 0 and Nk + 1 take what
 // lies outside the edges and are never read.
-template <int H, int C, int NP, bool COMP, int MU, bool RUNS>
+// BFLY (y-slab of the multi-GPU transform, read straight from the receive buffer of the pencil transpose, layout (x, y_local,
+// k)): the first radix-2 DIF stage of the x transform - a(x) + a(x + n/2) and (a(x) - a(x + n/2)) exp(-2 pi i x / n) - is
+// applied while staging: a thread loads both rows of each of its eight pairs, the sums are transformed and binned as the
+// half of even frequencies, then the differences as the odd half.  No unpack pass, no second copy of the slab.
+template <int H, int C, int NP, bool COMP, int MU, bool RUNS, bool BFLY = false>
 __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restrict__ data, XBinGeom g, BinArgs b, XDesc d,
-                                                          const float2 *__restrict__ twH) {
+                                                          const float2 *__restrict__ twH, const float2 *__restrict__ twN) {
     constexpr int CP = colpitch_of<H>();
-    constexpr int NLD = (H * (C / 2)) / XB_THREADS;
+    constexpr int NLD = (H * (C / 2)) / XB_THREADS * (BFLY ? 2 : 1);
     static_assert((H * (C / 2)) % XB_THREADS == 0 && wave_local(H), "tile shape");
     constexpr int RUN = (H / 2) / 64;                     // values of |i| per lane (8, 4): a run shares its pad term
     static_assert(RUN == 8 || RUN == 4, "run length");
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     const int n = g.n;
     const int ntile_c = (g.kzlen + C - 1) / C;
     const int64_t S = g.xs;
-    const int n_outer = 2 * g.ny;
+    const int n_outer = (BFLY ? 1 : 2) * g.ny;
     const float inv2 = g.inv_size * g.inv_size;
     const int sh = d.sh;
     const unsigned int *lut0 = lut - d.off;
@@ -452,23 +456,46 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     };
     auto prefetch = [&](const float2 *p) {
 #pragma unroll
-        for (int q = 0; q < NLD; q++) {
+        for (int q = 0; q < 8; q++) {
             const int e = q * XB_THREADS + tid;
             const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
             gload16_async(regs[q], p + (int64_t)y * S + c2);
+            if constexpr (BFLY) gload16_async(regs[8 + q], p + (int64_t)(y + H) * S + c2);
         }
     };
     // registers -> LDS THROUGH the first radix-8 pass: load q of a thread is row tid / (C/2) + q * H/8 of its column pair,
     // i.e. the eight loads are the inputs r = 0..7 of butterfly j = tid / (C/2) of the first DIF pass (sub-length H):
     // the staged tile is never written raw and read back (one LDS round trip of the tile less)
-    static_assert(NLD == 8 && H / 8 == XB_THREADS / (C / 2), "the loads of a thread form one radix-8 butterfly per column");
-    auto stage = [&]() {
-#pragma unroll
-        for (int q = 0; q < NLD; q++) touch(regs[q]);
+    static_assert((H * (C / 2)) / XB_THREADS == 8 && H / 8 == XB_THREADS / (C / 2), "the loads of a thread form one radix-8 butterfly per column");
+    // half: BFLY only - 0 stages the sums of the row pairs and leaves the twiddled differences in regs[0..8) (the upper
+    // eight registers are free from then on: 32 values stay live across the first half's work, not 64), 1 stages those.
+    // The eight twiddles exp(-2 pi i x / n) of the thread's rows x = j + q H/8 are re-read per tile (a 16-KB table that
+    // lives in the L1; no prefetch is outstanding at this point, so the ordinary loads wait for nothing else)
+    auto stage = [&](int half = 0) {
         const int c2 = (tid % (C / 2)) * 2, jb = tid / (C / 2);
         float2 u[8], w[8];
+        if constexpr (!BFLY) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) u[q] = make_float2(regs[q].x, regs[q].y), w[q] = make_float2(regs[q].z, regs[q].w);
+            for (int q = 0; q < NLD; q++) touch(regs[q]);
+#pragma unroll
+            for (int q = 0; q < 8; q++) u[q] = make_float2(regs[q].x, regs[q].y), w[q] = make_float2(regs[q].z, regs[q].w);
+        } else if (half == 0) {
+#pragma unroll
+            for (int q = 0; q < NLD; q++) touch(regs[q]);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float2 tx = twN[jb + q * (H / 8)];
+                const v4f a = regs[q], bb = regs[8 + q];
+                u[q] = make_float2(a.x + bb.x, a.y + bb.y), w[q] = make_float2(a.z + bb.z, a.w + bb.w);
+                const float2 d0 = cmul(make_float2(a.x - bb.x, a.y - bb.y), tx), d1 = cmul(make_float2(a.z - bb.z, a.w - bb.w), tx);
+                v4f dd;
+                dd.x = d0.x, dd.y = d0.y, dd.z = d1.x, dd.w = d1.y;
+                regs[q] = dd;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) u[q] = make_float2(regs[q].x, regs[q].y), w[q] = make_float2(regs[q].z, regs[q].w);
+        }
         dft<8>(u);
         dft<8>(w);
 #pragma unroll
@@ -491,127 +518,157 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     // lane-only LDS offsets of the RUN pairs (a = RUN lane + s and its mirror)
     const int a0 = lane * RUN;
     const int offA = padq(a0);
-    __syncthreads();
-    if (og < n_og) {
-        prefetch(tile_ptr(og * ostep + grp, ct));
-        wait_vmcnt<0>();
-        stage();
-        for (;;) {
-            __syncthreads();
-            const int o_cur = og * ostep + grp, ct_cur = ct;
-            og += dg, ct += dc;
-            if (ct >= ntile_c) ct -= ntile_c, og++;
-            const bool has_next = og < n_og;
-            if (has_next) prefetch(tile_ptr(og * ostep + grp, ct));
-            const int xh = o_cur >= g.ny ? 1 : 0, yr = g.y0 + o_cur - xh * g.ny;
-            const int j = ((yr & (H - 1)) << 1) | (yr >= H ? 1 : 0);
-            const int jj = j < n / 2 ? j : j - n;
-            // mirrors: xh = 1: H-1-a; xh = 0: H-a (a >= 1), a = 0 is its own mirror (i = 0, one mode)
-            const int offB = xh ? padq(H - 1 - a0) : padq(H - 1 - a0) + 1;      // minus s (xh = 0: s >= 1)
-            const int offB0 = xh ? offB : padq((H - a0) & (H - 1));
-            const float mB0 = (!xh && lane == 0) ? 0.f : 1.f;
+    // transform (the passes behind the staged one) and bin the C columns of the staged tile: half xh of x, y-row yr, column tile
+    auto process = [&](const int xh, const int yr, const int ct_cur) {
+        const int j = ((yr & (H - 1)) << 1) | (yr >= H ? 1 : 0);
+        const int jj = j < n / 2 ? j : j - n;
+        // mirrors: xh = 1: H-1-a; xh = 0: H-a (a >= 1), a = 0 is its own mirror (i = 0, one mode)
+        const int offB = xh ? padq(H - 1 - a0) : padq(H - 1 - a0) + 1;      // minus s (xh = 0: s >= 1)
+        const int offB0 = xh ? offB : padq((H - a0) & (H - 1));
+        const float mB0 = (!xh && lane == 0) ? 0.f : 1.f;
 #pragma unroll 1
-            for (int c = wave; c < C; c += XB_THREADS / 64) {
-                float2 *col = lds + c * CP;
-                if (!(g.dbg & 1)) {
-                    dif_pass_w_regtw<H, H / 8, 8>(col, tw2, lane);          // the passes behind the one stage() performed
-                    PassesW<H, H / 64>::run(col, nullptr, lane);            // last pass: no twiddles
-                    wave_sync();
-                }
-                const int k = ct_cur * C + c;
-                if (k >= g.kzlen || (g.dbg & 2)) continue;
-                const int r2 = jj * jj + k * k;
-                if (r2 > d.vtop) continue;                     // the whole column lies beyond the last edge
-                int Uk[MU > 1 ? MU - 1 : 1];
-#pragma unroll
-                for (int m = 0; m < MU - 1; m++) Uk[m] = Ul[k * (MU - 1) + m];
-                const float k2f = (float)(k * k);
-                const float scale = (k == 0 ? 1.f : 2.f) * inv2;   // weight (:258-262) times f32(1/M)^2 (:1058-1060)
-                float wjk = 1.f;
-                if (COMP) wjk = Wl[j] * Wl[k];
-                float2 vA[RUN], vB[RUN];
-                if (g.dbg & 8) {
-#pragma unroll
-                    for (int s = 0; s < RUN; s++) vA[s] = vB[s] = make_float2(1.f, (float)(a0 + s));
-                } else {
-#pragma unroll
-                    for (int s = 0; s < RUN; s++) vA[s] = col[offA + s];
-                    vB[0] = col[offB0];
-#pragma unroll
-                    for (int s = 1; s < RUN; s++) vB[s] = col[offB - s];
-                }
-                const int i0 = 2 * a0 + xh;
-                int v = r2 + i0 * i0, inc = 4 * i0 + 4;
-                int cur = 0, curk = 0;
-                float sp = 0.f, s2 = 0.f, s4 = 0.f;
-                auto flush = [&]() {
-                    if (!(g.dbg & 4)) {
-                        atomicAdd(&h_sum[cur], (double)sp);
-                        if (NP > 0) {
-                            atomicAdd(&h_m2[curk], (double)s2);
-                            atomicAdd(&h_m4[curk], (double)s4);
-                        }
-                    }
-                };
-                auto bin = [&](int vv, float p, bool first) {
-                    const float vf1 = fmaxf((float)vv, 1.f);            // kmag2 = 0: the cell of 1, mu2 = 0 (:243)
-                    const int eb = xd_eb(lut0, sh, vv, vf1);
-                    int bmu = 0;
-#pragma unroll
-                    for (int m = 0; m < MU - 1; m++) bmu += vv <= Uk[m] ? 1 : 0;
-                    const int tb = (int)__umul24(eb, Nmu) + bmu;
-                    const float pw = p * scale;
-                    float t2 = 0.f, t4 = 0.f;
-                    if (NP > 0) {
-                        const float mu2 = k2f * __builtin_amdgcn_rcpf(vf1);
-                        t2 = pw * mu2;
-                        t4 = t2 * mu2;
-                    }
-                    if (RUNS) {
-                        if (first) {
-                            cur = tb, curk = eb;
-                        } else if (tb != cur) {
-                            flush();
-                            cur = tb, curk = eb;
-                            sp = s2 = s4 = 0.f;
-                        }
-                        sp += pw, s2 += t2, s4 += t4;
-                    } else if ((unsigned int)(eb - 1) < (unsigned int)Nk && !(g.dbg & 4)) {
-                        atomicAdd(&h_sum[tb], (double)pw);
-                        if (NP > 0) {
-                            atomicAdd(&h_m2[eb], (double)t2);
-                            atomicAdd(&h_m4[eb], (double)t4);
-                        }
-                    }
-                };
-#pragma unroll
-                for (int s = 0; s < RUN; s++) {
-                    float pA = vA[s].x * vA[s].x + vA[s].y * vA[s].y;      // get_raw_power (:726)
-                    float pB = vB[s].x * vB[s].x + vB[s].y * vB[s].y;
-                    if (COMP) {                                            // (:1065-1069)
-                        const int fA = a0 + s, fB = xh ? H - 1 - fA : (H - fA) & (H - 1);
-                        const float sA = __builtin_amdgcn_rcpf(Wl[2 * fA + xh] * wjk), sB = __builtin_amdgcn_rcpf(Wl[2 * fB + xh] * wjk);
-                        pA *= sA * sA, pB *= sB * sB;
-                    }
-                    if (s == 0) pB *= mB0;
-                    bin(v, pA + pB, s == 0);
-                    v += inc, inc += 8;
-                }
-                if (!xh && lane == 63) {       // i = n/2 (a = H/2): one mode, last lane of the even half
-                    const float2 q = (g.dbg & 8) ? make_float2(1.f, 1.f) : col[padq(H / 2)];
-                    float p = q.x * q.x + q.y * q.y;
-                    if (COMP) {
-                        const float sc = __builtin_amdgcn_rcpf(Wl[H] * wjk);
-                        p *= sc * sc;
-                    }
-                    bin(r2 + H * H, p, false);
-                }
-                if (RUNS && (unsigned int)(curk - 1) < (unsigned int)Nk) flush();
+        for (int c = wave; c < C; c += XB_THREADS / 64) {
+            float2 *col = lds + c * CP;
+            if (!(g.dbg & 1)) {
+                dif_pass_w_regtw<H, H / 8, 8>(col, tw2, lane);          // the passes behind the one stage() performed
+                PassesW<H, H / 64>::run(col, nullptr, lane);            // last pass: no twiddles
+                wave_sync();
             }
-            if (!has_next) break;
-            __syncthreads();
+            const int k = ct_cur * C + c;
+            if (k >= g.kzlen || (g.dbg & 2)) continue;
+            const int r2 = jj * jj + k * k;
+            if (r2 > d.vtop) continue;                     // the whole column lies beyond the last edge
+            int Uk[MU > 1 ? MU - 1 : 1];
+#pragma unroll
+            for (int m = 0; m < MU - 1; m++) Uk[m] = Ul[k * (MU - 1) + m];
+            const float k2f = (float)(k * k);
+            const float scale = (k == 0 ? 1.f : 2.f) * inv2;   // weight (:258-262) times f32(1/M)^2 (:1058-1060)
+            float wjk = 1.f;
+            if (COMP) wjk = Wl[j] * Wl[k];
+            float2 vA[RUN], vB[RUN];
+            if (g.dbg & 8) {
+#pragma unroll
+                for (int s = 0; s < RUN; s++) vA[s] = vB[s] = make_float2(1.f, (float)(a0 + s));
+            } else {
+#pragma unroll
+                for (int s = 0; s < RUN; s++) vA[s] = col[offA + s];
+                vB[0] = col[offB0];
+#pragma unroll
+                for (int s = 1; s < RUN; s++) vB[s] = col[offB - s];
+            }
+            const int i0 = 2 * a0 + xh;
+            int v = r2 + i0 * i0, inc = 4 * i0 + 4;
+            int cur = 0, curk = 0;
+            float sp = 0.f, s2 = 0.f, s4 = 0.f;
+            auto flush = [&]() {
+                if (!(g.dbg & 4)) {
+                    atomicAdd(&h_sum[cur], (double)sp);
+                    if (NP > 0) {
+                        atomicAdd(&h_m2[curk], (double)s2);
+                        atomicAdd(&h_m4[curk], (double)s4);
+                    }
+                }
+            };
+            auto bin = [&](int vv, float p, bool first) {
+                const float vf1 = fmaxf((float)vv, 1.f);            // kmag2 = 0: the cell of 1, mu2 = 0 (:243)
+                const int eb = xd_eb(lut0, sh, vv, vf1);
+                int bmu = 0;
+#pragma unroll
+                for (int m = 0; m < MU - 1; m++) bmu += vv <= Uk[m] ? 1 : 0;
+                const int tb = (int)__umul24(eb, Nmu) + bmu;
+                const float pw = p * scale;
+                float t2 = 0.f, t4 = 0.f;
+                if (NP > 0) {
+                    const float mu2 = k2f * __builtin_amdgcn_rcpf(vf1);
+                    t2 = pw * mu2;
+                    t4 = t2 * mu2;
+                }
+                if (RUNS) {
+                    if (first) {
+                        cur = tb, curk = eb;
+                    } else if (tb != cur) {
+                        flush();
+                        cur = tb, curk = eb;
+                        sp = s2 = s4 = 0.f;
+                    }
+                    sp += pw, s2 += t2, s4 += t4;
+                } else if ((unsigned int)(eb - 1) < (unsigned int)Nk && !(g.dbg & 4)) {
+                    atomicAdd(&h_sum[tb], (double)pw);
+                    if (NP > 0) {
+                        atomicAdd(&h_m2[eb], (double)t2);
+                        atomicAdd(&h_m4[eb], (double)t4);
+                    }
+                }
+            };
+#pragma unroll
+            for (int s = 0; s < RUN; s++) {
+                float pA = vA[s].x * vA[s].x + vA[s].y * vA[s].y;      // get_raw_power (:726)
+                float pB = vB[s].x * vB[s].x + vB[s].y * vB[s].y;
+                if (COMP) {                                            // (:1065-1069)
+                    const int fA = a0 + s, fB = xh ? H - 1 - fA : (H - fA) & (H - 1);
+                    const float sA = __builtin_amdgcn_rcpf(Wl[2 * fA + xh] * wjk), sB = __builtin_amdgcn_rcpf(Wl[2 * fB + xh] * wjk);
+                    pA *= sA * sA, pB *= sB * sB;
+                }
+                if (s == 0) pB *= mB0;
+                bin(v, pA + pB, s == 0);
+                v += inc, inc += 8;
+            }
+            if (!xh && lane == 63) {       // i = n/2 (a = H/2): one mode, last lane of the even half
+                const float2 q = (g.dbg & 8) ? make_float2(1.f, 1.f) : col[padq(H / 2)];
+                float p = q.x * q.x + q.y * q.y;
+                if (COMP) {
+                    const float sc = __builtin_amdgcn_rcpf(Wl[H] * wjk);
+                    p *= sc * sc;
+                }
+                bin(r2 + H * H, p, false);
+            }
+            if (RUNS && (unsigned int)(curk - 1) < (unsigned int)Nk) flush();
+        }
+    };
+    __syncthreads();
+    if constexpr (!BFLY) {
+        if (og < n_og) {
+            prefetch(tile_ptr(og * ostep + grp, ct));
             wait_vmcnt<0>();
             stage();
+            for (;;) {
+                __syncthreads();
+                const int o_cur = og * ostep + grp, ct_cur = ct;
+                og += dg, ct += dc;
+                if (ct >= ntile_c) ct -= ntile_c, og++;
+                const bool has_next = og < n_og;
+                if (has_next) prefetch(tile_ptr(og * ostep + grp, ct));
+                const int xh = o_cur >= g.ny ? 1 : 0;
+                process(xh, g.y0 + o_cur - xh * g.ny, ct_cur);
+                if (!has_next) break;
+                __syncthreads();     // every wave is done with the tile
+                wait_vmcnt<0>();     // no stores in this kernel: the prefetch is all that is outstanding
+                stage();
+            }
+        }
+    } else {
+        // one (y-row, column tile) per trip, both halves of x from one set of loads: sums, then differences.  The loads of
+        // the next trip are issued once the differences have left the registers and fly during the second half's work
+        if (og < n_og) {
+            prefetch(data + (int64_t)(og * ostep + grp) * g.ys + ct * C);
+            wait_vmcnt<0>();
+            for (;;) {
+                const int o_cur = og * ostep + grp, ct_cur = ct;
+                stage(0);
+                __syncthreads();
+                process(0, g.y0 + o_cur, ct_cur);
+                __syncthreads();
+                stage(1);
+                og += dg, ct += dc;
+                if (ct >= ntile_c) ct -= ntile_c, og++;
+                const bool has_next = og < n_og;
+                if (has_next) prefetch(data + (int64_t)(og * ostep + grp) * g.ys + ct * C);
+                __syncthreads();
+                process(1, g.y0 + o_cur, ct_cur);
+                if (!has_next) break;
+                __syncthreads();
+                wait_vmcnt<0>();
+            }
         }
     }
     __syncthreads();
@@ -803,25 +860,25 @@ int xdesc_get(int n, int Nk, int Nmu, const float *h_e2, const float *d_ke, cons
     return 0;
 }
 
-template <int H, int C, int NP, bool COMP, int MU>
+template <int H, int C, int NP, bool COMP, int MU, bool BFLY = false>
 int launch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const XDesc &d, size_t lds) {
-    const bool runs = option("pk_xbin_pairs") == 0;
-    auto kern = runs ? fft_x_bin2<H, C, NP, COMP, MU, true> : fft_x_bin2<H, C, NP, COMP, MU, false>;
+    const bool runs = BFLY || option("pk_xbin_pairs") == 0;
+    auto kern = runs ? fft_x_bin2<H, C, NP, COMP, MU, true, BFLY> : fft_x_bin2<H, C, NP, COMP, MU, false, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, XB_THREADS, lds));
-    const int64_t ntiles = (int64_t)2 * g.ny * ((g.kzlen + C - 1) / C);
+    const int64_t ntiles = (int64_t)(BFLY ? 1 : 2) * g.ny * ((g.kzlen + C - 1) / C);
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)fft_num_cus() * std::max(per_cu, 1));
-    const float2 *tw = fft_twiddles(H);
-    if (!tw) return -1;
-    ABACUS_LAUNCH("fft_x_bin", kern, dim3(grid), dim3(XB_THREADS), lds, data, g, b, d, tw);
+    const float2 *tw = fft_twiddles(H), *twn = fft_twiddles(2 * H);
+    if (!tw || !twn) return -1;
+    ABACUS_LAUNCH("fft_x_bin", kern, dim3(grid), dim3(XB_THREADS), lds, data, g, b, d, tw, twn);
     return 0;
 }
 
-template <int H, int C>
+template <int H, int C, bool BFLY = false>
 int dispatch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const XDesc &d, size_t lds) {
 #define XB2(NP, MU)                                                                  \
-    (g.W ? launch_xbin2<H, C, NP, true, MU>(data, g, b, d, lds) : launch_xbin2<H, C, NP, false, MU>(data, g, b, d, lds))
+    (g.W ? launch_xbin2<H, C, NP, true, MU, BFLY>(data, g, b, d, lds) : launch_xbin2<H, C, NP, false, MU, BFLY>(data, g, b, d, lds))
 #define XB2_MU(NP) (b.Nmu <= 1 ? XB2(NP, 1) : b.Nmu <= 4 ? XB2(NP, 4) : XB2(NP, 8))
     switch (b.Np) {
         case 0: return XB2_MU(0);
@@ -898,13 +955,17 @@ int xbin_release() {
 // radix-2 stage of x); only the cached-geometry kernel serves it, and `put_geom` says whether this rank contributes the
 // mesh-wide N_mode / sum |k| to the histogram that is all-reduced afterwards.
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
-                  int y0, int ny_local, int put_geom) {
+                  int y0, int ny_local, int put_geom, int layout) {
     XBinGeom g;
     g.n = n, g.kzlen = n / 2 + 1, g.pitch_c = pitch_r / 2, g.inv_size = inv_size, g.W = W_dev, g.dbg = dbg;
-    const bool slab = ny_local > 0;
-    g.xs = slab ? g.pitch_c : (int64_t)n * g.pitch_c;
-    g.ys = slab ? (int64_t)n * g.pitch_c : g.pitch_c;
+    // layout 0: the whole mesh (x, y, k) behind the fused z / y passes; 1: a y-slab (y_local, x, k) behind the unpack with
+    // the x butterfly; 2: a y-slab as the pencil transpose delivers it, (x, y_local, k), the x butterfly applied here (BFLY)
+    const bool slab = layout != 0;
+    if (slab && ny_local < 1) return fail("fft_x_bin: empty y-slab");
     g.ny = slab ? ny_local : n, g.y0 = slab ? y0 : 0, g.put_geom = slab ? put_geom : 1;
+    if (layout == 1) g.xs = g.pitch_c, g.ys = (int64_t)n * g.pitch_c;
+    else if (layout == 2) g.xs = (int64_t)g.ny * g.pitch_c, g.ys = g.pitch_c;
+    else g.xs = (int64_t)n * g.pitch_c, g.ys = g.pitch_c;
     const float2 *data = reinterpret_cast<const float2 *>(mesh);
     if (n != 2048 && n != 1024) return fail("fft_x_bin: unsupported mesh %d", n);
     const int C = n == 2048 ? 8 : 16;
@@ -915,6 +976,10 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
     g_last_gen = x ? 2 : 1;
     if (x) {
         const XDesc d = x->dev();
+        if (layout == 2) {
+            if (n == 2048) return dispatch_xbin2<1024, 8, true>(data, g, b, d, xbin2_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, d.ncell, comp));
+            return dispatch_xbin2<512, 16, true>(data, g, b, d, xbin2_lds_bytes<512, 16>(n, b.Nk, b.Nmu, d.ncell, comp));
+        }
         if (n == 2048) return dispatch_xbin2<1024, 8>(data, g, b, d, xbin2_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, d.ncell, comp));
         return dispatch_xbin2<512, 16>(data, g, b, d, xbin2_lds_bytes<512, 16>(n, b.Nk, b.Nmu, d.ncell, comp));
     }

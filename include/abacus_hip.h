@@ -320,13 +320,20 @@ int64_t abacus_bin_raw_bytes(int Nk, int Nmu, const int64_t *poles, int Np);
  * segments; rows of x and y then come out in the order f = 2 (r mod n/2) + (r div n/2), which abacus_slab_bin_dev and
  * abacus_slab_xbin_dev undo); needs an even number of planes per abacus_slab_fft_zy_dev call */
 int abacus_slab_fused(int nmesh);
-/* last x pass FUSED with the binning on the unpacked (y_local, x, k) block (auto power of one non-interlaced field):
- * replaces abacus_slab_fft_x_dev + abacus_slab_bin_dev.  Returns 0 (raw sums in the host buffer raw_out), 1 when this mesh /
- * histogram is not served (call the two-step form instead), < 0 on error.  put_geom = 1 on exactly one rank: N_mode and
+/* last x pass FUSED with the binning on a y-slab (auto power of one non-interlaced field): replaces abacus_slab_fft_x_dev +
+ * abacus_slab_bin_dev.  from_transpose = 0: `mesh` is the unpacked (y_local, x, k) block (abacus_slab_unpack_dev has applied
+ * the first radix-2 stage of x); from_transpose = 1: `mesh` is the RECEIVE buffer of the pencil transpose as it arrived,
+ * layout (x, y_local, k) - no unpack at all, the kernel loads rows x and x + n/2 together and applies that stage while
+ * staging (one rank: the slab itself after its z / y passes).  Returns 0 (raw sums in the host buffer raw_out), 1 when this
+ * mesh / histogram is not served (use the two-step form), < 0 on error.  put_geom = 1 on exactly one rank: N_mode and
  * sum |k| are mesh-wide quantities taken from the cached geometry of (nmesh, edges), not from the y-slab */
 int abacus_slab_xbin_dev(const void *mesh, int nmesh, int y0, int ny_local, double Lbox, const float *W_host,
                          const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
-                         int put_geom, void *raw_out);
+                         int put_geom, int from_transpose, void *raw_out);
+/* z and y passes of planes [x_begin, x_begin + x_count) of the slab at `mesh` with the y pass writing the send buffer of the
+ * pencil transpose directly (fused form, more than one rank): replaces abacus_slab_fft_zy_dev + abacus_slab_pack_dev of that
+ * chunk.  Returns 1 when not served that way (call the two) */
+int abacus_slab_fft_zy_pack_dev(float *mesh, void *send, int nmesh, int nx_local, int world, int x_begin, int x_count);
 /* particle routing on the device: stable bucket sort of (pos (n,3) float32, w or NULL) by the rank that owns the wrapped x
  * (x-slabs of width Lbox / world); counts[world] on the host.  The blocks then travel with abacus_comm_all_to_all_v. */
 int abacus_slab_route_dev(const float *pos, int64_t n, const float *w, double Lbox, int world, float *pos_out, float *w_out,
