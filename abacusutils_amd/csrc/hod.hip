@@ -1225,13 +1225,11 @@ template <int EBLOCK, int SBT>
 __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const unsigned short *__restrict__ kept_c,
                                                    const unsigned short *__restrict__ kept_s,
                                                    const int *__restrict__ sb_counts, int64_t *__restrict__ totals,
-                                                   EmitPtrs in, abacus_hod_params p, OutCols o, int dbg, int g0, int totals_block) {
-    // g0: first superblock of this launch (the centrals' and the satellites' emission may be launched separately - the
-    // centrals' while the satellites are still being decided); totals_block: the superblock that reports the totals (-1: none)
+                                                   EmitPtrs in, abacus_hod_params p, OutCols o, int dbg) {
     constexpr int SB_OBJ = SBT * TILE;
     __shared__ int64_t red[EBLOCK / 64][6];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int g = blockIdx.x + g0;
+    const int g = blockIdx.x;
     const bool sat = g >= nsb_c;
     const int S = sat ? g - nsb_c : g;
     const int *sb_c = sb_counts, *sb_s = sb_counts + (int64_t)nsb_c * 4;
@@ -1242,7 +1240,7 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
     for (int s = tid; s < S; s += EBLOCK)
 #pragma unroll
         for (int t = 0; t < 3; t++) v[t] += sb_mine[(int64_t)s * 4 + t];
-    if (sat || g == totals_block)
+    if (sat || g == 0)
         for (int s = tid; s < nsb_c; s += EBLOCK)
 #pragma unroll
             for (int t = 0; t < 3; t++) v[3 + t] += sb_c[(int64_t)s * 4 + t];
@@ -1258,7 +1256,7 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
 #pragma unroll
         for (int w = 0; w < EBLOCK / 64; w++) v[t] += red[w][t];
     }
-    if (g == totals_block) {   // totals for the host: Ncent[3], Nsat[3]
+    if (g == 0) {   // totals for the host: Ncent[3], Nsat[3]
         int64_t s3[3] = {0, 0, 0};
         for (int s = tid; s < nsb_s; s += EBLOCK)
 #pragma unroll
@@ -1802,8 +1800,6 @@ struct abacus_hod_state {
     int kept_sb_tiles = 0;
     int64_t *d_totals = nullptr;  // 6
     int64_t *h_totals = nullptr;  // pinned, 6
-    hipStream_t side = nullptr;   // emission of the centrals runs here while the satellites are decided on the library stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // outputs
     DevBuf out[3];
     int64_t cap[3] = {0, 0, 0};
@@ -2107,9 +2103,7 @@ void set_superblocks(abacus_hod_state *st, const abacus_hod_params *p) {
     st->nsb_s = (int)ceil_div(st->ntile_s, sbt);
 }
 
-// part 0: every superblock in one launch on the library stream; 1: the centrals' superblocks on `on` (no totals); 2: the
-// satellites' superblocks (and the totals) on the library stream
-int launch_emit(abacus_hod_state *st, int part = 0, hipStream_t on = nullptr) {
+int launch_emit(abacus_hod_state *st) {
     const int nemit = st->nsb_c + st->nsb_s;
     if (nemit == 0) {
         HIP_TRY(hipMemsetAsync(st->d_totals, 0, 6 * sizeof(int64_t), stream()));
@@ -2125,27 +2119,15 @@ int launch_emit(abacus_hod_state *st, int part = 0, hipStream_t on = nullptr) {
     // 115 us at LRG + ELG + QSO on 1e7 + 1e7), 256 for LRG alone (12 vs 20 us: the larger workgroups only cost launch time)
     int eb = option("hod_eblock");
     if (eb != 256 && eb != 512) eb = (st->params.want_ELG || st->params.want_QSO) ? 512 : 256;
-    const int g0 = part == 2 ? st->nsb_c : 0;
-    const int count = part == 0 ? nemit : (part == 1 ? st->nsb_c : st->nsb_s);
-    const int totals_block = part == 1 ? -1 : g0;
-    if (count == 0) return 0;
-#define EMIT_ARGS st->nsb_c, st->nsb_s, st->kept_c, st->kept_s, st->sb_counts, st->d_totals, in, st->params, out_cols(st), option("dbg"), g0, totals_block
-#define EMIT(EB, SBT)                                                                                     \
-    do {                                                                                                  \
-        if (part == 1) {   /* side stream: outside the per-kernel profiler of the library stream */       \
-            hod_emit<EB, SBT><<<dim3(count), dim3(EB), 0, on>>>(EMIT_ARGS);                               \
-            HIP_TRY(hipGetLastError());                                                                   \
-        } else {                                                                                          \
-            ABACUS_LAUNCH("hod_emit", (hod_emit<EB, SBT>), dim3(count), dim3(EB), 0, EMIT_ARGS);          \
-        }                                                                                                 \
-    } while (0)
+#define EMIT(EB, SBT)                                                                                                       \
+    ABACUS_LAUNCH("hod_emit", (hod_emit<EB, SBT>), dim3(nemit), dim3(EB), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s, \
+                  st->sb_counts, st->d_totals, in, st->params, out_cols(st), option("dbg"))
     const bool sparse = st->sb_tiles == SB_TILES_SPARSE;
     if (eb == 256 && sparse) EMIT(256, SB_TILES_SPARSE);
     else if (eb == 256) EMIT(256, SB_TILES_DENSE);
     else if (sparse) EMIT(512, SB_TILES_SPARSE);
     else EMIT(512, SB_TILES_DENSE);
 #undef EMIT
-#undef EMIT_ARGS
     return 0;
 }
 
@@ -2730,54 +2712,24 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     // the two-stage satellite filter bounds the conformity variants by their largest, so it does not wait for the exact
     // central decisions: one filter launch for both kinds, then the exact passes in order
     const bool filter_first = conf && use32 && cheap.s_ok;
-    // dense mixes: the centrals are emitted on a second stream while the satellites are decided (their columns depend on the
-    // central decisions alone; both launches are latency-bound gathers at a few waves per SIMD and share the machine well);
-    // the satellites' emission follows on the library stream.  `hod_nooverlap` (A/B) keeps one emission launch at the end.
-    const bool overlap = (p->want_ELG || p->want_QSO) && st->nsb_c > 0 && st->nsb_s > 0 && !option("hod_nooverlap");
-    if (overlap && !st->side) {
-        HIP_TRY(hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
-    }
-#define EMIT_CENTRALS_ASIDE                                            \
-    if (overlap) {                                                     \
-        HIP_TRY(hipEventRecord(st->ev_fork, stream()));                \
-        HIP_TRY(hipStreamWaitEvent(st->side, st->ev_fork, 0));         \
-        ABACUS_TRY(launch_emit(st, 1, st->side));                      \
-        HIP_TRY(hipEventRecord(st->ev_join, st->side));                \
-    }
     if (!conf) {
         FILTER(0, ntile)
-        if (overlap) {
-            EXACT(0, st->nsb_c);
-            EMIT_CENTRALS_ASIDE
-            EXACT(st->nsb_c, st->nsb_s);
-        } else {
-            EXACT(0, nsb);
-        }
+        EXACT(0, nsb);
     } else if (filter_first) {
         FILTER(0, ntile)
         EXACT(0, st->nsb_c);
-        EMIT_CENTRALS_ASIDE
         EXACT(st->nsb_c, st->nsb_s);
     } else {
         FILTER(0, st->ntile_c)
         EXACT(0, st->nsb_c);
-        EMIT_CENTRALS_ASIDE
         FILTER(st->ntile_c, st->ntile_s)
         EXACT(st->nsb_c, st->nsb_s);
     }
-#undef EMIT_CENTRALS_ASIDE
 #undef FILTER
 #undef EXACT
 #undef EXACT_
     // speculative emission into the current buffers (writes past capacity are suppressed on the device)
-    if (overlap) {
-        HIP_TRY(hipStreamWaitEvent(stream(), st->ev_join, 0));
-        ABACUS_TRY(launch_emit(st, 2));
-    } else {
-        ABACUS_TRY(launch_emit(st));
-    }
+    ABACUS_TRY(launch_emit(st));
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
     st->have_run = true;
     st->counts_valid = false;
@@ -2904,12 +2856,6 @@ int abacus_hod_free(abacus_hod_state *st) {
     (void)st->ngal_bins.release(), (void)st->ngal_tables.release(), (void)st->ngal_out.release();
     (void)st->nfw_counts.release(), (void)st->nfw_offsets.release(), (void)st->nfw_draw.release(), (void)st->nfw_scan.release();
     if (st->h_totals) (void)hipHostFree(st->h_totals);
-    if (st->side) {
-        (void)hipStreamSynchronize(st->side);
-        (void)hipStreamDestroy(st->side);
-        (void)hipEventDestroy(st->ev_fork);
-        (void)hipEventDestroy(st->ev_join);
-    }
     for (int t = 0; t < 3; t++) (void)st->out[t].release();
     (void)st->shadow.release();
     (void)st->keys.release();
