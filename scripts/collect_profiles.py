@@ -22,7 +22,8 @@ FETCH_FACTOR = {'fft_cols<2048, 8>': 1.0}   # 64-B row segments; every other ker
 # the fused last pass at 2048^3 (fft_x_bin<1024, 8, ...>) also reads 64-B row segments (8 complex columns): factor 1 like
 # fft_cols<2048, 8>.  Its raw FETCH_SIZE is 0.78 of the known 4M-byte read (part of the 64-B segments pair up into 128-B
 # requests tallied at 64 B): the guide calls such widths uncalibrated - the entry carries `note`.
-FETCH_PREFIX = {'fft_x_bin<1024, 8': (1.0, 'uncalibrated width (64-B row segments): raw FETCH_SIZE, known read = 4 B per mesh cell')}
+FETCH_PREFIX = {'fft_x_bin<1024, 8': (1.0, 'uncalibrated width (64-B row segments): raw FETCH_SIZE, known read = 4 B per mesh cell'),
+                'fft_x_bin2<1024, 8': (1.0, 'uncalibrated width (64-B row segments): raw FETCH_SIZE, known read = 4 B per mesh cell')}
 
 for d in ('prof_hod', 'prof_pk1024', 'prof_pk2048'):
     # gpurun MERGES its output into gpurun_out/: summaries of earlier calls are still there - take the newest
