@@ -486,3 +486,55 @@ def test_fused_last_pass_matches_spectrum_bin(options, nmesh, comp):
             np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6, err_msg=name)
             if kw['poles']:
                 np.testing.assert_allclose(a['poles'], b['poles'], rtol=2e-6, atol=2e-7 * np.abs(b['power']).max(), err_msg=name)
+
+
+def _random_edges(rng, nmesh, box):
+    """k / mu edges of every flavour the geometry descriptor has to resolve or decline: linear, logarithmic, ragged, bins far
+    narrower than a fundamental mode, first edge above zero, last edge short of / beyond Nyquist and beyond the corner"""
+    kny = np.pi * nmesh / box
+    kind = rng.integers(0, 5)
+    nk = int(rng.integers(1, 700))
+    kmax = kny * rng.choice([0.1, 0.5, 1.0, 1.0 + 1e-9, 1.3, 1.8])
+    if kind == 0:
+        ke = np.linspace(0.0, kmax, nk + 1)
+    elif kind == 1:
+        ke = np.geomspace(2 * np.pi / box * rng.choice([0.3, 0.9999, 1.7]), kmax, nk + 1)
+    elif kind == 2:
+        ke = np.sort(np.concatenate(([rng.random() * 0.02], rng.random(min(nk, 60)) * kmax)))
+    elif kind == 3:
+        ke = np.linspace(kmax * 0.2, kmax, min(nk, 40) + 1)
+    else:
+        ke = np.concatenate((np.linspace(0, 0.01 * kmax, 30), np.geomspace(0.011 * kmax, kmax, 20)))
+    nmu = int(rng.integers(1, 9))
+    nmu = max(1, min(nmu, 3800 // max(len(ke) - 1, 1)))          # the comparator (spectrum_bin) holds 20 B of LDS per bin
+    me = np.linspace(0.0, 1.0, nmu + 1) if rng.random() < 0.6 else np.sort(np.concatenate(([0.0, 1.0], rng.random(nmu - 1))))
+    poles = [[], [0], [0, 2], [0, 2, 4], [4], [2, 4]][int(rng.integers(0, 6))]
+    return ke, me, poles
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_fused_last_pass_random_edges(options, seed):
+    """the cached-geometry kernel (integer thresholds, cell table, per-kz mu thresholds, validated over every mode of the mesh
+    by xbin_geometry) against the x pass + spectrum_bin on random bin edges: N_mode exact, sums to rounding; edges the table
+    cannot resolve must fall back to the first-generation kernel and agree all the same"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    rng = np.random.default_rng(1000 + seed)
+    nmesh, box = 1024, 1000.0
+    pos = synth.synth_positions(400_000, box, seed=200 + seed, clustered=True)
+    for _ in range(3):
+        ke, me, poles = _random_edges(rng, nmesh, box)
+        comp = bool(rng.integers(0, 2))
+        kw = dict(kbins=ke, mubins=me, poles=poles, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=False)
+        a = calc_power(pos.copy(), box, **kw)
+        gen = _lib.lib().abacus_power_xbin_generation()
+        assert gen in (1, 2)
+        options.set('pk_noxbin', 1)
+        b = calc_power(pos.copy(), box, **kw)
+        options.set('pk_noxbin', 0)
+        np.testing.assert_array_equal(a['N_mode'], b['N_mode'], err_msg=f'gen {gen}')
+        scale = np.abs(np.asarray(b['power'])).max()
+        np.testing.assert_allclose(a['power'], b['power'], rtol=3e-6, atol=3e-7 * scale, err_msg=f'gen {gen}')
+        np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)
+        if poles:
+            np.testing.assert_allclose(a['poles'], b['poles'], rtol=3e-6, atol=5e-7 * scale)
