@@ -1,28 +1,33 @@
-"""Multi-GPU P(k): x-slab mesh decomposition of `calc_power` over the GPUs of one node.
+"""Multi-GPU P(k): slab decomposition of `calc_power` over the GPUs of one node.
 
 New functionality relative to the reference (its TSC "can't readily scale to multiple nodes",
 docs/tutorials/analysis/tsc.ipynb:19); the result is the same estimator as
 abacusnbody/analysis/power_spectrum.py:1131-1319 evaluated on the union of the ranks' particles.
 
-One process per GPU.  Rank r owns mesh planes [r*n/W, (r+1)*n/W) and the particles whose wrapped x lies in that
-slab (`route_particles` moves them there).  Per field:
+One process per GPU.  FOLDED SLABS: the mesh is cut into 2 W slabs of h = n / (2 W) planes and rank r owns slabs r and
+r + W, i.e. the planes [r h, (r + 1) h) and the same range + n/2, together with the particles whose wrapped x lies there
+(`route_particles(..., fold=True)` moves them).  Planes x and x + n/2 therefore sit on ONE rank, which is what the fused
+form of the transform needs (the first radix-2 stage of the x transform pairs exactly those planes, csrc/fft.hip): every
+rank runs the kernels of the single-GPU path on its pairs.  Per field:
 
-    deposit           local planes + GHOST planes on both sides (TSC cloud +-1 cell, +1 for the half-cell
+    deposit           each of the two slabs + GHOST planes on both sides (TSC cloud +-1 cell, +1 for the half-cell
                       interlacing shift, +1 for round-half-even at the upper slab edge)      [device]
-    ghost exchange    the ghost blocks go to the two ring neighbours, which add them         [send/recv, 2 x 3 planes]
-    z, y FFT passes   on the owned planes                                                    [device]
-    pencil transpose  (x_local, y, k) -> (y_local, x, k): pack, ALL-TO-ALL, unpack           [RCCL all-to-all over xGMI:
+    ghost exchange    the ghost blocks go to the ring neighbours, which add them             [send/recv, 4 x 3 planes]
+    z, y FFT passes   on the owned plane pairs (fused form: + first radix-2 stage of y and x)  [device]
+    pencil transpose  (x_local, y, k) -> (y_local, x, k): ALL-TO-ALL of send[peer][2 h][y_local][k], which the y pass wrote
+                      itself where the fused form runs                                       [RCCL all-to-all over xGMI:
                       one block per peer, every link busy at once]
-    x FFT pass        on the y-slab                                                          [device]
-    binning           raw (k, mu) / multipole sums of the y-slab                             [device]
+    x FFT pass + binning   on the y-slab, straight from the receive buffer where the fused last pass serves the histogram
+                      (no unpack, no spectrum in HBM); otherwise unpack, x pass, raw sums     [device]
     all-reduce        of the few-KB histogram, then bin_kmu's normalisation                  [RCCL all-reduce]
 
 Collectives: `abacusutils_amd.comm.RcclComm` - RCCL through the C ABI (abacus_comm_*), enqueued on the library stream
-between the kernels, no host synchronisation inside a spectrum; the pencil transpose is cut into chunks of x-planes and
+between the kernels, no host synchronisation inside a spectrum; the pencil transpose is cut into chunks of plane pairs and
 every chunk's all-to-all runs on the communicator's stream while the next chunk's z / y passes run.  A single process
-needs no transport (`abacusutils_amd.comm.LocalComm`).  The host-staged stand-in with the same methods over
-torch.distributed gloo lives with the tests (tests/gloo_comm.py: CPU container, or several ranks sharing one GPU).
-Restrictions: nmesh a power of two in [64, 2048] (hand-written FFT passes), nmesh % W == 0, nmesh/W >= GHOST.
+needs no transport (`abacusutils_amd.comm.LocalComm`): its two slabs are the whole periodic mesh.  The host-staged stand-in
+with the same methods over torch.distributed gloo lives with the tests (tests/gloo_comm.py: CPU container, or several
+ranks sharing one GPU).
+Restrictions: nmesh a power of two in [64, 2048] (hand-written FFT passes), nmesh % (2 W) == 0, nmesh / (2 W) >= GHOST.
 """
 import ctypes as C
 
@@ -91,27 +96,31 @@ class HipSlabBackend:
         dw = w if (w is None or isinstance(w, _lib.DeviceArray)) else _lib.DeviceArray(np.ascontiguousarray(w, dtype=np.float32))
         return dpos, dw
 
-    def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste, sub=0.0):
-        """planes [xoff, xoff + nx_total) (mod nmesh) as rho * norm - sub"""
+    def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste, sub=0.0, xoff2=-1):
+        """planes [xoff, xoff + nx_total) (mod nmesh) as rho * norm - sub - with xoff2 >= 0 a second window of nx_total planes
+        from xoff2 behind the first; a plane in both windows takes its deposits in the first.  Particles outside are skipped"""
         pos, w = particles
         n = pos.shape[0]
         _lib.check(_lib.lib().abacus_slab_deposit_dev(pos.ptr, C.c_int64(n), None if w is None else w.ptr, mesh.ptr(0),
-                                                      int(nmesh), int(xoff), int(nx_total), C.c_double(Lbox),
+                                                      int(nmesh), int(xoff), int(xoff2), int(nx_total), C.c_double(Lbox),
                                                       C.c_double(offset), C.c_double(norm), int(paste), C.c_double(sub)))
 
     def axpy(self, dst, dst_off, src, src_off, nfloat, add):
         _lib.check(_lib.lib().abacus_slab_axpy_dev(dst.ptr(dst_off), None if src is None else src.ptr(src_off),
                                                    C.c_int64(nfloat), C.c_float(add)))
 
-    def fft_zy(self, mesh, off, nmesh, nxl):
-        _lib.check(_lib.lib().abacus_slab_fft_zy_dev(mesh.ptr(off), int(nmesh), int(nxl)))
+    def fft_zy(self, mesh, off, send, nmesh, world, xsep, xg0, p0, pc):
+        """z / y passes of the plane pairs [p0, p0 + pc) of this rank's folded slab (first half at float offset `off`, global
+        plane xg0; second half `xsep` planes behind it); send = None: in place, else into the send buffer of the transpose"""
+        _lib.check(_lib.lib().abacus_slab_fft_zy_dev(mesh.ptr(off), None if send is None else send.ptr(0), int(nmesh),
+                                                     int(world), C.c_int64(xsep), int(xg0), int(p0), int(pc)))
 
-    def pack(self, mesh, off, send, nmesh, nxl, world, x0=0, nxc=None):
-        _lib.check(_lib.lib().abacus_slab_pack_dev(mesh.ptr(off), send.ptr(0), int(nmesh), int(nxl), int(world), int(x0),
-                                                   int(nxl if nxc is None else nxc)))
+    def pack(self, mesh, off, send, nmesh, world, xsep, p0, pc):
+        _lib.check(_lib.lib().abacus_slab_pack_dev(mesh.ptr(off), send.ptr(0), int(nmesh), int(world), C.c_int64(xsep),
+                                                   int(p0), int(pc)))
 
-    def unpack(self, recv, out, off, nmesh, nxl, world):
-        _lib.check(_lib.lib().abacus_slab_unpack_dev(recv.ptr(0), out.ptr(off), int(nmesh), int(nxl), int(world)))
+    def unpack(self, recv, out, off, nmesh, world):
+        _lib.check(_lib.lib().abacus_slab_unpack_dev(recv.ptr(0), out.ptr(off), int(nmesh), int(world)))
 
     def fft_x(self, data, off, nmesh, nyl):
         _lib.check(_lib.lib().abacus_slab_fft_x_dev(data.ptr(off), int(nmesh), int(nyl)))
@@ -129,22 +138,13 @@ class HipSlabBackend:
                                                   len(poles), _lib.ptr(raw)))
         return raw
 
-    def fft_zy_pack(self, mesh, off, send, nmesh, nxl, world, x0, nxc):
-        """z / y passes of planes [x0, x0 + nxc) with the y pass writing the send buffer (no pack pass); False when the
-        library does not serve this mesh / rank count that way (then fft_zy + pack)"""
-        rc = _lib.lib().abacus_slab_fft_zy_pack_dev(mesh.ptr(off), send.ptr(0), int(nmesh), int(nxl), int(world), int(x0), int(nxc))
-        if rc == 1:
-            return False
-        _lib.check(rc)
-        return True
-
-    def xbin_raw(self, field, nmesh, y0, nyl, Lbox, W, ke, me, poles, put_geom, from_transpose=False):
+    def xbin_raw(self, field, nmesh, world, y0, nyl, Lbox, W, ke, me, poles, put_geom, from_transpose=False):
         """last x pass fused with the binning (auto power, one non-interlaced field, nmesh 1024 / 2048): raw sums, or None
-        when the library does not serve this mesh / histogram that way (then fft_x + bin_raw).  from_transpose: `field` is
-        the receive buffer of the pencil transpose, (x, y_local, k), not yet unpacked"""
+        when the library does not serve this mesh / histogram that way (then unpack + fft_x + bin_raw).  from_transpose:
+        `field` is the receive buffer of the pencil transpose, (peer, 2 h, y_local, k), not yet unpacked"""
         buf, off = field
         raw = np.zeros(self.raw_bytes(len(ke) - 1, len(me) - 1, poles), dtype=np.uint8)
-        rc = _lib.lib().abacus_slab_xbin_dev(buf.ptr(off), int(nmesh), int(y0), int(nyl), C.c_double(Lbox),
+        rc = _lib.lib().abacus_slab_xbin_dev(buf.ptr(off), int(nmesh), int(world), int(y0), int(nyl), C.c_double(Lbox),
                                              None if W is None else _lib.ptr(W), _lib.ptr(ke), len(ke) - 1, _lib.ptr(me),
                                              len(me) - 1, _lib.ptr(poles), len(poles), int(bool(put_geom)),
                                              int(bool(from_transpose)), _lib.ptr(raw))
@@ -173,16 +173,24 @@ def finalize_raw(raw, Lbox, Nk, Nmu, poles):
     return power, N_mode, bp, Nmp, k_avg
 
 
-def route_particles(pos, w, Lbox, comm):
-    """send every particle to the rank that owns its x-slab (wrapped x in [r*L/W, (r+1)*L/W)), for catalogs whose
-    order is not slab-local (e.g. light-cone RSD moves galaxies across slabs).  With the RCCL communicator
-    and `_lib.DeviceArray` inputs the particles never leave HBM (bucket sort + all-to-all-v on the device); host arrays
-    and the gloo stand-in take the NumPy route below."""
+def slab_owner(xw, Lbox, world, fold):
+    """rank that owns wrapped float32 x: x-slabs of width L / W, or (fold) slab mod W of 2 W slabs - a rank then owns the
+    slabs r and r + W, the decomposition of `calc_power_slab`"""
+    nslab = 2 * world if fold else world
+    k = np.clip((xw * (np.float32(nslab) / np.float32(Lbox))).astype(np.int64), 0, nslab - 1)
+    return k % world
+
+
+def route_particles(pos, w, Lbox, comm, fold=False):
+    """send every particle to the rank that owns its slab (`slab_owner`; `fold=True` for `calc_power_slab`), for catalogs
+    whose order is not slab-local (e.g. light-cone RSD moves galaxies across slabs).  With the RCCL
+    communicator and `_lib.DeviceArray` inputs the particles never leave HBM (bucket sort + all-to-all-v on the device); host
+    arrays and the gloo stand-in take the NumPy route below."""
     if getattr(comm, 'device', False) and isinstance(pos, _lib.DeviceArray):
-        return comm.route_particles(pos, w, Lbox)
+        return comm.route_particles(pos, w, Lbox, fold=fold)
     pos = np.ascontiguousarray(pos, dtype=np.float32)
     xw = pos[:, 0] - np.floor(pos[:, 0] / np.float32(Lbox)) * np.float32(Lbox)
-    owner = np.minimum((xw * (comm.world / np.float32(Lbox))).astype(np.int64), comm.world - 1)
+    owner = slab_owner(xw, Lbox, comm.world, fold)
     order = np.argsort(owner, kind='stable')
     counts = np.bincount(owner, minlength=comm.world)
     starts = np.concatenate(([0], np.cumsum(counts)))
@@ -198,15 +206,16 @@ def route_particles(pos, w, Lbox, comm):
 def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None, k_max=None, logk=False, paste='TSC',
                     nmesh=128, compensated=True, interlaced=True, w=None, pos2=None, w2=None, poles=None,
                     squeeze_mu_axis=True, n_total=None, n_total2=None):
-    """`calc_power` (abacusnbody/analysis/power_spectrum.py:1131-1319) over x-slabs.  `pos` / `pos2` are THIS rank's
-    particles (already inside its x-slab, see `route_particles`); every rank returns the full Table."""
+    """`calc_power` (abacusnbody/analysis/power_spectrum.py:1131-1319) over folded slabs.  `pos` / `pos2` are THIS rank's
+    particles (already inside its two slabs, see `route_particles(..., fold=True)`; others are ignored); every rank returns
+    the full Table."""
     if comm is None:   # launched with WORLD_SIZE > 1: RCCL (one communicator per process, reused); else no transport
         from ..comm import default_comm
         comm = default_comm()
     backend = backend or HipSlabBackend()
     W, r = comm.world, comm.rank
-    if nmesh % W or nmesh // W < GHOST:
-        raise ValueError(f'nmesh={nmesh} must be divisible by the {W} ranks and leave at least {GHOST} planes per slab')
+    if nmesh % (2 * W) or nmesh // (2 * W) < GHOST:
+        raise ValueError(f'nmesh={nmesh} must be divisible by twice the {W} ranks and leave at least {GHOST} planes per slab')
     if kbins is None:
         kbins = nmesh
     if k_max is None:
@@ -223,18 +232,22 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     ke = np.ascontiguousarray(kbins, dtype=np.float64)
     me = np.ascontiguousarray(mubins, dtype=np.float64)
 
-    nxl = nmesh // W
+    h = nmesh // (2 * W)                  # plane pairs of a rank: planes [r h, (r + 1) h) and the same + nmesh / 2
+    nyl = nmesh // W
     pitch = backend.pitch(nmesh)
     plane = nmesh * pitch
     G = GHOST if comm.collective else 0   # one rank without a transport: the periodic mesh has no ghost planes
     g = G * plane
+    win = h + 2 * G                       # planes of one slab's window; the buffer holds the two windows back to back
+    xsep = win                            # so the halves of a pair lie `win` planes apart
     d = Lbox / nmesh
     nfields = (2 if interlaced else 1) * (2 if pos2 is not None else 1)
-    meshes = [backend.new_buffer((nxl + 2 * G) * plane) for _ in range(nfields)]
-    send = backend.new_buffer(nxl * plane)
-    recv = backend.new_buffer(nxl * plane)
-    ghost = backend.new_buffer(max(2 * g, 4))
-    x0 = r * nxl
+    meshes = [backend.new_buffer(2 * win * plane) for _ in range(nfields)]
+    send = backend.new_buffer(2 * h * plane)
+    recv = backend.new_buffer(2 * h * plane)
+    ghost = backend.new_buffer(max(4 * g, 4))
+    xa = r * h                            # first plane of the first slab; the second starts at xa + nmesh / 2
+    own = g                               # float offset of the first owned plane
 
     # auto power of one non-interlaced field: the last x pass can bin straight from LDS (no spectrum write + re-read)
     try_xbin = pos2 is None and not interlaced and hasattr(backend, 'xbin_raw')
@@ -243,42 +256,46 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         norm = float(np.float32(float(nmesh) ** 3 / float(ntot)))   # dtype(field.size / tot_weight) (:856,894)
         # every cell is written as rho * norm - 1 (the overdensity's "-1" costs no pass of its own); a ghost block holds
         # contribution - 1, so its owner adds ghost + 1
-        backend.deposit(particles, mesh, nmesh, (x0 - G) % nmesh, nxl + 2 * G, Lbox, offset, norm, code, sub=1.0)
-        # left ghost block -> left neighbour, right ghost block -> right neighbour
         if comm.collective:
-            comm.ring_exchange(backend, mesh, 0, (G + nxl) * plane, ghost, g)
-            # ghost[0:g]  came from the right neighbour (its left ghosts)  = my last G owned planes
-            # ghost[g:2g] came from the left neighbour (its right ghosts)  = my first G owned planes
-            backend.axpy(mesh, nxl * plane, ghost, 0, g, 1.0)
-            backend.axpy(mesh, G * plane, ghost, g, g, 1.0)
-        # z / y passes, pack and pencil transpose in chunks of x-planes: chunk c is on the links (the communicator's
-        # stream) while chunk c+1 is transformed.  Where the library offers it the y pass writes the send buffer itself (no
-        # pack pass), and - auto power of one non-interlaced field - the last x pass reads the receive buffer as it arrived,
-        # applies the x butterfly while staging and bins from LDS (no unpack pass, no x pass, no spectrum in HBM); one rank
-        # without a transport then needs neither buffer: its own slab is the "received" block.
-        nchunk = comm.transpose_chunks(nxl) if comm.collective else 1
-        cx = nxl // nchunk
-        nyl = nmesh // W
+            backend.deposit(particles, mesh, nmesh, (xa - G) % nmesh, win, Lbox, offset, norm, code, sub=1.0,
+                            xoff2=(xa + nmesh // 2 - G) % nmesh)
+            # the 2 W slabs form one ring: slab v's neighbours are v - 1 and v + 1, i.e. the same half of the neighbouring
+            # rank - except across the seam (rank W - 1 -> rank 0), where the halves swap
+            for s_ in (0, 1):
+                comm.ring_exchange(backend, mesh, s_ * win * plane, (s_ * win + G + h) * plane, ghost, g, recv_off=2 * s_ * g)
+            for s_ in (0, 1):
+                # ghost[2 s g : +g]      came from rank + 1 (the low ghosts of its half s)  = the last G owned planes of my
+                #                        half s, or of my other half if rank + 1 wrapped to 0
+                # ghost[(2 s + 1) g : +g] came from rank - 1 (the high ghosts of its half s) = the first G owned planes
+                hi = s_ ^ 1 if r == W - 1 else s_
+                lo = s_ ^ 1 if r == 0 else s_
+                backend.axpy(mesh, (hi * win + h) * plane, ghost, 2 * s_ * g, g, 1.0)
+                backend.axpy(mesh, (lo * win + G) * plane, ghost, (2 * s_ + 1) * g, g, 1.0)
+        else:
+            backend.deposit(particles, mesh, nmesh, 0, nmesh, Lbox, offset, norm, code, sub=1.0)
+        # z / y passes and pencil transpose in chunks of plane pairs: chunk c is on the links (the communicator's stream)
+        # while chunk c+1 is transformed; the passes write the send buffer.  Auto power of one non-interlaced field: the
+        # last x pass then reads the receive buffer as it arrived and bins from LDS (no unpack pass, no x pass, no
+        # spectrum in HBM); one rank without a transport needs neither buffer: its own mesh is the "received" block.
+        nchunk = comm.transpose_chunks(h) if comm.collective else 1
+        cp = h // nchunk
         direct = try_xbin and not comm.collective           # one rank, fused last pass: no transpose at all
         for c in range(nchunk):
-            if direct:
-                backend.fft_zy(mesh, (G + c * cx) * plane, nmesh, cx)
-                continue
-            packed = comm.collective and hasattr(backend, 'fft_zy_pack') and \
-                backend.fft_zy_pack(mesh, G * plane, send, nmesh, nxl, W, c * cx, cx)
-            if not packed:
-                backend.fft_zy(mesh, (G + c * cx) * plane, nmesh, cx)
-                backend.pack(mesh, G * plane, send, nmesh, nxl, W, c * cx, cx)
+            backend.fft_zy(mesh, own, None if direct else send, nmesh, W, xsep, xa, c * cp, cp)
             if comm.collective:
-                comm.all_to_all_piece(backend, send, recv, nxl * nyl * pitch, c * cx * nyl * pitch, cx * nyl * pitch,
-                                      overlap=nchunk > 1)
+                for s_ in (0, 1):                             # the chunk's planes of either half within every peer block
+                    comm.all_to_all_piece(backend, send, recv, 2 * h * nyl * pitch, (s_ * h + c * cp) * nyl * pitch,
+                                          cp * nyl * pitch, overlap=nchunk > 1)
         if comm.collective:
             comm.join()
-        if try_xbin:                                          # (x, y_local, k) as delivered: handed to the fused last pass
-            return (mesh, G * plane) if direct else (recv if comm.collective else send, 0)
-        backend.unpack(recv if comm.collective else send, mesh, G * plane, nmesh, nxl, W)   # mesh now holds (y_local, x, k)
-        backend.fft_x(mesh, G * plane, nmesh, nxl)
-        return (mesh, G * plane)
+        if direct:
+            return (mesh, own)
+        got = recv if comm.collective else send
+        if try_xbin:                                          # (peer, 2 h, y_local, k) as delivered: for the fused last pass
+            return (got, 0)
+        backend.unpack(got, mesh, 0, nmesh, W)               # mesh now holds (y_local, x, k)
+        backend.fft_x(mesh, 0, nmesh, nyl)
+        return (mesh, 0)
 
     sets = [(pos, w, n_total)] + ([(pos2, w2, n_total2)] if pos2 is not None else [])
     fields = []
@@ -297,17 +314,17 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         fields += [(None, 0), (None, 0)]
     raw = None
     if try_xbin:
-        raw = backend.xbin_raw(fields[0], nmesh, r * nxl, nxl, Lbox, Wk, ke, me, poles_arr, r == 0, from_transpose=True)
-        if raw is None:      # not served: unpack (with the x butterfly where the form is fused), x pass, binning
-            src, _ = fields[0]
-            if src is meshes[0]:                              # one rank went straight from its slab: it still has to be packed
-                backend.pack(meshes[0], G * plane, send, nmesh, nxl, W, 0, nxl)
+        raw = backend.xbin_raw(fields[0], nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, r == 0, from_transpose=True)
+        if raw is None:      # not served: unpack, x pass, binning
+            src, off = fields[0]
+            if src is meshes[0]:                              # one rank went straight from its mesh: it still has to be packed
+                backend.pack(meshes[0], off, send, nmesh, W, xsep, 0, h)
                 src = send
-            backend.unpack(src, meshes[0], G * plane, nmesh, nxl, W)
-            backend.fft_x(meshes[0], G * plane, nmesh, nxl)
-            fields[0] = (meshes[0], G * plane)
+            backend.unpack(src, meshes[0], 0, nmesh, W)
+            backend.fft_x(meshes[0], 0, nmesh, nyl)
+            fields[0] = (meshes[0], 0)
     if raw is None:
-        raw = backend.bin_raw(fields, nmesh, r * nxl, nxl, Lbox, Wk, interlaced, ke, me, poles_arr)
+        raw = backend.bin_raw(fields, nmesh, r * nyl, nyl, Lbox, Wk, interlaced, ke, me, poles_arr)
     raw = comm.all_reduce_raw(raw, (len(ke) - 1) * (len(me) - 1))
     power, N_mode, bp, Nmp, k_avg = backend.finalize(raw, Lbox, len(ke) - 1, len(me) - 1, poles_arr)
     for b in meshes + [send, recv, ghost]:

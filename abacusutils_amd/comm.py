@@ -179,10 +179,10 @@ class RcclComm:
         return out
 
     # ---- mesh-sized exchanges (device buffers of analysis.slab_power.HipBuf; float32 element counts) -----
-    def ring_exchange(self, backend, buf, left_off, right_off, recv, n):
-        """buf[left_off:+n] -> rank-1, buf[right_off:+n] -> rank+1; recv[0:n] <- from rank+1, recv[n:2n] <- from rank-1"""
-        _lib.check(_lib.lib().abacus_comm_ring_exchange(self._h, buf.ptr(left_off), buf.ptr(right_off), recv.ptr(0),
-                                                        recv.ptr(n), C.c_uint64(4 * int(n))))
+    def ring_exchange(self, backend, buf, left_off, right_off, recv, n, recv_off=0):
+        """buf[left_off:+n] -> rank-1, buf[right_off:+n] -> rank+1; recv[recv_off:+n] <- from rank+1, the next n <- from rank-1"""
+        _lib.check(_lib.lib().abacus_comm_ring_exchange(self._h, buf.ptr(left_off), buf.ptr(right_off), recv.ptr(recv_off),
+                                                        recv.ptr(recv_off + n), C.c_uint64(4 * int(n))))
 
     def all_to_all(self, backend, send, recv, n_total):
         _lib.check(_lib.lib().abacus_comm_all_to_all(self._h, send.ptr(0), recv.ptr(0),
@@ -232,17 +232,18 @@ class RcclComm:
         allb = self.all_gather_array(pad)
         return [pickle.loads(allb[r, :sizes[r]].tobytes()) for r in range(self.world)]
 
-    def transpose_chunks(self, nxl):
-        """pieces the pencil transpose is cut into so that the links work while the next planes are transformed"""
+    def transpose_chunks(self, npair):
+        """pieces the pencil transpose is cut into so that the links work while the next plane pairs are transformed"""
         for c in (4, 2):
-            if self.world > 1 and nxl % c == 0 and nxl // c >= 8:
+            if self.world > 1 and npair % c == 0 and npair // c >= 8:
                 return c
         return 1
 
     # ---- particle routing on the device ------------------------------------------------------------------
-    def route_particles(self, dpos, dw, Lbox):
-        """every particle to the rank that owns its x-slab, without leaving HBM: stable bucket sort by owner
-        (abacus_slab_route_dev), counts all-gathered, ONE grouped send/recv of the variable blocks.
+    def route_particles(self, dpos, dw, Lbox, fold=False):
+        """every particle to the rank that owns its x-slab (fold: its folded slab pair, analysis/slab_power.py), without
+        leaving HBM: stable bucket sort by owner (abacus_slab_route_dev), counts all-gathered, ONE grouped send/recv of the
+        variable blocks.
         dpos: DeviceArray (n, 3) float32; dw: DeviceArray (n,) float32 or None.  Returns new DeviceArrays."""
         L = _lib.lib()
         W = self.world
@@ -251,7 +252,7 @@ class RcclComm:
         sw = None if dw is None else _lib.DeviceArray(nbytes=max(n, 1) * 4, dtype=np.float32, shape=(n,))
         counts = np.zeros(W, dtype=np.int64)
         _lib.check(L.abacus_slab_route_dev(dpos.ptr, C.c_int64(n), None if dw is None else dw.ptr, C.c_double(Lbox), W,
-                                           spos.ptr, None if sw is None else sw.ptr, _lib.ptr(counts)))
+                                           int(bool(fold)), spos.ptr, None if sw is None else sw.ptr, _lib.ptr(counts)))
         allc = self.all_gather_array(counts)            # allc[r, p] = particles rank r holds for rank p
         rcounts = allc[:, self.rank].copy()
         nrecv = int(rcounts.sum())

@@ -40,10 +40,17 @@ namespace {
 // transforms each, over rows [0, n/2) and [n/2, n): half the rows per LDS tile, twice the columns - 128-B row
 // segments at n = 2048, which the memory system serves at the in-place floor instead of 3.4 TB/s.
 // Row r of either half then holds frequency 2 (r mod n/2) + (r div n/2) along that axis.
+// ZFold: which plane pairs a fused launch works on.  Pair p (0 <= p < npair) is the planes p and xsep + p of `mesh` and stands
+// for the global planes xg0 + p and xg0 + p + n/2 (the twiddle of the x stage is exp(-2 pi i (xg0 + p) / n)).  The whole
+// mesh: npair = xsep = n/2, xg0 = 0; a rank of a multi-GPU run owns h pairs of planes n/2 apart (the folded slabs of
+// analysis/slab_power.py), stored xsep = h + ghost planes apart.
+struct ZFold {
+    int npair, xsep, xg0;
+};
 template <int N, int B, int FUSE, int F1 = 0>
 __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh, int64_t nrows, int pitch_r,
                                                          const float2 *__restrict__ twN, const float2 *__restrict__ tw2N,
-                                                         int dbg) {
+                                                         int dbg, ZFold zf) {
     constexpr int CP = colpitch_of<N>();
     constexpr int NLD = (B * (N / 2) + Z_THREADS - 1) / Z_THREADS;   // 16-B loads per thread and tile
     extern __shared__ __align__(16) unsigned char smem[];
@@ -55,15 +62,12 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
     for (int q = tid; q <= N; q += Z_THREADS) tw2[q] = tw2N[q];
     static_assert(!FUSE || B == 4, "the fused first stages work on 2 x 2 rows");
     constexpr int NF = 2 * N;                               // mesh size n
-    // FUSE == 2 (x-slabs of a multi-GPU mesh: x + n/2 lives on another rank): only the y stage is fused; a tile is the rows
-    // (x, y), (x, y+n/2), (x+1, y), (x+1, y+n/2) of two adjacent planes, nrows = nx_local * n with nx_local even
-    const int64_t ntiles = FUSE == 1 ? (int64_t)N * N : FUSE == 2 ? nrows / 4 : (nrows + B - 1) / B;
+    const int64_t ntiles = FUSE ? (int64_t)zf.npair * N : (nrows + B - 1) / B;
     // first row of a tile, and the row of its r-th member
     auto row_of = [&](int64_t tile, int r) -> int64_t {
         if (!FUSE) return tile * B + r;
         const int64_t x = tile / N, y = tile % N;
-        if (FUSE == 2) return (2 * x + (r >> 1)) * NF + y + (r & 1) * N;
-        return (x + (r >> 1) * N) * NF + y + (r & 1) * N;
+        return (x + (r >> 1) * (int64_t)zf.xsep) * NF + y + (r & 1) * N;
     };
     const int pitch_c = pitch_r / 2;
     v4f regs[NLD];
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
             const int x = (int)(tile / N), y = (int)(tile % N);
             float sy, cy, sx, cx;
             sincospif((float)y / (float)N, &sy, &cy);        // W_n^y = exp(-2 pi i y / n), n = 2N
-            sincospif((float)x / (float)N, &sx, &cx);
+            sincospif((float)(zf.xg0 + x) / (float)N, &sx, &cx);
             const float2 Wy = make_float2(cy, -sy), Wx = make_float2(cx, -sx);
             for (int k2 = tid; k2 < pitch_c / 2; k2 += Z_THREADS) {
                 const int k0 = k2 * 2;
@@ -202,10 +206,6 @@ __global__ __launch_bounds__(Z_THREADS) void fft_z_r2c(float *__restrict__ mesh,
                 for (int u = 0; u < 2; u++) {   // rows: 0 = (x, y), 1 = (x, y+H), 2 = (x+H, y), 3 = (x+H, y+H)
                     const float2 A = cadd(X[0][u], X[1][u]), Bv = cmul(csub(X[0][u], X[1][u]), Wy);
                     const float2 Cv = cadd(X[2][u], X[3][u]), D = cmul(csub(X[2][u], X[3][u]), Wy);
-                    if (FUSE == 2) {            // rows 2, 3 belong to the next plane: no x stage here
-                        X[0][u] = A, X[1][u] = Bv, X[2][u] = Cv, X[3][u] = D;
-                        continue;
-                    }
                     X[0][u] = cadd(A, Cv);
                     X[2][u] = cmul(csub(A, Cv), Wx);
                     X[1][u] = cadd(Bv, D);
@@ -399,31 +399,31 @@ int get_tables(int n, Tables **out) {
 }
 
 template <int N, int B, int FUSE, int F1>
-int launch_z1(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
+int launch_z1(float *mesh, int64_t nrows, int pitch_r, Tables *t, ZFold zf) {
     const size_t lds = (size_t)(2 * N + 2 + B * colpitch_of<N>()) * sizeof(float2);
     auto kern = fft_z_r2c<N, B, FUSE, F1>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t ntiles = FUSE == 1 ? (int64_t)N * N : FUSE == 2 ? nrows / 4 : ceil_div(nrows, B);
+    const int64_t ntiles = FUSE ? (int64_t)zf.npair * N : ceil_div(nrows, B);
     int per_cu = 1;   // persistent grid = exactly the resident workgroups (a larger grid would run in two uneven waves)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, Z_THREADS, lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)num_cus() * std::max(per_cu, 1));
     ABACUS_LAUNCH("fft_z_r2c", kern, dim3(grid), dim3(Z_THREADS), lds, mesh, nrows, pitch_r, t->twHalf.as<float2>(),
-                  t->tw2.as<float2>(), option("dbg_fft"));
+                  t->tw2.as<float2>(), option("dbg_fft"), zf);
     return 0;
 }
 // z pass at N = 1024, option fft_zmode (A/B): 0 = production; 1..4 = F1 bits + 1 (bit 0: first radix-8 pass fused with the
 // staging, bit 1: twiddles as lane constants)
 template <int N, int B, int FUSE = 0>
-int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t) {
+int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t, ZFold zf = ZFold{N, N, 0}) {
     if constexpr (N == 1024) {
         switch (option("fft_zmode")) {
-            case 1: return launch_z1<N, B, FUSE, 0>(mesh, nrows, pitch_r, t);
-            case 2: return launch_z1<N, B, FUSE, 1>(mesh, nrows, pitch_r, t);
-            case 3: return launch_z1<N, B, FUSE, 2>(mesh, nrows, pitch_r, t);
-            case 4: return launch_z1<N, B, FUSE, 3>(mesh, nrows, pitch_r, t);
+            case 1: return launch_z1<N, B, FUSE, 0>(mesh, nrows, pitch_r, t, zf);
+            case 2: return launch_z1<N, B, FUSE, 1>(mesh, nrows, pitch_r, t, zf);
+            case 3: return launch_z1<N, B, FUSE, 2>(mesh, nrows, pitch_r, t, zf);
+            case 4: return launch_z1<N, B, FUSE, 3>(mesh, nrows, pitch_r, t, zf);
         }
     }
-    return launch_z1<N, B, FUSE, 0>(mesh, nrows, pitch_r, t);
+    return launch_z1<N, B, FUSE, 0>(mesh, nrows, pitch_r, t, zf);
 }
 
 template <int N, int C, bool F1, bool PACK = false>
@@ -539,34 +539,44 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x) {
     return launch_cols<H, C>("fft_cols_x", data, S, ntile_c, 2 * (int64_t)N, pitch_c, th->twN.as<float2>(), N, (int64_t)H * S);
 }
 
-// The fused form on an x-slab (multi-GPU mesh): z pass with the first radix-2 stage of y only (x + n/2 lives on another
-// rank), y pass as two n/2-point transforms per plane with C columns; the first radix-2 stage of x is applied by the
-// unpack step behind the pencil transpose (power.hip slab_unpack_bfly), the x pass is then fft_native_fused_x_slab or the
-// fused last pass + binning (xbin.hip).  Row orders as in the single-GPU fused form.
-// pack_out != nullptr: the y pass writes the send buffer of the pencil transpose (ColsPack); the planes given are planes
-// [x0, x0 + nx_local) of a slab of nxl_total planes decomposed over `world` ranks
+// The fused form on the folded slabs of a multi-GPU mesh (analysis/slab_power.py): a rank owns h plane pairs (x, x + n/2),
+// the first half at `mesh`, the second xsep planes behind it, so the z pass fuses the first radix-2 stage of y AND x exactly
+// as on the whole mesh (ZFold) and everything behind it is the single-GPU form: the y pass as two n/2-point transforms per
+// plane with C columns, the x pass - behind the pencil transpose - two n/2-point transforms over the sum rows and the
+// difference rows (fft_native_fused_x_slab, or the fused last pass + binning of xbin.hip).  Works on pairs [p0, p0 + pc).
+// pack_out != nullptr: the y pass writes the send buffer of the pencil transpose (ColsPack), send[peer][s h + p][yl][k]
 template <int N, int C>
-int fft3d_fused_zy_slab(float *mesh, int pitch_r, Tables *t, Tables *th, int64_t nx_local, float *pack_out = nullptr,
-                        int world = 1, int nxl_total = 0, int x0 = 0) {
+int fft3d_fused_zy_slab(float *mesh, int pitch_r, Tables *t, Tables *th, int h, int64_t xsep, int xg0, int p0, int pc,
+                        float *pack_out, int world) {
     constexpr int H = N / 2;
     const int pitch_c = pitch_r / 2, ntile_c = (N / 2 + 1 + C - 1) / C;
     if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
-    if (nx_local % 2) return fail("fft: the fused slab transform needs an even number of planes (got %lld)", (long long)nx_local);
-    ABACUS_TRY((launch_z<N / 2, 4, 2>(mesh, nx_local * N, pitch_r, t)));
-    if (!pack_out)
-        return launch_cols<H, C>("fft_cols_y", reinterpret_cast<float2 *>(mesh), pitch_c, ntile_c, 2 * nx_local, (int64_t)H * pitch_c,
-                                 th->twN.as<float2>());
-    const int nyl = N / world;
+    const int64_t plane = (int64_t)N * pitch_r;
+    ABACUS_TRY((launch_z<N / 2, 4, 1>(mesh + p0 * plane, 0, pitch_r, t, ZFold{pc, (int)xsep, xg0 + p0})));
     ColsPack pk;
-    pk.out = reinterpret_cast<float2 *>(pack_out);
-    pk.lg_nyl = 0;
-    while ((1 << pk.lg_nyl) < nyl) pk.lg_nyl++;
-    if ((1 << pk.lg_nyl) != nyl || nyl > H) return fail("fft: packed y pass needs a power-of-two number of ranks >= 2 or one rank (nyl %d)", nyl);
-    pk.x0 = x0;
-    pk.x_stride = (int64_t)nyl * pitch_c;
-    pk.peer_stride = (int64_t)nxl_total * nyl * pitch_c;
-    return launch_cols1<H, C, false, true>("fft_cols_y", reinterpret_cast<float2 *>(mesh), pitch_c, ntile_c, 2 * nx_local,
-                                            (int64_t)H * pitch_c, th->twN.as<float2>(), (int64_t)1 << 40, 0, pk);
+    if (pack_out) {
+        const int nyl = N / world;
+        pk.out = reinterpret_cast<float2 *>(pack_out);
+        pk.lg_nyl = 0;
+        while ((1 << pk.lg_nyl) < nyl) pk.lg_nyl++;
+        if ((1 << pk.lg_nyl) != nyl || nyl > H) return fail("fft: packed y pass needs a power-of-two number of ranks >= 2 (nyl %d)", nyl);
+        pk.x_stride = (int64_t)nyl * pitch_c;
+        pk.peer_stride = 2 * (int64_t)h * nyl * pitch_c;
+    }
+    for (int s = 0; s < 2; s++) {
+        float2 *data = reinterpret_cast<float2 *>(mesh + (s * xsep + p0) * plane);
+        if (!pack_out) {
+            if (xsep == pc && p0 == 0) {     // the halves are contiguous (one rank, whole mesh): one launch
+                return launch_cols<H, C>("fft_cols_y", data, pitch_c, ntile_c, 4 * (int64_t)pc, (int64_t)H * pitch_c, th->twN.as<float2>());
+            }
+            ABACUS_TRY((launch_cols<H, C>("fft_cols_y", data, pitch_c, ntile_c, 2 * (int64_t)pc, (int64_t)H * pitch_c, th->twN.as<float2>())));
+        } else {
+            pk.x0 = s * h + p0;
+            ABACUS_TRY((launch_cols1<H, C, false, true>("fft_cols_y", data, pitch_c, ntile_c, 2 * (int64_t)pc, (int64_t)H * pitch_c,
+                                                        th->twN.as<float2>(), (int64_t)1 << 40, 0, pk)));
+        }
+    }
+    return 0;
 }
 template <int N, int C>
 int fft3d_fused_x_slab(float *mesh, int pitch_r, Tables *th, int64_t ny_local) {
@@ -576,15 +586,16 @@ int fft3d_fused_x_slab(float *mesh, int pitch_r, Tables *th, int64_t ny_local) {
     return launch_cols<H, C>("fft_cols_x", reinterpret_cast<float2 *>(mesh), pitch_c, ntile_c, 2 * ny_local, (int64_t)H * pitch_c,
                              th->twN.as<float2>());
 }
-int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int64_t nx_local, float *pack_out, int world, int nxl_total,
-                             int x0) {
+int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int h, int64_t xsep, int xg0, int p0, int pc, float *pack_out,
+                             int world) {
     Tables *t, *th;
     ABACUS_TRY(get_tables(n, &t));
     ABACUS_TRY(get_tables(n / 2, &th));
+    if (h < 1 || pc < 1 || p0 < 0 || p0 + pc > h || xsep < h) return fail("fft: plane pairs [%d, +%d) of %d", p0, pc, h);
     switch (n) {
-        case 256: return fft3d_fused_zy_slab<256, 16>(mesh, pitch_r, t, th, nx_local, pack_out, world, nxl_total, x0);
-        case 1024: return fft3d_fused_zy_slab<1024, 16>(mesh, pitch_r, t, th, nx_local, pack_out, world, nxl_total, x0);
-        case 2048: return fft3d_fused_zy_slab<2048, 16>(mesh, pitch_r, t, th, nx_local, pack_out, world, nxl_total, x0);
+        case 256: return fft3d_fused_zy_slab<256, 16>(mesh, pitch_r, t, th, h, xsep, xg0, p0, pc, pack_out, world);
+        case 1024: return fft3d_fused_zy_slab<1024, 16>(mesh, pitch_r, t, th, h, xsep, xg0, p0, pc, pack_out, world);
+        case 2048: return fft3d_fused_zy_slab<2048, 16>(mesh, pitch_r, t, th, h, xsep, xg0, p0, pc, pack_out, world);
     }
     return fail("fft: the fused transform supports n = 1024 and 2048");
 }

@@ -109,14 +109,17 @@ int partition_impl(const void *pos_, int64_t n, const void *w_, int npartition, 
     return rc;
 }
 
-// owner of a particle in the x-slab decomposition of the mesh: wrapped x in [r L/W, (r+1) L/W), float32 like the deposit
-__global__ void route_keys(const float *__restrict__ pos, int64_t n, float box, float inv_width, int world,
+// owner of a particle in the x-slab decomposition of the mesh: wrapped x in [r L/W, (r+1) L/W), float32 like the deposit.
+// fold: the box is cut into 2 W slabs and rank r owns slabs r and r + W (planes x and x + n/2 on one rank: the folded slabs
+// of the P(k) estimator) - the caller passes inv_width = 2 W / L and slabs = 2 W
+__global__ void route_keys(const float *__restrict__ pos, int64_t n, float box, float inv_width, int slabs, int world,
                            int *__restrict__ keys, unsigned int *__restrict__ idx, unsigned long long *__restrict__ hist) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float x = pos[3 * i];
         const float xw = x - floorf(x / box) * box;
         int k = (int)(xw * inv_width);
-        k = max(min(k, world - 1), 0);
+        k = max(min(k, slabs - 1), 0);
+        if (k >= world) k -= world;
         keys[i] = k;
         idx[i] = (unsigned int)i;
         atomicAdd(&hist[k], 1ull);
@@ -128,8 +131,8 @@ __global__ void route_keys(const float *__restrict__ pos, int64_t n, float box, 
 // Particle routing of the slab P(k) on the device (no reference counterpart: the reference's mesh is single-process):
 // stable bucket sort of (pos, w) by owning rank; counts[world] on the host.  The variable-size blocks then travel with
 // abacus_comm_all_to_all_v.
-extern "C" int abacus_slab_route_dev(const float *pos, int64_t n, const float *w, double Lbox, int world, float *pos_out,
-                                     float *w_out, int64_t *counts) {
+extern "C" int abacus_slab_route_dev(const float *pos, int64_t n, const float *w, double Lbox, int world, int fold,
+                                     float *pos_out, float *w_out, int64_t *counts) {
     ABACUS_ENTER();
     if (world < 1 || !counts || (n > 0 && (!pos || !pos_out)) || (w && !w_out)) return fail("abacus_slab_route_dev: bad argument");
     if (n >= (int64_t)1 << 31) return fail("abacus_slab_route_dev: more than 2^31 particles per rank");
@@ -145,7 +148,8 @@ extern "C" int abacus_slab_route_dev(const float *pos, int64_t n, const float *w
     if (n > 0) {
         const int nblk = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
         const float box = (float)Lbox;
-        ABACUS_LAUNCH("route_keys", route_keys, dim3(nblk), dim3(256), 0, pos, n, box, (float)world / box, world, keys.as<int>(),
+        ABACUS_LAUNCH("route_keys", route_keys, dim3(nblk), dim3(256), 0, pos, n, box, (float)(fold ? 2 * world : world) / box,
+                      fold ? 2 * world : world, world, keys.as<int>(),
                       idx.as<unsigned int>(), hist.as<unsigned long long>());
         int end_bit = 1;
         while ((1ll << end_bit) < world) end_bit++;

@@ -47,17 +47,17 @@ int fft_native_r2c_inplace(float *mesh, int n, int pitch_r);
 int fft_native_zy(float *mesh, int n, int pitch_r, int64_t nx_local);
 int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_stride, int64_t y_stride);
 int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
-                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub = 0.0);
+                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub, int xoff2);
 int fft_native_release();
 int fft_native_fused_supported(int n);
 int fft_native_r2c_fused(float *mesh, int n, int pitch_r);   // rows come out in the permuted order of fft.hip's fused form
 int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r);
 bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
-                  int y0 = 0, int ny_local = 0, int put_geom = 1, int layout = 0);
+                  int y0 = 0, int ny_local = 0, int put_geom = 1, int layout = 0, int world = 1);
 bool xbin2_supported(int n, const BinArgs &b, bool comp);
-int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int64_t nx_local, float *pack_out = nullptr, int world = 1,
-                             int nxl_total = 0, int x0 = 0);
+int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int h, int64_t xsep, int xg0, int p0, int pc, float *pack_out,
+                             int world);
 int fft_native_fused_x_slab(float *mesh, int n, int pitch_r, int64_t ny_local);
 double xbin_last_build_ms();
 int xbin_last_gen();
@@ -488,49 +488,32 @@ __global__ void slab_axpy(float *__restrict__ dst, const float *__restrict__ src
     }
 }
 
-// send[p][xl][yl][k] = data[xl][p*nyl + yl][k] for the planes xl in [x0, x0 + nxc)   (rows of `pitch` complex, copied as
-// 16-B pieces); a chunk of planes at a time, so that the transpose of a chunk is on the links while the next is transformed
-__global__ void slab_pack(const float4 *__restrict__ data, float4 *__restrict__ send, int n, int nxl, int nyl, int world,
-                          int pitch4, int x0, int nxc) {
-    const int64_t rows = (int64_t)world * nxc * nyl;
+// Folded slabs: a rank owns h plane pairs (x, x + n/2); `data` holds the first planes of the pairs, the second ones xsep
+// planes behind them.  send[q][s h + p][yl][k] = data[s xsep + p][q nyl + yl][k] for the pairs p in [p0, p0 + pc) (rows of
+// `pitch` complex, copied as 16-B pieces); a chunk of pairs at a time, so that the transpose of a chunk is on the links while
+// the next is transformed
+__global__ void slab_pack(const float4 *__restrict__ data, float4 *__restrict__ send, int n, int h, int64_t xsep, int nyl,
+                          int world, int pitch4, int p0, int pc) {
+    const int64_t rows = (int64_t)world * 2 * pc * nyl;
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-        const int yl = (int)(r % nyl), xl = x0 + (int)((r / nyl) % nxc), p = (int)(r / ((int64_t)nyl * nxc));
-        const float4 *src = data + ((int64_t)xl * n + (p * nyl + yl)) * pitch4;
-        float4 *dst = send + (((int64_t)p * nxl + xl) * nyl + yl) * pitch4;
-        for (int q = threadIdx.x; q < pitch4; q += blockDim.x) dst[q] = src[q];
+        const int yl = (int)(r % nyl), u = (int)((r / nyl) % (2 * pc)), q = (int)(r / ((int64_t)nyl * 2 * pc));
+        const int sh = u / pc, p = p0 + u % pc;
+        const float4 *src = data + ((sh * xsep + p) * n + (q * nyl + yl)) * pitch4;
+        float4 *dst = send + (((int64_t)q * 2 * h + sh * h + p) * nyl + yl) * pitch4;
+        for (int t = threadIdx.x; t < pitch4; t += blockDim.x) dst[t] = src[t];
     }
 }
-// out[yl][r*nxl + xl][k] = recv[r][xl][yl][k]
-__global__ void slab_unpack(const float4 *__restrict__ recv, float4 *__restrict__ out, int n, int nxl, int nyl, int world,
+// out[yl][s n/2 + q h + p][k] = recv[q][s h + p][yl][k]: behind the transpose row s n/2 + i is plane i of half s of x - the
+// plain transform's plane x = s n/2 + i, or in the fused form the sum (s = 0) / twiddled difference (s = 1) of planes i, i + n/2
+__global__ void slab_unpack(const float4 *__restrict__ recv, float4 *__restrict__ out, int n, int h, int nyl, int world,
                             int pitch4) {
-    const int64_t rows = (int64_t)world * nxl * nyl;
+    const int64_t rows = (int64_t)world * 2 * h * nyl;
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-        const int yl = (int)(r % nyl), xl = (int)((r / nyl) % nxl), p = (int)(r / ((int64_t)nyl * nxl));
+        const int yl = (int)(r % nyl), u = (int)((r / nyl) % (2 * h)), q = (int)(r / ((int64_t)nyl * 2 * h));
+        const int sh = u / h, p = u % h;
         const float4 *src = recv + r * pitch4;
-        float4 *dst = out + ((int64_t)yl * n + (p * nxl + xl)) * pitch4;
-        for (int q = threadIdx.x; q < pitch4; q += blockDim.x) dst[q] = src[q];
-    }
-}
-
-// the same with the first radix-2 DIF stage of the x transform applied on the way (fused slab form): for x < n/2
-// out[yl][x] = a(x) + a(x + n/2), out[yl][x + n/2] = (a(x) - a(x + n/2)) * exp(-2 pi i x / n) - after the pencil transpose
-// both planes are on this rank.  Rows [0, n/2) / [n/2, n) of x then feed two independent n/2-point transforms (fft.hip).
-__global__ void slab_unpack_bfly(const float4 *__restrict__ recv, float4 *__restrict__ out, int n, int nxl, int nyl, int pitch4) {
-    const int h = n / 2;
-    const int64_t rows = (int64_t)h * nyl;
-    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-        const int yl = (int)(r % nyl), x = (int)(r / nyl), x2 = x + h;
-        const float4 *sa = recv + (((int64_t)(x / nxl) * nxl + x % nxl) * nyl + yl) * pitch4;
-        const float4 *sb = recv + (((int64_t)(x2 / nxl) * nxl + x2 % nxl) * nyl + yl) * pitch4;
-        float4 *da = out + ((int64_t)yl * n + x) * pitch4, *db = out + ((int64_t)yl * n + x2) * pitch4;
-        float sn, cs;
-        sincospif((float)x / (float)h, &sn, &cs);     // W_n^x = (cs, -sn)
-        for (int q = threadIdx.x; q < pitch4; q += blockDim.x) {
-            const float4 a = sa[q], b = sb[q];
-            const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-            da[q] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-            db[q] = make_float4(d.x * cs + d.y * sn, d.y * cs - d.x * sn, d.z * cs + d.w * sn, d.w * cs - d.z * sn);
-        }
+        float4 *dst = out + ((int64_t)yl * n + (sh * (n / 2) + q * h + p)) * pitch4;
+        for (int t = threadIdx.x; t < pitch4; t += blockDim.x) dst[t] = src[t];
     }
 }
 
@@ -1186,15 +1169,16 @@ int abacus_pk_from_deltak(const void *field, const void *field2, int nmesh, doub
 
 int abacus_slab_pitch(int nmesh) { return pitch_r(nmesh); }
 
-int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int nx_local,
+int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int xoff2, int nx_local,
                             double Lbox, double offset, double norm, int paste, double sub) {
     ABACUS_ENTER();
     ABACUS_TRY(check_common(nmesh, paste));
     if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
-    if (nx_local == nmesh && xoff == 0)   // the whole periodic mesh on one rank: the single-GPU deposit (fast list build)
+    if (xoff < 0 || xoff >= nmesh || xoff2 >= nmesh || nx_local < 1) return fail("abacus_slab_deposit_dev: window [%d | %d, +%d)", xoff, xoff2, nx_local);
+    if (xoff2 < 0 && nx_local == nmesh && xoff == 0)   // the whole periodic mesh on one rank: the single-GPU deposit (fast list build)
         return tsc_deposit_f32(pos, n, w, mesh, nmesh, pitch_r(nmesh), Lbox, offset, paste == 0, norm, paste, 0, sub);
-    return tsc_deposit_slab_f32(pos, n, w, mesh, nmesh, xoff, nx_local, pitch_r(nmesh), Lbox, offset, paste == 0, norm,
-                                paste, sub);
+    return tsc_deposit_slab_f32(pos, n, w, mesh, nmesh, xoff, xoff2 < 0 ? nx_local : 2 * nx_local, pitch_r(nmesh), Lbox, offset,
+                                paste == 0, norm, paste, sub, xoff2 < 0 ? -1 : xoff2);
 }
 
 int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add) {
@@ -1211,54 +1195,60 @@ static bool slab_fused(int nmesh) { return use_fused_fft(nmesh) && !option("slab
 
 int abacus_slab_fused(int nmesh) { return slab_fused(nmesh) ? 1 : 0; }
 
-int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local) {
-    ABACUS_ENTER();
-    if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
-    if (slab_fused(nmesh)) return fft_native_fused_zy_slab(mesh, nmesh, pitch_r(nmesh), nx_local);
-    return fft_native_zy(mesh, nmesh, pitch_r(nmesh), nx_local);
-}
-
-// z and y passes of planes [x_begin, x_begin + x_count) of the slab at `mesh` (plane 0 = first owned plane) with the y pass
-// writing the send buffer of the pencil transpose directly (fused form only): replaces abacus_slab_fft_zy_dev +
-// abacus_slab_pack_dev of that chunk.  Returns 1 when this mesh / rank count is not served that way (call the two).
-int abacus_slab_fft_zy_pack_dev(float *mesh, void *send, int nmesh, int nx_local, int world, int x_begin, int x_count) {
-    ABACUS_ENTER();
-    if (!slab_fused(nmesh) || option("slab_nopackfuse")) return 1;
-    if (world < 1 || nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
-    const int nyl = nmesh / world;
-    if ((nyl & (nyl - 1)) || nyl > nmesh / 2) {
-        if (world != 1) return 1;
-    }
-    if (world == 1) return 1;    // one rank: the transpose is the identity in this layout, no send buffer is needed at all
-    if (x_begin < 0 || x_count < 1 || x_begin + x_count > nx_local) return fail("abacus_slab_fft_zy_pack_dev: planes [%d, +%d) of %d", x_begin, x_count, nx_local);
-    return fft_native_fused_zy_slab(mesh + (size_t)x_begin * nmesh * pitch_r(nmesh), nmesh, pitch_r(nmesh), x_count, (float *)send,
-                                    world, nx_local, x_begin);
-}
-
-int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world, int x_begin, int x_count) {
-    ABACUS_ENTER();
-    if (nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
-    if (x_begin < 0 || x_count < 1 || x_begin + x_count > nx_local) return fail("abacus_slab_pack_dev: planes [%d, +%d) of %d", x_begin, x_count, nx_local);
-    const int nyl = nmesh / world, pitch4 = pitch_r(nmesh) / 4;
-    const int grid = (int)std::min<int64_t>((int64_t)world * x_count * nyl, 256 * 32);
-    ABACUS_LAUNCH("slab_pack", slab_pack, dim3(grid), dim3(256), 0, (const float4 *)data, (float4 *)send, nmesh, nx_local,
-                  nyl, world, pitch4, x_begin, x_count);
+static int slab_fold(const char *who, int nmesh, int world, int *h) {
+    if (world < 1 || nmesh % (2 * world)) return fail("%s: nmesh %d must be divisible by twice the %d ranks", who, nmesh, world);
+    *h = nmesh / (2 * world);
     return 0;
 }
 
-int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int nx_local, int world) {
-    ABACUS_ENTER();
-    if (nmesh % world) return fail("slab path: nmesh must be divisible by the number of ranks");
+static int slab_pack_launch(const void *data, void *send, int nmesh, int world, int h, int64_t xsep, int p0, int pc) {
     const int nyl = nmesh / world, pitch4 = pitch_r(nmesh) / 4;
+    const int grid = (int)std::min<int64_t>((int64_t)world * 2 * pc * nyl, 256 * 32);
+    ABACUS_LAUNCH("slab_pack", slab_pack, dim3(grid), dim3(256), 0, (const float4 *)data, (float4 *)send, nmesh, h, xsep, nyl,
+                  world, pitch4, p0, pc);
+    return 0;
+}
+
+// z and y passes of the plane pairs [p0, p0 + pc) of a rank's folded slab: `mesh` is the first plane of the rank's first
+// half (global plane xg0), the second half (global plane xg0 + nmesh/2) starts xsep planes behind it, h = nmesh / (2 world)
+// pairs in all.  send == NULL: in place.  send != NULL: the result goes to the send buffer of the pencil transpose,
+// send[peer][s h + p][y_local][k] - written by the y pass itself where the fused form runs, by a pack pass otherwise.
+int abacus_slab_fft_zy_dev(float *mesh, void *send, int nmesh, int world, int64_t xsep, int xg0, int p0, int pc) {
+    ABACUS_ENTER();
+    if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    int h;
+    ABACUS_TRY(slab_fold("abacus_slab_fft_zy_dev", nmesh, world, &h));
+    if (p0 < 0 || pc < 1 || p0 + pc > h || xsep < h) return fail("abacus_slab_fft_zy_dev: pairs [%d, +%d) of %d, halves %lld planes apart", p0, pc, h, (long long)xsep);
+    const int pr = pitch_r(nmesh), nyl = nmesh / world;
+    const size_t plane = (size_t)nmesh * pr;
     if (slab_fused(nmesh)) {
-        const int grid = (int)std::min<int64_t>((int64_t)(nmesh / 2) * nyl, 256 * 32);
-        ABACUS_LAUNCH("slab_unpack", slab_unpack_bfly, dim3(grid), dim3(256), 0, (const float4 *)recv, (float4 *)out, nmesh,
-                      nx_local, nyl, pitch4);
-        return 0;
+        const bool ypack = send && !option("slab_nopackfuse") && world > 1 && !(nyl & (nyl - 1));
+        ABACUS_TRY(fft_native_fused_zy_slab(mesh, nmesh, pr, h, xsep, xg0, p0, pc, ypack ? (float *)send : nullptr, world));
+        if (ypack || !send) return 0;
+    } else {
+        ABACUS_TRY(fft_native_zy(mesh + (size_t)p0 * plane, nmesh, pr, pc));
+        ABACUS_TRY(fft_native_zy(mesh + ((size_t)xsep + p0) * plane, nmesh, pr, pc));
+        if (!send) return 0;
     }
-    const int grid = (int)std::min<int64_t>((int64_t)world * nx_local * nyl, 256 * 32);
-    ABACUS_LAUNCH("slab_unpack", slab_unpack, dim3(grid), dim3(256), 0, (const float4 *)recv, (float4 *)out, nmesh,
-                  nx_local, nyl, world, pitch4);
+    return slab_pack_launch(mesh, send, nmesh, world, h, xsep, p0, pc);
+}
+
+int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int world, int64_t xsep, int p0, int pc) {
+    ABACUS_ENTER();
+    int h;
+    ABACUS_TRY(slab_fold("abacus_slab_pack_dev", nmesh, world, &h));
+    if (p0 < 0 || pc < 1 || p0 + pc > h || xsep < h) return fail("abacus_slab_pack_dev: pairs [%d, +%d) of %d", p0, pc, h);
+    return slab_pack_launch(data, send, nmesh, world, h, xsep, p0, pc);
+}
+
+int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int world) {
+    ABACUS_ENTER();
+    int h;
+    ABACUS_TRY(slab_fold("abacus_slab_unpack_dev", nmesh, world, &h));
+    const int nyl = nmesh / world, pitch4 = pitch_r(nmesh) / 4;
+    const int grid = (int)std::min<int64_t>((int64_t)world * 2 * h * nyl, 256 * 32);
+    ABACUS_LAUNCH("slab_unpack", slab_unpack, dim3(grid), dim3(256), 0, (const float4 *)recv, (float4 *)out, nmesh, h, nyl,
+                  world, pitch4);
     return 0;
 }
 
@@ -1288,16 +1278,21 @@ int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void
     return run_bin(s, Lbox, kedges, Nk, muedges, Nmu, poles, Np, nullptr, nullptr, nullptr, nullptr, nullptr, raw_out);
 }
 
-// Last pass fused with the binning on a y-slab: `mesh` is the unpacked (y_local, x, k) block BEFORE its x pass (auto power
-// of one non-interlaced field).  Returns 0 with the raw sums in raw_out, 1 if this mesh / histogram is not served by the
-// fused last pass (the caller then runs abacus_slab_fft_x_dev + abacus_slab_bin_dev), < 0 on error.  put_geom: exactly one
-// rank passes 1 (the mesh-wide N_mode and sum |k| come from the cached geometry, not from the y-slab).
-int abacus_slab_xbin_dev(const void *mesh, int nmesh, int y0, int ny_local, double Lbox, const float *W_host,
+// Last pass fused with the binning on a y-slab BEFORE its x pass (auto power of one non-interlaced field).  from_transpose
+// = 1: `mesh` is the receive buffer of the pencil transpose of a `world`-rank run as it arrived, (peer, 2 h, y_local, k)
+// - with one rank the slab itself, in place -; 0: the unpacked (y_local, x, k) block.  Returns 0 with the raw sums in
+// raw_out, 1 if this mesh / histogram is not served by the fused last pass (the caller then runs abacus_slab_unpack_dev,
+// abacus_slab_fft_x_dev, abacus_slab_bin_dev), < 0 on error.  put_geom: exactly one rank passes 1 (the mesh-wide N_mode and
+// sum |k| come from the cached geometry, not from the y-slab).
+int abacus_slab_xbin_dev(const void *mesh, int nmesh, int world, int y0, int ny_local, double Lbox, const float *W_host,
                          const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
                          int put_geom, int from_transpose, void *raw_out) {
     ABACUS_ENTER();
     if (!slab_fused(nmesh) || option("pk_noxbin") || (nmesh != 1024 && nmesh != 2048)) return 1;
     if (from_transpose && option("slab_nounpackfuse")) return 1;
+    int h;
+    ABACUS_TRY(slab_fold("abacus_slab_xbin_dev", nmesh, world, &h));
+    if (from_transpose && (h & (h - 1))) return 1;
     const float *W_dev;
     ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
     BinArgs b;
@@ -1306,7 +1301,7 @@ int abacus_slab_xbin_dev(const void *mesh, int nmesh, int y0, int ny_local, doub
     if (!xbin2_supported(nmesh, b, W_dev != nullptr)) return 1;
     const double M = (double)nmesh * nmesh * nmesh;
     ABACUS_TRY(fft_x_bin_run((const float *)mesh, nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, y0, ny_local,
-                             put_geom ? 1 : 0, from_transpose ? 2 : 1));
+                             put_geom ? 1 : 0, from_transpose ? 2 : 1, world));
     HIP_TRY(hipMemcpyAsync(raw_out, g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;

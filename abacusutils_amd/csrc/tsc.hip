@@ -46,6 +46,8 @@ struct TileGeom {
     int64_t zstride;      // elements per z-row in memory (gz, or a padded pitch for the in-place R2C layout)
     int gxg, xoff;        // x-slab meshes: global x size (scale + periodic wrap) and global index of local plane 0;
                           // gxg == gx, xoff == 0 for a full mesh
+    int xoff2, xwin;      // folded slabs (two windows of xwin = gx / 2 planes each, back to back in memory): global index
+                          // of the second window's first plane; xoff2 < 0: one window of gx planes
     int shx, shy, shz;    // log2 of the tile shape where it is a power of two (the usual 16 x 16 x 32), else -1:
                           // cell -> tile by a shift instead of a runtime integer division (nine per particle and pass)
     int f4x, f4y, f4z;    // four consecutive (periodically wrapped) cells always lie in at most two tiles of this
@@ -66,11 +68,17 @@ __device__ __forceinline__ int wrapcell(int c, int g) {
     return c;
 }
 
-// global x cell -> local plane index of an x-slab mesh (-1: not held by this slab)
+// global x cell -> local plane index of an x-slab mesh (-1: not held by this slab).  Two windows: a plane both hold (their
+// ghost regions may overlap when the slabs are thin) belongs to the first, so every contribution is written exactly once
 __device__ __forceinline__ int xloc(int i, const TileGeom &g) {
-    int l = wrapcell(i, g.gxg) - g.xoff;
+    const int c = wrapcell(i, g.gxg);
+    int l = c - g.xoff;
     if (l < 0) l += g.gxg;
-    return l < g.gx ? l : -1;
+    if (g.xoff2 < 0) return l < g.gx ? l : -1;
+    if (l < g.xwin) return l;
+    l = c - g.xoff2;
+    if (l < 0) l += g.gxg;
+    return l < g.xwin ? g.xwin + l : -1;
 }
 
 template <typename PT>
@@ -854,16 +862,17 @@ struct ListCache {
     bool valid = false;
     const void *pos = nullptr;
     int64_t n = 0, zstride = 0, nentries = 0;
-    int gx = 0, gy = 0, gz = 0, gxg = 0, xoff = 0, cic = 0;
+    int gx = 0, gy = 0, gz = 0, gxg = 0, xoff = 0, xoff2 = -1, cic = 0;
     double box = 0;
     void *entries = nullptr;
 };
 ListCache g_lists;
 
-TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int TZ, int gxg, int xoff) {
+TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int TZ, int gxg, int xoff, int xoff2) {
     TileGeom g;
     g.gx = gx, g.gy = gy, g.gz = gz;
     g.gxg = gxg, g.xoff = xoff;
+    g.xoff2 = xoff2, g.xwin = xoff2 < 0 ? gx : gx / 2;
     g.tx = std::min(TX, gx), g.ty = std::min(TY, gy), g.tz = std::min(TZ, gz);
     g.ntx = (gx + g.tx - 1) / g.tx, g.nty = (gy + g.ty - 1) / g.ty, g.ntz = (gz + g.tz - 1) / g.tz;
     auto lg = [](int v) {
@@ -881,12 +890,13 @@ TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int 
 template <typename PT, typename GT, bool CIC>
 int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy, int gz, int64_t zstride, double box,
                 double offset, int wrap, int zero_grid, double norm, int *wrapped_out, int gxg = -1, int xoff = 0,
-                double sub = 1.0, int list_mode = 0) {
+                double sub = 1.0, int list_mode = 0, int xoff2 = -1) {
     if (gxg < 0) gxg = gx;
+    if (xoff2 >= 0 && (gx % 2 || gx / 2 > gxg)) return fail("tsc: two windows of %d planes in a mesh of %d", gx, gxg);
     if (gx < 1 || gy < 1 || gz < 1) return fail("tsc: empty mesh");
     if (gxg > 32767 || gy > 32767 || gz > 32767) return fail("tsc: mesh dimension > 32767 (int16 cell index of the reference)");
     constexpr int TX = 16, TY = 16, TZ = 32;   // 8192 float64 cells = 64 KiB of LDS -> two workgroups per CU
-    const TileGeom g = make_geom(gx, gy, gz, zstride, TX, TY, TZ, gxg, xoff);
+    const TileGeom g = make_geom(gx, gy, gz, zstride, TX, TY, TZ, gxg, xoff, xoff2);
     const int64_t ntiles64 = (int64_t)g.ntx * g.nty * g.ntz;
     if (ntiles64 > 0x7fffffff) return fail("tsc: too many tiles");
     const int ntiles = (int)ntiles64;
@@ -911,7 +921,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     const int ext = share ? 1 : 0;
     const bool reuse = share && list_mode == 2 && g_lists.valid && g_lists.pos == (const void *)pos && g_lists.n == n &&
                        g_lists.zstride == zstride && g_lists.gx == gx && g_lists.gy == gy && g_lists.gz == gz &&
-                       g_lists.gxg == gxg && g_lists.xoff == xoff && g_lists.cic == (CIC ? 1 : 0) && g_lists.box == box &&
+                       g_lists.gxg == gxg && g_lists.xoff == xoff && g_lists.xoff2 == xoff2 && g_lists.cic == (CIC ? 1 : 0) && g_lists.box == box &&
                        sizeof(PT) == 4;
     if (!reuse) g_lists.valid = false;   // every build below overwrites the buffers the cache points into
     if (reuse) {
@@ -998,7 +1008,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     if (share && list_mode == 1 && !reuse) {
         g_lists.valid = true;
         g_lists.pos = pos, g_lists.n = n, g_lists.zstride = zstride, g_lists.nentries = nentries_total;
-        g_lists.gx = gx, g_lists.gy = gy, g_lists.gz = gz, g_lists.gxg = gxg, g_lists.xoff = xoff, g_lists.cic = CIC ? 1 : 0;
+        g_lists.gx = gx, g_lists.gy = gy, g_lists.gz = gz, g_lists.gxg = gxg, g_lists.xoff = xoff, g_lists.xoff2 = xoff2, g_lists.cic = CIC ? 1 : 0;
         g_lists.box = box, g_lists.entries = entries;
     }
     const int dbg = option("dbg_tsc");
@@ -1093,16 +1103,16 @@ int tsc_deposit_f64pos(double *pos, int64_t n, const double *w, float *grid, int
     return deposit_dev<double, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
                                              nullptr, -1, 0, sub, 0);
 }
-// x-slab variant: `grid` holds planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh, ghosts included;
-// written as rho*norm - sub (sub = 1: the overdensity's "-1" in every cell; a ghost block is then added to its owner as
-// ghost + 1)
+// x-slab variant: `grid` holds planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh, ghosts included - or, with
+// xoff2 >= 0, two windows of nx_local / 2 planes each starting at xoff and xoff2 (folded slabs) -; written as
+// rho*norm - sub (sub = 1: the overdensity's "-1" in every cell; a ghost block is then added to its owner as ghost + 1)
 int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
-                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub) {
+                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub, int xoff2) {
     if (cic)
         return deposit_dev<float, float, true>(pos, n, w, grid, nx_local, nmesh, nmesh, zstride, box, offset, 0, 1, norm,
-                                               nullptr, nmesh, xoff, sub);
+                                               nullptr, nmesh, xoff, sub, 0, xoff2);
     return deposit_dev<float, float, false>(pos, n, w, grid, nx_local, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
-                                            nullptr, nmesh, xoff, sub);
+                                            nullptr, nmesh, xoff, sub, 0, xoff2);
 }
 int tsc_release_work() {
     g_lists.valid = false;

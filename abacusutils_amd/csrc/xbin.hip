@@ -45,10 +45,15 @@ struct XBinGeom {
     float inv_size;             // f32(1/M)
     const float *W;             // (n,) compensation window or nullptr
     int dbg;                    // ablation: 1 skip the transform, 2 skip the binning, 4 no histogram atomics, 8 no LDS reads in the binning
-    // fft_x_bin2 only - where the rows live: element (x, y, k) at data[x * xs + (y - y0) * ys + k] for the ny rows
-    // y0 <= y < y0 + ny of this launch (full mesh: xs = n * pitch_c, ys = pitch_c, ny = n; y-slab of the multi-GPU
-    // transform, layout (y_local, x, k): xs = pitch_c, ys = n * pitch_c)
-    int64_t xs, ys;
+    // fft_x_bin2 only - where the rows live.  Row i (0 <= i < n/2) of half s of x (s = 0: the sums of the first radix-2
+    // stage = even frequencies, s = 1: the twiddled differences = odd frequencies) of y-row y0 <= y < y0 + ny sits at
+    //   data[(i >> lgh) * ps + (s * h + (i & (h - 1))) * xs + (y - y0) * ys + k],   h = 1 << lgh
+    // full mesh (x, y, k): h = n/2, xs = n * pitch_c, ys = pitch_c, ny = n; y-slab (y_local, x, k): h = n/2, xs = pitch_c,
+    // ys = n * pitch_c; receive buffer of the pencil transpose of a W-rank run, (peer, 2 h, y_local, k) with h = n / (2 W):
+    // xs = ny * pitch_c, ys = pitch_c, ps = 2 h * xs - the folded slabs of slab_power.py, every peer's block holding its
+    // h sum rows, then its h difference rows
+    int64_t xs, ys, ps;
+    int lgh;
     int ny, y0;
     int put_geom;               // copy the cached N_mode / sum |k| into the accumulators (one rank of a slab run does)
 };
@@ -403,15 +408,13 @@ __global__ __launch_bounds__(256) void xbin_geometry(int n, int Nk, int Nmu, con
 // bin in registers and adds them to the LDS histogram when the bin changes (fine bins: every step or two; coarse bins:
 // once per column); !RUNS: one LDS atomic per pair and accumulator.  LDS histogram rows eb = 0 and Nk + 1 take what
 // lies outside the edges and are never read.
-// BFLY (y-slab of the multi-GPU transform, read straight from the receive buffer of the pencil transpose, layout (x, y_local,
-// k)): the first radix-2 DIF stage of the x transform - a(x) + a(x + n/2) and (a(x) - a(x + n/2)) exp(-2 pi i x / n) - is
-// applied while staging: a thread loads both rows of each of its eight pairs, the sums are transformed and binned as the
-// half of even frequencies, then the differences as the odd half.  No unpack pass, no second copy of the slab.
-template <int H, int C, int NP, bool COMP, int MU, bool RUNS, bool BFLY = false>
+// The rows of a tile may come straight from the receive buffer of a multi-GPU pencil transpose (XBinGeom: every peer's block
+// holds a run of h rows of either half): no unpack pass, no second copy of the slab.
+template <int H, int C, int NP, bool COMP, int MU, bool RUNS>
 __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restrict__ data, XBinGeom g, BinArgs b, XDesc d,
-                                                          const float2 *__restrict__ twH, const float2 *__restrict__ twN) {
+                                                          const float2 *__restrict__ twH) {
     constexpr int CP = colpitch_of<H>();
-    constexpr int NLD = (H * (C / 2)) / XB_THREADS * (BFLY ? 2 : 1);
+    constexpr int NLD = (H * (C / 2)) / XB_THREADS;
     static_assert((H * (C / 2)) % XB_THREADS == 0 && wave_local(H), "tile shape");
     constexpr int RUN = (H / 2) / 64;                     // values of |i| per lane (8, 4): a run shares its pad term
     static_assert(RUN == 8 || RUN == 4, "run length");
@@ -444,58 +447,36 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     const int n = g.n;
     const int ntile_c = (g.kzlen + C - 1) / C;
     const int64_t S = g.xs;
-    const int n_outer = (BFLY ? 1 : 2) * g.ny;
+    const int n_outer = 2 * g.ny;
     const float inv2 = g.inv_size * g.inv_size;
     const int sh = d.sh;
     const unsigned int *lut0 = lut - d.off;
 
     v4f regs[NLD];
+    const int lgh = g.lgh, hmask = (1 << lgh) - 1;
     auto tile_ptr = [&](int o, int ct) {
         const int xh = o >= g.ny ? 1 : 0, yr = o - xh * g.ny;
-        return data + (int64_t)xh * H * S + (int64_t)yr * g.ys + ct * C;
+        return data + ((int64_t)xh << lgh) * S + (int64_t)yr * g.ys + ct * C;
     };
     auto prefetch = [&](const float2 *p) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int e = q * XB_THREADS + tid;
             const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
-            gload16_async(regs[q], p + (int64_t)y * S + c2);
-            if constexpr (BFLY) gload16_async(regs[8 + q], p + (int64_t)(y + H) * S + c2);
+            gload16_async(regs[q], p + (int64_t)(y >> lgh) * g.ps + (int64_t)(y & hmask) * S + c2);
         }
     };
     // registers -> LDS THROUGH the first radix-8 pass: load q of a thread is row tid / (C/2) + q * H/8 of its column pair,
     // i.e. the eight loads are the inputs r = 0..7 of butterfly j = tid / (C/2) of the first DIF pass (sub-length H):
     // the staged tile is never written raw and read back (one LDS round trip of the tile less)
     static_assert((H * (C / 2)) / XB_THREADS == 8 && H / 8 == XB_THREADS / (C / 2), "the loads of a thread form one radix-8 butterfly per column");
-    // half: BFLY only - 0 stages the sums of the row pairs and leaves the twiddled differences in regs[0..8) (the upper
-    // eight registers are free from then on: 32 values stay live across the first half's work, not 64), 1 stages those.
-    // The eight twiddles exp(-2 pi i x / n) of the thread's rows x = j + q H/8 are re-read per tile (a 16-KB table that
-    // lives in the L1; no prefetch is outstanding at this point, so the ordinary loads wait for nothing else)
-    auto stage = [&](int half = 0) {
+    auto stage = [&]() {
         const int c2 = (tid % (C / 2)) * 2, jb = tid / (C / 2);
         float2 u[8], w[8];
-        if constexpr (!BFLY) {
 #pragma unroll
-            for (int q = 0; q < NLD; q++) touch(regs[q]);
+        for (int q = 0; q < NLD; q++) touch(regs[q]);
 #pragma unroll
-            for (int q = 0; q < 8; q++) u[q] = make_float2(regs[q].x, regs[q].y), w[q] = make_float2(regs[q].z, regs[q].w);
-        } else if (half == 0) {
-#pragma unroll
-            for (int q = 0; q < NLD; q++) touch(regs[q]);
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const float2 tx = twN[jb + q * (H / 8)];
-                const v4f a = regs[q], bb = regs[8 + q];
-                u[q] = make_float2(a.x + bb.x, a.y + bb.y), w[q] = make_float2(a.z + bb.z, a.w + bb.w);
-                const float2 d0 = cmul(make_float2(a.x - bb.x, a.y - bb.y), tx), d1 = cmul(make_float2(a.z - bb.z, a.w - bb.w), tx);
-                v4f dd;
-                dd.x = d0.x, dd.y = d0.y, dd.z = d1.x, dd.w = d1.y;
-                regs[q] = dd;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; q++) u[q] = make_float2(regs[q].x, regs[q].y), w[q] = make_float2(regs[q].z, regs[q].w);
-        }
+        for (int q = 0; q < 8; q++) u[q] = make_float2(regs[q].x, regs[q].y), w[q] = make_float2(regs[q].z, regs[q].w);
         dft<8>(u);
         dft<8>(w);
 #pragma unroll
@@ -626,49 +607,23 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
         }
     };
     __syncthreads();
-    if constexpr (!BFLY) {
-        if (og < n_og) {
-            prefetch(tile_ptr(og * ostep + grp, ct));
-            wait_vmcnt<0>();
+    if (og < n_og) {
+        prefetch(tile_ptr(og * ostep + grp, ct));
+        wait_vmcnt<0>();
+        stage();
+        for (;;) {
+            __syncthreads();
+            const int o_cur = og * ostep + grp, ct_cur = ct;
+            og += dg, ct += dc;
+            if (ct >= ntile_c) ct -= ntile_c, og++;
+            const bool has_next = og < n_og;
+            if (has_next) prefetch(tile_ptr(og * ostep + grp, ct));
+            const int xh = o_cur >= g.ny ? 1 : 0;
+            process(xh, g.y0 + o_cur - xh * g.ny, ct_cur);
+            if (!has_next) break;
+            __syncthreads();     // every wave is done with the tile
+            wait_vmcnt<0>();     // no stores in this kernel: the prefetch is all that is outstanding
             stage();
-            for (;;) {
-                __syncthreads();
-                const int o_cur = og * ostep + grp, ct_cur = ct;
-                og += dg, ct += dc;
-                if (ct >= ntile_c) ct -= ntile_c, og++;
-                const bool has_next = og < n_og;
-                if (has_next) prefetch(tile_ptr(og * ostep + grp, ct));
-                const int xh = o_cur >= g.ny ? 1 : 0;
-                process(xh, g.y0 + o_cur - xh * g.ny, ct_cur);
-                if (!has_next) break;
-                __syncthreads();     // every wave is done with the tile
-                wait_vmcnt<0>();     // no stores in this kernel: the prefetch is all that is outstanding
-                stage();
-            }
-        }
-    } else {
-        // one (y-row, column tile) per trip, both halves of x from one set of loads: sums, then differences.  The loads of
-        // the next trip are issued once the differences have left the registers and fly during the second half's work
-        if (og < n_og) {
-            prefetch(data + (int64_t)(og * ostep + grp) * g.ys + ct * C);
-            wait_vmcnt<0>();
-            for (;;) {
-                const int o_cur = og * ostep + grp, ct_cur = ct;
-                stage(0);
-                __syncthreads();
-                process(0, g.y0 + o_cur, ct_cur);
-                __syncthreads();
-                stage(1);
-                og += dg, ct += dc;
-                if (ct >= ntile_c) ct -= ntile_c, og++;
-                const bool has_next = og < n_og;
-                if (has_next) prefetch(data + (int64_t)(og * ostep + grp) * g.ys + ct * C);
-                __syncthreads();
-                process(1, g.y0 + o_cur, ct_cur);
-                if (!has_next) break;
-                __syncthreads();
-                wait_vmcnt<0>();
-            }
         }
     }
     __syncthreads();
@@ -860,25 +815,25 @@ int xdesc_get(int n, int Nk, int Nmu, const float *h_e2, const float *d_ke, cons
     return 0;
 }
 
-template <int H, int C, int NP, bool COMP, int MU, bool BFLY = false>
+template <int H, int C, int NP, bool COMP, int MU>
 int launch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const XDesc &d, size_t lds) {
-    const bool runs = BFLY || option("pk_xbin_pairs") == 0;
-    auto kern = runs ? fft_x_bin2<H, C, NP, COMP, MU, true, BFLY> : fft_x_bin2<H, C, NP, COMP, MU, false, false>;
+    const bool runs = option("pk_xbin_pairs") == 0;
+    auto kern = runs ? fft_x_bin2<H, C, NP, COMP, MU, true> : fft_x_bin2<H, C, NP, COMP, MU, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, XB_THREADS, lds));
-    const int64_t ntiles = (int64_t)(BFLY ? 1 : 2) * g.ny * ((g.kzlen + C - 1) / C);
+    const int64_t ntiles = (int64_t)2 * g.ny * ((g.kzlen + C - 1) / C);
     const unsigned int grid = (unsigned int)std::min<int64_t>(ntiles, (int64_t)fft_num_cus() * std::max(per_cu, 1));
-    const float2 *tw = fft_twiddles(H), *twn = fft_twiddles(2 * H);
-    if (!tw || !twn) return -1;
-    ABACUS_LAUNCH("fft_x_bin", kern, dim3(grid), dim3(XB_THREADS), lds, data, g, b, d, tw, twn);
+    const float2 *tw = fft_twiddles(H);
+    if (!tw) return -1;
+    ABACUS_LAUNCH("fft_x_bin", kern, dim3(grid), dim3(XB_THREADS), lds, data, g, b, d, tw);
     return 0;
 }
 
-template <int H, int C, bool BFLY = false>
+template <int H, int C>
 int dispatch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const XDesc &d, size_t lds) {
 #define XB2(NP, MU)                                                                  \
-    (g.W ? launch_xbin2<H, C, NP, true, MU, BFLY>(data, g, b, d, lds) : launch_xbin2<H, C, NP, false, MU, BFLY>(data, g, b, d, lds))
+    (g.W ? launch_xbin2<H, C, NP, true, MU>(data, g, b, d, lds) : launch_xbin2<H, C, NP, false, MU>(data, g, b, d, lds))
 #define XB2_MU(NP) (b.Nmu <= 1 ? XB2(NP, 1) : b.Nmu <= 4 ? XB2(NP, 4) : XB2(NP, 8))
     switch (b.Np) {
         case 0: return XB2_MU(0);
@@ -950,22 +905,30 @@ int xbin_release() {
 }
 
 // `mesh` holds the fused transform after its z and y passes (fft_native_r2c_fused_zy); bins |delta_k|^2 of every mode
-// into the accumulators of `b` (zeroed by the caller).  ny_local > 0: `mesh` is the y-slab [y0, y0 + ny_local) of a
-// multi-GPU transform in the layout (y_local, x, k) behind the pencil transpose (slab_unpack_bfly has applied the first
-// radix-2 stage of x); only the cached-geometry kernel serves it, and `put_geom` says whether this rank contributes the
-// mesh-wide N_mode / sum |k| to the histogram that is all-reduced afterwards.
+// into the accumulators of `b` (zeroed by the caller).  layout 0: the whole mesh (x, y, k); 1: the y-slab [y0, y0 +
+// ny_local) of a multi-GPU transform unpacked to (y_local, x, k); 2: the same y-slab as the pencil transpose of a
+// `world`-rank run delivers it, (peer, 2 h, y_local, k), h = n / (2 world) (folded slabs: each peer sends the sum rows, then
+// the difference rows of its h plane pairs; with one rank that IS the whole mesh in place).  Only the cached-geometry kernel
+// serves the slab forms, and `put_geom` says whether this rank contributes the mesh-wide N_mode / sum |k| to the
+// histogram that is all-reduced afterwards.
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
-                  int y0, int ny_local, int put_geom, int layout) {
+                  int y0, int ny_local, int put_geom, int layout, int world) {
     XBinGeom g;
     g.n = n, g.kzlen = n / 2 + 1, g.pitch_c = pitch_r / 2, g.inv_size = inv_size, g.W = W_dev, g.dbg = dbg;
-    // layout 0: the whole mesh (x, y, k) behind the fused z / y passes; 1: a y-slab (y_local, x, k) behind the unpack with
-    // the x butterfly; 2: a y-slab as the pencil transpose delivers it, (x, y_local, k), the x butterfly applied here (BFLY)
     const bool slab = layout != 0;
     if (slab && ny_local < 1) return fail("fft_x_bin: empty y-slab");
     g.ny = slab ? ny_local : n, g.y0 = slab ? y0 : 0, g.put_geom = slab ? put_geom : 1;
+    int h = n / 2;
+    g.ps = 0;
     if (layout == 1) g.xs = g.pitch_c, g.ys = (int64_t)n * g.pitch_c;
-    else if (layout == 2) g.xs = (int64_t)g.ny * g.pitch_c, g.ys = g.pitch_c;
-    else g.xs = (int64_t)n * g.pitch_c, g.ys = g.pitch_c;
+    else if (layout == 2) {
+        if (world < 1 || (n / 2) % world || ((n / 2 / world) & (n / 2 / world - 1)))
+            return fail("fft_x_bin: %d ranks do not fold a mesh of %d into power-of-two runs of planes", world, n);
+        h = n / 2 / world;
+        g.xs = (int64_t)g.ny * g.pitch_c, g.ys = g.pitch_c, g.ps = 2 * (int64_t)h * g.xs;
+    } else g.xs = (int64_t)n * g.pitch_c, g.ys = g.pitch_c;
+    g.lgh = 0;
+    while ((1 << g.lgh) < h) g.lgh++;
     const float2 *data = reinterpret_cast<const float2 *>(mesh);
     if (n != 2048 && n != 1024) return fail("fft_x_bin: unsupported mesh %d", n);
     const int C = n == 2048 ? 8 : 16;
@@ -976,10 +939,6 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
     g_last_gen = x ? 2 : 1;
     if (x) {
         const XDesc d = x->dev();
-        if (layout == 2) {
-            if (n == 2048) return dispatch_xbin2<1024, 8, true>(data, g, b, d, xbin2_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, d.ncell, comp));
-            return dispatch_xbin2<512, 16, true>(data, g, b, d, xbin2_lds_bytes<512, 16>(n, b.Nk, b.Nmu, d.ncell, comp));
-        }
         if (n == 2048) return dispatch_xbin2<1024, 8>(data, g, b, d, xbin2_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, d.ncell, comp));
         return dispatch_xbin2<512, 16>(data, g, b, d, xbin2_lds_bytes<512, 16>(n, b.Nk, b.Nmu, d.ncell, comp));
     }

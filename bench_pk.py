@@ -171,9 +171,10 @@ def cpu_baseline_pk(L, gpu_ms=None):
 
 
 def bench_pk_slab(args, dist):
-    """strong scaling of ONE nmesh^3 P(k) over the N GPUs: x-slab deposit with ghost planes, ring exchange, z/y passes,
-    all-to-all pencil transpose (chunked, overlapping the passes), x pass, y-slab binning, all-reduce
-    (abacusutils_amd/analysis/slab_power.py).  Particles (args.npk in total, uniform, generated inside each rank's slab)
+    """strong scaling of ONE nmesh^3 P(k) over the N GPUs: deposit into the rank's two folded slabs (planes x and x + n/2 on
+    one rank) with ghost planes, ring exchange, fused z / y passes writing the send buffer, all-to-all pencil transpose
+    (chunked, overlapping the passes), last pass + binning from the receive buffer, all-reduce
+    (abacusutils_amd/analysis/slab_power.py).  Particles (args.npk in total, uniform, generated inside each rank's slabs)
     are resident in HBM; collectives are RCCL through the C ABI (dist.comm)."""
     from abacusutils_amd import _lib
     from abacusutils_amd.analysis import slab_power as sp
@@ -186,9 +187,11 @@ def bench_pk_slab(args, dist):
     n_local = ntot // W
     rng = np.random.default_rng(300 + r)
     pos = rng.random((n_local, 3), dtype=np.float32)
-    pos[:, 0] = (pos[:, 0] + np.float32(r)) * np.float32(L / W)
+    # rank r owns the slabs r and r + W of the 2 W slabs of width L / (2 W): first half of the particles in one, rest in the other
+    slab = np.where(np.arange(n_local) < n_local // 2, r, r + W).astype(np.float32)
+    pos[:, 0] = (pos[:, 0] * np.float32(0.99999) + slab) * np.float32(L / (2 * W))   # clear of the upper edge in float32
     pos[:, 1:] *= np.float32(L)
-    np.minimum(pos[:, 0], np.nextafter(np.float32((r + 1) * L / W), np.float32(0)), out=pos[:, 0])
+    assert np.array_equal(sp.slab_owner(pos[:, 0], L, W, True), np.full(n_local, r))
     dpos = _lib.DeviceArray(pos)
     kw = dict(kbins=min(512, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste='TSC', nmesh=nmesh,
               compensated=False, interlaced=False, poles=[0, 2, 4], n_total=n_local * W)
@@ -210,7 +213,7 @@ def bench_pk_slab(args, dist):
     out = {'metric': f'wall-clock of one {nmesh}^3 TSC+FFT P(k) slab-decomposed over {W} GPUs', 'value': dt * 1e3,
            'unit': 'ms', 'n_gpus': W, 'rccl_ranks': W if dist.comm is not None else 0, 'steps': steps, 'scaling': 'strong',
            'higher_is_better': False, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': f'{n_local * W:.0e} uniform particles in x-slabs, nmesh {nmesh}, TSC, non-interlaced, '
+           'config': {'workload': f'{n_local * W:.0e} uniform particles in folded x-slabs, nmesh {nmesh}, TSC, non-interlaced, '
                                   'RCCL through the C ABI: ring send/recv of ghost planes, chunked all-to-all of the '
                                   'pencil transpose (grouped ncclSend/ncclRecv), all-reduce of the histogram'},
            'bytes_sent_per_rank_per_step': sent,

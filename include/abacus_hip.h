@@ -289,24 +289,36 @@ int abacus_power_xbin_generation(void);
  * calc_power: x-slab mesh decomposition, ghost-plane exchange-add, local z/y FFT passes, all-to-all pencil transpose,
  * x FFT pass and binning on y-slabs, all-reduce of the (k, mu) histogram.  The collectives are the
  * abacus_comm_* entry points below (RCCL); these entry points are the device-side pieces.
- * All pointers are DEVICE pointers; nmesh must be a power of two in [64, 2048] and divisible by the number of ranks.
+ * All pointers are DEVICE pointers; nmesh must be a power of two in [64, 2048] and divisible by twice the number of ranks.
  * Mesh rows have abacus_slab_pitch(nmesh) floats (128-B aligned rows; complex rows of pitch/2).
  */
 int abacus_slab_pitch(int nmesh);
-/* deposit into planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh as rho*norm - sub (ghost planes included).
+/* deposit into planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh as rho*norm - sub (ghost planes included);
+ * xoff2 >= 0: TWO windows of nx_local planes each, starting at xoff and xoff2 and stored back to back (the two slabs of a
+ * rank's folded pair with their ghosts) - a plane both windows hold receives its deposits in the first.  Particles whose
+ * clouds lie outside are skipped.
  * sub = 1: every cell already carries the "-1" of the overdensity (normalize_field, power_spectrum.py:860-901) - a ghost
  * block is then added to its owner as `ghost + 1` (abacus_slab_axpy_dev with add = 1) and no pass over the mesh is spent
- * on the subtraction; nx_local == nmesh with xoff == 0 is the whole periodic mesh (one rank: no ghosts at all) */
-int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int nx_local,
+ * on the subtraction; xoff2 < 0 and nx_local == nmesh with xoff == 0 is the whole periodic mesh (one rank: no ghosts) */
+int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int xoff2, int nx_local,
                             double Lbox, double offset, double norm, int paste, double sub);
 /* dst[i] += src[i] + add  (ghost-plane accumulation; a constant alone with src == NULL) */
 int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add);
-/* z and y passes of the 3-D R2C FFT on nx_local owned planes, in place */
-int abacus_slab_fft_zy_dev(float *mesh, int nmesh, int nx_local);
-/* (x_local, y, k) -> send[p][x_local][y_local][k] for the planes [x_begin, x_begin + x_count) of the slab (a chunk of
- * the pencil transpose), and recv[r][x_local][y_local][k] -> (y_local, x, k) */
-int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int nx_local, int world, int x_begin, int x_count);
-int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int nx_local, int world);
+/* FOLDED SLABS.  With W ranks the mesh is cut into 2 W slabs of h = nmesh / (2 W) planes and rank r owns slabs r and
+ * r + W: the planes x and x + nmesh/2 of a pair sit on ONE rank, so the fused form of the transform (first radix-2 stage of
+ * y and x inside the z pass, fft.hip) runs on a slab exactly as on the whole mesh.  A rank's buffer holds its two halves
+ * `xsep` planes apart (ghost planes in between).
+ *
+ * z and y passes of the plane pairs [p0, p0 + pc) of the rank's h pairs: `mesh` = first plane of the first half (global
+ * plane xg0; the second half is global plane xg0 + nmesh/2).  send == NULL: in place.  send != NULL: the result goes to the
+ * send buffer of the pencil transpose, send[peer][s h + p][y_local][k] (s = 0 / 1: first / second half) - written by the y
+ * pass itself where the fused form runs with more than one rank, by a pack pass otherwise */
+int abacus_slab_fft_zy_dev(float *mesh, void *send, int nmesh, int world, int64_t xsep, int xg0, int p0, int pc);
+/* the pack pass alone (pairs [p0, p0 + pc)), and recv[q][s h + p][y_local][k] -> out[y_local][s nmesh/2 + q h + p][k]: row
+ * s nmesh/2 + i of x is plane i of half s - the plane itself in the plain form; in the fused form the sum (s = 0) or the
+ * twiddled difference (s = 1) of planes i and i + nmesh/2, i.e. the inputs of the two nmesh/2-point transforms */
+int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int world, int64_t xsep, int p0, int pc);
+int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int world);
 /* x pass on a y-slab in the (y_local, x, k) layout, in place */
 int abacus_slab_fft_x_dev(float *data, int nmesh, int ny_local);
 /* raw (un-normalised) bin sums of a y-slab: counts u64[Nk*Nmu], sum P f64[Nk*Nmu], sum k f64[Nk*Nmu],
@@ -316,28 +328,24 @@ int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void
                         const double *muedges, int Nmu, const int64_t *poles, int Np, void *raw_out);
 int64_t abacus_bin_raw_bytes(int Nk, int Nmu, const int64_t *poles, int Np);
 /* 1 if the slab entry points above run the FUSED form of the transform for this mesh (nmesh 1024 / 2048, like the single-GPU
- * path: first radix-2 stage of y inside the z pass, of x inside the unpack, n/2-point column passes with 128-B row
- * segments; rows of x and y then come out in the order f = 2 (r mod n/2) + (r div n/2), which abacus_slab_bin_dev and
- * abacus_slab_xbin_dev undo); needs an even number of planes per abacus_slab_fft_zy_dev call */
+ * path: n/2-point column passes with 128-B row segments; rows of x and y then come out in the order
+ * f = 2 (r mod n/2) + (r div n/2), which abacus_slab_bin_dev and abacus_slab_xbin_dev undo) */
 int abacus_slab_fused(int nmesh);
 /* last x pass FUSED with the binning on a y-slab (auto power of one non-interlaced field): replaces abacus_slab_fft_x_dev +
- * abacus_slab_bin_dev.  from_transpose = 0: `mesh` is the unpacked (y_local, x, k) block (abacus_slab_unpack_dev has applied
- * the first radix-2 stage of x); from_transpose = 1: `mesh` is the RECEIVE buffer of the pencil transpose as it arrived,
- * layout (x, y_local, k) - no unpack at all, the kernel loads rows x and x + n/2 together and applies that stage while
- * staging (one rank: the slab itself after its z / y passes).  Returns 0 (raw sums in the host buffer raw_out), 1 when this
- * mesh / histogram is not served (use the two-step form), < 0 on error.  put_geom = 1 on exactly one rank: N_mode and
- * sum |k| are mesh-wide quantities taken from the cached geometry of (nmesh, edges), not from the y-slab */
-int abacus_slab_xbin_dev(const void *mesh, int nmesh, int y0, int ny_local, double Lbox, const float *W_host,
+ * abacus_slab_bin_dev.  from_transpose = 0: `mesh` is the unpacked (y_local, x, k) block; from_transpose = 1: `mesh` is the
+ * RECEIVE buffer of the pencil transpose of a `world`-rank run as it arrived, (peer, 2 h, y_local, k) - no unpack at all,
+ * the kernel gathers the rows of a column from the peers' blocks while staging (one rank: the slab itself after its z / y
+ * passes).  Returns 0 (raw sums in the host buffer raw_out), 1 when this mesh / histogram is not served (use the two-step
+ * form), < 0 on error.  put_geom = 1 on exactly one rank: N_mode and sum |k| are mesh-wide quantities taken from the
+ * cached geometry of (nmesh, edges), not from the y-slab */
+int abacus_slab_xbin_dev(const void *mesh, int nmesh, int world, int y0, int ny_local, double Lbox, const float *W_host,
                          const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
                          int put_geom, int from_transpose, void *raw_out);
-/* z and y passes of planes [x_begin, x_begin + x_count) of the slab at `mesh` with the y pass writing the send buffer of the
- * pencil transpose directly (fused form, more than one rank): replaces abacus_slab_fft_zy_dev + abacus_slab_pack_dev of that
- * chunk.  Returns 1 when not served that way (call the two) */
-int abacus_slab_fft_zy_pack_dev(float *mesh, void *send, int nmesh, int nx_local, int world, int x_begin, int x_count);
 /* particle routing on the device: stable bucket sort of (pos (n,3) float32, w or NULL) by the rank that owns the wrapped x
- * (x-slabs of width Lbox / world); counts[world] on the host.  The blocks then travel with abacus_comm_all_to_all_v. */
-int abacus_slab_route_dev(const float *pos, int64_t n, const float *w, double Lbox, int world, float *pos_out, float *w_out,
-                          int64_t *counts);
+ * (fold = 0: x-slabs of width Lbox / world; fold = 1: the folded slabs above, rank = slab mod world of 2 world slabs);
+ * counts[world] on the host.  The blocks then travel with abacus_comm_all_to_all_v. */
+int abacus_slab_route_dev(const float *pos, int64_t n, const float *w, double Lbox, int world, int fold, float *pos_out,
+                          float *w_out, int64_t *counts);
 /* bin_kmu's normalisation (analysis/power_spectrum.py:276-293, 789-792) of reduced raw sums; host only */
 int abacus_bin_finalize(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *poles, int Np, float *power,
                         int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg);

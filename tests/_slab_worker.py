@@ -43,15 +43,15 @@ def main():
         from gloo_comm import GlooSlabComm
         comm = GlooSlabComm(force_collectives=a.force_collectives)
     L = 500.0
-    # every rank draws the same catalogue and keeps an arbitrary half: route_particles moves them to their slabs
+    # every rank draws the same catalogue and keeps an arbitrary half: route_particles moves them to their (folded) slabs
     pos = synth_positions(a.n, L, seed=11)
     w = np.random.default_rng(5).random(a.n, dtype=np.float32) + np.float32(0.5)
     mine = slice(comm.rank, None, comm.world)
     if a.rccl:   # device-resident particles, routed without leaving HBM
         p1, w1 = sp.route_particles(_lib.DeviceArray(np.ascontiguousarray(pos[mine])),
-                                    _lib.DeviceArray(np.ascontiguousarray(w[mine])), L, comm)
+                                    _lib.DeviceArray(np.ascontiguousarray(w[mine])), L, comm, fold=True)
     else:
-        p1, w1 = sp.route_particles(pos[mine], w[mine], L, comm)
+        p1, w1 = sp.route_particles(pos[mine], w[mine], L, comm, fold=True)
     kw = dict(kbins=a.kbins, mubins=4, paste='TSC', nmesh=a.nmesh, compensated=bool(a.compensated),
               interlaced=bool(a.interlaced), poles=[0, 2, 4])
     if a.backend == 'numpy':
@@ -66,7 +66,8 @@ def main():
     extra = {}
     if a.cross:
         pos2 = synth_positions(a.n // 2, L, seed=12)
-        p2, _ = sp.route_particles(_lib.DeviceArray(np.ascontiguousarray(pos2[mine])) if a.rccl else pos2[mine], None, L, comm)
+        p2, _ = sp.route_particles(_lib.DeviceArray(np.ascontiguousarray(pos2[mine])) if a.rccl else pos2[mine], None, L, comm,
+                                    fold=True)
         extra = dict(pos2=p2)
     t = sp.calc_power_slab(p1, L, comm=comm, backend=backend, w=w1, **kw, **extra)
     np.savez(f'{a.out}.rank{comm.rank}.npz', n_local=p1.shape[0], **{k: np.asarray(t[k]) for k in t.keys()})

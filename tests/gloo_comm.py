@@ -37,9 +37,9 @@ class GlooSlabComm:
         for q in reqs:
             q.wait()
 
-    def ring_exchange(self, backend, buf, left_off, right_off, recv, n):
+    def ring_exchange(self, backend, buf, left_off, right_off, recv, n, recv_off=0):
         """send buf[left_off:+n] to rank-1 and buf[right_off:+n] to rank+1;
-        recv[0:n] <- what rank+1 sent left, recv[n:2n] <- what rank-1 sent right"""
+        recv[recv_off:+n] <- what rank+1 sent left, the next n <- what rank-1 sent right"""
         if not self.collective:   # the ring neighbour is this rank (periodic box): callers add the ghosts in place
             raise RuntimeError('ring_exchange needs an initialised process group')
         import torch
@@ -58,8 +58,8 @@ class GlooSlabComm:
                    self.dist.P2POp(self.dist.irecv, r_from_left, left, self.group)]
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()
-        recv.set(0, r_from_right.numpy())
-        recv.set(n, r_from_left.numpy())
+        recv.set(recv_off, r_from_right.numpy())
+        recv.set(recv_off + n, r_from_left.numpy())
 
     def all_to_all(self, backend, send, recv, n_total):
         self.all_to_all_piece(backend, send, recv, n_total // self.world, 0, n_total // self.world)
@@ -78,8 +78,8 @@ class GlooSlabComm:
     def join(self):
         pass
 
-    def transpose_chunks(self, nxl):
-        return 2 if (self.collective and nxl % 2 == 0 and nxl >= 4) else 1   # the chunked code path, in the CPU tests too
+    def transpose_chunks(self, npair):
+        return 2 if (self.collective and npair % 2 == 0 and npair >= 4) else 1   # the chunked code path, in the CPU tests too
 
     def all_reduce_raw(self, raw, n_u64):
         """sum the raw histogram over ranks: first n_u64 entries are uint64 counts, the rest float64"""

@@ -34,7 +34,7 @@ class NumpySlabBackend:
     def upload_particles(self, pos, w):
         return (np.array(pos, dtype=np.float32), None if w is None else np.asarray(w, dtype=np.float32))
 
-    def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste, sub=0.0):
+    def deposit(self, particles, mesh, nmesh, xoff, nx_total, Lbox, offset, norm, paste, sub=0.0, xoff2=-1):
         assert paste == 0, 'CPU stand-in: TSC only'
         pos, w = particles
         full = np.zeros((nmesh,) * 3, dtype=np.float32)
@@ -43,10 +43,16 @@ class NumpySlabBackend:
             oracle.wrap_inplace(p, Lbox)
             oracle.tsc_scatter(p, full, Lbox, weights=w, offset=offset)
         pitch = self.pitch(nmesh)
-        win = np.zeros((nx_total, nmesh, pitch), dtype=np.float32)
-        win[:, :, :nmesh] = -np.float32(sub)           # window planes past one period receive no deposit: 0 * norm - sub
-        for i in range(min(nx_total, nmesh)):          # plane i of the window = global plane (xoff + i) mod n
-            win[i, :, :nmesh] = full[(xoff + i) % nmesh] * np.float32(norm) - np.float32(sub)
+        nwin = 1 if xoff2 < 0 else 2
+        win = np.zeros((nwin * nx_total, nmesh, pitch), dtype=np.float32)
+        win[:, :, :nmesh] = -np.float32(sub)           # planes that receive no deposit: 0 * norm - sub
+        taken = set()                                  # a plane both windows hold receives its deposits in the first
+        for k, x0 in enumerate((xoff, xoff2)[:nwin]):
+            for i in range(nx_total):                  # plane i of the window = global plane (x0 + i) mod n
+                gp = (x0 + i) % nmesh
+                if gp not in taken:
+                    taken.add(gp)
+                    win[k * nx_total + i, :, :nmesh] = full[gp] * np.float32(norm) - np.float32(sub)
         mesh.a[:win.size] = win.ravel()
 
     def axpy(self, dst, dst_off, src, src_off, n, add):
@@ -63,29 +69,38 @@ class NumpySlabBackend:
         pitch = self.pitch(nmesh)
         return buf.a[off:off + nx * nmesh * pitch].view(np.complex64).reshape(nx, nmesh, pitch // 2)
 
-    def fft_zy(self, mesh, off, nmesh, nxl):
-        r = self._real(mesh, off, nmesh, nxl)[:, :, :nmesh].astype(np.float64)
-        f = np.fft.fft(np.fft.rfft(r, axis=2), axis=1)
-        c = self._cplx(mesh, off, nmesh, nxl)
-        c[:] = 0
-        c[:, :, :nmesh // 2 + 1] = f.astype(np.complex64)
+    def fft_zy(self, mesh, off, send, nmesh, world, xsep, xg0, p0, pc):
+        """plain form: z and y transforms of the planes [p0, p0 + pc) of either half, then (send given) the pack step"""
+        plane = nmesh * self.pitch(nmesh)
+        for s_ in (0, 1):
+            o = off + (s_ * xsep + p0) * plane
+            r = self._real(mesh, o, nmesh, pc)[:, :, :nmesh].astype(np.float64)
+            f = np.fft.fft(np.fft.rfft(r, axis=2), axis=1)
+            c = self._cplx(mesh, o, nmesh, pc)
+            c[:] = 0
+            c[:, :, :nmesh // 2 + 1] = f.astype(np.complex64)
+        if send is not None:
+            self.pack(mesh, off, send, nmesh, world, xsep, p0, pc)
 
-    def pack(self, mesh, off, send, nmesh, nxl, world, x0=0, nxc=None):
-        c = self._cplx(mesh, off, nmesh, nxl)
-        nyl = nmesh // world
-        pc = c.shape[2]
-        x1 = nxl if nxc is None else x0 + nxc
-        s = send.a[:nxl * nmesh * pc * 2].view(np.complex64).reshape(world, nxl, nyl, pc)
-        for p in range(world):
-            s[p, x0:x1] = c[x0:x1, p * nyl:(p + 1) * nyl, :]
+    def pack(self, mesh, off, send, nmesh, world, xsep, p0, pc):
+        h, nyl = nmesh // (2 * world), nmesh // world
+        plane = nmesh * self.pitch(nmesh)
+        pcx = self.pitch(nmesh) // 2
+        s = send.a[:2 * h * nmesh * pcx * 2].view(np.complex64).reshape(world, 2 * h, nyl, pcx)
+        for s_ in (0, 1):
+            c = self._cplx(mesh, off + (s_ * xsep + p0) * plane, nmesh, pc)
+            for q in range(world):
+                s[q, s_ * h + p0:s_ * h + p0 + pc] = c[:, q * nyl:(q + 1) * nyl, :]
 
-    def unpack(self, recv, out, off, nmesh, nxl, world):
-        nyl = nmesh // world
+    def unpack(self, recv, out, off, nmesh, world):
+        h, nyl = nmesh // (2 * world), nmesh // world
         o = self._cplx(out, off, nmesh, nyl)             # (y_local, x, k)
-        pc = o.shape[2]
-        r = recv.a[:nxl * nmesh * pc * 2].view(np.complex64).reshape(world, nxl, nyl, pc).copy()
+        pcx = o.shape[2]
+        r = recv.a[:2 * h * nmesh * pcx * 2].view(np.complex64).reshape(world, 2 * h, nyl, pcx).copy()
         for q in range(world):
-            o[:, q * nxl:(q + 1) * nxl, :] = r[q].transpose(1, 0, 2)
+            for s_ in (0, 1):
+                x0 = s_ * (nmesh // 2) + q * h
+                o[:, x0:x0 + h, :] = r[q, s_ * h:(s_ + 1) * h].transpose(1, 0, 2)
 
     def fft_x(self, data, off, nmesh, nyl):
         c = self._cplx(data, off, nmesh, nyl)

@@ -64,7 +64,7 @@ for nmesh, n, nofuse in ((512, 3_000_000, 0), (1024, 5_000_000, 0), (1024, 5_000
     pos[:, 0] -= np.float32(L / 2)                      # x outside [0, L): routing wraps it
     kw = dict(kbins=min(256, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L, paste='TSC', nmesh=nmesh, compensated=nmesh != 1024,
               interlaced=(nmesh == 512), poles=[0, 2, 4])
-    dpos, _ = c.route_particles(_lib.DeviceArray(pos), None, L)
+    dpos, _ = c.route_particles(_lib.DeviceArray(pos), None, L, fold=True)
     _lib.set_option('slab_nofuse', nofuse)
     assert _lib.lib().abacus_slab_fused(nmesh) == (1 if nmesh >= 1024 and not nofuse else 0)
     tab = calc_power_slab(dpos, L, comm=c, backend=HipSlabBackend(), n_total=n, **kw)
@@ -92,11 +92,13 @@ def test_rccl_single_rank_collectives():
     assert r.returncode == 0 and 'COMM-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_route_buckets_match_numpy():
+@pytest.mark.parametrize('fold', [False, True])
+def test_route_buckets_match_numpy(fold):
     """abacus_slab_route_dev: owners and the stable order inside a bucket equal the host formula of route_particles"""
     import ctypes as C
 
     from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.slab_power import slab_owner
     n, W, L = 200000, 8, 500.0
     pos = (np.random.default_rng(5).random((n, 3), dtype=np.float32) * 3 - 1) * np.float32(L)
     w = np.random.default_rng(6).random(n, dtype=np.float32)
@@ -104,9 +106,10 @@ def test_route_buckets_match_numpy():
     op = _lib.DeviceArray(nbytes=n * 12, dtype=np.float32, shape=(n, 3))
     ow = _lib.DeviceArray(nbytes=n * 4, dtype=np.float32, shape=(n,))
     counts = np.zeros(W, dtype=np.int64)
-    _lib.check(_lib.lib().abacus_slab_route_dev(dp.ptr, C.c_int64(n), dw.ptr, C.c_double(L), W, op.ptr, ow.ptr, _lib.ptr(counts)))
+    _lib.check(_lib.lib().abacus_slab_route_dev(dp.ptr, C.c_int64(n), dw.ptr, C.c_double(L), W, int(fold), op.ptr, ow.ptr,
+                                                _lib.ptr(counts)))
     xw = pos[:, 0] - np.floor(pos[:, 0] / np.float32(L)) * np.float32(L)
-    owner = np.minimum((xw * (W / np.float32(L))).astype(np.int64), W - 1)
+    owner = slab_owner(xw, L, W, fold)
     order = np.argsort(owner, kind='stable')
     np.testing.assert_array_equal(counts, np.bincount(owner, minlength=W))
     np.testing.assert_array_equal(op.get(), pos[order])
