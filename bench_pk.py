@@ -284,7 +284,8 @@ def bench_pairs(args, dist):
     # what the first cell-list kernel evaluated for the same counts: every ordered pair of the 27 cells of size r_max
     ncell_r = int(np.floor(L / 30.0 * 0.9999))
     cand_27 = float(n) * (n / L**3) * 27 * (L / ncell_r) ** 3
-    OPS = 30.0                  # vector instructions per candidate pair in the inner loop (ISA count of pair_count3<0>)
+    OPS = 20.0                  # vector instructions per candidate pair in the inner loop (ISA count of pair_count3<0, LUT>:
+                                # 15 for a pair out of range, 23 for one that is counted, a quarter of them are)
     VALU_PEAK = 256 * 4 * 16 * 2.4e9   # lanes x clock: 3.9e13 lane-operations per second
     tk = kern.get('pair_count', dt * 1e3) * 1e-3
     out = {'metric': 'candidate pair separations per second, DD(r) to 30 Mpc/h', 'value': cand * dist.world / dt,
