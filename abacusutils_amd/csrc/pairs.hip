@@ -19,6 +19,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "../../include/abacus_hip.h"
 #include "common.hpp"
 
@@ -61,9 +63,12 @@ __device__ __forceinline__ float funkey(unsigned int k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+// COUNT: per-cell counters by global atomics (counting sort, small inputs); else the cell ids become the keys of a radix sort
+// and idx the values
+template <bool COUNT>
 __global__ void cell_count(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
                            int64_t n, CellGrid g, unsigned int *__restrict__ counts, unsigned int *__restrict__ cellid,
-                           int *__restrict__ outside, Frame *__restrict__ frame) {
+                           unsigned int *__restrict__ idx, int *__restrict__ outside, Frame *__restrict__ frame) {
     bool out = false;
     unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -71,7 +76,8 @@ __global__ void cell_count(const float *__restrict__ x, const float *__restrict_
         const int c = (cell_coord(v[0], g.ncx, g.inv_box) * g.ncy + cell_coord(v[1], g.ncy, g.inv_box)) * g.ncz +
                       cell_coord(v[2], g.ncz, g.inv_box);
         cellid[i] = (unsigned int)c;
-        atomicAdd(&counts[c], 1u);
+        if (COUNT) atomicAdd(&counts[c], 1u);
+        else idx[i] = (unsigned int)i;
         out = out || !(v[0] >= 0.f && v[0] < g.box && v[1] >= 0.f && v[1] < g.box && v[2] >= 0.f && v[2] < g.box);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
@@ -80,13 +86,21 @@ __global__ void cell_count(const float *__restrict__ x, const float *__restrict_
         }
     }
     if (out) *outside = 1;   // some coordinate is not in [0, L)
+    // frame: wave reduction, then ONE pair of global atomics per workgroup and dimension (one per wave was 10^5 atomics
+    // on six addresses: 1 ms of this kernel's 1.1)
+    __shared__ unsigned int s_mn[3], s_mx[3];
+    if (threadIdx.x < 3) s_mn[threadIdx.x] = 0xffffffffu, s_mx[threadIdx.x] = 0u;
+    __syncthreads();
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         unsigned int a = mn[d], b = mx[d];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) a = min(a, (unsigned int)__shfl_xor((int)a, off, 64)), b = max(b, (unsigned int)__shfl_xor((int)b, off, 64));
-        if ((threadIdx.x & 63) == 0 && a <= b) atomicMin(&frame->mn[d], a), atomicMax(&frame->mx[d], b);
+        if ((threadIdx.x & 63) == 0 && a <= b) atomicMin(&s_mn[d], a), atomicMax(&s_mx[d], b);
     }
+    __syncthreads();
+    if (threadIdx.x < 3 && s_mn[threadIdx.x] <= s_mx[threadIdx.x])
+        atomicMin(&frame->mn[threadIdx.x], s_mn[threadIdx.x]), atomicMax(&frame->mx[threadIdx.x], s_mx[threadIdx.x]);
 }
 
 __global__ void cell_fill(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
@@ -99,6 +113,29 @@ __global__ void cell_fill(const float *__restrict__ x, const float *__restrict__
         sx[s] = x[i];
         sy[s] = y[i];
         sz[s] = z[i];
+    }
+}
+
+// behind the radix sort of (cell id, point index): the points in cell order (ties in input order: the sort is stable, so
+// the sorted arrays do not depend on the run) ...
+__global__ void cell_gather(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, int64_t n,
+                            const unsigned int *__restrict__ idx, float *__restrict__ sx, float *__restrict__ sy,
+                            float *__restrict__ sz) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int i = idx[s];
+        sx[s] = x[i], sy[s] = y[i], sz[s] = z[i];
+    }
+}
+// ... and the first point of every cell: start[c] = number of keys below c (c = 0 .. ncell)
+__global__ void cell_starts(const unsigned int *__restrict__ keys, int64_t n, int64_t ncell, int64_t *__restrict__ start) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= ncell; c += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)keys[mid] < c) lo = mid + 1;
+            else hi = mid;
+        }
+        start[c] = lo;
     }
 }
 
@@ -655,7 +692,7 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
 }
 
 struct SortedSet {
-    DevBuf raw, sorted, counts, cellid, start;
+    DevBuf raw, sorted, counts, cellid, start, keys2, idx, idx2, tmp;
     float *sx, *sy, *sz;
     int64_t n;
 };
@@ -680,7 +717,7 @@ int sort_into_cells(const void *hx, const void *hy, const void *hz, int where, i
     s.sx = s.sorted.as<float>();
     s.sy = s.sx + n1;
     s.sz = s.sy + n1;
-    const int nblk = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 256), 1), 4096);
+    const int nblk = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 256), 1), 2048);
     if (where == 1) {   // caller's device arrays, read in place
         rx = (const float *)hx, ry = (const float *)hy, rz = (const float *)hz;
     } else {
@@ -694,10 +731,33 @@ int sort_into_cells(const void *hx, const void *hy, const void *hz, int where, i
         }
         rx = bx, ry = by, rz = bz;
     }
+    // large inputs: stable radix sort of (cell id, index) + gather + a search per cell (10^7 points: 0.6 ms against 2.2 ms of
+    // the counting sort below, whose two passes are a global atomic per point each)
+    if (n >= 200000 && n < ((int64_t)1 << 31) && !option("pairs_countsort")) {
+        ABACUS_TRY(s.keys2.reserve(n1 * 4));
+        ABACUS_TRY(s.idx.reserve(n1 * 4));
+        ABACUS_TRY(s.idx2.reserve(n1 * 4));
+        ABACUS_LAUNCH("pair_cell_count", cell_count<false>, dim3(nblk), dim3(256), 0, rx, ry, rz, n, g, (unsigned int *)nullptr,
+                      s.cellid.as<unsigned int>(), s.idx.as<unsigned int>(), d_outside, d_frame);
+        int end_bit = 1;
+        while (((int64_t)1 << end_bit) < ncell) end_bit++;
+        size_t tmp_bytes = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, s.cellid.as<unsigned int>(), s.keys2.as<unsigned int>(),
+                                                 s.idx.as<unsigned int>(), s.idx2.as<unsigned int>(), (int)n, 0, end_bit, stream());
+        ABACUS_TRY(s.tmp.reserve(tmp_bytes));
+        if (hipcub::DeviceRadixSort::SortPairs(s.tmp.p, tmp_bytes, s.cellid.as<unsigned int>(), s.keys2.as<unsigned int>(),
+                                               s.idx.as<unsigned int>(), s.idx2.as<unsigned int>(), (int)n, 0, end_bit,
+                                               stream()) != hipSuccess)
+            return fail("abacus_paircount: radix sort failed");
+        ABACUS_LAUNCH("pair_cell_fill", cell_gather, dim3(nblk), dim3(256), 0, rx, ry, rz, n, s.idx2.as<unsigned int>(), s.sx, s.sy, s.sz);
+        const int cblk = (int)std::min<int64_t>(ceil_div(ncell + 1, 256), 8192);
+        ABACUS_LAUNCH("pair_cell_starts", cell_starts, dim3(cblk), dim3(256), 0, s.keys2.as<unsigned int>(), n, ncell, s.start.as<int64_t>());
+        return 0;
+    }
     HIP_TRY(hipMemsetAsync(s.counts.p, 0, (size_t)(ncell + 1) * 4, stream()));
     if (n > 0)
-        ABACUS_LAUNCH("pair_cell_count", cell_count, dim3(nblk), dim3(256), 0, rx, ry, rz, n, g,
-                      s.counts.as<unsigned int>(), s.cellid.as<unsigned int>(), d_outside, d_frame);
+        ABACUS_LAUNCH("pair_cell_count", cell_count<true>, dim3(nblk), dim3(256), 0, rx, ry, rz, n, g,
+                      s.counts.as<unsigned int>(), s.cellid.as<unsigned int>(), (unsigned int *)nullptr, d_outside, d_frame);
     ABACUS_TRY(exclusive_scan_u32(s.counts.as<unsigned int>(), ncell, s.start.as<int64_t>(), scratch, 1));
     if (n > 0)
         ABACUS_LAUNCH("pair_cell_fill", cell_fill, dim3(nblk), dim3(256), 0, rx, ry, rz, n,
