@@ -80,16 +80,43 @@ __global__ void prep_halo_factors(const unsigned int *__restrict__ N, int64_t n,
 }
 
 // ---- particle selection -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 prep_philox(uint4 c, uint2 k) {
+#include "rng_device.hpp"
+
+// The random columns of the two tables drawn on the device (`rng=<seed>` of prepare_slab_arrays; the reference draws them from
+// NumPy's global generator, :984-996,1029 - same distributions and dtypes, a different stream).  Row r stands for the object of
+// global index g = index0 + (index ? index[r] : r).  Halos (stream 4, five blocks of four words): `randoms` U[0,1) float64;
+// `randoms_exp` = sign * Exp(1) * scale per component (:986-988: (randint(0,2)*2-1) * exponential(scale)); `randoms_gaus_vrms`
+// = N(0,1) * scale (Box-Muller; log / sin / cos by the fixed float64 evaluations of rng_device.hpp, so the oracle
+// restates the stream bit for bit).  One uniform per object on a stream of the caller's (5: the particles' `randoms`, 6: the
+// halo mask's draws).
+__global__ void prep_halo_randoms(int64_t n, const long long *__restrict__ index, long long index0, uint2 key,
+                                  const double *__restrict__ scale, double *__restrict__ rnd, double *__restrict__ rexp,
+                                  double *__restrict__ rgaus) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long g = (unsigned long long)(index ? index[r] + index0 : index0 + r);
+        const unsigned int g0 = (unsigned int)g, g1 = (unsigned int)(g >> 32);
+        const uint4 b0 = philox4x32_10(make_uint4(g0, g1, 4u, 0u), key), b1 = philox4x32_10(make_uint4(g0, g1, 4u, 1u), key),
+                    b2 = philox4x32_10(make_uint4(g0, g1, 4u, 2u), key), b3 = philox4x32_10(make_uint4(g0, g1, 4u, 3u), key),
+                    b4 = philox4x32_10(make_uint4(g0, g1, 4u, 4u), key);
+        const double sc = scale[r];
+        rnd[r] = u53(b0.x, b0.y);
+        const double e[3] = {-det_log(1.0 - u53(b1.x, b1.y)), -det_log(1.0 - u53(b1.z, b1.w)), -det_log(1.0 - u53(b2.x, b2.y))};
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const unsigned int hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const unsigned int hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
+        for (int k = 0; k < 3; k++) rexp[3 * r + k] = ((b0.z >> k) & 1u ? 1.0 : -1.0) * (e[k] * sc);
+        const double m0 = sqrt(-2.0 * det_log(1.0 - u53(b2.z, b2.w))), m1 = sqrt(-2.0 * det_log(1.0 - u53(b3.z, b3.w)));
+        double s0, c0, s1, c1;
+        det_sincos2pi(u53(b3.x, b3.y), &s0, &c0);
+        det_sincos2pi(u53(b4.x, b4.y), &s1, &c1);
+        rgaus[3 * r] = (m0 * c0) * sc, rgaus[3 * r + 1] = (m0 * s0) * sc, rgaus[3 * r + 2] = (m1 * c1) * sc;
     }
-    return c;
+}
+__global__ void prep_part_randoms(int64_t n, const long long *__restrict__ index, long long index0, uint2 key,
+                                  unsigned int stream_id, double *__restrict__ rnd) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long g = (unsigned long long)(index ? index[r] + index0 : index0 + r);
+        const uint4 w = philox4x32_10(make_uint4((unsigned int)g, (unsigned int)(g >> 32), stream_id, 0u), key);
+        rnd[r] = u53(w.x, w.y);
+    }
 }
 
 // one wave per halo: host index of the halo's particles; sort key (candidate rank << 32 | Philox word) of candidates
@@ -120,7 +147,7 @@ __global__ void prep_keys(const int *__restrict__ host, const int *__restrict__ 
             if ((long long)ntarget[j] >= pnum[j]) sel = 1;  // the whole slice is kept: nothing to draw
             else {
                 const unsigned long long g = (unsigned long long)(part_index0 + q);
-                const uint4 w = prep_philox(make_uint4((unsigned int)g, (unsigned int)(g >> 32), 3u, 0u), k2);   // stream 3
+                const uint4 w = philox4x32_10(make_uint4((unsigned int)g, (unsigned int)(g >> 32), 3u, 0u), k2);   // stream 3
                 kq = ((unsigned long long)(unsigned int)j << 32) | w.x;
             }
         }
@@ -494,6 +521,38 @@ int abacus_prepare_particles(int64_t nh, const uint8_t *hmask, const int64_t *ps
         double *dst[5] = {ranks, ranksv, ranksp, ranksr, ranksc};
         for (int c = 0; c < 5; c++) HIP_TRY(hipMemcpyAsync(dst[c], d_r[c], (size_t)nsel * 8, hipMemcpyDeviceToHost, stream()));
     }
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_prepare_randoms(int64_t n, const int64_t *index, int64_t index0, uint64_t seed, int stream_id, const double *scale,
+                            double *randoms, double *randoms_exp, double *randoms_gaus) {
+    ABACUS_ENTER();
+    if (n < 0 || (n > 0 && !randoms)) return fail("abacus_prepare_randoms: null output");
+    if ((randoms_exp || randoms_gaus) && !(scale && randoms_exp && randoms_gaus))
+        return fail("abacus_prepare_randoms: the halo columns need the scale and both vector outputs");
+    if (randoms_exp ? stream_id != 4 : (stream_id < 5 || stream_id > 255))
+        return fail("abacus_prepare_randoms: stream %d (4 = the halo columns, 5 .. 255 = one uniform per object)", stream_id);
+    if (n == 0) return 0;
+    Tmp tmp;
+    long long *d_idx = nullptr;
+    double *d_sc = nullptr, *d_r, *d_e = nullptr, *d_g = nullptr;
+    if (index) ABACUS_TRY(tmp.upload(&d_idx, (const long long *)index, (size_t)n));
+    ABACUS_TRY(tmp.alloc(&d_r, (size_t)n));
+    const uint2 key = make_uint2((unsigned int)seed, (unsigned int)(seed >> 32));
+    if (randoms_exp) {
+        ABACUS_TRY(tmp.upload(&d_sc, scale, (size_t)n));
+        ABACUS_TRY(tmp.alloc(&d_e, (size_t)3 * n));
+        ABACUS_TRY(tmp.alloc(&d_g, (size_t)3 * n));
+        ABACUS_LAUNCH("prep_halo_randoms", prep_halo_randoms, dim3(grid_for(n)), dim3(256), 0, n, d_idx, (long long)index0, key, d_sc, d_r,
+                      d_e, d_g);
+        HIP_TRY(hipMemcpyAsync(randoms_exp, d_e, (size_t)n * 24, hipMemcpyDeviceToHost, stream()));
+        HIP_TRY(hipMemcpyAsync(randoms_gaus, d_g, (size_t)n * 24, hipMemcpyDeviceToHost, stream()));
+    } else {
+        ABACUS_LAUNCH("prep_part_randoms", prep_part_randoms, dim3(grid_for(n)), dim3(256), 0, n, d_idx, (long long)index0, key,
+                      (unsigned int)stream_id, d_r);
+    }
+    HIP_TRY(hipMemcpyAsync(randoms, d_r, (size_t)n * 8, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;
 }

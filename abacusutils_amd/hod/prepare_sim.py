@@ -14,8 +14,9 @@ Random numbers.  The reference consumes NumPy's global legacy generator in a fix
 one `np.random.choice(replace=False)` per kept halo :163/:172, :984-996 halo randoms, :1029 particle randoms).
 `rng='numpy'` reproduces exactly that - including the serial per-halo `choice` loop, which stays on the host - so a run
 seeded like the reference agrees with it value for value (tests/test_prepare_gpu.py against the reference's own prepare_slab).
-`rng=<int seed>` is the scalable form: halo and particle columns from `np.random.Generator(np.random.Philox(seed))`, the
-per-halo selection on the device from counter-based Philox keys (no per-halo serial work); same distributions, another stream.
+`rng=<int seed>` is the scalable form: every draw - the halo mask, the per-halo selection (counter-based Philox keys, no
+per-halo serial work), the random columns of both tables (abacus_prepare_randoms) - is made on the device as a function of
+(seed, global halo / particle index); same distributions and dtypes, another stream, restated by oracle/prepare_oracle.py.
 
 The light-cone edge correction of the environment (:469-597, randoms through a KD-tree) is not built: `halo_lc=True` with
 `want_AB` raises if any halo lies in the edge region.
@@ -127,11 +128,14 @@ def _targets_host(masses, pnum, MT):
 
 
 def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=True, Menv=None, shearmark=None, Lbox=None,
-                        mcut=1e11, halo_lc=False, rng='numpy', part_index0=0):
+                        mcut=1e11, halo_lc=False, rng='numpy', part_index0=0, halo_index0=0):
     """halos: dict of columns N, x_L2com, v_L2com, r25_L2com, r90_L2com, r98_L2com, npstartA, npoutA, id, sigmav3d_L2com (what
     CompaSOHaloCatalog loads for prepare_slab, :404-425); parts: dict with pos, vel of the slab's subsample-A particles in halo
     order.  Returns (halo table of the kept halos, particle table of the kept particles, mask over the input halos): dicts with
-    the field names and dtypes of the reference's 'halos' / 'particles' datasets (:1001-1045)."""
+    the field names and dtypes of the reference's 'halos' / 'particles' datasets (:1001-1045).
+    rng: 'numpy' consumes NumPy's global legacy generator in the reference's order (seed it like the reference and the tables
+    come out value for value); an integer seeds the device's counter-based generator - every draw is then a function of (seed,
+    global halo / particle index = halo_index0 / part_index0 + row), so slabs prepared on different GPUs fit together."""
     nh = len(halos['N'])
     N = np.ascontiguousarray(halos['N'], dtype=np.uint32)
     masses = halos['N'] * Mpart
@@ -140,8 +144,13 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
     numpy_mode = isinstance(rng, str)
     if numpy_mode and rng != 'numpy':
         raise ValueError("rng must be 'numpy' (the reference's global generator) or an integer seed")
-    gen = None if numpy_mode else np.random.Generator(np.random.Philox(int(rng)))
-    u = np.random.random(nh) if numpy_mode else gen.random(nh)                       # (:449)
+    seed = 0 if numpy_mode else int(rng) & (2**64 - 1)
+    if numpy_mode:
+        u = np.random.random(nh)                                                     # (:449)
+    else:
+        u = np.empty(nh)
+        _lib.check(_lib.lib().abacus_prepare_randoms(C.c_int64(nh), None, C.c_int64(halo_index0), C.c_uint64(seed), 6, None,
+                                                     _lib.ptr(u), None, None))
     p_halos, mask_halos, ntarget = _halo_factors(N, Mpart, MT, u=u, pnum=pnum)
     H = dict(halos)
     H['mask_subsample'] = mask_halos
@@ -183,7 +192,6 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
     r98 = np.ascontiguousarray(halos['r98_L2com'], dtype=np.float32)
     pstart_new, pnum_new = np.empty(nh), np.empty(nh)
     nsel = C.c_int64(0)
-    seed = 0 if numpy_mode else int(gen.integers(0, 2**63 - 1))
     L = _lib.lib()
 
     def call(sub_in, cap, outs, sub_out, ranks=False):
@@ -206,16 +214,21 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
     if n:
         call(submask, n, [sel_idx, sel_host, sel_np] + rk, None, ranks=want_ranks)
     H['npstartA'], H['npoutA'] = pstart_new, pnum_new
-    sig = np.repeat(halos['sigmav3d_L2com'], 3).reshape((-1, 3)) / np.sqrt(3)
-    if numpy_mode:                                                                   # (:984-996)
+    kept = np.flatnonzero(mask_halos)
+    if numpy_mode:                                                                   # (:984-996): drawn for every halo
+        sig = np.repeat(halos['sigmav3d_L2com'], 3).reshape((-1, 3)) / np.sqrt(3)
         H['randoms'] = np.random.random(nh)
         H['randoms_exp'] = (np.random.randint(0, 2, size=(nh, 3)) * 2 - 1) * np.random.exponential(scale=sig, size=(nh, 3))
         H['randoms_gaus_vrms'] = np.random.normal(loc=0, scale=sig, size=(nh, 3))
-    else:
-        H['randoms'] = gen.random(nh)
-        H['randoms_exp'] = (gen.integers(0, 2, size=(nh, 3)) * 2 - 1) * gen.exponential(scale=sig, size=(nh, 3))
-        H['randoms_gaus_vrms'] = gen.normal(loc=0, scale=sig, size=(nh, 3))
-    Hk = {k: np.asarray(v)[mask_halos] for k, v in H.items()}
+    Hk = {k: np.asarray(v)[kept] for k, v in H.items()}
+    if not numpy_mode:                                                               # drawn on the device, kept halos only
+        nk = len(kept)
+        scale = np.asarray(halos['sigmav3d_L2com'])[kept] / np.sqrt(3)
+        scale = np.ascontiguousarray(scale, dtype=np.float64)
+        Hk['randoms'], Hk['randoms_exp'], Hk['randoms_gaus_vrms'] = np.empty(nk), np.empty((nk, 3)), np.empty((nk, 3))
+        _lib.check(L.abacus_prepare_randoms(C.c_int64(nk), _lib.ptr(kept), C.c_int64(halo_index0), C.c_uint64(seed), 4,
+                                            _lib.ptr(scale), _lib.ptr(Hk['randoms']), _lib.ptr(Hk['randoms_exp']),
+                                            _lib.ptr(Hk['randoms_gaus_vrms'])))
 
     P = {'pos': pos[sel_idx], 'vel': vel[sel_idx]}
     if want_ranks:
@@ -226,7 +239,12 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
     P['halo_mass'] = masses[sel_host].astype(np.float64)
     P['Np'] = sel_np
     P['halo_id'] = np.asarray(halos['id'])[sel_host].astype(np.int64)
-    P['randoms'] = np.random.random(n) if numpy_mode else gen.random(n)              # (:1029)
+    if numpy_mode:
+        P['randoms'] = np.random.random(n)                                           # (:1029)
+    else:
+        P['randoms'] = np.empty(n)
+        _lib.check(L.abacus_prepare_randoms(C.c_int64(n), _lib.ptr(sel_idx), C.c_int64(part_index0), C.c_uint64(seed), 5, None,
+                                            _lib.ptr(P['randoms']), None, None))
     P['halo_deltac'] = H['deltac_rank'][sel_host]
     P['halo_fenv'] = H['fenv_rank'][sel_host]
     P['halo_shear'] = H['shear_rank'][sel_host]

@@ -420,7 +420,8 @@ def single(args):
                             # BASELINE config 3 itself (1024^3, 1e8 particles), with the CPU oracle timed on the same workload
                             ('pk_c3', lambda: bench_pk.bench_pk(args, dist, headline=False, nmesh=1024, variants=False)),
                             ('pairs', lambda: bench_pk.bench_pairs(args, dist)),
-                            ('catalog', lambda: bench_pk.bench_catalog(args, dist))):
+                            ('catalog', lambda: bench_pk.bench_catalog(args, dist)),
+                            ('prepare', lambda: bench_pk.bench_prepare(args, dist))):
                 try:                    # a secondary measurement must not take the headline down
                     out[key] = fn()
                 except Exception as e:

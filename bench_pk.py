@@ -421,3 +421,50 @@ def bench_catalog(args, dist):
         out['cpu_baseline'] = {'unpack_rvint particles/s': m / tr, 'unpack_pids particles/s': m / tp, 'cores': 1,
                                'kind': 'port', 'sample': f'{m} particles, NumPy restatement'}
     return out
+
+
+def bench_prepare(args, dist):
+    """prepare_sim's data-parallel core (reference hod/prepare_sim.py:296-1052 between loader and writer):
+    one synthetic CompaSO-like slab (synth.synth_compaso_slabs: 1e6 halos, ~8e6 subsample particles), MT sample with satellite
+    rank columns and assembly-bias ranks, selection drawn on the device (Philox).  The reference walks the halos in a
+    Python loop; the CPU baseline is the oracle's NumPy restatement of that loop on a bounded sample of the same slab."""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.hod import prepare_sim as prep
+    from abacusutils_amd.synth import synth_compaso_slabs
+    nh = 1_000_000
+    slabs, header = synth_compaso_slabs(numslabs=1, n_halo=nh, seed=900 + dist.rank, lbox=2000.0, subsample_frac=0.006)
+    halos, parts = slabs[0]['halos'], slabs[0]['parts']
+    Mpart, h = header['ParticleMassHMsun'], header['H0'] / 100.0
+    kw = dict(MT=True, want_ranks=True, want_AB=True, Lbox=header['BoxSize'])
+    prep.prepare_slab_arrays(halos, parts, Mpart, h, rng=7, **kw)      # warm-up: scratch allocations
+    _lib.sync()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    reps = 3
+    t0 = time.perf_counter()
+    for r in range(reps):
+        H, P, mask = prep.prepare_slab_arrays(halos, parts, Mpart, h, rng=11 + r, **kw)
+    _lib.sync()
+    dt = (time.perf_counter() - t0) / reps
+    _lib.profile_enable(False)
+    kern = {k: round(ms / reps, 4) for k, (ms, n) in _lib.profile_get().items() if n}
+    out = {'metric': 'halos/s through prepare_slab (subsample + particle selection + rank columns)', 'value': nh / dt,
+           'unit': 'halos/s', 'ms_per_slab': dt * 1e3, 'n_halos': nh, 'n_particles': int(len(parts['pos'])),
+           'halos_kept': int(mask.sum()), 'particles_kept': int(len(P['pos'])), 'kernels_ms': kern,
+           'kernels_ms_total': round(sum(kern.values()), 3),
+           'note': 'host arrays in, the two output tables as NumPy structured columns out (PCIe and the NumPy gathers of the '
+                   'kept rows included); kernels_ms_total is the device share'}
+    if dist.rank == 0 and dist.world == 1 and not args.no_cpu:
+        from oracle import prepare_oracle
+        ns = 200000                                   # the loop costs ~40 us per halo
+        hs = {k: v[:ns] for k, v in halos.items()}
+        npart_s = int(hs['npstartA'][-1] + hs['npoutA'][-1])
+        ps = {k: v[:npart_s] for k, v in parts.items()}
+        np.random.seed(5)
+        t1 = time.perf_counter()
+        prepare_oracle.prepare_slab_core(hs, ps, Mpart, h, True, want_ranks=True, want_AB=True, Lbox=header['BoxSize'])
+        tc = time.perf_counter() - t1
+        out['cpu_baseline'] = {'value': ns / tc, 'unit': 'halos/s', 'cores': 1, 'kind': 'port',
+                               'sample': f'the first {ns} halos ({npart_s} particles) of the same slab through the oracle\'s NumPy '
+                                         f'restatement of the reference loop, {tc:.1f} s'}
+    return out

@@ -474,6 +474,14 @@ int abacus_prepare_particles(int64_t nh, const uint8_t *hmask, const int64_t *ps
                              int64_t *n_sel, int64_t cap_sel, int64_t *sel_idx, int64_t *sel_host, double *sel_np, double *ranks,
                              double *ranksv, double *ranksp, double *ranksr, double *ranksc, uint8_t *submask_out);
 
+/* the random columns of the prepare_sim tables drawn on the device (Philox4x32-10, counter = global object index: shard
+ * invariant; NOT the reference's NumPy stream - prepare_sim.py:984-996,1029 - but its distributions and dtypes).  Row r stands
+ * for the object index0 + (index ? index[r] : r).  stream_id 4, with scale / randoms_exp / randoms_gaus: the halo columns
+ * `randoms` (n) U[0,1), `randoms_exp` (n,3) = +-Exp(1) * scale[r], `randoms_gaus_vrms` (n,3) = N(0,1) * scale[r]; stream_id
+ * 5 .. 255 without them: one U[0,1) per object (5: the particles' `randoms`, 6: the draws of the halo mask).  Host pointers. */
+int abacus_prepare_randoms(int64_t n, const int64_t *index, int64_t index0, uint64_t seed, int stream_id, const double *scale,
+                            double *randoms, double *randoms_exp, double *randoms_gaus);
+
 /* ---------------------------------------------------------------- catalogue side (upstream of the HOD) ---- */
 /*
  * replaces: abacusnbody/data/bitpacked.py:32-116 `unpack_rvint` / `_unpack_rvint`.  intdata: (n,3) int32, 20-bit

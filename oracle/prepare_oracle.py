@@ -184,3 +184,45 @@ def prepare_slab_core(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=True
     P['halo_fenv'] = H['fenv_rank'][hp]
     P['halo_shear'] = H['shear_rank'][hp]
     return Hk, P, mask_halos
+
+
+# ---- the device's own random columns (`rng=<seed>` of abacusutils_amd.hod.prepare_sim; csrc/prepare.hip prep_halo_randoms /
+# prep_part_randoms): Philox4x32-10 blocks (counter = global index, stream, block; key = seed) through the oracle's C restatement
+# of the generator - held to the published known-answer vectors by tests/test_oracle_reseed.py - and the fixed float64
+# evaluations of log / sin / cos.  Scalar loops: for small samples only.
+def _u53(a, b):
+    return float(((int(a) >> 5) << 26) | (int(b) >> 6)) * 1.1102230246251565e-16
+
+
+def device_uniform(seed, index, stream):
+    """one U[0,1) float64 per global object index on stream 5 (particle randoms) or 6 (halo mask draws)"""
+    from oracle import oracle
+    key = (int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    out = np.empty(len(index))
+    for r, g in enumerate(index):
+        w = oracle.philox4x32_10((int(g) & 0xFFFFFFFF, (int(g) >> 32) & 0xFFFFFFFF, stream, 0), key)
+        out[r] = _u53(w[0], w[1])
+    return out
+
+
+def device_halo_randoms(seed, index, scale):
+    """(randoms, randoms_exp, randoms_gaus_vrms) of the halos with global indices `index` and scales sigmav3d / sqrt(3)"""
+    from oracle import oracle
+    key = (int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    n = len(index)
+    rnd, rexp, rg = np.empty(n), np.empty((n, 3)), np.empty((n, 3))
+    for r, g in enumerate(index):
+        c = (int(g) & 0xFFFFFFFF, (int(g) >> 32) & 0xFFFFFFFF)
+        b = [oracle.philox4x32_10(c + (4, k), key) for k in range(5)]
+        sc = float(scale[r])
+        rnd[r] = _u53(b[0][0], b[0][1])
+        e = [-oracle.rs_log(1.0 - _u53(b[1][0], b[1][1])), -oracle.rs_log(1.0 - _u53(b[1][2], b[1][3])),
+             -oracle.rs_log(1.0 - _u53(b[2][0], b[2][1]))]
+        for k in range(3):
+            rexp[r, k] = (1.0 if (int(b[0][2]) >> k) & 1 else -1.0) * (e[k] * sc)
+        m0 = np.sqrt(-2.0 * oracle.rs_log(1.0 - _u53(b[2][2], b[2][3])))
+        m1 = np.sqrt(-2.0 * oracle.rs_log(1.0 - _u53(b[3][2], b[3][3])))
+        s0, c0 = oracle.rs_sincos2pi(_u53(b[3][0], b[3][1]))
+        s1, c1 = oracle.rs_sincos2pi(_u53(b[4][0], b[4][1]))
+        rg[r] = ((m0 * c0) * sc, (m0 * s0) * sc, (m1 * c1) * sc)
+    return rnd, rexp, rg

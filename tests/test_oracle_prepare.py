@@ -48,3 +48,19 @@ def test_prepare_slab_core_reproduces_the_reference(case):
     live = H['npoutA'] >= 0
     assert np.array_equal(H['npstartA'][live], np.concatenate(([0], np.cumsum(H['npoutA'][live])[:-1])))
     assert int(H['npoutA'][live].sum()) == len(P['pos'])
+
+
+def test_device_stream_restatement_is_sane():
+    """the oracle's restatement of the device's random columns (bit-compared with the kernels in tests/test_prepare_gpu.py):
+    ranges, rough moments, independence of index order"""
+    from oracle import prepare_oracle as po
+    idx = np.arange(4000) + 2**35
+    r, e, g = po.device_halo_randoms(9, idx, np.full(4000, 100.0))
+    assert 0 <= r.min() and r.max() < 1 and abs(r.mean() - 0.5) < 0.03
+    assert abs(np.abs(e).mean() / 100 - 1) < 0.05 and abs((e > 0).mean() - 0.5) < 0.03
+    assert abs(g.std() / 100 - 1) < 0.04 and abs(g.mean()) < 4
+    r2, e2, g2 = po.device_halo_randoms(9, idx[::-1], np.full(4000, 100.0))
+    np.testing.assert_array_equal(r2[::-1], r)
+    np.testing.assert_array_equal(g2[::-1], g)
+    u = po.device_uniform(9, idx, 5)
+    assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.03 and not np.array_equal(u, po.device_uniform(9, idx, 6))

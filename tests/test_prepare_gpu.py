@@ -180,3 +180,71 @@ def test_prepare_to_run_hod_end_to_end():
     want = oracle.gen_gal_cat(hd, pd, ball.tracers, ball.params, Nthread=4, enable_ranks=True, rsd=True)
     assert_mock_equal(mock, want, exact=True)
     assert len(mock['LRG']['x']) > 500 and len(mock['ELG']['x']) > 500
+
+
+def test_device_random_columns_match_the_oracle_bit_for_bit():
+    """abacus_prepare_randoms (the `rng=<seed>` columns) against the oracle's restatement of the stream: Philox blocks pinned by
+    the published vectors + the fixed float64 transforms; indices beyond 2^32, index lists and offsets (shard invariance)"""
+    import ctypes as C
+
+    from abacusutils_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    n, seed = 1500, 0x9abcdef012345678
+    index = np.sort(rng.integers(0, 2**40, n)).astype(np.int64)
+    scale = rng.uniform(10, 900, n)
+    r, e, g = np.empty(n), np.empty((n, 3)), np.empty((n, 3))
+    _lib.check(L.abacus_prepare_randoms(C.c_int64(n), _lib.ptr(index), C.c_int64(17), C.c_uint64(seed), 4, _lib.ptr(scale), _lib.ptr(r),
+                                        _lib.ptr(e), _lib.ptr(g)))
+    ro, eo, go = po.device_halo_randoms(seed, index + 17, scale)
+    np.testing.assert_array_equal(r, ro)
+    np.testing.assert_array_equal(e, eo)
+    np.testing.assert_array_equal(g, go)
+    for stream in (5, 6):
+        u = np.empty(n)
+        _lib.check(L.abacus_prepare_randoms(C.c_int64(n), None, C.c_int64(2**33 + 5), C.c_uint64(seed), stream, None, _lib.ptr(u), None, None))
+        np.testing.assert_array_equal(u, po.device_uniform(seed, 2**33 + 5 + np.arange(n), stream))
+    with pytest.raises(_lib.AbacusHipError):
+        _lib.check(L.abacus_prepare_randoms(C.c_int64(n), None, C.c_int64(0), C.c_uint64(seed), 4, None, _lib.ptr(u), None, None))
+
+
+def test_device_random_columns_distributions_and_shards():
+    """10^6 halos: uniform, two-sided exponential and normal moments with the per-halo scale; a slab prepared with
+    halo_index0 / part_index0 draws what the same objects draw inside a larger catalogue"""
+    import ctypes as C
+
+    from abacusutils_amd import _lib
+    L = _lib.lib()
+    n = 1_000_000
+    scale = np.full(n, 250.0)
+    r, e, g = np.empty(n), np.empty((n, 3)), np.empty((n, 3))
+    _lib.check(L.abacus_prepare_randoms(C.c_int64(n), None, C.c_int64(0), C.c_uint64(77), 4, _lib.ptr(scale), _lib.ptr(r), _lib.ptr(e),
+                                        _lib.ptr(g)))
+    assert 0.0 <= r.min() and r.max() < 1.0 and abs(r.mean() - 0.5) < 2e-3 and abs(r.var() - 1 / 12) < 1e-3
+    assert abs(np.abs(e).mean() / 250.0 - 1) < 5e-3 and abs((e > 0).mean() - 0.5) < 2e-3 and abs(e.mean()) < 1.0
+    assert abs(g.std() / 250.0 - 1) < 3e-3 and abs(g.mean()) < 0.8
+    cc = np.corrcoef(np.column_stack((r, e, g)).T)
+    assert np.abs(cc - np.eye(7)).max() < 6e-3
+    from scipy import stats
+    assert stats.kstest(g.ravel()[:200000] / 250.0, 'norm').pvalue > 1e-3
+    assert stats.kstest(np.abs(e).ravel()[:200000] / 250.0, 'expon').pvalue > 1e-3
+    # shards: rows [a, b) drawn with index0 = a equal the slice of the whole
+    a, b = 123456, 223456
+    r2, e2, g2 = np.empty(b - a), np.empty((b - a, 3)), np.empty((b - a, 3))
+    sc2 = scale[a:b].copy()       # (held: _lib.ptr does not keep its array alive)
+    _lib.check(L.abacus_prepare_randoms(C.c_int64(b - a), None, C.c_int64(a), C.c_uint64(77), 4, _lib.ptr(sc2), _lib.ptr(r2),
+                                        _lib.ptr(e2), _lib.ptr(g2)))
+    np.testing.assert_array_equal(r2, r[a:b])
+    np.testing.assert_array_equal(e2, e[a:b])
+    np.testing.assert_array_equal(g2, g[a:b])
+    from abacusutils_amd.hod import prepare_sim as ps
+    slabs, header = synth.synth_compaso_slabs(numslabs=1, n_halo=5000, seed=47, lbox=300.0)
+    halos, parts = slabs[0]['halos'], slabs[0]['parts']
+    Mpart, h = header['ParticleMassHMsun'], header['H0'] / 100.0
+    H, P, m = ps.prepare_slab_arrays(halos, parts, Mpart, h, True, rng=5, halo_index0=1000, part_index0=50000)
+    kept = np.flatnonzero(m)
+    ro, eo, go = po.device_halo_randoms(5, kept[:300] + 1000, np.asarray(halos['sigmav3d_L2com'])[kept[:300]] / np.sqrt(3))
+    np.testing.assert_array_equal(H['randoms'][:300], ro)
+    np.testing.assert_array_equal(H['randoms_exp'][:300], eo)
+    np.testing.assert_array_equal(H['randoms_gaus_vrms'][:300], go)
+    np.testing.assert_array_equal(m, po.device_uniform(5, 1000 + np.arange(len(m)), 6) < po.subsample_halos(halos['N'] * Mpart, True))
