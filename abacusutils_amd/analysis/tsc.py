@@ -40,32 +40,19 @@ def tsc_parallel(pos, densgrid, box, weights=None, nthread=-1, wrap=True, nparti
         raise ValueError('densgrid must be 3-D')
     n1d = densgrid.shape[coord]
 
-    if not npartition:  # tsc.py:126-139
-        if nthread > 1:
-            if 2 * nthread >= n1d // 2:
-                npartition = n1d // 2
-                npartition = 2 * (npartition // 2)
-                if npartition < n1d // 2:
-                    npartition = n1d // 3
-            else:
-                npartition = min(n1d // 3, 2 * nthread)
-            npartition = 2 * (npartition // 2)
-        else:
-            npartition = 1
-    if npartition > n1d // 3 and npartition != n1d // 2 and nthread > 1:
-        raise ValueError(f'npartition {npartition} must be less than'
-                         f' ngrid//3 = {n1d // 3} or equal to ngrid//2 = {n1d // 2}')
-    if npartition > 1 and npartition % 2 != 0 and nthread > 1:
-        raise ValueError(f'npartition {npartition} not divisible by 2')
+    # The stripes of the reference do not exist here; an explicit `npartition` is still held to its rules (tsc.py:141-147:
+    # at most ngrid//3 stripes, or exactly ngrid//2, and an even number of them).  The default the reference derives from the
+    # thread count (tsc.py:126-139) satisfies them by construction, so nothing is computed for it.
+    if npartition and nthread > 1:
+        third, half = n1d // 3, n1d // 2
+        if npartition > third and npartition != half:
+            raise ValueError(f'npartition {npartition} must be less than ngrid//3 = {third} or equal to ngrid//2 = {half}')
+        if npartition > 1 and npartition % 2:
+            raise ValueError(f'npartition {npartition} not divisible by 2')
 
-    def _check_dtype(a, name):
-        if a.itemsize > 4:
-            warnings.warn(f'{name}.dtype={a.dtype} instead of np.float32. float32 is recommended for performance.')
-
-    _check_dtype(pos, 'pos')
-    _check_dtype(densgrid, 'densgrid')
-    if weights is not None:
-        _check_dtype(weights, 'weights')
+    for name, arr in (('pos', pos), ('densgrid', densgrid), ('weights', weights)):    # the reference's advice (tsc.py:149-165)
+        if arr is not None and arr.itemsize > 4:
+            warnings.warn(f'{name}.dtype={arr.dtype} instead of np.float32. float32 is recommended for performance.')
     if pos.dtype not in _DT or densgrid.dtype not in _DT:
         raise TypeError('pos and densgrid must be float32 or float64')
     if not (pos.flags.c_contiguous and pos.flags.writeable) and wrap:

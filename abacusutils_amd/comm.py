@@ -80,6 +80,26 @@ def exchange_id(rank, world, make_id, path, timeout=180.0):
         time.sleep(0.02)
 
 
+def _run_with_deadline(fn, timeout, what):
+    """fn() in a daemon thread; its exception is re-raised here, TimeoutError(what) if it is still running after `timeout` s"""
+    import threading
+    box = {}
+
+    def body():
+        try:
+            fn()
+        except BaseException as e:   # noqa: BLE001 - handed to the caller
+            box['error'] = e
+
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(timeout)
+    if t.is_alive():
+        raise TimeoutError(what)
+    if 'error' in box:
+        raise box['error']
+
+
 class RcclComm:
     """ncclComm of `world` ranks on the library's device and stream.
 
@@ -101,9 +121,18 @@ class RcclComm:
 
         path = _rendezvous_path(key)
         blob = exchange_id(self.rank, self.world, make_id, path, timeout)
-        _lib.check(L.abacus_comm_init(self.rank, self.world, blob, ID_BYTES, C.byref(self._h)))
-        self.collective = True      # the collectives run (and are exercised) for a single rank as well
-        self.barrier()
+        # ncclCommInitRank and the first barrier block until every rank has joined and have no timeout of their own: a rank
+        # that died between the rendezvous and here would hang the others for good.  They run in a helper thread (ctypes
+        # releases the GIL) and the caller gives up after `timeout` - the stuck call still holds the library lock, so
+        # the only sound reaction to this error is to end the process (abacusutils_amd/launch.py does, by PID).
+        def join_ranks():
+            _lib.check(L.abacus_comm_init(self.rank, self.world, blob, ID_BYTES, C.byref(self._h)))
+            self.collective = True      # the collectives run (and are exercised) for a single rank as well
+            self.barrier()
+
+        _run_with_deadline(join_ranks, timeout,
+                           f'rank {self.rank}/{self.world}: ncclCommInitRank / first barrier did not return within {timeout:.0f} s '
+                           '(a peer rank is missing or the links are down); this process must exit')
         if self.rank == 0:
             try:
                 os.unlink(path)

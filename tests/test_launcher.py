@@ -9,6 +9,7 @@ import threading
 import time
 
 import numpy as np
+import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
@@ -101,3 +102,22 @@ def test_dist_without_ranks_is_trivial():
     d.barrier()
     d.finish()
     assert np.isfinite(d.max(1.0))
+
+
+def test_run_with_deadline():
+    """the watchdog around ncclCommInitRank: result and exceptions pass through, a call that never returns becomes TimeoutError"""
+    import threading
+    import time
+
+    from abacusutils_amd.comm import _run_with_deadline
+    seen = []
+    _run_with_deadline(lambda: seen.append(1), 5.0, 'x')
+    assert seen == [1]
+    with pytest.raises(KeyError):
+        _run_with_deadline(lambda: {}['missing'], 5.0, 'x')
+    gate = threading.Event()
+    t0 = time.time()
+    with pytest.raises(TimeoutError, match='stuck'):
+        _run_with_deadline(gate.wait, 0.3, 'stuck')
+    assert time.time() - t0 < 3
+    gate.set()
