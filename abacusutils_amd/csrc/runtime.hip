@@ -36,7 +36,16 @@ std::recursive_mutex &api_mutex() {
 }
 
 int ensure_init() {
-    if (g_inited) return 0;
+    // HIP's current device is a per-thread setting: every thread that enters the library is bound to the library's device once
+    // (a helper thread of a rank with LOCAL_RANK != 0 would otherwise work on device 0)
+    static thread_local bool t_bound = false;
+    if (g_inited) {
+        if (!t_bound) {
+            HIP_TRY(hipSetDevice(g_device));
+            t_bound = true;
+        }
+        return 0;
+    }
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_inited) return 0;
     int n = 0;
@@ -49,6 +58,7 @@ int ensure_init() {
         HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
         g_own_stream = true;
     }
+    t_bound = true;
     g_inited = true;
     return 0;
 }
