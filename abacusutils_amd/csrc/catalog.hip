@@ -153,6 +153,17 @@ __device__ __forceinline__ void p9_shorts(const unsigned char *c, int (&s)[6]) {
     s[4] = ((c[7] & 0x0F) | (c[6] << 4)) - 2048;
     s[5] = (((c[7] & 0xF0) << 4) | c[8]) - 2048;
 }
+// record r of a chunk staged in LDS as dwords: its 9 bytes start at byte 9 r, inside three consecutive aligned words -
+// three LDS reads and two byte alignments instead of nine byte reads
+__device__ __forceinline__ void p9_record(const unsigned int *words, int r, unsigned char (&c)[12]) {
+    const int b = r * 9, w = b >> 2, sh = b & 3;
+    const unsigned int a0 = words[w], a1 = words[w + 1], a2 = words[w + 2], a3 = sh ? words[w + 3] : 0u;
+    const unsigned int v0 = __builtin_amdgcn_alignbyte(a1, a0, (unsigned int)sh), v1 = __builtin_amdgcn_alignbyte(a2, a1, (unsigned int)sh),
+                       v2 = __builtin_amdgcn_alignbyte(a3, a2, (unsigned int)sh);
+    c[0] = v0 & 0xFF, c[1] = (v0 >> 8) & 0xFF, c[2] = (v0 >> 16) & 0xFF, c[3] = v0 >> 24;
+    c[4] = v1 & 0xFF, c[5] = (v1 >> 8) & 0xFF, c[6] = (v1 >> 16) & 0xFF, c[7] = v1 >> 24;
+    c[8] = v2 & 0xFF;
+}
 
 template <class F>
 struct P9Cell {
@@ -184,29 +195,49 @@ __device__ __forceinline__ void p9_stage(const unsigned char *__restrict__ data,
     const int64_t byte0 = rec0 * 9;
     const int nbytes = nrec_chunk * 9, nwords = nbytes / 4;
     const unsigned int *g = reinterpret_cast<const unsigned int *>(data + byte0);
+#pragma unroll 7
     for (int q = threadIdx.x; q < nwords; q += P9_NT) lds_words[q] = g[q];
     unsigned char *lb = reinterpret_cast<unsigned char *>(lds_words);
     for (int q = nwords * 4 + threadIdx.x; q < nbytes; q += P9_NT) lb[q] = data[byte0 + q];
 }
 
-__global__ __launch_bounds__(P9_NT) void pack9_count(const unsigned char *__restrict__ data, int64_t nrec,
+__global__ __launch_bounds__(P9_NT) void pack9_count(const unsigned char *__restrict__ data, int64_t nrec, int64_t nchunk,
                                                      unsigned int *__restrict__ counts, int *__restrict__ last_hdr) {
-    __shared__ unsigned int sm_cnt;
-    __shared__ int sm_last;
-    if (threadIdx.x == 0) sm_cnt = 0u, sm_last = -1;
-    __syncthreads();
-    const int64_t rec0 = (int64_t)blockIdx.x * P9_CH;
+    // ONE WAVE per chunk (a workgroup per chunk was dominated by its launch and its barrier: 13.5 KB of work), coalesced dword
+    // loads - a chunk starts at a multiple of 9 * P9_CH bytes, 4-byte aligned -: byte k of word q starts a record when
+    // 4 q + k is a multiple of 9; q advances by 64 per trip, 4 * 64 = 4 (mod 9)
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * (P9_NT / 64) + (threadIdx.x >> 6);
+    if (chunk >= nchunk) return;
+    const int64_t rec0 = chunk * P9_CH;
     const int m = (int)min((int64_t)P9_CH, nrec - rec0);
     unsigned int cnt = 0;
     int last = -1;
-    for (int r = threadIdx.x; r < m; r += P9_NT) {
-        if (data[(rec0 + r) * 9] == 0xFF) last = r;
-        else cnt++;
+    const int nbytes = m * 9, nwords = nbytes >> 2;
+    const unsigned int *g = reinterpret_cast<const unsigned int *>(data + rec0 * 9);
+    int r9 = (4 * lane) % 9;
+#pragma unroll 9
+    for (int q = lane; q < nwords; q += 64) {
+        const unsigned int v = g[q];
+        const int k = r9 ? 9 - r9 : 0;                   // first record start at or after byte 4 q
+        if (k < 4) {
+            if (((v >> (8 * k)) & 0xFFu) == 0xFFu) last = max(last, (4 * q + k) / 9);
+            else cnt++;
+        }
+        r9 += 4;
+        if (r9 >= 9) r9 -= 9;
     }
-    atomicAdd(&sm_cnt, cnt);
-    atomicMax(&sm_last, last);
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = sm_cnt, last_hdr[blockIdx.x] = sm_last;
+    for (int b = nwords * 4 + lane; b < nbytes; b += 64)
+        if (b % 9 == 0) {
+            if (data[rec0 * 9 + b] == 0xFF) last = max(last, b / 9);
+            else cnt++;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += (unsigned int)__shfl_xor((int)cnt, off, 64);
+        last = max(last, __shfl_xor(last, off, 64));
+    }
+    if (lane == 0) counts[chunk] = cnt, last_hdr[chunk] = last;
 }
 
 template <class F>
@@ -274,7 +305,8 @@ __global__ __launch_bounds__(P9_NT) void pack9_emit(const unsigned char *__restr
         for (int q = 0; q < P9_PER; q++) {
             const int r = r0 + q;
             if (r >= m) break;
-            const unsigned char *c = lb + r * 9;
+            unsigned char c[12];
+            p9_record(recs, r, c);
             if (c[0] == 0xFF) {
                 cell = p9_header<F>(c, boxsize, velz);
                 continue;
@@ -513,7 +545,7 @@ extern "C" int abacus_unpack_pack9(const uint8_t *data, int64_t nrec, double box
     ABACUS_TRY(b_counts.reserve((size_t)(nchunk + 1) * 4));
     ABACUS_TRY(b_last.reserve((size_t)nchunk * 4));
     ABACUS_TRY(b_off.reserve((size_t)(nchunk + 1) * 8));
-    ABACUS_LAUNCH("pack9_count", pack9_count, dim3((unsigned int)nchunk), dim3(P9_NT), 0, d_in, nrec,
+    ABACUS_LAUNCH("pack9_count", pack9_count, dim3((unsigned int)ceil_div(nchunk, P9_NT / 64)), dim3(P9_NT), 0, d_in, nrec, nchunk,
                   b_counts.as<unsigned int>(), b_last.as<int>());
     ABACUS_TRY(exclusive_scan_u32(b_counts.as<unsigned int>(), nchunk, b_off.as<int64_t>(), scratch, 0));
     if (op.dev || ov.dev) {
