@@ -88,12 +88,19 @@ def check(rc):
         raise AbacusHipError(lib().abacus_last_error().decode())
 
 
+class _ArrayPtr(C.c_void_p):
+    """void* that keeps its array alive: `ptr(x.copy())` or `ptr(a + b)` inside a call would otherwise hand the library the
+    address of an array freed before the call starts"""
+
+
 def ptr(a):
-    """void* of a C-contiguous ndarray (None -> NULL)"""
+    """void* of a C-contiguous ndarray (None -> NULL); the array lives at least as long as the returned object"""
     if a is None:
         return None
     assert a.flags.c_contiguous
-    return C.c_void_p(a.ctypes.data)
+    p = _ArrayPtr(a.ctypes.data)
+    p._keep = a
+    return p
 
 
 def device_name():
