@@ -291,6 +291,7 @@ def tsc_parallel(pos, densgrid, box, weights=None, nthread=-1, wrap=True, nparti
     else:
         ppart, wpart = pos, (None if weights is None else np.ascontiguousarray(weights, dtype=pos.dtype))
         starts = np.array([0, len(pos)], dtype=np.int64)
+    assert densgrid.dtype == np.float32, 'the stripe scatter of the oracle is float32-grid only (tsc_scatter takes float64 grids)'
     fn = getattr(lib(), f'oracle_tsc_parallel_{_suffix(ppart)}_f32')
     gx, gy, gz = densgrid.shape
     # The reference admits npartition == n1d//2 (tsc.py:128-134,141): stripes two cells wide, while a TSC cloud

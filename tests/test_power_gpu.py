@@ -29,13 +29,14 @@ def _check_golden(tab, g, name, rtol):
     np.testing.assert_allclose(tab['k_mid'], g[f'{name}.k_mid'], rtol=1e-15)
 
 
-def _check_oracle(tab, ref, rtol=RTOL):
+def _check_oracle(tab, ref, rtol=RTOL, poles_rtol_factor=1.0):
     np.testing.assert_array_equal(np.asarray(tab['N_mode']), ref['N_mode'])
     for k in ('power', 'k_avg', 'poles'):
         if k in ref:
             want = np.asarray(ref[k], dtype='f8')
-            np.testing.assert_allclose(np.asarray(tab[k], dtype='f8'), want, rtol=rtol,
-                                       atol=rtol * np.abs(want).max() * 0.1, err_msg=k)
+            rt = rtol * (poles_rtol_factor if k == 'poles' else 1.0)
+            np.testing.assert_allclose(np.asarray(tab[k], dtype='f8'), want, rtol=rt,
+                                       atol=rt * np.abs(want).max() * 0.1, err_msg=k)
 
 
 @pytest.mark.parametrize('paste', ['TSC', 'CIC'])
@@ -391,7 +392,10 @@ def test_random_option_sweep(seed):
     tab = calc_power(pos.copy(), box, **cp(kw))
     ref = oracle.calc_power(pos.copy(), box, nthread=4, accum64=True, **cp(kw))
     # window-compensated CIC amplifies float32 noise near Nyquist: the oracle comparison of those cases is looser
-    _check_oracle(tab, ref, rtol=1e-5 if kw['paste'] == 'TSC' else 3e-5)
+    # 13 P_6(mu) has coefficients up to 650 with alternating signs: the float32 noise of the modes (1e-6 of |delta_k|^2, FFT
+    # round-off that differs between the two transforms) is amplified accordingly in a bin of few modes (seed 5103 of the
+    # fuzz: 3.5e-5 in one l = 6 value)
+    _check_oracle(tab, ref, rtol=1e-5 if kw['paste'] == 'TSC' else 3e-5, poles_rtol_factor=5.0 if 6 in (poles or []) else 1.0)
     if 'N_mode_poles' in ref:
         np.testing.assert_array_equal(np.asarray(tab['N_mode_poles']), ref['N_mode_poles'])
 

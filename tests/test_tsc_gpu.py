@@ -228,4 +228,11 @@ def test_random_option_sweep(seed):
     oracle.tsc_parallel(p2, gb, box, weights=w, nthread=1, wrap=wrap, offset=offset)
     np.testing.assert_array_equal(p1, p2)
     scale = max(float(np.abs(gb).max()), 1e-30)
-    np.testing.assert_allclose(ga, gb, rtol=2e-5, atol=3e-6 * scale)
+    # the reference accumulates in the grid's float32; with 10^5 deposits per cell (2^3 ... 5^3 cells, 2e6 particles) that sum
+    # itself is off by up to a per cent.  The device accumulates in float64 (deviation 1): it is held
+    # tightly to the same scatter into a float64 grid, and to the float32 one within that scatter's own accumulation error
+    gc, p3 = grid0.astype(np.float64), pos.copy()
+    oracle.wrap_inplace(p3, box)
+    oracle.tsc_scatter(p3, gc, box, weights=w, offset=offset)
+    np.testing.assert_allclose(ga, gc, rtol=2e-6, atol=3e-6 * scale)
+    np.testing.assert_allclose(ga, gb, rtol=2e-5, atol=3e-6 * scale + 2.0 * float(np.abs(gb - gc).max()))
