@@ -203,11 +203,37 @@ __device__ __forceinline__ int fast_wrap(int c, int g) {
     c = c < 0 ? c + g : (c >= g ? c - g : c);
     return min(max(c, 0), g - 1);
 }
-template <typename PT, typename F>
+// SLAB (FAST == 2): an x-slab mesh (one or two windows of planes, TileGeom::xoff / xoff2) - y and z as above, along x every
+// cell of the cloud is mapped to its local plane (xloc; cells the slab does not hold drop out) and consecutive cells in the
+// same tile collapse: the list build of a rank of the multi-GPU estimator, which the generic code served at half the rate
+template <typename PT, bool SLAB, typename F>
 __device__ __forceinline__ void for_each_tile_fast(PT x, PT y, PT z, const TileGeom &g, PT offset, PT ihx, PT ihy, PT ihz, int ext,
                                                    F f) {
     Cloud<PT> c;
     tsc_cloud<PT>(x, y, z, offset, ihx, ihy, ihz, c);
+    if constexpr (SLAB) {
+        const int ya = fast_wrap(c.i[1] - 1, g.gy) >> g.shy, yb = fast_wrap(c.i[1] + 1 + ext, g.gy) >> g.shy;
+        const int za = fast_wrap(c.i[2] - 1, g.gz) >> g.shz, zb = fast_wrap(c.i[2] + 1 + ext, g.gz) >> g.shz;
+        const bool dy = ya != yb, dz = za != zb;
+        int last = -1;
+#pragma unroll
+        for (int a = -1; a <= 2; a++) {
+            if (a == 2 && !ext) break;
+            const int l = xloc(c.i[0] + a, g);
+            if (l < 0) continue;
+            const int t = l >> g.shx;
+            if (t == last) continue;
+            last = t;
+            const int ra = (t * g.nty + ya) * g.ntz, rb = (t * g.nty + yb) * g.ntz;
+            f((unsigned int)(ra + za));
+            if (dz) f((unsigned int)(ra + zb));
+            if (dy) {
+                f((unsigned int)(rb + za));
+                if (dz) f((unsigned int)(rb + zb));
+            }
+        }
+        return;
+    }
     const int xa = fast_wrap(c.i[0] - 1, g.gx) >> g.shx, xb = fast_wrap(c.i[0] + 1 + ext, g.gx) >> g.shx;
     const int ya = fast_wrap(c.i[1] - 1, g.gy) >> g.shy, yb = fast_wrap(c.i[1] + 1 + ext, g.gy) >> g.shy;
     const int za = fast_wrap(c.i[2] - 1, g.gz) >> g.shz, zb = fast_wrap(c.i[2] + 1 + ext, g.gz) >> g.shz;
@@ -370,7 +396,7 @@ __device__ __forceinline__ void for_each_tile(PT x, PT y, PT z, const TileGeom &
 
 // coarse pass over the particles: SCATTER=false counts entries per coarse bucket (and wraps in place),
 // SCATTER=true writes (entry, tile id) grouped by coarse bucket
-template <typename PT, bool CIC, bool SCATTER, bool FAST>
+template <typename PT, bool CIC, bool SCATTER, int FAST>
 __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int64_t n, const PT *__restrict__ weights,
                                                       TileGeom g, double box, double offset_, int wrap, int cshift,
                                                       int ncoarse, unsigned int *__restrict__ gcount,
@@ -402,7 +428,7 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
             }
         }
         auto count = [&](unsigned int tile) { atomicAdd(&hist[tile >> cshift], 1u); };
-        if constexpr (FAST) for_each_tile_fast<PT>(x, y, z, g, offset, ihx, ihy, ihz, ext, count);
+        if constexpr (FAST != 0) for_each_tile_fast<PT, FAST == 2>(x, y, z, g, offset, ihx, ihy, ihz, ext, count);
         else for_each_tile<PT, CIC>(x, y, z, g, box, offset, ihx, ihy, ihz, ext, count);
     }
     if (!SCATTER && any_changed) *wrapped_flag = 1;
@@ -437,7 +463,7 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
                 px[q] = pos[3 * p], py[q] = pos[3 * p + 1], pz[q] = pos[3 * p + 2];
                 pw[q] = weights ? weights[p] : (PT)1;
                 auto count = [&](unsigned int tile) { atomicAdd(&lcur[tile >> cshift], 1u); };
-                if constexpr (FAST) for_each_tile_fast<PT>(px[q], py[q], pz[q], g, offset, ihx, ihy, ihz, ext, count);
+                if constexpr (FAST != 0) for_each_tile_fast<PT, FAST == 2>(px[q], py[q], pz[q], g, offset, ihx, ihy, ihz, ext, count);
                 else for_each_tile<PT, CIC>(px[q], py[q], pz[q], g, box, offset, ihx, ihy, ihz, ext, count);
             }
         }
@@ -463,7 +489,7 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
                         stage_key[dst] = tile;
                     }
                 };
-                if constexpr (FAST) for_each_tile_fast<PT>(px[q], py[q], pz[q], g, offset, ihx, ihy, ihz, ext, place);
+                if constexpr (FAST != 0) for_each_tile_fast<PT, FAST == 2>(px[q], py[q], pz[q], g, offset, ihx, ihy, ihz, ext, place);
                 else for_each_tile<PT, CIC>(px[q], py[q], pz[q], g, box, offset, ihx, ihy, ihz, ext, place);
             }
         }
@@ -559,7 +585,7 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_fine(const int64_t *__restrict__ 
 }
 
 // contribution of one list entry to the LDS tile with origin (ox, oy, oz) and extent (dx, dy, dz)
-template <typename PT, int TYS, int TZS, bool CIC, typename ACC = double, bool FAST = false>
+template <typename PT, int TYS, int TZS, bool CIC, typename ACC = double, int FAST = 0>
 __device__ __forceinline__ void tile_accumulate(ACC *tile, const Entry<PT> &en, const TileGeom &g, int ox, int oy, int oz,
                                                 int dx, int dy, int dz, double box, PT offset, PT ihx, PT ihy, PT ihz) {
     int lx[3], ly[3], lz[3];
@@ -592,8 +618,8 @@ __device__ __forceinline__ void tile_accumulate(ACC *tile, const Entry<PT> &en, 
         tsc_cloud<PT>(en.x, en.y, en.z, offset, ihx, ihy, ihz, c);
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            if constexpr (FAST) {   // full mesh, wrapped positions: one compare-and-add each way (see for_each_tile_fast)
-                lx[a] = fast_wrap(c.i[0] + a - 1, g.gx) - ox;
+            if constexpr (FAST != 0) {   // wrapped positions: one compare-and-add each way (see for_each_tile_fast); x of a slab by its plane map
+                lx[a] = (FAST == 2 ? xloc(c.i[0] + a - 1, g) : fast_wrap(c.i[0] + a - 1, g.gx)) - ox;
                 ly[a] = fast_wrap(c.i[1] + a - 1, g.gy) - oy;
                 lz[a] = fast_wrap(c.i[2] + a - 1, g.gz) - oz;
             } else {
@@ -710,7 +736,7 @@ __device__ __forceinline__ void tsc_wait_vmcnt() {
 
 constexpr int TP_RANGE = 2048;   // consecutive tiles a persistent workgroup takes at a time (their list bounds sit in LDS)
 
-template <int TXS, int TYS, int TZS, bool CIC, int NT, typename ACC, bool FAST>
+template <int TXS, int TYS, int TZS, bool CIC, int NT, typename ACC, int FAST>
 __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__restrict__ entries, int64_t nentries,
                                                          const int64_t *__restrict__ tile_start, int ntiles, int range_len,
                                                          TileGeom g, double box, double offset_,
@@ -937,12 +963,14 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         HIP_TRY(hipMemsetAsync(gcount, 0, (size_t)(MS_BINS + 1) * sizeof(unsigned int), stream()));
         const int cgrid = (int)ceil_div(n, MS_CHUNK);
         // FAST: full mesh, power-of-two tiles obeying the four-cells-two-tiles rule, TSC (see for_each_tile_fast)
-        const bool fast = !CIC && wrap && g.gxg == g.gx && g.xoff == 0 && g.shx >= 0 && g.shy >= 0 && g.shz >= 0 && g.f4x && g.f4y &&
-                          g.f4z && g.gx >= 8 && g.gy >= 8 && g.gz >= 8;
+        const bool fastyz = !CIC && wrap && g.shx >= 0 && g.shy >= 0 && g.shz >= 0 && g.f4y && g.f4z && g.gy >= 8 && g.gz >= 8;
+        const bool fast = fastyz && g.gxg == g.gx && g.xoff == 0 && g.xoff2 < 0 && g.f4x && g.gx >= 8;
+        const bool fast_slab = fastyz && !fast && !option("tsc_noslabfast");   // an x-slab: y and z as on the full mesh
 #define MS_COARSE(SC, name, ...)                                                                                                  \
     do {                                                                                                                          \
-        if (fast) ABACUS_LAUNCH(name, (ms_coarse<PT, false, SC, true>), dim3(cgrid), dim3(MS_BLOCK), 0, __VA_ARGS__);             \
-        else ABACUS_LAUNCH(name, (ms_coarse<PT, CIC, SC, false>), dim3(cgrid), dim3(MS_BLOCK), 0, __VA_ARGS__);                   \
+        if (fast) ABACUS_LAUNCH(name, (ms_coarse<PT, false, SC, 1>), dim3(cgrid), dim3(MS_BLOCK), 0, __VA_ARGS__);                \
+        else if (fast_slab) ABACUS_LAUNCH(name, (ms_coarse<PT, false, SC, 2>), dim3(cgrid), dim3(MS_BLOCK), 0, __VA_ARGS__);      \
+        else ABACUS_LAUNCH(name, (ms_coarse<PT, CIC, SC, 0>), dim3(cgrid), dim3(MS_BLOCK), 0, __VA_ARGS__);                       \
     } while (0)
         MS_COARSE(false, "tsc_ms_coarse_count", pos, n, weights, g, box, offset, wrap, cshift, ncoarse, gcount,
                   (const int64_t *)nullptr, (Entry<PT> *)nullptr, (unsigned int *)nullptr, flag, ext);
@@ -1026,15 +1054,18 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
             // ACC = float (32-KiB tiles, 4 workgroups per CU) was measured 1.6-4.5x SLOWER (16.3 vs 9.3 ms at 2048^3, both
             // compile to native ds_add_f32 / ds_add_f64): kept float64, which also makes the mesh reproducible run to run
             // full mesh, TSC, positions wrapped into the box by the list build (`wrap`): single-step cell wraps suffice
-            const bool fastp = !CIC && wrap && g.gxg == g.gx && g.xoff == 0 && g.gx >= 8 && g.gy >= 8 && g.gz >= 8;
+            const bool fastp_yz = !CIC && wrap && g.gy >= 8 && g.gz >= 8;
+            const int fastp = !fastp_yz ? 0 : (g.gxg == g.gx && g.xoff == 0 && g.xoff2 < 0 && g.gx >= 8) ? 1 : (option("tsc_noslabfast") ? 0 : 2);
 #define LAUNCH_P(NTP, ACC, GRID, FASTP)                                                                               \
-    ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit_p<TX, TY, TZ, CIC && !FASTP, NTP, ACC, FASTP>), dim3(GRID), dim3(NTP), 0, \
+    ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit_p<TX, TY, TZ, CIC && FASTP == 0, NTP, ACC, FASTP>), dim3(GRID), dim3(NTP), 0, \
                   (const Entry<float> *)entries, (int64_t)nentries_total, (const int64_t *)tile_start, (int)ntiles,   \
                   range_len, g, box, offset, grid, zero_grid, (float)norm, (float)sub, dbg)
-            if (dense && fastp) LAUNCH_P(512, double, grid_p, true);
-            else if (dense) LAUNCH_P(512, double, grid_p, false);
-            else if (fastp) LAUNCH_P(256, double, grid_p, true);
-            else LAUNCH_P(256, double, grid_p, false);
+            if (dense && fastp == 1) LAUNCH_P(512, double, grid_p, 1);
+            else if (dense && fastp == 2) LAUNCH_P(512, double, grid_p, 2);
+            else if (dense) LAUNCH_P(512, double, grid_p, 0);
+            else if (fastp == 1) LAUNCH_P(256, double, grid_p, 1);
+            else if (fastp == 2) LAUNCH_P(256, double, grid_p, 2);
+            else LAUNCH_P(256, double, grid_p, 0);
 #undef LAUNCH_P
             return 0;
         }

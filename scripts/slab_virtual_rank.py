@@ -1,7 +1,7 @@
 """Per-rank kernel time of the slab P(k) at W ranks, measured on ONE GPU: rank R of W runs its deposit, z / y passes (y pass
 writing the send buffer), and the last pass + binning from a receive buffer, with the collectives stubbed out (the ring
 exchange and the all-to-all move nothing, so the spectrum is garbage - only the kernels' shapes and times are real).
-What an N-GPU run adds to these numbers is the time on the links.  Usage: slab_virtual_rank.py [W] [R] [nmesh] [npart_total]"""
+What an N-GPU run adds to these numbers is the time on the links.  Usage: slab_virtual_rank.py [W] [R] [nmesh] [npart_total] [option=value ...]"""
 import json
 import sys
 import time
@@ -48,6 +48,9 @@ def main():
     ntot = int(float(sys.argv[4])) if len(sys.argv) > 4 else 100_000_000
     L = 2000.0
     _lib.set_device(0)
+    for kv in sys.argv[5:]:                                  # option=value ...
+        k, _, v = kv.partition('=')
+        _lib.set_option(k, int(v or 1))
     n_local = ntot // W
     pos = np.random.default_rng(300 + R).random((n_local, 3), dtype=np.float32)
     slab = np.where(np.arange(n_local) < n_local // 2, R, R + W).astype(np.float32)
