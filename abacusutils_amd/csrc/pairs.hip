@@ -638,8 +638,10 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
                     if constexpr (LUT) {
                         // waves none of whose neighbour points needs the per-pair minimum image (all but those near the
                         // frame's cut) run the loop without that code
-                        auto run = [&](auto any_mixed) {
-                            constexpr bool MIX = decltype(any_mixed)::value;
+                        // ... and waves all of whose points come from segments without a periodic shift (every cell away from
+                        // the faces of the grid) run it without the shift additions
+                        auto run = [&](auto any_mixed, auto no_shift) {
+                            constexpr bool MIX = decltype(any_mixed)::value, PLAIN = decltype(no_shift)::value;
                             auto eval = [&](const int i, float &r2o, int &subo, bool &oko) {
                                 const int ii = i & 63;
                                 const float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vix), ii));
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
                                     const float my = dy > a.half ? -a.g.box : (dy < -a.half ? a.g.box : 0.f);
                                     const float mz = dz > a.half ? -a.g.box : (dz < -a.half ? a.g.box : 0.f);
                                     dx += mixed ? mx : sx, dy += mixed ? my : sy, dz += mixed ? mz : sz;
-                                } else {
+                                } else if (!PLAIN) {
                                     dx += sx, dy += sy, dz += sz;
                                 }
                                 const float adz = fabsf(dz);
@@ -685,8 +687,9 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
                                 count(r2, sub, ok, look(r2, ok));
                             }
                         };
-                        if (__any(mixed)) run(std::true_type());
-                        else run(std::false_type());
+                        if (__any(mixed)) run(std::true_type(), std::false_type());
+                        else if (__any(have && (flags & 0x1FF) != (2 | (2 << 3) | (2 << 6)))) run(std::false_type(), std::false_type());
+                        else run(std::false_type(), std::true_type());
                         continue;
                     }
                     for (int i = 0; i < ni; i++) {   // uniform trip count: readlane needs a wave-uniform index
