@@ -398,7 +398,7 @@ __global__ __launch_bounds__(PB) void pair_count2(PairArgs a, const int *__restr
 //     cells (c1, c1 + o) is (xi - xj) - L (w + s(c1) - s(c2)) with w the index wrap and s(c) = [c below the cut cell] - the
 //     same single float addition of 0 or -+L the per-pair minimum image performs.  Segments touching the cut cell or its
 //     two neighbours (mixed cells, float rounding at the cut) take the per-pair minimum image instead.
-constexpr int P3_WAVES = 4, P3_JCAP = 256, P3_ICAP = 64, P3_SLOTS = 64;
+constexpr int P3_WAVES = 4, P3_JCAP = 320, P3_ICAP = 64, P3_SLOTS = 64;
 
 //   * Bin of a pair (LUT): r^2 is a positive float, so its bit pattern is monotone in it; the pattern's top bits index a
 //     table of cells (2^m per octave, m chosen by the host so that no cell holds two edges) whose entry is the bin of the
