@@ -576,7 +576,7 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
         const int64_t j0 = cur.j0;
         const int len = cur.len, code = cur.code;
         // exclusive prefix of the segment lengths over the wave: the neighbour points of the cell form ONE virtual list, which
-        // is staged 128 at a time by all lanes at once (a segment at a time was one memory round trip per segment: 27 to 51
+        // is staged P3_JCAP (320) at a time by all lanes at once (a segment at a time was one memory round trip per segment: 27 to 51
         // dependent round trips per cell, 40 us - the kernel was latency-bound at 18 % of its instruction rate)
         int incl = len;
 #pragma unroll
