@@ -129,3 +129,46 @@ def test_slab_hip_rccl_single_rank(tmp_path, cross):
 def test_slab_forced_collectives_gloo_cpu(tmp_path):
     res = run_ranks(tmp_path, 1, 'numpy', 29642, flags=('--force-collectives',))
     check(res, reference(), 1, 20000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,rank,nmesh,n', [(4, 1, 256, 9_000_000), (8, 7, 512, 17_000_000), (2, 0, 128, 4_400_000), (4, 3, 64, 5000)])
+def test_two_window_deposit_of_a_rank_equals_the_planes_of_the_full_mesh(world, rank, nmesh, n):
+    """abacus_slab_deposit_dev with two windows (the folded slab pair of rank `rank` of `world`, ghosts included) on the particles
+    that rank owns (>= 2e6 of them: the multisplit list build with the slab fast path, and once with `tsc_noslabfast`; 5000:
+    the small-n path): every window plane equals the same plane of the whole-mesh deposit of those particles - bit for bit in the owned
+    planes' interior, and wherever both windows hold a plane the first one has the deposits and the second none"""
+    import ctypes as C
+
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis import slab_power as sp
+    box, G = 700.0, sp.GHOST
+    h = nmesh // (2 * world)
+    rng = np.random.default_rng(world * 100 + rank)
+    pos = (rng.random((n, 3), dtype=np.float32) * np.float32(box)).astype(np.float32)
+    mine = sp.slab_owner(pos[:, 0], box, world, True) == rank
+    pos = np.ascontiguousarray(pos[mine])
+    w = rng.uniform(0.5, 1.5, len(pos)).astype(np.float32)
+    be = sp.HipSlabBackend()
+    pitch = be.pitch(nmesh)
+    plane = nmesh * pitch
+    win = h + 2 * G
+    xa, xb = (rank * h - G) % nmesh, (rank * h + nmesh // 2 - G) % nmesh
+    full = sp.HipBuf(nmesh * plane)
+    be.deposit(be.upload_particles(pos, w), full, nmesh, 0, nmesh, box, 0.0, 1.0, 0, sub=0.0)
+    F = full.get(0, nmesh * plane).reshape(nmesh, nmesh, pitch)[:, :, :nmesh]
+    for noslabfast in (0, 1):
+        _lib.set_option('tsc_noslabfast', noslabfast)
+        two = sp.HipBuf(2 * win * plane)
+        be.deposit(be.upload_particles(pos, w), two, nmesh, xa, win, box, 0.0, 1.0, 0, sub=0.0, xoff2=xb)
+        T = two.get(0, 2 * win * plane).reshape(2 * win, nmesh, pitch)[:, :, :nmesh]
+        _lib.set_option('tsc_noslabfast', 0)
+        seen = set()
+        for k, x0 in enumerate((xa, xb)):
+            for i in range(win):
+                gp = (x0 + i) % nmesh
+                want = F[gp] if gp not in seen else np.zeros_like(F[gp])
+                seen.add(gp)
+                np.testing.assert_array_equal(T[k * win + i], want, err_msg=f'window {k} plane {i} (global {gp}), noslabfast={noslabfast}')
+        two.free()
+    full.free()
