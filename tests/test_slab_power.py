@@ -172,3 +172,44 @@ def test_two_window_deposit_of_a_rank_equals_the_planes_of_the_full_mesh(world, 
                 np.testing.assert_array_equal(T[k * win + i], want, err_msg=f'window {k} plane {i} (global {gp}), noslabfast={noslabfast}')
         two.free()
     full.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,nmesh,comp', [(8, 1024, 0), (8, 256, 1), (4, 512, 1)])
+def test_eight_ranks_as_threads_on_one_gpu(world, nmesh, comp):
+    """the north-star rank count on the one GPU of the box: W ranks of calc_power_slab as THREADS (tests/thread_comm.py; the
+    box allows six GPU processes), every rank with its own buffers, ghost ring over the 2 W slabs, all-to-all staged through
+    the host, the fused last pass reading blocks of eight peers (h = nmesh / 16) - against the single-GPU calc_power on the
+    union catalogue; 4 ranks of a 512^3 mesh: the plain three-pass form (unpack, x pass, spectrum_bin)"""
+    from thread_comm import run_ranks
+
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis import slab_power as sp
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    n = 600000
+    pos = synth_positions(n, L, seed=31, clustered=True)
+    w = np.random.default_rng(6).random(n, dtype=np.float32) + np.float32(0.5)
+    kw = dict(kbins=64 if nmesh >= 256 else 12, mubins=4, paste='TSC', nmesh=nmesh, compensated=bool(comp), interlaced=False,
+              poles=[0, 2, 4])
+    _lib.set_option('fft_fuse_small', 1 if nmesh == 256 else 0)
+    try:
+        ref = calc_power(pos.copy(), L, w=w, **kw)
+
+        def rank_fn(comm):
+            mine = slice(comm.rank, None, comm.world)
+            p1, w1 = sp.route_particles(pos[mine], w[mine], L, comm, fold=True)
+            t = sp.calc_power_slab(p1, L, comm=comm, backend=sp.HipSlabBackend(), w=w1, **kw)
+            return len(p1), {k: np.asarray(t[k]) for k in ('power', 'N_mode', 'poles', 'k_avg')}
+
+        res = run_ranks(world, rank_fn)
+    finally:
+        _lib.set_option('fft_fuse_small', 0)
+    assert sum(r[0] for r in res) == n
+    for _, t in res:
+        np.testing.assert_array_equal(t['N_mode'], np.asarray(ref['N_mode']))
+        scale = np.abs(np.asarray(ref['power'])).max()
+        np.testing.assert_allclose(t['power'], np.asarray(ref['power']), rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(t['poles'], np.asarray(ref['poles']), rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(t['k_avg'], np.asarray(ref['k_avg']), rtol=1e-6)
+    for _, t in res[1:]:
+        np.testing.assert_array_equal(t['power'], res[0][1]['power'])
