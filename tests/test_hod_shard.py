@@ -78,3 +78,24 @@ def test_sharded_hod_gloo_cpu(tmp_path):
 @pytest.mark.parametrize('world', [2, 3])
 def test_sharded_hod_hip(tmp_path, world):
     check(run_ranks(tmp_path, world, 'hip', 29660 + world), single())
+
+
+@pytest.mark.gpu
+def test_sharded_hod_eight_ranks_as_threads():
+    """eight shards on the one GPU (threads of one process, tests/thread_comm.py): the merged catalogue equals the
+    single-process one bit for bit, the all-reduced counts the totals"""
+    from thread_comm import run_ranks as run_threads
+
+    from abacusutils_amd import synth
+    from abacusutils_amd.hod import shard
+    hd, pd, params = synth.synth_hod_inputs(60000, 90000, seed=77)
+    tracers = {'LRG': dict(synth.LRG_PARAMS), 'ELG': dict(synth.ELG_PARAMS), 'QSO': dict(synth.QSO_PARAMS)}
+    tracers['ELG'].update(conf_c=0.4, conf_a=0.3)
+
+    def rank_fn(tc):
+        comm = shard.HodComm(tc)
+        cat = shard.run_hod_sharded(hd, pd, tracers, params, comm=comm, rsd=True)
+        local = shard.run_hod_sharded(hd, pd, tracers, params, comm=comm, rsd=True, gather=False)
+        return cat, comm.all_reduce_counts({t: (c['Ncent'], len(c['x']) - c['Ncent']) for t, c in local.items()})
+
+    check(run_threads(8, rank_fn), single())

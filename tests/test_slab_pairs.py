@@ -63,3 +63,22 @@ def test_slab_too_narrow():
         world, rank = 16, 0
     with pytest.raises(ValueError):
         sp.paircount_slab('r', np.zeros((4, 3), np.float32), 100.0, np.linspace(1, 10, 4), comm=Comm())
+
+
+@pytest.mark.gpu
+def test_slab_pairs_eight_ranks_as_threads(truth):
+    """eight x-slabs of width 12.5 for r_max = 12 on the one GPU (threads of one process, tests/thread_comm.py): exact counts"""
+    from thread_comm import run_ranks as run_threads
+
+    from abacusutils_amd.analysis import slab_pairs as sp
+    A, B = catalogues()
+
+    def rank_fn(comm):
+        mine = slice(comm.rank, None, comm.world)
+        res = {}
+        for name, c in CASES.items():
+            kw = {k: v for k, v in c.items() if k not in ('mode', 'bins', 'cross')}
+            res[name] = sp.paircount_slab(c['mode'], A[mine], 100.0, c['bins'], comm=comm, pos2=B[mine] if c['cross'] else None, **kw)
+        return res
+
+    check(run_threads(8, rank_fn), truth)

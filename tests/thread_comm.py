@@ -59,6 +59,13 @@ class ThreadComm:
     def all_reduce_int(self, v):
         return int(sum(self._exchange(int(v))))
 
+    # what hod.shard.HodComm needs from a transport
+    def all_reduce_array(self, a):
+        return np.sum(self._exchange(np.asarray(a).copy()), axis=0)
+
+    def all_gather_object(self, obj):
+        return self._exchange(obj)
+
     def all_to_all_host(self, arrays):
         allb = self._exchange([np.ascontiguousarray(a, dtype=np.float32).ravel() for a in arrays])
         return [allb[p][self.rank] for p in range(self.world)]
