@@ -213,3 +213,45 @@ def test_eight_ranks_as_threads_on_one_gpu(world, nmesh, comp):
         np.testing.assert_allclose(t['k_avg'], np.asarray(ref['k_avg']), rtol=1e-6)
     for _, t in res[1:]:
         np.testing.assert_array_equal(t['power'], res[0][1]['power'])
+
+
+@pytest.mark.gpu
+def test_config5_in_miniature_eight_ranks_as_threads():
+    """BASELINE config 5's composition on eight ranks (threads on the one GPU): sharded multi-tracer HOD -> every rank keeps its
+    galaxies -> folded-slab routing -> LRG x ELG cross P(k) over the slabs, and DD(r) of the ELGs over x-slabs - against the
+    single-process pipeline (one HOD, calc_power, the pair counter) on the same catalogue"""
+    from thread_comm import run_ranks
+
+    from abacusutils_amd import synth
+    from abacusutils_amd.analysis import slab_pairs, slab_power as sp
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from abacusutils_amd.analysis.tpcf_corrfunc import _paircount
+    from abacusutils_amd.hod import shard
+    from abacusutils_amd.hod.GRAND_HOD import gen_gal_cat
+    hd, pd, params = synth.synth_hod_inputs(400000, 600000, seed=91)
+    box = float(params['Lbox'])
+    tracers = {'LRG': dict(synth.LRG_PARAMS), 'ELG': dict(synth.ELG_PARAMS)}
+    kw = dict(kbins=24, mubins=3, paste='TSC', nmesh=128, compensated=True, interlaced=True, poles=[0, 2])
+    bins = np.geomspace(0.5, box / 8 * 0.9, 8).astype(np.float32)
+    one = gen_gal_cat(hd, pd, tracers, params, rsd=True)
+    xyz = {t: np.column_stack([one[t][c] for c in 'xyz']).astype(np.float32) for t in tracers}
+    assert len(xyz['LRG']) > 500 and len(xyz['ELG']) > 2000
+    ref_pk = calc_power(xyz['LRG'].copy(), box, pos2=xyz['ELG'].copy(), **kw)
+    e = xyz['ELG']
+    ref_dd = _paircount(0, e[:, 0], e[:, 1], e[:, 2], box, bins)
+
+    def rank_fn(tc):
+        local = shard.run_hod_sharded(hd, pd, tracers, params, comm=shard.HodComm(tc), rsd=True, gather=False)
+        mine = {t: np.column_stack([local[t][c] for c in 'xyz']).astype(np.float32) for t in tracers}
+        p1, _ = sp.route_particles(mine['LRG'], None, box, tc, fold=True)
+        p2, _ = sp.route_particles(mine['ELG'], None, box, tc, fold=True)
+        t = sp.calc_power_slab(p1, box, comm=tc, backend=sp.HipSlabBackend(), pos2=p2, **kw)
+        dd = slab_pairs.paircount_slab('r', mine['ELG'], box, bins, comm=tc)
+        return {k: np.asarray(t[k]) for k in ('power', 'N_mode', 'poles')}, dd
+
+    for t, dd in run_ranks(8, rank_fn):
+        np.testing.assert_array_equal(t['N_mode'], np.asarray(ref_pk['N_mode']))
+        scale = np.abs(np.asarray(ref_pk['power'])).max()
+        np.testing.assert_allclose(t['power'], np.asarray(ref_pk['power']), rtol=2e-5, atol=2e-6 * scale)
+        np.testing.assert_allclose(t['poles'], np.asarray(ref_pk['poles']), rtol=2e-5, atol=2e-6 * scale)
+        np.testing.assert_array_equal(dd, ref_dd)
