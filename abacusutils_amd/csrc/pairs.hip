@@ -68,7 +68,8 @@ __device__ __forceinline__ float funkey(unsigned int k) {
 template <bool COUNT>
 __global__ void cell_count(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
                            int64_t n, CellGrid g, unsigned int *__restrict__ counts, unsigned int *__restrict__ cellid,
-                           unsigned int *__restrict__ idx, int *__restrict__ outside, Frame *__restrict__ frame) {
+                           unsigned int *__restrict__ idx, float4 *__restrict__ packed, int *__restrict__ outside,
+                           Frame *__restrict__ frame) {
     bool out = false;
     unsigned int mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -77,7 +78,7 @@ __global__ void cell_count(const float *__restrict__ x, const float *__restrict_
                       cell_coord(v[2], g.ncz, g.inv_box);
         cellid[i] = (unsigned int)c;
         if (COUNT) atomicAdd(&counts[c], 1u);
-        else idx[i] = (unsigned int)i;
+        else idx[i] = (unsigned int)i, packed[i] = make_float4(v[0], v[1], v[2], 0.f);   // one 16-B piece per point for the gather
         out = out || !(v[0] >= 0.f && v[0] < g.box && v[1] >= 0.f && v[1] < g.box && v[2] >= 0.f && v[2] < g.box);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
@@ -118,12 +119,11 @@ __global__ void cell_fill(const float *__restrict__ x, const float *__restrict__
 
 // behind the radix sort of (cell id, point index): the points in cell order (ties in input order: the sort is stable, so
 // the sorted arrays do not depend on the run) ...
-__global__ void cell_gather(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, int64_t n,
-                            const unsigned int *__restrict__ idx, float *__restrict__ sx, float *__restrict__ sy,
-                            float *__restrict__ sz) {
+__global__ void cell_gather(const float4 *__restrict__ packed, int64_t n, const unsigned int *__restrict__ idx,
+                            float *__restrict__ sx, float *__restrict__ sy, float *__restrict__ sz) {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned int i = idx[s];
-        sx[s] = x[i], sy[s] = y[i], sz[s] = z[i];
+        const float4 p = packed[idx[s]];   // one memory sector per point instead of three (x, y, z live in separate arrays)
+        sx[s] = p.x, sy[s] = p.y, sz[s] = p.z;
     }
 }
 // ... and the first point of every cell: start[c] = number of keys below c (c = 0 .. ncell)
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
 }
 
 struct SortedSet {
-    DevBuf raw, sorted, counts, cellid, start, keys2, idx, idx2, tmp;
+    DevBuf raw, sorted, counts, cellid, start, keys2, idx, idx2, tmp, packed;
     float *sx, *sy, *sz;
     int64_t n;
 };
@@ -786,8 +786,9 @@ int sort_into_cells(const void *hx, const void *hy, const void *hz, int where, i
         ABACUS_TRY(s.keys2.reserve(n1 * 4));
         ABACUS_TRY(s.idx.reserve(n1 * 4));
         ABACUS_TRY(s.idx2.reserve(n1 * 4));
+        ABACUS_TRY(s.packed.reserve(n1 * 16));
         ABACUS_LAUNCH("pair_cell_count", cell_count<false>, dim3(nblk), dim3(256), 0, rx, ry, rz, n, g, (unsigned int *)nullptr,
-                      s.cellid.as<unsigned int>(), s.idx.as<unsigned int>(), d_outside, d_frame);
+                      s.cellid.as<unsigned int>(), s.idx.as<unsigned int>(), s.packed.as<float4>(), d_outside, d_frame);
         int end_bit = 1;
         while (((int64_t)1 << end_bit) < ncell) end_bit++;
         size_t tmp_bytes = 0;
@@ -798,7 +799,8 @@ int sort_into_cells(const void *hx, const void *hy, const void *hz, int where, i
                                                s.idx.as<unsigned int>(), s.idx2.as<unsigned int>(), (int)n, 0, end_bit,
                                                stream()) != hipSuccess)
             return fail("abacus_paircount: radix sort failed");
-        ABACUS_LAUNCH("pair_cell_fill", cell_gather, dim3(nblk), dim3(256), 0, rx, ry, rz, n, s.idx2.as<unsigned int>(), s.sx, s.sy, s.sz);
+        ABACUS_LAUNCH("pair_cell_fill", cell_gather, dim3(nblk), dim3(256), 0, s.packed.as<float4>(), n, s.idx2.as<unsigned int>(), s.sx,
+                      s.sy, s.sz);
         const int cblk = (int)std::min<int64_t>(ceil_div(ncell + 1, 256), 8192);
         ABACUS_LAUNCH("pair_cell_starts", cell_starts, dim3(cblk), dim3(256), 0, s.keys2.as<unsigned int>(), n, ncell, s.start.as<int64_t>());
         return 0;
@@ -806,7 +808,8 @@ int sort_into_cells(const void *hx, const void *hy, const void *hz, int where, i
     HIP_TRY(hipMemsetAsync(s.counts.p, 0, (size_t)(ncell + 1) * 4, stream()));
     if (n > 0)
         ABACUS_LAUNCH("pair_cell_count", cell_count<true>, dim3(nblk), dim3(256), 0, rx, ry, rz, n, g,
-                      s.counts.as<unsigned int>(), s.cellid.as<unsigned int>(), (unsigned int *)nullptr, d_outside, d_frame);
+                      s.counts.as<unsigned int>(), s.cellid.as<unsigned int>(), (unsigned int *)nullptr, (float4 *)nullptr, d_outside,
+                      d_frame);
     ABACUS_TRY(exclusive_scan_u32(s.counts.as<unsigned int>(), ncell, s.start.as<int64_t>(), scratch, 1));
     if (n > 0)
         ABACUS_LAUNCH("pair_cell_fill", cell_fill, dim3(nblk), dim3(256), 0, rx, ry, rz, n,
