@@ -444,7 +444,6 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
     const int ncx = a.g.ncx, ncy = a.g.ncy, ncz = a.g.ncz, W = 2 * R + 1;
     const int nrow = a.autocorr ? (W * W - 1) / 2 + 1 : W * W;     // half stencil: rows after (0, 0), then row (0, 0)
     const int nslot = 2 * nrow + (a.autocorr ? 1 : 0);
-    const int shi = nslot <= 32 ? 31 : 63;   // slots beyond nslot hold the total: the search may stop at the next power of two
     // s(c) - [c below the cut] - and the mixed set {cut-1, cut, cut+1} of a dimension
     auto below = [&](int d, int c) { return s_general[d] && c < s_cut[d] ? 1 : 0; };
     auto mixed1 = [&](int d, int c, int nc) {
@@ -585,8 +584,17 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
             if (lane >= d) incl += v;
         }
         const int M = __shfl(incl, 63, 64);
-        seg_j0[w][lane] = j0, seg_pre[w][lane] = incl - len, seg_code[w][lane] = code;
+        // the table holds the non-empty segments only, in order (half of the slots - the pieces that wrap in z - are empty for
+        // all but the outer cells): 14 of them for the half stencil, so the slot search of a staged point takes 4 steps, not 5
+        const bool nz = len > 0;
+        const unsigned long long nzmask = __ballot(nz);
+        const int nseg = __popcll(nzmask);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)nzmask, 0u));
+        const int slot = nz ? rank : nseg + (lane - rank);     // empty ones behind, as sentinels holding the total
+        seg_pre[w][slot] = nz ? incl - len : M;
+        if (nz) seg_j0[w][slot] = j0, seg_code[w][slot] = code;
         if (lane == 63) seg_pre[w][64] = M;
+        const int shi = nseg <= 16 ? 15 : (nseg <= 32 ? 31 : 63);
         wave_sync();
         for (int64_t i0 = cbeg; i0 < cend; i0 += P3_ICAP) {
             const int ni = (int)min((int64_t)P3_ICAP, cend - i0);
@@ -611,8 +619,8 @@ __global__ __launch_bounds__(P3_WAVES * 64) void pair_count3(PairArgs a, const F
                     tx[u] = ty[u] = tz[u] = 0.f;
                     if (q < cnt) {
                         const int v = base + q;
-                        int lo = 0, hi = shi;            // largest slot with seg_pre <= v (empty slots repeat the prefix:
-                        while (lo < hi) {                //  the LAST of equal prefixes is the non-empty one)
+                        int lo = 0, hi = shi;            // largest slot with seg_pre <= v
+                        while (lo < hi) {
                             const int mid = (lo + hi + 1) >> 1;
                             if (seg_pre[w][mid] <= v) lo = mid;
                             else hi = mid - 1;
