@@ -243,8 +243,13 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     d = Lbox / nmesh
     nfields = (2 if interlaced else 1) * (2 if pos2 is not None else 1)
     meshes = [backend.new_buffer(2 * win * plane) for _ in range(nfields)]
-    send = backend.new_buffer(2 * h * plane)
-    recv = backend.new_buffer(2 * h * plane)
+    lazy = {}                             # send / recv buffers of the transpose, allocated when a step needs them (one rank whose
+
+    def tbuf(name):                       # last pass bins straight from its mesh needs neither: 2 x 18 GB at 2048^3)
+        if name not in lazy:
+            lazy[name] = backend.new_buffer(2 * h * plane)
+        return lazy[name]
+
     ghost = backend.new_buffer(max(4 * g, 4))
     xa = r * h                            # first plane of the first slab; the second starts at xa + nmesh / 2
     own = g                               # float offset of the first owned plane
@@ -281,16 +286,16 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         cp = h // nchunk
         direct = try_xbin and not comm.collective           # one rank, fused last pass: no transpose at all
         for c in range(nchunk):
-            backend.fft_zy(mesh, own, None if direct else send, nmesh, W, xsep, xa, c * cp, cp)
+            backend.fft_zy(mesh, own, None if direct else tbuf('send'), nmesh, W, xsep, xa, c * cp, cp)
             if comm.collective:
                 for s_ in (0, 1):                             # the chunk's planes of either half within every peer block
-                    comm.all_to_all_piece(backend, send, recv, 2 * h * nyl * pitch, (s_ * h + c * cp) * nyl * pitch,
-                                          cp * nyl * pitch, overlap=nchunk > 1)
+                    comm.all_to_all_piece(backend, tbuf('send'), tbuf('recv'), 2 * h * nyl * pitch,
+                                          (s_ * h + c * cp) * nyl * pitch, cp * nyl * pitch, overlap=nchunk > 1)
         if comm.collective:
             comm.join()
         if direct:
             return (mesh, own)
-        got = recv if comm.collective else send
+        got = tbuf('recv') if comm.collective else tbuf('send')
         if try_xbin:                                          # (peer, 2 h, y_local, k) as delivered: for the fused last pass
             return (got, 0)
         backend.unpack(got, mesh, 0, nmesh, W)               # mesh now holds (y_local, x, k)
@@ -318,8 +323,8 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         if raw is None:      # not served: unpack, x pass, binning
             src, off = fields[0]
             if src is meshes[0]:                              # one rank went straight from its mesh: it still has to be packed
-                backend.pack(meshes[0], off, send, nmesh, W, xsep, 0, h)
-                src = send
+                backend.pack(meshes[0], off, tbuf('send'), nmesh, W, xsep, 0, h)
+                src = tbuf('send')
             backend.unpack(src, meshes[0], 0, nmesh, W)
             backend.fft_x(meshes[0], 0, nmesh, nyl)
             fields[0] = (meshes[0], 0)
@@ -327,7 +332,7 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         raw = backend.bin_raw(fields, nmesh, r * nyl, nyl, Lbox, Wk, interlaced, ke, me, poles_arr)
     raw = comm.all_reduce_raw(raw, (len(ke) - 1) * (len(me) - 1))
     power, N_mode, bp, Nmp, k_avg = backend.finalize(raw, Lbox, len(ke) - 1, len(me) - 1, poles_arr)
-    for b in meshes + [send, recv, ghost]:
+    for b in meshes + list(lazy.values()) + [ghost]:
         if hasattr(backend, 'release'):
             backend.release(b)
         elif hasattr(b, 'free'):
