@@ -296,7 +296,8 @@ def bench_pairs(args, dist):
            'roofline': {'bound': 'valu', 'kernel': 'pair_count', 'achieved': OPS * cand / tk / 1e12, 'peak': VALU_PEAK / 1e12,
                         'unit': 'T lane-ops/s', 'frac': OPS * cand / tk / VALU_PEAK,
                         'note': f'{OPS:.0f} vector instructions per candidate pair (inner loop of pair_count3); autocorrelation '
-                                'by half stencil: every unordered pair evaluated once'}}
+                                'by half stencil: every unordered pair evaluated once; two z-adjacent interior cells share one staged '
+                                'stencil, which adds the ~19 % of candidates a slice point sees of the other cell\'s far plane'}}
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu:
         from oracle import oracle
         cores = len(os.sched_getaffinity(0))
