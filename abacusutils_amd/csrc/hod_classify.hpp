@@ -72,6 +72,9 @@ CLS_HD Iv imul(Iv a, Iv b) {
     const float p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
     return widen(iv(fminf(fminf(p0, p1), fminf(p2, p3)), fmaxf(fmaxf(p0, p1), fmaxf(p2, p3))));
 }
+// product of two quantities that are non-negative by construction (occupation factors, weights, powers): two multiplies
+// instead of four and their min / max (a lower end that the widening pushed below zero counts as zero)
+CLS_HD Iv imul_pos(Iv a, Iv b) { return widen(iv(fmaxf(a.lo, 0.f) * fmaxf(b.lo, 0.f), a.hi * b.hi)); }
 CLS_HD Iv iscale(Iv a, float c) {   // c: a float constant known to 6e-8 (its error is inside the widening)
     return widen(c >= 0.f ? iv(a.lo * c, a.hi * c) : iv(a.hi * c, a.lo * c));
 }
@@ -180,7 +183,7 @@ CLS_HD int cent_classify(const ClsConst &c, double mass, double multis, double r
     if (c.want_LRG) {
         const Iv lc = affine(c.L.lc0, c.L.Ac, deltac, c.L.Bc, fenv, 0.f, 0.0);
         const Iv t = iscale(isub(lc, lM), c.L.inv_s);
-        m1 = imul(iscale(half_erfc(t, 0.f), c.L.ic), mu);
+        m1 = imul_pos(iscale(half_erfc(t, 0.f), c.L.ic), mu);
     }
     Iv m2 = m1;
     if (c.want_ELG) {
@@ -191,13 +194,13 @@ CLS_HD int cent_classify(const ClsConst &c, double mass, double multis, double r
         const Iv phi = iexp_neg((alo * alo) * h * (1.f - 4.f * CLS_R), (ahi * ahi) * h * (1.f + 4.f * CLS_R));
         const Iv y = iscale(d, c.E_gs);                              // gamma (logM - logM_cut) / sigma / sqrt(2)
         const Iv Phi = half_erfc(iv(-y.hi, -y.lo), 3e-16f);          // 0.5 (1 + erf(y)) = 0.5 erfc(-y)
-        m2 = iadd(m1, imul(iscale(imul(phi, Phi), c.E_K), mu));
+        m2 = iadd(m1, imul(iscale(imul_pos(phi, Phi), c.E_K), mu));      // E_K = 2 (p_max - 1/Q) ...: sign not guaranteed
     }
     Iv m3 = m2;
     if (c.want_QSO) {
         const Iv lc = affine(c.Q.lc0, c.Q.Ac, deltac, c.Q.Bc, fenv, 0.f, 0.0);
         const Iv t = iscale(isub(lc, lM), c.Q.inv_s);
-        m3 = iadd(m2, imul(iscale(half_erfc(t, 3e-16f), c.Q.ic), mu));
+        m3 = iadd(m2, imul_pos(iscale(half_erfc(t, 3e-16f), c.Q.ic), mu));
     }
     return pick_iv(r, m1, m2, m3);
 }
@@ -244,7 +247,7 @@ CLS_HD int sat_classify(const ClsConst &c, double hmass, double weights, double 
         const Iv M1 = T.is_const ? fconst(T.M1) : iexp10(affine(T.l10, T.As, d, T.Bs, f, 0.f, 0.0));
         const Iv Mcut = T.is_const ? fconst(T.Mcut) : iexp10(lc);
         const Iv t = iscale(isub(lc, ilog10(hmass)), T.inv_s);
-        Iv term = imul(imul(plaw_iv(M, T.kappa, Mcut, M1, T.alpha, T.alpha_is_one, ok), half_erfc(t, 0.f)), iscale(w, T.ic));
+        Iv term = imul_pos(imul_pos(plaw_iv(M, T.kappa, Mcut, M1, T.alpha, T.alpha_is_one, ok), half_erfc(t, 0.f)), iscale(w, T.ic));
         if (c.enable_ranks) term = imul(term, dec_iv(T.s, rk, rkv, rkp, rkr));
         m1 = term;
     }
@@ -275,7 +278,7 @@ CLS_HD int sat_classify(const ClsConst &c, double hmass, double weights, double 
         const Iv lc = affine(T.lc0, T.Ac, d, T.Bc, f, 0.f, 0.0);
         const Iv M1 = T.is_const ? fconst(T.M1) : iexp10(affine(T.l10, T.As, d, T.Bs, f, 0.f, 0.0));
         const Iv Mcut = T.is_const ? fconst(T.Mcut) : iexp10(lc);
-        Iv term = imul(plaw_iv(M, T.kappa, Mcut, M1, T.alpha, T.alpha_is_one, ok), iscale(w, T.ic));
+        Iv term = imul_pos(plaw_iv(M, T.kappa, Mcut, M1, T.alpha, T.alpha_is_one, ok), iscale(w, T.ic));
         if (c.enable_ranks) term = imul(term, dec_iv(T.s, rk, rkv, rkp, rkr));
         m3 = iadd(m2, term);
     }
