@@ -1192,14 +1192,14 @@ __device__ __forceinline__ void emit_one(const abacus_hod_params &p, const OutCo
     } else if (p.rsd) {
         z = wrap_box(z + vz * p.inv_velz2kms, p.lbox);
     }
-    o.c[t][0][j] = x;
-    o.c[t][1][j] = y;
-    o.c[t][2][j] = z;
-    o.c[t][3][j] = vx;
-    o.c[t][4][j] = vy;
-    o.c[t][5][j] = vz;
-    o.c[t][6][j] = mass;
-    o.id[t][j] = id;
+    __builtin_nontemporal_store(x, &o.c[t][0][j]);
+    __builtin_nontemporal_store(y, &o.c[t][1][j]);
+    __builtin_nontemporal_store(z, &o.c[t][2][j]);
+    __builtin_nontemporal_store(vx, &o.c[t][3][j]);
+    __builtin_nontemporal_store(vy, &o.c[t][4][j]);
+    __builtin_nontemporal_store(vz, &o.c[t][5][j]);
+    __builtin_nontemporal_store(mass, &o.c[t][6][j]);
+    __builtin_nontemporal_store(id, &o.id[t][j]);
 }
 
 // Ordered emission, one workgroup per superblock.  The output offset of a superblock is a workgroup reduction over
