@@ -175,7 +175,7 @@ def test_two_window_deposit_of_a_rank_equals_the_planes_of_the_full_mesh(world, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('world,nmesh,comp', [(8, 1024, 0), (8, 256, 1), (4, 512, 1)])
+@pytest.mark.parametrize('world,nmesh,comp', [(8, 1024, 0), (8, 256, 1), (4, 512, 1), (8, 2048, 1)])
 def test_eight_ranks_as_threads_on_one_gpu(world, nmesh, comp):
     """the north-star rank count on the one GPU of the box: W ranks of calc_power_slab as THREADS (tests/thread_comm.py; the
     box allows six GPU processes), every rank with its own buffers, ghost ring over the 2 W slabs, all-to-all staged through
@@ -186,7 +186,7 @@ def test_eight_ranks_as_threads_on_one_gpu(world, nmesh, comp):
     from abacusutils_amd import _lib
     from abacusutils_amd.analysis import slab_power as sp
     from abacusutils_amd.analysis.power_spectrum import calc_power
-    n = 600000
+    n = 600000 if nmesh < 2048 else 3_000_000       # 2048^3 on 8 ranks: BASELINE config 4's mesh, h = 128 planes per half
     pos = synth_positions(n, L, seed=31, clustered=True)
     w = np.random.default_rng(6).random(n, dtype=np.float32) + np.float32(0.5)
     kw = dict(kbins=64 if nmesh >= 256 else 12, mubins=4, paste='TSC', nmesh=nmesh, compensated=bool(comp), interlaced=False,
