@@ -607,6 +607,21 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
         }
     };
     __syncthreads();
+    // DEAD TILES: with ky^2 + kz^2 beyond the last edge already at the tile's first column no mode of the tile is binned,
+    // whatever kx - the corners of the (ky, kz) plane outside the circle of radius k_max: 21 % of the tiles when the bins end
+    // at the Nyquist frequency.  They are neither loaded nor transformed (N_mode and k_avg come from the cached geometry).
+    auto dead = [&](int o, int ctile) {
+        const int xh = o >= g.ny ? 1 : 0, yr = g.y0 + o - xh * g.ny;
+        const int j = ((yr & (H - 1)) << 1) | (yr >= H ? 1 : 0), jj = j < n / 2 ? j : j - n, k0 = ctile * C;
+        return !(g.dbg & 16) && jj * jj + k0 * k0 > d.vtop;
+    };
+    auto step = [&]() {
+        do {
+            og += dg, ct += dc;
+            if (ct >= ntile_c) ct -= ntile_c, og++;
+        } while (og < n_og && dead(og * ostep + grp, ct));
+    };
+    if (og < n_og && dead(og * ostep + grp, ct)) step();
     if (og < n_og) {
         prefetch(tile_ptr(og * ostep + grp, ct));
         wait_vmcnt<0>();
@@ -614,8 +629,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
         for (;;) {
             __syncthreads();
             const int o_cur = og * ostep + grp, ct_cur = ct;
-            og += dg, ct += dc;
-            if (ct >= ntile_c) ct -= ntile_c, og++;
+            step();
             const bool has_next = og < n_og;
             if (has_next) prefetch(tile_ptr(og * ostep + grp, ct));
             const int xh = o_cur >= g.ny ? 1 : 0;
