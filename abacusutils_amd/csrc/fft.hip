@@ -235,6 +235,11 @@ struct ColsPack {
     float2 *out;
     int lg_nyl, x0;
     int64_t peer_stride, x_stride;     // nxl * nyl * pitch_c, nyl * pitch_c (complex elements)
+    // x pass of the fused form in front of a binning that ends at k_max: a tile whose first column already has ky^2 + kz^2
+    // beyond skip_cut (in units of the fundamental, > 0 to enable) holds no mode the binning reads - it is not transformed.
+    // skip_n: mesh size (the y row of outer index o % skip_n holds frequency 2 (r mod n/2) + (r div n/2), folded)
+    float skip_cut = 0.f;
+    int skip_n = 0;
 };
 
 template <int N, int C, bool F1 = true, bool PACK = false>
@@ -306,6 +311,19 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
     const int n_og = n_outer / ostep;                       // outer indices of this group
     const int dg = (int)(qstep / (unsigned int)ntile_c), dc = (int)(qstep % (unsigned int)ntile_c);
     int og = (int)(q0 / (unsigned int)ntile_c), ct = (int)(q0 % (unsigned int)ntile_c);   // the q-th tile of the group
+    auto dead = [&](int o, int ctile) {
+        if (!(pk.skip_cut > 0.f)) return false;
+        const int yr = o % pk.skip_n, hh = pk.skip_n >> 1;
+        const int j = ((yr % hh) << 1) | (yr >= hh ? 1 : 0), jj = j < hh ? j : j - pk.skip_n, k0 = ctile * C;
+        return (float)(jj * jj + k0 * k0) > pk.skip_cut;
+    };
+    auto step = [&]() {
+        do {
+            og += dg, ct += dc;
+            if (ct >= ntile_c) ct -= ntile_c, og++;
+        } while (og < n_og && dead(og * ostep + grp, ct));
+    };
+    if (og < n_og && dead(og * ostep + grp, ct)) step();
     if (og >= n_og) return;
     int o_cur = og * ostep + grp, ct_cur = ct;
     float2 *gcur = tile_ptr(o_cur, ct);
@@ -315,8 +333,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
     stage();
     for (;;) {
         __syncthreads();
-        og += dg, ct += dc;
-        if (ct >= ntile_c) ct -= ntile_c, og++;
+        step();
         const bool has_next = og < n_og;
         const int o_next = og * ostep + grp, ct_next = ct;
         float2 *gnext = has_next ? tile_ptr(o_next, ct) : gcur;
@@ -442,11 +459,11 @@ int launch_cols1(const char *name, float2 *data, int64_t S, int ntile_c, int64_t
 }
 template <int N, int C>
 int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t outer, int64_t outer_stride, const float2 *tw,
-                int64_t outer_mod = (int64_t)1 << 40, int64_t outer_stride2 = 0) {
+                int64_t outer_mod = (int64_t)1 << 40, int64_t outer_stride2 = 0, ColsPack pk = ColsPack()) {
     if constexpr (wave_local(N))
         if (option("fft_cmode") == 1)
-            return launch_cols1<N, C, true>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2);
-    return launch_cols1<N, C, false>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2);
+            return launch_cols1<N, C, true>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2, pk);
+    return launch_cols1<N, C, false>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2, pk);
 }
 
 template <int N, int C, int BZ>
@@ -523,7 +540,7 @@ int fft_num_cus() { return num_cus(); }
 // x passes are n/2-point column transforms with C columns.  Output rows are in the permuted order
 // f = 2 (r mod n/2) + (r div n/2) along x and y (power.hip's binning undoes it in its index arithmetic).
 template <int N, int C>
-int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x) {
+int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x, float xcut = 0.f) {
     constexpr int H = N / 2;
     const int pitch_c = pitch_r / 2, kzlen = N / 2 + 1;
     const int ntile_c = (kzlen + C - 1) / C;
@@ -536,7 +553,10 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x) {
     if (!with_x) return 0;   // the caller runs the last pass fused with the binning (xbin.hip)
     // x: for every y and either half of x, H planes apart by N * pitch_c
     const int64_t S = (int64_t)N * pitch_c;
-    return launch_cols<H, C>("fft_cols_x", data, S, ntile_c, 2 * (int64_t)N, pitch_c, th->twN.as<float2>(), N, (int64_t)H * S);
+    ColsPack pk;
+    pk.out = nullptr, pk.lg_nyl = 0, pk.x0 = 0, pk.peer_stride = 0, pk.x_stride = 0;
+    pk.skip_cut = option("dbg_fft") & 16 ? 0.f : xcut, pk.skip_n = N;
+    return launch_cols<H, C>("fft_cols_x", data, S, ntile_c, 2 * (int64_t)N, pitch_c, th->twN.as<float2>(), N, (int64_t)H * S, pk);
 }
 
 // The fused form on the folded slabs of a multi-GPU mesh (analysis/slab_power.py): a rank owns h plane pairs (x, x + n/2),
@@ -613,18 +633,20 @@ int fft_native_fused_x_slab(float *mesh, int n, int pitch_r, int64_t ny_local) {
 // n = 256 only on request (tests against the CPU oracle): small meshes gain nothing from the fused form
 int fft_native_fused_supported(int n) { return n == 2048 || n == 1024 || (n == 256 && option("fft_fuse_small")); }
 
-static int fused_impl(float *mesh, int n, int pitch_r, bool with_x) {
+static int fused_impl(float *mesh, int n, int pitch_r, bool with_x, float xcut = 0.f) {
     Tables *t, *th;
     ABACUS_TRY(get_tables(n, &t));
     ABACUS_TRY(get_tables(n / 2, &th));
     switch (n) {
-        case 256: return fft3d_fused<256, 16>(mesh, pitch_r, t, th, with_x);
-        case 1024: return fft3d_fused<1024, 16>(mesh, pitch_r, t, th, with_x);
-        case 2048: return fft3d_fused<2048, 16>(mesh, pitch_r, t, th, with_x);
+        case 256: return fft3d_fused<256, 16>(mesh, pitch_r, t, th, with_x, xcut);
+        case 1024: return fft3d_fused<1024, 16>(mesh, pitch_r, t, th, with_x, xcut);
+        case 2048: return fft3d_fused<2048, 16>(mesh, pitch_r, t, th, with_x, xcut);
     }
     return fail("fft: the fused transform supports n = 1024 and 2048");
 }
-int fft_native_r2c_fused(float *mesh, int n, int pitch_r) { return fused_impl(mesh, n, pitch_r, true); }
+// xcut > 0: the caller bins the spectrum up to |k|^2 = xcut (fundamental units) and reads nothing beyond - the x pass leaves the
+// column tiles that lie entirely beyond untransformed (their content is then NOT the spectrum)
+int fft_native_r2c_fused(float *mesh, int n, int pitch_r, float xcut) { return fused_impl(mesh, n, pitch_r, true, xcut); }
 // z and y passes only: the x pass is left to fft_x_bin_run (last pass fused with the binning)
 int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r) { return fused_impl(mesh, n, pitch_r, false); }
 

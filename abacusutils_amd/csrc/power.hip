@@ -50,7 +50,7 @@ int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int
                          int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub, int xoff2);
 int fft_native_release();
 int fft_native_fused_supported(int n);
-int fft_native_r2c_fused(float *mesh, int n, int pitch_r);   // rows come out in the permuted order of fft.hip's fused form
+int fft_native_r2c_fused(float *mesh, int n, int pitch_r, float xcut = 0.f);   // rows come out in the permuted order of fft.hip's fused form
 int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r);
 bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
@@ -697,7 +697,7 @@ bool use_fused_fft(int nmesh) {
 
 // pf64: `pos` / `w` point to float64 values (cloud arithmetic in float64, analysis/tsc.py:400; float32 mesh)
 int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, int paste, int interlaced, int slot,
-                  bool fused = false, bool skip_x = false, DevBuf *dest = nullptr, int pf64 = 0) {
+                  bool fused = false, bool skip_x = false, DevBuf *dest = nullptr, int pf64 = 0, float xcut = 0.f) {
     if (!dest) dest = &g_ctx.mesh[slot];
     if (n <= 0) return fail("power: empty particle set");
     const bool native = fft_native_supported(nmesh) && !option("fft_hipfft");
@@ -723,7 +723,7 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
             ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste,
                                        interlaced ? (s == 0 ? 1 : 2) : 0));
         if (native && fused) {
-            ABACUS_TRY(skip_x ? fft_native_r2c_fused_zy(mesh, nmesh, (int)zstride) : fft_native_r2c_fused(mesh, nmesh, (int)zstride));
+            ABACUS_TRY(skip_x ? fft_native_r2c_fused_zy(mesh, nmesh, (int)zstride) : fft_native_r2c_fused(mesh, nmesh, (int)zstride, xcut));
         } else if (native) {
             ABACUS_TRY(fft_native_r2c_inplace(mesh, nmesh, (int)zstride));   // fft.hip: three passes, one per axis
         } else {
@@ -952,8 +952,16 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
                                 2.0 * M_PI / Lbox, 0);
         }
     }
-    ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, fused, false, nullptr, pf64));
-    if (cross) ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, interlaced, 2, fused, false, nullptr, pf64));
+    // the spectra of this call feed the binning below and nothing else: modes beyond its last k edge are never read, so the
+    // x pass may leave the column tiles that lie entirely beyond it untransformed (margin: one part in 1e5 + 1 against the
+    // float32 edge test of the binning)
+    float xcut = 0.f;
+    if (fused && Nk > 0) {
+        const double e = kedges[Nk] / (2.0 * M_PI / Lbox);
+        xcut = (float)(e * e * (1.0 + 1e-5) + 1.0);
+    }
+    ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, fused, false, nullptr, pf64, xcut));
+    if (cross) ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, interlaced, 2, fused, false, nullptr, pf64, xcut));
     SpecArgs s;
     fill_spec(s, nmesh, 1, interlaced, W_dev, cross);
     if (fused) {
