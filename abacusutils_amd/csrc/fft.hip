@@ -240,6 +240,10 @@ struct ColsPack {
     // skip_n: mesh size (the y row of outer index o % skip_n holds frequency 2 (r mod n/2) + (r div n/2), folded)
     float skip_cut = 0.f;
     int skip_n = 0;
+    // y pass (outer index o = 2 x + yhalf) in front of such a binning: output rows ky whose 16 columns all have
+    // ky^2 + kz^2 beyond wskip_cut are never read again - blocks of RS rows that are dead as a whole are not written back
+    // (the count of the stores a thread issues stays uniform over the workgroup, which the counted vmcnt wait needs)
+    float wskip_cut = 0.f;
 };
 
 template <int N, int C, bool F1 = true, bool PACK = false>
@@ -347,13 +351,24 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
                 Passes<N, N>::run(lds, CP, C, tw);
             }
         }
+        int nstored = NLD;
         if (!(dbg & 2)) {
             float2 *g = gcur;
+            const bool wskip = WHOLE && pk.wskip_cut > 0.f;
+            const int kz0 = ct_cur * C, half = o_cur & 1;
             // constant trip count: the compiler can then count these stores in its vmcnt bookkeeping
 #pragma unroll
             for (int q = 0; q < NLD; q++) {
                 const int e = q * FFT_THREADS + tid;
                 const int c2 = (e % (C / 2)) * 2, f = e / (C / 2);
+                if (wskip) {   // rows [q RS, (q + 1) RS) of this half: frequencies 2 f + half, |.| unimodal - the ends decide
+                    const int ja = 2 * (q * RS) + half, jb = 2 * (q * RS + RS - 1) + half;
+                    const int fa = ja < pk.skip_n / 2 ? ja : pk.skip_n - ja, fb = jb < pk.skip_n / 2 ? jb : pk.skip_n - jb, m = min(fa, fb);
+                    if ((float)(m * m + kz0 * kz0) > pk.wskip_cut) {
+                        nstored--;
+                        continue;
+                    }
+                }
                 if (WHOLE || f < N) {
                     const int p = padq(wave_local(N) ? f : revpos<N>(f));
                     const float2 a = lds[c2 * CP + p], b = lds[(c2 + 1) * CP + p];
@@ -371,6 +386,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
         __syncthreads();
         // the NLD stores above were issued after the prefetch loads: vmcnt(NLD) = all loads landed, stores in flight
         if (dbg & 2) wait_vmcnt<0>();
+        else if (nstored != NLD && NLD <= 16) wait_vmcnt_upto16(nstored);
         else wait_vmcnt<(NLD < 60 ? NLD : 0)>();
         stage();
         gcur = gnext, o_cur = o_next, ct_cur = ct_next;
@@ -548,8 +564,11 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x, fl
     ABACUS_TRY((launch_z<N / 2, 4, 1>(mesh, (int64_t)N * N, pitch_r, t)));
     float2 *data = reinterpret_cast<float2 *>(mesh);
     // y: 2 N half-planes of H rows each, contiguous in memory
+    ColsPack py;
+    py.out = nullptr, py.lg_nyl = 0, py.x0 = 0, py.peer_stride = 0, py.x_stride = 0;
+    py.wskip_cut = option("dbg_fft") & 16 ? 0.f : xcut, py.skip_n = N;
     ABACUS_TRY((launch_cols<H, C>("fft_cols_y", data, pitch_c, ntile_c, 2 * (int64_t)N, (int64_t)H * pitch_c,
-                                  th->twN.as<float2>())));
+                                  th->twN.as<float2>(), (int64_t)1 << 40, 0, py)));
     if (!with_x) return 0;   // the caller runs the last pass fused with the binning (xbin.hip)
     // x: for every y and either half of x, H planes apart by N * pitch_c
     const int64_t S = (int64_t)N * pitch_c;
@@ -648,7 +667,7 @@ static int fused_impl(float *mesh, int n, int pitch_r, bool with_x, float xcut =
 // column tiles that lie entirely beyond untransformed (their content is then NOT the spectrum)
 int fft_native_r2c_fused(float *mesh, int n, int pitch_r, float xcut) { return fused_impl(mesh, n, pitch_r, true, xcut); }
 // z and y passes only: the x pass is left to fft_x_bin_run (last pass fused with the binning)
-int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r) { return fused_impl(mesh, n, pitch_r, false); }
+int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r, float xcut) { return fused_impl(mesh, n, pitch_r, false, xcut); }
 
 int fft_native_release() {
     for (auto &kv : g_tables) {

@@ -41,6 +41,19 @@ __device__ __forceinline__ void wait_vmcnt_upto8(int k) {   // runtime count (un
         default: wait_vmcnt<0>(); break;
     }
 }
+__device__ __forceinline__ void wait_vmcnt_upto16(int k) {   // runtime count (uniform) 0 .. 16
+    switch (k) {
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        case 15: wait_vmcnt<15>(); break;
+        case 16: wait_vmcnt<16>(); break;
+        default: wait_vmcnt_upto8(k); break;
+    }
+}
 // ties registers to the wait above: their uses cannot be scheduled before it
 __device__ __forceinline__ void touch(v4f &a) {
     v4f t = a;

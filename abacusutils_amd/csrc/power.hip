@@ -51,7 +51,7 @@ int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int
 int fft_native_release();
 int fft_native_fused_supported(int n);
 int fft_native_r2c_fused(float *mesh, int n, int pitch_r, float xcut = 0.f);   // rows come out in the permuted order of fft.hip's fused form
-int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r);
+int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r, float xcut = 0.f);
 bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
                   int y0 = 0, int ny_local = 0, int put_geom = 1, int layout = 0, int world = 1);
@@ -723,7 +723,7 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
             ABACUS_TRY(tsc_deposit_f32(pos, n, w, mesh, nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste,
                                        interlaced ? (s == 0 ? 1 : 2) : 0));
         if (native && fused) {
-            ABACUS_TRY(skip_x ? fft_native_r2c_fused_zy(mesh, nmesh, (int)zstride) : fft_native_r2c_fused(mesh, nmesh, (int)zstride, xcut));
+            ABACUS_TRY(skip_x ? fft_native_r2c_fused_zy(mesh, nmesh, (int)zstride, xcut) : fft_native_r2c_fused(mesh, nmesh, (int)zstride, xcut));
         } else if (native) {
             ABACUS_TRY(fft_native_r2c_inplace(mesh, nmesh, (int)zstride));   // fft.hip: three passes, one per axis
         } else {
@@ -939,26 +939,26 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
     ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
     const bool fused = use_fused_fft(nmesh);
     const bool cross = pos2 != nullptr;
+    // the spectra of this call feed the binning below and nothing else: modes beyond its last k edge are never read, so the
+    // y pass need not write, and the x pass need not transform, what lies entirely beyond it (margin: one part in 1e5 + 1
+    // against the float32 edge test of the binning)
+    float xcut = 0.f;
+    if (fused && Nk > 0) {
+        const double e = kedges[Nk] / (2.0 * M_PI / Lbox);
+        xcut = (float)(e * e * (1.0 + 1e-5) + 1.0);
+    }
     if (fused && !interlaced && !cross && !option("pk_noxbin")) {
         // auto power of one field: the last FFT pass bins straight from LDS (xbin.hip) - no spectrum write + re-read
         BinArgs b;
         size_t acc_bytes = 0;
         ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
         if (xbin_supported(nmesh, Nk, Nmu, b, W_dev != nullptr)) {
-            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 0, 0, true, /*skip_x=*/true, nullptr, pf64));
+            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 0, 0, true, /*skip_x=*/true, nullptr, pf64, xcut));
             const double M = (double)nmesh * nmesh * nmesh;
             ABACUS_TRY(fft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg));
             return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
                                 2.0 * M_PI / Lbox, 0);
         }
-    }
-    // the spectra of this call feed the binning below and nothing else: modes beyond its last k edge are never read, so the
-    // x pass may leave the column tiles that lie entirely beyond it untransformed (margin: one part in 1e5 + 1 against the
-    // float32 edge test of the binning)
-    float xcut = 0.f;
-    if (fused && Nk > 0) {
-        const double e = kedges[Nk] / (2.0 * M_PI / Lbox);
-        xcut = (float)(e * e * (1.0 + 1e-5) + 1.0);
     }
     ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, fused, false, nullptr, pf64, xcut));
     if (cross) ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, interlaced, 2, fused, false, nullptr, pf64, xcut));
