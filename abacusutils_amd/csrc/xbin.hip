@@ -510,14 +510,16 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
 #pragma unroll 1
         for (int c = wave; c < C; c += XB_THREADS / 64) {
             float2 *col = lds + c * CP;
+            const int k = ct_cur * C + c;
+            const int r2 = jj * jj + k * k;
+            // padding columns of the last tile and columns that lie beyond the last edge as a whole: neither transformed nor binned
+            if (!(g.dbg & 16) && (k >= g.kzlen || r2 > d.vtop)) continue;
             if (!(g.dbg & 1)) {
                 dif_pass_w_regtw<H, H / 8, 8>(col, tw2, lane);          // the passes behind the one stage() performed
                 PassesW<H, H / 64>::run(col, nullptr, lane);            // last pass: no twiddles
                 wave_sync();
             }
-            const int k = ct_cur * C + c;
             if (k >= g.kzlen || (g.dbg & 2)) continue;
-            const int r2 = jj * jj + k * k;
             if (r2 > d.vtop) continue;                     // the whole column lies beyond the last edge
             int Uk[MU > 1 ? MU - 1 : 1];
 #pragma unroll
