@@ -111,6 +111,16 @@ def slab_environment(i, central, neighbours, numslabs, Lbox, Mpart, rad_outer=10
     return cid, cmass, Menv[:len(cid)]
 
 
+def _rows(a, idx):
+    """a[idx] along the first axis; a 2-D column is gathered as one item of row size (NumPy's fancy indexing of (n, 3) arrays
+    walks the elements: 2 - 3 times slower on the ~1e6-row tables of a slab)"""
+    a = np.asarray(a)
+    if a.ndim != 2 or not a.flags.c_contiguous or a.dtype.hasobject:
+        return a[idx]
+    v = a.view(np.dtype((np.void, a.dtype.itemsize * a.shape[1]))).ravel()
+    return np.take(v, idx).view(a.dtype).reshape(-1, a.shape[1])
+
+
 def _targets_host(masses, pnum, MT):
     """submask_particles' target count (:152-174) in the reference's own floating-point expressions (the host loop of
     rng='numpy' must draw exactly what the reference draws)"""
@@ -202,17 +212,30 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
             C.c_double(h), int(bool(ranks)), _lib.ptr(pstart_new), _lib.ptr(pnum_new), C.byref(nsel), C.c_int64(cap),
             *[_lib.ptr(o) for o in outs], _lib.ptr(sub_out)))
 
-    if submask is None:                          # device draw: size query first, then the same selection again
-        submask = np.zeros(max(npart, 1), dtype=np.uint8)[:npart]
-        call(None, 0, [None] * 8, submask)
+    # The number of kept particles is known before the call - the sum of the kept halos' targets (device draw) or of the host
+    # draw's mask - so the outputs are allocated once and a single call selects and emits (a size query plus a second call
+    # remains as the fallback should the bound ever be exceeded).
+    cap = int(submask.sum()) if submask is not None else int(ntarget[mask_halos].sum(dtype=np.int64))
+
+    def outputs(m):
+        return (np.empty(m, dtype=np.int64), np.empty(m, dtype=np.int64), np.empty(m),
+                [np.empty(m) for _ in RANK_COLUMNS] if want_ranks else [None] * 5)
+
+    sel_idx, sel_host, sel_np, rk = outputs(cap)
+    if cap:
+        call(submask, cap, [sel_idx, sel_host, sel_np] + rk, None, ranks=want_ranks)
     else:
         call(submask, 0, [None] * 8, None)
     n = int(nsel.value)
-    sel_idx, sel_host = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
-    sel_np = np.empty(n)
-    rk = [np.empty(n) for _ in RANK_COLUMNS] if want_ranks else [None] * 5
-    if n:
+    if n > cap:                                  # not expected: the bound above is exact for both kinds of draw
+        if submask is None:
+            submask = np.zeros(max(npart, 1), dtype=np.uint8)[:npart]
+            call(None, 0, [None] * 8, submask)
+        sel_idx, sel_host, sel_np, rk = outputs(n)
         call(submask, n, [sel_idx, sel_host, sel_np] + rk, None, ranks=want_ranks)
+    elif n < cap:
+        sel_idx, sel_host, sel_np = sel_idx[:n], sel_host[:n], sel_np[:n]
+        rk = [r[:n] if r is not None else None for r in rk]
     H['npstartA'], H['npoutA'] = pstart_new, pnum_new
     kept = np.flatnonzero(mask_halos)
     if numpy_mode:                                                                   # (:984-996): drawn for every halo
@@ -220,7 +243,7 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
         H['randoms'] = np.random.random(nh)
         H['randoms_exp'] = (np.random.randint(0, 2, size=(nh, 3)) * 2 - 1) * np.random.exponential(scale=sig, size=(nh, 3))
         H['randoms_gaus_vrms'] = np.random.normal(loc=0, scale=sig, size=(nh, 3))
-    Hk = {k: np.asarray(v)[kept] for k, v in H.items()}
+    Hk = {k: _rows(v, kept) for k, v in H.items()}
     if not numpy_mode:                                                               # drawn on the device, kept halos only
         nk = len(kept)
         scale = np.asarray(halos['sigmav3d_L2com'])[kept] / np.sqrt(3)
@@ -230,12 +253,12 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
                                             _lib.ptr(scale), _lib.ptr(Hk['randoms']), _lib.ptr(Hk['randoms_exp']),
                                             _lib.ptr(Hk['randoms_gaus_vrms'])))
 
-    P = {'pos': pos[sel_idx], 'vel': vel[sel_idx]}
+    P = {'pos': _rows(pos, sel_idx), 'vel': _rows(vel, sel_idx)}
     if want_ranks:
         for name, col in zip(RANK_COLUMNS, rk):
             P[name] = col
     P['downsample_halo'] = p_halos[sel_host]
-    P['halo_vel'] = hvel[sel_host].astype(np.float64)
+    P['halo_vel'] = _rows(hvel, sel_host).astype(np.float64)
     P['halo_mass'] = masses[sel_host].astype(np.float64)
     P['Np'] = sel_np
     P['halo_id'] = np.asarray(halos['id'])[sel_host].astype(np.int64)
