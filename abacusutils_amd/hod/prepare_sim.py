@@ -18,8 +18,10 @@ seeded like the reference agrees with it value for value (tests/test_prepare_gpu
 per-halo serial work), the random columns of both tables (abacus_prepare_randoms) - is made on the device as a function of
 (seed, global halo / particle index); same distributions and dtypes, another stream, restated by oracle/prepare_oracle.py.
 
-The light-cone edge correction of the environment (:469-597, randoms through a KD-tree) is not built: `halo_lc=True` with
-`want_AB` raises if any halo lies in the edge region.
+Light cones (`halo_lc=True`): the environment of halos within `rad_outer` of the survey boundary is corrected by the
+fraction of their annulus that lies inside it, measured with randoms (:474-616).  `lightcone_environment` draws the randoms
+on the host from `default_rng(seed)` in the reference's order (so a run seeded like the reference counts the same points)
+and counts them around the edge halos on the device (`abacus_menv` with unit-mass randoms; the reference queries a KD-tree).
 """
 import ctypes as C
 
@@ -28,7 +30,8 @@ import numpy as np
 from .. import _lib
 from .menv import do_Menv_from_tree
 
-__all__ = ['subsample_halos', 'prepare_slab_arrays', 'slab_environment', 'rank_in_mass_bins', 'reference_seed', 'save_subsample']
+__all__ = ['subsample_halos', 'prepare_slab_arrays', 'slab_environment', 'lightcone_environment', 'lightcone_edge_norm',
+           'rank_in_mass_bins', 'reference_seed', 'save_subsample']
 
 NBINS = 100          # mass bins of the rank columns (:454)
 RANK_COLUMNS = ('ranks', 'ranksv', 'ranksp', 'ranksr', 'ranksc')
@@ -121,6 +124,119 @@ def _rows(a, idx):
     return np.take(v, idx).view(a.dtype).reshape(-1, a.shape[1])
 
 
+LC_OFFSET = 10.0     # the light-cone catalogues stop this far inside the box faces (:481)
+
+
+def _lightcone_cuboids(Lbox, offset, origins, chi_max):
+    """(lo, hi) corners, relative to the observer, of the boxes a light-cone shell of outer radius chi_max can reach (:230-262):
+    the box around 0 with `offset` shaved off every face an observer in its corner looks through - all six for a single
+    observer in the centre - and, for the three-origin geometry once the shell reaches beyond the first box, its two copies."""
+    half = Lbox / 2.0
+    single = origins.shape[0] == 1
+    lo = np.array([-half + offset, -half + offset, -half + offset])
+    hi = np.array([half - offset, half - offset if single else half, half - offset if single else half])
+    shifts = [np.array([0.0, 0.0, 0.0])]
+    if not single:
+        if origins.shape[0] != 3 or not (np.all(origins[1] + np.array([0.0, 0.0, Lbox]) == origins[0])
+                                         and np.all(origins[2] + np.array([0.0, Lbox, 0.0]) == origins[0])):
+            raise ValueError('light-cone origins: one observer, or three with origins[1] = origins[0] - (0, 0, L) and '
+                             'origins[2] = origins[0] - (0, L, 0)')
+        if chi_max >= (Lbox - offset):
+            shifts += [np.array([0.0, 0.0, Lbox]), np.array([0.0, Lbox, 0.0])]
+    return [((c - origins[0]) + lo, (c - origins[0]) + hi) for c in shifts]
+
+
+def _lightcone_randoms(n, chi_min, chi_max, Lbox, offset, origins, rng):
+    """n uniform points of the shell [chi_min, chi_max) around origins[0] - the octant of positive directions when there are
+    three origins - cut to the boxes (gen_rand, :200-278: three `rng.random(n)` in this order: cos(theta), phi, radius).
+    Returns (positions (m, 3) float64, distances (m,))."""
+    if origins.shape[0] > 1:
+        cost = rng.random(n)
+        phi = rng.random(n) * np.pi / 2.0
+    else:
+        cost = rng.random(n) * 2.0 - 1.0
+        phi = rng.random(n) * 2.0 * np.pi
+    theta = np.arccos(cost)
+    st = np.sin(theta)
+    chi = rng.random(n) * (chi_max - chi_min) + chi_min
+    xyz = [st * np.cos(phi) * chi, st * np.sin(phi) * chi, np.cos(theta) * chi]
+    inside = np.zeros(n, dtype=bool)
+    for lo, hi in _lightcone_cuboids(Lbox, offset, origins, chi_max):
+        m = np.ones(n, dtype=bool)
+        for d in range(3):
+            m &= (xyz[d] > lo[d]) & (xyz[d] <= hi[d])
+        inside |= m
+    pos = np.vstack([c[inside] for c in xyz]).T
+    pos += origins[0]
+    return pos, chi[inside]
+
+
+def _lightcone_interior(pos, dist, Lbox, offset, origins, pad, r_min, r_max):
+    """points at least `pad` inside every boundary of the light-cone volume - the shaved box faces and the two shell radii
+    (:483-511, :516-529).  Python-float bounds against float32 columns compare in float32, as in the reference."""
+    half = Lbox / 2.0
+    lo = -(half - offset - pad)
+    hi_x = half - offset - pad
+    hi_yz = half - offset - pad if origins.shape[0] == 1 else 3.0 / 2 * Lbox - pad
+    return ((lo <= pos[:, 0]) & (hi_x >= pos[:, 0]) & (lo <= pos[:, 1]) & (hi_yz >= pos[:, 1]) & (lo <= pos[:, 2])
+            & (hi_yz >= pos[:, 2]) & (r_min + pad <= dist) & (r_max - pad >= dist))
+
+
+def lightcone_edge_norm(pos, r98, Lbox, origins, seed, rad_outer=10, rand_final=10):
+    """The edge halos of a light-cone catalogue and the completeness of their environment annulus (:474-597).
+
+    pos (n, 3), r98 (n,): halo positions and inner radii as the catalogue stores them (float32); origins: the header's
+    `LightConeOrigins`; seed: the `halo_lc_randoms_seed` of the slab (`reference_seed`).  Returns (index_bounds, rand_norm):
+    the halos closer than rad_outer to a boundary, and for each the number of randoms counted in [r98, rad_outer] over the
+    number expected in an unbounded field (~1 inside, < 1 at the boundary).  Randoms: `default_rng(seed)`, len(pos) per
+    round, until ten times as many as edge halos fell into the boundary layer of width 2 rad_outer; counted on the device."""
+    pos = np.asarray(pos)
+    r98 = np.asarray(r98)
+    Lbox = float(Lbox)
+    origins = np.asarray(origins, dtype=np.float64).reshape(-1, 3)
+    dist = np.sqrt(np.sum((pos - origins[0]) ** 2.0, axis=1))
+    r_min, r_max = dist.min(), dist.max()
+    edge = np.flatnonzero(~_lightcone_interior(pos, dist, Lbox, LC_OFFSET, origins, rad_outer, r_min, r_max))
+    norm = np.zeros(len(edge))
+    if len(edge) == 0:
+        return edge, norm
+    n = pos.shape[0]
+    shell = 4.0 / 3.0 * np.pi * (r_max**3 - r_min**3) if origins.shape[0] == 1 else 4.0 / 3.0 / 8.0 * np.pi * (r_max**3 - r_min**3)
+    density = n / shell                          # randoms per volume and round
+    rng = np.random.default_rng(seed)
+    centres = np.ascontiguousarray(pos[edge], dtype=np.float64)
+    inner = np.asarray(r98[edge], dtype=np.float64)
+    count = rounds = 0
+    while count < len(edge) * rand_final:
+        rpos, rdist = _lightcone_randoms(n, r_min, r_max, Lbox, LC_OFFSET, origins, rng)
+        rpos = rpos[~_lightcone_interior(rpos, rdist, Lbox, LC_OFFSET, origins, 2.0 * rad_outer, r_min, r_max)]
+        if len(rpos):
+            # randoms of mass 1 around centres of mass 0: every point is a centre (mcut < 0), only randoms weigh
+            both = np.concatenate([centres, rpos])
+            mass = np.concatenate([np.zeros(len(edge)), np.ones(len(rpos))])
+            ri = np.concatenate([inner, np.zeros(len(rpos))])
+            norm += do_Menv_from_tree(both, mass, r_inner=ri, r_outer=float(rad_outer), halo_lc=True, Lbox=Lbox, mcut=-1.0)[:len(edge)]
+        rounds += 1
+        count += len(rpos)
+    density *= rounds
+    norm /= (rad_outer**3.0 - r98[edge] ** 3.0) * 4.0 / 3.0 * np.pi * density
+    return edge, norm
+
+
+def lightcone_environment(pos, masses, r98, Lbox, origins, seed, rad_outer=10, mcut=1e11):
+    """Menv of a light-cone slab with the edge correction (:474-616): the open-geometry `do_Menv_from_tree`, divided for the
+    edge halos by the completeness of their annulus (0 where no random fell into it)."""
+    edge, norm = lightcone_edge_norm(pos, r98, Lbox, origins, seed, rad_outer=rad_outer)
+    Menv = do_Menv_from_tree(pos, masses, r_inner=r98, r_outer=rad_outer, halo_lc=True, Lbox=Lbox, mcut=mcut)
+    if len(edge):
+        empty = norm == 0.0
+        norm[empty] = 1.0
+        corrected = Menv[edge] / norm
+        corrected[empty] = 0.0
+        Menv[edge] = corrected
+    return Menv
+
+
 def _targets_host(masses, pnum, MT):
     """submask_particles' target count (:152-174) in the reference's own floating-point expressions (the host loop of
     rng='numpy' must draw exactly what the reference draws)"""
@@ -138,13 +254,15 @@ def _targets_host(masses, pnum, MT):
 
 
 def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=True, Menv=None, shearmark=None, Lbox=None,
-                        mcut=1e11, halo_lc=False, rng='numpy', part_index0=0, halo_index0=0):
+                        mcut=1e11, halo_lc=False, rng='numpy', part_index0=0, halo_index0=0, origins=None, lc_seed=None,
+                        rad_outer=10):
     """halos: dict of columns N, x_L2com, v_L2com, r25_L2com, r90_L2com, r98_L2com, npstartA, npoutA, id, sigmav3d_L2com (what
     CompaSOHaloCatalog loads for prepare_slab, :404-425); parts: dict with pos, vel of the slab's subsample-A particles in halo
     order.  Returns (halo table of the kept halos, particle table of the kept particles, mask over the input halos): dicts with
     the field names and dtypes of the reference's 'halos' / 'particles' datasets (:1001-1045).
     rng: 'numpy' consumes NumPy's global legacy generator in the reference's order (seed it like the reference and the tables
-    come out value for value); an integer seeds the device's counter-based generator - every draw is then a function of (seed,
+    come out value for value; light cones: pass `origins` (header LightConeOrigins) and `lc_seed`, the second value of
+    `reference_seed`); an integer seeds the device's counter-based generator - every draw is then a function of (seed,
     global halo / particle index = halo_index0 / part_index0 + row), so slabs prepared on different GPUs fit together."""
     nh = len(halos['N'])
     N = np.ascontiguousarray(halos['N'], dtype=np.uint32)
@@ -170,8 +288,11 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
     if want_AB:
         if halo_lc:
             if Menv is None:
-                raise ValueError('halo_lc with want_AB needs the environment masses (do_Menv_from_tree); the edge correction '
-                                 'with randoms (:469-597) is not built')
+                if origins is None or lc_seed is None or Lbox is None:
+                    raise ValueError('halo_lc with want_AB needs the environment masses (Menv), or Lbox, the light-cone origins '
+                                     'and the seed of the randoms (lc_seed, see reference_seed) to work them out')
+                Menv = lightcone_environment(halos['x_L2com'], masses, halos['r98_L2com'], Lbox, origins, lc_seed,
+                                             rad_outer=rad_outer, mcut=mcut)                # (:474-616)
             H['fenv_rank'] = rank_in_mass_bins(Menv, masses, mbins)                  # calc_fenv_opt (:618)
         else:
             H['fenv_rank'] = zeros.copy()         # ranked over the whole box later, by AbacusHOD.staging() (:758-759)

@@ -171,6 +171,44 @@ def synth_compaso_slabs(numslabs=3, n_halo=3000, seed=900, lbox=300.0, mpart=MPA
     return out, header
 
 
+def synth_lightcone_slab(n_halo=2500, seed=950, lbox=300.0, geometry='octant', chi=None, **kw):
+    """One slab of a halo light-cone catalogue as `prepare_slab(halo_lc=True)` sees it (hod/prepare_sim.py:362-433): the tables
+    of `synth_compaso_slabs` with the halos moved into a shell around the observer - `geometry='octant'`: the three-origin
+    layout of the base boxes (observer 10 Mpc/h inside the box corner, header `LightConeOrigins` of three rows), positive
+    directions only; `'centre'`: one observer in the middle of the box, the shell cut by the box faces.  The particles move
+    with their hosts.  Returns (slab dict, header)."""
+    slabs, header = synth_compaso_slabs(numslabs=1, n_halo=n_halo, seed=seed, lbox=lbox, **kw)
+    halos, parts = slabs[0]['halos'], slabs[0]['parts']
+    rng = np.random.default_rng(seed + 7919)
+    half, off = 0.5 * lbox, 10.0
+    if geometry == 'octant':
+        o0 = np.array([-half + off] * 3)
+        origins = np.array([o0, o0 - [0.0, 0.0, lbox], o0 - [0.0, lbox, 0.0]])
+        chi = chi or (0.3 * lbox, 0.85 * lbox)
+    elif geometry == 'centre':
+        origins = np.zeros((1, 3))
+        chi = chi or (0.2 * lbox, 0.5 * lbox)
+    else:
+        raise ValueError(geometry)
+    x = np.empty((0, 3), dtype=np.float32)
+    while len(x) < n_halo:
+        m = 4 * n_halo
+        u = _unit_vectors(rng, m)
+        if geometry == 'octant':
+            u = np.abs(u)
+        r = (chi[0] ** 3 + rng.random(m) * (chi[1] ** 3 - chi[0] ** 3)) ** (1.0 / 3.0)
+        cand = (origins[0] + u * r[:, None]).astype(np.float32)
+        hi = half - off if geometry == 'centre' else half
+        ok = np.all(cand > np.float32(-half + off), axis=1) & (cand[:, 0] <= np.float32(half - off)) & np.all(cand[:, 1:] <= np.float32(hi), axis=1)
+        x = np.concatenate([x, cand[ok]])[:n_halo]
+    shift = x - halos['x_L2com']
+    host = np.repeat(np.arange(n_halo), halos['npoutA'])
+    parts['pos'] = (parts['pos'] + shift[host]).astype(np.float32)
+    halos['x_L2com'] = x
+    header = dict(header, LightConeOrigins=[float(v) for v in origins.ravel()])
+    return dict(halos=halos, parts=parts), header
+
+
 def _unit_vectors(rng, n):
     u = rng.standard_normal((n, 3))
     return u / np.sqrt((u * u).sum(axis=1))[:, None]

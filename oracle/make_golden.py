@@ -30,7 +30,8 @@ What is captured
   pair_wrappers.npz           calc_xirppi_fast / calc_wp_fast / calc_multipole_fast / tpcf_multipole with a brute-force
         stand-in for Corrfunc's counters (pins the wrapper arithmetic, not Corrfunc).
 
-  prepare_sim.npz             prepare_sim.prepare_slab (hod/prepare_sim.py:296-1052) on seeded synthetic slabs with stand-ins
+  prepare_sim.npz             prepare_sim.prepare_slab (hod/prepare_sim.py:296-1052) on seeded synthetic slabs (periodic box and
+                              halo light cones) with stand-ins
         for its file layer (CompaSOHaloCatalog -> synth tables, h5py -> capture): three configurations (MT / LRG-only,
         ranks, assembly bias with the padded Menv, shear).
 
@@ -786,6 +787,13 @@ PREPARE_CASES = {
     'mt_ranks_ab_shear': (2, True, True, True, True),
 }
 PREPARE_SYNTH = dict(numslabs=3, n_halo=1500, seed=900, lbox=300.0)
+# halo light cones (halo_lc=True, :362-433 loader keys, :474-616 environment with the edge correction by randoms):
+# name: (geometry of synth.synth_lightcone_slab, slab index i (enters the seeds), MT, want_ranks)
+PREPARE_LC_CASES = {
+    'lc_octant': ('octant', 0, True, False),      # three origins, as the base boxes
+    'lc_centre': ('centre', 2, False, True),      # one observer in the middle of the box, as the huge boxes
+}
+PREPARE_LC_SYNTH = dict(n_halo=2500, seed=950, lbox=300.0)
 
 
 def prepare_shearmark(ndim=16, seed=5):
@@ -798,10 +806,18 @@ def gen_prepare():
     slabs, header = synth.synth_compaso_slabs(**PREPARE_SYNTH)
     captured = {}
 
-    class FakeCat:
-        halo_lc = False
+    lc = {}     # the light-cone slab the stand-in catalogue serves next (its file name carries no slab index)
 
+    class FakeCat:
         def __init__(self, slabname, subsamples=None, fields=None, cleaned=True, filter_func=None, **kw):
+            self.halo_lc = str(slabname).endswith('lc_halo_info.asdf')
+            if self.halo_lc:
+                self.header = dict(lc['header'])
+                rename = {'id': 'index_halo', 'x_L2com': 'pos_interp', 'v_L2com': 'vel_interp', 'N': 'N_interp'}   # (:370-373)
+                self.halos = Table({rename.get(k, k): v.copy() for k, v in lc['slab']['halos'].items()})
+                if subsamples:
+                    self.subsamples = Table({k: v.copy() for k, v in lc['slab']['parts'].items()})
+                return
             i = int(re.search(r'halo_info_(\d+)\.asdf', str(slabname)).group(1))
             self.header = dict(header)
             H = Table({k: v.copy() for k, v in slabs[i]['halos'].items()})
@@ -854,6 +870,31 @@ def gen_prepare():
             nk = len(out[f'{case}.halos.id'])
             print(case, 'halos kept', nk, 'particles kept', len(out[f'{case}.particles.pos']),
                   'env' if f'{case}.env.Menv' in out else 'no env')
+        # light cones: the corrected environment masses are an intermediate of the reference (the argument of its
+        # calc_fenv_opt, :618) - recorded on the way through, next to the tables it writes
+        ranker = PS.calc_fenv_opt
+        seen = {}
+
+        def recording_ranker(Menv, mbins, halosM):
+            seen['Menv'] = np.array(Menv, dtype=np.float64)
+            return ranker(Menv, mbins, halosM)
+
+        PS.calc_fenv_opt = recording_ranker
+        out['meta.lc_synth_json'] = np.array(__import__('json').dumps(PREPARE_LC_SYNTH))
+        for case, (geometry, i, MT, want_ranks) in PREPARE_LC_CASES.items():
+            captured.clear()
+            seen.clear()
+            lc['slab'], lc['header'] = synth.synth_lightcone_slab(geometry=geometry, **PREPARE_LC_SYNTH)
+            with contextlib.redirect_stdout(io.StringIO()):
+                PS.prepare_slab(i, td, '/sim', 'Synth', 0.5, 'lightcone', {}, MT, want_ranks, True, False, None, True, 600,
+                                halo_lc=True, nthread=1, overwrite=1, mcut=1e11, rad_outer=10, numslabs=1)
+            for (fn, dset), val in captured.items():
+                for k, v in val.items():
+                    out[f'{case}.{dset}.{k}'] = v
+            out[f'{case}.Menv_corrected'] = seen['Menv']
+            print(case, 'halos kept', len(out[f'{case}.halos.id']), 'particles kept', len(out[f'{case}.particles.pos']),
+                  'Menv > 0:', int((seen['Menv'] > 0).sum()))
+        PS.calc_fenv_opt = ranker
     np.savez_compressed(GOLD / 'prepare_sim.npz', **out)
     print('prepare_sim written', os.path.getsize(GOLD / 'prepare_sim.npz') // 1024, 'KiB')
 

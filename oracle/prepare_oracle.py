@@ -2,7 +2,8 @@
 `prepare_sim.prepare_slab` (abacusnbody/hod/prepare_sim.py:296-1052): halo down-sampling, concentration / environment /
 shear ranks, per-halo particle selection, the five satellite rank columns, the per-particle host columns and the random
 columns - everything between "the CompaSO loader handed over `halos` and `parts`" and "the two HDF5 datasets are written".
-File I/O, the CompaSO / ASDF readers and the light-cone edge correction (:469-597) are not restated.
+The light-cone edge correction of the environment (:474-616, `gen_rand` :200-278) is restated by `lightcone_menv`.
+File I/O and the CompaSO / ASDF readers are not restated.
 
 Pinned by golden vectors of the REFERENCE's own prepare_slab run under the shims of oracle/make_golden.py on seeded synthetic
 slabs (tests/golden/prepare_sim.npz, tests/test_oracle_prepare.py).  Random numbers: the reference consumes NumPy's global
@@ -184,6 +185,88 @@ def prepare_slab_core(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=True
     P['halo_fenv'] = H['fenv_rank'][hp]
     P['halo_shear'] = H['shear_rank'][hp]
     return Hk, P, mask_halos
+
+
+# ---- light cones: environment with the edge correction (:474-616) ------------------------------------------------------------
+def lightcone_shell_randoms(N, chi_min, chi_max, Lbox, offset, origins, rng):
+    """gen_rand (:200-278) with fac = 1: N points uniform in direction (the positive octant for the three-origin layout) and
+    in radius, kept where they fall into the light-cone boxes; returns positions in box coordinates and the radii"""
+    origin = origins[0]
+    octant = origins.shape[0] > 1
+    costheta = rng.random(N) if octant else rng.random(N) * 2.0 - 1.0                        # (:214-218)
+    phi = rng.random(N) * np.pi / 2.0 if octant else rng.random(N) * 2.0 * np.pi
+    theta = np.arccos(costheta)
+    chis = rng.random(N) * (chi_max - chi_min) + chi_min                                     # (:223)
+    xyz = np.empty((N, 3))
+    xyz[:, 0] = np.sin(theta) * np.cos(phi)
+    xyz[:, 1] = np.sin(theta) * np.sin(phi)
+    xyz[:, 2] = np.cos(theta)
+    xyz *= chis[:, None]
+    # the cube of half-width Lbox / 2 with `offset` removed from the faces the catalogue lacks (:242-254), seen from the observer
+    vert = (2 * ((np.arange(8)[:, None] & (1 << np.arange(3))) > 0) - 1) * (Lbox / 2.0)
+    neg, posi = vert < 0, vert > 0
+    vert[neg] += offset
+    vert[posi[:, 0], 0] -= offset
+    if not octant:
+        vert[posi[:, 1], 1] -= offset
+        vert[posi[:, 2], 2] -= offset
+    centres = [np.zeros(3) - origin]
+    if octant and chi_max >= (Lbox - offset):                                                # (:258-262)
+        centres += [np.array([0.0, 0.0, Lbox]) - origin, np.array([0.0, Lbox, 0.0]) - origin]
+    mask = np.zeros(N, dtype=bool)
+    for c in centres:
+        v = c + vert
+        mask |= np.all((xyz > v.min(axis=0)) & (xyz <= v.max(axis=0)), axis=1)              # is_in_cube (:181-197)
+    return xyz[mask] + origin, chis[mask]
+
+
+def lightcone_menv(pos, masses, r98, Lbox, origins, seed, rad_outer=10, mcut=1e11, offset=10.0, rand_final=10):
+    """Menv of a halo light-cone slab (:474-616): halos within rad_outer of a boundary (box faces less `offset`, the two
+    shell radii) have their annulus mass divided by the annulus' completeness, measured by counting randoms of
+    `default_rng(seed)` in [r98, rad_outer] around them (KD-tree ball queries).  Returns (Menv, index_bounds, rand_norm)."""
+    from . import oracle as O
+    origins = np.asarray(origins, dtype=np.float64).reshape(-1, 3)
+    single = origins.shape[0] == 1
+    alldist = np.sqrt(np.sum((pos - origins[0]) ** 2.0, axis=1))
+    r_min, r_max = alldist.min(), alldist.max()
+
+    def away_from_edges(p, d, pad):
+        lo = -(Lbox / 2.0 - offset - pad)
+        xhi = Lbox / 2.0 - offset - pad
+        yzhi = xhi if single else 3.0 / 2 * Lbox - pad
+        m = (lo <= p[:, 0]) & (xhi >= p[:, 0])
+        for ax in (1, 2):
+            m = m & (lo <= p[:, ax]) & (yzhi >= p[:, ax])
+        return m & (r_min + pad <= d) & (r_max - pad >= d)
+
+    index_bounds = np.arange(pos.shape[0], dtype=int)[~away_from_edges(pos, alldist, rad_outer)]
+    rand_norm = np.zeros(len(index_bounds))
+    if len(index_bounds) > 0:
+        rand_N = int(pos.shape[0])
+        vol = 4.0 / 3.0 * np.pi * (r_max**3 - r_min**3) if single else 4.0 / 3.0 / 8.0 * np.pi * (r_max**3 - r_min**3)
+        rand_n = rand_N / vol
+        rng = np.random.default_rng(seed)
+        count = repeats = 0
+        while count < len(index_bounds) * rand_final:
+            randpos, randdist = lightcone_shell_randoms(pos.shape[0], r_min, r_max, Lbox, offset, origins, rng)
+            randpos = randpos[~away_from_edges(randpos, randdist, 2.0 * rad_outer)]
+            if randpos.shape[0] > 0:
+                tree = cKDTree(randpos)
+                inner = tree.query_ball_point(pos[index_bounds], r=r98[index_bounds], return_length=True)
+                outer = tree.query_ball_point(pos[index_bounds], r=rad_outer, return_length=True)
+                rand_norm += outer - inner
+            repeats += 1
+            count += randpos.shape[0]
+        rand_n *= repeats
+        rand_norm /= (rad_outer**3.0 - r98[index_bounds] ** 3.0) * 4.0 / 3.0 * np.pi * rand_n
+    Menv = O.menv_brute(pos, masses, r98, rad_outer, True, Lbox, mcut=mcut)
+    if len(index_bounds) > 0:
+        zero = rand_norm == 0.0
+        norm = np.where(zero, 1.0, rand_norm)
+        fixed = Menv[index_bounds] / norm
+        fixed[zero] = 0.0
+        Menv[index_bounds] = fixed
+    return Menv, index_bounds, rand_norm
 
 
 # ---- the device's own random columns (`rng=<seed>` of abacusutils_amd.hod.prepare_sim; csrc/prepare.hip prep_halo_randoms /

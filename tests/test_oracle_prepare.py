@@ -15,10 +15,14 @@ CASES = {'mt_ab': (1, True, False, True, False), 'lrg_ranks_ab': (0, False, True
          'mt_ranks_ab_shear': (2, True, True, True, True)}
 
 
+LC_CASES = {'lc_octant': ('octant', 0, True, False), 'lc_centre': ('centre', 2, False, True)}
+
+
 def reference_seed(newseed, i):
-    """(:349-350) the slab's NumPy seed"""
+    """(:349-351) the slab's NumPy seed; returns the seed of the light-cone randoms"""
     seeder = np.random.default_rng(newseed + i)
     np.random.seed(seeder.integers(0, 2**32 - 1))
+    return seeder.integers(0, 2**32 - 1)
 
 
 def shearmark(ndim=16, seed=5):
@@ -48,6 +52,36 @@ def test_prepare_slab_core_reproduces_the_reference(case):
     live = H['npoutA'] >= 0
     assert np.array_equal(H['npstartA'][live], np.concatenate(([0], np.cumsum(H['npoutA'][live])[:-1])))
     assert int(H['npoutA'][live].sum()) == len(P['pos'])
+
+
+@pytest.mark.parametrize('case', list(LC_CASES))
+def test_lightcone_environment_reproduces_the_reference(case):
+    """halo light cones (:474-616): the environment masses after the edge correction by randoms - the argument of the
+    reference's calc_fenv_opt, recorded by oracle/make_golden.py - and then every column of the two tables"""
+    g = load_golden('prepare_sim')
+    geometry, i, MT, want_ranks = LC_CASES[case]
+    slab, header = synth.synth_lightcone_slab(geometry=geometry, **json.loads(str(g['meta.lc_synth_json'])))
+    halos, parts = slab['halos'], slab['parts']
+    lc_seed = reference_seed(600, i)
+    Mpart = header['ParticleMassHMsun']
+    Menv, edge, norm = po.lightcone_menv(halos['x_L2com'], halos['N'] * Mpart, halos['r98_L2com'], header['BoxSizeHMpc'],
+                                         header['LightConeOrigins'], lc_seed)
+    want = g[f'{case}.Menv_corrected']
+    assert 0.1 * len(want) < len(edge) < len(want) and (norm >= 0).all() and 0.2 < np.median(norm) < 1.2
+    np.testing.assert_allclose(Menv, want, rtol=1e-13, atol=0)
+    # the tables from the recorded masses: the mass sums of the restatement differ from the tree's in the last bits (order of
+    # summation), which swaps the ranks of halos with (nearly) equal environments
+    with np.errstate(all='ignore'):
+        H, P, mask = po.prepare_slab_core(halos, parts, Mpart, header['H0'] / 100.0, MT, want_ranks=want_ranks, want_AB=True,
+                                          Menv=want, Lbox=header['BoxSizeHMpc'], halo_lc=True)
+    rename = {'id': 'index_halo', 'x_L2com': 'pos_interp', 'v_L2com': 'vel_interp', 'N': 'N_interp'}   # the loader's keys (:370-373)
+    for k, alias in rename.items():
+        H[alias] = H[k]
+    for kind, got in (('halos', H), ('particles', P)):
+        keys = sorted(k.split('.', 2)[2] for k in g if k.startswith(f'{case}.{kind}.'))
+        assert sorted(got) == keys, (kind, sorted(got), keys)
+        for k in keys:
+            np.testing.assert_array_equal(got[k], g[f'{case}.{kind}.{k}'], err_msg=f'{kind}.{k}')
 
 
 def test_device_stream_restatement_is_sane():

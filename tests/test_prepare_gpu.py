@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = {'mt_ab': (1, True, False, True, False), 'lrg_ranks_ab': (0, False, True, True, False),
          'mt_ranks_ab_shear': (2, True, True, True, True)}
-EXACT = ('N', 'x_L2com', 'v_L2com', 'r25_L2com', 'r90_L2com', 'r98_L2com', 'id', 'sigmav3d_L2com', 'mask_subsample', 'npstartA',
+EXACT = ('N', 'x_L2com', 'v_L2com', 'N_interp', 'pos_interp', 'vel_interp', 'index_halo', 'r25_L2com', 'r90_L2com', 'r98_L2com', 'id', 'sigmav3d_L2com', 'mask_subsample', 'npstartA',
          'npoutA', 'randoms', 'randoms_exp', 'randoms_gaus_vrms', 'fenv_rank', 'deltac_rank', 'shear_rank',
          'pos', 'vel', 'halo_vel', 'halo_mass', 'Np', 'halo_id', 'halo_deltac', 'halo_fenv', 'halo_shear',
          'ranks', 'ranksv', 'ranksr')
@@ -73,6 +73,93 @@ def test_numpy_stream_reproduces_the_reference(case):
     np.testing.assert_array_equal(cid, g[f'{case}.env.id'])
     np.testing.assert_array_equal(cmass, g[f'{case}.env.mass'])
     np.testing.assert_allclose(Menv, g[f'{case}.env.Menv'], rtol=1e-12, atol=1e-12 * g[f'{case}.env.mass'].max())
+
+
+LC_CASES = {'lc_octant': ('octant', 0, True, False), 'lc_centre': ('centre', 2, False, True)}
+
+
+@pytest.mark.parametrize('case', list(LC_CASES))
+def test_lightcone_environment_reproduces_the_reference(case):
+    """halo light cones (:474-616): edge halos, completeness of their annulus from randoms counted on the device, corrected
+    environment masses - against the reference's own intermediate (the argument of its calc_fenv_opt) and the oracle - and
+    the two tables of prepare_slab(halo_lc=True)"""
+    from abacusutils_amd.hod import prepare_sim as ps
+    g = load_golden('prepare_sim')
+    geometry, i, MT, want_ranks = LC_CASES[case]
+    slab, header = synth.synth_lightcone_slab(geometry=geometry, **json.loads(str(g['meta.lc_synth_json'])))
+    halos, parts = slab['halos'], slab['parts']
+    Mpart, Lbox, origins = header['ParticleMassHMsun'], header['BoxSizeHMpc'], header['LightConeOrigins']
+    lc_seed = ps.reference_seed(600, i)
+    masses = halos['N'] * Mpart
+    # the counts are integers and the normalisation is the reference's expression: equal to the KD-tree's, bit for bit
+    Menv_o, edge_o, norm_o = po.lightcone_menv(halos['x_L2com'], masses, halos['r98_L2com'], Lbox, origins, lc_seed)
+    edge, norm = ps.lightcone_edge_norm(halos['x_L2com'], halos['r98_L2com'], Lbox, origins, lc_seed)
+    np.testing.assert_array_equal(edge, edge_o)
+    np.testing.assert_array_equal(norm, norm_o)
+    want = g[f'{case}.Menv_corrected']
+    Menv = ps.lightcone_environment(halos['x_L2com'], masses, halos['r98_L2com'], Lbox, origins, lc_seed)
+    np.testing.assert_allclose(Menv, want, rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(Menv == 0, want == 0)
+    rename = {'id': 'index_halo', 'x_L2com': 'pos_interp', 'v_L2com': 'vel_interp', 'N': 'N_interp'}   # the loader's keys (:370-373)
+
+    def tables(**kw):
+        ps.reference_seed(600, i)
+        H, P, mask = ps.prepare_slab_arrays(halos, parts, Mpart, header['H0'] / 100.0, MT, want_ranks=want_ranks, want_AB=True,
+                                            Lbox=Lbox, halo_lc=True, rng='numpy', **kw)
+        for k, alias in rename.items():
+            H[alias] = H[k]
+        return H, P, mask
+
+    gold = {kind: {k.split('.', 2)[2]: g[k] for k in g if k.startswith(f'{case}.{kind}.')} for kind in ('halos', 'particles')}
+
+    def check(H, P, mask, exact_env):
+        """every column as the reference wrote it; the environment rank (:618, calc_fenv_opt :283-293) where it is defined:
+        halos that share their environment mass with another halo of their mass bin - the many with none at all - are
+        ranked among themselves in whatever order an unstable argsort leaves them (NumPy's under the shim, Numba's in
+        production; the device orders ties by index), so a tie group is compared as a set"""
+        fr, hf = H.pop('fenv_rank'), P.pop('halo_fenv')
+        wfr = gold['halos']['fenv_rank']
+        compare_tables(H, {k: v for k, v in gold['halos'].items() if k != 'fenv_rank'}, f'{case}.halos')
+        compare_tables(P, {k: v for k, v in gold['particles'].items() if k != 'halo_fenv'}, f'{case}.particles')
+        mbins = np.logspace(np.log10(1e11), 15.5, 101)
+        used = want if exact_env else Menv
+        full = ps.rank_in_mass_bins(used, masses, mbins)                       # the device's ranks of ALL halos of the slab
+        full_o = po.rank_in_mass_bins(want, masses, mbins, denom='n-1')        # the oracle's (pinned to the reference's)
+        if exact_env:
+            np.testing.assert_array_equal(fr, full[mask])
+        else:       # the cell lists are filled through atomics: the order of a sum, and with it its last bit, varies from run to run
+            assert (fr == full[mask]).mean() > 0.98
+        np.testing.assert_array_equal(wfr, full_o[mask])
+        bins = np.searchsorted(mbins, masses)
+        _, group, size = np.unique(np.stack([bins.astype(np.float64), want]), axis=1, return_inverse=True, return_counts=True)
+        group = group.ravel()
+        single = size[group] == 1
+        assert single.sum() > 0.2 * len(full)
+        if exact_env:
+            np.testing.assert_array_equal(full[single], full_o[single])
+            np.testing.assert_array_equal(full[np.lexsort((full, group))], full_o[np.lexsort((full_o, group))])
+        else:
+            assert (full[single] == full_o[single]).mean() > 0.98
+            np.testing.assert_allclose(full[single], full_o[single], rtol=0, atol=0.1)
+            np.testing.assert_array_equal(full[np.lexsort((full, bins))], full_o[np.lexsort((full_o, bins))])
+        order = np.argsort(H['id'])
+        np.testing.assert_array_equal(hf, fr[order[np.searchsorted(H['id'][order], P['halo_id'])]])
+
+    # from the recorded masses
+    check(*tables(Menv=want), exact_env=True)
+    # the whole path (masses worked out here): sums in another order than the tree's differ in the last bits, which may
+    # swap the ranks of halos with nearly equal masses around them
+    check(*tables(origins=origins, lc_seed=lc_seed), exact_env=False)
+
+
+def test_lightcone_needs_its_inputs():
+    from abacusutils_amd.hod import prepare_sim as ps
+    slab, header = synth.synth_lightcone_slab(n_halo=300)
+    with pytest.raises(ValueError, match='origins'):
+        ps.prepare_slab_arrays(slab['halos'], slab['parts'], header['ParticleMassHMsun'], 0.67, True, want_AB=True, halo_lc=True,
+                               Lbox=header['BoxSizeHMpc'])
+    with pytest.raises(ValueError, match='origins'):
+        ps.lightcone_edge_norm(slab['halos']['x_L2com'], slab['halos']['r98_L2com'], 300.0, np.zeros((2, 3)), 1)
 
 
 @pytest.mark.parametrize('MT,want_ranks', [(True, True), (False, True), (True, False)])
