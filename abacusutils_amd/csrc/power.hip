@@ -39,6 +39,8 @@ using namespace abacus;
 namespace abacus {
 int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
                     double offset, int wrap, double norm, int cic, int list_mode = 0, double sub = 1.0);
+void tsc_wrapped_reset();
+int tsc_wrapped_seen();
 int tsc_deposit_f64pos(double *pos, int64_t n, const double *w, float *grid, int nmesh, int64_t zstride, double box,
                        double offset, int wrap, double norm, int cic, double sub = 1.0);
 int tsc_release_work();
@@ -1077,9 +1079,12 @@ static int power_from_host(void *pos, int64_t n, const void *w, void *pos2, int6
     float *pd, *wd, *pd2 = nullptr, *wd2 = nullptr;
     ABACUS_TRY(stage_particles((float *)pos, n, (const float *)w, g_ctx.pos, g_ctx.w, &pd, &wd, es));
     if (pos2) ABACUS_TRY(stage_particles((float *)pos2, n2, (const float *)w2, g_ctx.pos2, g_ctx.w2, &pd2, &wd2, es));
+    tsc_wrapped_reset();
     ABACUS_TRY(power_dev(pd, n, wd, pd2, n2, wd2, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu,
                          poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, pf64));
-    if (paste == 0) {  // TSC wraps the caller's positions in place (tsc.py:171-173); CIC does not wrap (cic.py)
+    // TSC wraps the caller's positions in place (tsc.py:171-173); CIC does not wrap (cic.py).  Nothing to copy back when
+    // every position already lay inside the box
+    if (paste == 0 && tsc_wrapped_seen()) {
         HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 3 * es, hipMemcpyDeviceToHost, stream()));
         if (pos2) HIP_TRY(hipMemcpyAsync(pos2, pd2, (size_t)n2 * 3 * es, hipMemcpyDeviceToHost, stream()));
         HIP_TRY(hipStreamSynchronize(stream()));
@@ -1119,10 +1124,11 @@ int abacus_field(float *pos, int64_t n, const float *w, double Lbox, int nmesh, 
     const int64_t zstride = pitch_r(nmesh);
     const double M = (double)nmesh * nmesh * nmesh;
     const double norm = (double)(float)(M / (double)n);   // dtype(field.size / tot_weight), tot_weight = len(pos) (:856,894)
+    tsc_wrapped_reset();
     ABACUS_TRY(tsc_deposit_f32(pd, n, wd, mesh, nmesh, zstride, Lbox, offset, paste == 0, norm, paste));
     HIP_TRY(hipMemcpy2DAsync(field, (size_t)nmesh * 4, mesh, (size_t)zstride * 4, (size_t)nmesh * 4, (size_t)nmesh * nmesh,
                              hipMemcpyDeviceToHost, stream()));
-    if (paste == 0) HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 12, hipMemcpyDeviceToHost, stream()));
+    if (paste == 0 && tsc_wrapped_seen()) HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 12, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;
 }
@@ -1136,6 +1142,7 @@ int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nme
     ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
     float *pd, *wd;
     ABACUS_TRY(stage_particles(pos, n, w, g_ctx.pos, g_ctx.w, &pd, &wd));
+    tsc_wrapped_reset();
     ABACUS_TRY(field_fft_dev(pd, n, wd, Lbox, nmesh, paste, interlaced, 0));
     SpecArgs s;
     fill_spec(s, nmesh, 1, interlaced, W_dev, false);
@@ -1148,7 +1155,7 @@ int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nme
     const size_t kz = (size_t)nmesh / 2 + 1;   // rows are pitched on the device, contiguous for the caller
     HIP_TRY(hipMemcpy2DAsync(out_c64, kz * 8, g_ctx.mesh[0].p, (size_t)s.pitch * 8, kz * 8, (size_t)nmesh * nmesh,
                              hipMemcpyDeviceToHost, stream()));
-    if (paste == 0) HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 12, hipMemcpyDeviceToHost, stream()));
+    if (paste == 0 && tsc_wrapped_seen()) HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 12, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;
 }

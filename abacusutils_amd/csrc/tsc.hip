@@ -913,6 +913,10 @@ TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int 
     return g;
 }
 
+// did any deposit since the last reset move a position into the box?  (the host entry points copy the positions back to the
+// caller - the reference wraps its argument in place, tsc.py:171-173 - only then: 1.2 GB over PCIe at 1e8 particles)
+static int g_wrapped_seen = 0;
+
 template <typename PT, typename GT, bool CIC>
 int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy, int gz, int64_t zstride, double box,
                 double offset, int wrap, int zero_grid, double norm, int *wrapped_out, int gxg = -1, int xoff = 0,
@@ -982,6 +986,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
         HIP_TRY(hipStreamSynchronize(stream()));
         if (wrapped_out) *wrapped_out = h_flag;
+        g_wrapped_seen |= h_flag;
         const int64_t total = h_start[ncoarse];
         nentries_total = total;
         int64_t maxbucket = 0;
@@ -1026,6 +1031,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
         HIP_TRY(hipStreamSynchronize(stream()));
         if (wrapped_out) *wrapped_out = h_flag;
+        g_wrapped_seen |= h_flag;
         nentries_total = total;
         ABACUS_TRY(g_work.entries.reserve((size_t)std::max<int64_t>(total, 1) * sizeof(Entry<PT>)));
         entries = g_work.entries.as<Entry<PT>>();
@@ -1113,6 +1119,8 @@ int deposit_host(void *pos_, int64_t n, const void *weights_, void *grid_, int g
 }  // namespace
 
 namespace abacus {
+void tsc_wrapped_reset() { g_wrapped_seen = 0; }
+int tsc_wrapped_seen() { return g_wrapped_seen; }
 // used by power.hip: float32 deposit into a (possibly padded) device mesh with fused normalisation
 // list_mode: 0 = lists for this deposit only; 1 = build lists that a following deposit of the same particles shifted by
 // up to half a cell can reuse (call with offset 0); 2 = reuse them (rebuilds when anything changed)

@@ -1,6 +1,8 @@
 """HIP power-spectrum path (deposit -> hipFFT -> fused binning) vs golden vectors of the reference's calc_power and
 vs the float64-accumulating CPU oracle.  Tolerance: 1e-5 relative on P (north_star), exact N_mode.
 Needs an MI355X: run with `-m gpu`."""
+import warnings
+
 import numpy as np
 import pytest
 from conftest import load_golden
@@ -198,6 +200,40 @@ def test_float64_positions_use_float64_cloud_weights(cross):
     assert a_in.dtype == np.float64 and a_in.min() >= 0.0 and a_in.max() < box        # wrapped like tsc_parallel does
     ref = oracle.calc_power(pos.copy(), box, nthread=4, accum64=True, **{k: (v.copy() if hasattr(v, 'copy') else v) for k, v in {**kw, **extra}.items()})
     _check_oracle(tab, ref)
+
+
+@pytest.mark.parametrize('n', [50_000, 2_500_000])       # the per-tile atomic list build and the multisplit
+def test_positions_are_wrapped_in_place_only_when_needed(n):
+    """the reference wraps the caller's positions in place (tsc.py:171-173, through calc_power / get_field / get_field_fft);
+    positions already inside the box come back untouched - the host entry points copy them back only when one moved"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power, get_field, get_field_fft
+    from oracle import oracle
+    rng = np.random.default_rng(23)
+    box = 1000.0
+    inside = (rng.random((n, 3), dtype=np.float32) * np.float32(box * 0.999999)).astype(np.float32)
+    outside = inside.copy()
+    outside[::7] += np.float32(box)
+    outside[3::11, 1] -= np.float32(box)
+    want = outside.copy()
+    oracle.wrap_inplace(want, box)
+    kw = dict(kbins=16, mubins=2, paste='TSC', nmesh=128, compensated=False, interlaced=False)
+    calls = {'calc_power': lambda p: calc_power(p, box, **kw), 'get_field': lambda p: get_field(p, box, 128, 'TSC'),
+             'get_field_fft': lambda p: get_field_fft(p, box, 128, 'TSC', None, None, False, False)}
+    results = {}
+    for name, f in calls.items():
+        a, b = inside.copy(), outside.copy()
+        ra, rb = f(a), f(b)
+        np.testing.assert_array_equal(a, inside, err_msg=name)
+        np.testing.assert_array_equal(b, want, err_msg=name)
+        results[name] = (ra, rb)
+    # the wrapped copy describes the same particles up to the rounding of x + L - L
+    np.testing.assert_allclose(results['calc_power'][1]['power'], results['calc_power'][0]['power'], rtol=2e-3)
+    # CIC does not wrap (cic.py): the array stays as it is
+    c = inside.copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        get_field(c, box, 64, 'CIC')
+    np.testing.assert_array_equal(c, inside)
 
 
 @pytest.mark.parametrize('nmesh', [1024])
