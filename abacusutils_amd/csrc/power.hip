@@ -810,8 +810,11 @@ int finalize_bins(const void *raw, double Lbox, int Nk, int Nmu, const int64_t *
 }
 
 // host side of a binning launch: pole coefficients, squared float32 edges (:217-218) and zeroed accumulators on the device
+// lo_excl / hi_incl (a k range binned in several passes, run_bin): the first edge of a pass that does not start the whole
+// range is raised by one float32 step - `v < edge'` is `v <= edge`, its modes ON the edge belong to the pass before, whose
+// last bin keeps them because ITS last edge is raised too (`v >= edge'` is `v > edge`)
 int prepare_bins(double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np_all,
-                 double dk_, BinArgs &b, size_t &acc_bytes) {
+                 double dk_, BinArgs &b, size_t &acc_bytes, int lo_excl = 0, int hi_incl = 0) {
     if (Nk < 1 || Nmu < 1) return fail("power: need at least one k bin and one mu bin");
     if (Np_all > MAX_POLES) return fail("power: more than %d multipoles requested", MAX_POLES);
     const double dk = dk_ > 0 ? dk_ : 2.0 * M_PI / Lbox;
@@ -829,6 +832,8 @@ int prepare_bins(double Lbox, const double *kedges, int Nk, const double *muedge
     std::vector<float> e2((size_t)Nk + 1 + Nmu + 1);
     for (int q = 0; q <= Nk; q++) e2[q] = (float)((kedges[q] / dk) * (kedges[q] / dk));
     for (int q = 0; q <= Nmu; q++) e2[Nk + 1 + q] = (float)(muedges[q] * muedges[q]);
+    if (lo_excl) e2[0] = nextafterf(e2[0], INFINITY);
+    if (hi_incl) e2[Nk] = nextafterf(e2[Nk], INFINITY);
     ABACUS_TRY(g_ctx.edges.reserve(e2.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(g_ctx.edges.p, e2.data(), e2.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));   // e2 is a local
@@ -862,24 +867,38 @@ int collect_bins(size_t acc_bytes, double Lbox, int Nk, int Nmu, const int64_t *
                          scale);
 }
 
-int run_bin(const SpecArgs &s_in, double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu,
-            const int64_t *poles, int Np_all, float *power, int64_t *N_mode, float *binned_poles,
-            int64_t *N_mode_poles, float *k_avg, void *raw_out = nullptr, double dk_ = 0, double scale = 0) {
+// LDS budget of one spectrum_bin launch: histogram + edges + tile
+struct BinBudget {
+    size_t hist_bytes, tile_bytes;
+    int64_t tile_modes;
+    static constexpr size_t lds_max = 160 * 1024;
+    bool fits() const { return hist_bytes + tile_bytes <= lds_max; }
+};
+BinBudget bin_budget(const SpecArgs &s, int Nk, int Nmu, int Np_nz) {
+    BinBudget g;
+    const size_t nb = (size_t)Nk * Nmu, npk = (size_t)Np_nz * Nk;
+    g.hist_bytes = nb * (8 + 8 + 4) + npk * 8 + (size_t)(Nk + 1 + Nmu + 1) * 4 + 64;
+    const bool inter = s.mode == 1 && s.interlaced, cross = s.cross != 0;
+    const int ept = (inter && cross) ? 4 : ((inter || cross) ? 8 : 16);
+    g.tile_modes = (int64_t)BIN_THREADS * ept;
+    g.tile_bytes = (size_t)(g.tile_modes + BIN_THREADS + 16) * 4;
+    return g;
+}
+
+int run_bin_once(const SpecArgs &s_in, double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu,
+                 const int64_t *poles, int Np_all, float *power, int64_t *N_mode, float *binned_poles,
+                 int64_t *N_mode_poles, float *k_avg, void *raw_out, double dk_, double scale, int lo_excl, int hi_incl) {
     SpecArgs s = s_in;
     s.lds_tables = 0;
     const double dk = dk_ > 0 ? dk_ : 2.0 * M_PI / Lbox;
     BinArgs b;
     size_t acc_bytes = 0;
-    ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np_all, dk_, b, acc_bytes));
-    const size_t nb = (size_t)Nk * Nmu, npk = (size_t)b.Np * Nk;
-    // LDS budget: histogram + edges + tile
-    const size_t hist_bytes = nb * (8 + 8 + 4) + npk * 8 + (size_t)(Nk + 1 + Nmu + 1) * 4 + 64;
-    const size_t lds_max = 160 * 1024;
+    ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np_all, dk_, b, acc_bytes, lo_excl, hi_incl));
+    const BinBudget bud = bin_budget(s, Nk, Nmu, b.Np);
+    const size_t hist_bytes = bud.hist_bytes, tile_bytes = bud.tile_bytes, lds_max = BinBudget::lds_max;
+    const int64_t tile_modes = bud.tile_modes;
     const bool inter = s.mode == 1 && s.interlaced, cross = s.cross != 0;
-    const int ept = (inter && cross) ? 4 : ((inter || cross) ? 8 : 16);
-    const int64_t tile_modes = (int64_t)BIN_THREADS * ept;
-    const size_t tile_bytes = (size_t)(tile_modes + BIN_THREADS + 16) * 4;
-    if (hist_bytes + tile_bytes > lds_max)
+    if (!bud.fits())
         return fail("power: %d x %d bins with %d multipoles do not fit the 160 KiB LDS histogram", Nk, Nmu, b.Np);
     size_t table_bytes = 0;
     if (s.mode == 1) table_bytes = (inter ? (size_t)2 * s.n * 8 : 0) + (s.compensated ? (size_t)s.n * 4 : 0);
@@ -914,6 +933,45 @@ int run_bin(const SpecArgs &s_in, double Lbox, const double *kedges, int Nk, con
 #undef LAUNCH_BIN
     return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np_all, power, N_mode, binned_poles, N_mode_poles, k_avg, raw_out, dk,
                         scale);
+}
+
+// The workgroup histogram of spectrum_bin lives in LDS (a few thousand (k, mu) bins).  A finer binning is done in several
+// passes over the spectrum, each with a run of consecutive k bins that fits - the reference takes any number of bins
+// (power_spectrum.py:150-300).  Modes on an edge shared by two passes are counted once, where one pass would count them
+// (prepare_bins).  Raw sums (`raw_out`, the multi-GPU reduction) are assembled in the one-pass layout.
+int run_bin(const SpecArgs &s, double Lbox, const double *kedges, int Nk, const double *muedges, int Nmu,
+            const int64_t *poles, int Np_all, float *power, int64_t *N_mode, float *binned_poles,
+            int64_t *N_mode_poles, float *k_avg, void *raw_out = nullptr, double dk_ = 0, double scale = 0) {
+    int Np_nz = 0;
+    for (int q = 0; q < Np_all && q < MAX_POLES; q++) Np_nz += poles[q] != 0;
+    if (Nk < 1 || Nmu < 1 || bin_budget(s, Nk, Nmu, Np_nz).fits())
+        return run_bin_once(s, Lbox, kedges, Nk, muedges, Nmu, poles, Np_all, power, N_mode, binned_poles, N_mode_poles, k_avg,
+                            raw_out, dk_, scale, 0, 0);
+    int kc = Nk;
+    while (kc > 1 && !bin_budget(s, kc, Nmu, Np_nz).fits()) kc = (kc + 1) / 2;
+    if (!bin_budget(s, kc, Nmu, Np_nz).fits())
+        return fail("power: %d mu bins with %d multipoles do not fit the 160 KiB LDS histogram even for one k bin", Nmu, Np_nz);
+    const size_t nb = (size_t)Nk * Nmu;
+    unsigned char *raw = static_cast<unsigned char *>(raw_out);
+    for (int a = 0; a < Nk; a += kc) {
+        const int n = std::min(kc, Nk - a);
+        const size_t nbc = (size_t)n * Nmu;
+        if (raw) {
+            std::vector<unsigned char> part(nbc * 24 + (size_t)Np_nz * n * 8);
+            ABACUS_TRY(run_bin_once(s, Lbox, kedges + a, n, muedges, Nmu, poles, Np_all, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    part.data(), dk_, scale, a > 0, a + n < Nk));
+            for (int f = 0; f < 3; f++)   // cnt | sum | ksum: (Nk, Nmu) each
+                memcpy(raw + ((size_t)f * nb + (size_t)a * Nmu) * 8, part.data() + (size_t)f * nbc * 8, nbc * 8);
+            for (int q = 0; q < Np_nz; q++)   // pole sums: (Np', Nk)
+                memcpy(raw + (3 * nb + (size_t)q * Nk + a) * 8, part.data() + (3 * nbc + (size_t)q * n) * 8, (size_t)n * 8);
+            continue;
+        }
+        std::vector<float> bp((size_t)std::max(Np_all, 1) * n);
+        ABACUS_TRY(run_bin_once(s, Lbox, kedges + a, n, muedges, Nmu, poles, Np_all, power + (size_t)a * Nmu, N_mode + (size_t)a * Nmu,
+                                bp.data(), N_mode_poles + a, k_avg + (size_t)a * Nmu, nullptr, dk_, scale, a > 0, a + n < Nk));
+        for (int q = 0; q < Np_all; q++) memcpy(binned_poles + (size_t)q * Nk + a, bp.data() + (size_t)q * n, (size_t)n * sizeof(float));
+    }
+    return 0;
 }
 
 int upload_W(const float *W_host, int nmesh, const float **W_dev) {

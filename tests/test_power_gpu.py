@@ -552,6 +552,35 @@ def _random_edges(rng, nmesh, box):
     return ke, me, poles
 
 
+@pytest.mark.parametrize('interlaced,cross', [(False, False), (True, False), (True, True)])
+def test_more_bins_than_one_histogram_holds(interlaced, cross):
+    """the reference takes any number of (k, mu) bins (power_spectrum.py:150-300); a binning finer than the LDS histogram of
+    one launch is done in several passes over runs of k bins.  k edges ON mode radii (|k|^2 integers in units of the
+    fundamental, every fourth edge) make the edges shared by two passes matter: against the oracle, N_mode exact"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    nmesh, box = 64, 500.0
+    kf = 2 * np.pi / box
+    Nk, Nmu = 900, 7
+    r2 = np.sort(np.random.default_rng(3).choice(np.arange(1, 3 * (nmesh // 2) ** 2), Nk + 1, replace=False)).astype(np.float64)
+    ke = np.sqrt(r2) * kf
+    ke[1::4] *= 1.0 + 1e-4                                                # the others between radii
+    ke = np.sort(ke)
+    me = np.linspace(0, 1, Nmu + 1)
+    pos = synth.synth_positions(60_000, box, seed=12, clustered=True)
+    extra = dict(pos2=synth.synth_positions(40_000, box, seed=13, clustered=True)) if cross else {}
+    kw = dict(kbins=ke, mubins=me, poles=[0, 2, 4], paste='TSC', nmesh=nmesh, compensated=True, interlaced=interlaced)
+    tab = calc_power(pos.copy(), box, **kw, **extra)
+    ref = oracle.calc_power(pos.copy(), box, nthread=4, accum64=True, **kw, **{k: v.copy() for k, v in extra.items()})
+    assert int(np.asarray(tab['N_mode']).sum()) > 0.5 * nmesh ** 3 / 2
+    # bins of a handful of modes: Re(d1 d2*) of a cross spectrum cancels, its float32 products show at 1e-5 of the bin's own value
+    _check_oracle(tab, ref, rtol=1e-4 if cross else RTOL)
+    # and the same numbers as the coarse binning they refine: every 100 fine bins merged
+    coarse = calc_power(pos.copy(), box, **dict(kw, kbins=ke[::100]), **extra)
+    fine_n = np.asarray(tab['N_mode']).reshape(Nk // 100, 100, Nmu).sum(axis=1)
+    np.testing.assert_array_equal(fine_n, coarse['N_mode'])
+
+
 @pytest.mark.parametrize('seed', range(12))
 def test_fused_last_pass_random_edges(options, seed):
     """the cached-geometry kernel (integer thresholds, cell table, per-kz mu thresholds, validated over every mode of the mesh

@@ -102,13 +102,15 @@ def test_slab_hip_fused_last_pass_on_y_slabs(tmp_path, world, compensated):
 
 
 @pytest.mark.gpu
-def test_slab_hip_matches_single_gpu_path(tmp_path):
-    """world=1 slab path against the product's own calc_power at a larger mesh"""
+@pytest.mark.parametrize('kbins,mubins', [(32, 5), (900, 7)])
+def test_slab_hip_matches_single_gpu_path(tmp_path, kbins, mubins):
+    """world=1 slab path against the product's own calc_power at a larger mesh; 900 x 7 bins: more than the LDS histogram of
+    one binning launch holds - the raw sums the ranks reduce are assembled from several passes over runs of k bins"""
     from abacusutils_amd.analysis import power_spectrum as ps
     from abacusutils_amd.analysis import slab_power as sp
     n, nmesh = 400000, 128
     pos = synth_positions(n, L, seed=21, clustered=True)
-    kw = dict(kbins=32, mubins=5, paste='TSC', nmesh=nmesh, compensated=True, interlaced=True, poles=[0, 2, 4])
+    kw = dict(kbins=kbins, mubins=mubins, paste='TSC', nmesh=nmesh, compensated=True, interlaced=True, poles=[0, 2, 4])
     a = ps.calc_power(pos.copy(), L, **kw)
     b = sp.calc_power_slab(pos.copy(), L, **kw)
     np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
