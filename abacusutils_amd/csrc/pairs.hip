@@ -876,12 +876,23 @@ static int paircount_impl(int mode, const void *x1, const void *y1, const void *
     ABACUS_ENTER();
     if (mode < 0 || mode > 2) return fail("abacus_paircount: unknown mode %d", mode);
     if (!x1 || !y1 || !z1 || !bins || !npairs || nbins < 1) return fail("abacus_paircount: null/empty argument");
-    if (nbins > 63) return fail("abacus_paircount: more than 63 separation bins");
     if (!(boxsize > 0)) return fail("abacus_paircount: boxsize must be positive");
     const int autocorr = x2 == nullptr;
     const int nsub = mode == 0 ? 1 : (mode == 1 ? npibins : nmubins);
     if (nsub < 1) return fail("abacus_paircount: need at least one pi / mu bin");
-    if ((int64_t)nbins * nsub > MAX_HIST) return fail("abacus_paircount: %d x %d bins exceed the LDS histogram", nbins, nsub);
+    if (nsub > MAX_HIST) return fail("abacus_paircount: %d pi / mu bins exceed the LDS histogram", nsub);
+    // One launch bins into at most 63 separation bins (the kernels' edge tables) and MAX_HIST counters in LDS.  More bins -
+    // Corrfunc takes any number - are counted in runs of consecutive separation bins, each a call of its own with its own,
+    // smaller reach; a pair ON an edge shared by two runs belongs to the upper bin in both ([lo, hi) bins)
+    const int run = std::min(63, MAX_HIST / nsub);
+    if (nbins > run) {
+        for (int a = 0; a < nbins; a += run) {
+            const int n = std::min(run, nbins - a);
+            ABACUS_TRY(paircount_impl(mode, x1, y1, z1, n1, x2, y2, z2, n2, where, boxsize, bins + a, n, pimax, npibins, mu_max,
+                                      nmubins, npairs + (size_t)a * nsub));
+        }
+        return 0;
+    }
     if (n1 >= ((int64_t)1 << 31) || n2 >= ((int64_t)1 << 31)) return fail("abacus_paircount: too many points");
     const float rmax = bins[nbins];
     for (int b = 0; b < nbins; b++)

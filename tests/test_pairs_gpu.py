@@ -217,6 +217,33 @@ def test_wrappers_vs_reference_golden():
     check_pair_wrappers(T)
 
 
+@pytest.mark.parametrize('mode,auto', [('r', True), ('rppi', False), ('smu', True)])
+def test_more_bins_than_one_launch_holds(mode, auto):
+    """Corrfunc takes any number of bins; one launch bins into at most 63 separation bins and 8192 LDS counters, more are
+    counted in runs of consecutive separation bins.  150 linear bins (x 60 pi bins = 9000, x 120 mu bins = 18000) against
+    the brute-force counter; integer-spaced points put pairs ON the edges shared by two runs"""
+    from abacusutils_amd.analysis import tpcf_corrfunc as T
+    from oracle import oracle
+    box = 240.0
+    rng = np.random.default_rng(8)
+    p1 = np.round(rng.random((2500, 3)) * box * 2) / 2                      # a half-integer lattice: separations hit the edges
+    p1 = (p1 % box).astype(np.float32)
+    x1, y1, z1 = (np.ascontiguousarray(p1[:, i]) for i in range(3))
+    x2, y2, z2 = (None, None, None) if auto else _points(2000, box, 4)
+    bins = (np.arange(151) * 0.25 + 0.5).astype(np.float32)                 # exact in float32: 0.5, 0.75, ..., 38
+    kw = dict(pimax=60.0, npibins=60) if mode == 'rppi' else (dict(mu_max=1.0, nmubins=120) if mode == 'smu' else {})
+    want = oracle.paircount_brute(mode, x1, y1, z1, box, bins, x2, y2, z2, nthread=oracle.max_threads(), **kw)
+    if mode == 'r':
+        got = T.DD(int(auto), 4, bins, x1, y1, z1, X2=x2, Y2=y2, Z2=z2, periodic=True, boxsize=box)['npairs']
+    elif mode == 'rppi':
+        got = T.DDrppi(int(auto), 4, binfile=bins, pimax=60.0, X1=x1, Y1=y1, Z1=z1, X2=x2, Y2=y2, Z2=z2, periodic=True,
+                       boxsize=box)['npairs']
+    else:
+        got = T.DDsmu(int(auto), 4, bins, 1.0, 120, x1, y1, z1, X2=x2, Y2=y2, Z2=z2, periodic=True, boxsize=box)['npairs']
+    assert want.sum() > 1000
+    np.testing.assert_array_equal(got, want)
+
+
 def test_bin_edge_conventions():
     """pairs that sit exactly ON an edge document the convention (Corrfunc's published kernels, restated from memory -
     the library is absent): r-bin b holds edges[b] <= r < edges[b+1]; DDrppi keeps |dz| < pimax with
