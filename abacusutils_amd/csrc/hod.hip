@@ -408,6 +408,10 @@ struct HodPtrs {
     int *sb_counts;                     // [nsb_c + nsb_s][4]
 };
 
+// Superblock S of a kind owns the tiles [S ntile / nsb, (S + 1) ntile / nsb): nsb >= ntile / SBT balanced runs of at most SBT
+// tiles (the host picks nsb, set_superblocks: a whole number of workgroups per CU for the dense mixes)
+__device__ __forceinline__ int sb_first_tile(int S, int ntile, int nsb) { return (int)((int64_t)S * ntile / nsb); }
+
 // One launch filters central tiles (global tile id < ntile_c) and satellite tiles alike; `first_tile` lets the host
 // split it in two when the satellite filter needs the exact central decisions (ELG conformity reads keep_cent[pinds]).
 // `need_env`: some wanted tracer has a non-zero Acent/Bcent (Ccent for the shear); otherwise deltac / fenv / shear
@@ -922,8 +926,8 @@ struct ExactCand {
 };
 
 template <int XB, bool PIPE, int SBT>
-__global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre,
-                                                abacus_cls::ClsConst cc, int use_cls, int clear_prev) {
+__device__ __forceinline__ void hod_exact_body(const HodPtrs &a, int first_sb, const abacus_hod_params &p, const SatPre &pre,
+                                               const abacus_cls::ClsConst &cc, int use_cls, int clear_prev) {
     constexpr int SB_TILES = SBT, SB_OBJ = SBT * TILE, SB_WORDS = SB_OBJ / 32;
     constexpr int WORDS_PER_THREAD = SB_WORDS / XB;
     static_assert(SB_WORDS % XB == 0 && XB <= 512 && SB_OBJ <= 65536, "bitmap words must divide over the workgroup");
@@ -939,13 +943,14 @@ __global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_
     const int g = (int)blockIdx.x + first_sb;
     const bool sat = g >= a.nsb_c;
     const int S = sat ? g - a.nsb_c : g;
-    const int ntile = sat ? a.ntile_s : a.ntile_c;
-    const int tile_first = S * SB_TILES;
+    const int ntile = sat ? a.ntile_s : a.ntile_c, nsb = sat ? a.nsb_s : a.nsb_c;
+    const int tile_first = sb_first_tile(S, ntile, nsb), ntl = sb_first_tile(S + 1, ntile, nsb) - tile_first;   // ntl <= SB_TILES
+    const int64_t obj_first = (int64_t)tile_first * TILE;
     const int *q_count = a.q_count + (sat ? a.ntile_c : 0);
     if (tid < SB_TILES) {
         const int t = tile_first + tid;
-        L.pre[tid + 1] = t < ntile ? q_count[t] : 0;
-        if ((clear_prev & 2) && t < ntile) a.q_count[(sat ? a.ntile_c : 0) + t] = 0;   // the index path counts into zeroed counters
+        L.pre[tid + 1] = tid < ntl ? q_count[t] : 0;
+        if ((clear_prev & 2) && tid < ntl) a.q_count[(sat ? a.ntile_c : 0) + t] = 0;   // the index path counts into zeroed counters
     }
     if (tid == 0) L.pre[0] = 0;
 #pragma unroll
@@ -962,8 +967,8 @@ __global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_
         // the end of this workgroup): un-keep those, then decide.  The host falls back to the zeroing filter whenever the
         // lists do not describe the masks (first populate, another superblock size, the NFW path in between).
         const int prev = a.sb_counts[(int64_t)g * 4] + a.sb_counts[(int64_t)g * 4 + 1] + a.sb_counts[(int64_t)g * 4 + 2];
-        const unsigned short *pk = (sat ? a.kept_s : a.kept_c) + (int64_t)S * SB_OBJ;
-        int8_t *keep = (sat ? a.keep_s : a.keep_c) + (int64_t)S * SB_OBJ;
+        const unsigned short *pk = (sat ? a.kept_s : a.kept_c) + obj_first;
+        int8_t *keep = (sat ? a.keep_s : a.keep_c) + obj_first;
         for (int e = tid; e < prev; e += XB) keep[pk[e]] = 0;
         __syncthreads();   // an object kept again is written again below, by whichever thread classifies it
     }
@@ -1150,7 +1155,7 @@ __global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_
     }
     const unsigned long long excl = before + incl - mine;
     const int T0 = (int)(all & 0x1fffff), T1 = (int)((all >> 21) & 0x1fffff), T2 = (int)((all >> 42) & 0x1fffff);
-    unsigned short *kept = (sat ? a.kept_s : a.kept_c) + (int64_t)S * SB_OBJ;
+    unsigned short *kept = (sat ? a.kept_s : a.kept_c) + obj_first;
     const int base[3] = {0, T0, T0 + T1};
 #pragma unroll
     for (int t = 0; t < 3; t++) {
@@ -1166,6 +1171,24 @@ __global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_
         }
     }
     if (tid < 4) a.sb_counts[(int64_t)g * 4 + tid] = tid == 0 ? T0 : (tid == 1 ? T1 : (tid == 2 ? T2 : 0));
+}
+
+// The pipelined form (dense mixes) runs at its ~150 registers, three workgroups per CU (set_superblocks counts on that); the
+// plain form (sparse mixes: LRG alone) is held to 128 registers - two or three values spilled - for a fourth wave per SIMD
+// under its dependent gathers: 38.4 -> 35.0 us at 4e7 + 4e7, no change at 1e7 + 1e7.  (The pipelined form held to 128 spills
+// twenty: 94 us instead of 81.)
+template <int XB, bool PIPE, int SBT>
+__global__ __launch_bounds__(XB) void hod_exact(HodPtrs a, int first_sb, abacus_hod_params p, SatPre pre,
+                                                abacus_cls::ClsConst cc, int use_cls, int clear_prev) {
+    static_assert(PIPE, "the plain form is hod_exact_plain");
+    hod_exact_body<XB, true, SBT>(a, first_sb, p, pre, cc, use_cls, clear_prev);
+}
+template <int XB, int SBT>
+__global__ __launch_bounds__(XB) __attribute__((amdgpu_waves_per_eu(4))) void hod_exact_plain(HodPtrs a, int first_sb,
+                                                                                               abacus_hod_params p, SatPre pre,
+                                                                                               abacus_cls::ClsConst cc, int use_cls,
+                                                                                               int clear_prev) {
+    hod_exact_body<XB, false, SBT>(a, first_sb, p, pre, cc, use_cls, clear_prev);
 }
 
 struct OutCols {
@@ -1222,16 +1245,17 @@ struct EmitPtrs {
 };
 
 template <int EBLOCK, int SBT>
-__global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const unsigned short *__restrict__ kept_c,
+__global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, int ntile_c, int ntile_s,
+                                                   const unsigned short *__restrict__ kept_c,
                                                    const unsigned short *__restrict__ kept_s,
                                                    const int *__restrict__ sb_counts, int64_t *__restrict__ totals,
                                                    EmitPtrs in, abacus_hod_params p, OutCols o, int dbg) {
-    constexpr int SB_OBJ = SBT * TILE;
     __shared__ int64_t red[EBLOCK / 64][6];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int g = blockIdx.x;
     const bool sat = g >= nsb_c;
     const int S = sat ? g - nsb_c : g;
+    const int64_t obj_first = (int64_t)sb_first_tile(S, sat ? ntile_s : ntile_c, sat ? nsb_s : nsb_c) * TILE;
     const int *sb_c = sb_counts, *sb_s = sb_counts + (int64_t)nsb_c * 4;
     const int *sb_mine = sat ? sb_s : sb_c;
     // v[0..2]: counts of the superblocks of my kind in front of me; v[3..5]: all central counts (satellite offset,
@@ -1279,7 +1303,7 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
     const int total = m0 + m1 + m2;
     if (total == 0) return;
     const int64_t off0 = v[0] + (sat ? v[3] : 0), off1 = v[1] + (sat ? v[4] : 0), off2 = v[2] + (sat ? v[5] : 0);
-    const unsigned short *kept = (sat ? kept_s : kept_c) + (int64_t)S * SB_OBJ;
+    const unsigned short *kept = (sat ? kept_s : kept_c) + obj_first;
     const double a0 = sat ? p.L_alpha_s : p.L_alpha_c, a1 = sat ? p.E_alpha_s : p.E_alpha_c,
                  a2 = sat ? p.Q_alpha_s : p.Q_alpha_c;
     if (in.hrec && in.prec && !(dbg & 3)) {
@@ -1295,7 +1319,7 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
         // particle (line 1) [id, mass] [pos0, pos1] [pos2, vel0] [vel1, vel2] [hvel0, hvel1] [hvel2, -]
         const int o1 = sat ? 16 : 48, o2 = sat ? 32 : 64, o3 = sat ? 48 : 80, o4 = sat ? 64 : 96, o5 = sat ? 80 : 112;
         auto issue = [&](unsigned int k, v4u (&r)[6]) {
-            const char *q = rec + ((int64_t)S * SB_OBJ + k) * rb;
+            const char *q = rec + (obj_first + k) * rb;
             aload16(r[0], q), aload16(r[1], q + o1), aload16(r[2], q + o2), aload16(r[3], q + o3), aload16(r[4], q + o4),
                 aload16(r[5], q + o5);
         };
@@ -1347,7 +1371,7 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, const u
     for (int e = tid; e < total; e += EBLOCK) {
         const int t = e < m0 ? 0 : (e < m0 + m1 ? 1 : 2);
         const int64_t j = t == 0 ? off0 + e : (t == 1 ? off1 + (e - m0) : off2 + (e - m0 - m1));
-        const int64_t i = (int64_t)S * SB_OBJ + kept[e];
+        const int64_t i = obj_first + kept[e];
         const double al = t == 0 ? a0 : (t == 1 ? a1 : a2);
         double x, y, z, vx, vy, vz, m;
         int64_t id;
@@ -2033,8 +2057,17 @@ void set_superblocks(abacus_hod_state *st, const abacus_hod_params *p) {
     int sbt = option("hod_sbtiles");
     if (sbt != SB_TILES_DENSE && sbt != SB_TILES_SPARSE) sbt = (p->want_ELG || p->want_QSO) ? SB_TILES_DENSE : SB_TILES_SPARSE;
     st->sb_tiles = sbt;
-    st->nsb_c = (int)ceil_div(st->ntile_c, sbt);
-    st->nsb_s = (int)ceil_div(st->ntile_s, sbt);
+    // Dense mixes: hod_exact is one round of workgroups (three fit a CU at its ~150 registers), and a CU that holds three of
+    // them is done a third later than one that holds two - 611 superblocks of 8 tiles at 1e7 objects left the 256 CUs with
+    // 2.4 on average and 3 at most.  A whole number of workgroups per CU (768: 6 or 7 tiles each) evens that out.
+    const int per_round = 3 * 256;
+    auto count = [&](int ntile) {
+        int n = (int)ceil_div(ntile, sbt);
+        if (sbt == SB_TILES_DENSE && n > 256 && !option("hod_nobalance")) n = (int)ceil_div(n, per_round) * per_round;
+        return std::min(n, std::max(ntile, 0));
+    };
+    st->nsb_c = count(st->ntile_c);
+    st->nsb_s = count(st->ntile_s);
 }
 
 int launch_emit(abacus_hod_state *st) {
@@ -2054,7 +2087,7 @@ int launch_emit(abacus_hod_state *st) {
     int eb = option("hod_eblock");
     if (eb != 256 && eb != 512) eb = (st->params.want_ELG || st->params.want_QSO) ? 512 : 256;
 #define EMIT(EB, SBT)                                                                                                       \
-    ABACUS_LAUNCH("hod_emit", (hod_emit<EB, SBT>), dim3(nemit), dim3(EB), 0, st->nsb_c, st->nsb_s, st->kept_c, st->kept_s, \
+    ABACUS_LAUNCH("hod_emit", (hod_emit<EB, SBT>), dim3(nemit), dim3(EB), 0, st->nsb_c, st->nsb_s, st->ntile_c, st->ntile_s, st->kept_c, st->kept_s, \
                   st->sb_counts, st->d_totals, in, st->params, out_cols(st), option("dbg"))
     const bool sparse = st->sb_tiles == SB_TILES_SPARSE;
     if (eb == 256 && sparse) EMIT(256, SB_TILES_SPARSE);
@@ -2232,7 +2265,8 @@ static int stage_fill(abacus_hod_state *st, const abacus_hod_arrays *a, int on_d
     // counters and kept lists sized for either superblock size (the populate picks one, set_superblocks)
     st->nsb_c = (int)ceil_div(st->ntile_c, SB_TILES_MIN);
     st->nsb_s = (int)ceil_div(st->ntile_s, SB_TILES_MIN);
-    HIP_TRY(hipMalloc((void **)&st->sb_counts, (size_t)(st->nsb_c + st->nsb_s + 1) * 4 * sizeof(int)));
+    // (set_superblocks rounds the counts of a populate up to a whole number of workgroups per CU: at most 768 more each)
+    HIP_TRY(hipMalloc((void **)&st->sb_counts, (size_t)(st->nsb_c + st->nsb_s + 2 * 768 + 1) * 4 * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&st->d_totals, 8 * sizeof(int64_t)));
     HIP_TRY(hipMalloc((void **)&st->q_count, (size_t)(ntiles > 0 ? ntiles : 1) * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&st->queue_c, (size_t)(st->ntile_c > 0 ? st->ntile_c : 1) * TILE * sizeof(unsigned short)));
@@ -2400,9 +2434,9 @@ int abacus_hod_populate_nfw(abacus_hod_state *st, const abacus_hod_params *p, co
         abacus_cls::ClsConst cc;
         abacus_cls::make_cls_const(*p, pre, cc);
         if (st->sb_tiles == SB_TILES_SPARSE)
-            ABACUS_LAUNCH("hod_exact", (hod_exact<256, false, SB_TILES_SPARSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1, 0);
+            ABACUS_LAUNCH("hod_exact", (hod_exact_plain<256, SB_TILES_SPARSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1, 0);
         else
-            ABACUS_LAUNCH("hod_exact", (hod_exact<256, false, SB_TILES_DENSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1, 0);
+            ABACUS_LAUNCH("hod_exact", (hod_exact_plain<256, SB_TILES_DENSE>), dim3(st->nsb_c), dim3(256), 0, a, 0, *p, pre, cc, 1, 0);
     }
     ABACUS_TRY(launch_emit(st));
     HIP_TRY(hipMemcpyAsync(st->h_totals, st->d_totals, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
@@ -2634,8 +2668,15 @@ int abacus_hod_populate_async(abacus_hod_state *st, const abacus_hod_params *p) 
     const int pipe_opt = option("hod_pipe");
     const bool pipe = a.hrec && a.prec && (pipe_opt == 2 || (pipe_opt != 1 && (p->want_ELG || p->want_QSO)));
     const bool sparse_sb = st->sb_tiles == SB_TILES_SPARSE;
-#define EXACT_(PIPE, SBT, first, count) \
-    ABACUS_LAUNCH("hod_exact", (hod_exact<256, PIPE, SBT>), dim3(count), dim3(256), 0, a, first, *p, pre, cc, nocls ? 0 : 1, exact_flags)
+#define EXACT_(PIPE, SBT, first, count)                                                                                      \
+    do {                                                                                                                     \
+        if (PIPE)                                                                                                            \
+            ABACUS_LAUNCH("hod_exact", (hod_exact<256, true, SBT>), dim3(count), dim3(256), 0, a, first, *p, pre, cc,        \
+                          nocls ? 0 : 1, exact_flags);                                                                       \
+        else                                                                                                                 \
+            ABACUS_LAUNCH("hod_exact", (hod_exact_plain<256, SBT>), dim3(count), dim3(256), 0, a, first, *p, pre, cc,        \
+                          nocls ? 0 : 1, exact_flags);                                                                       \
+    } while (0)
 #define EXACT(first, count)                                                    \
     if ((count) > 0) {                                                         \
         if (pipe && sparse_sb) EXACT_(true, SB_TILES_SPARSE, first, count);    \
