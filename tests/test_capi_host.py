@@ -102,7 +102,8 @@ def test_async_load_kernels_do_not_spill(tmp_path):
     """fft.hip and tsc.hip prefetch with untracked asynchronous loads (inline-asm global_load + hand-counted vmcnt): the
     compiler does not know those registers are pending, so it must never spill or copy them.  With zero spills and the
     `touch` barriers in the source that holds; this test pins the zero (it cross-compiles, no GPU needed).  The binning
-    and HOD kernels are held to zero spills as well (scratch traffic in their hot loops is a silent 2x)."""
+    and HOD kernels are held to zero spills as well (scratch traffic in their hot loops is a silent 2x), but for the plain
+    form of hod_exact."""
     import re
     import shutil
     import subprocess
@@ -125,7 +126,9 @@ def test_async_load_kernels_do_not_spill(tmp_path):
             name, spills = m.group(1), int(m.group(3))
             if any(n in name for n in names):
                 found += 1
-                assert spills == 0, (name, spills)
+                # hod_exact_plain (the form WITHOUT untracked loads) is held to 128 registers on purpose: a fourth wave per
+                # SIMD for a value or two in scratch outside its candidate loop
+                assert spills <= (3 if 'hod_exact_plain' in name else 0), (name, spills)
         assert found >= len(names)
 
 
