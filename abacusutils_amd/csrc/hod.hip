@@ -2082,15 +2082,19 @@ int launch_emit(abacus_hod_state *st) {
     const bool rec = st->rec_ok && st->rec_rand_ok;
     in.hrec = rec ? st->hrec.as<HaloRec>() : nullptr;
     in.prec = rec ? st->prec.as<PartRec>() : nullptr;
-    // workgroup size: 512 threads per superblock for the dense mixes (ELG / QSO: thousands of galaxies per superblock, 106 vs
-    // 115 us at LRG + ELG + QSO on 1e7 + 1e7), 256 for LRG alone (12 vs 20 us: the larger workgroups only cost launch time)
+    // workgroup size: 384 threads per superblock for the dense mixes (ELG / QSO: a few thousand galaxies per superblock; at
+    // its 86 registers three such workgroups fit a CU - all 768 central superblocks of 1e7 halos at once - where only two of
+    // 512 threads do: 92 vs 101 us at LRG + ELG + QSO on 1e7 + 1e7, 95 with 256), 256 for LRG alone (12 vs 20 us: the larger
+    // workgroups only cost launch time)
     int eb = option("hod_eblock");
-    if (eb != 256 && eb != 512) eb = (st->params.want_ELG || st->params.want_QSO) ? 512 : 256;
+    if (eb != 256 && eb != 384 && eb != 512) eb = (st->params.want_ELG || st->params.want_QSO) ? 384 : 256;
 #define EMIT(EB, SBT)                                                                                                       \
     ABACUS_LAUNCH("hod_emit", (hod_emit<EB, SBT>), dim3(nemit), dim3(EB), 0, st->nsb_c, st->nsb_s, st->ntile_c, st->ntile_s, st->kept_c, st->kept_s, \
                   st->sb_counts, st->d_totals, in, st->params, out_cols(st), option("dbg"))
     const bool sparse = st->sb_tiles == SB_TILES_SPARSE;
-    if (eb == 256 && sparse) EMIT(256, SB_TILES_SPARSE);
+    if (eb == 384 && sparse) EMIT(384, SB_TILES_SPARSE);
+    else if (eb == 384) EMIT(384, SB_TILES_DENSE);
+    else if (eb == 256 && sparse) EMIT(256, SB_TILES_SPARSE);
     else if (eb == 256) EMIT(256, SB_TILES_DENSE);
     else if (sparse) EMIT(512, SB_TILES_SPARSE);
     else EMIT(512, SB_TILES_DENSE);
