@@ -218,6 +218,9 @@ def lightcone_edge_norm(pos, r98, Lbox, origins, seed, rad_outer=10, rand_final=
             norm += do_Menv_from_tree(both, mass, r_inner=ri, r_outer=float(rad_outer), halo_lc=True, Lbox=Lbox, mcut=-1.0)[:len(edge)]
         rounds += 1
         count += len(rpos)
+        if rounds >= 1000 and count == 0:      # the reference would loop for ever: no random ever falls into the boundary layer
+            raise RuntimeError('lightcone_edge_norm: no randoms inside the light-cone volume near its boundary - do the '
+                               'origins and Lbox describe the catalogue?')
     density *= rounds
     norm /= (rad_outer**3.0 - r98[edge] ** 3.0) * 4.0 / 3.0 * np.pi * density
     return edge, norm
