@@ -462,8 +462,10 @@ int abacus_fenv_rank(const double *Menv, const double *halosM, int64_t n, const 
  *   index part_index0 + q).  Outputs: pstart_new / pnum_new per halo as the reference stores them (float64; -1 for dropped
  *   halos and halos without particles, :895-897, :979-981); *n_sel kept particles; if cap_sel >= *n_sel also their input index
  *   (ascending), host halo index, Np (:881) and, with want_ranks, the five rank columns ranks / ranksv / ranksp / ranksr /
- *   ranksc (:899-977).  Call with cap_sel = 0 first to size the outputs (pass the returned `submask_out` as `submask_in` of the
- *   second call, so that both calls see one draw).  Halo slices must be ordered like the halos (CompaSO's layout).
+ *   ranksc (:899-977).  The number of kept particles is known beforehand - the set bytes of `submask_in`, or the sum of
+ *   ntarget over the kept halos - so one call with cap_sel of that size does it all; a call with cap_sel = 0 only sizes the
+ *   outputs (pass its `submask_out` as `submask_in` of the second call, so that both see one draw).  Halo slices must be
+ *   ordered like the halos (CompaSO's layout).
  */
 int abacus_prepare_halo_factors(const uint32_t *N, int64_t n, double Mpart, int MT, const double *u, const int64_t *pnum,
                                 double *p_halos, uint8_t *mask, int32_t *ntarget);
