@@ -1198,6 +1198,9 @@ struct OutCols {
 };
 
 // galaxy emission shared by centrals (hod/GRAND_HOD.py:298-325) and satellites (:1134-1165)
+typedef __attribute__((address_space(1))) double *gdouble_p;   // the output columns are device allocations
+typedef __attribute__((address_space(1))) long long *gint64_p;
+
 __device__ __forceinline__ void emit_one(const abacus_hod_params &p, const OutCols &o, int t, int64_t j, double x,
                                          double y, double z, double vx, double vy, double vz, double mass,
                                          int64_t id) {
@@ -1215,14 +1218,14 @@ __device__ __forceinline__ void emit_one(const abacus_hod_params &p, const OutCo
     } else if (p.rsd) {
         z = wrap_box(z + vz * p.inv_velz2kms, p.lbox);
     }
-    __builtin_nontemporal_store(x, &o.c[t][0][j]);
-    __builtin_nontemporal_store(y, &o.c[t][1][j]);
-    __builtin_nontemporal_store(z, &o.c[t][2][j]);
-    __builtin_nontemporal_store(vx, &o.c[t][3][j]);
-    __builtin_nontemporal_store(vy, &o.c[t][4][j]);
-    __builtin_nontemporal_store(vz, &o.c[t][5][j]);
-    __builtin_nontemporal_store(mass, &o.c[t][6][j]);
-    __builtin_nontemporal_store(id, &o.id[t][j]);
+    __builtin_nontemporal_store(x, (gdouble_p)o.c[t][0] + j);
+    __builtin_nontemporal_store(y, (gdouble_p)o.c[t][1] + j);
+    __builtin_nontemporal_store(z, (gdouble_p)o.c[t][2] + j);
+    __builtin_nontemporal_store(vx, (gdouble_p)o.c[t][3] + j);
+    __builtin_nontemporal_store(vy, (gdouble_p)o.c[t][4] + j);
+    __builtin_nontemporal_store(vz, (gdouble_p)o.c[t][5] + j);
+    __builtin_nontemporal_store(mass, (gdouble_p)o.c[t][6] + j);
+    __builtin_nontemporal_store((long long)id, (gint64_p)o.id[t] + j);
 }
 
 // Ordered emission, one workgroup per superblock.  The output offset of a superblock is a workgroup reduction over
@@ -1249,9 +1252,16 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, int nti
                                                    const unsigned short *__restrict__ kept_c,
                                                    const unsigned short *__restrict__ kept_s,
                                                    const int *__restrict__ sb_counts, int64_t *__restrict__ totals,
-                                                   EmitPtrs in, abacus_hod_params p, OutCols o, int dbg) {
+                                                   EmitPtrs in, abacus_hod_params p, OutCols o_arg, int dbg) {
     __shared__ int64_t red[EBLOCK / 64][6];
+    // the column pointers and capacities are indexed by the galaxy's tracer: from a copy in LDS (an LDS read per use, counted
+    // by lgkmcnt) - indexing the kernel arguments at run time made every galaxy load them from the argument segment with
+    // vector memory loads, whose waits sat in front of the column stores
+    __shared__ OutCols o;
+    static_assert(sizeof(OutCols) % 8 == 0, "copied as 8-byte words");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < (int)(sizeof(OutCols) / 8))
+        reinterpret_cast<unsigned long long *>(&o)[tid] = reinterpret_cast<const unsigned long long *>(&o_arg)[tid];
     const int g = blockIdx.x;
     const bool sat = g >= nsb_c;
     const int S = sat ? g - nsb_c : g;
@@ -1357,12 +1367,21 @@ __global__ __launch_bounds__(EBLOCK) void hod_emit(int nsb_c, int nsb_s, int nti
                 vy = h1 + al * (dbl(r[3].x, r[3].y) - h1);
                 vz = h2 + al * (dbl(r[3].z, r[3].w) - h2);
             }
+            // the record of galaxy k + 1 and the kept index of k + 2 are requested BEFORE the eight column stores of galaxy k:
+            // vmcnt counts in order, so the wait below can leave exactly those stores outstanding (they drain under the next
+            // iteration) - unless a lane skipped its stores (catalogue buffers too small), then everything is waited for
+            const bool more = e + EBLOCK < total;
+            asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(vx), "+v"(vy), "+v"(vz), "+v"(m), "+v"(id));   // decoded: r[] is free
+            if (more) {
+                issue(k1, r);
+                aload_u16(k2, kept + min(e + 2 * EBLOCK, total - 1));
+            }
+            const bool stored = j < o.cap[t];
             emit_one(p, o, t, j, x, y, z, vx, vy, vz, m, id);
             e += EBLOCK;
-            if (e >= total) break;
-            issue(k1, r);
-            aload_u16(k2, kept + min(e + EBLOCK, total - 1));
-            await_vm<0>();
+            if (!more) break;
+            if (__all(stored)) await_vm<8>();
+            else await_vm<0>();
             touch1(k2);
             k1 = k2;
         }
