@@ -84,6 +84,46 @@ def test_lightcone_environment_reproduces_the_reference(case):
             np.testing.assert_array_equal(got[k], g[f'{case}.{kind}.{k}'], err_msg=f'{kind}.{k}')
 
 
+@pytest.mark.parametrize('geometry', ['octant', 'centre'])
+def test_lightcone_host_logic_matches_the_oracle(geometry):
+    """the host side of the product's light-cone environment (abacusutils_amd/hod/prepare_sim.py: the randoms of a round, the
+    boxes they are cut to, the edge set - plain NumPy, no GPU involved) against the oracle's restatement, which the test
+    above holds to the reference: same generator state in, same points and the same edge halos out"""
+    from abacusutils_amd.hod import prepare_sim as ps
+    slab, header = synth.synth_lightcone_slab(n_halo=1200, seed=77, geometry=geometry)
+    pos = slab['halos']['x_L2com']
+    Lbox = header['BoxSizeHMpc']
+    origins = np.asarray(header['LightConeOrigins']).reshape(-1, 3)
+    dist = np.sqrt(np.sum((pos - origins[0]) ** 2.0, axis=1))
+    r_min, r_max = dist.min(), dist.max()
+    for chi_max in (r_max, Lbox):                         # the second reaches beyond the first box: three boxes for the octant
+        a, ad = ps._lightcone_randoms(5000, r_min, chi_max, Lbox, 10.0, origins, np.random.default_rng(5))
+        b, bd = po.lightcone_shell_randoms(5000, r_min, chi_max, Lbox, 10.0, origins, np.random.default_rng(5))
+        assert 100 < len(a) <= 5000
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(ad, bd)
+    _, edge_o, _ = po.lightcone_menv(pos, slab['halos']['N'] * header['ParticleMassHMsun'], slab['halos']['r98_L2com'], Lbox,
+                                     origins, 3)
+    inside = ps._lightcone_interior(pos, dist, float(Lbox), ps.LC_OFFSET, origins, 10, r_min, r_max)
+    np.testing.assert_array_equal(np.flatnonzero(~inside), edge_o)
+    assert 0 < len(edge_o) < len(pos)
+    with pytest.raises(ValueError, match='origins'):
+        ps._lightcone_cuboids(Lbox, 10.0, np.zeros((2, 3)), r_max)
+
+
+def test_rows_gathers_like_fancy_indexing():
+    from abacusutils_amd.hod.prepare_sim import _rows
+    r = np.random.default_rng(0)
+    for a in (r.random((50, 3), dtype=np.float32), r.random(50), r.random((50, 3)), np.zeros((0, 3), dtype=np.float32),
+              r.random((50, 3))[:, ::-1], r.integers(0, 9, (50, 2)), r.random((50, 2, 2))):
+        for idx in (np.array([3, 1, 1, 49]), np.array([], dtype=np.int64)):
+            if len(a) == 0 and len(idx):
+                continue
+            got, want = _rows(a, idx), a[idx]
+            assert got.dtype == want.dtype and got.shape == want.shape
+            np.testing.assert_array_equal(got, want)
+
+
 def test_device_stream_restatement_is_sane():
     """the oracle's restatement of the device's random columns (bit-compared with the kernels in tests/test_prepare_gpu.py):
     ranges, rough moments, independence of index order"""
