@@ -584,10 +584,33 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_fine(const int64_t *__restrict__ 
     }
 }
 
+// One addend of an LDS tile cell.  ACC = double / float: a floating-point LDS atomic.  ACC = unsigned long long: FIXED POINT -
+// the addend v >= 0 (unweighted TSC / CIC: every cloud weight is non-negative) becomes round(v * 2^S) by one fused
+// multiply-add onto 2^52 (the integer then sits in the low mantissa bits: no float -> int64 conversion sequence) and goes
+// into the cell as an integer add.  Measured on MI355X (scripts/ubench/ldsatomic.hip, profiles/r04/ubench_ldsatomic.txt):
+// ds_add_u64 on random cells of a tile takes 12.2 cycles per wave instruction, ds_add_f64 21.5 - and integer sums do not
+// depend on the order of the adds at all, so the mesh is bit-reproducible run to run by construction.  S is picked by the
+// host so that n addends of at most 1 cannot overflow 63 bits (S = 36 at 1e8 particles: a resolution of 1.5e-11 per addend).
+template <typename ACC, typename V>
+__device__ __forceinline__ void acc_add(ACC *cell, V v, double fxscale) {
+    if constexpr (std::is_same<ACC, unsigned long long>::value) {
+        const double m = __builtin_fma((double)v, fxscale, 0x1p52);
+        atomicAdd(cell, (unsigned long long)__double_as_longlong(m) & 0x000fffffffffffffull);
+    } else {
+        atomicAdd(cell, (ACC)v);
+    }
+}
+template <typename ACC>
+__device__ __forceinline__ double acc_value(ACC a, double fxinv) {
+    if constexpr (std::is_same<ACC, unsigned long long>::value) return (double)a * fxinv;
+    else return (double)a;
+}
+
 // contribution of one list entry to the LDS tile with origin (ox, oy, oz) and extent (dx, dy, dz)
 template <typename PT, int TYS, int TZS, bool CIC, typename ACC = double, int FAST = 0>
 __device__ __forceinline__ void tile_accumulate(ACC *tile, const Entry<PT> &en, const TileGeom &g, int ox, int oy, int oz,
-                                                int dx, int dy, int dz, double box, PT offset, PT ihx, PT ihy, PT ihz) {
+                                                int dx, int dy, int dz, double box, PT offset, PT ihx, PT ihy, PT ihz,
+                                                double fxscale = 0.0) {
     int lx[3], ly[3], lz[3];
     if (CIC) {
         Cloud<double> c;
@@ -609,7 +632,7 @@ __device__ __forceinline__ void tile_accumulate(ACC *tile, const Entry<PT> &en, 
                 for (int cc = 0; cc < 3; cc++) {
                     if ((unsigned)lz[cc] >= (unsigned)dz) continue;
                     const double v = c.w[0][a] * c.w[1][b] * c.w[2][cc] * W;
-                    if (v != 0.0) atomicAdd(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], (ACC)v);
+                    if (v != 0.0) acc_add<ACC>(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], v, fxscale);
                 }
             }
         }
@@ -638,7 +661,7 @@ __device__ __forceinline__ void tile_accumulate(ACC *tile, const Entry<PT> &en, 
                 for (int cc = 0; cc < 3; cc++) {
                     if ((unsigned)lz[cc] >= (unsigned)dz) continue;
                     const PT v = c.w[0][a] * c.w[1][b] * c.w[2][cc] * en.w;  // wx*wy*wz*W (tsc.py:471-507)
-                    atomicAdd(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], (ACC)v);
+                    acc_add<ACC>(&tile[(lx[a] * TYS + ly[b]) * TZS + lz[cc]], v, fxscale);
                 }
             }
         }
@@ -741,7 +764,7 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
                                                          const int64_t *__restrict__ tile_start, int ntiles, int range_len,
                                                          TileGeom g, double box, double offset_,
                                                          float *__restrict__ grid, int zero_grid, float norm, float sub,
-                                                         int dbg) {
+                                                         int dbg, double fxscale) {
     constexpr int NPRE = 2;                                // prefetched entries per thread
     constexpr int FL = TXS * TYS * (TZS / 4) / NT;         // flush stores (16 B) per thread of a full tile
     static_assert((TXS * TYS * (TZS / 4)) % NT == 0 && 2 * FL + NPRE <= 60, "whole flush stores per thread");
@@ -754,6 +777,7 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
     }
     const float ihx = (float)(g.gxg / box), ihy = (float)(g.gy / box), ihz = (float)(g.gz / box);
     const float offset = (float)offset_;
+    const double fxinv = fxscale != 0.0 ? 1.0 / fxscale : 0.0;   // a power of two: exact
     const int64_t last = nentries > 0 ? nentries - 1 : 0;
     const int nranges = (ntiles + range_len - 1) / range_len;   // range_len <= TP_RANGE
     for (int r = blockIdx.x; r < nranges; r += gridDim.x) {
@@ -787,13 +811,13 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
             for (int q = 0; q < NPRE; q++) {
                 if (e0 + q * NT + tid < e1 && !(dbg & 1)) {
                     const Entry<float> en{cur[q].x, cur[q].y, cur[q].z, cur[q].w};
-                    tile_accumulate<float, TYS, TZS, CIC, ACC, FAST>(tile, en, g, ox, oy, oz, dx, dy, dz, box, offset, ihx, ihy, ihz);
+                    tile_accumulate<float, TYS, TZS, CIC, ACC, FAST>(tile, en, g, ox, oy, oz, dx, dy, dz, box, offset, ihx, ihy, ihz, fxscale);
                 }
             }
             bool extra = false;                            // tracked loads below: fall back to a full wait
             for (int64_t e = e0 + NPRE * NT + tid; e < e1; e += NT) {
                 const Entry<float> en = entries[e];        // a copy: a reference would be re-read around every LDS atomic
-                tile_accumulate<float, TYS, TZS, CIC, ACC, FAST>(tile, en, g, ox, oy, oz, dx, dy, dz, box, offset, ihx, ihy, ihz);
+                tile_accumulate<float, TYS, TZS, CIC, ACC, FAST>(tile, en, g, ox, oy, oz, dx, dy, dz, box, offset, ihx, ihy, ihz, fxscale);
             }
             extra = e1 - e0 > NPRE * NT;
             __syncthreads();
@@ -815,7 +839,19 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
 #pragma unroll
                 for (int st = 0; st < STEPS; st++, cell += XSTEP * TYS * TZS, dst += dstep) {
                     float v[4];
-                    if constexpr (sizeof(ACC) == 8) {
+                    if constexpr (std::is_same<ACC, unsigned long long>::value) {
+                        ulonglong2 *c2 = reinterpret_cast<ulonglong2 *>(cell);
+                        const ulonglong2 a01 = c2[0], a23 = c2[1];
+                        c2[0] = make_ulonglong2(0ull, 0ull);  // the tile is zero again for the next one
+                        c2[1] = make_ulonglong2(0ull, 0ull);
+                        double a[4] = {(double)a01.x * fxinv, (double)a01.y * fxinv, (double)a23.x * fxinv, (double)a23.y * fxinv};
+                        if (!zero_grid) {
+                            const float4 old = *reinterpret_cast<const float4 *>(dst);
+                            a[0] += (double)old.x, a[1] += (double)old.y, a[2] += (double)old.z, a[3] += (double)old.w;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; c++) v[c] = (float)a[c];
+                    } else if constexpr (sizeof(ACC) == 8) {
                         double2 *c2 = reinterpret_cast<double2 *>(cell);
                         const double2 a01 = c2[0], a23 = c2[1];
                         c2[0] = make_double2(0.0, 0.0);       // the tile is zero again for the next one
@@ -846,7 +882,7 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
             } else {
                 for (int q = tid; q < TXS * TYS * TZS; q += NT) {
                     const int z = q % TZS, y = (q / TZS) % TYS, x = q / (TZS * TYS);
-                    double acc = (double)tile[q];
+                    double acc = acc_value<ACC>(tile[q], fxinv);
                     tile[q] = (ACC)0;
                     if (x < dx && y < dy && z < dz) {
                         float *dst = grid + ((int64_t)(ox + x) * g.gy + (oy + y)) * g.zstride + (oz + z);
@@ -861,7 +897,7 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
             // vector-memory operations issued since the request for tile tt+1: [FL stores of tile tt-1] [NPRE loads of
             // tile tt+2] [FL stores of this tile] - when exactly so, vmcnt(2 FL + NPRE) means tile tt+1 has landed and
             // everything younger may stay in flight; otherwise wait for everything
-            const bool plain = full && zero_grid && !extra;
+            const bool plain = full && zero_grid && !extra && !(dbg & 2);   // (no stores issued: the count below would not hold)
             if (plain && prev_plain && more) tsc_wait_vmcnt<2 * FL + NPRE>();
             else tsc_wait_vmcnt<0>();
             prev_plain = plain;
@@ -876,7 +912,166 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
     }
 }
 
+// did any deposit since the last reset move a position into the box?  (the host entry points copy the positions back to the
+// caller - the reference wraps its argument in place, tsc.py:171-173 - only then: 1.2 GB over PCIe at 1e8 particles)
+static int g_wrapped_seen = 0;
+
+#include "tsc_lines.hpp"
+
 // ---- host-side driver ------------------------------------------------------------------------------------
+// second-generation lists (tsc_lines.hpp): work buffers and the staged entries kept for the second deposit of an
+// interlaced pair (the fine level is rebuilt per offset from the same staged entries)
+struct LinesWork {
+    DevBuf M, tot, tables, staged, C, tile_start, tile_cnt, entries, flag;
+};
+LinesWork g_lw;
+
+// block shape: tiles per block and blocks within the limits of a configuration (0: 512 tiles x 256 blocks, both scatter
+// kernels at two workgroups per CU; 1: 1024 x 1024), smallest surface-to-volume ratio of a block
+static bool lines_geometry(int gx, int gy, int gz, int64_t zstride, LGeom &g, int &cfg) {
+    if (gx % LN_TX || gy % LN_TY || gz % LN_TZ || gx / LN_TX > 256 || gy / LN_TY > 256 || gz / LN_TZ > 256) return false;
+    g.n[0] = gx, g.n[1] = gy, g.n[2] = gz;
+    g.nt[0] = gx / LN_TX, g.nt[1] = gy / LN_TY, g.nt[2] = gz / LN_TZ;
+    g.zstride = zstride;
+    const int T[3] = {LN_TX, LN_TY, LN_TZ};
+    for (cfg = 0; cfg < 2; cfg++) {
+        const int limT = cfg ? 1024 : 512, limB = cfg ? 1024 : 256;
+        double best = 1e30;
+        bool found = false;
+        for (int a = 0; a <= 5; a++)
+            for (int b = 0; b <= 5; b++)
+                for (int c = 0; c <= 5; c++) {
+                    const int sb[3] = {a, b, c};
+                    bool ok = true;
+                    int64_t nb = 1;
+                    double surf = 0;
+                    for (int d = 0; d < 3; d++) {
+                        if (g.nt[d] % (1 << sb[d])) ok = false;
+                        nb *= g.nt[d] >> sb[d];
+                        surf += 1.0 / ((double)T[d] * (1 << sb[d]));
+                    }
+                    if (!ok || (1 << (a + b + c)) > limT || nb > limB) continue;
+                    // every block at least two tiles... (a cloud touches at most two blocks per dimension only if a block
+                    // is at least five cells wide: always, a tile is 16)
+                    const double cost = surf + 1e-6 * (double)nb;
+                    if (cost < best) {
+                        best = cost, found = true;
+                        for (int d = 0; d < 3; d++) g.sb[d] = sb[d], g.nb[d] = g.nt[d] >> sb[d];
+                        g.tpb = 1 << (a + b + c);
+                        g.nbuckets = (int)nb;
+                    }
+                }
+        if (found) return true;
+    }
+    return false;
+}
+
+static int lines_fxscale(int64_t n, double &fxscale) {
+    int fxs = 40;
+    while (fxs > 8 && (double)std::max<int64_t>(n, 1) * std::ldexp(1.0, fxs) >= 0x1p62) fxs--;
+    fxscale = std::ldexp(1.0, fxs);
+    return fxs;
+}
+
+// lists + deposit of the second generation, for one deposit (an interlaced pair builds its lists twice: the staged entries
+// hold the in-cell offsets of ONE mesh offset)
+static int lines_deposit_run(float *pos, int64_t n, float *grid, const LGeom &g, int cfg, double box, double offset, int wrap,
+                             int zero_grid, double norm, double sub, int *wrapped_out) {
+    const int nb = g.nbuckets, ntiles = nb * g.tpb;
+    const int64_t CH = std::max<int64_t>(8192, ceil_div(n, 1024));
+    const int nchunk = (int)ceil_div(n, CH);
+    ABACUS_TRY(g_lw.M.reserve((size_t)nchunk * nb * sizeof(unsigned int)));
+    ABACUS_TRY(g_lw.tot.reserve((size_t)nb * sizeof(unsigned int)));
+    ABACUS_TRY(g_lw.flag.reserve(256));
+    unsigned int *M = g_lw.M.as<unsigned int>(), *tot = g_lw.tot.as<unsigned int>();
+    int *flag = g_lw.flag.as<int>();
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), stream()));
+    const float offA = (float)offset;
+    if (cfg == 0) ABACUS_LAUNCH("tsc_lines_count", (lines_count<256>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, flag);
+    else ABACUS_LAUNCH("tsc_lines_count", (lines_count<1024>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, flag);
+    ABACUS_LAUNCH("tsc_lines_colscan", lines_colscan, dim3(nb), dim3(1024), 0, M, nchunk, nb, tot);
+    std::vector<unsigned int> h_tot((size_t)nb);
+    int h_flag = 0;
+    HIP_TRY(hipMemcpyAsync(h_tot.data(), tot, (size_t)nb * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    if (wrapped_out) *wrapped_out = h_flag;
+    g_wrapped_seen |= h_flag;
+    // bucket starts on line boundaries; pieces of at most PIECE staged entries; one table upload
+    constexpr int64_t PIECE = 131072;
+    std::vector<unsigned int> gstart((size_t)nb + 1), fstart((size_t)nb + 1);
+    std::vector<int> piece_first((size_t)nb + 1);
+    std::vector<LnPiece> pieces;
+    int64_t gs = 0, fs = 0;
+    for (int b = 0; b < nb; b++) {
+        gstart[b] = (unsigned int)gs, fstart[b] = (unsigned int)fs;
+        piece_first[b] = (int)pieces.size();
+        for (int64_t e = 0; e < (int64_t)h_tot[b]; e += PIECE)
+            pieces.push_back(LnPiece{b, (unsigned int)(gs + e), (unsigned int)(gs + std::min<int64_t>(e + PIECE, h_tot[b])), e == 0});
+        gs += ((int64_t)h_tot[b] + 15) & ~(int64_t)15;
+        fs += ((int64_t)h_tot[b] + 15 * (int64_t)g.tpb + 15) & ~(int64_t)15;   // every tile list starts on a line boundary
+        if (gs >= 0xfff00000ll || fs >= 0xfff00000ll) return 1;                  // 32-bit entry indices: the caller falls back
+    }
+    gstart[nb] = (unsigned int)gs, fstart[nb] = (unsigned int)fs;
+    piece_first[nb] = (int)pieces.size();
+    const int np = (int)pieces.size();
+    const size_t o_g = 0, o_f = o_g + (size_t)(nb + 1) * 4, o_pf = o_f + (size_t)(nb + 1) * 4, o_p = (o_pf + (size_t)(nb + 1) * 4 + 15) & ~(size_t)15,
+                 tbytes = o_p + std::max<size_t>(pieces.size(), 1) * sizeof(LnPiece);
+    std::vector<char> blob(tbytes);
+    memcpy(blob.data() + o_g, gstart.data(), (size_t)(nb + 1) * 4);
+    memcpy(blob.data() + o_f, fstart.data(), (size_t)(nb + 1) * 4);
+    memcpy(blob.data() + o_pf, piece_first.data(), (size_t)(nb + 1) * 4);
+    if (np) memcpy(blob.data() + o_p, pieces.data(), pieces.size() * sizeof(LnPiece));
+    ABACUS_TRY(g_lw.tables.reserve(tbytes));
+    ABACUS_TRY(g_lw.staged.reserve((size_t)std::max<int64_t>(gs, 16) * sizeof(uint4)));
+    ABACUS_TRY(g_lw.C.reserve((size_t)std::max(np, 1) * g.tpb * sizeof(unsigned int)));
+    ABACUS_TRY(g_lw.tile_start.reserve((size_t)ntiles * sizeof(unsigned int)));
+    ABACUS_TRY(g_lw.tile_cnt.reserve((size_t)ntiles * sizeof(unsigned int)));
+    ABACUS_TRY(g_lw.entries.reserve((size_t)std::max<int64_t>(fs, 16) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyAsync(g_lw.tables.p, blob.data(), tbytes, hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));   // `blob` leaves scope
+    const char *tb = g_lw.tables.as<char>();
+    const unsigned int *d_gstart = reinterpret_cast<const unsigned int *>(tb + o_g), *d_fstart = reinterpret_cast<const unsigned int *>(tb + o_f);
+    const int *d_pfirst = reinterpret_cast<const int *>(tb + o_pf);
+    const LnPiece *d_pieces = reinterpret_cast<const LnPiece *>(tb + o_p);
+    uint4 *staged = g_lw.staged.as<uint4>();
+    unsigned int *C = g_lw.C.as<unsigned int>(), *tile_start = g_lw.tile_start.as<unsigned int>(), *tile_cnt = g_lw.tile_cnt.as<unsigned int>();
+    unsigned long long *entries = g_lw.entries.as<unsigned long long>();
+    if (cfg == 0) {
+        ABACUS_LAUNCH("tsc_lines_coarse", (lines_coarse<256, 8, 2304, 512>), dim3(nchunk), dim3(512), 0, (const float *)pos, n, g, box, offA, CH,
+                      (const unsigned int *)M, d_gstart, staged);
+        if (np) ABACUS_LAUNCH("tsc_lines_fcount", (lines_fcount<512>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb, C);
+        ABACUS_LAUNCH("tsc_lines_fscan", (lines_fscan<512>), dim3(nb), dim3(512), 0, C, d_pfirst, g, d_fstart, tile_start, tile_cnt);
+        if (np) ABACUS_LAUNCH("tsc_lines_fine", (lines_fine<512, 8, 3072, 512>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb,
+                              (const unsigned int *)C, entries);
+    } else {
+        ABACUS_LAUNCH("tsc_lines_coarse", (lines_coarse<1024, 4, 3072, 1024>), dim3(nchunk), dim3(1024), 0, (const float *)pos, n, g, box, offA, CH,
+                      (const unsigned int *)M, d_gstart, staged);
+        if (np) ABACUS_LAUNCH("tsc_lines_fcount", (lines_fcount<1024>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb, C);
+        ABACUS_LAUNCH("tsc_lines_fscan", (lines_fscan<1024>), dim3(nb), dim3(1024), 0, C, d_pfirst, g, d_fstart, tile_start, tile_cnt);
+        if (np) ABACUS_LAUNCH("tsc_lines_fine", (lines_fine<1024, 8, 4096, 1024>), dim3(np), dim3(1024), 0, (const uint4 *)staged, d_pieces, g.tpb,
+                              (const unsigned int *)C, entries);
+    }
+    // deposit
+    int dev = 0, ncu = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int range_len = (int)std::min<int64_t>(LD_RANGE, std::max<int64_t>(64, ceil_div(ntiles, (int64_t)ncu * 8)));
+    const int nranges = (int)ceil_div(ntiles, range_len);
+    const int grid_p = (int)std::min<int64_t>(nranges, (int64_t)ncu * 2);
+    const bool dense = gs / std::max(ntiles, 1) > 400;
+    double fxscale;
+    lines_fxscale(n, fxscale);
+    const int dbg = option("dbg_tsc") & 3;
+    if (dense)
+        ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit<512>), dim3(grid_p), dim3(512), 0, (const unsigned long long *)entries, (int64_t)fs,
+                      (const unsigned int *)tile_start, (const unsigned int *)tile_cnt, ntiles, range_len, g, grid, zero_grid, (float)norm, (float)sub, fxscale, dbg);
+    else
+        ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit<256>), dim3(grid_p), dim3(256), 0, (const unsigned long long *)entries, (int64_t)fs,
+                      (const unsigned int *)tile_start, (const unsigned int *)tile_cnt, ntiles, range_len, g, grid, zero_grid, (float)norm, (float)sub, fxscale, dbg);
+    return 0;
+}
+
 struct TscWork {
     DevBuf tile_count, tile_start, entries, flag, scan, gcount, gstart, stage_entry, stage_key;
 };
@@ -913,9 +1108,6 @@ TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int 
     return g;
 }
 
-// did any deposit since the last reset move a position into the box?  (the host entry points copy the positions back to the
-// caller - the reference wraps its argument in place, tsc.py:171-173 - only then: 1.2 GB over PCIe at 1e8 particles)
-static int g_wrapped_seen = 0;
 
 template <typename PT, typename GT, bool CIC>
 int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy, int gz, int64_t zstride, double box,
@@ -948,6 +1140,18 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     if (share && list_mode == 1 && offset != 0.0) return fail("tsc: shared lists are built at offset 0");
     if (share && list_mode == 2 && (offset < 0.0 || offset > 0.5 * box / gxg * 1.0000001))
         return fail("tsc: shared lists cover offsets up to half a cell");
+    // second-generation lists (tsc_lines.hpp): unweighted float32 TSC on a full periodic mesh of whole tiles
+    if constexpr (std::is_same<PT, float>::value && std::is_same<GT, float>::value && !CIC) {
+        LGeom lg;
+        int lcfg = 0;
+        const double cell = box / gx;
+        if (multisplit && !weights && wrap && gxg == gx && xoff == 0 && xoff2 < 0 && ntiles >= 4096 && !option("tsc_oldlists") &&
+            std::fabs(offset) <= cell && lines_geometry(gx, gy, gz, zstride, lg, lcfg)) {
+            g_lists.valid = false;
+            const int rc = lines_deposit_run(pos, n, grid, lg, lcfg, box, offset, wrap, zero_grid, norm, sub, wrapped_out);
+            if (rc <= 0) return rc;   // 1: more than 2^32 entries - the first-generation lists below
+        }
+    }
     const int ext = share ? 1 : 0;
     const bool reuse = share && list_mode == 2 && g_lists.valid && g_lists.pos == (const void *)pos && g_lists.n == n &&
                        g_lists.zstride == zstride && g_lists.gx == gx && g_lists.gy == gy && g_lists.gz == gz &&
@@ -1062,16 +1266,27 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
             // full mesh, TSC, positions wrapped into the box by the list build (`wrap`): single-step cell wraps suffice
             const bool fastp_yz = !CIC && wrap && g.gy >= 8 && g.gz >= 8;
             const int fastp = !fastp_yz ? 0 : (g.gxg == g.gx && g.xoff == 0 && g.xoff2 < 0 && g.gx >= 8) ? 1 : (option("tsc_noslabfast") ? 0 : 2);
+            // unweighted clouds (every addend in [0, 1]): fixed-point integer tile sums, see acc_add.  S leaves room for n addends
+            int fxs = 40;
+            while (fxs > 8 && (double)std::max<int64_t>(n, 1) * std::ldexp(1.0, fxs) >= 0x1p62) fxs--;
+            const bool fixed = !weights && fxs >= 24 && !option("tsc_f64acc");
+            const double fxscale = fixed ? std::ldexp(1.0, fxs) : 0.0;
 #define LAUNCH_P(NTP, ACC, GRID, FASTP)                                                                               \
     ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit_p<TX, TY, TZ, CIC && FASTP == 0, NTP, ACC, FASTP>), dim3(GRID), dim3(NTP), 0, \
                   (const Entry<float> *)entries, (int64_t)nentries_total, (const int64_t *)tile_start, (int)ntiles,   \
-                  range_len, g, box, offset, grid, zero_grid, (float)norm, (float)sub, dbg)
-            if (dense && fastp == 1) LAUNCH_P(512, double, grid_p, 1);
-            else if (dense && fastp == 2) LAUNCH_P(512, double, grid_p, 2);
-            else if (dense) LAUNCH_P(512, double, grid_p, 0);
-            else if (fastp == 1) LAUNCH_P(256, double, grid_p, 1);
-            else if (fastp == 2) LAUNCH_P(256, double, grid_p, 2);
-            else LAUNCH_P(256, double, grid_p, 0);
+                  range_len, g, box, offset, grid, zero_grid, (float)norm, (float)sub, dbg, fxscale)
+#define LAUNCH_PA(NTP, GRID, FASTP)                                       \
+    do {                                                                  \
+        if (fixed) LAUNCH_P(NTP, unsigned long long, GRID, FASTP);        \
+        else LAUNCH_P(NTP, double, GRID, FASTP);                          \
+    } while (0)
+            if (dense && fastp == 1) LAUNCH_PA(512, grid_p, 1);
+            else if (dense && fastp == 2) LAUNCH_PA(512, grid_p, 2);
+            else if (dense) LAUNCH_PA(512, grid_p, 0);
+            else if (fastp == 1) LAUNCH_PA(256, grid_p, 1);
+            else if (fastp == 2) LAUNCH_PA(256, grid_p, 2);
+            else LAUNCH_PA(256, grid_p, 0);
+#undef LAUNCH_PA
 #undef LAUNCH_P
             return 0;
         }
@@ -1155,6 +1370,15 @@ int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int
 }
 int tsc_release_work() {
     g_lists.valid = false;
+    ABACUS_TRY(g_lw.M.release());
+    ABACUS_TRY(g_lw.tot.release());
+    ABACUS_TRY(g_lw.tables.release());
+    ABACUS_TRY(g_lw.staged.release());
+    ABACUS_TRY(g_lw.C.release());
+    ABACUS_TRY(g_lw.tile_start.release());
+    ABACUS_TRY(g_lw.tile_cnt.release());
+    ABACUS_TRY(g_lw.entries.release());
+    ABACUS_TRY(g_lw.flag.release());
     ABACUS_TRY(g_work.tile_count.release());
     ABACUS_TRY(g_work.tile_start.release());
     ABACUS_TRY(g_work.entries.release());

@@ -1,0 +1,706 @@
+// TSC particle -> mesh, second generation ("line" lists): included by tsc.hip inside its anonymous namespace.
+// Replaces, for unweighted float32 particles on a full periodic mesh, the two-level multisplit ms_coarse / ms_fine and
+// the 16-B-entry tile deposit (_tsc_scatter, abacusnbody/analysis/tsc.py:394-507; _wrap_inplace :219-226).
+//
+// What was wrong with the first generation (profiles/r03/pmc_traffic.json, scripts/ubench/scatter.hip ->
+// profiles/r04/ubench_scatter.txt): its scatter passes append 2 - 5 entries (32 - 80 B) to each of 1024 open lists per
+// sub-chunk, and MI355X writes pieces of a 128-B line at a quarter of the rate of whole aligned lines (scattered aligned
+// runs: 16 B 0.42, 32 B 1.03, 64 B 3.35, 128 B 5.2 TB/s; a line written as two 64-B halves by consecutive stores of the
+// same lanes: 3.4 - the L2 does not merge them).  So here EVERY store of a list-building pass is a whole aligned line:
+//   lines_count    one pass over the particles: wrap in place, entries per (chunk of particles, coarse bucket) and the
+//                  tile entries each coarse bucket will hold; a coarse bucket is a BLOCK of 8 x 8 x 8 (16 x 8 x 8) tiles;
+//   lines_colscan  exclusive scan over the chunks: a chunk's run inside every bucket (exact, deterministic offsets);
+//   lines_coarse   chunk by chunk: the ONLY pass that evaluates the cloud geometry in floating point.  Per particle and
+//                  touched tile (1.25 on average) it stages the final 8-byte entry + the tile's index inside its bucket
+//                  (16 B), grouped by bucket.  A workgroup keeps the tail of every bucket's run that does not fill a line
+//                  yet in LDS (`carry`) and stores only whole lines - see split_round;
+//   lines_fcount / lines_fscan / lines_fine   inside a bucket, piece by piece of its staged entries: a plain split by
+//                  the staged tile key into the tile lists (8-byte entries, lists starting on line boundaries);
+//   lines_deposit  tile deposit from the packed entries, integer (fixed-point) LDS sums (acc_add).
+// An entry is tile-relative: per dimension the nearest cell's index inside the tile (biased by one: a cloud reaches one
+// cell over the tile's faces) and d = cell - p as a 16-bit fixed-point number.  p = (x + offset) * (n / L) is evaluated in
+// float32 exactly as the reference does; d is a multiple of ulp(p), i.e. of 2^-16 or coarser wherever p >= 128 cells, so
+// the 16-bit code is EXACT there and the cloud weights are the reference's float32 weights bit for bit; in the first 128
+// cells of a dimension d is rounded to 2^-16 of a cell (7.6e-6 of a cell at most: the reference's own tolerance on the
+// mesh is rtol 1e-4, tests/test_tsc.py:136).  d = +1/2 (p exactly between two cells, round-half-even picked the upper)
+// is stored as the lower cell with d = -1/2: the same three weights (1/2, 1/2, 0) on the same cells.
+//
+// (PMC, profiles/r04: these passes are bound by vector-instruction issue, not by HBM - a first form that staged raw
+// positions per bucket and enumerated a cloud's tiles again in the fine passes spent 537 vector instructions per staged
+// entry there.)
+// HBM traffic per particle: 12 B read twice, 16 B x 1.25 staged (write + 2 reads), 8 B x 1.25 entries (write + read)
+// = 104 B against 154 B of the first generation, all of it in whole lines.
+
+constexpr int LN_SHX = 4, LN_SHY = 4, LN_SHZ = 5;          // tile = 16 x 16 x 32 cells
+constexpr int LN_TX = 16, LN_TY = 16, LN_TZ = 32;
+constexpr int LN_ZP = LN_TZ + 4;                           // LDS row: two halo cells either side (no range tests along z)
+constexpr unsigned long long LN_INVALID = ~0ull;
+
+struct LGeom {
+    int n[3];        // mesh cells
+    int nt[3];       // tiles per dimension
+    int sb[3];       // log2 of the block shape (tiles)
+    int nb[3];       // blocks per dimension
+    int nbuckets;    // blocks = coarse buckets
+    int tpb;         // tiles per block
+    int64_t zstride;
+};
+
+// canonical nearest cell and fixed-point offset of one coordinate (see the header comment).  i in [-3, n + 2]
+__device__ __forceinline__ void ln_cell(float x, float offset, float ih, int n, int &i, int &m) {
+    const float p = (x + offset) * ih;                       // tsc.py:419-421, float32
+    float r = rintf(p);                                      // round half even, like np.round / llvm.rint
+    r = fminf(fmaxf(r, -2.f), (float)(n + 2));               // garbage positions (NaN, inf) stay inside the tables
+    const float d = r - p;                                   // exact for every finite p the clamp left alone
+    const float mf = fminf(fmaxf(rintf(d * 65536.f), -32768.f), 32768.f);
+    i = (int)r;
+    m = (int)mf;
+    if (m == 32768) i -= 1, m = -32768;
+}
+// the same cell without the code (the list-membership passes): m == 32768 <=> d * 65536 >= 32767.5 (ties go to the even 32768)
+__device__ __forceinline__ int ln_cell_i(float x, float offset, float ih, int n) {
+    const float p = (x + offset) * ih;
+    float r = rintf(p);
+    r = fminf(fmaxf(r, -2.f), (float)(n + 2));
+    const float d = r - p;
+    return (int)r - (d >= 0.49999237060546875f ? 1 : 0);
+}
+__device__ __forceinline__ int ln_wrap(int c, int n) { return c < 0 ? c + n : (c >= n ? c - n : c); }
+
+// the one or two tiles a dimension's cell range [lo, hi] (at most five cells) touches
+__device__ __forceinline__ void ln_tiles(int lo, int hi, int n, int sh, int &ta, int &tb) {
+    ta = ln_wrap(lo, n) >> sh;
+    tb = ln_wrap(hi, n) >> sh;
+}
+
+struct LnRange {
+    int ta[3], tb[3];    // tiles of the low / high end per dimension
+};
+// cell range of a particle's cloud(s): offset A alone, or (EXT) the union of the clouds at offsets A and B
+template <bool EXT>
+__device__ __forceinline__ LnRange ln_range(float x, float y, float z, const LGeom &g, float offA, float offB, float ihx, float ihy,
+                                            float ihz) {
+    LnRange r;
+    const float c[3] = {x, y, z}, ih[3] = {ihx, ihy, ihz};
+    const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int i = ln_cell_i(c[a], offA, ih[a], g.n[a]);
+        int lo = i - 1, hi = i + 1;
+        if (EXT) {
+            const int j = ln_cell_i(c[a], offB, ih[a], g.n[a]);
+            lo = min(lo, j - 1), hi = max(hi, j + 1);
+        }
+        ln_tiles(lo, hi, g.n[a], sh[a], r.ta[a], r.tb[a]);
+    }
+    return r;
+}
+
+// f(bucket, tiles of the cloud inside that bucket) for every coarse bucket the range touches (1, 2, 4 or 8)
+template <typename F>
+__device__ __forceinline__ void ln_for_buckets(const LnRange &r, const LGeom &g, F f) {
+    int ba[3], bb[3], nper = 1;
+    bool two[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        ba[a] = r.ta[a] >> g.sb[a], bb[a] = r.tb[a] >> g.sb[a];
+        two[a] = ba[a] != bb[a];
+        nper *= (!two[a] && r.ta[a] != r.tb[a]) ? 2 : 1;
+    }
+    const int x0 = ba[0] * g.nb[1], x1 = bb[0] * g.nb[1];
+    f((x0 + ba[1]) * g.nb[2] + ba[2], nper);
+    if (two[2]) f((x0 + ba[1]) * g.nb[2] + bb[2], nper);
+    if (two[1]) {
+        f((x0 + bb[1]) * g.nb[2] + ba[2], nper);
+        if (two[2]) f((x0 + bb[1]) * g.nb[2] + bb[2], nper);
+    }
+    if (two[0]) {
+        f((x1 + ba[1]) * g.nb[2] + ba[2], nper);
+        if (two[2]) f((x1 + ba[1]) * g.nb[2] + bb[2], nper);
+        if (two[1]) {
+            f((x1 + bb[1]) * g.nb[2] + ba[2], nper);
+            if (two[2]) f((x1 + bb[1]) * g.nb[2] + bb[2], nper);
+        }
+    }
+}
+
+struct LnF3 {
+    float x, y, z;   // 4-byte aligned: one global_load_dwordx3 per particle
+};
+
+// ---- counting pass ---------------------------------------------------------------------------------------------
+// chunk c = particles [c CH, (c + 1) CH): M[c][b] = staged entries ((particle, tile) pairs) of the chunk in bucket b
+template <int NB>
+__global__ __launch_bounds__(512) void lines_count(float *__restrict__ pos, int64_t n, LGeom g, double box, float offA, int wrap,
+                                                   int64_t CH, unsigned int *__restrict__ M, int *__restrict__ wrapped_flag) {
+    __shared__ unsigned int hist[NB];
+    const int tid = threadIdx.x;
+    for (int b = tid; b < NB; b += 512) hist[b] = 0u;
+    __syncthreads();
+    const float ihx = (float)(g.n[0] / box), ihy = (float)(g.n[1] / box), ihz = (float)(g.n[2] / box);
+    const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
+    bool any_changed = false;
+    for (int64_t p = p0 + tid; p < p1; p += 512) {
+        LnF3 q = *reinterpret_cast<const LnF3 *>(pos + 3 * p);
+        if (wrap) {
+            bool ch = false;
+            q.x = wrap1(q.x, box, ch), q.y = wrap1(q.y, box, ch), q.z = wrap1(q.z, box, ch);
+            if (ch) {
+                *reinterpret_cast<LnF3 *>(pos + 3 * p) = q;
+                any_changed = true;
+            }
+        }
+        const LnRange r = ln_range<false>(q.x, q.y, q.z, g, offA, offA, ihx, ihy, ihz);
+        ln_for_buckets(r, g, [&](int b, int ntile) { atomicAdd(&hist[b], (unsigned int)ntile); });
+    }
+    if (any_changed) *wrapped_flag = 1;
+    __syncthreads();
+    for (int b = tid; b < g.nbuckets; b += 512) M[(int64_t)blockIdx.x * g.nbuckets + b] = hist[b];
+}
+
+// column b of M: exclusive scan over the chunks (in place) and the bucket's total.  One workgroup per bucket
+__global__ __launch_bounds__(1024) void lines_colscan(unsigned int *__restrict__ M, int nchunk, int nbuckets,
+                                                      unsigned int *__restrict__ tot) {
+    __shared__ unsigned int wave_tot[16];
+    const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, wv = c >> 6;
+    const unsigned int v = c < nchunk ? M[(int64_t)c * nbuckets + b] : 0u;
+    unsigned int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    unsigned int before = 0;
+    for (int w = 0; w < wv; w++) before += wave_tot[w];
+    if (c < nchunk) M[(int64_t)c * nbuckets + b] = before + incl - v;
+    if (c == 1023) tot[b] = before + incl;
+}
+
+// ---- the streaming split: whole lines out, tails carried in LDS -------------------------------------------------
+// A workgroup streams its items in rounds.  Per round: count the new entries per bucket (LDS atomics); per bucket, with
+// cc entries carried from earlier rounds and its run position `done`, find how many entries can leave as WHOLE lines
+// (wlim: up to the last line boundary; everything in the final round); scan wlim -> slots of the round's output; copy the
+// carried entries that leave to their slots, place the new ones at slot or carry; store the output with adjacent lanes on
+// adjacent entries of a run - every store instruction covers whole, aligned lines of every bucket it touches.
+// exclusive scan of in[0, NB) -> out[] by the NT threads of the workgroup (ITEMS consecutive values per thread)
+template <int NB, int NT>
+__device__ __forceinline__ unsigned int ln_block_scan(const unsigned int *in, unsigned int *out, unsigned int *wave_tot) {
+    constexpr int ITEMS = (NB + NT - 1) / NT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned int v[ITEMS], sum = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const int idx = tid * ITEMS + q;
+        v[q] = idx < NB ? in[idx] : 0u;
+        sum += v[q];
+    }
+    unsigned int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    unsigned int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) {
+        const unsigned int t = wave_tot[w];
+        if (w < wv) before += t;
+        total += t;
+    }
+    unsigned int run = before + incl - sum;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const int idx = tid * ITEMS + q;
+        if (idx < NB) out[idx] = run;
+        run += v[q];
+    }
+    return total;
+}
+
+template <typename E, int NB, int LINE, int SBUF, int NT>
+struct SplitLds {
+    static constexpr int ITEMS = (NB + NT - 1) / NT;   // buckets owned by a thread: tid * ITEMS + q
+    E out[SBUF];
+    E carry[NB * (LINE - 1)];
+    unsigned short obid[SBUF];
+    unsigned int lcnt[2][NB];       // new entries per bucket, by round parity
+    unsigned int lcur[NB];          // placement cursors of the round
+    unsigned int ccnt[NB], done[NB], base[NB];
+    unsigned int obase[NB];         // global index of out[o] = obase[bucket] + o
+    unsigned int pa[NB], cb[NB];    // placement: rank k of a bucket's new entries goes to out[pa + k] while k < wd, else carry[cb + k]
+    int wd[NB];
+    unsigned int wave_tot[2][NT / 64];
+};
+
+// One round.  `count(f)`: f(bucket) for every entry of the calling thread's items; `place(f)`: f(bucket, entry) for the same
+// entries (the items sit in registers).  Buckets [last_lo, last_hi) send out everything they hold (the drain after the last
+// item).  Returns false - state untouched - when the round's output does not fit SBUF: the caller retries with fewer items.
+// Four workgroup barriers; the stores of a round are not waited for: they overlap the loads and the counting of the next.
+template <typename E, int NB, int LINE, int SBUF, int NT, typename COUNT, typename PLACE>
+__device__ __forceinline__ bool split_round(SplitLds<E, NB, LINE, SBUF, NT> &s, int nb, int par, int last_lo, int last_hi,
+                                            E *__restrict__ dst, COUNT count, PLACE place, int dbg = 0) {
+    constexpr int ITEMS = SplitLds<E, NB, LINE, SBUF, NT>::ITEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    count([&](int b) { atomicAdd(&s.lcnt[par][b], 1u); });
+    __syncthreads();
+    // owner step: how many entries of each owned bucket leave as whole lines
+    unsigned int w[ITEMS], cc[ITEMS], lc[ITEMS], sum = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const int b = tid * ITEMS + q;
+        w[q] = 0u, cc[q] = 0u, lc[q] = 0u;
+        if (b < nb) {
+            cc[q] = s.ccnt[b], lc[q] = s.lcnt[par][b];
+            const unsigned int avail = cc[q] + lc[q], pos0 = s.base[b] + s.done[b];
+            if (b >= last_lo && b < last_hi) w[q] = avail;
+            else {
+                const unsigned int end = (pos0 + avail) & ~(unsigned int)(LINE - 1);
+                w[q] = end > pos0 ? end - pos0 : 0u;
+            }
+        }
+        sum += w[q];
+    }
+    unsigned int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) s.wave_tot[par][wv] = incl;
+    __syncthreads();
+    unsigned int before = 0, ot = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; k++) {
+        const unsigned int t = s.wave_tot[par][k];
+        if (k < wv) before += t;
+        ot += t;
+    }
+    if (ot > (unsigned int)SBUF) {
+#pragma unroll
+        for (int q = 0; q < ITEMS; q++)
+            if (tid * ITEMS + q < NB) s.lcnt[par][tid * ITEMS + q] = 0u;
+        __syncthreads();
+        return false;
+    }
+    unsigned int run = before + incl - sum;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const int b = tid * ITEMS + q;
+        if (b < NB) {
+            s.lcur[b] = 0u;
+            s.lcnt[par ^ 1][b] = 0u;
+        }
+        if (b < nb) {
+            const unsigned int pos0 = s.base[b] + s.done[b];
+            s.obase[b] = pos0 - run;
+            s.pa[b] = run + cc[q];
+            s.wd[b] = (int)w[q] - (int)cc[q];
+            s.cb[b] = (unsigned int)(b * (LINE - 1)) + cc[q] - w[q];   // w > 0 implies w > cc: a carry never reaches a line boundary
+            s.ccnt[b] = cc[q] + lc[q] - w[q];
+            s.done[b] += w[q];
+            if (w[q] > 0u)                                             // the carried entries leave first
+                for (unsigned int j = 0; j < cc[q]; j++) {
+                    s.out[run + j] = s.carry[b * (LINE - 1) + j];
+                    s.obid[run + j] = (unsigned short)b;
+                }
+        }
+        run += w[q];
+    }
+    __syncthreads();
+    if (!(dbg & 32))
+    place([&](int b, const E &e) {
+        const unsigned int k = atomicAdd(&s.lcur[b], 1u);
+        if ((int)k < s.wd[b]) {
+            const unsigned int o = s.pa[b] + k;
+            s.out[o] = e;
+            s.obid[o] = (unsigned short)b;
+        } else {
+            s.carry[s.cb[b] + k] = e;
+        }
+    });
+    __syncthreads();
+    if (!(dbg & 16))
+        for (unsigned int o = tid; o < ot; o += NT) dst[(size_t)(unsigned int)(s.obase[s.obid[o]] + o)] = s.out[o];
+    return true;
+}
+
+template <typename E, int NB, int LINE, int SBUF, int NT>
+__device__ __forceinline__ void split_init(SplitLds<E, NB, LINE, SBUF, NT> &s) {
+    for (int b = threadIdx.x; b < NB; b += NT) s.ccnt[b] = 0u, s.done[b] = 0u, s.lcnt[0][b] = 0u, s.lcnt[1][b] = 0u, s.lcur[b] = 0u;
+}
+
+// after the last item: every carry leaves, slice by slice of buckets so that the output fits the buffer whatever they hold
+template <typename E, int NB, int LINE, int SBUF, int NT>
+__device__ __forceinline__ void split_drain(SplitLds<E, NB, LINE, SBUF, NT> &s, int nb, int &par, E *__restrict__ dst) {
+    constexpr int SL = SBUF / (LINE - 1);
+    for (int lo = 0; lo < nb; lo += SL, par ^= 1)
+        split_round<E, NB, LINE, SBUF, NT>(s, nb, par, lo, min(lo + SL, nb), dst, [](auto) {}, [](auto) {});
+}
+
+// ---- coarse scatter --------------------------------------------------------------------------------------------
+// The tiles of a particle's cloud: per dimension the tile of its lowest cell and, when the cloud reaches over that tile's
+// upper face, the next one (periodic) - 1, 2, 4 or 8 tiles.  The geometry is evaluated ONCE per particle into seven registers:
+//   b0, kl0      bucket, tile key (bits 0..15) and index code (bits 16..31) of the emission that takes the first tile everywhere;
+//   dlt[d]       what taking the second tile of dimension d adds: to the bucket (high half, signed) and to the key (low half,
+//                signed); the index code always loses T << shift;
+//   h            bit d: dimension d has a second tile; bit 31: no item;
+//   frac         the three 16-bit codes of the in-cell offsets.
+// Emission e adds the deltas of the dimensions its bits select: a few multiply-adds instead of a walk over tile coordinates.
+struct LnItem {
+    int b0;
+    unsigned int kl0, h;
+    int dlt[3];
+    unsigned long long frac;
+};
+__device__ __forceinline__ void ln_item(float x, float y, float z, float offset, float ihx, float ihy, float ihz, const LGeom &g, LnItem &it) {
+    const float c[3] = {x, y, z}, ih[3] = {ihx, ihy, ihz};
+    const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ}, T[3] = {LN_TX, LN_TY, LN_TZ};
+    const int sbk[3] = {g.sb[1] + g.sb[2], g.sb[2], 0};          // key shifts
+    const int sbb[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};           // bucket strides
+    it.b0 = 0, it.kl0 = 0u, it.h = 0u, it.frac = 0ull;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        int i, m;
+        ln_cell(c[a], offset, ih[a], g.n[a], i, m);
+        it.frac |= (unsigned long long)(unsigned int)(m + 32768) << (16 + 16 * a);
+        const int ta = min(ln_wrap(i - 1, g.n[a]) >> sh[a], g.nt[a] - 1), tb0 = ln_wrap(i + 1, g.n[a]) >> sh[a];
+        int l = i - (ta << sh[a]) + 1;                           // nearest cell relative to the first tile, biased by one
+        if (l > g.n[a] / 2) l -= g.n[a];
+        else if (l < -(g.n[a] / 2)) l += g.n[a];
+        const int h = tb0 != ta ? 1 : 0;
+        l = min(max(l, h ? T[a] : 0), T[a] + 1);                 // (garbage positions: the second tile's index stays >= 0)
+        int tb = ta + 1;
+        if (tb == g.nt[a]) tb = 0;
+        const int msk = (1 << g.sb[a]) - 1;
+        const int ba = (ta >> g.sb[a]) * sbb[a], bb = (tb >> g.sb[a]) * sbb[a];
+        const int ka = (ta & msk) << sbk[a], kb = (tb & msk) << sbk[a];
+        it.b0 += ba;
+        it.kl0 += (unsigned int)ka | ((unsigned int)l << (16 + 5 * a));
+        it.dlt[a] = ((bb - ba) << 16) | ((kb - ka) & 0xffff);
+        it.h |= (unsigned int)h << a;
+    }
+}
+// emission e of an item: bucket, and (key | index code << 16)
+__device__ __forceinline__ void ln_emit(const LnItem &it, int e, int &bucket, unsigned int &kl) {
+    int k = e, db = 0, dk = 0;
+    unsigned int dl = 0u;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int T[3] = {LN_TX, LN_TY, LN_TZ};
+        const int h = (it.h >> a) & 1, sel = h & k;
+        k >>= h;
+        db += sel * (it.dlt[a] >> 16);
+        dk += sel * (int)(short)(it.dlt[a] & 0xffff);
+        dl += (unsigned int)sel * ((unsigned int)T[a] << (16 + 5 * a));
+    }
+    bucket = it.b0 + db;
+    kl = it.kl0 + (unsigned int)dk - dl;
+}
+
+template <int NB, int LINE, int SBUF, int NT>
+__global__ __launch_bounds__(NT) void lines_coarse(const float *__restrict__ pos, int64_t n, LGeom g, double box, float offA,
+                                                   int64_t CH, const unsigned int *__restrict__ M,
+                                                   const unsigned int *__restrict__ gstart, uint4 *__restrict__ staged) {
+    __shared__ SplitLds<uint4, NB, LINE, SBUF, NT> s;
+    const int tid = threadIdx.x, nb = g.nbuckets;
+    split_init(s);
+    for (int b = tid; b < NB; b += NT) s.base[b] = b < nb ? gstart[b] + M[(int64_t)blockIdx.x * nb + b] : 0u;
+    __syncthreads();
+    const float ihx = (float)(g.n[0] / box), ihy = (float)(g.n[1] / box), ihz = (float)(g.n[2] / box);
+    const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
+    // items per round: in the steady state a round's output is about its input (1.25 entries per particle); a round whose
+    // output does not fit (clouds piled up on tile corners, every carry leaving at once) is retried with half the items
+    constexpr int PMAX = SBUF * 5 / 8 / NT * NT;
+    constexpr int PPT = PMAX / NT;
+    static_assert(PPT >= 1 && SBUF >= 8 * LINE + 64, "buffer too small");
+    int ptry = PMAX, par = 0;
+    int64_t s0 = p0;
+    while (s0 < p1) {
+        const int np = (int)min((int64_t)ptry, p1 - s0);
+        LnF3 q[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const int idx = k * NT + tid;
+            if (idx < np) q[k] = *reinterpret_cast<const LnF3 *>(pos + 3 * (s0 + idx));
+        }
+        LnItem it[PPT];
+        const bool ok = split_round<uint4, NB, LINE, SBUF, NT>(
+            s, nb, par, 0, 0, staged,
+            [&](auto f) {
+#pragma unroll
+                for (int k = 0; k < PPT; k++) {
+                    int cnt = 0;
+                    if (k * NT + tid < np) {
+                        ln_item(q[k].x, q[k].y, q[k].z, offA, ihx, ihy, ihz, g, it[k]);
+                        cnt = 1 << __popc(it[k].h);
+                    } else {
+                        it[k].h = 0x80000000u;
+                    }
+                    for (int e = 0; e < cnt; e++) {
+                        int b;
+                        unsigned int kl;
+                        ln_emit(it[k], e, b, kl);
+                        f(b);
+                    }
+                }
+            },
+            [&](auto f) {
+#pragma unroll
+                for (int k = 0; k < PPT; k++) {
+                    const int cnt = (it[k].h >> 31) ? 0 : 1 << __popc(it[k].h);
+                    for (int e = 0; e < cnt; e++) {
+                        int b;
+                        unsigned int kl;
+                        ln_emit(it[k], e, b, kl);
+                        f(b, make_uint4((unsigned int)it[k].frac | (kl >> 16), (unsigned int)(it[k].frac >> 32), kl & 0xffffu, 0u));
+                    }
+                }
+            });
+        if (ok) s0 += np, par ^= 1;
+        else ptry = max(ptry / 2, 1);   // a pile-up of clouds on tile corners: up to eight entries per particle
+    }
+    split_drain<uint4, NB, LINE, SBUF, NT>(s, nb, par, staged);
+}
+
+// ---- fine level ------------------------------------------------------------------------------------------------
+struct LnPiece {
+    int bucket;
+    unsigned int e0, e1;   // staged entries of the piece
+    int first;             // 1: first piece of its bucket
+};
+
+__device__ __forceinline__ void ln_bucket_coords(int b, const LGeom &g, int &B0, int &B1, int &B2) {
+    B2 = b % g.nb[2];
+    B1 = (b / g.nb[2]) % g.nb[1];
+    B0 = b / (g.nb[2] * g.nb[1]);
+}
+
+// entries per (piece, tile of its bucket): a histogram of the staged tile keys
+template <int NBF>
+__global__ __launch_bounds__(512) void lines_fcount(const uint4 *__restrict__ staged, const LnPiece *__restrict__ pieces, int tpb,
+                                                    unsigned int *__restrict__ C) {
+    __shared__ unsigned int hist[NBF];
+    const int tid = threadIdx.x;
+    const LnPiece pc = pieces[blockIdx.x];
+    for (int f = tid; f < NBF; f += 512) hist[f] = 0u;
+    __syncthreads();
+    for (unsigned int e = pc.e0 + tid; e < pc.e1; e += 512) atomicAdd(&hist[min(staged[e].z, (unsigned int)(NBF - 1))], 1u);
+    __syncthreads();
+    for (int f = tid; f < tpb; f += 512) C[(int64_t)blockIdx.x * tpb + f] = hist[f];
+}
+
+// one workgroup per bucket: C[piece][tile] -> the piece's offset inside the tile's list, list starts on line boundaries
+// (16 entries), tile_start / tile_cnt of the bucket's tiles.  fstart[b]: first entry slot of the bucket (a multiple of 16)
+template <int NBF>
+__global__ __launch_bounds__(NBF) void lines_fscan(unsigned int *__restrict__ C, const int *__restrict__ piece_first, LGeom g,
+                                                   const unsigned int *__restrict__ fstart, unsigned int *__restrict__ tile_start,
+                                                   unsigned int *__restrict__ tile_cnt) {
+    __shared__ unsigned int padded[NBF], start[NBF], wave_tot[NBF / 64];
+    const int b = blockIdx.x, f = threadIdx.x;
+    const int pa = piece_first[b], pb = piece_first[b + 1];
+    unsigned int run = 0;
+    if (f < g.tpb)
+        for (int p = pa; p < pb; p++) {
+            const unsigned int c = C[(int64_t)p * g.tpb + f];
+            C[(int64_t)p * g.tpb + f] = run;
+            run += c;
+        }
+    padded[f] = f < g.tpb ? (run + 15u) & ~15u : 0u;
+    __syncthreads();
+    ln_block_scan<NBF, NBF>(padded, start, wave_tot);
+    __syncthreads();
+    if (f < g.tpb) {
+        const unsigned int st = fstart[b] + start[f];
+        tile_start[(int64_t)b * g.tpb + f] = st;
+        tile_cnt[(int64_t)b * g.tpb + f] = run;
+        for (int p = pa; p < pb; p++) C[(int64_t)p * g.tpb + f] += st;
+    }
+}
+
+template <int NBF, int LINE, int SBUF, int NT>
+__global__ __launch_bounds__(NT) void lines_fine(const uint4 *__restrict__ staged, const LnPiece *__restrict__ pieces, int tpb,
+                                                 const unsigned int *__restrict__ C, unsigned long long *__restrict__ entries) {
+    __shared__ SplitLds<unsigned long long, NBF, LINE, SBUF, NT> s;
+    const int tid = threadIdx.x, nb = tpb;
+    const LnPiece pc = pieces[blockIdx.x];
+    split_init(s);
+    for (int f = tid; f < NBF; f += NT) s.base[f] = f < nb ? C[(int64_t)blockIdx.x * nb + f] : 0u;
+    __syncthreads();
+    constexpr int PMAX = (SBUF - SBUF / 8) / NT * NT;     // one entry out per entry in
+    constexpr int PPT = PMAX / NT;
+    static_assert(PPT >= 1 && SBUF >= 8 * LINE + 64, "buffer too small");
+    int ptry = PMAX, par = 0;
+    unsigned int s0 = pc.e0;
+    while (s0 < pc.e1) {
+        const int np = (int)min((unsigned int)ptry, pc.e1 - s0);
+        uint4 q[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const int idx = k * NT + tid;
+            if (idx < np) q[k] = staged[s0 + idx];
+        }
+        const bool ok = split_round<unsigned long long, NBF, LINE, SBUF, NT>(
+            s, nb, par, 0, 0, entries,
+            [&](auto f) {
+#pragma unroll
+                for (int k = 0; k < PPT; k++)
+                    if (k * NT + tid < np) f((int)min(q[k].z, (unsigned int)(NBF - 1)));
+            },
+            [&](auto f) {
+#pragma unroll
+                for (int k = 0; k < PPT; k++)
+                    if (k * NT + tid < np) f((int)min(q[k].z, (unsigned int)(NBF - 1)), ((unsigned long long)q[k].y << 32) | q[k].x);
+            });
+        if (ok) s0 += np, par ^= 1;
+        else ptry = max(ptry / 2, 1);
+    }
+    split_drain<unsigned long long, NBF, LINE, SBUF, NT>(s, nb, par, entries);
+}
+
+// ---- tile deposit from packed entries ----------------------------------------------------------------------------
+// The skeleton is tsc_tile_deposit_p's (persistent workgroups over ranges of consecutive tiles - consecutive in the BLOCKED
+// order of the lists -, entries of tile t + 2 requested before tile t is flushed, the flush re-zeroes the tile); new:
+// the entry decode (no float multiply, no rint, no periodic wrap: the list build resolved them), z rows with a halo of two
+// cells either side so that no z index is ever tested, x / y cells outside the tile dropped by predication, integer sums.
+constexpr int LD_RANGE = 512;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void lines_deposit(const unsigned long long *__restrict__ entries, int64_t capacity,
+                                                    const unsigned int *__restrict__ tile_start,
+                                                    const unsigned int *__restrict__ tile_cnt, int ntiles, int range_len, LGeom g,
+                                                    float *__restrict__ grid, int zero_grid, float norm, float sub, double fxscale,
+                                                    int dbg) {
+    constexpr int NPRE = 2;                                   // prefetched 16-B loads (two entries each) per thread
+    constexpr int FL = LN_TX * LN_TY * (LN_TZ / 4) / NT;      // flush stores (16 B) per thread
+    static_assert((LN_TX * LN_TY * (LN_TZ / 4)) % NT == 0 && 2 * FL + NPRE <= 60, "whole flush stores per thread");
+    __shared__ __align__(16) unsigned long long tile[LN_TX * LN_TY * LN_ZP];
+    __shared__ unsigned int bst[LD_RANGE + 2], bcn[LD_RANGE + 2];
+    const int tid = threadIdx.x;
+    {
+        float4 *t4 = reinterpret_cast<float4 *>(tile);
+        for (int q = tid; q < (int)(sizeof(tile) / 16); q += NT) t4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const double fxinv = 1.0 / fxscale;
+    const int64_t lastpair = capacity >= 2 ? capacity / 2 - 1 : 0;   // 16-B units that may be read
+    const int nranges = (ntiles + range_len - 1) / range_len;
+    const int lgtpb = __ffs(g.tpb) - 1;
+    for (int r = blockIdx.x; r < nranges; r += gridDim.x) {
+        const int t0 = r * range_len, nt = min(range_len, ntiles - t0);
+        __syncthreads();
+        for (int q = tid; q < nt; q += NT) bst[q] = tile_start[t0 + q], bcn[q] = tile_cnt[t0 + q];
+        __syncthreads();
+        tsc_v4f X[NPRE], Y[NPRE];
+        auto issue = [&](tsc_v4f(&set)[NPRE], int tt) {       // list starts are multiples of 16 entries: aligned 16-B loads
+            const int64_t u0 = (int64_t)(bst[tt] >> 1);
+#pragma unroll
+            for (int q = 0; q < NPRE; q++)
+                tsc_gload16_async(set[q], reinterpret_cast<const float4 *>(entries) + min(u0 + q * NT + tid, lastpair));
+        };
+        auto one = [&](unsigned long long e) {
+            const unsigned int lo = (unsigned int)e, hi = (unsigned int)(e >> 32);
+            const int lx = lo & 31, ly = (lo >> 5) & 31, lz = min((int)((lo >> 10) & 63), LN_TZ + 1);   // (clamped: an entry never indexes outside the tile's rows)
+            const float dx = ((float)(lo >> 16) - 32768.f) * (1.f / 65536.f), dy = ((float)(hi & 0xffffu) - 32768.f) * (1.f / 65536.f),
+                        dz = ((float)(hi >> 16) - 32768.f) * (1.f / 65536.f);
+            float wx[3], wy[3], wz[3];
+            const float d3[3] = {dx, dy, dz};
+            float *w3[3] = {wx, wy, wz};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {                    // _tsc_scatter's weights (tsc.py:428-451), float32, no contraction
+                const float d = d3[a], tm = 0.5f + d, tp = 0.5f - d;
+                w3[a][1] = 0.75f - d * d;
+                w3[a][0] = 0.5f * (tm * tm);
+                w3[a][2] = 0.5f * (tp * tp);
+            }
+            // cells lx - 2 .. lx (the nearest cell is lx - 1); z rows carry the halo: row index lz - 2 + 2 = lz .. lz + 2
+            unsigned long long *zrow = tile + lz;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const int cx = lx - 2 + a;
+                if ((unsigned)cx >= (unsigned)LN_TX) continue;
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const int cy = ly - 2 + b;
+                    if ((unsigned)cy >= (unsigned)LN_TY) continue;
+                    const float wxy = wx[a] * wy[b];
+                    unsigned long long *cell = zrow + (cx * LN_TY + cy) * LN_ZP;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) acc_add<unsigned long long>(cell + c, wxy * wz[c], fxscale);   // (wx wy) wz, tsc.py:471-507
+                }
+            }
+        };
+        bool prev_plain = false;
+        auto process = [&](tsc_v4f(&cur)[NPRE], int tt) {
+            const int tile_id = t0 + tt;
+            const int b = tile_id >> lgtpb, f = tile_id & (g.tpb - 1);
+            int B0, B1, B2;
+            ln_bucket_coords(b, g, B0, B1, B2);
+            const int fz = f & ((1 << g.sb[2]) - 1), fy = (f >> g.sb[2]) & ((1 << g.sb[1]) - 1), fx = f >> (g.sb[2] + g.sb[1]);
+            const int ox = ((B0 << g.sb[0]) + fx) << LN_SHX, oy = ((B1 << g.sb[1]) + fy) << LN_SHY, oz = ((B2 << g.sb[2]) + fz) << LN_SHZ;
+            const unsigned int cnt = bcn[tt];
+            const int64_t e0 = bst[tt];
+#pragma unroll
+            for (int q = 0; q < NPRE; q++) tsc_touch(cur[q]);
+#pragma unroll
+            for (int q = 0; q < NPRE; q++) {
+                const unsigned int k = 2u * (q * NT + tid);
+                if (!(dbg & 1)) {
+                    if (k < cnt) one(((unsigned long long)__float_as_uint(cur[q].y) << 32) | __float_as_uint(cur[q].x));
+                    if (k + 1 < cnt) one(((unsigned long long)__float_as_uint(cur[q].w) << 32) | __float_as_uint(cur[q].z));
+                }
+            }
+            for (unsigned int k = 2u * NPRE * NT + tid; k < cnt; k += NT) one(entries[e0 + k]);
+            const bool extra = cnt > 2u * NPRE * NT;
+            __syncthreads();
+            const bool more = tt + 2 < nt;
+            if (more) issue(cur, tt + 2);
+            {
+                constexpr int ZQ = LN_TZ / 4, ROWS = NT / ZQ;
+                static_assert(NT % ZQ == 0 && ROWS % LN_TY == 0 && (LN_TX * LN_TY) % ROWS == 0, "flush mapping");
+                constexpr int XSTEP = ROWS / LN_TY, STEPS = LN_TX / XSTEP;
+                const int zq = tid & (ZQ - 1), yy = (tid / ZQ) & (LN_TY - 1), x0 = tid / (ZQ * LN_TY);
+                unsigned long long *cell = &tile[(x0 * LN_TY + yy) * LN_ZP + 2 + 4 * zq];
+                float *dst = grid + ((int64_t)(ox + x0) * g.n[1] + (oy + yy)) * g.zstride + oz + 4 * zq;
+                const int64_t dstep = (int64_t)XSTEP * g.n[1] * g.zstride;
+#pragma unroll
+                for (int st = 0; st < STEPS; st++, cell += XSTEP * LN_TY * LN_ZP, dst += dstep) {
+                    ulonglong2 *c2 = reinterpret_cast<ulonglong2 *>(cell);
+                    const ulonglong2 a01 = c2[0], a23 = c2[1];
+                    c2[0] = make_ulonglong2(0ull, 0ull);
+                    c2[1] = make_ulonglong2(0ull, 0ull);
+                    if (zq == 0) c2[-1] = make_ulonglong2(0ull, 0ull);          // the row's halo cells
+                    if (zq == ZQ - 1) c2[2] = make_ulonglong2(0ull, 0ull);
+                    double a[4] = {(double)a01.x * fxinv, (double)a01.y * fxinv, (double)a23.x * fxinv, (double)a23.y * fxinv};
+                    if (!zero_grid) {
+                        const float4 old = *reinterpret_cast<const float4 *>(dst);
+                        a[0] += (double)old.x, a[1] += (double)old.y, a[2] += (double)old.z, a[3] += (double)old.w;
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) v[c] = (float)a[c];
+                    if (norm != 0.f) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) v[c] = v[c] * norm - sub;
+                    }
+                    if (!(dbg & 2)) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __syncthreads();
+            // see tsc_tile_deposit_p: [FL stores of tile tt-1] [NPRE loads of tile tt+2] [FL stores of this tile]
+            const bool plain = zero_grid && !extra && !(dbg & 2);
+            if (plain && prev_plain && more) tsc_wait_vmcnt<2 * FL + NPRE>();
+            else tsc_wait_vmcnt<0>();
+            prev_plain = plain;
+        };
+        issue(X, 0);
+        if (nt > 1) issue(Y, 1);
+        tsc_wait_vmcnt<0>();
+        for (int tt = 0; tt < nt; tt += 2) {
+            process(X, tt);
+            if (tt + 1 < nt) process(Y, tt + 1);
+        }
+    }
+}

@@ -72,6 +72,26 @@ def assert_mock_equal(got, want, exact=True, rtol=0.0):
                 np.testing.assert_allclose(a, b, rtol=rtol, atol=0, err_msg=f'{tr}.{col}')
 
 
+def assert_spectrum_close(got, want, rtol=1e-5, floor=0.1, err_msg=''):
+    """north_star tolerance on a binned spectrum: |got - want| <= rtol * max(|want|, floor * max|want|) element by element -
+    relative `rtol` for every value within a decade of the array's largest, and below that (a cross spectrum or an
+    l = 2, 4 multipole changing sign, the DC bin) an absolute floor of rtol * floor * max|want|: a relative error means
+    nothing at a zero crossing.  NaN (empty bins) must match."""
+    got, want = np.asarray(got, dtype='f8'), np.asarray(want, dtype='f8')
+    assert got.shape == want.shape, (err_msg, got.shape, want.shape)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan), f'{err_msg}: empty bins differ'
+    if nan.all():
+        return
+    scale = np.abs(want[~nan]).max()
+    tol = rtol * np.maximum(np.abs(want), floor * scale)
+    bad = ~nan & ~(np.abs(got - want) <= tol)
+    if bad.any():
+        rel = np.abs(got - want)[bad] / np.maximum(np.abs(want[bad]), floor * scale)
+        raise AssertionError(f'{err_msg}: {int(bad.sum())} of {want.size} values outside {rtol:g} (worst {rel.max():.3g} of the '
+                             f'floored value, {(np.abs(got - want)[bad] / scale).max():.3g} of the largest)')
+
+
 SYNTH_CASES = ['lrg', 'all_rich', 'all_rich_ranks', 'all_rich_norsd', 'all_rich_lc', 'elg_only', 'qso_only', 'lrg_qso']
 
 

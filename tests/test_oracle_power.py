@@ -6,7 +6,7 @@ goldens there are unusable; its invariants (tests/test_pow
 """
 import numpy as np
 import pytest
-from conftest import load_golden
+from conftest import assert_spectrum_close, load_golden
 
 from abacusutils_amd import synth
 from oracle import oracle
@@ -18,11 +18,14 @@ def _pos():
     return synth.synth_positions(N, L, seed=300, clustered=True)
 
 
-def _check(tab, g, name, rtol):
+RTOL = 1e-5   # the north_star tolerance, against what the REFERENCE returned (measured: power <= 9.1e-7, k_avg <= 1.8e-6,
+              # multipoles <= 5e-7 of the largest value in all 16 mode x accumulator combinations and the five extra cases)
+
+
+def _check(tab, g, name, rtol=RTOL):
     for k in ('power', 'k_avg', 'poles'):
         if f'{name}.{k}' in g:
-            np.testing.assert_allclose(np.asarray(tab[k]), g[f'{name}.{k}'], rtol=rtol, atol=rtol * 10,
-                                       err_msg=f'{name}.{k}')
+            assert_spectrum_close(tab[k], g[f'{name}.{k}'], rtol=rtol, err_msg=f'{name}.{k}')
     for k in ('N_mode', 'N_mode_poles'):
         if f'{name}.{k}' in g:
             np.testing.assert_array_equal(np.asarray(tab[k]), g[f'{name}.{k}'], err_msg=f'{name}.{k}')
@@ -42,13 +45,13 @@ def test_calc_power_modes(paste, comp, inter, accum64):
     # float32-accumulator mode follows the reference's nthread=1 order: agreement is at the float32 rounding
     # level (powf/x*x and f32 promotion differences of the shim, see test_oracle_tsc); float64 accumulators differ
     # from the reference's own float32 sums by its accumulation error.
-    _check(tab, g, name, rtol=2e-5 if paste == 'TSC' else 1e-4)
+    _check(tab, g, name)
     # invariant of tests/test_power.py:58-61: monopole == mode-weighted mean of the wedges
     p, nm = np.asarray(tab['power'], dtype='f8'), np.asarray(tab['N_mode'], dtype='f8')
     with np.errstate(invalid='ignore'):
         mono = np.nansum(p * nm, axis=1) / nm.sum(axis=1)
     ok = nm.sum(axis=1) > 0
-    np.testing.assert_allclose(np.asarray(tab['poles'])[ok, 0], mono[ok], rtol=2e-5)
+    np.testing.assert_allclose(np.asarray(tab['poles'])[ok, 0], mono[ok], rtol=1e-5 if not accum64 else 1e-6)
 
 
 def test_weights_squeeze():
@@ -58,7 +61,7 @@ def test_weights_squeeze():
     tab = oracle.calc_power(_pos(), L, kbins=10, mubins=None, paste='TSC', nmesh=NMESH, compensated=True,
                             interlaced=False, w=w, poles=[0, 2])
     assert tab['power'].ndim == 1 and 'mu_mid' not in tab
-    _check(tab, g, 'TSC_weights_squeeze', 2e-5)
+    _check(tab, g, 'TSC_weights_squeeze')
 
 
 def test_cross_logk_defaults_odd():
@@ -66,15 +69,15 @@ def test_cross_logk_defaults_odd():
     pos2 = synth.synth_positions(N // 2, L, seed=301, clustered=True)
     tab = oracle.calc_power(_pos(), L, kbins=9, mubins=3, paste='TSC', nmesh=NMESH, compensated=True, interlaced=True,
                             pos2=pos2, poles=[0, 2, 4])
-    _check(tab, g, 'TSC_cross', 5e-4)   # cross power passes through zero: absolute floor via atol in _check
+    _check(tab, g, 'TSC_cross')   # cross power passes through zero: the floor of assert_spectrum_close
     tab = oracle.calc_power(_pos(), L, kbins=8, mubins=2, logk=True, paste='TSC', nmesh=NMESH, compensated=False,
                             interlaced=False)
-    _check(tab, g, 'TSC_logk', 2e-5)
+    _check(tab, g, 'TSC_logk')
     tab = oracle.calc_power(_pos(), L, paste='TSC', nmesh=24, compensated=True, interlaced=True)
-    _check(tab, g, 'TSC_defaults_n24', 2e-5)
+    _check(tab, g, 'TSC_defaults_n24')
     tab = oracle.calc_power(_pos(), L, kbins=7, mubins=2, paste='TSC', nmesh=27, compensated=True, interlaced=True,
                             poles=[0, 2])
-    _check(tab, g, 'TSC_odd27', 2e-5)
+    _check(tab, g, 'TSC_odd27')
 
 
 def test_pk_from_deltak():
