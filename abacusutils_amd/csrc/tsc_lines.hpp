@@ -344,15 +344,14 @@ __device__ __forceinline__ void split_drain(SplitLds<E, NB, LINE, SBUF, NT> &s, 
 // ---- coarse scatter --------------------------------------------------------------------------------------------
 // The tiles of a particle's cloud: per dimension the tile of its lowest cell and, when the cloud reaches over that tile's
 // upper face, the next one (periodic) - 1, 2, 4 or 8 tiles.  The geometry is evaluated ONCE per particle into seven registers:
-//   b0, kl0      bucket, tile key (bits 0..15) and index code (bits 16..31) of the emission that takes the first tile everywhere;
-//   dlt[d]       what taking the second tile of dimension d adds: to the bucket (high half, signed) and to the key (low half,
-//                signed); the index code always loses T << shift;
-//   h            bit d: dimension d has a second tile; bit 31: no item;
+//   w0           (bucket << 16) + tile key of the emission that takes the first tile everywhere;
+//   l0           its index code (lx | ly << 5 | lz << 10), bits 16..18: dimension d has a second tile, bit 31: no item;
+//   dlt[d]       what taking the second tile of dimension d adds to w0 (bucket and key deltas in one word: sums modulo 2^32
+//                of words whose fields end up in range are exact); the index code always loses T << shift;
 //   frac         the three 16-bit codes of the in-cell offsets.
-// Emission e adds the deltas of the dimensions its bits select: a few multiply-adds instead of a walk over tile coordinates.
+// Emission e adds the deltas of the dimensions its bits select: two multiply-adds per dimension.
 struct LnItem {
-    int b0;
-    unsigned int kl0, h;
+    unsigned int w0, l0;
     int dlt[3];
     unsigned long long frac;
 };
@@ -361,45 +360,44 @@ __device__ __forceinline__ void ln_item(float x, float y, float z, float offset,
     const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ}, T[3] = {LN_TX, LN_TY, LN_TZ};
     const int sbk[3] = {g.sb[1] + g.sb[2], g.sb[2], 0};          // key shifts
     const int sbb[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};           // bucket strides
-    it.b0 = 0, it.kl0 = 0u, it.h = 0u, it.frac = 0ull;
+    it.w0 = 0u, it.l0 = 0u, it.frac = 0ull;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         int i, m;
         ln_cell(c[a], offset, ih[a], g.n[a], i, m);
         it.frac |= (unsigned long long)(unsigned int)(m + 32768) << (16 + 16 * a);
-        const int ta = min(ln_wrap(i - 1, g.n[a]) >> sh[a], g.nt[a] - 1), tb0 = ln_wrap(i + 1, g.n[a]) >> sh[a];
-        int l = i - (ta << sh[a]) + 1;                           // nearest cell relative to the first tile, biased by one
-        if (l > g.n[a] / 2) l -= g.n[a];
-        else if (l < -(g.n[a] / 2)) l += g.n[a];
-        const int h = tb0 != ta ? 1 : 0;
-        l = min(max(l, h ? T[a] : 0), T[a] + 1);                 // (garbage positions: the second tile's index stays >= 0)
-        int tb = ta + 1;
-        if (tb == g.nt[a]) tb = 0;
-        const int msk = (1 << g.sb[a]) - 1;
-        const int ba = (ta >> g.sb[a]) * sbb[a], bb = (tb >> g.sb[a]) * sbb[a];
-        const int ka = (ta & msk) << sbk[a], kb = (tb & msk) << sbk[a];
-        it.b0 += ba;
-        it.kl0 += (unsigned int)ka | ((unsigned int)l << (16 + 5 * a));
-        it.dlt[a] = ((bb - ba) << 16) | ((kb - ka) & 0xffff);
-        it.h |= (unsigned int)h << a;
+        // nearest cell -> its tile t and index c inside it; the cloud's first tile is t - 1 when c = 0 (cell i - 1 lies
+        // there), and the cloud has a second tile when c = 0 or c = T - 1
+        const int wi = min(max(ln_wrap(i, g.n[a]), 0), g.n[a] - 1);
+        const int cc = wi & (T[a] - 1), t = wi >> sh[a];
+        const bool lowface = cc == 0;
+        const int h = (lowface || cc == T[a] - 1) ? 1 : 0;
+        int ta = t - (lowface ? 1 : 0);
+        if (ta < 0) ta = g.nt[a] - 1;
+        const int l = lowface ? T[a] + 1 : cc + 1;               // nearest cell relative to the first tile, biased by one
+        const int msk = (1 << g.sb[a]) - 1, ka = ta & msk;
+        const bool cross = ka == msk;                            // the second tile lies in the next block
+        const int dk = cross ? -(msk << sbk[a]) : (1 << sbk[a]);
+        const int db = cross ? (ta == g.nt[a] - 1 ? -(g.nb[a] - 1) * sbb[a] : sbb[a]) : 0;
+        it.w0 += (unsigned int)(((ta >> g.sb[a]) * sbb[a]) << 16) + (unsigned int)(ka << sbk[a]);
+        it.l0 |= ((unsigned int)l << (5 * a)) | ((unsigned int)h << (16 + a));
+        it.dlt[a] = (db << 16) + dk;
     }
 }
-// emission e of an item: bucket, and (key | index code << 16)
-__device__ __forceinline__ void ln_emit(const LnItem &it, int e, int &bucket, unsigned int &kl) {
-    int k = e, db = 0, dk = 0;
-    unsigned int dl = 0u;
+// emission e >= 1 of an item: (bucket << 16) + key, and the index code
+__device__ __forceinline__ void ln_emit(const LnItem &it, int e, unsigned int &w, unsigned int &l) {
+    const int T[3] = {LN_TX, LN_TY, LN_TZ};
+    int k = e;
+    w = it.w0, l = it.l0 & 0xffffu;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const int T[3] = {LN_TX, LN_TY, LN_TZ};
-        const int h = (it.h >> a) & 1, sel = h & k;
+        const int h = (it.l0 >> (16 + a)) & 1, sel = h & k;
         k >>= h;
-        db += sel * (it.dlt[a] >> 16);
-        dk += sel * (int)(short)(it.dlt[a] & 0xffff);
-        dl += (unsigned int)sel * ((unsigned int)T[a] << (16 + 5 * a));
+        w += (unsigned int)(sel * it.dlt[a]);
+        l -= (unsigned int)sel * ((unsigned int)T[a] << (5 * a));
     }
-    bucket = it.b0 + db;
-    kl = it.kl0 + (unsigned int)dk - dl;
 }
+__device__ __forceinline__ int ln_item_count(const LnItem &it) { return (it.l0 >> 31) ? 0 : 1 << __popc((it.l0 >> 16) & 7u); }
 
 template <int NB, int LINE, int SBUF, int NT>
 __global__ __launch_bounds__(NT) void lines_coarse(const float *__restrict__ pos, int64_t n, LGeom g, double box, float offA,
@@ -412,56 +410,74 @@ __global__ __launch_bounds__(NT) void lines_coarse(const float *__restrict__ pos
     __syncthreads();
     const float ihx = (float)(g.n[0] / box), ihy = (float)(g.n[1] / box), ihz = (float)(g.n[2] / box);
     const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
-    // items per round: in the steady state a round's output is about its input (1.25 entries per particle); a round whose
-    // output does not fit (clouds piled up on tile corners, every carry leaving at once) is retried with half the items
+    // items per round: in the steady state a round's output is about its input (1.25 entries per particle).  A round whose
+    // output does not fit the buffer (clouds piled up on tile corners: eight entries per particle) is redone in G groups of
+    // its items: a round's output is at most LINE times its new entries (only a bucket that receives entries can reach a
+    // line boundary, and it sends out less than a line of carried entries beside them), so 8 x PMAX / G x LINE <= SBUF fits
     constexpr int PMAX = SBUF * 5 / 8 / NT * NT;
     constexpr int PPT = PMAX / NT;
-    static_assert(PPT >= 1 && SBUF >= 8 * LINE + 64, "buffer too small");
-    int ptry = PMAX, par = 0;
-    int64_t s0 = p0;
-    while (s0 < p1) {
-        const int np = (int)min((int64_t)ptry, p1 - s0);
-        LnF3 q[PPT];
+    constexpr int G = 64;
+    static_assert(PPT >= 1 && 8 * (PMAX / G) * LINE <= SBUF && (G & (G - 1)) == 0, "buffer too small");
+    int par = 0;
+    // software pipeline: the particles of round r + 1 are requested a round ahead, their geometry is evaluated behind the
+    // stores of round r (which nobody waits for)
+    LnF3 q[PPT];
+    LnItem it[PPT];
+    auto load = [&](int64_t s0) {
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            const int idx = k * NT + tid;
-            if (idx < np) q[k] = *reinterpret_cast<const LnF3 *>(pos + 3 * (s0 + idx));
+            const int64_t p = s0 + k * NT + tid;
+            if (p < p1) q[k] = *reinterpret_cast<const LnF3 *>(pos + 3 * p);
         }
-        LnItem it[PPT];
-        const bool ok = split_round<uint4, NB, LINE, SBUF, NT>(
-            s, nb, par, 0, 0, staged,
-            [&](auto f) {
+    };
+    auto geometry = [&](int64_t s0) {
 #pragma unroll
-                for (int k = 0; k < PPT; k++) {
-                    int cnt = 0;
-                    if (k * NT + tid < np) {
-                        ln_item(q[k].x, q[k].y, q[k].z, offA, ihx, ihy, ihz, g, it[k]);
-                        cnt = 1 << __popc(it[k].h);
-                    } else {
-                        it[k].h = 0x80000000u;
-                    }
-                    for (int e = 0; e < cnt; e++) {
-                        int b;
-                        unsigned int kl;
-                        ln_emit(it[k], e, b, kl);
-                        f(b);
-                    }
-                }
-            },
-            [&](auto f) {
+        for (int k = 0; k < PPT; k++) {
+            if (s0 + k * NT + tid < p1) ln_item(q[k].x, q[k].y, q[k].z, offA, ihx, ihy, ihz, g, it[k]);
+            else it[k].l0 = 0x80000000u;
+        }
+    };
+    load(p0);
+    geometry(p0);
+    load(p0 + PMAX);
+    for (int64_t s0 = p0; s0 < p1; s0 += PMAX) {
+        auto round = [&](int groups, int gi) {
+            return split_round<uint4, NB, LINE, SBUF, NT>(
+                s, nb, par, 0, 0, staged,
+                [&](auto f) {
 #pragma unroll
-                for (int k = 0; k < PPT; k++) {
-                    const int cnt = (it[k].h >> 31) ? 0 : 1 << __popc(it[k].h);
-                    for (int e = 0; e < cnt; e++) {
-                        int b;
-                        unsigned int kl;
-                        ln_emit(it[k], e, b, kl);
-                        f(b, make_uint4((unsigned int)it[k].frac | (kl >> 16), (unsigned int)(it[k].frac >> 32), kl & 0xffffu, 0u));
+                    for (int k = 0; k < PPT; k++) {
+                        const int cnt = ((k * NT + tid) & (groups - 1)) != gi ? 0 : ln_item_count(it[k]);
+                        if (cnt) f((int)(it[k].w0 >> 16));       // the first emission of every item: no walk
+                        for (int e = 1; e < cnt; e++) {
+                            unsigned int w, l;
+                            ln_emit(it[k], e, w, l);
+                            f((int)(w >> 16));
+                        }
                     }
-                }
-            });
-        if (ok) s0 += np, par ^= 1;
-        else ptry = max(ptry / 2, 1);   // a pile-up of clouds on tile corners: up to eight entries per particle
+                },
+                [&](auto f) {
+#pragma unroll
+                    for (int k = 0; k < PPT; k++) {
+                        const int cnt = ((k * NT + tid) & (groups - 1)) != gi ? 0 : ln_item_count(it[k]);
+                        const unsigned int flo = (unsigned int)it[k].frac, fhi = (unsigned int)(it[k].frac >> 32);
+                        if (cnt) f((int)(it[k].w0 >> 16), make_uint4(flo | (it[k].l0 & 0xffffu), fhi, it[k].w0 & 0xffffu, 0u));
+                        for (int e = 1; e < cnt; e++) {
+                            unsigned int w, l;
+                            ln_emit(it[k], e, w, l);
+                            f((int)(w >> 16), make_uint4(flo | l, fhi, w & 0xffffu, 0u));
+                        }
+                    }
+                });
+        };
+        if (round(1, 0)) par ^= 1;
+        else
+            for (int gi = 0; gi < G; gi++) {
+                round(G, gi);
+                par ^= 1;
+            }
+        geometry(s0 + PMAX);
+        load(s0 + 2 * PMAX);
     }
     split_drain<uint4, NB, LINE, SBUF, NT>(s, nb, par, staged);
 }
@@ -532,31 +548,44 @@ __global__ __launch_bounds__(NT) void lines_fine(const uint4 *__restrict__ stage
     __syncthreads();
     constexpr int PMAX = (SBUF - SBUF / 8) / NT * NT;     // one entry out per entry in
     constexpr int PPT = PMAX / NT;
-    static_assert(PPT >= 1 && SBUF >= 8 * LINE + 64, "buffer too small");
-    int ptry = PMAX, par = 0;
-    unsigned int s0 = pc.e0;
-    while (s0 < pc.e1) {
-        const int np = (int)min((unsigned int)ptry, pc.e1 - s0);
-        uint4 q[PPT];
+    constexpr int G = 16;                                 // see lines_coarse: LINE x PMAX / G <= SBUF always fits
+    static_assert(PPT >= 1 && (PMAX / G) * LINE <= SBUF && (G & (G - 1)) == 0, "buffer too small");
+    int par = 0;
+    uint4 q[PPT], nx[PPT];
+    auto load = [&](unsigned int s0) {
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            const int idx = k * NT + tid;
-            if (idx < np) q[k] = staged[s0 + idx];
+            const unsigned int e = s0 + k * NT + tid;
+            if (e < pc.e1) nx[k] = staged[e];
         }
-        const bool ok = split_round<unsigned long long, NBF, LINE, SBUF, NT>(
-            s, nb, par, 0, 0, entries,
-            [&](auto f) {
+    };
+    if (pc.e0 >= pc.e1) return;
+    load(pc.e0);
+    for (unsigned int s0 = pc.e0; s0 < pc.e1; s0 += PMAX) {
 #pragma unroll
-                for (int k = 0; k < PPT; k++)
-                    if (k * NT + tid < np) f((int)min(q[k].z, (unsigned int)(NBF - 1)));
-            },
-            [&](auto f) {
+        for (int k = 0; k < PPT; k++) q[k] = nx[k];
+        if (s0 + PMAX < pc.e1) load(s0 + PMAX);           // a round ahead
+        auto round = [&](int groups, int gi) {
+            return split_round<unsigned long long, NBF, LINE, SBUF, NT>(
+                s, nb, par, 0, 0, entries,
+                [&](auto f) {
 #pragma unroll
-                for (int k = 0; k < PPT; k++)
-                    if (k * NT + tid < np) f((int)min(q[k].z, (unsigned int)(NBF - 1)), ((unsigned long long)q[k].y << 32) | q[k].x);
-            });
-        if (ok) s0 += np, par ^= 1;
-        else ptry = max(ptry / 2, 1);
+                    for (int k = 0; k < PPT; k++)
+                        if (s0 + k * NT + tid < pc.e1 && ((k * NT + tid) & (groups - 1)) == gi) f((int)min(q[k].z, (unsigned int)(NBF - 1)));
+                },
+                [&](auto f) {
+#pragma unroll
+                    for (int k = 0; k < PPT; k++)
+                        if (s0 + k * NT + tid < pc.e1 && ((k * NT + tid) & (groups - 1)) == gi)
+                            f((int)min(q[k].z, (unsigned int)(NBF - 1)), ((unsigned long long)q[k].y << 32) | q[k].x);
+                });
+        };
+        if (round(1, 0)) par ^= 1;
+        else
+            for (int gi = 0; gi < G; gi++) {
+                round(G, gi);
+                par ^= 1;
+            }
     }
     split_drain<unsigned long long, NBF, LINE, SBUF, NT>(s, nb, par, entries);
 }
