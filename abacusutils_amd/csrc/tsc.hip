@@ -934,7 +934,7 @@ static bool lines_geometry(int gx, int gy, int gz, int64_t zstride, LGeom &g, in
     g.nt[0] = gx / LN_TX, g.nt[1] = gy / LN_TY, g.nt[2] = gz / LN_TZ;
     g.zstride = zstride;
     const int T[3] = {LN_TX, LN_TY, LN_TZ};
-    for (cfg = 0; cfg < 2; cfg++) {
+    for (cfg = option("tsc_lines_cfg1") ? 1 : 0; cfg < 2; cfg++) {
         const int limT = cfg ? 1024 : 512, limB = cfg ? 1024 : 256;
         double best = 1e30;
         bool found = false;
@@ -1059,10 +1059,17 @@ static int lines_deposit_run(float *pos, int64_t n, float *grid, const LGeom &g,
     const int range_len = (int)std::min<int64_t>(LD_RANGE, std::max<int64_t>(64, ceil_div(ntiles, (int64_t)ncu * 8)));
     const int nranges = (int)ceil_div(ntiles, range_len);
     const int grid_p = (int)std::min<int64_t>(nranges, (int64_t)ncu * 2);
+    const int dbg = option("dbg_tsc") & 3;
+    if (!option("tsc_acc64")) {   // 32-bit tile sums, four workgroups per CU
+        const int range32 = (int)std::min<int64_t>(LD32_RANGE, std::max<int64_t>(64, ceil_div(ntiles, (int64_t)ncu * 16)));
+        const int grid32 = (int)std::min<int64_t>(ceil_div(ntiles, range32), (int64_t)ncu * 4);
+        ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit32<256>), dim3(grid32), dim3(256), 0, (const unsigned long long *)entries, (int64_t)fs,
+                      (const unsigned int *)tile_start, (const unsigned int *)tile_cnt, ntiles, range32, g, grid, zero_grid, (float)norm, (float)sub, dbg);
+        return 0;
+    }
     const bool dense = gs / std::max(ntiles, 1) > 400;
     double fxscale;
     lines_fxscale(n, fxscale);
-    const int dbg = option("dbg_tsc") & 3;
     if (dense)
         ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit<512>), dim3(grid_p), dim3(512), 0, (const unsigned long long *)entries, (int64_t)fs,
                       (const unsigned int *)tile_start, (const unsigned int *)tile_cnt, ntiles, range_len, g, grid, zero_grid, (float)norm, (float)sub, fxscale, dbg);

@@ -21,8 +21,8 @@
 // cell over the tile's faces) and d = cell - p as a 16-bit fixed-point number.  p = (x + offset) * (n / L) is evaluated in
 // float32 exactly as the reference does; d is a multiple of ulp(p), i.e. of 2^-16 or coarser wherever p >= 128 cells, so
 // the 16-bit code is EXACT there and the cloud weights are the reference's float32 weights bit for bit; in the first 128
-// cells of a dimension d is rounded to 2^-16 of a cell (7.6e-6 of a cell at most: the reference's own tolerance on the
-// mesh is rtol 1e-4, tests/test_tsc.py:136).  d = +1/2 (p exactly between two cells, round-half-even picked the upper)
+// cells of a dimension d is rounded to 2^-16 of a cell, up or down without bias (ln_cell; 1.5e-5 of a cell at most: the
+// reference's own tolerance on the mesh is rtol 1e-4, tests/test_tsc.py:136).  d = +1/2 (p exactly between two cells, round-half-even picked the upper)
 // is stored as the lower cell with d = -1/2: the same three weights (1/2, 1/2, 0) on the same cells.
 //
 // (PMC, profiles/r04: these passes are bound by vector-instruction issue, not by HBM - a first form that staged raw
@@ -46,24 +46,33 @@ struct LGeom {
     int64_t zstride;
 };
 
-// canonical nearest cell and fixed-point offset of one coordinate (see the header comment).  i in [-3, n + 2]
-__device__ __forceinline__ void ln_cell(float x, float offset, float ih, int n, int &i, int &m) {
+// canonical nearest cell and fixed-point offset of one coordinate (see the header comment).  i in [-3, n + 2].
+// Where d needs more than 16 bits (the first 128 cells) it is rounded WITHOUT BIAS: up with a probability equal to the
+// fraction dropped, `u` in (0, 1) being a hash of the particle's three coordinates (ln_hash: a function of the input
+// alone, so the mesh is reproducible).  Round-to-nearest is not good enough: float32 catalogues sit on lattices - the
+// benchmark's positions, 24-bit uniforms times L on a power-of-two mesh, are 2^-14-lattice values less one ulp 59 % of the
+// time - on which every deterministic rule rounds one way; 4.5e-6 of a cell, the same for every particle below cell 128,
+// is a mass dipole of half a particle across that plane and 1.3e-4 in the 2-mode bin of the 1e8-particle spectrum.
+__device__ __forceinline__ void ln_cell(float x, float offset, float ih, int n, float u, int &i, int &m) {
     const float p = (x + offset) * ih;                       // tsc.py:419-421, float32
     float r = rintf(p);                                      // round half even, like np.round / llvm.rint
     r = fminf(fmaxf(r, -2.f), (float)(n + 2));               // garbage positions (NaN, inf) stay inside the tables
     const float d = r - p;                                   // exact for every finite p the clamp left alone
-    const float mf = fminf(fmaxf(rintf(d * 65536.f), -32768.f), 32768.f);
+    const float y = d * 65536.f, fl = floorf(y);             // exact; y - fl is the fraction a 16-bit code drops
+    const float mf = fminf(fmaxf(fl + ((y - fl) > u ? 1.f : 0.f), -32768.f), 32768.f);
     i = (int)r;
     m = (int)mf;
     if (m == 32768) i -= 1, m = -32768;
 }
-// the same cell without the code (the list-membership passes): m == 32768 <=> d * 65536 >= 32767.5 (ties go to the even 32768)
-__device__ __forceinline__ int ln_cell_i(float x, float offset, float ih, int n) {
-    const float p = (x + offset) * ih;
-    float r = rintf(p);
-    r = fminf(fmaxf(r, -2.f), (float)(n + 2));
-    const float d = r - p;
-    return (int)r - (d >= 0.49999237060546875f ? 1 : 0);
+// three 10-bit uniforms in (0, 1) from the bits of a particle's coordinates
+__device__ __forceinline__ void ln_hash(float x, float y, float z, float u[3]) {
+    unsigned int h = __float_as_uint(x) ^ __builtin_rotateleft32(__float_as_uint(y), 11) ^ __builtin_rotateleft32(__float_as_uint(z), 21);
+    h *= 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+#pragma unroll
+    for (int a = 0; a < 3; a++) u[a] = ((float)((h >> (10 * a)) & 1023u) + 0.5f) * (1.f / 1024.f);
 }
 __device__ __forceinline__ int ln_wrap(int c, int n) { return c < 0 ? c + n : (c >= n ? c - n : c); }
 
@@ -76,7 +85,7 @@ __device__ __forceinline__ void ln_tiles(int lo, int hi, int n, int sh, int &ta,
 struct LnRange {
     int ta[3], tb[3];    // tiles of the low / high end per dimension
 };
-// cell range of a particle's cloud(s): offset A alone, or (EXT) the union of the clouds at offsets A and B
+// tiles of a particle's cloud at offset A (the counting pass: the same canonical cell as lines_coarse evaluates)
 template <bool EXT>
 __device__ __forceinline__ LnRange ln_range(float x, float y, float z, const LGeom &g, float offA, float offB, float ihx, float ihy,
                                             float ihz) {
@@ -85,13 +94,19 @@ __device__ __forceinline__ LnRange ln_range(float x, float y, float z, const LGe
     const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const int i = ln_cell_i(c[a], offA, ih[a], g.n[a]);
-        int lo = i - 1, hi = i + 1;
-        if (EXT) {
-            const int j = ln_cell_i(c[a], offB, ih[a], g.n[a]);
-            lo = min(lo, j - 1), hi = max(hi, j + 1);
+        // the cell alone: ln_cell's code matters here only when it may reach 32768 (d within 2^-16 of +1/2: one particle
+        // in 30 000) - only then is the hash evaluated
+        const float p = (c[a] + offA) * ih[a];
+        float rr = rintf(p);
+        rr = fminf(fmaxf(rr, -2.f), (float)(g.n[a] + 2));
+        int i = (int)rr;
+        if ((rr - p) * 65536.f > 32767.f) {
+            float u[3];
+            int m;
+            ln_hash(x, y, z, u);
+            ln_cell(c[a], offA, ih[a], g.n[a], u[a], i, m);
         }
-        ln_tiles(lo, hi, g.n[a], sh[a], r.ta[a], r.tb[a]);
+        ln_tiles(i - 1, i + 1, g.n[a], sh[a], r.ta[a], r.tb[a]);
     }
     return r;
 }
@@ -361,10 +376,12 @@ __device__ __forceinline__ void ln_item(float x, float y, float z, float offset,
     const int sbk[3] = {g.sb[1] + g.sb[2], g.sb[2], 0};          // key shifts
     const int sbb[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};           // bucket strides
     it.w0 = 0u, it.l0 = 0u, it.frac = 0ull;
+    float u[3];
+    ln_hash(x, y, z, u);
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         int i, m;
-        ln_cell(c[a], offset, ih[a], g.n[a], i, m);
+        ln_cell(c[a], offset, ih[a], g.n[a], u[a], i, m);
         it.frac |= (unsigned long long)(unsigned int)(m + 32768) << (16 + 16 * a);
         // nearest cell -> its tile t and index c inside it; the cloud's first tile is t - 1 when c = 0 (cell i - 1 lies
         // there), and the cloud has a second tile when c = 0 or c = T - 1
@@ -719,6 +736,157 @@ __global__ __launch_bounds__(NT) void lines_deposit(const unsigned long long *__
             }
             __syncthreads();
             // see tsc_tile_deposit_p: [FL stores of tile tt-1] [NPRE loads of tile tt+2] [FL stores of this tile]
+            const bool plain = zero_grid && !extra && !(dbg & 2);
+            if (plain && prev_plain && more) tsc_wait_vmcnt<2 * FL + NPRE>();
+            else tsc_wait_vmcnt<0>();
+            prev_plain = plain;
+        };
+        issue(X, 0);
+        if (nt > 1) issue(Y, 1);
+        tsc_wait_vmcnt<0>();
+        for (int tt = 0; tt < nt; tt += 2) {
+            process(X, tt);
+            if (tt + 1 < nt) process(Y, tt + 1);
+        }
+    }
+}
+
+// ---- the same deposit with 32-bit tile sums ------------------------------------------------------------------------
+// The u64 deposit spends 0.95 ms of its 2.0 ms (BASELINE config 3) in LDS atomics and 1.1 ms in the flush, one after the
+// other: two 74-KB workgroups per CU run in lock step.  Here a cell is a 32-bit fixed-point sum with a PER-TILE scale
+// 2^S, S = 32 - floor(log2(entries of the tile)): no cell can overflow (an addend is at most 0.75^3 = 0.42), and the
+// resolution is ~2e-6 of the tile's MEAN cell whatever its density (2^-23 absolute at the 950 entries of a config-3 tile;
+// the reference's own float32 mesh carries 6e-8 relative per add, its tolerance on the mesh is rtol 1e-4).  Two z-adjacent
+// cells form one aligned 64-bit word, so the three cells of a cloud row take TWO 64-bit LDS atomics (the low half cannot
+// carry into the high one) instead of three: 18 per entry instead of 27.  The tile is 36 KB: four workgroups per CU,
+// whose accumulate and flush phases overlap.  Integer sums: the mesh does not depend on the order of the entries.
+constexpr int LD32_RANGE = 256;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void lines_deposit32(const unsigned long long *__restrict__ entries, int64_t capacity,
+                                                      const unsigned int *__restrict__ tile_start,
+                                                      const unsigned int *__restrict__ tile_cnt, int ntiles, int range_len, LGeom g,
+                                                      float *__restrict__ grid, int zero_grid, float norm, float sub, int dbg) {
+    constexpr int NPRE = 3;                                   // prefetched 16-B loads (two entries each) per thread
+    constexpr int FL = LN_TX * LN_TY * (LN_TZ / 4) / NT;      // flush stores (16 B) per thread
+    static_assert((LN_TX * LN_TY * (LN_TZ / 4)) % NT == 0 && 2 * FL + NPRE <= 60, "whole flush stores per thread");
+    __shared__ __align__(16) unsigned int tile[LN_TX * LN_TY * LN_ZP];
+    __shared__ unsigned int bst[LD32_RANGE + 2], bcn[LD32_RANGE + 2];
+    const int tid = threadIdx.x;
+    {
+        float4 *t4 = reinterpret_cast<float4 *>(tile);
+        for (int q = tid; q < (int)(sizeof(tile) / 16); q += NT) t4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int64_t lastpair = capacity >= 2 ? capacity / 2 - 1 : 0;
+    const int nranges = (ntiles + range_len - 1) / range_len;
+    const int lgtpb = __ffs(g.tpb) - 1;
+    for (int r = blockIdx.x; r < nranges; r += gridDim.x) {
+        const int t0 = r * range_len, nt = min(range_len, ntiles - t0);
+        __syncthreads();
+        for (int q = tid; q < nt; q += NT) bst[q] = tile_start[t0 + q], bcn[q] = tile_cnt[t0 + q];
+        __syncthreads();
+        tsc_v4f X[NPRE], Y[NPRE];
+        auto issue = [&](tsc_v4f(&set)[NPRE], int tt) {
+            const int64_t u0 = (int64_t)(bst[tt] >> 1);
+#pragma unroll
+            for (int q = 0; q < NPRE; q++)
+                tsc_gload16_async(set[q], reinterpret_cast<const float4 *>(entries) + min(u0 + q * NT + tid, lastpair));
+        };
+        float fx = 1.f;                                       // 2^S of the tile being accumulated
+        auto one = [&](unsigned long long e) {
+            const unsigned int lo = (unsigned int)e, hi = (unsigned int)(e >> 32);
+            const int lx = lo & 31, ly = (lo >> 5) & 31, lz = min((int)((lo >> 10) & 63), LN_TZ + 1);
+            const float dx = ((float)(lo >> 16) - 32768.f) * (1.f / 65536.f), dy = ((float)(hi & 0xffffu) - 32768.f) * (1.f / 65536.f),
+                        dz = ((float)(hi >> 16) - 32768.f) * (1.f / 65536.f);
+            float wx[3], wy[3], wz[3];
+            const float d3[3] = {dx, dy, dz};
+            float *w3[3] = {wx, wy, wz};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {                    // _tsc_scatter's weights (tsc.py:428-451), float32, no contraction
+                const float d = d3[a], tm = 0.5f + d, tp = 0.5f - d;
+                w3[a][1] = 0.75f - d * d;
+                w3[a][0] = 0.5f * (tm * tm);
+                w3[a][2] = 0.5f * (tp * tp);
+            }
+            const bool odd = lz & 1;
+            unsigned long long *zpair = reinterpret_cast<unsigned long long *>(tile) + (lz >> 1);   // cells lz .. lz + 2 of a halo'd row
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const int cx = lx - 2 + a;
+                if ((unsigned)cx >= (unsigned)LN_TX) continue;
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const int cy = ly - 2 + b;
+                    if ((unsigned)cy >= (unsigned)LN_TY) continue;
+                    const float wxy = wx[a] * wy[b];
+                    unsigned int sc[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) sc[c] = (unsigned int)__builtin_fmaf(wxy * wz[c], fx, 0.5f);   // (wx wy) wz, tsc.py:471-507
+                    const unsigned long long A = odd ? (unsigned long long)sc[0] << 32 : ((unsigned long long)sc[1] << 32) | sc[0];
+                    const unsigned long long B = odd ? ((unsigned long long)sc[2] << 32) | sc[1] : (unsigned long long)sc[2];
+                    unsigned long long *cell = zpair + (cx * LN_TY + cy) * (LN_ZP / 2);
+                    atomicAdd(cell, A);
+                    atomicAdd(cell + 1, B);
+                }
+            }
+        };
+        bool prev_plain = false;
+        auto process = [&](tsc_v4f(&cur)[NPRE], int tt) {
+            const int tile_id = t0 + tt;
+            const int b = tile_id >> lgtpb, f = tile_id & (g.tpb - 1);
+            int B0, B1, B2;
+            ln_bucket_coords(b, g, B0, B1, B2);
+            const int fz = f & ((1 << g.sb[2]) - 1), fy = (f >> g.sb[2]) & ((1 << g.sb[1]) - 1), fx_ = f >> (g.sb[2] + g.sb[1]);
+            const int ox = ((B0 << g.sb[0]) + fx_) << LN_SHX, oy = ((B1 << g.sb[1]) + fy) << LN_SHY, oz = ((B2 << g.sb[2]) + fz) << LN_SHZ;
+            const unsigned int cnt = bcn[tt];
+            const int64_t e0 = bst[tt];
+            const int S = min(32 - (31 - __clz((int)max(cnt, 1u))), 30);
+            fx = __uint_as_float((unsigned int)(127 + S) << 23);
+            const float fxinv = __uint_as_float((unsigned int)(127 - S) << 23);
+#pragma unroll
+            for (int q = 0; q < NPRE; q++) tsc_touch(cur[q]);
+#pragma unroll
+            for (int q = 0; q < NPRE; q++) {
+                const unsigned int k = 2u * (q * NT + tid);
+                if (!(dbg & 1)) {
+                    if (k < cnt) one(((unsigned long long)__float_as_uint(cur[q].y) << 32) | __float_as_uint(cur[q].x));
+                    if (k + 1 < cnt) one(((unsigned long long)__float_as_uint(cur[q].w) << 32) | __float_as_uint(cur[q].z));
+                }
+            }
+            for (unsigned int k = 2u * NPRE * NT + tid; k < cnt; k += NT) one(entries[e0 + k]);
+            const bool extra = cnt > 2u * NPRE * NT;
+            __syncthreads();
+            const bool more = tt + 2 < nt;
+            if (more) issue(cur, tt + 2);
+            {
+                constexpr int ZQ = LN_TZ / 4, ROWS = NT / ZQ;
+                static_assert(NT % ZQ == 0 && ROWS % LN_TY == 0 && (LN_TX * LN_TY) % ROWS == 0, "flush mapping");
+                constexpr int XSTEP = ROWS / LN_TY, STEPS = LN_TX / XSTEP;
+                const int zq = tid & (ZQ - 1), yy = (tid / ZQ) & (LN_TY - 1), x0 = tid / (ZQ * LN_TY);
+                unsigned int *cell = &tile[(x0 * LN_TY + yy) * LN_ZP + 2 + 4 * zq];     // 8-byte aligned: two 8-byte LDS accesses
+                float *dst = grid + ((int64_t)(ox + x0) * g.n[1] + (oy + yy)) * g.zstride + oz + 4 * zq;
+                const int64_t dstep = (int64_t)XSTEP * g.n[1] * g.zstride;
+#pragma unroll
+                for (int st = 0; st < STEPS; st++, cell += XSTEP * LN_TY * LN_ZP, dst += dstep) {
+                    uint2 *c2 = reinterpret_cast<uint2 *>(cell);
+                    const uint2 a01 = c2[0], a23 = c2[1];
+                    c2[0] = make_uint2(0u, 0u);
+                    c2[1] = make_uint2(0u, 0u);
+                    if (zq == 0) c2[-1] = make_uint2(0u, 0u);                            // the row's halo cells
+                    if (zq == ZQ - 1) c2[2] = make_uint2(0u, 0u);
+                    float v[4] = {(float)a01.x * fxinv, (float)a01.y * fxinv, (float)a23.x * fxinv, (float)a23.y * fxinv};
+                    if (!zero_grid) {
+                        const float4 old = *reinterpret_cast<const float4 *>(dst);
+                        v[0] += old.x, v[1] += old.y, v[2] += old.z, v[3] += old.w;
+                    }
+                    if (norm != 0.f) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) v[c] = v[c] * norm - sub;
+                    }
+                    if (!(dbg & 2)) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __syncthreads();
             const bool plain = zero_grid && !extra && !(dbg & 2);
             if (plain && prev_plain && more) tsc_wait_vmcnt<2 * FL + NPRE>();
             else tsc_wait_vmcnt<0>();
