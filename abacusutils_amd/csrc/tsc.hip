@@ -998,7 +998,9 @@ static int lines_deposit_run(float *pos, int64_t n, float *grid, const LGeom &g,
     if (wrapped_out) *wrapped_out = h_flag;
     g_wrapped_seen |= h_flag;
     // bucket starts on line boundaries; pieces of at most PIECE staged entries; one table upload
-    constexpr int64_t PIECE = 131072;
+    // pieces of 64 entries per tile of a bucket (32768 / 65536 staged entries): measured at BASELINE config 3, 32K 10.36 ms,
+    // 64K 10.40, 128K 10.52, 256K 10.58 (more, shorter workgroups balance better than longer runs per list help)
+    const int64_t PIECE = option("tsc_piece") > 0 ? (int64_t)option("tsc_piece") * 1024 : 64 * (int64_t)g.tpb;
     std::vector<unsigned int> gstart((size_t)nb + 1), fstart((size_t)nb + 1);
     std::vector<int> piece_first((size_t)nb + 1);
     std::vector<LnPiece> pieces;
@@ -1017,19 +1019,27 @@ static int lines_deposit_run(float *pos, int64_t n, float *grid, const LGeom &g,
     const int np = (int)pieces.size();
     const size_t o_g = 0, o_f = o_g + (size_t)(nb + 1) * 4, o_pf = o_f + (size_t)(nb + 1) * 4, o_p = (o_pf + (size_t)(nb + 1) * 4 + 15) & ~(size_t)15,
                  tbytes = o_p + std::max<size_t>(pieces.size(), 1) * sizeof(LnPiece);
-    std::vector<char> blob(tbytes);
-    memcpy(blob.data() + o_g, gstart.data(), (size_t)(nb + 1) * 4);
-    memcpy(blob.data() + o_f, fstart.data(), (size_t)(nb + 1) * 4);
-    memcpy(blob.data() + o_pf, piece_first.data(), (size_t)(nb + 1) * 4);
-    if (np) memcpy(blob.data() + o_p, pieces.data(), pieces.size() * sizeof(LnPiece));
+    // the tables go up from a page-locked buffer that outlives the call: nothing to wait for (the next call's tables are
+    // written after its own counting pass has been synchronised, i.e. after this copy)
+    static char *h_blob = nullptr;
+    static size_t h_blob_cap = 0;
+    if (tbytes > h_blob_cap) {
+        if (h_blob) HIP_TRY(hipHostFree(h_blob));
+        h_blob = nullptr, h_blob_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&h_blob, tbytes * 2, hipHostMallocDefault));
+        h_blob_cap = tbytes * 2;
+    }
+    memcpy(h_blob + o_g, gstart.data(), (size_t)(nb + 1) * 4);
+    memcpy(h_blob + o_f, fstart.data(), (size_t)(nb + 1) * 4);
+    memcpy(h_blob + o_pf, piece_first.data(), (size_t)(nb + 1) * 4);
+    if (np) memcpy(h_blob + o_p, pieces.data(), pieces.size() * sizeof(LnPiece));
     ABACUS_TRY(g_lw.tables.reserve(tbytes));
     ABACUS_TRY(g_lw.staged.reserve((size_t)std::max<int64_t>(gs, 16) * sizeof(uint4)));
     ABACUS_TRY(g_lw.C.reserve((size_t)std::max(np, 1) * g.tpb * sizeof(unsigned int)));
     ABACUS_TRY(g_lw.tile_start.reserve((size_t)ntiles * sizeof(unsigned int)));
     ABACUS_TRY(g_lw.tile_cnt.reserve((size_t)ntiles * sizeof(unsigned int)));
     ABACUS_TRY(g_lw.entries.reserve((size_t)std::max<int64_t>(fs, 16) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemcpyAsync(g_lw.tables.p, blob.data(), tbytes, hipMemcpyHostToDevice, stream()));
-    HIP_TRY(hipStreamSynchronize(stream()));   // `blob` leaves scope
+    HIP_TRY(hipMemcpyAsync(g_lw.tables.p, h_blob, tbytes, hipMemcpyHostToDevice, stream()));
     const char *tb = g_lw.tables.as<char>();
     const unsigned int *d_gstart = reinterpret_cast<const unsigned int *>(tb + o_g), *d_fstart = reinterpret_cast<const unsigned int *>(tb + o_f);
     const int *d_pfirst = reinterpret_cast<const int *>(tb + o_pf);

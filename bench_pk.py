@@ -87,10 +87,16 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
         'hipfft_r2c': 24.0 * M,            # three 1-D passes x (read + write) of the 4M-byte mesh/half-spectrum
         'fft_z_r2c': 8.0 * M, 'fft_cols_y': 8.0 * M, 'fft_cols_x': 8.0 * M,   # one pass each: read 4M + write 4M
         'fft_x_bin': 4.0 * M,              # last pass fused with the binning: one read of the half-spectrum, nothing written
-        'tsc_tile_deposit': 4.0 * M + 16.0 * 1.3 * n,
+        'tsc_tile_deposit': 4.0 * M + 8.0 * 1.25 * n,   # mesh written once + the 8-byte entries (1.25 per particle) read
         'spectrum_bin': 4.0 * M,
         'tsc_bin_count': 12.0 * n,
         'tsc_bin_fill': 12.0 * n + 16.0 * 1.3 * n,
+        # second-generation lists (csrc/tsc_lines.hpp): positions read twice, 16-byte staged (particle, tile) entries written
+        # once and read twice, 8-byte entries written once
+        'tsc_lines_count': 12.0 * n,
+        'tsc_lines_coarse': 12.0 * n + 16.0 * 1.25 * n,
+        'tsc_lines_fcount': 16.0 * 1.25 * n,
+        'tsc_lines_fine': 16.0 * 1.25 * n + 8.0 * 1.25 * n,
     }
     dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
     ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
