@@ -25,7 +25,8 @@ from .cic import cic_serial
 from .tsc import tsc_parallel
 
 __all__ = ['calc_power', 'calc_pk_from_deltak', 'get_k_mu_edges', 'get_field_fft', 'get_field',
-           'get_W_compensated', 'normalize_field']
+           'get_W_compensated', 'normalize_field', 'bin_kmu', 'get_raw_power', 'shift_field_fft',
+           'get_interlaced_field_fft']
 
 MAX_THREADS = 1
 
@@ -293,6 +294,62 @@ def calc_power_multi(columns, Lbox, kbins=None, mubins=None, k_max=None, logk=Fa
             out[(ta, tb)] = _power_table(outs, me, kbins, mubins, poles_arr, squeeze_mu_axis, return_mubins, meta)
     check(L.abacus_power_fields_release())
     return out
+
+
+# ---- the pieces of the chain as callables of their own (the reference exports them; calc_power runs them fused) -------
+def bin_kmu(n1d, L, kedges, muedges, weights, poles=np.empty(0, 'i8'), dtype=np.float32, fourier=True, nthread=MAX_THREADS):
+    """Mean and mode count in (k, mu) bins of an rfft-layout grid (n1d, n1d, n1d//2+1) or, fourier=False, of a real-space
+    grid (n1d, n1d, n1d) (:150-300) -> (weighted_counts (Nk, Nmu), counts (Nk, Nmu) int64, weighted_counts_poles (Np, Nk),
+    counts_poles (Nk,) int64, weighted_counts_k (Nk, Nmu)) - not multiplied by L^3, exactly as the reference returns them"""
+    w = _grid_f4(weights)
+    if int(n1d) != w.shape[0]:
+        raise ValueError(f'n1d = {n1d} but the grid is {w.shape}')
+    ke = np.ascontiguousarray(kedges, dtype=np.float64)
+    me = np.ascontiguousarray(muedges, dtype=np.float64)
+    po = np.ascontiguousarray(poles, dtype=np.int64)
+    power, N_mode, bp, Nmp, k_avg = _alloc_outputs(len(ke) - 1, len(me) - 1, len(po))
+    check(_lib.lib().abacus_bin_weights(ptr(w), int(n1d), int(w.shape[2]), C.c_double(L), int(bool(fourier)), ptr(ke), len(ke) - 1,
+                                        ptr(me), len(me) - 1, ptr(po), len(po), C.c_double(1.0), ptr(power), ptr(N_mode), ptr(bp),
+                                        ptr(Nmp), ptr(k_avg)))
+    dt = np.dtype(dtype)
+    return power.astype(dt, copy=False), N_mode, bp.astype(dt, copy=False), Nmp, k_avg.astype(dt, copy=False)
+
+
+def _c64(a, name):
+    a = np.asarray(a)
+    if a.dtype != np.complex64:
+        raise NotImplementedError(f'{name}: complex64 spectra only (float32 meshes), got {a.dtype}')
+    return np.ascontiguousarray(a)
+
+
+def get_raw_power(field_fft, field2_fft=None):
+    """|field_fft|^2, or Re(conj(field_fft) field2_fft) (:707-727) -> float32 array of the same shape"""
+    f1 = _c64(field_fft, 'get_raw_power')
+    f2 = None if field2_fft is None else _c64(field2_fft, 'get_raw_power')
+    if f2 is not None and f2.shape != f1.shape:
+        raise ValueError('field_fft and field2_fft differ in shape')
+    out = np.empty(f1.shape, dtype=np.float32)
+    check(_lib.lib().abacus_raw_power(ptr(f1), ptr(f2), C.c_int64(f1.size), ptr(out)))
+    return out
+
+
+def shift_field_fft(field_fft, field_shift_fft, n1d, L, d, dtype=np.float32):
+    """field_fft += field_shift_fft * exp(i (d / 2)(kx + ky + kz)); field_fft *= 0.5 / n1d^3, IN PLACE like the reference
+    (:904-948: it returns nothing)"""
+    if np.dtype(dtype) != np.float32 or not isinstance(field_fft, np.ndarray) or field_fft.dtype != np.complex64 or \
+            not field_fft.flags.c_contiguous:
+        raise NotImplementedError('shift_field_fft: C-contiguous complex64 spectra (float32 meshes) only')
+    n1d = int(n1d)
+    if field_fft.shape != (n1d, n1d, n1d // 2 + 1) or np.shape(field_shift_fft) != field_fft.shape:
+        raise ValueError(f'expected two ({n1d}, {n1d}, {n1d // 2 + 1}) spectra')
+    check(_lib.lib().abacus_shift_field_fft(ptr(field_fft), ptr(_c64(field_shift_fft, 'shift_field_fft')), n1d, C.c_double(L),
+                                            C.c_double(d)))
+
+
+def get_interlaced_field_fft(pos, Lbox, nmesh, paste, w, nthread=MAX_THREADS, verbose=False):
+    """the two deposits half a cell apart, their transforms and shift_field_fft (:951-998), fused on the device -> complex64
+    (nmesh, nmesh, nmesh//2+1), normalised by 0.5 / nmesh^3 like the reference's"""
+    return get_field_fft(pos, Lbox, nmesh, paste, w, None, False, True, nthread=nthread, verbose=verbose)
 
 
 # ---- ZCV-facing helpers (analysis/power_spectrum.py:303-660 of the reference) ------------------------------------

@@ -80,8 +80,14 @@ def exchange_id(rank, world, make_id, path, timeout=180.0):
         time.sleep(0.02)
 
 
+class RcclJoinTimeout(TimeoutError):
+    """ncclCommInitRank / the first barrier did not return: the helper thread is still inside the call (the first barrier
+    holds the library's API lock while it waits), so this process cannot be trusted with further library calls - it must
+    end and let the launcher start a fresh one.  `Dist.from_env` never turns this into a file-barrier fallback."""
+
+
 def _run_with_deadline(fn, timeout, what):
-    """fn() in a daemon thread; its exception is re-raised here, TimeoutError(what) if it is still running after `timeout` s"""
+    """fn() in a daemon thread; its exception is re-raised here, RcclJoinTimeout(what) if it is still running after `timeout` s"""
     import threading
     box = {}
 
@@ -95,7 +101,7 @@ def _run_with_deadline(fn, timeout, what):
     t.start()
     t.join(timeout)
     if t.is_alive():
-        raise TimeoutError(what)
+        raise RcclJoinTimeout(what)
     if 'error' in box:
         raise box['error']
 
@@ -449,6 +455,8 @@ class Dist:
         if int(os.environ.get('WORLD_SIZE', '1')) > 1:
             try:
                 return cls(RcclComm.from_env(**kw))
+            except RcclJoinTimeout:  # a join that never returned: a thread of this process is still inside the library
+                raise
             except Exception as e:   # noqa: BLE001 - whatever RCCL / the rendezvous raised
                 if not allow_file_fallback:
                     raise

@@ -152,16 +152,29 @@ int abacus_comm_unique_id(void *id, int len) {
 }
 
 int abacus_comm_init(int rank, int world, const void *id, int len, abacus_comm **out) {
-    ABACUS_ENTER();   // binds the device chosen with abacus_set_device: ncclCommInitRank takes the current device
-    if (!out) return fail("abacus_comm_init: null output");
-    if (world < 1 || rank < 0 || rank >= world) return fail("abacus_comm_init: rank %d of %d", rank, world);
-    if (!id || len < (int)sizeof(ncclUniqueId)) return fail("abacus_comm_init: the unique id must hold %d bytes", (int)sizeof(ncclUniqueId));
-    ABACUS_TRY(load_rccl());
     auto *c = new abacus_comm();
-    c->rank = rank, c->world = world;
     ncclUniqueId u;
-    memcpy(&u, id, sizeof u);
-    ncclResult_t r = R.CommInitRank(&c->nccl, world, u, rank);
+    {
+        ABACUS_ENTER();   // binds the device chosen with abacus_set_device: ncclCommInitRank takes the current device
+        if (!out || world < 1 || rank < 0 || rank >= world || !id || len < (int)sizeof(ncclUniqueId)) {
+            delete c;
+            return !out ? fail("abacus_comm_init: null output")
+                        : (!id || len < (int)sizeof(ncclUniqueId)) ? fail("abacus_comm_init: the unique id must hold %d bytes", (int)sizeof(ncclUniqueId))
+                                                                    : fail("abacus_comm_init: rank %d of %d", rank, world);
+        }
+        const int rc = load_rccl();
+        if (rc) {
+            delete c;
+            return rc;
+        }
+        c->rank = rank, c->world = world;
+        memcpy(&u, id, sizeof u);
+    }
+    // ncclCommInitRank blocks until EVERY rank has joined.  The library's API lock is NOT held across it: a caller that gives up
+    // on a join that never completes (comm.py: a deadline on a helper thread) must still be able to use the rest of the library
+    // - the file-barrier fallback of the HOD leg populates on this same process - instead of queueing behind a dead call.
+    const ncclResult_t r = R.CommInitRank(&c->nccl, world, u, rank);
+    ABACUS_ENTER();
     if (r != ncclSuccess) {
         delete c;
         return fail("ncclCommInitRank(rank %d of %d): %s", rank, world, R.GetErrorString(r));

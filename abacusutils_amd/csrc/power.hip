@@ -563,6 +563,37 @@ __global__ void helper_delta_mu2(const float2 *__restrict__ d, float2 *__restric
     }
 }
 
+// get_raw_power (:707-727): |a|^2, or Re(conj(a) b)
+__global__ void helper_raw_power(const float2 *__restrict__ a, const float2 *__restrict__ b, float *__restrict__ out, int64_t total) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const float2 u = a[q];
+        if (b) {
+            const float2 v = b[q];
+            out[q] = u.x * v.x + u.y * v.y;                      // (conj(u) v).real
+        } else {
+            const float m = hypotf(u.x, u.y);                    // np.abs(z) ** 2, like the reference
+            out[q] = m * m;
+        }
+    }
+}
+
+// shift_field_fft (:904-948): f += s * exp(i (d / 2) (kx + ky + kz)); f *= 0.5 / n^3 - float32 wavenumbers as the reference
+// forms them (k = f32(i) dk below n / 2, f32(i - n) dk from there on: the Nyquist plane takes the negative branch)
+__global__ void helper_shift_field(float2 *__restrict__ f, const float2 *__restrict__ s, int n, float dk, float halfd, float norm) {
+    const int kzlen = n / 2 + 1;
+    const int64_t total = (int64_t)n * n * kzlen;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(q % kzlen), j = (int)((q / kzlen) % n), i = (int)(q / ((int64_t)kzlen * n));
+        const float kx = i < n / 2 ? (float)i * dk : (float)(i - n) * dk, ky = j < n / 2 ? (float)j * dk : (float)(j - n) * dk,
+                    kz = (float)k * dk;
+        const float ph = halfd * (kx + ky + kz);
+        float sn, cs;
+        sincosf(ph, &sn, &cs);
+        const float2 a = f[q], b = s[q];
+        f[q] = make_float2((a.x + (b.x * cs - b.y * sn)) * norm, (a.y + (b.x * sn + b.y * cs)) * norm);
+    }
+}
+
 // expand_poles_to_3d (:451-505) with linear_interp (:508-537): Pk = sum_l interp(P_l)(|k|) * P_l(mu)
 __global__ void helper_expand_poles(float *__restrict__ out, int n, float dk, const float *__restrict__ k_ell,
                                     const float *__restrict__ P_ell, int nk, BinArgs b, int np_all,
@@ -1519,6 +1550,38 @@ int abacus_get_delta_mu2(const void *delta_c64, int n1d, void *out_c64) {
     ABACUS_LAUNCH("helper_delta_mu2", helper_delta_mu2, dim3(helper_grid(total)), dim3(256), 0, g_ctx.mesh[0].as<float2>(),
                   g_ctx.mesh[1].as<float2>(), n1d);
     HIP_TRY(hipMemcpyAsync(out_c64, g_ctx.mesh[1].p, (size_t)total * 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_raw_power(const void *field_c64, const void *field2_c64, int64_t total, float *out) {
+    ABACUS_ENTER();
+    if (!field_c64 || !out || total < 0) return fail("abacus_raw_power: bad arguments");
+    if (total == 0) return 0;
+    ABACUS_TRY(g_ctx.mesh[0].reserve((size_t)total * 8));
+    if (field2_c64) ABACUS_TRY(g_ctx.mesh[1].reserve((size_t)total * 8));
+    ABACUS_TRY(g_ctx.helper_in.reserve((size_t)total * 4));
+    HIP_TRY(hipMemcpyAsync(g_ctx.mesh[0].p, field_c64, (size_t)total * 8, hipMemcpyHostToDevice, stream()));
+    if (field2_c64) HIP_TRY(hipMemcpyAsync(g_ctx.mesh[1].p, field2_c64, (size_t)total * 8, hipMemcpyHostToDevice, stream()));
+    ABACUS_LAUNCH("helper_raw_power", helper_raw_power, dim3(helper_grid(total)), dim3(256), 0, (const float2 *)g_ctx.mesh[0].as<float2>(),
+                  (const float2 *)(field2_c64 ? g_ctx.mesh[1].as<float2>() : nullptr), g_ctx.helper_in.as<float>(), total);
+    HIP_TRY(hipMemcpyAsync(out, g_ctx.helper_in.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_shift_field_fft(void *field_c64, const void *shift_c64, int n1d, double Lbox, double d) {
+    ABACUS_ENTER();
+    if (!field_c64 || !shift_c64 || n1d < 2 || !(Lbox > 0)) return fail("abacus_shift_field_fft: bad arguments");
+    const int64_t total = (int64_t)n1d * n1d * (n1d / 2 + 1);
+    ABACUS_TRY(g_ctx.mesh[0].reserve((size_t)total * 8));
+    ABACUS_TRY(g_ctx.mesh[1].reserve((size_t)total * 8));
+    HIP_TRY(hipMemcpyAsync(g_ctx.mesh[0].p, field_c64, (size_t)total * 8, hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemcpyAsync(g_ctx.mesh[1].p, shift_c64, (size_t)total * 8, hipMemcpyHostToDevice, stream()));
+    const float dk = (float)(2.0 * M_PI / Lbox), halfd = (float)(0.5 * (double)(float)d), norm = (float)(0.5 / ((double)n1d * n1d * n1d));
+    ABACUS_LAUNCH("helper_shift_field", helper_shift_field, dim3(helper_grid(total)), dim3(256), 0, g_ctx.mesh[0].as<float2>(),
+                  (const float2 *)g_ctx.mesh[1].as<float2>(), n1d, dk, halfd, norm);
+    HIP_TRY(hipMemcpyAsync(field_c64, g_ctx.mesh[0].p, (size_t)total * 8, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;
 }

@@ -47,11 +47,12 @@ struct Tmp {   // device allocations of one call, released on every exit path
 };
 
 // ---- halos: kept fraction, mask, particle target --------------------------------------------------------------------------
-__global__ void prep_halo_factors(const unsigned int *__restrict__ N, int64_t n, double Mpart, int MT,
+// mass = N[i] * Mpart (halos counted in whole particles, prepare_slab's `halos['N'] * Mpart`), or mass64[i] when N is null
+__global__ void prep_halo_factors(const unsigned int *__restrict__ N, const double *__restrict__ mass64, int64_t n, double Mpart, int MT,
                                   const double *__restrict__ u, const long long *__restrict__ pnum, double *__restrict__ p_out,
                                   unsigned char *__restrict__ mask, int *__restrict__ ntarget) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double m = (double)N[i] * Mpart;
+        const double m = N ? (double)N[i] * Mpart : mass64[i];
         const double x = log10(m);
         double f;
         if (!MT) {                                             // LRG only (:103-108)
@@ -229,6 +230,11 @@ __device__ __forceinline__ bool key_before(double a, int ia, double b, int ib) {
     return a < b || (a == b && ia < ib);
 }
 
+// NumPy VERSION ASSUMPTION: the perihelion iteration below follows the reference's dtypes under NumPy >= 2 scalar promotion
+// (NEP 50): a float32 array element times a Python float stays float32 (1 / (log(1 + c) - c / (1 + c)) * 2 * 6.67e-11 and the
+// first iteration are float32).  Under NumPy 1.x value-based casting the same reference lines run in float64, alpha and x2
+// differ in their low bits and near-ties of `ranksp` may order differently: the goldens (oracle/make_golden.py, which
+// asserts numpy >= 2) and the "value for value" statement of DESIGN.md section 2 hold against a reference run under NumPy 2.
 __global__ __launch_bounds__(256) void prep_ranks(RankArgs A, int nwork) {
     extern __shared__ __align__(16) unsigned char smem[];
     for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
@@ -377,10 +383,26 @@ int abacus_prepare_halo_factors(const uint32_t *N, int64_t n, double Mpart, int 
     ABACUS_TRY(tmp.alloc(&dp, (size_t)n));
     if (mask) ABACUS_TRY(tmp.alloc(&dm, (size_t)n));
     if (ntarget) ABACUS_TRY(tmp.alloc(&dt, (size_t)n));
-    ABACUS_LAUNCH("prep_halo_factors", prep_halo_factors, dim3(grid_for(n)), dim3(256), 0, dN, n, Mpart, MT, du, dnum, dp, dm, dt);
+    ABACUS_LAUNCH("prep_halo_factors", prep_halo_factors, dim3(grid_for(n)), dim3(256), 0, (const unsigned int *)dN, (const double *)nullptr, n,
+                  Mpart, MT, du, dnum, dp, dm, dt);
     HIP_TRY(hipMemcpyAsync(p_halos, dp, (size_t)n * 8, hipMemcpyDeviceToHost, stream()));
     if (mask) HIP_TRY(hipMemcpyAsync(mask, dm, (size_t)n, hipMemcpyDeviceToHost, stream()));
     if (ntarget) HIP_TRY(hipMemcpyAsync(ntarget, dt, (size_t)n * 4, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_prepare_halo_factors_mass(const double *mass, int64_t n, int MT, double *p_halos) {
+    ABACUS_ENTER();
+    if (n < 0 || (n > 0 && (!mass || !p_halos))) return fail("abacus_prepare_halo_factors_mass: null argument");
+    if (n == 0) return 0;
+    Tmp tmp;
+    double *dmass, *dp;
+    ABACUS_TRY(tmp.upload(&dmass, mass, (size_t)n));
+    ABACUS_TRY(tmp.alloc(&dp, (size_t)n));
+    ABACUS_LAUNCH("prep_halo_factors", prep_halo_factors, dim3(grid_for(n)), dim3(256), 0, (const unsigned int *)nullptr, (const double *)dmass, n, 1.0,
+                  MT, (const double *)nullptr, (const long long *)nullptr, dp, (unsigned char *)nullptr, (int *)nullptr);
+    HIP_TRY(hipMemcpyAsync(p_halos, dp, (size_t)n * 8, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;
 }

@@ -678,6 +678,7 @@ size_t xbin2_lds_bytes(int n, int Nk, int Nmu, int ncell, bool comp) {
 // ---- descriptor cache (host) ---------------------------------------------------------------------------------------
 struct XDescHost {
     int n = 0, Nk = 0, Nmu = 0;
+    bool comp = false;         // part of the key: the window table shares the LDS the cell table is sized for (lds_other)
     std::vector<float> e2;     // kedges2 (Nk+1) then muedges2 (Nmu+1)
     bool ok = false;
     int ncell = 0, sh = 0, off = 0, vtop = 0;
@@ -776,10 +777,10 @@ bool xdesc_tables(int n, int Nk, int Nmu, const float *ke, const float *me, size
 }
 
 // descriptor of (n, edges): cached; built (tables + xbin_geometry over every mode) on first use
-int xdesc_get(int n, int Nk, int Nmu, const float *h_e2, const float *d_ke, const float *d_me, size_t lds_other, XDescHost **out) {
+int xdesc_get(int n, int Nk, int Nmu, bool comp, const float *h_e2, const float *d_ke, const float *d_me, size_t lds_other, XDescHost **out) {
     const size_t ne = (size_t)Nk + 1 + Nmu + 1;
     for (XDescHost *x : g_desc)
-        if (x->n == n && x->Nk == Nk && x->Nmu == Nmu && !memcmp(x->e2.data(), h_e2, ne * 4)) {
+        if (x->n == n && x->Nk == Nk && x->Nmu == Nmu && x->comp == comp && !memcmp(x->e2.data(), h_e2, ne * 4)) {
             x->stamp = ++g_desc_clock;
             *out = x;
             return 0;
@@ -794,7 +795,7 @@ int xdesc_get(int n, int Nk, int Nmu, const float *h_e2, const float *d_ke, cons
         g_desc.erase(g_desc.begin() + old);
     }
     XDescHost *x = new XDescHost;
-    x->n = n, x->Nk = Nk, x->Nmu = Nmu, x->e2.assign(h_e2, h_e2 + ne), x->stamp = ++g_desc_clock;
+    x->n = n, x->Nk = Nk, x->Nmu = Nmu, x->comp = comp, x->e2.assign(h_e2, h_e2 + ne), x->stamp = ++g_desc_clock;
     g_desc.push_back(x);
     *out = x;
     std::vector<unsigned int> lut;
@@ -884,7 +885,7 @@ static int xbin2_desc(int n, const BinArgs &b, bool comp, XDescHost **x) {
     if (option("pk_xbin_gen") == 1 || !b.h_edges2 || (n != 1024 && n != 2048) || b.Nmu > XD_USTRIDE) return 0;
     const size_t other = xbin2_lds_other(n, b.Nk, b.Nmu, comp);
     if (other + 64 * 4 > 160 * 1024) return 0;
-    ABACUS_TRY(xdesc_get(n, b.Nk, b.Nmu, b.h_edges2, b.kedges2, b.muedges2, other, x));
+    ABACUS_TRY(xdesc_get(n, b.Nk, b.Nmu, comp, b.h_edges2, b.kedges2, b.muedges2, other, x));
     if (!(*x)->ok || other + (size_t)(*x)->ncell * 4 > 160 * 1024) *x = nullptr;
     return 0;
 }

@@ -291,6 +291,32 @@ class LazyTracer(dict):
             self._load()
         return dict.pop(self, k, *default)
 
+    # writes materialise the columns first: a caller's assignment must not be overwritten by a later load, and the
+    # mock then no longer stands for what is in HBM (MockDict.device_xyz compares checksums of the loaded columns)
+    def __setitem__(self, k, v):
+        self._load()
+        dict.__setitem__(self, k, v)
+
+    def __delitem__(self, k):
+        self._load()
+        dict.__delitem__(self, k)
+
+    def update(self, *a, **kw):
+        self._load()
+        dict.update(self, *a, **kw)
+
+    def setdefault(self, k, default=None):
+        self._load()
+        return dict.setdefault(self, k, default)
+
+    def clear(self):
+        self.__dict__.pop('_staged', None)
+        dict.clear(self)
+
+    def popitem(self):
+        self._load()
+        return dict.popitem(self)
+
     def copy(self):
         self._load()
         return dict(dict.items(self))

@@ -626,10 +626,13 @@ class AbacusHOD:
         clustering['mu_binc'] = power['mu_mid'][0]
         return clustering
 
-    def apply_zcv(self, *a, **k):
+    def apply_zcv(self, mock_dict, config, load_presaved=False):
+        """signature of hod/abacus_hod.py:1474; Zel'dovich control variates (hod/zcv) are outside the MI355X hot-path scope"""
         raise NotImplementedError('Zel\'dovich control variates (hod/zcv) are outside the MI355X hot-path scope')
 
-    apply_zcv_xi = apply_zcv
+    def apply_zcv_xi(self, mock_dict, config, load_presaved=False):
+        """signature of hod/abacus_hod.py:1663; see apply_zcv"""
+        raise NotImplementedError('Zel\'dovich control variates (hod/zcv) are outside the MI355X hot-path scope')
 
     def gal_reader(self, output_dir=None, simname=None, sim_dir=None, z_mock=None, want_rsd=None, tracers=None):
         """Load `{tracer}s.dat` ECSV catalogs written by run_hod(write_to_disk=True) (:1887-1950)."""

@@ -59,13 +59,13 @@ def _halo_factors(N, Mpart, MT, u=None, pnum=None):
 
 def subsample_halos(m, MT, Mpart=None):
     """fraction of halos kept as a function of mass (:83-108), evaluated on the device.  `m` are masses; halos are counted in
-    whole particles, so pass `Mpart` for exact agreement with `halos['N'] * Mpart` (else m is taken as the count times 1)"""
-    m = np.asarray(m, dtype=np.float64)
-    if Mpart is None:
-        Mpart, N = 1.0, m
-    else:
-        N = np.rint(m / Mpart)
-    return _halo_factors(N.astype(np.uint32), float(Mpart), MT)[0]
+    whole particles, so pass `Mpart` for exact agreement with `halos['N'] * Mpart`; without it the masses are used as given"""
+    m = np.ascontiguousarray(m, dtype=np.float64)
+    if Mpart is None:            # the reference's signature: the formula on the float64 masses themselves
+        p = np.empty(len(m), dtype=np.float64)
+        _lib.check(_lib.lib().abacus_prepare_halo_factors_mass(_lib.ptr(m), C.c_int64(len(m)), int(bool(MT)), _lib.ptr(p)))
+        return p
+    return _halo_factors(np.rint(m / Mpart).astype(np.uint32), float(Mpart), MT)[0]
 
 
 def rank_in_mass_bins(values, masses, mbins):

@@ -407,6 +407,11 @@ int abacus_pk_to_xi(const float *Pk, int n, double Lbox, const double *redges, i
  * loop breaks at the first k_perp beyond the last edge (the rest of that i row is never visited): kept. */
 int abacus_bin_kppi(const float *weights, int n1d, int zdim, double Lbox, const double *kedges, int Nk, double pimax, int Npi,
                     int fourier, float *mean, int64_t *counts);
+/* get_raw_power (:707-727): |field|^2, or Re(conj(field) field2), of `total` complex64 values -> float32 */
+int abacus_raw_power(const void *field_c64, const void *field2_c64, int64_t total, float *out);
+/* shift_field_fft (:904-948), in place on `field`: (field + shift * exp(i (d / 2)(kx + ky + kz))) * 0.5 / n1d^3, float32
+ * wavenumbers as the reference forms them */
+int abacus_shift_field_fft(void *field_c64, const void *shift_c64, int n1d, double Lbox, double d);
 /* get_smoothing (:527-577), get_delta_mu2 (:580-617), expand_poles_to_3d (:451-505) */
 int abacus_get_smoothing(int n1d, double Lbox, double R, float *out);
 int abacus_get_delta_mu2(const void *delta_c64, int n1d, void *out_c64);
@@ -469,6 +474,8 @@ int abacus_fenv_rank(const double *Menv, const double *halosM, int64_t n, const 
  */
 int abacus_prepare_halo_factors(const uint32_t *N, int64_t n, double Mpart, int MT, const double *u, const int64_t *pnum,
                                 double *p_halos, uint8_t *mask, int32_t *ntarget);
+/* the reference's two-argument form, subsample_halos(m, MT) on float64 MASSES (hod/prepare_sim.py:83-108) */
+int abacus_prepare_halo_factors_mass(const double *mass, int64_t n, int MT, double *p_halos);
 int abacus_prepare_particles(int64_t nh, const uint8_t *hmask, const int64_t *pstart, const int64_t *pnum, const uint32_t *N,
                              const float *hpos, const float *hvel, const float *r25, const float *r98, int64_t npart,
                              const float *pos, const float *vel, const uint8_t *submask_in, const int32_t *ntarget, uint64_t seed,

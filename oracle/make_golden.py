@@ -21,6 +21,7 @@ What is captured
   power_cases.npz             calc_power for all paste x compensated x interlaced
         modes, cross spectra, poles, logk; bin_kmu / calc_pk_from_deltak.
 
+  power_exports.npz           bin_kmu, get_raw_power, shift_field_fft, get_interlaced_field_fft on seeded inputs
   power_helpers.npz           bin_kppi, project_3d_to_poles, pk_to_xi, expand_poles_to_3d, get_smoothing,
         get_delta_mu2 on seeded 16^3 / 21^3 inputs.
 
@@ -49,6 +50,10 @@ import warnings
 from pathlib import Path
 
 import numpy as np
+
+# the goldens record the reference's behaviour under NumPy >= 2 scalar promotion (NEP 50): prepare_sim's perihelion
+# iteration and a few float32 expressions of the spectrum code promote differently under NumPy 1.x (csrc/prepare.hip: prep_ranks)
+assert int(np.__version__.split('.')[0]) >= 2, 'golden vectors are generated under NumPy >= 2'
 
 REPO = Path(__file__).resolve().parent.parent
 REF = Path('/root/reference')
@@ -899,8 +904,48 @@ def gen_prepare():
     print('prepare_sim written', os.path.getsize(GOLD / 'prepare_sim.npz') // 1024, 'KiB')
 
 
+def gen_exports(P):
+    """the pieces of the calc_power chain the reference exports as functions of their own: bin_kmu, get_raw_power,
+    shift_field_fft, get_interlaced_field_fft (analysis/power_spectrum.py:150-300, 707-727, 904-998) on seeded inputs"""
+    warnings.simplefilter('ignore')
+    sys.path.insert(0, str(REPO))
+    from abacusutils_amd import synth
+    L = 300.0
+    out = {'meta.L': np.float64(L)}
+    for n in (16, 21):
+        kz = n // 2 + 1
+        rng = np.random.default_rng(90 + n)
+        f1 = (rng.standard_normal((n, n, kz)) + 1j * rng.standard_normal((n, n, kz))).astype(np.complex64)
+        f2 = (rng.standard_normal((n, n, kz)) + 1j * rng.standard_normal((n, n, kz))).astype(np.complex64)
+        out[f'n{n}.f1'], out[f'n{n}.f2'] = f1, f2
+        out[f'n{n}.raw_auto'] = P.get_raw_power(f1)
+        out[f'n{n}.raw_cross'] = P.get_raw_power(f1, f2)
+        ke = np.linspace(0.0, np.pi * n / L * 0.95, 8)
+        me = np.linspace(0.0, 1.0, 4)
+        out[f'n{n}.kedges'], out[f'n{n}.muedges'] = ke, me
+        res = P.bin_kmu(n, L, ke, me, out[f'n{n}.raw_auto'], poles=np.array([0, 2, 4]), nthread=1)
+        for name, a in zip(('power', 'N_mode', 'poles', 'N_mode_poles', 'k_avg'), res):
+            out[f'n{n}.kmu.{name}'] = a
+        xi = rng.standard_normal((n, n, n)).astype(np.float32)
+        re = np.linspace(0.0, L / 3, 6)
+        out[f'n{n}.xi'], out[f'n{n}.redges'] = xi, re
+        res = P.bin_kmu(n, L, re, np.array([0.0, 0.5, 1.0]), xi, poles=np.array([0, 2]), fourier=False, nthread=1)
+        for name, a in zip(('power', 'N_mode', 'poles', 'N_mode_poles', 'k_avg'), res):
+            out[f'n{n}.rmu.{name}'] = a
+        a = f1.copy()
+        P.shift_field_fft(a, f2, n, L, L / n)
+        out[f'n{n}.shifted'] = a
+        pos = synth.synth_positions(3000, L, seed=70 + n, clustered=True)
+        w = (0.5 + rng.random(3000, dtype=np.float32)).astype(np.float32)
+        out[f'n{n}.w'] = w
+        out[f'n{n}.il_tsc'] = P.get_interlaced_field_fft(pos.copy(), L, n, 'TSC', None, nthread=1)
+        out[f'n{n}.il_cic_w'] = P.get_interlaced_field_fft(pos.copy(), L, n, 'CIC', w, nthread=1)
+    np.savez_compressed(GOLD / 'power_exports.npz', **out)
+    print('power_exports written')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'catalog', 'sweep', 'ngal', 'pairs', 'prepare']
+    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'exports', 'catalog', 'sweep', 'ngal', 'pairs', 'prepare']
     G, T, P, C = import_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
     if 'hod' in which:
@@ -911,6 +956,8 @@ if __name__ == '__main__':
         gen_power(P)
     if 'helpers' in which:
         gen_helpers(P)
+    if 'exports' in which:
+        gen_exports(P)
     if 'catalog' in which:
         gen_catalog()
     if 'sweep' in which:

@@ -379,13 +379,32 @@ def get_field_fft(pos, Lbox, nmesh, paste, w, W, compensated, interlaced, nthrea
     return f
 
 
+def get_raw_power(field_fft, field2_fft=None):
+    """analysis/power_spectrum.py:707-727"""
+    if field2_fft is not None:
+        return (np.conj(field_fft) * field2_fft).real
+    return np.abs(field_fft) ** 2
+
+
+def shift_field_fft(field_fft, field_shift_fft, n1d, L, d):
+    """analysis/power_spectrum.py:904-948, in place"""
+    assert field_fft.dtype == np.complex64 and field_fft.flags.c_contiguous
+    lib().oracle_shift_field_fft(_ptr(field_fft), _ptr(np.ascontiguousarray(field_shift_fft, dtype=np.complex64)), int(n1d), _D(L), _D(d))
+
+
+def get_interlaced_field_fft(pos, Lbox, nmesh, paste, w, nthread=1):
+    """analysis/power_spectrum.py:951-998"""
+    return get_field_fft(pos, Lbox, nmesh, paste, w, None, False, True, nthread=nthread)
+
+
 def bin_kmu(n1d, L, kedges, muedges, weights, poles=np.empty(0, 'i8'), fourier=True, accum64=False, nthread=1):
     """analysis/power_spectrum.py:150-300"""
     kedges = _f8(kedges)
     muedges = _f8(muedges)
     poles = np.ascontiguousarray(poles, dtype=np.int64)
     Nk, Nmu, Np = len(kedges) - 1, len(muedges) - 1, len(poles)
-    weights = np.ascontiguousarray(weights, dtype=np.float32)
+    # a configuration-space grid is (n1d, n1d, n1d): the loops visit k < n1d // 2 + 1 of every row (:232-236)
+    weights = np.ascontiguousarray(np.asarray(weights, dtype=np.float32)[:, :, :n1d // 2 + 1])
     power = np.zeros((Nk, Nmu), dtype=np.float32)
     counts = np.zeros((Nk, Nmu), dtype=np.int64)
     bpoles = np.zeros((Np, Nk), dtype=np.float32)

@@ -121,3 +121,30 @@ def test_run_with_deadline():
         _run_with_deadline(gate.wait, 0.3, 'stuck')
     assert time.time() - t0 < 3
     gate.set()
+
+
+def test_join_timeout_is_not_turned_into_a_file_fallback(monkeypatch, tmp_path):
+    """ADVICE r03: a ncclCommInitRank / first barrier that never returns leaves a thread of this process inside the library;
+    `Dist.from_env(allow_file_fallback=True)` (the HOD leg of bench.py) must then END the rank - any other RCCL failure
+    still falls back to the file barrier and reports the error"""
+    from abacusutils_amd import comm
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.setenv('ABACUS_RDZV_DIR', str(tmp_path))
+
+    def stuck(cls, **kw):
+        raise comm.RcclJoinTimeout('rank 0/2: ncclCommInitRank did not return')
+
+    monkeypatch.setattr(comm.RcclComm, 'from_env', classmethod(stuck))
+    with pytest.raises(comm.RcclJoinTimeout):
+        comm.Dist.from_env(allow_file_fallback=True, key='t_join')
+    assert issubclass(comm.RcclJoinTimeout, TimeoutError)
+
+    def refused(cls, **kw):
+        raise RuntimeError('ncclCommInitRank: invalid usage (duplicate device)')
+
+    monkeypatch.setattr(comm.RcclComm, 'from_env', classmethod(refused))
+    d = comm.Dist.from_env(allow_file_fallback=True, key='t_join')
+    assert isinstance(d.comm, comm.FileComm) and 'duplicate device' in d.rccl_error
+    with pytest.raises(RuntimeError):
+        comm.Dist.from_env(allow_file_fallback=False, key='t_join')

@@ -47,6 +47,28 @@ def test_lazy_tracer_refuses_a_replaced_catalogue():
     assert t['Ncent'] == 0                  # the count never needed the device
 
 
+def test_writes_to_a_lazy_tracer_materialise_it_first():
+    """an assignment into a never-read lazy tracer must survive the load of the other columns, and the tracer
+    then counts as read (MockDict.device_xyz compares checksums of loaded columns, so an edited x is seen)"""
+    for write in (lambda t: t.__setitem__('x', np.full(5, -1.0)), lambda t: t.update(x=np.full(5, -1.0)),
+                  lambda t: t.setdefault('w', np.ones(5))):
+        st = FakeStaged()
+        t = LazyTracer(st, 'LRG', 2)
+        write(t)
+        assert st.fetched == 1 and '_staged' not in t.__dict__          # loaded BEFORE the write, no longer lazy
+        np.testing.assert_array_equal(t['y'], np.arange(5.0) + 1)       # reading another column does not reload
+        assert st.fetched == 1
+        if 'w' in t:
+            np.testing.assert_array_equal(t['x'], np.arange(5.0))
+        else:
+            np.testing.assert_array_equal(t['x'], np.full(5, -1.0))     # the caller's column is still there
+    st = FakeStaged()
+    t = LazyTracer(st, 'LRG', 2)
+    st.generation += 1
+    with pytest.raises(RuntimeError, match='never read'):
+        t['x'] = 0                                                       # stale: a write refuses like a read
+
+
 def test_mock_dict_pickles_as_a_plain_dict():
     st = FakeStaged()
     m = MockDict({'LRG': st.fetch('LRG'), 'ELG': LazyTracer(st, 'ELG', 2)})._bind(st)

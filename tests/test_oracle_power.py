@@ -145,3 +145,33 @@ def test_analytic_known_answer_matches_calc_power(paste, comp, inter):
     np.testing.assert_allclose(got['power'], ref['power'], rtol=5e-6, atol=5e-6 * scale)
     np.testing.assert_allclose(got['poles'], ref['poles'], rtol=5e-6, atol=5e-6 * scale)
     np.testing.assert_allclose(got['k_avg'], ref['k_avg'], rtol=1e-6)
+
+
+@pytest.mark.parametrize('n', [16, 21])
+def test_exported_pieces_against_reference_goldens(n):
+    """bin_kmu, get_raw_power, shift_field_fft, get_interlaced_field_fft of the reference (tests/golden/power_exports.npz,
+    oracle/make_golden.py exports) restated by the oracle"""
+    g = load_golden('power_exports')
+    Lb = float(g['meta.L'])
+    f1, f2 = g[f'n{n}.f1'], g[f'n{n}.f2']
+    np.testing.assert_allclose(oracle.get_raw_power(f1), g[f'n{n}.raw_auto'], rtol=1e-6)
+    np.testing.assert_allclose(oracle.get_raw_power(f1, f2), g[f'n{n}.raw_cross'], rtol=1e-5, atol=1e-6)
+    res = oracle.bin_kmu(n, Lb, g[f'n{n}.kedges'], g[f'n{n}.muedges'], g[f'n{n}.raw_auto'], poles=np.array([0, 2, 4]))
+    for name, a in zip(('power', 'N_mode', 'poles', 'N_mode_poles', 'k_avg'), res):
+        if name.startswith('N_'):
+            np.testing.assert_array_equal(a, g[f'n{n}.kmu.{name}'])
+        else:
+            assert_spectrum_close(a, g[f'n{n}.kmu.{name}'], rtol=1e-5, err_msg=name)
+    res = oracle.bin_kmu(n, Lb, g[f'n{n}.redges'], np.array([0.0, 0.5, 1.0]), g[f'n{n}.xi'], poles=np.array([0, 2]), fourier=False)
+    for name, a in zip(('power', 'N_mode', 'poles', 'N_mode_poles', 'k_avg'), res):
+        if name.startswith('N_'):
+            np.testing.assert_array_equal(a, g[f'n{n}.rmu.{name}'])
+        else:
+            assert_spectrum_close(a, g[f'n{n}.rmu.{name}'], rtol=1e-5, err_msg=name)
+    a = f1.copy()
+    oracle.shift_field_fft(a, f2, n, Lb, Lb / n)
+    assert np.abs(a - g[f'n{n}.shifted']).max() <= 2e-6 * np.abs(g[f'n{n}.shifted']).max()
+    pos = synth.synth_positions(3000, Lb, seed=70 + n, clustered=True)
+    for key, paste, w in ((f'n{n}.il_tsc', 'TSC', None), (f'n{n}.il_cic_w', 'CIC', g[f'n{n}.w'])):
+        b = oracle.get_interlaced_field_fft(pos.copy(), Lb, n, paste, w)
+        assert b.dtype == np.complex64 and np.abs(b - g[key]).max() <= 3e-6 * np.abs(g[key]).max(), key

@@ -605,3 +605,43 @@ def test_fused_last_pass_random_edges(options, seed):
         np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)
         if poles:
             np.testing.assert_allclose(a['poles'], b['poles'], rtol=3e-6, atol=5e-7 * scale)
+
+
+@pytest.mark.parametrize('n', [16, 21])
+def test_exported_pieces_of_the_chain(n):
+    """bin_kmu, get_raw_power, shift_field_fft, get_interlaced_field_fft as callables of their own with the reference's
+    signatures (analysis/power_spectrum.py:150-300, 707-727, 904-998), against what the reference returned
+    (tests/golden/power_exports.npz)"""
+    from abacusutils_amd.analysis import power_spectrum as ps
+    g = load_golden('power_exports')
+    Lb = float(g['meta.L'])
+    f1, f2 = g[f'n{n}.f1'], g[f'n{n}.f2']
+    raw = ps.get_raw_power(f1)
+    assert raw.dtype == np.float32 and raw.shape == f1.shape
+    np.testing.assert_allclose(raw, g[f'n{n}.raw_auto'], rtol=1e-6)
+    np.testing.assert_allclose(ps.get_raw_power(f1, f2), g[f'n{n}.raw_cross'], rtol=1e-5, atol=1e-6)
+    res = ps.bin_kmu(n, Lb, g[f'n{n}.kedges'], g[f'n{n}.muedges'], g[f'n{n}.raw_auto'], poles=np.array([0, 2, 4]))
+    for name, a in zip(('power', 'N_mode', 'poles', 'N_mode_poles', 'k_avg'), res):
+        want = g[f'n{n}.kmu.{name}']
+        assert a.shape == want.shape and a.dtype == want.dtype, name
+        if name.startswith('N_'):
+            np.testing.assert_array_equal(a, want)
+        else:
+            assert_spectrum_close(a, want, rtol=1e-5, err_msg=name)
+    res = ps.bin_kmu(n, Lb, g[f'n{n}.redges'], np.array([0.0, 0.5, 1.0]), g[f'n{n}.xi'], poles=np.array([0, 2]), fourier=False)
+    for name, a in zip(('power', 'N_mode', 'poles', 'N_mode_poles', 'k_avg'), res):
+        want = g[f'n{n}.rmu.{name}']
+        if name.startswith('N_'):
+            np.testing.assert_array_equal(a, want)
+        else:
+            assert_spectrum_close(a, want, rtol=1e-5, err_msg=name)
+    a = f1.copy()
+    assert ps.shift_field_fft(a, f2, n, Lb, Lb / n) is None          # in place, like the reference
+    assert np.abs(a - g[f'n{n}.shifted']).max() <= 2e-6 * np.abs(g[f'n{n}.shifted']).max()
+    pos = synth.synth_positions(3000, Lb, seed=70 + n, clustered=True)
+    for key, paste, w in ((f'n{n}.il_tsc', 'TSC', None), (f'n{n}.il_cic_w', 'CIC', g[f'n{n}.w'])):
+        b = ps.get_interlaced_field_fft(pos.copy(), Lb, n, paste, w)
+        assert b.dtype == np.complex64 and b.shape == g[key].shape
+        assert np.abs(b - g[key]).max() <= 5e-6 * np.abs(g[key]).max(), key
+    with pytest.raises(NotImplementedError):
+        ps.get_raw_power(f1.astype(np.complex128))

@@ -335,3 +335,15 @@ def test_device_random_columns_distributions_and_shards():
     np.testing.assert_array_equal(H['randoms_exp'][:300], eo)
     np.testing.assert_array_equal(H['randoms_gaus_vrms'][:300], go)
     np.testing.assert_array_equal(m, po.device_uniform(5, 1000 + np.arange(len(m)), 6) < po.subsample_halos(halos['N'] * Mpart, True))
+
+
+@pytest.mark.parametrize('MT', [False, True])
+def test_subsample_halos_on_masses_like_the_reference(MT):
+    """subsample_halos(m, MT) with the reference's two arguments evaluates the formula on the float64 MASSES
+    (hod/prepare_sim.py:83-108) - masses up to 1e15 used to be cast to uint32 particle counts"""
+    from abacusutils_amd.hod.prepare_sim import subsample_halos
+    from oracle import prepare_oracle as po
+    m = np.concatenate([10 ** np.random.default_rng(4).uniform(10.5, 15.2, 20000), [1e11, 1e12, 2.5e11, 4e11, 1e13, 9.99e12, 1e15]])
+    np.testing.assert_allclose(subsample_halos(m, MT), po.subsample_halos(m, MT), rtol=1e-13, atol=1e-300)
+    Mpart = 2.109081520453063e9
+    np.testing.assert_allclose(subsample_halos(m, MT, Mpart), po.subsample_halos(np.rint(m / Mpart) * Mpart, MT), rtol=1e-13, atol=1e-300)
