@@ -417,3 +417,179 @@ def save_subsample(halo_table, particle_table, halo_fn, particle_fn):
     for fn, name, tab in ((halo_fn, 'halos', halo_table), (particle_fn, 'particles', particle_table)):
         with h5py.File(fn, 'w') as f:
             f.create_dataset(name, data=compound(tab))
+
+
+# ---- the reference's drivers: one slab from the CompaSO files, and the loop over a simulation's slabs ------------------------
+def load_env_halos(slabname, cleaning, filter_func=None):
+    """the four columns the padded environment needs from a neighbouring slab (:53-66)"""
+    from ..data.compaso_halo_catalog import CompaSOHaloCatalog
+    cat = CompaSOHaloCatalog(slabname, fields=['N', 'x_L2com', 'r98_L2com', 'id'], cleaned=cleaning, filter_func=filter_func)
+    halos = cat.halos
+    if cleaning:
+        halos = halos[halos['N'] > 0]
+    return halos
+
+
+def _slab_paths(i, savedir, newseed, MT, want_ranks):
+    """output names of slab i (:316-343)"""
+    halos = f'{savedir}/halos_xcom_{i}_seed{newseed}_abacushod_oldfenv'
+    parts = f'{savedir}/particles_xcom_{i}_seed{newseed}_abacushod_oldfenv'
+    if MT:
+        halos += '_MT'
+        parts += '_MT'
+    if want_ranks:
+        parts += '_withranks'
+    return halos + '_new.h5', parts + '_new.h5', f'{savedir}/env_xcom_{i}_abacushod_localenv_new.h5'
+
+
+def prepare_slab(i, savedir, simdir, simname, z_mock, z_type, tracer_flags, MT, want_ranks, want_AB, want_shear, shearmark,
+                 cleaning, newseed, halo_lc=False, nthread=1, overwrite=1, mcut=1e11, rad_outer=10, numslabs=None,
+                 return_tables=False):
+    """Subsample slab i of a simulation for the HOD (hod/prepare_sim.py:295-1052, the reference's signature): load the slab's
+    CompaSO halos and subsample-A particles (abacusutils_amd.data.compaso_halo_catalog), run the subsampling on the device
+    (`prepare_slab_arrays(rng='numpy')`: NumPy's global generator, seeded and consumed like the reference, so the tables come
+    out value for value), write the reference's three HDF5 files.  Returns 0 like the reference; `return_tables=True`
+    (extension) returns (halo table, particle table, env sidecar or None) and writes files only if h5py is importable."""
+    import os
+
+    from ..data.compaso_halo_catalog import CompaSOHaloCatalog
+    fn_halos, fn_parts, fn_env = _slab_paths(i, savedir, newseed, MT, want_ranks)
+    print('processing slab ', i)
+    lc_seed = reference_seed(newseed, i)                                             # (:345-347)
+    need_env_file = want_AB and (not halo_lc)
+    if (not int(overwrite)) and os.path.exists(fn_halos) and os.path.exists(fn_parts) and ((not need_env_file) or os.path.exists(fn_env)):
+        print('files exists, skipping ', i)
+        return 0
+    zdir = 'z' + str(z_mock).ljust(5, '0')
+    if halo_lc:
+        slabname = f'{simdir}/{simname}/{zdir}/lc_halo_info.asdf'
+        id_key, pos_key, vel_key, N_key = 'index_halo', 'pos_interp', 'vel_interp', 'N_interp'
+    else:
+        slabname = f'{simdir}/{simname}/halos/{zdir}/halo_info/halo_info_{str(i).zfill(3)}.asdf'
+        id_key, pos_key, vel_key, N_key = 'id', 'x_L2com', 'v_L2com', 'N'
+    fields = [N_key, pos_key, vel_key, 'r90_L2com', 'r25_L2com', 'r98_L2com', 'npstartA', 'npoutA', id_key, 'sigmav3d_L2com']
+    with_parts = z_type in ('primary', 'lightcone')
+    if not with_parts:
+        raise NotImplementedError('prepare_slab at a secondary redshift (no particle subsamples on disk): the reference itself '
+                                  'goes on to use the particles it did not load (:804-806)')
+    cat = CompaSOHaloCatalog(slabname, subsamples=dict(A=True, rv=True), fields=fields, cleaned=cleaning)
+    assert halo_lc == cat.halo_lc
+    halos = cat.halos
+    if halo_lc:
+        halos['id'], halos['x_L2com'], halos['v_L2com'], halos['N'] = halos[id_key], halos[pos_key], halos[vel_key], halos[N_key]
+    parts = cat.subsamples
+    if cleaning:
+        # the subsample indexing of the halos that stay is untouched by the selection: npstartA still addresses `parts`
+        halos = halos[halos['N'] > 0]
+    header = cat.header
+    Lbox, Mpart, h = header['BoxSizeHMpc'], header['ParticleMassHMsun'], header['H0'] / 100.0
+    env = None
+    if want_AB and not halo_lc:
+        if numslabs is None:
+            raise ValueError('prepare_slab needs numslabs for the padded env calculation.')
+        dx_slab = Lbox / numslabs
+        x_center = -0.5 * Lbox + (i + 0.5) * dx_slab
+        xu = x_center + _periodic_dx(np.asarray(halos['x_L2com'])[:, 0], x_center, Lbox)
+        neighbours = []
+        for d in range(1, max(1, int(np.ceil(rad_outer / dx_slab))) + 1):            # (:651-704)
+            for j, edge in (((i - d) % numslabs, xu.min()), ((i + d) % numslabs, xu.max())):
+                name = f'{simdir}/{simname}/halos/{zdir}/halo_info/halo_info_{str(j).zfill(3)}.asdf'
+                nb = load_env_halos(name, cleaning, filter_func=lambda t, e=edge: np.abs(_periodic_dx(t['x_L2com'][:, 0], e, Lbox)) <= rad_outer)
+                if len(nb):
+                    neighbours.append(nb)
+        env = slab_environment(i, halos, neighbours, numslabs, Lbox, Mpart, rad_outer=rad_outer, mcut=mcut)
+    origins = np.asarray(header['LightConeOrigins']).reshape(-1, 3) if halo_lc and 'LightConeOrigins' in header else None
+    H, P, _ = prepare_slab_arrays(dict(halos), {'pos': parts['pos'], 'vel': parts['vel']}, Mpart, h, MT, want_ranks=want_ranks,
+                                  want_AB=want_AB, shearmark=shearmark if want_shear else None, Lbox=Lbox, mcut=mcut,
+                                  halo_lc=halo_lc, rng='numpy', origins=origins, lc_seed=lc_seed, rad_outer=rad_outer)
+    try:
+        import h5py  # noqa: F401
+        have_h5 = True
+    except ImportError:
+        have_h5 = False
+        if not return_tables:
+            raise ImportError('prepare_slab writes HDF5 files like the reference and needs h5py (or pass return_tables=True and hand '
+                              'the tables to AbacusHOD.from_prepared)') from None
+    if have_h5:
+        import h5py
+        os.makedirs(savedir, exist_ok=True)
+        if env is not None:                                                          # (:748-756)
+            if os.path.exists(fn_env):
+                os.remove(fn_env)
+            with h5py.File(fn_env, 'w') as f:
+                for k, v in zip(('id', 'mass', 'Menv'), env):
+                    f.create_dataset(k, data=v)
+        for fn in (fn_halos, fn_parts):
+            if os.path.exists(fn):
+                os.remove(fn)
+        save_subsample(H, P, fn_halos, fn_parts)
+    if return_tables:
+        return H, P, env
+    return 0
+
+
+_PRIMARY_Z = [3.0, 2.5, 2.0, 1.7, 1.4, 1.1, 0.8, 0.5, 0.4, 0.3, 0.2, 0.1, 0.0]
+_SECONDARY_Z = [0.15, 0.25, 0.35, 0.45, 0.575, 0.65, 0.725, 0.875, 0.95, 1.025, 1.175, 1.25, 1.325, 1.475, 1.55, 1.625, 1.85, 2.25,
+                2.75, 3.0, 5.0, 8.0]
+
+
+def main(path2config, params=None, alt_simname=None, alt_z=None, newseed=600, halo_lc=False, overwrite=1):
+    """prepare_sim for every slab of the simulation a config names (hod/prepare_sim.py:1130-1291, the reference's signature).
+    The slabs are prepared one after the other in this process (the reference spreads them over a process pool; a GPU process
+    is not forked)."""
+    import os
+    from pathlib import Path
+
+    import yaml
+    print('compiling compaso halo catalogs into subsampled catalogs')
+    config = yaml.safe_load(open(path2config))
+    if params:
+        config.update(params)
+    if alt_simname:
+        config['sim_params']['sim_name'] = alt_simname
+    if alt_z:
+        config['sim_params']['z_mock'] = alt_z
+    simname, simdir = config['sim_params']['sim_name'], config['sim_params']['sim_dir']
+    z_mock = float(config['sim_params']['z_mock'])
+    savedir = config['sim_params']['subsample_dir'] + simname + '/z' + str(z_mock).ljust(5, '0')
+    cleaning = config['sim_params']['cleaned_halos']
+    if 'halo_lc' in config['sim_params']:
+        halo_lc = config['sim_params']['halo_lc']
+    if halo_lc:
+        ztype = 'lightcone'
+    elif z_mock in _PRIMARY_Z:
+        ztype = 'primary'
+    elif z_mock in _SECONDARY_Z:
+        ztype = 'secondary'
+    else:
+        raise Exception('illegal redshift')
+    if halo_lc:
+        halo_info_fns = [str(Path(simdir) / Path(simname) / ('z%4.3f' % z_mock) / 'lc_halo_info.asdf')]
+    else:
+        search_path = Path(simdir) / Path(simname) / 'halos' / ('z%4.3f' % z_mock) / 'halo_info'
+        halo_info_fns = list(sorted(search_path.glob('*.asdf')))
+        if not halo_info_fns:
+            raise ValueError(f'no halo info files found in {search_path}')
+    numslabs = len(halo_info_fns)
+    os.makedirs(savedir, exist_ok=True)
+    tracer_flags = config['HOD_params']['tracer_flags']
+    MT = bool(tracer_flags['ELG'] or tracer_flags['QSO'])
+    want_ranks = config['HOD_params'].get('want_ranks', False)
+    want_AB = config['HOD_params'].get('want_AB', False)
+    want_shear = config['HOD_params'].get('want_shear', False)
+    shearmark = None
+    if want_shear:
+        if (not ztype == 'primary') and (not halo_lc):
+            raise Exception('redshift does not have particle data, cant compute shear')
+        Ndim, Rsm = config['HOD_params'].get('shear_N', 1000), config['HOD_params'].get('shear_R', 2)
+        partdown = config['HOD_params'].get('partdown', 100)
+        shear_fn = savedir + '/shear_N' + str(Ndim) + '_R' + str(Rsm) + '_down' + str(partdown)
+        if os.path.exists(shear_fn + '.npy'):
+            shearmark = np.load(shear_fn + '.npy')
+        else:
+            raise NotImplementedError('the shear field (calc_shearmark, :1055-1127: field particles, smoothing, tidal tensor) is not '
+                                      f'computed by the MI355X build: supply {shear_fn}.npy')
+    for i in range(numslabs):
+        prepare_slab(i, savedir=savedir, simdir=simdir, simname=simname, z_mock=z_mock, z_type=ztype, tracer_flags=tracer_flags,
+                     MT=MT, want_ranks=want_ranks, want_AB=want_AB, want_shear=want_shear, shearmark=shearmark, cleaning=cleaning,
+                     newseed=newseed, halo_lc=halo_lc, nthread=1, overwrite=overwrite, numslabs=numslabs)

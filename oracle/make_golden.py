@@ -944,8 +944,59 @@ def gen_exports(P):
     print('power_exports written')
 
 
+def gen_mini_prepare():
+    """the reference-HELD pin of prepare_sim (tests/test_hod.py:89-100): its Mini_N64_L32 subsample files (all three slabs) as
+    arrays -> prepare_mini.npz; the reference reader's own catalogues of that simulation (tests/ref_data/test_halos_clean.asdf,
+    test_halos_unclean.asdf, test_subsamples_clean.asdf, test_subsamples_unclean.asdf: outputs of the real CompaSOHaloCatalog,
+    tests/test_data.py:29-158) for the columns the MI355X reader unpacks -> compaso_mini.npz; and the simulation's input files
+    this needs (halo_info, halo_rv / halo_pid A and B, cleaned_halo_info, cleaned_rvpid: the reference's test DATA) copied to
+    tests/golden/Mini_N64_L32/ in the reference's directory layout"""
+    import shutil
+    sys.path.insert(0, str(REPO))
+    from abacusutils_amd.data.asdf import AsdfFile
+    sub = REF / 'tests' / 'ref_hod' / 'Mini_N64_L32' / 'z0.000'
+    out = {}
+    for i in range(3):
+        for kind, dset in (('halos', 'halos'), ('particles', 'particles')):
+            a = read_h5(sub / f'{kind}_xcom_{i}_seed600_abacushod_oldfenv_MT_new.h5', dset)
+            for name in a.dtype.names:
+                out[f's{i}.{kind}.{name}'] = np.ascontiguousarray(a[name])
+    np.savez_compressed(GOLD / 'prepare_mini.npz', **out)
+    cols = ['id', 'npstartA', 'npstartB', 'npoutA', 'npoutB', 'N', 'x_L2com', 'v_L2com', 'sigmav3d_L2com', 'r100_L2com', 'r25_L2com',
+            'r50_L2com', 'r90_L2com', 'r98_L2com', 'x_com', 'v_com', 'sigmav3d_com', 'r10_com', 'rvcirc_max_L2com', 'SO_radius',
+            'SO_central_particle', 'SO_central_density', 'vcirc_max_L2com', 'meanSpeed_com', 'N_merge', 'is_merged_to', 'haloindex']
+    out = {}
+    for tag in ('clean', 'unclean'):
+        af = AsdfFile(REF / 'tests' / 'ref_data' / f'test_halos_{tag}.asdf')
+        for c in cols:
+            if c in af.names():
+                out[f'halos_{tag}.{c}'] = af.array(c)
+        af = AsdfFile(REF / 'tests' / 'ref_data' / f'test_subsamples_{tag}.asdf')
+        for c in af.names():
+            out[f'subsamples_{tag}.{c}'] = af.array(c)
+    np.savez_compressed(GOLD / 'compaso_mini.npz', **out)
+    dst = GOLD / 'Mini_N64_L32'
+    if dst.exists():
+        shutil.rmtree(dst)
+    src = REF / 'tests' / 'Mini_N64_L32' / 'halos' / 'z0.000'
+    for d in ('halo_info', 'halo_rv_A', 'halo_rv_B', 'halo_pid_A', 'halo_pid_B'):
+        (dst / 'Mini_N64_L32' / 'halos' / 'z0.000' / d).mkdir(parents=True)
+        for f in sorted((src / d).glob('*.asdf')):
+            shutil.copyfile(f, dst / 'Mini_N64_L32' / 'halos' / 'z0.000' / d / f.name)
+    csrc = REF / 'tests' / 'cleaning' / 'Mini_N64_L32' / 'z0.000'
+    for d in ('cleaned_halo_info', 'cleaned_rvpid'):
+        (dst / 'cleaning' / 'Mini_N64_L32' / 'z0.000' / d).mkdir(parents=True)
+        for f in sorted((csrc / d).glob('*.asdf')):
+            shutil.copyfile(f, dst / 'cleaning' / 'Mini_N64_L32' / 'z0.000' / d / f.name)
+    shutil.copyfile(REF / 'tests' / 'abacus_hod.yaml', dst / 'abacus_hod.yaml')
+    for f in dst.rglob('*'):
+        if f.is_file():
+            f.chmod(0o644)
+    print('prepare_mini / compaso_mini written;', sum(f.stat().st_size for f in dst.rglob('*') if f.is_file()) // 1024, 'KiB of input files')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'exports', 'catalog', 'sweep', 'ngal', 'pairs', 'prepare']
+    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'exports', 'catalog', 'sweep', 'ngal', 'pairs', 'prepare', 'mini']
     G, T, P, C = import_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
     if 'hod' in which:
@@ -958,6 +1009,8 @@ if __name__ == '__main__':
         gen_helpers(P)
     if 'exports' in which:
         gen_exports(P)
+    if 'mini' in which:
+        gen_mini_prepare()
     if 'catalog' in which:
         gen_catalog()
     if 'sweep' in which:
