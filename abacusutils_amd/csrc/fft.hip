@@ -506,7 +506,15 @@ int fft_x(float2 *data, int pitch_c, Tables *t, int64_t ny_local, int64_t x_stri
 
 namespace abacus {
 
-bool fft_native_supported(int n) { return n >= 64 && n <= 2048 && (n & (n - 1)) == 0; }
+bool gfft_supported(int n, int is_double);
+int gfft_r2c_inplace_f32(float *mesh, int n, int pitch_r);
+int gfft_release();
+
+// the tuned power-of-two kernels of this file (also what the slab-decomposed transform needs)
+bool fft_native_pow2(int n) { return n >= 64 && n <= 2048 && (n & (n - 1)) == 0; }
+// ... or the mixed-radix kernels of gfft.hip (even sizes with factors 2, 3, 5, 7, 11, 13: 72, 96, 384, 550, 768, 1536 ...);
+// option fft_nogeneric sends those to hipFFT again (comparator)
+bool fft_native_supported(int n) { return fft_native_pow2(n) || (gfft_supported(n, 0) && !option("fft_nogeneric")); }
 
 // z and y passes over `nx_local` consecutive x-planes (the part of the transform that is local to an x-slab)
 int fft_native_zy(float *mesh, int n, int pitch_r, int64_t nx_local) {
@@ -541,6 +549,7 @@ int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_st
 }
 
 int fft_native_r2c_inplace(float *mesh, int n, int pitch_r) {
+    if (!fft_native_pow2(n)) return gfft_r2c_inplace_f32(mesh, n, pitch_r);
     ABACUS_TRY(fft_native_zy(mesh, n, pitch_r, n));
     return fft_native_x(mesh, n, pitch_r, n, (int64_t)n * (pitch_r / 2), pitch_r / 2);
 }
@@ -676,7 +685,7 @@ int fft_native_release() {
         ABACUS_TRY(kv.second.tw2.release());
     }
     g_tables.clear();
-    return 0;
+    return gfft_release();
 }
 
 }  // namespace abacus

@@ -1,0 +1,356 @@
+// Mixed-radix 3-D R2C transform for the meshes the power-of-two kernels of fft.hip do not cover, and for float64 meshes:
+// nmesh = 2^a 3^b 5^c 7^d 11^e 13^f (even) - AbacusHOD.compute_power's default num_cells = 550 (hod/abacus_hod.py:1347),
+// the reference's own test mesh 72 (tests/test_power.py:33), 96, 384, 768, 1536 ... - replaces scipy.fft.rfftn at
+// analysis/power_spectrum.py:980,986,1059 there.  In place on the padded R2C layout (n, n, pitch), no work area, three
+// passes, each one read + one write of the mesh:
+//   gfft_rows   rows of n reals -> n/2 + 1 complex: a length-n/2 complex transform of (x[2m], x[2m+1]) and the even / odd split;
+//   gfft_cols   y, then x: tiles of C adjacent kz columns x all n rows in LDS (C x 8 B row segments).
+// A sequence is transformed by Stockham autosort stages in LDS (natural order out, no digit reversal), one radix
+// 2 / 3 / 4 / 5 / 7 / 8 / 11 / 13 per stage from a runtime plan; a stage reads all its butterflies into registers, meets at
+// a barrier and writes them back, so the tile needs one buffer.  Templated on the scalar type: float for calc_power's
+// default, double for dtype=np.float64 meshes (analysis/power_spectrum.py:808,1148).
+// The power-of-two meshes keep the tuned kernels of fft.hip (wave-local passes, fused stages): this path runs at roughly
+// hipFFT's rate, not at theirs.
+#include <cmath>
+#include <map>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace abacus;
+
+namespace {
+
+constexpr int G_NT = 512;
+constexpr int G_MAXF = 14;
+
+template <typename T>
+struct C2 {
+    T x, y;
+};
+template <typename T>
+__device__ __forceinline__ C2<T> cmul(C2<T> a, C2<T> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+template <typename T>
+__device__ __forceinline__ C2<T> cadd(C2<T> a, C2<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T>
+__device__ __forceinline__ C2<T> csub(C2<T> a, C2<T> b) { return {a.x - b.x, a.y - b.y}; }
+
+struct GPlan {
+    int n;                 // sequence length
+    int nf;                // stages
+    int radix[G_MAXF];
+};
+
+// ---- small DFTs in registers (forward, exp(-2 pi i jk / R)), natural order in and out ----------------------------------
+template <typename T>
+__device__ __forceinline__ void dft4g(C2<T> &a0, C2<T> &a1, C2<T> &a2, C2<T> &a3) {
+    const C2<T> t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
+    a0 = cadd(t0, t2);
+    a2 = csub(t0, t2);
+    a1 = {t1.x + t3.y, t1.y - t3.x};   // t1 - i t3
+    a3 = {t1.x - t3.y, t1.y + t3.x};   // t1 + i t3
+}
+// odd prime R: out[k], out[R - k] from the sums / differences of the pairs (j, R - j): (R - 1)^2 / 2 real multiplies by cosines
+// and as many by sines
+// cos(2 pi i / R), sin(2 pi i / R) for i = 1 .. (R - 1) / 2
+template <int R>
+__host__ __device__ constexpr double trig_c(int i) {
+    if (R == 3) return -0.5;
+    if (R == 5) return i == 1 ? 0.30901699437494742410 : -0.80901699437494742410;
+    if (R == 7) return i == 1 ? 0.62348980185873353053 : i == 2 ? -0.22252093395631440429 : -0.90096886790241912624;
+    if (R == 11)
+        return i == 1 ? 0.84125353283118116886 : i == 2 ? 0.41541501300188642553 : i == 3 ? -0.14231483827328514044
+             : i == 4 ? -0.65486073394528506406 : -0.95949297361449738989;
+    return i == 1 ? 0.88545602565320989590 : i == 2 ? 0.56806474673115580251 : i == 3 ? 0.12053668025532305335
+         : i == 4 ? -0.35460488704253562597 : i == 5 ? -0.74851074817110109863 : -0.97094181742605202716;
+}
+template <int R>
+__host__ __device__ constexpr double trig_s(int i) {
+    if (R == 3) return 0.86602540378443864676;
+    if (R == 5) return i == 1 ? 0.95105651629515357212 : 0.58778525229247312917;
+    if (R == 7) return i == 1 ? 0.78183148246802980871 : i == 2 ? 0.97492791218182360702 : 0.43388373911755812048;
+    if (R == 11)
+        return i == 1 ? 0.54064081745559758211 : i == 2 ? 0.90963199535451837141 : i == 3 ? 0.98982144188093273238
+             : i == 4 ? 0.75574957435425828377 : 0.28173255684142969771;
+    return i == 1 ? 0.46472317204376854566 : i == 2 ? 0.82298386589365639458 : i == 3 ? 0.99270887409805399280
+         : i == 4 ? 0.93501624268541482344 : i == 5 ? 0.66312265824079520238 : 0.23931566428755776715;
+}
+template <typename T, int R>
+__device__ __forceinline__ void dft_prime(C2<T> (&a)[R]) {
+    constexpr int H = (R - 1) / 2;
+    C2<T> p[H], m[H];
+#pragma unroll
+    for (int j = 0; j < H; j++) p[j] = cadd(a[j + 1], a[R - 1 - j]), m[j] = csub(a[j + 1], a[R - 1 - j]);
+    C2<T> sum = a[0];
+#pragma unroll
+    for (int j = 0; j < H; j++) sum = cadd(sum, p[j]);
+    C2<T> out[R];
+    out[0] = sum;
+#pragma unroll
+    for (int k = 1; k <= H; k++) {
+        T re = a[0].x, im = a[0].y, sr = 0, si = 0;
+#pragma unroll
+        for (int j = 1; j <= H; j++) {
+            const int q = (j * k) % R;                    // cos(2 pi q / R), sin(2 pi q / R) from the half table
+            const int qi = q <= H ? q : R - q;
+            const T cq = (T)trig_c<R>(qi), sq = (T)(q <= H ? trig_s<R>(qi) : -trig_s<R>(qi));
+            re += cq * p[j - 1].x, im += cq * p[j - 1].y;
+            sr += sq * m[j - 1].x, si += sq * m[j - 1].y;
+        }
+        // out[k] = A - i B with A = (re, im), B = (sr, si): exp(-i t) = cos t - i sin t
+        out[k] = {re + si, im - sr};
+        out[R - k] = {re - si, im + sr};
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) a[k] = out[k];
+}
+template <typename T, int R>
+__device__ __forceinline__ void dftg(C2<T> (&a)[R]) {
+    if constexpr (R == 2) {
+        const C2<T> t = a[0];
+        a[0] = cadd(t, a[1]);
+        a[1] = csub(t, a[1]);
+    } else if constexpr (R == 4) {
+        dft4g(a[0], a[1], a[2], a[3]);
+    } else if constexpr (R == 8) {
+        dft4g(a[0], a[2], a[4], a[6]);
+        dft4g(a[1], a[3], a[5], a[7]);
+        const T h = (T)0.70710678118654752440;
+        const C2<T> o0 = a[1], o1 = {h * (a[3].x + a[3].y), h * (a[3].y - a[3].x)}, o2 = {a[5].y, -a[5].x},
+                    o3 = {h * (a[7].y - a[7].x), -h * (a[7].x + a[7].y)};
+        const C2<T> e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+        a[0] = cadd(e0, o0), a[4] = csub(e0, o0);
+        a[1] = cadd(e1, o1), a[5] = csub(e1, o1);
+        a[2] = cadd(e2, o2), a[6] = csub(e2, o2);
+        a[3] = cadd(e3, o3), a[7] = csub(e3, o3);
+    } else {
+        dft_prime<T, R>(a);
+    }
+}
+
+// ---- one Stockham stage over `nseq` sequences of N elements in LDS (sequence s at lds + s * pitch) ---------------------
+// thread j of a sequence: v[r] = in[j + r N/R] * W_{Ns R}^{r (j mod Ns)}; DFT_R; out[(j / Ns) Ns R + (j mod Ns) + r Ns] = v[r]
+// tw: exp(-2 pi i q / NT_) for q < NT_, NT_ = tws * N (the row pass shares the n-entry table of its even / odd split: tws = 2)
+template <typename T, int R, int MAXV>
+__device__ __forceinline__ void g_stage(C2<T> *lds, int nseq, int pitch, int N, int Ns, const C2<T> *__restrict__ tw, int tws) {
+    constexpr int MAXIT = (MAXV + R - 1) / R;
+    const int BPS = N / R, total = nseq * BPS, step = tws * (N / (Ns * R));
+    C2<T> v[MAXIT][R];
+    int off[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+        const int b = it * G_NT + threadIdx.x;
+        off[it] = -1;
+        if (b < total) {
+            const int s = b / BPS, j = b - s * BPS, q = j / Ns, k = j - q * Ns;
+            const C2<T> *c = lds + s * pitch;
+#pragma unroll
+            for (int r = 0; r < R; r++) v[it][r] = c[j + r * BPS];
+            if (Ns > 1) {
+#pragma unroll
+                for (int r = 1; r < R; r++) v[it][r] = cmul(v[it][r], tw[r * k * step]);
+            }
+            dftg<T, R>(v[it]);
+            off[it] = s * pitch + q * Ns * R + k;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++)
+        if (off[it] >= 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) lds[off[it] + r * Ns] = v[it][r];
+        }
+    __syncthreads();
+}
+
+template <typename T, int MAXV>
+__device__ __forceinline__ void g_transform(C2<T> *lds, int nseq, int pitch, const GPlan &p, const C2<T> *__restrict__ tw, int tws) {
+    int Ns = 1;
+    for (int f = 0; f < p.nf; f++) {
+        const int R = p.radix[f];
+        switch (R) {
+            case 2: g_stage<T, 2, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
+            case 3: g_stage<T, 3, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
+            case 4: g_stage<T, 4, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
+            case 5: g_stage<T, 5, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
+            case 7: g_stage<T, 7, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
+            case 8: g_stage<T, 8, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
+            case 11: g_stage<T, 11, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
+            default: g_stage<T, 13, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
+        }
+        Ns *= R;
+    }
+}
+
+// ---- rows: n reals -> n/2 + 1 complex, in place (row pitch `pitch_r` scalars) ------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t nrows, int n, int pitch_r, int nseq, GPlan p,
+                                                  const C2<T> *__restrict__ twn) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    C2<T> *lds = reinterpret_cast<C2<T> *>(smem);
+    const int Nh = n / 2, pitch = Nh + 1;
+    for (int64_t r0 = (int64_t)blockIdx.x * nseq; r0 < nrows; r0 += (int64_t)gridDim.x * nseq) {
+        const int ns = (int)min((int64_t)nseq, nrows - r0);
+        for (int q = threadIdx.x; q < ns * Nh; q += G_NT) {
+            const int s = q / Nh, m = q - s * Nh;
+            lds[s * pitch + m] = reinterpret_cast<const C2<T> *>(mesh + (r0 + s) * pitch_r)[m];
+        }
+        __syncthreads();
+        g_transform<T, MAXV>(lds, ns, pitch, p, twn, 2);
+        // X[k] = (Z[k] + conj Z[Nh - k]) / 2 - (i / 2) w^k (Z[k] - conj Z[Nh - k]),  w = exp(-2 pi i / n),  Z[Nh] = Z[0]
+        for (int q = threadIdx.x; q < ns * (Nh + 1); q += G_NT) {
+            const int s = q / (Nh + 1), k = q - s * (Nh + 1);
+            const C2<T> zk = lds[s * pitch + (k == Nh ? 0 : k)], zm = lds[s * pitch + (k == 0 ? 0 : Nh - k)];
+            const C2<T> e = {(T)0.5 * (zk.x + zm.x), (T)0.5 * (zk.y - zm.y)};      // even part
+            const C2<T> o = {(T)0.5 * (zk.x - zm.x), (T)0.5 * (zk.y + zm.y)};      // (Z[k] - conj Z[Nh - k]) / 2
+            const C2<T> w = k == Nh ? C2<T>{(T)-1, (T)0} : twn[k];
+            const C2<T> wo = cmul(w, o);
+            reinterpret_cast<C2<T> *>(mesh + (r0 + s) * pitch_r)[k] = {e.x + wo.y, e.y - wo.x};   // e - i w o
+        }
+        __syncthreads();
+    }
+}
+
+// ---- columns: element (row, col) of tile t at data[tile_base(t) + row * S + col] ------------------------------------------
+// tiles: outer index o < nouter (stride outer_stride) x column tile ct < ntile_c (C columns)
+template <typename T, int MAXV>
+__global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int n, int64_t S, int C, int ntile_c, int ncols,
+                                                  int64_t nouter, int64_t outer_stride, GPlan p, const C2<T> *__restrict__ twn) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    C2<T> *lds = reinterpret_cast<C2<T> *>(smem);
+    const int pitch = n + 1;
+    const int64_t ntiles = nouter * ntile_c;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t o = t / ntile_c;
+        const int c0 = (int)(t - o * ntile_c) * C, nc = min(C, ncols - c0);
+        C2<T> *base = data + o * outer_stride + c0;
+        for (int q = threadIdx.x; q < n * C; q += G_NT) {
+            const int row = q / C, c = q - row * C;
+            if (c < nc) lds[c * pitch + row] = base[(int64_t)row * S + c];
+        }
+        __syncthreads();
+        g_transform<T, MAXV>(lds, nc, pitch, p, twn, 1);
+        for (int q = threadIdx.x; q < n * C; q += G_NT) {
+            const int row = q / C, c = q - row * C;
+            if (c < nc) base[(int64_t)row * S + c] = lds[c * pitch + row];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------------
+bool make_plan(int n, GPlan &p) {
+    p.n = n, p.nf = 0;
+    int m = n;
+    for (int R : {8, 4, 2, 3, 5, 7, 11, 13})
+        while (m % R == 0 && m > 1) {
+            if (p.nf >= G_MAXF) return false;
+            p.radix[p.nf++] = R;
+            m /= R;
+        }
+    return m == 1;
+}
+
+template <typename T>
+struct GTables {
+    std::map<int, DevBuf> tw;   // n -> exp(-2 pi i q / n), q < n
+    int get(int n, const C2<T> **out) {
+        auto it = tw.find(n);
+        if (it == tw.end()) {
+            std::vector<C2<T>> h((size_t)n);
+            for (int q = 0; q < n; q++) {
+                const double a = -2.0 * M_PI * (double)q / (double)n;
+                h[q] = {(T)std::cos(a), (T)std::sin(a)};
+            }
+            DevBuf b;
+            ABACUS_TRY(b.reserve(h.size() * sizeof(C2<T>)));
+            HIP_TRY(hipMemcpyAsync(b.p, h.data(), h.size() * sizeof(C2<T>), hipMemcpyHostToDevice, stream()));
+            HIP_TRY(hipStreamSynchronize(stream()));
+            it = tw.emplace(n, b).first;
+        }
+        *out = it->second.as<C2<T>>();
+        return 0;
+    }
+    int release() {
+        for (auto &kv : tw) ABACUS_TRY(kv.second.release());
+        tw.clear();
+        return 0;
+    }
+};
+GTables<float> g_tw32;
+GTables<double> g_tw64;
+template <typename T>
+GTables<T> &tables();
+template <>
+GTables<float> &tables<float>() { return g_tw32; }
+template <>
+GTables<double> &tables<double>() { return g_tw64; }
+
+template <typename T>
+constexpr int maxv() { return sizeof(T) == 4 ? 24 : 12; }   // complex values a thread holds in a stage: 512 threads x 24 x 8 B = 96 KiB of LDS
+
+int num_cus_g() {
+    int dev = 0, ncu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    return ncu;
+}
+
+template <typename T>
+int r2c_inplace(T *mesh, int n, int pitch_r) {
+    constexpr int MAXV = maxv<T>();
+    GPlan ph, pn;
+    if (n < 4 || (n & 1) || !make_plan(n / 2, ph) || !make_plan(n, pn)) return fail("gfft: mesh size %d is not an even product of 2, 3, 5, 7, 11, 13", n);
+    const int cap = MAXV * G_NT;                                   // complex values of a tile
+    if (n > cap) return fail("gfft: mesh size %d beyond the LDS tile", n);
+    if (pitch_r < n + 2 || (pitch_r & 1)) return fail("gfft: row pitch %d too small for %d + 2", pitch_r, n);
+    const C2<T> *twn;
+    ABACUS_TRY(tables<T>().get(n, &twn));
+    const int ncu = num_cus_g();
+    {   // rows
+        const int Nh = n / 2;
+        const int nseq = std::max(1, std::min(64, cap / (Nh + 1)));
+        const size_t lds = (size_t)nseq * (Nh + 1) * sizeof(C2<T>);
+        auto kern = gfft_rows<T, MAXV>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int64_t nrows = (int64_t)n * n;
+        const unsigned int grid = (unsigned int)std::min<int64_t>(ceil_div(nrows, nseq), (int64_t)ncu * 2);
+        ABACUS_LAUNCH("gfft_rows", kern, dim3(grid), dim3(G_NT), lds, mesh, nrows, n, pitch_r, nseq, ph, twn);
+    }
+    const int pitch_c = pitch_r / 2, kzlen = n / 2 + 1;
+    int C = 1;
+    while (C * 2 <= 16 && (C * 2) * (n + 1) <= cap) C *= 2;
+    const size_t lds = (size_t)C * (n + 1) * sizeof(C2<T>);
+    auto kern = gfft_cols<T, MAXV>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int ntile_c = (kzlen + C - 1) / C;
+    const unsigned int grid = (unsigned int)std::min<int64_t>((int64_t)n * ntile_c, (int64_t)ncu * (lds > 80 * 1024 ? 1 : 2));
+    C2<T> *data = reinterpret_cast<C2<T> *>(mesh);
+    // y: for every x plane, columns along y (stride pitch_c); x: for every y row, columns along x (stride n * pitch_c)
+    ABACUS_LAUNCH("gfft_cols_y", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)pitch_c, C, ntile_c, kzlen, (int64_t)n,
+                  (int64_t)n * pitch_c, pn, twn);
+    ABACUS_LAUNCH("gfft_cols_x", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)n * pitch_c, C, ntile_c, kzlen, (int64_t)n,
+                  (int64_t)pitch_c, pn, twn);
+    return 0;
+}
+
+}  // namespace
+
+namespace abacus {
+
+// even sizes whose factors are 2, 3, 5, 7, 11, 13 and that fit the LDS tile (float: n <= 6144 by the cap, held to 4096)
+bool gfft_supported(int n, int is_double) {
+    GPlan p;
+    if (n < 8 || n > 4096 || (n & 1)) return false;
+    if (!make_plan(n, p) || !make_plan(n / 2, p)) return false;
+    return n <= (is_double ? maxv<double>() : maxv<float>()) * G_NT / 2;   // at least two columns per tile
+}
+int gfft_r2c_inplace_f32(float *mesh, int n, int pitch_r) { return r2c_inplace<float>(mesh, n, pitch_r); }
+int gfft_r2c_inplace_f64(double *mesh, int n, int pitch_r) { return r2c_inplace<double>(mesh, n, pitch_r); }
+int gfft_release() {
+    ABACUS_TRY(g_tw32.release());
+    return g_tw64.release();
+}
+
+}  // namespace abacus

@@ -45,6 +45,7 @@ int tsc_deposit_f64pos(double *pos, int64_t n, const double *w, float *grid, int
                        double offset, int wrap, double norm, int cic, double sub = 1.0);
 int tsc_release_work();
 bool fft_native_supported(int n);
+bool fft_native_pow2(int n);
 int fft_native_r2c_inplace(float *mesh, int n, int pitch_r);
 int fft_native_zy(float *mesh, int n, int pitch_r, int64_t nx_local);
 int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_stride, int64_t y_stride);
@@ -1277,7 +1278,7 @@ int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, 
                             double Lbox, double offset, double norm, int paste, double sub) {
     ABACUS_ENTER();
     ABACUS_TRY(check_common(nmesh, paste));
-    if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    if (!fft_native_pow2(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
     if (xoff < 0 || xoff >= nmesh || xoff2 >= nmesh || nx_local < 1) return fail("abacus_slab_deposit_dev: window [%d | %d, +%d)", xoff, xoff2, nx_local);
     if (xoff2 < 0 && nx_local == nmesh && xoff == 0)   // the whole periodic mesh on one rank: the single-GPU deposit (fast list build)
         return tsc_deposit_f32(pos, n, w, mesh, nmesh, pitch_r(nmesh), Lbox, offset, paste == 0, norm, paste, 0, sub);
@@ -1319,7 +1320,7 @@ static int slab_pack_launch(const void *data, void *send, int nmesh, int world, 
 // send[peer][s h + p][y_local][k] - written by the y pass itself where the fused form runs, by a pack pass otherwise.
 int abacus_slab_fft_zy_dev(float *mesh, void *send, int nmesh, int world, int64_t xsep, int xg0, int p0, int pc) {
     ABACUS_ENTER();
-    if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    if (!fft_native_pow2(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
     int h;
     ABACUS_TRY(slab_fold("abacus_slab_fft_zy_dev", nmesh, world, &h));
     if (p0 < 0 || pc < 1 || p0 + pc > h || xsep < h) return fail("abacus_slab_fft_zy_dev: pairs [%d, +%d) of %d, halves %lld planes apart", p0, pc, h, (long long)xsep);
@@ -1358,7 +1359,7 @@ int abacus_slab_unpack_dev(const void *recv, void *out, int nmesh, int world) {
 
 int abacus_slab_fft_x_dev(float *data, int nmesh, int ny_local) {
     ABACUS_ENTER();
-    if (!fft_native_supported(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
+    if (!fft_native_pow2(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
     if (slab_fused(nmesh)) return fft_native_fused_x_slab(data, nmesh, pitch_r(nmesh), ny_local);
     const int pc = pitch_r(nmesh) / 2;
     return fft_native_x(data, nmesh, pitch_r(nmesh), ny_local, pc, (int64_t)nmesh * pc);   // layout (y_local, x, k)

@@ -173,9 +173,34 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
             for tr in tracers:
                 st.fetch(tr)
         out['ms_per_step_with_d2h'] = (time.perf_counter() - t2) / 10 * 1e3
+        # run_hod(reseed=s) every step (hod/abacus_hod.py:775-839): new hrandoms / hveldev / prandoms from the device generator,
+        # then the keys and the random fields of the packed records are rebuilt before the populate - what `stage_ms` hides
+        try:
+            st.reseed(1, hsigma3d=hd['hsigma3d'])
+            st.populate(p)
+            _lib.profile_reset()
+            _lib.profile_enable(True)
+            for q in range(3):
+                st.reseed(100 + q)
+                st.populate(p)
+            _lib.profile_enable(False)
+            rk = {k: round(ms / n, 4) for k, (ms, n) in _lib.profile_get().items() if n}
+            _lib.sync()
+            t3 = time.perf_counter()
+            for q in range(10):
+                st.reseed(200 + q)
+                st.populate(p)
+            _lib.sync()
+            out['reseed'] = {'ms_per_step': (time.perf_counter() - t3) / 10 * 1e3, 'kernels_ms': rk,
+                             'note': 'st.reseed(seed) + populate per step: Philox draws for every halo and particle, keys and '
+                                     'record fields rebuilt, keys streamed (the mass-sorted index belongs to unchanged keys)'}
+        except Exception as e:   # a secondary measurement must not take the headline down
+            out['reseed'] = {'error': repr(e)}
     # roofline of the dominant kernel: algorithmic bytes of the layout it streams / HIP-event duration
     bh, bp = filter_bytes_per_object(tracers, enable_ranks)
     step_bytes = bh * nh + bp * npart + 152.0 * ngal     # + gather 88 B and write 64 B per galaxy
+    elg = 'ELG' in tracers
+    survey_bytes = (40.0 + (8.0 if elg else 0.0)) * nh + (40.0 + (9.0 if elg else 0.0) + (32.0 if enable_ranks else 0.0)) * npart + 152.0 * ngal
     if 'hod_deal' in warm:
         step_bytes = 6.0 * (cand[0] + cand[1]) + 130.0 * (cand[0] + cand[1]) + 192.0 * ngal   # index path: no key stream
     kern = dict(warm)
@@ -199,6 +224,11 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
                            'frac': ach / HBM_PEAK_GBS,
                            'traffic': pmc_traffic('hod', dom_name) if c2 else None,
                            'algorithmic_bytes': fbytes,
+                           # SURVEY.md 8d's yardstick for the WHOLE step - 40 B per halo and per particle streamed, 152 B per
+                           # galaxy - beside the bytes this implementation really touches: a survey_frac above 1 says the step does
+                           # not stream the catalogue at all (candidates are prefixes of a mass-sorted key index built at staging)
+                           'survey_bytes': survey_bytes,
+                           'survey_frac': survey_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                            'layout': {
                                'hod_filter': f'packed filter keys built at staging ({bh:.0f} B per halo + {bp:.0f} B per particle: a 2-B key = mass bin + a '
                                              '9-bit code of a lower bound of random / weight; + 1 B of keep mask zeroed for mixes with ELG / QSO); the float64 '
@@ -346,7 +376,12 @@ def run_leg(args):
         from bench_pk import bench_pk_slab
         out = bench_pk_slab(args, dist)
     if dist.comm is not None:
-        out['rccl'] = dist.comm.info()
+        info = dist.comm.info()
+        # what EVERY rank saw, gathered through the communicator itself (one scalar all-reduce per rank: under torchrun the
+        # orchestrator of rank 0 only ever sees its own child): ranks that took part, bytes each put on the links
+        sent = [dist.sum(float(info.get('bytes_sent', 0)) if dist.rank == r else 0.0) for r in range(dist.world)]
+        seen = int(round(dist.sum(1.0)))
+        out['rccl'] = dict(info, ranks_seen=seen, bytes_sent_per_rank=[int(b) for b in sent])
         if dist.rccl_error:
             out['rccl']['error'] = dist.rccl_error
     if dist.rank == 0:

@@ -86,6 +86,7 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
     alg = {
         'hipfft_r2c': 24.0 * M,            # three 1-D passes x (read + write) of the 4M-byte mesh/half-spectrum
         'fft_z_r2c': 8.0 * M, 'fft_cols_y': 8.0 * M, 'fft_cols_x': 8.0 * M,   # one pass each: read 4M + write 4M
+        'gfft_rows': 8.0 * M, 'gfft_cols_y': 8.0 * M, 'gfft_cols_x': 8.0 * M,  # mixed-radix passes (csrc/gfft.hip): the same
         'fft_x_bin': 4.0 * M,              # last pass fused with the binning: one read of the half-spectrum, nothing written
         'tsc_tile_deposit': 4.0 * M + 8.0 * 1.25 * n,   # mesh written once + the 8-byte entries (1.25 per particle) read
         'spectrum_bin': 4.0 * M,

@@ -645,3 +645,29 @@ def test_exported_pieces_of_the_chain(n):
         assert np.abs(b - g[key]).max() <= 5e-6 * np.abs(g[key]).max(), key
     with pytest.raises(NotImplementedError):
         ps.get_raw_power(f1.astype(np.complex128))
+
+
+@pytest.mark.parametrize('nmesh,npart', [(72, 40_000), (96, 50_000), (110, 60_000), (182, 100_000), (384, 400_000), (550, 2_500_000)])
+def test_mixed_radix_meshes_take_the_native_transform(nmesh, npart, options):
+    """meshes with factors 3, 5, 7, 11, 13 - the reference's own test mesh 72 (tests/test_power.py:33), compute_power's default
+    num_cells = 550 (hod/abacus_hod.py:1347) - go through the hand-written mixed-radix passes of csrc/gfft.hip, not hipFFT:
+    calc_power against the oracle (scipy's pocketfft = the reference's transform) at 1e-5, and the spectrum itself against
+    the hipFFT path (option fft_nogeneric)"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power, get_field_fft
+    from oracle import oracle
+    box = 1000.0
+    pos = synth.synth_positions(npart, box, seed=nmesh, clustered=True)
+    kw = dict(kbins=20, mubins=3, k_max=np.pi * nmesh / box, paste='TSC', nmesh=nmesh, compensated=True, interlaced=True, poles=[0, 2, 4])
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    tab = calc_power(pos.copy(), box, **kw)
+    _lib.profile_enable(False)
+    prof = _lib.profile_get()
+    assert any(k.startswith('gfft_') for k in prof) and 'hipfft_r2c' not in prof, sorted(prof)
+    _check_oracle(tab, oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw))
+    if nmesh <= 182:
+        a = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, False)
+        options.set('fft_nogeneric', 1)
+        b = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, False)
+        assert np.abs(a - b).max() <= 3e-6 * np.abs(b).max()
