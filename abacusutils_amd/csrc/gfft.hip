@@ -130,11 +130,23 @@ __device__ __forceinline__ void dftg(C2<T> (&a)[R]) {
 
 // ---- one Stockham stage over `nseq` sequences of N elements in LDS (sequence s at lds + s * pitch) ---------------------
 // thread j of a sequence: v[r] = in[j + r N/R] * W_{Ns R}^{r (j mod Ns)}; DFT_R; out[(j / Ns) Ns R + (j mod Ns) + r Ns] = v[r]
-// tw: exp(-2 pi i q / NT_) for q < NT_, NT_ = tws * N (the row pass shares the n-entry table of its even / odd split: tws = 2)
+// tw: exp(-2 pi i q / NT_) for q < NT_, NT_ = tws * N (the row pass shares the n-entry table of its even / odd split: tws = 2),
+// a copy in LDS.  Element i of a sequence sits at padded position i + (i >> PADS): the writes of a stage have stride Ns
+// across r and R Ns across lanes - without the pad every lane of a wave would hit the same few banks.
+template <typename T>
+constexpr int pads() { return sizeof(T) == 4 ? 5 : 4; }      // one pad element per 256 B of a sequence
+template <typename T>
+__device__ __forceinline__ int gpad(int i) { return i + (i >> pads<T>()); }
+__host__ __device__ constexpr int gpad_len(int n, int sh) { return n + (n >> sh) + 1; }
+// floor(a / d) for a, d < 65536 by a multiply (m = 2^32 / d rounded up)
+__device__ __forceinline__ unsigned int magic_of(unsigned int d) { return 0xffffffffu / d + 1u; }
+__device__ __forceinline__ int fdiv(int a, unsigned int m) { return (int)__umulhi((unsigned int)a, m); }
+
 template <typename T, int R, int MAXV>
-__device__ __forceinline__ void g_stage(C2<T> *lds, int nseq, int pitch, int N, int Ns, const C2<T> *__restrict__ tw, int tws) {
+__device__ __forceinline__ void g_stage(C2<T> *lds, int nseq, int pitch, int N, int Ns, const C2<T> *tw, int tws) {
     constexpr int MAXIT = (MAXV + R - 1) / R;
     const int BPS = N / R, total = nseq * BPS, step = tws * (N / (Ns * R));
+    const unsigned int mB = BPS > 1 ? magic_of(BPS) : 0u, mN = Ns > 1 ? magic_of(Ns) : 0u;
     C2<T> v[MAXIT][R];
     int off[MAXIT];
 #pragma unroll
@@ -142,30 +154,32 @@ __device__ __forceinline__ void g_stage(C2<T> *lds, int nseq, int pitch, int N, 
         const int b = it * G_NT + threadIdx.x;
         off[it] = -1;
         if (b < total) {
-            const int s = b / BPS, j = b - s * BPS, q = j / Ns, k = j - q * Ns;
+            const int s = BPS > 1 ? fdiv(b, mB) : b, j = b - s * BPS, q = Ns > 1 ? fdiv(j, mN) : j, k = j - q * Ns;
             const C2<T> *c = lds + s * pitch;
 #pragma unroll
-            for (int r = 0; r < R; r++) v[it][r] = c[j + r * BPS];
+            for (int r = 0; r < R; r++) v[it][r] = c[gpad<T>(j + r * BPS)];
             if (Ns > 1) {
 #pragma unroll
                 for (int r = 1; r < R; r++) v[it][r] = cmul(v[it][r], tw[r * k * step]);
             }
             dftg<T, R>(v[it]);
-            off[it] = s * pitch + q * Ns * R + k;
+            off[it] = (q * Ns * R + k) | (s << 20);     // sequence above bit 20, element index below
         }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < MAXIT; it++)
         if (off[it] >= 0) {
+            C2<T> *c = lds + (off[it] >> 20) * pitch;
+            const int e0 = off[it] & 0xfffff;
 #pragma unroll
-            for (int r = 0; r < R; r++) lds[off[it] + r * Ns] = v[it][r];
+            for (int r = 0; r < R; r++) c[gpad<T>(e0 + r * Ns)] = v[it][r];
         }
     __syncthreads();
 }
 
 template <typename T, int MAXV>
-__device__ __forceinline__ void g_transform(C2<T> *lds, int nseq, int pitch, const GPlan &p, const C2<T> *__restrict__ tw, int tws) {
+__device__ __forceinline__ void g_transform(C2<T> *lds, int nseq, int pitch, const GPlan &p, const C2<T> *tw, int tws) {
     int Ns = 1;
     for (int f = 0; f < p.nf; f++) {
         const int R = p.radix[f];
@@ -184,27 +198,31 @@ __device__ __forceinline__ void g_transform(C2<T> *lds, int nseq, int pitch, con
 }
 
 // ---- rows: n reals -> n/2 + 1 complex, in place (row pitch `pitch_r` scalars) ------------------------------------------
+// LDS: [n twiddles][nseq sequences of gpad_len(n / 2)]
 template <typename T, int MAXV>
 __global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t nrows, int n, int pitch_r, int nseq, GPlan p,
                                                   const C2<T> *__restrict__ twn) {
     extern __shared__ __align__(16) unsigned char smem[];
-    C2<T> *lds = reinterpret_cast<C2<T> *>(smem);
-    const int Nh = n / 2, pitch = Nh + 1;
+    C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
+    C2<T> *lds = tw + n;
+    for (int q = threadIdx.x; q < n; q += G_NT) tw[q] = twn[q];
+    const int Nh = n / 2, pitch = gpad_len(Nh, pads<T>());
+    const unsigned int mH = magic_of(Nh), mH1 = magic_of(Nh + 1);
     for (int64_t r0 = (int64_t)blockIdx.x * nseq; r0 < nrows; r0 += (int64_t)gridDim.x * nseq) {
         const int ns = (int)min((int64_t)nseq, nrows - r0);
         for (int q = threadIdx.x; q < ns * Nh; q += G_NT) {
-            const int s = q / Nh, m = q - s * Nh;
-            lds[s * pitch + m] = reinterpret_cast<const C2<T> *>(mesh + (r0 + s) * pitch_r)[m];
+            const int s = fdiv(q, mH), m = q - s * Nh;
+            lds[s * pitch + gpad<T>(m)] = reinterpret_cast<const C2<T> *>(mesh + (r0 + s) * pitch_r)[m];
         }
         __syncthreads();
-        g_transform<T, MAXV>(lds, ns, pitch, p, twn, 2);
+        g_transform<T, MAXV>(lds, ns, pitch, p, tw, 2);
         // X[k] = (Z[k] + conj Z[Nh - k]) / 2 - (i / 2) w^k (Z[k] - conj Z[Nh - k]),  w = exp(-2 pi i / n),  Z[Nh] = Z[0]
         for (int q = threadIdx.x; q < ns * (Nh + 1); q += G_NT) {
-            const int s = q / (Nh + 1), k = q - s * (Nh + 1);
-            const C2<T> zk = lds[s * pitch + (k == Nh ? 0 : k)], zm = lds[s * pitch + (k == 0 ? 0 : Nh - k)];
+            const int s = fdiv(q, mH1), k = q - s * (Nh + 1);
+            const C2<T> zk = lds[s * pitch + gpad<T>(k == Nh ? 0 : k)], zm = lds[s * pitch + gpad<T>(k == 0 ? 0 : Nh - k)];
             const C2<T> e = {(T)0.5 * (zk.x + zm.x), (T)0.5 * (zk.y - zm.y)};      // even part
             const C2<T> o = {(T)0.5 * (zk.x - zm.x), (T)0.5 * (zk.y + zm.y)};      // (Z[k] - conj Z[Nh - k]) / 2
-            const C2<T> w = k == Nh ? C2<T>{(T)-1, (T)0} : twn[k];
+            const C2<T> w = k == Nh ? C2<T>{(T)-1, (T)0} : tw[k];
             const C2<T> wo = cmul(w, o);
             reinterpret_cast<C2<T> *>(mesh + (r0 + s) * pitch_r)[k] = {e.x + wo.y, e.y - wo.x};   // e - i w o
         }
@@ -213,27 +231,51 @@ __global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t 
 }
 
 // ---- columns: element (row, col) of tile t at data[tile_base(t) + row * S + col] ------------------------------------------
-// tiles: outer index o < nouter (stride outer_stride) x column tile ct < ntile_c (C columns)
+// tiles: outer index o < nouter (stride outer_stride) x column tile ct < ntile_c (C columns, C a power of two)
 template <typename T, int MAXV>
-__global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int n, int64_t S, int C, int ntile_c, int ncols,
+__global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int n, int64_t S, int lgC, int ntile_c, int ncols,
                                                   int64_t nouter, int64_t outer_stride, GPlan p, const C2<T> *__restrict__ twn) {
     extern __shared__ __align__(16) unsigned char smem[];
-    C2<T> *lds = reinterpret_cast<C2<T> *>(smem);
-    const int pitch = n + 1;
+    C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
+    C2<T> *lds = tw + n;
+    for (int q = threadIdx.x; q < n; q += G_NT) tw[q] = twn[q];
+    const int C = 1 << lgC, pitch = gpad_len(n, pads<T>());
     const int64_t ntiles = nouter * ntile_c;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // software pipeline: the next tile is requested into registers (MAXV complex values per thread) before the current one is
+    // transformed, so its loads are in flight under the stages and the stores of the current tile
+    C2<T> nx[MAXV];
+    auto tile_base = [&](int64_t t, int &nc) {
         const int64_t o = t / ntile_c;
-        const int c0 = (int)(t - o * ntile_c) * C, nc = min(C, ncols - c0);
-        C2<T> *base = data + o * outer_stride + c0;
-        for (int q = threadIdx.x; q < n * C; q += G_NT) {
-            const int row = q / C, c = q - row * C;
-            if (c < nc) lds[c * pitch + row] = base[(int64_t)row * S + c];
+        const int c0 = (int)(t - o * ntile_c) * C;
+        nc = min(C, ncols - c0);
+        return data + o * outer_stride + c0;
+    };
+    auto request = [&](int64_t t) {
+        int nc;
+        const C2<T> *base = tile_base(t, nc);
+#pragma unroll
+        for (int it = 0; it < MAXV; it++) {
+            const int q = it * G_NT + threadIdx.x;
+            const int row = q >> lgC, c = q & (C - 1);
+            if (row < n && c < nc) nx[it] = base[(int64_t)row * S + c];
+        }
+    };
+    if ((int64_t)blockIdx.x < ntiles) request(blockIdx.x);
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int nc;
+        C2<T> *base = tile_base(t, nc);
+#pragma unroll
+        for (int it = 0; it < MAXV; it++) {
+            const int q = it * G_NT + threadIdx.x;
+            const int row = q >> lgC, c = q & (C - 1);
+            if (row < n && c < nc) lds[c * pitch + gpad<T>(row)] = nx[it];
         }
         __syncthreads();
-        g_transform<T, MAXV>(lds, nc, pitch, p, twn, 1);
+        if (t + gridDim.x < ntiles) request(t + gridDim.x);
+        g_transform<T, MAXV>(lds, nc, pitch, p, tw, 1);
         for (int q = threadIdx.x; q < n * C; q += G_NT) {
-            const int row = q / C, c = q - row * C;
-            if (c < nc) base[(int64_t)row * S + c] = lds[c * pitch + row];
+            const int row = q >> lgC, c = q & (C - 1);
+            if (c < nc) base[(int64_t)row * S + c] = lds[c * pitch + gpad<T>(row)];
         }
         __syncthreads();
     }
@@ -310,27 +352,29 @@ int r2c_inplace(T *mesh, int n, int pitch_r) {
     const int ncu = num_cus_g();
     {   // rows
         const int Nh = n / 2;
-        const int nseq = std::max(1, std::min(64, cap / (Nh + 1)));
-        const size_t lds = (size_t)nseq * (Nh + 1) * sizeof(C2<T>);
+        // rows are contiguous in memory: small tiles (about 48 KB of LDS, three workgroups per CU) lose nothing
+        const int nseq = std::max(1, std::min(std::min(64, cap / Nh), (int)(40 * 1024 / sizeof(C2<T>)) / Nh));
+        const size_t lds = ((size_t)n + (size_t)nseq * gpad_len(Nh, pads<T>())) * sizeof(C2<T>);
         auto kern = gfft_rows<T, MAXV>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t nrows = (int64_t)n * n;
-        const unsigned int grid = (unsigned int)std::min<int64_t>(ceil_div(nrows, nseq), (int64_t)ncu * 2);
+        const unsigned int grid = (unsigned int)std::min<int64_t>(ceil_div(nrows, nseq), (int64_t)ncu * std::max<int64_t>(1, std::min<int64_t>(3, (150 * 1024) / (int64_t)lds)));
         ABACUS_LAUNCH("gfft_rows", kern, dim3(grid), dim3(G_NT), lds, mesh, nrows, n, pitch_r, nseq, ph, twn);
     }
     const int pitch_c = pitch_r / 2, kzlen = n / 2 + 1;
-    int C = 1;
-    while (C * 2 <= 16 && (C * 2) * (n + 1) <= cap) C *= 2;
-    const size_t lds = (size_t)C * (n + 1) * sizeof(C2<T>);
+    int lgC = 0;
+    while ((2 << lgC) <= 16 && (2 << lgC) * n <= cap) lgC++;
+    const int C = 1 << lgC;
+    const size_t lds = ((size_t)n + (size_t)C * gpad_len(n, pads<T>())) * sizeof(C2<T>);
     auto kern = gfft_cols<T, MAXV>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ntile_c = (kzlen + C - 1) / C;
     const unsigned int grid = (unsigned int)std::min<int64_t>((int64_t)n * ntile_c, (int64_t)ncu * (lds > 80 * 1024 ? 1 : 2));
     C2<T> *data = reinterpret_cast<C2<T> *>(mesh);
     // y: for every x plane, columns along y (stride pitch_c); x: for every y row, columns along x (stride n * pitch_c)
-    ABACUS_LAUNCH("gfft_cols_y", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)pitch_c, C, ntile_c, kzlen, (int64_t)n,
+    ABACUS_LAUNCH("gfft_cols_y", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)pitch_c, lgC, ntile_c, kzlen, (int64_t)n,
                   (int64_t)n * pitch_c, pn, twn);
-    ABACUS_LAUNCH("gfft_cols_x", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)n * pitch_c, C, ntile_c, kzlen, (int64_t)n,
+    ABACUS_LAUNCH("gfft_cols_x", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)n * pitch_c, lgC, ntile_c, kzlen, (int64_t)n,
                   (int64_t)pitch_c, pn, twn);
     return 0;
 }
