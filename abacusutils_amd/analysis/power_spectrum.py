@@ -114,11 +114,19 @@ def get_field(pos, Lbox, nmesh, paste, w=None, d=0.0, nthread=MAX_THREADS, dtype
         raise ValueError(f'Unknown pasting method: {paste}')
     if paste_u == 'CIC':
         warnings.warn('Note that currently CIC pasting, unlike TSC, supports only a non-parallel implementation.')
+    if np.dtype(dtype) == np.float64:     # float64 mesh: float64 accumulation and normalisation, cloud weights in the dtype of pos
+        p, f64 = _pos_any(pos)
+        field = np.empty((nmesh, nmesh, nmesh), dtype=np.float64)
+        check(_lib.lib().abacus_field_f64(ptr(p), int(f64), C.c_int64(len(p)), ptr(_w_like(w, f64)), C.c_double(Lbox), int(nmesh),
+                                          0 if paste_u == 'TSC' else 1, C.c_double(d), ptr(field)))
+        return field
+    if np.dtype(dtype) != np.float32:
+        raise TypeError(f'mesh dtype {np.dtype(dtype)}: float32 or float64')
     p4 = _pos_f4(pos)
     field = np.empty((nmesh, nmesh, nmesh), dtype=np.float32)
     check(_lib.lib().abacus_field(ptr(p4), C.c_int64(len(p4)), ptr(_f4(w)), C.c_double(Lbox), int(nmesh),
                                   0 if paste_u == 'TSC' else 1, C.c_double(d), ptr(field)))
-    return field if np.dtype(dtype) == np.float32 else field.astype(dtype)
+    return field
 
 
 def _f4(a):
@@ -133,6 +141,18 @@ def _pos_f4(pos):
     return np.ascontiguousarray(pos, dtype=np.float32).copy()
 
 
+def _pos_any(pos):
+    """(array, is_float64): float64 positions keep their dtype (cloud weights in float64, analysis/tsc.py:400), anything else
+    becomes float32; C-contiguous writeable inputs are used - and wrapped - in place"""
+    if pos.dtype == np.float64:
+        return _pos_f8(pos), True
+    return _pos_f4(pos), False
+
+
+def _w_like(w, f64):
+    return None if w is None else np.ascontiguousarray(w, dtype=np.float64 if f64 else np.float32)
+
+
 def _pos_f8(pos):
     """float64 C-contiguous positions are used (and wrapped) in place, anything else is converted to a float64 copy"""
     if pos.dtype == np.float64 and pos.flags.c_contiguous and pos.flags.writeable:
@@ -142,12 +162,20 @@ def _pos_f8(pos):
 
 def get_field_fft(pos, Lbox, nmesh, paste, w, W, compensated, interlaced, nthread=MAX_THREADS, verbose=False,
                   dtype=np.float32):
-    """delta_k of the particles as a complex64 (nmesh, nmesh, nmesh//2+1) array (:1001-1070)."""
+    """delta_k of the particles as a complex64 (nmesh, nmesh, nmesh//2+1) array (:1001-1070); complex128 with
+    dtype=np.float64 and interlaced=False - the reference's interlaced branch never sees `dtype` (:1048-1052: float32 meshes,
+    complex64 spectrum whatever was asked), and neither does this one"""
     code = _paste_code(paste, ':')
-    if np.dtype(dtype) != np.float32:
-        raise NotImplementedError('the device path works on float32 meshes (the reference default)')
+    if np.dtype(dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise TypeError(f'mesh dtype {np.dtype(dtype)}: float32 or float64')
     if compensated:
         assert W is not None
+    if np.dtype(dtype) == np.float64 and not interlaced:
+        p, f64 = _pos_any(pos)
+        out = np.empty((nmesh, nmesh, nmesh // 2 + 1), dtype=np.complex128)
+        check(_lib.lib().abacus_field_fft_f64(ptr(p), int(f64), C.c_int64(len(p)), ptr(_w_like(w, f64)), C.c_double(Lbox), int(nmesh),
+                                              code, ptr(_f4(W)) if compensated else None, ptr(out)))
+        return out
     p = _pos_f4(pos)
     out = np.empty((nmesh, nmesh, nmesh // 2 + 1), dtype=np.complex64)
     check(_lib.lib().abacus_field_fft(ptr(p), C.c_int64(len(p)), ptr(_f4(w)), C.c_double(Lbox), int(nmesh), code,
@@ -200,9 +228,8 @@ def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste
     return_mubins = mubins is not None
     if mubins is None:
         mubins = 1
-    if np.dtype(dtype) != np.float32:
-        raise NotImplementedError('the device path works on float32 meshes (the reference default); float64 POSITIONS are '
-                                  'honoured (their cloud weights are evaluated in float64)')
+    if np.dtype(dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise TypeError(f'mesh dtype {np.dtype(dtype)}: float32 or float64')
 
     meta = dict(Lbox=Lbox, logk=logk, paste=paste, nmesh=nmesh, compensated=compensated, interlaced=interlaced,
                 poles=poles, nthread=nthread, N_pos=len(pos), is_weighted=w is not None, field_dtype=dtype,
@@ -213,6 +240,20 @@ def calc_power(pos, Lbox, kbins=None, mubins=None, k_max=None, logk=False, paste
 
     code = _paste_code(paste, '')
     W, poles_arr, kbins, mubins, ke, me = _power_setup(Lbox, nmesh, paste, compensated, interlaced, poles, k_max, kbins, mubins, logk)
+
+    if np.dtype(dtype) == np.float64 and not interlaced:
+        # float64 meshes and transform (csrc/gfft.hip in double precision); the interlaced branch of the reference ignores dtype
+        # (get_field_fft :1048-1052) and so falls through to the float32 path below, like there
+        f64 = pos.dtype == np.float64 or (pos2 is not None and pos2.dtype == np.float64)
+        cast = _pos_f8 if f64 else _pos_f4
+        p1 = cast(pos)
+        p2 = None if pos2 is None else cast(pos2)
+        outs = _alloc_outputs(len(ke) - 1, len(me) - 1, len(poles_arr))
+        check(_lib.lib().abacus_power_f64(
+            ptr(p1), int(f64), C.c_int64(len(p1)), ptr(_w_like(w, f64)), ptr(p2), C.c_int64(0 if p2 is None else len(p2)),
+            ptr(_w_like(w2, f64)), C.c_double(Lbox), int(nmesh), code, ptr(_f4(W)), ptr(ke), len(ke) - 1, ptr(me), len(me) - 1,
+            ptr(poles_arr), len(poles_arr), *[ptr(o) for o in outs]))
+        return _power_table(outs, me, kbins, mubins, poles_arr, squeeze_mu_axis, return_mubins, meta)
 
     # the cloud weights are evaluated in the dtype of the positions (analysis/tsc.py:400): float64 positions go through the
     # float64 deposit (both sets then; the mesh and the transform are float32 either way)

@@ -241,38 +241,18 @@ __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int 
     for (int q = threadIdx.x; q < n; q += G_NT) tw[q] = twn[q];
     const int C = 1 << lgC, pitch = gpad_len(n, pads<T>());
     const int64_t ntiles = nouter * ntile_c;
-    // software pipeline: the next tile is requested into registers (MAXV complex values per thread) before the current one is
-    // transformed, so its loads are in flight under the stages and the stores of the current tile
-    C2<T> nx[MAXV];
-    auto tile_base = [&](int64_t t, int &nc) {
-        const int64_t o = t / ntile_c;
-        const int c0 = (int)(t - o * ntile_c) * C;
-        nc = min(C, ncols - c0);
-        return data + o * outer_stride + c0;
-    };
-    auto request = [&](int64_t t) {
-        int nc;
-        const C2<T> *base = tile_base(t, nc);
-#pragma unroll
-        for (int it = 0; it < MAXV; it++) {
-            const int q = it * G_NT + threadIdx.x;
-            const int row = q >> lgC, c = q & (C - 1);
-            if (row < n && c < nc) nx[it] = base[(int64_t)row * S + c];
-        }
-    };
-    if ((int64_t)blockIdx.x < ntiles) request(blockIdx.x);
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        int nc;
-        C2<T> *base = tile_base(t, nc);
-#pragma unroll
-        for (int it = 0; it < MAXV; it++) {
-            const int q = it * G_NT + threadIdx.x;
+        const int64_t o = t / ntile_c;
+        const int c0 = (int)(t - o * ntile_c) * C, nc = min(C, ncols - c0);
+        C2<T> *base = data + o * outer_stride + c0;
+        for (int q = threadIdx.x; q < n * C; q += G_NT) {
             const int row = q >> lgC, c = q & (C - 1);
-            if (row < n && c < nc) lds[c * pitch + gpad<T>(row)] = nx[it];
+            if (c < nc) lds[c * pitch + gpad<T>(row)] = base[(int64_t)row * S + c];
         }
         __syncthreads();
-        if (t + gridDim.x < ntiles) request(t + gridDim.x);
         g_transform<T, MAXV>(lds, nc, pitch, p, tw, 1);
+        // (requesting the next tile into registers before the transform - 24 values per thread - was measured: the kernel spills
+        // and gains nothing, 18.5 vs 19.0 ms at 1536^3: the stages are bound by their index arithmetic, not by the memory phases)
         for (int q = threadIdx.x; q < n * C; q += G_NT) {
             const int row = q >> lgC, c = q & (C - 1);
             if (c < nc) base[(int64_t)row * S + c] = lds[c * pitch + gpad<T>(row)];
@@ -352,8 +332,7 @@ int r2c_inplace(T *mesh, int n, int pitch_r) {
     const int ncu = num_cus_g();
     {   // rows
         const int Nh = n / 2;
-        // rows are contiguous in memory: small tiles (about 48 KB of LDS, three workgroups per CU) lose nothing
-        const int nseq = std::max(1, std::min(std::min(64, cap / Nh), (int)(40 * 1024 / sizeof(C2<T>)) / Nh));
+        const int nseq = std::max(1, std::min(64, cap / Nh));   // (tiles of a third, three workgroups per CU: 22.5 vs 19.8 ms at 1536^3)
         const size_t lds = ((size_t)n + (size_t)nseq * gpad_len(Nh, pads<T>())) * sizeof(C2<T>);
         auto kern = gfft_rows<T, MAXV>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -41,6 +41,10 @@ int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmes
                     double offset, int wrap, double norm, int cic, int list_mode = 0, double sub = 1.0);
 void tsc_wrapped_reset();
 int tsc_wrapped_seen();
+int tsc_deposit_f64mesh(void *pos, int pos_f64, int64_t n, const void *w, double *grid, int nmesh, int64_t zstride, double box,
+                        double offset, int wrap, double norm, int cic, double sub);
+bool gfft_supported(int n, int is_double);
+int gfft_r2c_inplace_f64(double *mesh, int n, int pitch_r);
 int tsc_deposit_f64pos(double *pos, int64_t n, const double *w, float *grid, int nmesh, int64_t zstride, double box,
                        double offset, int wrap, double norm, int cic, double sub = 1.0);
 int tsc_release_work();
@@ -1647,3 +1651,156 @@ int abacus_power_release(void) {
 }
 
 }  // extern "C"
+
+// ---- float64 meshes: get_field / get_field_fft / calc_power with dtype=np.float64 (analysis/power_spectrum.py:808-857, 1001-1070,
+// 1131-1319) --------------------------------------------------------------------------------------------------------------------
+// What dtype changes in the reference: the mesh, its normalisation, the transform and 1/M scaling are float64 (complex128
+// spectrum), the compensation divides by the float32 window products; an INTERLACED field ignores it (get_interlaced_field_fft is
+// called without dtype, :1048-1052: float32 meshes, complex64 spectrum) and bin_kmu is called with its default float32
+// arithmetic whatever the mesh (:787-789), its float64 weights entering float32 accumulators.  Here: float64 deposit
+// (tsc.hip), the mixed-radix double-precision transform of gfft.hip, raw power in float64, then the usual binning (float64
+// accumulators over the weights rounded to float32).
+namespace {
+int pitch_r64(int n) { return (n + 2 + 15) / 16 * 16; }          // doubles per z row: rows start on 128-B lines
+
+// spectrum *= inv_size; /= (W[i] W[j]) W[k] (float32 products like the reference's broadcast, :1063-1069)
+__global__ void f64_scale_compensate(double2 *__restrict__ f, int n, int pitch_c, double inv_size, const float *__restrict__ W) {
+    const int kzlen = n / 2 + 1;
+    const int64_t total = (int64_t)n * n * kzlen;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(q % kzlen);
+        const int64_t row = q / kzlen;
+        double2 v = f[row * pitch_c + k];
+        v.x *= inv_size, v.y *= inv_size;
+        if (W) {
+            const float w = (W[row / n] * W[row % n]) * W[k];
+            v.x /= (double)w, v.y /= (double)w;
+        }
+        f[row * pitch_c + k] = v;
+    }
+}
+// get_raw_power (:707-727) of padded float64 spectra into contiguous float32 weights (n, n, kzlen)
+__global__ void f64_raw_power(const double2 *__restrict__ a, const double2 *__restrict__ b, int n, int pitch_c, float *__restrict__ out) {
+    const int kzlen = n / 2 + 1;
+    const int64_t total = (int64_t)n * n * kzlen;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(q % kzlen);
+        const int64_t row = q / kzlen;
+        const double2 u = a[row * pitch_c + k];
+        double p;
+        if (b) {
+            const double2 v = b[row * pitch_c + k];
+            p = u.x * v.x + u.y * v.y;
+        } else {
+            const double m = hypot(u.x, u.y);
+            p = m * m;
+        }
+        out[q] = (float)p;
+    }
+}
+
+// deposit + normalise + transform of one particle set into g_ctx.mesh[slot] (float64, padded in-place R2C layout)
+int field64_dev(void *pos, int pos_f64, int64_t n, const void *w, double L, int nmesh, int paste, double offset, int slot, bool transform,
+                const float *W_dev) {
+    if (n <= 0) return fail("power: empty particle set");
+    const int pr = pitch_r64(nmesh);
+    ABACUS_TRY(g_ctx.mesh[slot].reserve((size_t)nmesh * nmesh * pr * sizeof(double)));
+    double *mesh = g_ctx.mesh[slot].as<double>();
+    const double M = (double)nmesh * nmesh * nmesh;
+    ABACUS_TRY(tsc_deposit_f64mesh(pos, pos_f64, n, w, mesh, nmesh, pr, L, offset, paste == 0, M / (double)n, paste, 1.0));
+    if (!transform) return 0;
+    if (!gfft_supported(nmesh, 1))
+        return fail("power: a float64 mesh of %d cells per side is not supported (even sizes up to 3072 with factors 2, 3, 5, 7, 11, 13)", nmesh);
+    ABACUS_TRY(gfft_r2c_inplace_f64(mesh, nmesh, pr));
+    const int64_t total = (int64_t)nmesh * nmesh * (nmesh / 2 + 1);
+    ABACUS_LAUNCH("f64_scale_compensate", f64_scale_compensate, dim3(helper_grid(total)), dim3(256), 0, reinterpret_cast<double2 *>(mesh), nmesh,
+                  pr / 2, 1.0 / M, W_dev);
+    return 0;
+}
+
+// host particles (float32 or float64) -> device copies in g_ctx.pos / g_ctx.w (slot 0) or pos2 / w2
+int stage_particles_any(const void *pos, int pos_f64, int64_t n, const void *w, DevBuf &dp, DevBuf &dw, void **pd, void **wd) {
+    const size_t es = pos_f64 ? 8 : 4;
+    ABACUS_TRY(dp.reserve((size_t)std::max<int64_t>(n, 1) * 3 * es));
+    HIP_TRY(hipMemcpyAsync(dp.p, pos, (size_t)n * 3 * es, hipMemcpyHostToDevice, stream()));
+    *pd = dp.p, *wd = nullptr;
+    if (w) {
+        ABACUS_TRY(dw.reserve((size_t)std::max<int64_t>(n, 1) * es));
+        HIP_TRY(hipMemcpyAsync(dw.p, w, (size_t)n * es, hipMemcpyHostToDevice, stream()));
+        *wd = dw.p;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int abacus_field_f64(void *pos, int pos_f64, int64_t n, const void *w, double Lbox, int nmesh, int paste, double offset, double *field) {
+    ABACUS_ENTER();
+    ABACUS_TRY(check_common(nmesh, paste));
+    if (!field || !pos) return fail("abacus_field_f64: null argument");
+    void *pd, *wd;
+    ABACUS_TRY(stage_particles_any(pos, pos_f64, n, w, g_ctx.pos, g_ctx.w, &pd, &wd));
+    tsc_wrapped_reset();
+    ABACUS_TRY(field64_dev(pd, pos_f64, n, wd, Lbox, nmesh, paste, offset, 0, false, nullptr));
+    const int pr = pitch_r64(nmesh);
+    HIP_TRY(hipMemcpy2DAsync(field, (size_t)nmesh * 8, g_ctx.mesh[0].p, (size_t)pr * 8, (size_t)nmesh * 8, (size_t)nmesh * nmesh,
+                             hipMemcpyDeviceToHost, stream()));
+    if (paste == 0 && tsc_wrapped_seen()) HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 3 * (pos_f64 ? 8 : 4), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_field_fft_f64(void *pos, int pos_f64, int64_t n, const void *w, double Lbox, int nmesh, int paste, const float *W_host,
+                         void *out_c128) {
+    ABACUS_ENTER();
+    ABACUS_TRY(check_common(nmesh, paste));
+    if (!out_c128 || !pos) return fail("abacus_field_fft_f64: null argument");
+    const float *W_dev;
+    ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
+    void *pd, *wd;
+    ABACUS_TRY(stage_particles_any(pos, pos_f64, n, w, g_ctx.pos, g_ctx.w, &pd, &wd));
+    tsc_wrapped_reset();
+    ABACUS_TRY(field64_dev(pd, pos_f64, n, wd, Lbox, nmesh, paste, 0.0, 0, true, W_dev));
+    const int pr = pitch_r64(nmesh), kzlen = nmesh / 2 + 1;
+    HIP_TRY(hipMemcpy2DAsync(out_c128, (size_t)kzlen * 16, g_ctx.mesh[0].p, (size_t)pr * 8, (size_t)kzlen * 16, (size_t)nmesh * nmesh,
+                             hipMemcpyDeviceToHost, stream()));
+    if (paste == 0 && tsc_wrapped_seen()) HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 3 * (pos_f64 ? 8 : 4), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int abacus_power_f64(void *pos, int pos_f64, int64_t n, const void *w, void *pos2, int64_t n2, const void *w2, double Lbox, int nmesh,
+                     int paste, const float *W_host, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
+                     int Np, float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
+    ABACUS_ENTER();
+    ABACUS_TRY(check_common(nmesh, paste));
+    if (!pos) return fail("abacus_power_f64: null positions");
+    const float *W_dev;
+    ABACUS_TRY(upload_W(W_host, nmesh, &W_dev));
+    void *pd, *wd, *pd2 = nullptr, *wd2 = nullptr;
+    ABACUS_TRY(stage_particles_any(pos, pos_f64, n, w, g_ctx.pos, g_ctx.w, &pd, &wd));
+    tsc_wrapped_reset();
+    ABACUS_TRY(field64_dev(pd, pos_f64, n, wd, Lbox, nmesh, paste, 0.0, 0, true, W_dev));
+    const bool wrapped1 = paste == 0 && tsc_wrapped_seen();
+    bool wrapped2 = false;
+    if (pos2) {
+        ABACUS_TRY(stage_particles_any(pos2, pos_f64, n2, w2, g_ctx.pos2, g_ctx.w2, &pd2, &wd2));
+        tsc_wrapped_reset();
+        ABACUS_TRY(field64_dev(pd2, pos_f64, n2, wd2, Lbox, nmesh, paste, 0.0, 1, true, W_dev));
+        wrapped2 = paste == 0 && tsc_wrapped_seen();
+    }
+    const int pr = pitch_r64(nmesh), kzlen = nmesh / 2 + 1;
+    const int64_t total = (int64_t)nmesh * nmesh * kzlen;
+    ABACUS_TRY(g_ctx.helper_in.reserve((size_t)total * 4));
+    ABACUS_LAUNCH("f64_raw_power", f64_raw_power, dim3(helper_grid(total)), dim3(256), 0, (const double2 *)g_ctx.mesh[0].as<double2>(),
+                  (const double2 *)(pos2 ? g_ctx.mesh[1].as<double2>() : nullptr), nmesh, pr / 2, g_ctx.helper_in.as<float>());
+    if (wrapped1) HIP_TRY(hipMemcpyAsync(pos, pd, (size_t)n * 3 * (pos_f64 ? 8 : 4), hipMemcpyDeviceToHost, stream()));
+    if (wrapped2) HIP_TRY(hipMemcpyAsync(pos2, pd2, (size_t)n2 * 3 * (pos_f64 ? 8 : 4), hipMemcpyDeviceToHost, stream()));
+    // bin_kmu on the raw power (its default float32 edge arithmetic, :787-789), times L^3 (:792-795)
+    return bin_real_grid(g_ctx.helper_in.as<float>(), nmesh, kzlen, 1.0f, Lbox, 2.0 * M_PI / Lbox, Lbox * Lbox * Lbox, kedges, Nk, muedges, Nmu,
+                         poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg);
+}
+
+}  // extern "C"
+

@@ -1374,6 +1374,17 @@ int tsc_deposit_f64pos(double *pos, int64_t n, const double *w, float *grid, int
     return deposit_dev<double, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
                                              nullptr, -1, 0, sub, 0);
 }
+// float64 MESH (dtype=np.float64 of get_field / calc_power, analysis/power_spectrum.py:808,1148): cloud arithmetic in the position
+// dtype, accumulation and normalisation in float64
+int tsc_deposit_f64mesh(void *pos, int pos_f64, int64_t n, const void *w, double *grid, int nmesh, int64_t zstride, double box,
+                        double offset, int wrap, double norm, int cic, double sub) {
+    if (pos_f64) {
+        if (cic) return deposit_dev<double, double, true>((double *)pos, n, (const double *)w, grid, nmesh, nmesh, nmesh, zstride, box, offset, 0, 1, norm, nullptr, -1, 0, sub, 0);
+        return deposit_dev<double, double, false>((double *)pos, n, (const double *)w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm, nullptr, -1, 0, sub, 0);
+    }
+    if (cic) return deposit_dev<float, double, true>((float *)pos, n, (const float *)w, grid, nmesh, nmesh, nmesh, zstride, box, offset, 0, 1, norm, nullptr, -1, 0, sub, 0);
+    return deposit_dev<float, double, false>((float *)pos, n, (const float *)w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm, nullptr, -1, 0, sub, 0);
+}
 // x-slab variant: `grid` holds planes [xoff, xoff + nx_local) (mod nmesh) of the global mesh, ghosts included - or, with
 // xoff2 >= 0, two windows of nx_local / 2 planes each starting at xoff and xoff2 (folded slabs) -; written as
 // rho*norm - sub (sub = 1: the overdensity's "-1" in every cell; a ghost block is then added to its owner as ghost + 1)

@@ -230,6 +230,19 @@ int abacus_field(float *pos, int64_t n, const float *w, double Lbox, int nmesh, 
 int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nmesh, int paste, const float *W,
                      int interlaced, void *out_c64);
 /*
+ * float64 MESHES: get_field / get_field_fft / calc_power with dtype=np.float64 (analysis/power_spectrum.py:808-857, 1001-1070,
+ * 1131-1319), non-interlaced (the reference's interlaced branch ignores dtype, :1048-1052).  pos_f64: the positions (and weights)
+ * are float64 - the cloud weights are evaluated in the dtype of the positions (analysis/tsc.py:400).  The mesh is deposited,
+ * normalised and transformed in float64 (csrc/gfft.hip: even sizes up to 3072 with factors 2, 3, 5, 7, 11, 13); field:
+ * (nmesh,)*3 float64, out_c128: (nmesh, nmesh, nmesh/2+1) complex128; abacus_power_f64 returns what bin_kmu returns, times L^3.
+ */
+int abacus_field_f64(void *pos, int pos_f64, int64_t n, const void *w, double Lbox, int nmesh, int paste, double offset, double *field);
+int abacus_field_fft_f64(void *pos, int pos_f64, int64_t n, const void *w, double Lbox, int nmesh, int paste, const float *W,
+                         void *out_c128);
+int abacus_power_f64(void *pos, int pos_f64, int64_t n, const void *w, void *pos2, int64_t n2, const void *w2, double Lbox, int nmesh,
+                     int paste, const float *W, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
+                     int Np, float *power, int64_t *N_mode, float *binned_poles, int64_t *N_mode_poles, float *k_avg);
+/*
  * replaces: calc_pk_from_deltak = get_raw_power + bin_kmu (analysis/power_spectrum.py:730-805, 707-727, 150-300)
  * on host spectra.  field2 may be NULL (auto power).  Outputs as bin_kmu returns them, already multiplied by L^3:
  * power (Nk,Nmu) f32, N_mode (Nk,Nmu) i64, binned_poles (Np,Nk) f32, N_mode_poles (Nk) i64, k_avg (Nk,Nmu) f32.

@@ -22,6 +22,7 @@ What is captured
         modes, cross spectra, poles, logk; bin_kmu / calc_pk_from_deltak.
 
   power_exports.npz           bin_kmu, get_raw_power, shift_field_fft, get_interlaced_field_fft on seeded inputs
+  power_f64.npz               get_field / get_field_fft / calc_power with dtype=np.float64
   power_helpers.npz           bin_kppi, project_3d_to_poles, pk_to_xi, expand_poles_to_3d, get_smoothing,
         get_delta_mu2 on seeded 16^3 / 21^3 inputs.
 
@@ -944,6 +945,37 @@ def gen_exports(P):
     print('power_exports written')
 
 
+def gen_power64(P):
+    """calc_power / get_field / get_field_fft of the reference with dtype=np.float64 (float64 mesh and transform; its
+    interlaced branch ignores dtype, :1048-1052), float32 and float64 positions, TSC and CIC, cross spectrum"""
+    warnings.simplefilter('ignore')
+    sys.path.insert(0, str(REPO))
+    from abacusutils_amd import synth
+    L, N = 500.0, 20000
+    out = {'meta.L': np.float64(L), 'meta.N': np.int64(N)}
+    pos = synth.synth_positions(N, L, seed=300, clustered=True)
+    pos2 = synth.synth_positions(N // 2, L, seed=301, clustered=True)
+    w = (0.5 + np.random.default_rng(5).random(N, dtype=np.float32)).astype(np.float32)
+    out['w'] = w
+    for n in (24, 30):
+        out[f'n{n}.field_tsc'] = P.get_field(pos.copy(), L, n, 'TSC', w, dtype=np.float64)
+        out[f'n{n}.field_cic_p8'] = P.get_field(pos.astype(np.float64), L, n, 'CIC', None, dtype=np.float64)
+        W = P.get_W_compensated(L, n, 'TSC', False)
+        out[f'n{n}.fft_tsc_comp'] = P.get_field_fft(pos.copy(), L, n, 'TSC', w, W, True, False, dtype=np.float64)
+        out[f'n{n}.fft_tsc_p8'] = P.get_field_fft(pos.astype(np.float64), L, n, 'TSC', None, None, False, False, dtype=np.float64)
+        il = P.get_field_fft(pos.copy(), L, n, 'TSC', None, W, True, True, dtype=np.float64)
+        out[f'n{n}.fft_interlaced_dtype'] = np.array(str(il.dtype))
+        for name, kw in (('auto', dict(compensated=True, interlaced=False, w=w)),
+                         ('cross', dict(compensated=False, interlaced=False, pos2=pos2.copy())),
+                         ('interlaced', dict(compensated=True, interlaced=True))):
+            tab = P.calc_power(pos.copy(), L, kbins=10, mubins=3, k_max=np.pi * n / L + 1e-6, paste='TSC', nmesh=n, poles=[0, 2, 4],
+                               dtype=np.float64, **kw)
+            for c in ('power', 'N_mode', 'poles', 'N_mode_poles', 'k_avg'):
+                out[f'n{n}.{name}.{c}'] = np.asarray(tab[c])
+    np.savez_compressed(GOLD / 'power_f64.npz', **out)
+    print('power_f64 written', os.path.getsize(GOLD / 'power_f64.npz') // 1024, 'KiB')
+
+
 def gen_mini_prepare():
     """the reference-HELD pin of prepare_sim (tests/test_hod.py:89-100): its Mini_N64_L32 subsample files (all three slabs) as
     arrays -> prepare_mini.npz; the reference reader's own catalogues of that simulation (tests/ref_data/test_halos_clean.asdf,
@@ -996,7 +1028,7 @@ def gen_mini_prepare():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'exports', 'catalog', 'sweep', 'ngal', 'pairs', 'prepare', 'mini']
+    which = sys.argv[1:] or ['hod', 'tsc', 'power', 'helpers', 'exports', 'catalog', 'sweep', 'ngal', 'pairs', 'prepare', 'mini', 'power64']
     G, T, P, C = import_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
     if 'hod' in which:
@@ -1011,6 +1043,8 @@ if __name__ == '__main__':
         gen_exports(P)
     if 'mini' in which:
         gen_mini_prepare()
+    if 'power64' in which:
+        gen_power64(P)
     if 'catalog' in which:
         gen_catalog()
     if 'sweep' in which:

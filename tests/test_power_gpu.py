@@ -673,3 +673,41 @@ def test_mixed_radix_meshes_take_the_native_transform(nmesh, npart, options):
         options.set('fft_generic', 0)
         b = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, False)
         assert np.abs(a - b).max() <= 3e-6 * np.abs(b).max()
+
+
+@pytest.mark.parametrize('n', [24, 30])
+def test_float64_meshes_against_reference_goldens(n):
+    """dtype=np.float64 of get_field / get_field_fft / calc_power (analysis/power_spectrum.py:808, 1001, 1148): float64 mesh,
+    normalisation and transform (csrc/gfft.hip in double precision) against what the shimmed reference returned
+    (tests/golden/power_f64.npz) - the mesh and the spectrum at 1e-12 of their largest value; the binned power is float32 in
+    the reference whatever the mesh (bin_kmu is called with its default dtype, :787-789), so it is held to the usual 1e-5.
+    The interlaced branch of the reference ignores dtype (:1048-1052)"""
+    from abacusutils_amd.analysis import power_spectrum as ps
+    g = load_golden('power_f64')
+    Lb, N = float(g['meta.L']), int(g['meta.N'])
+    pos = synth.synth_positions(N, Lb, seed=300, clustered=True)
+    pos2 = synth.synth_positions(N // 2, Lb, seed=301, clustered=True)
+    w = g['w']
+
+    def close(a, want, tol=1e-12):
+        assert a.dtype == want.dtype and a.shape == want.shape
+        assert np.abs(a - want).max() <= tol * np.abs(want).max()
+
+    close(ps.get_field(pos.copy(), Lb, n, 'TSC', w, dtype=np.float64), g[f'n{n}.field_tsc'])
+    close(ps.get_field(pos.astype(np.float64), Lb, n, 'CIC', None, dtype=np.float64), g[f'n{n}.field_cic_p8'])
+    W = ps.get_W_compensated(Lb, n, 'TSC', False)
+    close(ps.get_field_fft(pos.copy(), Lb, n, 'TSC', w, W, True, False, dtype=np.float64), g[f'n{n}.fft_tsc_comp'], 1e-11)
+    close(ps.get_field_fft(pos.astype(np.float64), Lb, n, 'TSC', None, None, False, False, dtype=np.float64), g[f'n{n}.fft_tsc_p8'])
+    il = ps.get_field_fft(pos.copy(), Lb, n, 'TSC', None, W, True, True, dtype=np.float64)
+    assert str(il.dtype) == str(g[f'n{n}.fft_interlaced_dtype']) == 'complex64'
+    for name, kw in (('auto', dict(compensated=True, interlaced=False, w=w)), ('cross', dict(compensated=False, interlaced=False, pos2=pos2.copy())),
+                     ('interlaced', dict(compensated=True, interlaced=True))):
+        tab = ps.calc_power(pos.copy(), Lb, kbins=10, mubins=3, k_max=np.pi * n / Lb + 1e-6, paste='TSC', nmesh=n, poles=[0, 2, 4],
+                            dtype=np.float64, **kw)
+        for c in ('N_mode', 'N_mode_poles'):
+            np.testing.assert_array_equal(np.asarray(tab[c]), g[f'n{n}.{name}.{c}'])
+        for c in ('power', 'poles', 'k_avg'):
+            assert np.asarray(tab[c]).dtype == g[f'n{n}.{name}.{c}'].dtype == np.float32
+            assert_spectrum_close(tab[c], g[f'n{n}.{name}.{c}'], rtol=1e-5, err_msg=f'{name}.{c}')
+    with pytest.raises(TypeError):
+        ps.calc_power(pos.copy(), Lb, nmesh=n, dtype=np.float16)
