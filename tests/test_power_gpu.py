@@ -693,10 +693,12 @@ def test_float64_meshes_against_reference_goldens(n):
         assert a.dtype == want.dtype and a.shape == want.shape
         assert np.abs(a - want).max() <= tol * np.abs(want).max()
 
-    close(ps.get_field(pos.copy(), Lb, n, 'TSC', w, dtype=np.float64), g[f'n{n}.field_tsc'])
+    # float32 positions: the cloud weights are float32 (analysis/tsc.py:400) and the SHIMMED reference evaluates d**2 through
+    # NumPy's float32 power where Numba (and the device) multiply - one float32 ulp of a weight, 4e-8 of the mesh (measured)
+    close(ps.get_field(pos.copy(), Lb, n, 'TSC', w, dtype=np.float64), g[f'n{n}.field_tsc'], 2e-7)
     close(ps.get_field(pos.astype(np.float64), Lb, n, 'CIC', None, dtype=np.float64), g[f'n{n}.field_cic_p8'])
     W = ps.get_W_compensated(Lb, n, 'TSC', False)
-    close(ps.get_field_fft(pos.copy(), Lb, n, 'TSC', w, W, True, False, dtype=np.float64), g[f'n{n}.fft_tsc_comp'], 1e-11)
+    close(ps.get_field_fft(pos.copy(), Lb, n, 'TSC', w, W, True, False, dtype=np.float64), g[f'n{n}.fft_tsc_comp'], 2e-7)
     close(ps.get_field_fft(pos.astype(np.float64), Lb, n, 'TSC', None, None, False, False, dtype=np.float64), g[f'n{n}.fft_tsc_p8'])
     il = ps.get_field_fft(pos.copy(), Lb, n, 'TSC', None, W, True, True, dtype=np.float64)
     assert str(il.dtype) == str(g[f'n{n}.fft_interlaced_dtype']) == 'complex64'
