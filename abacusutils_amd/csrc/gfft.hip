@@ -35,6 +35,11 @@ __device__ __forceinline__ C2<T> cadd(C2<T> a, C2<T> b) { return {a.x + b.x, a.y
 template <typename T>
 __device__ __forceinline__ C2<T> csub(C2<T> a, C2<T> b) { return {a.x - b.x, a.y - b.y}; }
 
+template <typename T>
+struct alignas(2 * sizeof(C2<T>)) CPair {
+    C2<T> a, b;
+};
+
 struct GPlan {
     int n;                 // sequence length
     int nf;                // stages
@@ -128,134 +133,185 @@ __device__ __forceinline__ void dftg(C2<T> (&a)[R]) {
     }
 }
 
-// ---- one Stockham stage over `nseq` sequences of N elements in LDS (sequence s at lds + s * pitch) ---------------------
-// thread j of a sequence: v[r] = in[j + r N/R] * W_{Ns R}^{r (j mod Ns)}; DFT_R; out[(j / Ns) Ns R + (j mod Ns) + r Ns] = v[r]
-// tw: exp(-2 pi i q / NT_) for q < NT_, NT_ = tws * N (the row pass shares the n-entry table of its even / odd split: tws = 2),
-// a copy in LDS.  Element i of a sequence sits at padded position i + (i >> PADS): the writes of a stage have stride Ns
-// across r and R Ns across lanes - without the pad every lane of a wave would hit the same few banks.
-template <typename T>
-constexpr int pads() { return sizeof(T) == 4 ? 5 : 4; }      // one pad element per 256 B of a sequence
-template <typename T>
-__device__ __forceinline__ int gpad(int i) { return i + (i >> pads<T>()); }
-__host__ __device__ constexpr int gpad_len(int n, int sh) { return n + (n >> sh) + 1; }
-// floor(a / d) for a, d < 65536 by a multiply (m = 2^32 / d rounded up)
-__device__ __forceinline__ unsigned int magic_of(unsigned int d) { return 0xffffffffu / d + 1u; }
+// ---- Stockham stages over NSEQ interleaved sequences of N elements in LDS ----------------------------------------------------
+// Element e of sequence s sits at lds[e * P + s], P = NSEQ + 1: the tile of a column pass is the mesh's own (row, column)
+// layout, and the odd pitch spreads the stride-R rows a stage writes over the banks.  A work item is butterfly j of CG adjacent
+// sequences (4 in float, 2 in double): the stage's index arithmetic - j -> (j / Ns, j mod Ns), twiddle indices - and the
+// twiddle reads are shared by the CG sequences (the first form of this file did them per element and was bound by them:
+// 60.9 ms at 1536^3 against hipFFT's 38.5).
+//   v[r] = in[j + r N/R] * W_{Ns R}^{r (j mod Ns)};  DFT_R;  out[(j / Ns) Ns R + (j mod Ns) + r Ns] = v[r]
+// tw: exp(-2 pi i q / (tws N)) in LDS (the row pass shares the n-entry table of its even / odd split: tws = 2)
+__device__ __forceinline__ unsigned int magic_of(unsigned int d) { return 0xffffffffu / d + 1u; }   // floor(a / d), a, d < 65536
 __device__ __forceinline__ int fdiv(int a, unsigned int m) { return (int)__umulhi((unsigned int)a, m); }
+template <typename T>
+constexpr int cg_of() { return sizeof(T) == 4 ? 4 : 2; }
 
 template <typename T, int R, int MAXV>
-__device__ __forceinline__ void g_stage(C2<T> *lds, int nseq, int pitch, int N, int Ns, const C2<T> *tw, int tws) {
-    constexpr int MAXIT = (MAXV + R - 1) / R;
-    const int BPS = N / R, total = nseq * BPS, step = tws * (N / (Ns * R));
-    const unsigned int mB = BPS > 1 ? magic_of(BPS) : 0u, mN = Ns > 1 ? magic_of(Ns) : 0u;
-    C2<T> v[MAXIT][R];
+__device__ __forceinline__ void g_stage(C2<T> *lds, int lgG, int P, int N, int Ns, const C2<T> *tw, int tws) {
+    constexpr int CG = cg_of<T>();
+    constexpr int MAXIT = (MAXV + R * CG - 1) / (R * CG);
+    const int BPS = N / R, total = BPS << lgG, step = tws * (N / (Ns * R));
+    const unsigned int mN = Ns > 1 ? magic_of(Ns) : 0u;
+    C2<T> v[MAXIT][CG][R];
     int off[MAXIT];
 #pragma unroll
     for (int it = 0; it < MAXIT; it++) {
-        const int b = it * G_NT + threadIdx.x;
+        const int item = it * G_NT + threadIdx.x;
         off[it] = -1;
-        if (b < total) {
-            const int s = BPS > 1 ? fdiv(b, mB) : b, j = b - s * BPS, q = Ns > 1 ? fdiv(j, mN) : j, k = j - q * Ns;
-            const C2<T> *c = lds + s * pitch;
+        if (item < total) {
+            const int j = item >> lgG, c0 = (item & ((1 << lgG) - 1)) * CG;
+            const int q = Ns > 1 ? fdiv(j, mN) : j, k = j - q * Ns;
+            const C2<T> *src = lds + j * P + c0;
 #pragma unroll
-            for (int r = 0; r < R; r++) v[it][r] = c[gpad<T>(j + r * BPS)];
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int c = 0; c < CG; c++) v[it][c][r] = src[r * BPS * P + c];
             if (Ns > 1) {
 #pragma unroll
-                for (int r = 1; r < R; r++) v[it][r] = cmul(v[it][r], tw[r * k * step]);
+                for (int r = 1; r < R; r++) {
+                    const C2<T> w = tw[r * k * step];
+#pragma unroll
+                    for (int c = 0; c < CG; c++) v[it][c][r] = cmul(v[it][c][r], w);
+                }
             }
-            dftg<T, R>(v[it]);
-            off[it] = (q * Ns * R + k) | (s << 20);     // sequence above bit 20, element index below
+#pragma unroll
+            for (int c = 0; c < CG; c++) dftg<T, R>(v[it][c]);
+            off[it] = (q * Ns * R + k) * P + c0;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < MAXIT; it++)
         if (off[it] >= 0) {
-            C2<T> *c = lds + (off[it] >> 20) * pitch;
-            const int e0 = off[it] & 0xfffff;
+            C2<T> *dst = lds + off[it];
 #pragma unroll
-            for (int r = 0; r < R; r++) c[gpad<T>(e0 + r * Ns)] = v[it][r];
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int c = 0; c < CG; c++) dst[r * Ns * P + c] = v[it][c][r];
         }
     __syncthreads();
 }
 
 template <typename T, int MAXV>
-__device__ __forceinline__ void g_transform(C2<T> *lds, int nseq, int pitch, const GPlan &p, const C2<T> *tw, int tws) {
+__device__ __forceinline__ void g_transform(C2<T> *lds, int lgG, int P, const GPlan &p, const C2<T> *tw, int tws) {
     int Ns = 1;
     for (int f = 0; f < p.nf; f++) {
         const int R = p.radix[f];
         switch (R) {
-            case 2: g_stage<T, 2, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
-            case 3: g_stage<T, 3, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
-            case 4: g_stage<T, 4, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
-            case 5: g_stage<T, 5, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
-            case 7: g_stage<T, 7, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
-            case 8: g_stage<T, 8, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
-            case 11: g_stage<T, 11, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
-            default: g_stage<T, 13, MAXV>(lds, nseq, pitch, p.n, Ns, tw, tws); break;
+            case 2: g_stage<T, 2, MAXV>(lds, lgG, P, p.n, Ns, tw, tws); break;
+            case 3: g_stage<T, 3, MAXV>(lds, lgG, P, p.n, Ns, tw, tws); break;
+            case 4: g_stage<T, 4, MAXV>(lds, lgG, P, p.n, Ns, tw, tws); break;
+            case 5: g_stage<T, 5, MAXV>(lds, lgG, P, p.n, Ns, tw, tws); break;
+            case 7: g_stage<T, 7, MAXV>(lds, lgG, P, p.n, Ns, tw, tws); break;
+            case 8: g_stage<T, 8, MAXV>(lds, lgG, P, p.n, Ns, tw, tws); break;
+            case 11: g_stage<T, 11, MAXV>(lds, lgG, P, p.n, Ns, tw, tws); break;
+            default: g_stage<T, 13, MAXV>(lds, lgG, P, p.n, Ns, tw, tws); break;
         }
         Ns *= R;
     }
 }
 
 // ---- rows: n reals -> n/2 + 1 complex, in place (row pitch `pitch_r` scalars) ------------------------------------------
-// LDS: [n twiddles][nseq sequences of gpad_len(n / 2)]
+// a tile is NSEQ = CG << lgG rows (a power of two); LDS: [n twiddles][(n / 2) x (NSEQ + 1)]
 template <typename T, int MAXV>
-__global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t nrows, int n, int pitch_r, int nseq, GPlan p,
-                                                  const C2<T> *__restrict__ twn) {
+__global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t nrows, int n, int pitch_r, int lgG, GPlan p,
+                                                  const C2<T> *__restrict__ twn, int dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
     C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
     C2<T> *lds = tw + n;
     for (int q = threadIdx.x; q < n; q += G_NT) tw[q] = twn[q];
-    const int Nh = n / 2, pitch = gpad_len(Nh, pads<T>());
-    const unsigned int mH = magic_of(Nh), mH1 = magic_of(Nh + 1);
-    for (int64_t r0 = (int64_t)blockIdx.x * nseq; r0 < nrows; r0 += (int64_t)gridDim.x * nseq) {
-        const int ns = (int)min((int64_t)nseq, nrows - r0);
-        for (int q = threadIdx.x; q < ns * Nh; q += G_NT) {
-            const int s = fdiv(q, mH), m = q - s * Nh;
-            lds[s * pitch + gpad<T>(m)] = reinterpret_cast<const C2<T> *>(mesh + (r0 + s) * pitch_r)[m];
+    const int NSEQ = cg_of<T>() << lgG, P = NSEQ + 1, Nh = n / 2;
+    const unsigned int mH1 = magic_of(Nh + 1);
+    for (int64_t r0 = (int64_t)blockIdx.x * NSEQ; r0 < nrows; r0 += (int64_t)gridDim.x * NSEQ) {
+        const int ns = (int)min((int64_t)NSEQ, nrows - r0);
+        {   // a batch of 16-byte loads (two complex of a row) in flight before its LDS stores: with one workgroup per CU nothing
+            // else hides the latency.  An odd n / 2 reads one complex into the row's padding (pitch_r >= n + 2) and drops it.
+            constexpr int B = MAXV / 4;
+            using Pair = CPair<T>;
+            const int np2 = (Nh + 1) >> 1, total2 = NSEQ * np2;
+            const unsigned int mP = magic_of(np2);
+            Pair v[B];
+#pragma unroll 1
+            for (int q0 = threadIdx.x; q0 < total2; q0 += B * G_NT) {
+#pragma unroll
+                for (int it = 0; it < B; it++) {
+                    const int q = q0 + it * G_NT, s = fdiv(q, mP), m2 = q - s * np2;
+                    v[it] = (q < total2 && s < ns && !(dbg & 2)) ? reinterpret_cast<const Pair *>(mesh + (r0 + s) * pitch_r)[m2]
+                                                                 : Pair{{(T)0, (T)0}, {(T)0, (T)0}};
+                }
+#pragma unroll
+                for (int it = 0; it < B; it++) {
+                    const int q = q0 + it * G_NT, s = fdiv(q, mP), m2 = q - s * np2;
+                    if (q < total2) {
+                        lds[(2 * m2) * P + s] = v[it].a;
+                        if (2 * m2 + 1 < Nh) lds[(2 * m2 + 1) * P + s] = v[it].b;
+                    }
+                }
+            }
         }
         __syncthreads();
-        g_transform<T, MAXV>(lds, ns, pitch, p, tw, 2);
+        if (!(dbg & 1)) g_transform<T, MAXV>(lds, lgG, P, p, tw, 2);
         // X[k] = (Z[k] + conj Z[Nh - k]) / 2 - (i / 2) w^k (Z[k] - conj Z[Nh - k]),  w = exp(-2 pi i / n),  Z[Nh] = Z[0]
         for (int q = threadIdx.x; q < ns * (Nh + 1); q += G_NT) {
             const int s = fdiv(q, mH1), k = q - s * (Nh + 1);
-            const C2<T> zk = lds[s * pitch + gpad<T>(k == Nh ? 0 : k)], zm = lds[s * pitch + gpad<T>(k == 0 ? 0 : Nh - k)];
+            const C2<T> zk = lds[(k == Nh ? 0 : k) * P + s], zm = lds[(k == 0 ? 0 : Nh - k) * P + s];
             const C2<T> e = {(T)0.5 * (zk.x + zm.x), (T)0.5 * (zk.y - zm.y)};      // even part
             const C2<T> o = {(T)0.5 * (zk.x - zm.x), (T)0.5 * (zk.y + zm.y)};      // (Z[k] - conj Z[Nh - k]) / 2
             const C2<T> w = k == Nh ? C2<T>{(T)-1, (T)0} : tw[k];
             const C2<T> wo = cmul(w, o);
-            reinterpret_cast<C2<T> *>(mesh + (r0 + s) * pitch_r)[k] = {e.x + wo.y, e.y - wo.x};   // e - i w o
+            if (!(dbg & 2) || e.x == (T)1.2345) reinterpret_cast<C2<T> *>(mesh + (r0 + s) * pitch_r)[k] = {e.x + wo.y, e.y - wo.x};   // e - i w o
         }
         __syncthreads();
     }
 }
 
 // ---- columns: element (row, col) of tile t at data[tile_base(t) + row * S + col] ------------------------------------------
-// tiles: outer index o < nouter (stride outer_stride) x column tile ct < ntile_c (C columns, C a power of two)
+// tiles: outer index o < nouter (stride outer_stride) x column tile ct < ntile_c (C = CG << lgG columns)
 template <typename T, int MAXV>
-__global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int n, int64_t S, int lgC, int ntile_c, int ncols,
-                                                  int64_t nouter, int64_t outer_stride, GPlan p, const C2<T> *__restrict__ twn) {
+__global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int n, int64_t S, int lgG, int ntile_c, int ncols,
+                                                  int64_t nouter, int64_t outer_stride, GPlan p, const C2<T> *__restrict__ twn, int dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
     C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
     C2<T> *lds = tw + n;
     for (int q = threadIdx.x; q < n; q += G_NT) tw[q] = twn[q];
-    const int C = 1 << lgC, pitch = gpad_len(n, pads<T>());
+    const int lgC = lgG + (cg_of<T>() == 4 ? 2 : 1), C = 1 << lgC, P = C + 1;
     const int64_t ntiles = nouter * ntile_c;
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int64_t o = t / ntile_c;
         const int c0 = (int)(t - o * ntile_c) * C, nc = min(C, ncols - c0);
         C2<T> *base = data + o * outer_stride + c0;
-        for (int q = threadIdx.x; q < n * C; q += G_NT) {
-            const int row = q >> lgC, c = q & (C - 1);
-            if (c < nc) lds[c * pitch + gpad<T>(row)] = base[(int64_t)row * S + c];
+        {   // 16-byte loads: two adjacent columns of a row per lane, a batch in flight before its LDS stores
+            constexpr int B = MAXV / 4;
+            const int total2 = n << (lgC - 1);
+            CPair<T> v[B];
+#pragma unroll 1
+            for (int q0 = threadIdx.x; q0 < total2; q0 += B * G_NT) {
+#pragma unroll
+                for (int it = 0; it < B; it++) {
+                    const int q = q0 + it * G_NT, row = q >> (lgC - 1), c = (q & (C / 2 - 1)) * 2;
+                    v[it] = CPair<T>{{(T)0, (T)0}, {(T)0, (T)0}};
+                    if (q < total2 && !(dbg & 2)) {
+                        const C2<T> *src = base + (int64_t)row * S + c;
+                        if (c + 1 < nc) v[it] = *reinterpret_cast<const CPair<T> *>(src);
+                        else if (c < nc) v[it].a = *src;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < B; it++) {
+                    const int q = q0 + it * G_NT, row = q >> (lgC - 1), c = (q & (C / 2 - 1)) * 2;
+                    if (q < total2) lds[row * P + c] = v[it].a, lds[row * P + c + 1] = v[it].b;
+                }
+            }
         }
         __syncthreads();
-        g_transform<T, MAXV>(lds, nc, pitch, p, tw, 1);
-        // (requesting the next tile into registers before the transform - 24 values per thread - was measured: the kernel spills
-        // and gains nothing, 18.5 vs 19.0 ms at 1536^3: the stages are bound by their index arithmetic, not by the memory phases)
-        for (int q = threadIdx.x; q < n * C; q += G_NT) {
-            const int row = q >> lgC, c = q & (C - 1);
-            if (c < nc) base[(int64_t)row * S + c] = lds[c * pitch + gpad<T>(row)];
+        if (!(dbg & 1)) g_transform<T, MAXV>(lds, lgG, P, p, tw, 1);
+        for (int q = threadIdx.x; q < (n << (lgC - 1)); q += G_NT) {
+            const int row = q >> (lgC - 1), c = (q & (C / 2 - 1)) * 2;
+            const CPair<T> w = {lds[row * P + c], lds[row * P + c + 1]};
+            if ((dbg & 2) && w.a.x != (T)1.2345) continue;
+            C2<T> *dst = base + (int64_t)row * S + c;
+            if (c + 1 < nc) *reinterpret_cast<CPair<T> *>(dst) = w;
+            else if (c < nc) *dst = w.a;
         }
         __syncthreads();
     }
@@ -319,6 +375,26 @@ int num_cus_g() {
     return ncu;
 }
 
+template <typename T, int MAXV>
+int launch_rows(T *mesh, int n, int pitch_r, const GPlan &ph, const C2<T> *twn, int ncu, int dbg) {
+    constexpr int CG = sizeof(T) == 4 ? 4 : 2;
+    const int Nh = n / 2, cap = MAXV * G_NT;
+    int lgG = 0;                                 // NSEQ = CG << lgG rows per tile, NSEQ x n / 2 values <= cap
+    while ((CG << (lgG + 1)) <= 32 && (CG << (lgG + 1)) * Nh <= cap) lgG++;
+    const int NSEQ = CG << lgG;
+    const size_t lds = ((size_t)n + (size_t)Nh * (NSEQ + 1)) * sizeof(C2<T>);
+    auto kern = gfft_rows<T, MAXV>;
+    static size_t lds_set = 0;                   // hipFuncSetAttribute is not free: once per size, not per launch
+    if (lds > lds_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    const int64_t nrows = (int64_t)n * n;
+    const unsigned int grid = (unsigned int)std::min<int64_t>(ceil_div(nrows, NSEQ), (int64_t)ncu * (lds > 80 * 1024 ? 1 : 2));
+    ABACUS_LAUNCH("gfft_rows", kern, dim3(grid), dim3(G_NT), lds, mesh, nrows, n, pitch_r, lgG, ph, twn, dbg);
+    return 0;
+}
+
 template <typename T>
 int r2c_inplace(T *mesh, int n, int pitch_r) {
     constexpr int MAXV = maxv<T>();
@@ -329,32 +405,29 @@ int r2c_inplace(T *mesh, int n, int pitch_r) {
     if (pitch_r < n + 2 || (pitch_r & 1)) return fail("gfft: row pitch %d too small for %d + 2", pitch_r, n);
     const C2<T> *twn;
     ABACUS_TRY(tables<T>().get(n, &twn));
-    const int ncu = num_cus_g();
-    {   // rows
-        const int Nh = n / 2;
-        const int nseq = std::max(1, std::min(64, cap / Nh));   // (tiles of a third, three workgroups per CU: 22.5 vs 19.8 ms at 1536^3)
-        const size_t lds = ((size_t)n + (size_t)nseq * gpad_len(Nh, pads<T>())) * sizeof(C2<T>);
-        auto kern = gfft_rows<T, MAXV>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int64_t nrows = (int64_t)n * n;
-        const unsigned int grid = (unsigned int)std::min<int64_t>(ceil_div(nrows, nseq), (int64_t)ncu * std::max<int64_t>(1, std::min<int64_t>(3, (150 * 1024) / (int64_t)lds)));
-        ABACUS_LAUNCH("gfft_rows", kern, dim3(grid), dim3(G_NT), lds, mesh, nrows, n, pitch_r, nseq, ph, twn);
-    }
+    const int ncu = num_cus_g(), dbg = (int)option("gfft_dbg");   // diagnostic: 1 no stages, 2 no mesh traffic (results are wrong)
+    constexpr int CG = sizeof(T) == 4 ? 4 : 2;
+    // rows: half-size tiles (two workgroups per CU) measured slower at 1536 (13.3 against 11.9 ms) and equal below
+    ABACUS_TRY((launch_rows<T, MAXV>(mesh, n, pitch_r, ph, twn, ncu, dbg)));
     const int pitch_c = pitch_r / 2, kzlen = n / 2 + 1;
-    int lgC = 0;
-    while ((2 << lgC) <= 16 && (2 << lgC) * n <= cap) lgC++;
-    const int C = 1 << lgC;
-    const size_t lds = ((size_t)n + (size_t)C * gpad_len(n, pads<T>())) * sizeof(C2<T>);
+    int lgG = 0;
+    while ((CG << (lgG + 1)) <= 16 && (CG << (lgG + 1)) * n <= cap) lgG++;
+    const int C = CG << lgG;
+    const size_t lds = ((size_t)n + (size_t)n * (C + 1)) * sizeof(C2<T>);
     auto kern = gfft_cols<T, MAXV>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
     const int ntile_c = (kzlen + C - 1) / C;
     const unsigned int grid = (unsigned int)std::min<int64_t>((int64_t)n * ntile_c, (int64_t)ncu * (lds > 80 * 1024 ? 1 : 2));
     C2<T> *data = reinterpret_cast<C2<T> *>(mesh);
     // y: for every x plane, columns along y (stride pitch_c); x: for every y row, columns along x (stride n * pitch_c)
-    ABACUS_LAUNCH("gfft_cols_y", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)pitch_c, lgC, ntile_c, kzlen, (int64_t)n,
-                  (int64_t)n * pitch_c, pn, twn);
-    ABACUS_LAUNCH("gfft_cols_x", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)n * pitch_c, lgC, ntile_c, kzlen, (int64_t)n,
-                  (int64_t)pitch_c, pn, twn);
+    ABACUS_LAUNCH("gfft_cols_y", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)pitch_c, lgG, ntile_c, kzlen, (int64_t)n,
+                  (int64_t)n * pitch_c, pn, twn, dbg);
+    ABACUS_LAUNCH("gfft_cols_x", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)n * pitch_c, lgG, ntile_c, kzlen, (int64_t)n,
+                  (int64_t)pitch_c, pn, twn, dbg);
     return 0;
 }
 
@@ -367,7 +440,7 @@ bool gfft_supported(int n, int is_double) {
     GPlan p;
     if (n < 8 || n > 4096 || (n & 1)) return false;
     if (!make_plan(n, p) || !make_plan(n / 2, p)) return false;
-    return n <= (is_double ? maxv<double>() : maxv<float>()) * G_NT / 2;   // at least two columns per tile
+    return n * (is_double ? 2 : 4) <= (is_double ? maxv<double>() : maxv<float>()) * G_NT;   // at least one column group per tile
 }
 int gfft_r2c_inplace_f32(float *mesh, int n, int pitch_r) { return r2c_inplace<float>(mesh, n, pitch_r); }
 int gfft_r2c_inplace_f64(double *mesh, int n, int pitch_r) { return r2c_inplace<double>(mesh, n, pitch_r); }

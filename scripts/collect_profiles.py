@@ -25,7 +25,7 @@ FETCH_FACTOR = {'fft_cols<2048, 8>': 1.0}   # 64-B row segments; every other ker
 FETCH_PREFIX = {'fft_x_bin<1024, 8': (1.0, 'uncalibrated width (64-B row segments): raw FETCH_SIZE, known read = 4 B per mesh cell'),
                 'fft_x_bin2<1024, 8': (1.0, 'uncalibrated width (64-B row segments): raw FETCH_SIZE, known read = 4 B per mesh cell')}
 
-for d in ('prof_hod', 'prof_pk1024', 'prof_pk2048'):
+for d in ('prof_hod', 'prof_pk1024', 'prof_pk1536', 'prof_pk2048'):
     # gpurun MERGES its output into gpurun_out/: summaries of earlier calls are still there - take the newest
     found = sorted(glob.glob(os.path.join(src, d, '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime)
     if found:

@@ -4,11 +4,11 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/gfft
 mkdir -p "$O"
 for NM in ${MESHES:-96 384 550 768 1536}; do
-  for spec in gen:fft_generic=1 hip; do
+  for spec in gen hip:fft_hipfft=1; do
     mode=${spec%%:*}; opt_=()
     [ "$spec" != "$mode" ] && opt_=(--option "${spec#*:}")
     NP=$(( NM > 600 ? 100000000 : 20000000 ))
-    timeout -k 10 300 python bench.py --workload pk --nmesh $NM --npk $NP --steps 4 --warmup 1 --no-cpu "${opt_[@]}" > "$O/pk${NM}_$mode.json" 2> "$O/pk${NM}_$mode.err" || { tail -3 "$O/pk${NM}_$mode.err"; exit 1; }
+    timeout -k 10 300 python bench.py --workload pk --nmesh $NM --npk $NP --steps 6 --warmup 2 --no-cpu "${opt_[@]}" > "$O/pk${NM}_$mode.json" 2> "$O/pk${NM}_$mode.err" || { tail -3 "$O/pk${NM}_$mode.err"; exit 1; }
     python - "$O/pk${NM}_$mode.json" "$NM $mode" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

@@ -20,11 +20,11 @@ bench)
 prof)
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_hod" -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu --no-pk --no-hod-extra > "$O/prof_hod.log" 2>&1
-  for NM in 1024 2048; do
+  for NM in 1024 1536 2048; do
     timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_pk$NM" -- python3 "$R/bench.py" --workload pk --nmesh $NM --steps 3 --warmup 1 --no-cpu > "$O/prof_pk$NM.log" 2>&1
   done
   cd "$R"
-  for d in prof_hod prof_pk1024 prof_pk2048; do
+  for d in prof_hod prof_pk1024 prof_pk1536 prof_pk2048; do
     f=$(find "$O/$d" -name "*kernel_stats.csv" | head -1); echo "== $d"; cut -c1-160 "$f" | head -14
     find "$O/$d" -name "*kernel_trace.csv" -delete; find "$O/$d" -name "*.db" -delete
   done
@@ -33,7 +33,9 @@ pmc)
   cd /tmp
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/pmc_hod_$C" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu --no-pk --no-hod-extra > "$O/pmc_hod_$C.log" 2>&1
-    timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/pmc_pk2048_$C" -- python3 "$R/bench.py" --workload pk --nmesh 2048 --steps 2 --warmup 1 --no-cpu > "$O/pmc_pk2048_$C.log" 2>&1
+    for NM in 1024 2048; do
+      timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/pmc_pk${NM}_$C" -- python3 "$R/bench.py" --workload pk --nmesh $NM --steps 2 --warmup 1 --no-cpu > "$O/pmc_pk${NM}_$C.log" 2>&1
+    done
   done
   cd "$R"
   python3 scripts/summarize_pmc.py "$O" > "$O/pmc_summary.json"; cat "$O/pmc_summary.json" | head -60

@@ -650,8 +650,8 @@ def test_exported_pieces_of_the_chain(n):
 @pytest.mark.parametrize('nmesh,npart', [(72, 40_000), (96, 50_000), (110, 60_000), (182, 100_000), (384, 400_000), (550, 2_500_000)])
 def test_mixed_radix_meshes_take_the_native_transform(nmesh, npart, options):
     """meshes with factors 3, 5, 7, 11, 13 - the reference's own test mesh 72 (tests/test_power.py:33), compute_power's default
-    num_cells = 550 (hod/abacus_hod.py:1347) - through the hand-written mixed-radix passes of csrc/gfft.hip (option
-    fft_generic: hipFFT is the faster transform at these sizes and stays the default, the float64 meshes always take gfft):
+    num_cells = 550 (hod/abacus_hod.py:1347) - through the hand-written mixed-radix passes of csrc/gfft.hip (the default
+    for every even size with factors up to 13; the float64 meshes take the same kernels in double):
     calc_power against the oracle (scipy's pocketfft = the reference's transform) at 1e-5, and the spectrum itself against
     the hipFFT path"""
     from abacusutils_amd import _lib
@@ -660,7 +660,6 @@ def test_mixed_radix_meshes_take_the_native_transform(nmesh, npart, options):
     box = 1000.0
     pos = synth.synth_positions(npart, box, seed=nmesh, clustered=True)
     kw = dict(kbins=20, mubins=3, k_max=np.pi * nmesh / box, paste='TSC', nmesh=nmesh, compensated=True, interlaced=True, poles=[0, 2, 4])
-    options.set('fft_generic', 1)
     _lib.profile_reset()
     _lib.profile_enable(True)
     tab = calc_power(pos.copy(), box, **kw)
@@ -670,7 +669,7 @@ def test_mixed_radix_meshes_take_the_native_transform(nmesh, npart, options):
     _check_oracle(tab, oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw))
     if nmesh <= 182:
         a = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, False)
-        options.set('fft_generic', 0)
+        options.set('fft_hipfft', 1)
         b = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, False)
         assert np.abs(a - b).max() <= 3e-6 * np.abs(b).max()
 
