@@ -513,8 +513,8 @@ int gfft_release();
 // the tuned power-of-two kernels of this file (also what the slab-decomposed transform needs)
 bool fft_native_pow2(int n) { return n >= 64 && n <= 2048 && (n & (n - 1)) == 0; }
 // ... or the mixed-radix kernels of gfft.hip (even sizes with factors 2, 3, 5, 7, 11, 13: 72, 96, 384, 550, 768, 1536 ...).
-// Per 3-D transform against hipFFT (profiles/r04/gfft_vs_hipfft.txt): 384^3 0.56 vs 0.58 ms, 550^3 1.72 vs 1.96, 768^3 4.0 vs 4.7,
-// 1152^3 17.1 vs 17.1, 1536^3 36.8 vs 39.3.  Sizes neither family covers (odd, or a prime factor above 13) go to hipFFT.
+// Per 3-D transform against hipFFT (profiles/r04/gfft_vs_hipfft.txt): 384^3 0.53 vs 0.58 ms, 550^3 1.51 vs 1.90, 768^3 3.5 vs 4.6,
+// 1152^3 14.4 vs 16.9, 1536^3 30.4 vs 38.8.  Sizes neither family covers (odd, or a prime factor above 13) go to hipFFT.
 bool fft_native_supported(int n) { return fft_native_pow2(n) || gfft_supported(n, 0); }
 
 // z and y passes over `nx_local` consecutive x-planes (the part of the transform that is local to an x-slab)

@@ -9,8 +9,9 @@
 // 2 / 3 / 4 / 5 / 7 / 8 / 11 / 13 per stage from a runtime plan; a stage reads all its butterflies into registers, meets at
 // a barrier and writes them back, so the tile needs one buffer.  Templated on the scalar type: float for calc_power's
 // default, double for dtype=np.float64 meshes (analysis/power_spectrum.py:808,1148).
-// The power-of-two meshes keep the tuned kernels of fft.hip (wave-local passes, fused stages): this path runs at roughly
-// hipFFT's rate, not at theirs.
+// The power-of-two meshes keep the tuned kernels of fft.hip (wave-local passes, fused stages, 0.5 of the HBM peak); this
+// path runs at 0.35 - 0.37 per pass (1536^3: 30.4 ms against hipFFT's 38.8, profiles/r04/gfft_vs_hipfft.txt): a pass is
+// bound by the vector ALU of its stages (~8.7 ms of compute at 1536^3), which the prefetch hides the loads behind.
 #include <cmath>
 #include <map>
 #include <vector>
@@ -36,9 +37,30 @@ template <typename T>
 __device__ __forceinline__ C2<T> csub(C2<T> a, C2<T> b) { return {a.x - b.x, a.y - b.y}; }
 
 template <typename T>
-struct alignas(2 * sizeof(C2<T>)) CPair {
+struct alignas(16) CPair {
     C2<T> a, b;
 };
+
+// loads through vector types: a conditional assignment of a 16-byte struct from global memory is lowered to a copy into a
+// stack slot (scratch, and a wait per load) - a vector value stays in registers
+template <typename T>
+__device__ __forceinline__ CPair<T> ld_pair(const C2<T> *p) {
+    if constexpr (sizeof(T) == 4) {
+        typedef float V4 __attribute__((ext_vector_type(4)));
+        const V4 v = *reinterpret_cast<const V4 *>(p);
+        return {{v.x, v.y}, {v.z, v.w}};
+    } else {
+        typedef double V2 __attribute__((ext_vector_type(2)));
+        const V2 a = reinterpret_cast<const V2 *>(p)[0], b = reinterpret_cast<const V2 *>(p)[1];
+        return {{a.x, a.y}, {b.x, b.y}};
+    }
+}
+template <typename T>
+__device__ __forceinline__ C2<T> ld_one(const C2<T> *p) {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    const V2 a = *reinterpret_cast<const V2 *>(p);
+    return {a.x, a.y};
+}
 
 struct GPlan {
     int n;                 // sequence length
@@ -148,8 +170,11 @@ constexpr int cg_of() { return sizeof(T) == 4 ? 4 : 2; }
 
 template <typename T, int R, int MAXV>
 __device__ __forceinline__ void g_stage(C2<T> *lds, int lgG, int P, int N, int Ns, const C2<T> *tw, int tws) {
-    constexpr int CG = cg_of<T>();
+    // the large radices take half the sequences per item (their butterflies hold R x CG values: the registers of a prefetched
+    // tile must survive them)
+    constexpr int CG = R >= 7 ? cg_of<T>() / 2 : cg_of<T>();
     constexpr int MAXIT = (MAXV + R * CG - 1) / (R * CG);
+    lgG += cg_of<T>() == CG ? 0 : 1;
     const int BPS = N / R, total = BPS << lgG, step = tws * (N / (Ns * R));
     const unsigned int mN = Ns > 1 ? magic_of(Ns) : 0u;
     C2<T> v[MAXIT][CG][R];
@@ -266,7 +291,11 @@ __global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t 
 }
 
 // ---- columns: element (row, col) of tile t at data[tile_base(t) + row * S + col] ------------------------------------------
-// tiles: outer index o < nouter (stride outer_stride) x column tile ct < ntile_c (C = CG << lgG columns)
+// tiles: outer index o < nouter (stride outer_stride) x column tile ct < ntile_c (C = CG << lgG columns).
+// One workgroup per CU (the tile fills the LDS), so the loads of the NEXT tile are issued into registers before the stages
+// of the current one and land in LDS after its write-back: the memory phase (7 ms of a 1536^3 pass) runs under the
+// stages (8.7 ms) instead of in front of them (1536^3: 12.2 -> 9.7 ms per pass).  The row pass keeps batched loads in
+// front of its stages: walking a row per thread group, which the one-pointer prefetch needs, measured 12.1 ms against 10.3.
 template <typename T, int MAXV>
 __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int n, int64_t S, int lgG, int ntile_c, int ncols,
                                                   int64_t nouter, int64_t outer_stride, GPlan p, const C2<T> *__restrict__ twn, int dbg) {
@@ -276,36 +305,64 @@ __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int 
     for (int q = threadIdx.x; q < n; q += G_NT) tw[q] = twn[q];
     const int lgC = lgG + (cg_of<T>() == 4 ? 2 : 1), C = 1 << lgC, P = C + 1;
     const int64_t ntiles = nouter * ntile_c;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int total2 = n << (lgC - 1);            // 16-byte (32-byte in double) pairs of adjacent columns: <= MAXV / 2 per thread
+    constexpr int NPRE = MAXV / 2;
+    CPair<T> pre[NPRE];
+    auto tile_base = [&](int64_t t, int &nc) {
         const int64_t o = t / ntile_c;
-        const int c0 = (int)(t - o * ntile_c) * C, nc = min(C, ncols - c0);
-        C2<T> *base = data + o * outer_stride + c0;
-        {   // 16-byte loads: two adjacent columns of a row per lane, a batch in flight before its LDS stores
-            constexpr int B = MAXV / 4;
-            const int total2 = n << (lgC - 1);
-            CPair<T> v[B];
-#pragma unroll 1
-            for (int q0 = threadIdx.x; q0 < total2; q0 += B * G_NT) {
+        const int c0 = (int)(t - o * ntile_c) * C;
+        nc = min(C, ncols - c0);
+        return data + o * outer_stride + c0;
+    };
+    // pair q = it * G_NT + tid of a tile: column pair c = 2 (q mod C / 2) is the thread's own for every it, its row advances
+    // by dr = G_NT / (C / 2) - one pointer and a uniform stride, no per-load offsets to keep
+    const int c = (threadIdx.x & (C / 2 - 1)) * 2, row0 = threadIdx.x >> (lgC - 1), dr = G_NT >> (lgC - 1);
+    auto issue = [&](int64_t t) {
+        int nc;
+        const C2<T> *src = tile_base(t, nc) + (int64_t)row0 * S + c;
+        const int64_t stride = (int64_t)dr * S;
+        const int mode = (dbg & 2) ? 0 : c + 1 < nc ? 2 : c < nc ? 1 : 0;
 #pragma unroll
-                for (int it = 0; it < B; it++) {
-                    const int q = q0 + it * G_NT, row = q >> (lgC - 1), c = (q & (C / 2 - 1)) * 2;
-                    v[it] = CPair<T>{{(T)0, (T)0}, {(T)0, (T)0}};
-                    if (q < total2 && !(dbg & 2)) {
-                        const C2<T> *src = base + (int64_t)row * S + c;
-                        if (c + 1 < nc) v[it] = *reinterpret_cast<const CPair<T> *>(src);
-                        else if (c < nc) v[it].a = *src;
+        for (int it = 0; it < NPRE; it++) {
+            if constexpr (sizeof(T) == 4) {
+                pre[it] = CPair<T>{{(T)0, (T)0}, {(T)0, (T)0}};
+                if (row0 + it * dr < n) {
+                    if (mode == 2) pre[it] = *reinterpret_cast<const CPair<T> *>(src);
+                    else if (mode == 1) pre[it].a = *src;
+                }
+            } else {     // (a conditional 16-byte struct assignment from global memory would go through a stack slot)
+                T ax = 0, ay = 0, bx = 0, by = 0;
+                if (row0 + it * dr < n) {
+                    if (mode == 2) {
+                        const CPair<T> v = ld_pair(src);
+                        ax = v.a.x, ay = v.a.y, bx = v.b.x, by = v.b.y;
+                    } else if (mode == 1) {
+                        const C2<T> v = ld_one(src);
+                        ax = v.x, ay = v.y;
                     }
                 }
+                pre[it].a = {ax, ay}, pre[it].b = {bx, by};
+            }
+            src += stride;
+        }
+    };
+    int64_t t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    for (; t < ntiles; t += gridDim.x) {
+        {
+            C2<T> *l = lds + row0 * P + c;
 #pragma unroll
-                for (int it = 0; it < B; it++) {
-                    const int q = q0 + it * G_NT, row = q >> (lgC - 1), c = (q & (C / 2 - 1)) * 2;
-                    if (q < total2) lds[row * P + c] = v[it].a, lds[row * P + c + 1] = v[it].b;
-                }
+            for (int it = 0; it < NPRE; it++) {
+                if (row0 + it * dr < n) l[0] = pre[it].a, l[1] = pre[it].b;
+                l += dr * P;
             }
         }
         __syncthreads();
+        if (t + gridDim.x < ntiles && !(dbg & 4)) issue(t + gridDim.x);
         if (!(dbg & 1)) g_transform<T, MAXV>(lds, lgG, P, p, tw, 1);
-        for (int q = threadIdx.x; q < (n << (lgC - 1)); q += G_NT) {
+        int nc;
+        C2<T> *base = tile_base(t, nc);
+        for (int q = threadIdx.x; q < total2; q += G_NT) {
             const int row = q >> (lgC - 1), c = (q & (C / 2 - 1)) * 2;
             const CPair<T> w = {lds[row * P + c], lds[row * P + c + 1]};
             if ((dbg & 2) && w.a.x != (T)1.2345) continue;
@@ -314,6 +371,7 @@ __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int 
             else if (c < nc) *dst = w.a;
         }
         __syncthreads();
+        if (t + gridDim.x < ntiles && (dbg & 4)) issue(t + gridDim.x);
     }
 }
 
