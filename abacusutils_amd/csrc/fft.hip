@@ -507,7 +507,7 @@ int fft_x(float2 *data, int pitch_c, Tables *t, int64_t ny_local, int64_t x_stri
 namespace abacus {
 
 bool gfft_supported(int n, int is_double);
-int gfft_r2c_inplace_f32(float *mesh, int n, int pitch_r);
+int gfft_r2c_inplace_f32(float *mesh, int n, int pitch_r, float xcut);
 int gfft_release();
 
 // the tuned power-of-two kernels of this file (also what the slab-decomposed transform needs)
@@ -549,8 +549,9 @@ int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_st
     return fail("fft: unsupported size %d", n);
 }
 
-int fft_native_r2c_inplace(float *mesh, int n, int pitch_r) {
-    if (!fft_native_pow2(n)) return gfft_r2c_inplace_f32(mesh, n, pitch_r);
+// xcut > 0 (mixed-radix sizes): see fft_native_r2c_fused
+int fft_native_r2c_inplace(float *mesh, int n, int pitch_r, float xcut) {
+    if (!fft_native_pow2(n)) return gfft_r2c_inplace_f32(mesh, n, pitch_r, xcut);
     ABACUS_TRY(fft_native_zy(mesh, n, pitch_r, n));
     return fft_native_x(mesh, n, pitch_r, n, (int64_t)n * (pitch_r / 2), pitch_r / 2);
 }

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t 
 // front of its stages: walking a row per thread group, which the one-pointer prefetch needs, measured 12.1 ms against 10.3.
 template <typename T, int MAXV>
 __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int n, int64_t S, int lgG, int ntile_c, int ncols,
-                                                  int64_t nouter, int64_t outer_stride, GPlan p, const C2<T> *__restrict__ twn, int dbg) {
+                                                  int64_t nouter, int64_t outer_stride, GPlan p, const C2<T> *__restrict__ twn, int dbg, float xcut) {
     extern __shared__ __align__(16) unsigned char smem[];
     C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
     C2<T> *lds = tw + n;
@@ -346,9 +346,24 @@ __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int 
             src += stride;
         }
     };
+    // xcut > 0 (x pass, the caller bins up to |k|^2 = xcut in fundamental units and reads nothing beyond): tiles whose first
+    // column already has ky^2 + kz^2 > xcut hold no mode anybody reads - neither loaded nor transformed
+    auto dead = [&](int64_t t) {
+        if (!(xcut > 0.f)) return false;
+        const int64_t o = t / ntile_c;
+        const int j = (int)o, jj = j < n / 2 ? j : j - n, k0 = (int)(t - o * ntile_c) * C;
+        return (float)(jj * jj + k0 * k0) > xcut;
+    };
+    auto next = [&](int64_t t) {
+        do t += gridDim.x;
+        while (t < ntiles && dead(t));
+        return t;
+    };
     int64_t t = blockIdx.x;
+    if (t < ntiles && dead(t)) t = next(t);
     if (t < ntiles) issue(t);
-    for (; t < ntiles; t += gridDim.x) {
+    for (int64_t tn; t < ntiles; t = tn) {
+        tn = next(t);
         {
             C2<T> *l = lds + row0 * P + c;
 #pragma unroll
@@ -358,7 +373,7 @@ __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int 
             }
         }
         __syncthreads();
-        if (t + gridDim.x < ntiles && !(dbg & 4)) issue(t + gridDim.x);
+        if (tn < ntiles && !(dbg & 4)) issue(tn);
         if (!(dbg & 1)) g_transform<T, MAXV>(lds, lgG, P, p, tw, 1);
         int nc;
         C2<T> *base = tile_base(t, nc);
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int 
             else if (c < nc) *dst = w.a;
         }
         __syncthreads();
-        if (t + gridDim.x < ntiles && (dbg & 4)) issue(t + gridDim.x);
+        if (tn < ntiles && (dbg & 4)) issue(tn);
     }
 }
 
@@ -454,7 +469,7 @@ int launch_rows(T *mesh, int n, int pitch_r, const GPlan &ph, const C2<T> *twn, 
 }
 
 template <typename T>
-int r2c_inplace(T *mesh, int n, int pitch_r) {
+int r2c_inplace(T *mesh, int n, int pitch_r, float xcut = 0.f) {
     constexpr int MAXV = maxv<T>();
     GPlan ph, pn;
     if (n < 4 || (n & 1) || !make_plan(n / 2, ph) || !make_plan(n, pn)) return fail("gfft: mesh size %d is not an even product of 2, 3, 5, 7, 11, 13", n);
@@ -483,9 +498,9 @@ int r2c_inplace(T *mesh, int n, int pitch_r) {
     C2<T> *data = reinterpret_cast<C2<T> *>(mesh);
     // y: for every x plane, columns along y (stride pitch_c); x: for every y row, columns along x (stride n * pitch_c)
     ABACUS_LAUNCH("gfft_cols_y", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)pitch_c, lgG, ntile_c, kzlen, (int64_t)n,
-                  (int64_t)n * pitch_c, pn, twn, dbg);
+                  (int64_t)n * pitch_c, pn, twn, dbg, 0.f);
     ABACUS_LAUNCH("gfft_cols_x", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)n * pitch_c, lgG, ntile_c, kzlen, (int64_t)n,
-                  (int64_t)pitch_c, pn, twn, dbg);
+                  (int64_t)pitch_c, pn, twn, dbg, xcut);
     return 0;
 }
 
@@ -500,7 +515,7 @@ bool gfft_supported(int n, int is_double) {
     if (!make_plan(n, p) || !make_plan(n / 2, p)) return false;
     return n * (is_double ? 2 : 4) <= (is_double ? maxv<double>() : maxv<float>()) * G_NT;   // at least one column group per tile
 }
-int gfft_r2c_inplace_f32(float *mesh, int n, int pitch_r) { return r2c_inplace<float>(mesh, n, pitch_r); }
+int gfft_r2c_inplace_f32(float *mesh, int n, int pitch_r, float xcut) { return r2c_inplace<float>(mesh, n, pitch_r, xcut); }
 int gfft_r2c_inplace_f64(double *mesh, int n, int pitch_r) { return r2c_inplace<double>(mesh, n, pitch_r); }
 int gfft_release() {
     ABACUS_TRY(g_tw32.release());

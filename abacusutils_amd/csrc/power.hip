@@ -50,7 +50,7 @@ int tsc_deposit_f64pos(double *pos, int64_t n, const double *w, float *grid, int
 int tsc_release_work();
 bool fft_native_supported(int n);
 bool fft_native_pow2(int n);
-int fft_native_r2c_inplace(float *mesh, int n, int pitch_r);
+int fft_native_r2c_inplace(float *mesh, int n, int pitch_r, float xcut = 0.f);
 int fft_native_zy(float *mesh, int n, int pitch_r, int64_t nx_local);
 int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_stride, int64_t y_stride);
 int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
@@ -763,7 +763,7 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
         if (native && fused) {
             ABACUS_TRY(skip_x ? fft_native_r2c_fused_zy(mesh, nmesh, (int)zstride, xcut) : fft_native_r2c_fused(mesh, nmesh, (int)zstride, xcut));
         } else if (native) {
-            ABACUS_TRY(fft_native_r2c_inplace(mesh, nmesh, (int)zstride));   // fft.hip: three passes, one per axis
+            ABACUS_TRY(fft_native_r2c_inplace(mesh, nmesh, (int)zstride, xcut));   // three passes, one per axis
         } else {
             prof_begin("hipfft_r2c");
             hipfftResult r = hipfftExecR2C(plan, (hipfftReal *)mesh, (hipfftComplex *)mesh);
@@ -1039,7 +1039,7 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
     // y pass need not write, and the x pass need not transform, what lies entirely beyond it (margin: one part in 1e5 + 1
     // against the float32 edge test of the binning)
     float xcut = 0.f;
-    if (fused && Nk > 0) {
+    if ((fused || !fft_native_pow2(nmesh)) && Nk > 0) {
         const double e = kedges[Nk] / (2.0 * M_PI / Lbox);
         xcut = (float)(e * e * (1.0 + 1e-5) + 1.0);
     }
