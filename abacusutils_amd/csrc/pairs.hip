@@ -843,10 +843,11 @@ int sort_into_cells(const void *hx, const void *hy, const void *hz, int where, i
         (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, s.cellid.as<unsigned int>(), s.keys2.as<unsigned int>(),
                                                  s.idx.as<unsigned int>(), s.idx2.as<unsigned int>(), (int)n, 0, end_bit, stream());
         ABACUS_TRY(s.tmp.reserve(tmp_bytes));
-        if (hipcub::DeviceRadixSort::SortPairs(s.tmp.p, tmp_bytes, s.cellid.as<unsigned int>(), s.keys2.as<unsigned int>(),
-                                               s.idx.as<unsigned int>(), s.idx2.as<unsigned int>(), (int)n, 0, end_bit,
-                                               stream()) != hipSuccess)
-            return fail("abacus_paircount: radix sort failed");
+        prof_begin("pair_cell_sort");         // library kernels (rocPRIM radix sort of the cell ids): listed with the hand-written ones
+        const hipError_t sorted = hipcub::DeviceRadixSort::SortPairs(s.tmp.p, tmp_bytes, s.cellid.as<unsigned int>(), s.keys2.as<unsigned int>(),
+                                                                     s.idx.as<unsigned int>(), s.idx2.as<unsigned int>(), (int)n, 0, end_bit, stream());
+        prof_end("pair_cell_sort");
+        if (sorted != hipSuccess) return fail("abacus_paircount: radix sort failed");
         ABACUS_LAUNCH("pair_cell_fill", cell_gather, dim3(nblk), dim3(256), 0, s.packed.as<float4>(), n, s.idx2.as<unsigned int>(), s.sx,
                       s.sy, s.sz);
         const int cblk = (int)std::min<int64_t>(ceil_div(ncell + 1, 256), 8192);
