@@ -61,7 +61,8 @@ int fft_native_r2c_fused(float *mesh, int n, int pitch_r, float xcut = 0.f);   /
 int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r, float xcut = 0.f);
 bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
-                  int y0 = 0, int ny_local = 0, int put_geom = 1, int layout = 0, int world = 1);
+                  int y0 = 0, int ny_local = 0, int put_geom = 1, int layout = 0, int world = 1, const float *mesh_shifted = nullptr,
+                  const float2 *phase = nullptr);
 bool xbin2_supported(int n, const BinArgs &b, bool comp);
 int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int h, int64_t xsep, int xg0, int p0, int pc, float *pack_out,
                              int world);
@@ -1043,15 +1044,17 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
         const double e = kedges[Nk] / (2.0 * M_PI / Lbox);
         xcut = (float)(e * e * (1.0 + 1e-5) + 1.0);
     }
-    if (fused && !interlaced && !cross && !option("pk_noxbin")) {
-        // auto power of one field: the last FFT pass bins straight from LDS (xbin.hip) - no spectrum write + re-read
+    if (fused && !cross && !option("pk_noxbin") && !(interlaced && option("pk_noxbin_inter"))) {
+        // auto power of one field (or of its interlaced pair): the last FFT pass bins straight from LDS (xbin.hip) - no
+        // spectrum write + re-read; the interlaced pair needs the cached-geometry kernel
         BinArgs b;
         size_t acc_bytes = 0;
         ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
-        if (xbin_supported(nmesh, Nk, Nmu, b, W_dev != nullptr)) {
-            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 0, 0, true, /*skip_x=*/true, nullptr, pf64, xcut));
+        if (interlaced ? xbin2_supported(nmesh, b, W_dev != nullptr) : xbin_supported(nmesh, Nk, Nmu, b, W_dev != nullptr)) {
+            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, true, /*skip_x=*/true, nullptr, pf64, xcut));
             const double M = (double)nmesh * nmesh * nmesh;
-            ABACUS_TRY(fft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg));
+            ABACUS_TRY(fft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, 0, 0, 1, 0, 1,
+                                     interlaced ? g_ctx.mesh[1].as<float>() : nullptr, g_ctx.phase.as<float2>()));
             return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
                                 2.0 * M_PI / Lbox, 0);
         }

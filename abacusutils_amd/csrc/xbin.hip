@@ -56,6 +56,11 @@ struct XBinGeom {
     int lgh;
     int ny, y0;
     int put_geom;               // copy the cached N_mode / sum |k| into the accumulators (one rank of a slab run does)
+    // interlaced (fft_x_bin2<.., INTER>): the half-cell-shifted field's mesh in the same layout, the table of the exact
+    // phases exp(i pi m / n), m < 2n, and f32(0.5 / M) (analysis/power_spectrum.py:932-947, 996-998)
+    const float2 *data2 = nullptr;
+    const float2 *phase = nullptr;
+    float half_inv_size = 0.f;
 };
 
 template <int H, int C, int NP, bool COMP>
@@ -410,7 +415,11 @@ __global__ __launch_bounds__(256) void xbin_geometry(int n, int Nk, int Nmu, con
 // lies outside the edges and are never read.
 // The rows of a tile may come straight from the receive buffer of a multi-GPU pencil transpose (XBinGeom: every peer's block
 // holds a run of h rows of either half): no unpack pass, no second copy of the slab.
-template <int H, int C, int NP, bool COMP, int MU, bool RUNS>
+// INTER: the interlaced pair of fields in one pass.  A tile of the unshifted field is transformed first and every wave keeps
+// the values of its column(s) in registers; the same tile of the shifted field follows through the same LDS, and the bin
+// takes |(a + a' exp(i pi m / n)) f32(0.5 / M)|^2, m = i + j + k - what spectrum_bin<INTER> computes from two spectra in
+// HBM, without the two x passes writing them (2 x 8M bytes) and the binning reading them back (8M).
+template <int H, int C, int NP, bool COMP, int MU, bool RUNS, bool INTER = false>
 __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restrict__ data, XBinGeom g, BinArgs b, XDesc d,
                                                           const float2 *__restrict__ twH) {
     constexpr int CP = colpitch_of<H>();
@@ -434,8 +443,8 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     float2 tw1[8], tw2[8];
 #pragma unroll
     for (int r = 1; r < 8; r++) {
-        tw1[r] = twH[(tid / (C / 2)) * r];
-        tw2[r] = twH[(lane % (H / 64)) * r * 8];
+        tw1[r] = INTER ? make_float2(0.f, 0.f) : twH[(tid / (C / 2)) * r];
+        tw2[r] = (INTER && H == 1024) ? make_float2(0.f, 0.f) : twH[(lane % (H / 64)) * r * 8];
     }
     tw1[0] = tw2[0] = make_float2(1.f, 0.f);
     for (int q = tid; q < nbx; q += XB_THREADS) h_sum[q] = 0.0;
@@ -448,15 +457,15 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     const int ntile_c = (g.kzlen + C - 1) / C;
     const int64_t S = g.xs;
     const int n_outer = 2 * g.ny;
-    const float inv2 = g.inv_size * g.inv_size;
+    const float inv2 = INTER ? g.half_inv_size * g.half_inv_size : g.inv_size * g.inv_size;
     const int sh = d.sh;
     const unsigned int *lut0 = lut - d.off;
 
     v4f regs[NLD];
     const int lgh = g.lgh, hmask = (1 << lgh) - 1;
-    auto tile_ptr = [&](int o, int ct) {
+    auto tile_ptr = [&](int o, int ct, const float2 *base) {
         const int xh = o >= g.ny ? 1 : 0, yr = o - xh * g.ny;
-        return data + ((int64_t)xh << lgh) * S + (int64_t)yr * g.ys + ct * C;
+        return base + ((int64_t)xh << lgh) * S + (int64_t)yr * g.ys + ct * C;
     };
     auto prefetch = [&](const float2 *p) {
 #pragma unroll
@@ -481,8 +490,10 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
         dft<8>(w);
 #pragma unroll
         for (int r = 1; r < 8; r++) {
-            u[r] = cmul(u[r], tw1[r]);
-            w[r] = cmul(w[r], tw1[r]);
+            // INTER: the kept columns of the first field need the registers - the staging twiddles come from the (cached) table
+            const float2 t = INTER ? twH[(tid / (C / 2)) * r] : tw1[r];
+            u[r] = cmul(u[r], t);
+            w[r] = cmul(w[r], t);
         }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -500,21 +511,35 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     const int a0 = lane * RUN;
     const int offA = padq(a0);
     // transform (the passes behind the staged one) and bin the C columns of the staged tile: half xh of x, y-row yr, column tile
-    auto process = [&](const int xh, const int yr, const int ct_cur) {
+    // columns per wave, and what a wave keeps of the first field's columns between the two halves of an interlaced tile
+    constexpr int NCW = C / (XB_THREADS / 64);
+    static_assert(NCW * (XB_THREADS / 64) == C, "whole columns per wave");
+    float2 keepA[INTER ? NCW : 1][RUN], keepB[INTER ? NCW : 1][RUN], keepQ[INTER ? NCW : 1];
+    // mode 0: transform and bin (one field); 1: transform and keep (first field of an interlaced pair); 2: transform, combine
+    // with what was kept, bin
+    auto process = [&](const int xh, const int yr, const int ct_cur, const int mode) {
         const int j = ((yr & (H - 1)) << 1) | (yr >= H ? 1 : 0);
         const int jj = j < n / 2 ? j : j - n;
         // mirrors: xh = 1: H-1-a; xh = 0: H-a (a >= 1), a = 0 is its own mirror (i = 0, one mode)
         const int offB = xh ? padq(H - 1 - a0) : padq(H - 1 - a0) + 1;      // minus s (xh = 0: s >= 1)
         const int offB0 = xh ? offB : padq((H - a0) & (H - 1));
         const float mB0 = (!xh && lane == 0) ? 0.f : 1.f;
-#pragma unroll 1
-        for (int c = wave; c < C; c += XB_THREADS / 64) {
+#pragma unroll
+        for (int ci = 0; ci < NCW; ci++) {
+            const int c = wave + ci * (XB_THREADS / 64);
             float2 *col = lds + c * CP;
             const int k = ct_cur * C + c;
             const int r2 = jj * jj + k * k;
             // padding columns of the last tile and columns that lie beyond the last edge as a whole: neither transformed nor binned
             if (!(g.dbg & 16) && (k >= g.kzlen || r2 > d.vtop)) continue;
             if (!(g.dbg & 1)) {
+                if (INTER && H == 1024) {   // one column per wave and 32 registers of kept values: the lane's twiddles only while the pass runs
+                    float2 twl[8];
+                    twl[0] = make_float2(1.f, 0.f);
+#pragma unroll
+                    for (int r = 1; r < 8; r++) twl[r] = twH[(lane % (H / 64)) * r * 8];
+                    dif_pass_w_regtw<H, H / 8, 8>(col, twl, lane);
+                } else
                 dif_pass_w_regtw<H, H / 8, 8>(col, tw2, lane);          // the passes behind the one stage() performed
                 PassesW<H, H / 64>::run(col, nullptr, lane);            // last pass: no twiddles
                 wave_sync();
@@ -539,7 +564,30 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
 #pragma unroll
                 for (int s = 1; s < RUN; s++) vB[s] = col[offB - s];
             }
+            if (INTER && mode == 1) {          // first field: keep the column, bin nothing
+#pragma unroll
+                for (int s = 0; s < RUN; s++) keepA[INTER ? ci : 0][s] = vA[s], keepB[INTER ? ci : 0][s] = vB[s];
+                keepQ[INTER ? ci : 0] = (!xh && lane == 63) ? col[padq(H / 2)] : make_float2(0.f, 0.f);
+                continue;
+            }
             const int i0 = 2 * a0 + xh;
+            if (INTER) {                        // second field: a + a' exp(i pi m / n), m = i + j + k folded into [0, 2n)
+                // the phases of a lane's run from the table at its first pair, then by the rotation exp(+-2 pi i / n) per step
+                // (i advances by 2): two table reads per lane and column instead of 2 RUN gathers over a 16-KB table
+                const int mjk = jj + k;
+                int mp = mjk + i0, mm = mjk - i0;
+                mp += mp < 0 ? 2 * n : 0, mm += mm < 0 ? 2 * n : 0;
+                float2 pp = g.phase[mp], pm = g.phase[mm];
+                const float2 rot = g.phase[2];
+#pragma unroll
+                for (int s = 0; s < RUN; s++) {
+                    const float2 a = keepA[INTER ? ci : 0][s], bq = keepB[INTER ? ci : 0][s];
+                    vA[s] = make_float2(a.x + (vA[s].x * pp.x - vA[s].y * pp.y), a.y + (vA[s].x * pp.y + vA[s].y * pp.x));
+                    vB[s] = make_float2(bq.x + (vB[s].x * pm.x - vB[s].y * pm.y), bq.y + (vB[s].x * pm.y + vB[s].y * pm.x));
+                    pp = make_float2(pp.x * rot.x - pp.y * rot.y, pp.x * rot.y + pp.y * rot.x);
+                    pm = make_float2(pm.x * rot.x + pm.y * rot.y, pm.y * rot.x - pm.x * rot.y);
+                }
+            }
             int v = r2 + i0 * i0, inc = 4 * i0 + 4;
             int cur = 0, curk = 0;
             float sp = 0.f, s2 = 0.f, s4 = 0.f;
@@ -597,7 +645,13 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
                 v += inc, inc += 8;
             }
             if (!xh && lane == 63) {       // i = n/2 (a = H/2): one mode, last lane of the even half
-                const float2 q = (g.dbg & 8) ? make_float2(1.f, 1.f) : col[padq(H / 2)];
+                float2 q = (g.dbg & 8) ? make_float2(1.f, 1.f) : col[padq(H / 2)];
+                if (INTER) {
+                    int m = jj + k + H;
+                    m += m < 0 ? 2 * n : 0;
+                    const float2 ph = g.phase[m], a = keepQ[INTER ? ci : 0];
+                    q = make_float2(a.x + (q.x * ph.x - q.y * ph.y), a.y + (q.x * ph.y + q.y * ph.x));
+                }
                 float p = q.x * q.x + q.y * q.y;
                 if (COMP) {
                     const float sc = __builtin_amdgcn_rcpf(Wl[H] * wjk);
@@ -625,17 +679,25 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     };
     if (og < n_og && dead(og * ostep + grp, ct)) step();
     if (og < n_og) {
-        prefetch(tile_ptr(og * ostep + grp, ct));
+        prefetch(tile_ptr(og * ostep + grp, ct, data));
         wait_vmcnt<0>();
         stage();
         for (;;) {
             __syncthreads();
             const int o_cur = og * ostep + grp, ct_cur = ct;
+            const int xh = o_cur >= g.ny ? 1 : 0;
+            if (INTER) {         // the shifted field's tile follows the unshifted one through the same LDS
+                prefetch(tile_ptr(o_cur, ct_cur, g.data2));
+                process(xh, g.y0 + o_cur - xh * g.ny, ct_cur, 1);
+                __syncthreads();
+                wait_vmcnt<0>();
+                stage();
+                __syncthreads();
+            }
             step();
             const bool has_next = og < n_og;
-            if (has_next) prefetch(tile_ptr(og * ostep + grp, ct));
-            const int xh = o_cur >= g.ny ? 1 : 0;
-            process(xh, g.y0 + o_cur - xh * g.ny, ct_cur);
+            if (has_next) prefetch(tile_ptr(og * ostep + grp, ct, data));
+            process(xh, g.y0 + o_cur - xh * g.ny, ct_cur, INTER ? 2 : 0);
             if (!has_next) break;
             __syncthreads();     // every wave is done with the tile
             wait_vmcnt<0>();     // no stores in this kernel: the prefetch is all that is outstanding
@@ -835,7 +897,8 @@ int xdesc_get(int n, int Nk, int Nmu, bool comp, const float *h_e2, const float 
 template <int H, int C, int NP, bool COMP, int MU>
 int launch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const XDesc &d, size_t lds) {
     const bool runs = option("pk_xbin_pairs") == 0;
-    auto kern = runs ? fft_x_bin2<H, C, NP, COMP, MU, true> : fft_x_bin2<H, C, NP, COMP, MU, false>;
+    auto kern = g.data2 ? fft_x_bin2<H, C, NP, COMP, MU, true, true>
+                        : (runs ? fft_x_bin2<H, C, NP, COMP, MU, true> : fft_x_bin2<H, C, NP, COMP, MU, false>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, XB_THREADS, lds));
@@ -929,9 +992,14 @@ int xbin_release() {
 // serves the slab forms, and `put_geom` says whether this rank contributes the mesh-wide N_mode / sum |k| to the
 // histogram that is all-reduced afterwards.
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
-                  int y0, int ny_local, int put_geom, int layout, int world) {
+                  int y0, int ny_local, int put_geom, int layout, int world, const float *mesh_shifted, const float2 *phase) {
     XBinGeom g;
     g.n = n, g.kzlen = n / 2 + 1, g.pitch_c = pitch_r / 2, g.inv_size = inv_size, g.W = W_dev, g.dbg = dbg;
+    if (mesh_shifted) {
+        if (!phase || layout != 0) return fail("fft_x_bin: the interlaced form needs the phase table and the whole mesh");
+        g.data2 = reinterpret_cast<const float2 *>(mesh_shifted), g.phase = phase;
+        g.half_inv_size = (float)(0.5 / ((double)n * n * n));
+    }
     const bool slab = layout != 0;
     if (slab && ny_local < 1) return fail("fft_x_bin: empty y-slab");
     g.ny = slab ? ny_local : n, g.y0 = slab ? y0 : 0, g.put_geom = slab ? put_geom : 1;
@@ -959,7 +1027,7 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
         if (n == 2048) return dispatch_xbin2<1024, 8>(data, g, b, d, xbin2_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, d.ncell, comp));
         return dispatch_xbin2<512, 16>(data, g, b, d, xbin2_lds_bytes<512, 16>(n, b.Nk, b.Nmu, d.ncell, comp));
     }
-    if (slab) return fail("fft_x_bin: no geometry descriptor for this histogram (y-slab form)");
+    if (slab || mesh_shifted) return fail("fft_x_bin: no geometry descriptor for this histogram (y-slab / interlaced form)");
     if (!xbin1_supported(n, b.Nk, b.Nmu, b, comp)) return fail("fft_x_bin: histogram does not fit");
     if (n == 2048) return dispatch_xbin<1024, 8>(data, g, b, xbin_lds_bytes<1024, 8>(n, b.Nk, b.Nmu, b.Np, comp));
     return dispatch_xbin<512, 16>(data, g, b, xbin_lds_bytes<512, 16>(n, b.Nk, b.Nmu, b.Np, comp));

@@ -135,12 +135,17 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
             W = ps.get_W_compensated(L, nmesh, 'TSC', True).astype(np.float32)
             step(1, W)
             _lib.sync()
+            _lib.profile_reset()
+            _lib.profile_enable(True)
             t1 = time.perf_counter()
             for _ in range(max(1, steps // 2)):
                 step(1, W)
             _lib.sync()
             dti = (time.perf_counter() - t1) / max(1, steps // 2)
-            out['interlaced_compensated'] = {'ms_per_step': dti * 1e3,
+            _lib.profile_enable(False)
+            # per step: two deposits and two z / y passes, one fused last pass over both fields
+            kern_i = {k: ms / max(1, steps // 2) for k, (ms, c) in _lib.profile_get().items() if c}
+            out['interlaced_compensated'] = {'ms_per_step': dti * 1e3, 'kernels_ms_per_step': kern_i,
                                              'whole_step_GBs': (24.0 * n + 80.0 * M) / dti / 1e9,
                                              'whole_step_frac': (24.0 * n + 80.0 * M) / dti / 1e9 / HBM_PEAK_GBS}
         except Exception as e:

@@ -526,6 +526,45 @@ def test_fused_last_pass_matches_spectrum_bin(options, nmesh, comp):
                 np.testing.assert_allclose(a['poles'], b['poles'], rtol=2e-6, atol=2e-7 * np.abs(b['power']).max(), err_msg=name)
 
 
+@pytest.mark.parametrize('nmesh,comp', [(1024, True), (1024, False), (2048, True)])
+def test_fused_last_pass_interlaced_pair_matches_spectrum_bin(options, nmesh, comp):
+    """the interlaced form of the fused last pass (fft_x_bin2<.., INTER>: the unshifted field's tile kept in registers, the
+    shifted field's tile through the same LDS, (a + a' exp(i pi m / n)) f32(0.5 / M) binned from there) against two x passes
+    + spectrum_bin<INTER> on the same particles (option pk_noxbin_inter): the reference's default mode of calc_power
+    (interlaced=True, compensated=True; analysis/power_spectrum.py:951-998), identical values per mode, float64 sums to
+    rounding; and against the oracle at 1024"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    box = 1000.0
+    pos = synth.synth_positions(2_000_000, box, seed=91, clustered=True)
+    w = np.random.default_rng(4).random(len(pos), dtype=np.float32) + np.float32(0.5)
+    cases = (dict(kbins=64, mubins=4, poles=[0, 2, 4]), dict(kbins=300, mubins=None, poles=[0, 2], k_max=np.pi * nmesh / box + 1e-6),
+             dict(kbins=np.array([0.0, 0.02, 0.021, 0.3, 0.31, 2.0]), mubins=np.array([0.0, 0.05, 0.5, 0.51, 1.0]), poles=[2]),
+             dict(kbins=24, mubins=8, poles=[], logk=True, k_max=2.0, w=w))
+    for kw in (cases if nmesh == 1024 else cases[:2]):
+        kw = dict(kw, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=True)
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        a = calc_power(pos.copy(), box, **kw)
+        _lib.profile_enable(False)
+        prof = _lib.profile_get()
+        assert 'fft_x_bin' in prof and 'spectrum_bin' not in prof and 'fft_cols_x' not in prof, sorted(prof)
+        options.set('pk_noxbin_inter', 1)
+        b = calc_power(pos.copy(), box, **kw)
+        options.set('pk_noxbin_inter', 0)
+        np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
+        scale = np.abs(np.asarray(b['power'])).max()
+        np.testing.assert_allclose(a['power'], b['power'], rtol=3e-6, atol=3e-7 * scale)
+        np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)
+        if kw['poles']:
+            np.testing.assert_allclose(a['poles'], b['poles'], rtol=3e-6, atol=5e-7 * scale)
+    if nmesh == 1024:
+        from oracle import oracle
+        kw = dict(kbins=20, mubins=3, k_max=1.2, paste='TSC', nmesh=1024, compensated=comp, interlaced=True, poles=[0, 2])
+        small = synth.synth_positions(300_000, box, seed=92, clustered=True)
+        _check_oracle(calc_power(small.copy(), box, **kw), oracle.calc_power(small.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw))
+
+
 def _random_edges(rng, nmesh, box):
     """k / mu edges of every flavour the geometry descriptor has to resolve or decline: linear, logarithmic, ragged, bins far
     narrower than a fundamental mode, first edge above zero, last edge short of / beyond Nyquist and beyond the corner"""
