@@ -981,20 +981,27 @@ static int lines_deposit_run(float *pos, int64_t n, float *grid, const LGeom &g,
     const int64_t CH = std::max<int64_t>(8192, ceil_div(n, 1024));
     const int nchunk = (int)ceil_div(n, CH);
     ABACUS_TRY(g_lw.M.reserve((size_t)nchunk * nb * sizeof(unsigned int)));
-    ABACUS_TRY(g_lw.tot.reserve((size_t)nb * sizeof(unsigned int)));
-    ABACUS_TRY(g_lw.flag.reserve(256));
+    // the block totals and the "a position was wrapped" flag come back in ONE copy into page-locked memory (a pageable
+    // destination goes through a staging kernel per copy: two of them and their gaps were 60 us of every deposit)
+    ABACUS_TRY(g_lw.tot.reserve((size_t)(nb + 1) * sizeof(unsigned int)));
     unsigned int *M = g_lw.M.as<unsigned int>(), *tot = g_lw.tot.as<unsigned int>();
-    int *flag = g_lw.flag.as<int>();
+    int *flag = reinterpret_cast<int *>(tot + nb);
     HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), stream()));
     const float offA = (float)offset;
     if (cfg == 0) ABACUS_LAUNCH("tsc_lines_count", (lines_count<256>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, flag);
     else ABACUS_LAUNCH("tsc_lines_count", (lines_count<1024>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, flag);
     ABACUS_LAUNCH("tsc_lines_colscan", lines_colscan, dim3(nb), dim3(1024), 0, M, nchunk, nb, tot);
-    std::vector<unsigned int> h_tot((size_t)nb);
-    int h_flag = 0;
-    HIP_TRY(hipMemcpyAsync(h_tot.data(), tot, (size_t)nb * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
-    HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    static unsigned int *h_tot = nullptr;
+    static int h_tot_cap = 0;
+    if (nb + 1 > h_tot_cap) {
+        if (h_tot) HIP_TRY(hipHostFree(h_tot));
+        h_tot = nullptr, h_tot_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&h_tot, (size_t)(nb + 1) * sizeof(unsigned int) * 2, hipHostMallocDefault));
+        h_tot_cap = 2 * (nb + 1);
+    }
+    HIP_TRY(hipMemcpyAsync(h_tot, tot, (size_t)(nb + 1) * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
+    const int h_flag = (int)h_tot[nb];
     if (wrapped_out) *wrapped_out = h_flag;
     g_wrapped_seen |= h_flag;
     // bucket starts on line boundaries; pieces of at most PIECE staged entries; one table upload
