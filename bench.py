@@ -122,7 +122,15 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
 
     # timed region: HIP events only around the dominant kernel (a pair of event records per launch costs a few
     # microseconds, which is not negligible against a 0.1-ms step); the other kernels' durations are the warm-up's
-    dom_name = max((k for k in warm if k in STEP), key=lambda k: warm[k] * launches.get(k, 1.0), default=None)
+    # At C2 the three kernels of the index path take 11 - 16 us each and trade places from run to run (launch-latency sized):
+    # "the dominant kernel" is the one that moves the most bytes among those that take at least half as long as the longest
+    # (picked by duration alone, noise made the line's roofline jump between 0.13 for hod_exact and 0.007 for hod_deal)
+    bh0, bp0 = filter_bytes_per_object(tracers, enable_ranks)
+    nc0 = float(cand[0] + cand[1])
+    dom_bytes = {'hod_filter': bh0 * nh + bp0 * npart, 'hod_deal': 6.0 * nc0, 'hod_exact': 130.0 * nc0, 'hod_emit': 192.0 * ngal}
+    tmax = max((warm[k] * launches.get(k, 1.0) for k in warm if k in STEP), default=0.0)
+    dom_name = max((k for k in warm if k in STEP and warm[k] * launches.get(k, 1.0) >= 0.5 * tmax),
+                   key=lambda k: dom_bytes.get(k, 0.0), default=None)
     _lib.profile_reset()
     _lib.profile_select(dom_name)
     _lib.profile_enable(True)
