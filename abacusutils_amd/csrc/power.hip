@@ -671,6 +671,7 @@ __global__ __launch_bounds__(256) void helper_bin_kppi(const float *__restrict__
 // ---- host side ------------------------------------------------------------------------------------------
 struct PowerCtx {
     std::map<int, hipfftHandle> plans;
+    std::map<int, hipfftHandle> plans64;    // padded in-place D2Z (float64 meshes of sizes the mixed-radix kernels do not cover)
     DevBuf mesh[4];       // field1, field1 shifted, field2, field2 shifted
     DevBuf W, phase, edges, accum, pos, pos2, w, w2;
     DevBuf helper_in, helper_tab;          // staging of caller-supplied real grids / small tables (ZCV helpers)
@@ -1638,6 +1639,8 @@ int abacus_power_release(void) {
     g_ctx.plans.clear();
     for (auto &kv : g_ctx.c2r_plans) (void)hipfftDestroy(kv.second);
     g_ctx.c2r_plans.clear();
+    for (auto &kv : g_ctx.plans64) (void)hipfftDestroy(kv.second);
+    g_ctx.plans64.clear();
     ABACUS_TRY(g_ctx.helper_in.release());
     ABACUS_TRY(g_ctx.helper_tab.release());
     for (auto &m : g_ctx.mesh) ABACUS_TRY(m.release());
@@ -1712,9 +1715,23 @@ int field64_dev(void *pos, int pos_f64, int64_t n, const void *w, double L, int 
     const double M = (double)nmesh * nmesh * nmesh;
     ABACUS_TRY(tsc_deposit_f64mesh(pos, pos_f64, n, w, mesh, nmesh, pr, L, offset, paste == 0, M / (double)n, paste, 1.0));
     if (!transform) return 0;
-    if (!gfft_supported(nmesh, 1))
-        return fail("power: a float64 mesh of %d cells per side is not supported (even sizes up to 3072 with factors 2, 3, 5, 7, 11, 13)", nmesh);
-    ABACUS_TRY(gfft_r2c_inplace_f64(mesh, nmesh, pr));
+    if (gfft_supported(nmesh, 1)) {
+        ABACUS_TRY(gfft_r2c_inplace_f64(mesh, nmesh, pr));
+    } else {   // odd sizes, prime factors above 13: hipFFT's double-precision transform on the same padded in-place layout
+        auto it = g_ctx.plans64.find(nmesh);
+        if (it == g_ctx.plans64.end()) {
+            hipfftHandle h;
+            int dims[3] = {nmesh, nmesh, nmesh};
+            int inembed[3] = {nmesh, nmesh, pr}, onembed[3] = {nmesh, nmesh, pr / 2};
+            ABACUS_TRY(fft_check(hipfftPlanMany(&h, 3, dims, inembed, 1, 1, onembed, 1, 1, HIPFFT_D2Z, 1), "hipfftPlanMany (D2Z)"));
+            it = g_ctx.plans64.emplace(nmesh, h).first;
+        }
+        ABACUS_TRY(fft_check(hipfftSetStream(it->second, stream()), "hipfftSetStream"));
+        prof_begin("hipfft_d2z");
+        const hipfftResult r = hipfftExecD2Z(it->second, (hipfftDoubleReal *)mesh, (hipfftDoubleComplex *)mesh);
+        prof_end("hipfft_d2z");
+        ABACUS_TRY(fft_check(r, "hipfftExecD2Z"));
+    }
     const int64_t total = (int64_t)nmesh * nmesh * (nmesh / 2 + 1);
     ABACUS_LAUNCH("f64_scale_compensate", f64_scale_compensate, dim3(helper_grid(total)), dim3(256), 0, reinterpret_cast<double2 *>(mesh), nmesh,
                   pr / 2, 1.0 / M, W_dev);

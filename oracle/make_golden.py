@@ -957,7 +957,7 @@ def gen_power64(P):
     pos2 = synth.synth_positions(N // 2, L, seed=301, clustered=True)
     w = (0.5 + np.random.default_rng(5).random(N, dtype=np.float32)).astype(np.float32)
     out['w'] = w
-    for n in (24, 30):
+    for n in (24, 30, 21):
         out[f'n{n}.field_tsc'] = P.get_field(pos.copy(), L, n, 'TSC', w, dtype=np.float64)
         out[f'n{n}.field_cic_p8'] = P.get_field(pos.astype(np.float64), L, n, 'CIC', None, dtype=np.float64)
         W = P.get_W_compensated(L, n, 'TSC', False)
