@@ -14,6 +14,11 @@ namespace abacus {
 int fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 int ensure_init();
 hipStream_t stream();
+// Scratch blocks for the per-call temporaries of the host-array entry points (prepare.hip, staging.hip): hipMalloc + hipFree per
+// temporary cost those calls more than their kernels (abacus_prepare_randoms: 5 pairs, 7 ms of a 0.1-ms kernel).  A released
+// block is kept for the next call; abacus_scratch_release() frees what is not in use.
+int scratch_acquire(void **out, size_t bytes);
+void scratch_release(void *p);
 
 #define HIP_TRY(expr)                                                                                       \
     do {                                                                                                    \

@@ -28,12 +28,12 @@ struct Tmp {   // device allocations of one call, released on every exit path
     std::vector<void *> p;
     ~Tmp() {
         for (void *q : p)
-            if (q) (void)hipFree(q);
+            if (q) scratch_release(q);     // kept for the next call (runtime.hip), not freed
     }
     template <class T>
     int alloc(T **out, size_t count) {
         void *q = nullptr;
-        HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+        ABACUS_TRY(scratch_acquire(&q, std::max<size_t>(count, 1) * sizeof(T)));
         p.push_back(q);
         *out = static_cast<T *>(q);
         return 0;

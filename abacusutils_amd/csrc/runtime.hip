@@ -65,6 +65,60 @@ int ensure_init() {
 
 hipStream_t stream() { return g_stream; }
 
+namespace {
+struct ScratchBlock {
+    void *p;
+    size_t cap;
+    bool used;
+};
+std::vector<ScratchBlock> g_scratch_blocks;
+size_t scratch_idle_bytes() {
+    size_t b = 0;
+    for (const ScratchBlock &k : g_scratch_blocks)
+        if (!k.used) b += k.cap;
+    return b;
+}
+int scratch_trim() {
+    for (size_t i = 0; i < g_scratch_blocks.size();) {
+        if (!g_scratch_blocks[i].used) {
+            HIP_TRY(hipFree(g_scratch_blocks[i].p));
+            g_scratch_blocks.erase(g_scratch_blocks.begin() + (long)i);
+        } else i++;
+    }
+    return 0;
+}
+}  // namespace
+
+// smallest idle block that holds `bytes` without wasting more than half of itself; otherwise a new allocation (idle blocks
+// beyond 8 GiB are freed first)
+int scratch_acquire(void **out, size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    int best = -1;
+    for (size_t i = 0; i < g_scratch_blocks.size(); i++) {
+        const ScratchBlock &k = g_scratch_blocks[i];
+        if (!k.used && k.cap >= bytes && k.cap <= 2 * bytes + (1u << 20) && (best < 0 || k.cap < g_scratch_blocks[(size_t)best].cap)) best = (int)i;
+    }
+    if (best >= 0) {
+        g_scratch_blocks[(size_t)best].used = true;
+        *out = g_scratch_blocks[(size_t)best].p;
+        return 0;
+    }
+    if (scratch_idle_bytes() > ((size_t)8 << 30)) ABACUS_TRY(scratch_trim());
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        ABACUS_TRY(scratch_trim());          // out of memory with idle blocks around: give them back and try once more
+        HIP_TRY(hipMalloc(&q, bytes));
+    }
+    g_scratch_blocks.push_back(ScratchBlock{q, bytes, true});
+    *out = q;
+    return 0;
+}
+void scratch_release(void *p) {
+    for (ScratchBlock &k : g_scratch_blocks)
+        if (k.p == p) k.used = false;
+}
+
 // ---- profiler -------------------------------------------------------------------------------------------
 struct ProfEntry {
     double total_ms = 0;
@@ -287,6 +341,10 @@ int abacus_profile_enable(int on) {
     if (!on && g_prof) prof_drain();
     g_prof = on != 0;
     return 0;
+}
+int abacus_scratch_release(void) {
+    ABACUS_ENTER();
+    return scratch_trim();
 }
 int abacus_profile_select(const char *name) {
     g_prof_only = name ? name : "";

@@ -287,6 +287,9 @@ int abacus_power_from_fields(int slot_a, int slot_b, const float *W_host, const 
 int abacus_power_fields_release(void);
 /* releases cached FFT plans / work meshes / the cached binning geometry of fft_x_bin */
 int abacus_power_release(void);
+/* frees the idle scratch blocks the host-array entry points (abacus_prepare_*, abacus_argsort_i64, abacus_searchsorted_i64,
+ * abacus_fenv_rank) keep between calls instead of paying hipMalloc + hipFree per temporary */
+int abacus_scratch_release(void);
 /* milliseconds of the one-off geometry pass behind the most recent fused last pass (abacus_power_from_particles[_dev],
  * auto power, non-interlaced, nmesh 1024 / 2048): N_mode, k_avg and the (k, mu) bin of every mode depend on (nmesh, edges)
  * alone (power_spectrum.py:233-256), so they are computed once per (nmesh, edges) and cached; 0 if none was built */
