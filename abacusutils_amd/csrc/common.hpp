@@ -19,6 +19,7 @@ hipStream_t stream();
 // block is kept for the next call; abacus_scratch_release() frees what is not in use.
 int scratch_acquire(void **out, size_t bytes);
 void scratch_release(void *p);
+int scratch_trim_idle();
 
 #define HIP_TRY(expr)                                                                                       \
     do {                                                                                                    \
@@ -66,7 +67,12 @@ struct DevBuf {
         if (p) HIP_TRY(hipFree(p));
         p = nullptr;
         cap = 0;
-        HIP_TRY(hipMalloc(&p, nbytes));
+        if (hipMalloc(&p, nbytes) != hipSuccess) {   // idle scratch blocks may be what stands in the way
+            (void)hipGetLastError();
+            p = nullptr;
+            ABACUS_TRY(scratch_trim_idle());
+            HIP_TRY(hipMalloc(&p, nbytes));
+        }
         cap = nbytes;
         return 0;
     }

@@ -118,6 +118,7 @@ void scratch_release(void *p) {
     for (ScratchBlock &k : g_scratch_blocks)
         if (k.p == p) k.used = false;
 }
+int scratch_trim_idle() { return scratch_trim(); }
 
 // ---- profiler -------------------------------------------------------------------------------------------
 struct ProfEntry {

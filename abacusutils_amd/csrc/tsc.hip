@@ -1330,9 +1330,11 @@ int deposit_host(void *pos_, int64_t n, const void *weights_, void *grid_, int g
     GT *dgrid = nullptr;
     int rc = 0, wrapped = 0;
     do {
-        if (hipMalloc((void **)&dpos, std::max<size_t>(3 * n * sizeof(PT), 16)) != hipSuccess ||
-            hipMalloc((void **)&dgrid, cells * sizeof(GT)) != hipSuccess ||
-            (weights_ && hipMalloc((void **)&dw, std::max<size_t>(n * sizeof(PT), 16)) != hipSuccess)) {
+        // scratch blocks kept between calls (runtime.hip): a tsc_parallel call on NumPy arrays paid hipMalloc + hipFree of the
+        // particles and the mesh every time
+        if (scratch_acquire((void **)&dpos, std::max<size_t>(3 * n * sizeof(PT), 16)) != 0 ||
+            scratch_acquire((void **)&dgrid, cells * sizeof(GT)) != 0 ||
+            (weights_ && scratch_acquire((void **)&dw, std::max<size_t>(n * sizeof(PT), 16)) != 0)) {
             rc = fail("tsc: device allocation failed");
             break;
         }
@@ -1349,9 +1351,9 @@ int deposit_host(void *pos_, int64_t n, const void *weights_, void *grid_, int g
             (void)hipMemcpyAsync(pos_, dpos, 3 * n * sizeof(PT), hipMemcpyDeviceToHost, stream());
         if (hipStreamSynchronize(stream()) != hipSuccess) rc = fail("tsc: stream synchronisation failed");
     } while (0);
-    if (dpos) (void)hipFree(dpos);
-    if (dw) (void)hipFree(dw);
-    if (dgrid) (void)hipFree(dgrid);
+    if (dpos) scratch_release(dpos);
+    if (dw) scratch_release(dw);
+    if (dgrid) scratch_release(dgrid);
     return rc;
 }
 
