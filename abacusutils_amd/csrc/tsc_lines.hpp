@@ -786,11 +786,17 @@ __global__ __launch_bounds__(NT) void lines_deposit32(const unsigned long long *
         for (int q = tid; q < nt; q += NT) bst[q] = tile_start[t0 + q], bcn[q] = tile_cnt[t0 + q];
         __syncthreads();
         tsc_v4f X[NPRE], Y[NPRE];
+        // the NPRE loads per thread are issued whatever the list holds (the counted vmcnt waits below rely on it); lanes
+        // beyond the list read its first pair again - one request per wave instead of 1 KB of somebody else's entries
+        // (2048^3: 128 entries per tile on average against the 1536 the loads cover, 4.6 GB of useless requests)
         auto issue = [&](tsc_v4f(&set)[NPRE], int tt) {
             const int64_t u0 = (int64_t)(bst[tt] >> 1);
+            const int np2 = (int)((bcn[tt] + 1u) >> 1);
 #pragma unroll
-            for (int q = 0; q < NPRE; q++)
-                tsc_gload16_async(set[q], reinterpret_cast<const float4 *>(entries) + min(u0 + q * NT + tid, lastpair));
+            for (int q = 0; q < NPRE; q++) {
+                const int k = q * NT + tid;
+                tsc_gload16_async(set[q], reinterpret_cast<const float4 *>(entries) + min(u0 + (k < np2 ? k : 0), lastpair));
+            }
         };
         float fx = 1.f;                                       // 2^S of the tile being accumulated
         auto one = [&](unsigned long long e) {
