@@ -338,24 +338,7 @@ int dispatch_xbin(const float2 *data, const XBinGeom &g, const BinArgs &b, size_
 // against the float tests by xbin_geometry on the device.  That kernel also yields N_mode and sum |k| of every bin, which
 // depend on (n, edges) alone: the descriptor is cached per (n, edges) and the hot kernel accumulates only w * P and its
 // two mu moments - no counts, no k sums, no square root, no walk along the edges.
-struct XDesc {
-    const unsigned int *lut;   // (ncell) eb << 22 | min(T[eb], 2^22 - 1)
-    const int *U;              // (kzlen, ustride): largest kmag2 with mu2 > muedges2[m + 1], m = 0 .. Nmu-2; -1: none
-    int ncell, sh, off, ustride;
-    int vtop;                  // T[Nk]: every kmag2 above it lies beyond the last edge
-    const unsigned long long *cnt;   // (Nk * Nmu) N_mode
-    const double *ksum;              // (Nk * Nmu) sum of w * sqrt(kmag2)
-};
-
-constexpr int XD_USTRIDE = 8;            // mu thresholds kept per kz (Nmu <= 8 on this path)
-constexpr int XD_TMASK = 0x3fffff;
-
-// vf1 = max(f32(kmag2), 1): kmag2 = 0 (the DC mode) shares the cell of kmag2 = 1; lut0 = lut - off; the table covers every
-// kmag2 of the mesh, so the index needs no clamp
-__device__ __forceinline__ int xd_eb(const unsigned int *lut0, int sh, int v, float vf1) {
-    const unsigned int w = lut0[__float_as_uint(vf1) >> sh];
-    return (int)(w >> 22) + (v > (int)(w & XD_TMASK) ? 1 : 0);
-}
+#include "xdesc_device.hpp"
 
 // N_mode, sum |k| and the validation of the descriptor: one wave per (j, k) column, lanes over |i| (both signs at once)
 __global__ __launch_bounds__(256) void xbin_geometry(int n, int Nk, int Nmu, const float *__restrict__ ke,
@@ -961,6 +944,21 @@ bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp) {
     if (xbin1_supported(n, Nk, Nmu, b, comp)) return true;
     XDescHost *x = nullptr;
     return xbin2_desc(n, b, comp, &x) == 0 && x != nullptr;
+}
+
+// the descriptor of (n, edges of b) for a kernel that keeps `lds_other` bytes of LDS beside the cell table; ok = 0: these edges do
+// not fit the scheme (or any other mesh size than the two of the fused power-of-two pass asks with its own lds_other)
+int xdesc_lookup(int n, const BinArgs &b, bool comp, size_t lds_other, const unsigned int **lut, const int **U, int *ncell, int *sh, int *off,
+                 int *vtop, const unsigned long long **cnt, const double **ksum, int *ok) {
+    *ok = 0;
+    if (!b.h_edges2 || b.Nmu > XD_USTRIDE || lds_other + 64 * 4 > 160 * 1024) return 0;
+    XDescHost *x = nullptr;
+    ABACUS_TRY(xdesc_get(n, b.Nk, b.Nmu, comp, b.h_edges2, b.kedges2, b.muedges2, lds_other, &x));
+    if (!x->ok || lds_other + (size_t)x->ncell * 4 > 160 * 1024) return 0;
+    const XDesc d = x->dev();
+    *lut = d.lut, *U = d.U, *ncell = d.ncell, *sh = d.sh, *off = d.off, *vtop = d.vtop, *cnt = d.cnt, *ksum = d.ksum;
+    *ok = 1;
+    return 0;
 }
 
 // milliseconds the geometry pass of the most recently used descriptor took when it was built (bench.py reports it next to
