@@ -17,8 +17,14 @@
 #include <vector>
 
 #include "common.hpp"
+#include "bin_device.hpp"
 
 using namespace abacus;
+
+namespace abacus {
+int xdesc_lookup(int n, const BinArgs &b, bool comp, size_t lds_other, const unsigned int **lut, const int **U, int *ncell, int *sh, int *off,
+                 int *vtop, const unsigned long long **cnt, const double **ksum, int *ok);   // xbin.hip
+}
 
 namespace {
 
@@ -390,6 +396,179 @@ __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int 
     }
 }
 
+// ---- last pass fused with the (k, mu) / multipole binning, mixed-radix meshes ------------------------------------------------
+// The x pass of gfft_cols without its write-back: the transformed tile (all n x-rows of C kz columns of one y row) is binned
+// from LDS - |delta_k|^2 of the modes +i and -i of a column share their bin - into the workgroup's float64 LDS histogram, with
+// the cached geometry descriptor of xbin.hip (xdesc_device.hpp: bin of a mode from a cell table indexed by the float bits of
+// kmag2 and per-kz mu thresholds, N_mode and sum |k| precomputed; validated over every mode of the mesh when it is built).
+// The counterpart of fft_x_bin2 (xbin.hip) for the sizes gfft serves; natural frequency order, one wave per column, lane l
+// walks the run i = l RUN .. l RUN + RUN - 1 of |kx| and keeps the sums of its current bin in registers.
+// Replaces gfft_cols (x) + spectrum_bin for the auto power of one non-interlaced field: 4M bytes read instead of 4M read +
+// 4M written + 4M read.  analysis/power_spectrum.py:150-300 (bin_kmu), :707-727, :1058-1069.
+#include "xdesc_device.hpp"
+
+struct GXArgs {
+    int n, kzlen, lgG, ntile_c, ustride;
+    int64_t S, ys;            // element stride along x, along y
+    float inv2;               // f32(1/M)^2
+    const float *W;           // (n,) compensation window or nullptr
+};
+
+__global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__ data, GXArgs g, GPlan p, const C2<float> *__restrict__ twn,
+                                                   BinArgs b, XDesc d) {
+    typedef float T;
+    constexpr int MAXV = 24;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n = g.n, lgC = g.lgG + 2, C = 1 << lgC, P = C + 1;
+    const int Nk = b.Nk, Nmu = b.Nmu, nrow = Nk + 2, nbx = nrow * Nmu;
+    C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
+    C2<T> *lds = tw + n;
+    double *h_sum = reinterpret_cast<double *>(lds + (size_t)n * P);
+    double *h_m2 = h_sum + nbx, *h_m4 = h_m2 + nrow;
+    unsigned int *lut = reinterpret_cast<unsigned int *>(h_m4 + nrow);
+    int *Ul = reinterpret_cast<int *>(lut + d.ncell);
+    float *Wl = reinterpret_cast<float *>(Ul + g.kzlen * g.ustride);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int q = tid; q < n; q += G_NT) tw[q] = twn[q];
+    for (int q = tid; q < nbx; q += G_NT) h_sum[q] = 0.0;
+    for (int q = tid; q < 2 * nrow; q += G_NT) h_m2[q] = 0.0;
+    for (int q = tid; q < d.ncell; q += G_NT) lut[q] = d.lut[q];
+    for (int q = tid; q < g.kzlen * g.ustride; q += G_NT) Ul[q] = d.U[(q / g.ustride) * XD_USTRIDE + q % g.ustride];
+    const bool comp = g.W != nullptr;
+    if (comp)
+        for (int q = tid; q < n; q += G_NT) Wl[q] = g.W[q];
+    const unsigned int *lut0 = lut - d.off;
+    const int sh = d.sh, nmu1 = Nmu - 1;
+    const int64_t ntiles = (int64_t)n * g.ntile_c;
+    constexpr int NPRE = MAXV / 2;
+    CPair<T> pre[NPRE];
+    const int c = (tid & (C / 2 - 1)) * 2, row0 = tid >> (lgC - 1), dr = G_NT >> (lgC - 1);
+    auto issue = [&](int64_t t) {
+        const int64_t o = t / g.ntile_c;
+        const int c0 = (int)(t - o * g.ntile_c) * C, nc = min(C, g.kzlen - c0);
+        const C2<T> *src = data + o * g.ys + c0 + (int64_t)row0 * g.S + c;
+        const int64_t stride = (int64_t)dr * g.S;
+        const int mode = c + 1 < nc ? 2 : c < nc ? 1 : 0;
+#pragma unroll
+        for (int it = 0; it < NPRE; it++) {
+            pre[it] = CPair<T>{{(T)0, (T)0}, {(T)0, (T)0}};
+            if (row0 + it * dr < n) {
+                if (mode == 2) pre[it] = *reinterpret_cast<const CPair<T> *>(src);
+                else if (mode == 1) pre[it].a = *src;
+            }
+            src += stride;
+        }
+    };
+    auto dead = [&](int64_t t) {     // the tile's first column already beyond the last edge for every kx
+        const int64_t o = t / g.ntile_c;
+        const int j = (int)o, jj = j < n / 2 ? j : j - n, k0 = (int)(t - o * g.ntile_c) * C;
+        return jj * jj + k0 * k0 > d.vtop;
+    };
+    auto next = [&](int64_t t) {
+        do t += gridDim.x;
+        while (t < ntiles && dead(t));
+        return t;
+    };
+    const int RUN = (n / 2 + 1 + 63) / 64;
+    __syncthreads();
+    int64_t t = blockIdx.x;
+    if (t < ntiles && dead(t)) t = next(t);
+    if (t < ntiles) issue(t);
+    for (int64_t tn; t < ntiles; t = tn) {
+        tn = next(t);
+        {
+            C2<T> *l = lds + row0 * P + c;
+#pragma unroll
+            for (int it = 0; it < NPRE; it++) {
+                if (row0 + it * dr < n) l[0] = pre[it].a, l[1] = pre[it].b;
+                l += dr * P;
+            }
+        }
+        __syncthreads();
+        if (tn < ntiles) issue(tn);
+        g_transform<T, MAXV>(lds, g.lgG, P, p, tw, 1);       // ends on a workgroup barrier: the whole tile is transformed
+        const int64_t o = t / g.ntile_c;
+        const int j = (int)o, jj = j < n / 2 ? j : j - n, c0 = (int)(t - o * g.ntile_c) * C;
+#pragma unroll 1
+        for (int cc = wave; cc < C; cc += G_NT / 64) {
+            const int k = c0 + cc, r2 = jj * jj + k * k;
+            if (k >= g.kzlen || r2 > d.vtop) continue;             // padding column / the whole column beyond the last edge
+            int Uk[7];
+#pragma unroll
+            for (int m = 0; m < 7; m++) Uk[m] = m < nmu1 ? Ul[k * g.ustride + m] : -2;
+            const float k2f = (float)(k * k), scale = (k == 0 ? 1.f : 2.f) * g.inv2;      // weight (:258-262) x f32(1/M)^2 (:1058-1060)
+            const float wjk = comp ? Wl[j] * Wl[k] : 1.f;
+            int cur = 0, curk = 0;
+            float sp = 0.f, s2 = 0.f, s4 = 0.f;
+            bool first = true;
+            const int i0 = lane * RUN;
+            int v = r2 + i0 * i0;
+            for (int s = 0; s < RUN; s++) {
+                const int i = i0 + s;
+                if (2 * i > n) break;
+                const C2<T> a = lds[i * P + cc];
+                float pw = a.x * a.x + a.y * a.y;                                          // get_raw_power (:726)
+                if (comp) {                                                                // (:1065-1069)
+                    const float sA = __builtin_amdgcn_rcpf(Wl[i] * wjk);
+                    pw *= sA * sA;
+                }
+                if (i > 0 && 2 * i < n) {                                                  // the mode -i: same |k|, same mu
+                    const C2<T> bq = lds[(n - i) * P + cc];
+                    float pb = bq.x * bq.x + bq.y * bq.y;
+                    if (comp) {
+                        const float sB = __builtin_amdgcn_rcpf(Wl[n - i] * wjk);
+                        pb *= sB * sB;
+                    }
+                    pw += pb;
+                }
+                const float vf1 = fmaxf((float)v, 1.f);                                    // kmag2 = 0: the cell of 1, mu2 = 0 (:243)
+                const int eb = xd_eb(lut0, sh, v, vf1);
+                int bmu = 0;
+#pragma unroll
+                for (int m = 0; m < 7; m++) bmu += v <= Uk[m] ? 1 : 0;
+                const int tb = eb * Nmu + bmu;
+                pw *= scale;
+                const float mu2 = k2f * __builtin_amdgcn_rcpf(vf1);
+                const float t2 = pw * mu2, t4 = t2 * mu2;
+                if (!first && tb != cur) {
+                    if ((unsigned int)(curk - 1) < (unsigned int)Nk) {
+                        atomicAdd(&h_sum[cur], (double)sp);
+                        if (b.Np > 0) atomicAdd(&h_m2[curk], (double)s2), atomicAdd(&h_m4[curk], (double)s4);
+                    }
+                    sp = s2 = s4 = 0.f;
+                }
+                cur = tb, curk = eb, first = false;
+                sp += pw, s2 += t2, s4 += t4;
+                v += 2 * i + 1;
+            }
+            if (!first && (unsigned int)(curk - 1) < (unsigned int)Nk) {
+                atomicAdd(&h_sum[cur], (double)sp);
+                if (b.Np > 0) atomicAdd(&h_m2[curk], (double)s2), atomicAdd(&h_m4[curk], (double)s4);
+            }
+        }
+        __syncthreads();     // every wave is done with the tile
+    }
+    __syncthreads();
+    for (int q = tid; q < Nk * Nmu; q += G_NT) {
+        const double sm = h_sum[q + Nmu];           // row eb = bk + 1
+        if (sm != 0.0) atomicAdd(&b.g_sum[q], sm);
+        if (blockIdx.x == 0) b.g_cnt[q] = d.cnt[q], b.g_ksum[q] = d.ksum[q];
+    }
+    if (b.Np > 0) {
+        for (int bk = tid; bk < Nk; bk += G_NT) {
+            double s0 = 0.0;
+            for (int m = 0; m < Nmu; m++) s0 += h_sum[(bk + 1) * Nmu + m];
+            const double m2 = h_m2[bk + 1], m4 = h_m4[bk + 1];
+            for (int q = 0; q < b.Np; q++) {
+                const double c0q = b.poledeg[q] >= 0 ? b.polecoef[q][0] : 0.0, c1q = b.poledeg[q] >= 1 ? b.polecoef[q][1] : 0.0,
+                             c2q = b.poledeg[q] >= 2 ? b.polecoef[q][2] : 0.0;
+                const double vq = c0q * s0 + c1q * m2 + c2q * m4;
+                if (vq != 0.0) atomicAdd(&b.g_pole[q * Nk + bk], vq);
+            }
+        }
+    }
+}
+
 // ---- host -------------------------------------------------------------------------------------------------------------
 bool make_plan(int n, GPlan &p) {
     p.n = n, p.nf = 0;
@@ -469,7 +648,7 @@ int launch_rows(T *mesh, int n, int pitch_r, const GPlan &ph, const C2<T> *twn, 
 }
 
 template <typename T>
-int r2c_inplace(T *mesh, int n, int pitch_r, float xcut = 0.f) {
+int r2c_inplace(T *mesh, int n, int pitch_r, float xcut = 0.f, bool skip_x = false) {
     constexpr int MAXV = maxv<T>();
     GPlan ph, pn;
     if (n < 4 || (n & 1) || !make_plan(n / 2, ph) || !make_plan(n, pn)) return fail("gfft: mesh size %d is not an even product of 2, 3, 5, 7, 11, 13", n);
@@ -499,9 +678,30 @@ int r2c_inplace(T *mesh, int n, int pitch_r, float xcut = 0.f) {
     // y: for every x plane, columns along y (stride pitch_c); x: for every y row, columns along x (stride n * pitch_c)
     ABACUS_LAUNCH("gfft_cols_y", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)pitch_c, lgG, ntile_c, kzlen, (int64_t)n,
                   (int64_t)n * pitch_c, pn, twn, dbg, 0.f);
+    if (skip_x) return 0;       // the caller runs the last pass fused with the binning (gfft_x_bin)
     ABACUS_LAUNCH("gfft_cols_x", kern, dim3(grid), dim3(G_NT), lds, data, n, (int64_t)n * pitch_c, lgG, ntile_c, kzlen, (int64_t)n,
                   (int64_t)pitch_c, pn, twn, dbg, xcut);
     return 0;
+}
+
+// LDS of gfft_x_bin beside the cell table, and the column-tile width it leaves room for (lgG: C = 4 << lgG; -1: none)
+size_t gxbin_lds_other(int n, int C, int Nk, int Nmu, bool comp) {
+    return ((size_t)n + (size_t)n * (C + 1)) * 8 + (size_t)(Nk + 2) * Nmu * 8 + (size_t)2 * (Nk + 2) * 8 +
+           (size_t)(n / 2 + 1) * std::max(Nmu - 1, 1) * 4 + (comp ? (size_t)n * 4 : 0) + 16;
+}
+int gxbin_lgG(int n, int Nk, int Nmu, bool comp) {
+    for (int lgG = 2; lgG >= 0; lgG--) {
+        const int C = 4 << lgG;
+        if ((int64_t)C * n <= (int64_t)maxv<float>() * G_NT && gxbin_lds_other(n, C, Nk, Nmu, comp) + 6 * 1024 <= 160 * 1024) return lgG;
+    }
+    return -1;
+}
+bool gxbin_shape_ok(int n, const BinArgs &b) {
+    if (!b.h_edges2 || b.Np > 2 || b.Nmu > 8 || b.Nmu < 1) return false;
+    for (int q = 0; q < b.Np; q++)
+        if (b.poledeg[q] > 2) return false;
+    GPlan p;
+    return n >= 8 && n <= 2048 && !(n & 1) && make_plan(n, p) && make_plan(n / 2, p);
 }
 
 }  // namespace
@@ -517,6 +717,54 @@ bool gfft_supported(int n, int is_double) {
 }
 int gfft_r2c_inplace_f32(float *mesh, int n, int pitch_r, float xcut) { return r2c_inplace<float>(mesh, n, pitch_r, xcut); }
 int gfft_r2c_inplace_f64(double *mesh, int n, int pitch_r) { return r2c_inplace<double>(mesh, n, pitch_r); }
+// rows and y pass only: what gfft_x_bin_run continues from
+int gfft_r2c_zy_f32(float *mesh, int n, int pitch_r) { return r2c_inplace<float>(mesh, n, pitch_r, 0.f, true); }
+
+// can the fused last pass serve this mesh / histogram?  (builds the geometry descriptor of (n, edges) on first use)
+bool gfft_xbin_supported(int n, const BinArgs &b, bool comp) {
+    if (!gxbin_shape_ok(n, b)) return false;
+    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp);
+    if (lgG < 0) return false;
+    XDesc d;
+    int ok = 0;
+    if (xdesc_lookup(n, b, comp, gxbin_lds_other(n, 4 << lgG, b.Nk, b.Nmu, comp), &d.lut, &d.U, &d.ncell, &d.sh, &d.off, &d.vtop, &d.cnt, &d.ksum,
+                     &ok) != 0)
+        return false;
+    return ok != 0;
+}
+
+// `mesh` holds the transform after gfft_r2c_zy_f32; bins |delta_k|^2 of every mode into the accumulators of `b` (zeroed by the
+// caller), N_mode and sum |k| from the cached descriptor
+int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b) {
+    const bool comp = W_dev != nullptr;
+    if (!gxbin_shape_ok(n, b)) return fail("gfft_x_bin: unsupported mesh / histogram");
+    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp);
+    if (lgG < 0) return fail("gfft_x_bin: histogram does not fit beside a tile of %d rows", n);
+    const int C = 4 << lgG, pitch_c = pitch_r / 2, kzlen = n / 2 + 1;
+    const size_t other = gxbin_lds_other(n, C, b.Nk, b.Nmu, comp);
+    XDesc d;
+    int ok = 0;
+    ABACUS_TRY(xdesc_lookup(n, b, comp, other, &d.lut, &d.U, &d.ncell, &d.sh, &d.off, &d.vtop, &d.cnt, &d.ksum, &ok));
+    if (!ok) return fail("gfft_x_bin: no geometry descriptor for this histogram");
+    d.ustride = XD_USTRIDE;
+    GPlan pn;
+    if (!make_plan(n, pn)) return fail("gfft_x_bin: mesh size %d", n);
+    const C2<float> *twn;
+    ABACUS_TRY(tables<float>().get(n, &twn));
+    GXArgs g;
+    g.n = n, g.kzlen = kzlen, g.lgG = lgG, g.ntile_c = (kzlen + C - 1) / C, g.ustride = std::max(b.Nmu - 1, 1);
+    g.S = (int64_t)n * pitch_c, g.ys = pitch_c, g.inv2 = inv_size * inv_size, g.W = W_dev;
+    if (g.ntile_c * C > pitch_c) return fail("gfft_x_bin: row pitch too small");
+    const size_t lds = other + (size_t)d.ncell * 4;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gfft_x_bin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    const unsigned int grid = (unsigned int)std::min<int64_t>((int64_t)n * g.ntile_c, (int64_t)num_cus_g() * (lds > 80 * 1024 ? 1 : 2));
+    ABACUS_LAUNCH("gfft_x_bin", gfft_x_bin, dim3(grid), dim3(G_NT), lds, reinterpret_cast<const C2<float> *>(mesh), g, pn, twn, b, d);
+    return 0;
+}
 int gfft_release() {
     ABACUS_TRY(g_tw32.release());
     return g_tw64.release();

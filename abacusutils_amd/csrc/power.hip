@@ -64,6 +64,10 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
                   int y0 = 0, int ny_local = 0, int put_geom = 1, int layout = 0, int world = 1, const float *mesh_shifted = nullptr,
                   const float2 *phase = nullptr);
 bool xbin2_supported(int n, const BinArgs &b, bool comp);
+bool gfft_supported(int n, int is_double);
+int gfft_r2c_zy_f32(float *mesh, int n, int pitch_r);
+bool gfft_xbin_supported(int n, const BinArgs &b, bool comp);
+int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b);
 int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int h, int64_t xsep, int xg0, int p0, int pc, float *pack_out,
                              int world);
 int fft_native_fused_x_slab(float *mesh, int n, int pitch_r, int64_t ny_local);
@@ -764,6 +768,8 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
                                        interlaced ? (s == 0 ? 1 : 2) : 0));
         if (native && fused) {
             ABACUS_TRY(skip_x ? fft_native_r2c_fused_zy(mesh, nmesh, (int)zstride, xcut) : fft_native_r2c_fused(mesh, nmesh, (int)zstride, xcut));
+        } else if (native && skip_x && !fft_native_pow2(nmesh)) {
+            ABACUS_TRY(gfft_r2c_zy_f32(mesh, nmesh, (int)zstride));               // rows and y pass; gfft_x_bin follows
         } else if (native) {
             ABACUS_TRY(fft_native_r2c_inplace(mesh, nmesh, (int)zstride, xcut));   // three passes, one per axis
         } else {
@@ -1056,6 +1062,19 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
             const double M = (double)nmesh * nmesh * nmesh;
             ABACUS_TRY(fft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, 0, 0, 1, 0, 1,
                                      interlaced ? g_ctx.mesh[1].as<float>() : nullptr, g_ctx.phase.as<float2>()));
+            return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
+                                2.0 * M_PI / Lbox, 0);
+        }
+    }
+    if (!fused && !interlaced && !cross && !option("pk_noxbin") && !option("fft_hipfft") && !fft_native_pow2(nmesh) && gfft_supported(nmesh, 0)) {
+        // mixed-radix meshes (compute_power's default 550, 768 ...): the same fusion on gfft's natural-order x pass (gfft.hip)
+        BinArgs b;
+        size_t acc_bytes = 0;
+        ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
+        if (gfft_xbin_supported(nmesh, b, W_dev != nullptr)) {
+            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 0, 0, false, /*skip_x=*/true, nullptr, pf64, 0.f));
+            const double M = (double)nmesh * nmesh * nmesh;
+            ABACUS_TRY(gfft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b));
             return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
                                 2.0 * M_PI / Lbox, 0);
         }

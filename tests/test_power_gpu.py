@@ -710,7 +710,32 @@ def test_mixed_radix_meshes_take_the_native_transform(nmesh, npart, options):
         a = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, False)
         options.set('fft_hipfft', 1)
         b = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, False)
+        options.set('fft_hipfft', 0)
         assert np.abs(a - b).max() <= 3e-6 * np.abs(b).max()
+    # the auto power of one non-interlaced field: the last mixed-radix pass bins straight from LDS (gfft_x_bin) - against the
+    # separate x pass + spectrum_bin mode by mode, and against the oracle
+    for comp, kw2 in ((True, dict(kbins=20, mubins=3, poles=[0, 2, 4])), (False, dict(kbins=37, mubins=1, poles=[0, 2])),
+                      (False, dict(kbins=np.array([0.0, 0.013, 0.05, 0.051, 0.2, 0.9]) * nmesh / 72.0, mubins=np.array([0.0, 0.3, 0.31, 1.0]), poles=[]))):
+        kw2 = dict(kw2, k_max=np.pi * nmesh / box, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=False)
+        if not np.isscalar(kw2['kbins']):
+            kw2.pop('k_max')
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        fa = calc_power(pos.copy(), box, **kw2)
+        _lib.profile_enable(False)
+        prof = _lib.profile_get()
+        assert 'gfft_x_bin' in prof and 'spectrum_bin' not in prof and 'gfft_cols_x' not in prof, sorted(prof)
+        options.set('pk_noxbin', 1)
+        fb = calc_power(pos.copy(), box, **kw2)
+        options.set('pk_noxbin', 0)
+        np.testing.assert_array_equal(fa['N_mode'], fb['N_mode'])
+        scale = np.abs(np.asarray(fb['power'])).max()
+        np.testing.assert_allclose(fa['power'], fb['power'], rtol=3e-6, atol=3e-7 * scale)
+        np.testing.assert_allclose(fa['k_avg'], fb['k_avg'], rtol=1e-6)
+        if kw2['poles']:
+            np.testing.assert_allclose(fa['poles'], fb['poles'], rtol=3e-6, atol=5e-7 * scale)
+        if np.isscalar(kw2['kbins']):
+            _check_oracle(fa, oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw2))
 
 
 @pytest.mark.parametrize('n', [24, 30, 21])
