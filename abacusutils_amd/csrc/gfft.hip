@@ -690,7 +690,7 @@ size_t gxbin_lds_other(int n, int C, int Nk, int Nmu, bool comp) {
            (size_t)(n / 2 + 1) * std::max(Nmu - 1, 1) * 4 + (comp ? (size_t)n * 4 : 0) + 16;
 }
 int gxbin_lgG(int n, int Nk, int Nmu, bool comp) {
-    for (int lgG = 2; lgG >= 0; lgG--) {
+    for (int lgG = 2; lgG >= 1; lgG--) {     // 16 or 8 columns: 4 would read 32-byte row segments (0.4 of the 64-byte rate)
         const int C = 4 << lgG;
         if ((int64_t)C * n <= (int64_t)maxv<float>() * G_NT && gxbin_lds_other(n, C, Nk, Nmu, comp) + 6 * 1024 <= 160 * 1024) return lgG;
     }
