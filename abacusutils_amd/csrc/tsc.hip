@@ -1055,14 +1055,14 @@ static int lines_deposit_run(float *pos, int64_t n, float *grid, const LGeom &g,
     unsigned int *C = g_lw.C.as<unsigned int>(), *tile_start = g_lw.tile_start.as<unsigned int>(), *tile_cnt = g_lw.tile_cnt.as<unsigned int>();
     unsigned long long *entries = g_lw.entries.as<unsigned long long>();
     if (cfg == 0) {
-        ABACUS_LAUNCH("tsc_lines_coarse", (lines_coarse<256, 8, 2304, 512>), dim3(nchunk), dim3(512), 0, (const float *)pos, n, g, box, offA, CH,
+        ABACUS_LAUNCH("tsc_lines_coarse", (lines_coarse<256, 8, 2560, 512>), dim3(nchunk), dim3(512), 0, (const float *)pos, n, g, box, offA, CH,
                       (const unsigned int *)M, d_gstart, staged);
         if (np) ABACUS_LAUNCH("tsc_lines_fcount", (lines_fcount<512>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb, C);
         ABACUS_LAUNCH("tsc_lines_fscan", (lines_fscan<512>), dim3(nb), dim3(512), 0, C, d_pfirst, g, d_fstart, tile_start, tile_cnt);
         if (np) ABACUS_LAUNCH("tsc_lines_fine", (lines_fine<512, 8, 3072, 512>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb,
                               (const unsigned int *)C, entries);
     } else {
-        ABACUS_LAUNCH("tsc_lines_coarse", (lines_coarse<1024, 4, 3072, 1024>), dim3(nchunk), dim3(1024), 0, (const float *)pos, n, g, box, offA, CH,
+        ABACUS_LAUNCH("tsc_lines_coarse", (lines_coarse<1024, 4, 3328, 1024>), dim3(nchunk), dim3(1024), 0, (const float *)pos, n, g, box, offA, CH,
                       (const unsigned int *)M, d_gstart, staged);
         if (np) ABACUS_LAUNCH("tsc_lines_fcount", (lines_fcount<1024>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb, C);
         ABACUS_LAUNCH("tsc_lines_fscan", (lines_fscan<1024>), dim3(nb), dim3(1024), 0, C, d_pfirst, g, d_fstart, tile_start, tile_cnt);

@@ -236,11 +236,29 @@ __device__ __forceinline__ unsigned int ln_block_scan(const unsigned int *in, un
     return total;
 }
 
+// how an entry is kept in LDS: the staged records of the coarse pass are (entry lo, entry hi, key, 0) - three words, so
+// that a round of twice as many particles fits the same LDS (the fourth word is restored on the way out)
+template <typename E>
+struct SplitKeep {
+    typedef E type;
+    static __device__ __forceinline__ E pack(const E &e) { return e; }
+    static __device__ __forceinline__ E unpack(const E &e) { return e; }
+};
+struct LnU3 {
+    unsigned int x, y, z;
+};
+template <>
+struct SplitKeep<uint4> {
+    typedef LnU3 type;
+    static __device__ __forceinline__ LnU3 pack(const uint4 &e) { return LnU3{e.x, e.y, e.z}; }
+    static __device__ __forceinline__ uint4 unpack(const LnU3 &e) { return make_uint4(e.x, e.y, e.z, 0u); }
+};
+
 template <typename E, int NB, int LINE, int SBUF, int NT>
 struct SplitLds {
     static constexpr int ITEMS = (NB + NT - 1) / NT;   // buckets owned by a thread: tid * ITEMS + q
-    E out[SBUF];
-    E carry[NB * (LINE - 1)];
+    typename SplitKeep<E>::type out[SBUF];
+    typename SplitKeep<E>::type carry[NB * (LINE - 1)];
     unsigned short obid[SBUF];
     unsigned int lcnt[2][NB];       // new entries per bucket, by round parity
     unsigned int lcur[NB];          // placement cursors of the round
@@ -331,15 +349,15 @@ __device__ __forceinline__ bool split_round(SplitLds<E, NB, LINE, SBUF, NT> &s, 
         const unsigned int k = atomicAdd(&s.lcur[b], 1u);
         if ((int)k < s.wd[b]) {
             const unsigned int o = s.pa[b] + k;
-            s.out[o] = e;
+            s.out[o] = SplitKeep<E>::pack(e);
             s.obid[o] = (unsigned short)b;
         } else {
-            s.carry[s.cb[b] + k] = e;
+            s.carry[s.cb[b] + k] = SplitKeep<E>::pack(e);
         }
     });
     __syncthreads();
     if (!(dbg & 16))
-        for (unsigned int o = tid; o < ot; o += NT) dst[(size_t)(unsigned int)(s.obase[s.obid[o]] + o)] = s.out[o];
+        for (unsigned int o = tid; o < ot; o += NT) dst[(size_t)(unsigned int)(s.obase[s.obid[o]] + o)] = SplitKeep<E>::unpack(s.out[o]);
     return true;
 }
 
@@ -417,7 +435,7 @@ __device__ __forceinline__ void ln_emit(const LnItem &it, int e, unsigned int &w
 __device__ __forceinline__ int ln_item_count(const LnItem &it) { return (it.l0 >> 31) ? 0 : 1 << __popc((it.l0 >> 16) & 7u); }
 
 template <int NB, int LINE, int SBUF, int NT>
-__global__ __launch_bounds__(NT) void lines_coarse(const float *__restrict__ pos, int64_t n, LGeom g, double box, float offA,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void lines_coarse(const float *__restrict__ pos, int64_t n, LGeom g, double box, float offA,
                                                    int64_t CH, const unsigned int *__restrict__ M,
                                                    const unsigned int *__restrict__ gstart, uint4 *__restrict__ staged) {
     __shared__ SplitLds<uint4, NB, LINE, SBUF, NT> s;
