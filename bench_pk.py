@@ -88,6 +88,7 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
         'fft_z_r2c': 8.0 * M, 'fft_cols_y': 8.0 * M, 'fft_cols_x': 8.0 * M,   # one pass each: read 4M + write 4M
         'gfft_rows': 8.0 * M, 'gfft_cols_y': 8.0 * M, 'gfft_cols_x': 8.0 * M,  # mixed-radix passes (csrc/gfft.hip): the same
         'fft_x_bin': 4.0 * M,              # last pass fused with the binning: one read of the half-spectrum, nothing written
+        'gfft_x_bin': 4.0 * M,             # the same for the mixed-radix meshes (csrc/gfft.hip)
         'tsc_tile_deposit': 4.0 * M + 8.0 * 1.25 * n,   # mesh written once + the 8-byte entries (1.25 per particle) read
         'spectrum_bin': 4.0 * M,
         'tsc_bin_count': 12.0 * n,
