@@ -471,6 +471,8 @@ def single(args):
                             ('pk', lambda: bench_pk.bench_pk(args, dist, headline=False, cpu=False)),
                             # BASELINE config 3 itself (1024^3, 1e8 particles), with the CPU oracle timed on the same workload
                             ('pk_c3', lambda: bench_pk.bench_pk(args, dist, headline=False, nmesh=1024, variants=False)),
+                            # a mixed-radix mesh (csrc/gfft.hip; the reference takes any size, compute_power defaults to 550)
+                            ('pk_1536', lambda: bench_pk.bench_pk(args, dist, headline=False, nmesh=1536, cpu=False, variants=False)),
                             ('pairs', lambda: bench_pk.bench_pairs(args, dist)),
                             ('catalog', lambda: bench_pk.bench_catalog(args, dist)),
                             ('prepare', lambda: bench_pk.bench_prepare(args, dist))):
