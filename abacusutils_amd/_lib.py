@@ -270,6 +270,11 @@ def set_option(name, value=1):
     check(lib().abacus_set_option(name.encode(), int(value)))
 
 
+def scratch_release():
+    """free the library's idle scratch blocks (abacus_scratch_release): temporaries kept between calls"""
+    check(lib().abacus_scratch_release())
+
+
 def profile_enable(on=True):
     check(lib().abacus_profile_enable(int(on)))
 

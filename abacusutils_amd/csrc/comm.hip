@@ -170,9 +170,11 @@ int abacus_comm_init(int rank, int world, const void *id, int len, abacus_comm *
         c->rank = rank, c->world = world;
         memcpy(&u, id, sizeof u);
     }
-    // ncclCommInitRank blocks until EVERY rank has joined.  The library's API lock is NOT held across it: a caller that gives up
-    // on a join that never completes (comm.py: a deadline on a helper thread) must still be able to use the rest of the library
-    // - the file-barrier fallback of the HOD leg populates on this same process - instead of queueing behind a dead call.
+    // ncclCommInitRank blocks until EVERY rank has joined.  The library's API lock is NOT held across it, so that a caller whose
+    // deadline on the join expires (comm.py: RcclJoinTimeout from a helper thread) is not queued behind a dead call while it
+    // reports the failure.  Policy (comm.py, bench.py): such a process makes NO further library call and ends at once
+    // (os._exit) - the helper thread may still return into the code below - and the launcher starts a fresh process; the
+    // file-barrier fallback of the HOD leg is only taken when the join FAILED, never when it timed out.
     const ncclResult_t r = R.CommInitRank(&c->nccl, world, u, rank);
     ABACUS_ENTER();
     if (r != ncclSuccess) {

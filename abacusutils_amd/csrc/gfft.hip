@@ -713,7 +713,17 @@ bool gfft_supported(int n, int is_double) {
     GPlan p;
     if (n < 8 || n > 4096 || (n & 1)) return false;
     if (!make_plan(n, p) || !make_plan(n / 2, p)) return false;
-    return n * (is_double ? 2 : 4) <= (is_double ? maxv<double>() : maxv<float>()) * G_NT;   // at least one column group per tile
+    const int CG = is_double ? 2 : 4, cap = (is_double ? maxv<double>() : maxv<float>()) * G_NT;
+    if (n * CG > cap) return false;                                   // at least one column group per tile
+    // the dynamic LDS launch_rows / r2c_inplace will ask for must fit the CU's 160 KiB (double: 64 n bytes of column tile,
+    // beyond it above n = 2560; such sizes go to hipFFT instead of failing at the launch)
+    const size_t cbytes = is_double ? 16 : 8;
+    int lgR = 0, lgC = 0;
+    while ((CG << (lgR + 1)) <= 32 && (CG << (lgR + 1)) * (n / 2) <= cap) lgR++;
+    while ((CG << (lgC + 1)) <= 16 && (CG << (lgC + 1)) * n <= cap) lgC++;
+    const size_t lds_rows = ((size_t)n + (size_t)(n / 2) * ((CG << lgR) + 1)) * cbytes;
+    const size_t lds_cols = ((size_t)n + (size_t)n * ((CG << lgC) + 1)) * cbytes;
+    return std::max(lds_rows, lds_cols) <= (size_t)160 * 1024;
 }
 int gfft_r2c_inplace_f32(float *mesh, int n, int pitch_r, float xcut) { return r2c_inplace<float>(mesh, n, pitch_r, xcut); }
 int gfft_r2c_inplace_f64(double *mesh, int n, int pitch_r) { return r2c_inplace<double>(mesh, n, pitch_r); }

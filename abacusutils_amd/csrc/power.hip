@@ -701,13 +701,25 @@ int fft_check(hipfftResult r, const char *what) {
 // real-row pitch (floats): rows start on 128-B boundaries, >= n + 2 for the in-place R2C layout
 int pitch_r(int n) { return (n + 2 + 31) / 32 * 32; }
 
+// hipFFT allocates its work area when a plan is made: with idle scratch blocks of this library around, give them back and try
+// once more before reporting the failure
+template <typename F>
+hipfftResult plan_with_retry(F make) {
+    hipfftResult r = make();
+    if (r != HIPFFT_SUCCESS) {
+        (void)hipGetLastError();
+        if (scratch_trim_idle() == 0) r = make();
+    }
+    return r;
+}
+
 int get_plan(int n, hipfftHandle *out) {
     auto it = g_ctx.plans.find(n);
     if (it == g_ctx.plans.end()) {
         hipfftHandle h;
         int dims[3] = {n, n, n};
         int inembed[3] = {n, n, pitch_r(n)}, onembed[3] = {n, n, pitch_r(n) / 2};
-        ABACUS_TRY(fft_check(hipfftPlanMany(&h, 3, dims, inembed, 1, 1, onembed, 1, 1, HIPFFT_R2C, 1),   // batch 1: dist unused
+        ABACUS_TRY(fft_check(plan_with_retry([&] { return hipfftPlanMany(&h, 3, dims, inembed, 1, 1, onembed, 1, 1, HIPFFT_R2C, 1); }),   // batch 1: dist unused
                              "hipfftPlanMany"));
         it = g_ctx.plans.emplace(n, h).first;
     }
@@ -1504,7 +1516,7 @@ int abacus_pk_to_xi(const float *Pk, int n, double Lbox, const double *redges, i
     auto it = g_ctx.c2r_plans.find(n);
     if (it == g_ctx.c2r_plans.end()) {
         hipfftHandle h;
-        ABACUS_TRY(fft_check(hipfftPlan3d(&h, n, n, nz, HIPFFT_C2R), "hipfftPlan3d(C2R)"));
+        ABACUS_TRY(fft_check(plan_with_retry([&] { return hipfftPlan3d(&h, n, n, nz, HIPFFT_C2R); }), "hipfftPlan3d(C2R)"));
         it = g_ctx.c2r_plans.emplace(n, h).first;
     }
     ABACUS_TRY(fft_check(hipfftSetStream(it->second, stream()), "hipfftSetStream"));
@@ -1672,7 +1684,8 @@ int abacus_power_release(void) {
         ABACUS_TRY(b->release());
     g_ctx.phase_n = 0;
     ABACUS_TRY(fft_native_release());
-    return tsc_release_work();
+    ABACUS_TRY(tsc_release_work());
+    return scratch_trim_idle();
 }
 
 }  // extern "C"
@@ -1742,7 +1755,7 @@ int field64_dev(void *pos, int pos_f64, int64_t n, const void *w, double L, int 
             hipfftHandle h;
             int dims[3] = {nmesh, nmesh, nmesh};
             int inembed[3] = {nmesh, nmesh, pr}, onembed[3] = {nmesh, nmesh, pr / 2};
-            ABACUS_TRY(fft_check(hipfftPlanMany(&h, 3, dims, inembed, 1, 1, onembed, 1, 1, HIPFFT_D2Z, 1), "hipfftPlanMany (D2Z)"));
+            ABACUS_TRY(fft_check(plan_with_retry([&] { return hipfftPlanMany(&h, 3, dims, inembed, 1, 1, onembed, 1, 1, HIPFFT_D2Z, 1); }), "hipfftPlanMany (D2Z)"));
             it = g_ctx.plans64.emplace(nmesh, h).first;
         }
         ABACUS_TRY(fft_check(hipfftSetStream(it->second, stream()), "hipfftSetStream"));

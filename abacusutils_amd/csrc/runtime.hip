@@ -114,9 +114,18 @@ int scratch_acquire(void **out, size_t bytes) {
     *out = q;
     return 0;
 }
+// blocks above 1 GiB (a caller's whole mesh: 34 GB at 2048^3) are not kept idle - hipFFT work areas, RCCL buffers or another
+// framework in the process would run out of memory beside them; the small per-call temporaries are what the cache is for
 void scratch_release(void *p) {
-    for (ScratchBlock &k : g_scratch_blocks)
-        if (k.p == p) k.used = false;
+    for (size_t i = 0; i < g_scratch_blocks.size(); i++) {
+        ScratchBlock &k = g_scratch_blocks[i];
+        if (k.p != p) continue;
+        if (k.cap > ((size_t)1 << 30)) {
+            (void)hipFree(k.p);
+            g_scratch_blocks.erase(g_scratch_blocks.begin() + (long)i);
+        } else k.used = false;
+        return;
+    }
 }
 int scratch_trim_idle() { return scratch_trim(); }
 

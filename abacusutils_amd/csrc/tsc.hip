@@ -1165,6 +1165,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     if (share && list_mode == 2 && (offset < 0.0 || offset > 0.5 * box / gxg * 1.0000001))
         return fail("tsc: shared lists cover offsets up to half a cell");
     // second-generation lists (tsc_lines.hpp): unweighted float32 TSC on a full periodic mesh of whole tiles
+    int lines_wrapped = 0;   // its counting pass wrapped positions in place before it handed over to the first generation
     if constexpr (std::is_same<PT, float>::value && std::is_same<GT, float>::value && !CIC) {
         LGeom lg;
         int lcfg = 0;
@@ -1174,6 +1175,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
             g_lists.valid = false;
             const int rc = lines_deposit_run(pos, n, grid, lg, lcfg, box, offset, wrap, zero_grid, norm, sub, wrapped_out);
             if (rc <= 0) return rc;   // 1: more than 2^32 entries - the first-generation lists below
+            if (wrapped_out) lines_wrapped = *wrapped_out;
         }
     }
     const int ext = share ? 1 : 0;
@@ -1185,7 +1187,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     if (reuse) {
         entries = static_cast<Entry<PT> *>(g_lists.entries);
         nentries_total = g_lists.nentries;
-        if (wrapped_out) *wrapped_out = 0;
+        if (wrapped_out) *wrapped_out = lines_wrapped;
     } else if (multisplit) {
         const int ncoarse = (int)(((int64_t)ntiles + (1 << cshift) - 1) >> cshift);
         ABACUS_TRY(g_work.gcount.reserve((size_t)(MS_BINS + 1) * sizeof(unsigned int)));
@@ -1213,7 +1215,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
                                stream()));
         HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
         HIP_TRY(hipStreamSynchronize(stream()));
-        if (wrapped_out) *wrapped_out = h_flag;
+        if (wrapped_out) *wrapped_out = h_flag | lines_wrapped;
         g_wrapped_seen |= h_flag;
         const int64_t total = h_start[ncoarse];
         nentries_total = total;
@@ -1258,7 +1260,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         int h_flag = 0;
         HIP_TRY(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
         HIP_TRY(hipStreamSynchronize(stream()));
-        if (wrapped_out) *wrapped_out = h_flag;
+        if (wrapped_out) *wrapped_out = h_flag | lines_wrapped;
         g_wrapped_seen |= h_flag;
         nentries_total = total;
         ABACUS_TRY(g_work.entries.reserve((size_t)std::max<int64_t>(total, 1) * sizeof(Entry<PT>)));

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
             if (!xh && lane == 63) {       // i = n/2 (a = H/2): one mode, last lane of the even half
                 float2 q = (g.dbg & 8) ? make_float2(1.f, 1.f) : col[padq(H / 2)];
                 if (INTER) {
-                    int m = jj + k + H;
+                    int m = jj + k - H;            // i = n/2 folds to -n/2 (shift_field_fft, power_spectrum.py:940-942)
                     m += m < 0 ? 2 * n : 0;
                     const float2 ph = g.phase[m], a = keepQ[INTER ? ci : 0];
                     q = make_float2(a.x + (q.x * ph.x - q.y * ph.y), a.y + (q.x * ph.y + q.y * ph.x));

@@ -377,7 +377,14 @@ def run_leg(args):
     # binds GPU LOCAL_RANK, file rendezvous, ncclCommInitRank; raises without a HIP device.  The HOD leg has no data-path
     # collective (every rank populates its own shard): if the RCCL communicator cannot be created it still runs, with the
     # start barrier and the max over the ranks' timings through files, and says so in `rccl`
-    dist = Dist.from_env(allow_file_fallback=(args.leg == 'hod'))
+    from abacusutils_amd.comm import RcclJoinTimeout
+    try:
+        dist = Dist.from_env(allow_file_fallback=(args.leg == 'hod'))
+    except RcclJoinTimeout as e:
+        # a helper thread of this process is still inside ncclCommInitRank / the first barrier: no further library call, no
+        # interpreter teardown under it - report and leave at once (the orchestrator prints the fallback line)
+        print(f'BENCH-LEG-ERROR RcclJoinTimeout: {e}', file=sys.stderr, flush=True)
+        os._exit(3)
     if args.leg == 'hod':
         out = bench_hod(args, dist)
     else:

@@ -233,7 +233,7 @@ int abacus_field_fft(float *pos, int64_t n, const float *w, double Lbox, int nme
  * float64 MESHES: get_field / get_field_fft / calc_power with dtype=np.float64 (analysis/power_spectrum.py:808-857, 1001-1070,
  * 1131-1319), non-interlaced (the reference's interlaced branch ignores dtype, :1048-1052).  pos_f64: the positions (and weights)
  * are float64 - the cloud weights are evaluated in the dtype of the positions (analysis/tsc.py:400).  The mesh is deposited,
- * normalised and transformed in float64 (csrc/gfft.hip: even sizes up to 3072 with factors 2, 3, 5, 7, 11, 13; hipFFT's D2Z otherwise); field:
+ * normalised and transformed in float64 (csrc/gfft.hip: even sizes up to 2560 with factors 2, 3, 5, 7, 11, 13 - what fits the 160-KiB LDS tile in double; hipFFT's D2Z otherwise); field:
  * (nmesh,)*3 float64, out_c128: (nmesh, nmesh, nmesh/2+1) complex128; abacus_power_f64 returns what bin_kmu returns, times L^3.
  */
 int abacus_field_f64(void *pos, int pos_f64, int64_t n, const void *w, double Lbox, int nmesh, int paste, double offset, double *field);

@@ -467,15 +467,18 @@ def test_full_size_2048_analytic_known_answer(comp, inter):
     np.testing.assert_allclose(np.asarray(got['k_avg']), want['k_avg'], rtol=1e-6)
 
 
-def test_c3_full_size_against_oracle():
+@pytest.mark.parametrize('comp,inter', [(False, False), (True, True)])
+def test_c3_full_size_against_oracle(comp, inter):
     """BASELINE config 3 at full size: 1e8 uniform particles (seed 300) -> 1024^3 TSC + FFT + binning,
-    HIP against the CPU oracle (float64 accumulation) on the same inputs: N_mode exact, P(k, mu), multipoles <= 1e-5"""
+    HIP against the CPU oracle (float64 accumulation) on the same inputs: N_mode exact, P(k, mu), multipoles <= 1e-5.
+    Both modes SURVEY 8(d) names for the config: (compensated, interlaced) = (False, False) and the reference's defaults
+    (True, True) (analysis/power_spectrum.py:1131)"""
     from abacusutils_amd.analysis.power_spectrum import calc_power
     from oracle import oracle
     n, box, nmesh = 100_000_000, 2000.0, 1024
     pos = np.random.default_rng(300).random((n, 3), dtype=np.float32) * np.float32(box)
     kw = dict(kbins=512, mubins=4, k_max=np.pi * nmesh / box + 1e-6, paste='TSC', nmesh=nmesh, poles=[0, 2, 4],
-              compensated=False, interlaced=False)
+              compensated=comp, interlaced=inter)
     a = calc_power(pos, box, **kw)
     b = oracle.calc_power(pos, box, nthread=oracle.max_threads(), accum64=True, **kw)
     np.testing.assert_array_equal(np.asarray(a['N_mode']), b['N_mode'])
@@ -540,8 +543,10 @@ def test_fused_last_pass_interlaced_pair_matches_spectrum_bin(options, nmesh, co
     w = np.random.default_rng(4).random(len(pos), dtype=np.float32) + np.float32(0.5)
     cases = (dict(kbins=64, mubins=4, poles=[0, 2, 4]), dict(kbins=300, mubins=None, poles=[0, 2], k_max=np.pi * nmesh / box + 1e-6),
              dict(kbins=np.array([0.0, 0.02, 0.021, 0.3, 0.31, 2.0]), mubins=np.array([0.0, 0.05, 0.5, 0.51, 1.0]), poles=[2]),
-             dict(kbins=24, mubins=8, poles=[], logk=True, k_max=2.0, w=w))
-    for kw in (cases if nmesh == 1024 else cases[:2]):
+             dict(kbins=24, mubins=8, poles=[], logk=True, k_max=2.0, w=w),
+             # edges past k_Nyquist: the i = n/2 plane is binned with its phase folded to -n/2 (power_spectrum.py:940-942)
+             dict(kbins=40, mubins=3, poles=[0, 2, 4], k_max=1.7 * np.pi * nmesh / box))
+    for kw in (cases if nmesh == 1024 else cases[:2] + cases[4:]):
         kw = dict(kw, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=True)
         _lib.profile_reset()
         _lib.profile_enable(True)
@@ -562,6 +567,8 @@ def test_fused_last_pass_interlaced_pair_matches_spectrum_bin(options, nmesh, co
         from oracle import oracle
         kw = dict(kbins=20, mubins=3, k_max=1.2, paste='TSC', nmesh=1024, compensated=comp, interlaced=True, poles=[0, 2])
         small = synth.synth_positions(300_000, box, seed=92, clustered=True)
+        _check_oracle(calc_power(small.copy(), box, **kw), oracle.calc_power(small.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw))
+        kw.update(k_max=1.7 * np.pi * nmesh / box, kbins=34)       # past Nyquist: every x-Nyquist mode is binned
         _check_oracle(calc_power(small.copy(), box, **kw), oracle.calc_power(small.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw))
 
 
@@ -736,6 +743,26 @@ def test_mixed_radix_meshes_take_the_native_transform(nmesh, npart, options):
             np.testing.assert_allclose(fa['poles'], fb['poles'], rtol=3e-6, atol=5e-7 * scale)
         if np.isscalar(kw2['kbins']):
             _check_oracle(fa, oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw2))
+
+
+@pytest.mark.parametrize('logk', [False, True])
+def test_compute_power_default_mesh_550_interlaced_against_oracle(logk):
+    """what AbacusHOD.compute_power runs when asked for the reference's default estimator (hod/abacus_hod.py:1338-1347 ->
+    calc_power(..., nmesh=num_cells=550, paste='TSC', compensated=True, interlaced=True)): 3e6 clustered particles + a cross
+    spectrum against 1e6 others on the 550^3 mixed-radix mesh, against the oracle (N_mode exact, P and multipoles 1e-5)"""
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    box, nmesh = 2000.0, 550
+    pos = synth.synth_positions(3_000_000, box, seed=550, clustered=True)
+    pos2 = synth.synth_positions(1_000_000, box, seed=551, clustered=True)
+    kw = dict(kbins=40, mubins=5, k_max=0.6, logk=logk, paste='TSC', nmesh=nmesh, compensated=True, interlaced=True, poles=[0, 2, 4])
+    # the multipoles near their zero crossings (l = 4 at a tenth of the monopole) carry the float32 round-off of both
+    # transforms: observed 1.2e-5 of the floored value = 1.2e-6 of the spectrum's scale in one of 120 values
+    _check_oracle(calc_power(pos.copy(), box, **kw), oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw),
+                  poles_rtol_factor=2.0)
+    kw['pos2'] = pos2
+    _check_oracle(calc_power(pos.copy(), box, **kw), oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw),
+                  poles_rtol_factor=2.0)
 
 
 @pytest.mark.parametrize('n', [24, 30, 21])

@@ -95,3 +95,10 @@ def test_abacus_hod_methods():
     for name in METHODS:
         assert name in ref and hasattr(AbacusHOD, name), name
         _check(ref[name], getattr(AbacusHOD, name), f'AbacusHOD.{name}')
+
+
+def test_calc_power_spectrum_is_calc_power():
+    """BASELINE.json's north_star calls the estimator `calc_power_spectrum()`; the reference only has `calc_power`
+    (analysis/power_spectrum.py:1131) - both names are the same callable here"""
+    from abacusutils_amd.analysis import power_spectrum as ps
+    assert ps.calc_power_spectrum is ps.calc_power and 'calc_power_spectrum' in ps.__all__
