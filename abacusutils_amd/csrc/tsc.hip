@@ -917,6 +917,7 @@ __global__ __launch_bounds__(NT) void tsc_tile_deposit_p(const Entry<float> *__r
 static int g_wrapped_seen = 0;
 
 #include "tsc_lines.hpp"
+#include "tsc_lines3.hpp"
 
 // ---- host-side driver ------------------------------------------------------------------------------------
 // second-generation lists (tsc_lines.hpp): work buffers and the staged entries kept for the second deposit of an
@@ -971,6 +972,36 @@ static int lines_fxscale(int64_t n, double &fxscale) {
     while (fxs > 8 && (double)std::max<int64_t>(n, 1) * std::ldexp(1.0, fxs) >= 0x1p62) fxs--;
     fxscale = std::ldexp(1.0, fxs);
     return fxs;
+}
+
+// tile deposit from packed entries: 32-bit fixed-point tile sums (four workgroups per CU) or, `tsc_acc64`, 64-bit sums
+static int lines_launch_deposit(const unsigned long long *entries, int64_t fs, int64_t nentries, int64_t n, const unsigned int *tile_start,
+                                const unsigned int *tile_cnt, const LGeom &g, float *grid, int zero_grid, double norm, double sub) {
+    const int ntiles = g.nbuckets * g.tpb;
+    int dev = 0, ncu = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int range_len = (int)std::min<int64_t>(LD_RANGE, std::max<int64_t>(64, ceil_div(ntiles, (int64_t)ncu * 8)));
+    const int nranges = (int)ceil_div(ntiles, range_len);
+    const int grid_p = (int)std::min<int64_t>(nranges, (int64_t)ncu * 2);
+    const int dbg = option("dbg_tsc") & 3;
+    if (!option("tsc_acc64")) {   // 32-bit tile sums, four workgroups per CU
+        const int range32 = (int)std::min<int64_t>(LD32_RANGE, std::max<int64_t>(64, ceil_div(ntiles, (int64_t)ncu * 16)));
+        const int grid32 = (int)std::min<int64_t>(ceil_div(ntiles, range32), (int64_t)ncu * 4);
+        ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit32<256>), dim3(grid32), dim3(256), 0, entries, fs, tile_start, tile_cnt, ntiles, range32, g,
+                      grid, zero_grid, (float)norm, (float)sub, dbg);
+        return 0;
+    }
+    const bool dense = nentries / std::max(ntiles, 1) > 400;
+    double fxscale;
+    lines_fxscale(n, fxscale);
+    if (dense)
+        ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit<512>), dim3(grid_p), dim3(512), 0, entries, fs, tile_start, tile_cnt, ntiles, range_len, g,
+                      grid, zero_grid, (float)norm, (float)sub, fxscale, dbg);
+    else
+        ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit<256>), dim3(grid_p), dim3(256), 0, entries, fs, tile_start, tile_cnt, ntiles, range_len, g,
+                      grid, zero_grid, (float)norm, (float)sub, fxscale, dbg);
+    return 0;
 }
 
 // lists + deposit of the second generation, for one deposit (an interlaced pair builds its lists twice: the staged entries
@@ -1059,7 +1090,7 @@ static int lines_deposit_run(float *pos, int64_t n, float *grid, const LGeom &g,
                       (const unsigned int *)M, d_gstart, staged);
         if (np) ABACUS_LAUNCH("tsc_lines_fcount", (lines_fcount<512>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb, C);
         ABACUS_LAUNCH("tsc_lines_fscan", (lines_fscan<512>), dim3(nb), dim3(512), 0, C, d_pfirst, g, d_fstart, tile_start, tile_cnt);
-        if (np) ABACUS_LAUNCH("tsc_lines_fine", (lines_fine<512, 8, 3072, 512>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb,
+        if (np) ABACUS_LAUNCH("tsc_lines_fine", (lines_fine<512, 8, 2560, 512>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb,
                               (const unsigned int *)C, entries);
     } else {
         ABACUS_LAUNCH("tsc_lines_coarse", (lines_coarse<1024, 4, 3328, 1024>), dim3(nchunk), dim3(1024), 0, (const float *)pos, n, g, box, offA, CH,
@@ -1069,31 +1100,159 @@ static int lines_deposit_run(float *pos, int64_t n, float *grid, const LGeom &g,
         if (np) ABACUS_LAUNCH("tsc_lines_fine", (lines_fine<1024, 8, 4096, 1024>), dim3(np), dim3(1024), 0, (const uint4 *)staged, d_pieces, g.tpb,
                               (const unsigned int *)C, entries);
     }
-    // deposit
-    int dev = 0, ncu = 256;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const int range_len = (int)std::min<int64_t>(LD_RANGE, std::max<int64_t>(64, ceil_div(ntiles, (int64_t)ncu * 8)));
-    const int nranges = (int)ceil_div(ntiles, range_len);
-    const int grid_p = (int)std::min<int64_t>(nranges, (int64_t)ncu * 2);
-    const int dbg = option("dbg_tsc") & 3;
-    if (!option("tsc_acc64")) {   // 32-bit tile sums, four workgroups per CU
-        const int range32 = (int)std::min<int64_t>(LD32_RANGE, std::max<int64_t>(64, ceil_div(ntiles, (int64_t)ncu * 16)));
-        const int grid32 = (int)std::min<int64_t>(ceil_div(ntiles, range32), (int64_t)ncu * 4);
-        ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit32<256>), dim3(grid32), dim3(256), 0, (const unsigned long long *)entries, (int64_t)fs,
-                      (const unsigned int *)tile_start, (const unsigned int *)tile_cnt, ntiles, range32, g, grid, zero_grid, (float)norm, (float)sub, dbg);
-        return 0;
+    return lines_launch_deposit(entries, fs, gs, n, tile_start, tile_cnt, g, grid, zero_grid, norm, sub);
+}
+
+// ---- third generation (tsc_lines3.hpp): block records; one build serves both deposits of an interlaced pair ----------
+// diagnostic phase clocks of the split rounds (option tsc_lines_clk; abacus_tsc_lines_clocks reads and clears them)
+DevBuf g_lines_clk;
+static unsigned long long *lines_clk(int off) {
+    if (!option("tsc_lines_clk")) return nullptr;
+    if (!g_lines_clk.p) {
+        if (g_lines_clk.reserve(32 * sizeof(unsigned long long)) != 0) return nullptr;
+        (void)hipMemsetAsync(g_lines_clk.p, 0, 32 * sizeof(unsigned long long), stream());
     }
-    const bool dense = gs / std::max(ntiles, 1) > 400;
-    double fxscale;
-    lines_fxscale(n, fxscale);
-    if (dense)
-        ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit<512>), dim3(grid_p), dim3(512), 0, (const unsigned long long *)entries, (int64_t)fs,
-                      (const unsigned int *)tile_start, (const unsigned int *)tile_cnt, ntiles, range_len, g, grid, zero_grid, (float)norm, (float)sub, fxscale, dbg);
-    else
-        ABACUS_LAUNCH("tsc_tile_deposit", (lines_deposit<256>), dim3(grid_p), dim3(256), 0, (const unsigned long long *)entries, (int64_t)fs,
-                      (const unsigned int *)tile_start, (const unsigned int *)tile_cnt, ntiles, range_len, g, grid, zero_grid, (float)norm, (float)sub, fxscale, dbg);
+    return g_lines_clk.as<unsigned long long>() + off;
+}
+
+struct Lines3State {
+    bool valid = false;
+    const void *pos = nullptr;
+    int64_t n = 0, zstride = 0, fs = 0;
+    int gx = 0, gy = 0, gz = 0, cfg = 0, np = 0, ext = 0;
+    double box = 0, offset = 0;
+    LGeom g;
+    size_t o_f = 0, o_pf = 0, o_p = 0;
+};
+Lines3State g_l3;
+
+// count + coarse: the staged block records of `pos` at mesh offset `offset` (ext: blocks of the 4-cell union of the clouds at
+// `offset` and `offset` + half a cell).  Returns 1 when 32-bit indices do not hold the lists (caller falls back).
+static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double box, double offset, int wrap, int ext, int *wrapped_out) {
+    g_l3.valid = false;
+    const int nb = g.nbuckets;
+    const int64_t CH = std::max<int64_t>(8192, ceil_div(n, 1024));
+    const int nchunk = (int)ceil_div(n, CH);
+    ABACUS_TRY(g_lw.M.reserve((size_t)nchunk * nb * sizeof(unsigned int)));
+    // [records per block (nb)] [wrapped flag] [tile entries per block (nb)]: one read-back into page-locked memory
+    const size_t nword = (size_t)2 * nb + 1;
+    ABACUS_TRY(g_lw.tot.reserve(nword * sizeof(unsigned int)));
+    unsigned int *M = g_lw.M.as<unsigned int>(), *tot = g_lw.tot.as<unsigned int>();
+    int *flag = reinterpret_cast<int *>(tot + nb);
+    unsigned int *ent = tot + nb + 1;
+    HIP_TRY(hipMemsetAsync(flag, 0, (size_t)(nb + 1) * sizeof(unsigned int), stream()));
+    const float offA = (float)offset;
+#define L3_COUNT(NBK, EXT_) ABACUS_LAUNCH("tsc_lines_count", (lines3_count<NBK, EXT_>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, ent, flag)
+    if (cfg == 0) {
+        if (ext) L3_COUNT(256, true);
+        else L3_COUNT(256, false);
+    } else {
+        if (ext) L3_COUNT(1024, true);
+        else L3_COUNT(1024, false);
+    }
+#undef L3_COUNT
+    ABACUS_LAUNCH("tsc_lines_colscan", lines_colscan, dim3(nb), dim3(1024), 0, M, nchunk, nb, tot);
+    static unsigned int *h_tot = nullptr;
+    static size_t h_tot_cap = 0;
+    if (nword > h_tot_cap) {
+        if (h_tot) HIP_TRY(hipHostFree(h_tot));
+        h_tot = nullptr, h_tot_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&h_tot, nword * sizeof(unsigned int) * 2, hipHostMallocDefault));
+        h_tot_cap = 2 * nword;
+    }
+    HIP_TRY(hipMemcpyAsync(h_tot, tot, nword * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    const int h_flag = (int)h_tot[nb];
+    const unsigned int *h_ent = h_tot + nb + 1;
+    if (wrapped_out) *wrapped_out = h_flag;
+    g_wrapped_seen |= h_flag;
+    const int64_t PIECE = option("tsc_piece") > 0 ? (int64_t)option("tsc_piece") * 1024 : 64 * (int64_t)g.tpb;
+    std::vector<unsigned int> gstart((size_t)nb + 1), fstart((size_t)nb + 1);
+    std::vector<int> piece_first((size_t)nb + 1);
+    std::vector<LnPiece> pieces;
+    int64_t gs = 0, fs = 0;
+    for (int b = 0; b < nb; b++) {
+        gstart[b] = (unsigned int)gs, fstart[b] = (unsigned int)fs;
+        piece_first[b] = (int)pieces.size();
+        for (int64_t e = 0; e < (int64_t)h_tot[b]; e += PIECE)
+            pieces.push_back(LnPiece{b, (unsigned int)(gs + e), (unsigned int)(gs + std::min<int64_t>(e + PIECE, h_tot[b])), e == 0});
+        gs += ((int64_t)h_tot[b] + 15) & ~(int64_t)15;
+        fs += ((int64_t)h_ent[b] + 15 * (int64_t)g.tpb + 15) & ~(int64_t)15;   // every tile list starts on a line boundary
+        if (gs >= 0xfff00000ll || fs >= 0xfff00000ll) return 1;
+    }
+    gstart[nb] = (unsigned int)gs, fstart[nb] = (unsigned int)fs;
+    piece_first[nb] = (int)pieces.size();
+    const int np = (int)pieces.size();
+    const size_t o_g = 0, o_f = o_g + (size_t)(nb + 1) * 4, o_pf = o_f + (size_t)(nb + 1) * 4, o_p = (o_pf + (size_t)(nb + 1) * 4 + 15) & ~(size_t)15,
+                 tbytes = o_p + std::max<size_t>(pieces.size(), 1) * sizeof(LnPiece);
+    static char *h_blob = nullptr;
+    static size_t h_blob_cap = 0;
+    if (tbytes > h_blob_cap) {
+        if (h_blob) HIP_TRY(hipHostFree(h_blob));
+        h_blob = nullptr, h_blob_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&h_blob, tbytes * 2, hipHostMallocDefault));
+        h_blob_cap = tbytes * 2;
+    }
+    memcpy(h_blob + o_g, gstart.data(), (size_t)(nb + 1) * 4);
+    memcpy(h_blob + o_f, fstart.data(), (size_t)(nb + 1) * 4);
+    memcpy(h_blob + o_pf, piece_first.data(), (size_t)(nb + 1) * 4);
+    if (np) memcpy(h_blob + o_p, pieces.data(), pieces.size() * sizeof(LnPiece));
+    ABACUS_TRY(g_lw.tables.reserve(tbytes));
+    ABACUS_TRY(g_lw.staged.reserve((size_t)std::max<int64_t>(gs, 16) * sizeof(uint4)));
+    HIP_TRY(hipMemcpyAsync(g_lw.tables.p, h_blob, tbytes, hipMemcpyHostToDevice, stream()));
+    const unsigned int *d_gstart = reinterpret_cast<const unsigned int *>(g_lw.tables.as<char>() + o_g);
+    uint4 *staged = g_lw.staged.as<uint4>();
+#define L3_COARSE(NBK, LINE_, SBUF_, NT_, EXT_)                                                                                      \
+    ABACUS_LAUNCH("tsc_lines_coarse", (lines3_coarse<NBK, LINE_, SBUF_, NT_, EXT_>), dim3(nchunk), dim3(NT_), 0, (const float *)pos, n, g, box, \
+                  offA, CH, (const unsigned int *)M, d_gstart, staged, lines_clk(0))
+    if (cfg == 0) {
+        if (ext) L3_COARSE(256, 8, 2560, 512, true);
+        else L3_COARSE(256, 8, 2560, 512, false);
+    } else {
+        if (ext) L3_COARSE(1024, 4, 3328, 1024, true);
+        else L3_COARSE(1024, 4, 3328, 1024, false);
+    }
+#undef L3_COARSE
+    g_l3.pos = pos, g_l3.n = n, g_l3.fs = fs, g_l3.cfg = cfg, g_l3.np = np, g_l3.ext = ext;
+    g_l3.box = box, g_l3.offset = offset, g_l3.g = g;
+    g_l3.gx = g.n[0], g_l3.gy = g.n[1], g_l3.gz = g.n[2], g_l3.zstride = g.zstride;
+    g_l3.o_f = o_f, g_l3.o_pf = o_pf, g_l3.o_p = o_p;
+    g_l3.valid = true;
     return 0;
+}
+
+// fcount + fscan + fine + deposit from the staged records; org 1: the mesh origin half a cell further (needs an `ext` build)
+static int lines3_deposit(float *grid, int org, int zero_grid, double norm, double sub) {
+    const LGeom &g = g_l3.g;
+    const int nb = g.nbuckets, ntiles = nb * g.tpb, np = g_l3.np, cfg = g_l3.cfg;
+    const int64_t fs = g_l3.fs;
+    ABACUS_TRY(g_lw.C.reserve((size_t)std::max(np, 1) * g.tpb * sizeof(unsigned int)));
+    ABACUS_TRY(g_lw.tile_start.reserve((size_t)ntiles * sizeof(unsigned int)));
+    ABACUS_TRY(g_lw.tile_cnt.reserve((size_t)ntiles * sizeof(unsigned int)));
+    ABACUS_TRY(g_lw.entries.reserve((size_t)std::max<int64_t>(fs, 16) * sizeof(unsigned long long)));
+    const char *tb = g_lw.tables.as<char>();
+    const unsigned int *d_fstart = reinterpret_cast<const unsigned int *>(tb + g_l3.o_f);
+    const int *d_pfirst = reinterpret_cast<const int *>(tb + g_l3.o_pf);
+    const LnPiece *d_pieces = reinterpret_cast<const LnPiece *>(tb + g_l3.o_p);
+    const uint4 *staged = g_lw.staged.as<uint4>();
+    unsigned int *C = g_lw.C.as<unsigned int>(), *tile_start = g_lw.tile_start.as<unsigned int>(), *tile_cnt = g_lw.tile_cnt.as<unsigned int>();
+    unsigned long long *entries = g_lw.entries.as<unsigned long long>();
+#define L3_FINE(NBF, SBUF_, NT_, ORG_)                                                                                                 \
+    do {                                                                                                                               \
+        if (np) ABACUS_LAUNCH("tsc_lines_fcount", (lines3_fcount<NBF, ORG_>), dim3(np), dim3(512), 0, staged, d_pieces, g, C);          \
+        ABACUS_LAUNCH("tsc_lines_fscan", (lines_fscan<NBF>), dim3(nb), dim3(NBF), 0, C, d_pfirst, g, d_fstart, tile_start, tile_cnt);   \
+        if (np) ABACUS_LAUNCH("tsc_lines_fine", (lines3_fine<NBF, 8, SBUF_, NT_, ORG_>), dim3(np), dim3(NT_), 0, staged, d_pieces, g,  \
+                              (const unsigned int *)C, entries, lines_clk(16));                                                        \
+    } while (0)
+    if (cfg == 0) {
+        if (org) L3_FINE(512, 2560, 512, 1);
+        else L3_FINE(512, 2560, 512, 0);
+    } else {
+        if (org) L3_FINE(1024, 4096, 1024, 1);
+        else L3_FINE(1024, 4096, 1024, 0);
+    }
+#undef L3_FINE
+    return lines_launch_deposit(entries, fs, fs, g_l3.n, tile_start, tile_cnt, g, grid, zero_grid, norm, sub);
 }
 
 struct TscWork {
@@ -1173,7 +1332,24 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         if (multisplit && !weights && wrap && gxg == gx && xoff == 0 && xoff2 < 0 && ntiles >= 4096 && !option("tsc_oldlists") &&
             std::fabs(offset) <= cell && lines_geometry(gx, gy, gz, zstride, lg, lcfg)) {
             g_lists.valid = false;
-            const int rc = lines_deposit_run(pos, n, grid, lg, lcfg, box, offset, wrap, zero_grid, norm, sub, wrapped_out);
+            int rc;
+            if (option("tsc_lines_gen") == 2) {
+                g_l3.valid = false;
+                rc = lines_deposit_run(pos, n, grid, lg, lcfg, box, offset, wrap, zero_grid, norm, sub, wrapped_out);
+            } else {
+                // third generation (block records).  list_mode 1: built at offset 0 for both deposits of an interlaced pair;
+                // list_mode 2: the half-cell-shifted deposit from the records of that build, if nothing changed since
+                const bool want_share = list_mode != 0 && !option("tsc_noshare");
+                const bool reuse3 = want_share && list_mode == 2 && g_l3.valid && g_l3.ext && g_l3.pos == (const void *)pos && g_l3.n == n &&
+                                    g_l3.zstride == zstride && g_l3.gx == gx && g_l3.gy == gy && g_l3.gz == gz && g_l3.box == box &&
+                                    g_l3.offset == 0.0 && std::fabs(offset - 0.5 * cell) <= 1e-7 * cell;
+                if (reuse3) {
+                    if (wrapped_out) *wrapped_out = 0;
+                    return lines3_deposit(grid, 1, zero_grid, norm, sub);
+                }
+                rc = lines3_build(pos, n, lg, lcfg, box, offset, wrap, want_share && list_mode == 1 && offset == 0.0 ? 1 : 0, wrapped_out);
+                if (rc == 0) return lines3_deposit(grid, 0, zero_grid, norm, sub);
+            }
             if (rc <= 0) return rc;   // 1: more than 2^32 entries - the first-generation lists below
             if (wrapped_out) lines_wrapped = *wrapped_out;
         }
@@ -1407,8 +1583,19 @@ int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int
     return deposit_dev<float, float, false>(pos, n, w, grid, nx_local, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
                                             nullptr, nmesh, xoff, sub, 0, xoff2);
 }
+int tsc_lines_clocks(unsigned long long *out32) {
+    if (!g_lines_clk.p) {
+        memset(out32, 0, 32 * sizeof(unsigned long long));
+        return 0;
+    }
+    HIP_TRY(hipMemcpyAsync(out32, g_lines_clk.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemsetAsync(g_lines_clk.p, 0, 32 * sizeof(unsigned long long), stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
 int tsc_release_work() {
     g_lists.valid = false;
+    g_l3.valid = false;
     ABACUS_TRY(g_lw.M.release());
     ABACUS_TRY(g_lw.tot.release());
     ABACUS_TRY(g_lw.tables.release());
@@ -1432,6 +1619,12 @@ int tsc_release_work() {
 }  // namespace abacus
 
 extern "C" {
+
+int abacus_tsc_lines_clocks(unsigned long long *out32) {
+    ABACUS_ENTER();
+    if (!out32) return fail("abacus_tsc_lines_clocks: null argument");
+    return tsc_lines_clocks(out32);
+}
 
 int abacus_tsc_deposit(void *pos, int64_t n, const void *weights, int pos_dtype, void *grid, int gx, int gy, int gz,
                        int grid_dtype, double box, double offset, int wrap) {

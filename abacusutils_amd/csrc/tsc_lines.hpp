@@ -259,13 +259,13 @@ struct SplitLds {
     static constexpr int ITEMS = (NB + NT - 1) / NT;   // buckets owned by a thread: tid * ITEMS + q
     typename SplitKeep<E>::type out[SBUF];
     typename SplitKeep<E>::type carry[NB * (LINE - 1)];
-    unsigned short obid[SBUF];
+    unsigned int gdx[SBUF];         // global index of out[o]
     unsigned int lcnt[2][NB];       // new entries per bucket, by round parity
     unsigned int lcur[NB];          // placement cursors of the round
     unsigned int ccnt[NB], done[NB], base[NB];
-    unsigned int obase[NB];         // global index of out[o] = obase[bucket] + o
-    unsigned int pa[NB], cb[NB];    // placement: rank k of a bucket's new entries goes to out[pa + k] while k < wd, else carry[cb + k]
-    int wd[NB];
+    // placement of a bucket's new entries, one 16-byte read: rank k goes to out[x + k] while k < (int)y, else carry[z + k];
+    // w: global index of out[o] = w + o
+    uint4 pl[NB];
     unsigned int wave_tot[2][NT / 64];
 };
 
@@ -273,13 +273,32 @@ struct SplitLds {
 // entries (the items sit in registers).  Buckets [last_lo, last_hi) send out everything they hold (the drain after the last
 // item).  Returns false - state untouched - when the round's output does not fit SBUF: the caller retries with fewer items.
 // Four workgroup barriers; the stores of a round are not waited for: they overlap the loads and the counting of the next.
-template <typename E, int NB, int LINE, int SBUF, int NT, typename COUNT, typename PLACE>
+struct SplitNoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `mid()` runs between the placement and the write-out: work that WAITS for global loads issued a round earlier belongs there.
+// (Vector-memory operations retire in order and the compiler cannot count the write-out's stores - their number is not known
+// at compile time - so a wait for a load that follows them is a wait for all of them: the third generation's phase clocks,
+// scripts/gpu_lines_phases.sh, showed a quarter of a round spent in that wait.)
+template <typename E, int NB, int LINE, int SBUF, int NT, typename COUNT, typename PLACE, typename MID = SplitNoMid>
 __device__ __forceinline__ bool split_round(SplitLds<E, NB, LINE, SBUF, NT> &s, int nb, int par, int last_lo, int last_hi,
-                                            E *__restrict__ dst, COUNT count, PLACE place, int dbg = 0) {
+                                            E *__restrict__ dst, COUNT count, PLACE place, int dbg = 0,
+                                            unsigned long long *clk = nullptr, MID mid = MID()) {
     constexpr int ITEMS = SplitLds<E, NB, LINE, SBUF, NT>::ITEMS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // diagnostic (scripts/gpu_lines_phases.sh): shader-clock ticks of thread 0 per phase of the round, summed into clk[0..8]
+    unsigned long long tk = clk ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto tick = [&](int ph) {
+        if (clk && tid == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            atomicAdd(clk + ph, t - tk);
+            tk = t;
+        }
+    };
     count([&](int b) { atomicAdd(&s.lcnt[par][b], 1u); });
+    tick(0);
     __syncthreads();
+    tick(1);
     // owner step: how many entries of each owned bucket leave as whole lines
     unsigned int w[ITEMS], cc[ITEMS], lc[ITEMS], sum = 0;
 #pragma unroll
@@ -304,7 +323,9 @@ __device__ __forceinline__ bool split_round(SplitLds<E, NB, LINE, SBUF, NT> &s, 
         if (lane >= d) incl += t;
     }
     if (lane == 63) s.wave_tot[par][wv] = incl;
+    tick(2);
     __syncthreads();
+    tick(3);
     unsigned int before = 0, ot = 0;
 #pragma unroll
     for (int k = 0; k < NT / 64; k++) {
@@ -329,35 +350,48 @@ __device__ __forceinline__ bool split_round(SplitLds<E, NB, LINE, SBUF, NT> &s, 
         }
         if (b < nb) {
             const unsigned int pos0 = s.base[b] + s.done[b];
-            s.obase[b] = pos0 - run;
-            s.pa[b] = run + cc[q];
-            s.wd[b] = (int)w[q] - (int)cc[q];
-            s.cb[b] = (unsigned int)(b * (LINE - 1)) + cc[q] - w[q];   // w > 0 implies w > cc: a carry never reaches a line boundary
+            // w > 0 implies w > cc: a carry never reaches a line boundary
+            s.pl[b] = make_uint4(run + cc[q], (unsigned int)((int)w[q] - (int)cc[q]), (unsigned int)(b * (LINE - 1)) + cc[q] - w[q], pos0 - run);
             s.ccnt[b] = cc[q] + lc[q] - w[q];
             s.done[b] += w[q];
             if (w[q] > 0u)                                             // the carried entries leave first
                 for (unsigned int j = 0; j < cc[q]; j++) {
                     s.out[run + j] = s.carry[b * (LINE - 1) + j];
-                    s.obid[run + j] = (unsigned short)b;
+                    s.gdx[run + j] = pos0 + j;
                 }
         }
         run += w[q];
     }
+    tick(4);
     __syncthreads();
+    tick(5);
     if (!(dbg & 32))
     place([&](int b, const E &e) {
+        const uint4 P = s.pl[b];
         const unsigned int k = atomicAdd(&s.lcur[b], 1u);
-        if ((int)k < s.wd[b]) {
-            const unsigned int o = s.pa[b] + k;
+        if ((int)k < (int)P.y) {
+            const unsigned int o = P.x + k;
             s.out[o] = SplitKeep<E>::pack(e);
-            s.obid[o] = (unsigned short)b;
+            s.gdx[o] = P.w + o;
         } else {
-            s.carry[s.cb[b] + k] = SplitKeep<E>::pack(e);
+            s.carry[P.z + k] = SplitKeep<E>::pack(e);
         }
     });
+    tick(6);
     __syncthreads();
-    if (!(dbg & 16))
-        for (unsigned int o = tid; o < ot; o += NT) dst[(size_t)(unsigned int)(s.obase[s.obid[o]] + o)] = SplitKeep<E>::unpack(s.out[o]);
+    tick(7);
+    mid();
+    tick(9);
+    if (!(dbg & 16)) {
+        // fixed trip count: the LDS reads of all of a thread's slots are in flight together, then its stores
+        constexpr int WO = (SBUF + NT - 1) / NT;
+#pragma unroll
+        for (int j = 0; j < WO; j++) {
+            const unsigned int o = (unsigned int)(j * NT) + tid;
+            if (o < ot) dst[(size_t)s.gdx[o]] = SplitKeep<E>::unpack(s.out[o]);
+        }
+    }
+    tick(8);
     return true;
 }
 

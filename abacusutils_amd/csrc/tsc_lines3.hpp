@@ -1,0 +1,406 @@
+// TSC particle -> mesh, third generation of the list build ("block records"): included by tsc.hip after tsc_lines.hpp,
+// whose streaming split (split_round), tile-list layout, fscan and deposit kernels it keeps.
+// (_tsc_scatter, abacusnbody/analysis/tsc.py:394-507; _wrap_inplace :219-226; the half-cell-shifted second deposit of
+// get_interlaced_field_fft, abacusnbody/analysis/power_spectrum.py:951-998.)
+//
+// What was wrong with the second generation (profiles/r04, rocprofv3 + SQ counters): its coarse pass is bound by
+// vector-instruction issue - ~450 instructions per particle, half of them the per-particle loops over the 1 .. 8 tiles of a
+// cloud, run twice (count, place) by every lane of a wave as often as its busiest lane needs - and it stages one 16-byte
+// record per (particle, TILE): 1.35 records per particle written once and read twice.
+// Here the coarse level stops at the BLOCK (8 x 8 x 8 or 16 x 8 x 8 tiles, the coarse bucket):
+//   lines3_count    wraps the positions, counts (particle, block) records per chunk and block, and the tile entries each
+//                   block will hold (what sizes the entry lists);
+//   lines3_coarse   per particle and dimension ONE fixed-point coordinate S = floor(p 2^16) + 32767, p = (x + offset) n / L in
+//                   float32 as the reference evaluates it (tsc.py:419-421): S >> 16 is the nearest cell and ~S & 0xffff
+//                   the 16-bit code of the in-cell offset the tile entries carry (tsc_lines.hpp: exact wherever p >= 128
+//                   cells, rounded without bias below).  A record is the three coordinates relative to its block
+//                   (biased by two cells), one per block the cloud touches: 1.05 per particle;
+//   lines3_fcount / lines3_fine   decode a record with shifts, enumerate the tiles of the cloud INSIDE the block (integer
+//                   compares; a cloud's part in the neighbouring block is that block's record) and split by tile.
+// The half-cell-shifted deposit of an interlaced pair is the same record with 0x8000 added to every coordinate: built with
+// EXT (the 4-cell union of both clouds decides the blocks), one count + coarse pass serves both deposits; fcount / fine /
+// deposit run per origin (ORG).  Where p is exact the shifted coordinate p + 1/2 is what float32 (x + d/2) n/L gives; elsewhere
+// it differs from it by the reference's own rounding of that sum (<= 1 ulp of p).
+//
+// Entry format, tile lists, fscan and deposit: tsc_lines.hpp, unchanged.
+
+struct L3Dim {
+    int S;          // fixed-point coordinate + 32767 (cell = S >> 16)
+    int Blo;        // unwrapped block index of the cloud's lowest cell (offset by n cells: non-negative)
+    bool two;       // the cloud reaches into the next block
+    int nt;         // tiles the cloud touches in this dimension (1 or 2)
+};
+
+// coordinate of one dimension; `u` in (0, 1) decides the rounding of the bits a 2^-16 grid drops
+// ih16 = 65536 n / L: the power of two scales the float32 product (x + offset) n / L of tsc.py:419-421 exactly
+__device__ __forceinline__ int l3_S(float c, float offset, float ih16, int n, float u) {
+    float y = (c + offset) * ih16;
+    y = fminf(fmaxf(y, -131072.f), (float)(n + 2) * 65536.f);  // garbage positions (NaN, inf) stay inside the tables
+    const float fl = floorf(y);                                // exact
+    return (int)fl + ((y - fl) > u ? 1 : 0) + 32767;
+}
+
+template <bool EXT>
+__device__ __forceinline__ void l3_dim(int S, int n, int lgbc, int sh, L3Dim &d) {
+    const int i = S >> 16;                                     // [-2, n + 2]
+    const int lo = i - 1 + n, hi = i + (EXT ? 2 : 1) + n;      // cloud cells, offset by n (>= n - 3 > 0)
+    d.S = S;
+    d.Blo = lo >> lgbc;
+    d.two = d.Blo != (hi >> lgbc);
+    d.nt = 1 + ((lo >> sh) != (hi >> sh) ? 1 : 0);
+}
+__device__ __forceinline__ int l3_wrapB(int B, int nbk) {      // B <= 2 nbk
+    B -= B >= nbk ? nbk : 0;
+    B -= B >= nbk ? nbk : 0;
+    return B;
+}
+
+// ---- counting pass ---------------------------------------------------------------------------------------------
+// M[c][b] = records of chunk c in block b; ent[b] += tile entries of block b (EXT: of the 4-cell union cloud, a bound for both
+// origins).  Four particles per thread in flight (the second generation's one-particle loop ran at 2.7 TB/s: latency)
+template <int NB, bool EXT>
+__global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int64_t n, LGeom g, double box, float offA, int wrap,
+                                                    int64_t CH, unsigned int *__restrict__ M, unsigned int *__restrict__ ent,
+                                                    int *__restrict__ wrapped_flag) {
+    __shared__ unsigned int hrec[NB], hent[NB];
+    const int tid = threadIdx.x;
+    for (int b = tid; b < NB; b += 512) hrec[b] = 0u, hent[b] = 0u;
+    __syncthreads();
+    const float ih[3] = {(float)(g.n[0] / box) * 65536.f, (float)(g.n[1] / box) * 65536.f, (float)(g.n[2] / box) * 65536.f};
+    const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
+    const int lgbc[3] = {LN_SHX + g.sb[0], LN_SHY + g.sb[1], LN_SHZ + g.sb[2]};
+    const int bst[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};
+    const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
+    bool any_changed = false;
+    // positions in [0, boxlo] are inside the box whatever float32 makes of `box`: the float64 comparisons of _wrap_inplace
+    // (tsc.py:219-226) only for the others
+    const float boxlo = nextafterf((float)box, 0.f);
+    constexpr int U = 4;
+    for (int64_t pb = p0; pb < p1; pb += U * 512) {
+        LnF3 q[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int64_t p = pb + k * 512 + tid;
+            if (p < p1) q[k] = *reinterpret_cast<const LnF3 *>(pos + 3 * p);
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int64_t p = pb + k * 512 + tid;
+            if (p >= p1) continue;
+            if (wrap && !(fminf(fminf(q[k].x, q[k].y), q[k].z) >= 0.f && fmaxf(fmaxf(q[k].x, q[k].y), q[k].z) <= boxlo)) {
+                bool ch = false;
+                q[k].x = wrap1(q[k].x, box, ch), q[k].y = wrap1(q[k].y, box, ch), q[k].z = wrap1(q[k].z, box, ch);
+                if (ch) {
+                    *reinterpret_cast<LnF3 *>(pos + 3 * p) = q[k];
+                    any_changed = true;
+                }
+            }
+            const float c[3] = {q[k].x, q[k].y, q[k].z};
+            L3Dim d[3];
+            int b0 = 0, nper = 1;
+            unsigned int two = 0;
+            int db[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                // the cell alone: the rounding draw matters only when the dropped bits can carry into it (once in 65536)
+                float y = (c[a] + offA) * ih[a];
+                y = fminf(fmaxf(y, -131072.f), (float)(g.n[a] + 2) * 65536.f);
+                const float fl = floorf(y);
+                int S = (int)fl + 32767;
+                if ((S & 0xffff) == 0xffff && y > fl) {
+                    float u[3];
+                    ln_hash(c[0], c[1], c[2], u);
+                    S += (y - fl) > u[a] ? 1 : 0;
+                }
+                l3_dim<EXT>(S, g.n[a], lgbc[a], sh[a], d[a]);
+                const int B = l3_wrapB(d[a].Blo, g.nb[a]);
+                b0 += B * bst[a];
+                db[a] = ((B + 1 == g.nb[a] ? 0 : B + 1) - B) * bst[a];
+                two |= d[a].two ? 1u << a : 0u;
+                nper *= d[a].two ? 1 : d[a].nt;
+            }
+            unsigned int e = 0u;                                  // every subset of the dimensions that have a second block
+            do {
+                const int b = b0 + ((e & 1u) ? db[0] : 0) + ((e & 2u) ? db[1] : 0) + ((e & 4u) ? db[2] : 0);
+                atomicAdd(&hrec[b], 1u);
+                atomicAdd(&hent[b], (unsigned int)nper);
+                e = (e - two) & two;
+            } while (e);
+        }
+    }
+    if (any_changed) *wrapped_flag = 1;
+    __syncthreads();
+    for (int b = tid; b < g.nbuckets; b += 512) {
+        M[(int64_t)blockIdx.x * g.nbuckets + b] = hrec[b];
+        if (hent[b]) atomicAdd(&ent[b], hent[b]);
+    }
+}
+
+// ---- coarse scatter: one record per (particle, block) ----------------------------------------------------------------
+struct L3Item {
+    unsigned int w[3];   // the record of the first block in every dimension
+    unsigned int b0;     // its bucket; bit 31: no item
+    int db[3];           // bucket delta of the second block of a dimension
+    unsigned int two;    // bit a: dimension a has a second block
+};
+template <bool EXT>
+__device__ __forceinline__ void l3_item(float x, float y, float z, float offset, const float ih[3], const LGeom &g, const int lgbc[3],
+                                        const int bst[3], L3Item &it) {
+    const float c[3] = {x, y, z};
+    const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
+    float u[3];
+    ln_hash(x, y, z, u);
+    it.b0 = 0u, it.two = 0u;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        L3Dim d;
+        l3_dim<EXT>(l3_S(c[a], offset, ih[a], g.n[a], u[a]), g.n[a], lgbc[a], sh[a], d);
+        const int B = l3_wrapB(d.Blo, g.nb[a]);
+        it.b0 += (unsigned int)(B * bst[a]);
+        it.db[a] = ((B + 1 == g.nb[a] ? 0 : B + 1) - B) * bst[a];
+        it.two |= d.two ? 1u << a : 0u;
+        it.w[a] = (unsigned int)(d.S + ((g.n[a] + 2 - (d.Blo << lgbc[a])) << 16));   // (cell in block + 2) << 16 | low bits of S
+    }
+}
+
+template <int NB, int LINE, int SBUF, int NT, bool EXT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void lines3_coarse(const float *__restrict__ pos, int64_t n, LGeom g, double box,
+                                                                                           float offA, int64_t CH, const unsigned int *__restrict__ M,
+                                                                                           const unsigned int *__restrict__ gstart,
+                                                                                           uint4 *__restrict__ staged, unsigned long long *clk) {
+    __shared__ SplitLds<uint4, NB, LINE, SBUF, NT> s;
+    const int tid = threadIdx.x, nb = g.nbuckets;
+    split_init(s);
+    for (int b = tid; b < NB; b += NT) s.base[b] = b < nb ? gstart[b] + M[(int64_t)blockIdx.x * nb + b] : 0u;
+    __syncthreads();
+    const float ih[3] = {(float)(g.n[0] / box) * 65536.f, (float)(g.n[1] / box) * 65536.f, (float)(g.n[2] / box) * 65536.f};
+    const int lgbc[3] = {LN_SHX + g.sb[0], LN_SHY + g.sb[1], LN_SHZ + g.sb[2]};
+    const int bst[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};
+    const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
+    // a round's output is about its input (1.05 - 1.1 records per particle); a round that does not fit (clouds piled up on
+    // block corners: eight records per particle) is redone in G groups - see lines_coarse
+    constexpr int PMAX = SBUF * 3 / 4 / NT * NT;
+    constexpr int PPT = PMAX / NT;
+    constexpr int G = 64;
+    static_assert(PPT >= 1 && 8 * (PMAX / G) * LINE <= SBUF && (G & (G - 1)) == 0, "buffer too small");
+    int par = 0;
+    LnF3 q[PPT];
+    L3Item it[PPT];
+    auto load = [&](int64_t s0) {
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const int64_t p = s0 + k * NT + tid;
+            q[k] = LnF3{0.f, 0.f, 0.f};
+            if (p < p1) q[k] = *reinterpret_cast<const LnF3 *>(pos + 3 * p);
+        }
+    };
+    auto geometry = [&](int64_t s0) {          // (unconditional: an if / else over the items' fields left them in scratch memory)
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            l3_item<EXT>(q[k].x, q[k].y, q[k].z, offA, ih, g, lgbc, bst, it[k]);
+            const bool live = s0 + k * NT + tid < p1;
+            it[k].b0 |= live ? 0u : 0x80000000u;
+            it[k].two = live ? it[k].two : 0u;
+        }
+    };
+    // pipeline: the particles of round r + 2 are requested behind the stores of round r; their geometry is evaluated in round
+    // r + 1 BEFORE its write-out (split_round's `mid`: the items of round r + 1 are dead once they are placed), so the wait for
+    // them never covers stores younger than a round
+    load(p0);
+    geometry(p0);
+    load(p0 + PMAX);
+    for (int64_t s0 = p0; s0 < p1; s0 += PMAX) {
+        auto count = [&](int groups, int gi) {
+            return [&, groups, gi](auto f) {
+#pragma unroll
+                for (int k = 0; k < PPT; k++) {
+                    if ((it[k].b0 >> 31) || ((k * NT + tid) & (groups - 1)) != gi) continue;
+                    unsigned int e = 0u;
+                    do {
+                        f((int)it[k].b0 + ((e & 1u) ? it[k].db[0] : 0) + ((e & 2u) ? it[k].db[1] : 0) + ((e & 4u) ? it[k].db[2] : 0));
+                        e = (e - it[k].two) & it[k].two;
+                    } while (e);
+                }
+            };
+        };
+        auto place = [&](int groups, int gi) {
+            return [&, groups, gi](auto f) {
+#pragma unroll
+                for (int k = 0; k < PPT; k++) {
+                    if ((it[k].b0 >> 31) || ((k * NT + tid) & (groups - 1)) != gi) continue;
+                    unsigned int e = 0u;
+                    do {   // the second block of a dimension sees the cell one block further down
+                        f((int)it[k].b0 + ((e & 1u) ? it[k].db[0] : 0) + ((e & 2u) ? it[k].db[1] : 0) + ((e & 4u) ? it[k].db[2] : 0),
+                          make_uint4(it[k].w[0] - ((e & 1u) ? 1u << (16 + lgbc[0]) : 0u), it[k].w[1] - ((e & 2u) ? 1u << (16 + lgbc[1]) : 0u),
+                                     it[k].w[2] - ((e & 4u) ? 1u << (16 + lgbc[2]) : 0u), 0u));
+                        e = (e - it[k].two) & it[k].two;
+                    } while (e);
+                }
+            };
+        };
+        if (split_round<uint4, NB, LINE, SBUF, NT>(s, nb, par, 0, 0, staged, count(1, 0), place(1, 0), 0, clk, [&]() { geometry(s0 + PMAX); })) {
+            par ^= 1;
+        } else {
+            for (int gi = 0; gi < G; gi++) {
+                split_round<uint4, NB, LINE, SBUF, NT>(s, nb, par, 0, 0, staged, count(G, gi), place(G, gi));
+                par ^= 1;
+            }
+            geometry(s0 + PMAX);
+        }
+        load(s0 + 2 * PMAX);
+    }
+    split_drain<uint4, NB, LINE, SBUF, NT>(s, nb, par, staged);
+}
+
+// ---- fine level: a record -> the tiles of its cloud inside the block ---------------------------------------------------
+struct L3Rec {
+    unsigned int key0;    // tile of the first tile in every dimension (inside the block)
+    unsigned int h;       // bit a: dimension a has a second tile inside the block; bit 31: the cloud misses the block
+    unsigned int lo, hi;  // the entry of the first tile
+};
+template <int ORG>
+__device__ __forceinline__ void l3_decode(const uint4 &r, const LGeom &g, const int lgbc[3], L3Rec &o) {
+    const unsigned int w[3] = {r.x + (ORG ? 0x8000u : 0u), r.y + (ORG ? 0x8000u : 0u), r.z + (ORG ? 0x8000u : 0u)};
+    const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
+    const int ksh[3] = {g.sb[1] + g.sb[2], g.sb[2], 0};
+    unsigned int key = 0u, h = 0u, l = 0u;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int ir = (int)(w[a] >> 16) - 2, bc = 1 << lgbc[a];   // nearest cell relative to the block: [-2, bc + 1]
+        const int lo = max(ir - 1, 0), hi = min(ir + 1, bc - 1);
+        if (lo > hi) h |= 0x80000000u;                              // (only with EXT: the other origin's cloud alone reaches this block)
+        const int ta = lo >> sh[a], tb = hi >> sh[a];
+        key |= (unsigned int)ta << ksh[a];
+        h |= ta != tb ? 1u << a : 0u;
+        l |= (unsigned int)min(max(ir - (ta << sh[a]) + 1, 0), (1 << sh[a]) + 1) << (5 * a);   // nearest cell inside the first tile, biased by one
+    }
+    o.key0 = key, o.h = h;
+    o.lo = l | ((~w[0] & 0xffffu) << 16);
+    o.hi = (~w[1] & 0xffffu) | ((~w[2] & 0xffffu) << 16);
+}
+// tile key and entry of emission e (bit a: the second tile of dimension a)
+__device__ __forceinline__ void l3_emit(const L3Rec &o, int e, const LGeom &g, unsigned int &key, unsigned long long &entry) {
+    const unsigned int dk = ((e & 1) ? 1u << (g.sb[1] + g.sb[2]) : 0u) + ((e & 2) ? 1u << g.sb[2] : 0u) + ((e & 4) ? 1u : 0u);
+    const unsigned int dl = ((e & 1) ? (unsigned int)LN_TX : 0u) + ((e & 2) ? (unsigned int)LN_TY << 5 : 0u) + ((e & 4) ? (unsigned int)LN_TZ << 10 : 0u);
+    key = o.key0 + dk;
+    entry = ((unsigned long long)o.hi << 32) | (o.lo - dl);
+}
+
+template <int NBF, int ORG>
+__global__ __launch_bounds__(512) void lines3_fcount(const uint4 *__restrict__ staged, const LnPiece *__restrict__ pieces, LGeom g,
+                                                     unsigned int *__restrict__ C) {
+    __shared__ unsigned int hist[NBF];
+    const int tid = threadIdx.x, tpb = g.tpb;
+    const LnPiece pc = pieces[blockIdx.x];
+    const int lgbc[3] = {LN_SHX + g.sb[0], LN_SHY + g.sb[1], LN_SHZ + g.sb[2]};
+    for (int f = tid; f < NBF; f += 512) hist[f] = 0u;
+    __syncthreads();
+    constexpr int U = 4;
+    for (unsigned int e0 = pc.e0; e0 < pc.e1; e0 += U * 512) {
+        uint4 r[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (e0 + k * 512 + tid < pc.e1) r[k] = staged[e0 + k * 512 + tid];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            if (e0 + k * 512 + tid >= pc.e1) continue;
+            L3Rec o;
+            l3_decode<ORG>(r[k], g, lgbc, o);
+            if (o.h >> 31) continue;
+            unsigned int e = 0u;                                  // every subset of the dimensions that have a second tile
+            do {
+                const unsigned int key = o.key0 + ((e & 1u) ? 1u << (g.sb[1] + g.sb[2]) : 0u) + ((e & 2u) ? 1u << g.sb[2] : 0u) + ((e & 4u) ? 1u : 0u);
+                atomicAdd(&hist[min(key, (unsigned int)(NBF - 1))], 1u);
+                e = (e - o.h) & o.h;
+            } while (e);
+        }
+    }
+    __syncthreads();
+    for (int f = tid; f < tpb; f += 512) C[(int64_t)blockIdx.x * tpb + f] = hist[f];
+}
+
+template <int NBF, int LINE, int SBUF, int NT, int ORG>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void lines3_fine(const uint4 *__restrict__ staged, const LnPiece *__restrict__ pieces, LGeom g,
+                                                  const unsigned int *__restrict__ C, unsigned long long *__restrict__ entries,
+                                                  unsigned long long *clk) {
+    __shared__ SplitLds<unsigned long long, NBF, LINE, SBUF, NT> s;
+    const int tid = threadIdx.x, nb = g.tpb;
+    const LnPiece pc = pieces[blockIdx.x];
+    const int lgbc[3] = {LN_SHX + g.sb[0], LN_SHY + g.sb[1], LN_SHZ + g.sb[2]};
+    split_init(s);
+    for (int f = tid; f < NBF; f += NT) s.base[f] = f < nb ? C[(int64_t)blockIdx.x * nb + f] : 0u;
+    __syncthreads();
+    constexpr int PMAX = SBUF * 5 / 8 / NT * NT;          // 1.3 entries out per record in
+    constexpr int PPT = PMAX / NT;
+    constexpr int G = 64;                                 // see lines_coarse: 8 x LINE x PMAX / G <= SBUF always fits
+    static_assert(PPT >= 1 && 8 * (PMAX / G) * LINE <= SBUF && (G & (G - 1)) == 0, "buffer too small");
+    int par = 0;
+    uint4 nx[PPT];
+    L3Rec q[PPT];
+    auto load = [&](unsigned int s0) {
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const unsigned int e = s0 + k * NT + tid;
+            nx[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (e < pc.e1) nx[k] = staged[e];
+        }
+    };
+    if (pc.e0 >= pc.e1) return;
+    auto decode = [&](unsigned int s0) {
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            l3_decode<ORG>(nx[k], g, lgbc, q[k]);
+            q[k].h = s0 + k * NT + tid < pc.e1 ? q[k].h : 0x80000000u;
+        }
+    };
+    // the same pipeline as lines3_coarse: records of round r + 2 requested behind the stores of round r, decoded in round r + 1
+    // before its write-out
+    load(pc.e0);
+    decode(pc.e0);
+    load(pc.e0 + PMAX);
+    for (unsigned int s0 = pc.e0; s0 < pc.e1; s0 += PMAX) {
+        auto count = [&](int groups, int gi) {
+            return [&, groups, gi](auto f) {
+#pragma unroll
+                for (int k = 0; k < PPT; k++) {
+                    if ((q[k].h >> 31) || ((k * NT + tid) & (groups - 1)) != gi) continue;
+                    unsigned int e = 0u;
+                    do {
+                        unsigned int key;
+                        unsigned long long en;
+                        l3_emit(q[k], (int)e, g, key, en);
+                        f((int)min(key, (unsigned int)(NBF - 1)));
+                        e = (e - q[k].h) & q[k].h;
+                    } while (e);
+                }
+            };
+        };
+        auto place = [&](int groups, int gi) {
+            return [&, groups, gi](auto f) {
+#pragma unroll
+                for (int k = 0; k < PPT; k++) {
+                    if ((q[k].h >> 31) || ((k * NT + tid) & (groups - 1)) != gi) continue;
+                    unsigned int e = 0u;
+                    do {
+                        unsigned int key;
+                        unsigned long long en;
+                        l3_emit(q[k], (int)e, g, key, en);
+                        f((int)min(key, (unsigned int)(NBF - 1)), en);
+                        e = (e - q[k].h) & q[k].h;
+                    } while (e);
+                }
+            };
+        };
+        if (split_round<unsigned long long, NBF, LINE, SBUF, NT>(s, nb, par, 0, 0, entries, count(1, 0), place(1, 0), 0, clk, [&]() { decode(s0 + PMAX); })) {
+            par ^= 1;
+        } else {
+            for (int gi = 0; gi < G; gi++) {
+                split_round<unsigned long long, NBF, LINE, SBUF, NT>(s, nb, par, 0, 0, entries, count(G, gi), place(G, gi));
+                par ^= 1;
+            }
+            decode(s0 + PMAX);
+        }
+        load(s0 + 2 * PMAX);
+    }
+    split_drain<unsigned long long, NBF, LINE, SBUF, NT>(s, nb, par, entries);
+}

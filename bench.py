@@ -113,7 +113,7 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     # (the key index is built during it): the dominant kernel is picked from a few more, steady, untimed populates
     _lib.profile_reset()
     _lib.profile_enable(True)
-    for _ in range(5):
+    for _ in range(20):
         st.populate(p)
     st.wait_counts()
     _lib.profile_enable(False)
@@ -121,16 +121,16 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     cand = st.candidates()
 
     # timed region: HIP events only around the dominant kernel (a pair of event records per launch costs a few
-    # microseconds, which is not negligible against a 0.1-ms step); the other kernels' durations are the warm-up's
-    # At C2 the three kernels of the index path take 11 - 16 us each and trade places from run to run (launch-latency sized):
-    # "the dominant kernel" is the one that moves the most bytes among those that take at least half as long as the longest
-    # (picked by duration alone, noise made the line's roofline jump between 0.13 for hod_exact and 0.007 for hod_deal)
+    # microseconds, which is not negligible against a 0.1-ms step); the other kernels' durations are the warm-up's.
+    # The dominant kernel is the one that takes the LONGEST per step (duration x launches, from the 20 steady populates above);
+    # the pick by bytes among the near-equal kernels of the C2 index path (rounds 3 - 4) is reported beside it as `bytes_pick`
     bh0, bp0 = filter_bytes_per_object(tracers, enable_ranks)
     nc0 = float(cand[0] + cand[1])
     dom_bytes = {'hod_filter': bh0 * nh + bp0 * npart, 'hod_deal': 6.0 * nc0, 'hod_exact': 130.0 * nc0, 'hod_emit': 192.0 * ngal}
-    tmax = max((warm[k] * launches.get(k, 1.0) for k in warm if k in STEP), default=0.0)
-    dom_name = max((k for k in warm if k in STEP and warm[k] * launches.get(k, 1.0) >= 0.5 * tmax),
-                   key=lambda k: dom_bytes.get(k, 0.0), default=None)
+    per_step = {k: warm[k] * launches.get(k, 1.0) for k in warm if k in STEP}
+    tmax = max(per_step.values(), default=0.0)
+    dom_name = max(per_step, key=per_step.get, default=None)
+    bytes_pick = max((k for k in per_step if per_step[k] >= 0.5 * tmax), key=lambda k: dom_bytes.get(k, 0.0), default=None)
     _lib.profile_reset()
     _lib.profile_select(dom_name)
     _lib.profile_enable(True)
@@ -248,6 +248,9 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
                                'hod_emit': 'one 128-B packed record line gathered and 64 B of columns written per galaxy'}[dom_name] +
                                          '; keys, index, float32 shadows and packed records are built once per catalogue (`stage_ms`, outside the timed '
                                          'region), keys and index again after a reseed',
+                           'bytes_pick': None if bytes_pick is None else {
+                               'kernel': bytes_pick, 'frac': per_launch[bytes_pick] / (kern[bytes_pick] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               'note': 'the kernel moving the most bytes among those within 2x of the longest (rounds 3 - 4 quoted this one)'},
                            'whole_step_GBs': step_bytes / (dt / args.steps) / 1e9,
                            'whole_step_frac': step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
     st.free()

@@ -83,22 +83,24 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
     shot = L**3 / n
     M = float(nmesh) ** 3
     alg_bytes_total = 12.0 * n + 36.0 * M   # SURVEY.md 8d, non-interlaced
+    REC, ENT = (1 + 2 / 128) ** 2 * (1 + 2 / 256), (1 + 2 / 16) ** 2 * (1 + 2 / 32)   # 1.04 block records, 1.345 tile entries per particle
     alg = {
         'hipfft_r2c': 24.0 * M,            # three 1-D passes x (read + write) of the 4M-byte mesh/half-spectrum
         'fft_z_r2c': 8.0 * M, 'fft_cols_y': 8.0 * M, 'fft_cols_x': 8.0 * M,   # one pass each: read 4M + write 4M
         'gfft_rows': 8.0 * M, 'gfft_cols_y': 8.0 * M, 'gfft_cols_x': 8.0 * M,  # mixed-radix passes (csrc/gfft.hip): the same
         'fft_x_bin': 4.0 * M,              # last pass fused with the binning: one read of the half-spectrum, nothing written
         'gfft_x_bin': 4.0 * M,             # the same for the mixed-radix meshes (csrc/gfft.hip)
-        'tsc_tile_deposit': 4.0 * M + 8.0 * 1.25 * n,   # mesh written once + the 8-byte entries (1.25 per particle) read
+        'tsc_tile_deposit': 4.0 * M + 8.0 * ENT * n,    # mesh written once + the 8-byte tile entries read
         'spectrum_bin': 4.0 * M,
         'tsc_bin_count': 12.0 * n,
         'tsc_bin_fill': 12.0 * n + 16.0 * 1.3 * n,
-        # second-generation lists (csrc/tsc_lines.hpp): positions read twice, 16-byte staged (particle, tile) entries written
-        # once and read twice, 8-byte entries written once
+        # third-generation lists (csrc/tsc_lines3.hpp): positions read twice, 16-byte (particle, block) records written once and
+        # read twice, 8-byte (particle, tile) entries written once.  REC / ENT: records and entries per particle of a uniform
+        # catalogue with 16 x 16 x 32-cell tiles in blocks of 8 x 8 x 8 tiles
         'tsc_lines_count': 12.0 * n,
-        'tsc_lines_coarse': 12.0 * n + 16.0 * 1.25 * n,
-        'tsc_lines_fcount': 16.0 * 1.25 * n,
-        'tsc_lines_fine': 16.0 * 1.25 * n + 8.0 * 1.25 * n,
+        'tsc_lines_coarse': 12.0 * n + 16.0 * REC * n,
+        'tsc_lines_fcount': 16.0 * REC * n,
+        'tsc_lines_fine': 16.0 * REC * n + 8.0 * ENT * n,
     }
     dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
     ach = alg[dom] / (kern[dom] * 1e-3) / 1e9

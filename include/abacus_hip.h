@@ -208,6 +208,10 @@ int abacus_tsc_deposit(void *pos, int64_t n, const void *weights, int pos_dtype,
  * analysis/power_spectrum.py:842).  Enqueues on the library stream. */
 int abacus_tsc_deposit_dev(float *pos, int64_t n, const float *weights, float *grid, int gx, int gy, int gz,
                            double box, double offset, int wrap, int zero_grid, int cic);
+/* diagnostic (option tsc_lines_clk = 1): shader-clock ticks per phase of the list build's split rounds, summed over workgroups since
+ * the last call; out32[0..9] coarse pass (count, barrier, owner, barrier, owner + carries, barrier, place, barrier, write-out,
+ * geometry + loads), out32[16..24] fine pass.  Reads and clears. */
+int abacus_tsc_lines_clocks(unsigned long long *out32);
 /* replaces: cic_serial (analysis/cic.py:13-125): float64 math, float32 grid, no wrap */
 int abacus_cic_deposit(const void *pos, int64_t n, const void *weights, int pos_dtype, float *grid, int gx, int gy,
                        int gz, double box);

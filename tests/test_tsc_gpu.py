@@ -247,7 +247,7 @@ def _line_case(kind, shape, n, box, rng):
     if kind == 'slab':      # catalogue order: sorted along x (what a halo catalogue read slab by slab looks like)
         pos = (rng.random((n, 3), dtype='f4') * np.float32(box)).astype('f4')
         return pos[np.argsort(pos[:, 0], kind='stable')]
-    return ((rng.random((n, 3), dtype='f4') * 1.2 - 0.1) * np.float32(box)).astype('f4')   # some outside the box
+    return ((rng.random((n, 3), dtype='f4') * 1.2 - 0.1) * np.float32(box)).astype('f4')   # some outside the box ('uniform', 'wide')
 
 
 @pytest.mark.parametrize('kind,shape,n,offset', [('uniform', (512, 512, 512), 3_000_000, 0.0),
@@ -294,3 +294,61 @@ def test_line_lists_vs_first_generation_and_oracle(kind, shape, n, offset, optio
     tsc_parallel(pos.copy(), a64, box, offset=off)
     np.testing.assert_allclose(a64, a, rtol=3e-6, atol=3e-6 * scale)
     assert np.abs(a64 - b)[132:shape[0] - 3, 132:shape[1] - 3, 132:shape[2] - 3].max() <= 3e-7 * scale
+    # third generation (block records, csrc/tsc_lines3.hpp: the default) against the second (option tsc_lines_gen = 2): the
+    # same entries wherever the coordinates are exact, so with the order-independent integer tile sums the cells fed from
+    # p >= 128 alone are EQUAL; below, both round the dropped bits without bias, with different draws
+    options.set('tsc_acc64', 0)
+    options.set('tsc_lines_gen', 2)
+    g2, p4 = base.copy(), pos.copy()
+    tsc_parallel(p4, g2, box, offset=off)
+    np.testing.assert_array_equal(p4, p3)
+    np.testing.assert_allclose(g2, c, rtol=5e-5, atol=4e-6 * scale)
+    np.testing.assert_array_equal(a[132:shape[0] - 3, 132:shape[1] - 3, 132:shape[2] - 3], g2[132:shape[0] - 3, 132:shape[1] - 3, 132:shape[2] - 3])
+    np.testing.assert_allclose(a, g2, rtol=1e-4, atol=6e-6 * scale)      # two independent draws: sqrt(2) of either one's error
+
+
+@pytest.mark.parametrize('kind,nmesh,n', [('uniform', 512, 3_000_000), ('corners', 512, 2_200_000), ('uniform-cfg1', 512, 2_300_000),
+                                          ('wide', 768, 2_600_000)])
+def test_interlaced_pair_shares_one_block_record_build(kind, nmesh, n, options):
+    """an interlaced pair (analysis/power_spectrum.py:951-998: the second deposit at offset = half a cell) builds its block
+    records ONCE (csrc/tsc_lines3.hpp, EXT: the blocks of the 4-cell union of both clouds) and derives the shifted deposit's
+    tile entries from them by adding half a cell to the fixed-point coordinates.  The shifted mesh against the oracle's
+    _tsc_scatter at that offset and against the unshared build (option tsc_noshare: float32 (x + d/2) n/L evaluated per
+    particle), the spectrum against the oracle; the profiler must show ONE count / coarse pass and TWO fine passes"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power, get_field_fft
+    from abacusutils_amd.analysis.tsc import tsc_parallel
+    from oracle import oracle
+    rng = np.random.default_rng(777 + n)
+    box = 700.0
+    if kind.endswith('-cfg1'):
+        options.set('tsc_lines_cfg1', 1)
+        kind = kind[:-5]
+    pos = _line_case(kind, (nmesh,) * 3, n, box, rng)
+    kw = dict(kbins=24, mubins=3, paste='TSC', nmesh=nmesh, compensated=True, interlaced=True, poles=[0, 2, 4])
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    tab = calc_power(pos.copy(), box, **kw)
+    _lib.profile_enable(False)
+    prof = _lib.profile_get()
+    assert prof['tsc_lines_coarse'][1] == 1 and prof['tsc_lines_count'][1] == 1 and prof['tsc_lines_fine'][1] == 2, \
+        {k: v for k, v in prof.items() if k.startswith('tsc_')}
+    ref = oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw)
+    np.testing.assert_array_equal(np.asarray(tab['N_mode']), ref['N_mode'])
+    scale = np.abs(ref['power']).max()
+    np.testing.assert_allclose(np.asarray(tab['power']), ref['power'], rtol=1e-5, atol=1e-6 * scale)
+    np.testing.assert_allclose(np.asarray(tab['poles']), ref['poles'], rtol=1e-5, atol=2e-6 * scale)
+    # the interlaced spectrum itself, shared against unshared lists
+    a = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, True)
+    options.set('tsc_noshare', 1)
+    b = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, True)
+    options.set('tsc_noshare', 0)
+    assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
+    # and the shifted mesh alone against the oracle's deposit at that offset
+    off = 0.5 * box / nmesh
+    c = np.zeros((nmesh,) * 3, dtype='f4')
+    wrapped = pos.copy()
+    oracle.tsc_parallel(wrapped, c, box, nthread=4, offset=off)
+    d = np.zeros((nmesh,) * 3, dtype='f4')
+    tsc_parallel(pos.copy(), d, box, offset=off)          # unshared gen-3 build at the float32 offset
+    np.testing.assert_allclose(d, c, rtol=5e-5, atol=4e-6 * float(c.max()))
