@@ -410,10 +410,18 @@ __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int 
 struct GXArgs {
     int n, kzlen, lgG, ntile_c, ustride;
     int64_t S, ys;            // element stride along x, along y
-    float inv2;               // f32(1/M)^2
+    float inv2;               // f32(1/M)^2; interlaced pair: f32(0.5/M)^2
     const float *W;           // (n,) compensation window or nullptr
+    const C2<float> *data2;   // interlaced pair: the half-cell-shifted field after its rows and y passes
+    const float2 *phase;      // interlaced pair: exp(i pi q / n), q in [0, 2n)
 };
 
+// INTER: the interlaced pair of fields in one pass (the reference's default estimator, power_spectrum.py:951-998; what
+// AbacusHOD.compute_power runs on its default 550^3 mesh): both fields' tiles are transformed in LDS side by side and a mode is
+// binned as |(a + a' exp(i pi (i + j + k) / n)) f32(0.5 / M)|^2 with signed-folded i, j (shift_field_fft, :904-948; i = n/2
+// folds to -n/2) - what spectrum_bin<INTER> computes from two spectra in HBM, without the two x passes writing them and the
+// binning reading them back.
+template <bool INTER>
 __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__ data, GXArgs g, GPlan p, const C2<float> *__restrict__ twn,
                                                    BinArgs b, XDesc d) {
     typedef float T;
@@ -423,7 +431,8 @@ __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__
     const int Nk = b.Nk, Nmu = b.Nmu, nrow = Nk + 2, nbx = nrow * Nmu;
     C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
     C2<T> *lds = tw + n;
-    double *h_sum = reinterpret_cast<double *>(lds + (size_t)n * P);
+    C2<T> *lds2 = lds + (size_t)n * P;                                 // the shifted field's tile (INTER)
+    double *h_sum = reinterpret_cast<double *>(lds + (size_t)n * P * (INTER ? 2 : 1));
     double *h_m2 = h_sum + nbx, *h_m4 = h_m2 + nrow;
     unsigned int *lut = reinterpret_cast<unsigned int *>(h_m4 + nrow);
     int *Ul = reinterpret_cast<int *>(lut + d.ncell);
@@ -441,12 +450,13 @@ __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__
     const int sh = d.sh, nmu1 = Nmu - 1;
     const int64_t ntiles = (int64_t)n * g.ntile_c;
     constexpr int NPRE = MAXV / 2;
-    CPair<T> pre[NPRE];
+    CPair<T> pre[NPRE], pre2[INTER ? NPRE : 1];
     const int c = (tid & (C / 2 - 1)) * 2, row0 = tid >> (lgC - 1), dr = G_NT >> (lgC - 1);
     auto issue = [&](int64_t t) {
         const int64_t o = t / g.ntile_c;
         const int c0 = (int)(t - o * g.ntile_c) * C, nc = min(C, g.kzlen - c0);
-        const C2<T> *src = data + o * g.ys + c0 + (int64_t)row0 * g.S + c;
+        const int64_t off0 = o * g.ys + c0 + (int64_t)row0 * g.S + c;
+        const C2<T> *src = data + off0;
         const int64_t stride = (int64_t)dr * g.S;
         const int mode = c + 1 < nc ? 2 : c < nc ? 1 : 0;
 #pragma unroll
@@ -457,6 +467,18 @@ __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__
                 else if (mode == 1) pre[it].a = *src;
             }
             src += stride;
+        }
+        if (INTER) {
+            const C2<T> *src2 = g.data2 + off0;
+#pragma unroll
+            for (int it = 0; it < NPRE; it++) {
+                pre2[INTER ? it : 0] = CPair<T>{{(T)0, (T)0}, {(T)0, (T)0}};
+                if (row0 + it * dr < n) {
+                    if (mode == 2) pre2[INTER ? it : 0] = *reinterpret_cast<const CPair<T> *>(src2);
+                    else if (mode == 1) pre2[INTER ? it : 0].a = *src2;
+                }
+                src2 += stride;
+            }
         }
     };
     auto dead = [&](int64_t t) {     // the tile's first column already beyond the last edge for every kx
@@ -480,13 +502,17 @@ __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__
             C2<T> *l = lds + row0 * P + c;
 #pragma unroll
             for (int it = 0; it < NPRE; it++) {
-                if (row0 + it * dr < n) l[0] = pre[it].a, l[1] = pre[it].b;
+                if (row0 + it * dr < n) {
+                    l[0] = pre[it].a, l[1] = pre[it].b;
+                    if (INTER) l[(size_t)n * P] = pre2[INTER ? it : 0].a, l[(size_t)n * P + 1] = pre2[INTER ? it : 0].b;
+                }
                 l += dr * P;
             }
         }
         __syncthreads();
         if (tn < ntiles) issue(tn);
         g_transform<T, MAXV>(lds, g.lgG, P, p, tw, 1);       // ends on a workgroup barrier: the whole tile is transformed
+        if (INTER) g_transform<T, MAXV>(lds2, g.lgG, P, p, tw, 1);
         const int64_t o = t / g.ntile_c;
         const int j = (int)o, jj = j < n / 2 ? j : j - n, c0 = (int)(t - o * g.ntile_c) * C;
 #pragma unroll 1
@@ -506,14 +532,28 @@ __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__
             for (int s = 0; s < RUN; s++) {
                 const int i = i0 + s;
                 if (2 * i > n) break;
-                const C2<T> a = lds[i * P + cc];
+                C2<T> a = lds[i * P + cc];
+                if (INTER) {                                                               // a + a' exp(i pi m / n), m = ii + jj + k
+                    int m = (2 * i < n ? i : i - n) + jj + k;                              // (i = n/2 folds to -n/2, :940-942)
+                    m += m < 0 ? 2 * n : 0;
+                    const float2 ph = g.phase[m];
+                    const C2<T> a2 = lds2[i * P + cc];
+                    a = {a.x + (a2.x * ph.x - a2.y * ph.y), a.y + (a2.x * ph.y + a2.y * ph.x)};
+                }
                 float pw = a.x * a.x + a.y * a.y;                                          // get_raw_power (:726)
                 if (comp) {                                                                // (:1065-1069)
                     const float sA = __builtin_amdgcn_rcpf(Wl[i] * wjk);
                     pw *= sA * sA;
                 }
                 if (i > 0 && 2 * i < n) {                                                  // the mode -i: same |k|, same mu
-                    const C2<T> bq = lds[(n - i) * P + cc];
+                    C2<T> bq = lds[(n - i) * P + cc];
+                    if (INTER) {
+                        int m = -i + jj + k;
+                        m += m < 0 ? 2 * n : 0;
+                        const float2 ph = g.phase[m];
+                        const C2<T> b2 = lds2[(n - i) * P + cc];
+                        bq = {bq.x + (b2.x * ph.x - b2.y * ph.y), bq.y + (b2.x * ph.y + b2.y * ph.x)};
+                    }
                     float pb = bq.x * bq.x + bq.y * bq.y;
                     if (comp) {
                         const float sB = __builtin_amdgcn_rcpf(Wl[n - i] * wjk);
@@ -685,14 +725,14 @@ int r2c_inplace(T *mesh, int n, int pitch_r, float xcut = 0.f, bool skip_x = fal
 }
 
 // LDS of gfft_x_bin beside the cell table, and the column-tile width it leaves room for (lgG: C = 4 << lgG; -1: none)
-size_t gxbin_lds_other(int n, int C, int Nk, int Nmu, bool comp) {
-    return ((size_t)n + (size_t)n * (C + 1)) * 8 + (size_t)(Nk + 2) * Nmu * 8 + (size_t)2 * (Nk + 2) * 8 +
+size_t gxbin_lds_other(int n, int C, int Nk, int Nmu, bool comp, bool inter = false) {
+    return ((size_t)n + (size_t)n * (C + 1) * (inter ? 2 : 1)) * 8 + (size_t)(Nk + 2) * Nmu * 8 + (size_t)2 * (Nk + 2) * 8 +
            (size_t)(n / 2 + 1) * std::max(Nmu - 1, 1) * 4 + (comp ? (size_t)n * 4 : 0) + 16;
 }
-int gxbin_lgG(int n, int Nk, int Nmu, bool comp) {
+int gxbin_lgG(int n, int Nk, int Nmu, bool comp, bool inter = false) {
     for (int lgG = 2; lgG >= 1; lgG--) {     // 16 or 8 columns: 4 would read 32-byte row segments (0.4 of the 64-byte rate)
         const int C = 4 << lgG;
-        if ((int64_t)C * n <= (int64_t)maxv<float>() * G_NT && gxbin_lds_other(n, C, Nk, Nmu, comp) + 6 * 1024 <= 160 * 1024) return lgG;
+        if ((int64_t)C * n <= (int64_t)maxv<float>() * G_NT && gxbin_lds_other(n, C, Nk, Nmu, comp, inter) + 6 * 1024 <= 160 * 1024) return lgG;
     }
     return -1;
 }
@@ -731,13 +771,13 @@ int gfft_r2c_inplace_f64(double *mesh, int n, int pitch_r) { return r2c_inplace<
 int gfft_r2c_zy_f32(float *mesh, int n, int pitch_r) { return r2c_inplace<float>(mesh, n, pitch_r, 0.f, true); }
 
 // can the fused last pass serve this mesh / histogram?  (builds the geometry descriptor of (n, edges) on first use)
-bool gfft_xbin_supported(int n, const BinArgs &b, bool comp) {
+bool gfft_xbin_supported(int n, const BinArgs &b, bool comp, bool inter) {
     if (!gxbin_shape_ok(n, b)) return false;
-    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp);
+    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp, inter);
     if (lgG < 0) return false;
     XDesc d;
     int ok = 0;
-    if (xdesc_lookup(n, b, comp, gxbin_lds_other(n, 4 << lgG, b.Nk, b.Nmu, comp), &d.lut, &d.U, &d.ncell, &d.sh, &d.off, &d.vtop, &d.cnt, &d.ksum,
+    if (xdesc_lookup(n, b, comp, gxbin_lds_other(n, 4 << lgG, b.Nk, b.Nmu, comp, inter), &d.lut, &d.U, &d.ncell, &d.sh, &d.off, &d.vtop, &d.cnt, &d.ksum,
                      &ok) != 0)
         return false;
     return ok != 0;
@@ -745,13 +785,14 @@ bool gfft_xbin_supported(int n, const BinArgs &b, bool comp) {
 
 // `mesh` holds the transform after gfft_r2c_zy_f32; bins |delta_k|^2 of every mode into the accumulators of `b` (zeroed by the
 // caller), N_mode and sum |k| from the cached descriptor
-int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b) {
-    const bool comp = W_dev != nullptr;
+int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, const float *mesh2,
+                   const void *phase) {
+    const bool comp = W_dev != nullptr, inter = mesh2 != nullptr;
     if (!gxbin_shape_ok(n, b)) return fail("gfft_x_bin: unsupported mesh / histogram");
-    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp);
+    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp, inter);
     if (lgG < 0) return fail("gfft_x_bin: histogram does not fit beside a tile of %d rows", n);
     const int C = 4 << lgG, pitch_c = pitch_r / 2, kzlen = n / 2 + 1;
-    const size_t other = gxbin_lds_other(n, C, b.Nk, b.Nmu, comp);
+    const size_t other = gxbin_lds_other(n, C, b.Nk, b.Nmu, comp, inter);
     XDesc d;
     int ok = 0;
     ABACUS_TRY(xdesc_lookup(n, b, comp, other, &d.lut, &d.U, &d.ncell, &d.sh, &d.off, &d.vtop, &d.cnt, &d.ksum, &ok));
@@ -763,16 +804,21 @@ int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const 
     ABACUS_TRY(tables<float>().get(n, &twn));
     GXArgs g;
     g.n = n, g.kzlen = kzlen, g.lgG = lgG, g.ntile_c = (kzlen + C - 1) / C, g.ustride = std::max(b.Nmu - 1, 1);
-    g.S = (int64_t)n * pitch_c, g.ys = pitch_c, g.inv2 = inv_size * inv_size, g.W = W_dev;
+    g.S = (int64_t)n * pitch_c, g.ys = pitch_c, g.W = W_dev;
+    g.data2 = reinterpret_cast<const C2<float> *>(mesh2), g.phase = static_cast<const float2 *>(phase);
+    const float hs = inter ? (float)(0.5 * (double)inv_size) : inv_size;      // f32(0.5 / M) (:993-997) or f32(1 / M) (:1058-1060)
+    g.inv2 = hs * hs;
     if (g.ntile_c * C > pitch_c) return fail("gfft_x_bin: row pitch too small");
     const size_t lds = other + (size_t)d.ncell * 4;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gfft_x_bin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
+    static size_t lds_set[2] = {0, 0};
+    if (lds > lds_set[inter]) {
+        HIP_TRY(hipFuncSetAttribute(inter ? reinterpret_cast<const void *>(gfft_x_bin<true>) : reinterpret_cast<const void *>(gfft_x_bin<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[inter] = lds;
     }
     const unsigned int grid = (unsigned int)std::min<int64_t>((int64_t)n * g.ntile_c, (int64_t)num_cus_g() * (lds > 80 * 1024 ? 1 : 2));
-    ABACUS_LAUNCH("gfft_x_bin", gfft_x_bin, dim3(grid), dim3(G_NT), lds, reinterpret_cast<const C2<float> *>(mesh), g, pn, twn, b, d);
+    if (inter) ABACUS_LAUNCH("gfft_x_bin", gfft_x_bin<true>, dim3(grid), dim3(G_NT), lds, reinterpret_cast<const C2<float> *>(mesh), g, pn, twn, b, d);
+    else ABACUS_LAUNCH("gfft_x_bin", gfft_x_bin<false>, dim3(grid), dim3(G_NT), lds, reinterpret_cast<const C2<float> *>(mesh), g, pn, twn, b, d);
     return 0;
 }
 int gfft_release() {

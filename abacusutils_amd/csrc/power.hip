@@ -38,9 +38,11 @@ using namespace abacus;
 
 namespace abacus {
 int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
-                    double offset, int wrap, double norm, int cic, int list_mode = 0, double sub = 1.0);
+                    double offset, int wrap, double norm, int cic, int list_mode = 0, double sub = 1.0, int zero_grid = 1);
 void tsc_wrapped_reset();
 int tsc_wrapped_seen();
+void tsc_lines_defer(int on);
+int tsc_lines_deferred_check();
 int tsc_deposit_f64mesh(void *pos, int pos_f64, int64_t n, const void *w, double *grid, int nmesh, int64_t zstride, double box,
                         double offset, int wrap, double norm, int cic, double sub);
 bool gfft_supported(int n, int is_double);
@@ -66,8 +68,9 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
 bool xbin2_supported(int n, const BinArgs &b, bool comp);
 bool gfft_supported(int n, int is_double);
 int gfft_r2c_zy_f32(float *mesh, int n, int pitch_r);
-bool gfft_xbin_supported(int n, const BinArgs &b, bool comp);
-int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b);
+bool gfft_xbin_supported(int n, const BinArgs &b, bool comp, bool inter = false);
+int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, const float *mesh2 = nullptr,
+                   const void *phase = nullptr);
 int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int h, int64_t xsep, int xg0, int p0, int pc, float *pack_out,
                              int world);
 int fft_native_fused_x_slab(float *mesh, int n, int pitch_r, int64_t ny_local);
@@ -693,6 +696,29 @@ struct PowerCtx {
 };
 PowerCtx g_ctx;
 
+// Positions a host entry point has NOT uploaded yet: field_fft_dev uploads them itself - in batches on a copy stream, each
+// batch deposited (accumulating into the mesh) while the next is on the PCIe link - when the mesh is small enough for its
+// read-modify-write per batch to hide behind a batch's upload (BASELINE config 3: 1.2 GB at 56 GB/s = 21 ms of upload in front
+// of 10 ms of kernels; the reference's calc_power takes NumPy positions, analysis/power_spectrum.py:1131)
+struct HostSrc {
+    const void *host = nullptr;
+    float *dev = nullptr;
+    int64_t n = 0;
+    bool pending = false;
+};
+HostSrc g_hsrc[2];
+hipStream_t g_copy_stream = nullptr;
+hipEvent_t g_copy_ev[2] = {nullptr, nullptr};
+double g_last_batches = 0;   // diagnostic: batches of the last host upload (abacus_power_last_batches)
+
+int upload_batches(int64_t n, int nmesh) {
+    if (option("pk_nobatch")) return 1;
+    const double t_up = 12.0 * (double)n / 56e9, t_rmw = 8.0 * 4.0 * (double)nmesh * nmesh * nmesh / 4.5e12;
+    const int K = (int)std::floor(0.8 * t_up / std::max(t_rmw, 1e-9));
+    // batches of at least 8e6 particles: the list build of a batch must keep its two levels
+    return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)K, (int64_t)8, n / 8000000}));
+}
+
 int fft_check(hipfftResult r, const char *what) {
     if (r != HIPFFT_SUCCESS) return fail("%s failed (hipfftResult %d)", what, (int)r);
     return 0;
@@ -767,12 +793,47 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
     const double M = (double)nmesh * nmesh * nmesh;
     const double norm = (double)(float)(M / (double)n);   // dtype(field.size / tot_weight), tot_weight = len(pos) (:856,894)
     const double d = L / nmesh;
+    // positions still on the host (power_from_host): upload here, batch by batch where that pays
+    HostSrc *hs = nullptr;
+    for (HostSrc &h : g_hsrc)
+        if (h.pending && h.dev == pos && h.n == n) hs = &h;
+    bool deposited = false;
+    if (hs) {
+        hs->pending = false;
+        const int K = (paste == 0 && !w && !pf64 && nmesh % 32 == 0 && nmesh >= 256) ? upload_batches(n, nmesh) : 1;
+        g_last_batches = K;
+        if (K == 1) {
+            HIP_TRY(hipMemcpyAsync(pos, hs->host, (size_t)n * 12, hipMemcpyHostToDevice, stream()));
+        } else {
+            if (!g_copy_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
+                for (hipEvent_t &e : g_copy_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            for (int s = 0; s < (interlaced ? 2 : 1); s++) ABACUS_TRY(dest[s].reserve(mesh_bytes(nmesh)));
+            const int64_t nb = (n + K - 1) / K;
+            for (int b = 0; b < K; b++) {
+                const int64_t p0 = (int64_t)b * nb, pn = std::min<int64_t>(nb, n - p0);
+                if (pn <= 0) break;
+                const bool last = p0 + pn >= n;
+                // (a copy from pageable memory keeps this thread busy for its duration; the kernels of the batch before run meanwhile)
+                HIP_TRY(hipMemcpyAsync(pos + 3 * p0, static_cast<const float *>(hs->host) + 3 * p0, (size_t)pn * 12, hipMemcpyHostToDevice, g_copy_stream));
+                HIP_TRY(hipEventRecord(g_copy_ev[b & 1], g_copy_stream));
+                HIP_TRY(hipStreamWaitEvent(stream(), g_copy_ev[b & 1], 0));
+                // rho accumulates raw over the batches; the last flush applies rho * norm - 1 (deposit kernels: norm 0 = none)
+                for (int s = 0; s < (interlaced ? 2 : 1); s++)
+                    ABACUS_TRY(tsc_deposit_f32(pos + 3 * p0, pn, nullptr, dest[s].as<float>(), nmesh, zstride, L, s == 0 ? 0.0 : 0.5 * d, 1, last ? norm : 0.0,
+                                               0, interlaced ? (s == 0 ? 1 : 2) : 0, 1.0, b == 0 ? 1 : 0));
+            }
+            deposited = true;
+        }
+    }
     for (int s = 0; s < (interlaced ? 2 : 1); s++) {
         ABACUS_TRY(dest[s].reserve(mesh_bytes(nmesh)));
         float *mesh = dest[s].as<float>();
         // tsc_parallel wraps pos in place on the first call (tsc.py:171-173); the shifted deposit sees wrapped pos
         // interlaced: the lists of the first deposit are built to cover the half-cell-shifted one as well
-        if (pf64)
+        if (deposited) {
+        } else if (pf64)
             ABACUS_TRY(tsc_deposit_f64pos(reinterpret_cast<double *>(pos), n, reinterpret_cast<const double *>(w), mesh, nmesh,
                                           zstride, L, s == 0 ? 0.0 : 0.5 * d, paste == 0, norm, paste));
         else
@@ -1045,10 +1106,38 @@ int check_common(int nmesh, int paste) {
     return 0;
 }
 
+int power_dev_once(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, const float *w2, double Lbox, int nmesh,
+                   int paste, const float *W_host, int interlaced, const double *kedges, int Nk, const double *muedges,
+                   int Nmu, const int64_t *poles, int Np, float *power, int64_t *N_mode, float *binned_poles,
+                   int64_t *N_mode_poles, float *k_avg, int pf64);
+
+// The deposits of a spectrum run their list builds in deferred mode (tsc.hip): buffers sized from the previous build of the
+// same mesh, tables made on the device, no synchronise inside the deposit.  Every path below ends with the read-back of the
+// binned sums - a stream synchronise -, after which the builds' own needs are known: if one did not fit (a catalogue far more
+// clustered than the last one), the spectrum is computed again with exact sizes.
 int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, const float *w2, double Lbox, int nmesh,
               int paste, const float *W_host, int interlaced, const double *kedges, int Nk, const double *muedges,
               int Nmu, const int64_t *poles, int Np, float *power, int64_t *N_mode, float *binned_poles,
               int64_t *N_mode_poles, float *k_avg, int pf64 = 0) {
+    tsc_lines_defer(1);
+    int rc = power_dev_once(pos, n, w, pos2, n2, w2, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu, poles, Np, power, N_mode,
+                            binned_poles, N_mode_poles, k_avg, pf64);
+    tsc_lines_defer(0);
+    if (rc != 0) {
+        (void)hipStreamSynchronize(stream());
+        (void)tsc_lines_deferred_check();
+        return rc;
+    }
+    if (tsc_lines_deferred_check())
+        rc = power_dev_once(pos, n, w, pos2, n2, w2, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu, poles, Np, power, N_mode,
+                            binned_poles, N_mode_poles, k_avg, pf64);
+    return rc;
+}
+
+int power_dev_once(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, const float *w2, double Lbox, int nmesh,
+                   int paste, const float *W_host, int interlaced, const double *kedges, int Nk, const double *muedges,
+                   int Nmu, const int64_t *poles, int Np, float *power, int64_t *N_mode, float *binned_poles,
+                   int64_t *N_mode_poles, float *k_avg, int pf64) {
     ABACUS_TRY(check_common(nmesh, paste));
     ABACUS_TRY(ensure_phase(nmesh));
     const float *W_dev;
@@ -1078,15 +1167,18 @@ int power_dev(float *pos, int64_t n, const float *w, float *pos2, int64_t n2, co
                                 2.0 * M_PI / Lbox, 0);
         }
     }
-    if (!fused && !interlaced && !cross && !option("pk_noxbin") && !option("fft_hipfft") && !fft_native_pow2(nmesh) && gfft_supported(nmesh, 0)) {
-        // mixed-radix meshes (compute_power's default 550, 768 ...): the same fusion on gfft's natural-order x pass (gfft.hip)
+    if (!fused && !cross && !option("pk_noxbin") && !(interlaced && option("pk_noxbin_inter")) && !option("fft_hipfft") && !fft_native_pow2(nmesh) &&
+        gfft_supported(nmesh, 0)) {
+        // mixed-radix meshes (compute_power's default 550, 768 ...): the same fusion on gfft's natural-order x pass (gfft.hip);
+        // an interlaced pair where two tiles fit the LDS (n up to ~900)
         BinArgs b;
         size_t acc_bytes = 0;
         ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
-        if (gfft_xbin_supported(nmesh, b, W_dev != nullptr)) {
-            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 0, 0, false, /*skip_x=*/true, nullptr, pf64, 0.f));
+        if (gfft_xbin_supported(nmesh, b, W_dev != nullptr, interlaced != 0)) {
+            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, interlaced, 0, false, /*skip_x=*/true, nullptr, pf64, 0.f));
             const double M = (double)nmesh * nmesh * nmesh;
-            ABACUS_TRY(gfft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b));
+            ABACUS_TRY(gfft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b,
+                                      interlaced ? g_ctx.mesh[1].as<float>() : nullptr, g_ctx.phase.as<float2>()));
             return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
                                 2.0 * M_PI / Lbox, 0);
         }
@@ -1118,10 +1210,15 @@ __global__ void pack_pos_soa64(const double *__restrict__ x, const double *__res
 }
 
 // upload a host particle set into the context buffers; wrapped positions are copied back like the reference mutates them
-int stage_particles(float *pos, int64_t n, const float *w, DevBuf &dpos, DevBuf &dw, float **pd, float **wd, size_t es = 4) {
+int stage_particles(float *pos, int64_t n, const float *w, DevBuf &dpos, DevBuf &dw, float **pd, float **wd, size_t es = 4, HostSrc *later = nullptr) {
     // es: bytes per value (4 float32, 8 float64 - the pointers are then float64 arrays in disguise)
     ABACUS_TRY(dpos.reserve((size_t)std::max<int64_t>(n, 1) * 3 * es));
-    HIP_TRY(hipMemcpyAsync(dpos.p, pos, (size_t)n * 3 * es, hipMemcpyHostToDevice, stream()));
+    if (later && es == 4 && !w) {      // field_fft_dev uploads (in batches, behind the deposits) - see HostSrc
+        later->host = pos, later->dev = dpos.as<float>(), later->n = n, later->pending = true;
+    } else {
+        if (later) later->pending = false;
+        HIP_TRY(hipMemcpyAsync(dpos.p, pos, (size_t)n * 3 * es, hipMemcpyHostToDevice, stream()));
+    }
     *pd = dpos.as<float>();
     *wd = nullptr;
     if (w) {
@@ -1206,11 +1303,13 @@ static int power_from_host(void *pos, int64_t n, const void *w, void *pos2, int6
                            float *binned_poles, int64_t *N_mode_poles, float *k_avg) {
     const size_t es = pf64 ? 8 : 4;
     float *pd, *wd, *pd2 = nullptr, *wd2 = nullptr;
-    ABACUS_TRY(stage_particles((float *)pos, n, (const float *)w, g_ctx.pos, g_ctx.w, &pd, &wd, es));
-    if (pos2) ABACUS_TRY(stage_particles((float *)pos2, n2, (const float *)w2, g_ctx.pos2, g_ctx.w2, &pd2, &wd2, es));
+    ABACUS_TRY(stage_particles((float *)pos, n, (const float *)w, g_ctx.pos, g_ctx.w, &pd, &wd, es, &g_hsrc[0]));
+    if (pos2) ABACUS_TRY(stage_particles((float *)pos2, n2, (const float *)w2, g_ctx.pos2, g_ctx.w2, &pd2, &wd2, es, &g_hsrc[1]));
     tsc_wrapped_reset();
-    ABACUS_TRY(power_dev(pd, n, wd, pd2, n2, wd2, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu,
-                         poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, pf64));
+    const int rc = power_dev(pd, n, wd, pd2, n2, wd2, Lbox, nmesh, paste, W_host, interlaced, kedges, Nk, muedges, Nmu,
+                             poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, pf64);
+    g_hsrc[0].pending = g_hsrc[1].pending = false;
+    ABACUS_TRY(rc);
     // TSC wraps the caller's positions in place (tsc.py:171-173); CIC does not wrap (cic.py).  Nothing to copy back when
     // every position already lay inside the box
     if (paste == 0 && tsc_wrapped_seen()) {
@@ -1662,6 +1761,7 @@ int abacus_expand_poles_to_3d(const double *k_ell, const double *P_ell, int nk, 
 }
 
 double abacus_power_geometry_ms(void) { return xbin_last_build_ms(); }
+double abacus_power_last_batches(void) { return g_last_batches; }
 int abacus_power_xbin_generation(void) { return xbin_last_gen(); }
 
 int abacus_power_release(void) {

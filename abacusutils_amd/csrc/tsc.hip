@@ -420,6 +420,11 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_coarse(PT *__restrict__ pos, int6
             x = wrap1(x, box, ch);
             y = wrap1(y, box, ch);
             z = wrap1(z, box, ch);
+            if (ext) {   // lists shared with the second deposit of an interlaced pair: the reference wraps again before it
+                x = wrap1(x, box, ch);
+                y = wrap1(y, box, ch);
+                z = wrap1(z, box, ch);
+            }
             if (ch) {
                 pos[3 * p] = x;
                 pos[3 * p + 1] = y;
@@ -1126,6 +1131,34 @@ struct Lines3State {
 };
 Lines3State g_l3;
 
+// Deferred mode (tsc_lines_defer(1), set by the P(k) pipeline around its deposits): a build whose mesh matches the last EXACT
+// build sizes its buffers from that build's records / entries per particle and makes its tables on the device
+// (lines3_tables) - no stream synchronise between the counting and the scattering pass.  What the build needed comes back
+// asynchronously into page-locked memory; the pipeline reads it after its own final synchronise
+// (tsc_lines_deferred_check) and, should the buffers have been too small, runs again with deferred mode off.
+struct L3Caps {
+    bool valid = false;
+    int gx = 0, gy = 0, gz = 0, cfg = 0, ext = 0;
+    double rec_pp = 0, ent_pp = 0;
+};
+L3Caps g_l3_caps;
+bool g_l3_defer = false;
+unsigned int *g_l3_pend = nullptr;   // page-locked: 32 slots of 8 words
+int g_l3_npend = 0;
+
+void lines_defer_set(int on) { g_l3_defer = on != 0; }
+// after a stream synchronise: 1 if a deferred build of this pipeline did not fit its buffers (its mesh is garbage)
+int lines_deferred_check() {
+    int over = 0;
+    for (int i = 0; i < g_l3_npend; i++) {
+        g_wrapped_seen |= (int)g_l3_pend[8 * i + 4];
+        over |= g_l3_pend[8 * i + 3] ? 1 : 0;
+    }
+    g_l3_npend = 0;
+    if (over) g_l3_caps.valid = false, g_l3.valid = false;
+    return over;
+}
+
 // count + coarse: the staged block records of `pos` at mesh offset `offset` (ext: blocks of the 4-cell union of the clouds at
 // `offset` and `offset` + half a cell).  Returns 1 when 32-bit indices do not hold the lists (caller falls back).
 static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double box, double offset, int wrap, int ext, int *wrapped_out) {
@@ -1152,6 +1185,56 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
     }
 #undef L3_COUNT
     ABACUS_LAUNCH("tsc_lines_colscan", lines_colscan, dim3(nb), dim3(1024), 0, M, nchunk, nb, tot);
+    const int64_t PIECE = option("tsc_piece") > 0 ? (int64_t)option("tsc_piece") * 1024 : 64 * (int64_t)g.tpb;
+#define L3_COARSE(NBK, LINE_, SBUF_, NT_, EXT_, GSTART, NEED)                                                                        \
+    ABACUS_LAUNCH("tsc_lines_coarse", (lines3_coarse<NBK, LINE_, SBUF_, NT_, EXT_>), dim3(nchunk), dim3(NT_), 0, (const float *)pos, n, g, box, \
+                  offA, CH, (const unsigned int *)M, GSTART, g_lw.staged.as<uint4>(), lines_clk(0), NEED)
+#define L3_COARSE_ALL(GSTART, NEED)                                  \
+    do {                                                             \
+        if (cfg == 0) {                                              \
+            if (ext) L3_COARSE(256, 8, 2560, 512, true, GSTART, NEED);     \
+            else L3_COARSE(256, 8, 2560, 512, false, GSTART, NEED);        \
+        } else {                                                     \
+            if (ext) L3_COARSE(1024, 4, 3328, 1024, true, GSTART, NEED);   \
+            else L3_COARSE(1024, 4, 3328, 1024, false, GSTART, NEED);      \
+        }                                                            \
+    } while (0)
+    auto remember = [&](int np_, int64_t fs_, size_t o_f_, size_t o_pf_, size_t o_p_) {
+        g_l3.pos = pos, g_l3.n = n, g_l3.fs = fs_, g_l3.cfg = cfg, g_l3.np = np_, g_l3.ext = ext;
+        g_l3.box = box, g_l3.offset = offset, g_l3.g = g;
+        g_l3.gx = g.n[0], g_l3.gy = g.n[1], g_l3.gz = g.n[2], g_l3.zstride = g.zstride;
+        g_l3.o_f = o_f_, g_l3.o_pf = o_pf_, g_l3.o_p = o_p_;
+        g_l3.valid = true;
+    };
+    // ---- deferred: sizes from the last exact build of this mesh, tables on the device, no synchronise
+    const L3Caps &cp = g_l3_caps;
+    if (g_l3_defer && cp.valid && cp.gx == g.n[0] && cp.gy == g.n[1] && cp.gz == g.n[2] && cp.cfg == cfg && cp.ext == ext && g_l3_npend < 32 &&
+        option("tsc_lines_sync") != 1 && nb <= 1024) {
+        // (diagnostic: tsc_lines_sync = 2 sizes the record buffer for a twentieth of the particles - the overflow path of the tests)
+        const double shrink = option("tsc_lines_sync") == 2 ? 0.05 : 1.03;
+        const int64_t gs_cap = ((int64_t)((double)n * cp.rec_pp * shrink) + 16 * (int64_t)nb + 65536) & ~(int64_t)15;
+        const int64_t fs_cap = ((int64_t)((double)n * cp.ent_pp * 1.03) + (15 * (int64_t)g.tpb + 16) * nb + 65536) & ~(int64_t)15;
+        const int64_t np_cap64 = gs_cap / PIECE + nb + 1;
+        if (gs_cap < 0xfff00000ll && fs_cap < 0xfff00000ll && np_cap64 < (1 << 24)) {
+            const int np_cap = (int)np_cap64;
+            const size_t o_g = 0, o_f = o_g + (size_t)(nb + 1) * 4, o_pf = o_f + (size_t)(nb + 1) * 4, o_p = (o_pf + (size_t)(nb + 1) * 4 + 15) & ~(size_t)15,
+                         o_n = o_p + (size_t)np_cap * sizeof(LnPiece), tbytes = o_n + 32;
+            ABACUS_TRY(g_lw.tables.reserve(tbytes));
+            ABACUS_TRY(g_lw.staged.reserve((size_t)gs_cap * sizeof(uint4)));
+            if (!g_l3_pend) HIP_TRY(hipHostMalloc((void **)&g_l3_pend, 32 * 8 * sizeof(unsigned int), hipHostMallocDefault));
+            char *tb = g_lw.tables.as<char>();
+            unsigned int *d_need = reinterpret_cast<unsigned int *>(tb + o_n);
+            ABACUS_LAUNCH("tsc_lines_tables", lines3_tables, dim3(1), dim3(1024), 0, (const unsigned int *)tot, (const unsigned int *)ent, (const int *)flag, nb, g.tpb,
+                          (unsigned int)PIECE, (unsigned long long)gs_cap, (unsigned long long)fs_cap, np_cap, reinterpret_cast<unsigned int *>(tb + o_g),
+                          reinterpret_cast<unsigned int *>(tb + o_f), reinterpret_cast<int *>(tb + o_pf), reinterpret_cast<LnPiece *>(tb + o_p), d_need);
+            HIP_TRY(hipMemcpyAsync(g_l3_pend + 8 * g_l3_npend, d_need, 5 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+            g_l3_npend++;
+            L3_COARSE_ALL(reinterpret_cast<const unsigned int *>(tb + o_g), (const unsigned int *)d_need);
+            if (wrapped_out) *wrapped_out = 0;   // (known only after the pipeline's synchronise: tsc_lines_deferred_check)
+            remember(np_cap, fs_cap, o_f, o_pf, o_p);
+            return 0;
+        }
+    }
     static unsigned int *h_tot = nullptr;
     static size_t h_tot_cap = 0;
     if (nword > h_tot_cap) {
@@ -1166,7 +1249,6 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
     const unsigned int *h_ent = h_tot + nb + 1;
     if (wrapped_out) *wrapped_out = h_flag;
     g_wrapped_seen |= h_flag;
-    const int64_t PIECE = option("tsc_piece") > 0 ? (int64_t)option("tsc_piece") * 1024 : 64 * (int64_t)g.tpb;
     std::vector<unsigned int> gstart((size_t)nb + 1), fstart((size_t)nb + 1);
     std::vector<int> piece_first((size_t)nb + 1);
     std::vector<LnPiece> pieces;
@@ -1180,6 +1262,9 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
         fs += ((int64_t)h_ent[b] + 15 * (int64_t)g.tpb + 15) & ~(int64_t)15;   // every tile list starts on a line boundary
         if (gs >= 0xfff00000ll || fs >= 0xfff00000ll) return 1;
     }
+    // what a deferred build of this mesh may assume (records and tile entries per particle, padding included)
+    g_l3_caps.valid = n > 0, g_l3_caps.gx = g.n[0], g_l3_caps.gy = g.n[1], g_l3_caps.gz = g.n[2], g_l3_caps.cfg = cfg, g_l3_caps.ext = ext;
+    g_l3_caps.rec_pp = (double)gs / (double)std::max<int64_t>(n, 1), g_l3_caps.ent_pp = (double)fs / (double)std::max<int64_t>(n, 1);
     gstart[nb] = (unsigned int)gs, fstart[nb] = (unsigned int)fs;
     piece_first[nb] = (int)pieces.size();
     const int np = (int)pieces.size();
@@ -1201,23 +1286,10 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
     ABACUS_TRY(g_lw.staged.reserve((size_t)std::max<int64_t>(gs, 16) * sizeof(uint4)));
     HIP_TRY(hipMemcpyAsync(g_lw.tables.p, h_blob, tbytes, hipMemcpyHostToDevice, stream()));
     const unsigned int *d_gstart = reinterpret_cast<const unsigned int *>(g_lw.tables.as<char>() + o_g);
-    uint4 *staged = g_lw.staged.as<uint4>();
-#define L3_COARSE(NBK, LINE_, SBUF_, NT_, EXT_)                                                                                      \
-    ABACUS_LAUNCH("tsc_lines_coarse", (lines3_coarse<NBK, LINE_, SBUF_, NT_, EXT_>), dim3(nchunk), dim3(NT_), 0, (const float *)pos, n, g, box, \
-                  offA, CH, (const unsigned int *)M, d_gstart, staged, lines_clk(0))
-    if (cfg == 0) {
-        if (ext) L3_COARSE(256, 8, 2560, 512, true);
-        else L3_COARSE(256, 8, 2560, 512, false);
-    } else {
-        if (ext) L3_COARSE(1024, 4, 3328, 1024, true);
-        else L3_COARSE(1024, 4, 3328, 1024, false);
-    }
+    L3_COARSE_ALL(d_gstart, (const unsigned int *)nullptr);
+#undef L3_COARSE_ALL
 #undef L3_COARSE
-    g_l3.pos = pos, g_l3.n = n, g_l3.fs = fs, g_l3.cfg = cfg, g_l3.np = np, g_l3.ext = ext;
-    g_l3.box = box, g_l3.offset = offset, g_l3.g = g;
-    g_l3.gx = g.n[0], g_l3.gy = g.n[1], g_l3.gz = g.n[2], g_l3.zstride = g.zstride;
-    g_l3.o_f = o_f, g_l3.o_pf = o_pf, g_l3.o_p = o_p;
-    g_l3.valid = true;
+    remember(np, fs, o_f, o_pf, o_p);
     return 0;
 }
 
@@ -1540,15 +1612,17 @@ int deposit_host(void *pos_, int64_t n, const void *weights_, void *grid_, int g
 namespace abacus {
 void tsc_wrapped_reset() { g_wrapped_seen = 0; }
 int tsc_wrapped_seen() { return g_wrapped_seen; }
+void tsc_lines_defer(int on) { lines_defer_set(on); }
+int tsc_lines_deferred_check() { return lines_deferred_check(); }
 // used by power.hip: float32 deposit into a (possibly padded) device mesh with fused normalisation
 // list_mode: 0 = lists for this deposit only; 1 = build lists that a following deposit of the same particles shifted by
 // up to half a cell can reuse (call with offset 0); 2 = reuse them (rebuilds when anything changed)
 int tsc_deposit_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int64_t zstride, double box,
-                    double offset, int wrap, double norm, int cic, int list_mode, double sub) {
+                    double offset, int wrap, double norm, int cic, int list_mode, double sub, int zero_grid) {
     if (cic)
-        return deposit_dev<float, float, true>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, 0, 1, norm,
+        return deposit_dev<float, float, true>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, 0, zero_grid, norm,
                                                nullptr, -1, 0, sub, list_mode);
-    return deposit_dev<float, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
+    return deposit_dev<float, float, false>(pos, n, w, grid, nmesh, nmesh, nmesh, zstride, box, offset, wrap, zero_grid, norm,
                                             nullptr, -1, 0, sub, list_mode);
 }
 // float64 positions (and weights): the cloud weights are evaluated in the position dtype like the reference does

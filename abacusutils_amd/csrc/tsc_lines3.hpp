@@ -90,6 +90,10 @@ __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int
             if (wrap && !(fminf(fminf(q[k].x, q[k].y), q[k].z) >= 0.f && fmaxf(fmaxf(q[k].x, q[k].y), q[k].z) <= boxlo)) {
                 bool ch = false;
                 q[k].x = wrap1(q[k].x, box, ch), q[k].y = wrap1(q[k].y, box, ch), q[k].z = wrap1(q[k].z, box, ch);
+                // EXT: this build also serves the second deposit of an interlaced pair, before which the reference wraps the
+                // (wrapped) positions AGAIN (get_interlaced_field_fft calls tsc_parallel twice, power_spectrum.py:980-986): a
+                // coordinate just below zero that the first wrap rounded up to `box` itself comes back as 0
+                if (EXT) q[k].x = wrap1(q[k].x, box, ch), q[k].y = wrap1(q[k].y, box, ch), q[k].z = wrap1(q[k].z, box, ch);
                 if (ch) {
                     *reinterpret_cast<LnF3 *>(pos + 3 * p) = q[k];
                     any_changed = true;
@@ -136,6 +140,55 @@ __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int
     }
 }
 
+// ---- tables of a build, made on the device ------------------------------------------------------------------------
+// What the host used to derive from the block totals between the counting and the scattering pass (a stream synchronise,
+// a read-back, an upload: 0.15 ms of BASELINE config 3's step with the GPU idle): block starts of the staged records (gstart)
+// and of the tile lists (fstart), both on line boundaries, and the pieces of at most PIECE records the fine level works on.
+// The buffers are sized by the caller BEFORE the totals are known (from the previous build of the same mesh); need[] reports
+// what was needed and need[3] != 0 says "did not fit": every later kernel of the build then does nothing, and the caller - who
+// learns of it at its next synchronisation - runs the build again with exact sizes (tsc.hip: lines3_build, deferred mode).
+__global__ __launch_bounds__(1024) void lines3_tables(const unsigned int *__restrict__ tot, const unsigned int *__restrict__ ent, const int *__restrict__ wflag,
+                                                      int nb, int tpb, unsigned int PIECE, unsigned long long gs_cap, unsigned long long fs_cap, int np_cap,
+                                                      unsigned int *__restrict__ gstart, unsigned int *__restrict__ fstart, int *__restrict__ piece_first,
+                                                      LnPiece *__restrict__ pieces, unsigned int *__restrict__ need) {
+    __shared__ unsigned long long sg[1024], sf[1024];
+    __shared__ unsigned int sp[1024];
+    __shared__ int bad;
+    const int b = threadIdx.x;
+    const unsigned int t = b < nb ? tot[b] : 0u, en = b < nb ? ent[b] : 0u;
+    const unsigned long long g = b < nb ? ((unsigned long long)t + 15ull) & ~15ull : 0ull;
+    const unsigned long long f = b < nb ? ((unsigned long long)en + 15ull * (unsigned long long)tpb + 15ull) & ~15ull : 0ull;
+    const unsigned int npc = (t + PIECE - 1u) / PIECE;
+    sg[b] = g, sf[b] = f, sp[b] = npc;
+    if (b == 0) bad = 0;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {             // inclusive scans (a thousand values, once per build)
+        const unsigned long long ag = b >= d ? sg[b - d] : 0ull, af = b >= d ? sf[b - d] : 0ull;
+        const unsigned int ap = b >= d ? sp[b - d] : 0u;
+        __syncthreads();
+        sg[b] += ag, sf[b] += af, sp[b] += ap;
+        __syncthreads();
+    }
+    const unsigned long long gs = sg[1023], fs = sf[1023];
+    const unsigned int np = sp[1023];
+    if (b == 0) {
+        const int over = gs > gs_cap || fs > fs_cap || np > (unsigned int)np_cap || gs >= 0xfff00000ull || fs >= 0xfff00000ull;
+        bad = over;
+        need[0] = (unsigned int)min(gs, 0xffffffffull), need[1] = (unsigned int)min(fs, 0xffffffffull), need[2] = np, need[3] = (unsigned int)over;
+        need[4] = (unsigned int)*wflag;
+    }
+    __syncthreads();
+    const bool over = bad != 0;
+    const unsigned int g0 = over ? 0u : (unsigned int)(sg[b] - g), f0 = over ? 0u : (unsigned int)(sf[b] - f);
+    const int p0 = over ? 0 : (int)(sp[b] - npc);
+    if (b < nb) gstart[b] = g0, fstart[b] = f0, piece_first[b] = p0;
+    if (b == nb - 1) gstart[nb] = over ? 0u : (unsigned int)gs, fstart[nb] = over ? 0u : (unsigned int)fs, piece_first[nb] = over ? 0 : (int)np;
+    if (!over && b < nb)
+        for (unsigned int j = 0; j < npc; j++)
+            pieces[p0 + (int)j] = LnPiece{b, g0 + j * PIECE, g0 + min((j + 1u) * PIECE, t), j == 0u ? 1 : 0};
+    for (int p = (over ? 0 : (int)np) + b; p < np_cap; p += 1024) pieces[p] = LnPiece{0, 0u, 0u, 0};
+}
+
 // ---- coarse scatter: one record per (particle, block) ----------------------------------------------------------------
 struct L3Item {
     unsigned int w[3];   // the record of the first block in every dimension
@@ -167,9 +220,11 @@ template <int NB, int LINE, int SBUF, int NT, bool EXT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void lines3_coarse(const float *__restrict__ pos, int64_t n, LGeom g, double box,
                                                                                            float offA, int64_t CH, const unsigned int *__restrict__ M,
                                                                                            const unsigned int *__restrict__ gstart,
-                                                                                           uint4 *__restrict__ staged, unsigned long long *clk) {
+                                                                                           uint4 *__restrict__ staged, unsigned long long *clk,
+                                                                                           const unsigned int *__restrict__ need) {
     __shared__ SplitLds<uint4, NB, LINE, SBUF, NT> s;
     const int tid = threadIdx.x, nb = g.nbuckets;
+    if (need && need[3]) return;                          // the tables did not fit the buffers (lines3_tables): nothing is written
     split_init(s);
     for (int b = tid; b < NB; b += NT) s.base[b] = b < nb ? gstart[b] + M[(int64_t)blockIdx.x * nb + b] : 0u;
     __syncthreads();

@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--no-hod-extra', action='store_true', help='skip the hod_multi and hod_large legs')
     ap.add_argument('--no-slab', action='store_true', help='N > 1: skip the slab-decomposed P(k) leg (RCCL all-to-all)')
     ap.add_argument('--slab-timeout', type=float, default=240.0, help='seconds before the slab leg is abandoned')
+    ap.add_argument('--slab-presorted', action='store_true',
+                    help='slab leg: particles generated inside every rank\'s own folded slabs (no routing in the timed step)')
     ap.add_argument('--hod-timeout', type=float, default=270.0, help='N > 1: seconds before the headline leg is abandoned')
     ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE',
                     help='diagnostic option of the library (abacus_set_option), e.g. hod_nocls=1: A/B timing of a comparator path')
@@ -420,6 +422,10 @@ def orchestrate(args, under_launcher):
     is_root = ranks is None or 0 in ranks
     common = ['--gpus', str(world), '--steps', str(args.steps), '--warmup', str(args.warmup), '--nhalo', str(args.nhalo),
               '--npart', str(args.npart), '--nmesh', str(args.nmesh), '--npk', str(args.npk), '--no-cpu']
+    if args.slab_presorted:
+        common.append('--slab-presorted')
+    for o in args.option:
+        common += ['--option', o]
 
     def leg(name, timeout):
         res = launch_ranks([sys.executable, os.path.abspath(__file__), '--leg', name] + common, world, ranks=ranks,
@@ -490,6 +496,18 @@ def single(args):
                     out[key] = fn()
                 except Exception as e:
                     out[key] = {'error': repr(e)}
+            # the metric's own mesh (2048^3) has no CPU call of its own in the default run (a float32 mesh + complex spectrum of
+            # 2 x 34 GB through pocketfft: minutes): an ESTIMATE from the measured config-3 call, labelled as one
+            try:
+                c3 = out['pk_c3']['cpu_baseline']
+                scale = 8.0 * 33.0 / 30.0      # mesh cells x log2(M): the transform dominates the CPU call
+                out['pk']['cpu_baseline'] = {
+                    'value': c3['value'] / (33.0 / 30.0), 'unit': c3['unit'], 'cores': c3['cores'], 'kind': 'port', 'estimated': True,
+                    'ms': c3['ms'] * scale,
+                    'sample': f"NOT MEASURED at 2048^3: the oracle's config-3 call of this run ({c3['ms']:.0f} ms at 1024^3, "
+                              f"{c3['cores']} threads) scaled by cells x log2(cells) = {scale:.1f}; the measured baseline is pk_c3.cpu_baseline"}
+            except (KeyError, TypeError):
+                pass
     else:
         from bench_pk import bench_pk
         out = bench_pk(args, dist, headline=True)

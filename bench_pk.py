@@ -59,12 +59,28 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
             len(poles), *[_lib.ptr(o) for o in outs]))
 
     steps = max(1, min(args.steps, 10))
-    for _ in range(max(1, min(args.warmup, 2))):
+    _lib.sync()
+    tf = time.perf_counter()
+    step()                                   # the first call of this mesh: allocations, twiddle tables, the geometry descriptor
+    _lib.sync()                              # of the (k, mu) bins, an exact (synchronous) list build
+    first_call_ms = (time.perf_counter() - tf) * 1e3
+    for _ in range(max(1, min(args.warmup, 2)) - 1):
         step()
     lib.abacus_power_geometry_ms.restype = C.c_double
     geometry_ms = float(lib.abacus_power_geometry_ms())   # one-off pass of the first call (cached per (nmesh, edges))
     xbin_gen = int(lib.abacus_power_xbin_generation())
+    # per-kernel table from two untimed steps with every launch bracketed by HIP events; in the TIMED region only the dominant
+    # kernel is bracketed (a pair of event records per launch costs a few microseconds of a 10-ms step and a barrier packet each)
     _lib.profile_reset()
+    _lib.profile_enable(True)
+    for _ in range(2):
+        step()
+    _lib.sync()
+    _lib.profile_enable(False)
+    kern = {k: ms / c for k, (ms, c) in _lib.profile_get().items() if c}
+    dom0 = max(kern, key=kern.get)
+    _lib.profile_reset()
+    _lib.profile_select(dom0)
     _lib.profile_enable(True)
     dist.barrier()
     _lib.sync()
@@ -76,8 +92,8 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
     dist.barrier()
     dt = dist.max(t1 - t0) / steps
     _lib.profile_enable(False)
-    prof = _lib.profile_get()
-    kern = {k: ms / c for k, (ms, c) in prof.items() if c}
+    _lib.profile_select(None)
+    kern.update({k: ms / c for k, (ms, c) in _lib.profile_get().items() if c})   # the dominant kernel: measured in the timed steps
 
     power = outs[0].copy()
     shot = L**3 / n
@@ -122,6 +138,7 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
                    'nmesh': nmesh, 'n_particles': n},
         'kernels_ms': {k: round(v, 4) for k, v in kern.items()},
         'geometry_ms': round(geometry_ms, 3),
+        'first_call_ms': round(first_call_ms, 2),
         'geometry_note': 'N_mode, k_avg and the cell table of the (k, mu) bins depend on (nmesh, edges) alone: one pass over the '
                          f'modes at the first spectrum of a mesh / edge set, cached (fused last pass generation {xbin_gen}); outside the timed steps',
         'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot),
@@ -137,23 +154,43 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
         try:
             W = ps.get_W_compensated(L, nmesh, 'TSC', True).astype(np.float32)
             step(1, W)
+            step(1, W)
             _lib.sync()
-            _lib.profile_reset()
-            _lib.profile_enable(True)
             t1 = time.perf_counter()
             for _ in range(max(1, steps // 2)):
                 step(1, W)
             _lib.sync()
             dti = (time.perf_counter() - t1) / max(1, steps // 2)
+            _lib.profile_reset()
+            _lib.profile_enable(True)
+            step(1, W)
+            _lib.sync()
             _lib.profile_enable(False)
-            # per step: two deposits and two z / y passes, one fused last pass over both fields
-            kern_i = {k: ms / max(1, steps // 2) for k, (ms, c) in _lib.profile_get().items() if c}
+            # per step: one list build, two fine passes / deposits / z / y passes, one fused last pass over both fields
+            kern_i = {k: ms for k, (ms, c) in _lib.profile_get().items() if c}
             out['interlaced_compensated'] = {'ms_per_step': dti * 1e3, 'kernels_ms_per_step': kern_i,
                                              'whole_step_GBs': (24.0 * n + 80.0 * M) / dti / 1e9,
                                              'whole_step_frac': (24.0 * n + 80.0 * M) / dti / 1e9 / HBM_PEAK_GBS}
         except Exception as e:
             out['interlaced_compensated'] = {'error': repr(e)}
     dpos.free()
+    # the drop-in call itself: calc_power on the NumPy positions (PCIe included; never the `value`): the upload runs in batches
+    # on a copy stream, each batch deposited while the next is on the link (csrc/power.hip, HostSrc)
+    if nmesh == 1024 and dist.world == 1 and variants is False:
+        try:
+            ckw = dict(kbins=min(512, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste='TSC', nmesh=nmesh, compensated=False,
+                       interlaced=False, poles=[0, 2, 4])
+            th = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ps.calc_power(pos, L, **ckw)
+                th.append((time.perf_counter() - t1) * 1e3)
+            lib.abacus_power_last_batches.restype = C.c_double
+            out['ms_per_call_host_arrays'] = round(min(th[1:]), 2)
+            out['host_arrays_note'] = (f'calc_power(pos: NumPy float32 ({n}, 3), ...) per call, best of two after a first call of {th[0]:.1f} ms: '
+                                       f'1.2 GB over PCIe in {int(lib.abacus_power_last_batches())} batches behind the deposits')
+        except Exception as e:
+            out['ms_per_call_host_arrays'] = repr(e)
     lib.abacus_power_release()
     if cpu and dist.rank == 0 and dist.world == 1 and not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline_pk(L, out['ms_per_step'] if nmesh == 1024 else None)
@@ -202,36 +239,68 @@ def bench_pk_slab(args, dist):
     n_local = ntot // W
     rng = np.random.default_rng(300 + r)
     pos = rng.random((n_local, 3), dtype=np.float32)
-    # rank r owns the slabs r and r + W of the 2 W slabs of width L / (2 W): first half of the particles in one, rest in the other
-    slab = np.where(np.arange(n_local) < n_local // 2, r, r + W).astype(np.float32)
-    pos[:, 0] = (pos[:, 0] * np.float32(0.99999) + slab) * np.float32(L / (2 * W))   # clear of the upper edge in float32
-    pos[:, 1:] *= np.float32(L)
-    assert np.array_equal(sp.slab_owner(pos[:, 0], L, W, True), np.full(n_local, r))
+    # BASELINE config 4: the galaxies come out of halo-range shards (abacusutils_amd/hod/shard.py: a rank's halos are a
+    # contiguous id range, not an x-slab), so every rank starts with particles from ALL OVER the box and the timed step begins
+    # with `route_particles` (bucket sort by folded-slab owner + all-to-all-v over xGMI): (W - 1) / W of the catalogue moves.
+    # `--slab-presorted`: the round-4 leg, particles generated inside the rank's own folded slabs (routing moves nothing)
+    presorted = bool(getattr(args, 'slab_presorted', False))
+    if presorted:
+        slab = np.where(np.arange(n_local) < n_local // 2, r, r + W).astype(np.float32)
+        pos[:, 0] = (pos[:, 0] * np.float32(0.99999) + slab) * np.float32(L / (2 * W))   # clear of the upper edge in float32
+        pos[:, 1:] *= np.float32(L)
+        assert np.array_equal(sp.slab_owner(pos[:, 0], L, W, True), np.full(n_local, r))
+    else:
+        pos *= np.float32(L)
     dpos = _lib.DeviceArray(pos)
     kw = dict(kbins=min(512, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste='TSC', nmesh=nmesh,
               compensated=False, interlaced=False, poles=[0, 2, 4], n_total=n_local * W)
     steps = max(1, min(args.steps, 5))
-    tab = sp.calc_power_slab(dpos, L, comm=comm, backend=backend, **kw)   # warm-up: allocations, tables, RCCL channels
+    can_route = getattr(comm, 'device', False) or W == 1
+
+    def one_step():
+        if presorted or not can_route or W == 1:
+            return sp.calc_power_slab(dpos, L, comm=comm, backend=backend, **kw), 0
+        rpos, _ = sp.route_particles(dpos, None, L, comm, fold=True)
+        tab_ = sp.calc_power_slab(rpos, L, comm=comm, backend=backend, **kw)
+        nrecv = rpos.shape[0]
+        rpos.free()
+        return tab_, nrecv
+
+    tab, nrecv = one_step()                 # warm-up: allocations, tables, RCCL channels
     sent0 = comm.info()['bytes_sent'] if dist.comm is not None else 0
     dist.barrier()
     _lib.sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        tab = sp.calc_power_slab(dpos, L, comm=comm, backend=backend, **kw)
+        tab, nrecv = one_step()
     _lib.sync()
     t1 = time.perf_counter()
     dist.barrier()
     dt = dist.max(t1 - t0) / steps
     sent = (comm.info()['bytes_sent'] - sent0) / steps if dist.comm is not None else 0
+    # the routing on its own (same particles, same destination): what it adds to the step and what it puts on the links
+    routing = None
+    if not presorted and can_route and W > 1:
+        s0 = comm.info()['bytes_sent']
+        dist.barrier()
+        _lib.sync()
+        tr = time.perf_counter()
+        for _ in range(steps):
+            rp, _ = sp.route_particles(dpos, None, L, comm, fold=True)
+            rp.free()
+        _lib.sync()
+        routing = {'ms': dist.max(time.perf_counter() - tr) / steps * 1e3, 'bytes_sent_per_rank': (comm.info()['bytes_sent'] - s0) / steps,
+                   'particles_received': int(nrecv)}
     power = np.asarray(tab['power'])
     shot = L**3 / (n_local * W)
     out = {'metric': f'wall-clock of one {nmesh}^3 TSC+FFT P(k) slab-decomposed over {W} GPUs', 'value': dt * 1e3,
            'unit': 'ms', 'n_gpus': W, 'rccl_ranks': W if dist.comm is not None else 0, 'steps': steps, 'scaling': 'strong',
            'higher_is_better': False, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': f'{n_local * W:.0e} uniform particles in folded x-slabs, nmesh {nmesh}, TSC, non-interlaced, '
+           'config': {'workload': f'{n_local * W:.0e} uniform particles, nmesh {nmesh}, folded x-slabs, TSC, non-interlaced, '
                                   'RCCL through the C ABI: ring send/recv of ghost planes, chunked all-to-all of the '
                                   'pencil transpose (grouped ncclSend/ncclRecv), all-reduce of the histogram'},
-           'bytes_sent_per_rank_per_step': sent,
+           'bytes_sent_per_rank_per_step': sent, 'routing': routing,
+           'particles': 'presorted into the folded slabs' if presorted else 'box-wide on every rank (halo-range shards): routed inside the timed step',
            'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot)}
     # the pencil transpose on its own: every rank sends 1/W of its slab to each peer at once (one xGMI link per peer)
     if dist.comm is not None and W > 1:

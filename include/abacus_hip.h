@@ -298,6 +298,10 @@ int abacus_scratch_release(void);
  * auto power, non-interlaced, nmesh 1024 / 2048): N_mode, k_avg and the (k, mu) bin of every mode depend on (nmesh, edges)
  * alone (power_spectrum.py:233-256), so they are computed once per (nmesh, edges) and cached; 0 if none was built */
 double abacus_power_geometry_ms(void);
+/* diagnostic: batches in which the most recent abacus_power_from_particles uploaded its (first) host position array - more than one
+ * when the upload runs on a copy stream behind the deposits of the batches before (csrc/power.hip, HostSrc; option pk_nobatch = 1
+ * forces one) */
+double abacus_power_last_batches(void);
 /* which fused last pass served the most recent spectrum: 2 = cached-geometry kernel, 1 = first generation (bin walk in the
  * kernel: more than 8 mu bins, edges the cell table cannot resolve, option pk_xbin_gen = 1), 0 = none yet */
 int abacus_power_xbin_generation(void);

@@ -9,12 +9,13 @@ for w in "$@"; do
 case $w in
 tests)
   make -s -C oracle
-  timeout 2700 python -m pytest tests -m gpu -q 2>&1 | tail -40 | tee "$O/gpu_tests.log"
+  # (progress goes to the file as it happens: a run that writes nothing for seven minutes is taken to be hung)
+  timeout 2700 python -u -m pytest tests -m gpu -q -p no:cacheprovider > "$O/gpu_tests.log" 2>&1; tail -40 "$O/gpu_tests.log"
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12 | tee "$O/smoke.log"
   ;;
 only:*)
   make -s -C oracle
-  timeout 2400 python -m pytest tests -m gpu -x -q -k "${w#only:}" 2>&1 | tail -40 | tee "$O/gpu_only.log"
+  timeout 2400 python -u -m pytest tests -m gpu -x -q -p no:cacheprovider -k "${w#only:}" > "$O/gpu_only.log" 2>&1; tail -40 "$O/gpu_only.log"
   ;;
 bench)
   timeout 1500 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"; cat "$O/bench_default.json"; tail -3 "$O/bench_default.err"

@@ -713,6 +713,18 @@ def test_mixed_radix_meshes_take_the_native_transform(nmesh, npart, options):
     prof = _lib.profile_get()
     assert any(k.startswith('gfft_') for k in prof) and 'hipfft_r2c' not in prof, sorted(prof)
     _check_oracle(tab, oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw))
+    # the interlaced pair, too, is binned by the last pass straight from LDS (gfft_x_bin<INTER>: both fields' tiles side by side)
+    # - against two x passes + spectrum_bin<INTER> (option pk_noxbin_inter) mode by mode
+    assert 'gfft_x_bin' in prof and 'spectrum_bin' not in prof and 'gfft_cols_x' not in prof, sorted(prof)
+    options.set('pk_noxbin_inter', 1)
+    tab_u = calc_power(pos.copy(), box, **kw)
+    options.set('pk_noxbin_inter', 0)
+    np.testing.assert_array_equal(tab['N_mode'], tab_u['N_mode'])
+    sc = np.abs(np.asarray(tab_u['power'])).max()
+    np.testing.assert_allclose(tab['power'], tab_u['power'], rtol=3e-6, atol=3e-7 * sc)
+    np.testing.assert_allclose(tab['poles'], tab_u['poles'], rtol=3e-6, atol=5e-7 * sc)
+    kw_ny = dict(kw, k_max=1.6 * np.pi * nmesh / box, compensated=False)     # past Nyquist: the folded i = n/2 plane is binned
+    _check_oracle(calc_power(pos.copy(), box, **kw_ny), oracle.calc_power(pos.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw_ny))
     if nmesh <= 182:
         a = get_field_fft(pos.copy(), box, nmesh, 'TSC', None, None, False, False)
         options.set('fft_hipfft', 1)
@@ -804,3 +816,34 @@ def test_float64_meshes_against_reference_goldens(n):
             assert_spectrum_close(tab[c], g[f'n{n}.{name}.{c}'], rtol=1e-5, err_msg=f'{name}.{c}')
     with pytest.raises(TypeError):
         ps.calc_power(pos.copy(), Lb, nmesh=n, dtype=np.float16)
+
+
+@pytest.mark.parametrize('interlaced', [False, True])
+def test_host_positions_uploaded_in_batches_behind_the_deposits(interlaced, options):
+    """calc_power on NumPy positions (the reference's call, analysis/power_spectrum.py:1131): where the mesh is small against
+    the catalogue the upload runs in batches on a copy stream and every batch is deposited - accumulating into the mesh, the
+    normalisation applied by the last flush - while the next is on the PCIe link (csrc/power.hip, HostSrc).  Same spectrum as
+    the one-copy path (option pk_nobatch) and as the oracle; positions wrapped in place identically"""
+    import ctypes as C
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    from oracle import oracle
+    rng = np.random.default_rng(17)
+    box, nmesh, n = 1500.0, 512, 24_000_000
+    pos = ((rng.random((n, 3), dtype='f4') * np.float32(1.02) - np.float32(0.01)) * np.float32(box)).astype('f4')   # some outside the box
+    kw = dict(kbins=40, mubins=3, paste='TSC', nmesh=nmesh, compensated=interlaced, interlaced=interlaced, poles=[0, 2, 4])
+    p1, p2, p3 = pos.copy(), pos.copy(), pos.copy()
+    a = calc_power(p1, box, **kw)
+    last = _lib.lib().abacus_power_last_batches
+    last.restype = C.c_double
+    assert last() >= 2, last()
+    options.set('pk_nobatch', 1)
+    b = calc_power(p2, box, **kw)
+    assert last() == 1
+    np.testing.assert_array_equal(p1, p2)
+    assert not np.array_equal(p1, pos)                       # something was wrapped
+    np.testing.assert_array_equal(np.asarray(a['N_mode']), np.asarray(b['N_mode']))
+    scale = np.abs(np.asarray(b['power'])).max()
+    np.testing.assert_allclose(a['power'], b['power'], rtol=2e-6, atol=2e-7 * scale)
+    _check_oracle(a, oracle.calc_power(p3, box, nthread=oracle.max_threads(), accum64=True, **kw))
+    np.testing.assert_array_equal(p1, p3)

@@ -352,3 +352,47 @@ def test_interlaced_pair_shares_one_block_record_build(kind, nmesh, n, options):
     d = np.zeros((nmesh,) * 3, dtype='f4')
     tsc_parallel(pos.copy(), d, box, offset=off)          # unshared gen-3 build at the float32 offset
     np.testing.assert_allclose(d, c, rtol=5e-5, atol=4e-6 * float(c.max()))
+
+
+def test_deferred_list_build_and_its_overflow_path(options):
+    """inside calc_power the list build of a mesh seen before sizes its buffers from the previous build and makes its tables on
+    the device (csrc/tsc.hip deferred mode: no stream synchronise between the counting and the scattering pass).  Same
+    spectrum as the synchronous build (option tsc_lines_sync = 1), bit for bit; a second catalogue ten times as clustered -
+    and option tsc_lines_sync = 2, buffers for a twentieth of the particles - overflows them: the pipeline notices after its
+    final synchronise and runs again with exact sizes"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    rng = np.random.default_rng(31)
+    box, nmesh, n = 900.0, 512, 2_400_000
+    pos = (rng.random((n, 3), dtype='f4') * np.float32(box)).astype('f4')
+    kw = dict(kbins=32, mubins=3, paste='TSC', nmesh=nmesh, compensated=False, interlaced=False, poles=[0, 2])
+    options.set('tsc_lines_sync', 1)
+    ref = calc_power(pos.copy(), box, **kw)
+    options.set('tsc_lines_sync', 0)
+
+    def run(p):
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        t = calc_power(p.copy(), box, **kw)
+        _lib.profile_enable(False)
+        return t, _lib.profile_get()
+
+    first, _ = run(pos)                         # (the exact build above left its sizes behind: this one is deferred already)
+    second, prof = run(pos)
+    assert 'tsc_lines_tables' in prof and prof['tsc_lines_count'][1] == 1, sorted(prof)
+    for t in (first, second):
+        np.testing.assert_array_equal(np.asarray(t['N_mode']), np.asarray(ref['N_mode']))
+        np.testing.assert_array_equal(np.asarray(t['power']), np.asarray(ref['power']))
+    # a catalogue that needs far more room per block than the last one: half of it inside one block of tiles
+    clustered = pos.copy()
+    clustered[: n // 2] *= np.float32(0.12)
+    options.set('tsc_lines_sync', 1)
+    want = calc_power(clustered.copy(), box, **kw)
+    options.set('tsc_lines_sync', 0)
+    calc_power(pos.copy(), box, **kw)           # sizes of the uniform catalogue again
+    got, prof = run(clustered)
+    np.testing.assert_array_equal(np.asarray(got['power']), np.asarray(want['power']))
+    options.set('tsc_lines_sync', 2)
+    got2, prof2 = run(pos)
+    assert prof2['tsc_lines_count'][1] == 2 and prof2['tsc_lines_tables'][1] == 1, {k: v[1] for k, v in prof2.items() if k.startswith('tsc_')}
+    np.testing.assert_array_equal(np.asarray(got2['power']), np.asarray(ref['power']))
