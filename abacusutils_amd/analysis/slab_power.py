@@ -101,9 +101,14 @@ class HipSlabBackend:
         from xoff2 behind the first; a plane in both windows takes its deposits in the first.  Particles outside are skipped"""
         pos, w = particles
         n = pos.shape[0]
-        _lib.check(_lib.lib().abacus_slab_deposit_dev(pos.ptr, C.c_int64(n), None if w is None else w.ptr, mesh.ptr(0),
-                                                      int(nmesh), int(xoff), int(xoff2), int(nx_total), C.c_double(Lbox),
-                                                      C.c_double(offset), C.c_double(norm), int(paste), C.c_double(sub)))
+        # a buffer padded to whole 16-plane tiles (calc_power_slab allocates it so) lets the deposit take the single-GPU path's
+        # third-generation lists on the window planes
+        planes = (nx_total if xoff2 < 0 else 2 * nx_total)
+        have = mesh.n // (int(nmesh) * self.pitch(nmesh))
+        nx_alloc = -(-planes // 16) * 16
+        _lib.check(_lib.lib().abacus_slab_deposit_padded_dev(
+            pos.ptr, C.c_int64(n), None if w is None else w.ptr, mesh.ptr(0), int(nmesh), int(xoff), int(xoff2), int(nx_total),
+            C.c_double(Lbox), C.c_double(offset), C.c_double(norm), int(paste), C.c_double(sub), int(nx_alloc if have >= nx_alloc else 0)))
 
     def axpy(self, dst, dst_off, src, src_off, nfloat, add):
         _lib.check(_lib.lib().abacus_slab_axpy_dev(dst.ptr(dst_off), None if src is None else src.ptr(src_off),
@@ -242,7 +247,8 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     xsep = win                            # so the halves of a pair lie `win` planes apart
     d = Lbox / nmesh
     nfields = (2 if interlaced else 1) * (2 if pos2 is not None else 1)
-    meshes = [backend.new_buffer(2 * win * plane) for _ in range(nfields)]
+    # (two windows back to back, padded to whole 16-plane tiles for the list build of the deposit)
+    meshes = [backend.new_buffer(-(-2 * win // 16) * 16 * plane) for _ in range(nfields)]
     lazy = {}                             # send / recv buffers of the transpose, allocated when a step needs them (one rank whose
 
     def tbuf(name):                       # last pass bins straight from its mesh needs neither: 2 x 18 GB at 2048^3)

@@ -56,7 +56,7 @@ int fft_native_r2c_inplace(float *mesh, int n, int pitch_r, float xcut = 0.f);
 int fft_native_zy(float *mesh, int n, int pitch_r, int64_t nx_local);
 int fft_native_x(float *mesh, int n, int pitch_r, int64_t ny_local, int64_t x_stride, int64_t y_stride);
 int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
-                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub, int xoff2);
+                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub, int xoff2, int nx_alloc = 0);
 int fft_native_release();
 int fft_native_fused_supported(int n);
 int fft_native_r2c_fused(float *mesh, int n, int pitch_r, float xcut = 0.f);   // rows come out in the permuted order of fft.hip's fused form
@@ -713,7 +713,7 @@ double g_last_batches = 0;   // diagnostic: batches of the last host upload (aba
 
 int upload_batches(int64_t n, int nmesh) {
     if (option("pk_nobatch")) return 1;
-    const double t_up = 12.0 * (double)n / 56e9, t_rmw = 8.0 * 4.0 * (double)nmesh * nmesh * nmesh / 4.5e12;
+    const double t_up = 12.0 * (double)n / 56e9, t_rmw = 8.0 * (double)nmesh * nmesh * nmesh / 4.5e12;   // the mesh read and written once per batch
     const int K = (int)std::floor(0.8 * t_up / std::max(t_rmw, 1e-9));
     // batches of at least 8e6 particles: the list build of a batch must keep its two levels
     return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)K, (int64_t)8, n / 8000000}));
@@ -1412,8 +1412,8 @@ int abacus_pk_from_deltak(const void *field, const void *field2, int nmesh, doub
 
 int abacus_slab_pitch(int nmesh) { return pitch_r(nmesh); }
 
-int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int xoff2, int nx_local,
-                            double Lbox, double offset, double norm, int paste, double sub) {
+int abacus_slab_deposit_padded_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int xoff2, int nx_local,
+                                   double Lbox, double offset, double norm, int paste, double sub, int nx_alloc) {
     ABACUS_ENTER();
     ABACUS_TRY(check_common(nmesh, paste));
     if (!fft_native_pow2(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
@@ -1421,7 +1421,12 @@ int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, 
     if (xoff2 < 0 && nx_local == nmesh && xoff == 0)   // the whole periodic mesh on one rank: the single-GPU deposit (fast list build)
         return tsc_deposit_f32(pos, n, w, mesh, nmesh, pitch_r(nmesh), Lbox, offset, paste == 0, norm, paste, 0, sub);
     return tsc_deposit_slab_f32(pos, n, w, mesh, nmesh, xoff, xoff2 < 0 ? nx_local : 2 * nx_local, pitch_r(nmesh), Lbox, offset,
-                                paste == 0, norm, paste, sub, xoff2 < 0 ? -1 : xoff2);
+                                paste == 0, norm, paste, sub, xoff2 < 0 ? -1 : xoff2, nx_alloc);
+}
+
+int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int xoff2, int nx_local,
+                            double Lbox, double offset, double norm, int paste, double sub) {
+    return abacus_slab_deposit_padded_dev(pos, n, w, mesh, nmesh, xoff, xoff2, nx_local, Lbox, offset, norm, paste, sub, 0);
 }
 
 int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add) {

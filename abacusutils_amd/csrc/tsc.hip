@@ -1161,7 +1161,8 @@ int lines_deferred_check() {
 
 // count + coarse: the staged block records of `pos` at mesh offset `offset` (ext: blocks of the 4-cell union of the clouds at
 // `offset` and `offset` + half a cell).  Returns 1 when 32-bit indices do not hold the lists (caller falls back).
-static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double box, double offset, int wrap, int ext, int *wrapped_out) {
+static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double box, double offset, int wrap, int ext, int *wrapped_out,
+                        const L3Win &wn = L3Win{0, 0, 0, 0, -1}) {
     g_l3.valid = false;
     const int nb = g.nbuckets;
     const int64_t CH = std::max<int64_t>(8192, ceil_div(n, 1024));
@@ -1175,7 +1176,7 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
     unsigned int *ent = tot + nb + 1;
     HIP_TRY(hipMemsetAsync(flag, 0, (size_t)(nb + 1) * sizeof(unsigned int), stream()));
     const float offA = (float)offset;
-#define L3_COUNT(NBK, EXT_) ABACUS_LAUNCH("tsc_lines_count", (lines3_count<NBK, EXT_>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, ent, flag)
+#define L3_COUNT(NBK, EXT_) ABACUS_LAUNCH("tsc_lines_count", (lines3_count<NBK, EXT_>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, ent, flag, wn)
     if (cfg == 0) {
         if (ext) L3_COUNT(256, true);
         else L3_COUNT(256, false);
@@ -1188,7 +1189,7 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
     const int64_t PIECE = option("tsc_piece") > 0 ? (int64_t)option("tsc_piece") * 1024 : 64 * (int64_t)g.tpb;
 #define L3_COARSE(NBK, LINE_, SBUF_, NT_, EXT_, GSTART, NEED)                                                                        \
     ABACUS_LAUNCH("tsc_lines_coarse", (lines3_coarse<NBK, LINE_, SBUF_, NT_, EXT_>), dim3(nchunk), dim3(NT_), 0, (const float *)pos, n, g, box, \
-                  offA, CH, (const unsigned int *)M, GSTART, g_lw.staged.as<uint4>(), lines_clk(0), NEED)
+                  offA, CH, (const unsigned int *)M, GSTART, g_lw.staged.as<uint4>(), lines_clk(0), NEED, wn)
 #define L3_COARSE_ALL(GSTART, NEED)                                  \
     do {                                                             \
         if (cfg == 0) {                                              \
@@ -1208,7 +1209,7 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
     };
     // ---- deferred: sizes from the last exact build of this mesh, tables on the device, no synchronise
     const L3Caps &cp = g_l3_caps;
-    if (g_l3_defer && cp.valid && cp.gx == g.n[0] && cp.gy == g.n[1] && cp.gz == g.n[2] && cp.cfg == cfg && cp.ext == ext && g_l3_npend < 32 &&
+    if (g_l3_defer && !wn.on && cp.valid && cp.gx == g.n[0] && cp.gy == g.n[1] && cp.gz == g.n[2] && cp.cfg == cfg && cp.ext == ext && g_l3_npend < 32 &&
         option("tsc_lines_sync") != 1 && nb <= 1024) {
         // (diagnostic: tsc_lines_sync = 2 sizes the record buffer for a twentieth of the particles - the overflow path of the tests)
         const double shrink = option("tsc_lines_sync") == 2 ? 0.05 : 1.03;
@@ -1263,7 +1264,7 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
         if (gs >= 0xfff00000ll || fs >= 0xfff00000ll) return 1;
     }
     // what a deferred build of this mesh may assume (records and tile entries per particle, padding included)
-    g_l3_caps.valid = n > 0, g_l3_caps.gx = g.n[0], g_l3_caps.gy = g.n[1], g_l3_caps.gz = g.n[2], g_l3_caps.cfg = cfg, g_l3_caps.ext = ext;
+    g_l3_caps.valid = n > 0 && !wn.on, g_l3_caps.gx = g.n[0], g_l3_caps.gy = g.n[1], g_l3_caps.gz = g.n[2], g_l3_caps.cfg = cfg, g_l3_caps.ext = ext;
     g_l3_caps.rec_pp = (double)gs / (double)std::max<int64_t>(n, 1), g_l3_caps.ent_pp = (double)fs / (double)std::max<int64_t>(n, 1);
     gstart[nb] = (unsigned int)gs, fstart[nb] = (unsigned int)fs;
     piece_first[nb] = (int)pieces.size();
@@ -1367,7 +1368,7 @@ TileGeom make_geom(int gx, int gy, int gz, int64_t zstride, int TX, int TY, int 
 template <typename PT, typename GT, bool CIC>
 int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy, int gz, int64_t zstride, double box,
                 double offset, int wrap, int zero_grid, double norm, int *wrapped_out, int gxg = -1, int xoff = 0,
-                double sub = 1.0, int list_mode = 0, int xoff2 = -1) {
+                double sub = 1.0, int list_mode = 0, int xoff2 = -1, int nx_alloc = 0) {
     if (gxg < 0) gxg = gx;
     if (xoff2 >= 0 && (gx % 2 || gx / 2 > gxg)) return fail("tsc: two windows of %d planes in a mesh of %d", gx, gxg);
     if (gx < 1 || gy < 1 || gz < 1) return fail("tsc: empty mesh");
@@ -1424,6 +1425,24 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
             }
             if (rc <= 0) return rc;   // 1: more than 2^32 entries - the first-generation lists below
             if (wrapped_out) lines_wrapped = *wrapped_out;
+        }
+    }
+    // the same lists for the windows of a slab-decomposed mesh (one or two x-windows stored back to back in a buffer the caller
+    // padded to `nx_alloc` planes, a whole number of tiles): tsc_lines3.hpp, L3Win
+    if constexpr (std::is_same<PT, float>::value && std::is_same<GT, float>::value && !CIC) {
+        const int win = xoff2 < 0 ? gx : gx / 2;
+        const int dsep = xoff2 < 0 ? gxg : std::min((xoff2 - xoff + gxg) % gxg, (xoff - xoff2 + gxg) % gxg);
+        LGeom lg;
+        int lcfg = 0;
+        if (multisplit && !weights && wrap && gxg != gx && nx_alloc >= gx && nx_alloc % LN_TX == 0 && nx_alloc < gx + LN_TX && win <= dsep &&
+            win >= 8 && zero_grid && !option("tsc_oldlists") && option("tsc_lines_gen") != 2 && std::fabs(offset) <= box / gxg &&
+            (int64_t)(nx_alloc / LN_TX) * (gy / LN_TY) * (gz / LN_TZ) >= 4096 && lines_geometry(nx_alloc, gy, gz, zstride, lg, lcfg)) {
+            g_lists.valid = false;
+            const L3Win wn{1, gxg, win, xoff, xoff2};
+            const int rc = lines3_build(pos, n, lg, lcfg, box, offset, wrap, 0, wrapped_out, wn);
+            if (rc == 0) return lines3_deposit(grid, 0, zero_grid, norm, sub);
+            if (rc < 0) return rc;
+            if (wrapped_out) lines_wrapped |= *wrapped_out;
         }
     }
     const int ext = share ? 1 : 0;
@@ -1650,12 +1669,12 @@ int tsc_deposit_f64mesh(void *pos, int pos_f64, int64_t n, const void *w, double
 // xoff2 >= 0, two windows of nx_local / 2 planes each starting at xoff and xoff2 (folded slabs) -; written as
 // rho*norm - sub (sub = 1: the overdensity's "-1" in every cell; a ghost block is then added to its owner as ghost + 1)
 int tsc_deposit_slab_f32(float *pos, int64_t n, const float *w, float *grid, int nmesh, int xoff, int nx_local,
-                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub, int xoff2) {
+                         int64_t zstride, double box, double offset, int wrap, double norm, int cic, double sub, int xoff2, int nx_alloc) {
     if (cic)
         return deposit_dev<float, float, true>(pos, n, w, grid, nx_local, nmesh, nmesh, zstride, box, offset, 0, 1, norm,
                                                nullptr, nmesh, xoff, sub, 0, xoff2);
     return deposit_dev<float, float, false>(pos, n, w, grid, nx_local, nmesh, nmesh, zstride, box, offset, wrap, 1, norm,
-                                            nullptr, nmesh, xoff, sub, 0, xoff2);
+                                            nullptr, nmesh, xoff, sub, 0, xoff2, nx_alloc);
 }
 int tsc_lines_clocks(unsigned long long *out32) {
     if (!g_lines_clk.p) {

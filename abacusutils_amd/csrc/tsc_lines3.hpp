@@ -55,18 +55,48 @@ __device__ __forceinline__ int l3_wrapB(int B, int nbk) {      // B <= 2 nbk
     return B;
 }
 
+// x-windows of a slab-decomposed mesh (analysis/slab_power.py: a rank's folded pair of slabs with their ghost planes, stored
+// back to back and padded to whole tiles): the local plane of global cell i is w * win + ((i - xoff_w) mod n).  A particle is
+// listed when its whole cloud lies inside one window (the particles a rank owns always do: ghost planes >= the cloud's reach);
+// the first window wins where both hold it; the others are skipped.  on = 0: the mesh is the whole periodic box.
+struct L3Win {
+    int on, n, win, xoff, xoff2;
+};
+// S of the x dimension -> the same coordinate in local planes; false: the particle is not listed
+template <bool EXT>
+__device__ __forceinline__ bool l3_window(const L3Win &wn, int &S) {
+    if (!wn.on) return true;
+    const int i = S >> 16, reach = EXT ? 2 : 1;
+    int u = i - wn.xoff;
+    u += u < 0 ? wn.n : 0;
+    u -= u >= wn.n ? wn.n : 0;
+    int base = 0;
+    bool in = u >= 1 && u + reach <= wn.win - 1;
+    if (!in && wn.xoff2 >= 0) {
+        u = i - wn.xoff2;
+        u += u < 0 ? wn.n : 0;
+        u -= u >= wn.n ? wn.n : 0;
+        in = u >= 1 && u + reach <= wn.win - 1;
+        base = wn.win;
+    }
+    S += (u + base - i) * 65536;
+    return in;
+}
+
 // ---- counting pass ---------------------------------------------------------------------------------------------
 // M[c][b] = records of chunk c in block b; ent[b] += tile entries of block b (EXT: of the 4-cell union cloud, a bound for both
 // origins).  Four particles per thread in flight (the second generation's one-particle loop ran at 2.7 TB/s: latency)
 template <int NB, bool EXT>
 __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int64_t n, LGeom g, double box, float offA, int wrap,
                                                     int64_t CH, unsigned int *__restrict__ M, unsigned int *__restrict__ ent,
-                                                    int *__restrict__ wrapped_flag) {
+                                                    int *__restrict__ wrapped_flag, L3Win wn) {
     __shared__ unsigned int hrec[NB], hent[NB];
     const int tid = threadIdx.x;
     for (int b = tid; b < NB; b += 512) hrec[b] = 0u, hent[b] = 0u;
     __syncthreads();
-    const float ih[3] = {(float)(g.n[0] / box) * 65536.f, (float)(g.n[1] / box) * 65536.f, (float)(g.n[2] / box) * 65536.f};
+    // (x: cells of the GLOBAL mesh - a slab's local mesh g.n[0] is only its windows)
+    const int ncell[3] = {wn.on ? wn.n : g.n[0], g.n[1], g.n[2]};
+    const float ih[3] = {(float)(ncell[0] / box) * 65536.f, (float)(g.n[1] / box) * 65536.f, (float)(g.n[2] / box) * 65536.f};
     const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
     const int lgbc[3] = {LN_SHX + g.sb[0], LN_SHY + g.sb[1], LN_SHZ + g.sb[2]};
     const int bst[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};
@@ -104,11 +134,12 @@ __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int
             int b0 = 0, nper = 1;
             unsigned int two = 0;
             int db[3];
+            bool listed = true;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
                 // the cell alone: the rounding draw matters only when the dropped bits can carry into it (once in 65536)
                 float y = (c[a] + offA) * ih[a];
-                y = fminf(fmaxf(y, -131072.f), (float)(g.n[a] + 2) * 65536.f);
+                y = fminf(fmaxf(y, -131072.f), (float)(ncell[a] + 2) * 65536.f);
                 const float fl = floorf(y);
                 int S = (int)fl + 32767;
                 if ((S & 0xffff) == 0xffff && y > fl) {
@@ -116,6 +147,7 @@ __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int
                     ln_hash(c[0], c[1], c[2], u);
                     S += (y - fl) > u[a] ? 1 : 0;
                 }
+                if (a == 0) listed = l3_window<EXT>(wn, S);
                 l3_dim<EXT>(S, g.n[a], lgbc[a], sh[a], d[a]);
                 const int B = l3_wrapB(d[a].Blo, g.nb[a]);
                 b0 += B * bst[a];
@@ -123,6 +155,7 @@ __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int
                 two |= d[a].two ? 1u << a : 0u;
                 nper *= d[a].two ? 1 : d[a].nt;
             }
+            if (!listed) continue;
             unsigned int e = 0u;                                  // every subset of the dimensions that have a second block
             do {
                 const int b = b0 + ((e & 1u) ? db[0] : 0) + ((e & 2u) ? db[1] : 0) + ((e & 4u) ? db[2] : 0);
@@ -198,22 +231,26 @@ struct L3Item {
 };
 template <bool EXT>
 __device__ __forceinline__ void l3_item(float x, float y, float z, float offset, const float ih[3], const LGeom &g, const int lgbc[3],
-                                        const int bst[3], L3Item &it) {
+                                        const int bst[3], const L3Win &wn, L3Item &it) {
     const float c[3] = {x, y, z};
     const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
     float u[3];
     ln_hash(x, y, z, u);
     it.b0 = 0u, it.two = 0u;
+    bool listed = true;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         L3Dim d;
-        l3_dim<EXT>(l3_S(c[a], offset, ih[a], g.n[a], u[a]), g.n[a], lgbc[a], sh[a], d);
+        int S = l3_S(c[a], offset, ih[a], (a == 0 && wn.on) ? wn.n : g.n[a], u[a]);
+        if (a == 0) listed = l3_window<EXT>(wn, S);
+        l3_dim<EXT>(S, g.n[a], lgbc[a], sh[a], d);
         const int B = l3_wrapB(d.Blo, g.nb[a]);
         it.b0 += (unsigned int)(B * bst[a]);
         it.db[a] = ((B + 1 == g.nb[a] ? 0 : B + 1) - B) * bst[a];
         it.two |= d.two ? 1u << a : 0u;
         it.w[a] = (unsigned int)(d.S + ((g.n[a] + 2 - (d.Blo << lgbc[a])) << 16));   // (cell in block + 2) << 16 | low bits of S
     }
+    if (!listed) it.b0 = 0x80000000u, it.two = 0u;
 }
 
 template <int NB, int LINE, int SBUF, int NT, bool EXT>
@@ -221,14 +258,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void li
                                                                                            float offA, int64_t CH, const unsigned int *__restrict__ M,
                                                                                            const unsigned int *__restrict__ gstart,
                                                                                            uint4 *__restrict__ staged, unsigned long long *clk,
-                                                                                           const unsigned int *__restrict__ need) {
+                                                                                           const unsigned int *__restrict__ need, L3Win wn) {
     __shared__ SplitLds<uint4, NB, LINE, SBUF, NT> s;
     const int tid = threadIdx.x, nb = g.nbuckets;
     if (need && need[3]) return;                          // the tables did not fit the buffers (lines3_tables): nothing is written
     split_init(s);
     for (int b = tid; b < NB; b += NT) s.base[b] = b < nb ? gstart[b] + M[(int64_t)blockIdx.x * nb + b] : 0u;
     __syncthreads();
-    const float ih[3] = {(float)(g.n[0] / box) * 65536.f, (float)(g.n[1] / box) * 65536.f, (float)(g.n[2] / box) * 65536.f};
+    const float ih[3] = {(float)((wn.on ? wn.n : g.n[0]) / box) * 65536.f, (float)(g.n[1] / box) * 65536.f, (float)(g.n[2] / box) * 65536.f};
     const int lgbc[3] = {LN_SHX + g.sb[0], LN_SHY + g.sb[1], LN_SHZ + g.sb[2]};
     const int bst[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};
     const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
@@ -252,7 +289,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void li
     auto geometry = [&](int64_t s0) {          // (unconditional: an if / else over the items' fields left them in scratch memory)
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            l3_item<EXT>(q[k].x, q[k].y, q[k].z, offA, ih, g, lgbc, bst, it[k]);
+            l3_item<EXT>(q[k].x, q[k].y, q[k].z, offA, ih, g, lgbc, bst, wn, it[k]);
             const bool live = s0 + k * NT + tid < p1;
             it[k].b0 |= live ? 0u : 0x80000000u;
             it[k].two = live ? it[k].two : 0u;

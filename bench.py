@@ -336,8 +336,20 @@ def bench_calls(args, dist):
         run(i)
         state['pk'] = ball.compute_power(state['m'], 32, 4, 0.5, False, poles=[0, 2], num_cells=512)
 
+    def run_pk550(i):   # compute_power's own default mesh (hod/abacus_hod.py:1347) with the reference's default estimator of calc_power
+        run(i)
+        state['pk'] = ball.compute_power(state['m'], 32, 4, 0.5, False, poles=[0, 2], num_cells=550, compensated=True, interlaced=True)
+
     out['run_hod_plus_compute_wp_ms'] = loop(10, run_wp)
     out['run_hod_plus_compute_power_ms'] = loop(10, run_pk)
+    try:
+        from abacusutils_amd import _lib
+        out['run_hod_plus_compute_power_550_interlaced_ms'] = loop(10, run_pk550)
+        _lib.set_option('pk_noxbin_inter', 1)           # two x passes + spectrum_bin<INTER>: what round 4 ran
+        out['run_hod_plus_compute_power_550_interlaced_unfused_ms'] = loop(10, run_pk550)
+        _lib.set_option('pk_noxbin_inter', 0)
+    except Exception as e:   # noqa: BLE001
+        out['run_hod_plus_compute_power_550_interlaced_ms'] = repr(e)
     out['compute_note'] = 'lazy mock fed to compute_wp (8 log bins to 30 Mpc/h, pimax 30) / compute_power (512^3 TSC, 32 x 4 bins, poles 0, 2): galaxies never leave HBM'
     if ball._staged is not None:
         ball._staged.free()

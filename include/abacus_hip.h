@@ -326,6 +326,12 @@ int abacus_slab_pitch(int nmesh);
  * on the subtraction; xoff2 < 0 and nx_local == nmesh with xoff == 0 is the whole periodic mesh (one rank: no ghosts) */
 int abacus_slab_deposit_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int xoff2, int nx_local,
                             double Lbox, double offset, double norm, int paste, double sub);
+/* the same with a `mesh` buffer the caller padded to nx_alloc planes, nx_alloc the window planes (nx_local, or 2 nx_local with two
+ * windows) rounded up to a multiple of 16: unweighted float32 TSC of >= 2e6 particles then takes the third-generation list build
+ * of the single-GPU path on the windows' local planes (csrc/tsc_lines3.hpp, L3Win); the padding planes are overwritten.
+ * nx_alloc = 0: no padding, the first-generation lists (what abacus_slab_deposit_dev runs). */
+int abacus_slab_deposit_padded_dev(float *pos, int64_t n, const float *w, float *mesh, int nmesh, int xoff, int xoff2, int nx_local,
+                                   double Lbox, double offset, double norm, int paste, double sub, int nx_alloc);
 /* dst[i] += src[i] + add  (ghost-plane accumulation; a constant alone with src == NULL) */
 int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add);
 /* FOLDED SLABS.  With W ranks the mesh is cut into 2 W slabs of h = nmesh / (2 W) planes and rank r owns slabs r and

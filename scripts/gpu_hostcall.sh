@@ -27,9 +27,14 @@ for what in ('pageable', 'pinned'):
 for nmesh in (1024, 2048):
     kw = dict(kbins=512, mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste='TSC', nmesh=nmesh, compensated=False,
               interlaced=False, poles=[0, 2, 4])
-    for rep in range(3):
-        t = time.perf_counter(); tab = calc_power(pos, L, **kw); dt = time.perf_counter() - t
-        print(f'calc_power from NumPy, nmesh {nmesh}: {dt * 1e3:.1f} ms (P mean {float(np.mean(tab["power"])):.3f})', flush=True)
+    import ctypes as C
+    last = _lib.lib().abacus_power_last_batches; last.restype = C.c_double
+    for opt in (0, 1):      # batched upload behind the deposits (the default where it pays) / one copy in front (pk_nobatch)
+        _lib.set_option('pk_nobatch', opt)
+        for rep in range(3):
+            t = time.perf_counter(); tab = calc_power(pos, L, **kw); dt = time.perf_counter() - t
+            print(f'calc_power from NumPy, nmesh {nmesh}, {int(last())} upload batch(es): {dt * 1e3:.1f} ms (P mean {float(np.mean(tab["power"])):.3f})', flush=True)
+    _lib.set_option('pk_nobatch', 0)
     moved = pos.copy(); moved[::1000, 0] += np.float32(L)
     t = time.perf_counter(); calc_power(moved, L, **kw); dt = time.perf_counter() - t
     print(f'  with positions to wrap (copied back): {dt * 1e3:.1f} ms', flush=True)

@@ -177,6 +177,49 @@ def test_two_window_deposit_of_a_rank_equals_the_planes_of_the_full_mesh(world, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('world,rank', [(8, 7), (8, 0), (4, 2)])
+def test_two_window_deposit_takes_the_block_record_lists(world, rank):
+    """unweighted float32 TSC into a rank's two windows, the buffer padded to whole 16-plane tiles as calc_power_slab allocates it:
+    the deposit runs the third-generation list build of the single-GPU path on the windows' local planes (csrc/tsc_lines3.hpp,
+    L3Win; asserted from the profiler) and every window plane equals the same plane of the whole-mesh deposit of those
+    particles - to the resolution of the per-tile fixed-point sums (the two meshes tile differently); rank W - 1 / rank 0: the
+    windows that wrap around the box"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis import slab_power as sp
+    box, G, nmesh, n = 700.0, sp.GHOST, 1024, 20_000_000
+    h = nmesh // (2 * world)
+    rng = np.random.default_rng(world * 10 + rank)
+    pos = (rng.random((n, 3), dtype=np.float32) * np.float32(box)).astype(np.float32)
+    pos = np.ascontiguousarray(pos[sp.slab_owner(pos[:, 0], box, world, True) == rank])
+    assert len(pos) >= 2_000_000
+    be = sp.HipSlabBackend()
+    pitch = be.pitch(nmesh)
+    plane = nmesh * pitch
+    win = h + 2 * G
+    xa, xb = (rank * h - G) % nmesh, (rank * h + nmesh // 2 - G) % nmesh
+    full = sp.HipBuf(nmesh * plane)
+    be.deposit(be.upload_particles(pos, None), full, nmesh, 0, nmesh, box, 0.0, 1.0, 0, sub=0.0)
+    F = full.get(0, nmesh * plane).reshape(nmesh, nmesh, pitch)[:, :, :nmesh]
+    full.free()
+    padded = -(-2 * win // 16) * 16
+    two = sp.HipBuf(padded * plane)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    be.deposit(be.upload_particles(pos, None), two, nmesh, xa, win, box, 0.0, 1.0, 0, sub=0.0, xoff2=xb)
+    _lib.profile_enable(False)
+    prof = _lib.profile_get()
+    assert 'tsc_lines_coarse' in prof and 'tsc_ms_coarse_scatter' not in prof, sorted(prof)
+    T = two.get(0, padded * plane).reshape(padded, nmesh, pitch)[:, :, :nmesh]
+    two.free()
+    assert abs(float(T.sum(dtype='f8')) / len(pos) - 1) < 2e-6          # every owned particle's whole cloud is in the windows
+    scale = float(F.max())
+    for k, x0 in enumerate((xa, xb)):
+        for i in range(win):
+            np.testing.assert_allclose(T[k * win + i], F[(x0 + i) % nmesh], rtol=2e-6, atol=2e-6 * scale, err_msg=f'window {k} plane {i}')
+    assert not T[2 * win:].any()                                         # the padding planes
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('world,nmesh,comp', [(8, 1024, 0), (8, 256, 1), (4, 512, 1), (8, 2048, 1)])
 def test_eight_ranks_as_threads_on_one_gpu(world, nmesh, comp):
     """the north-star rank count on the one GPU of the box: W ranks of calc_power_slab as THREADS (tests/thread_comm.py; the
