@@ -1176,7 +1176,8 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
     unsigned int *ent = tot + nb + 1;
     HIP_TRY(hipMemsetAsync(flag, 0, (size_t)(nb + 1) * sizeof(unsigned int), stream()));
     const float offA = (float)offset;
-#define L3_COUNT(NBK, EXT_) ABACUS_LAUNCH("tsc_lines_count", (lines3_count<NBK, EXT_>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, ent, flag, wn)
+    const size_t count_lds = (size_t)3 * (std::max({wn.on ? wn.n : g.n[0], g.n[1], g.n[2]}) + 5) * sizeof(unsigned int);
+#define L3_COUNT(NBK, EXT_) ABACUS_LAUNCH("tsc_lines_count", (lines3_count<NBK, EXT_>), dim3(nchunk), dim3(512), count_lds, pos, n, g, box, offA, wrap, CH, M, ent, flag, wn)
     if (cfg == 0) {
         if (ext) L3_COUNT(256, true);
         else L3_COUNT(256, false);

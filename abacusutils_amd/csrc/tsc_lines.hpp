@@ -365,18 +365,35 @@ __device__ __forceinline__ bool split_round(SplitLds<E, NB, LINE, SBUF, NT> &s, 
     tick(4);
     __syncthreads();
     tick(5);
-    if (!(dbg & 32))
-    place([&](int b, const E &e) {
-        const uint4 P = s.pl[b];
-        const unsigned int k = atomicAdd(&s.lcur[b], 1u);
-        if ((int)k < (int)P.y) {
-            const unsigned int o = P.x + k;
-            s.out[o] = SplitKeep<E>::pack(e);
-            s.gdx[o] = P.w + o;
-        } else {
-            s.carry[P.z + k] = SplitKeep<E>::pack(e);
-        }
-    });
+    if (!(dbg & 32)) {
+        // two ways to place: `place(f)` with f(bucket, entry) doing everything per entry (an LDS round trip per entry: the rank
+        // comes back before the entry can go anywhere), or `place(rank, put)`: the caller takes the ranks of SEVERAL entries first
+        // - their atomics are in flight together - and hands each entry over afterwards
+        auto rank = [&](int b) { return atomicAdd(&s.lcur[b], 1u); };
+        auto put = [&](int b, unsigned int k, const E &e) {
+            const uint4 P = s.pl[b];
+            if ((int)k < (int)P.y) {
+                const unsigned int o = P.x + k;
+                s.out[o] = SplitKeep<E>::pack(e);
+                s.gdx[o] = P.w + o;
+            } else {
+                s.carry[P.z + k] = SplitKeep<E>::pack(e);
+            }
+        };
+        if constexpr (std::is_invocable_v<PLACE, decltype(rank), decltype(put)>) place(rank, put);
+        else
+            place([&](int b, const E &e) {
+                const uint4 P = s.pl[b];
+                const unsigned int k = atomicAdd(&s.lcur[b], 1u);
+                if ((int)k < (int)P.y) {
+                    const unsigned int o = P.x + k;
+                    s.out[o] = SplitKeep<E>::pack(e);
+                    s.gdx[o] = P.w + o;
+                } else {
+                    s.carry[P.z + k] = SplitKeep<E>::pack(e);
+                }
+            });
+    }
     tick(6);
     __syncthreads();
     tick(7);

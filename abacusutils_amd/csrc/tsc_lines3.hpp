@@ -86,19 +86,41 @@ __device__ __forceinline__ bool l3_window(const L3Win &wn, int &S) {
 // ---- counting pass ---------------------------------------------------------------------------------------------
 // M[c][b] = records of chunk c in block b; ent[b] += tile entries of block b (EXT: of the 4-cell union cloud, a bound for both
 // origins).  Four particles per thread in flight (the second generation's one-particle loop ran at 2.7 TB/s: latency)
+// What the counting pass needs of a coordinate is a function of its nearest cell alone: a table per dimension, built in LDS by
+// every workgroup (3 (n + 5) words: cells -2 .. n + 2), replaces ~35 vector instructions per particle and dimension (block of
+// the cloud's two ends, periodic wraps, the window map of a slab mesh) by one LDS read - the pass was bound by vector issue
+// (SQ counters, profiles/r05): 170 instructions per particle.  Entry: bits 0..9 the block's bucket contribution / stride,
+// 10..20 the bucket delta of the second block / stride + 1024, 21 two blocks, 22 two tiles, 23 not listed (slab windows)
+template <bool EXT>
+__device__ __forceinline__ unsigned int l3_count_entry(int i, int a, const LGeom &g, const L3Win &wn) {
+    const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
+    const int lgbc = sh[a] + g.sb[a];
+    int S = i * 65536 + 32768;                              // any coordinate whose nearest cell is i
+    const bool listed = a == 0 ? l3_window<EXT>(wn, S) : true;
+    L3Dim d;
+    l3_dim<EXT>(S, g.n[a], lgbc, sh[a], d);
+    const int B = l3_wrapB(max(d.Blo, 0), g.nb[a]);
+    const int dB = (B + 1 == g.nb[a] ? 0 : B + 1) - B;
+    return (unsigned int)B | ((unsigned int)(dB + 1024) << 10) | (d.two ? 1u << 21 : 0u) | (d.nt == 2 ? 1u << 22 : 0u) | (listed ? 0u : 1u << 23);
+}
+
 template <int NB, bool EXT>
 __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int64_t n, LGeom g, double box, float offA, int wrap,
                                                     int64_t CH, unsigned int *__restrict__ M, unsigned int *__restrict__ ent,
                                                     int *__restrict__ wrapped_flag, L3Win wn) {
     __shared__ unsigned int hrec[NB], hent[NB];
+    extern __shared__ unsigned int l3_tab[];              // [3][tabn]
     const int tid = threadIdx.x;
-    for (int b = tid; b < NB; b += 512) hrec[b] = 0u, hent[b] = 0u;
-    __syncthreads();
     // (x: cells of the GLOBAL mesh - a slab's local mesh g.n[0] is only its windows)
     const int ncell[3] = {wn.on ? wn.n : g.n[0], g.n[1], g.n[2]};
+    const int tabn = max(ncell[0], max(ncell[1], ncell[2])) + 5;
+    for (int b = tid; b < NB; b += 512) hrec[b] = 0u, hent[b] = 0u;
+    for (int q = tid; q < 3 * tabn; q += 512) {
+        const int a = q / tabn, i = q - a * tabn - 2;
+        l3_tab[q] = i <= ncell[a] + 2 ? l3_count_entry<EXT>(i, a, g, wn) : 0u;
+    }
+    __syncthreads();
     const float ih[3] = {(float)(ncell[0] / box) * 65536.f, (float)(g.n[1] / box) * 65536.f, (float)(g.n[2] / box) * 65536.f};
-    const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
-    const int lgbc[3] = {LN_SHX + g.sb[0], LN_SHY + g.sb[1], LN_SHZ + g.sb[2]};
     const int bst[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};
     const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
     bool any_changed = false;
@@ -130,11 +152,7 @@ __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int
                 }
             }
             const float c[3] = {q[k].x, q[k].y, q[k].z};
-            L3Dim d[3];
-            int b0 = 0, nper = 1;
-            unsigned int two = 0;
-            int db[3];
-            bool listed = true;
+            unsigned int t[3];
 #pragma unroll
             for (int a = 0; a < 3; a++) {
                 // the cell alone: the rounding draw matters only when the dropped bits can carry into it (once in 65536)
@@ -147,20 +165,21 @@ __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int
                     ln_hash(c[0], c[1], c[2], u);
                     S += (y - fl) > u[a] ? 1 : 0;
                 }
-                if (a == 0) listed = l3_window<EXT>(wn, S);
-                l3_dim<EXT>(S, g.n[a], lgbc[a], sh[a], d[a]);
-                const int B = l3_wrapB(d[a].Blo, g.nb[a]);
-                b0 += B * bst[a];
-                db[a] = ((B + 1 == g.nb[a] ? 0 : B + 1) - B) * bst[a];
-                two |= d[a].two ? 1u << a : 0u;
-                nper *= d[a].two ? 1 : d[a].nt;
+                t[a] = l3_tab[a * tabn + (S >> 16) + 2];
             }
-            if (!listed) continue;
+            if ((t[0] >> 23) & 1u) continue;                   // not listed (outside the slab's windows)
+            const int b0 = (int)(t[0] & 1023u) * bst[0] + (int)(t[1] & 1023u) * bst[1] + (int)(t[2] & 1023u);
+            const int db[3] = {((int)((t[0] >> 10) & 2047u) - 1024) * bst[0], ((int)((t[1] >> 10) & 2047u) - 1024) * bst[1],
+                               (int)((t[2] >> 10) & 2047u) - 1024};
+            const unsigned int two = ((t[0] >> 21) & 1u) | (((t[1] >> 21) & 1u) << 1) | (((t[2] >> 21) & 1u) << 2);
+            // tile entries of each block the cloud touches: a dimension with two blocks gives one tile to each
+            const unsigned int nper = (((t[0] >> 21) & 1u) ? 1u : 1u + ((t[0] >> 22) & 1u)) * (((t[1] >> 21) & 1u) ? 1u : 1u + ((t[1] >> 22) & 1u)) *
+                                      (((t[2] >> 21) & 1u) ? 1u : 1u + ((t[2] >> 22) & 1u));
             unsigned int e = 0u;                                  // every subset of the dimensions that have a second block
             do {
                 const int b = b0 + ((e & 1u) ? db[0] : 0) + ((e & 2u) ? db[1] : 0) + ((e & 4u) ? db[2] : 0);
                 atomicAdd(&hrec[b], 1u);
-                atomicAdd(&hent[b], (unsigned int)nper);
+                atomicAdd(&hent[b], nper);
                 e = (e - two) & two;
             } while (e);
         }
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void li
     int par = 0;
     LnF3 q[PPT];
     L3Item it[PPT];
-    auto load = [&](int64_t s0) {
+    auto load = [&](int64_t s0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
             const int64_t p = s0 + k * NT + tid;
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void li
             if (p < p1) q[k] = *reinterpret_cast<const LnF3 *>(pos + 3 * p);
         }
     };
-    auto geometry = [&](int64_t s0) {          // (unconditional: an if / else over the items' fields left them in scratch memory)
+    auto geometry = [&](int64_t s0) __attribute__((always_inline)) {          // (unconditional: an if / else over the items' fields left them in scratch memory)
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
             l3_item<EXT>(q[k].x, q[k].y, q[k].z, offA, ih, g, lgbc, bst, wn, it[k]);
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void li
     int par = 0;
     uint4 nx[PPT];
     L3Rec q[PPT];
-    auto load = [&](unsigned int s0) {
+    auto load = [&](unsigned int s0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
             const unsigned int e = s0 + k * NT + tid;
@@ -438,7 +457,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void li
         }
     };
     if (pc.e0 >= pc.e1) return;
-    auto decode = [&](unsigned int s0) {
+    auto decode = [&](unsigned int s0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
             l3_decode<ORG>(nx[k], g, lgbc, q[k]);
@@ -467,6 +486,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void li
                 }
             };
         };
+        // (taking the ranks of a record's 1 .. 8 entries together - eight predicated slots per record, their LDS atomics in
+        // flight at once - was measured: 1.83 ms against 1.12 for this per-lane loop at BASELINE config 3; a wave executes every
+        // slot one of its lanes fills)
         auto place = [&](int groups, int gi) {
             return [&, groups, gi](auto f) {
 #pragma unroll
