@@ -421,7 +421,9 @@ struct GXArgs {
 // binned as |(a + a' exp(i pi (i + j + k) / n)) f32(0.5 / M)|^2 with signed-folded i, j (shift_field_fft, :904-948; i = n/2
 // folds to -n/2) - what spectrum_bin<INTER> computes from two spectra in HBM, without the two x passes writing them and the
 // binning reading them back.
-template <bool INTER>
+// LEAN: the twiddle table and the per-kz mu thresholds stay in global memory (read through the vector cache) - what lets a
+// 1536-row tile, the float64 histogram of 512 k bins and the cell table share the 160 KiB of LDS
+template <bool INTER, bool LEAN>
 __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__ data, GXArgs g, GPlan p, const C2<float> *__restrict__ twn,
                                                    BinArgs b, XDesc d) {
     typedef float T;
@@ -429,20 +431,23 @@ __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__
     extern __shared__ __align__(16) unsigned char smem[];
     const int n = g.n, lgC = g.lgG + 2, C = 1 << lgC, P = C + 1;
     const int Nk = b.Nk, Nmu = b.Nmu, nrow = Nk + 2, nbx = nrow * Nmu;
-    C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
-    C2<T> *lds = tw + n;
+    C2<T> *twl = reinterpret_cast<C2<T> *>(smem);
+    C2<T> *lds = twl + (LEAN ? 0 : n);
     C2<T> *lds2 = lds + (size_t)n * P;                                 // the shifted field's tile (INTER)
     double *h_sum = reinterpret_cast<double *>(lds + (size_t)n * P * (INTER ? 2 : 1));
     double *h_m2 = h_sum + nbx, *h_m4 = h_m2 + nrow;
     unsigned int *lut = reinterpret_cast<unsigned int *>(h_m4 + nrow);
     int *Ul = reinterpret_cast<int *>(lut + d.ncell);
-    float *Wl = reinterpret_cast<float *>(Ul + g.kzlen * g.ustride);
+    float *Wl = reinterpret_cast<float *>(Ul + (LEAN ? 0 : g.kzlen * g.ustride));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int q = tid; q < n; q += G_NT) tw[q] = twn[q];
+    const C2<T> *tw = LEAN ? twn : twl;
+    if (!LEAN)
+        for (int q = tid; q < n; q += G_NT) twl[q] = twn[q];
     for (int q = tid; q < nbx; q += G_NT) h_sum[q] = 0.0;
     for (int q = tid; q < 2 * nrow; q += G_NT) h_m2[q] = 0.0;
     for (int q = tid; q < d.ncell; q += G_NT) lut[q] = d.lut[q];
-    for (int q = tid; q < g.kzlen * g.ustride; q += G_NT) Ul[q] = d.U[(q / g.ustride) * XD_USTRIDE + q % g.ustride];
+    if (!LEAN)
+        for (int q = tid; q < g.kzlen * g.ustride; q += G_NT) Ul[q] = d.U[(q / g.ustride) * XD_USTRIDE + q % g.ustride];
     const bool comp = g.W != nullptr;
     if (comp)
         for (int q = tid; q < n; q += G_NT) Wl[q] = g.W[q];
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__
             if (k >= g.kzlen || r2 > d.vtop) continue;             // padding column / the whole column beyond the last edge
             int Uk[7];
 #pragma unroll
-            for (int m = 0; m < 7; m++) Uk[m] = m < nmu1 ? Ul[k * g.ustride + m] : -2;
+            for (int m = 0; m < 7; m++) Uk[m] = m < nmu1 ? (LEAN ? d.U[k * XD_USTRIDE + m] : Ul[k * g.ustride + m]) : -2;
             const float k2f = (float)(k * k), scale = (k == 0 ? 1.f : 2.f) * g.inv2;      // weight (:258-262) x f32(1/M)^2 (:1058-1060)
             const float wjk = comp ? Wl[j] * Wl[k] : 1.f;
             int cur = 0, curk = 0;
@@ -725,15 +730,22 @@ int r2c_inplace(T *mesh, int n, int pitch_r, float xcut = 0.f, bool skip_x = fal
 }
 
 // LDS of gfft_x_bin beside the cell table, and the column-tile width it leaves room for (lgG: C = 4 << lgG; -1: none)
-size_t gxbin_lds_other(int n, int C, int Nk, int Nmu, bool comp, bool inter = false) {
-    return ((size_t)n + (size_t)n * (C + 1) * (inter ? 2 : 1)) * 8 + (size_t)(Nk + 2) * Nmu * 8 + (size_t)2 * (Nk + 2) * 8 +
-           (size_t)(n / 2 + 1) * std::max(Nmu - 1, 1) * 4 + (comp ? (size_t)n * 4 : 0) + 16;
+size_t gxbin_lds_other(int n, int C, int Nk, int Nmu, bool comp, bool inter = false, bool lean = false) {
+    return ((lean ? 0 : (size_t)n) + (size_t)n * (C + 1) * (inter ? 2 : 1)) * 8 + (size_t)(Nk + 2) * Nmu * 8 + (size_t)2 * (Nk + 2) * 8 +
+           (lean ? 0 : (size_t)(n / 2 + 1) * std::max(Nmu - 1, 1) * 4) + (comp ? (size_t)n * 4 : 0) + 16;
 }
-int gxbin_lgG(int n, int Nk, int Nmu, bool comp, bool inter = false) {
-    for (int lgG = 2; lgG >= 1; lgG--) {     // 16 or 8 columns: 4 would read 32-byte row segments (0.4 of the 64-byte rate)
-        const int C = 4 << lgG;
-        if ((int64_t)C * n <= (int64_t)maxv<float>() * G_NT && gxbin_lds_other(n, C, Nk, Nmu, comp, inter) + 6 * 1024 <= 160 * 1024) return lgG;
-    }
+// column-tile width (lgG: C = 4 << lgG) and whether the lean form (twiddles and mu thresholds in global memory) is needed; -1: none
+int gxbin_lgG(int n, int Nk, int Nmu, bool comp, bool inter = false, bool *lean_out = nullptr) {
+    for (int lean = 0; lean < 2; lean++)
+        for (int lgG = 2; lgG >= 1; lgG--) {     // 16 or 8 columns: 4 would read 32-byte row segments (0.4 of the 64-byte rate)
+            const int C = 4 << lgG;
+            // room for the cell table beside it: 6 KiB at least (24 KiB with the fine bins a mesh beyond 1152 brings)
+            const size_t room = n > 1152 ? 24 * 1024 : 6 * 1024;
+            if ((int64_t)C * n <= (int64_t)maxv<float>() * G_NT && gxbin_lds_other(n, C, Nk, Nmu, comp, inter, lean != 0) + room <= 160 * 1024) {
+                if (lean_out) *lean_out = lean != 0;
+                return lgG;
+            }
+        }
     return -1;
 }
 bool gxbin_shape_ok(int n, const BinArgs &b) {
@@ -773,11 +785,12 @@ int gfft_r2c_zy_f32(float *mesh, int n, int pitch_r) { return r2c_inplace<float>
 // can the fused last pass serve this mesh / histogram?  (builds the geometry descriptor of (n, edges) on first use)
 bool gfft_xbin_supported(int n, const BinArgs &b, bool comp, bool inter) {
     if (!gxbin_shape_ok(n, b)) return false;
-    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp, inter);
+    bool lean = false;
+    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp, inter, &lean);
     if (lgG < 0) return false;
     XDesc d;
     int ok = 0;
-    if (xdesc_lookup(n, b, comp, gxbin_lds_other(n, 4 << lgG, b.Nk, b.Nmu, comp, inter), &d.lut, &d.U, &d.ncell, &d.sh, &d.off, &d.vtop, &d.cnt, &d.ksum,
+    if (xdesc_lookup(n, b, comp, gxbin_lds_other(n, 4 << lgG, b.Nk, b.Nmu, comp, inter, lean), &d.lut, &d.U, &d.ncell, &d.sh, &d.off, &d.vtop, &d.cnt, &d.ksum,
                      &ok) != 0)
         return false;
     return ok != 0;
@@ -789,10 +802,11 @@ int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const 
                    const void *phase) {
     const bool comp = W_dev != nullptr, inter = mesh2 != nullptr;
     if (!gxbin_shape_ok(n, b)) return fail("gfft_x_bin: unsupported mesh / histogram");
-    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp, inter);
+    bool lean = false;
+    const int lgG = gxbin_lgG(n, b.Nk, b.Nmu, comp, inter, &lean);
     if (lgG < 0) return fail("gfft_x_bin: histogram does not fit beside a tile of %d rows", n);
     const int C = 4 << lgG, pitch_c = pitch_r / 2, kzlen = n / 2 + 1;
-    const size_t other = gxbin_lds_other(n, C, b.Nk, b.Nmu, comp, inter);
+    const size_t other = gxbin_lds_other(n, C, b.Nk, b.Nmu, comp, inter, lean);
     XDesc d;
     int ok = 0;
     ABACUS_TRY(xdesc_lookup(n, b, comp, other, &d.lut, &d.U, &d.ncell, &d.sh, &d.off, &d.vtop, &d.cnt, &d.ksum, &ok));
@@ -810,15 +824,20 @@ int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const 
     g.inv2 = hs * hs;
     if (g.ntile_c * C > pitch_c) return fail("gfft_x_bin: row pitch too small");
     const size_t lds = other + (size_t)d.ncell * 4;
-    static size_t lds_set[2] = {0, 0};
-    if (lds > lds_set[inter]) {
-        HIP_TRY(hipFuncSetAttribute(inter ? reinterpret_cast<const void *>(gfft_x_bin<true>) : reinterpret_cast<const void *>(gfft_x_bin<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set[inter] = lds;
+    static size_t lds_set[4] = {0, 0, 0, 0};
+    const void *kerns[4] = {reinterpret_cast<const void *>(gfft_x_bin<false, false>), reinterpret_cast<const void *>(gfft_x_bin<true, false>),
+                            reinterpret_cast<const void *>(gfft_x_bin<false, true>), reinterpret_cast<const void *>(gfft_x_bin<true, true>)};
+    const int kv = (inter ? 1 : 0) + (lean ? 2 : 0);
+    if (lds > lds_set[kv]) {
+        HIP_TRY(hipFuncSetAttribute(kerns[kv], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[kv] = lds;
     }
     const unsigned int grid = (unsigned int)std::min<int64_t>((int64_t)n * g.ntile_c, (int64_t)num_cus_g() * (lds > 80 * 1024 ? 1 : 2));
-    if (inter) ABACUS_LAUNCH("gfft_x_bin", gfft_x_bin<true>, dim3(grid), dim3(G_NT), lds, reinterpret_cast<const C2<float> *>(mesh), g, pn, twn, b, d);
-    else ABACUS_LAUNCH("gfft_x_bin", gfft_x_bin<false>, dim3(grid), dim3(G_NT), lds, reinterpret_cast<const C2<float> *>(mesh), g, pn, twn, b, d);
+    const C2<float> *m0 = reinterpret_cast<const C2<float> *>(mesh);
+    if (kv == 0) ABACUS_LAUNCH("gfft_x_bin", (gfft_x_bin<false, false>), dim3(grid), dim3(G_NT), lds, m0, g, pn, twn, b, d);
+    else if (kv == 1) ABACUS_LAUNCH("gfft_x_bin", (gfft_x_bin<true, false>), dim3(grid), dim3(G_NT), lds, m0, g, pn, twn, b, d);
+    else if (kv == 2) ABACUS_LAUNCH("gfft_x_bin", (gfft_x_bin<false, true>), dim3(grid), dim3(G_NT), lds, m0, g, pn, twn, b, d);
+    else ABACUS_LAUNCH("gfft_x_bin", (gfft_x_bin<true, true>), dim3(grid), dim3(G_NT), lds, m0, g, pn, twn, b, d);
     return 0;
 }
 int gfft_release() {

@@ -883,7 +883,13 @@ __global__ __launch_bounds__(NT) void lines_deposit32(const unsigned long long *
                 w3[a][0] = 0.5f * (tm * tm);
                 w3[a][2] = 0.5f * (tp * tp);
             }
+            // the three z weights in the four cells of the two aligned pairs they fall into (one of the outer two is empty): decided
+            // once per entry, so that a row costs four scaled products (packed two by two) and no selects (SQ counters: the kernel
+            // keeps the vector units 2/3 busy)
+            typedef float ln_v2f __attribute__((ext_vector_type(2)));
             const bool odd = lz & 1;
+            const ln_v2f wzA = {odd ? 0.f : wz[0], odd ? wz[0] : wz[1]}, wzB = {odd ? wz[1] : wz[2], odd ? wz[2] : 0.f};
+            const ln_v2f fx2 = {fx, fx}, half2 = {0.5f, 0.5f};
             unsigned long long *zpair = reinterpret_cast<unsigned long long *>(tile) + (lz >> 1);   // cells lz .. lz + 2 of a halo'd row
 #pragma unroll
             for (int a = 0; a < 3; a++) {
@@ -894,14 +900,12 @@ __global__ __launch_bounds__(NT) void lines_deposit32(const unsigned long long *
                     const int cy = ly - 2 + b;
                     if ((unsigned)cy >= (unsigned)LN_TY) continue;
                     const float wxy = wx[a] * wy[b];
-                    unsigned int sc[3];
-#pragma unroll
-                    for (int c = 0; c < 3; c++) sc[c] = (unsigned int)__builtin_fmaf(wxy * wz[c], fx, 0.5f);   // (wx wy) wz, tsc.py:471-507
-                    const unsigned long long A = odd ? (unsigned long long)sc[0] << 32 : ((unsigned long long)sc[1] << 32) | sc[0];
-                    const unsigned long long B = odd ? ((unsigned long long)sc[2] << 32) | sc[1] : (unsigned long long)sc[2];
+                    const ln_v2f w2 = {wxy, wxy};
+                    // (wx wy) wz, tsc.py:471-507, as packed float32 operations (v_pk_mul_f32 / v_pk_fma_f32: the same roundings)
+                    const ln_v2f sA = __builtin_elementwise_fma(w2 * wzA, fx2, half2), sB = __builtin_elementwise_fma(w2 * wzB, fx2, half2);
                     unsigned long long *cell = zpair + (cx * LN_TY + cy) * (LN_ZP / 2);
-                    atomicAdd(cell, A);
-                    atomicAdd(cell + 1, B);
+                    atomicAdd(cell, ((unsigned long long)(unsigned int)sA.y << 32) | (unsigned int)sA.x);
+                    atomicAdd(cell + 1, ((unsigned long long)(unsigned int)sB.y << 32) | (unsigned int)sB.x);
                 }
             }
         };

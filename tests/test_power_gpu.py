@@ -847,3 +847,30 @@ def test_host_positions_uploaded_in_batches_behind_the_deposits(interlaced, opti
     np.testing.assert_allclose(a['power'], b['power'], rtol=2e-6, atol=2e-7 * scale)
     _check_oracle(a, oracle.calc_power(p3, box, nthread=oracle.max_threads(), accum64=True, **kw))
     np.testing.assert_array_equal(p1, p3)
+
+
+def test_mixed_radix_1536_fused_last_pass(options):
+    """1536^3 (the bench's `pk_1536` leg): the 1536-row tile, the float64 histogram of 512 k bins and the cell table only share the
+    LDS in the lean form of gfft_x_bin (twiddles and mu thresholds read from global memory) - against the separate x pass +
+    spectrum_bin mode by mode, with the bench's 2-dk bins and with coarse compensated bins"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    box, nmesh = 2000.0, 1536
+    pos = synth.synth_positions(3_000_000, box, seed=1536, clustered=True)
+    for kw in (dict(kbins=512, mubins=4, k_max=np.pi * nmesh / box + 1e-6, poles=[0, 2, 4], compensated=False),
+               dict(kbins=48, mubins=3, poles=[0, 2], compensated=True)):
+        kw = dict(kw, paste='TSC', nmesh=nmesh, interlaced=False)
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        a = calc_power(pos.copy(), box, **kw)
+        _lib.profile_enable(False)
+        prof = _lib.profile_get()
+        assert 'gfft_x_bin' in prof and 'spectrum_bin' not in prof and 'gfft_cols_x' not in prof, sorted(prof)
+        options.set('pk_noxbin', 1)
+        b = calc_power(pos.copy(), box, **kw)
+        options.set('pk_noxbin', 0)
+        np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
+        scale = np.abs(np.asarray(b['power'])).max()
+        np.testing.assert_allclose(a['power'], b['power'], rtol=3e-6, atol=3e-7 * scale)
+        np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)
+        np.testing.assert_allclose(a['poles'], b['poles'], rtol=3e-6, atol=5e-7 * scale)
