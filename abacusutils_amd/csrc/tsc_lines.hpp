@@ -919,7 +919,12 @@ __global__ __launch_bounds__(NT) void lines_deposit32(const unsigned long long *
             const int ox = ((B0 << g.sb[0]) + fx_) << LN_SHX, oy = ((B1 << g.sb[1]) + fy) << LN_SHY, oz = ((B2 << g.sb[2]) + fz) << LN_SHZ;
             const unsigned int cnt = bcn[tt];
             const int64_t e0 = bst[tt];
-            const int S = min(32 - (31 - __clz((int)max(cnt, 1u))), 30);
+            // a list beyond 2^17 entries (a pile-up: millions of particles in one tile) is accumulated and flushed in slices of
+            // 2^17, the mesh taking the float32 sum of the slices: the scale of a slice never drops below 2^15 (with ONE scale
+            // for 2.3e6 entries, 2^11, the addends below 2^-12 - the corners of every cloud - were lost: 6e-5 of the mass)
+            constexpr unsigned int SLICE = 1u << 17;
+            const unsigned int nslice = cnt > SLICE ? (cnt + SLICE - 1) / SLICE : 1u;
+            const int S = min(32 - (31 - __clz((int)max(min(cnt, SLICE), 1u))), 30);
             fx = __uint_as_float((unsigned int)(127 + S) << 23);
             const float fxinv = __uint_as_float((unsigned int)(127 - S) << 23);
 #pragma unroll
@@ -932,11 +937,16 @@ __global__ __launch_bounds__(NT) void lines_deposit32(const unsigned long long *
                     if (k + 1 < cnt) one(((unsigned long long)__float_as_uint(cur[q].w) << 32) | __float_as_uint(cur[q].z));
                 }
             }
-            for (unsigned int k = 2u * NPRE * NT + tid; k < cnt; k += NT) one(entries[e0 + k]);
             const bool extra = cnt > 2u * NPRE * NT;
-            __syncthreads();
             const bool more = tt + 2 < nt;
-            if (more) issue(cur, tt + 2);
+            for (unsigned int sl = 0; sl < nslice; sl++) {
+            const bool first_sl = sl == 0, last_sl = sl + 1 == nslice;
+            {
+                const unsigned int k0 = first_sl ? 2u * NPRE * NT : sl * SLICE, k1 = last_sl ? cnt : (sl + 1) * SLICE;
+                for (unsigned int k = k0 + tid; k < k1; k += NT) one(entries[e0 + k]);
+            }
+            __syncthreads();
+            if (more && last_sl) issue(cur, tt + 2);
             {
                 constexpr int ZQ = LN_TZ / 4, ROWS = NT / ZQ;
                 static_assert(NT % ZQ == 0 && ROWS % LN_TY == 0 && (LN_TX * LN_TY) % ROWS == 0, "flush mapping");
@@ -954,11 +964,11 @@ __global__ __launch_bounds__(NT) void lines_deposit32(const unsigned long long *
                     if (zq == 0) c2[-1] = make_uint2(0u, 0u);                            // the row's halo cells
                     if (zq == ZQ - 1) c2[2] = make_uint2(0u, 0u);
                     float v[4] = {(float)a01.x * fxinv, (float)a01.y * fxinv, (float)a23.x * fxinv, (float)a23.y * fxinv};
-                    if (!zero_grid) {
+                    if (!zero_grid || !first_sl) {
                         const float4 old = *reinterpret_cast<const float4 *>(dst);
                         v[0] += old.x, v[1] += old.y, v[2] += old.z, v[3] += old.w;
                     }
-                    if (norm != 0.f) {
+                    if (norm != 0.f && last_sl) {
 #pragma unroll
                         for (int c = 0; c < 4; c++) v[c] = v[c] * norm - sub;
                     }
@@ -966,6 +976,8 @@ __global__ __launch_bounds__(NT) void lines_deposit32(const unsigned long long *
                 }
             }
             __syncthreads();
+            if (!last_sl) tsc_wait_vmcnt<0>();      // the next slice's flush reads what this one wrote
+            }
             const bool plain = zero_grid && !extra && !(dbg & 2);
             if (plain && prev_plain && more) tsc_wait_vmcnt<2 * FL + NPRE>();
             else tsc_wait_vmcnt<0>();

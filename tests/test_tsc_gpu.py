@@ -244,6 +244,13 @@ def _line_case(kind, shape, n, box, rng):
                            rng.integers(0, shape[2] // 256, n) * 256], axis=1)
         cells = (corner + rng.uniform(-0.45, 0.45, (n, 3))) % np.array(shape)
         return (cells * (box / np.array(shape))).astype('f4')
+    if kind == 'blob':      # nine tenths of the catalogue inside a few cells (one tile's list holds millions of entries, one block
+        # nearly every record), the rest uniform
+        pos = (rng.random((n, 3), dtype='f4') * np.float32(box)).astype('f4')
+        m = n - n // 10
+        centre = np.array([0.37, 0.52, 0.81]) * box
+        pos[:m] = (centre + rng.normal(0.0, 1.5 * box / shape[0], (m, 3))).astype('f4')
+        return pos
     if kind == 'slab':      # catalogue order: sorted along x (what a halo catalogue read slab by slab looks like)
         pos = (rng.random((n, 3), dtype='f4') * np.float32(box)).astype('f4')
         return pos[np.argsort(pos[:, 0], kind='stable')]
@@ -255,6 +262,7 @@ def _line_case(kind, shape, n, box, rng):
                                                  ('uniform', (512, 512, 512), 2_100_000, -0.7),
                                                  ('corners', (512, 512, 512), 2_200_000, 0.0),
                                                  ('slab', (512, 256, 512), 2_400_000, 0.5),
+                                                 ('blob', (512, 512, 512), 2_600_000, 0.0),
                                                  ('uniform-cfg1', (512, 512, 512), 2_300_000, 0.0),
                                                  ('corners-cfg1', (512, 512, 512), 2_050_000, 0.25)])
 def test_line_lists_vs_first_generation_and_oracle(kind, shape, n, offset, options):
@@ -282,8 +290,12 @@ def test_line_lists_vs_first_generation_and_oracle(kind, shape, n, offset, optio
     np.testing.assert_array_equal(p1, p3)   # wrapped identically
     np.testing.assert_array_equal(p2, p3)
     scale = float(c.max())
-    assert abs(float((a - base).sum(dtype='f8')) / n - 1) < 2e-6
-    np.testing.assert_allclose(a, c, rtol=5e-5, atol=4e-6 * scale)
+    # (a pile-up of 2e6 particles in a few cells: the float32 MESH resolves 1e-7 of cells holding 1e5 - the sum over the cells
+    # of `a - base` cannot conserve the mass better than that)
+    assert abs(float((a - base).sum(dtype='f8')) / n - 1) < (1e-5 if kind == 'blob' else 2e-6)
+    # blob: the oracle, like the reference, sums a cell in float32 - 1e5 addends into cells of 3e4 lose the small ones (5e-4
+    # low, measured); the first generation's float64 tile sums (`b`) are the yardstick there
+    np.testing.assert_allclose(a, c, rtol=2e-3 if kind == 'blob' else 5e-5, atol=4e-6 * scale)
     np.testing.assert_allclose(a, b, rtol=5e-5, atol=4e-6 * scale)
     # cells fed only by particles at p >= 128 in every dimension (the top cells also take the periodic images of p < 1/2):
     # with 64-bit tile sums (option tsc_acc64; the default 32-bit sums resolve 2^-S of a cell value, S from the tile's list)
@@ -302,8 +314,12 @@ def test_line_lists_vs_first_generation_and_oracle(kind, shape, n, offset, optio
     g2, p4 = base.copy(), pos.copy()
     tsc_parallel(p4, g2, box, offset=off)
     np.testing.assert_array_equal(p4, p3)
-    np.testing.assert_allclose(g2, c, rtol=5e-5, atol=4e-6 * scale)
-    np.testing.assert_array_equal(a[132:shape[0] - 3, 132:shape[1] - 3, 132:shape[2] - 3], g2[132:shape[0] - 3, 132:shape[1] - 3, 132:shape[2] - 3])
+    np.testing.assert_allclose(g2, c, rtol=2e-3 if kind == 'blob' else 5e-5, atol=4e-6 * scale)
+    inner = (slice(132, shape[0] - 3), slice(132, shape[1] - 3), slice(132, shape[2] - 3))
+    if kind == 'blob':     # lists beyond 2^17 entries are deposited in slices whose float32 sums depend on the order of the list
+        np.testing.assert_allclose(a[inner], g2[inner], rtol=1e-6)
+    else:
+        np.testing.assert_array_equal(a[inner], g2[inner])
     np.testing.assert_allclose(a, g2, rtol=1e-4, atol=6e-6 * scale)      # two independent draws: sqrt(2) of either one's error
 
 
