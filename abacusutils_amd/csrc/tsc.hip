@@ -1403,8 +1403,10 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         LGeom lg;
         int lcfg = 0;
         const double cell = box / gx;
+        // (|offset| up to two cells of the FINEST dimension: the lists take nearest cells -2 .. n + 2)
+        const double mincell = box / std::max(gx, std::max(gy, gz));
         if (multisplit && !weights && wrap && gxg == gx && xoff == 0 && xoff2 < 0 && ntiles >= 4096 && !option("tsc_oldlists") &&
-            std::fabs(offset) <= cell && lines_geometry(gx, gy, gz, zstride, lg, lcfg)) {
+            std::fabs(offset) <= (option("tsc_lines_gen") == 2 ? mincell : 2.0 * mincell) && lines_geometry(gx, gy, gz, zstride, lg, lcfg)) {
             g_lists.valid = false;
             int rc;
             if (option("tsc_lines_gen") == 2) {
@@ -1436,7 +1438,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         LGeom lg;
         int lcfg = 0;
         if (multisplit && !weights && wrap && gxg != gx && nx_alloc >= gx && nx_alloc % LN_TX == 0 && nx_alloc < gx + LN_TX && win <= dsep &&
-            win >= 8 && zero_grid && !option("tsc_oldlists") && option("tsc_lines_gen") != 2 && std::fabs(offset) <= box / gxg &&
+            win >= 8 && zero_grid && !option("tsc_oldlists") && option("tsc_lines_gen") != 2 && std::fabs(offset) <= 2.0 * box / std::max(gxg, std::max(gy, gz)) &&
             (int64_t)(nx_alloc / LN_TX) * (gy / LN_TY) * (gz / LN_TZ) >= 4096 && lines_geometry(nx_alloc, gy, gz, zstride, lg, lcfg)) {
             g_lists.valid = false;
             const L3Win wn{1, gxg, win, xoff, xoff2};

@@ -35,7 +35,9 @@ struct L3Dim {
 // ih16 = 65536 n / L: the power of two scales the float32 product (x + offset) n / L of tsc.py:419-421 exactly
 __device__ __forceinline__ int l3_S(float c, float offset, float ih16, int n, float u) {
     float y = (c + offset) * ih16;
-    y = fminf(fmaxf(y, -131072.f), (float)(n + 2) * 65536.f);  // garbage positions (NaN, inf) stay inside the tables
+    // nearest cells -2 .. n + 2 (p in (-2.5, n + 2.5): positions inside the box at offsets up to two cells); garbage positions
+    // (NaN, inf) stay inside the tables
+    y = fminf(fmaxf(y, -163839.f), (float)(n + 2) * 65536.f + 32000.f);
     const float fl = floorf(y);                                // exact
     return (int)fl + ((y - fl) > u ? 1 : 0) + 32767;
 }
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512) void lines3_count(float *__restrict__ pos, int
             for (int a = 0; a < 3; a++) {
                 // the cell alone: the rounding draw matters only when the dropped bits can carry into it (once in 65536)
                 float y = (c[a] + offA) * ih[a];
-                y = fminf(fmaxf(y, -131072.f), (float)(ncell[a] + 2) * 65536.f);
+                y = fminf(fmaxf(y, -163839.f), (float)(ncell[a] + 2) * 65536.f + 32000.f);      // as l3_S
                 const float fl = floorf(y);
                 int S = (int)fl + 32767;
                 if ((S & 0xffff) == 0xffff && y > fl) {
