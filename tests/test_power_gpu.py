@@ -635,16 +635,17 @@ def test_fused_last_pass_random_edges(options, seed):
     rng = np.random.default_rng(1000 + seed)
     nmesh, box = 1024, 1000.0
     pos = synth.synth_positions(400_000, box, seed=200 + seed, clustered=True)
-    for _ in range(3):
+    for it in range(3):
         ke, me, poles = _random_edges(rng, nmesh, box)
         comp = bool(rng.integers(0, 2))
-        kw = dict(kbins=ke, mubins=me, poles=poles, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=False)
+        inter = it == 2        # the interlaced pair through the same descriptor (edges past Nyquist: the folded i = n/2 plane)
+        kw = dict(kbins=ke, mubins=me, poles=poles, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=inter)
         a = calc_power(pos.copy(), box, **kw)
         gen = _lib.lib().abacus_power_xbin_generation()
         assert gen in (1, 2)
-        options.set('pk_noxbin', 1)
+        options.set('pk_noxbin_inter' if inter else 'pk_noxbin', 1)
         b = calc_power(pos.copy(), box, **kw)
-        options.set('pk_noxbin', 0)
+        options.set('pk_noxbin_inter' if inter else 'pk_noxbin', 0)
         np.testing.assert_array_equal(a['N_mode'], b['N_mode'], err_msg=f'gen {gen}')
         scale = np.abs(np.asarray(b['power'])).max()
         np.testing.assert_allclose(a['power'], b['power'], rtol=3e-6, atol=3e-7 * scale, err_msg=f'gen {gen}')
