@@ -114,11 +114,26 @@ class HipSlabBackend:
         _lib.check(_lib.lib().abacus_slab_axpy_dev(dst.ptr(dst_off), None if src is None else src.ptr(src_off),
                                                    C.c_int64(nfloat), C.c_float(add)))
 
-    def fft_zy(self, mesh, off, send, nmesh, world, xsep, xg0, p0, pc):
+    def fft_zy(self, mesh, off, send, nmesh, world, xsep, xg0, p0, pc, compact=None):
         """z / y passes of the plane pairs [p0, p0 + pc) of this rank's folded slab (first half at float offset `off`, global
-        plane xg0; second half `xsep` planes behind it); send = None: in place, else into the send buffer of the transpose"""
+        plane xg0; second half `xsep` planes behind it); send = None: in place, else into the send buffer of the transpose -
+        compact = (Lbox, k_last): the compact one of `transpose_layout`"""
+        if compact is not None:
+            _lib.check(_lib.lib().abacus_slab_fft_zy_compact_dev(mesh.ptr(off), send.ptr(0), int(nmesh), int(world), C.c_int64(xsep),
+                                                                 int(xg0), int(p0), int(pc), C.c_double(compact[0]), C.c_double(compact[1])))
+            return
         _lib.check(_lib.lib().abacus_slab_fft_zy_dev(mesh.ptr(off), None if send is None else send.ptr(0), int(nmesh),
                                                      int(world), C.c_int64(xsep), int(xg0), int(p0), int(pc)))
+
+    def transpose_layout(self, nmesh, world, Lbox, k_last):
+        """complex elements per plane of the COMPACT transpose block for every destination rank (columns beyond the binning's
+        last edge stay at home, csrc/fft.hip slab_layout), or None where the regular layout has to serve"""
+        P = np.zeros(int(world), dtype=np.int64)
+        rc = _lib.lib().abacus_slab_transpose_layout(int(nmesh), int(world), C.c_double(Lbox), C.c_double(k_last), _lib.ptr(P))
+        if rc == 1:
+            return None
+        _lib.check(rc)
+        return P
 
     def pack(self, mesh, off, send, nmesh, world, xsep, p0, pc):
         _lib.check(_lib.lib().abacus_slab_pack_dev(mesh.ptr(off), send.ptr(0), int(nmesh), int(world), C.c_int64(xsep),
@@ -147,12 +162,12 @@ class HipSlabBackend:
         """last x pass fused with the binning (auto power, one non-interlaced field, nmesh 1024 / 2048): raw sums, or None
         when the library does not serve this mesh / histogram that way (then unpack + fft_x + bin_raw).  from_transpose:
         `field` is the receive buffer of the pencil transpose, (peer, 2 h, y_local, k), not yet unpacked"""
-        buf, off = field
+        buf, off = field if field is not None else (None, 0)   # field None: a query (0 / None, nothing computed)
         raw = np.zeros(self.raw_bytes(len(ke) - 1, len(me) - 1, poles), dtype=np.uint8)
-        rc = _lib.lib().abacus_slab_xbin_dev(buf.ptr(off), int(nmesh), int(world), int(y0), int(nyl), C.c_double(Lbox),
+        rc = _lib.lib().abacus_slab_xbin_dev(None if buf is None else buf.ptr(off), int(nmesh), int(world), int(y0), int(nyl), C.c_double(Lbox),
                                              None if W is None else _lib.ptr(W), _lib.ptr(ke), len(ke) - 1, _lib.ptr(me),
                                              len(me) - 1, _lib.ptr(poles), len(poles), int(bool(put_geom)),
-                                             int(bool(from_transpose)), _lib.ptr(raw))
+                                             int(from_transpose), _lib.ptr(raw))
         if rc == 1:
             return None
         _lib.check(rc)
@@ -253,7 +268,10 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
 
     def tbuf(name):                       # last pass bins straight from its mesh needs neither: 2 x 18 GB at 2048^3)
         if name not in lazy:
-            lazy[name] = backend.new_buffer(2 * h * plane)
+            if Pc is None:
+                lazy[name] = backend.new_buffer(2 * h * plane)
+            else:                         # compact: what goes out to all peers / what comes in from them (floats)
+                lazy[name] = backend.new_buffer(2 * 2 * h * int(Pc.sum() if name == 'send' else W * Pc[r]))
         return lazy[name]
 
     ghost = backend.new_buffer(max(4 * g, 4))
@@ -262,6 +280,14 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
 
     # auto power of one non-interlaced field: the last x pass can bin straight from LDS (no spectrum write + re-read)
     try_xbin = pos2 is None and not interlaced and hasattr(backend, 'xbin_raw')
+    # ... and then nothing but that binning reads the transposed spectrum: the columns of a row beyond its last edge need not
+    # cross the links (COMPACT transpose, csrc/fft.hip slab_layout: -21 % with bins up to the Nyquist frequency)
+    Pc = None
+    if try_xbin and comm.collective and hasattr(backend, 'transpose_layout') and hasattr(comm, 'all_to_all_piece_v'):
+        if backend.xbin_raw(None, nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, False, from_transpose=True) is not None:
+            Pc = backend.transpose_layout(nmesh, W, Lbox, float(ke[-1]))
+    if Pc is not None:
+        csoff = np.concatenate(([0], np.cumsum(2 * h * Pc)[:-1]))          # complex offset of every peer's block in the send buffer
 
     def spectrum(particles, ntot, offset, mesh):
         norm = float(np.float32(float(nmesh) ** 3 / float(ntot)))   # dtype(field.size / tot_weight) (:856,894)
@@ -292,6 +318,14 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         cp = h // nchunk
         direct = try_xbin and not comm.collective           # one rank, fused last pass: no transpose at all
         for c in range(nchunk):
+            if Pc is not None:
+                backend.fft_zy(mesh, own, tbuf('send'), nmesh, W, xsep, xa, c * cp, cp, compact=(Lbox, float(ke[-1])))
+                for s_ in (0, 1):                             # the chunk's planes of either half: cp P[p] elements to peer p
+                    comm.all_to_all_piece_v(backend, tbuf('send'), tbuf('recv'),
+                                            2 * (csoff + (s_ * h + c * cp) * Pc), 2 * cp * Pc,
+                                            2 * (np.arange(W) * 2 * h + s_ * h + c * cp) * Pc[r], np.full(W, 2 * cp * Pc[r]),
+                                            overlap=nchunk > 1)
+                continue
             backend.fft_zy(mesh, own, None if direct else tbuf('send'), nmesh, W, xsep, xa, c * cp, cp)
             if comm.collective:
                 for s_ in (0, 1):                             # the chunk's planes of either half within every peer block
@@ -325,7 +359,10 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         fields += [(None, 0), (None, 0)]
     raw = None
     if try_xbin:
-        raw = backend.xbin_raw(fields[0], nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, r == 0, from_transpose=True)
+        raw = backend.xbin_raw(fields[0], nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, r == 0,
+                               from_transpose=2 if Pc is not None else True)
+        if raw is None and Pc is not None:
+            raise RuntimeError('calc_power_slab: the fused last pass declined a compact transpose it had accepted')
         if raw is None:      # not served: unpack, x pass, binning
             src, off = fields[0]
             if src is meshes[0]:                              # one rank went straight from its mesh: it still has to be packed

@@ -230,6 +230,14 @@ class RcclComm:
                                                              C.c_uint64(4 * int(offset)), C.c_uint64(4 * int(n)),
                                                              int(bool(overlap))))
 
+    def all_to_all_piece_v(self, backend, send, recv, send_off, send_n, recv_off, recv_n, overlap=True):
+        """a piece of a transpose whose peer blocks differ in size (the compact transpose of slab_power.py): per peer the
+        float offset / count inside the send and the receive buffer; one grouped send / recv, on the communicator's stream
+        behind an event fork when `overlap`"""
+        a = [np.ascontiguousarray(4 * np.asarray(v, dtype=np.int64)).astype(np.uint64) for v in (send_n, send_off, recv_n, recv_off)]
+        _lib.check(_lib.lib().abacus_comm_all_to_all_v_async(self._h, send.ptr(0), _lib.ptr(a[0]), _lib.ptr(a[1]), recv.ptr(0),
+                                                             _lib.ptr(a[2]), _lib.ptr(a[3]), int(bool(overlap))))
+
     def join(self):
         _lib.check(_lib.lib().abacus_comm_join(self._h))
 

@@ -262,6 +262,13 @@ int abacus_comm_all_to_all_v(abacus_comm *c, const void *send, const uint64_t *s
     return exchange(c, (const char *)send, send_bytes, send_off, (char *)recv, recv_bytes, recv_off, stream());
 }
 
+int abacus_comm_all_to_all_v_async(abacus_comm *c, const void *send, const uint64_t *send_bytes, const uint64_t *send_off, void *recv,
+                                   const uint64_t *recv_bytes, const uint64_t *recv_off, int async) {
+    ABACUS_ENTER();
+    if (!c || !send_bytes || !send_off || !recv_bytes || !recv_off) return fail("abacus_comm_all_to_all_v_async: null argument");
+    return exchange(c, (const char *)send, send_bytes, send_off, (char *)recv, recv_bytes, recv_off, pick_stream(c, async));
+}
+
 int abacus_comm_ring_exchange(abacus_comm *c, const void *to_left, const void *to_right, void *from_right, void *from_left,
                               uint64_t bytes) {
     ABACUS_ENTER();

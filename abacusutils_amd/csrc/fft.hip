@@ -249,6 +249,14 @@ struct ColsPack {
     // (the count of the stores a thread issues stays uniform over the workgroup, which the counted vmcnt wait needs)
     float wskip_cut = 0.f;
     int64_t dst_off = 0;               // out of place: rows are written dst_off complex elements from where they were read
+    // COMPACT pencil transpose (slab_layout below): a row travels with its live columns only.  Output row yr sits row_off[yr]
+    // complex elements into its peer's plane block and holds row_len[yr] columns (a multiple of 16, the same for the 16 rows of
+    // an aligned group: a wave's rows of one store slot lie in one group, so a skipped slot is skipped by the whole wave and
+    // its hand-counted vmcnt stays exact).  Table per row: {its offset in the send buffer for plane 0 of its peer's block
+    // (lo, hi), elements per plane of that block, live columns}.  Lane q of a wave loads the entry of the first row the wave
+    // stores in slot q - one vector load per tile, issued BEFORE the prefetch of the next tile so that it never sits in
+    // vmcnt between the stores - and the store loop takes it from there with readlane
+    const uint4 *row_ent = nullptr;
 };
 
 template <int N, int C, bool F1 = true, bool PACK = false>
@@ -346,6 +354,14 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
         const bool has_next = og < n_og;
         const int o_next = og * ostep + grp, ct_next = ct;
         float2 *gnext = has_next ? tile_ptr(o_next, ct) : gcur;
+        uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (PACK) {
+            static_assert(NLD <= 64, "one lane per store slot");
+            if (pk.row_ent && (tid & 63) < NLD) {
+                const int f0 = ((tid & 63) * FFT_THREADS + (tid & ~63)) / (C / 2);
+                ent = pk.row_ent[(o_cur & 1) * N + min(f0, N - 1)];
+            }
+        }
         if (has_next) prefetch(gnext);
         if (!(dbg & 1)) {
             if constexpr (wave_local(N)) {
@@ -374,14 +390,32 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
                         continue;
                     }
                 }
+                uint2 pl0 = make_uint2(0u, 0u);
+                int64_t base0 = 0;
+                int f0 = 0;
+                if constexpr (PACK) {
+                    if (pk.row_ent) {   // compact transpose: this wave's rows of the slot (one aligned group) end before this tile
+                        f0 = __builtin_amdgcn_readfirstlane((q * FFT_THREADS + (tid & ~63)) / (C / 2));
+                        pl0 = make_uint2((unsigned int)__builtin_amdgcn_readlane((int)ent.z, q), (unsigned int)__builtin_amdgcn_readlane((int)ent.w, q));
+                        base0 = (int64_t)(((uint64_t)(unsigned int)__builtin_amdgcn_readlane((int)ent.y, q) << 32) |
+                                          (unsigned int)__builtin_amdgcn_readlane((int)ent.x, q));
+                        if (ct_cur * C >= (int)pl0.y) {
+                            nstored--;
+                            continue;
+                        }
+                    }
+                }
                 if (WHOLE || f < N) {
                     const int p = padq(wave_local(N) ? f : revpos<N>(f));
                     const float2 a = lds[c2 * CP + p], b = lds[(c2 + 1) * CP + p];
                     float2 *dst = g + pk.dst_off + (int64_t)f * S + c2;
                     if constexpr (PACK) {
                         const int yr = (o_cur & 1) * N + f;
-                        dst = pk.out + (int64_t)(yr >> pk.lg_nyl) * pk.peer_stride + (int64_t)(pk.x0 + (o_cur >> 1)) * pk.x_stride +
-                              (int64_t)(yr & ((1 << pk.lg_nyl) - 1)) * S + ct_cur * C + c2;
+                        if (pk.row_ent)
+                            dst = pk.out + base0 + (int64_t)(pk.x0 + (o_cur >> 1)) * (int64_t)pl0.x + (f - f0) * (int)pl0.y + ct_cur * C + c2;   // (the rows of a group lie back to back)
+                        else
+                            dst = pk.out + (int64_t)(yr >> pk.lg_nyl) * pk.peer_stride + (int64_t)(pk.x0 + (o_cur >> 1)) * pk.x_stride +
+                                  (int64_t)(yr & ((1 << pk.lg_nyl) - 1)) * S + ct_cur * C + c2;
                     }
                     *reinterpret_cast<float4 *>(dst) = make_float4(a.x, a.y, b.x, b.y);
                 }
@@ -391,7 +425,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols(float2 *__restrict__ dat
         __syncthreads();
         // the NLD stores above were issued after the prefetch loads: vmcnt(NLD) = all loads landed, stores in flight
         if (dbg & 2) wait_vmcnt<0>();
-        else if (nstored != NLD && NLD <= 16) wait_vmcnt_upto16(nstored);
+        else if (nstored != NLD && NLD <= 16) wait_vmcnt_upto16(__builtin_amdgcn_readfirstlane(nstored));   // (the same in every lane of a wave)
         else wait_vmcnt<(NLD < 60 ? NLD : 0)>();
         stage();
         gcur = gnext, o_cur = o_next, ct_cur = ct_next;
@@ -609,6 +643,92 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x, fl
     return launch_cols<H, C>("fft_cols_x", data, S, ntile_c, 2 * (int64_t)N, pitch_c, th->twN.as<float2>(), N, (int64_t)H * S, pk);
 }
 
+// ---- compact pencil transpose ---------------------------------------------------------------------------------------------
+// When the spectrum goes to a binning that ends at |k|^2 = cut (fundamental units) and nowhere else, the columns of a y row beyond
+// sqrt(cut - ky^2) are never read: 21 % of the half-spectrum when the bins end at the Nyquist frequency.  They need not cross the
+// links.  A row of the transposed layout keeps its first row_len columns - a multiple of 16, decided for aligned groups of 16
+// rows from the smallest |ky| of the group (a wave of the y pass stores 8 or 16 rows of one group at a time) - and the rows of
+// a peer's plane block are packed back to back.  Sender (fft_cols<PACK>, ColsPack) and receiver (fft_x_bin2, XBinGeom) take the
+// same tables, a function of (n, ranks, cut) alone.
+struct SlabLayout {
+    int n = 0, W = 0;
+    float cut = 0.f;
+    std::vector<unsigned int> row_off;      // (n) offset of permuted row yr inside its peer's plane block, complex elements
+    std::vector<unsigned short> row_len;    // (n)
+    std::vector<int64_t> P;                 // (W) elements per plane of the block that goes to peer p
+    DevBuf d_off;                           // row_off (receiver: fft_x_bin2)
+    std::map<int, DevBuf> d_ent;            // sender table per h (planes of a rank / 2): ColsPack::row_ent
+};
+static std::vector<SlabLayout *> g_slab_layouts;
+
+const SlabLayout *slab_layout(int n, int W, float cut, int pitch_c) {
+    if (!(cut > 0.f) || W < 1 || W > 16 || n % W || (n / W) % 16 || (n != 256 && n != 1024 && n != 2048)) return nullptr;
+    for (const SlabLayout *l : g_slab_layouts)
+        if (l->n == n && l->W == W && l->cut == cut) return l;
+    SlabLayout *l = new SlabLayout();
+    l->n = n, l->W = W, l->cut = cut;
+    l->row_off.resize((size_t)n), l->row_len.resize((size_t)n), l->P.assign((size_t)W, 0);
+    const int H = n / 2, nyl = n / W, ntile = (n / 2 + 1 + 15) / 16;
+    if (ntile * 16 > pitch_c) {
+        delete l;
+        return nullptr;
+    }
+    for (int g0 = 0; g0 < n; g0 += 16) {
+        int m = n;
+        for (int yr = g0; yr < g0 + 16; yr++) {          // permuted row yr holds frequency 2 (yr mod n/2) + (yr div n/2)
+            const int j = 2 * (yr % H) + yr / H;
+            m = std::min(m, j < H ? j : n - j);
+        }
+        int live = 0;
+        for (int ct = 0; ct < ntile; ct++) live += (float)(m * m + (ct * 16) * (ct * 16)) > cut ? 0 : 1;   // the binning's own test
+        for (int yr = g0; yr < g0 + 16; yr++) {
+            const int p = yr / nyl;
+            l->row_len[(size_t)yr] = (unsigned short)(live * 16);
+            l->row_off[(size_t)yr] = (unsigned int)l->P[(size_t)p];
+            l->P[(size_t)p] += live * 16;
+        }
+    }
+    if (l->d_off.reserve((size_t)n * 4) != 0 ||
+        hipMemcpyAsync(l->d_off.p, l->row_off.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream()) != hipSuccess ||
+        hipStreamSynchronize(stream()) != hipSuccess) {
+        delete l;
+        return nullptr;
+    }
+    g_slab_layouts.push_back(l);
+    return l;
+}
+// the sender's tables for blocks of 2 h planes per peer
+static int slab_layout_sender(SlabLayout *l, int h, const uint4 **row_ent) {
+    auto it = l->d_ent.find(h);
+    if (it == l->d_ent.end()) {
+        const int n = l->n, nyl = n / l->W;
+        std::vector<int64_t> poff((size_t)l->W);
+        std::vector<uint4> ent((size_t)n);
+        int64_t off = 0;
+        for (int p = 0; p < l->W; p++) poff[(size_t)p] = off, off += 2 * (int64_t)h * l->P[(size_t)p];
+        for (int yr = 0; yr < n; yr++) {
+            const int p = yr / nyl;
+            const uint64_t base = (uint64_t)(poff[(size_t)p] + l->row_off[(size_t)yr]);
+            ent[(size_t)yr] = make_uint4((unsigned int)base, (unsigned int)(base >> 32), (unsigned int)l->P[(size_t)p], l->row_len[(size_t)yr]);
+        }
+        DevBuf b;
+        ABACUS_TRY(b.reserve((size_t)n * 16));
+        HIP_TRY(hipMemcpyAsync(b.p, ent.data(), (size_t)n * 16, hipMemcpyHostToDevice, stream()));
+        HIP_TRY(hipStreamSynchronize(stream()));
+        it = l->d_ent.emplace(h, b).first;
+    }
+    *row_ent = it->second.as<uint4>();
+    return 0;
+}
+int slab_layout_query(int n, int W, float cut, int pitch_c, int64_t *P_out, const unsigned int **row_off_dev) {
+    const SlabLayout *l = slab_layout(n, W, cut, pitch_c);
+    if (!l) return 1;
+    if (P_out)
+        for (int p = 0; p < W; p++) P_out[p] = l->P[(size_t)p];
+    if (row_off_dev) *row_off_dev = l->d_off.as<unsigned int>();
+    return 0;
+}
+
 // The fused form on the folded slabs of a multi-GPU mesh (analysis/slab_power.py): a rank owns h plane pairs (x, x + n/2),
 // the first half at `mesh`, the second xsep planes behind it, so the z pass fuses the first radix-2 stage of y AND x exactly
 // as on the whole mesh (ZFold) and everything behind it is the single-GPU form: the y pass as two n/2-point transforms per
@@ -617,7 +737,7 @@ int fft3d_fused(float *mesh, int pitch_r, Tables *t, Tables *th, bool with_x, fl
 // pack_out != nullptr: the y pass writes the send buffer of the pencil transpose (ColsPack), send[peer][s h + p][yl][k]
 template <int N, int C>
 int fft3d_fused_zy_slab(float *mesh, int pitch_r, Tables *t, Tables *th, int h, int64_t xsep, int xg0, int p0, int pc,
-                        float *pack_out, int world) {
+                        float *pack_out, int world, const SlabLayout *lay) {
     constexpr int H = N / 2;
     const int pitch_c = pitch_r / 2, ntile_c = (N / 2 + 1 + C - 1) / C;
     if (ntile_c * C > pitch_c) return fail("fft: row pitch too small for the column tiles");
@@ -632,6 +752,7 @@ int fft3d_fused_zy_slab(float *mesh, int pitch_r, Tables *t, Tables *th, int h, 
         if ((1 << pk.lg_nyl) != nyl || nyl > H) return fail("fft: packed y pass needs a power-of-two number of ranks >= 2 (nyl %d)", nyl);
         pk.x_stride = (int64_t)nyl * pitch_c;
         pk.peer_stride = 2 * (int64_t)h * nyl * pitch_c;
+        if (lay) ABACUS_TRY(slab_layout_sender(const_cast<SlabLayout *>(lay), h, &pk.row_ent));   // compact transpose
     }
     for (int s = 0; s < 2; s++) {
         float2 *data = reinterpret_cast<float2 *>(mesh + (s * xsep + p0) * plane);
@@ -657,15 +778,21 @@ int fft3d_fused_x_slab(float *mesh, int pitch_r, Tables *th, int64_t ny_local) {
                              th->twN.as<float2>());
 }
 int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int h, int64_t xsep, int xg0, int p0, int pc, float *pack_out,
-                             int world) {
+                             int world, float cut) {
     Tables *t, *th;
     ABACUS_TRY(get_tables(n, &t));
     ABACUS_TRY(get_tables(n / 2, &th));
     if (h < 1 || pc < 1 || p0 < 0 || p0 + pc > h || xsep < h) return fail("fft: plane pairs [%d, +%d) of %d", p0, pc, h);
+    const SlabLayout *lay = nullptr;
+    if (cut > 0.f) {
+        if (!pack_out) return fail("fft: the compact transpose needs the packed y pass");
+        lay = slab_layout(n, world, cut, pitch_r / 2);
+        if (!lay) return fail("fft: no compact transpose layout for a mesh of %d over %d ranks", n, world);
+    }
     switch (n) {
-        case 256: return fft3d_fused_zy_slab<256, 16>(mesh, pitch_r, t, th, h, xsep, xg0, p0, pc, pack_out, world);
-        case 1024: return fft3d_fused_zy_slab<1024, 16>(mesh, pitch_r, t, th, h, xsep, xg0, p0, pc, pack_out, world);
-        case 2048: return fft3d_fused_zy_slab<2048, 16>(mesh, pitch_r, t, th, h, xsep, xg0, p0, pc, pack_out, world);
+        case 256: return fft3d_fused_zy_slab<256, 16>(mesh, pitch_r, t, th, h, xsep, xg0, p0, pc, pack_out, world, lay);
+        case 1024: return fft3d_fused_zy_slab<1024, 16>(mesh, pitch_r, t, th, h, xsep, xg0, p0, pc, pack_out, world, lay);
+        case 2048: return fft3d_fused_zy_slab<2048, 16>(mesh, pitch_r, t, th, h, xsep, xg0, p0, pc, pack_out, world, lay);
     }
     return fail("fft: the fused transform supports n = 1024 and 2048");
 }
@@ -702,6 +829,12 @@ int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r, float xcut) { retur
 
 int fft_native_release() {
     ABACUS_TRY(g_scratch.release());
+    for (SlabLayout *l : g_slab_layouts) {
+        ABACUS_TRY(l->d_off.release());
+        for (auto &kv : l->d_ent) ABACUS_TRY(kv.second.release());
+        delete l;
+    }
+    g_slab_layouts.clear();
     for (auto &kv : g_tables) {
         ABACUS_TRY(kv.second.twN.release());
         ABACUS_TRY(kv.second.twHalf.release());

@@ -64,7 +64,7 @@ int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r, float xcut = 0.f);
 bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
                   int y0 = 0, int ny_local = 0, int put_geom = 1, int layout = 0, int world = 1, const float *mesh_shifted = nullptr,
-                  const float2 *phase = nullptr);
+                  const float2 *phase = nullptr, const unsigned int *row_off = nullptr, int64_t plane_elems = 0);
 bool xbin2_supported(int n, const BinArgs &b, bool comp);
 bool gfft_supported(int n, int is_double);
 int gfft_r2c_zy_f32(float *mesh, int n, int pitch_r);
@@ -72,7 +72,8 @@ bool gfft_xbin_supported(int n, const BinArgs &b, bool comp, bool inter = false)
 int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, const float *mesh2 = nullptr,
                    const void *phase = nullptr);
 int fft_native_fused_zy_slab(float *mesh, int n, int pitch_r, int h, int64_t xsep, int xg0, int p0, int pc, float *pack_out,
-                             int world);
+                             int world, float cut = 0.f);
+int slab_layout_query(int n, int W, float cut, int pitch_c, int64_t *P_out, const unsigned int **row_off_dev);
 int fft_native_fused_x_slab(float *mesh, int n, int pitch_r, int64_t ny_local);
 double xbin_last_build_ms();
 int xbin_last_gen();
@@ -1461,17 +1462,36 @@ static int slab_pack_launch(const void *data, void *send, int nmesh, int world, 
 // half (global plane xg0), the second half (global plane xg0 + nmesh/2) starts xsep planes behind it, h = nmesh / (2 world)
 // pairs in all.  send == NULL: in place.  send != NULL: the result goes to the send buffer of the pencil transpose,
 // send[peer][s h + p][y_local][k] - written by the y pass itself where the fused form runs, by a pack pass otherwise.
-int abacus_slab_fft_zy_dev(float *mesh, void *send, int nmesh, int world, int64_t xsep, int xg0, int p0, int pc) {
+// what the binning's last edge leaves of a row: |k|^2 in fundamental units with the margin of power_dev's xcut
+static float slab_cut(double Lbox, double k_last) {
+    const double e = k_last / (2.0 * M_PI / Lbox);
+    return (float)(e * e * (1.0 + 1e-5) + 1.0);
+}
+static bool slab_compact_ok(int nmesh, int world) {
+    const int nyl = nmesh / std::max(world, 1);
+    return slab_fused(nmesh) && (nmesh == 1024 || nmesh == 2048) && world > 1 && world <= 16 && !(nyl & (nyl - 1)) && nyl % 16 == 0 &&
+           !option("slab_nopackfuse") && !option("slab_nounpackfuse") && !option("slab_nocompact") && !option("pk_noxbin");
+}
+
+// COMPACT pencil transpose: complex elements per plane of the block that goes to every peer (P_out[world]) when the columns beyond
+// the binning's last edge k_last stay at home (fft.hip, slab_layout); 1 = not available for this mesh / rank count (regular layout)
+int abacus_slab_transpose_layout(int nmesh, int world, double Lbox, double k_last, int64_t *P_out) {
     ABACUS_ENTER();
+    if (!P_out || !slab_compact_ok(nmesh, world)) return 1;
+    return slab_layout_query(nmesh, world, slab_cut(Lbox, k_last), pitch_r(nmesh) / 2, P_out, nullptr);
+}
+
+static int slab_fft_zy(float *mesh, void *send, int nmesh, int world, int64_t xsep, int xg0, int p0, int pc, float cut) {
     if (!fft_native_pow2(nmesh)) return fail("slab path: nmesh must be a power of two in [64, 2048]");
     int h;
     ABACUS_TRY(slab_fold("abacus_slab_fft_zy_dev", nmesh, world, &h));
     if (p0 < 0 || pc < 1 || p0 + pc > h || xsep < h) return fail("abacus_slab_fft_zy_dev: pairs [%d, +%d) of %d, halves %lld planes apart", p0, pc, h, (long long)xsep);
     const int pr = pitch_r(nmesh), nyl = nmesh / world;
     const size_t plane = (size_t)nmesh * pr;
+    if (cut > 0.f && (!send || !slab_compact_ok(nmesh, world))) return fail("abacus_slab_fft_zy_compact_dev: no compact layout for this run");
     if (slab_fused(nmesh)) {
         const bool ypack = send && !option("slab_nopackfuse") && world > 1 && !(nyl & (nyl - 1));
-        ABACUS_TRY(fft_native_fused_zy_slab(mesh, nmesh, pr, h, xsep, xg0, p0, pc, ypack ? (float *)send : nullptr, world));
+        ABACUS_TRY(fft_native_fused_zy_slab(mesh, nmesh, pr, h, xsep, xg0, p0, pc, ypack ? (float *)send : nullptr, world, cut));
         if (ypack || !send) return 0;
     } else {
         ABACUS_TRY(fft_native_zy(mesh + (size_t)p0 * plane, nmesh, pr, pc));
@@ -1479,6 +1499,16 @@ int abacus_slab_fft_zy_dev(float *mesh, void *send, int nmesh, int world, int64_
         if (!send) return 0;
     }
     return slab_pack_launch(mesh, send, nmesh, world, h, xsep, p0, pc);
+}
+int abacus_slab_fft_zy_dev(float *mesh, void *send, int nmesh, int world, int64_t xsep, int xg0, int p0, int pc) {
+    ABACUS_ENTER();
+    return slab_fft_zy(mesh, send, nmesh, world, xsep, xg0, p0, pc, 0.f);
+}
+// the same, writing the COMPACT send buffer of abacus_slab_transpose_layout(nmesh, world, Lbox, k_last)
+int abacus_slab_fft_zy_compact_dev(float *mesh, void *send, int nmesh, int world, int64_t xsep, int xg0, int p0, int pc, double Lbox,
+                                   double k_last) {
+    ABACUS_ENTER();
+    return slab_fft_zy(mesh, send, nmesh, world, xsep, xg0, p0, pc, slab_cut(Lbox, k_last));
 }
 
 int abacus_slab_pack_dev(const void *data, void *send, int nmesh, int world, int64_t xsep, int p0, int pc) {
@@ -1532,6 +1562,9 @@ int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void
 // raw_out, 1 if this mesh / histogram is not served by the fused last pass (the caller then runs abacus_slab_unpack_dev,
 // abacus_slab_fft_x_dev, abacus_slab_bin_dev), < 0 on error.  put_geom: exactly one rank passes 1 (the mesh-wide N_mode and
 // sum |k| come from the cached geometry, not from the y-slab).
+// from_transpose = 2: the COMPACT receive buffer (abacus_slab_transpose_layout with the binning's last edge); mesh == NULL: a
+// query - 0 if the fused last pass will serve this mesh / histogram from the transpose, 1 if not (nothing is computed, the
+// geometry descriptor is built and cached)
 int abacus_slab_xbin_dev(const void *mesh, int nmesh, int world, int y0, int ny_local, double Lbox, const float *W_host,
                          const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
                          int put_geom, int from_transpose, void *raw_out) {
@@ -1547,9 +1580,16 @@ int abacus_slab_xbin_dev(const void *mesh, int nmesh, int world, int y0, int ny_
     size_t acc_bytes = 0;
     ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
     if (!xbin2_supported(nmesh, b, W_dev != nullptr)) return 1;
+    if (!mesh) return 0;
+    const unsigned int *row_off = nullptr;
+    int64_t P[16] = {0};
+    if (from_transpose == 2) {
+        if (!slab_compact_ok(nmesh, world) || Nk < 1) return fail("abacus_slab_xbin_dev: no compact layout for this run");
+        ABACUS_TRY(slab_layout_query(nmesh, world, slab_cut(Lbox, kedges[Nk]), pitch_r(nmesh) / 2, P, &row_off));
+    }
     const double M = (double)nmesh * nmesh * nmesh;
     ABACUS_TRY(fft_x_bin_run((const float *)mesh, nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, y0, ny_local,
-                             put_geom ? 1 : 0, from_transpose ? 2 : 1, world));
+                             put_geom ? 1 : 0, from_transpose ? 2 : 1, world, nullptr, nullptr, row_off, P[y0 / std::max(ny_local, 1)]));
     HIP_TRY(hipMemcpyAsync(raw_out, g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;

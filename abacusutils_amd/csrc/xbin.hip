@@ -61,6 +61,9 @@ struct XBinGeom {
     const float2 *data2 = nullptr;
     const float2 *phase = nullptr;
     float half_inv_size = 0.f;
+    // compact pencil transpose (fft.hip, slab_layout): row yr of the y-slab starts row_off[y0 + yr] elements into a plane block
+    // (xs = elements per plane of the blocks this rank receives) instead of yr * ys
+    const unsigned int *row_off = nullptr;
 };
 
 template <int H, int C, int NP, bool COMP>
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     const int lgh = g.lgh, hmask = (1 << lgh) - 1;
     auto tile_ptr = [&](int o, int ct, const float2 *base) {
         const int xh = o >= g.ny ? 1 : 0, yr = o - xh * g.ny;
-        return base + ((int64_t)xh << lgh) * S + (int64_t)yr * g.ys + ct * C;
+        return base + ((int64_t)xh << lgh) * S + (g.row_off ? (int64_t)g.row_off[g.y0 + yr] : (int64_t)yr * g.ys) + ct * C;
     };
     auto prefetch = [&](const float2 *p) {
 #pragma unroll
@@ -990,7 +993,8 @@ int xbin_release() {
 // serves the slab forms, and `put_geom` says whether this rank contributes the mesh-wide N_mode / sum |k| to the
 // histogram that is all-reduced afterwards.
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
-                  int y0, int ny_local, int put_geom, int layout, int world, const float *mesh_shifted, const float2 *phase) {
+                  int y0, int ny_local, int put_geom, int layout, int world, const float *mesh_shifted, const float2 *phase,
+                  const unsigned int *row_off, int64_t plane_elems) {
     XBinGeom g;
     g.n = n, g.kzlen = n / 2 + 1, g.pitch_c = pitch_r / 2, g.inv_size = inv_size, g.W = W_dev, g.dbg = dbg;
     if (mesh_shifted) {
@@ -1009,6 +1013,7 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
             return fail("fft_x_bin: %d ranks do not fold a mesh of %d into power-of-two runs of planes", world, n);
         h = n / 2 / world;
         g.xs = (int64_t)g.ny * g.pitch_c, g.ys = g.pitch_c, g.ps = 2 * (int64_t)h * g.xs;
+        if (row_off) g.row_off = row_off, g.xs = plane_elems, g.ps = 2 * (int64_t)h * g.xs;   // compact transpose
     } else g.xs = (int64_t)n * g.pitch_c, g.ys = g.pitch_c;
     g.lgh = 0;
     while ((1 << g.lgh) < h) g.lgh++;

@@ -344,6 +344,17 @@ int abacus_slab_axpy_dev(float *dst, const float *src, int64_t nfloat, float add
  * send buffer of the pencil transpose, send[peer][s h + p][y_local][k] (s = 0 / 1: first / second half) - written by the y
  * pass itself where the fused form runs with more than one rank, by a pack pass otherwise */
 int abacus_slab_fft_zy_dev(float *mesh, void *send, int nmesh, int world, int64_t xsep, int xg0, int p0, int pc);
+/* COMPACT pencil transpose (new functionality like the rest of the slab path; csrc/fft.hip `slab_layout`).  When the spectrum goes
+ * to a binning that ends at k_last and nowhere else, the columns of a y row beyond sqrt(k_last^2 - ky^2) never cross the links:
+ * a row keeps its first row_len columns (a multiple of 16, decided per aligned group of 16 rows), the rows of a peer's plane block
+ * are packed back to back - 21 % fewer bytes when the bins end at the Nyquist frequency.
+ * abacus_slab_transpose_layout: P_out[p] = complex elements per plane of the block that goes to peer p (so a rank sends
+ * 2 h P_out[p] elements to p and receives 2 h P_out[rank] from everybody); returns 1 when this mesh / rank count has no compact
+ * form (then use the regular layout).  abacus_slab_fft_zy_compact_dev writes that send buffer; the receive buffer is read by
+ * abacus_slab_xbin_dev(from_transpose = 2) */
+int abacus_slab_transpose_layout(int nmesh, int world, double Lbox, double k_last, int64_t *P_out);
+int abacus_slab_fft_zy_compact_dev(float *mesh, void *send, int nmesh, int world, int64_t xsep, int xg0, int p0, int pc, double Lbox,
+                                   double k_last);
 /* the pack pass alone (pairs [p0, p0 + pc)), and recv[q][s h + p][y_local][k] -> out[y_local][s nmesh/2 + q h + p][k]: row
  * s nmesh/2 + i of x is plane i of half s - the plane itself in the plain form; in the fused form the sum (s = 0) or the
  * twiddled difference (s = 1) of planes i and i + nmesh/2, i.e. the inputs of the two nmesh/2-point transforms */
@@ -409,6 +420,9 @@ int abacus_comm_all_to_all_strided(abacus_comm *c, const void *send, void *recv,
 /* variable blocks (device-side particle routing): byte counts and offsets per peer, host arrays of `world` entries */
 int abacus_comm_all_to_all_v(abacus_comm *c, const void *send, const uint64_t *send_bytes, const uint64_t *send_off, void *recv,
                              const uint64_t *recv_bytes, const uint64_t *recv_off);
+/* the same on the communicator's own stream behind an event fork when async != 0 (chunks of the compact pencil transpose) */
+int abacus_comm_all_to_all_v_async(abacus_comm *c, const void *send, const uint64_t *send_bytes, const uint64_t *send_off, void *recv,
+                                   const uint64_t *recv_bytes, const uint64_t *recv_off, int async);
 /* ghost blocks: to_left -> rank-1, to_right -> rank+1; from_right <- what rank+1 sent left, from_left <- what rank-1 sent
  * right (one rank: its own blocks come back, the periodic box) */
 int abacus_comm_ring_exchange(abacus_comm *c, const void *to_left, const void *to_right, void *from_right, void *from_left,

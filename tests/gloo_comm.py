@@ -75,6 +75,18 @@ class GlooSlabComm:
         for p in range(self.world):
             recv.set(p * peer_stride + offset, outs[p].numpy())
 
+    def all_to_all_piece_v(self, backend, send, recv, send_off, send_n, recv_off, recv_n, overlap=False):
+        """peer blocks of different sizes (the compact transpose of slab_power.py)"""
+        if not self.collective:
+            raise RuntimeError('all_to_all needs an initialised process group')
+        import torch
+        backend.sync()
+        ins = [torch.from_numpy(send.get(int(send_off[p]), int(send_n[p]))) for p in range(self.world)]
+        outs = [torch.empty(int(recv_n[p]), dtype=torch.float32) for p in range(self.world)]
+        self._pairwise(ins, outs)
+        for p in range(self.world):
+            recv.set(int(recv_off[p]), outs[p].numpy())
+
     def join(self):
         pass
 

@@ -43,6 +43,13 @@ c.join()
 _lib.sync()
 out = dst.get(0, n)
 assert np.array_equal(out[1024:5120], x[1024:5120]) and not out[:1024].any() and not out[5120:].any()
+# a piece of a transpose with peer blocks of different sizes (the compact transpose): offsets / counts per peer, async form
+dst.set(0, np.zeros(2 * n, dtype=np.float32))
+c.all_to_all_piece_v(None, src, dst, [512], [3000], [2048], [3000], overlap=True)
+c.join()
+_lib.sync()
+out = dst.get(0, n)
+assert np.array_equal(out[2048:5048], x[512:3512]) and not out[:2048].any() and not out[5048:].any()
 c.ring_exchange(None, src, 0, n // 2, dst, n // 2)
 _lib.sync()
 assert np.array_equal(dst.get(0, n // 2), x[:n // 2]) and np.array_equal(dst.get(n // 2, n // 2), x[n // 2:])

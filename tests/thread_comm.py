@@ -40,8 +40,18 @@ class ThreadComm:
     def all_to_all_piece(self, backend, send, recv, peer_stride, offset, n, overlap=False):
         backend.sync()
         allb = self._exchange([send.get(p * peer_stride + offset, n) for p in range(self.world)])
+        self.floats_sent = getattr(self, 'floats_sent', 0) + int(n) * (self.world - 1)
         for p in range(self.world):
             recv.set(p * peer_stride + offset, allb[p][self.rank])
+
+    def all_to_all_piece_v(self, backend, send, recv, send_off, send_n, recv_off, recv_n, overlap=False):
+        """peer blocks of different sizes (the compact transpose): float offsets / counts per peer on either side"""
+        backend.sync()
+        allb = self._exchange([send.get(int(send_off[p]), int(send_n[p])) for p in range(self.world)])
+        self.floats_sent = getattr(self, 'floats_sent', 0) + int(sum(int(send_n[p]) for p in range(self.world) if p != self.rank))
+        for p in range(self.world):
+            assert len(allb[p][self.rank]) == int(recv_n[p])
+            recv.set(int(recv_off[p]), allb[p][self.rank])
 
     def join(self):
         pass
