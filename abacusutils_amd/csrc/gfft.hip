@@ -242,11 +242,49 @@ __device__ __forceinline__ void g_transform(C2<T> *lds, int lgG, int P, const GP
     }
 }
 
+// Compile-time plans (make_plan's order; checked against it at launch) for the meshes the bench and compute_power's default
+// run: the stage loop unrolls with N, Ns and the tile pitch as constants - the index arithmetic of a stage folds and the LDS
+// offsets r * (N / R) * P, r * Ns * P become instruction immediates instead of one vector add per access.
+template <int N>
+struct GFixed {
+    static constexpr int nf = 0;
+    static constexpr int radix[1] = {0};
+};
+#define GFIXED(N, ...)                                                \
+    template <>                                                       \
+    struct GFixed<N> {                                                \
+        static constexpr int radix[] = {__VA_ARGS__};                 \
+        static constexpr int nf = sizeof(radix) / sizeof(int);        \
+    };
+GFIXED(1536, 8, 8, 8, 3)
+GFIXED(768, 8, 8, 4, 3)
+GFIXED(384, 8, 8, 2, 3)
+GFIXED(550, 2, 5, 5, 11)
+GFIXED(275, 5, 5, 11)
+#undef GFIXED
+template <int N>
+bool fixed_plan_matches(const GPlan &p) {
+    if (p.n != N || p.nf != GFixed<N>::nf) return false;
+    for (int f = 0; f < p.nf; f++)
+        if (p.radix[f] != GFixed<N>::radix[f]) return false;
+    return true;
+}
+template <typename T, int MAXV, int N, int LGG, int F = 0, int NS = 1>
+__device__ __forceinline__ void g_transform_fixed(C2<T> *lds, const C2<T> *tw, int tws) {
+    if constexpr (F < GFixed<N>::nf) {
+        constexpr int R = GFixed<N>::radix[F];
+        g_stage<T, R, MAXV>(lds, LGG, (cg_of<T>() << LGG) + 1, N, NS, tw, tws);
+        g_transform_fixed<T, MAXV, N, LGG, F + 1, NS * R>(lds, tw, tws);
+    }
+}
+
 // ---- rows: n reals -> n/2 + 1 complex, in place (row pitch `pitch_r` scalars) ------------------------------------------
 // a tile is NSEQ = CG << lgG rows (a power of two); LDS: [n twiddles][(n / 2) x (NSEQ + 1)]
-template <typename T, int MAXV>
-__global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t nrows, int n, int pitch_r, int lgG, GPlan p,
+// FN > 0: the mesh size and lgG are compile-time (GFixed<FN / 2>)
+template <typename T, int MAXV, int FN = 0, int FLG = 0>
+__global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t nrows, int n_, int pitch_r, int lgG_, GPlan p,
                                                   const C2<T> *__restrict__ twn, int dbg) {
+    const int n = FN > 0 ? FN : n_, lgG = FN > 0 ? FLG : lgG_;
     extern __shared__ __align__(16) unsigned char smem[];
     C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
     C2<T> *lds = tw + n;
@@ -281,7 +319,10 @@ __global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t 
             }
         }
         __syncthreads();
-        if (!(dbg & 1)) g_transform<T, MAXV>(lds, lgG, P, p, tw, 2);
+        if (!(dbg & 1)) {
+            if constexpr (FN > 0) g_transform_fixed<T, MAXV, FN / 2, FLG>(lds, tw, 2);
+            else g_transform<T, MAXV>(lds, lgG, P, p, tw, 2);
+        }
         // X[k] = (Z[k] + conj Z[Nh - k]) / 2 - (i / 2) w^k (Z[k] - conj Z[Nh - k]),  w = exp(-2 pi i / n),  Z[Nh] = Z[0]
         for (int q = threadIdx.x; q < ns * (Nh + 1); q += G_NT) {
             const int s = fdiv(q, mH1), k = q - s * (Nh + 1);
@@ -302,9 +343,10 @@ __global__ __launch_bounds__(G_NT) void gfft_rows(T *__restrict__ mesh, int64_t 
 // of the current one and land in LDS after its write-back: the memory phase (7 ms of a 1536^3 pass) runs under the
 // stages (8.7 ms) instead of in front of them (1536^3: 12.2 -> 9.7 ms per pass).  The row pass keeps batched loads in
 // front of its stages: walking a row per thread group, which the one-pointer prefetch needs, measured 12.1 ms against 10.3.
-template <typename T, int MAXV>
-__global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int n, int64_t S, int lgG, int ntile_c, int ncols,
+template <typename T, int MAXV, int FN = 0, int FLG = 0>
+__global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int n_, int64_t S, int lgG_, int ntile_c, int ncols,
                                                   int64_t nouter, int64_t outer_stride, GPlan p, const C2<T> *__restrict__ twn, int dbg, float xcut) {
+    const int n = FN > 0 ? FN : n_, lgG = FN > 0 ? FLG : lgG_;
     extern __shared__ __align__(16) unsigned char smem[];
     C2<T> *tw = reinterpret_cast<C2<T> *>(smem);
     C2<T> *lds = tw + n;
@@ -380,7 +422,10 @@ __global__ __launch_bounds__(G_NT) void gfft_cols(C2<T> *__restrict__ data, int 
         }
         __syncthreads();
         if (tn < ntiles && !(dbg & 4)) issue(tn);
-        if (!(dbg & 1)) g_transform<T, MAXV>(lds, lgG, P, p, tw, 1);
+        if (!(dbg & 1)) {
+            if constexpr (FN > 0) g_transform_fixed<T, MAXV, FN, FLG>(lds, tw, 1);
+            else g_transform<T, MAXV>(lds, lgG, P, p, tw, 1);
+        }
         int nc;
         C2<T> *base = tile_base(t, nc);
         for (int q = threadIdx.x; q < total2; q += G_NT) {
@@ -423,13 +468,13 @@ struct GXArgs {
 // binning reading them back.
 // LEAN: the twiddle table and the per-kz mu thresholds stay in global memory (read through the vector cache) - what lets a
 // 1536-row tile, the float64 histogram of 512 k bins and the cell table share the 160 KiB of LDS
-template <bool INTER, bool LEAN>
+template <bool INTER, bool LEAN, int FN = 0, int FLG = 0>
 __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__ data, GXArgs g, GPlan p, const C2<float> *__restrict__ twn,
                                                    BinArgs b, XDesc d) {
     typedef float T;
     constexpr int MAXV = 24;
     extern __shared__ __align__(16) unsigned char smem[];
-    const int n = g.n, lgC = g.lgG + 2, C = 1 << lgC, P = C + 1;
+    const int n = FN > 0 ? FN : g.n, lgG = FN > 0 ? FLG : g.lgG, lgC = lgG + 2, C = 1 << lgC, P = C + 1;   // FN > 0: compile-time plan (GFixed)
     const int Nk = b.Nk, Nmu = b.Nmu, nrow = Nk + 2, nbx = nrow * Nmu;
     C2<T> *twl = reinterpret_cast<C2<T> *>(smem);
     C2<T> *lds = twl + (LEAN ? 0 : n);
@@ -516,8 +561,13 @@ __global__ __launch_bounds__(G_NT) void gfft_x_bin(const C2<float> *__restrict__
         }
         __syncthreads();
         if (tn < ntiles) issue(tn);
-        g_transform<T, MAXV>(lds, g.lgG, P, p, tw, 1);       // ends on a workgroup barrier: the whole tile is transformed
-        if (INTER) g_transform<T, MAXV>(lds2, g.lgG, P, p, tw, 1);
+        if constexpr (FN > 0) {
+            g_transform_fixed<T, MAXV, FN, FLG>(lds, tw, 1);
+            if (INTER) g_transform_fixed<T, MAXV, FN, FLG>(lds2, tw, 1);
+        } else {
+            g_transform<T, MAXV>(lds, lgG, P, p, tw, 1);       // ends on a workgroup barrier: the whole tile is transformed
+            if (INTER) g_transform<T, MAXV>(lds2, lgG, P, p, tw, 1);
+        }
         const int64_t o = t / g.ntile_c;
         const int j = (int)o, jj = j < n / 2 ? j : j - n, c0 = (int)(t - o * g.ntile_c) * C;
 #pragma unroll 1
@@ -672,6 +722,17 @@ int num_cus_g() {
     return ncu;
 }
 
+// hipFuncSetAttribute is not free: once per kernel and size, not per launch
+int kernel_lds(const void *kern, size_t lds) {
+    static std::map<const void *, size_t> set;
+    size_t &have = set[kern];
+    if (lds > have) {
+        HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        have = lds;
+    }
+    return 0;
+}
+
 template <typename T, int MAXV>
 int launch_rows(T *mesh, int n, int pitch_r, const GPlan &ph, const C2<T> *twn, int ncu, int dbg) {
     constexpr int CG = sizeof(T) == 4 ? 4 : 2;
@@ -680,12 +741,15 @@ int launch_rows(T *mesh, int n, int pitch_r, const GPlan &ph, const C2<T> *twn, 
     while ((CG << (lgG + 1)) <= 32 && (CG << (lgG + 1)) * Nh <= cap) lgG++;
     const int NSEQ = CG << lgG;
     const size_t lds = ((size_t)n + (size_t)Nh * (NSEQ + 1)) * sizeof(C2<T>);
-    auto kern = gfft_rows<T, MAXV>;
-    static size_t lds_set = 0;                   // hipFuncSetAttribute is not free: once per size, not per launch
-    if (lds > lds_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
+    void (*kern)(T *, int64_t, int, int, int, GPlan, const C2<T> *, int) = gfft_rows<T, MAXV>;
+    if constexpr (sizeof(T) == 4) {
+        if (!option("gfft_nofixed")) {
+            if (n == 1536 && lgG == 2 && fixed_plan_matches<768>(ph)) kern = gfft_rows<T, MAXV, 1536, 2>;
+            else if (n == 768 && lgG == 3 && fixed_plan_matches<384>(ph)) kern = gfft_rows<T, MAXV, 768, 3>;
+            else if (n == 550 && lgG == 3 && fixed_plan_matches<275>(ph)) kern = gfft_rows<T, MAXV, 550, 3>;
+        }
     }
+    ABACUS_TRY(kernel_lds(reinterpret_cast<const void *>(kern), lds));
     const int64_t nrows = (int64_t)n * n;
     const unsigned int grid = (unsigned int)std::min<int64_t>(ceil_div(nrows, NSEQ), (int64_t)ncu * (lds > 80 * 1024 ? 1 : 2));
     ABACUS_LAUNCH("gfft_rows", kern, dim3(grid), dim3(G_NT), lds, mesh, nrows, n, pitch_r, lgG, ph, twn, dbg);
@@ -711,12 +775,15 @@ int r2c_inplace(T *mesh, int n, int pitch_r, float xcut = 0.f, bool skip_x = fal
     while ((CG << (lgG + 1)) <= 16 && (CG << (lgG + 1)) * n <= cap) lgG++;
     const int C = CG << lgG;
     const size_t lds = ((size_t)n + (size_t)n * (C + 1)) * sizeof(C2<T>);
-    auto kern = gfft_cols<T, MAXV>;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
+    void (*kern)(C2<T> *, int, int64_t, int, int, int, int64_t, int64_t, GPlan, const C2<T> *, int, float) = gfft_cols<T, MAXV>;
+    if constexpr (sizeof(T) == 4) {
+        if (!option("gfft_nofixed")) {
+            if (n == 1536 && lgG == 1 && fixed_plan_matches<1536>(pn)) kern = gfft_cols<T, MAXV, 1536, 1>;
+            else if (n == 768 && lgG == 2 && fixed_plan_matches<768>(pn)) kern = gfft_cols<T, MAXV, 768, 2>;
+            else if (n == 550 && lgG == 2 && fixed_plan_matches<550>(pn)) kern = gfft_cols<T, MAXV, 550, 2>;
+        }
     }
+    ABACUS_TRY(kernel_lds(reinterpret_cast<const void *>(kern), lds));
     const int ntile_c = (kzlen + C - 1) / C;
     const unsigned int grid = (unsigned int)std::min<int64_t>((int64_t)n * ntile_c, (int64_t)ncu * (lds > 80 * 1024 ? 1 : 2));
     C2<T> *data = reinterpret_cast<C2<T> *>(mesh);
@@ -824,20 +891,20 @@ int gfft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const 
     g.inv2 = hs * hs;
     if (g.ntile_c * C > pitch_c) return fail("gfft_x_bin: row pitch too small");
     const size_t lds = other + (size_t)d.ncell * 4;
-    static size_t lds_set[4] = {0, 0, 0, 0};
-    const void *kerns[4] = {reinterpret_cast<const void *>(gfft_x_bin<false, false>), reinterpret_cast<const void *>(gfft_x_bin<true, false>),
-                            reinterpret_cast<const void *>(gfft_x_bin<false, true>), reinterpret_cast<const void *>(gfft_x_bin<true, true>)};
-    const int kv = (inter ? 1 : 0) + (lean ? 2 : 0);
-    if (lds > lds_set[kv]) {
-        HIP_TRY(hipFuncSetAttribute(kerns[kv], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set[kv] = lds;
+    using XKern = void (*)(const C2<float> *, GXArgs, GPlan, const C2<float> *, BinArgs, XDesc);
+    XKern kern = inter ? (lean ? gfft_x_bin<true, true> : gfft_x_bin<true, false>) : (lean ? gfft_x_bin<false, true> : gfft_x_bin<false, false>);
+    if (!option("gfft_nofixed")) {
+#define GXF(I, L, N, G) \
+    if (inter == I && lean == L && n == N && lgG == G && fixed_plan_matches<N>(pn)) kern = gfft_x_bin<I, L, N, G>;
+        GXF(false, true, 1536, 1)
+        GXF(false, false, 768, 2) GXF(false, false, 768, 1) GXF(true, false, 768, 1)
+        GXF(false, false, 550, 2) GXF(false, false, 550, 1) GXF(true, false, 550, 2) GXF(true, false, 550, 1)
+#undef GXF
     }
+    ABACUS_TRY(kernel_lds(reinterpret_cast<const void *>(kern), lds));
     const unsigned int grid = (unsigned int)std::min<int64_t>((int64_t)n * g.ntile_c, (int64_t)num_cus_g() * (lds > 80 * 1024 ? 1 : 2));
     const C2<float> *m0 = reinterpret_cast<const C2<float> *>(mesh);
-    if (kv == 0) ABACUS_LAUNCH("gfft_x_bin", (gfft_x_bin<false, false>), dim3(grid), dim3(G_NT), lds, m0, g, pn, twn, b, d);
-    else if (kv == 1) ABACUS_LAUNCH("gfft_x_bin", (gfft_x_bin<true, false>), dim3(grid), dim3(G_NT), lds, m0, g, pn, twn, b, d);
-    else if (kv == 2) ABACUS_LAUNCH("gfft_x_bin", (gfft_x_bin<false, true>), dim3(grid), dim3(G_NT), lds, m0, g, pn, twn, b, d);
-    else ABACUS_LAUNCH("gfft_x_bin", (gfft_x_bin<true, true>), dim3(grid), dim3(G_NT), lds, m0, g, pn, twn, b, d);
+    ABACUS_LAUNCH("gfft_x_bin", kern, dim3(grid), dim3(G_NT), lds, m0, g, pn, twn, b, d);
     return 0;
 }
 int gfft_release() {

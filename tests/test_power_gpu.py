@@ -875,3 +875,28 @@ def test_mixed_radix_1536_fused_last_pass(options):
         np.testing.assert_allclose(a['power'], b['power'], rtol=3e-6, atol=3e-7 * scale)
         np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)
         np.testing.assert_allclose(a['poles'], b['poles'], rtol=3e-6, atol=5e-7 * scale)
+
+
+@pytest.mark.parametrize('nmesh,npart', [(550, 1_000_000), (768, 2_000_000), (1536, 3_000_000)])
+def test_mixed_radix_compile_time_plans_equal_the_runtime_plan(options, nmesh, npart):
+    """550 / 768 / 1536: the row and y passes run stage sequences with the mesh size, the stage strides and the tile pitch as
+    compile-time constants (csrc/gfft.hip GFixed) - the same butterflies in the same order as the runtime plan
+    (option gfft_nofixed), so the spectra agree to the last few bits (FMA contraction may differ between the two compilations)"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    box = 2000.0
+    pos = synth.synth_positions(npart, box, seed=nmesh, clustered=True)
+    kw = dict(kbins=40, mubins=4, poles=[0, 2, 4], compensated=True, paste='TSC', nmesh=nmesh)
+    for interlaced in (False, True):
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        a = calc_power(pos.copy(), box, interlaced=interlaced, **kw)
+        _lib.profile_enable(False)
+        assert 'gfft_rows' in _lib.profile_get(), sorted(_lib.profile_get())
+        options.set('gfft_nofixed', 1)
+        b = calc_power(pos.copy(), box, interlaced=interlaced, **kw)
+        options.set('gfft_nofixed', 0)
+        np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
+        scale = np.abs(np.asarray(b['power'])).max()
+        np.testing.assert_allclose(a['power'], b['power'], rtol=2e-6, atol=2e-7 * scale)
+        np.testing.assert_allclose(a['poles'], b['poles'], rtol=2e-6, atol=5e-7 * scale)
