@@ -1168,6 +1168,22 @@ int power_dev_once(float *pos, int64_t n, const float *w, float *pos2, int64_t n
                                 2.0 * M_PI / Lbox, 0);
         }
     }
+    if (fused && cross && !interlaced && !option("pk_noxbin") && !option("pk_noxbin_cross")) {
+        // cross power of two non-interlaced fields: both stop after their y pass, the last pass runs over the pair of tiles and
+        // bins Re(conj(a) b) from LDS (fft_x_bin2<.., CROSS>) - two spectrum writes and two re-reads less
+        BinArgs b;
+        size_t acc_bytes = 0;
+        ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
+        if (xbin2_supported(nmesh, b, W_dev != nullptr)) {
+            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 0, 0, true, /*skip_x=*/true, nullptr, pf64, xcut));
+            ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, 0, 2, true, /*skip_x=*/true, nullptr, pf64, xcut));
+            const double M = (double)nmesh * nmesh * nmesh;
+            ABACUS_TRY(fft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, 0, 0, 1, 0, 1,
+                                     g_ctx.mesh[2].as<float>(), nullptr));
+            return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
+                                2.0 * M_PI / Lbox, 0);
+        }
+    }
     if (!fused && !cross && !option("pk_noxbin") && !(interlaced && option("pk_noxbin_inter")) && !option("fft_hipfft") && !fft_native_pow2(nmesh) &&
         gfft_supported(nmesh, 0)) {
         // mixed-radix meshes (compute_power's default 550, 768 ...): the same fusion on gfft's natural-order x pass (gfft.hip);

@@ -59,7 +59,7 @@ struct XBinGeom {
     // interlaced (fft_x_bin2<.., INTER>): the half-cell-shifted field's mesh in the same layout, the table of the exact
     // phases exp(i pi m / n), m < 2n, and f32(0.5 / M) (analysis/power_spectrum.py:932-947, 996-998)
     const float2 *data2 = nullptr;
-    const float2 *phase = nullptr;
+    const float2 *phase = nullptr;      // nullptr with data2: the CROSS form (data2 = the second field, no shift)
     float half_inv_size = 0.f;
     // compact pencil transpose (fft.hip, slab_layout): row yr of the y-slab starts row_off[y0 + yr] elements into a plane block
     // (xs = elements per plane of the blocks this rank receives) instead of yr * ys
@@ -405,7 +405,9 @@ __global__ __launch_bounds__(256) void xbin_geometry(int n, int Nk, int Nmu, con
 // the values of its column(s) in registers; the same tile of the shifted field follows through the same LDS, and the bin
 // takes |(a + a' exp(i pi m / n)) f32(0.5 / M)|^2, m = i + j + k - what spectrum_bin<INTER> computes from two spectra in
 // HBM, without the two x passes writing them (2 x 8M bytes) and the binning reading them back (8M).
-template <int H, int C, int NP, bool COMP, int MU, bool RUNS, bool INTER = false>
+// CROSS (with INTER): the second tile is ANOTHER field's (pos2 of calc_power, not interlaced): the bin takes
+// Re(conj(a) b) f32(1 / M)^2 - get_raw_power's cross form (power_spectrum.py:722-726) - instead of the interlaced combination.
+template <int H, int C, int NP, bool COMP, int MU, bool RUNS, bool INTER = false, bool CROSS = false>
 __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restrict__ data, XBinGeom g, BinArgs b, XDesc d,
                                                           const float2 *__restrict__ twH) {
     constexpr int CP = colpitch_of<H>();
@@ -443,7 +445,8 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     const int ntile_c = (g.kzlen + C - 1) / C;
     const int64_t S = g.xs;
     const int n_outer = 2 * g.ny;
-    const float inv2 = INTER ? g.half_inv_size * g.half_inv_size : g.inv_size * g.inv_size;
+    static_assert(!CROSS || INTER, "the cross form runs the two-tile schedule");
+    const float inv2 = (INTER && !CROSS) ? g.half_inv_size * g.half_inv_size : g.inv_size * g.inv_size;
     const int sh = d.sh;
     const unsigned int *lut0 = lut - d.off;
 
@@ -557,7 +560,14 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
                 continue;
             }
             const int i0 = 2 * a0 + xh;
-            if (INTER) {                        // second field: a + a' exp(i pi m / n), m = i + j + k folded into [0, 2n)
+            if constexpr (CROSS) {              // second field b: Re(conj(a) b), left in .x (the power below takes it from there)
+#pragma unroll
+                for (int s = 0; s < RUN; s++) {
+                    const float2 a = keepA[INTER ? ci : 0][s], bq = keepB[INTER ? ci : 0][s];
+                    vA[s].x = a.x * vA[s].x + a.y * vA[s].y;
+                    vB[s].x = bq.x * vB[s].x + bq.y * vB[s].y;
+                }
+            } else if (INTER) {                 // second field: a + a' exp(i pi m / n), m = i + j + k folded into [0, 2n)
                 // the phases of a lane's run from the table at its first pair, then by the rotation exp(+-2 pi i / n) per step
                 // (i advances by 2): two table reads per lane and column instead of 2 RUN gathers over a 16-KB table
                 const int mjk = jj + k;
@@ -619,8 +629,8 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
             };
 #pragma unroll
             for (int s = 0; s < RUN; s++) {
-                float pA = vA[s].x * vA[s].x + vA[s].y * vA[s].y;      // get_raw_power (:726)
-                float pB = vB[s].x * vB[s].x + vB[s].y * vB[s].y;
+                float pA = CROSS ? vA[s].x : vA[s].x * vA[s].x + vA[s].y * vA[s].y;      // get_raw_power (:726)
+                float pB = CROSS ? vB[s].x : vB[s].x * vB[s].x + vB[s].y * vB[s].y;
                 if (COMP) {                                            // (:1065-1069)
                     const int fA = a0 + s, fB = xh ? H - 1 - fA : (H - fA) & (H - 1);
                     const float sA = __builtin_amdgcn_rcpf(Wl[2 * fA + xh] * wjk), sB = __builtin_amdgcn_rcpf(Wl[2 * fB + xh] * wjk);
@@ -632,13 +642,19 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
             }
             if (!xh && lane == 63) {       // i = n/2 (a = H/2): one mode, last lane of the even half
                 float2 q = (g.dbg & 8) ? make_float2(1.f, 1.f) : col[padq(H / 2)];
-                if (INTER) {
-                    int m = jj + k - H;            // i = n/2 folds to -n/2 (shift_field_fft, power_spectrum.py:940-942)
-                    m += m < 0 ? 2 * n : 0;
-                    const float2 ph = g.phase[m], a = keepQ[INTER ? ci : 0];
-                    q = make_float2(a.x + (q.x * ph.x - q.y * ph.y), a.y + (q.x * ph.y + q.y * ph.x));
+                float p;
+                if constexpr (CROSS) {
+                    const float2 a = keepQ[INTER ? ci : 0];
+                    p = a.x * q.x + a.y * q.y;
+                } else {
+                    if (INTER) {
+                        int m = jj + k - H;            // i = n/2 folds to -n/2 (shift_field_fft, power_spectrum.py:940-942)
+                        m += m < 0 ? 2 * n : 0;
+                        const float2 ph = g.phase[m], a = keepQ[INTER ? ci : 0];
+                        q = make_float2(a.x + (q.x * ph.x - q.y * ph.y), a.y + (q.x * ph.y + q.y * ph.x));
+                    }
+                    p = q.x * q.x + q.y * q.y;
                 }
-                float p = q.x * q.x + q.y * q.y;
                 if (COMP) {
                     const float sc = __builtin_amdgcn_rcpf(Wl[H] * wjk);
                     p *= sc * sc;
@@ -883,7 +899,7 @@ int xdesc_get(int n, int Nk, int Nmu, bool comp, const float *h_e2, const float 
 template <int H, int C, int NP, bool COMP, int MU>
 int launch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const XDesc &d, size_t lds) {
     const bool runs = option("pk_xbin_pairs") == 0;
-    auto kern = g.data2 ? fft_x_bin2<H, C, NP, COMP, MU, true, true>
+    auto kern = g.data2 ? (g.phase ? fft_x_bin2<H, C, NP, COMP, MU, true, true> : fft_x_bin2<H, C, NP, COMP, MU, true, true, true>)
                         : (runs ? fft_x_bin2<H, C, NP, COMP, MU, true> : fft_x_bin2<H, C, NP, COMP, MU, false>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1;
@@ -998,7 +1014,8 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
     XBinGeom g;
     g.n = n, g.kzlen = n / 2 + 1, g.pitch_c = pitch_r / 2, g.inv_size = inv_size, g.W = W_dev, g.dbg = dbg;
     if (mesh_shifted) {
-        if (!phase || layout != 0) return fail("fft_x_bin: the interlaced form needs the phase table and the whole mesh");
+        // phase table: the interlaced pair (whole mesh only); none: `mesh_shifted` is a second field in the same layout, cross power
+        if (phase && layout != 0) return fail("fft_x_bin: the interlaced form needs the whole mesh");
         g.data2 = reinterpret_cast<const float2 *>(mesh_shifted), g.phase = phase;
         g.half_inv_size = (float)(0.5 / ((double)n * n * n));
     }

@@ -173,6 +173,40 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
                                              'whole_step_frac': (24.0 * n + 80.0 * M) / dti / 1e9 / HBM_PEAK_GBS}
         except Exception as e:
             out['interlaced_compensated'] = {'error': repr(e)}
+        # cross power of two fields (LRG x ELG of BASELINE config 5 on one GPU: a second catalogue of n / 2 particles), non-
+        # interlaced: both fields stop after their y pass, the fused last pass bins Re(conj(a) b) from the pair of tiles
+        try:
+            n2 = n // 2
+            pos2 = np.random.default_rng(900 + dist.rank).random((n2, 3), dtype=np.float32)
+            pos2 *= np.float32(L)
+            dpos2 = _lib.DeviceArray(pos2)
+            del pos2
+
+            def cstep():
+                _lib.check(lib.abacus_power_from_particles_dev(
+                    dpos.ptr, C.c_int64(n), None, dpos2.ptr, C.c_int64(n2), None, C.c_double(L), int(nmesh), 0, None, 0,
+                    _lib.ptr(ke), len(ke) - 1, _lib.ptr(me), len(me) - 1, _lib.ptr(poles), len(poles), *[_lib.ptr(o) for o in outs]))
+            cstep()
+            cstep()
+            _lib.sync()
+            t1 = time.perf_counter()
+            for _ in range(max(1, steps // 2)):
+                cstep()
+            _lib.sync()
+            dtc = (time.perf_counter() - t1) / max(1, steps // 2)
+            _lib.profile_reset()
+            _lib.profile_enable(True)
+            cstep()
+            _lib.sync()
+            _lib.profile_enable(False)
+            out['cross'] = {'ms_per_step': dtc * 1e3, 'n_particles_2': n2,
+                            'kernels_ms_per_step': {k: ms for k, (ms, c) in _lib.profile_get().items() if c},
+                            # two deposits + two z / y passes + one read of both half-spectra
+                            'whole_step_GBs': (12.0 * (n + n2) + 48.0 * M) / dtc / 1e9,
+                            'whole_step_frac': (12.0 * (n + n2) + 48.0 * M) / dtc / 1e9 / HBM_PEAK_GBS}
+            dpos2.free()
+        except Exception as e:
+            out['cross'] = {'error': repr(e)}
     dpos.free()
     # the drop-in call itself: calc_power on the NumPy positions (PCIe included; never the `value`): the upload runs in batches
     # on a copy stream, each batch deposited while the next is on the link (csrc/power.hip, HostSrc)

@@ -529,6 +529,49 @@ def test_fused_last_pass_matches_spectrum_bin(options, nmesh, comp):
                 np.testing.assert_allclose(a['poles'], b['poles'], rtol=2e-6, atol=2e-7 * np.abs(b['power']).max(), err_msg=name)
 
 
+@pytest.mark.parametrize('nmesh,comp', [(1024, True), (1024, False), (2048, False)])
+def test_fused_last_pass_cross_power_matches_spectrum_bin(options, nmesh, comp):
+    """the cross form of the fused last pass (fft_x_bin2<.., CROSS>: the first field's tile kept in registers, the second
+    field's through the same LDS, Re(conj(a) b) f32(1 / M)^2 binned from there - get_raw_power with field2_fft,
+    analysis/power_spectrum.py:707-727) against two complete transforms + spectrum_bin on the same particles (option
+    pk_noxbin_cross), and against the oracle at 1024: LRG x ELG of BASELINE config 5 runs this"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    box = 1000.0
+    pos = synth.synth_positions(2_000_000, box, seed=191, clustered=True)
+    pos2 = synth.synth_positions(1_200_000, box, seed=192, clustered=True)
+    pos2[:400_000] = pos[:400_000]            # a shared population: the cross power is not just noise around zero
+    w = np.random.default_rng(14).random(len(pos), dtype=np.float32) + np.float32(0.5)
+    cases = (dict(kbins=64, mubins=4, poles=[0, 2, 4]), dict(kbins=300, mubins=None, poles=[0, 2], k_max=np.pi * nmesh / box + 1e-6),
+             dict(kbins=24, mubins=8, poles=[], logk=True, k_max=2.0, w=w),
+             dict(kbins=40, mubins=3, poles=[0, 2, 4], k_max=1.7 * np.pi * nmesh / box))
+    for kw in (cases if nmesh == 1024 else cases[:2]):
+        kw = dict(kw, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=False)
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        a = calc_power(pos.copy(), box, pos2=pos2.copy(), **kw)
+        _lib.profile_enable(False)
+        prof = _lib.profile_get()
+        assert 'fft_x_bin' in prof and 'spectrum_bin' not in prof and 'fft_cols_x' not in prof, sorted(prof)
+        options.set('pk_noxbin_cross', 1)
+        b = calc_power(pos.copy(), box, pos2=pos2.copy(), **kw)
+        options.set('pk_noxbin_cross', 0)
+        np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
+        scale = np.abs(np.asarray(b['power'])).max()
+        np.testing.assert_allclose(a['power'], b['power'], rtol=3e-6, atol=3e-7 * scale)
+        np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)
+        if kw['poles']:
+            np.testing.assert_allclose(a['poles'], b['poles'], rtol=3e-6, atol=5e-7 * scale)
+    if nmesh == 1024:
+        from oracle import oracle
+        kw = dict(kbins=20, mubins=3, k_max=1.2, paste='TSC', nmesh=1024, compensated=comp, interlaced=False, poles=[0, 2])
+        s1 = synth.synth_positions(300_000, box, seed=193, clustered=True)
+        s2 = synth.synth_positions(200_000, box, seed=194, clustered=True)
+        s2[:80_000] = s1[:80_000]
+        _check_oracle(calc_power(s1.copy(), box, pos2=s2.copy(), **kw),
+                      oracle.calc_power(s1.copy(), box, pos2=s2.copy(), nthread=oracle.max_threads(), accum64=True, **kw))
+
+
 @pytest.mark.parametrize('nmesh,comp', [(1024, True), (1024, False), (2048, True)])
 def test_fused_last_pass_interlaced_pair_matches_spectrum_bin(options, nmesh, comp):
     """the interlaced form of the fused last pass (fft_x_bin2<.., INTER>: the unshifted field's tile kept in registers, the
