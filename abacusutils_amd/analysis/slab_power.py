@@ -158,16 +158,20 @@ class HipSlabBackend:
                                                   len(poles), _lib.ptr(raw)))
         return raw
 
-    def xbin_raw(self, field, nmesh, world, y0, nyl, Lbox, W, ke, me, poles, put_geom, from_transpose=False):
-        """last x pass fused with the binning (auto power, one non-interlaced field, nmesh 1024 / 2048): raw sums, or None
-        when the library does not serve this mesh / histogram that way (then unpack + fft_x + bin_raw).  from_transpose:
-        `field` is the receive buffer of the pencil transpose, (peer, 2 h, y_local, k), not yet unpacked"""
+    xbin_cross = True      # xbin_raw takes field2: the cross power of two non-interlaced fields from the same pass
+
+    def xbin_raw(self, field, nmesh, world, y0, nyl, Lbox, W, ke, me, poles, put_geom, from_transpose=False, field2=None):
+        """last x pass fused with the binning (one non-interlaced field, or the cross power with a second one; nmesh 1024 /
+        2048): raw sums, or None when the library does not serve this mesh / histogram that way (then unpack + fft_x +
+        bin_raw).  from_transpose: `field` is the receive buffer of the pencil transpose, (peer, 2 h, y_local, k), not yet
+        unpacked"""
         buf, off = field if field is not None else (None, 0)   # field None: a query (0 / None, nothing computed)
         raw = np.zeros(self.raw_bytes(len(ke) - 1, len(me) - 1, poles), dtype=np.uint8)
-        rc = _lib.lib().abacus_slab_xbin_dev(None if buf is None else buf.ptr(off), int(nmesh), int(world), int(y0), int(nyl), C.c_double(Lbox),
-                                             None if W is None else _lib.ptr(W), _lib.ptr(ke), len(ke) - 1, _lib.ptr(me),
-                                             len(me) - 1, _lib.ptr(poles), len(poles), int(bool(put_geom)),
-                                             int(from_transpose), _lib.ptr(raw))
+        rc = _lib.lib().abacus_slab_xbin_cross_dev(None if buf is None else buf.ptr(off), None if field2 is None else field2[0].ptr(field2[1]),
+                                                   int(nmesh), int(world), int(y0), int(nyl), C.c_double(Lbox),
+                                                   None if W is None else _lib.ptr(W), _lib.ptr(ke), len(ke) - 1, _lib.ptr(me),
+                                                   len(me) - 1, _lib.ptr(poles), len(poles), int(bool(put_geom)),
+                                                   int(from_transpose), _lib.ptr(raw))
         if rc == 1:
             return None
         _lib.check(rc)
@@ -267,7 +271,7 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     lazy = {}                             # send / recv buffers of the transpose, allocated when a step needs them (one rank whose
 
     def tbuf(name):                       # last pass bins straight from its mesh needs neither: 2 x 18 GB at 2048^3)
-        if name not in lazy:
+        if name not in lazy:              # ('send', 'recv'; 'recv2': the second field of a fused cross power keeps its own)
             if Pc is None:
                 lazy[name] = backend.new_buffer(2 * h * plane)
             else:                         # compact: what goes out to all peers / what comes in from them (floats)
@@ -278,8 +282,9 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     xa = r * h                            # first plane of the first slab; the second starts at xa + nmesh / 2
     own = g                               # float offset of the first owned plane
 
-    # auto power of one non-interlaced field: the last x pass can bin straight from LDS (no spectrum write + re-read)
-    try_xbin = pos2 is None and not interlaced and hasattr(backend, 'xbin_raw')
+    # auto power of one non-interlaced field, or the cross power of two: the last x pass can bin straight from LDS (no
+    # spectrum write + re-read)
+    try_xbin = not interlaced and hasattr(backend, 'xbin_raw') and (pos2 is None or getattr(backend, 'xbin_cross', False))
     # ... and then nothing but that binning reads the transposed spectrum: the columns of a row beyond its last edge need not
     # cross the links (COMPACT transpose, csrc/fft.hip slab_layout: -21 % with bins up to the Nyquist frequency)
     Pc = None
@@ -289,7 +294,7 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     if Pc is not None:
         csoff = np.concatenate(([0], np.cumsum(2 * h * Pc)[:-1]))          # complex offset of every peer's block in the send buffer
 
-    def spectrum(particles, ntot, offset, mesh):
+    def spectrum(particles, ntot, offset, mesh, recv='recv'):
         norm = float(np.float32(float(nmesh) ** 3 / float(ntot)))   # dtype(field.size / tot_weight) (:856,894)
         # every cell is written as rho * norm - 1 (the overdensity's "-1" costs no pass of its own); a ghost block holds
         # contribution - 1, so its owner adds ghost + 1
@@ -321,7 +326,7 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
             if Pc is not None:
                 backend.fft_zy(mesh, own, tbuf('send'), nmesh, W, xsep, xa, c * cp, cp, compact=(Lbox, float(ke[-1])))
                 for s_ in (0, 1):                             # the chunk's planes of either half: cp P[p] elements to peer p
-                    comm.all_to_all_piece_v(backend, tbuf('send'), tbuf('recv'),
+                    comm.all_to_all_piece_v(backend, tbuf('send'), tbuf(recv),
                                             2 * (csoff + (s_ * h + c * cp) * Pc), 2 * cp * Pc,
                                             2 * (np.arange(W) * 2 * h + s_ * h + c * cp) * Pc[r], np.full(W, 2 * cp * Pc[r]),
                                             overlap=nchunk > 1)
@@ -329,13 +334,13 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
             backend.fft_zy(mesh, own, None if direct else tbuf('send'), nmesh, W, xsep, xa, c * cp, cp)
             if comm.collective:
                 for s_ in (0, 1):                             # the chunk's planes of either half within every peer block
-                    comm.all_to_all_piece(backend, tbuf('send'), tbuf('recv'), 2 * h * nyl * pitch,
+                    comm.all_to_all_piece(backend, tbuf('send'), tbuf(recv), 2 * h * nyl * pitch,
                                           (s_ * h + c * cp) * nyl * pitch, cp * nyl * pitch, overlap=nchunk > 1)
         if comm.collective:
             comm.join()
         if direct:
             return (mesh, own)
-        got = tbuf('recv') if comm.collective else tbuf('send')
+        got = tbuf(recv) if comm.collective else tbuf('send')
         if try_xbin:                                          # (peer, 2 h, y_local, k) as delivered: for the fused last pass
             return (got, 0)
         backend.unpack(got, mesh, 0, nmesh, W)               # mesh now holds (y_local, x, k)
@@ -348,7 +353,7 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     for p_, w_, nt in sets:
         ntot = nt if nt is not None else comm.all_reduce_int(p_.shape[0])   # tot_weight = len(pos), also with weights (:1021)
         particles = backend.upload_particles(p_, w_)
-        fields.append(spectrum(particles, ntot, 0.0, meshes[mi]))
+        fields.append(spectrum(particles, ntot, 0.0, meshes[mi], 'recv' if not fields else 'recv2'))
         mi += 1
         if interlaced:
             fields.append(spectrum(particles, ntot, 0.5 * d, meshes[mi]))
@@ -359,18 +364,20 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         fields += [(None, 0), (None, 0)]
     raw = None
     if try_xbin:
+        xkw = dict(field2=fields[2]) if pos2 is not None else {}
         raw = backend.xbin_raw(fields[0], nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, r == 0,
-                               from_transpose=2 if Pc is not None else True)
+                               from_transpose=2 if Pc is not None else True, **xkw)
         if raw is None and Pc is not None:
             raise RuntimeError('calc_power_slab: the fused last pass declined a compact transpose it had accepted')
         if raw is None:      # not served: unpack, x pass, binning
-            src, off = fields[0]
-            if src is meshes[0]:                              # one rank went straight from its mesh: it still has to be packed
-                backend.pack(meshes[0], off, tbuf('send'), nmesh, W, xsep, 0, h)
-                src = tbuf('send')
-            backend.unpack(src, meshes[0], 0, nmesh, W)
-            backend.fft_x(meshes[0], 0, nmesh, nyl)
-            fields[0] = (meshes[0], 0)
+            for fi, mj in ((0, 0),) + (((2, 1),) if pos2 is not None else ()):
+                src, off = fields[fi]
+                if src is meshes[mj]:                         # one rank went straight from its mesh: it still has to be packed
+                    backend.pack(meshes[mj], off, tbuf('send'), nmesh, W, xsep, 0, h)
+                    src = tbuf('send')
+                backend.unpack(src, meshes[mj], 0, nmesh, W)
+                backend.fft_x(meshes[mj], 0, nmesh, nyl)
+                fields[fi] = (meshes[mj], 0)
     if raw is None:
         raw = backend.bin_raw(fields, nmesh, r * nyl, nyl, Lbox, Wk, interlaced, ke, me, poles_arr)
     raw = comm.all_reduce_raw(raw, (len(ke) - 1) * (len(me) - 1))

@@ -303,6 +303,57 @@ def test_compact_transpose_sends_a_fifth_less(world, nmesh, kfrac):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('world,nmesh', [(8, 1024), (4, 2048), (1, 1024)])
+def test_cross_power_over_slabs_takes_the_fused_last_pass(world, nmesh):
+    """calc_power_slab(pos, pos2=..., interlaced=False) - LRG x ELG of BASELINE config 5: both fields stop after their y pass, each
+    crosses the links in the compact layout into its own receive buffer, and ONE fused last pass bins Re(conj(a) b) from the pair
+    (fft_x_bin2<.., CROSS>).  Against the single-GPU cross power (1e-5, N_mode exact), bit-identical between the compact and the
+    regular transpose, and no separate x pass / spectrum_bin launched"""
+    from thread_comm import run_ranks
+
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis import slab_power as sp
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    n = 500000 if nmesh < 2048 else 1_500_000
+    pos = synth_positions(n, L, seed=61, clustered=True)
+    pos2 = synth_positions(n // 2, L, seed=62, clustered=True)
+    pos2[:n // 5] = pos[:n // 5]
+    kw = dict(kbins=48, mubins=3, paste='TSC', nmesh=nmesh, compensated=True, interlaced=False, poles=[0, 2, 4])
+    ref = calc_power(pos.copy(), L, pos2=pos2.copy(), **kw)
+
+    def rank_fn(comm):
+        mine = slice(comm.rank, None, comm.world)
+        p1, _ = sp.route_particles(pos[mine], None, L, comm, fold=True)
+        p2, _ = sp.route_particles(pos2[mine], None, L, comm, fold=True)
+        t = sp.calc_power_slab(p1, L, comm=comm, backend=sp.HipSlabBackend(), pos2=p2, **kw)
+        return getattr(comm, 'floats_sent', 0), {k: np.asarray(t[k]) for k in ('power', 'N_mode', 'poles', 'k_avg')}
+
+    out = {}
+    for mode in ('compact', 'regular'):
+        _lib.set_option('slab_nocompact', 1 if mode == 'regular' else 0)
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        try:
+            out[mode] = run_ranks(world, rank_fn)
+        finally:
+            _lib.profile_enable(False)
+            _lib.set_option('slab_nocompact', 0)
+        prof = _lib.profile_get()
+        assert 'fft_x_bin' in prof and 'spectrum_bin' not in prof and 'fft_cols_x' not in prof, sorted(prof)
+    if world > 1:
+        sent = {m: sum(r[0] for r in out[m]) for m in out}
+        assert sent['compact'] <= 0.80 * sent['regular'], sent
+    for (_, a), (_, b) in zip(out['compact'], out['regular']):
+        for k in ('power', 'N_mode', 'poles', 'k_avg'):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    scale = np.abs(np.asarray(ref['power'])).max()
+    for _, t in out['compact']:
+        np.testing.assert_array_equal(t['N_mode'], np.asarray(ref['N_mode']))
+        np.testing.assert_allclose(t['power'], np.asarray(ref['power']), rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(t['poles'], np.asarray(ref['poles']), rtol=1e-5, atol=1e-6 * scale)
+
+
+@pytest.mark.gpu
 def test_config5_in_miniature_eight_ranks_as_threads():
     """BASELINE config 5's composition on eight ranks (threads on the one GPU): sharded multi-tracer HOD -> every rank keeps its
     galaxies -> folded-slab routing -> LRG x ELG cross P(k) over the slabs, and DD(r) of the ELGs over x-slabs - against the
