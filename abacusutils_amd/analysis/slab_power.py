@@ -158,16 +158,18 @@ class HipSlabBackend:
                                                   len(poles), _lib.ptr(raw)))
         return raw
 
-    xbin_cross = True      # xbin_raw takes field2: the cross power of two non-interlaced fields from the same pass
+    xbin_pair = True       # xbin_raw takes field2: a second field (cross power) or the shifted deposit of an interlaced pair
 
-    def xbin_raw(self, field, nmesh, world, y0, nyl, Lbox, W, ke, me, poles, put_geom, from_transpose=False, field2=None):
-        """last x pass fused with the binning (one non-interlaced field, or the cross power with a second one; nmesh 1024 /
-        2048): raw sums, or None when the library does not serve this mesh / histogram that way (then unpack + fft_x +
-        bin_raw).  from_transpose: `field` is the receive buffer of the pencil transpose, (peer, 2 h, y_local, k), not yet
-        unpacked"""
+    def xbin_raw(self, field, nmesh, world, y0, nyl, Lbox, W, ke, me, poles, put_geom, from_transpose=False, field2=None,
+                 interlaced=False, cross=False):
+        """last x pass fused with the binning (one non-interlaced field; with field2 the cross power with a second one or,
+        `interlaced`, the auto power of the interlaced pair (field, field2 = shifted); nmesh 1024 / 2048): raw sums, or None
+        when the library does not serve this mesh / histogram that way (then unpack + fft_x + bin_raw).  from_transpose:
+        `field` is the receive buffer of the pencil transpose, (peer, 2 h, y_local, k), not yet unpacked"""
         buf, off = field if field is not None else (None, 0)   # field None: a query (0 / None, nothing computed)
         raw = np.zeros(self.raw_bytes(len(ke) - 1, len(me) - 1, poles), dtype=np.uint8)
-        rc = _lib.lib().abacus_slab_xbin_cross_dev(None if buf is None else buf.ptr(off), None if field2 is None else field2[0].ptr(field2[1]),
+        rc = _lib.lib().abacus_slab_xbin_pair_dev(None if buf is None else buf.ptr(off), None if field2 is None else field2[0].ptr(field2[1]),
+                                                   1 if interlaced else 2 if (field2 is not None or cross) else 0,
                                                    int(nmesh), int(world), int(y0), int(nyl), C.c_double(Lbox),
                                                    None if W is None else _lib.ptr(W), _lib.ptr(ke), len(ke) - 1, _lib.ptr(me),
                                                    len(me) - 1, _lib.ptr(poles), len(poles), int(bool(put_geom)),
@@ -284,10 +286,14 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
 
     # auto power of one non-interlaced field, or the cross power of two: the last x pass can bin straight from LDS (no
     # spectrum write + re-read)
-    try_xbin = not interlaced and hasattr(backend, 'xbin_raw') and (pos2 is None or getattr(backend, 'xbin_cross', False))
+    # (likewise a pair of fields through one pass: the interlaced pair of an auto power, the two fields of a cross power)
+    try_xbin = hasattr(backend, 'xbin_raw') and (nfields == 1 or (nfields == 2 and getattr(backend, 'xbin_pair', False)))
     # ... and then nothing but that binning reads the transposed spectrum: the columns of a row beyond its last edge need not
     # cross the links (COMPACT transpose, csrc/fft.hip slab_layout: -21 % with bins up to the Nyquist frequency)
     Pc = None
+    if try_xbin and nfields == 2:       # asked before any work: will the pair be served?  (else the plain three-pass form)
+        try_xbin = backend.xbin_raw(None, nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, False, from_transpose=True,
+                                    interlaced=interlaced, cross=pos2 is not None) is not None
     if try_xbin and comm.collective and hasattr(backend, 'transpose_layout') and hasattr(comm, 'all_to_all_piece_v'):
         if backend.xbin_raw(None, nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, False, from_transpose=True) is not None:
             Pc = backend.transpose_layout(nmesh, W, Lbox, float(ke[-1]))
@@ -356,7 +362,7 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         fields.append(spectrum(particles, ntot, 0.0, meshes[mi], 'recv' if not fields else 'recv2'))
         mi += 1
         if interlaced:
-            fields.append(spectrum(particles, ntot, 0.5 * d, meshes[mi]))
+            fields.append(spectrum(particles, ntot, 0.5 * d, meshes[mi], 'recv2' if try_xbin else 'recv'))
             mi += 1
         else:
             fields.append((None, 0))
@@ -364,13 +370,13 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         fields += [(None, 0), (None, 0)]
     raw = None
     if try_xbin:
-        xkw = dict(field2=fields[2]) if pos2 is not None else {}
+        xkw = dict(field2=fields[2]) if pos2 is not None else dict(field2=fields[1], interlaced=True) if interlaced else {}
         raw = backend.xbin_raw(fields[0], nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, r == 0,
                                from_transpose=2 if Pc is not None else True, **xkw)
         if raw is None and Pc is not None:
             raise RuntimeError('calc_power_slab: the fused last pass declined a compact transpose it had accepted')
         if raw is None:      # not served: unpack, x pass, binning
-            for fi, mj in ((0, 0),) + (((2, 1),) if pos2 is not None else ()):
+            for fi, mj in ((0, 0),) + (((2, 1),) if pos2 is not None else ((1, 1),) if interlaced else ()):
                 src, off = fields[fi]
                 if src is meshes[mj]:                         # one rank went straight from its mesh: it still has to be packed
                     backend.pack(meshes[mj], off, tbuf('send'), nmesh, W, xsep, 0, h)

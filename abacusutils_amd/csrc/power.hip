@@ -1584,16 +1584,23 @@ int abacus_slab_bin_dev(const void *a, const void *as, const void *b, const void
 int abacus_slab_xbin_dev(const void *mesh, int nmesh, int world, int y0, int ny_local, double Lbox, const float *W_host,
                          const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
                          int put_geom, int from_transpose, void *raw_out) {
-    return abacus_slab_xbin_cross_dev(mesh, nullptr, nmesh, world, y0, ny_local, Lbox, W_host, kedges, Nk, muedges, Nmu, poles, Np, put_geom,
-                                      from_transpose, raw_out);
+    return abacus_slab_xbin_pair_dev(mesh, nullptr, 0, nmesh, world, y0, ny_local, Lbox, W_host, kedges, Nk, muedges, Nmu, poles, Np, put_geom,
+                                     from_transpose, raw_out);
 }
 
-// the same over TWO fields in the same layout (mesh2 != NULL): their cross power Re(conj(a) b), calc_power(pos, pos2=...,
-// interlaced=False) over slabs - LRG x ELG of BASELINE config 5.  mesh2 == NULL: abacus_slab_xbin_dev
-int abacus_slab_xbin_cross_dev(const void *mesh, const void *mesh2, int nmesh, int world, int y0, int ny_local, double Lbox,
-                               const float *W_host, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
-                               int Np, int put_geom, int from_transpose, void *raw_out) {
+// the same over TWO fields in the same layout.  pair_mode 2: their cross power Re(conj(a) b), calc_power(pos, pos2=...,
+// interlaced=False) over slabs - LRG x ELG of BASELINE config 5; pair_mode 1: mesh2 is the half-cell-shifted deposit of the
+// same particles, the auto power of the interlaced combination (calc_power's default mode, power_spectrum.py:951-998);
+// pair_mode 0 (mesh2 ignored): abacus_slab_xbin_dev.  The query form (mesh == NULL) answers for the pair_mode it is given
+int abacus_slab_xbin_pair_dev(const void *mesh, const void *mesh2, int pair_mode, int nmesh, int world, int y0, int ny_local, double Lbox,
+                              const float *W_host, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
+                              int Np, int put_geom, int from_transpose, void *raw_out) {
     ABACUS_ENTER();
+    if (pair_mode < 0 || pair_mode > 2) return fail("abacus_slab_xbin_pair_dev: pair_mode %d", pair_mode);
+    if (mesh && pair_mode && !mesh2) return fail("abacus_slab_xbin_pair_dev: pair_mode %d without a second field", pair_mode);
+    if ((pair_mode == 1 && option("pk_noxbin_inter")) || (pair_mode == 2 && option("pk_noxbin_cross"))) return 1;
+    if (pair_mode == 1) ABACUS_TRY(ensure_phase(nmesh));
+    if (!pair_mode) mesh2 = nullptr;
     if (!slab_fused(nmesh) || option("pk_noxbin") || (nmesh != 1024 && nmesh != 2048)) return 1;
     if (from_transpose && option("slab_nounpackfuse")) return 1;
     int h;
@@ -1614,7 +1621,8 @@ int abacus_slab_xbin_cross_dev(const void *mesh, const void *mesh2, int nmesh, i
     }
     const double M = (double)nmesh * nmesh * nmesh;
     ABACUS_TRY(fft_x_bin_run((const float *)mesh, nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, y0, ny_local,
-                             put_geom ? 1 : 0, from_transpose ? 2 : 1, world, (const float *)mesh2, nullptr, row_off, P[y0 / std::max(ny_local, 1)]));
+                             put_geom ? 1 : 0, from_transpose ? 2 : 1, world, (const float *)mesh2,
+                             pair_mode == 1 ? g_ctx.phase.as<float2>() : nullptr, row_off, P[y0 / std::max(ny_local, 1)]));
     HIP_TRY(hipMemcpyAsync(raw_out, g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;

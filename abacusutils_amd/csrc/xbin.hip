@@ -1014,8 +1014,7 @@ int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const f
     XBinGeom g;
     g.n = n, g.kzlen = n / 2 + 1, g.pitch_c = pitch_r / 2, g.inv_size = inv_size, g.W = W_dev, g.dbg = dbg;
     if (mesh_shifted) {
-        // phase table: the interlaced pair (whole mesh only); none: `mesh_shifted` is a second field in the same layout, cross power
-        if (phase && layout != 0) return fail("fft_x_bin: the interlaced form needs the whole mesh");
+        // phase table: the interlaced pair; none: `mesh_shifted` is a second field, cross power - in the layout of `mesh` either way
         g.data2 = reinterpret_cast<const float2 *>(mesh_shifted), g.phase = phase;
         g.half_inv_size = (float)(0.5 / ((double)n * n * n));
     }

@@ -382,11 +382,13 @@ int abacus_slab_fused(int nmesh);
 int abacus_slab_xbin_dev(const void *mesh, int nmesh, int world, int y0, int ny_local, double Lbox, const float *W_host,
                          const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles, int Np,
                          int put_geom, int from_transpose, void *raw_out);
-/* the same over two fields in the same layout: their cross power Re(conj(a) b) (calc_power(pos, pos2=..., interlaced=False),
- * analysis/power_spectrum.py:707-727 with field2_fft); mesh2 == NULL is abacus_slab_xbin_dev */
-int abacus_slab_xbin_cross_dev(const void *mesh, const void *mesh2, int nmesh, int world, int y0, int ny_local, double Lbox,
-                               const float *W_host, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
-                               int Np, int put_geom, int from_transpose, void *raw_out);
+/* the same over two fields in the same layout.  pair_mode 2: their cross power Re(conj(a) b) (calc_power(pos, pos2=...,
+ * interlaced=False), analysis/power_spectrum.py:707-727 with field2_fft); pair_mode 1: mesh2 is the half-cell-shifted deposit of
+ * the same particles - the auto power of the interlaced combination (:951-998); pair_mode 0 is abacus_slab_xbin_dev (mesh2
+ * ignored).  The query form (mesh == NULL) answers for the pair_mode given */
+int abacus_slab_xbin_pair_dev(const void *mesh, const void *mesh2, int pair_mode, int nmesh, int world, int y0, int ny_local, double Lbox,
+                              const float *W_host, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
+                              int Np, int put_geom, int from_transpose, void *raw_out);
 /* particle routing on the device: stable bucket sort of (pos (n,3) float32, w or NULL) by the rank that owns the wrapped x
  * (fold = 0: x-slabs of width Lbox / world; fold = 1: the folded slabs above, rank = slab mod world of 2 world slabs);
  * counts[world] on the host.  The blocks then travel with abacus_comm_all_to_all_v. */

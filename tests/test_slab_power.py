@@ -303,12 +303,14 @@ def test_compact_transpose_sends_a_fifth_less(world, nmesh, kfrac):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('world,nmesh', [(8, 1024), (4, 2048), (1, 1024)])
-def test_cross_power_over_slabs_takes_the_fused_last_pass(world, nmesh):
-    """calc_power_slab(pos, pos2=..., interlaced=False) - LRG x ELG of BASELINE config 5: both fields stop after their y pass, each
-    crosses the links in the compact layout into its own receive buffer, and ONE fused last pass bins Re(conj(a) b) from the pair
-    (fft_x_bin2<.., CROSS>).  Against the single-GPU cross power (1e-5, N_mode exact), bit-identical between the compact and the
-    regular transpose, and no separate x pass / spectrum_bin launched"""
+@pytest.mark.parametrize('world,nmesh,mode', [(8, 1024, 'cross'), (4, 2048, 'cross'), (1, 1024, 'cross'), (8, 1024, 'interlaced'),
+                                              (8, 2048, 'interlaced'), (1, 1024, 'interlaced')])
+def test_field_pairs_over_slabs_take_the_fused_last_pass(world, nmesh, mode):
+    """calc_power_slab(pos, pos2=..., interlaced=False) - LRG x ELG of BASELINE config 5 - and calc_power_slab(pos,
+    interlaced=True) - the reference's default mode: both fields of the pair stop after their y pass, each crosses the links in
+    the compact layout into its own receive buffer, and ONE fused last pass bins Re(conj(a) b), or |a + a' exp(i pi m / n)|^2 / 4,
+    from the pair (fft_x_bin2<.., INTER[, CROSS]>).  Against the single-GPU spectrum (1e-5, N_mode exact), bit-identical between
+    the compact and the regular transpose, and no separate x pass / spectrum_bin launched"""
     from thread_comm import run_ranks
 
     from abacusutils_amd import _lib
@@ -316,15 +318,17 @@ def test_cross_power_over_slabs_takes_the_fused_last_pass(world, nmesh):
     from abacusutils_amd.analysis.power_spectrum import calc_power
     n = 500000 if nmesh < 2048 else 1_500_000
     pos = synth_positions(n, L, seed=61, clustered=True)
-    pos2 = synth_positions(n // 2, L, seed=62, clustered=True)
-    pos2[:n // 5] = pos[:n // 5]
-    kw = dict(kbins=48, mubins=3, paste='TSC', nmesh=nmesh, compensated=True, interlaced=False, poles=[0, 2, 4])
-    ref = calc_power(pos.copy(), L, pos2=pos2.copy(), **kw)
+    pos2 = None
+    if mode == 'cross':
+        pos2 = synth_positions(n // 2, L, seed=62, clustered=True)
+        pos2[:n // 5] = pos[:n // 5]
+    kw = dict(kbins=48, mubins=3, paste='TSC', nmesh=nmesh, compensated=True, interlaced=mode == 'interlaced', poles=[0, 2, 4])
+    ref = calc_power(pos.copy(), L, pos2=None if pos2 is None else pos2.copy(), **kw)
 
     def rank_fn(comm):
         mine = slice(comm.rank, None, comm.world)
         p1, _ = sp.route_particles(pos[mine], None, L, comm, fold=True)
-        p2, _ = sp.route_particles(pos2[mine], None, L, comm, fold=True)
+        p2 = None if pos2 is None else sp.route_particles(pos2[mine], None, L, comm, fold=True)[0]
         t = sp.calc_power_slab(p1, L, comm=comm, backend=sp.HipSlabBackend(), pos2=p2, **kw)
         return getattr(comm, 'floats_sent', 0), {k: np.asarray(t[k]) for k in ('power', 'N_mode', 'poles', 'k_avg')}
 
