@@ -461,7 +461,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
         for (int q = 0; q < 8; q++) {
             const int e = q * XB_THREADS + tid;
             const int c2 = (e % (C / 2)) * 2, y = e / (C / 2);
-            gload16_async(regs[q], p + (int64_t)(y >> lgh) * g.ps + (int64_t)(y & hmask) * S + c2);
+            if (!(g.dbg & 32)) gload16_async(regs[q], p + (int64_t)(y >> lgh) * g.ps + (int64_t)(y & hmask) * S + c2);   // 32: ablation, no loads
         }
     };
     // registers -> LDS THROUGH the first radix-8 pass: load q of a thread is row tid / (C/2) + q * H/8 of its column pair,
