@@ -596,17 +596,22 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
                     }
                 }
             };
-            auto bin = [&](int vv, float p, bool first) {
+            // where a mode goes: independent of the data - the RUN look-ups of a lane's run are issued together, ahead of the
+            // run-length accumulation below (one after the other, each behind its own LDS round trip, they were a third of the
+            // binning's time at two waves per SIMD)
+            auto locate = [&](int vv, int &tb, int &eb, float &mu2) {
                 const float vf1 = fmaxf((float)vv, 1.f);            // kmag2 = 0: the cell of 1, mu2 = 0 (:243)
-                const int eb = xd_eb(lut0, sh, vv, vf1);
+                eb = xd_eb(lut0, sh, vv, vf1);
                 int bmu = 0;
 #pragma unroll
                 for (int m = 0; m < MU - 1; m++) bmu += vv <= Uk[m] ? 1 : 0;
-                const int tb = (int)__umul24(eb, Nmu) + bmu;
+                tb = (int)__umul24(eb, Nmu) + bmu;
+                mu2 = NP > 0 ? k2f * __builtin_amdgcn_rcpf(vf1) : 0.f;
+            };
+            auto bin = [&](int tb, int eb, float mu2, float p, bool first) {
                 const float pw = p * scale;
                 float t2 = 0.f, t4 = 0.f;
                 if (NP > 0) {
-                    const float mu2 = k2f * __builtin_amdgcn_rcpf(vf1);
                     t2 = pw * mu2;
                     t4 = t2 * mu2;
                 }
@@ -627,6 +632,16 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
                     }
                 }
             };
+            constexpr bool HOIST = !INTER;       // (the pair forms hold a kept column in registers: no room for the look-ups of a run)
+            int tbs[HOIST ? RUN : 1], ebs[HOIST ? RUN : 1];
+            float mu2s[HOIST ? RUN : 1];
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int s = 0; s < RUN; s++) {
+                    locate(v, tbs[s], ebs[s], mu2s[s]);
+                    v += inc, inc += 8;
+                }
+            }
 #pragma unroll
             for (int s = 0; s < RUN; s++) {
                 float pA = CROSS ? vA[s].x : vA[s].x * vA[s].x + vA[s].y * vA[s].y;      // get_raw_power (:726)
@@ -637,8 +652,15 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
                     pA *= sA * sA, pB *= sB * sB;
                 }
                 if (s == 0) pB *= mB0;
-                bin(v, pA + pB, s == 0);
-                v += inc, inc += 8;
+                if constexpr (HOIST) {
+                    bin(tbs[s], ebs[s], mu2s[s], pA + pB, s == 0);
+                } else {
+                    int tb1, eb1;
+                    float mu21;
+                    locate(v, tb1, eb1, mu21);
+                    v += inc, inc += 8;
+                    bin(tb1, eb1, mu21, pA + pB, s == 0);
+                }
             }
             if (!xh && lane == 63) {       // i = n/2 (a = H/2): one mode, last lane of the even half
                 float2 q = (g.dbg & 8) ? make_float2(1.f, 1.f) : col[padq(H / 2)];
@@ -659,7 +681,10 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
                     const float sc = __builtin_amdgcn_rcpf(Wl[H] * wjk);
                     p *= sc * sc;
                 }
-                bin(r2 + H * H, p, false);
+                int tbq, ebq;
+                float mu2q;
+                locate(r2 + H * H, tbq, ebq, mu2q);
+                bin(tbq, ebq, mu2q, p, false);
             }
             if (RUNS && (unsigned int)(curk - 1) < (unsigned int)Nk) flush();
         }
