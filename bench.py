@@ -131,10 +131,13 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
     dom_bytes = {'hod_filter': bh0 * nh + bp0 * npart, 'hod_deal': 6.0 * nc0, 'hod_exact': 130.0 * nc0, 'hod_emit': 192.0 * ngal}
     per_step = {k: warm[k] * launches.get(k, 1.0) for k in warm if k in STEP}
     tmax = max(per_step.values(), default=0.0)
-    # (the three kernels of the C2 index path lie within a microsecond of each other and trade places from run to run: kernels
-    # within 10 % of the longest count as a tie, which the one moving more bytes wins - never the 0.7-MB dealing kernel over the
-    # gather kernel on a coin toss)
-    dom_name = max((k for k in per_step if per_step[k] >= 0.9 * tmax), key=lambda k: (dom_bytes.get(k, 0.0), per_step[k]), default=None)
+    # (the three kernels of the C2 index path lie within two microseconds of each other and trade places from run to run - 13.7 / 15.6
+    # / 11.5 us in one run, 15.2 / 13.9 / 11.3 in the next: hod_deal, the 6-B-per-candidate work distribution in front of the gather,
+    # is the dominant kernel only where it clearly is, more than 1.5 x the longest of the kernels that touch the catalogue)
+    others = {k: v for k, v in per_step.items() if k != 'hod_deal'}
+    dom_name = max(others, key=others.get, default=None)
+    if 'hod_deal' in per_step and (dom_name is None or per_step['hod_deal'] > 1.5 * others[dom_name]):
+        dom_name = 'hod_deal'
     bytes_pick = max((k for k in per_step if per_step[k] >= 0.5 * tmax), key=lambda k: dom_bytes.get(k, 0.0), default=None)
     _lib.profile_reset()
     _lib.profile_select(dom_name)
@@ -253,8 +256,9 @@ def measure_hod(args, dist, nh, npart, tracers, enable_ranks, with_ranks, label,
                                'hod_emit': 'one 128-B packed record line gathered and 64 B of columns written per galaxy'}[dom_name] +
                                          '; keys, index, float32 shadows and packed records are built once per catalogue (`stage_ms`, outside the timed '
                                          'region), keys and index again after a reseed',
-                           'pick': 'the kernel that takes longest per step; kernels within 10 % of the longest are a tie (they trade places from '
-                                   'run to run), broken by algorithmic bytes. Durations of this run: ' +
+                           'pick': 'the kernel that takes longest per step among those that touch the catalogue (hod_deal, the work distribution '
+                                   'in front of the gather, only where it takes more than 1.5 x the longest of them: the three kernels of the C2 '
+                                   'index path trade places from run to run). Durations of this run: ' +
                                    ', '.join(f'{k} {per_step[k] * 1e3:.1f} us' for k in sorted(per_step, key=per_step.get, reverse=True)),
                            'bytes_pick': None if bytes_pick is None else {
                                'kernel': bytes_pick, 'frac': per_launch[bytes_pick] / (kern[bytes_pick] * 1e-3) / 1e9 / HBM_PEAK_GBS,
