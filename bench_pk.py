@@ -336,6 +336,39 @@ def bench_pk_slab(args, dist):
            'bytes_sent_per_rank_per_step': sent, 'routing': routing,
            'particles': 'presorted into the folded slabs' if presorted else 'box-wide on every rank (halo-range shards): routed inside the timed step',
            'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot)}
+    # BASELINE config 5's spectrum over the same ranks: the cross power with a second catalogue of half the size (LRG x ELG), routed
+    # like the first; both fields cross the links in the compact layout and one fused last pass bins the pair
+    try:
+        n2 = n_local // 2
+        pos2 = np.random.default_rng(900 + r).random((n2, 3), dtype=np.float32)
+        pos2 *= np.float32(L)
+        dpos2 = _lib.DeviceArray(pos2)
+        del pos2
+        ckw = dict(kw, n_total=n_local * W, n_total2=n2 * W)
+
+        def cross_step():
+            if not can_route or W == 1:
+                return sp.calc_power_slab(dpos, L, comm=comm, backend=backend, pos2=dpos2, **ckw)
+            r1, _ = sp.route_particles(dpos, None, L, comm, fold=True)
+            r2, _ = sp.route_particles(dpos2, None, L, comm, fold=True)
+            t_ = sp.calc_power_slab(r1, L, comm=comm, backend=backend, pos2=r2, **ckw)
+            r1.free()
+            r2.free()
+            return t_
+        ctab = cross_step()
+        dist.barrier()
+        _lib.sync()
+        tc = time.perf_counter()
+        csteps = max(1, steps // 2)
+        for _ in range(csteps):
+            ctab = cross_step()
+        _lib.sync()
+        tcd = dist.max(time.perf_counter() - tc) / csteps
+        out['cross'] = {'ms': tcd * 1e3, 'n_particles_2': n2 * W, 'steps': csteps,
+                        'mean_abs_P_over_shot_noise': float(np.mean(np.abs(np.asarray(ctab['power'])[len(power) // 4:, :])) / shot)}
+        dpos2.free()
+    except Exception as e:      # a secondary measurement must not take the leg down
+        out['cross'] = {'error': repr(e)}
     # the pencil transpose on its own: every rank sends 1/W of its slab to each peer at once (one xGMI link per peer)
     if dist.comm is not None and W > 1:
         pitch = backend.pitch(nmesh)
