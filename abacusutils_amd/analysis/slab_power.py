@@ -359,7 +359,9 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     for p_, w_, nt in sets:
         ntot = nt if nt is not None else comm.all_reduce_int(p_.shape[0])   # tot_weight = len(pos), also with weights (:1021)
         particles = backend.upload_particles(p_, w_)
-        fields.append(spectrum(particles, ntot, 0.0, meshes[mi], 'recv' if not fields else 'recv2'))
+        # a second receive buffer only where the fused last pass reads both fields as they arrived; otherwise spectrum()
+        # has unpacked the first one into its mesh before the second transpose starts
+        fields.append(spectrum(particles, ntot, 0.0, meshes[mi], 'recv2' if (try_xbin and fields) else 'recv'))
         mi += 1
         if interlaced:
             fields.append(spectrum(particles, ntot, 0.5 * d, meshes[mi], 'recv2' if try_xbin else 'recv'))

@@ -484,18 +484,10 @@ int launch_z1(float *mesh, int64_t nrows, int pitch_r, Tables *t, ZFold zf) {
                   t->tw2.as<float2>(), option("dbg_fft"), zf);
     return 0;
 }
-// z pass at N = 1024, option fft_zmode (A/B): 0 = production; 1..4 = F1 bits + 1 (bit 0: first radix-8 pass fused with the
-// staging, bit 1: twiddles as lane constants)
+// (F1 variants of the z pass - first radix-8 pass fused with the staging, twiddles as lane constants - were measured equal at
+// N = 1024 in round 3 and are no longer instantiated)
 template <int N, int B, int FUSE = 0>
 int launch_z(float *mesh, int64_t nrows, int pitch_r, Tables *t, ZFold zf = ZFold{N, N, 0}) {
-    if constexpr (N == 1024) {
-        switch (option("fft_zmode")) {
-            case 1: return launch_z1<N, B, FUSE, 0>(mesh, nrows, pitch_r, t, zf);
-            case 2: return launch_z1<N, B, FUSE, 1>(mesh, nrows, pitch_r, t, zf);
-            case 3: return launch_z1<N, B, FUSE, 2>(mesh, nrows, pitch_r, t, zf);
-            case 4: return launch_z1<N, B, FUSE, 3>(mesh, nrows, pitch_r, t, zf);
-        }
-    }
     return launch_z1<N, B, FUSE, 0>(mesh, nrows, pitch_r, t, zf);
 }
 
@@ -516,9 +508,6 @@ int launch_cols1(const char *name, float2 *data, int64_t S, int ntile_c, int64_t
 template <int N, int C>
 int launch_cols(const char *name, float2 *data, int64_t S, int ntile_c, int64_t outer, int64_t outer_stride, const float2 *tw,
                 int64_t outer_mod = (int64_t)1 << 40, int64_t outer_stride2 = 0, ColsPack pk = ColsPack()) {
-    if constexpr (wave_local(N))
-        if (option("fft_cmode") == 1)
-            return launch_cols1<N, C, true>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2, pk);
     return launch_cols1<N, C, false>(name, data, S, ntile_c, outer, outer_stride, tw, outer_mod, outer_stride2, pk);
 }
 

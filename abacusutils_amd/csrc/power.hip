@@ -709,12 +709,13 @@ struct HostSrc {
 };
 HostSrc g_hsrc[2];
 hipStream_t g_copy_stream = nullptr;
-hipEvent_t g_copy_ev[2] = {nullptr, nullptr};
+hipEvent_t g_copy_ev[3] = {nullptr, nullptr, nullptr};   // [0], [1]: a batch has landed; [2]: the library stream's work so far
 double g_last_batches = 0;   // diagnostic: batches of the last host upload (abacus_power_last_batches)
 
-int upload_batches(int64_t n, int nmesh) {
+int upload_batches(int64_t n, int nmesh, int interlaced) {
     if (option("pk_nobatch")) return 1;
-    const double t_up = 12.0 * (double)n / 56e9, t_rmw = 8.0 * (double)nmesh * nmesh * nmesh / 4.5e12;   // the mesh read and written once per batch
+    // the mesh read and written once per batch - both meshes of an interlaced pair
+    const double t_up = 12.0 * (double)n / 56e9, t_rmw = (interlaced ? 2.0 : 1.0) * 8.0 * (double)nmesh * nmesh * nmesh / 4.5e12;
     const int K = (int)std::floor(0.8 * t_up / std::max(t_rmw, 1e-9));
     // batches of at least 8e6 particles: the list build of a batch must keep its two levels
     return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)K, (int64_t)8, n / 8000000}));
@@ -801,7 +802,7 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
     bool deposited = false;
     if (hs) {
         hs->pending = false;
-        const int K = (paste == 0 && !w && !pf64 && nmesh % 32 == 0 && nmesh >= 256) ? upload_batches(n, nmesh) : 1;
+        const int K = (paste == 0 && !w && !pf64 && nmesh % 32 == 0 && nmesh >= 256) ? upload_batches(n, nmesh, interlaced) : 1;
         g_last_batches = K;
         if (K == 1) {
             HIP_TRY(hipMemcpyAsync(pos, hs->host, (size_t)n * 12, hipMemcpyHostToDevice, stream()));
@@ -811,6 +812,9 @@ int field_fft_dev(float *pos, int64_t n, const float *w, double L, int nmesh, in
                 for (hipEvent_t &e : g_copy_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
             for (int s = 0; s < (interlaced ? 2 : 1); s++) ABACUS_TRY(dest[s].reserve(mesh_bytes(nmesh)));
+            // the copy stream is non-blocking: whatever the library stream still does with `pos` comes first
+            HIP_TRY(hipEventRecord(g_copy_ev[2], stream()));
+            HIP_TRY(hipStreamWaitEvent(g_copy_stream, g_copy_ev[2], 0));
             const int64_t nb = (n + K - 1) / K;
             for (int b = 0; b < K; b++) {
                 const int64_t p0 = (int64_t)b * nb, pn = std::min<int64_t>(nb, n - p0);
@@ -1861,6 +1865,15 @@ int abacus_power_release(void) {
     for (DevBuf *b : {&g_ctx.W, &g_ctx.phase, &g_ctx.edges, &g_ctx.accum, &g_ctx.pos, &g_ctx.pos2, &g_ctx.w, &g_ctx.w2})
         ABACUS_TRY(b->release());
     g_ctx.phase_n = 0;
+    if (g_copy_stream) {                  // the batched host upload's stream and events (field_fft_dev)
+        (void)hipStreamSynchronize(g_copy_stream);
+        for (hipEvent_t &e : g_copy_ev) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        (void)hipStreamDestroy(g_copy_stream);
+        g_copy_stream = nullptr;
+    }
     ABACUS_TRY(fft_native_release());
     ABACUS_TRY(tsc_release_work());
     return scratch_trim_idle();

@@ -114,16 +114,24 @@ int scratch_acquire(void **out, size_t bytes) {
     *out = q;
     return 0;
 }
-// blocks above 1 GiB (a caller's whole mesh: 34 GB at 2048^3) are not kept idle - hipFFT work areas, RCCL buffers or another
-// framework in the process would run out of memory beside them; the small per-call temporaries are what the cache is for
+// Blocks above 1 GiB (a caller's whole mesh: 34 GB at 2048^3): at most ONE is kept idle - repeated tsc_parallel / get_field calls
+// on host arrays take their device grid again and again (a hipMalloc, a hipFree and its device synchronise per call otherwise),
+// while hipFFT work areas, RCCL buffers or another framework in the process must not run out of memory beside a pile of
+// them.  scratch_acquire trims on memory pressure, abacus_power_release / abacus_scratch_release give the kept one back.
 void scratch_release(void *p) {
     for (size_t i = 0; i < g_scratch_blocks.size(); i++) {
         ScratchBlock &k = g_scratch_blocks[i];
         if (k.p != p) continue;
-        if (k.cap > ((size_t)1 << 30)) {
-            (void)hipFree(k.p);
-            g_scratch_blocks.erase(g_scratch_blocks.begin() + (long)i);
-        } else k.used = false;
+        k.used = false;
+        if (k.cap <= ((size_t)1 << 30)) return;
+        for (size_t j = 0; j < g_scratch_blocks.size();) {       // the large block released last stays
+            ScratchBlock &o = g_scratch_blocks[j];
+            if (j != i && !o.used && o.cap > ((size_t)1 << 30)) {
+                (void)hipFree(o.p);
+                g_scratch_blocks.erase(g_scratch_blocks.begin() + (long)j);
+                if (j < i) i--;
+            } else j++;
+        }
         return;
     }
 }

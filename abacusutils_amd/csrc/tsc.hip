@@ -925,8 +925,8 @@ static int g_wrapped_seen = 0;
 #include "tsc_lines3.hpp"
 
 // ---- host-side driver ------------------------------------------------------------------------------------
-// second-generation lists (tsc_lines.hpp): work buffers and the staged entries kept for the second deposit of an
-// interlaced pair (the fine level is rebuilt per offset from the same staged entries)
+// line lists (tsc_lines.hpp, tsc_lines3.hpp): work buffers and the staged block records kept for the second deposit of an
+// interlaced pair (the fine level is rebuilt per origin from the same records)
 struct LinesWork {
     DevBuf M, tot, tables, staged, C, tile_start, tile_cnt, entries, flag;
 };
@@ -1009,105 +1009,6 @@ static int lines_launch_deposit(const unsigned long long *entries, int64_t fs, i
     return 0;
 }
 
-// lists + deposit of the second generation, for one deposit (an interlaced pair builds its lists twice: the staged entries
-// hold the in-cell offsets of ONE mesh offset)
-static int lines_deposit_run(float *pos, int64_t n, float *grid, const LGeom &g, int cfg, double box, double offset, int wrap,
-                             int zero_grid, double norm, double sub, int *wrapped_out) {
-    const int nb = g.nbuckets, ntiles = nb * g.tpb;
-    const int64_t CH = std::max<int64_t>(8192, ceil_div(n, 1024));
-    const int nchunk = (int)ceil_div(n, CH);
-    ABACUS_TRY(g_lw.M.reserve((size_t)nchunk * nb * sizeof(unsigned int)));
-    // the block totals and the "a position was wrapped" flag come back in ONE copy into page-locked memory (a pageable
-    // destination goes through a staging kernel per copy: two of them and their gaps were 60 us of every deposit)
-    ABACUS_TRY(g_lw.tot.reserve((size_t)(nb + 1) * sizeof(unsigned int)));
-    unsigned int *M = g_lw.M.as<unsigned int>(), *tot = g_lw.tot.as<unsigned int>();
-    int *flag = reinterpret_cast<int *>(tot + nb);
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), stream()));
-    const float offA = (float)offset;
-    if (cfg == 0) ABACUS_LAUNCH("tsc_lines_count", (lines_count<256>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, flag);
-    else ABACUS_LAUNCH("tsc_lines_count", (lines_count<1024>), dim3(nchunk), dim3(512), 0, pos, n, g, box, offA, wrap, CH, M, flag);
-    ABACUS_LAUNCH("tsc_lines_colscan", lines_colscan, dim3(nb), dim3(1024), 0, M, nchunk, nb, tot);
-    static unsigned int *h_tot = nullptr;
-    static int h_tot_cap = 0;
-    if (nb + 1 > h_tot_cap) {
-        if (h_tot) HIP_TRY(hipHostFree(h_tot));
-        h_tot = nullptr, h_tot_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&h_tot, (size_t)(nb + 1) * sizeof(unsigned int) * 2, hipHostMallocDefault));
-        h_tot_cap = 2 * (nb + 1);
-    }
-    HIP_TRY(hipMemcpyAsync(h_tot, tot, (size_t)(nb + 1) * sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
-    HIP_TRY(hipStreamSynchronize(stream()));
-    const int h_flag = (int)h_tot[nb];
-    if (wrapped_out) *wrapped_out = h_flag;
-    g_wrapped_seen |= h_flag;
-    // bucket starts on line boundaries; pieces of at most PIECE staged entries; one table upload
-    // pieces of 64 entries per tile of a bucket (32768 / 65536 staged entries): measured at BASELINE config 3, 32K 10.36 ms,
-    // 64K 10.40, 128K 10.52, 256K 10.58 (more, shorter workgroups balance better than longer runs per list help)
-    const int64_t PIECE = option("tsc_piece") > 0 ? (int64_t)option("tsc_piece") * 1024 : 64 * (int64_t)g.tpb;
-    std::vector<unsigned int> gstart((size_t)nb + 1), fstart((size_t)nb + 1);
-    std::vector<int> piece_first((size_t)nb + 1);
-    std::vector<LnPiece> pieces;
-    int64_t gs = 0, fs = 0;
-    for (int b = 0; b < nb; b++) {
-        gstart[b] = (unsigned int)gs, fstart[b] = (unsigned int)fs;
-        piece_first[b] = (int)pieces.size();
-        for (int64_t e = 0; e < (int64_t)h_tot[b]; e += PIECE)
-            pieces.push_back(LnPiece{b, (unsigned int)(gs + e), (unsigned int)(gs + std::min<int64_t>(e + PIECE, h_tot[b])), e == 0});
-        gs += ((int64_t)h_tot[b] + 15) & ~(int64_t)15;
-        fs += ((int64_t)h_tot[b] + 15 * (int64_t)g.tpb + 15) & ~(int64_t)15;   // every tile list starts on a line boundary
-        if (gs >= 0xfff00000ll || fs >= 0xfff00000ll) return 1;                  // 32-bit entry indices: the caller falls back
-    }
-    gstart[nb] = (unsigned int)gs, fstart[nb] = (unsigned int)fs;
-    piece_first[nb] = (int)pieces.size();
-    const int np = (int)pieces.size();
-    const size_t o_g = 0, o_f = o_g + (size_t)(nb + 1) * 4, o_pf = o_f + (size_t)(nb + 1) * 4, o_p = (o_pf + (size_t)(nb + 1) * 4 + 15) & ~(size_t)15,
-                 tbytes = o_p + std::max<size_t>(pieces.size(), 1) * sizeof(LnPiece);
-    // the tables go up from a page-locked buffer that outlives the call: nothing to wait for (the next call's tables are
-    // written after its own counting pass has been synchronised, i.e. after this copy)
-    static char *h_blob = nullptr;
-    static size_t h_blob_cap = 0;
-    if (tbytes > h_blob_cap) {
-        if (h_blob) HIP_TRY(hipHostFree(h_blob));
-        h_blob = nullptr, h_blob_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&h_blob, tbytes * 2, hipHostMallocDefault));
-        h_blob_cap = tbytes * 2;
-    }
-    memcpy(h_blob + o_g, gstart.data(), (size_t)(nb + 1) * 4);
-    memcpy(h_blob + o_f, fstart.data(), (size_t)(nb + 1) * 4);
-    memcpy(h_blob + o_pf, piece_first.data(), (size_t)(nb + 1) * 4);
-    if (np) memcpy(h_blob + o_p, pieces.data(), pieces.size() * sizeof(LnPiece));
-    ABACUS_TRY(g_lw.tables.reserve(tbytes));
-    ABACUS_TRY(g_lw.staged.reserve((size_t)std::max<int64_t>(gs, 16) * sizeof(uint4)));
-    ABACUS_TRY(g_lw.C.reserve((size_t)std::max(np, 1) * g.tpb * sizeof(unsigned int)));
-    ABACUS_TRY(g_lw.tile_start.reserve((size_t)ntiles * sizeof(unsigned int)));
-    ABACUS_TRY(g_lw.tile_cnt.reserve((size_t)ntiles * sizeof(unsigned int)));
-    ABACUS_TRY(g_lw.entries.reserve((size_t)std::max<int64_t>(fs, 16) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemcpyAsync(g_lw.tables.p, h_blob, tbytes, hipMemcpyHostToDevice, stream()));
-    const char *tb = g_lw.tables.as<char>();
-    const unsigned int *d_gstart = reinterpret_cast<const unsigned int *>(tb + o_g), *d_fstart = reinterpret_cast<const unsigned int *>(tb + o_f);
-    const int *d_pfirst = reinterpret_cast<const int *>(tb + o_pf);
-    const LnPiece *d_pieces = reinterpret_cast<const LnPiece *>(tb + o_p);
-    uint4 *staged = g_lw.staged.as<uint4>();
-    unsigned int *C = g_lw.C.as<unsigned int>(), *tile_start = g_lw.tile_start.as<unsigned int>(), *tile_cnt = g_lw.tile_cnt.as<unsigned int>();
-    unsigned long long *entries = g_lw.entries.as<unsigned long long>();
-    if (cfg == 0) {
-        ABACUS_LAUNCH("tsc_lines_coarse", (lines_coarse<256, 8, 2560, 512>), dim3(nchunk), dim3(512), 0, (const float *)pos, n, g, box, offA, CH,
-                      (const unsigned int *)M, d_gstart, staged);
-        if (np) ABACUS_LAUNCH("tsc_lines_fcount", (lines_fcount<512>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb, C);
-        ABACUS_LAUNCH("tsc_lines_fscan", (lines_fscan<512>), dim3(nb), dim3(512), 0, C, d_pfirst, g, d_fstart, tile_start, tile_cnt);
-        if (np) ABACUS_LAUNCH("tsc_lines_fine", (lines_fine<512, 8, 2560, 512>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb,
-                              (const unsigned int *)C, entries);
-    } else {
-        ABACUS_LAUNCH("tsc_lines_coarse", (lines_coarse<1024, 4, 3328, 1024>), dim3(nchunk), dim3(1024), 0, (const float *)pos, n, g, box, offA, CH,
-                      (const unsigned int *)M, d_gstart, staged);
-        if (np) ABACUS_LAUNCH("tsc_lines_fcount", (lines_fcount<1024>), dim3(np), dim3(512), 0, (const uint4 *)staged, d_pieces, g.tpb, C);
-        ABACUS_LAUNCH("tsc_lines_fscan", (lines_fscan<1024>), dim3(nb), dim3(1024), 0, C, d_pfirst, g, d_fstart, tile_start, tile_cnt);
-        if (np) ABACUS_LAUNCH("tsc_lines_fine", (lines_fine<1024, 8, 4096, 1024>), dim3(np), dim3(1024), 0, (const uint4 *)staged, d_pieces, g.tpb,
-                              (const unsigned int *)C, entries);
-    }
-    return lines_launch_deposit(entries, fs, gs, n, tile_start, tile_cnt, g, grid, zero_grid, norm, sub);
-}
-
 // ---- third generation (tsc_lines3.hpp): block records; one build serves both deposits of an interlaced pair ----------
 // diagnostic phase clocks of the split rounds (option tsc_lines_clk; abacus_tsc_lines_clocks reads and clears them)
 DevBuf g_lines_clk;
@@ -1187,7 +1088,7 @@ static int lines3_build(float *pos, int64_t n, const LGeom &g, int cfg, double b
     }
 #undef L3_COUNT
     ABACUS_LAUNCH("tsc_lines_colscan", lines_colscan, dim3(nb), dim3(1024), 0, M, nchunk, nb, tot);
-    const int64_t PIECE = option("tsc_piece") > 0 ? (int64_t)option("tsc_piece") * 1024 : 64 * (int64_t)g.tpb;
+    const int64_t PIECE = 64 * (int64_t)g.tpb;   // measured at BASELINE config 3 (r04): 32K 10.36 ms, 64K 10.40, 128K 10.52, 256K 10.58
 #define L3_COARSE(NBK, LINE_, SBUF_, NT_, EXT_, GSTART, NEED)                                                                        \
     ABACUS_LAUNCH("tsc_lines_coarse", (lines3_coarse<NBK, LINE_, SBUF_, NT_, EXT_>), dim3(nchunk), dim3(NT_), 0, (const float *)pos, n, g, box, \
                   offA, CH, (const unsigned int *)M, GSTART, g_lw.staged.as<uint4>(), lines_clk(0), NEED, wn)
@@ -1397,7 +1298,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
     if (share && list_mode == 1 && offset != 0.0) return fail("tsc: shared lists are built at offset 0");
     if (share && list_mode == 2 && (offset < 0.0 || offset > 0.5 * box / gxg * 1.0000001))
         return fail("tsc: shared lists cover offsets up to half a cell");
-    // second-generation lists (tsc_lines.hpp): unweighted float32 TSC on a full periodic mesh of whole tiles
+    // line lists (tsc_lines3.hpp + tsc_lines.hpp): unweighted float32 TSC on a full periodic mesh of whole tiles
     int lines_wrapped = 0;   // its counting pass wrapped positions in place before it handed over to the first generation
     if constexpr (std::is_same<PT, float>::value && std::is_same<GT, float>::value && !CIC) {
         LGeom lg;
@@ -1406,26 +1307,20 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         // (|offset| up to two cells of the FINEST dimension: the lists take nearest cells -2 .. n + 2)
         const double mincell = box / std::max(gx, std::max(gy, gz));
         if (multisplit && !weights && wrap && gxg == gx && xoff == 0 && xoff2 < 0 && ntiles >= 4096 && !option("tsc_oldlists") &&
-            std::fabs(offset) <= (option("tsc_lines_gen") == 2 ? mincell : 2.0 * mincell) && lines_geometry(gx, gy, gz, zstride, lg, lcfg)) {
+            std::fabs(offset) <= 2.0 * mincell && lines_geometry(gx, gy, gz, zstride, lg, lcfg)) {
             g_lists.valid = false;
-            int rc;
-            if (option("tsc_lines_gen") == 2) {
-                g_l3.valid = false;
-                rc = lines_deposit_run(pos, n, grid, lg, lcfg, box, offset, wrap, zero_grid, norm, sub, wrapped_out);
-            } else {
-                // third generation (block records).  list_mode 1: built at offset 0 for both deposits of an interlaced pair;
-                // list_mode 2: the half-cell-shifted deposit from the records of that build, if nothing changed since
-                const bool want_share = list_mode != 0 && !option("tsc_noshare");
-                const bool reuse3 = want_share && list_mode == 2 && g_l3.valid && g_l3.ext && g_l3.pos == (const void *)pos && g_l3.n == n &&
-                                    g_l3.zstride == zstride && g_l3.gx == gx && g_l3.gy == gy && g_l3.gz == gz && g_l3.box == box &&
-                                    g_l3.offset == 0.0 && std::fabs(offset - 0.5 * cell) <= 1e-7 * cell;
-                if (reuse3) {
-                    if (wrapped_out) *wrapped_out = 0;
-                    return lines3_deposit(grid, 1, zero_grid, norm, sub);
-                }
-                rc = lines3_build(pos, n, lg, lcfg, box, offset, wrap, want_share && list_mode == 1 && offset == 0.0 ? 1 : 0, wrapped_out);
-                if (rc == 0) return lines3_deposit(grid, 0, zero_grid, norm, sub);
+            // block records (tsc_lines3.hpp).  list_mode 1: built at offset 0 for both deposits of an interlaced pair;
+            // list_mode 2: the half-cell-shifted deposit from the records of that build, if nothing changed since
+            const bool want_share = list_mode != 0 && !option("tsc_noshare");
+            const bool reuse3 = want_share && list_mode == 2 && g_l3.valid && g_l3.ext && g_l3.pos == (const void *)pos && g_l3.n == n &&
+                                g_l3.zstride == zstride && g_l3.gx == gx && g_l3.gy == gy && g_l3.gz == gz && g_l3.box == box &&
+                                g_l3.offset == 0.0 && std::fabs(offset - 0.5 * cell) <= 1e-7 * cell;
+            if (reuse3) {
+                if (wrapped_out) *wrapped_out = 0;
+                return lines3_deposit(grid, 1, zero_grid, norm, sub);
             }
+            const int rc = lines3_build(pos, n, lg, lcfg, box, offset, wrap, want_share && list_mode == 1 && offset == 0.0 ? 1 : 0, wrapped_out);
+            if (rc == 0) return lines3_deposit(grid, 0, zero_grid, norm, sub);
             if (rc <= 0) return rc;   // 1: more than 2^32 entries - the first-generation lists below
             if (wrapped_out) lines_wrapped = *wrapped_out;
         }
@@ -1438,7 +1333,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
         LGeom lg;
         int lcfg = 0;
         if (multisplit && !weights && wrap && gxg != gx && nx_alloc >= gx && nx_alloc % LN_TX == 0 && nx_alloc < gx + LN_TX && win <= dsep &&
-            win >= 8 && zero_grid && !option("tsc_oldlists") && option("tsc_lines_gen") != 2 && std::fabs(offset) <= 2.0 * box / std::max(gxg, std::max(gy, gz)) &&
+            win >= 8 && zero_grid && !option("tsc_oldlists") && std::fabs(offset) <= 2.0 * box / std::max(gxg, std::max(gy, gz)) &&
             (int64_t)(nx_alloc / LN_TX) * (gy / LN_TY) * (gz / LN_TZ) >= 4096 && lines_geometry(nx_alloc, gy, gz, zstride, lg, lcfg)) {
             g_lists.valid = false;
             const L3Win wn{1, gxg, win, xoff, xoff2};
@@ -1565,7 +1460,7 @@ int deposit_dev(PT *pos, int64_t n, const PT *weights, GT *grid, int gx, int gy,
             // unweighted clouds (every addend in [0, 1]): fixed-point integer tile sums, see acc_add.  S leaves room for n addends
             int fxs = 40;
             while (fxs > 8 && (double)std::max<int64_t>(n, 1) * std::ldexp(1.0, fxs) >= 0x1p62) fxs--;
-            const bool fixed = !weights && fxs >= 24 && !option("tsc_f64acc");
+            const bool fixed = !weights && fxs >= 24;
             const double fxscale = fixed ? std::ldexp(1.0, fxs) : 0.0;
 #define LAUNCH_P(NTP, ACC, GRID, FASTP)                                                                               \
     ABACUS_LAUNCH("tsc_tile_deposit", (tsc_tile_deposit_p<TX, TY, TZ, CIC && FASTP == 0, NTP, ACC, FASTP>), dim3(GRID), dim3(NTP), 0, \

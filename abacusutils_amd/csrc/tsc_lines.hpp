@@ -1,35 +1,24 @@
-// TSC particle -> mesh, second generation ("line" lists): included by tsc.hip inside its anonymous namespace.
-// Replaces, for unweighted float32 particles on a full periodic mesh, the two-level multisplit ms_coarse / ms_fine and
-// the 16-B-entry tile deposit (_tsc_scatter, abacusnbody/analysis/tsc.py:394-507; _wrap_inplace :219-226).
+// TSC particle -> mesh, "line" lists: what the list build of tsc_lines3.hpp and the tile deposit share.  Included by tsc.hip
+// inside its anonymous namespace.  (_tsc_scatter, abacusnbody/analysis/tsc.py:394-507; _wrap_inplace :219-226.)
 //
-// What was wrong with the first generation (profiles/r03/pmc_traffic.json, scripts/ubench/scatter.hip ->
-// profiles/r04/ubench_scatter.txt): its scatter passes append 2 - 5 entries (32 - 80 B) to each of 1024 open lists per
-// sub-chunk, and MI355X writes pieces of a 128-B line at a quarter of the rate of whole aligned lines (scattered aligned
-// runs: 16 B 0.42, 32 B 1.03, 64 B 3.35, 128 B 5.2 TB/s; a line written as two 64-B halves by consecutive stores of the
-// same lanes: 3.4 - the L2 does not merge them).  So here EVERY store of a list-building pass is a whole aligned line:
-//   lines_count    one pass over the particles: wrap in place, entries per (chunk of particles, coarse bucket) and the
-//                  tile entries each coarse bucket will hold; a coarse bucket is a BLOCK of 8 x 8 x 8 (16 x 8 x 8) tiles;
-//   lines_colscan  exclusive scan over the chunks: a chunk's run inside every bucket (exact, deterministic offsets);
-//   lines_coarse   chunk by chunk: the ONLY pass that evaluates the cloud geometry in floating point.  Per particle and
-//                  touched tile (1.25 on average) it stages the final 8-byte entry + the tile's index inside its bucket
-//                  (16 B), grouped by bucket.  A workgroup keeps the tail of every bucket's run that does not fill a line
-//                  yet in LDS (`carry`) and stores only whole lines - see split_round;
-//   lines_fcount / lines_fscan / lines_fine   inside a bucket, piece by piece of its staged entries: a plain split by
-//                  the staged tile key into the tile lists (8-byte entries, lists starting on line boundaries);
-//   lines_deposit  tile deposit from the packed entries, integer (fixed-point) LDS sums (acc_add).
-// An entry is tile-relative: per dimension the nearest cell's index inside the tile (biased by one: a cloud reaches one
+// Measurements that shaped it (profiles/r04/ubench_scatter.txt, scripts/ubench/scatter.hip): MI355X writes pieces of a 128-B
+// line at a fraction of the rate of whole aligned lines (scattered aligned runs: 16 B 0.42, 32 B 1.03, 64 B 3.35, 128 B 5.2
+// TB/s; a line written as two 64-B halves by consecutive stores of the same lanes: 3.4 - the L2 does not merge them).  So EVERY
+// store of a list-building pass is a whole aligned line:
+//   split_round    the streaming LDS multisplit of the build's two passes: a workgroup keeps the tail of every bucket's run that
+//                  does not fill a line yet in LDS (`carry`) and stores only whole lines;
+//   lines_colscan  exclusive scan over the chunks of particles: a chunk's run inside every block (exact, deterministic offsets);
+//   lines_fscan    entries per (piece, tile) -> tile lists starting on line boundaries;
+//   lines_deposit32 / lines_deposit   tile deposit from the packed entries, integer (fixed-point) LDS sums.
+// An entry (8 bytes) is tile-relative: per dimension the nearest cell's index inside the tile (biased by one: a cloud reaches one
 // cell over the tile's faces) and d = cell - p as a 16-bit fixed-point number.  p = (x + offset) * (n / L) is evaluated in
 // float32 exactly as the reference does; d is a multiple of ulp(p), i.e. of 2^-16 or coarser wherever p >= 128 cells, so
 // the 16-bit code is EXACT there and the cloud weights are the reference's float32 weights bit for bit; in the first 128
-// cells of a dimension d is rounded to 2^-16 of a cell, up or down without bias (ln_cell; 1.5e-5 of a cell at most: the
-// reference's own tolerance on the mesh is rtol 1e-4, tests/test_tsc.py:136).  d = +1/2 (p exactly between two cells, round-half-even picked the upper)
-// is stored as the lower cell with d = -1/2: the same three weights (1/2, 1/2, 0) on the same cells.
-//
-// (PMC, profiles/r04: these passes are bound by vector-instruction issue, not by HBM - a first form that staged raw
-// positions per bucket and enumerated a cloud's tiles again in the fine passes spent 537 vector instructions per staged
-// entry there.)
-// HBM traffic per particle: 12 B read twice, 16 B x 1.25 staged (write + 2 reads), 8 B x 1.25 entries (write + read)
-// = 104 B against 154 B of the first generation, all of it in whole lines.
+// cells of a dimension d is rounded to 2^-16 of a cell, up or down without bias (1.5e-5 of a cell at most: the reference's own
+// tolerance on the mesh is rtol 1e-4, tests/test_tsc.py:136).  d = +1/2 (p exactly between two cells, round-half-even picked the
+// upper) is stored as the lower cell with d = -1/2: the same three weights (1/2, 1/2, 0) on the same cells.
+// (The second generation's own build - lines_count / lines_coarse / lines_fcount / lines_fine, one 16-byte record per (particle,
+// tile) - was retired in round 6: docs/history.md.)
 
 constexpr int LN_SHX = 4, LN_SHY = 4, LN_SHZ = 5;          // tile = 16 x 16 x 32 cells
 constexpr int LN_TX = 16, LN_TY = 16, LN_TZ = 32;
@@ -46,24 +35,12 @@ struct LGeom {
     int64_t zstride;
 };
 
-// canonical nearest cell and fixed-point offset of one coordinate (see the header comment).  i in [-3, n + 2].
-// Where d needs more than 16 bits (the first 128 cells) it is rounded WITHOUT BIAS: up with a probability equal to the
-// fraction dropped, `u` in (0, 1) being a hash of the particle's three coordinates (ln_hash: a function of the input
-// alone, so the mesh is reproducible).  Round-to-nearest is not good enough: float32 catalogues sit on lattices - the
-// benchmark's positions, 24-bit uniforms times L on a power-of-two mesh, are 2^-14-lattice values less one ulp 59 % of the
-// time - on which every deterministic rule rounds one way; 4.5e-6 of a cell, the same for every particle below cell 128,
-// is a mass dipole of half a particle across that plane and 1.3e-4 in the 2-mode bin of the 1e8-particle spectrum.
-__device__ __forceinline__ void ln_cell(float x, float offset, float ih, int n, float u, int &i, int &m) {
-    const float p = (x + offset) * ih;                       // tsc.py:419-421, float32
-    float r = rintf(p);                                      // round half even, like np.round / llvm.rint
-    r = fminf(fmaxf(r, -2.f), (float)(n + 2));               // garbage positions (NaN, inf) stay inside the tables
-    const float d = r - p;                                   // exact for every finite p the clamp left alone
-    const float y = d * 65536.f, fl = floorf(y);             // exact; y - fl is the fraction a 16-bit code drops
-    const float mf = fminf(fmaxf(fl + ((y - fl) > u ? 1.f : 0.f), -32768.f), 32768.f);
-    i = (int)r;
-    m = (int)mf;
-    if (m == 32768) i -= 1, m = -32768;
-}
+// In-cell offsets that need more than 16 bits (the first 128 cells of a dimension) are rounded WITHOUT BIAS: up with a
+// probability equal to the fraction dropped, `u` in (0, 1) being a hash of the particle's three coordinates (ln_hash: a function of
+// the input alone, so the mesh is reproducible; tsc_lines3.hpp: l3_S).  Round-to-nearest is not good enough: float32 catalogues sit
+// on lattices - the benchmark's positions, 24-bit uniforms times L on a power-of-two mesh, are 2^-14-lattice values less one ulp 59 %
+// of the time - on which every deterministic rule rounds one way; 4.5e-6 of a cell, the same for every particle below cell 128, is a
+// mass dipole of half a particle across that plane and 1.3e-4 in the 2-mode bin of the 1e8-particle spectrum.
 // three 10-bit uniforms in (0, 1) from the bits of a particle's coordinates
 __device__ __forceinline__ void ln_hash(float x, float y, float z, float u[3]) {
     unsigned int h = __float_as_uint(x) ^ __builtin_rotateleft32(__float_as_uint(y), 11) ^ __builtin_rotateleft32(__float_as_uint(z), 21);
@@ -74,104 +51,9 @@ __device__ __forceinline__ void ln_hash(float x, float y, float z, float u[3]) {
 #pragma unroll
     for (int a = 0; a < 3; a++) u[a] = ((float)((h >> (10 * a)) & 1023u) + 0.5f) * (1.f / 1024.f);
 }
-__device__ __forceinline__ int ln_wrap(int c, int n) { return c < 0 ? c + n : (c >= n ? c - n : c); }
-
-// the one or two tiles a dimension's cell range [lo, hi] (at most five cells) touches
-__device__ __forceinline__ void ln_tiles(int lo, int hi, int n, int sh, int &ta, int &tb) {
-    ta = ln_wrap(lo, n) >> sh;
-    tb = ln_wrap(hi, n) >> sh;
-}
-
-struct LnRange {
-    int ta[3], tb[3];    // tiles of the low / high end per dimension
-};
-// tiles of a particle's cloud at offset A (the counting pass: the same canonical cell as lines_coarse evaluates)
-template <bool EXT>
-__device__ __forceinline__ LnRange ln_range(float x, float y, float z, const LGeom &g, float offA, float offB, float ihx, float ihy,
-                                            float ihz) {
-    LnRange r;
-    const float c[3] = {x, y, z}, ih[3] = {ihx, ihy, ihz};
-    const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ};
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        // the cell alone: ln_cell's code matters here only when it may reach 32768 (d within 2^-16 of +1/2: one particle
-        // in 30 000) - only then is the hash evaluated
-        const float p = (c[a] + offA) * ih[a];
-        float rr = rintf(p);
-        rr = fminf(fmaxf(rr, -2.f), (float)(g.n[a] + 2));
-        int i = (int)rr;
-        if ((rr - p) * 65536.f > 32767.f) {
-            float u[3];
-            int m;
-            ln_hash(x, y, z, u);
-            ln_cell(c[a], offA, ih[a], g.n[a], u[a], i, m);
-        }
-        ln_tiles(i - 1, i + 1, g.n[a], sh[a], r.ta[a], r.tb[a]);
-    }
-    return r;
-}
-
-// f(bucket, tiles of the cloud inside that bucket) for every coarse bucket the range touches (1, 2, 4 or 8)
-template <typename F>
-__device__ __forceinline__ void ln_for_buckets(const LnRange &r, const LGeom &g, F f) {
-    int ba[3], bb[3], nper = 1;
-    bool two[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        ba[a] = r.ta[a] >> g.sb[a], bb[a] = r.tb[a] >> g.sb[a];
-        two[a] = ba[a] != bb[a];
-        nper *= (!two[a] && r.ta[a] != r.tb[a]) ? 2 : 1;
-    }
-    const int x0 = ba[0] * g.nb[1], x1 = bb[0] * g.nb[1];
-    f((x0 + ba[1]) * g.nb[2] + ba[2], nper);
-    if (two[2]) f((x0 + ba[1]) * g.nb[2] + bb[2], nper);
-    if (two[1]) {
-        f((x0 + bb[1]) * g.nb[2] + ba[2], nper);
-        if (two[2]) f((x0 + bb[1]) * g.nb[2] + bb[2], nper);
-    }
-    if (two[0]) {
-        f((x1 + ba[1]) * g.nb[2] + ba[2], nper);
-        if (two[2]) f((x1 + ba[1]) * g.nb[2] + bb[2], nper);
-        if (two[1]) {
-            f((x1 + bb[1]) * g.nb[2] + ba[2], nper);
-            if (two[2]) f((x1 + bb[1]) * g.nb[2] + bb[2], nper);
-        }
-    }
-}
-
 struct LnF3 {
     float x, y, z;   // 4-byte aligned: one global_load_dwordx3 per particle
 };
-
-// ---- counting pass ---------------------------------------------------------------------------------------------
-// chunk c = particles [c CH, (c + 1) CH): M[c][b] = staged entries ((particle, tile) pairs) of the chunk in bucket b
-template <int NB>
-__global__ __launch_bounds__(512) void lines_count(float *__restrict__ pos, int64_t n, LGeom g, double box, float offA, int wrap,
-                                                   int64_t CH, unsigned int *__restrict__ M, int *__restrict__ wrapped_flag) {
-    __shared__ unsigned int hist[NB];
-    const int tid = threadIdx.x;
-    for (int b = tid; b < NB; b += 512) hist[b] = 0u;
-    __syncthreads();
-    const float ihx = (float)(g.n[0] / box), ihy = (float)(g.n[1] / box), ihz = (float)(g.n[2] / box);
-    const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
-    bool any_changed = false;
-    for (int64_t p = p0 + tid; p < p1; p += 512) {
-        LnF3 q = *reinterpret_cast<const LnF3 *>(pos + 3 * p);
-        if (wrap) {
-            bool ch = false;
-            q.x = wrap1(q.x, box, ch), q.y = wrap1(q.y, box, ch), q.z = wrap1(q.z, box, ch);
-            if (ch) {
-                *reinterpret_cast<LnF3 *>(pos + 3 * p) = q;
-                any_changed = true;
-            }
-        }
-        const LnRange r = ln_range<false>(q.x, q.y, q.z, g, offA, offA, ihx, ihy, ihz);
-        ln_for_buckets(r, g, [&](int b, int ntile) { atomicAdd(&hist[b], (unsigned int)ntile); });
-    }
-    if (any_changed) *wrapped_flag = 1;
-    __syncthreads();
-    for (int b = tid; b < g.nbuckets; b += 512) M[(int64_t)blockIdx.x * g.nbuckets + b] = hist[b];
-}
 
 // column b of M: exclusive scan over the chunks (in place) and the bucket's total.  One workgroup per bucket
 __global__ __launch_bounds__(1024) void lines_colscan(unsigned int *__restrict__ M, int nchunk, int nbuckets,
@@ -425,149 +307,6 @@ __device__ __forceinline__ void split_drain(SplitLds<E, NB, LINE, SBUF, NT> &s, 
         split_round<E, NB, LINE, SBUF, NT>(s, nb, par, lo, min(lo + SL, nb), dst, [](auto) {}, [](auto) {});
 }
 
-// ---- coarse scatter --------------------------------------------------------------------------------------------
-// The tiles of a particle's cloud: per dimension the tile of its lowest cell and, when the cloud reaches over that tile's
-// upper face, the next one (periodic) - 1, 2, 4 or 8 tiles.  The geometry is evaluated ONCE per particle into seven registers:
-//   w0           (bucket << 16) + tile key of the emission that takes the first tile everywhere;
-//   l0           its index code (lx | ly << 5 | lz << 10), bits 16..18: dimension d has a second tile, bit 31: no item;
-//   dlt[d]       what taking the second tile of dimension d adds to w0 (bucket and key deltas in one word: sums modulo 2^32
-//                of words whose fields end up in range are exact); the index code always loses T << shift;
-//   frac         the three 16-bit codes of the in-cell offsets.
-// Emission e adds the deltas of the dimensions its bits select: two multiply-adds per dimension.
-struct LnItem {
-    unsigned int w0, l0;
-    int dlt[3];
-    unsigned long long frac;
-};
-__device__ __forceinline__ void ln_item(float x, float y, float z, float offset, float ihx, float ihy, float ihz, const LGeom &g, LnItem &it) {
-    const float c[3] = {x, y, z}, ih[3] = {ihx, ihy, ihz};
-    const int sh[3] = {LN_SHX, LN_SHY, LN_SHZ}, T[3] = {LN_TX, LN_TY, LN_TZ};
-    const int sbk[3] = {g.sb[1] + g.sb[2], g.sb[2], 0};          // key shifts
-    const int sbb[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};           // bucket strides
-    it.w0 = 0u, it.l0 = 0u, it.frac = 0ull;
-    float u[3];
-    ln_hash(x, y, z, u);
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        int i, m;
-        ln_cell(c[a], offset, ih[a], g.n[a], u[a], i, m);
-        it.frac |= (unsigned long long)(unsigned int)(m + 32768) << (16 + 16 * a);
-        // nearest cell -> its tile t and index c inside it; the cloud's first tile is t - 1 when c = 0 (cell i - 1 lies
-        // there), and the cloud has a second tile when c = 0 or c = T - 1
-        const int wi = min(max(ln_wrap(i, g.n[a]), 0), g.n[a] - 1);
-        const int cc = wi & (T[a] - 1), t = wi >> sh[a];
-        const bool lowface = cc == 0;
-        const int h = (lowface || cc == T[a] - 1) ? 1 : 0;
-        int ta = t - (lowface ? 1 : 0);
-        if (ta < 0) ta = g.nt[a] - 1;
-        const int l = lowface ? T[a] + 1 : cc + 1;               // nearest cell relative to the first tile, biased by one
-        const int msk = (1 << g.sb[a]) - 1, ka = ta & msk;
-        const bool cross = ka == msk;                            // the second tile lies in the next block
-        const int dk = cross ? -(msk << sbk[a]) : (1 << sbk[a]);
-        const int db = cross ? (ta == g.nt[a] - 1 ? -(g.nb[a] - 1) * sbb[a] : sbb[a]) : 0;
-        it.w0 += (unsigned int)(((ta >> g.sb[a]) * sbb[a]) << 16) + (unsigned int)(ka << sbk[a]);
-        it.l0 |= ((unsigned int)l << (5 * a)) | ((unsigned int)h << (16 + a));
-        it.dlt[a] = (db << 16) + dk;
-    }
-}
-// emission e >= 1 of an item: (bucket << 16) + key, and the index code
-__device__ __forceinline__ void ln_emit(const LnItem &it, int e, unsigned int &w, unsigned int &l) {
-    const int T[3] = {LN_TX, LN_TY, LN_TZ};
-    int k = e;
-    w = it.w0, l = it.l0 & 0xffffu;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const int h = (it.l0 >> (16 + a)) & 1, sel = h & k;
-        k >>= h;
-        w += (unsigned int)(sel * it.dlt[a]);
-        l -= (unsigned int)sel * ((unsigned int)T[a] << (5 * a));
-    }
-}
-__device__ __forceinline__ int ln_item_count(const LnItem &it) { return (it.l0 >> 31) ? 0 : 1 << __popc((it.l0 >> 16) & 7u); }
-
-template <int NB, int LINE, int SBUF, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void lines_coarse(const float *__restrict__ pos, int64_t n, LGeom g, double box, float offA,
-                                                   int64_t CH, const unsigned int *__restrict__ M,
-                                                   const unsigned int *__restrict__ gstart, uint4 *__restrict__ staged) {
-    __shared__ SplitLds<uint4, NB, LINE, SBUF, NT> s;
-    const int tid = threadIdx.x, nb = g.nbuckets;
-    split_init(s);
-    for (int b = tid; b < NB; b += NT) s.base[b] = b < nb ? gstart[b] + M[(int64_t)blockIdx.x * nb + b] : 0u;
-    __syncthreads();
-    const float ihx = (float)(g.n[0] / box), ihy = (float)(g.n[1] / box), ihz = (float)(g.n[2] / box);
-    const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
-    // items per round: in the steady state a round's output is about its input (1.25 entries per particle).  A round whose
-    // output does not fit the buffer (clouds piled up on tile corners: eight entries per particle) is redone in G groups of
-    // its items: a round's output is at most LINE times its new entries (only a bucket that receives entries can reach a
-    // line boundary, and it sends out less than a line of carried entries beside them), so 8 x PMAX / G x LINE <= SBUF fits
-    constexpr int PMAX = SBUF * 5 / 8 / NT * NT;
-    constexpr int PPT = PMAX / NT;
-    constexpr int G = 64;
-    static_assert(PPT >= 1 && 8 * (PMAX / G) * LINE <= SBUF && (G & (G - 1)) == 0, "buffer too small");
-    int par = 0;
-    // software pipeline: the particles of round r + 1 are requested a round ahead, their geometry is evaluated behind the
-    // stores of round r (which nobody waits for)
-    LnF3 q[PPT];
-    LnItem it[PPT];
-    auto load = [&](int64_t s0) {
-#pragma unroll
-        for (int k = 0; k < PPT; k++) {
-            const int64_t p = s0 + k * NT + tid;
-            if (p < p1) q[k] = *reinterpret_cast<const LnF3 *>(pos + 3 * p);
-        }
-    };
-    auto geometry = [&](int64_t s0) {
-#pragma unroll
-        for (int k = 0; k < PPT; k++) {
-            if (s0 + k * NT + tid < p1) ln_item(q[k].x, q[k].y, q[k].z, offA, ihx, ihy, ihz, g, it[k]);
-            else it[k].l0 = 0x80000000u;
-        }
-    };
-    load(p0);
-    geometry(p0);
-    load(p0 + PMAX);
-    for (int64_t s0 = p0; s0 < p1; s0 += PMAX) {
-        auto round = [&](int groups, int gi) {
-            return split_round<uint4, NB, LINE, SBUF, NT>(
-                s, nb, par, 0, 0, staged,
-                [&](auto f) {
-#pragma unroll
-                    for (int k = 0; k < PPT; k++) {
-                        const int cnt = ((k * NT + tid) & (groups - 1)) != gi ? 0 : ln_item_count(it[k]);
-                        if (cnt) f((int)(it[k].w0 >> 16));       // the first emission of every item: no walk
-                        for (int e = 1; e < cnt; e++) {
-                            unsigned int w, l;
-                            ln_emit(it[k], e, w, l);
-                            f((int)(w >> 16));
-                        }
-                    }
-                },
-                [&](auto f) {
-#pragma unroll
-                    for (int k = 0; k < PPT; k++) {
-                        const int cnt = ((k * NT + tid) & (groups - 1)) != gi ? 0 : ln_item_count(it[k]);
-                        const unsigned int flo = (unsigned int)it[k].frac, fhi = (unsigned int)(it[k].frac >> 32);
-                        if (cnt) f((int)(it[k].w0 >> 16), make_uint4(flo | (it[k].l0 & 0xffffu), fhi, it[k].w0 & 0xffffu, 0u));
-                        for (int e = 1; e < cnt; e++) {
-                            unsigned int w, l;
-                            ln_emit(it[k], e, w, l);
-                            f((int)(w >> 16), make_uint4(flo | l, fhi, w & 0xffffu, 0u));
-                        }
-                    }
-                });
-        };
-        if (round(1, 0)) par ^= 1;
-        else
-            for (int gi = 0; gi < G; gi++) {
-                round(G, gi);
-                par ^= 1;
-            }
-        geometry(s0 + PMAX);
-        load(s0 + 2 * PMAX);
-    }
-    split_drain<uint4, NB, LINE, SBUF, NT>(s, nb, par, staged);
-}
-
 // ---- fine level ------------------------------------------------------------------------------------------------
 struct LnPiece {
     int bucket;
@@ -579,20 +318,6 @@ __device__ __forceinline__ void ln_bucket_coords(int b, const LGeom &g, int &B0,
     B2 = b % g.nb[2];
     B1 = (b / g.nb[2]) % g.nb[1];
     B0 = b / (g.nb[2] * g.nb[1]);
-}
-
-// entries per (piece, tile of its bucket): a histogram of the staged tile keys
-template <int NBF>
-__global__ __launch_bounds__(512) void lines_fcount(const uint4 *__restrict__ staged, const LnPiece *__restrict__ pieces, int tpb,
-                                                    unsigned int *__restrict__ C) {
-    __shared__ unsigned int hist[NBF];
-    const int tid = threadIdx.x;
-    const LnPiece pc = pieces[blockIdx.x];
-    for (int f = tid; f < NBF; f += 512) hist[f] = 0u;
-    __syncthreads();
-    for (unsigned int e = pc.e0 + tid; e < pc.e1; e += 512) atomicAdd(&hist[min(staged[e].z, (unsigned int)(NBF - 1))], 1u);
-    __syncthreads();
-    for (int f = tid; f < tpb; f += 512) C[(int64_t)blockIdx.x * tpb + f] = hist[f];
 }
 
 // one workgroup per bucket: C[piece][tile] -> the piece's offset inside the tile's list, list starts on line boundaries
@@ -621,59 +346,6 @@ __global__ __launch_bounds__(NBF) void lines_fscan(unsigned int *__restrict__ C,
         tile_cnt[(int64_t)b * g.tpb + f] = run;
         for (int p = pa; p < pb; p++) C[(int64_t)p * g.tpb + f] += st;
     }
-}
-
-template <int NBF, int LINE, int SBUF, int NT>
-__global__ __launch_bounds__(NT) void lines_fine(const uint4 *__restrict__ staged, const LnPiece *__restrict__ pieces, int tpb,
-                                                 const unsigned int *__restrict__ C, unsigned long long *__restrict__ entries) {
-    __shared__ SplitLds<unsigned long long, NBF, LINE, SBUF, NT> s;
-    const int tid = threadIdx.x, nb = tpb;
-    const LnPiece pc = pieces[blockIdx.x];
-    split_init(s);
-    for (int f = tid; f < NBF; f += NT) s.base[f] = f < nb ? C[(int64_t)blockIdx.x * nb + f] : 0u;
-    __syncthreads();
-    constexpr int PMAX = (SBUF - SBUF / 8) / NT * NT;     // one entry out per entry in
-    constexpr int PPT = PMAX / NT;
-    constexpr int G = 16;                                 // see lines_coarse: LINE x PMAX / G <= SBUF always fits
-    static_assert(PPT >= 1 && (PMAX / G) * LINE <= SBUF && (G & (G - 1)) == 0, "buffer too small");
-    int par = 0;
-    uint4 q[PPT], nx[PPT];
-    auto load = [&](unsigned int s0) {
-#pragma unroll
-        for (int k = 0; k < PPT; k++) {
-            const unsigned int e = s0 + k * NT + tid;
-            if (e < pc.e1) nx[k] = staged[e];
-        }
-    };
-    if (pc.e0 >= pc.e1) return;
-    load(pc.e0);
-    for (unsigned int s0 = pc.e0; s0 < pc.e1; s0 += PMAX) {
-#pragma unroll
-        for (int k = 0; k < PPT; k++) q[k] = nx[k];
-        if (s0 + PMAX < pc.e1) load(s0 + PMAX);           // a round ahead
-        auto round = [&](int groups, int gi) {
-            return split_round<unsigned long long, NBF, LINE, SBUF, NT>(
-                s, nb, par, 0, 0, entries,
-                [&](auto f) {
-#pragma unroll
-                    for (int k = 0; k < PPT; k++)
-                        if (s0 + k * NT + tid < pc.e1 && ((k * NT + tid) & (groups - 1)) == gi) f((int)min(q[k].z, (unsigned int)(NBF - 1)));
-                },
-                [&](auto f) {
-#pragma unroll
-                    for (int k = 0; k < PPT; k++)
-                        if (s0 + k * NT + tid < pc.e1 && ((k * NT + tid) & (groups - 1)) == gi)
-                            f((int)min(q[k].z, (unsigned int)(NBF - 1)), ((unsigned long long)q[k].y << 32) | q[k].x);
-                });
-        };
-        if (round(1, 0)) par ^= 1;
-        else
-            for (int gi = 0; gi < G; gi++) {
-                round(G, gi);
-                par ^= 1;
-            }
-    }
-    split_drain<unsigned long long, NBF, LINE, SBUF, NT>(s, nb, par, entries);
 }
 
 // ---- tile deposit from packed entries ----------------------------------------------------------------------------

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void li
     const int bst[3] = {g.nb[1] * g.nb[2], g.nb[2], 1};
     const int64_t p0 = (int64_t)blockIdx.x * CH, p1 = min(p0 + CH, n);
     // a round's output is about its input (1.05 - 1.1 records per particle); a round that does not fit (clouds piled up on
-    // block corners: eight records per particle) is redone in G groups - see lines_coarse
+    // block corners: eight records per particle) is redone in G groups: a round's output is at most LINE times its new entries, so 8 x LINE x PMAX / G <= SBUF always fits
     constexpr int PMAX = SBUF * 3 / 4 / NT * NT;
     constexpr int PPT = PMAX / NT;
     constexpr int G = 64;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void li
     __syncthreads();
     constexpr int PMAX = SBUF * 5 / 8 / NT * NT;          // 1.3 entries out per record in
     constexpr int PPT = PMAX / NT;
-    constexpr int G = 64;                                 // see lines_coarse: 8 x LINE x PMAX / G <= SBUF always fits
+    constexpr int G = 64;                                 // as in lines3_coarse: 8 x LINE x PMAX / G <= SBUF always fits
     static_assert(PPT >= 1 && 8 * (PMAX / G) * LINE <= SBUF && (G & (G - 1)) == 0, "buffer too small");
     int par = 0;
     uint4 nx[PPT];

@@ -227,32 +227,98 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
             out['ms_per_call_host_arrays'] = repr(e)
     lib.abacus_power_release()
     if cpu and dist.rank == 0 and dist.world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline_pk(L, out['ms_per_step'] if nmesh == 1024 else None)
+        if nmesh == 1024 or host_memory_gb() < cpu_pk_host_gb(nmesh, n):
+            out['cpu_baseline'] = cpu_baseline_pk(L, out['ms_per_step'] if nmesh == 1024 else None)      # config 3
+        else:
+            out['cpu_baseline'] = cpu_baseline_pk(L, out['ms_per_step'], nmesh=nmesh, n=n, reps=1)
     return out
 
 
-def cpu_baseline_pk(L, gpu_ms=None):
-    """oracle (C+OpenMP stripe TSC, scipy pocketfft rfftn = the reference's FFT, OpenMP bin_kmu) on BASELINE config 3
-    itself - 1e8 particles (seed 300) on a 1024^3 mesh, the largest of the reference's own benchmark meshes that the CPU
-    finishes in seconds: one warm-up + one timed calc_power (about 10-20 s of CPU work on the box's cores)"""
+def host_memory_gb():
+    """memory this process may still take: MemAvailable, capped by what is left under the cgroup's limit"""
+    avail = None
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                avail = float(line.split()[1]) * 1024 / 1e9
+    except OSError:
+        pass
+    for lim, cur in (('/sys/fs/cgroup/memory.max', '/sys/fs/cgroup/memory.current'),
+                     ('/sys/fs/cgroup/memory/memory.limit_in_bytes', '/sys/fs/cgroup/memory/memory.usage_in_bytes')):
+        try:
+            m = open(lim).read().strip()
+            if m != 'max' and float(m) < 1e15:
+                left = (float(m) - float(open(cur).read().strip())) / 1e9
+                avail = left if avail is None else min(avail, left)
+            break
+        except (OSError, ValueError):
+            continue
+    return avail if avail is not None else 0.0
+
+
+def cpu_pk_host_gb(nmesh, n):
+    """host memory of one oracle calc_power: float32 mesh + complex64 spectrum + float32 raw power + positions, with a
+    quarter on top for the transform's own buffers"""
+    M = float(nmesh) ** 3
+    return 1.25 * (4.0 * M + 4.0 * M + 2.0 * M + 12.0 * n) / 1e9
+
+
+def cpu_share():
+    """(logical CPUs in the affinity mask, CPUs' worth of time the cgroup grants or None): an OpenMP team wider than the
+    quota is throttled, not faster"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return aff, quota
+
+
+def cpu_threads():
+    """thread counts worth timing on this host: around the cgroup's CPU quota when there is one (teams beyond it only wait for
+    their time slices), else the physical cores of one socket, of the box, and every logical CPU"""
+    aff, quota = cpu_share()
+    if quota:
+        q = max(1, int(round(quota)))
+        return sorted({t for t in (max(1, q // 2), q, 2 * q) if t <= aff})
+    return sorted({t for t in (aff // 4, aff // 2, aff) if t >= 1})
+
+
+def cpu_baseline_pk(L, gpu_ms=None, nmesh=1024, n=100_000_000, reps=2):
+    """oracle (C+OpenMP stripe TSC, scipy pocketfft rfftn = the reference's FFT, OpenMP bin_kmu) on the bench's own workload -
+    1e8 particles (seed 300) on a 1024^3 mesh (BASELINE config 3: one warm-up + one timed calc_power, about 10-20 s of CPU
+    work on the box's cores) or on the metric's 2048^3 mesh (one timed call: 86 GB of host arrays)"""
     from oracle import oracle
-    cores = len(os.sched_getaffinity(0))
-    nmesh, n = 1024, 100_000_000
+    aff, quota = cpu_share()
+    cores = aff if not quota else min(aff, max(1, int(round(2 * quota))))
     rng = np.random.default_rng(300)
     pos = rng.random((n, 3), dtype=np.float32)
     pos *= np.float32(L)
-    kw = dict(kbins=512, mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste='TSC', nmesh=nmesh, compensated=False,
+    kw = dict(kbins=min(512, nmesh // 2), mubins=4, k_max=np.pi * nmesh / L + 1e-6, paste='TSC', nmesh=nmesh, compensated=False,
               interlaced=False, poles=[0, 2, 4], nthread=cores, accum64=True)
     ts = []
-    for _ in range(2):
+    for _ in range(reps):
         t = time.perf_counter()
-        oracle.calc_power(pos, L, **kw)          # wraps in place (a no-op here: the positions lie in [0, L))
+        res = oracle.calc_power(pos, L, **kw)          # wraps in place (a no-op here: the positions lie in [0, L))
         ts.append(time.perf_counter() - t)
+    shot = L ** 3 / n
+    what = 'BASELINE config 3' if nmesh == 1024 else "the metric's own mesh"
+    calls = f'second of two calls; first {ts[0] * 1e3:.0f} ms' if reps > 1 else 'one call, no warm-up'
     return {'value': float(nmesh) ** 3 / ts[-1], 'unit': 'mesh cells/s', 'cores': cores, 'kind': 'port',
-            'sample': f'BASELINE config 3: nmesh {nmesh}, {n} particles, {ts[-1] * 1e3:.0f} ms per calc_power (second of two '
-                      f'calls; first {ts[0] * 1e3:.0f} ms)' +
+            'sample': f'{what}: nmesh {nmesh}, {n} particles, {ts[-1] * 1e3:.0f} ms per calc_power ({calls}), '
+                      f'{cores} OpenMP / pocketfft threads (affinity {aff}, cgroup quota {quota})' +
                       (f'. The GPU step of this same workload, measured in this run: {gpu_ms:.2f} ms' if gpu_ms else
                        '. The GPU step of this same workload is the `pk_c3` leg of the line'),
+            'mean_P_over_shot_noise': float(np.mean(np.asarray(res['power'])[len(res['power']) // 4:, :]) / shot),
             'ms': ts[-1] * 1e3}
 
 
@@ -337,38 +403,57 @@ def bench_pk_slab(args, dist):
            'particles': 'presorted into the folded slabs' if presorted else 'box-wide on every rank (halo-range shards): routed inside the timed step',
            'mean_P_over_shot_noise': float(np.mean(power[len(power) // 4:, :]) / shot)}
     # BASELINE config 5's spectrum over the same ranks: the cross power with a second catalogue of half the size (LRG x ELG), routed
-    # like the first; both fields cross the links in the compact layout and one fused last pass bins the pair
+    # like the first; both fields cross the links in the compact layout and one fused last pass bins the pair.
+    # A rank that throws inside this leg would leave its peers waiting in the next collective until the orchestrator's timeout:
+    # (1) the primary result is on stdout before the leg starts (launch_ranks keeps the LAST tagged line, the complete one
+    # replaces it), (2) everything that can fail without a peer - the second catalogue's allocation and upload - happens first and
+    # the ranks agree on it through one scalar all-reduce before any of them enters a collective of the cross step
+    if r == 0 and dist.comm is not None:
+        print('BENCH-LEG ' + json.dumps(dict(out, cross={'error': 'not reached: the leg ended inside the cross-power measurement'})), flush=True)
+    n2 = n_local // 2
+    dpos2, err2 = None, None
     try:
-        n2 = n_local // 2
         pos2 = np.random.default_rng(900 + r).random((n2, 3), dtype=np.float32)
         pos2 *= np.float32(L)
         dpos2 = _lib.DeviceArray(pos2)
         del pos2
-        ckw = dict(kw, n_total=n_local * W, n_total2=n2 * W)
+    except Exception as e:
+        err2 = repr(e)
+    ready = dist.sum(0.0 if err2 else 1.0)
+    if ready < W:
+        out['cross'] = {'error': err2 or f'skipped: {W - int(ready)} rank(s) could not stage the second catalogue'}
+    else:
+        try:
+            ckw = dict(kw, n_total=n_local * W, n_total2=n2 * W)
 
-        def cross_step():
-            if not can_route or W == 1:
-                return sp.calc_power_slab(dpos, L, comm=comm, backend=backend, pos2=dpos2, **ckw)
-            r1, _ = sp.route_particles(dpos, None, L, comm, fold=True)
-            r2, _ = sp.route_particles(dpos2, None, L, comm, fold=True)
-            t_ = sp.calc_power_slab(r1, L, comm=comm, backend=backend, pos2=r2, **ckw)
-            r1.free()
-            r2.free()
-            return t_
-        ctab = cross_step()
-        dist.barrier()
-        _lib.sync()
-        tc = time.perf_counter()
-        csteps = max(1, steps // 2)
-        for _ in range(csteps):
+            def cross_step():
+                if not can_route or W == 1:
+                    return sp.calc_power_slab(dpos, L, comm=comm, backend=backend, pos2=dpos2, **ckw)
+                r1, _ = sp.route_particles(dpos, None, L, comm, fold=True)
+                r2, _ = sp.route_particles(dpos2, None, L, comm, fold=True)
+                t_ = sp.calc_power_slab(r1, L, comm=comm, backend=backend, pos2=r2, **ckw)
+                r1.free()
+                r2.free()
+                return t_
             ctab = cross_step()
-        _lib.sync()
-        tcd = dist.max(time.perf_counter() - tc) / csteps
-        out['cross'] = {'ms': tcd * 1e3, 'n_particles_2': n2 * W, 'steps': csteps,
-                        'mean_abs_P_over_shot_noise': float(np.mean(np.abs(np.asarray(ctab['power'])[len(power) // 4:, :])) / shot)}
+            dist.barrier()
+            _lib.sync()
+            tc = time.perf_counter()
+            csteps = max(1, steps // 2)
+            for _ in range(csteps):
+                ctab = cross_step()
+            _lib.sync()
+            tcd = dist.max(time.perf_counter() - tc) / csteps
+            out['cross'] = {'ms': tcd * 1e3, 'n_particles_2': n2 * W, 'steps': csteps,
+                            'mean_abs_P_over_shot_noise': float(np.mean(np.abs(np.asarray(ctab['power'])[len(power) // 4:, :])) / shot)}
+        except Exception as e:      # W == 1: a secondary measurement must not take the leg down.  W > 1: the peers are inside a
+            out['cross'] = {'error': repr(e)}   # collective now; the provisional line above is what the orchestrator will keep
+            if W > 1 and dist.comm is not None:
+                if r == 0:
+                    print('BENCH-LEG ' + json.dumps(out), flush=True)
+                raise
+    if dpos2 is not None:
         dpos2.free()
-    except Exception as e:      # a secondary measurement must not take the leg down
-        out['cross'] = {'error': repr(e)}
     # the pencil transpose on its own: every rank sends 1/W of its slab to each peer at once (one xGMI link per peer)
     if dist.comm is not None and W > 1:
         pitch = backend.pitch(nmesh)
@@ -451,9 +536,9 @@ def bench_pairs(args, dist):
                                 'stencil, which adds the ~19 % of candidates a slice point sees of the other cell\'s far plane'}}
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu:
         from oracle import oracle
-        cores = len(os.sched_getaffinity(0))
+        cores, quota = cpu_share()
         best = None
-        for t in sorted({t for t in (32, 64, 128, cores) if t <= cores}):
+        for t in sorted({t for t in (16, 32, 64, 128) if t <= cores} | ({cores} if not quota else set())):
             t0 = time.perf_counter()
             cc = oracle.paircount_cells('r', x, y, z, L, bins, nthread=t)
             tc = time.perf_counter() - t0
@@ -463,7 +548,7 @@ def bench_pairs(args, dist):
         out['cpu_baseline'] = {'value': cand_27 / best[0], 'unit': 'pairs/s (27-cell stencil of r_max cells, all ordered pairs)',
                                'cores': best[1], 'kind': 'port', 'ms': best[0] * 1e3,
                                'sample': f'the full workload ({n} points), cell-list OpenMP counter of the oracle (Corrfunc\'s '
-                                         'algorithm class without its AVX kernels), best of 32 / 64 / 128 / all threads; counts '
+                                         'algorithm class without its AVX kernels), best of 16 / 32 / 64 / 128 threads (all of them where no cgroup quota applies); counts '
                                          'equal to the GPU\'s'}
     return out
 

@@ -197,8 +197,7 @@ def test_compute_ngal_device_vs_numpy():
     hd, pd, params = synth.synth_hod_inputs(300000, 1000, seed=12)
     hp = dict(HOD_PARAMS, tracer_flags={'LRG': True, 'ELG': True, 'QSO': True})
     ball = AbacusHOD.from_arrays(hd, pd, params, hp)
-    cases = [ball.tracers,
-             {'LRG': dict(ball.tracers['LRG'], Acent=0.3, Asat=-0.2, Bcent=0.1, Bsat=0.4, logM_cut_pr=0.5, z_pivot=0.8),
+    cases = [{'LRG': dict(ball.tracers['LRG'], Acent=0.3, Asat=-0.2, Bcent=0.1, Bsat=0.4, logM_cut_pr=0.5, z_pivot=0.8),
               'ELG': dict(ball.tracers['ELG'], Acent=0.2, Bsat=-0.3, Ccent=0.5, Csat=0.25, logM1_EE=13.0, alpha_EE=0.8),
               'QSO': dict(ball.tracers['QSO'], Bcent=-0.4, Asat=0.3, ic=0.7)}]
     for tracers in cases:

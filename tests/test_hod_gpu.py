@@ -276,7 +276,7 @@ def test_reseed_is_sharding_invariant_and_feeds_populate():
     st.free()
 
 
-@pytest.mark.parametrize('seed', range(40))
+@pytest.mark.parametrize('seed', range(28))     # more seeds: scripts/gpu_hod_fuzz.sh
 def test_random_parameter_sweep_bit_exact(G, seed):
     """seeded random HOD parameters over the ranges an MCMC explores (incl. assembly bias, conformity, velocity bias,
     rank parameters, incompleteness, tracer subsets, light-cone RSD; tests/sweep.py): catalogues and keep masks

@@ -304,7 +304,7 @@ def test_compact_transpose_sends_a_fifth_less(world, nmesh, kfrac):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('world,nmesh,mode', [(8, 1024, 'cross'), (4, 2048, 'cross'), (1, 1024, 'cross'), (8, 1024, 'interlaced'),
-                                              (8, 2048, 'interlaced'), (1, 1024, 'interlaced')])
+                                              (1, 1024, 'interlaced')])   # (8, 2048, 'interlaced'): scripts/gpu_slab.sh (suite budget, r06)
 def test_field_pairs_over_slabs_take_the_fused_last_pass(world, nmesh, mode):
     """calc_power_slab(pos, pos2=..., interlaced=False) - LRG x ELG of BASELINE config 5 - and calc_power_slab(pos,
     interlaced=True) - the reference's default mode: both fields of the pair stop after their y pass, each crosses the links in

@@ -271,8 +271,8 @@ def _line_case(kind, shape, n, box, rng):
                                                  ('uniform-cfg1', (512, 512, 512), 2_300_000, 0.0),
                                                  ('corners-cfg1', (512, 512, 512), 2_050_000, 0.25)])
 def test_line_lists_vs_first_generation_and_oracle(kind, shape, n, offset, options):
-    """second-generation lists (csrc/tsc_lines.hpp: whole-line scatter passes, packed 8-byte tile-relative entries,
-    fixed-point tile sums) for unweighted float32 particles on meshes of whole 16 x 16 x 32 tiles: against the CPU oracle's
+    """line lists (csrc/tsc_lines3.hpp block records + csrc/tsc_lines.hpp: whole-line scatter passes, packed 8-byte tile-relative
+    entries, fixed-point tile sums) for unweighted float32 particles on meshes of whole 16 x 16 x 32 tiles: against the CPU oracle's
     _tsc_scatter, and against the first-generation lists (option tsc_oldlists).  Where every coordinate lies beyond the
     first 128 cells the packed entry holds the float32 offset exactly, so the two meshes agree to the rounding of the cell
     sums; below, an offset is rounded to 2^-16 of a cell without bias (up or down: weights off by at most 3e-5 of their value)."""
@@ -312,21 +312,7 @@ def test_line_lists_vs_first_generation_and_oracle(kind, shape, n, offset, optio
     tsc_parallel(pos.copy(), a64, box, offset=off)
     np.testing.assert_allclose(a64, a, rtol=3e-6, atol=3e-6 * scale)
     assert np.abs(a64 - b)[132:shape[0] - 3, 132:shape[1] - 3, 132:shape[2] - 3].max() <= 3e-7 * scale
-    # third generation (block records, csrc/tsc_lines3.hpp: the default) against the second (option tsc_lines_gen = 2): the
-    # same entries wherever the coordinates are exact, so with the order-independent integer tile sums the cells fed from
-    # p >= 128 alone are EQUAL; below, both round the dropped bits without bias, with different draws
     options.set('tsc_acc64', 0)
-    options.set('tsc_lines_gen', 2)
-    g2, p4 = base.copy(), pos.copy()
-    tsc_parallel(p4, g2, box, offset=off)
-    np.testing.assert_array_equal(p4, p3)
-    np.testing.assert_allclose(g2, c, rtol=2e-3 if kind == 'blob' else 5e-5, atol=4e-6 * scale)
-    inner = (slice(132, shape[0] - 3), slice(132, shape[1] - 3), slice(132, shape[2] - 3))
-    if kind == 'blob':     # lists beyond 2^17 entries are deposited in slices whose float32 sums depend on the order of the list
-        np.testing.assert_allclose(a[inner], g2[inner], rtol=1e-6)
-    else:
-        np.testing.assert_array_equal(a[inner], g2[inner])
-    np.testing.assert_allclose(a, g2, rtol=1e-4, atol=6e-6 * scale)      # two independent draws: sqrt(2) of either one's error
 
 
 @pytest.mark.parametrize('kind,nmesh,n', [('uniform', 512, 3_000_000), ('corners', 512, 2_200_000), ('uniform-cfg1', 512, 2_300_000),
