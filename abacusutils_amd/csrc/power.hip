@@ -64,7 +64,8 @@ int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r, float xcut = 0.f);
 bool xbin_supported(int n, int Nk, int Nmu, const BinArgs &b, bool comp);
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
                   int y0 = 0, int ny_local = 0, int put_geom = 1, int layout = 0, int world = 1, const float *mesh_shifted = nullptr,
-                  const float2 *phase = nullptr, const unsigned int *row_off = nullptr, int64_t plane_elems = 0);
+                  const float2 *phase = nullptr, const unsigned int *row_off = nullptr, int64_t plane_elems = 0,
+                  const float *mesh_b = nullptr, const float *mesh_b_shifted = nullptr);
 bool xbin2_supported(int n, const BinArgs &b, bool comp);
 bool gfft_supported(int n, int is_double);
 int gfft_r2c_zy_f32(float *mesh, int n, int pitch_r);
@@ -1184,6 +1185,23 @@ int power_dev_once(float *pos, int64_t n, const float *w, float *pos2, int64_t n
             const double M = (double)nmesh * nmesh * nmesh;
             ABACUS_TRY(fft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, 0, 0, 1, 0, 1,
                                      g_ctx.mesh[2].as<float>(), nullptr));
+            return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
+                                2.0 * M_PI / Lbox, 0);
+        }
+    }
+    if (fused && cross && interlaced && !option("pk_noxbin") && !option("pk_noxbin_cross") && !option("pk_noxbin_inter")) {
+        // cross power of two INTERLACED fields (calc_power's defaults with pos2): all four meshes stop after their y pass and one
+        // last pass takes the four tiles through LDS (fft_x_bin2<.., QUAD>) - four spectrum writes and four re-reads less
+        BinArgs b;
+        size_t acc_bytes = 0;
+        ABACUS_TRY(prepare_bins(Lbox, kedges, Nk, muedges, Nmu, poles, Np, 0, b, acc_bytes));
+        if (xbin2_supported(nmesh, b, W_dev != nullptr)) {
+            ABACUS_TRY(field_fft_dev(pos, n, w, Lbox, nmesh, paste, 1, 0, true, /*skip_x=*/true, nullptr, pf64, xcut));
+            ABACUS_TRY(field_fft_dev(pos2, n2, w2, Lbox, nmesh, paste, 1, 2, true, /*skip_x=*/true, nullptr, pf64, xcut));
+            const double M = (double)nmesh * nmesh * nmesh;
+            ABACUS_TRY(fft_x_bin_run(g_ctx.mesh[0].as<float>(), nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, 0, 0, 1, 0, 1,
+                                     g_ctx.mesh[1].as<float>(), g_ctx.phase.as<float2>(), nullptr, 0, g_ctx.mesh[2].as<float>(),
+                                     g_ctx.mesh[3].as<float>()));
             return collect_bins(acc_bytes, Lbox, Nk, Nmu, poles, Np, power, N_mode, binned_poles, N_mode_poles, k_avg, nullptr,
                                 2.0 * M_PI / Lbox, 0);
         }

@@ -61,6 +61,9 @@ struct XBinGeom {
     const float2 *data2 = nullptr;
     const float2 *phase = nullptr;      // nullptr with data2: the CROSS form (data2 = the second field, no shift)
     float half_inv_size = 0.f;
+    // QUAD (interlaced CROSS power, four fields): data / data2 = the first catalogue's unshifted and shifted meshes, data3 / data4
+    // the second catalogue's, all in one layout
+    const float2 *data3 = nullptr, *data4 = nullptr;
     // compact pencil transpose (fft.hip, slab_layout): row yr of the y-slab starts row_off[y0 + yr] elements into a plane block
     // (xs = elements per plane of the blocks this rank receives) instead of yr * ys
     const unsigned int *row_off = nullptr;
@@ -407,7 +410,13 @@ __global__ __launch_bounds__(256) void xbin_geometry(int n, int Nk, int Nmu, con
 // HBM, without the two x passes writing them (2 x 8M bytes) and the binning reading them back (8M).
 // CROSS (with INTER): the second tile is ANOTHER field's (pos2 of calc_power, not interlaced): the bin takes
 // Re(conj(a) b) f32(1 / M)^2 - get_raw_power's cross form (power_spectrum.py:722-726) - instead of the interlaced combination.
-template <int H, int C, int NP, bool COMP, int MU, bool RUNS, bool INTER = false, bool CROSS = false>
+// QUAD (with INTER): the cross power of two INTERLACED fields - calc_power(pos, pos2=..., interlaced=True), the reference's
+// defaults with a second catalogue (power_spectrum.py:1200-1260 -> get_interlaced_field_fft twice, then get_raw_power's cross
+// form): four tiles follow each other through the same LDS.  a: kept; a': K = a + a' e^{i pi m / n} kept in its place; b: the
+// lane keeps ONE float per pair of modes, P = w Re(conj(K) b) (the product is linear in the second field, so the pair b, b' never
+// has to be held); b': P += w Re(conj(K) b' e^{i pi m / n}), binned with f32(0.5 / M)^2.  Four x-pass write-backs and
+// spectrum_bin's four reads less than the three-pass form.
+template <int H, int C, int NP, bool COMP, int MU, bool RUNS, bool INTER = false, bool CROSS = false, bool QUAD = false>
 __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restrict__ data, XBinGeom g, BinArgs b, XDesc d,
                                                           const float2 *__restrict__ twH) {
     constexpr int CP = colpitch_of<H>();
@@ -446,6 +455,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     const int64_t S = g.xs;
     const int n_outer = 2 * g.ny;
     static_assert(!CROSS || INTER, "the cross form runs the two-tile schedule");
+    static_assert(!QUAD || (INTER && !CROSS), "the four-field form is the interlaced schedule run twice");
     const float inv2 = (INTER && !CROSS) ? g.half_inv_size * g.half_inv_size : g.inv_size * g.inv_size;
     const int sh = d.sh;
     const unsigned int *lut0 = lut - d.off;
@@ -504,8 +514,10 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
     constexpr int NCW = C / (XB_THREADS / 64);
     static_assert(NCW * (XB_THREADS / 64) == C, "whole columns per wave");
     float2 keepA[INTER ? NCW : 1][RUN], keepB[INTER ? NCW : 1][RUN], keepQ[INTER ? NCW : 1];
+    float part[QUAD ? NCW : 1][RUN], partQ[QUAD ? NCW : 1];
     // mode 0: transform and bin (one field); 1: transform and keep (first field of an interlaced pair); 2: transform, combine
-    // with what was kept, bin
+    // with what was kept, bin; QUAD: 3: combine with what was kept and keep the sum, 4: first half of the cross product, kept
+    // per pair of modes, 5: second half, bin
     auto process = [&](const int xh, const int yr, const int ct_cur, const int mode) {
         const int j = ((yr & (H - 1)) << 1) | (yr >= H ? 1 : 0);
         const int jj = j < n / 2 ? j : j - n;
@@ -560,7 +572,63 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
                 continue;
             }
             const int i0 = 2 * a0 + xh;
-            if constexpr (CROSS) {              // second field b: Re(conj(a) b), left in .x (the power below takes it from there)
+            float psum[QUAD ? RUN : 1], pq = 0.f;
+            if constexpr (QUAD) {
+                float2 q = (!xh && lane == 63) ? col[padq(H / 2)] : make_float2(0.f, 0.f);   // i = n/2: one mode, last lane of the even half
+                if (mode == 3 || mode == 5) {       // the shifted deposits: times e^{i pi m / n}, m = i + j + k (INTER's phases)
+                    const int mjk = jj + k;
+                    int mp = mjk + i0, mm = mjk - i0;
+                    mp += mp < 0 ? 2 * n : 0, mm += mm < 0 ? 2 * n : 0;
+                    float2 pp = g.phase[mp], pm = g.phase[mm];
+                    const float2 rot = g.phase[2];
+#pragma unroll
+                    for (int s = 0; s < RUN; s++) {
+                        vA[s] = make_float2(vA[s].x * pp.x - vA[s].y * pp.y, vA[s].x * pp.y + vA[s].y * pp.x);
+                        vB[s] = make_float2(vB[s].x * pm.x - vB[s].y * pm.y, vB[s].x * pm.y + vB[s].y * pm.x);
+                        pp = make_float2(pp.x * rot.x - pp.y * rot.y, pp.x * rot.y + pp.y * rot.x);
+                        pm = make_float2(pm.x * rot.x + pm.y * rot.y, pm.y * rot.x - pm.x * rot.y);
+                    }
+                    int m = mjk - H;               // i = n/2 folds to -n/2 (shift_field_fft, power_spectrum.py:940-942)
+                    m += m < 0 ? 2 * n : 0;
+                    const float2 ph = g.phase[m];
+                    q = make_float2(q.x * ph.x - q.y * ph.y, q.x * ph.y + q.y * ph.x);
+                }
+                if (mode == 3) {                    // K = a + a' e^{..}
+#pragma unroll
+                    for (int s = 0; s < RUN; s++) {
+                        keepA[QUAD ? ci : 0][s].x += vA[s].x, keepA[QUAD ? ci : 0][s].y += vA[s].y;
+                        keepB[QUAD ? ci : 0][s].x += vB[s].x, keepB[QUAD ? ci : 0][s].y += vB[s].y;
+                    }
+                    keepQ[QUAD ? ci : 0].x += q.x, keepQ[QUAD ? ci : 0].y += q.y;
+                    continue;
+                }
+#pragma unroll
+                for (int s = 0; s < RUN; s++) {    // w Re(conj(K) v) of the pair (i, -i): same |k|, same mu, one bin
+                    const float2 a = keepA[QUAD ? ci : 0][s], bq = keepB[QUAD ? ci : 0][s];
+                    float pA = a.x * vA[s].x + a.y * vA[s].y, pB = bq.x * vB[s].x + bq.y * vB[s].y;
+                    if (COMP) {
+                        const int fA = a0 + s, fB = xh ? H - 1 - fA : (H - fA) & (H - 1);
+                        const float sA = __builtin_amdgcn_rcpf(Wl[2 * fA + xh] * wjk), sB = __builtin_amdgcn_rcpf(Wl[2 * fB + xh] * wjk);
+                        pA *= sA * sA, pB *= sB * sB;
+                    }
+                    if (s == 0) pB *= mB0;
+                    psum[s] = pA + pB;
+                }
+                pq = keepQ[QUAD ? ci : 0].x * q.x + keepQ[QUAD ? ci : 0].y * q.y;
+                if (COMP) {
+                    const float sc = __builtin_amdgcn_rcpf(Wl[H] * wjk);
+                    pq *= sc * sc;
+                }
+                if (mode == 4) {
+#pragma unroll
+                    for (int s = 0; s < RUN; s++) part[QUAD ? ci : 0][s] = psum[s];
+                    partQ[QUAD ? ci : 0] = pq;
+                    continue;
+                }
+#pragma unroll
+                for (int s = 0; s < RUN; s++) psum[s] += part[QUAD ? ci : 0][s];
+                pq += partQ[QUAD ? ci : 0];
+            } else if constexpr (CROSS) {              // second field b: Re(conj(a) b), left in .x (the power below takes it from there)
 #pragma unroll
                 for (int s = 0; s < RUN; s++) {
                     const float2 a = keepA[INTER ? ci : 0][s], bq = keepB[INTER ? ci : 0][s];
@@ -644,9 +712,9 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
             }
 #pragma unroll
             for (int s = 0; s < RUN; s++) {
-                float pA = CROSS ? vA[s].x : vA[s].x * vA[s].x + vA[s].y * vA[s].y;      // get_raw_power (:726)
-                float pB = CROSS ? vB[s].x : vB[s].x * vB[s].x + vB[s].y * vB[s].y;
-                if (COMP) {                                            // (:1065-1069)
+                float pA = QUAD ? psum[QUAD ? s : 0] : CROSS ? vA[s].x : vA[s].x * vA[s].x + vA[s].y * vA[s].y;      // get_raw_power (:726)
+                float pB = QUAD ? 0.f : CROSS ? vB[s].x : vB[s].x * vB[s].x + vB[s].y * vB[s].y;
+                if (COMP && !QUAD) {                                   // (:1065-1069)
                     const int fA = a0 + s, fB = xh ? H - 1 - fA : (H - fA) & (H - 1);
                     const float sA = __builtin_amdgcn_rcpf(Wl[2 * fA + xh] * wjk), sB = __builtin_amdgcn_rcpf(Wl[2 * fB + xh] * wjk);
                     pA *= sA * sA, pB *= sB * sB;
@@ -665,7 +733,9 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
             if (!xh && lane == 63) {       // i = n/2 (a = H/2): one mode, last lane of the even half
                 float2 q = (g.dbg & 8) ? make_float2(1.f, 1.f) : col[padq(H / 2)];
                 float p;
-                if constexpr (CROSS) {
+                if constexpr (QUAD) {
+                    p = pq;
+                } else if constexpr (CROSS) {
                     const float2 a = keepQ[INTER ? ci : 0];
                     p = a.x * q.x + a.y * q.y;
                 } else {
@@ -677,7 +747,7 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
                     }
                     p = q.x * q.x + q.y * q.y;
                 }
-                if (COMP) {
+                if (COMP && !QUAD) {
                     const float sc = __builtin_amdgcn_rcpf(Wl[H] * wjk);
                     p *= sc * sc;
                 }
@@ -721,10 +791,24 @@ __global__ __launch_bounds__(XB_THREADS) void fft_x_bin2(const float2 *__restric
                 stage();
                 __syncthreads();
             }
+            if (QUAD) {          // ... then the second catalogue's pair
+                prefetch(tile_ptr(o_cur, ct_cur, g.data3));
+                process(xh, g.y0 + o_cur - xh * g.ny, ct_cur, 3);
+                __syncthreads();
+                wait_vmcnt<0>();
+                stage();
+                __syncthreads();
+                prefetch(tile_ptr(o_cur, ct_cur, g.data4));
+                process(xh, g.y0 + o_cur - xh * g.ny, ct_cur, 4);
+                __syncthreads();
+                wait_vmcnt<0>();
+                stage();
+                __syncthreads();
+            }
             step();
             const bool has_next = og < n_og;
             if (has_next) prefetch(tile_ptr(og * ostep + grp, ct, data));
-            process(xh, g.y0 + o_cur - xh * g.ny, ct_cur, INTER ? 2 : 0);
+            process(xh, g.y0 + o_cur - xh * g.ny, ct_cur, QUAD ? 5 : INTER ? 2 : 0);
             if (!has_next) break;
             __syncthreads();     // every wave is done with the tile
             wait_vmcnt<0>();     // no stores in this kernel: the prefetch is all that is outstanding
@@ -924,8 +1008,9 @@ int xdesc_get(int n, int Nk, int Nmu, bool comp, const float *h_e2, const float 
 template <int H, int C, int NP, bool COMP, int MU>
 int launch_xbin2(const float2 *data, const XBinGeom &g, const BinArgs &b, const XDesc &d, size_t lds) {
     const bool runs = option("pk_xbin_pairs") == 0;
-    auto kern = g.data2 ? (g.phase ? fft_x_bin2<H, C, NP, COMP, MU, true, true> : fft_x_bin2<H, C, NP, COMP, MU, true, true, true>)
-                        : (runs ? fft_x_bin2<H, C, NP, COMP, MU, true> : fft_x_bin2<H, C, NP, COMP, MU, false>);
+    auto kern = g.data3 ? fft_x_bin2<H, C, NP, COMP, MU, true, true, false, true>
+                : g.data2 ? (g.phase ? fft_x_bin2<H, C, NP, COMP, MU, true, true> : fft_x_bin2<H, C, NP, COMP, MU, true, true, true>)
+                          : (runs ? fft_x_bin2<H, C, NP, COMP, MU, true> : fft_x_bin2<H, C, NP, COMP, MU, false>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, XB_THREADS, lds));
@@ -1035,13 +1120,17 @@ int xbin_release() {
 // histogram that is all-reduced afterwards.
 int fft_x_bin_run(const float *mesh, int n, int pitch_r, float inv_size, const float *W_dev, const BinArgs &b, int dbg,
                   int y0, int ny_local, int put_geom, int layout, int world, const float *mesh_shifted, const float2 *phase,
-                  const unsigned int *row_off, int64_t plane_elems) {
+                  const unsigned int *row_off, int64_t plane_elems, const float *mesh_b, const float *mesh_b_shifted) {
     XBinGeom g;
     g.n = n, g.kzlen = n / 2 + 1, g.pitch_c = pitch_r / 2, g.inv_size = inv_size, g.W = W_dev, g.dbg = dbg;
     if (mesh_shifted) {
         // phase table: the interlaced pair; none: `mesh_shifted` is a second field, cross power - in the layout of `mesh` either way
         g.data2 = reinterpret_cast<const float2 *>(mesh_shifted), g.phase = phase;
         g.half_inv_size = (float)(0.5 / ((double)n * n * n));
+    }
+    if (mesh_b || mesh_b_shifted) {     // the interlaced cross power: (mesh, mesh_shifted) x (mesh_b, mesh_b_shifted)
+        if (!mesh_shifted || !phase || !mesh_b || !mesh_b_shifted) return fail("fft_x_bin: the four-field form needs both interlaced pairs and the phase table");
+        g.data3 = reinterpret_cast<const float2 *>(mesh_b), g.data4 = reinterpret_cast<const float2 *>(mesh_b_shifted);
     }
     const bool slab = layout != 0;
     if (slab && ny_local < 1) return fail("fft_x_bin: empty y-slab");

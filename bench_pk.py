@@ -204,6 +204,39 @@ def bench_pk(args, dist, headline, nmesh=None, cpu=True, variants=True):
                             # two deposits + two z / y passes + one read of both half-spectra
                             'whole_step_GBs': (12.0 * (n + n2) + 48.0 * M) / dtc / 1e9,
                             'whole_step_frac': (12.0 * (n + n2) + 48.0 * M) / dtc / 1e9 / HBM_PEAK_GBS}
+            # the reference's DEFAULT estimator with a second catalogue: interlaced + compensated cross power, four fields through
+            # one fused last pass (fft_x_bin2<.., QUAD>); `unfused_ms_per_step`: four complete transforms + spectrum_bin<INTER, CROSS>
+            try:
+                W4 = ps.get_W_compensated(L, nmesh, 'TSC', True).astype(np.float32)
+
+                def qstep():
+                    _lib.check(lib.abacus_power_from_particles_dev(
+                        dpos.ptr, C.c_int64(n), None, dpos2.ptr, C.c_int64(n2), None, C.c_double(L), int(nmesh), 0, _lib.ptr(W4), 1,
+                        _lib.ptr(ke), len(ke) - 1, _lib.ptr(me), len(me) - 1, _lib.ptr(poles), len(poles), *[_lib.ptr(o) for o in outs]))
+
+                def timed(reps):
+                    qstep()
+                    _lib.sync()
+                    t1_ = time.perf_counter()
+                    for _ in range(reps):
+                        qstep()
+                    _lib.sync()
+                    return (time.perf_counter() - t1_) / reps
+                dtq = timed(max(1, steps // 3))
+                _lib.profile_reset()
+                _lib.profile_enable(True)
+                qstep()
+                _lib.sync()
+                _lib.profile_enable(False)
+                kq = {k: ms for k, (ms, c) in _lib.profile_get().items() if c}
+                _lib.set_option('pk_noxbin_cross', 1)
+                dtu = timed(max(1, steps // 3))
+                _lib.set_option('pk_noxbin_cross', 0)
+                out['interlaced_cross'] = {'ms_per_step': dtq * 1e3, 'unfused_ms_per_step': dtu * 1e3, 'n_particles_2': n2,
+                                           'kernels_ms_per_step': kq}
+            except Exception as e:
+                _lib.set_option('pk_noxbin_cross', 0)
+                out['interlaced_cross'] = {'error': repr(e)}
             dpos2.free()
         except Exception as e:
             out['cross'] = {'error': repr(e)}

@@ -615,6 +615,54 @@ def test_fused_last_pass_interlaced_pair_matches_spectrum_bin(options, nmesh, co
         _check_oracle(calc_power(small.copy(), box, **kw), oracle.calc_power(small.copy(), box, nthread=oracle.max_threads(), accum64=True, **kw))
 
 
+@pytest.mark.parametrize('nmesh,comp', [(1024, True), (1024, False), (2048, True)])
+def test_fused_last_pass_interlaced_cross_matches_spectrum_bin(options, nmesh, comp):
+    """the four-field form of the fused last pass (fft_x_bin2<.., QUAD>): the cross power of two INTERLACED fields - the
+    reference's defaults with a second catalogue, calc_power(pos, pos2=..., interlaced=True, compensated=True)
+    (analysis/power_spectrum.py:1200-1260: get_interlaced_field_fft per catalogue, then get_raw_power's cross form :722-726) -
+    against four complete transforms + spectrum_bin<INTER, CROSS> on the same particles (option pk_noxbin_cross) mode by mode,
+    incl. edges past Nyquist (the folded i = n/2 plane), and against the oracle at 1024"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.analysis.power_spectrum import calc_power
+    box = 1000.0
+    pos = synth.synth_positions(2_000_000, box, seed=291, clustered=True)
+    pos2 = synth.synth_positions(1_200_000, box, seed=292, clustered=True)
+    pos2[:400_000] = pos[:400_000]            # a shared population: the cross power is not just noise around zero
+    w = np.random.default_rng(24).random(len(pos), dtype=np.float32) + np.float32(0.5)
+    cases = (dict(kbins=64, mubins=4, poles=[0, 2, 4]), dict(kbins=300, mubins=None, poles=[0, 2], k_max=np.pi * nmesh / box + 1e-6),
+             dict(kbins=24, mubins=8, poles=[], logk=True, k_max=2.0, w=w),
+             dict(kbins=np.array([0.0, 0.02, 0.021, 0.3, 0.31, 2.0]), mubins=np.array([0.0, 0.05, 0.5, 0.51, 1.0]), poles=[2]),
+             dict(kbins=40, mubins=3, poles=[0, 2, 4], k_max=1.7 * np.pi * nmesh / box))
+    for kw in (cases if nmesh == 1024 else cases[:2] + cases[4:]):
+        kw = dict(kw, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=True)
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        a = calc_power(pos.copy(), box, pos2=pos2.copy(), **kw)
+        _lib.profile_enable(False)
+        prof = _lib.profile_get()
+        assert 'fft_x_bin' in prof and 'spectrum_bin' not in prof and 'fft_cols_x' not in prof, sorted(prof)
+        options.set('pk_noxbin_cross', 1)
+        b = calc_power(pos.copy(), box, pos2=pos2.copy(), **kw)
+        options.set('pk_noxbin_cross', 0)
+        np.testing.assert_array_equal(a['N_mode'], b['N_mode'])
+        scale = np.abs(np.asarray(b['power'])).max()
+        np.testing.assert_allclose(a['power'], b['power'], rtol=3e-6, atol=3e-7 * scale)
+        np.testing.assert_allclose(a['k_avg'], b['k_avg'], rtol=1e-6)
+        if kw['poles']:
+            np.testing.assert_allclose(a['poles'], b['poles'], rtol=3e-6, atol=5e-7 * scale)
+    if nmesh == 1024:
+        from oracle import oracle
+        kw = dict(kbins=20, mubins=3, k_max=1.2, paste='TSC', nmesh=1024, compensated=comp, interlaced=True, poles=[0, 2])
+        s1 = synth.synth_positions(300_000, box, seed=293, clustered=True)
+        s2 = synth.synth_positions(200_000, box, seed=294, clustered=True)
+        s2[:80_000] = s1[:80_000]
+        _check_oracle(calc_power(s1.copy(), box, pos2=s2.copy(), **kw),
+                      oracle.calc_power(s1.copy(), box, pos2=s2.copy(), nthread=oracle.max_threads(), accum64=True, **kw))
+        kw.update(k_max=1.7 * np.pi * nmesh / box, kbins=34)       # past Nyquist: every x-Nyquist mode is binned
+        _check_oracle(calc_power(s1.copy(), box, pos2=s2.copy(), **kw),
+                      oracle.calc_power(s1.copy(), box, pos2=s2.copy(), nthread=oracle.max_threads(), accum64=True, **kw))
+
+
 def _random_edges(rng, nmesh, box):
     """k / mu edges of every flavour the geometry descriptor has to resolve or decline: linear, logarithmic, ragged, bins far
     narrower than a fundamental mode, first edge above zero, last edge short of / beyond Nyquist and beyond the corner"""
