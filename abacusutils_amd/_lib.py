@@ -270,6 +270,11 @@ def set_option(name, value=1):
     check(lib().abacus_set_option(name.encode(), int(value)))
 
 
+def get_option(name):
+    """current value of a diagnostic option (0 when never set)"""
+    return int(lib().abacus_get_option(name.encode()))
+
+
 def scratch_release():
     """free the library's idle scratch blocks (abacus_scratch_release): temporaries kept between calls"""
     check(lib().abacus_scratch_release())

@@ -48,6 +48,7 @@ int option(const char *name);
 // profiler hooks: no-ops unless abacus_profile_enable(1)
 void prof_begin(const char *name);
 void prof_end(const char *name);
+bool prof_enabled();
 
 // Launch a kernel on the library stream, bracketed by profiler events when profiling is on.
 #define ABACUS_LAUNCH(name, kernel, grid, block, shmem, ...)                                     \

@@ -18,6 +18,9 @@
 #include "../../include/abacus_hip.h"
 #include "common.hpp"
 
+namespace abacus {
+int fenv_rank_device(const double *d_M, const double *d_env, int64_t n, const double *d_edges, int n_edges, double *d_out);   // staging.hip
+}
 using namespace abacus;
 
 namespace {
@@ -360,6 +363,92 @@ int exclusive_sum(const T *in, T *out, int64_t n, Tmp &tmp) {
     return 0;
 }
 
+// ---- the whole slab on the device (abacus_prepare_slab): gathers of the kept rows ------------------------------------------
+bool on_device(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // plain host memory: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+// a column of the caller's: used in place when it already lives in HBM (the reader's unpack kernels leave pos / vel there), else uploaded
+template <class T>
+int stage_col(Tmp &t, const T *src, size_t count, const T **out) {
+    if (!src || on_device(src)) {
+        *out = src;
+        return 0;
+    }
+    T *d;
+    ABACUS_TRY(t.upload(&d, src, count));
+    *out = d;
+    return 0;
+}
+__global__ void prep_mass_deltac(const unsigned int *__restrict__ N, const float *__restrict__ r25, const float *__restrict__ r98, int64_t n,
+                                 double Mpart, double *__restrict__ mass, double *__restrict__ dval) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        mass[i] = (double)N[i] * Mpart;                      // halos['N'] * Mpart (:445)
+        dval[i] = (double)(r98[i] / r25[i]);                 // float32 ratio, ranked in float64 (:762-773)
+    }
+}
+__global__ void prep_flag_u8(const unsigned char *__restrict__ m, int64_t n, long long *__restrict__ flag) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) flag[i] = m[i] ? 1 : 0;
+}
+__global__ void prep_compact(const long long *__restrict__ flag, const long long *__restrict__ slot, int64_t n, long long *__restrict__ idx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (flag[i]) idx[slot[i]] = i;
+}
+// rows of W 4-byte words
+template <int W>
+__global__ void prep_gather_w(const unsigned int *__restrict__ src, const long long *__restrict__ idx, int64_t n, unsigned int *__restrict__ dst) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * W; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / W;
+        dst[e] = src[idx[r] * W + (e - r * W)];
+    }
+}
+__global__ void prep_gather_f3d(const float *__restrict__ src, const long long *__restrict__ idx, int64_t n, double *__restrict__ dst) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * 3; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / 3;
+        dst[e] = (double)src[idx[r] * 3 + (e - r * 3)];      // hvel[host].astype(float64)
+    }
+}
+__global__ void prep_gather_recip(const double *__restrict__ p, const long long *__restrict__ idx, int64_t n, double *__restrict__ dst) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) dst[r] = 1.0 / p[idx[r]];
+}
+__global__ void prep_gather_scale(const float *__restrict__ sig, const long long *__restrict__ idx, int64_t n, double *__restrict__ dst) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+        dst[r] = (double)sig[idx[r]] / 1.7320508075688772;   // sigmav3d[kept] / np.sqrt(3): float32 column, float64 scalar
+}
+
+// what one abacus_prepare_slab call leaves in HBM for abacus_prepare_slab_fetch
+struct SlabOut {
+    Tmp *tmp = nullptr;
+    int64_t nk = 0, ns = 0;
+    int want_ranks = 0;
+    bool ranks_on_side = false;      // the rank columns are being written on g_slab_side: the fetch copies them behind g_slab_ranked
+    void *hcol[ABACUS_PREP_HALO_COLS] = {};
+    size_t hbytes[ABACUS_PREP_HALO_COLS] = {};
+    void *pcol[ABACUS_PREP_PART_COLS] = {};
+    size_t pbytes[ABACUS_PREP_PART_COLS] = {};
+    void clear();
+};
+SlabOut g_slab;
+// prep_ranks (2.7 of the slab's 4 ms of kernels) runs on a stream of its own, so that the copies of the other columns - the copy
+// engine - go out under it; with the profiler on it stays on the library stream (whose event pairs time it)
+hipStream_t g_slab_side = nullptr;
+hipEvent_t g_slab_ready = nullptr, g_slab_ranked = nullptr;
+void SlabOut::clear() {
+    if (ranks_on_side && g_slab_side) (void)hipStreamSynchronize(g_slab_side);   // nothing may still read what goes back to the pool
+    delete tmp;
+    *this = SlabOut();
+}
+
+template <int W>
+int gather_w(const void *src, const long long *idx, int64_t n, void *dst) {
+    if (n > 0) ABACUS_LAUNCH("prep_gather", (prep_gather_w<W>), dim3(grid_for(n * W)), dim3(256), 0, (const unsigned int *)src, idx, n, (unsigned int *)dst);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -576,6 +665,315 @@ int abacus_prepare_randoms(int64_t n, const int64_t *index, int64_t index0, uint
     }
     HIP_TRY(hipMemcpyAsync(randoms, d_r, (size_t)n * 8, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+// ---- one slab, device-resident from the inputs to the two tables (hod/prepare_sim.py:296-1052 between loader and writer) --------
+// Everything abacusutils_amd/hod/prepare_sim.py::prepare_slab_arrays does with rng = <seed> - the halo mask, the down-sampling
+// factors, the mass-bin rank of the concentration, the per-halo particle selection, the new offsets, the five satellite rank columns,
+// the kept rows of every column of both tables and their random columns - without a column crossing PCIe twice: inputs are used in
+// place when they are device pointers (the reader's unpack kernels leave pos / vel in HBM) or uploaded once, the tables stay in HBM
+// until abacus_prepare_slab_fetch copies each column out (one copy per column, into the caller's - ideally page-locked - arrays).
+// Same Philox streams as the column-by-column path (6: halo mask, 3: selection keys, 4: halo randoms, 5: particle randoms), so
+// both paths produce identical tables (tests/test_prepare_gpu.py).
+int abacus_prepare_slab(const abacus_prepare_slab_args *a, int64_t *n_halo_kept, int64_t *n_part_kept, uint8_t *mask_out) {
+    ABACUS_ENTER();
+    if (!a || !n_halo_kept || !n_part_kept) return fail("abacus_prepare_slab: null argument");
+    const int64_t nh = a->nh, npart = a->npart;
+    if (nh < 0 || npart < 0) return fail("abacus_prepare_slab: negative size");
+    if (nh >= ((int64_t)1 << 31) || npart >= ((int64_t)1 << 31)) return fail("abacus_prepare_slab: slab too large for 32-bit indices");
+    if (nh > 0 && (!a->N || !a->x || !a->v || !a->r25 || !a->r90 || !a->r98 || !a->npstartA || !a->npoutA || !a->id || !a->sigmav))
+        return fail("abacus_prepare_slab: null halo column");
+    if (npart > 0 && (!a->pos || !a->vel)) return fail("abacus_prepare_slab: null particle column");
+    if (a->n_edges != 0 && (a->n_edges < 2 || a->n_edges > 60000 || !a->mbins)) return fail("abacus_prepare_slab: %d mass-bin edges", a->n_edges);
+    for (int b = 0; b + 1 < a->n_edges; b++)
+        if (!(a->mbins[b + 1] > a->mbins[b])) return fail("abacus_prepare_slab: the mass bin edges must increase");
+    g_slab.clear();
+    *n_halo_kept = *n_part_kept = 0;
+    if (nh == 0) return 0;
+    g_slab.tmp = new Tmp();
+    Tmp &t = *g_slab.tmp;
+    Tmp &w = t;       // (work arrays too stay until the fetch: the rank kernel reads them on a stream of its own)
+    const size_t np1 = (size_t)std::max<int64_t>(npart, 1);
+    const uint2 key = make_uint2((unsigned int)a->seed, (unsigned int)(a->seed >> 32));
+    // ---- inputs
+    const unsigned int *dN;
+    const float *dx, *dv, *dr25, *dr90, *dr98, *dsig, *dpos, *dvel;
+    const long long *dps, *dpn, *did;
+    ABACUS_TRY(stage_col(w, (const unsigned int *)a->N, (size_t)nh, &dN));
+    ABACUS_TRY(stage_col(w, a->x, (size_t)nh * 3, &dx));
+    ABACUS_TRY(stage_col(w, a->v, (size_t)nh * 3, &dv));
+    ABACUS_TRY(stage_col(w, a->r25, (size_t)nh, &dr25));
+    ABACUS_TRY(stage_col(w, a->r90, (size_t)nh, &dr90));
+    ABACUS_TRY(stage_col(w, a->r98, (size_t)nh, &dr98));
+    ABACUS_TRY(stage_col(w, a->sigmav, (size_t)nh, &dsig));
+    ABACUS_TRY(stage_col(w, (const long long *)a->npstartA, (size_t)nh, &dps));
+    ABACUS_TRY(stage_col(w, (const long long *)a->npoutA, (size_t)nh, &dpn));
+    ABACUS_TRY(stage_col(w, (const long long *)a->id, (size_t)nh, &did));
+    ABACUS_TRY(stage_col(w, a->pos, (size_t)npart * 3, &dpos));
+    ABACUS_TRY(stage_col(w, a->vel, (size_t)npart * 3, &dvel));
+    // ---- halos: mask draws (stream 6), kept fraction, targets; masses and the ranked concentration
+    double *d_u, *d_p, *d_mass, *d_dval, *d_deltac, *d_fenv, *d_shear;
+    unsigned char *d_hmask;
+    int *d_nt;
+    ABACUS_TRY(w.alloc(&d_u, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_p, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_hmask, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_nt, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_mass, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_dval, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_deltac, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_fenv, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_shear, (size_t)nh));
+    ABACUS_LAUNCH("prep_part_randoms", prep_part_randoms, dim3(grid_for(nh)), dim3(256), 0, nh, (const long long *)nullptr, (long long)a->halo_index0,
+                  key, 6u, d_u);
+    ABACUS_LAUNCH("prep_halo_factors", prep_halo_factors, dim3(grid_for(nh)), dim3(256), 0, dN, (const double *)nullptr, nh, a->Mpart, a->MT,
+                  (const double *)d_u, dpn, d_p, d_hmask, d_nt);
+    ABACUS_LAUNCH("prep_mass_deltac", prep_mass_deltac, dim3(grid_for(nh)), dim3(256), 0, dN, dr25, dr98, nh, a->Mpart, d_mass, d_dval);
+    if (a->n_edges) {
+        double *d_edges;
+        ABACUS_TRY(w.upload(&d_edges, a->mbins, (size_t)a->n_edges));
+        ABACUS_TRY(fenv_rank_device(d_mass, d_dval, nh, d_edges, a->n_edges, d_deltac));
+    } else HIP_TRY(hipMemsetAsync(d_deltac, 0, (size_t)nh * 8, stream()));
+    if (a->fenv_rank) HIP_TRY(hipMemcpyAsync(d_fenv, a->fenv_rank, (size_t)nh * 8, hipMemcpyDefault, stream()));
+    else HIP_TRY(hipMemsetAsync(d_fenv, 0, (size_t)nh * 8, stream()));
+    if (a->shear_rank) HIP_TRY(hipMemcpyAsync(d_shear, a->shear_rank, (size_t)nh * 8, hipMemcpyDefault, stream()));
+    else HIP_TRY(hipMemsetAsync(d_shear, 0, (size_t)nh * 8, stream()));
+    // ---- particle selection: Philox keys, one stable sort of (halo, key), the first ntarget of every halo's run
+    unsigned char *d_sub;
+    long long *d_kept, *d_kstart;
+    int *d_host, *d_bad;
+    ABACUS_TRY(w.alloc(&d_host, np1));
+    ABACUS_TRY(w.alloc(&d_bad, 4));
+    ABACUS_TRY(w.alloc(&d_sub, np1));
+    HIP_TRY(hipMemsetAsync(d_host, 0xff, np1 * 4, stream()));
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 16, stream()));
+    ABACUS_LAUNCH("prep_fill_host", prep_fill_host, dim3((unsigned int)std::min<int64_t>(ceil_div(nh, 4), 256 * 32)), dim3(256), 0, dps, dpn,
+                  (const unsigned char *)d_hmask, nh, npart, d_host, d_bad);
+    {
+        unsigned long long *k0, *k1;
+        unsigned int *i0, *i1;
+        long long *ccount, *cstart;
+        ABACUS_TRY(w.alloc(&k0, np1));
+        ABACUS_TRY(w.alloc(&k1, np1));
+        ABACUS_TRY(w.alloc(&i0, np1));
+        ABACUS_TRY(w.alloc(&i1, np1));
+        ABACUS_TRY(w.alloc(&ccount, (size_t)nh));
+        ABACUS_TRY(w.alloc(&cstart, (size_t)nh));
+        ABACUS_LAUNCH("prep_keys", prep_keys, dim3(grid_for(npart)), dim3(256), 0, (const int *)d_host, (const int *)d_nt, dpn, npart,
+                      (unsigned long long)a->seed, (long long)a->part_index0, k0, i0, d_sub);
+        ABACUS_LAUNCH("prep_cand_count", prep_cand_count, dim3(grid_for(nh)), dim3(256), 0, (const unsigned char *)d_hmask, dpn, (const int *)d_nt, nh, ccount);
+        ABACUS_TRY(exclusive_sum(ccount, cstart, nh, w));
+        if (npart > 0) {
+            size_t bytes = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, k1, i0, i1, (int)npart, 0, 64, stream()));
+            void *ws;
+            ABACUS_TRY(w.alloc((unsigned char **)&ws, bytes));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ws, bytes, k0, k1, i0, i1, (int)npart, 0, 64, stream()));
+            ABACUS_LAUNCH("prep_pick", prep_pick, dim3(grid_for(npart)), dim3(256), 0, (const unsigned long long *)k1, (const unsigned int *)i1, npart,
+                          (const long long *)cstart, (const int *)d_nt, d_sub);
+        }
+    }
+    ABACUS_TRY(w.alloc(&d_kept, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_kstart, (size_t)nh));
+    ABACUS_LAUNCH("prep_count", prep_count, dim3((unsigned int)std::min<int64_t>(ceil_div(nh, 4), 256 * 32)), dim3(256), 0, dps, dpn,
+                  (const unsigned char *)d_hmask, (const unsigned char *)d_sub, nh, d_kept);
+    ABACUS_TRY(exclusive_sum(d_kept, d_kstart, nh, w));
+    double *d_psn, *d_pnn;
+    ABACUS_TRY(w.alloc(&d_psn, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_pnn, (size_t)nh));
+    ABACUS_LAUNCH("prep_halo_offsets", prep_halo_offsets, dim3(grid_for(nh)), dim3(256), 0, (const unsigned char *)d_hmask, dpn, (const long long *)d_kept,
+                  (const long long *)d_kstart, nh, d_psn, d_pnn);
+    // ---- kept halos: flags -> slots
+    long long *d_hflag, *d_hslot;
+    ABACUS_TRY(w.alloc(&d_hflag, (size_t)nh));
+    ABACUS_TRY(w.alloc(&d_hslot, (size_t)nh));
+    ABACUS_LAUNCH("prep_flags", prep_flag_u8, dim3(grid_for(nh)), dim3(256), 0, (const unsigned char *)d_hmask, nh, d_hflag);
+    ABACUS_TRY(exclusive_sum(d_hflag, d_hslot, nh, w));
+    // halos with two or more kept particles are the rank kernel's work list; its size and the largest halo come back with the counts
+    int *d_work = nullptr, *d_cnt = nullptr;
+    int cnt[2] = {0, 0};
+    if (a->want_ranks) {
+        ABACUS_TRY(w.alloc(&d_work, (size_t)nh));
+        ABACUS_TRY(w.alloc(&d_cnt, 4));
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, stream()));
+        ABACUS_LAUNCH("prep_rank_work", prep_rank_work, dim3(grid_for(nh)), dim3(256), 0, (const long long *)d_kept, nh, d_work, d_cnt, d_cnt + 1);
+        HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, stream()));
+    }
+    long long tail[4] = {0, 0, 0, 0};
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&tail[0], d_kstart + (nh - 1), 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemcpyAsync(&tail[1], d_kept + (nh - 1), 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemcpyAsync(&tail[2], d_hslot + (nh - 1), 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemcpyAsync(&tail[3], d_hflag + (nh - 1), 8, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream()));
+    if (mask_out) HIP_TRY(hipMemcpyAsync(mask_out, d_hmask, (size_t)nh, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    if (bad) {
+        g_slab.clear();
+        return fail("abacus_prepare_slab: a halo's [npstartA, npstartA + npoutA) lies outside the particle array");
+    }
+    const int64_t ns = tail[0] + tail[1], nk = tail[2] + tail[3];
+    g_slab.nk = nk, g_slab.ns = ns, g_slab.want_ranks = a->want_ranks;
+    *n_halo_kept = nk, *n_part_kept = ns;
+    // ---- the particle table
+    long long *d_sidx = nullptr, *d_shost = nullptr;
+    if (ns > 0) {
+        long long *d_flag, *d_slot;
+        double *d_snp;
+        ABACUS_TRY(w.alloc(&d_flag, np1));
+        ABACUS_TRY(w.alloc(&d_slot, np1));
+        ABACUS_TRY(w.alloc(&d_sidx, (size_t)ns));
+        ABACUS_TRY(w.alloc(&d_shost, (size_t)ns));
+        ABACUS_TRY(t.alloc(&d_snp, (size_t)ns));
+        ABACUS_LAUNCH("prep_flags", prep_flags, dim3(grid_for(npart)), dim3(256), 0, (const unsigned char *)d_sub, (const int *)d_host, npart, d_flag);
+        ABACUS_TRY(exclusive_sum(d_flag, d_slot, npart, w));
+        ABACUS_LAUNCH("prep_emit", prep_emit, dim3(grid_for(npart)), dim3(256), 0, (const long long *)d_flag, (const long long *)d_slot, (const int *)d_host,
+                      (const long long *)d_kept, npart, d_sidx, d_shost, d_snp);
+        auto pout = [&](int c, size_t bytes, void **dev) {
+            unsigned char *q;
+            int rc = t.alloc(&q, bytes);
+            g_slab.pcol[c] = q, g_slab.pbytes[c] = bytes, *dev = q;
+            return rc;
+        };
+        void *o;
+        ABACUS_TRY(pout(ABACUS_PREP_P_POS, (size_t)ns * 12, &o));
+        ABACUS_TRY(gather_w<3>(dpos, d_sidx, ns, o));
+        ABACUS_TRY(pout(ABACUS_PREP_P_VEL, (size_t)ns * 12, &o));
+        ABACUS_TRY(gather_w<3>(dvel, d_sidx, ns, o));
+        if (a->want_ranks) {
+            double *d_r[5];
+            for (int c = 0; c < 5; c++) {
+                ABACUS_TRY(pout(ABACUS_PREP_P_RANKS + c, (size_t)ns * 8, &o));
+                d_r[c] = (double *)o;
+            }
+            const size_t lds = (size_t)((3 * (size_t)cnt[1] * 4 + 15) / 16) * 16 + (size_t)5 * cnt[1] * 8;
+            if (cnt[0] > 0 && lds > 160 * 1024) {
+                g_slab.clear();
+                return fail("abacus_prepare_slab: %d kept particles in one halo exceed the rank kernel's LDS", cnt[1]);
+            }
+            RankArgs A;
+            A.pos = dpos, A.vel = dvel, A.hpos = dx, A.hvel = dv, A.N = dN, A.r25 = dr25, A.r98 = dr98;
+            A.pstart = dps, A.pnum = dpn, A.kept = d_kept, A.kstart = d_kstart, A.sel_idx = d_sidx;
+            A.Mpart = a->Mpart, A.h = a->h;
+            A.ranks = d_r[0], A.ranksv = d_r[1], A.ranksp = d_r[2], A.ranksr = d_r[3], A.ranksc = d_r[4];
+            A.work = d_work, A.kmax = cnt[1];
+            if (cnt[0] > 0) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(prep_ranks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (prof_enabled()) {
+                ABACUS_LAUNCH("prep_rank_single", prep_rank_single, dim3(grid_for(nh)), dim3(256), 0, (const long long *)d_kept, (const long long *)d_kstart, nh,
+                              d_r[0], d_r[1], d_r[2], d_r[3], d_r[4]);
+                if (cnt[0] > 0) ABACUS_LAUNCH("prep_ranks", prep_ranks, dim3((unsigned int)std::min(cnt[0], 256 * 8)), dim3(256), lds, A, cnt[0]);
+            } else {
+                if (!g_slab_side) {
+                    HIP_TRY(hipStreamCreateWithFlags(&g_slab_side, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&g_slab_ready, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&g_slab_ranked, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(g_slab_ready, stream()));          // kept list, offsets, inputs: all written on the library stream
+                HIP_TRY(hipStreamWaitEvent(g_slab_side, g_slab_ready, 0));
+                prep_rank_single<<<dim3(grid_for(nh)), dim3(256), 0, g_slab_side>>>((const long long *)d_kept, (const long long *)d_kstart, nh, d_r[0], d_r[1],
+                                                                                 d_r[2], d_r[3], d_r[4]);
+                if (cnt[0] > 0) prep_ranks<<<dim3((unsigned int)std::min(cnt[0], 256 * 8)), dim3(256), lds, g_slab_side>>>(A, cnt[0]);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(g_slab_ranked, g_slab_side));
+                g_slab.ranks_on_side = true;
+            }
+        }
+        ABACUS_TRY(pout(ABACUS_PREP_P_DOWNSAMPLE, (size_t)ns * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_p, d_shost, ns, o));
+        ABACUS_TRY(pout(ABACUS_PREP_P_HALO_VEL, (size_t)ns * 24, &o));
+        ABACUS_LAUNCH("prep_gather", prep_gather_f3d, dim3(grid_for(ns * 3)), dim3(256), 0, dv, (const long long *)d_shost, ns, (double *)o);
+        ABACUS_TRY(pout(ABACUS_PREP_P_HALO_MASS, (size_t)ns * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_mass, d_shost, ns, o));
+        g_slab.pcol[ABACUS_PREP_P_NP] = d_snp, g_slab.pbytes[ABACUS_PREP_P_NP] = (size_t)ns * 8;
+        ABACUS_TRY(pout(ABACUS_PREP_P_HALO_ID, (size_t)ns * 8, &o));
+        ABACUS_TRY(gather_w<2>(did, d_shost, ns, o));
+        ABACUS_TRY(pout(ABACUS_PREP_P_RANDOMS, (size_t)ns * 8, &o));
+        ABACUS_LAUNCH("prep_part_randoms", prep_part_randoms, dim3(grid_for(ns)), dim3(256), 0, ns, (const long long *)d_sidx, (long long)a->part_index0, key,
+                      5u, (double *)o);
+        ABACUS_TRY(pout(ABACUS_PREP_P_DELTAC, (size_t)ns * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_deltac, d_shost, ns, o));
+        ABACUS_TRY(pout(ABACUS_PREP_P_FENV, (size_t)ns * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_fenv, d_shost, ns, o));
+        ABACUS_TRY(pout(ABACUS_PREP_P_SHEAR, (size_t)ns * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_shear, d_shost, ns, o));
+    }
+    // ---- the halo table
+    if (nk > 0) {
+        long long *d_kidx;
+        ABACUS_TRY(w.alloc(&d_kidx, (size_t)nk));
+        ABACUS_LAUNCH("prep_compact", prep_compact, dim3(grid_for(nh)), dim3(256), 0, (const long long *)d_hflag, (const long long *)d_hslot, nh, d_kidx);
+        auto hout = [&](int c, size_t bytes, void **dev) {
+            unsigned char *q;
+            int rc = t.alloc(&q, bytes);
+            g_slab.hcol[c] = q, g_slab.hbytes[c] = bytes, *dev = q;
+            return rc;
+        };
+        void *o;
+        ABACUS_TRY(hout(ABACUS_PREP_H_N, (size_t)nk * 4, &o));
+        ABACUS_TRY(gather_w<1>(dN, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_X, (size_t)nk * 12, &o));
+        ABACUS_TRY(gather_w<3>(dx, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_V, (size_t)nk * 12, &o));
+        ABACUS_TRY(gather_w<3>(dv, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_R25, (size_t)nk * 4, &o));
+        ABACUS_TRY(gather_w<1>(dr25, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_R90, (size_t)nk * 4, &o));
+        ABACUS_TRY(gather_w<1>(dr90, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_R98, (size_t)nk * 4, &o));
+        ABACUS_TRY(gather_w<1>(dr98, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_NPSTART, (size_t)nk * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_psn, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_NPOUT, (size_t)nk * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_pnn, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_ID, (size_t)nk * 8, &o));
+        ABACUS_TRY(gather_w<2>(did, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_SIGMAV, (size_t)nk * 4, &o));
+        ABACUS_TRY(gather_w<1>(dsig, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_MASK, (size_t)nk, &o));
+        HIP_TRY(hipMemsetAsync(o, 1, (size_t)nk, stream()));
+        ABACUS_TRY(hout(ABACUS_PREP_H_MULTI, (size_t)nk * 8, &o));
+        ABACUS_LAUNCH("prep_gather", prep_gather_recip, dim3(grid_for(nk)), dim3(256), 0, (const double *)d_p, (const long long *)d_kidx, nk, (double *)o);
+        ABACUS_TRY(hout(ABACUS_PREP_H_FENV, (size_t)nk * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_fenv, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_DELTAC, (size_t)nk * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_deltac, d_kidx, nk, o));
+        ABACUS_TRY(hout(ABACUS_PREP_H_SHEAR, (size_t)nk * 8, &o));
+        ABACUS_TRY(gather_w<2>(d_shear, d_kidx, nk, o));
+        double *d_scale, *d_rnd, *d_rexp, *d_rgaus;
+        ABACUS_TRY(w.alloc(&d_scale, (size_t)nk));
+        ABACUS_LAUNCH("prep_gather", prep_gather_scale, dim3(grid_for(nk)), dim3(256), 0, dsig, (const long long *)d_kidx, nk, d_scale);
+        ABACUS_TRY(hout(ABACUS_PREP_H_RANDOMS, (size_t)nk * 8, &o));
+        d_rnd = (double *)o;
+        ABACUS_TRY(hout(ABACUS_PREP_H_REXP, (size_t)nk * 24, &o));
+        d_rexp = (double *)o;
+        ABACUS_TRY(hout(ABACUS_PREP_H_RGAUS, (size_t)nk * 24, &o));
+        d_rgaus = (double *)o;
+        ABACUS_LAUNCH("prep_halo_randoms", prep_halo_randoms, dim3(grid_for(nk)), dim3(256), 0, nk, (const long long *)d_kidx, (long long)a->halo_index0, key,
+                      (const double *)d_scale, d_rnd, d_rexp, d_rgaus);
+    }
+    // the work arrays go back to the pool behind the kernels above (one stream); the table columns stay until the fetch
+    return 0;
+}
+
+// copies the columns of the tables the last abacus_prepare_slab left in HBM into the caller's arrays (NULL = not wanted; sizes as
+// the two counts of that call say) and releases them.  halo_cols[ABACUS_PREP_HALO_COLS], part_cols[ABACUS_PREP_PART_COLS].
+int abacus_prepare_slab_fetch(void *const *halo_cols, void *const *part_cols) {
+    ABACUS_ENTER();
+    if (!g_slab.tmp) return fail("abacus_prepare_slab_fetch: no prepared slab (call abacus_prepare_slab first)");
+    for (int c = 0; c < ABACUS_PREP_HALO_COLS; c++)
+        if (halo_cols && halo_cols[c] && g_slab.hcol[c] && g_slab.hbytes[c])
+            HIP_TRY(hipMemcpyAsync(halo_cols[c], g_slab.hcol[c], g_slab.hbytes[c], hipMemcpyDeviceToHost, stream()));
+    auto is_rank = [](int c) { return c >= ABACUS_PREP_P_RANKS && c < ABACUS_PREP_P_RANKS + 5; };
+    for (int pass = 0; pass < 2; pass++) {        // the rank columns last: their kernel may still be running beside these copies
+        if (pass == 1 && g_slab.ranks_on_side) HIP_TRY(hipStreamWaitEvent(stream(), g_slab_ranked, 0));
+        for (int c = 0; c < ABACUS_PREP_PART_COLS; c++)
+            if (is_rank(c) == (pass == 1) && part_cols && part_cols[c] && g_slab.pcol[c] && g_slab.pbytes[c])
+                HIP_TRY(hipMemcpyAsync(part_cols[c], g_slab.pcol[c], g_slab.pbytes[c], hipMemcpyDeviceToHost, stream()));
+    }
+    if (g_slab.ranks_on_side) HIP_TRY(hipStreamWaitEvent(stream(), g_slab_ranked, 0));   // (also when no rank column was asked for)
+    HIP_TRY(hipStreamSynchronize(stream()));
+    g_slab.clear();
     return 0;
 }
 

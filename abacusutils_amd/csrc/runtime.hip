@@ -160,6 +160,8 @@ static hipEvent_t pool_get() {
     return e;
 }
 
+bool prof_enabled() { return g_prof; }
+
 void prof_begin(const char *name) {
     if (!g_prof) return;
     if (!g_prof_only.empty() && g_prof_only != name) return;
@@ -211,8 +213,8 @@ extern "C" {
 
 int abacus_set_option(const char *name, int value) {
     if (!name) return abacus::fail("abacus_set_option: null name");
-    static const char *known[] = {"dbg", "dbg_fft", "dbg_tsc", "fft_fuse_small", "fft_hipfft", "fft_inplace", "fft_cmode", "gfft_dbg", "gfft_nofixed", "fft_nofuse", "fft_zmode", "hod_eblock", "hod_f64filter",
-                                  "hod_nobalance", "hod_nocls", "hod_noindex", "hod_nokeys", "hod_nolazy", "hod_norec", "hod_one_stage", "hod_pipe", "hod_sbtiles", "pairs_countsort", "pairs_gen", "pairs_noblocks", "pairs_nolut", "pk_nobatch", "pk_noxbin", "pk_noxbin_cross", "pk_noxbin_inter", "pk_xbin_gen", "pk_xbin_pairs", "slab_nocompact", "slab_nofuse", "slab_nopackfuse", "slab_nounpackfuse", "tsc_acc64", "tsc_atomic", "tsc_f64acc", "tsc_lines_cfg1", "tsc_lines_clk", "tsc_lines_gen", "tsc_lines_sync", "tsc_noshare", "tsc_noslabfast", "tsc_oldlists", "tsc_piece"};
+    static const char *known[] = {"dbg", "dbg_fft", "dbg_tsc", "fft_fuse_small", "fft_hipfft", "fft_inplace", "gfft_dbg", "gfft_nofixed", "fft_nofuse", "hod_eblock", "hod_f64filter",
+                                  "hod_nobalance", "hod_nocls", "hod_noindex", "hod_nokeys", "hod_nolazy", "hod_norec", "hod_one_stage", "hod_pipe", "hod_sbtiles", "pairs_countsort", "pairs_gen", "pairs_noblocks", "pairs_nolut", "pk_nobatch", "pk_noxbin", "pk_noxbin_cross", "pk_noxbin_inter", "pk_xbin_gen", "pk_xbin_pairs", "prep_columnwise", "slab_nocompact", "slab_nofuse", "slab_nopackfuse", "slab_nounpackfuse", "tsc_acc64", "tsc_atomic", "tsc_lines_cfg1", "tsc_lines_clk", "tsc_lines_sync", "tsc_noshare", "tsc_noslabfast", "tsc_oldlists"};
     bool ok = false;
     for (const char *k : known) ok = ok || !strcmp(k, name);
     if (!ok) return abacus::fail("abacus_set_option: unknown option '%s'", name);

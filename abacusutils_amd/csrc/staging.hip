@@ -189,25 +189,19 @@ int abacus_searchsorted_i64(const int64_t *sorted, int64_t n, const int64_t *que
     return 0;
 }
 
-int abacus_fenv_rank(const double *Menv, const double *halosM, int64_t n, const double *mbins, int n_edges, double *out) {
-    ABACUS_ENTER();
-    if (n < 0 || (n > 0 && (!Menv || !halosM || !out)) || !mbins) return fail("abacus_fenv_rank: null argument");
-    if (n_edges < 2 || n_edges > 60000) return fail("abacus_fenv_rank: %d bin edges", n_edges);
-    if (n >= ((int64_t)1 << 31)) return fail("abacus_fenv_rank: more than 2^31 - 1 halos");
-    for (int b = 0; b + 1 < n_edges; b++)
-        if (!(mbins[b + 1] > mbins[b])) return fail("abacus_fenv_rank: the mass bin edges must increase");
-    if (n == 0) return 0;
+}  // extern "C"
+
+namespace abacus {
+// calc_fenv_opt on device arrays (d_M masses, d_env the ranked quantity, d_edges the n_edges increasing bin edges, all float64 in
+// HBM) -> d_out: what abacus_fenv_rank runs between its copies; prepare.hip's device-resident slab path calls it directly
+int fenv_rank_device(const double *d_M, const double *d_env, int64_t n, const double *d_edges, int n_edges, double *d_out) {
+    if (n <= 0) return 0;
     const int nb = n_edges - 1;
     Tmp t;
-    double *d_M, *d_env, *d_edges, *d_out;
     unsigned long long *k0, *k1;
     unsigned int *v0, *v1, *v2;
     unsigned short *bin, *b0, *b1;
     int64_t *start, *end;
-    ABACUS_TRY(t.alloc(&d_M, n));
-    ABACUS_TRY(t.alloc(&d_env, n));
-    ABACUS_TRY(t.alloc(&d_edges, n_edges));
-    ABACUS_TRY(t.alloc(&d_out, n));
     ABACUS_TRY(t.alloc(&k0, n));
     ABACUS_TRY(t.alloc(&k1, n));
     ABACUS_TRY(t.alloc(&v0, n));
@@ -218,9 +212,6 @@ int abacus_fenv_rank(const double *Menv, const double *halosM, int64_t n, const 
     ABACUS_TRY(t.alloc(&b1, n));
     ABACUS_TRY(t.alloc(&start, nb));
     ABACUS_TRY(t.alloc(&end, nb));
-    HIP_TRY(hipMemcpyAsync(d_M, halosM, n * 8, hipMemcpyHostToDevice, stream()));
-    HIP_TRY(hipMemcpyAsync(d_env, Menv, n * 8, hipMemcpyHostToDevice, stream()));
-    HIP_TRY(hipMemcpyAsync(d_edges, mbins, (size_t)n_edges * 8, hipMemcpyHostToDevice, stream()));
     HIP_TRY(hipMemsetAsync(start, 0, (size_t)nb * 8, stream()));
     HIP_TRY(hipMemsetAsync(end, 0, (size_t)nb * 8, stream()));
     const int g = grid_for(n);
@@ -233,6 +224,31 @@ int abacus_fenv_rank(const double *Menv, const double *halosM, int64_t n, const 
     ABACUS_TRY(sort_pairs(t, b0, b1, v1, v2, n, 16));
     ABACUS_LAUNCH("staging_bin_starts", bin_starts, dim3(g), dim3(256), 0, b1, n, start, end);
     ABACUS_LAUNCH("staging_rank", write_rank, dim3(g), dim3(256), 0, b1, v2, n, start, end, d_out);
+    // the scratch blocks of `t` go back to the pool here; the stream is in order, so a later acquirer's kernels run behind these
+    return 0;
+}
+}  // namespace abacus
+
+extern "C" {
+
+int abacus_fenv_rank(const double *Menv, const double *halosM, int64_t n, const double *mbins, int n_edges, double *out) {
+    ABACUS_ENTER();
+    if (n < 0 || (n > 0 && (!Menv || !halosM || !out)) || !mbins) return fail("abacus_fenv_rank: null argument");
+    if (n_edges < 2 || n_edges > 60000) return fail("abacus_fenv_rank: %d bin edges", n_edges);
+    if (n >= ((int64_t)1 << 31)) return fail("abacus_fenv_rank: more than 2^31 - 1 halos");
+    for (int b = 0; b + 1 < n_edges; b++)
+        if (!(mbins[b + 1] > mbins[b])) return fail("abacus_fenv_rank: the mass bin edges must increase");
+    if (n == 0) return 0;
+    Tmp t;
+    double *d_M, *d_env, *d_edges, *d_out;
+    ABACUS_TRY(t.alloc(&d_M, n));
+    ABACUS_TRY(t.alloc(&d_env, n));
+    ABACUS_TRY(t.alloc(&d_edges, n_edges));
+    ABACUS_TRY(t.alloc(&d_out, n));
+    HIP_TRY(hipMemcpyAsync(d_M, halosM, n * 8, hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemcpyAsync(d_env, Menv, n * 8, hipMemcpyHostToDevice, stream()));
+    HIP_TRY(hipMemcpyAsync(d_edges, mbins, (size_t)n_edges * 8, hipMemcpyHostToDevice, stream()));
+    ABACUS_TRY(fenv_rank_device(d_M, d_env, n, d_edges, n_edges, d_out));
     HIP_TRY(hipMemcpyAsync(out, d_out, n * 8, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;

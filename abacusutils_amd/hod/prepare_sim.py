@@ -7,8 +7,9 @@ What runs where
            new halo offsets, kept-particle list, Np and the five satellite rank columns (`abacus_prepare_particles`); the
            concentration / shear / (light-cone) environment ranks per mass bin (`abacus_fenv_rank`); the environment masses
            (`do_Menv_from_tree`).
-  host     drawing the random numbers, gathering the kept rows, file I/O (optional, needs h5py).  The CompaSO / ASDF readers
-           are out of scope: the caller passes the tables.
+  host     drawing the random numbers and gathering the kept rows in the `rng='numpy'` form; file I/O (optional, needs h5py).
+           With `rng=<seed>` the whole slab goes through HBM once (`abacus_prepare_slab`: inputs uploaded once or used in place as
+           device arrays, kept rows gathered on the device, every output column copied out once into page-locked memory).
 
 Random numbers.  The reference consumes NumPy's global legacy generator in a fixed order (:349-350 seed, :449 halo mask,
 one `np.random.choice(replace=False)` per kept halo :163/:172, :984-996 halo randoms, :1029 particle randoms).
@@ -273,6 +274,101 @@ def _targets_host(masses, pnum, MT):
     return out
 
 
+class _SlabArgs(C.Structure):      # struct abacus_prepare_slab_args (include/abacus_hip.h)
+    _fields_ = ([('nh', C.c_int64), ('npart', C.c_int64)]
+                + [(k, C.c_void_p) for k in ('N', 'x', 'v', 'r25', 'r90', 'r98', 'sigmav', 'npstartA', 'npoutA', 'id', 'pos', 'vel',
+                                             'fenv_rank', 'shear_rank', 'mbins')]
+                + [('n_edges', C.c_int32), ('MT', C.c_int32), ('want_ranks', C.c_int32), ('pad_', C.c_int32), ('Mpart', C.c_double),
+                   ('h', C.c_double), ('seed', C.c_uint64), ('halo_index0', C.c_int64), ('part_index0', C.c_int64)])
+
+
+# columns of the two tables in the order of the library's column arrays (ABACUS_PREP_H_* / ABACUS_PREP_P_*): name, dtype, row shape
+_SLAB_HALO_IN = (('N', np.uint32, ()), ('x_L2com', np.float32, (3,)), ('v_L2com', np.float32, (3,)), ('r25_L2com', np.float32, ()),
+                 ('r90_L2com', np.float32, ()), ('r98_L2com', np.float32, ()), ('npstartA', np.int64, ()), ('npoutA', np.int64, ()),
+                 ('id', None, ()), ('sigmav3d_L2com', np.float32, ()))
+_SLAB_HALO_OUT = (('N', np.uint32, ()), ('x_L2com', np.float32, (3,)), ('v_L2com', np.float32, (3,)), ('r25_L2com', np.float32, ()),
+                  ('r90_L2com', np.float32, ()), ('r98_L2com', np.float32, ()), ('npstartA', np.float64, ()), ('npoutA', np.float64, ()),
+                  ('id', None, ()), ('sigmav3d_L2com', np.float32, ()), ('mask_subsample', np.bool_, ()), ('multi_halos', np.float64, ()),
+                  ('fenv_rank', np.float64, ()), ('deltac_rank', np.float64, ()), ('shear_rank', np.float64, ()), ('randoms', np.float64, ()),
+                  ('randoms_exp', np.float64, (3,)), ('randoms_gaus_vrms', np.float64, (3,)))
+_SLAB_PART_OUT = ((('pos', np.float32, (3,)), ('vel', np.float32, (3,))) + tuple((k, np.float64, ()) for k in RANK_COLUMNS)
+                  + (('downsample_halo', np.float64, ()), ('halo_vel', np.float64, (3,)), ('halo_mass', np.float64, ()), ('Np', np.float64, ()),
+                     ('halo_id', np.int64, ()), ('randoms', np.float64, ()), ('halo_deltac', np.float64, ()), ('halo_fenv', np.float64, ()),
+                     ('halo_shear', np.float64, ())))
+
+
+def _slab_col(a, dtype, keep):
+    """pointer of one input column: a device array is used where it is, anything else as a contiguous NumPy array of `dtype`"""
+    if isinstance(a, _lib.DeviceArray):
+        if dtype is not None and a.dtype != np.dtype(dtype):
+            raise TypeError(f'device column of dtype {a.dtype}, expected {np.dtype(dtype)}')
+        keep.append(a)
+        return C.c_void_p(a.ptr.value)
+    a = np.ascontiguousarray(a) if dtype is None else np.ascontiguousarray(a, dtype=dtype)
+    keep.append(a)
+    return C.c_void_p(a.ctypes.data)
+
+
+def _prepare_slab_device(halos, parts, Mpart, h, MT, want_ranks, want_AB, fenv_rank, shear_rank, mbins, seed, part_index0, halo_index0):
+    """prepare_slab_arrays with rng = <seed> as ONE pass through HBM (abacus_prepare_slab / abacus_prepare_slab_fetch): every input
+    column is uploaded once (or used in place when it is a `_lib.DeviceArray` - what the reader's unpack kernels produce), the kept
+    rows of both tables are gathered on the device and every output column is copied out once, into page-locked memory"""
+    keep = []
+    id_col = halos['id']
+    id_dtype = id_col.dtype if isinstance(id_col, _lib.DeviceArray) else np.asarray(id_col).dtype
+    if np.dtype(id_dtype).itemsize != 8:
+        raise TypeError(f'halo ids of dtype {id_dtype}: 8-byte integers expected')
+    nh = int(halos['N'].shape[0])
+    npart = int(parts['pos'].shape[0])
+    a = _SlabArgs()
+    a.nh, a.npart = nh, npart
+    for field, (name, dt, _) in zip(('N', 'x', 'v', 'r25', 'r90', 'r98', 'npstartA', 'npoutA', 'id', 'sigmav'), _SLAB_HALO_IN):
+        setattr(a, field, _slab_col(halos[name], dt, keep))
+    a.pos, a.vel = _slab_col(parts['pos'], np.float32, keep), _slab_col(parts['vel'], np.float32, keep)
+    a.fenv_rank = None if fenv_rank is None else _slab_col(fenv_rank, np.float64, keep)
+    a.shear_rank = None if shear_rank is None else _slab_col(shear_rank, np.float64, keep)
+    if want_AB:
+        a.mbins, a.n_edges = _slab_col(mbins, np.float64, keep), len(mbins)
+    else:
+        a.mbins, a.n_edges = None, 0
+    a.MT, a.want_ranks, a.Mpart, a.h = int(bool(MT)), int(bool(want_ranks)), float(Mpart), float(h)
+    a.seed, a.halo_index0, a.part_index0 = int(seed), int(halo_index0), int(part_index0)
+    nk, ns = C.c_int64(0), C.c_int64(0)
+    mask8 = np.empty(nh, dtype=np.uint8)
+    L = _lib.lib()
+    _lib.check(L.abacus_prepare_slab(C.byref(a), C.byref(nk), C.byref(ns), _lib.ptr(mask8)))
+    nk, ns = int(nk.value), int(ns.value)
+
+    def table(spec, n, skip=()):
+        cols, ptrs = {}, []
+        for name, dt, tail in spec:
+            if name in skip:
+                ptrs.append(None)
+                continue
+            arr = _lib.pinned_empty((n,) + tail, id_dtype if dt is None else dt)
+            cols[name] = arr
+            ptrs.append(arr.ctypes.data if n else None)
+        return cols, (C.c_void_p * len(ptrs))(*ptrs)
+
+    Hk, hp = table(_SLAB_HALO_OUT, nk)
+    P, pp = table(_SLAB_PART_OUT, ns, skip=() if want_ranks else RANK_COLUMNS)
+    _lib.check(L.abacus_prepare_slab_fetch(hp, pp))
+    mask = mask8.astype(bool)
+    # the caller's key order (columns the library does not know are gathered here, like before)
+    kept = None
+    out = {}
+    for k, v in halos.items():
+        if k in Hk:
+            out[k] = Hk[k]
+        else:
+            if kept is None:
+                kept = np.flatnonzero(mask)
+            out[k] = _rows(v.get() if isinstance(v, _lib.DeviceArray) else v, kept)
+    for name, _, _ in _SLAB_HALO_OUT[10:]:
+        out[name] = Hk[name]
+    return out, P, mask
+
+
 def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=True, Menv=None, shearmark=None, Lbox=None,
                         mcut=1e11, halo_lc=False, rng='numpy', part_index0=0, halo_index0=0, origins=None, lc_seed=None,
                         rad_outer=10):
@@ -285,14 +381,40 @@ def prepare_slab_arrays(halos, parts, Mpart, h, MT, want_ranks=False, want_AB=Tr
     `reference_seed`); an integer seeds the device's counter-based generator - every draw is then a function of (seed,
     global halo / particle index = halo_index0 / part_index0 + row), so slabs prepared on different GPUs fit together."""
     nh = len(halos['N'])
-    N = np.ascontiguousarray(halos['N'], dtype=np.uint32)
-    masses = halos['N'] * Mpart
-    pstart = np.ascontiguousarray(halos['npstartA'], dtype=np.int64)
-    pnum = np.ascontiguousarray(halos['npoutA'], dtype=np.int64)
     numpy_mode = isinstance(rng, str)
     if numpy_mode and rng != 'numpy':
         raise ValueError("rng must be 'numpy' (the reference's global generator) or an integer seed")
     seed = 0 if numpy_mode else int(rng) & (2**64 - 1)
+    def _fits(col, dt):      # the device path returns the library's dtypes: only for inputs that already carry them
+        d = col.dtype if isinstance(col, _lib.DeviceArray) else np.asarray(col).dtype
+        return (d.kind in 'iu' and d.itemsize == 8) if dt is None else d == np.dtype(dt)
+
+    if (not numpy_mode and not _lib.get_option('prep_columnwise') and all(k in halos and _fits(halos[k], dt) for k, dt, _ in _SLAB_HALO_IN)
+            and _fits(parts['pos'], np.float32) and _fits(parts['vel'], np.float32)):
+        # every draw is made on the device: the slab goes through HBM once (abacus_prepare_slab); the per-halo rank columns that need
+        # host-side inputs (light-cone environment, shear) are computed as before and handed over
+        mbins = np.logspace(np.log10(mcut), 15.5, NBINS + 1)
+        fenv = shear = None
+        def hcol(k):         # a host copy of a column the host-side rank inputs need
+            return halos[k].get() if isinstance(halos[k], _lib.DeviceArray) else np.asarray(halos[k])
+        hN = hcol('N')
+        if want_AB and halo_lc:
+            if Menv is None:
+                if origins is None or lc_seed is None or Lbox is None:
+                    raise ValueError('halo_lc with want_AB needs the environment masses (Menv), or Lbox, the light-cone origins '
+                                     'and the seed of the randoms (lc_seed, see reference_seed) to work them out')
+                Menv = lightcone_environment(hcol('x_L2com'), hN * Mpart, hcol('r98_L2com'), Lbox, origins, lc_seed,
+                                             rad_outer=rad_outer, mcut=mcut)
+            fenv = rank_in_mass_bins(Menv, hN * Mpart, mbins)
+        if shearmark is not None:
+            ndim = len(shearmark)
+            g = (hcol('x_L2com') / (Lbox / ndim)).astype(int) % ndim
+            shear = rank_in_mass_bins(shearmark[g[:, 0], g[:, 1], g[:, 2]], hN * Mpart, mbins)
+        return _prepare_slab_device(halos, parts, Mpart, h, MT, want_ranks, want_AB, fenv, shear, mbins, seed, part_index0, halo_index0)
+    N = np.ascontiguousarray(halos['N'], dtype=np.uint32)
+    masses = halos['N'] * Mpart
+    pstart = np.ascontiguousarray(halos['npstartA'], dtype=np.int64)
+    pnum = np.ascontiguousarray(halos['npoutA'], dtype=np.int64)
     if numpy_mode:
         u = np.random.random(nh)                                                     # (:449)
     else:

@@ -706,24 +706,59 @@ def bench_prepare(args, dist):
     halos, parts = slabs[0]['halos'], slabs[0]['parts']
     Mpart, h = header['ParticleMassHMsun'], header['H0'] / 100.0
     kw = dict(MT=True, want_ranks=True, want_AB=True, Lbox=header['BoxSize'])
-    prep.prepare_slab_arrays(halos, parts, Mpart, h, rng=7, **kw)      # warm-up: scratch allocations
+    # warm-up: scratch allocations, and TWO sets of page-locked output columns (the caller holds one result while the next slab is
+    # prepared: a pipeline over slabs reaches that state after its second slab; pinning ~400 MB costs tens of ms once)
+    keep_a = prep.prepare_slab_arrays(halos, parts, Mpart, h, rng=7, **kw)
+    keep_b = prep.prepare_slab_arrays(halos, parts, Mpart, h, rng=8, **kw)
+    del keep_a, keep_b
     _lib.sync()
-    _lib.profile_reset()
-    _lib.profile_enable(True)
     reps = 3
     t0 = time.perf_counter()
     for r in range(reps):
         H, P, mask = prep.prepare_slab_arrays(halos, parts, Mpart, h, rng=11 + r, **kw)
     _lib.sync()
     dt = (time.perf_counter() - t0) / reps
+    # the per-kernel table from one more, untimed call (with the profiler on the rank kernel stays on the library stream instead of
+    # running beside the copies of the other columns)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    prep.prepare_slab_arrays(halos, parts, Mpart, h, rng=11, **kw)
+    _lib.sync()
     _lib.profile_enable(False)
-    kern = {k: round(ms / reps, 4) for k, (ms, n) in _lib.profile_get().items() if n}
+    kern = {k: round(ms, 4) for k, (ms, n) in _lib.profile_get().items() if n}
+    # the same slab with its CompaSO columns already in HBM (where the reader's rvint / PID unpack kernels leave them), and through the
+    # column-by-column path of rounds 3 - 5 (host gathers of the kept rows)
+    extra = {}
+    try:
+        dh = {k: _lib.DeviceArray(v) for k, v in halos.items()}
+        dp = {k: _lib.DeviceArray(v) for k, v in parts.items()}
+        prep.prepare_slab_arrays(dh, dp, Mpart, h, rng=5, **kw)
+        _lib.sync()
+        t1 = time.perf_counter()
+        for r in range(reps):
+            prep.prepare_slab_arrays(dh, dp, Mpart, h, rng=21 + r, **kw)
+        _lib.sync()
+        extra['ms_per_slab_device_columns'] = (time.perf_counter() - t1) / reps * 1e3
+        for a in list(dh.values()) + list(dp.values()):
+            a.free()
+        _lib.set_option('prep_columnwise', 1)
+        prep.prepare_slab_arrays(halos, parts, Mpart, h, rng=5, **kw)
+        t1 = time.perf_counter()
+        for r in range(reps):
+            prep.prepare_slab_arrays(halos, parts, Mpart, h, rng=31 + r, **kw)
+        extra['ms_per_slab_column_by_column'] = (time.perf_counter() - t1) / reps * 1e3
+    except Exception as e:   # noqa: BLE001
+        extra['error'] = repr(e)
+    finally:
+        _lib.set_option('prep_columnwise', 0)
     out = {'metric': 'halos/s through prepare_slab (subsample + particle selection + rank columns)', 'value': nh / dt,
            'unit': 'halos/s', 'ms_per_slab': dt * 1e3, 'n_halos': nh, 'n_particles': int(len(parts['pos'])),
            'halos_kept': int(mask.sum()), 'particles_kept': int(len(P['pos'])), 'kernels_ms': kern,
            'kernels_ms_total': round(sum(kern.values()), 3),
-           'note': 'host arrays in, the two output tables as NumPy structured columns out (PCIe and the NumPy gathers of the '
-                   'kept rows included); kernels_ms_total is the device share'}
+           'note': 'ms_per_slab: NumPy columns in, the two tables as NumPy columns out - one pass through HBM (abacus_prepare_slab: every '
+                   'input uploaded once, kept rows gathered on the device, every output column copied out once into page-locked memory); '
+                   'ms_per_slab_device_columns: the CompaSO columns already in HBM; ms_per_slab_column_by_column: the path of rounds 3 - 5; '
+                   'kernels_ms_total is the device share', **extra}
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu:
         from oracle import prepare_oracle
         ns = 200000                                   # the loop costs ~40 us per halo

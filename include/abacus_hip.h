@@ -534,6 +534,44 @@ int abacus_prepare_particles(int64_t nh, const uint8_t *hmask, const int64_t *ps
                              int64_t *n_sel, int64_t cap_sel, int64_t *sel_idx, int64_t *sel_host, double *sel_np, double *ranks,
                              double *ranksv, double *ranksp, double *ranksr, double *ranksc, uint8_t *submask_out);
 
+/*
+ * The same slab prepared WITHOUT a column crossing PCIe twice (what hod/prepare_sim.py:296-1052 does between its loader and its
+ * writer, `rng = <seed>` form): abacus_prepare_slab takes the CompaSO columns prepare_slab loads (:404-425; host pointers are
+ * uploaded once, device pointers - what the reader's unpack kernels produce - are used in place), draws the halo mask, selects the
+ * particles, ranks them and gathers the kept rows of every column of both tables in HBM; abacus_prepare_slab_fetch copies the
+ * columns out, one copy each.  mbins / n_edges: the mass bins of the concentration rank (n_edges = 0: deltac_rank = 0, the
+ * reference's want_AB = False); fenv_rank / shear_rank: per-halo columns the caller computed (light cones, shear) or NULL = 0.
+ * mask_out (nh bytes, host, may be NULL): the halo mask.  Streams and values are those of abacus_prepare_halo_factors /
+ * _particles / _randoms with the same seed: both paths give identical tables.
+ */
+typedef struct abacus_prepare_slab_args {
+    int64_t nh, npart;
+    const uint32_t *N;                           /* (nh) */
+    const float *x, *v;                          /* (nh, 3) x_L2com, v_L2com */
+    const float *r25, *r90, *r98, *sigmav;       /* (nh) */
+    const int64_t *npstartA, *npoutA;            /* (nh) */
+    const void *id;                              /* (nh) 8-byte ids */
+    const float *pos, *vel;                      /* (npart, 3) subsample-A particles in halo order */
+    const double *fenv_rank, *shear_rank;        /* (nh) or NULL */
+    const double *mbins;                         /* (n_edges) host */
+    int32_t n_edges, MT, want_ranks, pad_;
+    double Mpart, h;
+    uint64_t seed;
+    int64_t halo_index0, part_index0;
+} abacus_prepare_slab_args;
+enum {  /* columns of the halo table, in the order of halo_cols[] */
+    ABACUS_PREP_H_N = 0, ABACUS_PREP_H_X, ABACUS_PREP_H_V, ABACUS_PREP_H_R25, ABACUS_PREP_H_R90, ABACUS_PREP_H_R98, ABACUS_PREP_H_NPSTART,
+    ABACUS_PREP_H_NPOUT, ABACUS_PREP_H_ID, ABACUS_PREP_H_SIGMAV, ABACUS_PREP_H_MASK, ABACUS_PREP_H_MULTI, ABACUS_PREP_H_FENV, ABACUS_PREP_H_DELTAC,
+    ABACUS_PREP_H_SHEAR, ABACUS_PREP_H_RANDOMS, ABACUS_PREP_H_REXP, ABACUS_PREP_H_RGAUS, ABACUS_PREP_HALO_COLS
+};
+enum {  /* columns of the particle table, in the order of part_cols[]; RANKS .. RANKS + 4 = ranks, ranksv, ranksp, ranksr, ranksc */
+    ABACUS_PREP_P_POS = 0, ABACUS_PREP_P_VEL, ABACUS_PREP_P_RANKS, ABACUS_PREP_P_DOWNSAMPLE = ABACUS_PREP_P_RANKS + 5, ABACUS_PREP_P_HALO_VEL,
+    ABACUS_PREP_P_HALO_MASS, ABACUS_PREP_P_NP, ABACUS_PREP_P_HALO_ID, ABACUS_PREP_P_RANDOMS, ABACUS_PREP_P_DELTAC, ABACUS_PREP_P_FENV,
+    ABACUS_PREP_P_SHEAR, ABACUS_PREP_PART_COLS
+};
+int abacus_prepare_slab(const abacus_prepare_slab_args *args, int64_t *n_halo_kept, int64_t *n_part_kept, uint8_t *mask_out);
+int abacus_prepare_slab_fetch(void *const *halo_cols, void *const *part_cols);
+
 /* the random columns of the prepare_sim tables drawn on the device (Philox4x32-10, counter = global object index: shard
  * invariant; NOT the reference's NumPy stream - prepare_sim.py:984-996,1029 - but its distributions and dtypes).  Row r stands
  * for the object index0 + (index ? index[r] : r).  stream_id 4, with scale / randoms_exp / randoms_gaus: the halo columns

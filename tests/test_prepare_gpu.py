@@ -240,6 +240,42 @@ def want_mt(halos, Mpart):
     return np.array([po.particle_target(m[j], int(halos['npoutA'][j]), True) if halos['npoutA'][j] > 0 else 0 for j in range(len(m))])
 
 
+@pytest.mark.parametrize('MT,want_ranks,want_AB,shear', [(True, True, True, True), (False, True, True, False), (True, False, False, False)])
+def test_one_pass_slab_equals_the_column_by_column_path(MT, want_ranks, want_AB, shear, options):
+    """rng = <seed>: the slab through HBM once (abacus_prepare_slab: inputs uploaded once or used in place as device arrays, kept
+    rows gathered on the device, one copy per output column) against the column-by-column path (option prep_columnwise: the host
+    gathers of hod/prepare_sim.py:984-1045's tables) - same Philox streams, so every column of both tables and the mask are EQUAL,
+    key order and dtypes included; also with the CompaSO columns already in HBM (what the reader's unpack kernels leave there)"""
+    from abacusutils_amd import _lib
+    from abacusutils_amd.hod import prepare_sim as ps
+    slabs, header = synth.synth_compaso_slabs(numslabs=1, n_halo=60000, seed=77, lbox=700.0)
+    halos, parts = slabs[0]['halos'], slabs[0]['parts']
+    Mpart, h = header['ParticleMassHMsun'], header['H0'] / 100.0
+    kw = dict(want_ranks=want_ranks, want_AB=want_AB, shearmark=shearmark() if shear else None, Lbox=header['BoxSizeHMpc'], rng=4242,
+              part_index0=2**33 + 11, halo_index0=2**32 + 3)
+    options.set('prep_columnwise', 1)
+    H0, P0, m0 = ps.prepare_slab_arrays(halos, parts, Mpart, h, MT, **kw)
+    options.set('prep_columnwise', 0)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    H1, P1, m1 = ps.prepare_slab_arrays(halos, parts, Mpart, h, MT, **kw)
+    _lib.profile_enable(False)
+    assert 'prep_compact' in _lib.profile_get(), sorted(_lib.profile_get())      # the one-pass path ran
+    dev_h = {k: _lib.DeviceArray(v) for k, v in halos.items()}
+    dev_p = {k: _lib.DeviceArray(v) for k, v in parts.items()}
+    H2, P2, m2 = ps.prepare_slab_arrays(dev_h, dev_p, Mpart, h, MT, **kw)
+    for a in list(dev_h.values()) + list(dev_p.values()):
+        a.free()
+    assert len(P0['pos']) > 1000 and m0.sum() > 1000
+    for H, P, m, label in ((H1, P1, m1, 'host columns'), (H2, P2, m2, 'device columns')):
+        np.testing.assert_array_equal(m, m0, err_msg=label)
+        for got, want in ((H, H0), (P, P0)):
+            assert list(got) == list(want), (label, list(got), list(want))
+            for k in want:
+                assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape, (label, k, got[k].dtype, want[k].dtype, got[k].shape, want[k].shape)
+                np.testing.assert_array_equal(got[k], want[k], err_msg=f'{label}.{k}')
+
+
 def test_prepare_to_run_hod_end_to_end():
     """three synthetic slabs -> prepare on the device (Philox selection, ranks, padded environments) -> AbacusHOD.from_prepared
     -> run_hod: the catalogue is the oracle's on the same staged arrays; the staged arrays carry what staging() derives
