@@ -11,7 +11,7 @@ for w in $what; do
 case $w in
 tests)
   make -s -C oracle
-  timeout 2400 python -u -m pytest tests -m gpu -x -q -p no:cacheprovider > "$O/gpu_tests.log" 2>&1; tail -15 "$O/gpu_tests.log"
+  timeout -k 10 900 python -u -m pytest tests -m gpu -x -q -p no:cacheprovider --durations=40 > "$O/gpu_tests.log" 2>&1; tail -15 "$O/gpu_tests.log"
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12 | tee "$O/smoke.log"
   ;;
 bench)
