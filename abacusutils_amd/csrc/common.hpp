@@ -20,6 +20,10 @@ hipStream_t stream();
 int scratch_acquire(void **out, size_t bytes);
 void scratch_release(void *p);
 int scratch_trim_idle();
+// the mesh buffers the P(k) entry points keep between calls (power.hip: up to four fields, 35 GB each at 2048^3; fft.hip: the second
+// mesh of the out-of-place passes) hold nothing between calls: given back when an allocation of the caller's fails (abacus_malloc)
+int power_trim_caches();
+int fft_trim_scratch();
 
 #define HIP_TRY(expr)                                                                                       \
     do {                                                                                                    \

@@ -816,6 +816,8 @@ int fft_native_r2c_fused(float *mesh, int n, int pitch_r, float xcut) { return f
 // z and y passes only: the x pass is left to fft_x_bin_run (last pass fused with the binning)
 int fft_native_r2c_fused_zy(float *mesh, int n, int pitch_r, float xcut) { return fused_impl(mesh, n, pitch_r, false, xcut); }
 
+int fft_trim_scratch() { return g_scratch.release(); }
+
 int fft_native_release() {
     ABACUS_TRY(g_scratch.release());
     for (SlabLayout *l : g_slab_layouts) {

@@ -1864,6 +1864,19 @@ double abacus_power_geometry_ms(void) { return xbin_last_build_ms(); }
 double abacus_power_last_batches(void) { return g_last_batches; }
 int abacus_power_xbin_generation(void) { return xbin_last_gen(); }
 
+}  // extern "C"
+
+namespace abacus {
+int power_trim_caches() {
+    HIP_TRY(hipStreamSynchronize(stream()));
+    for (auto &m : g_ctx.mesh) ABACUS_TRY(m.release());
+    ABACUS_TRY(fft_trim_scratch());
+    return 0;
+}
+}  // namespace abacus
+
+extern "C" {
+
 int abacus_power_release(void) {
     ABACUS_TRY(xbin_release());
     for (auto &kv : g_ctx.plans) (void)hipfftDestroy(kv.second);

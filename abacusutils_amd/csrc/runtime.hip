@@ -270,7 +270,17 @@ int abacus_set_stream(void *s) {
 
 int abacus_malloc(void **dptr, uint64_t nbytes) {
     ABACUS_ENTER();
-    HIP_TRY(hipMalloc(dptr, nbytes ? nbytes : 1));
+    if (hipMalloc(dptr, nbytes ? nbytes : 1) != hipSuccess) {
+        // idle scratch blocks of this library (one mesh-sized block may be kept between calls, scratch_release) must not stand
+        // between a caller and memory it asks for: give them back and try once more
+        (void)hipGetLastError();
+        ABACUS_TRY(scratch_trim());
+        if (hipMalloc(dptr, nbytes ? nbytes : 1) != hipSuccess) {   // ... nor the P(k) context's idle meshes (140 GB after a 2048^3 interlaced cross power)
+            (void)hipGetLastError();
+            ABACUS_TRY(power_trim_caches());
+            HIP_TRY(hipMalloc(dptr, nbytes ? nbytes : 1));
+        }
+    }
     return 0;
 }
 int abacus_free(void *dptr) {

@@ -30,5 +30,5 @@ for seed in range(S0, S0 + NS):
         print('seed', seed, 'FAILED', repr(e)[:300], flush=True)
     if (seed - S0 + 1) % 50 == 0:
         print('progress', seed - S0 + 1, 'failing', bad, 'last generation counts', gens, round(time.time() - t0, 1), 's', flush=True)
-print('cases', NS, 'x 4 edge sets, failing', bad, 'generation of the last set per seed', gens)
+print('cases', NS, 'x 5 edge sets (auto, auto, interlaced pair, cross, interlaced cross), failing', bad, 'generation of the last set per seed', gens)
 PY

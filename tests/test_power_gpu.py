@@ -727,18 +727,18 @@ def test_fused_last_pass_random_edges(options, seed):
     nmesh, box = 1024, 1000.0
     pos = synth.synth_positions(400_000, box, seed=200 + seed, clustered=True)
     pos2 = np.concatenate((pos[:100_000], synth.synth_positions(150_000, box, seed=700 + seed, clustered=True)))
-    for it in range(4):
+    for it in range(5):
         ke, me, poles = _random_edges(rng, nmesh, box)
         comp = bool(rng.integers(0, 2))
-        inter = it == 2        # the interlaced pair through the same descriptor (edges past Nyquist: the folded i = n/2 plane)
-        cross = it == 3        # the cross power of two fields through the two-tile schedule
+        inter = it in (2, 4)   # the interlaced pair through the same descriptor (edges past Nyquist: the folded i = n/2 plane)
+        cross = it in (3, 4)   # the cross power of two fields through the two-tile schedule; 4: of two INTERLACED fields (four tiles)
         kw = dict(kbins=ke, mubins=me, poles=poles, paste='TSC', nmesh=nmesh, compensated=comp, interlaced=inter)
         if cross:
             kw['pos2'] = pos2.copy()
         a = calc_power(pos.copy(), box, **kw)
         gen = _lib.lib().abacus_power_xbin_generation()
         assert gen in (1, 2)
-        off = 'pk_noxbin_inter' if inter else 'pk_noxbin_cross' if cross else 'pk_noxbin'
+        off = 'pk_noxbin_cross' if cross else 'pk_noxbin_inter' if inter else 'pk_noxbin'
         options.set(off, 1)
         b = calc_power(pos.copy(), box, **kw)
         options.set(off, 0)
