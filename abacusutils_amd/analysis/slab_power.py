@@ -159,17 +159,20 @@ class HipSlabBackend:
         return raw
 
     xbin_pair = True       # xbin_raw takes field2: a second field (cross power) or the shifted deposit of an interlaced pair
+    xbin_quad = True       # ... and field3 / field4: the interlaced pair of a second catalogue (interlaced cross power)
 
     def xbin_raw(self, field, nmesh, world, y0, nyl, Lbox, W, ke, me, poles, put_geom, from_transpose=False, field2=None,
-                 interlaced=False, cross=False):
+                 interlaced=False, cross=False, field3=None, field4=None):
         """last x pass fused with the binning (one non-interlaced field; with field2 the cross power with a second one or,
         `interlaced`, the auto power of the interlaced pair (field, field2 = shifted); nmesh 1024 / 2048): raw sums, or None
         when the library does not serve this mesh / histogram that way (then unpack + fft_x + bin_raw).  from_transpose:
         `field` is the receive buffer of the pencil transpose, (peer, 2 h, y_local, k), not yet unpacked"""
         buf, off = field if field is not None else (None, 0)   # field None: a query (0 / None, nothing computed)
         raw = np.zeros(self.raw_bytes(len(ke) - 1, len(me) - 1, poles), dtype=np.uint8)
-        rc = _lib.lib().abacus_slab_xbin_pair_dev(None if buf is None else buf.ptr(off), None if field2 is None else field2[0].ptr(field2[1]),
-                                                   1 if interlaced else 2 if (field2 is not None or cross) else 0,
+        fp = lambda f: None if f is None else f[0].ptr(f[1])  # noqa: E731
+        rc = _lib.lib().abacus_slab_xbin_quad_dev(None if buf is None else buf.ptr(off), fp(field2), fp(field3), fp(field4),
+                                                   3 if (interlaced and (cross or field3 is not None)) else 1 if interlaced
+                                                   else 2 if (field2 is not None or cross) else 0,
                                                    int(nmesh), int(world), int(y0), int(nyl), C.c_double(Lbox),
                                                    None if W is None else _lib.ptr(W), _lib.ptr(ke), len(ke) - 1, _lib.ptr(me),
                                                    len(me) - 1, _lib.ptr(poles), len(poles), int(bool(put_geom)),
@@ -287,11 +290,12 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
     # auto power of one non-interlaced field, or the cross power of two: the last x pass can bin straight from LDS (no
     # spectrum write + re-read)
     # (likewise a pair of fields through one pass: the interlaced pair of an auto power, the two fields of a cross power)
-    try_xbin = hasattr(backend, 'xbin_raw') and (nfields == 1 or (nfields == 2 and getattr(backend, 'xbin_pair', False)))
+    try_xbin = hasattr(backend, 'xbin_raw') and (nfields == 1 or (nfields == 2 and getattr(backend, 'xbin_pair', False)) or
+                                                 (nfields == 4 and getattr(backend, 'xbin_quad', False)))
     # ... and then nothing but that binning reads the transposed spectrum: the columns of a row beyond its last edge need not
     # cross the links (COMPACT transpose, csrc/fft.hip slab_layout: -21 % with bins up to the Nyquist frequency)
     Pc = None
-    if try_xbin and nfields == 2:       # asked before any work: will the pair be served?  (else the plain three-pass form)
+    if try_xbin and nfields >= 2:       # asked before any work: will the pair / the four be served?  (else the plain three-pass form)
         try_xbin = backend.xbin_raw(None, nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, False, from_transpose=True,
                                     interlaced=interlaced, cross=pos2 is not None) is not None
     if try_xbin and comm.collective and hasattr(backend, 'transpose_layout') and hasattr(comm, 'all_to_all_piece_v'):
@@ -361,10 +365,12 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         particles = backend.upload_particles(p_, w_)
         # a second receive buffer only where the fused last pass reads both fields as they arrived; otherwise spectrum()
         # has unpacked the first one into its mesh before the second transpose starts
-        fields.append(spectrum(particles, ntot, 0.0, meshes[mi], 'recv2' if (try_xbin and fields) else 'recv'))
+        # (four fields through one fused last pass: four receive buffers)
+        rname = (lambda q: 'recv' if not q else f'recv{q + 1}') if try_xbin else (lambda q: 'recv')
+        fields.append(spectrum(particles, ntot, 0.0, meshes[mi], rname(len(fields))))
         mi += 1
         if interlaced:
-            fields.append(spectrum(particles, ntot, 0.5 * d, meshes[mi], 'recv2' if try_xbin else 'recv'))
+            fields.append(spectrum(particles, ntot, 0.5 * d, meshes[mi], rname(len(fields))))
             mi += 1
         else:
             fields.append((None, 0))
@@ -372,13 +378,14 @@ def calc_power_slab(pos, Lbox, comm=None, backend=None, kbins=None, mubins=None,
         fields += [(None, 0), (None, 0)]
     raw = None
     if try_xbin:
-        xkw = dict(field2=fields[2]) if pos2 is not None else dict(field2=fields[1], interlaced=True) if interlaced else {}
+        xkw = (dict(field2=fields[1], field3=fields[2], field4=fields[3], interlaced=True, cross=True) if (pos2 is not None and interlaced)
+               else dict(field2=fields[2]) if pos2 is not None else dict(field2=fields[1], interlaced=True) if interlaced else {})
         raw = backend.xbin_raw(fields[0], nmesh, W, r * nyl, nyl, Lbox, Wk, ke, me, poles_arr, r == 0,
                                from_transpose=2 if Pc is not None else True, **xkw)
         if raw is None and Pc is not None:
             raise RuntimeError('calc_power_slab: the fused last pass declined a compact transpose it had accepted')
         if raw is None:      # not served: unpack, x pass, binning
-            for fi, mj in ((0, 0),) + (((2, 1),) if pos2 is not None else ((1, 1),) if interlaced else ()):
+            for fi, mj in zip([q for q, f in enumerate(fields) if f[0] is not None], range(nfields)):   # field slot -> its mesh, in order
                 src, off = fields[fi]
                 if src is meshes[mj]:                         # one rank went straight from its mesh: it still has to be packed
                     backend.pack(meshes[mj], off, tbuf('send'), nmesh, W, xsep, 0, h)

@@ -1617,12 +1617,27 @@ int abacus_slab_xbin_dev(const void *mesh, int nmesh, int world, int y0, int ny_
 int abacus_slab_xbin_pair_dev(const void *mesh, const void *mesh2, int pair_mode, int nmesh, int world, int y0, int ny_local, double Lbox,
                               const float *W_host, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
                               int Np, int put_geom, int from_transpose, void *raw_out) {
-    ABACUS_ENTER();
     if (pair_mode < 0 || pair_mode > 2) return fail("abacus_slab_xbin_pair_dev: pair_mode %d", pair_mode);
+    return abacus_slab_xbin_quad_dev(mesh, mesh2, nullptr, nullptr, pair_mode, nmesh, world, y0, ny_local, Lbox, W_host, kedges, Nk, muedges, Nmu,
+                                     poles, Np, put_geom, from_transpose, raw_out);
+}
+
+// ... and over FOUR: pair_mode 3, the cross power of two INTERLACED fields (calc_power's defaults with pos2 over slabs): mesh /
+// mesh2 = the first catalogue's unshifted / shifted deposit, mesh3 / mesh4 the second catalogue's, all in one layout
+// (fft_x_bin2<.., QUAD>).  pair_mode 0 - 2: abacus_slab_xbin_pair_dev (mesh3 / mesh4 ignored)
+int abacus_slab_xbin_quad_dev(const void *mesh, const void *mesh2, const void *mesh3, const void *mesh4, int pair_mode, int nmesh, int world,
+                              int y0, int ny_local, double Lbox, const float *W_host, const double *kedges, int Nk, const double *muedges,
+                              int Nmu, const int64_t *poles, int Np, int put_geom, int from_transpose, void *raw_out) {
+    ABACUS_ENTER();
+    if (pair_mode < 0 || pair_mode > 3) return fail("abacus_slab_xbin_quad_dev: pair_mode %d", pair_mode);
     if (mesh && pair_mode && !mesh2) return fail("abacus_slab_xbin_pair_dev: pair_mode %d without a second field", pair_mode);
-    if ((pair_mode == 1 && option("pk_noxbin_inter")) || (pair_mode == 2 && option("pk_noxbin_cross"))) return 1;
-    if (pair_mode == 1) ABACUS_TRY(ensure_phase(nmesh));
+    if (mesh && pair_mode == 3 && (!mesh3 || !mesh4)) return fail("abacus_slab_xbin_quad_dev: pair_mode 3 needs four fields");
+    if ((pair_mode == 1 && option("pk_noxbin_inter")) || (pair_mode == 2 && option("pk_noxbin_cross")) ||
+        (pair_mode == 3 && (option("pk_noxbin_inter") || option("pk_noxbin_cross"))))
+        return 1;
+    if (pair_mode == 1 || pair_mode == 3) ABACUS_TRY(ensure_phase(nmesh));
     if (!pair_mode) mesh2 = nullptr;
+    if (pair_mode != 3) mesh3 = mesh4 = nullptr;
     if (!slab_fused(nmesh) || option("pk_noxbin") || (nmesh != 1024 && nmesh != 2048)) return 1;
     if (from_transpose && option("slab_nounpackfuse")) return 1;
     int h;
@@ -1644,7 +1659,8 @@ int abacus_slab_xbin_pair_dev(const void *mesh, const void *mesh2, int pair_mode
     const double M = (double)nmesh * nmesh * nmesh;
     ABACUS_TRY(fft_x_bin_run((const float *)mesh, nmesh, pitch_r(nmesh), (float)(1.0 / M), W_dev, b, b.dbg, y0, ny_local,
                              put_geom ? 1 : 0, from_transpose ? 2 : 1, world, (const float *)mesh2,
-                             pair_mode == 1 ? g_ctx.phase.as<float2>() : nullptr, row_off, P[y0 / std::max(ny_local, 1)]));
+                             (pair_mode == 1 || pair_mode == 3) ? g_ctx.phase.as<float2>() : nullptr, row_off, P[y0 / std::max(ny_local, 1)],
+                             (const float *)mesh3, (const float *)mesh4));
     HIP_TRY(hipMemcpyAsync(raw_out, g_ctx.accum.p, acc_bytes, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     return 0;

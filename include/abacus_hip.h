@@ -389,6 +389,12 @@ int abacus_slab_xbin_dev(const void *mesh, int nmesh, int world, int y0, int ny_
 int abacus_slab_xbin_pair_dev(const void *mesh, const void *mesh2, int pair_mode, int nmesh, int world, int y0, int ny_local, double Lbox,
                               const float *W_host, const double *kedges, int Nk, const double *muedges, int Nmu, const int64_t *poles,
                               int Np, int put_geom, int from_transpose, void *raw_out);
+/* ... and over four: pair_mode 3 = the cross power of two INTERLACED fields (calc_power(pos, pos2=..., interlaced=True) over slabs,
+ * analysis/power_spectrum.py:1200-1260): mesh / mesh2 the first catalogue's unshifted / shifted deposit, mesh3 / mesh4 the second
+ * catalogue's, all in the layout of `mesh`; pair_mode 0 - 2 as abacus_slab_xbin_pair_dev (mesh3 / mesh4 ignored) */
+int abacus_slab_xbin_quad_dev(const void *mesh, const void *mesh2, const void *mesh3, const void *mesh4, int pair_mode, int nmesh, int world,
+                              int y0, int ny_local, double Lbox, const float *W_host, const double *kedges, int Nk, const double *muedges,
+                              int Nmu, const int64_t *poles, int Np, int put_geom, int from_transpose, void *raw_out);
 /* particle routing on the device: stable bucket sort of (pos (n,3) float32, w or NULL) by the rank that owns the wrapped x
  * (fold = 0: x-slabs of width Lbox / world; fold = 1: the folded slabs above, rank = slab mod world of 2 world slabs);
  * counts[world] on the host.  The blocks then travel with abacus_comm_all_to_all_v. */

@@ -304,7 +304,8 @@ def test_compact_transpose_sends_a_fifth_less(world, nmesh, kfrac):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('world,nmesh,mode', [(8, 1024, 'cross'), (4, 2048, 'cross'), (1, 1024, 'cross'), (8, 1024, 'interlaced'),
-                                              (1, 1024, 'interlaced')])   # (8, 2048, 'interlaced'): scripts/gpu_slab.sh (suite budget, r06)
+                                              (1, 1024, 'interlaced'),    # (8, 2048, 'interlaced'): scripts/gpu_slab.sh (suite budget, r06)
+                                              (8, 1024, 'interlaced_cross'), (1, 1024, 'interlaced_cross')])
 def test_field_pairs_over_slabs_take_the_fused_last_pass(world, nmesh, mode):
     """calc_power_slab(pos, pos2=..., interlaced=False) - LRG x ELG of BASELINE config 5 - and calc_power_slab(pos,
     interlaced=True) - the reference's default mode: both fields of the pair stop after their y pass, each crosses the links in
@@ -319,10 +320,11 @@ def test_field_pairs_over_slabs_take_the_fused_last_pass(world, nmesh, mode):
     n = 500000 if nmesh < 2048 else 1_500_000
     pos = synth_positions(n, L, seed=61, clustered=True)
     pos2 = None
-    if mode == 'cross':
+    if mode in ('cross', 'interlaced_cross'):
         pos2 = synth_positions(n // 2, L, seed=62, clustered=True)
         pos2[:n // 5] = pos[:n // 5]
-    kw = dict(kbins=48, mubins=3, paste='TSC', nmesh=nmesh, compensated=True, interlaced=mode == 'interlaced', poles=[0, 2, 4])
+    # interlaced_cross: calc_power's defaults with a second catalogue - four fields, four receive buffers, fft_x_bin2<.., QUAD>
+    kw = dict(kbins=48, mubins=3, paste='TSC', nmesh=nmesh, compensated=True, interlaced=mode in ('interlaced', 'interlaced_cross'), poles=[0, 2, 4])
     ref = calc_power(pos.copy(), L, pos2=None if pos2 is None else pos2.copy(), **kw)
 
     def rank_fn(comm):
