@@ -24,10 +24,23 @@ __global__ __launch_bounds__(NT) void pencil_deposit(const unsigned long long *_
     __syncthreads();
     const float fx = 4194304.f, fxinv = 1.f / 4194304.f;        // 2^22: 5722 entries per pencil leave the guard bit
     typedef float v2f __attribute__((ext_vector_type(2)));
+    // the entries of the NEXT pencil are requested before the flush of the current one (as lines_deposit32 requests its lists ahead)
+    constexpr int NE = 6;                                        // 6 x 1024 entries cover a pencil's list
+    unsigned long long nx[NE];
+    auto request = [&](int p) {
+#pragma unroll
+        for (int q = 0; q < NE; q++) nx[q] = (p < npencil && q * NT + tid < per) ? entries[(int64_t)p * per + q * NT + tid] : ~0ull;
+    };
+    request(blockIdx.x);
     for (int p = blockIdx.x; p < npencil; p += gridDim.x) {
-        const unsigned long long *list = entries + (int64_t)p * per;
-        for (int k = tid; k < per; k += NT) {
-            const unsigned long long e = list[k];
+        unsigned long long cur[NE];
+#pragma unroll
+        for (int q = 0; q < NE; q++) cur[q] = nx[q];
+        request(p + gridDim.x);
+#pragma unroll 1
+        for (int q = 0; q < NE; q++) {
+            const unsigned long long e = cur[q];
+            if (e == ~0ull) continue;
             const unsigned int lo = (unsigned int)e, hi = (unsigned int)(e >> 32);
             const int lx = lo & 7, ly = (lo >> 3) & 15, lz = (lo >> 7) & 1023;            // nearest cell + 1 in x, y; z cell
             const float dx = ((float)(hi & 0xffffu) - 32768.f) * (1.f / 65536.f), dy = ((float)(hi >> 16) - 32768.f) * (1.f / 65536.f),
