@@ -34,6 +34,36 @@ def test_struct_layout_matches_oracle():
     assert [f[0] for f in _lib.HodParams._fields_] == [f[0] for f in oracle.HodParams._fields_]
 
 
+def test_ctypes_mirrors_match_the_header(tmp_path):
+    """the ctypes Structures the host code passes by pointer against what a C compiler makes of include/abacus_hip.h: total
+    size and the offset of every field (abacus_hod_params: _lib.HodParams; abacus_prepare_slab_args: prepare_sim._SlabArgs) and
+    the column counts of the prepare_slab tables"""
+    import shutil
+    import subprocess
+    from abacusutils_amd.hod import prepare_sim as ps
+    gcc = shutil.which('gcc')
+    if not gcc:
+        pytest.skip('gcc not available')
+    checks = (('abacus_hod_params', _lib.HodParams), ('abacus_prepare_slab_args', ps._SlabArgs))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "abacus_hip.h"', 'int main(void) {']
+    for cname, cls in checks:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  printf("HALO_COLS %d\\n", (int)ABACUS_PREP_HALO_COLS);', '  printf("PART_COLS %d\\n", (int)ABACUS_PREP_PART_COLS);',
+              '  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call([gcc, '-I', os.path.join(str(REPO), 'include'), str(src), '-o', str(exe)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in checks:
+        assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got[f'{cname}.{fname}']) == getattr(cls, fname).offset, (cname, fname)
+    assert int(got['HALO_COLS']) == len(ps._SLAB_HALO_OUT) and int(got['PART_COLS']) == len(ps._SLAB_PART_OUT)
+
+
 def test_marshal_params_matches_oracle_marshalling():
     """gen_gals parameter handling (hod/GRAND_HOD.py:1342-1475): z-evolution, defaults, required keys"""
     from abacusutils_amd.hod.GRAND_HOD import marshal_params
