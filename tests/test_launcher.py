@@ -148,3 +148,35 @@ def test_join_timeout_is_not_turned_into_a_file_fallback(monkeypatch, tmp_path):
     assert isinstance(d.comm, comm.FileComm) and 'duplicate device' in d.rccl_error
     with pytest.raises(RuntimeError):
         comm.Dist.from_env(allow_file_fallback=False, key='t_join')
+
+
+def test_cpu_share_helpers_follow_the_cgroup_quota(monkeypatch, tmp_path):
+    """bench_pk.cpu_share / cpu_threads / host_memory_gb and oracle.max_threads: the team sizes of the CPU baselines and of the
+    tests' oracle calls follow the cgroup's CPU quota where there is one (the GPU box of round 6: 256 logical CPUs, cpu.max = 16)"""
+    import builtins
+    import os
+
+    import bench_pk
+    from oracle import oracle
+    files = {'/sys/fs/cgroup/cpu.max': '1600000 100000\n', '/sys/fs/cgroup/memory.max': str(64 << 30) + '\n',
+             '/sys/fs/cgroup/memory.current': str(4 << 30) + '\n'}
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if str(path) in files:
+            p = tmp_path / str(path).strip('/').replace('/', '_')
+            p.write_text(files[str(path)])
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, 'open', fake_open)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(256)))
+    assert bench_pk.cpu_share() == (256, 16.0)
+    assert bench_pk.cpu_threads() == [8, 16, 32]
+    assert bench_pk.host_memory_gb() <= 60 * 2**30 / 1e9 + 1e-6          # capped by what the cgroup has left (60 GiB)
+    assert oracle.cpu_quota() == 16.0
+    assert oracle.max_threads() <= 32
+    files['/sys/fs/cgroup/cpu.max'] = 'max 100000\n'
+    assert bench_pk.cpu_share() == (256, None) and bench_pk.cpu_threads() == [64, 128, 256]
+    assert oracle.cpu_quota() is None
+    assert bench_pk.cpu_pk_host_gb(2048, 100_000_000) > 100 > bench_pk.cpu_pk_host_gb(1024, 100_000_000)
